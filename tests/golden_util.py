@@ -1,0 +1,53 @@
+"""Load tests/golden fixtures (written by tools/gen_golden.py from the imported reference)."""
+import os
+
+import numpy as np
+import torch
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
+
+VARIANT_CFG = {
+    'houlsby': dict(),
+    'houlsby_gelu': dict(adapter_activation='GELU'),
+    'houlsby_parallel': dict(is_serial='None'),
+    'pfeiffer': dict(adapter_type='pfeiffer', adapter_activation='relu'),
+    'pfeiffer_ver2': dict(adapter_type='pfeiffer_ver2'),
+    'compacter': dict(adapter_type='compacter'),
+    'houlsby_cpc': dict(arch='cpc'),
+    'finetune_all': dict(adapter_type='none'),
+    'roberta_cpc_pfeiffer': dict(adapter_type='pfeiffer', adapter_activation='relu', arch='cpc',
+                                 encoder='roberta', bert_ln_eps=1e-5, pad_token_id=1),
+}
+LRS = dict(fine_tune_lr=5e-5, lr=1e-4, adapter_bert_lr=1.5e-4, adapter_sasrec_lr=1.5e-4)
+
+
+def base_name(k):
+    if k.startswith('model.'):
+        k = k[len('model.'):]
+    return k.replace('.self_output.', '.').replace('.transformer_block.', '.')
+
+
+def strip(k):
+    return k[len('model.'):] if k.startswith('model.') else k
+
+
+def load_variant(name):
+    """-> (sd with reference key names ('model.' prefix of CompacterModel stripped), cfg, fixture dict, trainable names)."""
+    from oracle.ref_cpu import DEFAULT_CFG
+    base_file = 'base_roberta.npz' if name.startswith('roberta') else 'base.npz'
+    base = np.load(os.path.join(GOLDEN, base_file))
+    fx = np.load(os.path.join(GOLDEN, name + '.npz'))
+    base_sd = {k[3:]: torch.from_numpy(base[k]) for k in base.files if k.startswith('sd/')}
+    sd = {}
+    for k in fx['all_keys']:
+        k = str(k)
+        if 'sd/' + k in fx.files:
+            sd[strip(k)] = torch.from_numpy(fx['sd/' + k])
+        else:
+            sd[strip(k)] = base_sd[base_name(k)]
+    cfg = dict(DEFAULT_CFG)
+    cfg.update(bert_heads=2)
+    cfg.update(VARIANT_CFG[name])
+    trainable = [strip(str(k)) for k in fx['trainable']]
+    batch = (torch.from_numpy(base['sample_items']).view(-1, 60), torch.from_numpy(base['log_mask']))
+    return sd, cfg, fx, trainable, batch, base
