@@ -1,0 +1,245 @@
+"""ctypes binding of liba4r_hip.so (C ABI declared in include/a4r.h).
+
+The library is the product's only compute path: if it is missing or a call fails this module
+raises -- there is no PyTorch / CPU fallback.  Tensors are passed as raw device pointers plus
+leading dimensions; kernels are enqueued on torch's current HIP stream.
+"""
+import ctypes as C
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'liba4r_hip.so')
+
+BF16, F32 = 0, 1
+ACT_NONE, ACT_RELU, ACT_GELU, ACT_GELU_TANH, ACT_LEAKY = 0, 1, 2, 3, 4
+ACT_BY_NAME = {'none': 0, 'relu': 1, 'RELU': 1, 'gelu': 2, 'GELU': 2, 'gelu_new': 3, 'leaky_relu': 4}
+
+EXPORTS = [
+    'a4r_version', 'a4r_gemm_nt', 'a4r_gemm_tn', 'a4r_colsum', 'a4r_attn_fwd', 'a4r_attn_bwd', 'a4r_embed_ln',
+    'a4r_ln_fwd', 'a4r_ln_bwd', 'a4r_gather_rows', 'a4r_scatter_rows', 'a4r_act_bwd_f32', 'a4r_score_bce_fwd',
+    'a4r_score_bce_bwd', 'a4r_emb_grad_add_inputs', 'a4r_take_inputs', 'a4r_adam_step', 'a4r_pack_matrices',
+    'a4r_eval_rank',
+]
+
+
+class GemmArgs(C.Structure):
+    _fields_ = [('A', C.c_void_p), ('B', C.c_void_p), ('C', C.c_void_p), ('bias', C.c_void_p), ('C2', C.c_void_p),
+                ('R1', C.c_void_p), ('R2', C.c_void_p), ('Pre', C.c_void_p),
+                ('M', C.c_int32), ('N', C.c_int32), ('K', C.c_int32),
+                ('lda', C.c_int32), ('ldb', C.c_int32), ('ldc', C.c_int32), ('ldc2', C.c_int32),
+                ('ldr1', C.c_int32), ('ldr2', C.c_int32), ('ldpre', C.c_int32),
+                ('in_dtype', C.c_int32), ('out_dtype', C.c_int32), ('act', C.c_int32), ('dact', C.c_int32),
+                ('alpha', C.c_float), ('drop_p', C.c_float), ('drop_site', C.c_uint32), ('drop_seed', C.c_uint64)]
+
+
+class AttnArgs(C.Structure):
+    _fields_ = [('qkv', C.c_void_p), ('ld', C.c_int32), ('q_off', C.c_int32), ('k_off', C.c_int32), ('v_off', C.c_int32),
+                ('out', C.c_void_p), ('ldo', C.c_int32), ('dout', C.c_void_p), ('dqkv', C.c_void_p), ('key_mask', C.c_void_p),
+                ('n_items', C.c_int32), ('S', C.c_int32), ('n_heads', C.c_int32), ('dh', C.c_int32), ('causal', C.c_int32),
+                ('dtype', C.c_int32), ('scale', C.c_float), ('mask_neg', C.c_float),
+                ('drop_p', C.c_float), ('drop_site', C.c_uint32), ('drop_seed', C.c_uint64)]
+
+
+class PackDesc(C.Structure):
+    _fields_ = [('src_off', C.c_int64), ('dst', C.c_void_p), ('rows', C.c_int32), ('cols', C.c_int32),
+                ('rows_pad', C.c_int32), ('cols_pad', C.c_int32), ('transpose', C.c_int32), ('pad_', C.c_int32)]
+
+
+_lib = None
+
+
+def lib():
+    """Load the HIP library once; fail loudly when it is absent."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f'{LIB_PATH} not found: build it with `python -c "import __graft_entry__ as g; g.build()"` '
+                '(hipcc --offload-arch=gfx950).  adapter4rec_amd has no CPU / PyTorch fallback.')
+        _lib = C.CDLL(LIB_PATH)
+        for name in EXPORTS:
+            getattr(_lib, name).restype = C.c_int
+    return _lib
+
+
+def _check(rc, what):
+    if rc != 0:
+        raise RuntimeError(f'{what} failed with status {rc} ' + {-1: '(invalid argument)', -2: '(launch failure)'}.get(rc, ''))
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _p(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
+
+
+def _dt(t):
+    if t.dtype == torch.bfloat16:
+        return BF16
+    if t.dtype == torch.float32:
+        return F32
+    raise TypeError(f'unsupported dtype {t.dtype}')
+
+
+def _ld(t):
+    assert t.dim() == 2 and t.stride(1) == 1, 'row-major 2-D tensor expected'
+    return t.stride(0)
+
+
+def require_gpu(*tensors):
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise RuntimeError('adapter4rec_amd kernels need device tensors (no CPU fallback)')
+
+
+# ------------------------------------------------------------------ wrappers
+def gemm_nt(A, B, Cout, bias=None, C2=None, R1=None, R2=None, Pre=None, act=0, dact=0, alpha=1.0,
+            drop_p=0.0, drop_site=0, drop_seed=0, M=None):
+    require_gpu(A, B, Cout)
+    g = GemmArgs()
+    g.A, g.B, g.C, g.bias, g.C2, g.R1, g.R2, g.Pre = _p(A), _p(B), _p(Cout), _p(bias), _p(C2), _p(R1), _p(R2), _p(Pre)
+    g.M = A.shape[0] if M is None else M
+    g.N, g.K = B.shape[0], B.shape[1]
+    assert A.shape[1] == g.K and Cout.shape[1] == g.N
+    g.lda, g.ldb, g.ldc = _ld(A), _ld(B), _ld(Cout)
+    g.ldc2 = _ld(C2) if C2 is not None else 0
+    g.ldr1 = _ld(R1) if R1 is not None else 0
+    g.ldr2 = _ld(R2) if R2 is not None else 0
+    g.ldpre = _ld(Pre) if Pre is not None else 0
+    g.in_dtype, g.out_dtype = _dt(A), _dt(Cout)
+    assert _dt(B) == g.in_dtype
+    for t in (C2, R1, R2, Pre):
+        assert t is None or _dt(t) == g.out_dtype
+    assert bias is None or bias.dtype == torch.float32
+    g.act, g.dact, g.alpha = act, dact, alpha
+    g.drop_p, g.drop_site, g.drop_seed = drop_p, drop_site, drop_seed
+    _check(lib().a4r_gemm_nt(_stream(), C.byref(g)), 'a4r_gemm_nt')
+
+
+def gemm_tn(X, Y, Cacc, M=None):
+    require_gpu(X, Y, Cacc)
+    assert Cacc.dtype == torch.float32 and _dt(X) == _dt(Y)
+    M = X.shape[0] if M is None else M
+    _check(lib().a4r_gemm_tn(_stream(), _p(X), C.c_int(_ld(X)), _p(Y), C.c_int(_ld(Y)), _p(Cacc), C.c_int(_ld(Cacc)),
+                             C.c_int(M), C.c_int(X.shape[1]), C.c_int(Y.shape[1]), C.c_int(_dt(X))), 'a4r_gemm_tn')
+
+
+def colsum(X, out, M=None):
+    require_gpu(X, out)
+    M = X.shape[0] if M is None else M
+    _check(lib().a4r_colsum(_stream(), _p(X), C.c_int(_ld(X)), _p(out), C.c_int(M), C.c_int(X.shape[1]), C.c_int(_dt(X))), 'a4r_colsum')
+
+
+def _attn_args(qkv, q_off, k_off, v_off, key_mask, n_items, S, n_heads, dh, causal, scale, mask_neg, drop_p, drop_site, drop_seed):
+    a = AttnArgs()
+    a.qkv, a.ld, a.q_off, a.k_off, a.v_off = _p(qkv), _ld(qkv), q_off, k_off, v_off
+    a.key_mask = _p(key_mask)
+    a.n_items, a.S, a.n_heads, a.dh, a.causal, a.dtype = n_items, S, n_heads, dh, int(causal), _dt(qkv)
+    a.scale, a.mask_neg = scale, mask_neg
+    a.drop_p, a.drop_site, a.drop_seed = drop_p, drop_site, drop_seed
+    return a
+
+
+def attn_fwd(qkv, out, key_mask, n_items, S, n_heads, dh, q_off, k_off, v_off, causal, scale, mask_neg,
+             drop_p=0.0, drop_site=0, drop_seed=0):
+    require_gpu(qkv, out)
+    a = _attn_args(qkv, q_off, k_off, v_off, key_mask, n_items, S, n_heads, dh, causal, scale, mask_neg, drop_p, drop_site, drop_seed)
+    a.out, a.ldo = _p(out), _ld(out)
+    _check(lib().a4r_attn_fwd(_stream(), C.byref(a)), 'a4r_attn_fwd')
+
+
+def attn_bwd(qkv, dout, dqkv, key_mask, n_items, S, n_heads, dh, q_off, k_off, v_off, causal, scale, mask_neg,
+             drop_p=0.0, drop_site=0, drop_seed=0):
+    require_gpu(qkv, dout, dqkv)
+    assert _ld(dqkv) == _ld(qkv)
+    a = _attn_args(qkv, q_off, k_off, v_off, key_mask, n_items, S, n_heads, dh, causal, scale, mask_neg, drop_p, drop_site, drop_seed)
+    a.dout, a.ldo, a.dqkv = _p(dout), _ld(dout), _p(dqkv)
+    _check(lib().a4r_attn_bwd(_stream(), C.byref(a)), 'a4r_attn_bwd')
+
+
+def embed_ln(ids, word, pos, type0, gamma, beta, eps, out, n_items, S, roberta=False, pad_id=0,
+             drop_p=0.0, drop_site=0, drop_seed=0):
+    require_gpu(ids, word, out)
+    assert ids.dtype == torch.int64 and ids.stride(1) == 1
+    _check(lib().a4r_embed_ln(_stream(), _p(ids), C.c_int(ids.stride(0)), _p(word), _p(pos), _p(type0), _p(gamma), _p(beta),
+                              C.c_float(eps), _p(out), C.c_int(_ld(out)), C.c_int(n_items), C.c_int(S), C.c_int(word.shape[1]),
+                              C.c_int(int(roberta)), C.c_int(pad_id), C.c_int(_dt(out)),
+                              C.c_float(drop_p), C.c_uint32(drop_site), C.c_uint64(drop_seed)), 'a4r_embed_ln')
+
+
+def ln_fwd(v, gamma, beta, eps, y, stats, M=None, add=None, drop_p=0.0, drop_site=0, drop_seed=0):
+    require_gpu(v, y)
+    M = v.shape[0] if M is None else M
+    _check(lib().a4r_ln_fwd(_stream(), _p(v), C.c_int(_ld(v)), _p(add), C.c_int(add.shape[0] if add is not None else 0),
+                            _p(gamma), _p(beta), C.c_float(eps), _p(y), C.c_int(_ld(y)), _p(stats), C.c_int(M),
+                            C.c_int(v.shape[1]), C.c_int(_dt(v)), C.c_float(drop_p), C.c_uint32(drop_site), C.c_uint64(drop_seed)),
+           'a4r_ln_fwd')
+
+
+def ln_bwd(dy, v, stats, gamma, dv, M=None, add=None, dgamma=None, dbeta=None, dbias=None, drop_p=0.0, drop_site=0, drop_seed=0):
+    require_gpu(dy, v, dv)
+    M = v.shape[0] if M is None else M
+    _check(lib().a4r_ln_bwd(_stream(), _p(dy), C.c_int(_ld(dy)), _p(v), C.c_int(_ld(v)), _p(add),
+                            C.c_int(add.shape[0] if add is not None else 0), _p(stats), _p(gamma), _p(dv), C.c_int(_ld(dv)),
+                            _p(dgamma), _p(dbeta), _p(dbias), C.c_int(M), C.c_int(v.shape[1]), C.c_int(_dt(v)),
+                            C.c_float(drop_p), C.c_uint32(drop_site), C.c_uint64(drop_seed)), 'a4r_ln_bwd')
+
+
+def gather_rows(src, dst, n, row_step):
+    require_gpu(src, dst)
+    _check(lib().a4r_gather_rows(_stream(), _p(src), C.c_int(_ld(src)), _p(dst), C.c_int(_ld(dst)), C.c_int(n), C.c_int(row_step),
+                                 C.c_int(src.shape[1]), C.c_int(_dt(src))), 'a4r_gather_rows')
+
+
+def scatter_rows(src, dst, n, row_step):
+    require_gpu(src, dst)
+    _check(lib().a4r_scatter_rows(_stream(), _p(src), C.c_int(_ld(src)), _p(dst), C.c_int(_ld(dst)), C.c_int(n), C.c_int(row_step),
+                                  C.c_int(src.shape[1]), C.c_int(_dt(src))), 'a4r_scatter_rows')
+
+
+def act_bwd_f32(dy, pre, dx, act):
+    require_gpu(dy, pre, dx)
+    _check(lib().a4r_act_bwd_f32(_stream(), _p(dy), _p(pre), _p(dx), C.c_int64(dy.numel()), C.c_int(act)), 'a4r_act_bwd_f32')
+
+
+def score_bce_fwd(emb, prec, log_mask, pos, neg, loss_ws, B, L, E, cpc):
+    require_gpu(emb, prec)
+    _check(lib().a4r_score_bce_fwd(_stream(), _p(emb), _p(prec), _p(log_mask), _p(pos), _p(neg), _p(loss_ws),
+                                   C.c_int(B), C.c_int(L), C.c_int(E), C.c_int(int(cpc))), 'a4r_score_bce_fwd')
+
+
+def score_bce_bwd(emb, prec, log_mask, pos, neg, loss_ws, loss_scale, d_prec, d_emb, B, L, E, cpc):
+    require_gpu(emb, prec)
+    _check(lib().a4r_score_bce_bwd(_stream(), _p(emb), _p(prec), _p(log_mask), _p(pos), _p(neg), _p(loss_ws), C.c_float(loss_scale),
+                                   _p(d_prec), _p(d_emb), C.c_int(B), C.c_int(L), C.c_int(E), C.c_int(int(cpc))), 'a4r_score_bce_bwd')
+
+
+def emb_grad_add_inputs(d_in, d_emb, B, L, E):
+    _check(lib().a4r_emb_grad_add_inputs(_stream(), _p(d_in), C.c_int(_ld(d_in)), _p(d_emb), C.c_int(B), C.c_int(L), C.c_int(E)),
+           'a4r_emb_grad_add_inputs')
+
+
+def take_inputs(emb, out, B, L, E):
+    _check(lib().a4r_take_inputs(_stream(), _p(emb), _p(out), C.c_int(_ld(out)), C.c_int(B), C.c_int(L), C.c_int(E)), 'a4r_take_inputs')
+
+
+def adam_step(p, g, m, v, seg_end, seg_group, group_lr, step, beta1=0.9, beta2=0.999, eps=1e-8, grad_scale=1.0):
+    require_gpu(p, g, m, v, seg_end, seg_group, group_lr)
+    _check(lib().a4r_adam_step(_stream(), _p(p), _p(g), _p(m), _p(v), C.c_int64(p.numel()), _p(seg_end), _p(seg_group),
+                               C.c_int(seg_end.numel()), _p(group_lr), C.c_int(step), C.c_float(beta1), C.c_float(beta2),
+                               C.c_float(eps), C.c_float(grad_scale)), 'a4r_adam_step')
+
+
+def pack_matrices(flat, desc_dev, n_desc, max_elems, dtype):
+    _check(lib().a4r_pack_matrices(_stream(), _p(flat), _p(desc_dev), C.c_int(n_desc), C.c_int(max_elems), C.c_int(dtype)),
+           'a4r_pack_matrices')
+
+
+def eval_rank(prec, item_emb, target, hist_ptr, hist_idx, rank):
+    require_gpu(prec, item_emb, target, hist_ptr, hist_idx, rank)
+    _check(lib().a4r_eval_rank(_stream(), _p(prec), _p(item_emb), _p(target), _p(hist_ptr), _p(hist_idx), _p(rank),
+                               C.c_int(prec.shape[0]), C.c_int(item_emb.shape[0]), C.c_int(prec.shape[1])), 'a4r_eval_rank')

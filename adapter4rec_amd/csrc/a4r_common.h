@@ -1,0 +1,190 @@
+// Common device helpers for the a4r HIP kernels (gfx950 / CDNA4 only).
+//
+// Everything matmul-shaped in this library is expressed through ONE tile primitive:
+// a 16x16 output tile accumulated from "16-byte chunks": lane l of the wave supplies, for
+// operand A, 16 bytes of row (l & 15) at chunk (l >> 4) of the current K step, and the same
+// for operand B (B is always addressed [n][k], i.e. the "NT" form y = x W^T).
+//   T = __bf16 : chunk = 8 elements, one v_mfma_f32_16x16x32_bf16 covers K = 32
+//   T = float  : chunk = 4 elements, four v_mfma_f32_16x16x4_f32 cover K = 16
+//                (step s uses element s of every lane's chunk: k = 4*kg + s, a bijection on 16 k's)
+// so bf16 and fp32 instantiations of a kernel share all addressing (rows of 16-byte chunks).
+// Accumulator layout of the 16x16 tile (both forms): col = lane & 15, row = (lane >> 4) * 4 + reg.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define A4R_DEV __device__ __forceinline__
+
+typedef __bf16 bf16_t;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
+typedef __attribute__((ext_vector_type(4))) float f32x4_t;
+
+enum { A4R_BF16 = 0, A4R_F32 = 1 };
+enum { A4R_ACT_NONE = 0, A4R_ACT_RELU = 1, A4R_ACT_GELU = 2, A4R_ACT_GELU_TANH = 3, A4R_ACT_LEAKY = 4 };
+
+// ---------------------------------------------------------------- error codes (C ABI)
+#define A4R_OK 0
+#define A4R_EINVAL (-1)   // bad shape / alignment / dtype
+#define A4R_ELAUNCH (-2)  // hipGetLastError() != hipSuccess after launch
+
+static inline int a4r_launch_status() { return hipGetLastError() == hipSuccess ? A4R_OK : A4R_ELAUNCH; }
+
+// ---------------------------------------------------------------- element traits
+template <typename T> struct Elem;
+template <> struct Elem<float> {
+    static constexpr int PER16 = 4;
+    static A4R_DEV float ld(const float* p) { return *p; }
+    static A4R_DEV void st(float* p, float v) { *p = v; }
+    static A4R_DEV void unpack(const uint4& v, float* o) {
+        o[0] = __uint_as_float(v.x); o[1] = __uint_as_float(v.y); o[2] = __uint_as_float(v.z); o[3] = __uint_as_float(v.w);
+    }
+    static A4R_DEV uint4 pack(const float* o) {
+        return make_uint4(__float_as_uint(o[0]), __float_as_uint(o[1]), __float_as_uint(o[2]), __float_as_uint(o[3]));
+    }
+};
+A4R_DEV float bf16_bits_to_f32(unsigned u) { return __uint_as_float(u << 16); }
+A4R_DEV unsigned f32_to_bf16_bits(float f) {       // plain cast: v_cvt_pk_bf16_f32, RNE, NaN stays NaN
+    bf16_t b = (bf16_t)f;
+    return (unsigned)__builtin_bit_cast(unsigned short, b);
+}
+template <> struct Elem<bf16_t> {
+    static constexpr int PER16 = 8;
+    static A4R_DEV float ld(const bf16_t* p) { return (float)(*p); }
+    static A4R_DEV void st(bf16_t* p, float v) { *p = (bf16_t)v; }
+    static A4R_DEV void unpack(const uint4& v, float* o) {
+        o[0] = bf16_bits_to_f32(v.x & 0xffffu); o[1] = bf16_bits_to_f32(v.x >> 16);
+        o[2] = bf16_bits_to_f32(v.y & 0xffffu); o[3] = bf16_bits_to_f32(v.y >> 16);
+        o[4] = bf16_bits_to_f32(v.z & 0xffffu); o[5] = bf16_bits_to_f32(v.z >> 16);
+        o[6] = bf16_bits_to_f32(v.w & 0xffffu); o[7] = bf16_bits_to_f32(v.w >> 16);
+    }
+    static A4R_DEV uint4 pack(const float* o) {
+        return make_uint4(f32_to_bf16_bits(o[0]) | (f32_to_bf16_bits(o[1]) << 16),
+                          f32_to_bf16_bits(o[2]) | (f32_to_bf16_bits(o[3]) << 16),
+                          f32_to_bf16_bits(o[4]) | (f32_to_bf16_bits(o[5]) << 16),
+                          f32_to_bf16_bits(o[6]) | (f32_to_bf16_bits(o[7]) << 16));
+    }
+};
+
+// load / store N consecutive elements of T (N a multiple of PER16) as fp32, 16 bytes at a time
+template <typename T, int N> A4R_DEV void load_vec(const T* p, float* o) {
+#pragma unroll
+    for (int i = 0; i < N / Elem<T>::PER16; ++i) {
+        uint4 v = *reinterpret_cast<const uint4*>(p + i * Elem<T>::PER16);
+        Elem<T>::unpack(v, o + i * Elem<T>::PER16);
+    }
+}
+template <typename T, int N> A4R_DEV void store_vec(T* p, const float* o) {
+#pragma unroll
+    for (int i = 0; i < N / Elem<T>::PER16; ++i)
+        *reinterpret_cast<uint4*>(p + i * Elem<T>::PER16) = Elem<T>::pack(o + i * Elem<T>::PER16);
+}
+
+// ---------------------------------------------------------------- the tile primitive
+template <typename T> struct Mma;
+template <> struct Mma<bf16_t> {
+    static constexpr int KSTEP = 32;   // K covered by one chunk step (4 lane groups x 8 elements)
+    static A4R_DEV void mma(const uint4& a, const uint4& b, f32x4_t& c) {
+        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);
+    }
+};
+template <> struct Mma<float> {
+    static constexpr int KSTEP = 16;
+    static A4R_DEV void mma(const uint4& a, const uint4& b, f32x4_t& c) {
+        c = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.x), __uint_as_float(b.x), c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.y), __uint_as_float(b.y), c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.z), __uint_as_float(b.z), c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.w), __uint_as_float(b.w), c, 0, 0, 0);
+    }
+};
+
+// Gather one operand chunk DOWN a column of a row-major LDS tile (the "transposed" operand form:
+// the contraction index runs along tile rows).  Lane (i = l & 15, kg = l >> 4) collects
+// tile[k0 + kg*PER16 + j][col0 + i], j = 0..PER16-1.  stride_b = tile row stride in bytes.
+template <typename T> A4R_DEV uint4 gather_chunk(const char* tile, int stride_b, int k0, int col0, int lane) {
+    constexpr int PER = Elem<T>::PER16;
+    const char* p = tile + (k0 + (lane >> 4) * PER) * stride_b + (col0 + (lane & 15)) * (int)sizeof(T);
+    if constexpr (sizeof(T) == 4) {
+        uint4 r;
+        r.x = *reinterpret_cast<const unsigned*>(p);
+        r.y = *reinterpret_cast<const unsigned*>(p + stride_b);
+        r.z = *reinterpret_cast<const unsigned*>(p + 2 * stride_b);
+        r.w = *reinterpret_cast<const unsigned*>(p + 3 * stride_b);
+        return r;
+    } else {
+        unsigned e[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) e[j] = *reinterpret_cast<const unsigned short*>(p + j * stride_b);
+        return make_uint4(e[0] | (e[1] << 16), e[2] | (e[3] << 16), e[4] | (e[5] << 16), e[6] | (e[7] << 16));
+    }
+}
+
+// ---------------------------------------------------------------- activations
+A4R_DEV float act_fwd(float x, int act) {
+    switch (act) {
+        case A4R_ACT_RELU: return x > 0.f ? x : 0.f;
+        case A4R_ACT_GELU: return 0.5f * x * (1.f + erff(x * 0.70710678118654752440f));
+        case A4R_ACT_GELU_TANH: {
+            float u = 0.7978845608028654f * (x + 0.044715f * x * x * x);
+            return 0.5f * x * (1.f + tanhf(u));
+        }
+        case A4R_ACT_LEAKY: return x > 0.f ? x : 0.01f * x;
+        default: return x;
+    }
+}
+A4R_DEV float act_bwd(float x, int act) {   // d act(x) / dx
+    switch (act) {
+        case A4R_ACT_RELU: return x > 0.f ? 1.f : 0.f;
+        case A4R_ACT_GELU: {
+            float cdf = 0.5f * (1.f + erff(x * 0.70710678118654752440f));
+            float pdf = 0.3989422804014327f * __expf(-0.5f * x * x);
+            return cdf + x * pdf;
+        }
+        case A4R_ACT_GELU_TANH: {
+            float x2 = x * x;
+            float u = 0.7978845608028654f * (x + 0.044715f * x * x2);
+            float t = tanhf(u);
+            float du = 0.7978845608028654f * (1.f + 3.f * 0.044715f * x2);
+            return 0.5f * (1.f + t) + 0.5f * x * (1.f - t * t) * du;
+        }
+        case A4R_ACT_LEAKY: return x > 0.f ? 1.f : 0.01f;
+        default: return 1.f;
+    }
+}
+
+// ---------------------------------------------------------------- counter-based dropout
+// One splitmix64 hash yields four 16-bit lots; element e keeps iff lot(e) >= thr16 (thr16 = round(p * 65536)).
+// The mask is a pure function of (seed, site, e), so backward regenerates it instead of storing it.
+A4R_DEV uint64_t a4r_hash64(uint64_t seed, uint32_t site, uint64_t idx) {
+    uint64_t x = seed + 0x9E3779B97F4A7C15ull * (idx + 1) + ((uint64_t)site << 40);
+    x ^= x >> 30; x *= 0xBF58476D1CE4E5B9ull;
+    x ^= x >> 27; x *= 0x94D049BB133111EBull;
+    x ^= x >> 31;
+    return x;
+}
+A4R_DEV bool dropout_keep(uint64_t seed, uint32_t site, uint64_t e, uint32_t thr16) {
+    uint64_t h = a4r_hash64(seed, site, e >> 2);
+    return ((uint32_t)(h >> (16 * (e & 3))) & 0xffffu) >= thr16;
+}
+static inline uint32_t a4r_thr16(float p) {
+    if (p <= 0.f) return 0;
+    float t = p * 65536.f + 0.5f;
+    return t >= 65535.f ? 65535u : (uint32_t)t;
+}
+static inline float a4r_keep_scale(float p) { return p > 0.f ? 1.f / (1.f - (float)a4r_thr16(p) / 65536.f) : 1.f; }
+
+// ---------------------------------------------------------------- wave reductions (64 lanes)
+A4R_DEV float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+A4R_DEV float group16_sum(float v) {   // across the 16 lanes that share (lane >> 4)
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+A4R_DEV float group16_max(float v) {
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}

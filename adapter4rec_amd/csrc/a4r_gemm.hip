@@ -1,0 +1,240 @@
+// a4r_gemm_nt: C[M,N] = epilogue(A[M,K] . B[N,K]^T) on the gfx950 matrix cores.
+//
+// Tile 128 x BN (BN = 128 or 64) x 128 bytes of K per stage (64 bf16 / 32 fp32), 256 threads =
+// 4 waves laid out 2 (M) x 2 (N); each wave owns a 64 x BN/2 block of 16x16 MFMA tiles.
+// LDS image of a stage: rows of 128 bytes = eight 16-byte chunks, chunk slot c of row r holds
+// global chunk c ^ ((r >> 1) & 7): with ds_read_b128's 16-lane groups every fragment read
+// (16 rows x 4 chunk columns) touches 16 distinct 16-byte slots of the 256-byte bank row.
+// Two stages are double-buffered (register staging: the next stage's global loads are issued
+// before the MFMAs of the current one and written to LDS after them; one barrier per stage).
+// The epilogue goes through LDS (fp32 [128][BN]) so that bias/activation/residual/dropout run on
+// 8 consecutive columns per thread and every global access is 16 bytes per lane.
+// Workgroup -> tile map is XCD-aware: blocks that share an XCD (blockIdx % 8) walk consecutive
+// N-tiles of the same 128-row A panel, which therefore stays in that XCD's L2.
+#include "a4r_common.h"
+#include "../../include/a4r.h"
+
+namespace {
+
+template <typename TI, typename TO, int BN>
+__global__ void __launch_bounds__(256) gemm_nt_kernel(const a4r_gemm_t p, int ntm, int ntn, uint32_t thr16, float keep_scale) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int BM = 128, ROWB = 128;
+    constexpr int PER = Elem<TI>::PER16;
+    constexpr int KT = ROWB / (int)sizeof(TI);
+    constexpr int A_BYTES = BM * ROWB, B_BYTES = BN * ROWB, STAGE = A_BYTES + B_BYTES;
+    constexpr int NI = BN / 32;          // 16-column tiles per wave
+    constexpr int NLB = BN / 32;         // 16-byte chunks of B each thread stages (BN*8/256)
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+
+    // bijective XCD-aware remap of the 1-D grid
+    const int nt = ntm * ntn;
+    const int bid = blockIdx.x, xcd = bid & 7, j = bid >> 3, q = nt >> 3, r = nt & 7;
+    const int L = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + j;
+    const int tm = L / ntn, tn = L % ntn;
+
+    // copy the by-value argument's fields into registers (a captured struct would live in scratch)
+    const int lda = p.lda, ldb = p.ldb, ldc = p.ldc, ldc2 = p.ldc2, ldr1 = p.ldr1, ldr2 = p.ldr2, ldpre = p.ldpre;
+    const int Kdim = p.K, Ndim = p.N, act = p.act, dact = p.dact;
+    const float alpha = p.alpha;
+    const float* __restrict__ biasp = p.bias;
+    const uint64_t drop_seed = p.drop_seed;
+    const uint32_t drop_site = p.drop_site;
+    const TI* __restrict__ A = reinterpret_cast<const TI*>(p.A) + (size_t)tm * BM * lda;
+    const TI* __restrict__ B = reinterpret_cast<const TI*>(p.B) + (size_t)tn * BN * ldb;
+    TO* __restrict__ C = reinterpret_cast<TO*>(p.C);
+    TO* __restrict__ C2 = reinterpret_cast<TO*>(p.C2);
+    const TO* __restrict__ R1 = reinterpret_cast<const TO*>(p.R1);
+    const TO* __restrict__ R2 = reinterpret_cast<const TO*>(p.R2);
+    const TO* __restrict__ Pre = reinterpret_cast<const TO*>(p.Pre);
+
+    // register staging of one K stage (macros, not lambdas: by-reference captures of the staging
+    // arrays would be demoted to scratch memory)
+    uint4 ra0, ra1, ra2, ra3, rb0, rb1, rb2, rb3;
+    const int srow = tid >> 3, sch = tid & 7;                        // chunk id = tid + 256*i -> row = srow + 32*i
+    const int soff = srow * ROWB + ((sch ^ ((srow >> 1) & 7)) << 4);   // (row+32i)>>1 & 7 == (srow>>1)&7 since 32i>>1 = 16i
+    const TI* __restrict__ Ag = A + (size_t)srow * lda + sch * PER;
+    const TI* __restrict__ Bg = B + (size_t)srow * ldb + sch * PER;
+#define A4R_GLOAD(kt_)                                                                         \
+    {                                                                                          \
+        const int k0_ = (kt_) * KT;                                                            \
+        ra0 = *reinterpret_cast<const uint4*>(Ag + k0_);                                       \
+        ra1 = *reinterpret_cast<const uint4*>(Ag + (size_t)32 * lda + k0_);                    \
+        ra2 = *reinterpret_cast<const uint4*>(Ag + (size_t)64 * lda + k0_);                    \
+        ra3 = *reinterpret_cast<const uint4*>(Ag + (size_t)96 * lda + k0_);                    \
+        rb0 = *reinterpret_cast<const uint4*>(Bg + k0_);                                       \
+        rb1 = *reinterpret_cast<const uint4*>(Bg + (size_t)32 * ldb + k0_);                    \
+        if constexpr (NLB == 4) {                                                              \
+            rb2 = *reinterpret_cast<const uint4*>(Bg + (size_t)64 * ldb + k0_);                \
+            rb3 = *reinterpret_cast<const uint4*>(Bg + (size_t)96 * ldb + k0_);                \
+        }                                                                                      \
+    }
+#define A4R_SWRITE(buf_)                                                                       \
+    {                                                                                          \
+        char* As_ = smem + (buf_) * STAGE + soff;                                              \
+        char* Bs_ = As_ + A_BYTES;                                                             \
+        *reinterpret_cast<uint4*>(As_) = ra0;                                                  \
+        *reinterpret_cast<uint4*>(As_ + 32 * ROWB) = ra1;                                      \
+        *reinterpret_cast<uint4*>(As_ + 64 * ROWB) = ra2;                                      \
+        *reinterpret_cast<uint4*>(As_ + 96 * ROWB) = ra3;                                      \
+        *reinterpret_cast<uint4*>(Bs_) = rb0;                                                  \
+        *reinterpret_cast<uint4*>(Bs_ + 32 * ROWB) = rb1;                                      \
+        if constexpr (NLB == 4) {                                                              \
+            *reinterpret_cast<uint4*>(Bs_ + 64 * ROWB) = rb2;                                  \
+            *reinterpret_cast<uint4*>(Bs_ + 96 * ROWB) = rb3;                                  \
+        }                                                                                      \
+    }
+
+    f32x4_t acc[4][NI];
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+    const int nk = Kdim / KT;
+    A4R_GLOAD(0);
+    A4R_SWRITE(0);
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+        const int cur = kt & 1;
+        if (kt + 1 < nk) A4R_GLOAD(kt + 1);
+        const char* As = smem + cur * STAGE;
+        const char* Bs = As + A_BYTES;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const int ch = ks * 4 + (lane >> 4);
+            uint4 af[4], bf[NI];
+#pragma unroll
+            for (int mi = 0; mi < 4; ++mi) {
+                const int row = wm * 64 + mi * 16 + (lane & 15);
+                af[mi] = *reinterpret_cast<const uint4*>(As + row * ROWB + ((ch ^ ((row >> 1) & 7)) << 4));
+            }
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni) {
+                const int row = wn * (BN / 2) + ni * 16 + (lane & 15);
+                bf[ni] = *reinterpret_cast<const uint4*>(Bs + row * ROWB + ((ch ^ ((row >> 1) & 7)) << 4));
+            }
+#pragma unroll
+            for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < NI; ++ni) Mma<TI>::mma(af[mi], bf[ni], acc[mi][ni]);
+        }
+        if (kt + 1 < nk) A4R_SWRITE(cur ^ 1);
+        __syncthreads();
+    }
+
+#undef A4R_GLOAD
+#undef A4R_SWRITE
+    // ---- epilogue through LDS
+    float* Cs = reinterpret_cast<float*>(smem);
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr) {
+                const int row = wm * 64 + mi * 16 + (lane >> 4) * 4 + rr;
+                const int col = wn * (BN / 2) + ni * 16 + (lane & 15);
+                Cs[row * BN + col] = acc[mi][ni][rr];
+            }
+    __syncthreads();
+    constexpr int TPR = BN / 8, RPP = 256 / TPR;
+    const int c8 = (tid % TPR) * 8;
+    const int gcol = tn * BN + c8;
+    float bias[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) bias[e] = biasp ? biasp[gcol + e] : 0.f;
+    for (int pass = 0; pass < BM / RPP; ++pass) {
+        const int row = pass * RPP + tid / TPR;
+        const size_t grow = (size_t)tm * BM + row;
+        float v[8];
+        {
+            const float4 lo = *reinterpret_cast<const float4*>(Cs + row * BN + c8);
+            const float4 hi = *reinterpret_cast<const float4*>(Cs + row * BN + c8 + 4);
+            v[0] = lo.x; v[1] = lo.y; v[2] = lo.z; v[3] = lo.w; v[4] = hi.x; v[5] = hi.y; v[6] = hi.z; v[7] = hi.w;
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = v[e] * alpha + bias[e];
+        if (C2) store_vec<TO, 8>(C2 + grow * ldc2 + gcol, v);
+        if (act != A4R_ACT_NONE) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = act_fwd(v[e], act);
+        }
+        if (dact != A4R_ACT_NONE) {
+            float pre[8];
+            load_vec<TO, 8>(Pre + grow * ldpre + gcol, pre);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] *= act_bwd(pre[e], dact);
+        }
+        if (R1) {
+            float t[8];
+            load_vec<TO, 8>(R1 + grow * ldr1 + gcol, t);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] += t[e];
+        }
+        if (R2) {
+            float t[8];
+            load_vec<TO, 8>(R2 + grow * ldr2 + gcol, t);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] += t[e];
+        }
+        if (thr16) {
+            const uint64_t e0 = (uint64_t)grow * (uint64_t)Ndim + (uint64_t)gcol;   // gcol % 8 == 0
+            const uint64_t h0 = a4r_hash64(drop_seed, drop_site, e0 >> 2);
+            const uint64_t h1 = a4r_hash64(drop_seed, drop_site, (e0 >> 2) + 1);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                v[e] = (((uint32_t)(h0 >> (16 * e)) & 0xffffu) >= thr16) ? v[e] * keep_scale : 0.f;
+                v[e + 4] = (((uint32_t)(h1 >> (16 * e)) & 0xffffu) >= thr16) ? v[e + 4] * keep_scale : 0.f;
+            }
+        }
+        store_vec<TO, 8>(C + grow * ldc + gcol, v);
+    }
+}
+
+template <typename TI, typename TO, int BN>
+int launch(hipStream_t s, const a4r_gemm_t& g) {
+    constexpr int LDS = (2 * (128 * 128 + BN * 128) > 128 * BN * 4) ? 2 * (128 * 128 + BN * 128) : 128 * BN * 4;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_kernel<TI, TO, BN>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+        attr_set = true;
+    }
+    const int ntm = g.M / 128, ntn = g.N / BN;
+    hipLaunchKernelGGL((gemm_nt_kernel<TI, TO, BN>), dim3(ntm * ntn), dim3(256), LDS, s, g, ntm, ntn,
+                       a4r_thr16(g.drop_p), a4r_keep_scale(g.drop_p));
+    return a4r_launch_status();
+}
+
+template <typename TI, typename TO>
+int launch_bn(hipStream_t s, const a4r_gemm_t& g) {
+    return (g.N % 128 == 0) ? launch<TI, TO, 128>(s, g) : launch<TI, TO, 64>(s, g);
+}
+
+inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+}  // namespace
+
+extern "C" int a4r_gemm_nt(void* stream, const a4r_gemm_t* gp) {
+    if (!gp) return A4R_EINVAL;
+    const a4r_gemm_t& g = *gp;
+    if (!g.A || !g.B || !g.C) return A4R_EINVAL;
+    if (g.M <= 0 || g.N <= 0 || g.K <= 0 || g.M % 128 || g.N % 64 || g.K % 64) return A4R_EINVAL;
+    const int isz = g.in_dtype == A4R_F32 ? 4 : 2, osz = g.out_dtype == A4R_F32 ? 4 : 2;
+    if ((g.in_dtype != A4R_F32 && g.in_dtype != A4R_BF16) || (g.out_dtype != A4R_F32 && g.out_dtype != A4R_BF16)) return A4R_EINVAL;
+    if (g.lda < g.K || g.ldb < g.K || g.ldc < g.N) return A4R_EINVAL;
+    if ((g.lda * isz) % 16 || (g.ldb * isz) % 16 || (g.ldc * osz) % 16) return A4R_EINVAL;
+    if (!aligned16(g.A) || !aligned16(g.B) || !aligned16(g.C)) return A4R_EINVAL;
+    if (g.C2 && (!aligned16(g.C2) || (g.ldc2 * osz) % 16 || g.ldc2 < g.N)) return A4R_EINVAL;
+    if (g.R1 && (!aligned16(g.R1) || (g.ldr1 * osz) % 16 || g.ldr1 < g.N)) return A4R_EINVAL;
+    if (g.R2 && (!aligned16(g.R2) || (g.ldr2 * osz) % 16 || g.ldr2 < g.N)) return A4R_EINVAL;
+    if (g.dact != A4R_ACT_NONE && (!g.Pre || !aligned16(g.Pre) || (g.ldpre * osz) % 16 || g.ldpre < g.N)) return A4R_EINVAL;
+    if (g.drop_p < 0.f || g.drop_p >= 1.f) return A4R_EINVAL;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    if (g.in_dtype == A4R_BF16 && g.out_dtype == A4R_BF16) return launch_bn<bf16_t, bf16_t>(s, g);
+    if (g.in_dtype == A4R_F32 && g.out_dtype == A4R_F32) return launch_bn<float, float>(s, g);
+    if (g.in_dtype == A4R_BF16 && g.out_dtype == A4R_F32) return launch_bn<bf16_t, float>(s, g);
+    return launch_bn<float, bf16_t>(s, g);
+}

@@ -1,0 +1,193 @@
+// Scoring head + BCE loss (model/model.py:53-68, ModelCPC :118-133), Adam, parameter re-packing.
+// All fp32; these are tiny, launch-latency-bound kernels.
+#include "a4r_common.h"
+#include "../../include/a4r.h"
+
+namespace {
+
+A4R_DEV float softplusf(float x) { return fmaxf(x, 0.f) + log1pf(expf(-fabsf(x))); }
+A4R_DEV float sigmoidf(float x) { return 1.f / (1.f + expf(-x)); }
+
+// one wave per (b, t), t in [0, L-1): pos = prec[b,t] . emb[b,t+1,0], neg = prec[b,t] . emb[b,t,1]
+__global__ void __launch_bounds__(256) score_fwd_kernel(const float* __restrict__ emb, const float* __restrict__ prec,
+                                                        const float* __restrict__ log_mask, float* __restrict__ pos,
+                                                        float* __restrict__ neg, float* __restrict__ ws, int B, int L, int E, int cpc) {
+    const int lane = threadIdx.x & 63;
+    const int T = L - 1;
+    float lsum = 0.f, lcnt = 0.f;
+    for (int r = blockIdx.x * 4 + (threadIdx.x >> 6); r < B * T; r += gridDim.x * 4) {
+        const int b = r / T, t = r % T;
+        const float* pv = prec + (size_t)r * E;
+        const float* tp = emb + (((size_t)b * L + t + 1) * 2 + 0) * E;
+        const float* tn = emb + (((size_t)b * L + t) * 2 + 1) * E;
+        float sp = 0.f, sn = 0.f;
+        for (int e = lane; e < E; e += 64) { sp += pv[e] * tp[e]; sn += pv[e] * tn[e]; }
+        sp = wave_sum(sp);
+        sn = wave_sum(sn);
+        if (lane == 0) {
+            pos[r] = sp;
+            neg[r] = sn;
+            const bool valid = cpc ? (t == T - 1) : (log_mask[r] != 0.f);
+            if (valid) { lsum += softplusf(-sp) + softplusf(sn); lcnt += 1.f; }
+        }
+    }
+    if (lane == 0 && lcnt > 0.f) { atomicAdd(ws + 1, lsum); atomicAdd(ws + 2, lcnt); }
+}
+__global__ void loss_finalize_kernel(float* ws) { ws[0] = ws[1] / ws[2]; }
+
+// one wave per (b, l): d_emb[b,l,0] = dpos(t=l-1) * prec[b,l-1];  d_emb[b,l,1] = dneg(t=l) * prec[b,l];
+// and per (b, t): d_prec[b,t] = dpos * emb[b,t+1,0] + dneg * emb[b,t,1]
+__global__ void __launch_bounds__(256) score_bwd_kernel(const float* __restrict__ emb, const float* __restrict__ prec,
+                                                        const float* __restrict__ log_mask, const float* __restrict__ pos,
+                                                        const float* __restrict__ neg, const float* __restrict__ ws, float loss_scale,
+                                                        float* __restrict__ d_prec, float* __restrict__ d_emb, int B, int L, int E, int cpc) {
+    const int lane = threadIdx.x & 63;
+    const int T = L - 1;
+    const float g = loss_scale / ws[2];
+    for (int r = blockIdx.x * 4 + (threadIdx.x >> 6); r < B * L; r += gridDim.x * 4) {
+        const int b = r / L, l = r % L;
+        float dpos_prev = 0.f, dneg_here = 0.f, dpos_here = 0.f;
+        if (l >= 1) {
+            const int t = l - 1, i = b * T + t;
+            const bool valid = cpc ? (t == T - 1) : (log_mask[i] != 0.f);
+            if (valid) dpos_prev = (sigmoidf(pos[i]) - 1.f) * g;
+        }
+        if (l < T) {
+            const int i = b * T + l;
+            const bool valid = cpc ? (l == T - 1) : (log_mask[i] != 0.f);
+            if (valid) { dneg_here = sigmoidf(neg[i]) * g; dpos_here = (sigmoidf(pos[i]) - 1.f) * g; }
+        }
+        float* de0 = d_emb + (((size_t)b * L + l) * 2 + 0) * E;
+        float* de1 = d_emb + (((size_t)b * L + l) * 2 + 1) * E;
+        for (int e = lane; e < E; e += 64) {
+            de0[e] = (l >= 1) ? dpos_prev * prec[((size_t)b * T + l - 1) * E + e] : 0.f;
+            de1[e] = (l < T) ? dneg_here * prec[((size_t)b * T + l) * E + e] : 0.f;
+            if (l < T)
+                d_prec[((size_t)b * T + l) * E + e] = dpos_here * emb[(((size_t)b * L + l + 1) * 2 + 0) * E + e] +
+                                                      dneg_here * emb[(((size_t)b * L + l) * 2 + 1) * E + e];
+        }
+    }
+}
+
+__global__ void __launch_bounds__(256) emb_grad_add_inputs_kernel(const float* __restrict__ d_in, int ldi, float* __restrict__ d_emb,
+                                                                  int B, int L, int E) {
+    const int T = L - 1;
+    const size_t total = (size_t)B * T * E;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const int e = (int)(i % E);
+        const size_t r = i / E;
+        const int b = (int)(r / T), l = (int)(r % T);
+        d_emb[(((size_t)b * L + l) * 2 + 0) * E + e] += d_in[r * ldi + e];
+    }
+}
+__global__ void __launch_bounds__(256) take_inputs_kernel(const float* __restrict__ emb, float* __restrict__ out, int ldo, int B, int L, int E) {
+    const int T = L - 1;
+    const size_t total = (size_t)B * T * E;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const int e = (int)(i % E);
+        const size_t r = i / E;
+        const int b = (int)(r / T), l = (int)(r % T);
+        out[r * ldo + e] = emb[(((size_t)b * L + l) * 2 + 0) * E + e];
+    }
+}
+
+// ------------------------------------------------------------------ Adam over a flat buffer
+__global__ void __launch_bounds__(256) adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                                   float* __restrict__ v, int64_t n, const int32_t* __restrict__ seg_end,
+                                                   const int32_t* __restrict__ seg_group, int n_seg, const float* __restrict__ group_lr,
+                                                   float bc1, float bc2_sqrt, float beta1, float beta2, float eps, float grad_scale) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        int lo = 0, hi = n_seg - 1;            // first segment with seg_end > i
+        while (lo < hi) {
+            const int mid = (lo + hi) >> 1;
+            if (seg_end[mid] > i) hi = mid; else lo = mid + 1;
+        }
+        const float lr = group_lr[seg_group[lo]];
+        const float gi = g[i] * grad_scale;
+        const float mi = beta1 * m[i] + (1.f - beta1) * gi;
+        const float vi = beta2 * v[i] + (1.f - beta2) * gi * gi;
+        m[i] = mi;
+        v[i] = vi;
+        // torch.optim.Adam: p -= (lr / bc1) * m / (sqrt(v) / sqrt(bc2) + eps)
+        p[i] -= (lr / bc1) * mi / (sqrtf(vi) / bc2_sqrt + eps);
+    }
+}
+
+struct PackDesc {   // mirrors a4r_pack_desc_t
+    int64_t src_off; void* dst; int32_t rows, cols, rows_pad, cols_pad, transpose, pad_;
+};
+template <typename T>
+__global__ void __launch_bounds__(256) pack_kernel(const float* __restrict__ flat, const PackDesc* __restrict__ desc) {
+    const PackDesc d = desc[blockIdx.y];
+    T* dst = reinterpret_cast<T*>(d.dst);
+    const int total = d.rows_pad * d.cols_pad;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
+        const int r = i / d.cols_pad, c = i % d.cols_pad;     // destination coordinates
+        const int sr = d.transpose ? c : r, sc = d.transpose ? r : c;
+        float val = 0.f;
+        if (sr < d.rows && sc < d.cols) val = flat[d.src_off + (int64_t)sr * d.cols + sc];
+        Elem<T>::st(dst + i, val);
+    }
+}
+
+}  // namespace
+
+extern "C" int a4r_score_bce_fwd(void* stream, const float* emb, const float* prec, const float* log_mask,
+                                 float* pos, float* neg, float* loss_ws, int B, int L, int E, int cpc) {
+    if (!emb || !prec || !log_mask || !pos || !neg || !loss_ws || B <= 0 || L < 2 || E <= 0) return A4R_EINVAL;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    int grid = (B * (L - 1) + 3) / 4; if (grid > 1024) grid = 1024;
+    hipLaunchKernelGGL(score_fwd_kernel, dim3(grid), dim3(256), 0, s, emb, prec, log_mask, pos, neg, loss_ws, B, L, E, cpc);
+    hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(1), 0, s, loss_ws);
+    return a4r_launch_status();
+}
+
+extern "C" int a4r_score_bce_bwd(void* stream, const float* emb, const float* prec, const float* log_mask,
+                                 const float* pos, const float* neg, const float* loss_ws, float loss_scale,
+                                 float* d_prec, float* d_emb, int B, int L, int E, int cpc) {
+    if (!emb || !prec || !log_mask || !pos || !neg || !loss_ws || !d_prec || !d_emb || B <= 0 || L < 2 || E <= 0) return A4R_EINVAL;
+    int grid = (B * L + 3) / 4; if (grid > 1024) grid = 1024;
+    hipLaunchKernelGGL(score_bwd_kernel, dim3(grid), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), emb, prec, log_mask, pos, neg,
+                       loss_ws, loss_scale, d_prec, d_emb, B, L, E, cpc);
+    return a4r_launch_status();
+}
+
+extern "C" int a4r_emb_grad_add_inputs(void* stream, const float* d_in, int ldi, float* d_emb, int B, int L, int E) {
+    if (!d_in || !d_emb || B <= 0 || L < 2 || E <= 0 || ldi < E) return A4R_EINVAL;
+    const size_t total = (size_t)B * (L - 1) * E;
+    int grid = (int)((total + 255) / 256); if (grid > 1024) grid = 1024;
+    hipLaunchKernelGGL(emb_grad_add_inputs_kernel, dim3(grid), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), d_in, ldi, d_emb, B, L, E);
+    return a4r_launch_status();
+}
+
+extern "C" int a4r_take_inputs(void* stream, const float* emb, float* out, int ldo, int B, int L, int E) {
+    if (!emb || !out || B <= 0 || L < 2 || E <= 0 || ldo < E) return A4R_EINVAL;
+    const size_t total = (size_t)B * (L - 1) * E;
+    int grid = (int)((total + 255) / 256); if (grid > 1024) grid = 1024;
+    hipLaunchKernelGGL(take_inputs_kernel, dim3(grid), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), emb, out, ldo, B, L, E);
+    return a4r_launch_status();
+}
+
+extern "C" int a4r_adam_step(void* stream, float* p, const float* g, float* m, float* v, int64_t n,
+                             const int32_t* seg_end, const int32_t* seg_group, int n_seg,
+                             const float* group_lr, int step, float beta1, float beta2, float eps, float grad_scale) {
+    if (!p || !g || !m || !v || !seg_end || !seg_group || !group_lr || n <= 0 || n_seg <= 0 || step < 1) return A4R_EINVAL;
+    const float bc1 = 1.f - powf(beta1, (float)step);
+    const float bc2 = 1.f - powf(beta2, (float)step);
+    int grid = (int)((n + 255) / 256); if (grid > 2048) grid = 2048;
+    hipLaunchKernelGGL(adam_kernel, dim3(grid), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), p, g, m, v, n, seg_end, seg_group,
+                       n_seg, group_lr, bc1, sqrtf(bc2), beta1, beta2, eps, grad_scale);
+    return a4r_launch_status();
+}
+
+extern "C" int a4r_pack_matrices(void* stream, const float* flat, const a4r_pack_desc_t* desc_dev, int n_desc, int max_elems, int dtype) {
+    if (!flat || !desc_dev || n_desc <= 0 || max_elems <= 0 || (dtype != A4R_BF16 && dtype != A4R_F32)) return A4R_EINVAL;
+    int gx = (max_elems + 255) / 256; if (gx > 64) gx = 64;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    const PackDesc* d = reinterpret_cast<const PackDesc*>(desc_dev);
+    if (dtype == A4R_BF16) hipLaunchKernelGGL(pack_kernel<bf16_t>, dim3(gx, n_desc), dim3(256), 0, s, flat, d);
+    else hipLaunchKernelGGL(pack_kernel<float>, dim3(gx, n_desc), dim3(256), 0, s, flat, d);
+    return a4r_launch_status();
+}
+
+extern "C" int a4r_version(void) { return 100; }

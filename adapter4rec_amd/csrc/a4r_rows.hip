@@ -1,0 +1,350 @@
+// Row kernels (HBM-bound): embeddings + LayerNorm, LayerNorm forward/backward, CLS gather/scatter,
+// small elementwise helpers.  One 64-lane wave owns one row of width H <= 1024 (H % 8 == 0): lane l
+// holds the 8-element groups l and l + 64, so every global access is 16 B (bf16) / 2 x 16 B (fp32)
+// per lane and the row statistics are two wave reductions.  All arithmetic is fp32.
+#include "a4r_common.h"
+#include "../../include/a4r.h"
+
+namespace {
+
+constexpr int MAXG = 2;   // 8-element groups per lane: H <= 64 * 2 * 8 = 1024
+
+template <typename T>
+A4R_DEV void row_load(const T* p, int ng, int lane, float (&v)[MAXG][8]) {
+#pragma unroll
+    for (int g = 0; g < MAXG; ++g) {
+        const int gi = lane + 64 * g;
+        if (gi < ng) load_vec<T, 8>(p + gi * 8, v[g]);
+        else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[g][e] = 0.f;
+        }
+    }
+}
+template <typename T>
+A4R_DEV void row_store(T* p, int ng, int lane, const float (&v)[MAXG][8]) {
+#pragma unroll
+    for (int g = 0; g < MAXG; ++g) {
+        const int gi = lane + 64 * g;
+        if (gi < ng) store_vec<T, 8>(p + gi * 8, v[g]);
+    }
+}
+
+// mean / rstd of one row held across the wave (two-pass, values already in registers)
+A4R_DEV void row_stats(const float (&v)[MAXG][8], int ng, int lane, int H, float eps, float& mean, float& rstd) {
+    float s = 0.f;
+#pragma unroll
+    for (int g = 0; g < MAXG; ++g)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) s += v[g][e];
+    mean = wave_sum(s) / (float)H;
+    float q = 0.f;
+#pragma unroll
+    for (int g = 0; g < MAXG; ++g) {
+        if (lane + 64 * g < ng) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { const float d = v[g][e] - mean; q += d * d; }
+        }
+    }
+    rstd = rsqrtf(wave_sum(q) / (float)H + eps);
+}
+
+A4R_DEV void row_dropout(float (&v)[MAXG][8], int ng, int lane, size_t row, int H, uint64_t seed, uint32_t site, uint32_t thr16, float scale) {
+#pragma unroll
+    for (int g = 0; g < MAXG; ++g) {
+        const int gi = lane + 64 * g;
+        if (gi < ng) {
+            const uint64_t e0 = (uint64_t)row * (uint64_t)H + (uint64_t)gi * 8;
+            const uint64_t h0 = a4r_hash64(seed, site, e0 >> 2), h1 = a4r_hash64(seed, site, (e0 >> 2) + 1);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                v[g][e] = (((uint32_t)(h0 >> (16 * e)) & 0xffffu) >= thr16) ? v[g][e] * scale : 0.f;
+                v[g][e + 4] = (((uint32_t)(h1 >> (16 * e)) & 0xffffu) >= thr16) ? v[g][e + 4] * scale : 0.f;
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------ embeddings + LN
+template <typename T>
+__global__ void __launch_bounds__(256) embed_ln_kernel(const int64_t* __restrict__ ids, int ld_ids, const float* __restrict__ word,
+                                                       const float* __restrict__ pos, const float* __restrict__ type0,
+                                                       const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
+                                                       T* __restrict__ out, int ldo, int n_rows, int S, int H, int roberta, int pad_id,
+                                                       uint64_t seed, uint32_t site, uint32_t thr16, float scale) {
+    const int lane = threadIdx.x & 63;
+    const int ng = H / 8;
+    for (int row = blockIdx.x * 4 + (threadIdx.x >> 6); row < n_rows; row += gridDim.x * 4) {
+        const int item = row / S, s = row % S;
+        const int64_t* idr = ids + (size_t)item * ld_ids;
+        const int64_t id = idr[s];
+        int pid = s;
+        if (roberta) {        // cumsum(id != pad) * (id != pad) + pad
+            int c = 0;
+            for (int t = 0; t <= s; ++t) c += (idr[t] != pad_id);
+            pid = (id != pad_id) ? c + pad_id : pad_id;
+        }
+        float v[MAXG][8], a[MAXG][8], b[MAXG][8];
+        row_load<float>(word + (size_t)id * H, ng, lane, v);
+        row_load<float>(pos + (size_t)pid * H, ng, lane, a);
+        row_load<float>(type0, ng, lane, b);
+#pragma unroll
+        for (int g = 0; g < MAXG; ++g)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[g][e] += a[g][e] + b[g][e];
+        float mean, rstd;
+        row_stats(v, ng, lane, H, eps, mean, rstd);
+        row_load<float>(gamma, ng, lane, a);
+        row_load<float>(beta, ng, lane, b);
+#pragma unroll
+        for (int g = 0; g < MAXG; ++g)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[g][e] = (v[g][e] - mean) * rstd * a[g][e] + b[g][e];
+        if (thr16) row_dropout(v, ng, lane, row, H, seed, site, thr16, scale);
+        row_store<T>(out + (size_t)row * ldo, ng, lane, v);
+    }
+}
+
+// ------------------------------------------------------------------ LN forward
+template <typename T>
+__global__ void __launch_bounds__(256) ln_fwd_kernel(const T* __restrict__ vin, int ldv, const float* __restrict__ add, int add_rows,
+                                                     const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
+                                                     T* __restrict__ y, int ldy, float* __restrict__ stats, int M, int H,
+                                                     uint64_t seed, uint32_t site, uint32_t thr16, float scale) {
+    const int lane = threadIdx.x & 63;
+    const int ng = H / 8;
+    float ga[MAXG][8], be[MAXG][8];
+    row_load<float>(gamma, ng, lane, ga);
+    row_load<float>(beta, ng, lane, be);
+    for (int row = blockIdx.x * 4 + (threadIdx.x >> 6); row < M; row += gridDim.x * 4) {
+        float v[MAXG][8];
+        row_load<T>(vin + (size_t)row * ldv, ng, lane, v);
+        if (add) {
+            float a[MAXG][8];
+            row_load<float>(add + (size_t)(row % add_rows) * H, ng, lane, a);
+#pragma unroll
+            for (int g = 0; g < MAXG; ++g)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[g][e] += a[g][e];
+        }
+        float mean, rstd;
+        row_stats(v, ng, lane, H, eps, mean, rstd);
+        if (stats && lane == 0) { stats[2 * (size_t)row] = mean; stats[2 * (size_t)row + 1] = rstd; }
+#pragma unroll
+        for (int g = 0; g < MAXG; ++g)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[g][e] = (v[g][e] - mean) * rstd * ga[g][e] + be[g][e];
+        if (thr16) row_dropout(v, ng, lane, row, H, seed, site, thr16, scale);
+        row_store<T>(y + (size_t)row * ldy, ng, lane, v);
+    }
+}
+
+// ------------------------------------------------------------------ LN backward
+// dv = rstd * (dxhat - mean(dxhat) - xhat * mean(dxhat * xhat)), dxhat = dy * gamma (dy first goes back through
+// the forward's dropout mask).  Column sums (dgamma, dbeta, dbias = sum dv) are kept per lane over the rows a
+// wave visits, reduced over the block's 4 waves in LDS, and flushed with one atomic per column per block.
+template <typename T>
+__global__ void __launch_bounds__(256) ln_bwd_kernel(const T* __restrict__ dy, int lddy, const T* __restrict__ vin, int ldv,
+                                                     const float* __restrict__ add, int add_rows, const float* __restrict__ stats,
+                                                     const float* __restrict__ gamma, T* __restrict__ dv, int lddv,
+                                                     float* __restrict__ dgamma, float* __restrict__ dbeta, float* __restrict__ dbias,
+                                                     int M, int H, uint64_t seed, uint32_t site, uint32_t thr16, float scale) {
+    __shared__ float red[3][4][1024];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int ng = H / 8;
+    float ga[MAXG][8];
+    row_load<float>(gamma, ng, lane, ga);
+    float sg[MAXG][8], sb[MAXG][8], sv[MAXG][8];
+#pragma unroll
+    for (int g = 0; g < MAXG; ++g)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { sg[g][e] = 0.f; sb[g][e] = 0.f; sv[g][e] = 0.f; }
+    for (int row = blockIdx.x * 4 + wave; row < M; row += gridDim.x * 4) {
+        float v[MAXG][8], d[MAXG][8];
+        row_load<T>(vin + (size_t)row * ldv, ng, lane, v);
+        row_load<T>(dy + (size_t)row * lddy, ng, lane, d);
+        if (add) {
+            float a[MAXG][8];
+            row_load<float>(add + (size_t)(row % add_rows) * H, ng, lane, a);
+#pragma unroll
+            for (int g = 0; g < MAXG; ++g)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[g][e] += a[g][e];
+        }
+        if (thr16) row_dropout(d, ng, lane, row, H, seed, site, thr16, scale);
+        const float mean = stats[2 * (size_t)row], rstd = stats[2 * (size_t)row + 1];
+        float c1 = 0.f, c2 = 0.f;
+#pragma unroll
+        for (int g = 0; g < MAXG; ++g) {
+            if (lane + 64 * g < ng) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const float xh = (v[g][e] - mean) * rstd;
+                    sg[g][e] += d[g][e] * xh;
+                    sb[g][e] += d[g][e];
+                    const float dx = d[g][e] * ga[g][e];
+                    v[g][e] = xh;
+                    d[g][e] = dx;
+                    c1 += dx;
+                    c2 += dx * xh;
+                }
+            }
+        }
+        c1 = wave_sum(c1) / (float)H;
+        c2 = wave_sum(c2) / (float)H;
+#pragma unroll
+        for (int g = 0; g < MAXG; ++g) {
+            if (lane + 64 * g < ng) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    d[g][e] = rstd * (d[g][e] - c1 - v[g][e] * c2);
+                    sv[g][e] += d[g][e];
+                }
+            }
+        }
+        row_store<T>(dv + (size_t)row * lddv, ng, lane, d);
+    }
+    if (!dgamma && !dbeta && !dbias) return;      // uniform across the block
+#pragma unroll
+    for (int g = 0; g < MAXG; ++g) {
+        const int gi = lane + 64 * g;
+        if (gi < ng) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                red[0][wave][gi * 8 + e] = sg[g][e];
+                red[1][wave][gi * 8 + e] = sb[g][e];
+                red[2][wave][gi * 8 + e] = sv[g][e];
+            }
+        }
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < H; c += 256) {
+        if (dgamma) atomicAdd(dgamma + c, red[0][0][c] + red[0][1][c] + red[0][2][c] + red[0][3][c]);
+        if (dbeta) atomicAdd(dbeta + c, red[1][0][c] + red[1][1][c] + red[1][2][c] + red[1][3][c]);
+        if (dbias) atomicAdd(dbias + c, red[2][0][c] + red[2][1][c] + red[2][2][c] + red[2][3][c]);
+    }
+}
+
+// ------------------------------------------------------------------ row gather / scatter, elementwise
+template <typename T, bool SCATTER>
+__global__ void __launch_bounds__(256) rows_copy_kernel(const T* __restrict__ in, int ldi, T* __restrict__ out, int ldo,
+                                                        int n, int row_step, int H) {
+    constexpr int PER = Elem<T>::PER16;
+    const int cpr = H / PER;
+    const size_t total = (size_t)n * cpr;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const size_t r = i / cpr;
+        const int c = (int)(i % cpr) * PER;
+        const size_t ri = SCATTER ? r : r * row_step, ro = SCATTER ? r * row_step : r;
+        *reinterpret_cast<uint4*>(out + ro * ldo + c) = *reinterpret_cast<const uint4*>(in + ri * ldi + c);
+    }
+}
+
+__global__ void __launch_bounds__(256) act_bwd_f32_kernel(const float* __restrict__ dy, const float* __restrict__ pre,
+                                                          float* __restrict__ dx, int64_t n, int act) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256)
+        dx[i] = dy[i] * act_bwd(pre[i], act);
+}
+
+inline bool bad_dtype(int d) { return d != A4R_F32 && d != A4R_BF16; }
+inline bool misaligned(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) != 0; }
+inline int row_grid(int rows) { int g = (rows + 3) / 4; return g > 2048 ? 2048 : (g < 1 ? 1 : g); }
+
+}  // namespace
+
+extern "C" int a4r_embed_ln(void* stream, const int64_t* ids, int ld_ids, const float* word, const float* pos,
+                            const float* type0, const float* gamma, const float* beta, float eps,
+                            void* out, int ldo, int n_items, int S, int H, int roberta, int pad_id, int dtype,
+                            float drop_p, uint32_t drop_site, uint64_t drop_seed) {
+    if (!ids || !word || !pos || !type0 || !gamma || !beta || !out) return A4R_EINVAL;
+    if (bad_dtype(dtype) || n_items <= 0 || S <= 0 || H <= 0 || H % 8 || H > 1024 || ld_ids < S) return A4R_EINVAL;
+    const int esz = dtype == A4R_F32 ? 4 : 2;
+    if ((ldo * esz) % 16 || ldo < H || misaligned(out) || misaligned(word) || misaligned(pos) || misaligned(type0)) return A4R_EINVAL;
+    if (drop_p < 0.f || drop_p >= 1.f) return A4R_EINVAL;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    const int rows = n_items * S;
+    const uint32_t thr = a4r_thr16(drop_p);
+    const float sc = a4r_keep_scale(drop_p);
+    if (dtype == A4R_BF16)
+        hipLaunchKernelGGL(embed_ln_kernel<bf16_t>, dim3(row_grid(rows)), dim3(256), 0, s, ids, ld_ids, word, pos, type0, gamma, beta, eps,
+                           (bf16_t*)out, ldo, rows, S, H, roberta, pad_id, drop_seed, drop_site, thr, sc);
+    else
+        hipLaunchKernelGGL(embed_ln_kernel<float>, dim3(row_grid(rows)), dim3(256), 0, s, ids, ld_ids, word, pos, type0, gamma, beta, eps,
+                           (float*)out, ldo, rows, S, H, roberta, pad_id, drop_seed, drop_site, thr, sc);
+    return a4r_launch_status();
+}
+
+extern "C" int a4r_ln_fwd(void* stream, const void* v, int ldv, const float* add, int add_rows,
+                          const float* gamma, const float* beta, float eps,
+                          void* y, int ldy, float* stats, int M, int H, int dtype,
+                          float drop_p, uint32_t drop_site, uint64_t drop_seed) {
+    if (!v || !gamma || !beta || !y || bad_dtype(dtype) || M <= 0 || H <= 0 || H % 8 || H > 1024) return A4R_EINVAL;
+    const int esz = dtype == A4R_F32 ? 4 : 2;
+    if ((ldv * esz) % 16 || (ldy * esz) % 16 || ldv < H || ldy < H || misaligned(v) || misaligned(y)) return A4R_EINVAL;
+    if (add && (add_rows <= 0 || misaligned(add))) return A4R_EINVAL;
+    if (drop_p < 0.f || drop_p >= 1.f) return A4R_EINVAL;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    const uint32_t thr = a4r_thr16(drop_p);
+    const float sc = a4r_keep_scale(drop_p);
+    if (dtype == A4R_BF16)
+        hipLaunchKernelGGL(ln_fwd_kernel<bf16_t>, dim3(row_grid(M)), dim3(256), 0, s, (const bf16_t*)v, ldv, add, add_rows, gamma, beta, eps,
+                           (bf16_t*)y, ldy, stats, M, H, drop_seed, drop_site, thr, sc);
+    else
+        hipLaunchKernelGGL(ln_fwd_kernel<float>, dim3(row_grid(M)), dim3(256), 0, s, (const float*)v, ldv, add, add_rows, gamma, beta, eps,
+                           (float*)y, ldy, stats, M, H, drop_seed, drop_site, thr, sc);
+    return a4r_launch_status();
+}
+
+extern "C" int a4r_ln_bwd(void* stream, const void* dy, int lddy, const void* v, int ldv, const float* add, int add_rows,
+                          const float* stats, const float* gamma, void* dv, int lddv,
+                          float* dgamma, float* dbeta, float* dbias, int M, int H, int dtype,
+                          float drop_p, uint32_t drop_site, uint64_t drop_seed) {
+    if (!dy || !v || !stats || !gamma || !dv || bad_dtype(dtype) || M <= 0 || H <= 0 || H % 8 || H > 1024) return A4R_EINVAL;
+    const int esz = dtype == A4R_F32 ? 4 : 2;
+    if ((lddy * esz) % 16 || (ldv * esz) % 16 || (lddv * esz) % 16 || lddy < H || ldv < H || lddv < H) return A4R_EINVAL;
+    if (misaligned(dy) || misaligned(v) || misaligned(dv)) return A4R_EINVAL;
+    if (add && (add_rows <= 0 || misaligned(add))) return A4R_EINVAL;
+    if (drop_p < 0.f || drop_p >= 1.f) return A4R_EINVAL;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    const uint32_t thr = a4r_thr16(drop_p);
+    const float sc = a4r_keep_scale(drop_p);
+    int grid = row_grid(M);
+    if (grid > 512) grid = 512;      // bounds the column-sum atomics: 512 blocks x H per accumulator
+    if (dtype == A4R_BF16)
+        hipLaunchKernelGGL(ln_bwd_kernel<bf16_t>, dim3(grid), dim3(256), 0, s, (const bf16_t*)dy, lddy, (const bf16_t*)v, ldv, add, add_rows,
+                           stats, gamma, (bf16_t*)dv, lddv, dgamma, dbeta, dbias, M, H, drop_seed, drop_site, thr, sc);
+    else
+        hipLaunchKernelGGL(ln_bwd_kernel<float>, dim3(grid), dim3(256), 0, s, (const float*)dy, lddy, (const float*)v, ldv, add, add_rows,
+                           stats, gamma, (float*)dv, lddv, dgamma, dbeta, dbias, M, H, drop_seed, drop_site, thr, sc);
+    return a4r_launch_status();
+}
+
+static int rows_copy(void* stream, const void* in, int ldi, void* out, int ldo, int n, int row_step, int H, int dtype, bool scatter) {
+    if (!in || !out || bad_dtype(dtype) || n <= 0 || row_step <= 0 || H <= 0) return A4R_EINVAL;
+    const int esz = dtype == A4R_F32 ? 4 : 2;
+    if ((H * esz) % 16 || (ldi * esz) % 16 || (ldo * esz) % 16 || misaligned(in) || misaligned(out)) return A4R_EINVAL;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    const size_t total = (size_t)n * (H * esz / 16);
+    int grid = (int)((total + 255) / 256); if (grid > 2048) grid = 2048;
+    if (dtype == A4R_BF16) {
+        if (scatter) hipLaunchKernelGGL((rows_copy_kernel<bf16_t, true>), dim3(grid), dim3(256), 0, s, (const bf16_t*)in, ldi, (bf16_t*)out, ldo, n, row_step, H);
+        else hipLaunchKernelGGL((rows_copy_kernel<bf16_t, false>), dim3(grid), dim3(256), 0, s, (const bf16_t*)in, ldi, (bf16_t*)out, ldo, n, row_step, H);
+    } else {
+        if (scatter) hipLaunchKernelGGL((rows_copy_kernel<float, true>), dim3(grid), dim3(256), 0, s, (const float*)in, ldi, (float*)out, ldo, n, row_step, H);
+        else hipLaunchKernelGGL((rows_copy_kernel<float, false>), dim3(grid), dim3(256), 0, s, (const float*)in, ldi, (float*)out, ldo, n, row_step, H);
+    }
+    return a4r_launch_status();
+}
+extern "C" int a4r_gather_rows(void* stream, const void* in, int ldi, void* out, int ldo, int n, int row_step, int H, int dtype) {
+    return rows_copy(stream, in, ldi, out, ldo, n, row_step, H, dtype, false);
+}
+extern "C" int a4r_scatter_rows(void* stream, const void* in, int ldi, void* out, int ldo, int n, int row_step, int H, int dtype) {
+    return rows_copy(stream, in, ldi, out, ldo, n, row_step, H, dtype, true);
+}
+
+extern "C" int a4r_act_bwd_f32(void* stream, const float* dy, const float* pre, float* dx, int64_t n, int act) {
+    if (!dy || !pre || !dx || n <= 0) return A4R_EINVAL;
+    int grid = (int)((n + 255) / 256); if (grid > 2048) grid = 2048;
+    hipLaunchKernelGGL(act_bwd_f32_kernel, dim3(grid), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), dy, pre, dx, n, act);
+    return a4r_launch_status();
+}

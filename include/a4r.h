@@ -1,0 +1,149 @@
+/* a4r.h -- C ABI of liba4r_hip.so: the MI355X-native kernels behind the adapter-tuned
+ * TransRec training step (reference: westlake-repl/Adapter4Rec).
+ *
+ * The reference has no FFI: its hot path is eager PyTorch called from Python
+ * (Downstream/Text/run.py:595-600 -> model/model.py:48-70).  Each entry point below replaces
+ * the op sequence of the cited reference lines; the host mirror of the reference's Python
+ * interface (adapter4rec_amd/model, engine.py) binds them through ctypes.
+ *
+ * Conventions
+ *  - every pointer is a DEVICE pointer unless stated; the caller owns all memory;
+ *  - `stream` is a hipStream_t (0 = default stream); calls only enqueue work, they never
+ *    synchronise, allocate or free -- so they can be captured into a hipGraph;
+ *  - matrices are row-major, leading dimensions in ELEMENTS; row counts of activations are
+ *    padded by the caller to a multiple of 128 (padding rows hold finite values);
+ *  - dtype: A4R_BF16 (0) = bf16 storage / fp32 accumulate, A4R_F32 (1) = fp32 everywhere;
+ *  - return value: 0 ok, -1 invalid argument (shape/alignment/dtype), -2 launch failure.
+ *    No entry point aborts.
+ */
+#ifndef A4R_H
+#define A4R_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define A4R_BF16 0
+#define A4R_F32 1
+#define A4R_ACT_NONE 0
+#define A4R_ACT_RELU 1
+#define A4R_ACT_GELU 2       /* exact erf form (HF "gelu", nn.GELU) */
+#define A4R_ACT_GELU_TANH 3  /* HF "gelu_new" (compacter, model/modules.py:220) */
+#define A4R_ACT_LEAKY 4
+
+int a4r_version(void);
+
+/* C[M,N] = epilogue(alpha * A[M,K] . B[N,K]^T): every nn.Linear on the path (HF BertSelfAttention
+ * q/k/v, BertSelfOutput.dense, BertIntermediate, BertOutput.dense; AdapterBlock fc_down/fc_up
+ * model/modules.py:130-134; SASRec w_Q/w_K/w_V/fc/w_1/w_2 modules.py:23-28,63-74) and its dgrad.
+ * epilogue, in order: + bias[N]; C2 = copy (saved pre-activation); act; * act'(Pre) if dact;
+ * + R1 + R2 (residuals); dropout(p, seed, site) regenerated identically in backward; store C.
+ * M % 128 == 0, N % 64 == 0, K % 64 == 0.  A,B have in_dtype; C,C2,R1,R2,Pre have out_dtype. */
+typedef struct {
+    const void* A; const void* B; void* C;
+    const float* bias; void* C2; const void* R1; const void* R2; const void* Pre;
+    int32_t M, N, K;
+    int32_t lda, ldb, ldc, ldc2, ldr1, ldr2, ldpre;
+    int32_t in_dtype, out_dtype;
+    int32_t act, dact;
+    float alpha;
+    float drop_p; uint32_t drop_site; uint64_t drop_seed;
+} a4r_gemm_t;
+int a4r_gemm_nt(void* stream, const a4r_gemm_t* g);
+
+/* C[P,Q] (fp32, +=) = X[M,P]^T . Y[M,Q]: weight gradients of the trainable adapter matrices
+ * (autograd of AdapterBlock, model/modules.py:130-134).  P % 64 == 0, Q % 64 == 0, M % 64 == 0.
+ * C must be zeroed (or hold the running sum) before the call; accumulation uses fp32 atomics. */
+int a4r_gemm_tn(void* stream, const void* X, int ldx, const void* Y, int ldy, float* C, int ldc,
+                int M, int P, int Q, int dtype);
+
+/* colsum[N] (fp32, +=) = sum over rows of X[M,N]: bias gradients. N % 8 == 0. */
+int a4r_colsum(void* stream, const void* X, int ldx, float* out, int M, int N, int dtype);
+
+/* Short-sequence self-attention, one wave per (item, head), S <= 32, dh in {32, 64}.
+ * BERT layer: HF BertSelfAttention (called from model/encoders.py:53); SASRec: SelfAttention
+ * model/modules.py:31-42 with the mask of model/encoders.py:24-28.
+ * qkv [n_items*S, ld]: q at column q_off, k at k_off, v at v_off, head h at +h*dh.
+ * score = q.k * scale + (allowed ? 0 : mask_neg), allowed = key_mask[item][key] != 0 and
+ * (!causal or key <= query); softmax over the S keys; attention-prob dropout; . V. */
+typedef struct {
+    const void* qkv; int32_t ld; int32_t q_off, k_off, v_off;
+    void* out; int32_t ldo;              /* fwd: ctx [n_items*S, ldo], head h at column h*dh */
+    const void* dout; void* dqkv;        /* bwd: d ctx (ldo) -> d qkv (ld, same offsets) */
+    const float* key_mask;               /* [n_items, S] (0 = masked) or NULL */
+    int32_t n_items, S, n_heads, dh, causal, dtype;
+    float scale, mask_neg;
+    float drop_p; uint32_t drop_site; uint64_t drop_seed;
+} a4r_attn_t;
+int a4r_attn_fwd(void* stream, const a4r_attn_t* a);
+int a4r_attn_bwd(void* stream, const a4r_attn_t* a);
+
+/* HF BertEmbeddings / RobertaEmbeddings: word[id] + pos[pos_id] + type[0] -> LayerNorm -> dropout.
+ * ids [n_items, S] int64 with row stride ld_ids (the reference hands over ids||mask rows of 2*S,
+ * model/encoders.py:49-52).  roberta != 0: pos_id = cumsum(id != pad) * (id != pad) + pad. */
+int a4r_embed_ln(void* stream, const int64_t* ids, int ld_ids, const float* word, const float* pos,
+                 const float* type0, const float* gamma, const float* beta, float eps,
+                 void* out, int ldo, int n_items, int S, int H, int roberta, int pad_id, int dtype,
+                 float drop_p, uint32_t drop_site, uint64_t drop_seed);
+
+/* y = LayerNorm(v) * gamma + beta over rows of width H (H % 8 == 0, H <= 1024);
+ * stats[2*row] = mean, stats[2*row+1] = rstd (fp32) saved for backward.  add (optional, fp32 [add_rows, H])
+ * is added to v first with row index (row % add_rows): SASRec position embedding (modules.py:101-106). */
+int a4r_ln_fwd(void* stream, const void* v, int ldv, const float* add, int add_rows,
+               const float* gamma, const float* beta, float eps,
+               void* y, int ldy, float* stats, int M, int H, int dtype,
+               float drop_p, uint32_t drop_site, uint64_t drop_seed);
+/* dv = LN backward of dy (through the same dropout mask when drop_p > 0); dgamma/dbeta (+=, fp32,
+ * optional: --finetune_layernorm, run.py:496-501); dbias (+= column sums of dv, optional: the bias
+ * gradient of the Linear whose output feeds v). */
+int a4r_ln_bwd(void* stream, const void* dy, int lddy, const void* v, int ldv, const float* add, int add_rows,
+               const float* stats, const float* gamma, void* dv, int lddv,
+               float* dgamma, float* dbeta, float* dbias, int M, int H, int dtype,
+               float drop_p, uint32_t drop_site, uint64_t drop_seed);
+
+/* out[i, :] = in[i * row_stride_rows, :] (CLS gather, model/encoders.py:55) and its scatter-transpose. */
+int a4r_gather_rows(void* stream, const void* in, int ldi, void* out, int ldo, int n, int row_step, int H, int dtype);
+int a4r_scatter_rows(void* stream, const void* in, int ldi, void* out, int ldo, int n, int row_step, int H, int dtype);
+
+/* y = x * act'(pre) elementwise on [M,N] fp32 (GELU backward of the item head, encoders.py:57). */
+int a4r_act_bwd_f32(void* stream, const float* dy, const float* pre, float* dx, int64_t n, int act);
+
+/* Scoring head + loss, model/model.py:53-68 (SASRec) / :118-133 (CPC).
+ * emb [B, L, 2, E] fp32 item embeddings (L = max_seq_len + 1), prec [B, L-1, E] user-encoder output,
+ * log_mask [B, L-1].  fwd: pos/neg scores [B, L-1]; loss_ws = 4 floats zeroed by the caller:
+ * [0] loss (mean over valid positions of softplus(-pos) + softplus(neg)), [1] sum, [2] valid count.
+ * bwd: d_prec [B, L-1, E] and d_emb [B, L, 2, E] (the target-side part; the caller adds the input side). */
+int a4r_score_bce_fwd(void* stream, const float* emb, const float* prec, const float* log_mask,
+                      float* pos, float* neg, float* loss_ws, int B, int L, int E, int cpc);
+int a4r_score_bce_bwd(void* stream, const float* emb, const float* prec, const float* log_mask,
+                      const float* pos, const float* neg, const float* loss_ws, float loss_scale,
+                      float* d_prec, float* d_emb, int B, int L, int E, int cpc);
+/* d_emb[b, l, 0, :] += d_in[b*(L-1) + l, :] for l < L-1 (gradient wrt the user-encoder input, model.py:57). */
+int a4r_emb_grad_add_inputs(void* stream, const float* d_in, int ldi, float* d_emb, int B, int L, int E);
+/* out[b*(L-1) + l, :] = emb[b, l, 0, :], l < L-1  (model.py:57) */
+int a4r_take_inputs(void* stream, const float* emb, float* out, int ldo, int B, int L, int E);
+
+/* torch.optim.Adam as configured at Downstream/Text/run.py:524-529 (betas .9/.999, eps 1e-8, no decay)
+ * over one flat fp32 buffer; element i belongs to the first segment with seg_end[seg] > i and uses
+ * group_lr[seg_group[seg]].  g is multiplied by grad_scale first (1/world for the DDP average). */
+int a4r_adam_step(void* stream, float* p, const float* g, float* m, float* v, int64_t n,
+                  const int32_t* seg_end, const int32_t* seg_group, int n_seg,
+                  const float* group_lr, int step, float beta1, float beta2, float eps, float grad_scale);
+
+/* Refresh the kernel-side copies of trainable matrices after an optimiser step:
+ * dst[rows_pad, cols_pad] (dtype) = src (fp32 [rows, cols] at flat + src_off) or its transpose, zero padded. */
+typedef struct {
+    int64_t src_off; void* dst; int32_t rows, cols, rows_pad, cols_pad, transpose, pad_;
+} a4r_pack_desc_t;
+int a4r_pack_matrices(void* stream, const float* flat, const a4r_pack_desc_t* desc_dev, int n_desc, int max_elems, int dtype);
+
+/* Eval (data_utils/metrics.py:82-116): for user u with vector prec[u] (fp32 [U,E]) and item table
+ * item_emb (fp32 [N1,E], row 0 = pad item): rank[u] = 1 + #{i in 1..N1-1, i not in hist(u),
+ * score_i > score_target(u)} without materialising [U,N1].  hist in CSR form (hist_ptr [U+1], hist_idx). */
+int a4r_eval_rank(void* stream, const float* prec, const float* item_emb, const int32_t* target,
+                  const int32_t* hist_ptr, const int32_t* hist_idx, int32_t* rank, int U, int N1, int E);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,441 @@
+"""GPU: every C-ABI kernel against a plain torch fp32 reference of the same op (per-kernel parity).
+
+fp32 instantiations are held to 1e-4-class tolerances (they are exact fp32 MFMA chains); bf16
+instantiations to bf16-rounding tolerances (inputs are pre-rounded to bf16 so only accumulation
+order and the output rounding differ).
+"""
+import math
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+DT = {'bf16': torch.bfloat16, 'f32': torch.float32}
+
+
+def dev():
+    return torch.device('cuda:0')
+
+
+def rnd(*shape, dtype=torch.float32, scale=1.0, seed=None):
+    g = torch.Generator(device='cpu')
+    g.manual_seed(seed if seed is not None else sum(shape) * 7919 + len(shape))
+    return (torch.randn(*shape, generator=g) * scale).to(dtype).to(dev())
+
+
+def close(got, ref, dtype, what, atol32=2e-4, rtol32=2e-4, atol16=None, rtol16=3e-2):
+    got = got.float().cpu()
+    ref = ref.float().cpu()
+    assert torch.isfinite(got).all(), f'{what}: non-finite output'
+    if dtype == torch.float32:
+        atol, rtol = atol32, rtol32
+    else:
+        atol = atol16 if atol16 is not None else 3e-2 * max(1.0, float(ref.abs().max()))
+        rtol = rtol16
+    err = (got - ref).abs()
+    lim = atol + rtol * ref.abs()
+    bad = err > lim
+    assert not bad.any(), (f'{what}: {int(bad.sum())}/{bad.numel()} out of tolerance, max err {float(err.max()):.3e} '
+                           f'(ref max {float(ref.abs().max()):.3e}) first bad idx {bad.nonzero()[0].tolist()}')
+
+
+def act_ref(x, act):
+    if act == 1:
+        return torch.relu(x)
+    if act == 2:
+        return torch.nn.functional.gelu(x)
+    if act == 3:
+        return torch.nn.functional.gelu(x, approximate='tanh')
+    if act == 4:
+        return torch.nn.functional.leaky_relu(x, 0.01)
+    return x
+
+
+# ------------------------------------------------------------------ GEMM NT
+@pytest.mark.parametrize('dt', ['f32', 'bf16'])
+@pytest.mark.parametrize('M,N,K', [(128, 64, 64), (256, 128, 128), (384, 768, 768), (256, 2304, 768), (128, 192, 3072), (256, 64, 768)])
+def test_gemm_plain(dt, M, N, K):
+    from adapter4rec_amd import _lib as L
+    t = DT[dt]
+    A, B = rnd(M, K, dtype=t, seed=1), rnd(N, K, dtype=t, scale=0.05, seed=2)
+    Cc = torch.zeros(M, N, dtype=t, device=dev())
+    L.gemm_nt(A, B, Cc)
+    close(Cc, A.float() @ B.float().t(), t, f'gemm {dt} {M}x{N}x{K}')
+
+
+def test_gemm_identity_asymmetric():
+    """A = I with an asymmetric B catches swapped row/col maps (guide section 3)."""
+    from adapter4rec_amd import _lib as L
+    for t in (torch.float32, torch.bfloat16):
+        A = torch.zeros(128, 128, dtype=t, device=dev())
+        A[:, :] = torch.eye(128)
+        B = (torch.arange(128 * 128, dtype=torch.float32).view(128, 128) % 251 - 125).to(t).to(dev())   # small ints: exact in bf16
+        Cc = torch.zeros(128, 128, dtype=t, device=dev())
+        L.gemm_nt(A, B, Cc)
+        assert torch.equal(Cc.float().cpu(), B.float().t().cpu())
+
+
+@pytest.mark.parametrize('dt', ['f32', 'bf16'])
+def test_gemm_epilogue_full(dt):
+    from adapter4rec_amd import _lib as L
+    t = DT[dt]
+    M, N, K = 256, 192, 128
+    A, B = rnd(M, K, dtype=t, seed=3), rnd(N, K, dtype=t, scale=0.1, seed=4)
+    bias = rnd(N, seed=5)
+    R1, R2, Pre = rnd(M, N, dtype=t, seed=6), rnd(M, N, dtype=t, seed=7), rnd(M, N, dtype=t, seed=8)
+    for act, dact in [(0, 0), (1, 0), (2, 0), (3, 0), (0, 2), (0, 1), (4, 3)]:
+        Cc = torch.zeros(M, N, dtype=t, device=dev())
+        C2 = torch.zeros(M, N, dtype=t, device=dev())
+        L.gemm_nt(A, B, Cc, bias=bias, C2=C2, R1=R1, R2=R2, Pre=Pre, act=act, dact=dact, alpha=0.5)
+        pre = 0.5 * (A.float() @ B.float().t()) + bias
+        ref = act_ref(pre, act)
+        if dact:
+            p = Pre.float().clone().requires_grad_(True)
+            act_ref(p, dact).sum().backward()
+            ref = ref * p.grad
+        ref = ref + R1.float() + R2.float()
+        close(C2, pre, t, f'gemm C2 act={act}')
+        close(Cc, ref, t, f'gemm epilogue act={act} dact={dact}')
+
+
+def test_gemm_mixed_dtypes_and_views():
+    from adapter4rec_amd import _lib as L
+    M, N, K = 128, 64, 768
+    big = rnd(M, K + 64, dtype=torch.bfloat16, seed=9)
+    A = big[:, 64:]                          # lda != K
+    B = rnd(N, K, dtype=torch.bfloat16, scale=0.05, seed=10)
+    Cc = torch.zeros(M, N, dtype=torch.float32, device=dev())
+    L.gemm_nt(A, B, Cc)
+    close(Cc, A.float() @ B.float().t(), torch.float32, 'bf16->f32', atol32=2e-3, rtol32=1e-3)
+    A32, B32 = rnd(M, 64, seed=11), rnd(768, 64, scale=0.1, seed=12)
+    C16 = torch.zeros(M, 768, dtype=torch.bfloat16, device=dev())
+    L.gemm_nt(A32, B32, C16)
+    close(C16, A32 @ B32.t(), torch.bfloat16, 'f32->bf16')
+
+
+def test_gemm_dropout_properties():
+    from adapter4rec_amd import _lib as L
+    M, N, K = 256, 768, 64
+    A, B = rnd(M, K, seed=13), rnd(N, K, seed=14)
+    base = torch.zeros(M, N, device=dev())
+    L.gemm_nt(A, B, base)
+    d1, d2, d3 = torch.zeros_like(base), torch.zeros_like(base), torch.zeros_like(base)
+    L.gemm_nt(A, B, d1, drop_p=0.1, drop_site=3, drop_seed=1234)
+    L.gemm_nt(A, B, d2, drop_p=0.1, drop_site=3, drop_seed=1234)
+    L.gemm_nt(A, B, d3, drop_p=0.1, drop_site=4, drop_seed=1234)
+    assert torch.equal(d1, d2), 'dropout must be a pure function of (seed, site, index)'
+    assert not torch.equal(d1, d3)
+    kept = d1 != 0
+    frac = 1.0 - kept.float().mean().item()
+    assert abs(frac - 0.1) < 0.01, frac
+    scale = 1.0 / (1.0 - round(0.1 * 65536) / 65536)
+    torch.testing.assert_close(d1[kept], base[kept] * scale, rtol=1e-5, atol=1e-5)
+
+
+def test_gemm_rejects_bad_shapes():
+    from adapter4rec_amd import _lib as L
+    A, B = rnd(100, 64), rnd(64, 64)
+    with pytest.raises(RuntimeError):
+        L.gemm_nt(A, B, torch.zeros(100, 64, device=dev()))      # M % 128 != 0
+
+
+# ------------------------------------------------------------------ GEMM TN / colsum
+@pytest.mark.parametrize('dt', ['f32', 'bf16'])
+@pytest.mark.parametrize('M,P,Q', [(64, 64, 64), (1280, 768, 64), (1280, 64, 768), (640, 128, 192)])
+def test_gemm_tn(dt, M, P, Q):
+    from adapter4rec_amd import _lib as L
+    t = DT[dt]
+    X, Y = rnd(M, P, dtype=t, seed=15), rnd(M, Q, dtype=t, seed=16)
+    Cc = torch.ones(P, Q, device=dev())
+    L.gemm_tn(X, Y, Cc)
+    ref = 1.0 + X.float().t() @ Y.float()
+    close(Cc, ref, torch.float32, f'gemm_tn {dt}', atol32=2e-3 if dt == 'f32' else 2e-2, rtol32=1e-3)
+
+
+@pytest.mark.parametrize('dt', ['f32', 'bf16'])
+def test_colsum(dt):
+    from adapter4rec_amd import _lib as L
+    t = DT[dt]
+    for M, N in [(1280, 768), (640, 64), (100, 16)]:
+        X = rnd(M, N, dtype=t, seed=17)
+        out = torch.zeros(N, device=dev())
+        L.colsum(X, out)
+        close(out, X.float().sum(0), torch.float32, 'colsum', atol32=2e-3, rtol32=1e-3)
+
+
+# ------------------------------------------------------------------ attention
+def attn_ref(qkv, key_mask, n_items, S, nh, dh, causal, scale, mask_neg, offs):
+    Hd = nh * dh
+    q, k, v = [qkv[:n_items * S, o:o + Hd].float().view(n_items, S, nh, dh).transpose(1, 2) for o in offs]
+    sc = q @ k.transpose(-1, -2) * scale
+    allowed = (key_mask != 0)[:, None, None, :].expand(n_items, 1, S, S)
+    if causal:
+        allowed = torch.tril(allowed)
+    sc = sc + torch.where(allowed, torch.zeros((), device=sc.device), torch.full((), mask_neg, device=sc.device))
+    p = torch.softmax(sc, -1)
+    return (p @ v).transpose(1, 2).reshape(n_items * S, Hd)
+
+
+ATTN_CASES = [('bert', 30, 12, 64, False, torch.finfo(torch.float32).min), ('bert2', 30, 2, 64, False, torch.finfo(torch.float32).min),
+              ('sasrec', 20, 2, 32, True, -1e9), ('full32', 32, 3, 64, True, -1e9)]
+
+
+@pytest.mark.parametrize('dt', ['f32', 'bf16'])
+@pytest.mark.parametrize('name,S,nh,dh,causal,neg', ATTN_CASES)
+def test_attention_fwd_bwd(dt, name, S, nh, dh, causal, neg):
+    from adapter4rec_amd import _lib as L
+    t = DT[dt]
+    n_items, Hd = 11, nh * dh
+    Mp = ((n_items * S + 127) // 128) * 128
+    qkv = rnd(Mp, 3 * Hd, dtype=t, seed=21)
+    km = torch.ones(n_items, S)
+    km[1, S // 2:] = 0                    # ragged title
+    km[2, :] = 0                          # all-PAD item: fully masked rows must stay finite (uniform softmax)
+    km[3, :3] = 0                         # left padding (SASRec style)
+    km = km.to(dev())
+    scale = 1.0 / math.sqrt(dh)
+    offs = (0, Hd, 2 * Hd)
+    out = torch.zeros(Mp, Hd, dtype=t, device=dev())
+    L.attn_fwd(qkv, out, km, n_items, S, nh, dh, *offs, causal, scale, neg)
+    qr = qkv.float().clone().requires_grad_(True)
+    ref = attn_ref(qr, km, n_items, S, nh, dh, causal, scale, neg, offs)
+    close(out[:n_items * S], ref.detach(), t, f'attn fwd {name} {dt}', atol32=1e-4, rtol32=1e-4)
+    assert torch.count_nonzero(out[n_items * S:]) == 0
+    dout = rnd(Mp, Hd, dtype=t, seed=22)
+    dout[n_items * S:] = 0
+    dqkv = torch.zeros_like(qkv)
+    L.attn_bwd(qkv, dout, dqkv, km, n_items, S, nh, dh, *offs, causal, scale, neg)
+    ref.backward(dout[:n_items * S].float())
+    close(dqkv[:n_items * S], qr.grad[:n_items * S], t, f'attn bwd {name} {dt}', atol32=2e-4, rtol32=2e-4,
+          atol16=4e-2 * float(qr.grad.abs().max()))
+
+
+@pytest.mark.parametrize('dt', ['f32', 'bf16'])
+def test_attention_dropout_adjoint(dt):
+    """With dropout on, out is linear in V: <out, dO> == <V, dV> iff fwd and bwd regenerate the same mask."""
+    from adapter4rec_amd import _lib as L
+    t = DT[dt]
+    n_items, S, nh, dh = 9, 30, 4, 64
+    Hd = nh * dh
+    Mp = 384
+    qkv = rnd(Mp, 3 * Hd, dtype=t, seed=23)
+    km = torch.ones(n_items, S, device=dev())
+    args = (km, n_items, S, nh, dh, 0, Hd, 2 * Hd, False, 0.125, -1e9)
+    out = torch.zeros(Mp, Hd, dtype=t, device=dev())
+    out0 = torch.zeros_like(out)
+    L.attn_fwd(qkv, out0, *args)
+    L.attn_fwd(qkv, out, *args, drop_p=0.25, drop_site=5, drop_seed=77)
+    assert not torch.allclose(out.float(), out0.float())
+    dout = rnd(Mp, Hd, dtype=t, seed=24)
+    dout[n_items * S:] = 0
+    dqkv = torch.zeros_like(qkv)
+    L.attn_bwd(qkv, dout, dqkv, *args, drop_p=0.25, drop_site=5, drop_seed=77)
+    lhs = (out.float() * dout.float()).sum().item()
+    rhs = (qkv[:, 2 * Hd:].float() * dqkv[:, 2 * Hd:].float()).sum().item()
+    assert abs(lhs - rhs) <= (2e-3 if dt == 'f32' else 3e-2) * max(1.0, abs(lhs)), (lhs, rhs)
+
+
+# ------------------------------------------------------------------ row kernels
+@pytest.mark.parametrize('dt', ['f32', 'bf16'])
+@pytest.mark.parametrize('roberta', [False, True])
+def test_embed_ln(dt, roberta):
+    from adapter4rec_amd import _lib as L
+    t = DT[dt]
+    n_items, S, H, V = 7, 30, 768, 500
+    g = torch.Generator().manual_seed(5)
+    ids = torch.randint(3, V, (n_items, 2 * S), generator=g)
+    pad = 1 if roberta else 0
+    ids[1, 10:S] = pad
+    ids[2, :S] = 0
+    ids = ids.to(dev())
+    word, pos, typ = rnd(V, H, seed=31), rnd(S + 4, H, seed=32), rnd(2, H, seed=33)
+    gamma, beta = rnd(H, seed=34) * 0.1 + 1, rnd(H, seed=35) * 0.1
+    out = torch.zeros(256, H, dtype=t, device=dev())
+    L.embed_ln(ids, word, pos, typ[0].contiguous(), gamma, beta, 1e-12, out, n_items, S, roberta=roberta, pad_id=pad)
+    idv = ids[:, :S]
+    if roberta:
+        m = (idv != pad).long()
+        pid = torch.cumsum(m, 1) * m + pad
+    else:
+        pid = torch.arange(S, device=dev()).expand(n_items, S)
+    x = word[idv] + pos[pid] + typ[0]
+    ref = torch.nn.functional.layer_norm(x, (H,), gamma, beta, 1e-12).view(-1, H)
+    close(out[:n_items * S], ref, t, f'embed_ln {dt}', atol32=1e-4)
+
+
+@pytest.mark.parametrize('dt', ['f32', 'bf16'])
+@pytest.mark.parametrize('H', [64, 128, 768, 1024])
+def test_ln_fwd_bwd(dt, H):
+    from adapter4rec_amd import _lib as L
+    t = DT[dt]
+    M = 256
+    v = rnd(M, H, dtype=t, seed=41, scale=2.0)
+    add = rnd(20, H, seed=42) if H == 64 else None
+    gamma, beta = rnd(H, seed=43) * 0.2 + 1, rnd(H, seed=44) * 0.1
+    y = torch.zeros(M, H, dtype=t, device=dev())
+    stats = torch.zeros(M, 2, device=dev())
+    L.ln_fwd(v, gamma, beta, 1e-6, y, stats, add=add)
+    vr = v.float().clone().requires_grad_(True)
+    gr, br = gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
+    vin = vr + (add[torch.arange(M, device=dev()) % 20] if add is not None else 0)
+    ref = torch.nn.functional.layer_norm(vin, (H,), gr, br, 1e-6)
+    close(y, ref.detach(), t, f'ln fwd H={H}', atol32=1e-4)
+    dy = rnd(M, H, dtype=t, seed=45)
+    dv = torch.zeros(M, H, dtype=t, device=dev())
+    dg, db, dbias = torch.zeros(H, device=dev()), torch.zeros(H, device=dev()), torch.zeros(H, device=dev())
+    L.ln_bwd(dy, v, stats, gamma, dv, add=add, dgamma=dg, dbeta=db, dbias=dbias)
+    ref.backward(dy.float())
+    close(dv, vr.grad, t, f'ln bwd dv H={H}', atol32=2e-4)
+    tol = dict(atol32=5e-3, rtol32=2e-3) if dt == 'f32' else dict(atol32=0.5, rtol32=5e-2)
+    close(dg, gr.grad, torch.float32, 'ln dgamma', **tol)
+    close(db, br.grad, torch.float32, 'ln dbeta', **tol)
+    close(dbias, dv.float().sum(0), torch.float32, 'ln dbias', atol32=5e-3, rtol32=2e-3)
+
+
+def test_ln_dropout_adjoint():
+    from adapter4rec_amd import _lib as L
+    M, H = 128, 64
+    v, gamma, beta = rnd(M, H, seed=46), torch.ones(H, device=dev()), torch.zeros(H, device=dev())
+    y, y0, stats = torch.zeros(M, H, device=dev()), torch.zeros(M, H, device=dev()), torch.zeros(M, 2, device=dev())
+    L.ln_fwd(v, gamma, beta, 1e-6, y0, stats)
+    L.ln_fwd(v, gamma, beta, 1e-6, y, stats, drop_p=0.3, drop_site=9, drop_seed=5)
+    kept = y != 0
+    assert abs(1 - kept.float().mean().item() - 0.3) < 0.03
+    # backward must apply the same mask: feed dy = 1 on kept entries only vs dy = 1 everywhere
+    dv_a, dv_b = torch.zeros(M, H, device=dev()), torch.zeros(M, H, device=dev())
+    ones = torch.ones(M, H, device=dev())
+    L.ln_bwd(ones, v, stats, gamma, dv_a, drop_p=0.3, drop_site=9, drop_seed=5)
+    scale = 1.0 / (1.0 - round(0.3 * 65536) / 65536)
+    L.ln_bwd(kept.float() * scale, v, stats, gamma, dv_b)
+    torch.testing.assert_close(dv_a, dv_b, rtol=1e-4, atol=1e-5)
+
+
+@pytest.mark.parametrize('dt', ['f32', 'bf16'])
+def test_gather_scatter_rows(dt):
+    from adapter4rec_amd import _lib as L
+    t = DT[dt]
+    n, S, H = 10, 30, 768
+    x = rnd(384, H, dtype=t, seed=51)
+    g = torch.zeros(128, H, dtype=t, device=dev())
+    L.gather_rows(x, g, n, S)
+    assert torch.equal(g[:n], x[0:n * S:S])
+    back = torch.zeros_like(x)
+    L.scatter_rows(g, back, n, S)
+    assert torch.equal(back[0:n * S:S], g[:n])
+    assert torch.count_nonzero(back) == torch.count_nonzero(g[:n])
+
+
+def test_act_bwd_f32():
+    from adapter4rec_amd import _lib as L
+    dy, pre = rnd(300, 64, seed=52), rnd(300, 64, seed=53)
+    for act in (1, 2, 3):
+        dx = torch.zeros_like(dy)
+        L.act_bwd_f32(dy, pre, dx, act)
+        p = pre.clone().requires_grad_(True)
+        act_ref(p, act).backward(dy)
+        close(dx, p.grad, torch.float32, f'act_bwd {act}')
+
+
+# ------------------------------------------------------------------ head / optimiser / eval
+@pytest.mark.parametrize('cpc', [False, True])
+def test_score_bce(cpc):
+    from adapter4rec_amd import _lib as L
+    B, Ls, E = 6, 21, 64
+    emb = rnd(B, Ls, 2, E, seed=61).requires_grad_(True)
+    prec = rnd(B, Ls - 1, E, seed=62).requires_grad_(True)
+    mask = torch.ones(B, Ls - 1)
+    mask[1, :7] = 0
+    mask[2, :16] = 0
+    mask = mask.to(dev())
+    pos, neg = torch.zeros(B, Ls - 1, device=dev()), torch.zeros(B, Ls - 1, device=dev())
+    ws = torch.zeros(4, device=dev())
+    L.score_bce_fwd(emb.detach(), prec.detach(), mask, pos, neg, ws, B, Ls, E, cpc)
+    tp, tn = emb[:, 1:, 0], emb[:, :-1, 1]
+    bce = torch.nn.BCEWithLogitsLoss()
+    if cpc:
+        ps, ns = (prec[:, -1] * tp[:, -1]).sum(-1), (prec[:, -1] * tn[:, -1]).sum(-1)
+        loss = bce(ps, torch.ones_like(ps)) + bce(ns, torch.zeros_like(ns))
+    else:
+        ps, ns = (prec * tp).sum(-1), (prec * tn).sum(-1)
+        idx = mask != 0
+        loss = bce(ps[idx], torch.ones_like(ps[idx])) + bce(ns[idx], torch.zeros_like(ns[idx]))
+        close(pos, ps.detach(), torch.float32, 'pos scores')
+        close(neg, ns.detach(), torch.float32, 'neg scores')
+    assert abs(ws[0].item() - loss.item()) < 1e-5
+    loss.backward()
+    d_prec, d_emb = torch.zeros_like(prec), torch.full_like(emb, 7.0)
+    L.score_bce_bwd(emb.detach(), prec.detach(), mask, pos, neg, ws, 1.0, d_prec, d_emb, B, Ls, E, cpc)
+    close(d_prec, prec.grad, torch.float32, 'd_prec', atol32=1e-6)
+    close(d_emb, emb.grad, torch.float32, 'd_emb', atol32=1e-6)
+    # input-side pieces
+    take = torch.zeros(128, E, device=dev())
+    L.take_inputs(emb.detach(), take, B, Ls, E)
+    assert torch.equal(take[:B * (Ls - 1)].view(B, Ls - 1, E), emb.detach()[:, :-1, 0])
+    d_in = rnd(128, E, seed=63)
+    before = d_emb.clone()
+    L.emb_grad_add_inputs(d_in, d_emb, B, Ls, E)
+    before[:, :-1, 0] += d_in[:B * (Ls - 1)].view(B, Ls - 1, E)
+    close(d_emb, before, torch.float32, 'emb_grad_add_inputs')
+
+
+def test_adam_matches_torch():
+    from adapter4rec_amd import _lib as L
+    sizes, groups, lrs = [1000, 64, 4096, 17], [2, 2, 3, 1], [5e-5, 1e-4, 1.5e-4, 2e-4]
+    n = sum(sizes)
+    p = rnd(n, seed=71)
+    params = [torch.nn.Parameter(x.clone()) for x in torch.split(p.clone(), sizes)]
+    opt = torch.optim.Adam([{'params': [q], 'lr': lrs[g]} for q, g in zip(params, groups)])
+    m, v = torch.zeros(n, device=dev()), torch.zeros(n, device=dev())
+    seg_end = torch.tensor([sum(sizes[:i + 1]) for i in range(len(sizes))], dtype=torch.int32, device=dev())
+    seg_group = torch.tensor(groups, dtype=torch.int32, device=dev())
+    glr = torch.tensor(lrs, device=dev())
+    for step in range(1, 4):
+        g = rnd(n, seed=72 + step)
+        for q, gg in zip(params, torch.split(g, sizes)):
+            q.grad = gg.clone()
+        opt.step()
+        L.adam_step(p, g, m, v, seg_end, seg_group, glr, step)
+    torch.testing.assert_close(p, torch.cat([q.detach() for q in params]), rtol=1e-5, atol=1e-7)
+
+
+def test_pack_matrices():
+    import ctypes as C
+    from adapter4rec_amd import _lib as L
+    flat = rnd(16 * 64 + 768 * 64, seed=73)
+    d1 = torch.zeros(64, 64, dtype=torch.bfloat16, device=dev())       # [16,64] -> padded [64,64]
+    d2 = torch.zeros(64, 768, dtype=torch.bfloat16, device=dev())      # [768,64] -> transpose [64,768]
+    descs = (L.PackDesc * 2)()
+    descs[0] = L.PackDesc(0, d1.data_ptr(), 16, 64, 64, 64, 0, 0)
+    descs[1] = L.PackDesc(16 * 64, d2.data_ptr(), 768, 64, 64, 768, 1, 0)
+    raw = torch.frombuffer(bytearray(bytes(descs)), dtype=torch.uint8).to(dev())
+    L.pack_matrices(flat, raw, 2, 64 * 768, L.BF16)
+    w1 = flat[:16 * 64].view(16, 64)
+    assert torch.equal(d1[:16].float(), w1.bfloat16().float()) and torch.count_nonzero(d1[16:]) == 0
+    assert torch.equal(d2.float(), flat[16 * 64:].view(768, 64).t().bfloat16().float())
+
+
+def test_eval_rank():
+    from adapter4rec_amd import _lib as L
+    U, N1, E = 37, 1001, 64
+    prec, items = rnd(U, E, seed=81), rnd(N1, E, seed=82)
+    g = torch.Generator().manual_seed(3)
+    target = torch.randint(1, N1, (U,), generator=g).int()
+    hist, ptr = [], [0]
+    for u in range(U):
+        h = torch.randint(1, N1, (int(torch.randint(0, 23, (1,), generator=g)),), generator=g).tolist()
+        h = [x for x in h if x != int(target[u])]
+        hist += h
+        ptr.append(len(hist))
+    rank = torch.zeros(U, dtype=torch.int32, device=dev())
+    L.eval_rank(prec, items, target.to(dev()), torch.tensor(ptr, dtype=torch.int32, device=dev()),
+                torch.tensor(hist + [0], dtype=torch.int32, device=dev()), rank)
+    sc = (prec.double() @ items.double().t()).cpu()
+    ref = []
+    for u in range(U):
+        s = sc[u].clone()
+        tsc = s[int(target[u])].item()
+        s[torch.tensor(hist[ptr[u]:ptr[u + 1]], dtype=torch.long)] = -float('inf')
+        ref.append(int((s[1:] > tsc).sum()) + 1)
+    got = rank.cpu().tolist()
+    assert sum(abs(a - b) for a, b in zip(got, ref)) <= 1, (got, ref)     # fp32 vs fp64 near-ties
