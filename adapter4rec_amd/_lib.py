@@ -20,7 +20,7 @@ EXPORTS = [
     'a4r_version', 'a4r_gemm_nt', 'a4r_gemm_tn', 'a4r_colsum', 'a4r_attn_fwd', 'a4r_attn_bwd', 'a4r_embed_ln',
     'a4r_ln_fwd', 'a4r_ln_bwd', 'a4r_gather_rows', 'a4r_scatter_rows', 'a4r_act_bwd_f32', 'a4r_score_bce_fwd',
     'a4r_score_bce_bwd', 'a4r_emb_grad_add_inputs', 'a4r_take_inputs', 'a4r_adam_step', 'a4r_pack_matrices',
-    'a4r_eval_rank',
+    'a4r_eval_rank', 'a4r_dropout_apply',
 ]
 
 
@@ -31,7 +31,7 @@ class GemmArgs(C.Structure):
                 ('lda', C.c_int32), ('ldb', C.c_int32), ('ldc', C.c_int32), ('ldc2', C.c_int32),
                 ('ldr1', C.c_int32), ('ldr2', C.c_int32), ('ldpre', C.c_int32),
                 ('in_dtype', C.c_int32), ('out_dtype', C.c_int32), ('act', C.c_int32), ('dact', C.c_int32),
-                ('alpha', C.c_float), ('drop_p', C.c_float), ('drop_site', C.c_uint32), ('drop_seed', C.c_uint64)]
+                ('drop_first', C.c_int32), ('alpha', C.c_float), ('drop_p', C.c_float), ('drop_site', C.c_uint32), ('drop_seed', C.c_uint64)]
 
 
 class AttnArgs(C.Structure):
@@ -98,7 +98,7 @@ def require_gpu(*tensors):
 
 # ------------------------------------------------------------------ wrappers
 def gemm_nt(A, B, Cout, bias=None, C2=None, R1=None, R2=None, Pre=None, act=0, dact=0, alpha=1.0,
-            drop_p=0.0, drop_site=0, drop_seed=0, M=None):
+            drop_p=0.0, drop_site=0, drop_seed=0, M=None, drop_first=False):
     require_gpu(A, B, Cout)
     g = GemmArgs()
     g.A, g.B, g.C, g.bias, g.C2, g.R1, g.R2, g.Pre = _p(A), _p(B), _p(Cout), _p(bias), _p(C2), _p(R1), _p(R2), _p(Pre)
@@ -115,7 +115,7 @@ def gemm_nt(A, B, Cout, bias=None, C2=None, R1=None, R2=None, Pre=None, act=0, d
     for t in (C2, R1, R2, Pre):
         assert t is None or _dt(t) == g.out_dtype
     assert bias is None or bias.dtype == torch.float32
-    g.act, g.dact, g.alpha = act, dact, alpha
+    g.act, g.dact, g.alpha, g.drop_first = act, dact, alpha, int(drop_first)
     g.drop_p, g.drop_site, g.drop_seed = drop_p, drop_site, drop_seed
     _check(lib().a4r_gemm_nt(_stream(), C.byref(g)), 'a4r_gemm_nt')
 
@@ -180,11 +180,12 @@ def ln_fwd(v, gamma, beta, eps, y, stats, M=None, add=None, drop_p=0.0, drop_sit
            'a4r_ln_fwd')
 
 
-def ln_bwd(dy, v, stats, gamma, dv, M=None, add=None, dgamma=None, dbeta=None, dbias=None, drop_p=0.0, drop_site=0, drop_seed=0):
+def ln_bwd(dy, v, stats, gamma, dv, M=None, add=None, dgamma=None, dbeta=None, dbias=None, dres=None,
+           drop_p=0.0, drop_site=0, drop_seed=0):
     require_gpu(dy, v, dv)
     M = v.shape[0] if M is None else M
     _check(lib().a4r_ln_bwd(_stream(), _p(dy), C.c_int(_ld(dy)), _p(v), C.c_int(_ld(v)), _p(add),
-                            C.c_int(add.shape[0] if add is not None else 0), _p(stats), _p(gamma), _p(dv), C.c_int(_ld(dv)),
+                            C.c_int(add.shape[0] if add is not None else 0), _p(stats), _p(gamma), _p(dres), C.c_int(_ld(dres) if dres is not None else 0), _p(dv), C.c_int(_ld(dv)),
                             _p(dgamma), _p(dbeta), _p(dbias), C.c_int(M), C.c_int(v.shape[1]), C.c_int(_dt(v)),
                             C.c_float(drop_p), C.c_uint32(drop_site), C.c_uint64(drop_seed)), 'a4r_ln_bwd')
 
@@ -199,6 +200,13 @@ def scatter_rows(src, dst, n, row_step):
     require_gpu(src, dst)
     _check(lib().a4r_scatter_rows(_stream(), _p(src), C.c_int(_ld(src)), _p(dst), C.c_int(_ld(dst)), C.c_int(n), C.c_int(row_step),
                                   C.c_int(src.shape[1]), C.c_int(_dt(src))), 'a4r_scatter_rows')
+
+
+def dropout_apply(x, y, drop_p, drop_site, drop_seed, M=None):
+    require_gpu(x, y)
+    M = x.shape[0] if M is None else M
+    _check(lib().a4r_dropout_apply(_stream(), _p(x), C.c_int(_ld(x)), _p(y), C.c_int(_ld(y)), C.c_int(M), C.c_int(x.shape[1]),
+                                   C.c_int(_dt(x)), C.c_float(drop_p), C.c_uint32(drop_site), C.c_uint64(drop_seed)), 'a4r_dropout_apply')
 
 
 def act_bwd_f32(dy, pre, dx, act):

@@ -36,7 +36,7 @@ __global__ void __launch_bounds__(256) gemm_nt_kernel(const a4r_gemm_t p, int nt
 
     // copy the by-value argument's fields into registers (a captured struct would live in scratch)
     const int lda = p.lda, ldb = p.ldb, ldc = p.ldc, ldc2 = p.ldc2, ldr1 = p.ldr1, ldr2 = p.ldr2, ldpre = p.ldpre;
-    const int Kdim = p.K, Ndim = p.N, act = p.act, dact = p.dact;
+    const int Kdim = p.K, Ndim = p.N, act = p.act, dact = p.dact, drop_first = p.drop_first;
     const float alpha = p.alpha;
     const float* __restrict__ biasp = p.bias;
     const uint64_t drop_seed = p.drop_seed;
@@ -167,6 +167,17 @@ __global__ void __launch_bounds__(256) gemm_nt_kernel(const a4r_gemm_t p, int nt
 #pragma unroll
             for (int e = 0; e < 8; ++e) v[e] *= act_bwd(pre[e], dact);
         }
+        auto dropout8 = [&]() {
+            const uint64_t e0 = (uint64_t)grow * (uint64_t)Ndim + (uint64_t)gcol;   // gcol % 8 == 0
+            const uint64_t h0 = a4r_hash64(drop_seed, drop_site, e0 >> 2);
+            const uint64_t h1 = a4r_hash64(drop_seed, drop_site, (e0 >> 2) + 1);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                v[e] = (((uint32_t)(h0 >> (16 * e)) & 0xffffu) >= thr16) ? v[e] * keep_scale : 0.f;
+                v[e + 4] = (((uint32_t)(h1 >> (16 * e)) & 0xffffu) >= thr16) ? v[e + 4] * keep_scale : 0.f;
+            }
+        };
+        if (thr16 && drop_first) dropout8();
         if (R1) {
             float t[8];
             load_vec<TO, 8>(R1 + grow * ldr1 + gcol, t);
@@ -179,16 +190,7 @@ __global__ void __launch_bounds__(256) gemm_nt_kernel(const a4r_gemm_t p, int nt
 #pragma unroll
             for (int e = 0; e < 8; ++e) v[e] += t[e];
         }
-        if (thr16) {
-            const uint64_t e0 = (uint64_t)grow * (uint64_t)Ndim + (uint64_t)gcol;   // gcol % 8 == 0
-            const uint64_t h0 = a4r_hash64(drop_seed, drop_site, e0 >> 2);
-            const uint64_t h1 = a4r_hash64(drop_seed, drop_site, (e0 >> 2) + 1);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                v[e] = (((uint32_t)(h0 >> (16 * e)) & 0xffffu) >= thr16) ? v[e] * keep_scale : 0.f;
-                v[e + 4] = (((uint32_t)(h1 >> (16 * e)) & 0xffffu) >= thr16) ? v[e + 4] * keep_scale : 0.f;
-            }
-        }
+        if (thr16 && !drop_first) dropout8();
         store_vec<TO, 8>(C + grow * ldc + gcol, v);
     }
 }

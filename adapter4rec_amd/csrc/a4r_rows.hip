@@ -146,7 +146,8 @@ __global__ void __launch_bounds__(256) ln_fwd_kernel(const T* __restrict__ vin, 
 template <typename T>
 __global__ void __launch_bounds__(256) ln_bwd_kernel(const T* __restrict__ dy, int lddy, const T* __restrict__ vin, int ldv,
                                                      const float* __restrict__ add, int add_rows, const float* __restrict__ stats,
-                                                     const float* __restrict__ gamma, T* __restrict__ dv, int lddv,
+                                                     const float* __restrict__ gamma, const T* __restrict__ dres, int lddres,
+                                                     T* __restrict__ dv, int lddv,
                                                      float* __restrict__ dgamma, float* __restrict__ dbeta, float* __restrict__ dbias,
                                                      int M, int H, uint64_t seed, uint32_t site, uint32_t thr16, float scale) {
     __shared__ float red[3][4][1024];
@@ -202,6 +203,14 @@ __global__ void __launch_bounds__(256) ln_bwd_kernel(const T* __restrict__ dy, i
                 }
             }
         }
+        if (dres) {      // residual branch by-passing this LayerNorm (not part of dbias)
+            float rr[MAXG][8];
+            row_load<T>(dres + (size_t)row * lddres, ng, lane, rr);
+#pragma unroll
+            for (int g = 0; g < MAXG; ++g)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) d[g][e] += rr[g][e];
+        }
         row_store<T>(dv + (size_t)row * lddv, ng, lane, d);
     }
     if (!dgamma && !dbeta && !dbias) return;      // uniform across the block
@@ -237,6 +246,27 @@ __global__ void __launch_bounds__(256) rows_copy_kernel(const T* __restrict__ in
         const int c = (int)(i % cpr) * PER;
         const size_t ri = SCATTER ? r : r * row_step, ro = SCATTER ? r * row_step : r;
         *reinterpret_cast<uint4*>(out + ro * ldo + c) = *reinterpret_cast<const uint4*>(in + ri * ldi + c);
+    }
+}
+
+template <typename T>
+__global__ void __launch_bounds__(256) dropout_apply_kernel(const T* __restrict__ x, int ldx, T* __restrict__ y, int ldy, int M, int N,
+                                                            uint64_t seed, uint32_t site, uint32_t thr16, float scale) {
+    const int c8n = N / 8;
+    const size_t total = (size_t)M * c8n;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const size_t row = i / c8n;
+        const int col = (int)(i % c8n) * 8;
+        float v[8];
+        load_vec<T, 8>(x + row * ldx + col, v);
+        const uint64_t e0 = (uint64_t)row * (uint64_t)N + (uint64_t)col;
+        const uint64_t h0 = a4r_hash64(seed, site, e0 >> 2), h1 = a4r_hash64(seed, site, (e0 >> 2) + 1);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            v[e] = (((uint32_t)(h0 >> (16 * e)) & 0xffffu) >= thr16) ? v[e] * scale : 0.f;
+            v[e + 4] = (((uint32_t)(h1 >> (16 * e)) & 0xffffu) >= thr16) ? v[e + 4] * scale : 0.f;
+        }
+        store_vec<T, 8>(y + row * ldy + col, v);
     }
 }
 
@@ -296,9 +326,10 @@ extern "C" int a4r_ln_fwd(void* stream, const void* v, int ldv, const float* add
 }
 
 extern "C" int a4r_ln_bwd(void* stream, const void* dy, int lddy, const void* v, int ldv, const float* add, int add_rows,
-                          const float* stats, const float* gamma, void* dv, int lddv,
+                          const float* stats, const float* gamma, const void* dres, int lddres, void* dv, int lddv,
                           float* dgamma, float* dbeta, float* dbias, int M, int H, int dtype,
                           float drop_p, uint32_t drop_site, uint64_t drop_seed) {
+    if (dres && (misaligned(dres) || (lddres * (dtype == A4R_F32 ? 4 : 2)) % 16 || lddres < H)) return A4R_EINVAL;
     if (!dy || !v || !stats || !gamma || !dv || bad_dtype(dtype) || M <= 0 || H <= 0 || H % 8 || H > 1024) return A4R_EINVAL;
     const int esz = dtype == A4R_F32 ? 4 : 2;
     if ((lddy * esz) % 16 || (ldv * esz) % 16 || (lddv * esz) % 16 || lddy < H || ldv < H || lddv < H) return A4R_EINVAL;
@@ -312,10 +343,10 @@ extern "C" int a4r_ln_bwd(void* stream, const void* dy, int lddy, const void* v,
     if (grid > 512) grid = 512;      // bounds the column-sum atomics: 512 blocks x H per accumulator
     if (dtype == A4R_BF16)
         hipLaunchKernelGGL(ln_bwd_kernel<bf16_t>, dim3(grid), dim3(256), 0, s, (const bf16_t*)dy, lddy, (const bf16_t*)v, ldv, add, add_rows,
-                           stats, gamma, (bf16_t*)dv, lddv, dgamma, dbeta, dbias, M, H, drop_seed, drop_site, thr, sc);
+                           stats, gamma, (const bf16_t*)dres, lddres, (bf16_t*)dv, lddv, dgamma, dbeta, dbias, M, H, drop_seed, drop_site, thr, sc);
     else
         hipLaunchKernelGGL(ln_bwd_kernel<float>, dim3(grid), dim3(256), 0, s, (const float*)dy, lddy, (const float*)v, ldv, add, add_rows,
-                           stats, gamma, (float*)dv, lddv, dgamma, dbeta, dbias, M, H, drop_seed, drop_site, thr, sc);
+                           stats, gamma, (const float*)dres, lddres, (float*)dv, lddv, dgamma, dbeta, dbias, M, H, drop_seed, drop_site, thr, sc);
     return a4r_launch_status();
 }
 
@@ -346,5 +377,22 @@ extern "C" int a4r_act_bwd_f32(void* stream, const float* dy, const float* pre, 
     if (!dy || !pre || !dx || n <= 0) return A4R_EINVAL;
     int grid = (int)((n + 255) / 256); if (grid > 2048) grid = 2048;
     hipLaunchKernelGGL(act_bwd_f32_kernel, dim3(grid), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), dy, pre, dx, n, act);
+    return a4r_launch_status();
+}
+
+extern "C" int a4r_dropout_apply(void* stream, const void* x, int ldx, void* y, int ldy, int M, int N, int dtype,
+                                 float drop_p, uint32_t drop_site, uint64_t drop_seed) {
+    if (!x || !y || bad_dtype(dtype) || M <= 0 || N <= 0 || N % 8 || drop_p < 0.f || drop_p >= 1.f) return A4R_EINVAL;
+    const int esz = dtype == A4R_F32 ? 4 : 2;
+    if ((ldx * esz) % 16 || (ldy * esz) % 16 || ldx < N || ldy < N || misaligned(x) || misaligned(y)) return A4R_EINVAL;
+    const size_t total = (size_t)M * (N / 8);
+    int grid = (int)((total + 255) / 256); if (grid > 4096) grid = 4096;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    if (dtype == A4R_BF16)
+        hipLaunchKernelGGL(dropout_apply_kernel<bf16_t>, dim3(grid), dim3(256), 0, s, (const bf16_t*)x, ldx, (bf16_t*)y, ldy, M, N,
+                           drop_seed, drop_site, a4r_thr16(drop_p), a4r_keep_scale(drop_p));
+    else
+        hipLaunchKernelGGL(dropout_apply_kernel<float>, dim3(grid), dim3(256), 0, s, (const float*)x, ldx, (float*)y, ldy, M, N,
+                           drop_seed, drop_site, a4r_thr16(drop_p), a4r_keep_scale(drop_p));
     return a4r_launch_status();
 }

@@ -1,0 +1,710 @@
+"""MI355X-native execution engine for the adapter-tuned TransRec step.
+
+Replaces, behind ``Model.forward`` / ``Bert_Encoder`` / ``User_Encoder`` (reference:
+Downstream/Text/model/model.py:48-70, encoders.py:24-29,89-99), the eager op sequence
+BERT/RoBERTa item encoder (+ Houlsby / Pfeiffer / Compacter adapters) -> SASRec/CPC user encoder
+-> dot-product BCE head -> backward (dgrad-only through the frozen backbone) with launches of the
+C-ABI kernels in liba4r_hip.so.  Python here only owns buffers, pointers and launch order.
+
+Data layout in HBM
+  * activations: row-major [M_pad, width], M = items * S tokens (S = title length) padded to 128 rows;
+    bf16 (or fp32 in --compute_dtype fp32) for the item encoder, fp32 for the tiny SASRec side;
+  * frozen weights: packed once in compute dtype, both W [out, in] (forward, "NT" GEMM operand) and
+    W^T [in, out] (dgrad operand) -- 2 x 170 MB bf16 for BERT-base, never touched again;
+  * trainable tensors: ONE flat fp32 buffer (parameters are views into it), one flat fp32 gradient
+    buffer (what RCCL all-reduces), Adam moments alongside; kernel-side bf16/transposed/padded copies
+    of the adapter matrices are refreshed by one pack launch per step.
+"""
+import math
+
+import torch
+
+from . import _lib as L
+from .model.bert import backbone_geometry
+from .model.modules import AdapterBlock, AdapterPfeifferBlock, HyperComplexAdapterBlock, PHMLinear
+
+FMIN = float(torch.finfo(torch.float32).min)
+
+
+def pad_to(n, m):
+    return (n + m - 1) // m * m
+
+
+class _LN:
+    """LayerNorm parameters (fp32) + optional gradient sinks."""
+
+    def __init__(self, mod, eng):
+        self.gamma, self.beta, self.eps = mod.weight, mod.bias, mod.eps
+        self.g_gamma = eng.grad_view(mod.weight)
+        self.g_beta = eng.grad_view(mod.bias)
+
+
+class _Adapter:
+    """One bottleneck adapter: kernel-side copies (compute dtype, bottleneck padded to 64) + gradient sinks."""
+
+    def __init__(self, mod, width, eng, dt):
+        self.kind = mod.kind
+        self.act = L.ACT_BY_NAME[mod.activation_name]
+        dev = eng.dev
+        if isinstance(mod, HyperComplexAdapterBlock):
+            self.d = mod.down_sampler.out_features
+            self.virtual = (mod.down_sampler, mod.up_sampler)
+            b_down, b_up = mod.down_sampler.b, mod.up_sampler.b
+            for lin in self.virtual:     # gradients of these arrive through _virtual_backward
+                for q in (lin.W_left, lin.W_right, lin.phm_rule):
+                    if q is not None:
+                        eng.grad_view(q)
+        else:
+            self.d = mod.fc_down.out_features
+            self.virtual = None
+            self.p_wd, self.p_wu = mod.fc_down.weight, mod.fc_up.weight
+            b_down, b_up = mod.fc_down.bias, mod.fc_up.bias
+        self.dp = pad_to(self.d, 64)
+        self.width = width
+        self.wd = torch.zeros(self.dp, width, dtype=dt, device=dev)      # fc_down.weight  [d, H]
+        self.wdT = torch.zeros(width, self.dp, dtype=dt, device=dev)
+        self.wu = torch.zeros(width, self.dp, dtype=dt, device=dev)      # fc_up.weight    [H, d]
+        self.wuT = torch.zeros(self.dp, width, dtype=dt, device=dev)
+        self.p_bd, self.p_bu = b_down, b_up
+        self.bd = torch.zeros(self.dp, dtype=torch.float32, device=dev)  # padded copy of fc_down.bias
+        self.bu = b_up                                                   # [H] fp32, used in place
+        self.g_bu = eng.grad_view(b_up)
+        self.g_bd = eng.grad_view(b_down)
+        self.g_wd = self.g_wu = None
+        if self.virtual is None:
+            self.g_wd, self.g_wu = eng.grad_view(self.p_wd), eng.grad_view(self.p_wu)
+            eng.add_pack(self.p_wd, self.wd, False)
+            eng.add_pack(self.p_wd, self.wdT, True)
+            eng.add_pack(self.p_wu, self.wu, False)
+            eng.add_pack(self.p_wu, self.wuT, True)
+        else:
+            eng.add_virtual(self)
+        eng.add_pack_bias(b_down, self.bd)
+        # scratch for padded weight gradients (used when d < dp, or for virtual matrices)
+        direct = self.virtual is None and self.d == self.dp
+        self.s_wd = None if direct else torch.zeros(self.dp, width, dtype=torch.float32, device=dev)
+        self.s_wu = None if direct else torch.zeros(width, self.dp, dtype=torch.float32, device=dev)
+        self.s_bd = None if self.d == self.dp else torch.zeros(self.dp, dtype=torch.float32, device=dev)
+
+
+class _Block:
+    """One post-LN transformer block (BERT layer or SASRec block) with optional adapters."""
+    pass
+
+
+class TransRecEngine:
+    def __init__(self, model, args, arch='sasrec', dtype='bf16', phm_owner=None):
+        self.model, self.args, self.arch = model, args, arch
+        self.root = phm_owner if phm_owner is not None else model
+        p0 = next(model.parameters())
+        self._require_device(p0)
+        self.dev = p0.device
+        if dtype not in ('bf16', 'fp32'):
+            raise ValueError("compute_dtype must be 'bf16' or 'fp32'")
+        self.T = torch.bfloat16 if dtype == 'bf16' else torch.float32
+        self.S = args.num_words_title
+        self.E = args.embedding_dim
+        self.Lseq = args.max_seq_len + 1
+        self.seed = int(getattr(args, 'dropout_seed', 0x5eed))
+        self.step_count = 0
+        self._packs_T, self._packs_b, self._virtual = [], [], []
+        self._collect_trainables()
+        bert = model.bert_encoder.text_encoders['title'].bert_model
+        self.geo = backbone_geometry(bert)
+        if self.geo['hidden_act'] not in ('gelu',):
+            raise NotImplementedError(f"hidden_act {self.geo['hidden_act']}")
+        self._build_bert(bert)
+        self._build_head()
+        self._build_sasrec()
+        self._check_coverage()
+        self._finalize_packs()
+        self.cap_items = 0
+        self.cap_users = 0
+        self._bufs, self._saved_bert, self._saved_sas = {}, None, None
+        self._ctx = None
+        self._saved_M = self._saved_Mu = 0
+
+    def _require_device(self, p0):
+        if not p0.is_cuda:
+            raise RuntimeError('adapter4rec_amd runs on an MI355X only: move the model to a cuda device first '
+                               '(there is no CPU / PyTorch fallback path)')
+        L.lib()
+
+    # ------------------------------------------------------------------ trainable bookkeeping
+    def _collect_trainables(self):
+        named = [(n, p) for n, p in self.root.named_parameters() if p.requires_grad]
+        self.trainable_names = [n for n, _ in named]
+        self.trainable_params = [p for _, p in named]
+        self.n_trainable = len(named)
+        sizes = [p.numel() for p in self.trainable_params]
+        self.offsets, o = {}, 0
+        for p, n in zip(self.trainable_params, sizes):
+            o = pad_to(o, 4)                                  # 16-byte aligned segments (row kernels load gamma/beta as uint4)
+            self.offsets[id(p)] = (o, n)
+            o += n
+        total = pad_to(max(o, 4), 4)
+        self.flat_p = torch.zeros(total, dtype=torch.float32, device=self.dev)
+        self.flat_g = torch.zeros(total, dtype=torch.float32, device=self.dev)
+        self.flat_gs = torch.zeros(total, dtype=torch.float32, device=self.dev)      # scratch target of the autograd path
+        self._grad_target = self.flat_gs
+        for p in self.trainable_params:                       # parameters become views into the flat buffer
+            off, n = self.offsets[id(p)]
+            if p.dtype != torch.float32:
+                raise TypeError('trainable parameters must be fp32 (master copy)')
+            self.flat_p[off:off + n].copy_(p.data.reshape(-1))
+            p.data = self.flat_p[off:off + n].view(p.shape)
+            p._a4r_flat = (self, off, n)
+        self._covered = set()
+
+    def grad_view(self, p):
+        """fp32 view for p's gradient inside the CURRENT target flat buffer, resolved at use time."""
+        if not p.requires_grad:
+            return None
+        self._covered.add(id(p))
+        off, n = self.offsets[id(p)]
+        shape = tuple(p.shape)
+        return lambda: self._grad_target[off:off + n].view(shape)
+
+    def add_pack(self, p, dst, transpose):
+        self._packs_T.append((p, dst, transpose))
+
+    def add_pack_bias(self, p, dst):
+        self._packs_b.append((p, dst))
+
+    def add_virtual(self, adapter):
+        self._virtual.append(adapter)
+
+    def _check_coverage(self):
+        missing = [n for n, p in zip(self.trainable_names, self.trainable_params) if id(p) not in self._covered]
+        if missing:
+            raise NotImplementedError(
+                'the native path trains adapter / Pfeiffer-LN / LayerNorm / compacter tensors (frozen backbone, dgrad only); '
+                f'no native weight-gradient kernel for: {missing[:6]}{" ..." if len(missing) > 6 else ""} '
+                '(full fine-tuning, --fine_tune_to all, is a later row of SURVEY.md section 8(f))')
+
+    def _finalize_packs(self):
+        """Descriptor tables (device) for a4r_pack_matrices: parameters live in flat_p, so src_off is static."""
+        def table(entries, frozen_src=None):
+            if not entries:
+                return None
+            arr = (L.PackDesc * len(entries))()
+            mx = 0
+            for i, (p, dst, tr) in enumerate(entries):
+                rows, cols = (p.shape[0], p.shape[1]) if p.dim() == 2 else (1, p.shape[0])
+                rp, cp = (dst.shape[0], dst.shape[1]) if dst.dim() == 2 else (1, dst.shape[0])
+                off = self.offsets[id(p)][0] if frozen_src is None else frozen_src[i]
+                arr[i] = L.PackDesc(off, dst.data_ptr(), rows, cols, rp, cp, int(tr), 0)
+                mx = max(mx, rp * cp)
+            return torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(self.dev), len(entries), mx
+        tr_T = [(p, d, t) for p, d, t in self._packs_T if p.requires_grad]
+        fr_T = [(p, d, t) for p, d, t in self._packs_T if not p.requires_grad]
+        tr_b = [(p, d, False) for p, d in self._packs_b if p.requires_grad]
+        fr_b = [(p, d, False) for p, d in self._packs_b if not p.requires_grad]
+        self._tab_T = table(tr_T)
+        self._tab_b = table(tr_b)
+        # frozen adapters (e.g. eval of a loaded checkpoint with requires_grad False): pack once from a private flat copy
+        if fr_T or fr_b:
+            src = torch.cat([p.data.reshape(-1).float() for p, _, _ in fr_T + fr_b])
+            offs, o = [], 0
+            for p, _, _ in fr_T + fr_b:
+                offs.append(o)
+                o += p.numel()
+            if fr_T:
+                t = table(fr_T, offs[:len(fr_T)])
+                L.pack_matrices(src, t[0], t[1], t[2], L.BF16 if self.T == torch.bfloat16 else L.F32)
+            if fr_b:
+                t = table(fr_b, offs[len(fr_T):])
+                L.pack_matrices(src, t[0], t[1], t[2], L.F32)
+            torch.cuda.current_stream().synchronize()
+        # compacter: effective matrices are functions of (phm_rule, W_left, W_right): built by torch each step
+        self._virt_flat = None
+        if self._virtual:
+            n = sum(2 * a.d * a.width for a in self._virtual)
+            self._virt_flat = torch.zeros(n, dtype=torch.float32, device=self.dev)
+            ents, offs, o = [], [], 0
+            for a in self._virtual:
+                a.v_off = o
+                wd_shape = torch.empty(a.d, a.width)       # [d, H] then [H, d]
+                wu_shape = torch.empty(a.width, a.d)
+                for shp, dst, tr in ((wd_shape, a.wd, False), (wd_shape, a.wdT, True)):
+                    ents.append((shp, dst, tr)); offs.append(o)
+                o += a.d * a.width
+                for shp, dst, tr in ((wu_shape, a.wu, False), (wu_shape, a.wuT, True)):
+                    ents.append((shp, dst, tr)); offs.append(o)
+                o += a.d * a.width
+            self._tab_virt = table(ents, offs)
+
+    def pack_trainables(self):
+        """Refresh the kernel-side copies of the trainable matrices (call after every optimiser step)."""
+        dt = L.BF16 if self.T == torch.bfloat16 else L.F32
+        if self._tab_T:
+            L.pack_matrices(self.flat_p, self._tab_T[0], self._tab_T[1], self._tab_T[2], dt)
+        if self._tab_b:
+            L.pack_matrices(self.flat_p, self._tab_b[0], self._tab_b[1], self._tab_b[2], L.F32)
+        self._virt_graph = None
+        if self._virtual:
+            effs = []
+            with torch.enable_grad():
+                for a in self._virtual:
+                    wd, wu = a.virtual[0].effective_weight(), a.virtual[1].effective_weight()
+                    effs += [wd, wu]
+                    n = a.d * a.width
+                    self._virt_flat[a.v_off:a.v_off + n].copy_(wd.detach().reshape(-1))
+                    self._virt_flat[a.v_off + n:a.v_off + 2 * n].copy_(wu.detach().reshape(-1))
+            self._virt_graph = effs
+            L.pack_matrices(self._virt_flat, self._tab_virt[0], self._tab_virt[1], self._tab_virt[2], dt)
+
+    # ------------------------------------------------------------------ frozen weight packing
+    def _w(self, t, dt=None):
+        return t.detach().to(self.dev, dt or self.T).contiguous()
+
+    def _wT(self, t, dt=None):
+        return t.detach().to(self.dev, dt or self.T).t().contiguous()
+
+    def _f32(self, t):
+        return t.detach().to(self.dev, torch.float32).contiguous()
+
+    def _adapter_of(self, wrapper, attr, width, dt):
+        mod = getattr(wrapper, attr, None)
+        if mod is None:
+            return None
+        if not isinstance(mod, (AdapterBlock, AdapterPfeifferBlock, HyperComplexAdapterBlock)):
+            raise NotImplementedError(f'adapter module {type(mod).__name__}')
+        return _Adapter(mod, width, self, dt)
+
+    def _so(self, mod, width, dt):
+        """(dense, LayerNorm, adapter, placement, LN_new) of a plain or wrapped self-output."""
+        if hasattr(mod, 'self_output'):
+            so = mod.self_output
+            placement = getattr(mod, 'placement', 'serial')
+            if placement == 'parallel':
+                raise NotImplementedError('parallel Houlsby (--is_serial None) is a SURVEY.md 8(f) "next" row')
+            ln_new = _LN(mod.LN, self) if hasattr(mod, 'LN') else None
+            return so.dense, so.LayerNorm, self._adapter_of(mod, 'adapter', width, dt), placement, ln_new
+        return mod.dense, mod.LayerNorm, None, None, None
+
+    def _build_bert(self, bert):
+        g = self.geo
+        H, nh = g['hidden_size'], g['num_attention_heads']
+        self.H, self.F = H, g['intermediate_size']
+        if H % 64 or self.F % 64 or (H // nh) not in (32, 64) or self.S > 32:
+            raise NotImplementedError(f'encoder geometry H={H} F={self.F} heads={nh} S={self.S}')
+        emb = bert.embeddings
+        self.emb_word, self.emb_pos = self._f32(emb.word_embeddings.weight), self._f32(emb.position_embeddings.weight)
+        self.emb_type0 = self._f32(emb.token_type_embeddings.weight[0])
+        self.emb_ln = _LN(emb.LayerNorm, self)
+        if emb.LayerNorm.weight.requires_grad:
+            raise NotImplementedError('training the embedding LayerNorm (--finetune_layernorm) is not wired yet')
+        self.roberta = g['model_type'] == 'roberta'
+        self.pad_id = int(g['pad_token_id'])
+        self.p_hidden = float(g['hidden_dropout_prob'])
+        self.p_attn = float(g['attention_probs_dropout_prob'])
+        self.bert_blocks = []
+        for i, layer in enumerate(bert.encoder.layer):
+            b = _Block()
+            att = layer.attention.self
+            for lin in (att.query, att.key, att.value):
+                if type(lin).__name__ != 'Linear':
+                    raise NotImplementedError('LoRA q/v (loralib) is not wired into the native path yet')
+            b.H, b.F, b.nh, b.dh, b.S = H, self.F, nh, H // nh, self.S
+            b.causal, b.mask_neg, b.scale = False, FMIN, 1.0 / math.sqrt(H // nh)
+            b.ffn_act = L.ACT_GELU
+            b.p_hidden, b.p_attn, b.site = self.p_hidden, self.p_attn, 16 * i
+            b.wqkv = self._w(torch.cat([att.query.weight, att.key.weight, att.value.weight], 0))
+            b.wqkvT = b.wqkv.t().contiguous()
+            b.bqkv = self._f32(torch.cat([att.query.bias, att.key.bias, att.value.bias], 0))
+            d1, ln1, ad1, pl1, lnn1 = self._so(layer.attention.output, H, self.T)
+            d2, ln2, ad2, pl2, lnn2 = self._so(layer.output, H, self.T)
+            b.wo, b.woT, b.bo = self._w(d1.weight), self._wT(d1.weight), self._f32(d1.bias)
+            b.wi, b.wiT, b.bi = self._w(layer.intermediate.dense.weight), self._wT(layer.intermediate.dense.weight), self._f32(layer.intermediate.dense.bias)
+            b.wo2, b.wo2T, b.bo2 = self._w(d2.weight), self._wT(d2.weight), self._f32(d2.bias)
+            b.ln1, b.ln2 = _LN(ln1, self), _LN(ln2, self)
+            b.ad1, b.ad2, b.pl1, b.pl2, b.lnn1, b.lnn2 = ad1, ad2, pl1, pl2, lnn1, lnn2
+            b.need_dx = i > 0
+            b.T = self.T
+            self.bert_blocks.append(b)
+
+    def _build_head(self):
+        fc = self.model.bert_encoder.text_encoders['title'].fc
+        self.fc_w = self._w(fc.weight)                         # [E, H] compute dtype (forward operand)
+        self.fc_wT32 = self._wT(fc.weight, torch.float32)      # [H, E] fp32 (dgrad operand: d_pre is fp32)
+        self.fc_b = self._f32(fc.bias)
+        if fc.weight.requires_grad or self.E % 64:
+            raise NotImplementedError('item head: frozen fc with embedding_dim % 64 == 0')
+
+    def _build_sasrec(self):
+        te = self.model.user_encoder.transformer_encoder
+        E, nh = self.E, self.args.num_attention_heads
+        if (E // nh) not in (32, 64) or self.Lseq - 1 > 32:
+            raise NotImplementedError(f'SASRec geometry E={E} heads={nh} T={self.Lseq - 1}')
+        self.pos_emb = self._f32(te.position_embedding.weight)
+        self.sas_ln0 = _LN(te.layer_norm, self)
+        self.p_sas = float(self.args.drop_rate)
+        f32 = torch.float32
+        self.sas_blocks = []
+        for j, blk in enumerate(te.transformer_blocks):
+            tb = blk.transformer_block if hasattr(blk, 'transformer_block') else blk
+            mha, ff = tb.multi_head_attention, tb.feed_forward
+            for lin in (mha.w_Q, mha.w_K, mha.w_V):
+                if type(lin).__name__ != 'Linear':
+                    raise NotImplementedError('LoRA w_Q/w_V (loralib) is not wired into the native path yet')
+            b = _Block()
+            b.H, b.F, b.nh, b.dh, b.S = E, ff.w_1.out_features, nh, E // nh, self.Lseq - 1
+            b.causal, b.mask_neg, b.scale = True, -1e9, 1.0 / math.sqrt(E // nh)
+            b.ffn_act = L.ACT_RELU
+            b.p_hidden, b.p_attn, b.site = self.p_sas, self.p_sas, 4096 + 16 * j
+            b.wqkv = self._w(torch.cat([mha.w_Q.weight, mha.w_K.weight, mha.w_V.weight], 0), f32)
+            b.wqkvT = b.wqkv.t().contiguous()
+            b.bqkv = None
+            b.wo, b.woT, b.bo = self._w(mha.fc.weight, f32), self._wT(mha.fc.weight, f32), None
+            b.wi, b.wiT, b.bi = self._w(ff.w_1.weight, f32), self._wT(ff.w_1.weight, f32), self._f32(ff.w_1.bias)
+            b.wo2, b.wo2T, b.bo2 = self._w(ff.w_2.weight, f32), self._wT(ff.w_2.weight, f32), self._f32(ff.w_2.bias)
+            b.ln1, b.ln2 = _LN(mha.layer_norm, self), _LN(ff.layer_norm, self)
+            placement = getattr(blk, 'placement', None) if blk is not tb else None
+            if placement == 'parallel':
+                raise NotImplementedError('parallel Houlsby (--is_serial None) is a SURVEY.md 8(f) "next" row')
+            b.ad1 = b.ad2 = b.lnn1 = b.lnn2 = None
+            b.pl1 = b.pl2 = None
+            if blk is not tb:
+                if placement == 'pfeiffer':
+                    b.ad2, b.pl2, b.lnn2 = self._adapter_of(blk, 'adapter', E, f32), 'pfeiffer', _LN(blk.LN, self)
+                else:
+                    b.ad1 = self._adapter_of(blk, 'adapter1', E, f32)
+                    b.ad2 = self._adapter_of(blk, 'adapter2', E, f32)
+                    b.pl1 = 'serial' if b.ad1 else None
+                    b.pl2 = 'serial' if b.ad2 else None
+            b.need_dx = True
+            b.T = f32
+            self.sas_blocks.append(b)
+
+    # ------------------------------------------------------------------ buffers
+    def _buf(self, name, rows, cols, dt):
+        key = (name, cols, dt)
+        t = self._bufs.get(key)
+        if t is None or t.shape[0] < rows:
+            t = torch.zeros(rows, cols, dtype=dt, device=self.dev)
+            self._bufs[key] = t
+        return t[:rows]
+
+    def _block_bufs(self, tag, blk, M, shared):
+        """Activation buffers of one block: `shared` => transient set reused by every block (inference)."""
+        pre = tag if not shared else tag.split('.')[0] + '.shared'
+        T, H, F = blk.T, blk.H, blk.F
+        d = {}
+        d['qkv'] = self._buf(pre + '.qkv', M, 3 * H, T)
+        d['h1'] = self._buf(pre + '.h1', M, H, T)
+        d['v1'] = self._buf(pre + '.v1', M, H, T)
+        d['st1'] = self._buf(pre + '.st1', M, 2, torch.float32)
+        d['upre'] = self._buf(pre + '.upre', M, F, T)
+        d['h2'] = self._buf(pre + '.h2', M, H, T)
+        d['v2'] = self._buf(pre + '.v2', M, H, T)
+        d['st2'] = self._buf(pre + '.st2', M, 2, torch.float32)
+        for k, ad, pl in (('1', blk.ad1, blk.pl1), ('2', blk.ad2, blk.pl2)):
+            if ad is not None:
+                d['zp' + k] = self._buf(pre + '.zp' + k, M, ad.dp, T)
+                d['z' + k] = self._buf(pre + '.z' + k, M, ad.dp, T)
+                if pl == 'pfeiffer':
+                    d['t' + k] = self._buf(pre + '.t' + k, M, H, T)
+                    d['va' + k] = self._buf(pre + '.va' + k, M, H, T)
+                    d['sta' + k] = self._buf(pre + '.sta' + k, M, 2, torch.float32)
+        return d
+
+    # ------------------------------------------------------------------ one block, forward
+    def _sub_forward(self, blk, which, dense_in, w, bias, resid, ln, ad, pl, lnn, bufs, M, p_drop, site, seed, out):
+        """dense -> dropout -> [adapter] -> LN(residual + .)  for the attention-output (which='1') or FFN-output ('2') half."""
+        h, v, st = bufs['h' + which], bufs['v' + which], bufs['st' + which]
+        if ad is None:
+            L.gemm_nt(dense_in, w, v, bias=bias, R1=resid, drop_p=p_drop, drop_site=site, drop_seed=seed, drop_first=True, M=M)
+            L.ln_fwd(v, ln.gamma, ln.beta, ln.eps, out, st, M=M)
+            return
+        zp, z = bufs['zp' + which], bufs['z' + which]
+        if pl == 'pfeiffer':          # model.py:321-329 / :458-471
+            va, t, sta = bufs['va' + which], bufs['t' + which], bufs['sta' + which]
+            L.gemm_nt(dense_in, w, va, bias=bias, R1=resid, drop_p=p_drop, drop_site=site, drop_seed=seed, drop_first=True, M=M)   # h + input
+            L.ln_fwd(va, ln.gamma, ln.beta, ln.eps, t, sta, M=M)
+            L.gemm_nt(t, ad.wd, z, bias=ad.bd, C2=zp, act=ad.act, M=M)
+            L.gemm_nt(z, ad.wu, v, bias=ad.bu, R1=va, M=M)                   # adapter(t) + h + input
+            L.ln_fwd(v, lnn.gamma, lnn.beta, lnn.eps, out, st, M=M)
+            return
+        L.gemm_nt(dense_in, w, h, bias=bias, drop_p=p_drop, drop_site=site, drop_seed=seed, M=M)
+        L.gemm_nt(h, ad.wd, z, bias=ad.bd, C2=zp, act=ad.act, M=M)
+        if ad.kind == 'compacter':    # no inner residual (modules.py:248-252)
+            L.gemm_nt(z, ad.wu, v, bias=ad.bu, R1=resid, M=M)
+        else:                         # Houlsby: fc_up(act(fc_down(h))) + h, then + input (model.py:292-297)
+            L.gemm_nt(z, ad.wu, v, bias=ad.bu, R1=h, R2=resid, M=M)
+        L.ln_fwd(v, ln.gamma, ln.beta, ln.eps, out, st, M=M)
+
+    def _block_forward(self, blk, x, key_mask, n_items, M, bufs, train, seed, x_out):
+        T, H = blk.T, blk.H
+        pa = blk.p_attn if train else 0.0
+        ph = blk.p_hidden if train else 0.0
+        L.gemm_nt(x, blk.wqkv, bufs['qkv'], bias=blk.bqkv, M=M)
+        ctx = self._buf('ctx', M, H, T)
+        L.attn_fwd(bufs['qkv'], ctx, key_mask, n_items, blk.S, blk.nh, blk.dh, 0, H, 2 * H, blk.causal, blk.scale, blk.mask_neg,
+                   drop_p=pa, drop_site=blk.site, drop_seed=seed)
+        x1 = self._buf('x1', M, H, T)
+        self._sub_forward(blk, '1', ctx, blk.wo, blk.bo, x, blk.ln1, blk.ad1, blk.pl1, blk.lnn1, bufs, M, ph, blk.site + 1, seed, x1)
+        u = self._buf('u', M, blk.F, T)
+        L.gemm_nt(x1, blk.wi, u, bias=blk.bi, C2=bufs['upre'], act=blk.ffn_act, M=M)
+        self._sub_forward(blk, '2', u, blk.wo2, blk.bo2, x1, blk.ln2, blk.ad2, blk.pl2, blk.lnn2, bufs, M, ph, blk.site + 2, seed, x_out)
+
+    # ------------------------------------------------------------------ one block, backward
+    def _sub_backward(self, blk, which, dy, ln, ad, pl, lnn, bufs, M, p_drop, site, seed):
+        """Backward of _sub_forward.  Returns (d_dense_out, d_resid): gradient wrt the dense output (already through
+        its dropout mask) and wrt the residual input.  Writes adapter / LN parameter gradients."""
+        T, H = blk.T, blk.H
+        v, st = bufs['v' + which], bufs['st' + which]
+        gg = lambda f: f() if f is not None else None
+        if ad is None:
+            dv = self._buf('dv' + which, M, H, T)
+            L.ln_bwd(dy, v, st, ln.gamma, dv, M=M, dgamma=gg(ln.g_gamma), dbeta=gg(ln.g_beta))
+            if p_drop > 0:
+                dh = self._buf('dh' + which, M, H, T)
+                L.dropout_apply(dv, dh, p_drop, site, seed, M=M)
+                return dh, dv
+            return dv, dv
+        zp, z = bufs['zp' + which], bufs['z' + which]
+        dzp = self._buf('dzp', M, ad.dp, T)
+        dv = self._buf('dv' + which, M, H, T)
+        dh = self._buf('dh' + which, M, H, T)
+        if pl == 'pfeiffer':
+            va, t, sta = bufs['va' + which], bufs['t' + which], bufs['sta' + which]
+            L.ln_bwd(dy, v, st, lnn.gamma, dv, M=M, dgamma=gg(lnn.g_gamma), dbeta=gg(lnn.g_beta), dbias=gg(ad.g_bu))
+            L.gemm_nt(dv, ad.wuT, dzp, Pre=zp, dact=ad.act, M=M)
+            dt = self._buf('dt', M, H, T)
+            L.gemm_nt(dzp, ad.wdT, dt, M=M)
+            self._adapter_wgrads(ad, dv, z, dzp, t, M)
+            dva = self._buf('dva', M, H, T)
+            L.ln_bwd(dt, va, sta, ln.gamma, dva, M=M, dgamma=gg(ln.g_gamma), dbeta=gg(ln.g_beta), dres=dv)
+            if p_drop > 0:
+                L.dropout_apply(dva, dh, p_drop, site, seed, M=M)
+                return dh, dva
+            return dva, dva
+        h = bufs['h' + which]
+        L.ln_bwd(dy, v, st, ln.gamma, dv, M=M, dgamma=gg(ln.g_gamma), dbeta=gg(ln.g_beta), dbias=gg(ad.g_bu))
+        L.gemm_nt(dv, ad.wuT, dzp, Pre=zp, dact=ad.act, M=M)
+        if ad.kind == 'compacter':
+            L.gemm_nt(dzp, ad.wdT, dh, drop_p=p_drop, drop_site=site, drop_seed=seed, M=M)
+        else:
+            L.gemm_nt(dzp, ad.wdT, dh, R1=dv, drop_p=p_drop, drop_site=site, drop_seed=seed, M=M)
+        self._adapter_wgrads(ad, dv, z, dzp, h, M)
+        return dh, dv
+
+    def _adapter_wgrads(self, ad, dv, z, dzp, down_in, M):
+        """dW_up = dv^T z, dW_down = dzp^T down_in, db_down = colsum(dzp)  (db_up comes from ln_bwd's dbias)."""
+        if ad.virtual is None and ad.g_wu is None:
+            return                       # frozen adapter: nothing to accumulate
+        if ad.s_wu is None:
+            L.gemm_tn(dv, z, ad.g_wu(), M=M)
+            L.gemm_tn(dzp, down_in, ad.g_wd(), M=M)
+        else:
+            ad.s_wu.zero_()
+            ad.s_wd.zero_()
+            L.gemm_tn(dv, z, ad.s_wu, M=M)
+            L.gemm_tn(dzp, down_in, ad.s_wd, M=M)
+            if ad.virtual is None:
+                ad.g_wu().add_(ad.s_wu[:, :ad.d])
+                ad.g_wd().add_(ad.s_wd[:ad.d])
+        if ad.g_bd is not None:
+            if ad.s_bd is None:
+                L.colsum(dzp, ad.g_bd(), M=M)
+            else:
+                ad.s_bd.zero_()
+                L.colsum(dzp, ad.s_bd, M=M)
+                ad.g_bd().add_(ad.s_bd[:ad.d])
+
+    def _block_backward(self, blk, dx_out, key_mask, n_items, M, bufs, train, seed, dx_in):
+        T, H, F = blk.T, blk.H, blk.F
+        pa = blk.p_attn if train else 0.0
+        ph = blk.p_hidden if train else 0.0
+        dh2, dres2 = self._sub_backward(blk, '2', dx_out, blk.ln2, blk.ad2, blk.pl2, blk.lnn2, bufs, M, ph, blk.site + 2, seed)
+        du = self._buf('du', M, F, T)
+        L.gemm_nt(dh2, blk.wo2T, du, Pre=bufs['upre'], dact=blk.ffn_act, M=M)
+        dx1 = self._buf('dx1', M, H, T)
+        L.gemm_nt(du, blk.wiT, dx1, R1=dres2, M=M)
+        dh1, dres1 = self._sub_backward(blk, '1', dx1, blk.ln1, blk.ad1, blk.pl1, blk.lnn1, bufs, M, ph, blk.site + 1, seed)
+        if dx_in is None:       # first encoder layer: nothing trainable sits below its attention
+            return
+        dctx = self._buf('dctx', M, H, T)
+        L.gemm_nt(dh1, blk.woT, dctx, M=M)
+        dqkv = self._buf('dqkv', M, 3 * H, T)
+        L.attn_bwd(bufs['qkv'], dctx, dqkv, key_mask, n_items, blk.S, blk.nh, blk.dh, 0, H, 2 * H, blk.causal, blk.scale, blk.mask_neg,
+                   drop_p=pa, drop_site=blk.site, drop_seed=seed)
+        L.gemm_nt(dqkv, blk.wqkvT, dx_in, R1=dres1, M=M)
+
+    # ------------------------------------------------------------------ item tower / user tower
+    def _encode(self, news, n_items, train, seed, saved):
+        """news [n, 2S] int64 (ids || mask) -> (emb fp32 [Ipad, E], pre fp32 [Ipad, E]) ; keeps x_final for backward."""
+        S, H = self.S, self.H
+        M = pad_to(n_items * S, 128)
+        key_mask = self._buf('kmask', n_items, S, torch.float32)
+        key_mask.copy_(news[:, S:2 * S])
+        x = self._buf('xa', M, H, self.T)
+        L.embed_ln(news, self.emb_word, self.emb_pos, self.emb_type0, self.emb_ln.gamma, self.emb_ln.beta, self.emb_ln.eps,
+                   x, n_items, S, roberta=self.roberta, pad_id=self.pad_id,
+                   drop_p=self.p_hidden if train else 0.0, drop_site=999, drop_seed=seed)
+        other = self._buf('xb', M, H, self.T)
+        for i, blk in enumerate(self.bert_blocks):
+            bufs = saved[i] if saved is not None else self._block_bufs('bert.shared', blk, M, True)
+            self._block_forward(blk, x, key_mask, n_items, M, bufs, train, seed, other)
+            x, other = other, x
+        Ip = pad_to(n_items, 128)
+        cls = self._buf('cls', Ip, H, self.T)
+        L.gather_rows(x, cls, n_items, S)
+        emb = self._buf('emb', Ip, self.E, torch.float32)
+        pre = self._buf('embpre', Ip, self.E, torch.float32)
+        L.gemm_nt(cls, self.fc_w, emb, bias=self.fc_b, C2=pre, act=L.ACT_GELU, M=Ip)
+        return emb, pre, key_mask, M
+
+    def _user_forward(self, xin, log_mask, B, train, seed, saved):
+        """xin fp32 [Mu, E] rows (b, t) ; log_mask [B, T] -> prec [Mu, E]."""
+        E, Tn = self.E, self.Lseq - 1
+        Mu = pad_to(B * Tn, 128)
+        x = self._buf('sx_a', Mu, E, torch.float32)
+        st0 = self._buf('sst0', Mu, 2, torch.float32)
+        L.ln_fwd(xin, self.sas_ln0.gamma, self.sas_ln0.beta, self.sas_ln0.eps, x, st0, M=Mu, add=self.pos_emb[:Tn],
+                 drop_p=self.p_sas if train else 0.0, drop_site=4000, drop_seed=seed)
+        other = self._buf('sx_b', Mu, E, torch.float32)
+        for j, blk in enumerate(self.sas_blocks):
+            bufs = saved[j] if saved is not None else self._block_bufs('sas.shared', blk, Mu, True)
+            self._block_forward(blk, x, log_mask, B, Mu, bufs, train, seed, other)
+            x, other = other, x
+        return x, Mu
+
+    # ------------------------------------------------------------------ public: inference entry points
+    @torch.no_grad()
+    def encode_items(self, news):
+        L.require_gpu(news)
+        n = news.shape[0]
+        news = news.contiguous()
+        if news.dtype != torch.int64:
+            news = news.long()
+        self.pack_trainables()
+        emb, _, _, _ = self._encode(news, n, False, 0, None)
+        return emb[:n].clone()
+
+    @torch.no_grad()
+    def user_encode(self, input_embs, log_mask):
+        L.require_gpu(input_embs, log_mask)
+        B, Tn, E = input_embs.shape
+        assert Tn == self.Lseq - 1 and E == self.E
+        Mu = pad_to(B * Tn, 128)
+        xin = self._buf('sxin', Mu, E, torch.float32)
+        xin[:B * Tn].copy_(input_embs.reshape(B * Tn, E).float())
+        lm = log_mask.float().contiguous()
+        self.pack_trainables()
+        out, _ = self._user_forward(xin, lm, B, False, 0, None)
+        return out[:B * Tn].view(B, Tn, E).clone()
+
+    # ------------------------------------------------------------------ public: training step
+    def train_forward(self, sample_items, log_mask):
+        """sample_items [B*L*2, 2S] int64, log_mask [B, L-1] -> loss (0-d fp32 device tensor)."""
+        L.require_gpu(sample_items, log_mask)
+        train = self.model.training
+        n_items = sample_items.shape[0]
+        B = n_items // (2 * self.Lseq)
+        assert B * 2 * self.Lseq == n_items and log_mask.shape == (B, self.Lseq - 1)
+        news = sample_items.contiguous()
+        lm = log_mask.float().contiguous()
+        self.pack_trainables()
+        self.step_count += 1
+        seed = (self.seed * 1000003 + self.step_count) & 0xFFFFFFFFFFFF
+        M = pad_to(n_items * self.S, 128)
+        Mu = pad_to(B * (self.Lseq - 1), 128)
+        if self._saved_bert is None or self._saved_M < M or self._saved_Mu < Mu:
+            self._saved_bert = [self._block_bufs(f'bert.{i}', b, M, False) for i, b in enumerate(self.bert_blocks)]
+            self._saved_sas = [self._block_bufs(f'sas.{j}', b, Mu, False) for j, b in enumerate(self.sas_blocks)]
+            self._saved_M, self._saved_Mu = M, Mu
+        saved_b = [{k: v[:M] for k, v in d.items()} for d in self._saved_bert]
+        saved_s = [{k: v[:Mu] for k, v in d.items()} for d in self._saved_sas]
+        emb, pre, key_mask, M = self._encode(news, n_items, train, seed, saved_b)
+        xin = self._buf('sxin', Mu, self.E, torch.float32)
+        L.take_inputs(emb, xin, B, self.Lseq, self.E)
+        prec, Mu = self._user_forward(xin, lm, B, train, seed, saved_s)
+        pos = self._buf('pos', B, self.Lseq - 1, torch.float32)
+        neg = self._buf('neg', B, self.Lseq - 1, torch.float32)
+        ws = self._buf('lossws', 1, 4, torch.float32)
+        ws.zero_()
+        L.score_bce_fwd(emb, prec, lm, pos, neg, ws, B, self.Lseq, self.E, self.arch == 'cpc')
+        self._ctx = dict(B=B, n_items=n_items, M=M, Mu=Mu, seed=seed, train=train, lm=lm, key_mask=key_mask, emb=emb, pre=pre,
+                         prec=prec, xin=xin, pos=pos, neg=neg, ws=ws, saved_b=saved_b, saved_s=saved_s)
+        return ws[0, 0].clone()
+
+    def scores(self):
+        """(pos_score, neg_score) [B, L-1] of the last train_forward (parity instrumentation)."""
+        c = self._ctx
+        return c['pos'].clone(), c['neg'].clone()
+
+    def train_backward(self, grad_out=None, into_flat_grad=False):
+        """Native backward of the last train_forward.  into_flat_grad: accumulate straight into the flat
+        gradient buffer (fused path); else return per-parameter gradients for autograd to accumulate."""
+        c = self._ctx
+        if c is None:
+            raise RuntimeError('train_backward without train_forward')
+        self._ctx = None
+        target = self.flat_g if into_flat_grad else self.flat_gs
+        if not into_flat_grad:
+            target.zero_()
+        self._grad_target = target
+        B, n_items, M, Mu, seed = c['B'], c['n_items'], c['M'], c['Mu'], c['seed']
+        E, Tn = self.E, self.Lseq - 1
+        train = c['train']
+        Ip = pad_to(n_items, 128)
+        d_prec = self._buf('d_prec', Mu, E, torch.float32)
+        d_emb = self._buf('d_emb', Ip, E, torch.float32)
+        L.score_bce_bwd(c['emb'], c['prec'], c['lm'], c['pos'], c['neg'], c['ws'], 1.0, d_prec, d_emb, B, self.Lseq, E, self.arch == 'cpc')
+        # SASRec blocks, last to first
+        dx = d_prec
+        pp = [self._buf('sdx_a', Mu, E, torch.float32), self._buf('sdx_b', Mu, E, torch.float32)]
+        for k, j in enumerate(range(len(self.sas_blocks) - 1, -1, -1)):
+            self._block_backward(self.sas_blocks[j], dx, c['lm'], B, Mu, c['saved_s'][j], train, seed, pp[k % 2])
+            dx = pp[k % 2]
+        d_in = self._buf('sd_in', Mu, E, torch.float32)
+        st0 = self._buf('sst0', Mu, 2, torch.float32)
+        gg = lambda f: f() if f is not None else None
+        L.ln_bwd(dx, c['xin'], st0, self.sas_ln0.gamma, d_in, M=Mu, add=self.pos_emb[:Tn],
+                 dgamma=gg(self.sas_ln0.g_gamma), dbeta=gg(self.sas_ln0.g_beta),
+                 drop_p=self.p_sas if train else 0.0, drop_site=4000, drop_seed=seed)
+        L.emb_grad_add_inputs(d_in, d_emb, B, self.Lseq, E)
+        # item head backward: GELU, fc dgrad, scatter to the CLS rows
+        d_pre = self._buf('d_pre', Ip, E, torch.float32)
+        L.act_bwd_f32(d_emb, c['pre'], d_pre, L.ACT_GELU)
+        dcls = self._buf('dcls', Ip, self.H, self.T)
+        L.gemm_nt(d_pre, self.fc_wT32, dcls, M=Ip)
+        dxb = self._buf('dx_a', M, self.H, self.T)
+        dxb.zero_()
+        L.scatter_rows(dcls, dxb, n_items, self.S)
+        spare = self._buf('dx_b', M, self.H, self.T)
+        for i in range(len(self.bert_blocks) - 1, -1, -1):
+            blk = self.bert_blocks[i]
+            self._block_backward(blk, dxb, c['key_mask'], n_items, M, c['saved_b'][i], train, seed, spare if blk.need_dx else None)
+            dxb, spare = spare, dxb
+        if self._virtual:
+            self._virtual_backward()
+        if into_flat_grad:
+            return None
+        if grad_out is not None:
+            target.mul_(grad_out.to(target.dtype))
+        out = target.clone()
+        ddp = getattr(self.model, '_a4r_ddp', None)
+        if ddp is not None:                                   # DDP semantics: gradients averaged over ranks (run.py:503,599)
+            ddp.average_(out)
+        return [out[o:o + n].view(p.shape) for p, (o, n) in ((p, self.offsets[id(p)]) for p in self.trainable_params)]
+
+    def _virtual_backward(self):
+        """Compacter: chain the gradients of the effective matrices into (phm_rule, W_left, W_right) with autograd."""
+        effs, gouts = self._virt_graph, []
+        for a in self._virtual:
+            gouts += [a.s_wd[:a.d].contiguous(), a.s_wu[:, :a.d].contiguous()]
+        leaves = []
+        for a in self._virtual:
+            for lin in a.virtual:
+                leaves += [lin.W_left, lin.W_right]
+        rule = self._virtual[0].virtual[0].phm_rule
+        leaves = [p for p in dict.fromkeys(leaves + [rule]) if p.requires_grad]
+        grads = torch.autograd.grad(effs, leaves, gouts, allow_unused=True)
+        for p, g in zip(leaves, grads):
+            if g is not None:
+                off, n = self.offsets[id(p)]
+                self._grad_target[off:off + n].add_(g.reshape(-1))
+        self._virt_graph = None

@@ -1,0 +1,71 @@
+"""Adapter injection by module replacement, flag-for-flag as Downstream/Text/run.py:385-479
+(substring tests on --adapter_type incl. the reference's spelling 'houslby', 'pfeiffer_ver2' tested
+before 'pfeiffer', --is_serial 'None' selecting the parallel form)."""
+from .model import (BertAdaptedParallelSelfOutput, BertAdaptedSelfOutput, BertCompacterAdaptedSelfOutput,
+                    BertPfeifferAdaptedSelfOutput, CompacterModel, SASRecAdaptedSelfOutput,
+                    SASRecCompacterAdaptedSelfOutput, SASRecParallelAdaptedSelfOutput,
+                    SASRecPfeifferAdaptedSelfOutput, SASRecPfeifferVer2AdaptedSelfOutput)
+
+
+def freeze_all(model):
+    """--fine_tune_to None (run.py:369-371)."""
+    for p in model.parameters():
+        p.requires_grad = False
+
+
+def inject_adapters(model, args):
+    """Returns the (possibly wrapped: CompacterModel) model with adapters attached."""
+    if 'None' in args.adding_adapter_to:
+        return model
+    layers = model.bert_encoder.text_encoders['title'].bert_model.encoder.layer
+    blocks = model.user_encoder.transformer_encoder.transformer_blocks
+    t = args.adapter_type
+    if 'pfeiffer_ver2' in t:
+        for lyr in layers:
+            lyr.attention.output = BertAdaptedSelfOutput(lyr.attention.output, args)
+        for i, blk in enumerate(blocks):
+            blocks[i] = SASRecPfeifferVer2AdaptedSelfOutput(blk, args)
+    elif 'pfeiffer' in t:
+        for lyr in layers:
+            lyr.output = BertPfeifferAdaptedSelfOutput(lyr.output, args)
+        for i, blk in enumerate(blocks):
+            blocks[i] = SASRecPfeifferAdaptedSelfOutput(blk, args)
+    elif 'kadapter' in t or 'prompt' in t:
+        raise NotImplementedError(f'--adapter_type {t}: K-Adapter / soft prompt are outside the BASELINE configs (SURVEY.md 2.1 rows 13-14)')
+    elif 'lora' in t:
+        raise NotImplementedError('--adapter_type lora: native LoRA q/v path not wired yet (SURVEY.md 8(a) a7)')
+    elif 'compacter' in t:
+        for lyr in layers:
+            lyr.attention.output = BertCompacterAdaptedSelfOutput(lyr.attention.output, args)
+            lyr.output = BertCompacterAdaptedSelfOutput(lyr.output, args)
+        for i, blk in enumerate(blocks):
+            blocks[i] = SASRecCompacterAdaptedSelfOutput(blk, args)
+        model = CompacterModel(args, model)
+    elif 'houslby' in t:
+        serial = 'None' not in args.is_serial
+        bw = BertAdaptedSelfOutput if serial else BertAdaptedParallelSelfOutput
+        sw = SASRecAdaptedSelfOutput if serial else SASRecParallelAdaptedSelfOutput
+        for lyr in layers:
+            lyr.attention.output = bw(lyr.attention.output, args)
+            lyr.output = bw(lyr.output, args)
+        for i, blk in enumerate(blocks):
+            blocks[i] = sw(blk, args)
+    inner = getattr(model, 'model', model)
+    inner.invalidate_native()
+    return model
+
+
+def optimizer_groups(model, args):
+    """The four lr groups of run.py:505-529 (substring tests on parameter names)."""
+    groups = dict(bert=[], rec=[], abert=[], arec=[])
+    for name, p in model.named_parameters():
+        if not p.requires_grad:
+            continue
+        ad = 'adapter' in name or 'lora' in name
+        if 'bert_encoder' in name:
+            groups['abert' if ad else 'bert'].append(p)
+        else:
+            groups['arec' if ad else 'rec'].append(p)
+    out = [{'params': groups['bert'], 'lr': args.fine_tune_lr}, {'params': groups['rec'], 'lr': args.lr},
+           {'params': groups['abert'], 'lr': args.adapter_bert_lr}, {'params': groups['arec'], 'lr': args.adapter_sasrec_lr}]
+    return out

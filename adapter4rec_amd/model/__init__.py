@@ -1,0 +1,8 @@
+from .bert import BertBackbone, BERT_BASE, ROBERTA_BASE
+from .encoders import Bert_Encoder, Text_Encoder, User_Encoder
+from .model import (Model, ModelCPC, CompacterModel, BertAdaptedSelfOutput, BertAdaptedParallelSelfOutput,
+                    BertPfeifferAdaptedSelfOutput, BertCompacterAdaptedSelfOutput, SASRecAdaptedSelfOutput,
+                    SASRecParallelAdaptedSelfOutput, SASRecPfeifferAdaptedSelfOutput,
+                    SASRecPfeifferVer2AdaptedSelfOutput, SASRecCompacterAdaptedSelfOutput)
+from .modules import (AdapterBlock, AdapterPfeifferBlock, HyperComplexAdapterBlock, PHMLinear, TransformerBlock,
+                      TransformerEncoder, MultiHeadedAttention, PositionwiseFeedForward)

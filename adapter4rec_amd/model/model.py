@@ -1,0 +1,187 @@
+"""Model / ModelCPC and the adapter wrapper classes with the reference's constructor and call
+signatures (Downstream/Text/model/model.py) -- the drop-in boundary of SURVEY.md section 8(b).
+
+    model = Model(args, item_num, use_modal, bert_model)             # model.py:9-31
+    layer.attention.output = BertAdaptedSelfOutput(layer.attention.output, args)   # run.py:456-460
+    blocks[i] = SASRecAdaptedSelfOutput(blocks[i], args)             # run.py:462-465
+    loss = model(sample_items, log_mask, local_rank); loss.backward()               # run.py:597-599
+
+Forward/backward run on the MI355X-native engine (adapter4rec_amd/engine.py); there is no eager
+PyTorch path behind these classes.
+"""
+import torch
+from torch import nn
+from torch.nn.init import xavier_normal_
+
+from .bert import _Container
+from .encoders import Bert_Encoder, User_Encoder
+from .modules import AdapterBlock, AdapterPfeifferBlock, HyperComplexAdapterBlock, PHMLinear
+
+
+def _bert_dim(args):
+    name = args.bert_model_load
+    for key, dim in (('tiny', 128), ('mini', 256), ('medium', 512), ('base', 768), ('large', 1024)):
+        if key in name:
+            return dim
+    raise AssertionError('The pretrained model name should be defined correctly. such as bert-base-uncased so on')
+
+
+class _NativeLoss(torch.autograd.Function):
+    """loss = engine(sample_items, log_mask); backward() fills the adapter gradients from the native backward."""
+
+    @staticmethod
+    def forward(ctx, engine, sample_items, log_mask, *params):
+        ctx.engine = engine
+        ctx.n = len(params)
+        return engine.train_forward(sample_items, log_mask)
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        grads = ctx.engine.train_backward(grad_out)
+        return (None, None, None) + tuple(grads)
+
+
+class _TransRecBase(nn.Module):
+    arch = 'sasrec'
+
+    def __init__(self, args, item_num, use_modal, bert_model):
+        super().__init__()
+        if not use_modal:
+            raise NotImplementedError('ID tower (use_modal=False) is out of scope: Downstream/Text hard-codes is_use_modal=True (run.py:687)')
+        self.args = args
+        self.use_modal = use_modal
+        self.max_seq_len = args.max_seq_len + 1
+        self.l2_weight = args.l2_weight / 2
+        self.bert_encoder = Bert_Encoder(args=args, bert_model=bert_model)
+        self.user_encoder = User_Encoder(item_num=item_num, max_seq_len=args.max_seq_len, item_dim=args.embedding_dim,
+                                         num_attention_heads=args.num_attention_heads, dropout=args.drop_rate,
+                                         n_layers=args.transformer_block)
+        self.criterion = nn.BCEWithLogitsLoss()
+        self.bert_encoder._owner[0] = self
+        self.user_encoder._owner[0] = self
+        self._native = [None]          # engine, built lazily after adapter injection / .to(device)
+        self._phm_owner = [None]       # CompacterModel holding the shared phm_rule
+        self.compute_dtype = getattr(args, 'compute_dtype', 'bf16')
+        self.register_load_state_dict_post_hook(lambda module, incompatible: module.invalidate_native())
+
+    # -- engine plumbing
+    def invalidate_native(self):
+        self._native[0] = None
+
+    def _engine(self):
+        if self._native[0] is None:
+            from ..engine import TransRecEngine
+            self._native[0] = TransRecEngine(self, self.args, arch=self.arch, dtype=self.compute_dtype,
+                                             phm_owner=self._phm_owner[0])
+        return self._native[0]
+
+    def _apply(self, fn, *a, **k):      # .to(device) / .cuda() move tensors => rebuild the packed copies
+        self.invalidate_native()
+        return super()._apply(fn, *a, **k)
+
+    def forward(self, sample_items, log_mask, local_rank=None):
+        eng = self._engine()
+        if torch.is_grad_enabled() and eng.n_trainable:
+            return _NativeLoss.apply(eng, sample_items, log_mask, *eng.trainable_params)
+        return eng.train_forward(sample_items, log_mask)
+
+
+class Model(_TransRecBase):             # model.py:9-70
+    arch = 'sasrec'
+
+
+class ModelCPC(_TransRecBase):          # model.py:73-135
+    arch = 'cpc'
+
+
+class CompacterModel(nn.Module):        # Downstream/Text/run.py:70-83
+    def __init__(self, args, model):
+        super().__init__()
+        n = args.hypercomplex_division
+        self.model = model
+        self.phm_rule = nn.Parameter(torch.empty(n, n, n).normal_(mean=0, std=args.phm_init_range))
+        for _, sub in model.named_modules():
+            if isinstance(sub, PHMLinear):
+                sub.set_phm_rule(phm_rule=self.phm_rule)
+        model._phm_owner[0] = self
+        model.invalidate_native()
+
+    def forward(self, sample_items, log_mask, local_rank=None):
+        return self.model(sample_items, log_mask, local_rank)
+
+
+# ---------------------------------------------------------------- BERT-side wrappers
+class BertAdaptedSelfOutput(_Container):            # model.py:273-297 (Houlsby, serial)
+    placement = 'serial'
+
+    def __init__(self, self_output, args):
+        super().__init__()
+        self.self_output = self_output
+        self.adapter = AdapterBlock(args, _bert_dim(args), args.bert_adapter_down_size, args.adapter_dropout_rate)
+
+
+class BertAdaptedParallelSelfOutput(BertAdaptedSelfOutput):   # model.py:246-270
+    placement = 'parallel'
+
+
+class BertPfeifferAdaptedSelfOutput(_Container):    # model.py:300-329
+    placement = 'pfeiffer'
+
+    def __init__(self, self_output, args):
+        super().__init__()
+        self.self_output = self_output
+        self.adapter = AdapterPfeifferBlock(args, _bert_dim(args), args.bert_adapter_down_size, args.adapter_dropout_rate)
+        self.LN = nn.LayerNorm(_bert_dim(args), eps=1e-06)
+
+
+class BertCompacterAdaptedSelfOutput(_Container):   # model.py:696-720
+    placement = 'serial'
+
+    def __init__(self, self_output, args):
+        super().__init__()
+        self.self_output = self_output
+        self.adapter = HyperComplexAdapterBlock(args, _bert_dim(args), args.bert_adapter_down_size)
+
+
+# ---------------------------------------------------------------- SASRec-side wrappers
+class SASRecAdaptedSelfOutput(_Container):          # model.py:332-376
+    placement = 'serial'
+
+    def __init__(self, transformer_block, args):
+        super().__init__()
+        self.transformer_block = transformer_block
+        self.adapter1 = AdapterBlock(args, args.embedding_dim, args.adapter_down_size, args.adapter_dropout_rate)
+        self.adapter2 = AdapterBlock(args, args.embedding_dim, args.adapter_down_size, args.adapter_dropout_rate)
+
+
+class SASRecParallelAdaptedSelfOutput(SASRecAdaptedSelfOutput):   # model.py:474-520
+    placement = 'parallel'
+
+
+class SASRecPfeifferVer2AdaptedSelfOutput(_Container):   # model.py:379-423 (adapter after attention only)
+    placement = 'serial'
+
+    def __init__(self, transformer_block, args):
+        super().__init__()
+        self.transformer_block = transformer_block
+        self.adapter1 = AdapterBlock(args, args.embedding_dim, args.adapter_down_size, args.adapter_dropout_rate)
+
+
+class SASRecPfeifferAdaptedSelfOutput(_Container):  # model.py:426-471
+    placement = 'pfeiffer'
+
+    def __init__(self, transformer_block, args):
+        super().__init__()
+        self.transformer_block = transformer_block
+        self.adapter = AdapterPfeifferBlock(args, args.embedding_dim, args.adapter_down_size, args.adapter_dropout_rate)
+        self.LN = nn.LayerNorm(args.embedding_dim, eps=1e-06)
+
+
+class SASRecCompacterAdaptedSelfOutput(_Container):  # model.py:650-693
+    placement = 'serial'
+
+    def __init__(self, transformer_block, args):
+        super().__init__()
+        self.transformer_block = transformer_block
+        self.adapter1 = HyperComplexAdapterBlock(args, args.embedding_dim, args.adapter_down_size)
+        self.adapter2 = HyperComplexAdapterBlock(args, args.embedding_dim, args.adapter_down_size)

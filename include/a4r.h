@@ -37,7 +37,8 @@ int a4r_version(void);
  * q/k/v, BertSelfOutput.dense, BertIntermediate, BertOutput.dense; AdapterBlock fc_down/fc_up
  * model/modules.py:130-134; SASRec w_Q/w_K/w_V/fc/w_1/w_2 modules.py:23-28,63-74) and its dgrad.
  * epilogue, in order: + bias[N]; C2 = copy (saved pre-activation); act; * act'(Pre) if dact;
- * + R1 + R2 (residuals); dropout(p, seed, site) regenerated identically in backward; store C.
+ * [dropout if drop_first]; + R1 + R2 (residuals); [dropout if !drop_first]; store C.  The dropout mask is a
+ * pure function of (seed, site, row * N + col), so backward regenerates it instead of reading it.
  * M % 128 == 0, N % 64 == 0, K % 64 == 0.  A,B have in_dtype; C,C2,R1,R2,Pre have out_dtype. */
 typedef struct {
     const void* A; const void* B; void* C;
@@ -46,6 +47,7 @@ typedef struct {
     int32_t lda, ldb, ldc, ldc2, ldr1, ldr2, ldpre;
     int32_t in_dtype, out_dtype;
     int32_t act, dact;
+    int32_t drop_first;   /* 0: dropout after the residual adds (backward form); 1: before them (forward form) */
     float alpha;
     float drop_p; uint32_t drop_site; uint64_t drop_seed;
 } a4r_gemm_t;
@@ -95,15 +97,21 @@ int a4r_ln_fwd(void* stream, const void* v, int ldv, const float* add, int add_r
                float drop_p, uint32_t drop_site, uint64_t drop_seed);
 /* dv = LN backward of dy (through the same dropout mask when drop_p > 0); dgamma/dbeta (+=, fp32,
  * optional: --finetune_layernorm, run.py:496-501); dbias (+= column sums of dv, optional: the bias
- * gradient of the Linear whose output feeds v). */
+ * gradient of the Linear whose output feeds v).  dres (optional) is added to dv before it is stored
+ * (a residual branch that by-passes this LayerNorm: Pfeiffer, model/model.py:321-329). */
 int a4r_ln_bwd(void* stream, const void* dy, int lddy, const void* v, int ldv, const float* add, int add_rows,
-               const float* stats, const float* gamma, void* dv, int lddv,
+               const float* stats, const float* gamma, const void* dres, int lddres, void* dv, int lddv,
                float* dgamma, float* dbeta, float* dbias, int M, int H, int dtype,
                float drop_p, uint32_t drop_site, uint64_t drop_seed);
 
 /* out[i, :] = in[i * row_stride_rows, :] (CLS gather, model/encoders.py:55) and its scatter-transpose. */
 int a4r_gather_rows(void* stream, const void* in, int ldi, void* out, int ldo, int n, int row_step, int H, int dtype);
 int a4r_scatter_rows(void* stream, const void* in, int ldi, void* out, int ldo, int n, int row_step, int H, int dtype);
+
+/* y = x * keep_mask(seed, site, index) / (1 - p) elementwise on [M,N] (index = row * N + col): backward of a
+ * dropout whose forward ran inside a GEMM epilogue, for the cases no GEMM sits behind it. */
+int a4r_dropout_apply(void* stream, const void* x, int ldx, void* y, int ldy, int M, int N, int dtype,
+                      float drop_p, uint32_t drop_site, uint64_t drop_seed);
 
 /* y = x * act'(pre) elementwise on [M,N] fp32 (GELU backward of the item head, encoders.py:57). */
 int a4r_act_bwd_f32(void* stream, const float* dy, const float* pre, float* dx, int64_t n, int act);

@@ -1,0 +1,251 @@
+"""TEST-ONLY stand-in for adapter4rec_amd._lib: the same wrapper signatures, executed with plain torch on the CPU.
+
+Purpose: exercise the HOST logic of adapter4rec_amd/engine.py (buffer plumbing, launch order, gradient routing,
+optimizer binding) in the build container, which has no GPU.  It follows the semantics written in include/a4r.h.
+It is never imported by the package; tests monkeypatch it in.  Dropout must be off (p = 0).
+"""
+import ctypes
+import math
+
+import torch
+
+from adapter4rec_amd import _lib as REAL
+
+BF16, F32 = REAL.BF16, REAL.F32
+ACT_NONE, ACT_RELU, ACT_GELU, ACT_GELU_TANH, ACT_LEAKY = 0, 1, 2, 3, 4
+ACT_BY_NAME = REAL.ACT_BY_NAME
+PackDesc = REAL.PackDesc
+
+
+def lib():
+    return None
+
+
+def require_gpu(*t):
+    return None
+
+
+def _act(x, a):
+    if a == 1:
+        return torch.relu(x)
+    if a == 2:
+        return torch.nn.functional.gelu(x)
+    if a == 3:
+        return torch.nn.functional.gelu(x, approximate='tanh')
+    if a == 4:
+        return torch.nn.functional.leaky_relu(x, 0.01)
+    return x
+
+
+def _dact(pre, a):
+    with torch.enable_grad():        # callers may sit inside an autograd.Function.backward (grad mode off)
+        p = pre.detach().clone().requires_grad_(True)
+        _act(p, a).sum().backward()
+    return p.grad
+
+
+def gemm_nt(A, B, Cout, bias=None, C2=None, R1=None, R2=None, Pre=None, act=0, dact=0, alpha=1.0,
+            drop_p=0.0, drop_site=0, drop_seed=0, M=None, drop_first=False):
+    assert drop_p == 0.0
+    M = A.shape[0] if M is None else M
+    assert M % 128 == 0 and B.shape[0] % 64 == 0 and B.shape[1] % 64 == 0, (M, B.shape)
+    v = alpha * (A[:M].float() @ B.float().t())
+    if bias is not None:
+        v = v + bias
+    if C2 is not None:
+        C2[:M] = v.to(C2.dtype)
+    v = _act(v, act)
+    if dact:
+        v = v * _dact(Pre[:M].float(), dact)
+    if R1 is not None:
+        v = v + R1[:M].float()
+    if R2 is not None:
+        v = v + R2[:M].float()
+    Cout[:M] = v.to(Cout.dtype)
+
+
+def gemm_tn(X, Y, Cacc, M=None):
+    M = X.shape[0] if M is None else M
+    assert M % 64 == 0 and X.shape[1] % 64 == 0 and Y.shape[1] % 64 == 0
+    Cacc += X[:M].float().t() @ Y[:M].float()
+
+
+def colsum(X, out, M=None):
+    M = X.shape[0] if M is None else M
+    out += X[:M].float().sum(0)
+
+
+def _attn(qkv, key_mask, n_items, S, nh, dh, offs, causal, scale, mask_neg):
+    Hd = nh * dh
+    q, k, v = [qkv[:n_items * S, o:o + Hd].view(n_items, S, nh, dh).transpose(1, 2) for o in offs]
+    sc = q @ k.transpose(-1, -2) * scale
+    allowed = (key_mask != 0)[:, None, None, :].expand(n_items, 1, S, S)
+    if causal:
+        allowed = torch.tril(allowed)
+    sc = sc + torch.where(allowed, torch.tensor(0.0), torch.tensor(mask_neg))
+    return (torch.softmax(sc, -1) @ v).transpose(1, 2).reshape(n_items * S, Hd)
+
+
+def attn_fwd(qkv, out, key_mask, n_items, S, n_heads, dh, q_off, k_off, v_off, causal, scale, mask_neg,
+             drop_p=0.0, drop_site=0, drop_seed=0):
+    assert drop_p == 0.0
+    out[:n_items * S] = _attn(qkv.float(), key_mask, n_items, S, n_heads, dh, (q_off, k_off, v_off), causal, scale, mask_neg).to(out.dtype)
+
+
+def attn_bwd(qkv, dout, dqkv, key_mask, n_items, S, n_heads, dh, q_off, k_off, v_off, causal, scale, mask_neg,
+             drop_p=0.0, drop_site=0, drop_seed=0):
+    assert drop_p == 0.0
+    with torch.enable_grad():
+        q = qkv.float().clone().requires_grad_(True)
+        o = _attn(q, key_mask, n_items, S, n_heads, dh, (q_off, k_off, v_off), causal, scale, mask_neg)
+        o.backward(dout[:n_items * S].float())
+    dqkv[:n_items * S] = q.grad[:n_items * S].to(dqkv.dtype)
+
+
+def embed_ln(ids, word, pos, type0, gamma, beta, eps, out, n_items, S, roberta=False, pad_id=0,
+             drop_p=0.0, drop_site=0, drop_seed=0):
+    assert drop_p == 0.0
+    idv = ids[:, :S]
+    if roberta:
+        m = (idv != pad_id).long()
+        pid = torch.cumsum(m, 1) * m + pad_id
+    else:
+        pid = torch.arange(S).expand(n_items, S)
+    x = word[idv] + pos[pid] + type0
+    out[:n_items * S] = torch.nn.functional.layer_norm(x, (x.shape[-1],), gamma, beta, eps).view(n_items * S, -1).to(out.dtype)
+
+
+def ln_fwd(v, gamma, beta, eps, y, stats, M=None, add=None, drop_p=0.0, drop_site=0, drop_seed=0):
+    assert drop_p == 0.0
+    M = v.shape[0] if M is None else M
+    x = v[:M].float()
+    if add is not None:
+        x = x + add[torch.arange(M) % add.shape[0]]
+    mu = x.mean(-1, keepdim=True)
+    var = ((x - mu) ** 2).mean(-1, keepdim=True)
+    rstd = torch.rsqrt(var + eps)
+    stats[:M, 0] = mu[:, 0]
+    stats[:M, 1] = rstd[:, 0]
+    y[:M] = ((x - mu) * rstd * gamma + beta).to(y.dtype)
+
+
+def ln_bwd(dy, v, stats, gamma, dv, M=None, add=None, dgamma=None, dbeta=None, dbias=None, dres=None,
+           drop_p=0.0, drop_site=0, drop_seed=0):
+    assert drop_p == 0.0
+    M = v.shape[0] if M is None else M
+    x = v[:M].float()
+    if add is not None:
+        x = x + add[torch.arange(M) % add.shape[0]]
+    mu, rstd = stats[:M, 0:1], stats[:M, 1:2]
+    xh = (x - mu) * rstd
+    d = dy[:M].float()
+    if dgamma is not None:
+        dgamma += (d * xh).sum(0)
+    if dbeta is not None:
+        dbeta += d.sum(0)
+    dx = d * gamma
+    g = rstd * (dx - dx.mean(-1, keepdim=True) - xh * (dx * xh).mean(-1, keepdim=True))
+    if dbias is not None:
+        dbias += g.sum(0)
+    if dres is not None:
+        g = g + dres[:M].float()
+    dv[:M] = g.to(dv.dtype)
+
+
+def dropout_apply(x, y, drop_p, drop_site, drop_seed, M=None):
+    raise AssertionError('dropout is off in the simulator')
+
+
+def gather_rows(src, dst, n, row_step):
+    dst[:n] = src[0:n * row_step:row_step]
+
+
+def scatter_rows(src, dst, n, row_step):
+    dst[0:n * row_step:row_step] = src[:n]
+
+
+def act_bwd_f32(dy, pre, dx, act):
+    dx.copy_(dy * _dact(pre, act))
+
+
+def _valid(log_mask, B, T, cpc):
+    if cpc:
+        m = torch.zeros(B, T, dtype=torch.bool)
+        m[:, -1] = True
+        return m
+    return log_mask.view(B, T) != 0
+
+
+def score_bce_fwd(emb, prec, log_mask, pos, neg, loss_ws, B, L, E, cpc):
+    T = L - 1
+    e = emb[:B * L * 2].view(B, L, 2, E)
+    p = prec[:B * T].view(B, T, E)
+    ps, ns = (p * e[:, 1:, 0]).sum(-1), (p * e[:, :-1, 1]).sum(-1)
+    pos.view(-1)[:B * T] = ps.reshape(-1)
+    neg.view(-1)[:B * T] = ns.reshape(-1)
+    m = _valid(log_mask, B, T, cpc)
+    sp = torch.nn.functional.softplus
+    s = (sp(-ps[m]) + sp(ns[m])).sum()
+    loss_ws.view(-1)[1] = s
+    loss_ws.view(-1)[2] = float(m.sum())
+    loss_ws.view(-1)[0] = s / m.sum()
+
+
+def score_bce_bwd(emb, prec, log_mask, pos, neg, loss_ws, loss_scale, d_prec, d_emb, B, L, E, cpc):
+    T = L - 1
+    with torch.enable_grad():
+        e = emb[:B * L * 2].view(B, L, 2, E).clone().requires_grad_(True)
+        p = prec[:B * T].view(B, T, E).clone().requires_grad_(True)
+        ps, ns = (p * e[:, 1:, 0]).sum(-1), (p * e[:, :-1, 1]).sum(-1)
+        m = _valid(log_mask, B, T, cpc)
+        sp = torch.nn.functional.softplus
+        loss = (sp(-ps[m]) + sp(ns[m])).sum() / m.sum() * loss_scale
+        loss.backward()
+    d_prec[:B * T] = p.grad.view(B * T, E)
+    d_emb[:B * L * 2] = e.grad.view(B * L * 2, E)
+
+
+def emb_grad_add_inputs(d_in, d_emb, B, L, E):
+    T = L - 1
+    d_emb[:B * L * 2].view(B, L, 2, E)[:, :-1, 0] += d_in[:B * T].view(B, T, E)
+
+
+def take_inputs(emb, out, B, L, E):
+    T = L - 1
+    out[:B * T] = emb[:B * L * 2].view(B, L, 2, E)[:, :-1, 0].reshape(B * T, E)
+
+
+def adam_step(p, g, m, v, seg_end, seg_group, group_lr, step, beta1=0.9, beta2=0.999, eps=1e-8, grad_scale=1.0):
+    idx = torch.arange(p.numel())
+    seg = torch.searchsorted(seg_end.long(), idx, right=True).clamp(max=seg_end.numel() - 1)
+    lr = group_lr[seg_group.long()[seg]]
+    gi = g * grad_scale
+    m.mul_(beta1).add_(gi, alpha=1 - beta1)
+    v.mul_(beta2).addcmul_(gi, gi, value=1 - beta2)
+    bc1, bc2 = 1 - beta1 ** step, 1 - beta2 ** step
+    p.sub_((lr / bc1) * m / (v.sqrt() / math.sqrt(bc2) + eps))
+
+
+def pack_matrices(flat, desc_dev, n_desc, max_elems, dtype):
+    raw = bytes(desc_dev.numpy().tobytes())
+    arr = (PackDesc * n_desc).from_buffer_copy(raw)
+    tdt = torch.bfloat16 if dtype == BF16 else torch.float32
+    for d in arr:
+        src = flat[d.src_off:d.src_off + d.rows * d.cols].view(d.rows, d.cols)
+        if d.transpose:
+            src = src.t()
+        n = d.rows_pad * d.cols_pad
+        buf = (ctypes.c_char * (n * (2 if dtype == BF16 else 4))).from_address(d.dst)
+        dst = torch.frombuffer(buf, dtype=tdt).view(d.rows_pad, d.cols_pad)
+        dst.zero_()
+        dst[:src.shape[0], :src.shape[1]] = src.to(tdt)
+
+
+def eval_rank(prec, item_emb, target, hist_ptr, hist_idx, rank):
+    sc = prec @ item_emb.t()
+    for u in range(prec.shape[0]):
+        s = sc[u].clone()
+        ts = s[int(target[u])].item()
+        h = hist_idx[int(hist_ptr[u]):int(hist_ptr[u + 1])].long()
+        s[h] = -float('inf')
+        rank[u] = int((s[1:] > ts).sum()) + 1

@@ -1,0 +1,166 @@
+"""GPU: the whole native training step (Model.forward / backward / FusedAdam through the C ABI) against
+(a) golden vectors produced by the imported reference and (b) the CPU oracle, on identical weights and batches.
+
+fp32 compute mode is held to the north_star tolerance (scores / loss 1e-4 abs, gradients 1e-4 rel);
+bf16 mode to a bf16-rounding bound that is written next to each assertion.
+"""
+import argparse
+
+import numpy as np
+import pytest
+import torch
+
+from golden_util import LRS, VARIANT_CFG, load_variant, strip
+
+pytestmark = pytest.mark.gpu
+
+GEOM = dict(vocab_size=120, hidden_size=128, num_hidden_layers=2, num_attention_heads=2, intermediate_size=256,
+            max_position_embeddings=40, type_vocab_size=2, layer_norm_eps=1e-12, hidden_dropout_prob=0.1,
+            attention_probs_dropout_prob=0.1, pad_token_id=0, model_type='bert')
+ARGS = dict(houlsby=dict(), houlsby_gelu=dict(adapter_activation='GELU'),
+            pfeiffer=dict(adapter_type='pfeiffer', adapter_activation='relu'), pfeiffer_ver2=dict(adapter_type='pfeiffer_ver2'),
+            compacter=dict(adapter_type='compacter'), houlsby_cpc=dict(arch='cpc'),
+            roberta_cpc_pfeiffer=dict(adapter_type='pfeiffer', adapter_activation='relu', arch='cpc', bert_model_load='roberta_tiny'))
+
+
+def make_args(**kw):
+    a = argparse.Namespace(
+        max_seq_len=20, l2_weight=0, embedding_dim=64, num_attention_heads=2, drop_rate=0.1, transformer_block=2,
+        num_words_title=30, num_words_abstract=50, num_words_body=50, news_attributes=['title'], word_embedding_dim=128,
+        bert_model_load='bert_tiny', bert_adapter_down_size=64, adapter_down_size=16, adapter_dropout_rate=0.1,
+        adapter_activation='RELU', hypercomplex_division=4, phm_init_range=1e-4, adapter_type='houslby', is_serial='True',
+        adding_adapter_to='all', arch='sasrec', compute_dtype='fp32', **LRS)
+    for k, v in kw.items():
+        setattr(a, k, v)
+    return a
+
+
+def build(name, dtype='fp32'):
+    from adapter4rec_amd.inject import freeze_all, inject_adapters
+    from adapter4rec_amd.model import BertBackbone, Model, ModelCPC
+    sd, cfg, fx, trainable, (items, mask), base = load_variant(name)
+    args = make_args(compute_dtype=dtype, **ARGS[name])
+    geom = dict(GEOM)
+    if name.startswith('roberta'):
+        geom.update(max_position_embeddings=42, type_vocab_size=1, layer_norm_eps=1e-5, pad_token_id=1, model_type='roberta')
+    torch.manual_seed(0)
+    bert = BertBackbone(geom)
+    model = (ModelCPC if args.arch == 'cpc' else Model)(args, 200, True, bert)
+    freeze_all(model)
+    root = inject_adapters(model, args)
+    full = {str(k): sd[strip(str(k))] for k in fx['all_keys']}
+    root.load_state_dict(full, strict=True)           # the reference's own key names load unchanged
+    names = {n for n, p in root.named_parameters() if p.requires_grad}
+    assert names == {str(k) for k in fx['trainable']}, 'same trainable set as the reference'
+    root.to('cuda:0')
+    root.eval()                                       # dropout off: parity is defined without it
+    return root, args, sd, cfg, fx, items.to('cuda:0'), mask.to('cuda:0')
+
+
+@pytest.mark.parametrize('name', list(ARGS))
+def test_step_fp32_vs_reference_golden(name):
+    root, args, sd, cfg, fx, items, mask = build(name, 'fp32')
+    inner = getattr(root, 'model', root)
+    loss = root(items, mask, 0)
+    loss.backward()
+    eng = inner._engine()
+    # scores / loss within 1e-4 abs, checked against the reference's numbers and the oracle's
+    assert abs(loss.item() - float(fx['loss'])) < 1e-4, (loss.item(), float(fx['loss']))
+    from oracle import ref_cpu as R
+    with torch.no_grad():
+        out = R.model_forward(sd, items.cpu(), mask.cpu(), cfg)
+    embs = inner.bert_encoder(items)
+    np.testing.assert_allclose(embs.cpu().numpy(), fx['input_embs_all'], atol=1e-4, rtol=0)
+    if cfg['arch'] != 'cpc':
+        pos, neg = eng_scores(root, items, mask)
+        np.testing.assert_allclose(pos.cpu().numpy(), out['pos_score'].numpy(), atol=1e-4, rtol=0)
+        np.testing.assert_allclose(neg.cpu().numpy(), out['neg_score'].numpy(), atol=1e-4, rtol=0)
+    # adapter gradients within 1e-4 relative (of the tensor's max) vs the reference's autograd
+    params = dict(root.named_parameters())
+    for k in fx['trainable']:
+        k = str(k)
+        ref = fx['grad/' + k]
+        got = params[k].grad.cpu().numpy()
+        tol = 1e-6 + 1e-4 * np.abs(ref).max()
+        np.testing.assert_allclose(got, ref, atol=tol, rtol=0, err_msg=k)
+
+
+def eng_scores(root, items, mask):
+    inner = getattr(root, 'model', root)
+    eng = inner._engine()
+    with torch.no_grad():
+        eng.train_forward(items, mask)
+        s = eng.scores()
+        eng._ctx = None
+    return s
+
+
+@pytest.mark.parametrize('name', ['houlsby', 'pfeiffer', 'compacter'])
+def test_fused_adam_three_steps_vs_reference(name):
+    from adapter4rec_amd.inject import optimizer_groups
+    from adapter4rec_amd.optim import FusedAdam
+    root, args, sd, cfg, fx, items, mask = build(name, 'fp32')
+    opt = FusedAdam(optimizer_groups(root, args))
+    losses = []
+    params = dict(root.named_parameters())
+    for s in range(3):
+        opt.zero_grad()
+        loss = root(items, mask, 0)
+        loss.backward()
+        opt.step()
+        losses.append(loss.item())
+        if s in (0, 2):
+            for k in fx['trainable']:
+                k = str(k)
+                np.testing.assert_allclose(params[k].detach().cpu().numpy(), fx[f'adam{s + 1}/' + k], rtol=2e-4, atol=2e-7, err_msg=k)
+    np.testing.assert_allclose(losses, fx['adam_losses'], atol=1e-4, rtol=0)
+
+
+@pytest.mark.parametrize('name', ['houlsby', 'roberta_cpc_pfeiffer'])
+def test_step_bf16_bound(name):
+    """bf16 storage / fp32 accumulate.  Bound: each of the ~10 bf16 roundings per layer contributes <= 2^-9 relative;
+    on this 2-layer encoder scores (|s| <~ 10) stay within 0.15 abs and gradients within 6 % of the tensor's max."""
+    root, args, sd, cfg, fx, items, mask = build(name, 'bf16')
+    loss = root(items, mask, 0)
+    loss.backward()
+    assert abs(loss.item() - float(fx['loss'])) < 0.08, (loss.item(), float(fx['loss']))
+    inner = getattr(root, 'model', root)
+    embs = inner.bert_encoder(items)
+    ref = fx['input_embs_all']
+    err = np.abs(embs.cpu().numpy() - ref).max()
+    assert err < 0.06, err
+    params = dict(root.named_parameters())
+    worst = 0.0
+    for k in fx['trainable']:
+        k = str(k)
+        refg = fx['grad/' + k]
+        got = params[k].grad.cpu().numpy()
+        worst = max(worst, np.abs(got - refg).max() / (np.abs(refg).max() + 1e-12))
+    assert worst < 0.06, worst
+
+
+def test_dropout_training_mode_runs_and_is_seeded():
+    root, args, sd, cfg, fx, items, mask = build('houlsby', 'bf16')
+    root.train()
+    l1 = root(items, mask, 0)
+    l1.backward()
+    g1 = torch.cat([p.grad.reshape(-1) for p in root.parameters() if p.requires_grad]).clone()
+    assert torch.isfinite(l1) and torch.isfinite(g1).all()
+    assert abs(l1.item() - float(fx['loss'])) > 1e-3          # dropout changes the loss
+    inner = getattr(root, 'model', root)
+    inner._engine().step_count = 0                            # same seed => same masks => same loss
+    for p in root.parameters():
+        p.grad = None
+    l2 = root(items, mask, 0)
+    assert l2.item() == l1.item()
+
+
+def test_no_cpu_path():
+    from adapter4rec_amd.inject import freeze_all, inject_adapters
+    from adapter4rec_amd.model import BertBackbone, Model
+    args = make_args()
+    model = Model(args, 200, True, BertBackbone(GEOM))
+    freeze_all(model)
+    model = inject_adapters(model, args)
+    with pytest.raises(RuntimeError):
+        model(torch.zeros(42, 60, dtype=torch.long), torch.ones(1, 20), 'cpu')

@@ -1,0 +1,76 @@
+"""CPU: the engine's HOST logic (buffer plumbing, launch order, gradient routing, FusedAdam binding) driven through
+tests/sim_lib.py -- a torch restatement of the C-ABI kernels' documented semantics -- and checked against the
+reference's golden vectors.  This does not test the HIP kernels (tests/test_kernels_gpu.py, test_engine_gpu.py do);
+it keeps the Python orchestration honest in the GPU-less build container."""
+import numpy as np
+import pytest
+import torch
+
+import sim_lib
+from golden_util import strip
+import test_engine_gpu as TG
+
+
+@pytest.fixture
+def simulated(monkeypatch):
+    import adapter4rec_amd.engine as E
+    import adapter4rec_amd.optim as O
+    monkeypatch.setattr(E, 'L', sim_lib)
+    monkeypatch.setattr(O, 'L', sim_lib)
+    monkeypatch.setattr(E.TransRecEngine, '_require_device', lambda self, p0: None)
+
+
+def build_cpu(name):
+    import adapter4rec_amd.inject as I
+    from adapter4rec_amd.model import BertBackbone, Model, ModelCPC
+    from golden_util import load_variant
+    sd, cfg, fx, trainable, (items, mask), base = load_variant(name)
+    args = TG.make_args(compute_dtype='fp32', **TG.ARGS[name])
+    geom = dict(TG.GEOM)
+    if name.startswith('roberta'):
+        geom.update(max_position_embeddings=42, type_vocab_size=1, layer_norm_eps=1e-5, pad_token_id=1, model_type='roberta')
+    model = (ModelCPC if args.arch == 'cpc' else Model)(args, 200, True, BertBackbone(geom))
+    I.freeze_all(model)
+    root = I.inject_adapters(model, args)
+    root.load_state_dict({str(k): sd[strip(str(k))] for k in fx['all_keys']}, strict=True)
+    root.eval()
+    return root, args, fx, items, mask
+
+
+@pytest.mark.parametrize('name', list(TG.ARGS))
+def test_host_logic_forward_backward(simulated, name):
+    root, args, fx, items, mask = build_cpu(name)
+    loss = root(items, mask, 'cpu')
+    loss.backward()
+    assert abs(loss.item() - float(fx['loss'])) < 1e-4
+    inner = getattr(root, 'model', root)
+    np.testing.assert_allclose(inner.bert_encoder(items).numpy(), fx['input_embs_all'], atol=1e-4, rtol=0)
+    e = torch.from_numpy(fx['input_embs_all']).view(-1, 21, 2, 64)
+    prec = inner.user_encoder(e[:, :-1, 0].contiguous(), mask, 'cpu')
+    np.testing.assert_allclose(prec.numpy(), fx['prec_vec'], atol=1e-4, rtol=0)
+    params = dict(root.named_parameters())
+    for k in fx['trainable']:
+        k = str(k)
+        ref = fx['grad/' + k]
+        np.testing.assert_allclose(params[k].grad.numpy(), ref, atol=1e-6 + 1e-4 * np.abs(ref).max(), rtol=0, err_msg=k)
+
+
+@pytest.mark.parametrize('name', ['houlsby', 'compacter'])
+def test_host_logic_fused_adam(simulated, name):
+    from adapter4rec_amd.inject import optimizer_groups
+    from adapter4rec_amd.optim import FusedAdam
+    root, args, fx, items, mask = build_cpu(name)
+    opt = FusedAdam(optimizer_groups(root, args))
+    params = dict(root.named_parameters())
+    losses = []
+    for s in range(3):
+        opt.zero_grad()
+        loss = root(items, mask, 'cpu')
+        loss.backward()
+        opt.step()
+        losses.append(loss.item())
+        if s in (0, 2):
+            for k in fx['trainable']:
+                k = str(k)
+                np.testing.assert_allclose(params[k].detach().numpy(), fx[f'adam{s + 1}/' + k], rtol=2e-4, atol=2e-7, err_msg=k)
+    np.testing.assert_allclose(losses, fx['adam_losses'], atol=1e-4, rtol=0)
