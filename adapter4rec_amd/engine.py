@@ -196,28 +196,31 @@ class TransRecEngine:
                 arr[i] = L.PackDesc(off, dst.data_ptr(), rows, cols, rp, cp, int(tr), 0)
                 mx = max(mx, rp * cp)
             return torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(self.dev), len(entries), mx
-        tr_T = [(p, d, t) for p, d, t in self._packs_T if p.requires_grad]
-        fr_T = [(p, d, t) for p, d, t in self._packs_T if not p.requires_grad]
-        tr_b = [(p, d, False) for p, d in self._packs_b if p.requires_grad]
-        fr_b = [(p, d, False) for p, d in self._packs_b if not p.requires_grad]
-        self._tab_T = table(tr_T)
-        self._tab_b = table(tr_b)
-        # frozen adapters (e.g. eval of a loaded checkpoint with requires_grad False): pack once from a private flat copy
-        if fr_T or fr_b:
-            src = torch.cat([p.data.reshape(-1).float() for p, _, _ in fr_T + fr_b])
+        code = lambda t: L.BF16 if t.dtype == torch.bfloat16 else L.F32
+        every = list(self._packs_T) + [(p, d, False) for p, d in self._packs_b]
+        # one table per destination dtype (BERT-side copies are in compute dtype, SASRec-side and biases fp32)
+        self._tabs = []
+        for c in (L.BF16, L.F32):
+            ents = [(p, d, t) for p, d, t in every if p.requires_grad and code(d) == c]
+            if ents:
+                self._tabs.append(table(ents) + (c,))
+        # frozen adapters (e.g. eval of a loaded checkpoint with requires_grad False): packed once from a private flat copy
+        frozen = [(p, d, t) for p, d, t in every if not p.requires_grad]
+        if frozen:
+            src = torch.cat([p.data.reshape(-1).float() for p, _, _ in frozen])
             offs, o = [], 0
-            for p, _, _ in fr_T + fr_b:
+            for p, _, _ in frozen:
                 offs.append(o)
                 o += p.numel()
-            if fr_T:
-                t = table(fr_T, offs[:len(fr_T)])
-                L.pack_matrices(src, t[0], t[1], t[2], L.BF16 if self.T == torch.bfloat16 else L.F32)
-            if fr_b:
-                t = table(fr_b, offs[len(fr_T):])
-                L.pack_matrices(src, t[0], t[1], t[2], L.F32)
-            torch.cuda.current_stream().synchronize()
+            for c in (L.BF16, L.F32):
+                idx = [i for i, (_, d, _) in enumerate(frozen) if code(d) == c]
+                if idx:
+                    t = table([frozen[i] for i in idx], [offs[i] for i in idx])
+                    L.pack_matrices(src, t[0], t[1], t[2], c)
+            if self.dev.type == 'cuda':
+                torch.cuda.current_stream().synchronize()
         # compacter: effective matrices are functions of (phm_rule, W_left, W_right): built by torch each step
-        self._virt_flat = None
+        self._virt_flat, self._tabs_virt = None, []
         if self._virtual:
             n = sum(2 * a.d * a.width for a in self._virtual)
             self._virt_flat = torch.zeros(n, dtype=torch.float32, device=self.dev)
@@ -232,15 +235,15 @@ class TransRecEngine:
                 for shp, dst, tr in ((wu_shape, a.wu, False), (wu_shape, a.wuT, True)):
                     ents.append((shp, dst, tr)); offs.append(o)
                 o += a.d * a.width
-            self._tab_virt = table(ents, offs)
+            for c in (L.BF16, L.F32):
+                idx = [i for i, (_, d, _) in enumerate(ents) if code(d) == c]
+                if idx:
+                    self._tabs_virt.append(table([ents[i] for i in idx], [offs[i] for i in idx]) + (c,))
 
     def pack_trainables(self):
         """Refresh the kernel-side copies of the trainable matrices (call after every optimiser step)."""
-        dt = L.BF16 if self.T == torch.bfloat16 else L.F32
-        if self._tab_T:
-            L.pack_matrices(self.flat_p, self._tab_T[0], self._tab_T[1], self._tab_T[2], dt)
-        if self._tab_b:
-            L.pack_matrices(self.flat_p, self._tab_b[0], self._tab_b[1], self._tab_b[2], L.F32)
+        for tab, n, mx, c in self._tabs:
+            L.pack_matrices(self.flat_p, tab, n, mx, c)
         self._virt_graph = None
         if self._virtual:
             effs = []
@@ -252,7 +255,8 @@ class TransRecEngine:
                     self._virt_flat[a.v_off:a.v_off + n].copy_(wd.detach().reshape(-1))
                     self._virt_flat[a.v_off + n:a.v_off + 2 * n].copy_(wu.detach().reshape(-1))
             self._virt_graph = effs
-            L.pack_matrices(self._virt_flat, self._tab_virt[0], self._tab_virt[1], self._tab_virt[2], dt)
+            for tab, n, mx, c in self._tabs_virt:
+                L.pack_matrices(self._virt_flat, tab, n, mx, c)
 
     # ------------------------------------------------------------------ frozen weight packing
     def _w(self, t, dt=None):

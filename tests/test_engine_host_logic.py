@@ -74,3 +74,27 @@ def test_host_logic_fused_adam(simulated, name):
                 k = str(k)
                 np.testing.assert_allclose(params[k].detach().numpy(), fx[f'adam{s + 1}/' + k], rtol=2e-4, atol=2e-7, err_msg=k)
     np.testing.assert_allclose(losses, fx['adam_losses'], atol=1e-4, rtol=0)
+
+
+@pytest.mark.parametrize('name', ['houlsby', 'roberta_cpc_pfeiffer', 'compacter'])
+def test_host_logic_bf16_mode(simulated, name):
+    """bf16 storage for the item encoder, fp32 for the SASRec side: mixed-dtype plumbing (pack tables per dtype, mixed
+    GEMM in/out types) must keep the step within bf16 rounding of the fp32 oracle on well-conditioned weights."""
+    from golden_util import load_variant
+    from oracle import ref_cpu as R
+    root, args, fx, items, mask = build_cpu(name)
+    sd, cfg, *_ = load_variant(name)
+    sd = TG.condition(sd)
+    inner = getattr(root, 'model', root)
+    inner.compute_dtype = 'bf16'
+    root.load_state_dict({str(k): sd[strip(str(k))] for k in fx['all_keys']}, strict=True)
+    tr = [strip(str(k)) for k in fx['trainable']]
+    out, grads = R.loss_and_grads(sd, tr, items, mask, cfg)
+    loss = root(items, mask, 'cpu')
+    loss.backward()
+    assert abs(loss.item() - float(out['loss'].detach())) < 2e-2
+    params = dict(root.named_parameters())
+    for k in fx['trainable']:
+        k = str(k)
+        ref = grads[strip(k)].numpy()
+        assert np.abs(params[k].grad.numpy() - ref).max() <= 0.12 * np.abs(ref).max() + 1e-9, k
