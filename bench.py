@@ -1,0 +1,239 @@
+#!/usr/bin/env python
+"""bench.py -- user-sequences/sec of the adapter-tuned TransRec training step on MI355X.
+
+Workload (BASELINE.json configs[1]): SASRec + BERT-base + Houlsby adapters (width 64 in BERT, 16 in SASRec),
+title length 30, 21 + 21 item slots per user (seq_len 23 raw history), bf16 storage / fp32 accumulate,
+dropout ON (train mode), fused Adam on the adapter tensors, one RCCL all-reduce of the flat adapter-gradient
+buffer per step when --gpus > 1.  Synthetic data per SURVEY.md section 8(d): seed 123456, 65 536 items,
+canonical dense titles (30 tokens), every user a full 23-item history.  Random-init weights of the
+BERT-base geometry (no checkpoints in the image).
+
+A "step" = forward + backward + gradient all-reduce + Adam on one batch already resident in HBM.
+Prints ONE JSON line (rank 0).  `roofline` is for the dominant kernel (the bf16 MFMA GEMM), measured with HIP events
+in an instrumented pass run after the timed region; `cpu_baseline` times the CPU oracle (oracle/ref_cpu.py) on a
+bounded sample of the same workload on the host cores.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+MFMA_BF16_PEAK_TFLOPS = 2500.0      # dense bf16, /opt/skills/guides/MI355X_MICROARCH.md
+SEED = 123456
+
+
+def make_args(batch, dtype):
+    return argparse.Namespace(
+        max_seq_len=20, l2_weight=0, embedding_dim=64, num_attention_heads=2, drop_rate=0.1, transformer_block=2,
+        num_words_title=30, num_words_abstract=50, num_words_body=50, news_attributes=['title'], word_embedding_dim=768,
+        bert_model_load='bert_base_uncased', bert_adapter_down_size=64, adapter_down_size=16, adapter_dropout_rate=0.1,
+        adapter_activation='RELU', hypercomplex_division=4, phm_init_range=1e-4, adapter_type='houslby', is_serial='True',
+        adding_adapter_to='all', arch='sasrec', compute_dtype=dtype, batch_size=batch,
+        fine_tune_lr=5e-5, lr=1e-4, adapter_bert_lr=1.5e-4, adapter_sasrec_lr=1.5e-4)
+
+
+def synth_content(n_items, g):
+    """item_content [n_items + 1, 60]: [101, t_1..t_28, 102] || ones; item 0 = zeros (SURVEY.md 8(d) canonical variant)."""
+    c = torch.zeros(n_items + 1, 60, dtype=torch.int64)
+    c[1:, 1:29] = torch.randint(1000, 30000, (n_items, 28), generator=g)
+    c[1:, 0] = 101
+    c[1:, 29] = 102
+    c[1:, 30:] = 1
+    return c
+
+
+def synth_batches(content, n_items, batch, n_batches, g):
+    """Full 23-item histories: train seq = 21 items, log_mask = ones(20); one uniformly sampled negative per position."""
+    out = []
+    for _ in range(n_batches):
+        seqs = torch.stack([torch.randperm(n_items, generator=g)[:21] + 1 for _ in range(batch)])        # [B, 21]
+        negs = torch.randint(1, n_items + 1, (batch, 21), generator=g)
+        negs[:, -1] = 0
+        ids = torch.stack([seqs, negs], 2).view(-1)                                                      # [B*21*2]
+        out.append((content[ids].contiguous(), torch.ones(batch, 20)))
+    return out
+
+
+def build_model(args, device):
+    from adapter4rec_amd.inject import freeze_all, inject_adapters, optimizer_groups
+    from adapter4rec_amd.model import BERT_BASE, BertBackbone, Model
+    from adapter4rec_amd.optim import FusedAdam
+    torch.manual_seed(SEED)
+    model = Model(args, 65536, True, BertBackbone(BERT_BASE))
+    freeze_all(model)
+    model = inject_adapters(model, args)
+    model.to(device)
+    model.train()
+    opt = FusedAdam(optimizer_groups(model, args))
+    return model, opt
+
+
+class GemmProbe:
+    """HIP-event timing of every a4r_gemm_nt launch (instrumented pass only)."""
+
+    def __init__(self, L):
+        self.L, self.real, self.rec = L, L.gemm_nt, []
+
+    def __enter__(self):
+        def wrapped(A, B, Cout, *a, **k):
+            M = k.get('M') or A.shape[0]
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            self.real(A, B, Cout, *a, **k)
+            e1.record()
+            self.rec.append((str(A.dtype), str(Cout.dtype), M, B.shape[0], B.shape[1], e0, e1))
+        self.L.gemm_nt = wrapped
+        return self
+
+    def __exit__(self, *exc):
+        self.L.gemm_nt = self.real
+
+    def summary(self):
+        torch.cuda.synchronize()
+        agg = {}
+        for da, dc, M, N, K, e0, e1 in self.rec:
+            key = (da, dc, 128 if N % 128 == 0 else 64)
+            f, t, n = agg.get(key, (0.0, 0.0, 0))
+            agg[key] = (f + 2.0 * M * N * K, t + e0.elapsed_time(e1) * 1e-3, n + 1)
+        return agg
+
+
+def cpu_baseline(sample_users=4):
+    """The CPU oracle on a bounded sample: one training step (fwd + bwd + Adam), BERT-base + Houlsby, fp32."""
+    from oracle import ref_cpu as R
+    from adapter4rec_amd.inject import freeze_all, inject_adapters
+    from adapter4rec_amd.model import BERT_BASE, BertBackbone, Model
+    torch.set_num_threads(os.cpu_count() or 1)
+    args = make_args(sample_users, 'fp32')
+    torch.manual_seed(SEED)
+    model = Model(args, 65536, True, BertBackbone(BERT_BASE))
+    freeze_all(model)
+    model = inject_adapters(model, args)
+    sd = {k: v.detach() for k, v in model.state_dict().items()}
+    trainable = [n for n, p in model.named_parameters() if p.requires_grad]
+    g = torch.Generator().manual_seed(SEED)
+    content = synth_content(4096, g)
+    items, mask = synth_batches(content, 4096, sample_users, 1, g)[0]
+    cfg = dict(R.DEFAULT_CFG)
+    lrs = dict(fine_tune_lr=5e-5, lr=1e-4, adapter_bert_lr=1.5e-4, adapter_sasrec_lr=1.5e-4)
+    t0 = time.perf_counter()
+    R.train_steps(sd, trainable, [(items, mask)], cfg, lrs, 1)
+    dt = time.perf_counter() - t0
+    return dict(value=sample_users / dt, unit='user-sequences/sec', cores=torch.get_num_threads(), kind='port',
+                sample=f'1 train step (fwd+bwd+Adam) of oracle/ref_cpu.py, B={sample_users} users ({sample_users * 42} items x 30 tokens), '
+                       f'BERT-base+Houlsby fp32, dropout off, {dt:.1f} s')
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--batch', type=int, default=32, help='users per GPU per step (reference default: 32)')
+    ap.add_argument('--dtype', default='bf16', choices=['bf16', 'fp32'])
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-roofline', action='store_true')
+    a = ap.parse_args()
+
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local = int(os.environ.get('LOCAL_RANK', '0'))
+    if not torch.cuda.is_available():
+        raise SystemExit('bench.py needs an MI355X (no CPU fallback)')
+    torch.cuda.set_device(local)
+    device = torch.device('cuda', local)
+    import torch.distributed as dist
+    if world > 1:
+        dist.init_process_group('nccl', init_method='env://')
+    assert world == a.gpus or world == 1, f'--gpus {a.gpus} but WORLD_SIZE={world}'
+
+    from adapter4rec_amd import _lib as L
+    args = make_args(a.batch, a.dtype)
+    model, opt = build_model(args, device)
+    eng = model._engine()
+    g = torch.Generator().manual_seed(SEED + rank)            # users are sharded: every rank draws its own users
+    gc = torch.Generator().manual_seed(SEED)
+    content = synth_content(65536, gc)
+    batches = [(i.to(device), m.to(device)) for i, m in synth_batches(content, 65536, a.batch, 4, g)]
+    if world > 1:                                              # DDP constructor semantics: rank 0's trainables everywhere
+        dist.broadcast(eng.flat_p, 0)
+
+    def step(i):
+        items, mask = batches[i % len(batches)]
+        eng.flat_g.zero_()
+        loss = eng.train_forward(items, mask)
+        eng.train_backward(into_flat_grad=True)
+        if world > 1:
+            dist.all_reduce(eng.flat_g)
+        opt.step(grad_scale=1.0 / world)
+        return loss
+
+    for i in range(a.warmup):
+        loss = step(i)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(a.steps):
+        loss = step(a.warmup + i)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    loss_val = float(loss)
+    assert loss_val == loss_val, 'NaN loss'
+
+    roof = None
+    if rank == 0 and not a.no_roofline:
+        import adapter4rec_amd.engine as E
+        with GemmProbe(E.L) as probe:
+            for i in range(2):
+                step(a.warmup + a.steps + i)
+            agg = probe.summary()
+        tname = 'torch.bfloat16' if a.dtype == 'bf16' else 'torch.float32'
+        key = (tname, tname, 128)
+        f, t, n = agg[key]
+        ach = f / t / 1e12
+        total_f = sum(v[0] for v in agg.values())
+        total_t = sum(v[1] for v in agg.values())
+        peak = MFMA_BF16_PEAK_TFLOPS if a.dtype == 'bf16' else 157.3
+        roof = dict(bound='mfma', achieved=round(ach, 2), peak=peak, unit='TFLOP/s', frac=round(ach / peak, 4), traffic=None,
+                    kernel=f'gemm_nt_kernel<{a.dtype},{a.dtype},128>', launches_per_step=n // 2,
+                    avg_launch_us=round(t / n * 1e6, 2), flop_per_launch=f / n,
+                    all_gemm_tflops=round(total_f / total_t / 1e12, 2), gemm_time_share_of_step=round(total_t / 2 / (dt / a.steps), 3))
+
+    cpu = None
+    if rank == 0 and world == 1 and not a.no_cpu_baseline:
+        cpu = cpu_baseline()
+
+    if rank == 0:
+        users = world * a.batch * a.steps
+        out = {
+            'metric': 'user-sequences/sec, seq_len=23 BERT+SASRec+Adapter', 'value': round(users / dt, 2),
+            'unit': 'user-sequences/sec', 'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup,
+            'ms_per_step': round(dt / a.steps * 1e3, 3), 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+            'dtype': a.dtype, 'data': 'synthetic (seed 123456, 65536 items, 30-token titles, full 23-item histories; random-init BERT-base)',
+            'config': {'workload': 'MIND-shape SASRec+BERT-base+Houlsby adapter train step (fwd+bwd+allreduce+Adam), dropout on',
+                       'users_per_gpu': a.batch, 'global_batch': world * a.batch, 'seq_len': 23, 'title_tokens': 30,
+                       'items_per_user': 42, 'parallelism': f'dp{world}'},
+            'loss': round(loss_val, 5), 'roofline': roof, 'cpu_baseline': cpu,
+        }
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()
