@@ -20,7 +20,7 @@ EXPORTS = [
     'a4r_version', 'a4r_gemm_nt', 'a4r_gemm_tn', 'a4r_colsum', 'a4r_attn_fwd', 'a4r_attn_bwd', 'a4r_embed_ln',
     'a4r_ln_fwd', 'a4r_ln_bwd', 'a4r_gather_rows', 'a4r_scatter_rows', 'a4r_act_bwd_f32', 'a4r_score_bce_fwd',
     'a4r_score_bce_bwd', 'a4r_emb_grad_add_inputs', 'a4r_take_inputs', 'a4r_adam_step', 'a4r_pack_matrices',
-    'a4r_eval_rank', 'a4r_dropout_apply',
+    'a4r_eval_rank', 'a4r_dropout_apply', 'a4r_gemm_variant',
 ]
 
 
@@ -118,6 +118,10 @@ def gemm_nt(A, B, Cout, bias=None, C2=None, R1=None, R2=None, Pre=None, act=0, d
     g.act, g.dact, g.alpha, g.drop_first = act, dact, alpha, int(drop_first)
     g.drop_p, g.drop_site, g.drop_seed = drop_p, drop_site, drop_seed
     _check(lib().a4r_gemm_nt(_stream(), C.byref(g)), 'a4r_gemm_nt')
+
+
+def gemm_variant(v):
+    return lib().a4r_gemm_variant(C.c_int(v))
 
 
 def gemm_tn(X, Y, Cacc, M=None):

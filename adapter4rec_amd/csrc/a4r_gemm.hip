@@ -5,10 +5,18 @@
 // LDS image of a stage: rows of 128 bytes = eight 16-byte chunks, chunk slot c of row r holds
 // global chunk c ^ ((r >> 1) & 7): with ds_read_b128's 16-lane groups every fragment read
 // (16 rows x 4 chunk columns) touches 16 distinct 16-byte slots of the 256-byte bank row.
-// Two stages are double-buffered (register staging: the next stage's global loads are issued
-// before the MFMAs of the current one and written to LDS after them; one barrier per stage).
-// The epilogue goes through LDS (fp32 [128][BN]) so that bias/activation/residual/dropout run on
-// 8 consecutive columns per thread and every global access is 16 bytes per lane.
+//
+// K pipeline (GLDS = true, default): stages are filled by global_load_lds_dwordx4 (no VGPR round
+// trip; one wave-instruction writes 8 tile rows = 1 KiB linearly, so the swizzle is applied to the
+// per-lane SOURCE address).  The two stages are two DISTINCT __shared__ objects and the K loop is
+// unrolled by two, so that the compiler can prove the LDS-DMA into one stage does not alias the
+// ds_reads of the other -- with a single array indexed by (kt & 1) hipcc puts s_waitcnt vmcnt(0) in
+// front of the first ds_read of every K step and the loads no longer overlap the MFMAs.
+// One __syncthreads() per K step (its fence waits for the DMA: vmcnt(0) then s_barrier).
+// GLDS = false keeps the register-staged pipeline (loads issued before the MFMAs, ds_write after).
+//
+// The epilogue goes through LDS (fp32, 64 rows per stage object) so that bias / activation /
+// residual / dropout run on 8 consecutive columns per thread and every global access is 16 B/lane.
 // Workgroup -> tile map is XCD-aware: blocks that share an XCD (blockIdx % 8) walk consecutive
 // N-tiles of the same 128-row A panel, which therefore stays in that XCD's L2.
 #include "a4r_common.h"
@@ -16,23 +24,73 @@
 
 namespace {
 
-template <typename TI, typename TO, int BN>
+constexpr int ROWB = 128;   // bytes of K per tile row per stage
+
+template <typename TI, int BN>
+A4R_DEV void stage_glds(char* stage, const TI* __restrict__ A, int lda, const TI* __restrict__ B, int ldb, int k0, int wave, int lane) {
+    constexpr int PER = Elem<TI>::PER16;
+    constexpr int NLB = BN / 32;
+    const int glr = lane >> 3, glc = lane & 7;
+    char* Bs = stage + 128 * ROWB;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int q = 4 * wave + i, r = 8 * q + glr, c = glc ^ ((r >> 1) & 7);
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(A + (size_t)r * lda + k0 + c * PER),
+                                         (__attribute__((address_space(3))) void*)(stage + q * 1024), 16, 0, 0);
+    }
+#pragma unroll
+    for (int i = 0; i < NLB; ++i) {
+        const int q = NLB * wave + i, r = 8 * q + glr, c = glc ^ ((r >> 1) & 7);
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(B + (size_t)r * ldb + k0 + c * PER),
+                                         (__attribute__((address_space(3))) void*)(Bs + q * 1024), 16, 0, 0);
+    }
+}
+
+template <typename TI, int BN>
+A4R_DEV void compute_stage(const char* stage, int wm, int wn, int lane, f32x4_t (&acc)[4][BN / 32]) {
+    constexpr int NI = BN / 32;
+    const char* As = stage;
+    const char* Bs = stage + 128 * ROWB;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+        const int ch = ks * 4 + (lane >> 4);
+        uint4 af[4], bf[NI];
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi) {
+            const int row = wm * 64 + mi * 16 + (lane & 15);
+            af[mi] = *reinterpret_cast<const uint4*>(As + row * ROWB + ((ch ^ ((row >> 1) & 7)) << 4));
+        }
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) {
+            const int row = wn * (BN / 2) + ni * 16 + (lane & 15);
+            bf[ni] = *reinterpret_cast<const uint4*>(Bs + row * ROWB + ((ch ^ ((row >> 1) & 7)) << 4));
+        }
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni) Mma<TI>::mma(af[mi], bf[ni], acc[mi][ni]);
+    }
+}
+
+template <typename TI, typename TO, int BN, bool GLDS>
 __global__ void __launch_bounds__(256) gemm_nt_kernel(const a4r_gemm_t p, int ntm, int ntn, uint32_t thr16, float keep_scale) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    constexpr int BM = 128, ROWB = 128;
+    constexpr int BM = 128;
     constexpr int PER = Elem<TI>::PER16;
     constexpr int KT = ROWB / (int)sizeof(TI);
     constexpr int A_BYTES = BM * ROWB, B_BYTES = BN * ROWB, STAGE = A_BYTES + B_BYTES;
     constexpr int NI = BN / 32;          // 16-column tiles per wave
     constexpr int NLB = BN / 32;         // 16-byte chunks of B each thread stages (BN*8/256)
+    constexpr int SBYTES = (STAGE > 64 * BN * 4) ? STAGE : 64 * BN * 4;   // a stage also holds 64 fp32 epilogue rows
+    __shared__ __attribute__((aligned(16))) char lds0[SBYTES];
+    __shared__ __attribute__((aligned(16))) char lds1[SBYTES];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
 
     // bijective XCD-aware remap of the 1-D grid
     const int nt = ntm * ntn;
     const int bid = blockIdx.x, xcd = bid & 7, j = bid >> 3, q = nt >> 3, r = nt & 7;
-    const int L = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + j;
-    const int tm = L / ntn, tn = L % ntn;
+    const int Lt = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + j;
+    const int tm = Lt / ntn, tn = Lt % ntn;
 
     // copy the by-value argument's fields into registers (a captured struct would live in scratch)
     const int lda = p.lda, ldb = p.ldb, ldc = p.ldc, ldc2 = p.ldc2, ldr1 = p.ldr1, ldr2 = p.ldr2, ldpre = p.ldpre;
@@ -49,13 +107,33 @@ __global__ void __launch_bounds__(256) gemm_nt_kernel(const a4r_gemm_t p, int nt
     const TO* __restrict__ R2 = reinterpret_cast<const TO*>(p.R2);
     const TO* __restrict__ Pre = reinterpret_cast<const TO*>(p.Pre);
 
-    // register staging of one K stage (macros, not lambdas: by-reference captures of the staging
-    // arrays would be demoted to scratch memory)
-    uint4 ra0, ra1, ra2, ra3, rb0, rb1, rb2, rb3;
-    const int srow = tid >> 3, sch = tid & 7;                        // chunk id = tid + 256*i -> row = srow + 32*i
-    const int soff = srow * ROWB + ((sch ^ ((srow >> 1) & 7)) << 4);   // (row+32i)>>1 & 7 == (srow>>1)&7 since 32i>>1 = 16i
-    const TI* __restrict__ Ag = A + (size_t)srow * lda + sch * PER;
-    const TI* __restrict__ Bg = B + (size_t)srow * ldb + sch * PER;
+    f32x4_t acc[4][NI];
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    const int nk = Kdim / KT;
+
+    if constexpr (GLDS) {
+        stage_glds<TI, BN>(lds0, A, lda, B, ldb, 0, wave, lane);
+        __syncthreads();
+        for (int kt = 0; kt < nk; kt += 2) {
+            if (kt + 1 < nk) stage_glds<TI, BN>(lds1, A, lda, B, ldb, (kt + 1) * KT, wave, lane);
+            compute_stage<TI, BN>(lds0, wm, wn, lane, acc);
+            __syncthreads();
+            if (kt + 1 < nk) {
+                if (kt + 2 < nk) stage_glds<TI, BN>(lds0, A, lda, B, ldb, (kt + 2) * KT, wave, lane);
+                compute_stage<TI, BN>(lds1, wm, wn, lane, acc);
+                __syncthreads();
+            }
+        }
+    } else {
+        // register staging of one K stage (explicit scalars: arrays captured by reference went to scratch)
+        uint4 ra0, ra1, ra2, ra3, rb0, rb1, rb2, rb3;
+        const int srow = tid >> 3, sch = tid & 7;                          // chunk id = tid + 256*i -> row = srow + 32*i
+        const int soff = srow * ROWB + ((sch ^ ((srow >> 1) & 7)) << 4);   // ((srow + 32 i) >> 1) & 7 == (srow >> 1) & 7
+        const TI* __restrict__ Ag = A + (size_t)srow * lda + sch * PER;
+        const TI* __restrict__ Bg = B + (size_t)srow * ldb + sch * PER;
 #define A4R_GLOAD(kt_)                                                                         \
     {                                                                                          \
         const int k0_ = (kt_) * KT;                                                            \
@@ -70,9 +148,9 @@ __global__ void __launch_bounds__(256) gemm_nt_kernel(const a4r_gemm_t p, int nt
             rb3 = *reinterpret_cast<const uint4*>(Bg + (size_t)96 * ldb + k0_);                \
         }                                                                                      \
     }
-#define A4R_SWRITE(buf_)                                                                       \
+#define A4R_SWRITE(st_)                                                                        \
     {                                                                                          \
-        char* As_ = smem + (buf_) * STAGE + soff;                                              \
+        char* As_ = (st_) + soff;                                                              \
         char* Bs_ = As_ + A_BYTES;                                                             \
         *reinterpret_cast<uint4*>(As_) = ra0;                                                  \
         *reinterpret_cast<uint4*>(As_ + 32 * ROWB) = ra1;                                      \
@@ -85,59 +163,39 @@ __global__ void __launch_bounds__(256) gemm_nt_kernel(const a4r_gemm_t p, int nt
             *reinterpret_cast<uint4*>(Bs_ + 96 * ROWB) = rb3;                                  \
         }                                                                                      \
     }
-
-    f32x4_t acc[4][NI];
-#pragma unroll
-    for (int mi = 0; mi < 4; ++mi)
-#pragma unroll
-        for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-
-    const int nk = Kdim / KT;
-    A4R_GLOAD(0);
-    A4R_SWRITE(0);
-    __syncthreads();
-    for (int kt = 0; kt < nk; ++kt) {
-        const int cur = kt & 1;
-        if (kt + 1 < nk) A4R_GLOAD(kt + 1);
-        const char* As = smem + cur * STAGE;
-        const char* Bs = As + A_BYTES;
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            const int ch = ks * 4 + (lane >> 4);
-            uint4 af[4], bf[NI];
-#pragma unroll
-            for (int mi = 0; mi < 4; ++mi) {
-                const int row = wm * 64 + mi * 16 + (lane & 15);
-                af[mi] = *reinterpret_cast<const uint4*>(As + row * ROWB + ((ch ^ ((row >> 1) & 7)) << 4));
-            }
-#pragma unroll
-            for (int ni = 0; ni < NI; ++ni) {
-                const int row = wn * (BN / 2) + ni * 16 + (lane & 15);
-                bf[ni] = *reinterpret_cast<const uint4*>(Bs + row * ROWB + ((ch ^ ((row >> 1) & 7)) << 4));
-            }
-#pragma unroll
-            for (int mi = 0; mi < 4; ++mi)
-#pragma unroll
-                for (int ni = 0; ni < NI; ++ni) Mma<TI>::mma(af[mi], bf[ni], acc[mi][ni]);
-        }
-        if (kt + 1 < nk) A4R_SWRITE(cur ^ 1);
+        A4R_GLOAD(0);
+        A4R_SWRITE(lds0);
         __syncthreads();
-    }
-
+        for (int kt = 0; kt < nk; kt += 2) {
+            if (kt + 1 < nk) A4R_GLOAD(kt + 1);
+            compute_stage<TI, BN>(lds0, wm, wn, lane, acc);
+            if (kt + 1 < nk) A4R_SWRITE(lds1);
+            __syncthreads();
+            if (kt + 1 < nk) {
+                if (kt + 2 < nk) A4R_GLOAD(kt + 2);
+                compute_stage<TI, BN>(lds1, wm, wn, lane, acc);
+                if (kt + 2 < nk) A4R_SWRITE(lds0);
+                __syncthreads();
+            }
+        }
 #undef A4R_GLOAD
 #undef A4R_SWRITE
-    // ---- epilogue through LDS
-    float* Cs = reinterpret_cast<float*>(smem);
+    }
+
+    // ---- epilogue through LDS: tile rows 0..63 live in lds0, rows 64..127 in lds1 (fp32 [64][BN] each)
+    {
+        float* Cs = reinterpret_cast<float*>(wm == 0 ? lds0 : lds1);
 #pragma unroll
-    for (int mi = 0; mi < 4; ++mi)
+        for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
-        for (int ni = 0; ni < NI; ++ni)
+            for (int ni = 0; ni < NI; ++ni)
 #pragma unroll
-            for (int rr = 0; rr < 4; ++rr) {
-                const int row = wm * 64 + mi * 16 + (lane >> 4) * 4 + rr;
-                const int col = wn * (BN / 2) + ni * 16 + (lane & 15);
-                Cs[row * BN + col] = acc[mi][ni][rr];
-            }
+                for (int rr = 0; rr < 4; ++rr) {
+                    const int row = mi * 16 + (lane >> 4) * 4 + rr;
+                    const int col = wn * (BN / 2) + ni * 16 + (lane & 15);
+                    Cs[row * BN + col] = acc[mi][ni][rr];
+                }
+    }
     __syncthreads();
     constexpr int TPR = BN / 8, RPP = 256 / TPR;
     const int c8 = (tid % TPR) * 8;
@@ -148,10 +206,11 @@ __global__ void __launch_bounds__(256) gemm_nt_kernel(const a4r_gemm_t p, int nt
     for (int pass = 0; pass < BM / RPP; ++pass) {
         const int row = pass * RPP + tid / TPR;
         const size_t grow = (size_t)tm * BM + row;
+        const float* Cs = reinterpret_cast<const float*>(row < 64 ? lds0 : lds1) + (row & 63) * BN + c8;
         float v[8];
         {
-            const float4 lo = *reinterpret_cast<const float4*>(Cs + row * BN + c8);
-            const float4 hi = *reinterpret_cast<const float4*>(Cs + row * BN + c8 + 4);
+            const float4 lo = *reinterpret_cast<const float4*>(Cs);
+            const float4 hi = *reinterpret_cast<const float4*>(Cs + 4);
             v[0] = lo.x; v[1] = lo.y; v[2] = lo.z; v[3] = lo.w; v[4] = hi.x; v[5] = hi.y; v[6] = hi.z; v[7] = hi.w;
         }
 #pragma unroll
@@ -195,19 +254,19 @@ __global__ void __launch_bounds__(256) gemm_nt_kernel(const a4r_gemm_t p, int nt
     }
 }
 
-template <typename TI, typename TO, int BN>
-int launch(hipStream_t s, const a4r_gemm_t& g) {
-    constexpr int LDS = (2 * (128 * 128 + BN * 128) > 128 * BN * 4) ? 2 * (128 * 128 + BN * 128) : 128 * BN * 4;
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_kernel<TI, TO, BN>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-        attr_set = true;
-    }
+int g_variant = 1;   // 0 = register staging, 1 = direct-to-LDS staging (a4r_gemm_variant)
+
+template <typename TI, typename TO, int BN, bool GLDS>
+int launch_v(hipStream_t s, const a4r_gemm_t& g) {
     const int ntm = g.M / 128, ntn = g.N / BN;
-    hipLaunchKernelGGL((gemm_nt_kernel<TI, TO, BN>), dim3(ntm * ntn), dim3(256), LDS, s, g, ntm, ntn,
+    hipLaunchKernelGGL((gemm_nt_kernel<TI, TO, BN, GLDS>), dim3(ntm * ntn), dim3(256), 0, s, g, ntm, ntn,
                        a4r_thr16(g.drop_p), a4r_keep_scale(g.drop_p));
     return a4r_launch_status();
+}
+
+template <typename TI, typename TO, int BN>
+int launch(hipStream_t s, const a4r_gemm_t& g) {
+    return g_variant ? launch_v<TI, TO, BN, true>(s, g) : launch_v<TI, TO, BN, false>(s, g);
 }
 
 template <typename TI, typename TO>
@@ -218,6 +277,12 @@ int launch_bn(hipStream_t s, const a4r_gemm_t& g) {
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
 }  // namespace
+
+extern "C" int a4r_gemm_variant(int v) {
+    const int old = g_variant;
+    if (v == 0 || v == 1) g_variant = v;
+    return old;
+}
 
 extern "C" int a4r_gemm_nt(void* stream, const a4r_gemm_t* gp) {
     if (!gp) return A4R_EINVAL;

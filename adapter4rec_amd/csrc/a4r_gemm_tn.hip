@@ -92,21 +92,36 @@ __global__ void __launch_bounds__(256) gemm_tn_kernel(const T* __restrict__ X, i
     }
 }
 
-// block = 32 column groups (8 columns each) x 8 row lanes; grid.y strides the rows
+// block = NCG column groups (8 columns each, NCG = min(N/8, 32)) x 256/NCG row lanes; grid.y strides the rows.
+// Row lanes are reduced through LDS so that a block issues ONE atomic per column (all blocks hit the same
+// N addresses: per-thread atomics there ran at the contended-atomic rate, 0.8 ms for a 40k x 64 input).
 template <typename T>
-__global__ void __launch_bounds__(256) colsum_kernel(const T* __restrict__ X, int ldx, float* __restrict__ out, int M, int N) {
-    const int cg = blockIdx.x * 32 + (threadIdx.x & 31);
-    const int rlane = threadIdx.x >> 5;
-    if (cg * 8 >= N) return;
+__global__ void __launch_bounds__(256) colsum_kernel(const T* __restrict__ X, int ldx, float* __restrict__ out, int M, int N, int ncg) {
+    __shared__ float red[256][9];
+    const int nrl = 256 / ncg;
+    const int cgl = threadIdx.x % ncg, rlane = threadIdx.x / ncg;
+    const int cg = blockIdx.x * ncg + cgl;
     float s[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    for (int m = blockIdx.y * 8 + rlane; m < M; m += gridDim.y * 8) {
-        float v[8];
-        load_vec<T, 8>(X + (size_t)m * ldx + cg * 8, v);
+    if (cg * 8 < N && rlane < nrl) {
+        for (int m = blockIdx.y * nrl + rlane; m < M; m += gridDim.y * nrl) {
+            float v[8];
+            load_vec<T, 8>(X + (size_t)m * ldx + cg * 8, v);
 #pragma unroll
-        for (int e = 0; e < 8; ++e) s[e] += v[e];
+            for (int e = 0; e < 8; ++e) s[e] += v[e];
+        }
     }
 #pragma unroll
-    for (int e = 0; e < 8; ++e) atomicAdd(out + cg * 8 + e, s[e]);
+    for (int e = 0; e < 8; ++e) red[threadIdx.x][e] = s[e];
+    __syncthreads();
+    // thread t < ncg*8 sums column (t / 8 group, t % 8 element) over the row lanes
+    const int t = threadIdx.x;
+    if (t < ncg * 8) {
+        const int g = t >> 3, e = t & 7;
+        float acc = 0.f;
+        for (int r = 0; r < nrl; ++r) acc += red[r * ncg + g][e];
+        const int col = (blockIdx.x * ncg + g) * 8 + e;
+        if (col < N) atomicAdd(out + col, acc);
+    }
 }
 
 }  // namespace
@@ -137,11 +152,15 @@ extern "C" int a4r_colsum(void* stream, const void* X, int ldx, float* out, int 
     if (!X || !out || M <= 0 || N <= 0 || N % 8) return A4R_EINVAL;
     const int esz = dtype == A4R_F32 ? 4 : 2;
     if ((dtype != A4R_F32 && dtype != A4R_BF16) || (ldx * esz) % 16 || (reinterpret_cast<uintptr_t>(X) & 15u)) return A4R_EINVAL;
-    const int gx = (N / 8 + 31) / 32;
-    int gy = 512 / gx; if (gy < 1) gy = 1;
-    if (gy > (M + 7) / 8) gy = (M + 7) / 8;
+    int ncg = N / 8;                          // column groups per block: a power of two <= 32
+    if (ncg > 32) ncg = 32;
+    while (ncg & (ncg - 1)) ncg &= ncg - 1;
+    const int gx = (N / 8 + ncg - 1) / ncg;
+    const int nrl = 256 / ncg;
+    int gy = 256 / gx; if (gy < 1) gy = 1;
+    if (gy > (M + nrl - 1) / nrl) gy = (M + nrl - 1) / nrl;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-    if (dtype == A4R_BF16) hipLaunchKernelGGL(colsum_kernel<bf16_t>, dim3(gx, gy), dim3(256), 0, s, (const bf16_t*)X, ldx, out, M, N);
-    else hipLaunchKernelGGL(colsum_kernel<float>, dim3(gx, gy), dim3(256), 0, s, (const float*)X, ldx, out, M, N);
+    if (dtype == A4R_BF16) hipLaunchKernelGGL(colsum_kernel<bf16_t>, dim3(gx, gy), dim3(256), 0, s, (const bf16_t*)X, ldx, out, M, N, ncg);
+    else hipLaunchKernelGGL(colsum_kernel<float>, dim3(gx, gy), dim3(256), 0, s, (const float*)X, ldx, out, M, N, ncg);
     return a4r_launch_status();
 }

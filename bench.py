@@ -104,12 +104,25 @@ class GemmProbe:
         return agg
 
 
-def cpu_baseline(sample_users=4):
+def host_threads():
+    """Threads the CPU baseline may really use: CPU affinity, capped by the cgroup quota and by 32
+    (an over-subscribed pool -- 256 threads on a quota of a few cores -- ran 20x slower)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
+    try:
+        quota, period = open('/sys/fs/cgroup/cpu.max').read().split()
+        if quota != 'max':
+            n = min(n, max(1, int(float(quota) / float(period))))
+    except Exception:
+        pass
+    return max(1, min(n, 32))
+
+
+def cpu_baseline(sample_users=2):
     """The CPU oracle on a bounded sample: one training step (fwd + bwd + Adam), BERT-base + Houlsby, fp32."""
     from oracle import ref_cpu as R
     from adapter4rec_amd.inject import freeze_all, inject_adapters
     from adapter4rec_amd.model import BERT_BASE, BertBackbone, Model
-    torch.set_num_threads(os.cpu_count() or 1)
+    torch.set_num_threads(host_threads())
     args = make_args(sample_users, 'fp32')
     torch.manual_seed(SEED)
     model = Model(args, 65536, True, BertBackbone(BERT_BASE))

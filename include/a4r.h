@@ -52,6 +52,9 @@ typedef struct {
     float drop_p; uint32_t drop_site; uint64_t drop_seed;
 } a4r_gemm_t;
 int a4r_gemm_nt(void* stream, const a4r_gemm_t* g);
+/* tuning knob for A/B measurements: 0 = register-staged K pipeline, 1 = direct-to-LDS (global_load_lds) pipeline
+ * (default).  Results are identical; returns the previous setting (any other v only queries). */
+int a4r_gemm_variant(int v);
 
 /* C[P,Q] (fp32, +=) = X[M,P]^T . Y[M,Q]: weight gradients of the trainable adapter matrices
  * (autograd of AdapterBlock, model/modules.py:130-134).  P % 64 == 0, Q % 64 == 0, M % 64 == 0.

@@ -53,9 +53,18 @@ def act_ref(x, act):
 
 
 # ------------------------------------------------------------------ GEMM NT
+@pytest.fixture(params=[1, 0], ids=['glds', 'regstage'])
+def gemm_variant(request):
+    from adapter4rec_amd import _lib as L
+    old = L.gemm_variant(request.param)
+    yield request.param
+    L.gemm_variant(old)
+
+
 @pytest.mark.parametrize('dt', ['f32', 'bf16'])
-@pytest.mark.parametrize('M,N,K', [(128, 64, 64), (256, 128, 128), (384, 768, 768), (256, 2304, 768), (128, 192, 3072), (256, 64, 768)])
-def test_gemm_plain(dt, M, N, K):
+@pytest.mark.parametrize('M,N,K', [(128, 64, 64), (256, 128, 128), (384, 768, 768), (256, 2304, 768), (128, 192, 3072), (256, 64, 768),
+                                   (128, 128, 192), (128, 64, 320)])
+def test_gemm_plain(dt, M, N, K, gemm_variant):
     from adapter4rec_amd import _lib as L
     t = DT[dt]
     A, B = rnd(M, K, dtype=t, seed=1), rnd(N, K, dtype=t, scale=0.05, seed=2)
@@ -77,7 +86,7 @@ def test_gemm_identity_asymmetric():
 
 
 @pytest.mark.parametrize('dt', ['f32', 'bf16'])
-def test_gemm_epilogue_full(dt):
+def test_gemm_epilogue_full(dt, gemm_variant):
     from adapter4rec_amd import _lib as L
     t = DT[dt]
     M, N, K = 256, 192, 128
@@ -131,6 +140,11 @@ def test_gemm_dropout_properties():
     assert abs(frac - 0.1) < 0.01, frac
     scale = 1.0 / (1.0 - round(0.1 * 65536) / 65536)
     torch.testing.assert_close(d1[kept], base[kept] * scale, rtol=1e-5, atol=1e-5)
+    # forward form: dropout BEFORE the residual add (dense -> dropout -> + input)
+    R = rnd(M, N, seed=15)
+    d4 = torch.zeros_like(base)
+    L.gemm_nt(A, B, d4, R1=R, drop_p=0.1, drop_site=3, drop_seed=1234, drop_first=True)
+    torch.testing.assert_close(d4, d1 + R, rtol=1e-5, atol=1e-5)
 
 
 def test_gemm_rejects_bad_shapes():
