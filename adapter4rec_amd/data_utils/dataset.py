@@ -1,0 +1,75 @@
+"""Datasets / samplers with the reference's interface (Downstream/Text/data_utils/dataset.py)."""
+import math
+import random
+
+import numpy as np
+import torch
+from torch.utils.data import Dataset
+
+
+class BuildTrainDataset(Dataset):
+    """dataset.py:10-49: user -> (item contents [L, 2, 2*words] int64, log_mask [L-1] fp32); L = max_seq_len + 1.
+    Left-pads to L, masks the pad positions, and for every real position draws ONE negative uniformly from
+    1..item_num with python's `random`, rejecting items of the user's own sequence."""
+
+    def __init__(self, u2seq, item_content, item_num, max_seq_len, use_modal):
+        self.u2seq, self.item_content, self.item_num = u2seq, item_content, item_num
+        self.max_seq_len, self.use_modal = max_seq_len + 1, use_modal
+
+    def __len__(self):
+        return len(self.u2seq)
+
+    def __getitem__(self, user_id):
+        seq = self.u2seq[user_id]
+        pad = self.max_seq_len - len(seq)
+        n_tok = len(seq) - 1
+        log_mask = [0] * pad + [1] * n_tok
+        negs = []
+        for _ in range(n_tok):
+            s = random.randint(1, self.item_num)
+            while s in seq:
+                s = random.randint(1, self.item_num)
+            negs.append(s)
+        ids = torch.LongTensor(np.array([[0] * pad + list(seq), [0] * pad + negs + [0]])).transpose(0, 1)
+        if self.use_modal:
+            ids = self.item_content[ids]
+        return torch.LongTensor(ids), torch.FloatTensor(log_mask)
+
+
+class BuildEvalDataset(Dataset):
+    """dataset.py:52-78 (kept for interface parity; the native eval path does not materialise one-hot labels)."""
+
+    def __init__(self, u2seq, item_content, max_seq_len, item_num):
+        self.u2seq, self.item_content, self.max_seq_len, self.item_num = u2seq, item_content, max_seq_len + 1, item_num
+
+    def __len__(self):
+        return len(self.u2seq)
+
+    def __getitem__(self, user_id):
+        seq = self.u2seq[user_id]
+        tokens, target = seq[:-1], seq[-1]
+        pad = self.max_seq_len - len(seq)
+        log_mask = [0] * pad + [1] * len(tokens)
+        labels = np.zeros(self.item_num)
+        labels[target - 1] = 1.0
+        return torch.LongTensor([user_id]), self.item_content[[0] * pad + tokens], torch.FloatTensor(log_mask), labels
+
+
+class SequentialDistributedSampler(torch.utils.data.sampler.Sampler):
+    """dataset.py:81-108: contiguous shards, tail padded with the last index up to a multiple of batch_size * world."""
+
+    def __init__(self, dataset, batch_size, rank=None, num_replicas=None):
+        import torch.distributed as dist
+        self.num_replicas = dist.get_world_size() if num_replicas is None else num_replicas
+        self.rank = dist.get_rank() if rank is None else rank
+        self.dataset, self.batch_size = dataset, batch_size
+        self.num_samples = int(math.ceil(len(dataset) * 1.0 / batch_size / self.num_replicas)) * batch_size
+        self.total_size = self.num_samples * self.num_replicas
+
+    def __iter__(self):
+        idx = list(range(len(self.dataset)))
+        idx += [idx[-1]] * (self.total_size - len(idx))
+        return iter(idx[self.rank * self.num_samples:(self.rank + 1) * self.num_samples])
+
+    def __len__(self):
+        return self.num_samples

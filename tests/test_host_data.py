@@ -1,0 +1,112 @@
+"""CPU: host-side data path (a1) and the eval entry points (a13) against the reference's golden fixtures."""
+import logging
+import os
+import random
+
+import numpy as np
+import pytest
+import torch
+
+import sim_lib
+from golden_util import GOLDEN, load_variant, strip
+import test_engine_gpu as TG
+
+
+def test_build_train_dataset_matches_reference_fixture():
+    """(u2seq, item_content, python-random seed) -> (sample_items, log_mask), bit-exact."""
+    from adapter4rec_amd.data_utils import BuildTrainDataset
+    fx = np.load(os.path.join(GOLDEN, 'dataset.npz'))
+    seqs, o = {}, 0
+    for u, n in enumerate(fx['seq_len']):
+        seqs[u] = [int(x) for x in fx['seq_flat'][o:o + n]]
+        o += n
+    ds = BuildTrainDataset(u2seq=seqs, item_content=fx['item_content'], item_num=200, max_seq_len=20, use_modal=True)
+    random.seed(int(fx['seed']))
+    for u in range(len(seqs)):
+        items, mask = ds[u]
+        assert items.dtype == torch.int64 and tuple(items.shape) == (21, 2, 60)
+        np.testing.assert_array_equal(items.numpy(), fx['sample_items'][u])
+        np.testing.assert_array_equal(mask.numpy(), fx['log_mask'][u])
+
+
+def test_read_behaviors_split(tmp_path):
+    from adapter4rec_amd.data_utils import read_behaviors, read_news
+    news = tmp_path / 'news.tsv'
+    news.write_text(''.join(f'n{i}\ttitle {i}\n' for i in range(1, 41)))
+    beh = tmp_path / 'users.tsv'
+    rng = np.random.default_rng(0)
+    lines, raw = [], {}
+    for u in range(6):
+        n = [3, 5, 9, 23, 30, 26][u]
+        seq = [f'n{int(x)}' for x in rng.choice(np.arange(1, 41), size=n, replace=False)]
+        raw[f'u{u}'] = seq
+        lines.append(f'u{u}\t' + ' '.join(seq) + '\n')
+    beh.write_text(''.join(lines))
+    id2name, name2id = read_news(str(news))
+    log = logging.getLogger('t')
+    item_num, id2dic, tr, va, te, hv, ht = read_behaviors(str(beh), id2name, name2id, 20, 5, log)
+    assert len(tr) == 5                                  # the 3-item user is dropped (min_seq_len 5)
+    used = sorted({name2id[x] for k, s in raw.items() if len(s) >= 5 for x in s[-23:]})
+    assert item_num == len(used)
+    remap = {old: i + 1 for i, old in enumerate(used)}
+    for uid, (k, s) in enumerate((k, s) for k, s in raw.items() if len(s) >= 5):
+        full = [remap[name2id[x]] for x in s[-23:]]
+        assert tr[uid] == full[:-2] and va[uid] == full[-22:-1] and te[uid] == full[-21:]
+        assert hv[uid].tolist() == full[:-2] and ht[uid].tolist() == full[:-1]
+        assert len(te[uid]) <= 21 and len(tr[uid]) <= 21
+
+
+def test_sequential_sampler_pads_tail():
+    from adapter4rec_amd.data_utils import SequentialDistributedSampler
+    s0 = list(SequentialDistributedSampler(list(range(50)), 16, rank=0, num_replicas=2))
+    s1 = list(SequentialDistributedSampler(list(range(50)), 16, rank=1, num_replicas=2))
+    assert len(s0) == len(s1) == 32 and s0 == list(range(32)) and s1 == list(range(32, 50)) + [49] * 14
+
+
+def test_parameters_accept_reference_flags():
+    from adapter4rec_amd.parameters import parse_args
+    a = parse_args(['--mode', 'train', '--adapter_type', 'houslby', '--is_serial', 'True', '--bert_adapter_down_size', '64',
+                    '--adapter_down_size', '16', '--adapter_bert_lr', '1.5e-4', '--adapter_sasrec_lr', '1.5e-4',
+                    '--fine_tune_to', 'None', '--adding_adapter_to', 'all', '--local_rank', '2', '--arch', 'sasrec',
+                    '--news_attributes', 'title', '--freeze_paras_before', '0', '--finetune_layernorm', 'None'])
+    assert a.local_rank == 2 and a.news_attributes == ['title'] and a.adapter_type == 'houslby'
+    assert parse_args(['--local-rank', '5']).local_rank == 5
+
+
+@pytest.fixture
+def simulated(monkeypatch):
+    import adapter4rec_amd.engine as E
+    import adapter4rec_amd.data_utils.metrics as M
+    monkeypatch.setattr(E, 'L', sim_lib)
+    monkeypatch.setattr(M, 'L', sim_lib)
+    monkeypatch.setattr(E.TransRecEngine, '_require_device', lambda self, p0: None)
+
+
+def test_eval_entry_points_vs_reference_fixture(simulated):
+    """get_item_embeddings + eval_model (host logic; kernels simulated) reproduce the reference's HR@10 / nDCG@10."""
+    from test_engine_host_logic import build_cpu
+    from adapter4rec_amd.data_utils import eval_model, get_item_embeddings
+    from adapter4rec_amd.data_utils.metrics import eval_ranks
+    from oracle import ref_cpu as R
+    root, args, fx0, items, mask = build_cpu('houlsby')
+    base = np.load(os.path.join(GOLDEN, 'base.npz'))
+    fx = np.load(os.path.join(GOLDEN, 'eval.npz'))
+    emb = get_item_embeddings(root, base['item_content'], 64, args, True, 'cpu')
+    np.testing.assert_allclose(emb.numpy(), fx['item_embeddings'], atol=1e-4, rtol=0)
+    seqs, o = {}, 0
+    for u, n in enumerate(fx['full_seq_len']):
+        seqs[u] = [int(x) for x in fx['full_seq_flat'][o:o + n]]
+        o += n
+    log = logging.getLogger('t')
+    for tag in ('valid', 'test'):
+        ev, hist = {}, {}
+        for u, s in seqs.items():
+            tr, va, te, hv, ht = R.split_sequences(s, 20)
+            ev[u], hist[u] = (va, torch.tensor(hv)) if tag == 'valid' else (te, torch.tensor(ht))
+        hr = eval_model(root, hist, ev, emb, 16, args, 200, log, tag, 'cpu')
+        assert abs(hr - float(fx[tag + '_means'][0])) < 1e-3
+        ranks = eval_ranks(root, hist, ev, emb, 16, args, list(range(len(seqs)))).numpy()
+        per_user = fx[tag + '_hit_ndcg_per_user'][:len(ranks)]
+        np.testing.assert_array_equal((ranks <= 10).astype(np.float32), per_user[:, 0])
+        nd = np.where(ranks <= 10, 1.0 / np.log2(ranks + 1.0), 0.0)
+        assert abs(nd.mean() - float(fx[tag + '_means'][1])) < 1e-3
