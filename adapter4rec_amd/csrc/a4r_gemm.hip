@@ -254,7 +254,7 @@ __global__ void __launch_bounds__(256) gemm_nt_kernel(const a4r_gemm_t p, int nt
     }
 }
 
-int g_variant = 1;   // 0 = register staging, 1 = direct-to-LDS staging (a4r_gemm_variant)
+int g_variant = 2;   // 0 = 128-tile register staging, 1 = 128-tile direct-to-LDS, 2 = 256-tile ring where it applies (default)
 
 template <typename TI, typename TO, int BN, bool GLDS>
 int launch_v(hipStream_t s, const a4r_gemm_t& g) {
@@ -266,7 +266,7 @@ int launch_v(hipStream_t s, const a4r_gemm_t& g) {
 
 template <typename TI, typename TO, int BN>
 int launch(hipStream_t s, const a4r_gemm_t& g) {
-    return g_variant ? launch_v<TI, TO, BN, true>(s, g) : launch_v<TI, TO, BN, false>(s, g);
+    return g_variant != 0 ? launch_v<TI, TO, BN, true>(s, g) : launch_v<TI, TO, BN, false>(s, g);
 }
 
 template <typename TI, typename TO>
@@ -278,9 +278,11 @@ inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 
 
 }  // namespace
 
+int a4r_gemm_nt_256(hipStream_t s, const a4r_gemm_t& g);   // a4r_gemm256.hip
+
 extern "C" int a4r_gemm_variant(int v) {
     const int old = g_variant;
-    if (v == 0 || v == 1) g_variant = v;
+    if (v >= 0 && v <= 2) g_variant = v;
     return old;
 }
 
@@ -300,6 +302,7 @@ extern "C" int a4r_gemm_nt(void* stream, const a4r_gemm_t* gp) {
     if (g.dact != A4R_ACT_NONE && (!g.Pre || !aligned16(g.Pre) || (g.ldpre * osz) % 16 || g.ldpre < g.N)) return A4R_EINVAL;
     if (g.drop_p < 0.f || g.drop_p >= 1.f) return A4R_EINVAL;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    if (g_variant == 2 && g.M % 256 == 0 && g.N % 256 == 0 && g.K * isz >= 256) return a4r_gemm_nt_256(s, g);
     if (g.in_dtype == A4R_BF16 && g.out_dtype == A4R_BF16) return launch_bn<bf16_t, bf16_t>(s, g);
     if (g.in_dtype == A4R_F32 && g.out_dtype == A4R_F32) return launch_bn<float, float>(s, g);
     if (g.in_dtype == A4R_BF16 && g.out_dtype == A4R_F32) return launch_bn<bf16_t, float>(s, g);

@@ -1,0 +1,235 @@
+// gemm_nt_256_kernel: the large-tile path of a4r_gemm_nt (M % 256 == 0, N % 256 == 0, K >= 2 K-tiles).
+//
+// 256 x 256 output tile, 512 threads = 8 waves laid out 2 (M) x 4 (N); each wave owns 128 x 64 = 8 x 4 MFMA 16x16 tiles
+// (128 accumulator registers).  One workgroup per CU, two waves per SIMD.  Twice the flop per L2->LDS byte of the
+// 128 x 128 kernel, 64 MFMAs per 24 ds_read_b128 (was 32 per 16), and -- the point -- global loads stay IN FLIGHT ACROSS
+// BARRIERS: a K-tile (128 B of K per row) is cut into four 16 KiB "units"
+//     A_lo = tile rows {0-63, 128-191}   (what the two M-halves of waves read in phase 0)
+//     B_lo = B rows 64w + [0,32)         (phase 0)          B_hi = 64w + [32,64)   (phase 1)
+//     A_hi = tile rows {64-127, 192-255} (phase 2)
+// held in a 2-deep ring (2 x 64 KiB of LDS).  Each of the 4 phases of a K-tile is
+//     ds_read this phase's fragments | s_waitcnt vmcnt(8) lgkmcnt(0) | s_barrier | issue ONE unit (2 LDS-DMA per wave) | 16 MFMAs
+// The unit issued in a phase overwrites data whose last reader finished before the barrier just passed (WAR), and is
+// first read five phases later, after a counted wait + barrier has retired it (RAW): every unit has ~5 phases
+// (~1.5 us) to arrive and the matrix pipe never waits for memory in steady state.
+// LDS-DMA is issued through inline asm so that hipcc neither counts it nor inserts vmcnt(0) in front of the ds_reads
+// (it cannot prove the DMA target and the fragment reads disjoint inside one array); all vmcnt waits are explicit.
+//
+// Unit order in the instruction stream: A_lo(t), B_lo(t), B_hi(t), A_hi(t), A_lo(t+1), ...  (2 DMA instr each):
+//   phase 0 of tile u issues A_hi(u+1), phase 1 A_lo(u+2), phase 2 B_lo(u+2), phase 3 B_hi(u+2);
+//   "all but the newest 4 units have landed" (vmcnt(8)) before barrier k makes exactly the data of phase k+1 readable.
+#include "a4r_gemm_epi.h"
+
+namespace {
+
+constexpr int UNIT_BYTES = 16384;
+enum { U_ALO = 0, U_BLO = 1, U_BHI = 2, U_AHI = 3 };
+
+// one 1-KiB LDS-DMA: LDS[lds_dst + lane*16 .. +16) <- global[base + voff .. +16)
+A4R_DEV void glds16(const void* base, uint32_t voff, uint32_t lds_dst) {
+    uint32_t keep;
+    asm volatile(
+        "s_mov_b32 %0, m0\n\t"
+        "s_mov_b32 m0, %3\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dwordx4 %1, %2\n\t"
+        "s_mov_b32 m0, %0"
+        : "=&s"(keep)
+        : "v"(voff), "s"(base), "s"(lds_dst)
+        : "memory");
+}
+
+template <typename TI, typename TO>
+__global__ void __launch_bounds__(512, 2) gemm_nt_256_kernel(const a4r_gemm_t p, int ntm, int ntn, uint32_t thr16, float keep_scale) {
+    constexpr int ROWB = 128;
+    constexpr int KT = ROWB / (int)sizeof(TI);
+    __shared__ __attribute__((aligned(16))) char lds[8 * UNIT_BYTES];      // [buffer 2][unit 4][128 rows][128 B]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 2, wn = wave & 3;
+
+    // bijective XCD-aware remap of the 1-D grid
+    const int nt = ntm * ntn;
+    const int bid = blockIdx.x, xcd = bid & 7, j = bid >> 3, q8 = nt >> 3, r8 = nt & 7;
+    const int Lt = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + j;
+    const int tm = Lt / ntn, tn = Lt % ntn;
+
+    const int lda = p.lda, ldb = p.ldb;
+    const int nk = p.K / KT;
+    const char* Abase = reinterpret_cast<const char*>(reinterpret_cast<const TI*>(p.A) + (size_t)tm * 256 * lda);
+    const char* Bbase = reinterpret_cast<const char*>(reinterpret_cast<const TI*>(p.B) + (size_t)tn * 256 * ldb);
+    const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)lds;
+
+    // per-lane source offsets of this wave's two DMA instructions of each unit kind (bytes from the tile base)
+    uint32_t offA_lo[2], offA_hi[2], offB_lo[2], offB_hi[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int ul = 8 * (2 * wave + i) + (lane >> 3);                 // unit row 0..127
+        const int c = (lane & 7) ^ ((ul >> 1) & 7);                      // source chunk for linear LDS slot (lane & 7)
+        const int ra = ul + (ul >> 6) * 64;                              // A_lo tile row; A_hi = + 64
+        const int rb = ul + (ul >> 5) * 32;                              // B_lo tile row; B_hi = + 32
+        offA_lo[i] = (uint32_t)(ra * lda * (int)sizeof(TI) + c * 16);
+        offA_hi[i] = (uint32_t)((ra + 64) * lda * (int)sizeof(TI) + c * 16);
+        offB_lo[i] = (uint32_t)(rb * ldb * (int)sizeof(TI) + c * 16);
+        offB_hi[i] = (uint32_t)((rb + 32) * ldb * (int)sizeof(TI) + c * 16);
+    }
+    const uint32_t dma_dst = lds0 + (uint32_t)(2 * wave) * 1024u;       // + buffer*4*UNIT + kind*UNIT + i*1024
+
+#define A4R_ISSUE(kind_, tile_, base_, off_)                                                                         \
+    if ((tile_) < nk) {                                                                                              \
+        const char* src_ = (base_) + (size_t)(tile_) * ROWB;                                                         \
+        const uint32_t dst_ = dma_dst + (uint32_t)((((tile_) & 1) * 4 + (kind_)) * UNIT_BYTES);                       \
+        glds16(src_, off_[0], dst_);                                                                                 \
+        glds16(src_, off_[1], dst_ + 1024u);                                                                         \
+    }
+#define A4R_WAIT_BARRIER(steady_)                                                                                    \
+    if (steady_) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");                                         \
+    else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");                                                 \
+    __builtin_amdgcn_s_barrier();                                                                                    \
+    asm volatile("" ::: "memory");
+
+    f32x4_t acc[8][4];
+#pragma unroll
+    for (int mi = 0; mi < 8; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+    // fragment addressing (unit-local): A rows wm*64 + mi4*16 + (lane&15), B rows wn*32 + ni2*16 + (lane&15)
+    const int fr = lane & 15, kg = lane >> 4;
+    int a_off[4][2], b_off[2][2];
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const int row = wm * 64 + mi * 16 + fr, ch = ks * 4 + kg;
+            a_off[mi][ks] = row * ROWB + ((ch ^ ((row >> 1) & 7)) << 4);
+        }
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const int row = wn * 32 + ni * 16 + fr, ch = ks * 4 + kg;
+            b_off[ni][ks] = row * ROWB + ((ch ^ ((row >> 1) & 7)) << 4);
+        }
+
+    // ---- prologue: 7 units in stream order, then retire A_lo(0), B_lo(0)
+    A4R_ISSUE(U_ALO, 0, Abase, offA_lo)
+    A4R_ISSUE(U_BLO, 0, Bbase, offB_lo)
+    A4R_ISSUE(U_BHI, 0, Bbase, offB_hi)
+    A4R_ISSUE(U_AHI, 0, Abase, offA_hi)
+    A4R_ISSUE(U_ALO, 1, Abase, offA_lo)
+    A4R_ISSUE(U_BLO, 1, Bbase, offB_lo)
+    A4R_ISSUE(U_BHI, 1, Bbase, offB_hi)
+    asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+
+    uint4 af[4][2], b0[2][2], b1[2][2];
+    for (int u = 0; u < nk; ++u) {
+        const char* buf = lds + (u & 1) * 4 * UNIT_BYTES;
+        const bool steady = (u + 2 < nk);
+        // ---------------- phase 0: quadrant (rows 0-63, cols 0-31)
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) af[mi][ks] = *reinterpret_cast<const uint4*>(buf + U_ALO * UNIT_BYTES + a_off[mi][ks]);
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) b0[ni][ks] = *reinterpret_cast<const uint4*>(buf + U_BLO * UNIT_BYTES + b_off[ni][ks]);
+        A4R_WAIT_BARRIER(steady)
+        A4R_ISSUE(U_AHI, u + 1, Abase, offA_hi)
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < 2; ++ni) Mma<TI>::mma(af[mi][ks], b0[ni][ks], acc[mi][ni]);
+        // ---------------- phase 1: (rows 0-63, cols 32-63)
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) b1[ni][ks] = *reinterpret_cast<const uint4*>(buf + U_BHI * UNIT_BYTES + b_off[ni][ks]);
+        A4R_WAIT_BARRIER(steady)
+        A4R_ISSUE(U_ALO, u + 2, Abase, offA_lo)
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < 2; ++ni) Mma<TI>::mma(af[mi][ks], b1[ni][ks], acc[mi][2 + ni]);
+        // ---------------- phase 2: (rows 64-127, cols 32-63)
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) af[mi][ks] = *reinterpret_cast<const uint4*>(buf + U_AHI * UNIT_BYTES + a_off[mi][ks]);
+        A4R_WAIT_BARRIER(steady)
+        A4R_ISSUE(U_BLO, u + 2, Bbase, offB_lo)
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < 2; ++ni) Mma<TI>::mma(af[mi][ks], b1[ni][ks], acc[4 + mi][2 + ni]);
+        // ---------------- phase 3: (rows 64-127, cols 0-31), operands already in registers
+        A4R_WAIT_BARRIER(steady)
+        A4R_ISSUE(U_BHI, u + 2, Bbase, offB_hi)
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < 2; ++ni) Mma<TI>::mma(af[mi][ks], b0[ni][ks], acc[4 + mi][ni]);
+    }
+#undef A4R_ISSUE
+#undef A4R_WAIT_BARRIER
+
+    // ---- epilogue: two passes of 64 wave-rows through LDS (fp32 [8 waves][64][64] = 128 KiB)
+    const GemmEpi<TO> epi = make_epi<TO>(p, thr16, keep_scale);
+    float* Cw = reinterpret_cast<float*>(lds) + wave * 4096;
+#pragma unroll
+    for (int pass = 0; pass < 2; ++pass) {
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __syncthreads();                                    // every wave is done with the LDS contents
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+                for (int rr = 0; rr < 4; ++rr)
+                    Cw[(mi * 16 + kg * 4 + rr) * 64 + ni * 16 + fr] = acc[pass * 4 + mi][ni][rr];
+        __syncthreads();
+        const int row = tid >> 3, cg = tid & 7;
+#pragma unroll 1
+        for (int w = 0; w < 8; ++w) {
+            const float* src = reinterpret_cast<const float*>(lds) + w * 4096 + row * 64 + cg * 8;
+            const size_t grow = (size_t)tm * 256 + (w >> 2) * 128 + pass * 64 + row;
+            const int gcol = tn * 256 + (w & 3) * 64 + cg * 8;
+            float v[8], bias8[8];
+            const float4 lo = *reinterpret_cast<const float4*>(src);
+            const float4 hi = *reinterpret_cast<const float4*>(src + 4);
+            v[0] = lo.x; v[1] = lo.y; v[2] = lo.z; v[3] = lo.w; v[4] = hi.x; v[5] = hi.y; v[6] = hi.z; v[7] = hi.w;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) bias8[e] = epi.bias ? epi.bias[gcol + e] : 0.f;
+            epilogue8<TO>(v, bias8, grow, gcol, epi);
+        }
+    }
+}
+
+template <typename TI, typename TO>
+int launch256(hipStream_t s, const a4r_gemm_t& g) {
+    const int ntm = g.M / 256, ntn = g.N / 256;
+    hipLaunchKernelGGL((gemm_nt_256_kernel<TI, TO>), dim3(ntm * ntn), dim3(512), 0, s, g, ntm, ntn,
+                       a4r_thr16(g.drop_p), a4r_keep_scale(g.drop_p));
+    return a4r_launch_status();
+}
+
+}  // namespace
+
+// called by a4r_gemm_nt (a4r_gemm.hip) after argument validation
+int a4r_gemm_nt_256(hipStream_t s, const a4r_gemm_t& g) {
+    if (g.in_dtype == A4R_BF16 && g.out_dtype == A4R_BF16) return launch256<bf16_t, bf16_t>(s, g);
+    if (g.in_dtype == A4R_F32 && g.out_dtype == A4R_F32) return launch256<float, float>(s, g);
+    if (g.in_dtype == A4R_BF16 && g.out_dtype == A4R_F32) return launch256<bf16_t, float>(s, g);
+    return launch256<float, bf16_t>(s, g);
+}

@@ -540,7 +540,7 @@ class TransRecEngine:
     def _encode(self, news, n_items, train, seed, saved):
         """news [n, 2S] int64 (ids || mask) -> (emb fp32 [Ipad, E], pre fp32 [Ipad, E]) ; keeps x_final for backward."""
         S, H = self.S, self.H
-        M = pad_to(n_items * S, 128)
+        M = pad_to(n_items * S, 256)
         key_mask = self._buf('kmask', n_items, S, torch.float32)
         key_mask.copy_(news[:, S:2 * S])
         x = self._buf('xa', M, H, self.T)
@@ -613,7 +613,7 @@ class TransRecEngine:
         self.pack_trainables()
         self.step_count += 1
         seed = (self.seed * 1000003 + self.step_count) & 0xFFFFFFFFFFFF
-        M = pad_to(n_items * self.S, 128)
+        M = pad_to(n_items * self.S, 256)
         Mu = pad_to(B * (self.Lseq - 1), 128)
         if self._saved_bert is None or self._saved_M < M or self._saved_Mu < Mu:
             self._saved_bert = [self._block_bufs(f'bert.{i}', b, M, False) for i, b in enumerate(self.bert_blocks)]

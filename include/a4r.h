@@ -52,8 +52,10 @@ typedef struct {
     float drop_p; uint32_t drop_site; uint64_t drop_seed;
 } a4r_gemm_t;
 int a4r_gemm_nt(void* stream, const a4r_gemm_t* g);
-/* tuning knob for A/B measurements: 0 = register-staged K pipeline, 1 = direct-to-LDS (global_load_lds) pipeline
- * (default).  Results are identical; returns the previous setting (any other v only queries). */
+/* tuning knob for A/B measurements: 0 = 128x128 tile, register-staged K pipeline; 1 = 128x128 tile, direct-to-LDS
+ * (global_load_lds) pipeline; 2 (default) = 256x256 tile with a 2-deep LDS-DMA ring kept in flight across barriers
+ * wherever M % 256 == 0, N % 256 == 0 and K spans >= 2 stages, variant 1 elsewhere.  Results agree to fp32
+ * summation order; returns the previous setting (any other v only queries). */
 int a4r_gemm_variant(int v);
 
 /* C[P,Q] (fp32, +=) = X[M,P]^T . Y[M,Q]: weight gradients of the trainable adapter matrices

@@ -53,7 +53,7 @@ def act_ref(x, act):
 
 
 # ------------------------------------------------------------------ GEMM NT
-@pytest.fixture(params=[1, 0], ids=['glds', 'regstage'])
+@pytest.fixture(params=[2, 1, 0], ids=['tile256', 'glds', 'regstage'])
 def gemm_variant(request):
     from adapter4rec_amd import _lib as L
     old = L.gemm_variant(request.param)
@@ -63,7 +63,8 @@ def gemm_variant(request):
 
 @pytest.mark.parametrize('dt', ['f32', 'bf16'])
 @pytest.mark.parametrize('M,N,K', [(128, 64, 64), (256, 128, 128), (384, 768, 768), (256, 2304, 768), (128, 192, 3072), (256, 64, 768),
-                                   (128, 128, 192), (128, 64, 320)])
+                                   (128, 128, 192), (128, 64, 320), (256, 256, 128), (512, 768, 768), (256, 256, 192),
+                                   (768, 2304, 768), (256, 768, 3072), (256, 3072, 64)])
 def test_gemm_plain(dt, M, N, K, gemm_variant):
     from adapter4rec_amd import _lib as L
     t = DT[dt]
@@ -73,14 +74,15 @@ def test_gemm_plain(dt, M, N, K, gemm_variant):
     close(Cc, A.float() @ B.float().t(), t, f'gemm {dt} {M}x{N}x{K}')
 
 
-def test_gemm_identity_asymmetric():
+def test_gemm_identity_asymmetric(gemm_variant):
     """A = I with an asymmetric B catches swapped row/col maps (guide section 3)."""
     from adapter4rec_amd import _lib as L
+    n = 256
     for t in (torch.float32, torch.bfloat16):
-        A = torch.zeros(128, 128, dtype=t, device=dev())
-        A[:, :] = torch.eye(128)
-        B = (torch.arange(128 * 128, dtype=torch.float32).view(128, 128) % 251 - 125).to(t).to(dev())   # small ints: exact in bf16
-        Cc = torch.zeros(128, 128, dtype=t, device=dev())
+        A = torch.zeros(n, n, dtype=t, device=dev())
+        A[:, :] = torch.eye(n)
+        B = (torch.arange(n * n, dtype=torch.float32).view(n, n) % 251 - 125).to(t).to(dev())   # small ints: exact in bf16
+        Cc = torch.zeros(n, n, dtype=t, device=dev())
         L.gemm_nt(A, B, Cc)
         assert torch.equal(Cc.float().cpu(), B.float().t().cpu())
 
@@ -89,7 +91,7 @@ def test_gemm_identity_asymmetric():
 def test_gemm_epilogue_full(dt, gemm_variant):
     from adapter4rec_amd import _lib as L
     t = DT[dt]
-    M, N, K = 256, 192, 128
+    M, N, K = (256, 256, 192) if gemm_variant == 2 else (256, 192, 128)
     A, B = rnd(M, K, dtype=t, seed=3), rnd(N, K, dtype=t, scale=0.1, seed=4)
     bias = rnd(N, seed=5)
     R1, R2, Pre = rnd(M, N, dtype=t, seed=6), rnd(M, N, dtype=t, seed=7), rnd(M, N, dtype=t, seed=8)
@@ -123,9 +125,9 @@ def test_gemm_mixed_dtypes_and_views():
     close(C16, A32 @ B32.t(), torch.bfloat16, 'f32->bf16')
 
 
-def test_gemm_dropout_properties():
+def test_gemm_dropout_properties(gemm_variant):
     from adapter4rec_amd import _lib as L
-    M, N, K = 256, 768, 64
+    M, N, K = 256, 768, 128
     A, B = rnd(M, K, seed=13), rnd(N, K, seed=14)
     base = torch.zeros(M, N, device=dev())
     L.gemm_nt(A, B, base)
