@@ -48,16 +48,25 @@ __global__ void __launch_bounds__(512, 2) gemm_nt_256_kernel(const a4r_gemm_t p,
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 2, wn = wave & 3;
 
-    // bijective XCD-aware remap of the 1-D grid
+    // persistent workgroups: virtual block id vb = blockIdx.x + i * gridDim.x (gridDim.x is a multiple of 8 whenever the
+    // grid is smaller than the tile count, so vb & 7 -- the XCD group -- is the same for every tile a workgroup visits);
+    // bijective XCD-aware remap: workgroups that share an XCD walk consecutive N-tiles of one 256-row A panel.
     const int nt = ntm * ntn;
-    const int bid = blockIdx.x, xcd = bid & 7, j = bid >> 3, q8 = nt >> 3, r8 = nt & 7;
-    const int Lt = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + j;
-    const int tm = Lt / ntn, tn = Lt % ntn;
+    const int q8 = nt >> 3, r8 = nt & 7;
+    auto tile_of = [&](int vb) {
+        const int xcd = vb & 7, j = vb >> 3;
+        return (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + j;
+    };
+    int vb = blockIdx.x;
+    int Lt = tile_of(vb);
+    int tm = Lt / ntn, tn = Lt % ntn;
 
     const int lda = p.lda, ldb = p.ldb;
     const int nk = p.K / KT;
-    const char* Abase = reinterpret_cast<const char*>(reinterpret_cast<const TI*>(p.A) + (size_t)tm * 256 * lda);
-    const char* Bbase = reinterpret_cast<const char*>(reinterpret_cast<const TI*>(p.B) + (size_t)tn * 256 * ldb);
+    const TI* Ap = reinterpret_cast<const TI*>(p.A);
+    const TI* Bp = reinterpret_cast<const TI*>(p.B);
+    const char* Abase = reinterpret_cast<const char*>(Ap + (size_t)tm * 256 * lda);
+    const char* Bbase = reinterpret_cast<const char*>(Bp + (size_t)tn * 256 * ldb);
     const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)lds;
 
     // per-lane source offsets of this wave's two DMA instructions of each unit kind (bytes from the tile base)
@@ -89,10 +98,6 @@ __global__ void __launch_bounds__(512, 2) gemm_nt_256_kernel(const a4r_gemm_t p,
     asm volatile("" ::: "memory");
 
     f32x4_t acc[8][4];
-#pragma unroll
-    for (int mi = 0; mi < 8; ++mi)
-#pragma unroll
-        for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
     // fragment addressing (unit-local): A rows wm*64 + mi4*16 + (lane&15), B rows wn*32 + ni2*16 + (lane&15)
     const int fr = lane & 15, kg = lane >> 4;
@@ -112,17 +117,26 @@ __global__ void __launch_bounds__(512, 2) gemm_nt_256_kernel(const a4r_gemm_t p,
             b_off[ni][ks] = row * ROWB + ((ch ^ ((row >> 1) & 7)) << 4);
         }
 
-    // ---- prologue: 7 units in stream order, then retire A_lo(0), B_lo(0)
-    A4R_ISSUE(U_ALO, 0, Abase, offA_lo)
-    A4R_ISSUE(U_BLO, 0, Bbase, offB_lo)
-    A4R_ISSUE(U_BHI, 0, Bbase, offB_hi)
-    A4R_ISSUE(U_AHI, 0, Abase, offA_hi)
-    A4R_ISSUE(U_ALO, 1, Abase, offA_lo)
-    A4R_ISSUE(U_BLO, 1, Bbase, offB_lo)
+    // ---- prologue of a tile: 7 units in stream order (tiles 0 and 1 of the ring)
+#define A4R_PROLOGUE()                          \
+    A4R_ISSUE(U_ALO, 0, Abase, offA_lo)         \
+    A4R_ISSUE(U_BLO, 0, Bbase, offB_lo)         \
+    A4R_ISSUE(U_BHI, 0, Bbase, offB_hi)         \
+    A4R_ISSUE(U_AHI, 0, Abase, offA_hi)         \
+    A4R_ISSUE(U_ALO, 1, Abase, offA_lo)         \
+    A4R_ISSUE(U_BLO, 1, Bbase, offB_lo)         \
     A4R_ISSUE(U_BHI, 1, Bbase, offB_hi)
-    asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+    A4R_PROLOGUE()
+    asm volatile("s_waitcnt vmcnt(10)" ::: "memory");     // A_lo(0), B_lo(0) of the first tile have landed
+    const GemmEpi<TO> epi = make_epi<TO>(p, thr16, keep_scale);
+
+  for (;;) {                                              // ---- tiles of this workgroup
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
+#pragma unroll
+    for (int mi = 0; mi < 8; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
     uint4 af[4][2], b0[2][2], b1[2][2];
     for (int u = 0; u < nk; ++u) {
@@ -144,7 +158,7 @@ __global__ void __launch_bounds__(512, 2) gemm_nt_256_kernel(const a4r_gemm_t p,
 #pragma unroll
             for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
-                for (int ni = 0; ni < 2; ++ni) Mma<TI>::mma(af[mi][ks], b0[ni][ks], acc[mi][ni]);
+                for (int ni = 0; ni < 2; ++ni) Mma<TI>::mma(b0[ni][ks], af[mi][ks], acc[mi][ni]);
         // ---------------- phase 1: (rows 0-63, cols 32-63)
 #pragma unroll
         for (int ni = 0; ni < 2; ++ni)
@@ -157,7 +171,7 @@ __global__ void __launch_bounds__(512, 2) gemm_nt_256_kernel(const a4r_gemm_t p,
 #pragma unroll
             for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
-                for (int ni = 0; ni < 2; ++ni) Mma<TI>::mma(af[mi][ks], b1[ni][ks], acc[mi][2 + ni]);
+                for (int ni = 0; ni < 2; ++ni) Mma<TI>::mma(b1[ni][ks], af[mi][ks], acc[mi][2 + ni]);
         // ---------------- phase 2: (rows 64-127, cols 32-63)
 #pragma unroll
         for (int mi = 0; mi < 4; ++mi)
@@ -170,7 +184,7 @@ __global__ void __launch_bounds__(512, 2) gemm_nt_256_kernel(const a4r_gemm_t p,
 #pragma unroll
             for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
-                for (int ni = 0; ni < 2; ++ni) Mma<TI>::mma(af[mi][ks], b1[ni][ks], acc[4 + mi][2 + ni]);
+                for (int ni = 0; ni < 2; ++ni) Mma<TI>::mma(b1[ni][ks], af[mi][ks], acc[4 + mi][2 + ni]);
         // ---------------- phase 3: (rows 64-127, cols 0-31), operands already in registers
         A4R_WAIT_BARRIER(steady)
         A4R_ISSUE(U_BHI, u + 2, Bbase, offB_hi)
@@ -179,47 +193,77 @@ __global__ void __launch_bounds__(512, 2) gemm_nt_256_kernel(const a4r_gemm_t p,
 #pragma unroll
             for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
-                for (int ni = 0; ni < 2; ++ni) Mma<TI>::mma(af[mi][ks], b0[ni][ks], acc[4 + mi][ni]);
+                for (int ni = 0; ni < 2; ++ni) Mma<TI>::mma(b0[ni][ks], af[mi][ks], acc[4 + mi][ni]);
     }
+
+    // ---- epilogue straight from the accumulators.  The MFMA operands are swapped (B fragment first), so the tile is
+    // produced transposed: a lane's 4 registers of tile (mi, ni) are 4 CONSECUTIVE COLUMNS of one output row,
+    //     C[wave row mi*16 + (lane & 15)][wave col ni*16 + (lane >> 4)*4 + 0..3],
+    // i.e. 8 B (bf16) / 16 B (fp32) per lane and 32 B / 64 B runs per row -- no LDS round trip, no barriers, and the 32
+    // independent (mi, ni) groups give the memory system all the parallelism it needs (the LDS-staged form cost ~25 us per
+    // tile with one workgroup per CU).
+    // every LDS read of this tile completed before the last barrier: the ring is free, so the NEXT tile's first units
+    // are put in flight now and land while this tile's accumulators are being written out.
+    const int tm_done = tm, tn_done = tn;
+    vb += gridDim.x;
+    const bool more = vb < nt;
+    if (more) {
+        Lt = tile_of(vb);
+        tm = Lt / ntn;
+        tn = Lt % ntn;
+        Abase = reinterpret_cast<const char*>(Ap + (size_t)tm * 256 * lda);
+        Bbase = reinterpret_cast<const char*>(Bp + (size_t)tn * 256 * ldb);
+        A4R_PROLOGUE()
+    }
+    // Pair the lanes of 16-lane rows (l <-> l ^ 16) with v_permlane16_swap: lane (fr, kg) gives away the half it holds of
+    // the neighbouring tile and receives the missing half of its own, so that it ends up with 8 CONSECUTIVE columns
+    //   kg even: tile 2*pair,     columns (kg >> 1) * 8 .. + 7        kg odd: tile 2*pair + 1, same columns
+    // = one 16-byte (bf16) store per lane and 64-byte runs per row: half the store instructions of the 8-byte form,
+    // whose issue rate (not bandwidth) bounded the epilogue.
+    const size_t grow0 = (size_t)tm_done * 256 + wm * 128 + fr;
+    const int gcolp = tn_done * 256 + wn * 64 + (kg & 1) * 16 + (kg >> 1) * 8;      // + pair * 32
+    float bias8[2][8];
+#pragma unroll
+    for (int pr = 0; pr < 2; ++pr)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) bias8[pr][e] = epi.bias ? epi.bias[gcolp + pr * 32 + e] : 0.f;
+#define A4R_EPI_PAIR(mi_, pr_)                                                                                              \
+    {                                                                                                                       \
+        float v_[8];                                                                                                        \
+        _Pragma("unroll") for (int r_ = 0; r_ < 4; ++r_) {                                                                  \
+            const auto sw_ = __builtin_amdgcn_permlane16_swap(__float_as_uint(acc[mi_][2 * (pr_)][r_]),                     \
+                                                              __float_as_uint(acc[mi_][2 * (pr_) + 1][r_]), false, false);  \
+            v_[r_] = __uint_as_float(sw_[0]);                                                                               \
+            v_[4 + r_] = __uint_as_float(sw_[1]);                                                                           \
+        }                                                                                                                   \
+        epilogue8<TO>(v_, bias8[pr_], grow0 + (mi_) * 16, gcolp + (pr_) * 32, epi);                                         \
+    }
+#define A4R_EPI_ROW(mi_) A4R_EPI_PAIR(mi_, 0) A4R_EPI_PAIR(mi_, 1)
+    A4R_EPI_ROW(0) A4R_EPI_ROW(1) A4R_EPI_ROW(2) A4R_EPI_ROW(3) A4R_EPI_ROW(4) A4R_EPI_ROW(5) A4R_EPI_ROW(6) A4R_EPI_ROW(7)
+#undef A4R_EPI_ROW
+#undef A4R_EPI_PAIR
+    if (!more) break;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // stores of this tile + prologue loads of the next (vmcnt counts both)
+  }
+#undef A4R_PROLOGUE
 #undef A4R_ISSUE
 #undef A4R_WAIT_BARRIER
-
-    // ---- epilogue: two passes of 64 wave-rows through LDS (fp32 [8 waves][64][64] = 128 KiB)
-    const GemmEpi<TO> epi = make_epi<TO>(p, thr16, keep_scale);
-    float* Cw = reinterpret_cast<float*>(lds) + wave * 4096;
-#pragma unroll
-    for (int pass = 0; pass < 2; ++pass) {
-        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-        __syncthreads();                                    // every wave is done with the LDS contents
-#pragma unroll
-        for (int mi = 0; mi < 4; ++mi)
-#pragma unroll
-            for (int ni = 0; ni < 4; ++ni)
-#pragma unroll
-                for (int rr = 0; rr < 4; ++rr)
-                    Cw[(mi * 16 + kg * 4 + rr) * 64 + ni * 16 + fr] = acc[pass * 4 + mi][ni][rr];
-        __syncthreads();
-        const int row = tid >> 3, cg = tid & 7;
-#pragma unroll 1
-        for (int w = 0; w < 8; ++w) {
-            const float* src = reinterpret_cast<const float*>(lds) + w * 4096 + row * 64 + cg * 8;
-            const size_t grow = (size_t)tm * 256 + (w >> 2) * 128 + pass * 64 + row;
-            const int gcol = tn * 256 + (w & 3) * 64 + cg * 8;
-            float v[8], bias8[8];
-            const float4 lo = *reinterpret_cast<const float4*>(src);
-            const float4 hi = *reinterpret_cast<const float4*>(src + 4);
-            v[0] = lo.x; v[1] = lo.y; v[2] = lo.z; v[3] = lo.w; v[4] = hi.x; v[5] = hi.y; v[6] = hi.z; v[7] = hi.w;
-#pragma unroll
-            for (int e = 0; e < 8; ++e) bias8[e] = epi.bias ? epi.bias[gcol + e] : 0.f;
-            epilogue8<TO>(v, bias8, grow, gcol, epi);
-        }
-    }
 }
 
 template <typename TI, typename TO>
 int launch256(hipStream_t s, const a4r_gemm_t& g) {
     const int ntm = g.M / 256, ntn = g.N / 256;
-    hipLaunchKernelGGL((gemm_nt_256_kernel<TI, TO>), dim3(ntm * ntn), dim3(512), 0, s, g, ntm, ntn,
+    static int n_cu = 0;
+    if (n_cu == 0) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) n_cu = prop.multiProcessorCount;
+        if (n_cu <= 0) n_cu = 256;
+        n_cu &= ~7;                                        // multiple of 8: a workgroup stays on one XCD group
+        if (n_cu < 8) n_cu = 8;
+    }
+    const int grid = ntm * ntn < n_cu ? ntm * ntn : n_cu;
+    hipLaunchKernelGGL((gemm_nt_256_kernel<TI, TO>), dim3(grid), dim3(512), 0, s, g, ntm, ntn,
                        a4r_thr16(g.drop_p), a4r_keep_scale(g.drop_p));
     return a4r_launch_status();
 }

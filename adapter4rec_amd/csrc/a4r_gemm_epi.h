@@ -68,3 +68,63 @@ A4R_DEV void epilogue8(float (&v)[8], const float (&bias8)[8], size_t grow, int 
     if (e.thr16 && !e.drop_first) epi_dropout8(v, e0, e.drop_seed, e.drop_site, e.thr16, e.keep_scale);
     store_vec<TO, 8>(e.C + grow * e.ldc + gcol, v);
 }
+
+// ---- 4-column form (one lane's accumulator registers of a TRANSPOSED 16x16 MFMA tile: 4 consecutive columns of one row)
+template <typename T> A4R_DEV void load4(const T* p, float* o) {
+    if constexpr (sizeof(T) == 4) {
+        const float4 v = *reinterpret_cast<const float4*>(p);
+        o[0] = v.x; o[1] = v.y; o[2] = v.z; o[3] = v.w;
+    } else {
+        const uint2 v = *reinterpret_cast<const uint2*>(p);
+        o[0] = bf16_bits_to_f32(v.x & 0xffffu); o[1] = bf16_bits_to_f32(v.x >> 16);
+        o[2] = bf16_bits_to_f32(v.y & 0xffffu); o[3] = bf16_bits_to_f32(v.y >> 16);
+    }
+}
+template <typename T> A4R_DEV void store4(T* p, const float* o) {
+    if constexpr (sizeof(T) == 4) {
+        *reinterpret_cast<float4*>(p) = make_float4(o[0], o[1], o[2], o[3]);
+    } else {
+        *reinterpret_cast<uint2*>(p) = make_uint2(f32_to_bf16_bits(o[0]) | (f32_to_bf16_bits(o[1]) << 16),
+                                                  f32_to_bf16_bits(o[2]) | (f32_to_bf16_bits(o[3]) << 16));
+    }
+}
+
+template <typename TO>
+A4R_DEV void epilogue4(float (&v)[4], const float4& b4, size_t grow, int gcol, const GemmEpi<TO>& e) {
+    v[0] = v[0] * e.alpha + b4.x; v[1] = v[1] * e.alpha + b4.y; v[2] = v[2] * e.alpha + b4.z; v[3] = v[3] * e.alpha + b4.w;
+    if (e.C2) store4<TO>(e.C2 + grow * e.ldc2 + gcol, v);
+    if (e.act != A4R_ACT_NONE) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) v[i] = act_fwd(v[i], e.act);
+    }
+    if (e.dact != A4R_ACT_NONE) {
+        float pre[4];
+        load4<TO>(e.Pre + grow * e.ldpre + gcol, pre);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) v[i] *= act_bwd(pre[i], e.dact);
+    }
+    const uint64_t e0 = (uint64_t)grow * (uint64_t)e.N + (uint64_t)gcol;      // gcol % 4 == 0: one hash, four 16-bit lots
+    if (e.thr16 && e.drop_first) {
+        const uint64_t h = a4r_hash64(e.drop_seed, e.drop_site, e0 >> 2);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) v[i] = (((uint32_t)(h >> (16 * i)) & 0xffffu) >= e.thr16) ? v[i] * e.keep_scale : 0.f;
+    }
+    if (e.R1) {
+        float t[4];
+        load4<TO>(e.R1 + grow * e.ldr1 + gcol, t);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) v[i] += t[i];
+    }
+    if (e.R2) {
+        float t[4];
+        load4<TO>(e.R2 + grow * e.ldr2 + gcol, t);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) v[i] += t[i];
+    }
+    if (e.thr16 && !e.drop_first) {
+        const uint64_t h = a4r_hash64(e.drop_seed, e.drop_site, e0 >> 2);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) v[i] = (((uint32_t)(h >> (16 * i)) & 0xffffu) >= e.thr16) ? v[i] * e.keep_scale : 0.f;
+    }
+    store4<TO>(e.C + grow * e.ldc + gcol, v);
+}
