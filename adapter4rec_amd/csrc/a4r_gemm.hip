@@ -278,11 +278,11 @@ inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 
 
 }  // namespace
 
-int a4r_gemm_nt_256(hipStream_t s, const a4r_gemm_t& g);   // a4r_gemm256.hip
+int a4r_gemm_nt_256(hipStream_t s, const a4r_gemm_t& g, int sched);   // a4r_gemm256.hip
 
 extern "C" int a4r_gemm_variant(int v) {
     const int old = g_variant;
-    if (v >= 0 && v <= 2) g_variant = v;
+    if (v >= 0 && v <= 4) g_variant = v;
     return old;
 }
 
@@ -302,9 +302,9 @@ extern "C" int a4r_gemm_nt(void* stream, const a4r_gemm_t* gp) {
     if (g.dact != A4R_ACT_NONE && (!g.Pre || !aligned16(g.Pre) || (g.ldpre * osz) % 16 || g.ldpre < g.N)) return A4R_EINVAL;
     if (g.drop_p < 0.f || g.drop_p >= 1.f) return A4R_EINVAL;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-    if (g_variant == 2 && g.M % 256 == 0 && g.N % 256 == 0 && g.K * isz >= 256 &&
+    if (g_variant >= 2 && g.M % 256 == 0 && g.N % 256 == 0 && g.K * isz >= 256 &&
         (!g.bias || aligned16(g.bias)))
-        return a4r_gemm_nt_256(s, g);
+        return a4r_gemm_nt_256(s, g, g_variant - 2);
     if (g.in_dtype == A4R_BF16 && g.out_dtype == A4R_BF16) return launch_bn<bf16_t, bf16_t>(s, g);
     if (g.in_dtype == A4R_F32 && g.out_dtype == A4R_F32) return launch_bn<float, float>(s, g);
     if (g.in_dtype == A4R_BF16 && g.out_dtype == A4R_F32) return launch_bn<bf16_t, float>(s, g);

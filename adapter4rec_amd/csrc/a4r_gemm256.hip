@@ -39,7 +39,7 @@ A4R_DEV void glds16(const void* base, uint32_t voff, uint32_t lds_dst) {
         : "memory");
 }
 
-template <typename TI, typename TO>
+template <typename TI, typename TO, bool PH2, bool STAG>
 __global__ void __launch_bounds__(512, 2) gemm_nt_256_kernel(const a4r_gemm_t p, int ntm, int ntn, uint32_t thr16, float keep_scale) {
     constexpr int ROWB = 128;
     constexpr int KT = ROWB / (int)sizeof(TI);
@@ -91,11 +91,28 @@ __global__ void __launch_bounds__(512, 2) gemm_nt_256_kernel(const a4r_gemm_t p,
         glds16(src_, off_[0], dst_);                                                                                 \
         glds16(src_, off_[1], dst_ + 1024u);                                                                         \
     }
-#define A4R_WAIT_BARRIER(steady_)                                                                                    \
-    if (steady_) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");                                         \
+#define A4R_WAIT_BARRIER(steady_) A4R_WAIT_BARRIER_N(steady_, 8)
+#define A4R_WAIT_BARRIER_N(steady_, n_)                                                                              \
+    if (steady_) asm volatile("s_waitcnt vmcnt(" #n_ ") lgkmcnt(0)" ::: "memory");                                   \
     else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");                                                 \
     __builtin_amdgcn_s_barrier();                                                                                    \
     asm volatile("" ::: "memory");
+
+    // A phase after its barrier = {issue one unit's LDS-DMA} + {16 MFMAs}.  The two waves that share a SIMD (w and w + 4)
+    // run them in OPPOSITE order (STAG): while one wave spends ~200 cycles issuing DMA the other owns the matrix pipe,
+    // then they swap -- lockstep partners otherwise issue DMA together and fight for the pipe together.
+    const bool mfma_first = STAG && wave >= 4;
+#define A4R_MFMA16(bx_, m0_, n0_)                                                                     \
+    _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                                  \
+        _Pragma("unroll") for (int mi = 0; mi < 4; ++mi)                                              \
+            _Pragma("unroll") for (int ni = 0; ni < 2; ++ni)                                          \
+                Mma<TI>::mma(bx_[ni][ks], af[mi][ks], acc[(m0_) + mi][(n0_) + ni]);
+#define A4R_PHASE_BODY(issue_, bx_, m0_, n0_)                                                         \
+    if (!mfma_first) { issue_ }                                                                       \
+    __builtin_amdgcn_sched_barrier(0);                                                                \
+    A4R_MFMA16(bx_, m0_, n0_)                                                                         \
+    __builtin_amdgcn_sched_barrier(0);                                                                \
+    if (mfma_first) { issue_ }
 
     f32x4_t acc[8][4];
 
@@ -127,7 +144,8 @@ __global__ void __launch_bounds__(512, 2) gemm_nt_256_kernel(const a4r_gemm_t p,
     A4R_ISSUE(U_BLO, 1, Bbase, offB_lo)         \
     A4R_ISSUE(U_BHI, 1, Bbase, offB_hi)
     A4R_PROLOGUE()
-    asm volatile("s_waitcnt vmcnt(10)" ::: "memory");     // A_lo(0), B_lo(0) of the first tile have landed
+    if constexpr (PH2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");    // A_lo(0), B_lo(0), B_hi(0) of the first tile have landed
+    else asm volatile("s_waitcnt vmcnt(10)" ::: "memory");                // A_lo(0), B_lo(0)
     const GemmEpi<TO> epi = make_epi<TO>(p, thr16, keep_scale);
 
   for (;;) {                                              // ---- tiles of this workgroup
@@ -139,6 +157,56 @@ __global__ void __launch_bounds__(512, 2) gemm_nt_256_kernel(const a4r_gemm_t p,
         for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
     uint4 af[4][2], b0[2][2], b1[2][2];
+    if constexpr (PH2) {
+      // Two phases of 32 MFMAs per K-tile (half the barriers of the 4-phase form):
+      //   phase A: read A_lo, B_lo, B_hi | wait | barrier | issue A_hi(u+1)                      | quadrants (0,0), (0,1)
+      //   phase B: read A_hi             | wait | barrier | issue A_lo, B_lo, B_hi of tile u+2   | quadrants (1,1), (1,0)
+      // stream order ... A_hi(u) | A_lo B_lo B_hi (u+1) | A_hi(u+1) | ...: phase A needs A_hi(u) => the 3 newest units may
+      // be in flight (vmcnt(6)); phase B needs the three units of tile u+1 => only A_hi(u+1) may be (vmcnt(2)).
+      for (int u = 0; u < nk; ++u) {
+        const char* buf = lds + (u & 1) * 4 * UNIT_BYTES;
+        const bool steady = (u + 1 < nk);
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) af[mi][ks] = *reinterpret_cast<const uint4*>(buf + U_ALO * UNIT_BYTES + a_off[mi][ks]);
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                b0[ni][ks] = *reinterpret_cast<const uint4*>(buf + U_BLO * UNIT_BYTES + b_off[ni][ks]);
+                b1[ni][ks] = *reinterpret_cast<const uint4*>(buf + U_BHI * UNIT_BYTES + b_off[ni][ks]);
+            }
+        A4R_WAIT_BARRIER_N(steady, 6)
+        A4R_ISSUE(U_AHI, u + 1, Abase, offA_hi)
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < 2; ++ni) {
+                    Mma<TI>::mma(b0[ni][ks], af[mi][ks], acc[mi][ni]);
+                    Mma<TI>::mma(b1[ni][ks], af[mi][ks], acc[mi][2 + ni]);
+                }
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) af[mi][ks] = *reinterpret_cast<const uint4*>(buf + U_AHI * UNIT_BYTES + a_off[mi][ks]);
+        A4R_WAIT_BARRIER_N(steady, 2)
+        A4R_ISSUE(U_ALO, u + 2, Abase, offA_lo)
+        A4R_ISSUE(U_BLO, u + 2, Bbase, offB_lo)
+        A4R_ISSUE(U_BHI, u + 2, Bbase, offB_hi)
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < 2; ++ni) {
+                    Mma<TI>::mma(b1[ni][ks], af[mi][ks], acc[4 + mi][2 + ni]);
+                    Mma<TI>::mma(b0[ni][ks], af[mi][ks], acc[4 + mi][ni]);
+                }
+      }
+    } else
     for (int u = 0; u < nk; ++u) {
         const char* buf = lds + (u & 1) * 4 * UNIT_BYTES;
         const bool steady = (u + 2 < nk);
@@ -152,48 +220,24 @@ __global__ void __launch_bounds__(512, 2) gemm_nt_256_kernel(const a4r_gemm_t p,
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) b0[ni][ks] = *reinterpret_cast<const uint4*>(buf + U_BLO * UNIT_BYTES + b_off[ni][ks]);
         A4R_WAIT_BARRIER(steady)
-        A4R_ISSUE(U_AHI, u + 1, Abase, offA_hi)
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-            for (int mi = 0; mi < 4; ++mi)
-#pragma unroll
-                for (int ni = 0; ni < 2; ++ni) Mma<TI>::mma(b0[ni][ks], af[mi][ks], acc[mi][ni]);
+        A4R_PHASE_BODY(A4R_ISSUE(U_AHI, u + 1, Abase, offA_hi), b0, 0, 0)
         // ---------------- phase 1: (rows 0-63, cols 32-63)
 #pragma unroll
         for (int ni = 0; ni < 2; ++ni)
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) b1[ni][ks] = *reinterpret_cast<const uint4*>(buf + U_BHI * UNIT_BYTES + b_off[ni][ks]);
         A4R_WAIT_BARRIER(steady)
-        A4R_ISSUE(U_ALO, u + 2, Abase, offA_lo)
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-            for (int mi = 0; mi < 4; ++mi)
-#pragma unroll
-                for (int ni = 0; ni < 2; ++ni) Mma<TI>::mma(b1[ni][ks], af[mi][ks], acc[mi][2 + ni]);
+        A4R_PHASE_BODY(A4R_ISSUE(U_ALO, u + 2, Abase, offA_lo), b1, 0, 2)
         // ---------------- phase 2: (rows 64-127, cols 32-63)
 #pragma unroll
         for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) af[mi][ks] = *reinterpret_cast<const uint4*>(buf + U_AHI * UNIT_BYTES + a_off[mi][ks]);
         A4R_WAIT_BARRIER(steady)
-        A4R_ISSUE(U_BLO, u + 2, Bbase, offB_lo)
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-            for (int mi = 0; mi < 4; ++mi)
-#pragma unroll
-                for (int ni = 0; ni < 2; ++ni) Mma<TI>::mma(b1[ni][ks], af[mi][ks], acc[4 + mi][2 + ni]);
+        A4R_PHASE_BODY(A4R_ISSUE(U_BLO, u + 2, Bbase, offB_lo), b1, 4, 2)
         // ---------------- phase 3: (rows 64-127, cols 0-31), operands already in registers
         A4R_WAIT_BARRIER(steady)
-        A4R_ISSUE(U_BHI, u + 2, Bbase, offB_hi)
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-            for (int mi = 0; mi < 4; ++mi)
-#pragma unroll
-                for (int ni = 0; ni < 2; ++ni) Mma<TI>::mma(b0[ni][ks], af[mi][ks], acc[4 + mi][ni]);
+        A4R_PHASE_BODY(A4R_ISSUE(U_BHI, u + 2, Bbase, offB_hi), b0, 4, 0)
     }
 
     // ---- epilogue straight from the accumulators.  The MFMA operands are swapped (B fragment first), so the tile is
@@ -248,9 +292,12 @@ __global__ void __launch_bounds__(512, 2) gemm_nt_256_kernel(const a4r_gemm_t p,
 #undef A4R_PROLOGUE
 #undef A4R_ISSUE
 #undef A4R_WAIT_BARRIER
+#undef A4R_WAIT_BARRIER_N
+#undef A4R_PHASE_BODY
+#undef A4R_MFMA16
 }
 
-template <typename TI, typename TO>
+template <typename TI, typename TO, bool PH2, bool STAG>
 int launch256(hipStream_t s, const a4r_gemm_t& g) {
     const int ntm = g.M / 256, ntn = g.N / 256;
     static int n_cu = 0;
@@ -263,17 +310,25 @@ int launch256(hipStream_t s, const a4r_gemm_t& g) {
         if (n_cu < 8) n_cu = 8;
     }
     const int grid = ntm * ntn < n_cu ? ntm * ntn : n_cu;
-    hipLaunchKernelGGL((gemm_nt_256_kernel<TI, TO>), dim3(grid), dim3(512), 0, s, g, ntm, ntn,
+    hipLaunchKernelGGL((gemm_nt_256_kernel<TI, TO, PH2, STAG>), dim3(grid), dim3(512), 0, s, g, ntm, ntn,
                        a4r_thr16(g.drop_p), a4r_keep_scale(g.drop_p));
     return a4r_launch_status();
 }
 
+template <bool PH2, bool STAG>
+int dispatch256(hipStream_t s, const a4r_gemm_t& g) {
+    if (g.in_dtype == A4R_BF16 && g.out_dtype == A4R_BF16) return launch256<bf16_t, bf16_t, PH2, STAG>(s, g);
+    if (g.in_dtype == A4R_F32 && g.out_dtype == A4R_F32) return launch256<float, float, PH2, STAG>(s, g);
+    if (g.in_dtype == A4R_BF16 && g.out_dtype == A4R_F32) return launch256<bf16_t, float, PH2, STAG>(s, g);
+    return launch256<float, bf16_t, PH2, STAG>(s, g);
+}
+
 }  // namespace
 
-// called by a4r_gemm_nt (a4r_gemm.hip) after argument validation
-int a4r_gemm_nt_256(hipStream_t s, const a4r_gemm_t& g) {
-    if (g.in_dtype == A4R_BF16 && g.out_dtype == A4R_BF16) return launch256<bf16_t, bf16_t>(s, g);
-    if (g.in_dtype == A4R_F32 && g.out_dtype == A4R_F32) return launch256<float, float>(s, g);
-    if (g.in_dtype == A4R_BF16 && g.out_dtype == A4R_F32) return launch256<bf16_t, float>(s, g);
-    return launch256<float, bf16_t>(s, g);
+// called by a4r_gemm_nt (a4r_gemm.hip) after argument validation.  sched: 0 = 4 phases per K-tile, lockstep;
+// 1 = 2 phases per K-tile; 2 = 4 phases, SIMD partners staggered (DMA-first vs MFMA-first)
+int a4r_gemm_nt_256(hipStream_t s, const a4r_gemm_t& g, int sched) {
+    if (sched == 1) return dispatch256<true, false>(s, g);
+    if (sched == 2) return dispatch256<false, true>(s, g);
+    return dispatch256<false, false>(s, g);
 }

@@ -87,7 +87,9 @@ class GemmProbe:
             e0.record()
             self.real(A, B, Cout, *a, **k)
             e1.record()
-            self.rec.append((str(A.dtype), str(Cout.dtype), M, B.shape[0], B.shape[1], e0, e1))
+            N, K = B.shape[0], B.shape[1]
+            big = M % 256 == 0 and N % 256 == 0 and K * A.element_size() >= 256      # a4r_gemm_nt's dispatch rule
+            self.rec.append((str(A.dtype), str(Cout.dtype), 256 if big else (128 if N % 128 == 0 else 64), M, N, K, e0, e1))
         self.L.gemm_nt = wrapped
         return self
 
@@ -97,8 +99,8 @@ class GemmProbe:
     def summary(self):
         torch.cuda.synchronize()
         agg = {}
-        for da, dc, M, N, K, e0, e1 in self.rec:
-            key = (da, dc, 128 if N % 128 == 0 else 64)
+        for da, dc, tile, M, N, K, e0, e1 in self.rec:
+            key = (da, dc, tile)
             f, t, n = agg.get(key, (0.0, 0.0, 0))
             agg[key] = (f + 2.0 * M * N * K, t + e0.elapsed_time(e1) * 1e-3, n + 1)
         return agg
@@ -216,14 +218,14 @@ def main():
                 step(a.warmup + a.steps + i)
             agg = probe.summary()
         tname = 'torch.bfloat16' if a.dtype == 'bf16' else 'torch.float32'
-        key = (tname, tname, 128)
+        key = max((k for k in agg if k[0] == tname and k[1] == tname), key=lambda k: agg[k][1])     # most GPU time
         f, t, n = agg[key]
         ach = f / t / 1e12
         total_f = sum(v[0] for v in agg.values())
         total_t = sum(v[1] for v in agg.values())
         peak = MFMA_BF16_PEAK_TFLOPS if a.dtype == 'bf16' else 157.3
         roof = dict(bound='mfma', achieved=round(ach, 2), peak=peak, unit='TFLOP/s', frac=round(ach / peak, 4), traffic=None,
-                    kernel=f'gemm_nt_kernel<{a.dtype},{a.dtype},128>', launches_per_step=n // 2,
+                    kernel=(f'gemm_nt_256_kernel<{a.dtype},{a.dtype}>' if key[2] == 256 else f'gemm_nt_kernel<{a.dtype},{a.dtype},{key[2]}>'), launches_per_step=n // 2,
                     avg_launch_us=round(t / n * 1e6, 2), flop_per_launch=f / n,
                     all_gemm_tflops=round(total_f / total_t / 1e12, 2), gemm_time_share_of_step=round(total_t / 2 / (dt / a.steps), 3))
 

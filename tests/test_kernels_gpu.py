@@ -53,7 +53,7 @@ def act_ref(x, act):
 
 
 # ------------------------------------------------------------------ GEMM NT
-@pytest.fixture(params=[2, 1, 0], ids=['tile256', 'glds', 'regstage'])
+@pytest.fixture(params=[4, 3, 2, 1, 0], ids=['tile256stag', 'tile256x2ph', 'tile256', 'glds', 'regstage'])
 def gemm_variant(request):
     from adapter4rec_amd import _lib as L
     old = L.gemm_variant(request.param)
@@ -91,7 +91,7 @@ def test_gemm_identity_asymmetric(gemm_variant):
 def test_gemm_epilogue_full(dt, gemm_variant):
     from adapter4rec_amd import _lib as L
     t = DT[dt]
-    M, N, K = (256, 256, 192) if gemm_variant == 2 else (256, 192, 128)
+    M, N, K = (256, 256, 192) if gemm_variant >= 2 else (256, 192, 128)
     A, B = rnd(M, K, dtype=t, seed=3), rnd(N, K, dtype=t, scale=0.1, seed=4)
     bias = rnd(N, seed=5)
     R1, R2, Pre = rnd(M, N, dtype=t, seed=6), rnd(M, N, dtype=t, seed=7), rnd(M, N, dtype=t, seed=8)
