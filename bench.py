@@ -119,7 +119,7 @@ def host_threads():
     return max(1, min(n, 32))
 
 
-def cpu_baseline(sample_users=2):
+def cpu_baseline(sample_users=16):
     """The CPU oracle on a bounded sample: one training step (fwd + bwd + Adam), BERT-base + Houlsby, fp32."""
     from oracle import ref_cpu as R
     from adapter4rec_amd.inject import freeze_all, inject_adapters
