@@ -87,6 +87,29 @@ class _Adapter:
         self.s_bd = None if self.d == self.dp else torch.zeros(self.dp, dtype=torch.float32, device=dev)
 
 
+class _Lora:
+    """LoRA on one projection (q or v) of a fused qkv weight: W_eff = W + B A / r is re-merged into the packed qkv operand
+    every step (so forward and dgrad cost nothing extra); the low-rank gradients come from four skinny products in backward:
+    t = x A^T, dt = (dq B) s, dB = dq^T t s, dA = dt^T x."""
+
+    def __init__(self, mod, width, eng, dt, slot):
+        self.mod, self.slot, self.width = mod, slot, width
+        self.r, self.rp, self.scaling = mod.r, pad_to(mod.r, 64), float(mod.scaling)
+        dev = eng.dev
+        self.A = torch.zeros(self.rp, width, dtype=dt, device=dev)        # lora_A [r, in]        (NT operand of t = x A^T)
+        self.BT = torch.zeros(self.rp, width, dtype=dt, device=dev)       # lora_B^T [r, out]     (NT operand of dt = dq B)
+        eng.add_pack(mod.lora_A, self.A, False)
+        eng.add_pack(mod.lora_B, self.BT, True)
+        self.g_A, self.g_B = eng.grad_view(mod.lora_A), eng.grad_view(mod.lora_B)
+        self.g_bias = eng.grad_view(mod.bias) if mod.bias is not None else None
+        self.s_A = torch.zeros(self.rp, width, dtype=torch.float32, device=dev)
+        self.s_B = torch.zeros(width, self.rp, dtype=torch.float32, device=dev)
+
+    def merged(self):
+        m = self.mod
+        return m.weight.detach() + (m.lora_B.detach() @ m.lora_A.detach()) * self.scaling
+
+
 class _Block:
     """One post-LN transformer block (BERT layer or SASRec block) with optional adapters."""
     pass
@@ -244,6 +267,14 @@ class TransRecEngine:
         """Refresh the kernel-side copies of the trainable matrices (call after every optimiser step)."""
         for tab, n, mx, c in self._tabs:
             L.pack_matrices(self.flat_p, tab, n, mx, c)
+        for blk in self.bert_blocks + self.sas_blocks:        # LoRA: re-merge W + B A / r into the packed qkv operand
+            for lo in blk.lora:
+                H, sl = blk.H, lo.slot
+                w = lo.merged()
+                blk.wqkv[sl * H:(sl + 1) * H].copy_(w)
+                blk.wqkvT[:, sl * H:(sl + 1) * H].copy_(w.t())
+                if lo.mod.bias is not None:
+                    blk.bqkv[sl * H:(sl + 1) * H].copy_(lo.mod.bias.detach())
         self._virt_graph = None
         if self._virtual:
             effs = []
@@ -281,8 +312,6 @@ class TransRecEngine:
         if hasattr(mod, 'self_output'):
             so = mod.self_output
             placement = getattr(mod, 'placement', 'serial')
-            if placement == 'parallel':
-                raise NotImplementedError('parallel Houlsby (--is_serial None) is a SURVEY.md 8(f) "next" row')
             ln_new = _LN(mod.LN, self) if hasattr(mod, 'LN') else None
             return so.dense, so.LayerNorm, self._adapter_of(mod, 'adapter', width, dt), placement, ln_new
         return mod.dense, mod.LayerNorm, None, None, None
@@ -299,6 +328,7 @@ class TransRecEngine:
         self.emb_ln = _LN(emb.LayerNorm, self)
         if emb.LayerNorm.weight.requires_grad:
             raise NotImplementedError('training the embedding LayerNorm (--finetune_layernorm) is not wired yet')
+        self.cls_only = bool(getattr(self.args, 'cls_only_last', True))
         self.roberta = g['model_type'] == 'roberta'
         self.pad_id = int(g['pad_token_id'])
         self.p_hidden = float(g['hidden_dropout_prob'])
@@ -307,9 +337,12 @@ class TransRecEngine:
         for i, layer in enumerate(bert.encoder.layer):
             b = _Block()
             att = layer.attention.self
-            for lin in (att.query, att.key, att.value):
-                if type(lin).__name__ != 'Linear':
-                    raise NotImplementedError('LoRA q/v (loralib) is not wired into the native path yet')
+            b.lora = []
+            for slot, lin in enumerate((att.query, att.key, att.value)):
+                if type(lin).__name__ == 'LoRALinear':
+                    b.lora.append(_Lora(lin, H, self, self.T, slot))
+                elif type(lin).__name__ != 'Linear':
+                    raise NotImplementedError(f'projection module {type(lin).__name__}')
             b.H, b.F, b.nh, b.dh, b.S = H, self.F, nh, H // nh, self.S
             b.causal, b.mask_neg, b.scale = False, FMIN, 1.0 / math.sqrt(H // nh)
             b.ffn_act = L.ACT_GELU
@@ -327,6 +360,9 @@ class TransRecEngine:
             b.need_dx = i > 0
             b.T = self.T
             self.bert_blocks.append(b)
+        lastb = self.bert_blocks[-1]
+        if lastb.pl1 == 'parallel' or lastb.pl2 == 'parallel':
+            self.cls_only = False                  # the parallel form needs the sub-layer inputs per token row
 
     def _build_head(self):
         fc = self.model.bert_encoder.text_encoders['title'].fc
@@ -349,24 +385,25 @@ class TransRecEngine:
         for j, blk in enumerate(te.transformer_blocks):
             tb = blk.transformer_block if hasattr(blk, 'transformer_block') else blk
             mha, ff = tb.multi_head_attention, tb.feed_forward
-            for lin in (mha.w_Q, mha.w_K, mha.w_V):
-                if type(lin).__name__ != 'Linear':
-                    raise NotImplementedError('LoRA w_Q/w_V (loralib) is not wired into the native path yet')
             b = _Block()
+            b.lora = []
+            for slot, lin in enumerate((mha.w_Q, mha.w_K, mha.w_V)):
+                if type(lin).__name__ == 'LoRALinear':
+                    b.lora.append(_Lora(lin, E, self, f32, slot))
+                elif type(lin).__name__ != 'Linear':
+                    raise NotImplementedError(f'projection module {type(lin).__name__}')
             b.H, b.F, b.nh, b.dh, b.S = E, ff.w_1.out_features, nh, E // nh, self.Lseq - 1
             b.causal, b.mask_neg, b.scale = True, -1e9, 1.0 / math.sqrt(E // nh)
             b.ffn_act = L.ACT_RELU
             b.p_hidden, b.p_attn, b.site = self.p_sas, self.p_sas, 4096 + 16 * j
             b.wqkv = self._w(torch.cat([mha.w_Q.weight, mha.w_K.weight, mha.w_V.weight], 0), f32)
             b.wqkvT = b.wqkv.t().contiguous()
-            b.bqkv = None
+            b.bqkv = torch.zeros(3 * E, dtype=f32, device=self.dev) if b.lora else None       # lora.Linear carries a bias
             b.wo, b.woT, b.bo = self._w(mha.fc.weight, f32), self._wT(mha.fc.weight, f32), None
             b.wi, b.wiT, b.bi = self._w(ff.w_1.weight, f32), self._wT(ff.w_1.weight, f32), self._f32(ff.w_1.bias)
             b.wo2, b.wo2T, b.bo2 = self._w(ff.w_2.weight, f32), self._wT(ff.w_2.weight, f32), self._f32(ff.w_2.bias)
             b.ln1, b.ln2 = _LN(mha.layer_norm, self), _LN(ff.layer_norm, self)
             placement = getattr(blk, 'placement', None) if blk is not tb else None
-            if placement == 'parallel':
-                raise NotImplementedError('parallel Houlsby (--is_serial None) is a SURVEY.md 8(f) "next" row')
             b.ad1 = b.ad2 = b.lnn1 = b.lnn2 = None
             b.pl1 = b.pl2 = None
             if blk is not tb:
@@ -375,8 +412,8 @@ class TransRecEngine:
                 else:
                     b.ad1 = self._adapter_of(blk, 'adapter1', E, f32)
                     b.ad2 = self._adapter_of(blk, 'adapter2', E, f32)
-                    b.pl1 = 'serial' if b.ad1 else None
-                    b.pl2 = 'serial' if b.ad2 else None
+                    b.pl1 = (placement or 'serial') if b.ad1 else None
+                    b.pl2 = (placement or 'serial') if b.ad2 else None
             b.need_dx = True
             b.T = f32
             self.sas_blocks.append(b)
@@ -390,12 +427,19 @@ class TransRecEngine:
             self._bufs[key] = t
         return t[:rows]
 
-    def _block_bufs(self, tag, blk, M, shared):
-        """Activation buffers of one block: `shared` => transient set reused by every block (inference)."""
+    def _block_bufs(self, tag, blk, M, shared, Mc=None):
+        """Activation buffers of one block: `shared` => transient set reused by every block (inference).
+        Mc: row count of everything AFTER attention when only the CLS rows are carried on (last encoder layer)."""
         pre = tag if not shared else tag.split('.')[0] + '.shared'
         T, H, F = blk.T, blk.H, blk.F
         d = {}
         d['qkv'] = self._buf(pre + '.qkv', M, 3 * H, T)
+        if Mc is not None:
+            pre, M = pre + '.cls', Mc
+        if (blk.lora or blk.pl1 == 'parallel') and not shared:
+            d['xin'] = self._buf(pre + '.xin', d['qkv'].shape[0], H, T)
+        if blk.pl2 == 'parallel' and not shared:
+            d['x1s'] = self._buf(pre + '.x1s', M, H, T)
         d['h1'] = self._buf(pre + '.h1', M, H, T)
         d['v1'] = self._buf(pre + '.v1', M, H, T)
         d['st1'] = self._buf(pre + '.st1', M, 2, torch.float32)
@@ -430,6 +474,12 @@ class TransRecEngine:
             L.gemm_nt(z, ad.wu, v, bias=ad.bu, R1=va, M=M)                   # adapter(t) + h + input
             L.ln_fwd(v, lnn.gamma, lnn.beta, lnn.eps, out, st, M=M)
             return
+        if pl == 'parallel':          # model.py:265-270 / :474-520: LN(adapter(input) + dense_out + input), adapter has its inner residual
+            L.gemm_nt(dense_in, w, h, bias=bias, R1=resid, drop_p=p_drop, drop_site=site, drop_seed=seed, drop_first=True, M=M)   # h + input
+            L.gemm_nt(resid, ad.wd, z, bias=ad.bd, C2=zp, act=ad.act, M=M)
+            L.gemm_nt(z, ad.wu, v, bias=ad.bu, R1=h, R2=resid, M=M)          # up + (h + input) + input
+            L.ln_fwd(v, ln.gamma, ln.beta, ln.eps, out, st, M=M)
+            return
         L.gemm_nt(dense_in, w, h, bias=bias, drop_p=p_drop, drop_site=site, drop_seed=seed, M=M)
         L.gemm_nt(h, ad.wd, z, bias=ad.bd, C2=zp, act=ad.act, M=M)
         if ad.kind == 'compacter':    # no inner residual (modules.py:248-252)
@@ -438,15 +488,25 @@ class TransRecEngine:
             L.gemm_nt(z, ad.wu, v, bias=ad.bu, R1=h, R2=resid, M=M)
         L.ln_fwd(v, ln.gamma, ln.beta, ln.eps, out, st, M=M)
 
-    def _block_forward(self, blk, x, key_mask, n_items, M, bufs, train, seed, x_out):
+    def _block_forward(self, blk, x, key_mask, n_items, M, bufs, train, seed, x_out, cls_rows=None):
+        """cls_rows = Ip: after attention only row 0 of every item (the CLS token, all the item head reads,
+        model/encoders.py:55) is carried through attention-output, FFN and adapters: x_out is then [Ip, H]."""
         T, H = blk.T, blk.H
         pa = blk.p_attn if train else 0.0
         ph = blk.p_hidden if train else 0.0
         L.gemm_nt(x, blk.wqkv, bufs['qkv'], bias=blk.bqkv, M=M)
+        if 'xin' in bufs:
+            bufs['xin'].copy_(x)                     # LoRA backward needs the block input (t = x A^T, dA = dt^T x)
         ctx = self._buf('ctx', M, H, T)
         L.attn_fwd(bufs['qkv'], ctx, key_mask, n_items, blk.S, blk.nh, blk.dh, 0, H, 2 * H, blk.causal, blk.scale, blk.mask_neg,
                    drop_p=pa, drop_site=blk.site, drop_seed=seed)
+        if cls_rows is not None:
+            ctx_c, x_c = self._buf('ctx_c', cls_rows, H, T), self._buf('x_c', cls_rows, H, T)
+            L.gather_rows(ctx, ctx_c, n_items, blk.S)
+            L.gather_rows(x, x_c, n_items, blk.S)
+            ctx, x, M = ctx_c, x_c, cls_rows
         x1 = self._buf('x1', M, H, T)
+        x1 = bufs['x1s'] if 'x1s' in bufs else x1
         self._sub_forward(blk, '1', ctx, blk.wo, blk.bo, x, blk.ln1, blk.ad1, blk.pl1, blk.lnn1, bufs, M, ph, blk.site + 1, seed, x1)
         u = self._buf('u', M, blk.F, T)
         L.gemm_nt(x1, blk.wi, u, bias=blk.bi, C2=bufs['upre'], act=blk.ffn_act, M=M)
@@ -487,12 +547,38 @@ class TransRecEngine:
         h = bufs['h' + which]
         L.ln_bwd(dy, v, st, ln.gamma, dv, M=M, dgamma=gg(ln.g_gamma), dbeta=gg(ln.g_beta), dbias=gg(ad.g_bu))
         L.gemm_nt(dv, ad.wuT, dzp, Pre=zp, dact=ad.act, M=M)
+        if pl == 'parallel':
+            sub_in = bufs['xin'] if which == '1' else bufs['x1s']
+            dres = self._buf('dres' + which, M, H, T)
+            L.gemm_nt(dzp, ad.wdT, dres, R1=dv, R2=dv, M=M)            # adapter path + its inner residual + the outer residual
+            self._adapter_wgrads(ad, dv, z, dzp, sub_in, M)
+            if p_drop > 0:
+                L.dropout_apply(dv, dh, p_drop, site, seed, M=M)
+                return dh, dres
+            return dv, dres
         if ad.kind == 'compacter':
             L.gemm_nt(dzp, ad.wdT, dh, drop_p=p_drop, drop_site=site, drop_seed=seed, M=M)
         else:
             L.gemm_nt(dzp, ad.wdT, dh, R1=dv, drop_p=p_drop, drop_site=site, drop_seed=seed, M=M)
         self._adapter_wgrads(ad, dv, z, dzp, h, M)
         return dh, dv
+
+    def _lora_backward(self, blk, lo, dqkv, x, M):
+        H, T = blk.H, blk.T
+        dq = dqkv[:, lo.slot * H:(lo.slot + 1) * H]
+        t = self._buf('lora_t', M, lo.rp, T)
+        dt = self._buf('lora_dt', M, lo.rp, T)
+        L.gemm_nt(x, lo.A, t, M=M)                               # t  = x A^T
+        L.gemm_nt(dq, lo.BT, dt, alpha=lo.scaling, M=M)          # dt = (dq B) s
+        lo.s_A.zero_()
+        lo.s_B.zero_()
+        L.gemm_tn(dq, t, lo.s_B, M=M)                            # dB = dq^T t s
+        L.gemm_tn(dt, x, lo.s_A, M=M)                            # dA = dt^T x
+        if lo.g_B is not None:
+            lo.g_B().add_(lo.s_B[:, :lo.r], alpha=lo.scaling)
+            lo.g_A().add_(lo.s_A[:lo.r])
+        if lo.g_bias is not None:
+            L.colsum(dq, lo.g_bias(), M=M)
 
     def _adapter_wgrads(self, ad, dv, z, dzp, down_in, M):
         """dW_up = dv^T z, dW_down = dzp^T down_in, db_down = colsum(dzp)  (db_up comes from ln_bwd's dbias)."""
@@ -517,24 +603,40 @@ class TransRecEngine:
                 L.colsum(dzp, ad.s_bd, M=M)
                 ad.g_bd().add_(ad.s_bd[:ad.d])
 
-    def _block_backward(self, blk, dx_out, key_mask, n_items, M, bufs, train, seed, dx_in):
+    def _block_backward(self, blk, dx_out, key_mask, n_items, M, bufs, train, seed, dx_in, cls_rows=None):
         T, H, F = blk.T, blk.H, blk.F
         pa = blk.p_attn if train else 0.0
         ph = blk.p_hidden if train else 0.0
+        M_full = M
+        if cls_rows is not None:
+            M = cls_rows
         dh2, dres2 = self._sub_backward(blk, '2', dx_out, blk.ln2, blk.ad2, blk.pl2, blk.lnn2, bufs, M, ph, blk.site + 2, seed)
         du = self._buf('du', M, F, T)
         L.gemm_nt(dh2, blk.wo2T, du, Pre=bufs['upre'], dact=blk.ffn_act, M=M)
         dx1 = self._buf('dx1', M, H, T)
         L.gemm_nt(du, blk.wiT, dx1, R1=dres2, M=M)
         dh1, dres1 = self._sub_backward(blk, '1', dx1, blk.ln1, blk.ad1, blk.pl1, blk.lnn1, bufs, M, ph, blk.site + 1, seed)
-        if dx_in is None:       # first encoder layer: nothing trainable sits below its attention
+        if dx_in is None and not blk.lora:      # first encoder layer: nothing trainable sits below its attention
             return
-        dctx = self._buf('dctx', M, H, T)
+        dctx = self._buf('dctx_c' if cls_rows is not None else 'dctx', M, H, T)
         L.gemm_nt(dh1, blk.woT, dctx, M=M)
+        if cls_rows is not None:                   # back to token rows: gradients live on the CLS rows only
+            M = M_full
+            full = self._buf('dctx', M, H, T)
+            full.zero_()
+            L.scatter_rows(dctx, full, n_items, blk.S)
+            dctx = full
+            rfull = self._buf('dres_full', M, H, T)
+            rfull.zero_()
+            L.scatter_rows(dres1, rfull, n_items, blk.S)
+            dres1 = rfull
         dqkv = self._buf('dqkv', M, 3 * H, T)
         L.attn_bwd(bufs['qkv'], dctx, dqkv, key_mask, n_items, blk.S, blk.nh, blk.dh, 0, H, 2 * H, blk.causal, blk.scale, blk.mask_neg,
                    drop_p=pa, drop_site=blk.site, drop_seed=seed)
-        L.gemm_nt(dqkv, blk.wqkvT, dx_in, R1=dres1, M=M)
+        for lo in blk.lora:
+            self._lora_backward(blk, lo, dqkv, bufs['xin'], M)
+        if dx_in is not None:
+            L.gemm_nt(dqkv, blk.wqkvT, dx_in, R1=dres1, M=M)
 
     # ------------------------------------------------------------------ item tower / user tower
     def _encode(self, news, n_items, train, seed, saved):
@@ -548,13 +650,19 @@ class TransRecEngine:
                    x, n_items, S, roberta=self.roberta, pad_id=self.pad_id,
                    drop_p=self.p_hidden if train else 0.0, drop_site=999, drop_seed=seed)
         other = self._buf('xb', M, H, self.T)
-        for i, blk in enumerate(self.bert_blocks):
-            bufs = saved[i] if saved is not None else self._block_bufs('bert.shared', blk, M, True)
-            self._block_forward(blk, x, key_mask, n_items, M, bufs, train, seed, other)
-            x, other = other, x
         Ip = pad_to(n_items, 128)
         cls = self._buf('cls', Ip, H, self.T)
-        L.gather_rows(x, cls, n_items, S)
+        last = len(self.bert_blocks) - 1
+        for i, blk in enumerate(self.bert_blocks):
+            cmode = self.cls_only and i == last
+            bufs = saved[i] if saved is not None else self._block_bufs('bert.shared', blk, M, True, Mc=Ip if cmode else None)
+            if cmode:
+                self._block_forward(blk, x, key_mask, n_items, M, bufs, train, seed, cls, cls_rows=Ip)
+            else:
+                self._block_forward(blk, x, key_mask, n_items, M, bufs, train, seed, other)
+                x, other = other, x
+        if not self.cls_only:
+            L.gather_rows(x, cls, n_items, S)
         emb = self._buf('emb', Ip, self.E, torch.float32)
         pre = self._buf('embpre', Ip, self.E, torch.float32)
         L.gemm_nt(cls, self.fc_w, emb, bias=self.fc_b, C2=pre, act=L.ACT_GELU, M=Ip)
@@ -615,12 +723,14 @@ class TransRecEngine:
         seed = (self.seed * 1000003 + self.step_count) & 0xFFFFFFFFFFFF
         M = pad_to(n_items * self.S, 256)
         Mu = pad_to(B * (self.Lseq - 1), 128)
-        if self._saved_bert is None or self._saved_M < M or self._saved_Mu < Mu:
-            self._saved_bert = [self._block_bufs(f'bert.{i}', b, M, False) for i, b in enumerate(self.bert_blocks)]
+        if self._saved_bert is None or self._saved_M != M or self._saved_Mu != Mu:
+            Ipc = pad_to(n_items, 128)
+            nb = len(self.bert_blocks)
+            self._saved_bert = [self._block_bufs(f'bert.{i}', b, M, False, Mc=Ipc if (self.cls_only and i == nb - 1) else None)
+                                for i, b in enumerate(self.bert_blocks)]
             self._saved_sas = [self._block_bufs(f'sas.{j}', b, Mu, False) for j, b in enumerate(self.sas_blocks)]
             self._saved_M, self._saved_Mu = M, Mu
-        saved_b = [{k: v[:M] for k, v in d.items()} for d in self._saved_bert]
-        saved_s = [{k: v[:Mu] for k, v in d.items()} for d in self._saved_sas]
+        saved_b, saved_s = self._saved_bert, self._saved_sas
         emb, pre, key_mask, M = self._encode(news, n_items, train, seed, saved_b)
         xin = self._buf('sxin', Mu, self.E, torch.float32)
         L.take_inputs(emb, xin, B, self.Lseq, self.E)
@@ -676,12 +786,18 @@ class TransRecEngine:
         dcls = self._buf('dcls', Ip, self.H, self.T)
         L.gemm_nt(d_pre, self.fc_wT32, dcls, M=Ip)
         dxb = self._buf('dx_a', M, self.H, self.T)
-        dxb.zero_()
-        L.scatter_rows(dcls, dxb, n_items, self.S)
+        if not self.cls_only:
+            dxb.zero_()
+            L.scatter_rows(dcls, dxb, n_items, self.S)
         spare = self._buf('dx_b', M, self.H, self.T)
-        for i in range(len(self.bert_blocks) - 1, -1, -1):
+        last = len(self.bert_blocks) - 1
+        for i in range(last, -1, -1):
             blk = self.bert_blocks[i]
-            self._block_backward(blk, dxb, c['key_mask'], n_items, M, c['saved_b'][i], train, seed, spare if blk.need_dx else None)
+            if self.cls_only and i == last:
+                self._block_backward(blk, dcls, c['key_mask'], n_items, M, c['saved_b'][i], train, seed,
+                                     spare if blk.need_dx else None, cls_rows=Ip)
+            else:
+                self._block_backward(blk, dxb, c['key_mask'], n_items, M, c['saved_b'][i], train, seed, spare if blk.need_dx else None)
             dxb, spare = spare, dxb
         if self._virtual:
             self._virtual_backward()

@@ -32,8 +32,15 @@ def inject_adapters(model, args):
             blocks[i] = SASRecPfeifferAdaptedSelfOutput(blk, args)
     elif 'kadapter' in t or 'prompt' in t:
         raise NotImplementedError(f'--adapter_type {t}: K-Adapter / soft prompt are outside the BASELINE configs (SURVEY.md 2.1 rows 13-14)')
-    elif 'lora' in t:
-        raise NotImplementedError('--adapter_type lora: native LoRA q/v path not wired yet (SURVEY.md 8(a) a7)')
+    elif 'lora' in t:                                   # run.py:414-428: fresh lora.Linear modules replace q, v / w_Q, w_V
+        from .model.lora import LoRALinear
+        h = model.bert_encoder.text_encoders['title'].fc.in_features
+        for lyr in layers:
+            lyr.attention.self.query = LoRALinear(h, h, r=args.bert_adapter_down_size)
+            lyr.attention.self.value = LoRALinear(h, h, r=args.bert_adapter_down_size)
+        for blk in blocks:
+            blk.multi_head_attention.w_Q = LoRALinear(args.embedding_dim, args.embedding_dim, r=args.adapter_down_size)
+            blk.multi_head_attention.w_V = LoRALinear(args.embedding_dim, args.embedding_dim, r=args.adapter_down_size)
     elif 'compacter' in t:
         for lyr in layers:
             lyr.attention.output = BertCompacterAdaptedSelfOutput(lyr.attention.output, args)

@@ -6,3 +6,4 @@ from .model import (Model, ModelCPC, CompacterModel, BertAdaptedSelfOutput, Bert
                     SASRecPfeifferVer2AdaptedSelfOutput, SASRecCompacterAdaptedSelfOutput)
 from .modules import (AdapterBlock, AdapterPfeifferBlock, HyperComplexAdapterBlock, PHMLinear, TransformerBlock,
                       TransformerEncoder, MultiHeadedAttention, PositionwiseFeedForward)
+from .lora import LoRALinear

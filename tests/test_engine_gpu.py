@@ -17,7 +17,7 @@ pytestmark = pytest.mark.gpu
 GEOM = dict(vocab_size=120, hidden_size=128, num_hidden_layers=2, num_attention_heads=2, intermediate_size=256,
             max_position_embeddings=40, type_vocab_size=2, layer_norm_eps=1e-12, hidden_dropout_prob=0.1,
             attention_probs_dropout_prob=0.1, pad_token_id=0, model_type='bert')
-ARGS = dict(houlsby=dict(), houlsby_gelu=dict(adapter_activation='GELU'),
+ARGS = dict(houlsby=dict(), houlsby_gelu=dict(adapter_activation='GELU'), houlsby_parallel=dict(is_serial='None'),
             pfeiffer=dict(adapter_type='pfeiffer', adapter_activation='relu'), pfeiffer_ver2=dict(adapter_type='pfeiffer_ver2'),
             compacter=dict(adapter_type='compacter'), houlsby_cpc=dict(arch='cpc'),
             roberta_cpc_pfeiffer=dict(adapter_type='pfeiffer', adapter_activation='relu', arch='cpc', bert_model_load='roberta_tiny'))
@@ -250,3 +250,26 @@ def test_eval_pipeline_vs_reference_fixture():
         assert int(np.abs(ranks - oracle_ranks).sum()) <= 1          # bit-exact up to one fp32 near-tie
         nd = np.where(ranks <= 10, 1.0 / np.log2(ranks + 1.0), 0.0)
         assert abs(nd.mean() - float(fx[tag + '_means'][1])) < 1e-3
+
+
+@pytest.mark.parametrize('dtype', ['fp32', 'bf16'])
+def test_lora_vs_oracle(dtype):
+    """a7: LoRA on q/v (BERT) and w_Q/w_V (SASRec).  loralib is third party and absent => parity unpinned by the reference;
+    the native path is held to the oracle's restatement (fp32: 1e-4; bf16: the bound of test_step_bf16_bound)."""
+    from oracle import ref_cpu as R
+    from test_engine_host_logic import build_lora_cpu
+    model, args, osd, ocfg, items, mask = build_lora_cpu(dtype)
+    if dtype == 'bf16':
+        osd = condition(osd)
+        model.load_state_dict(osd, strict=True)
+    names = [n for n, p in model.named_parameters() if p.requires_grad]
+    out, grads = R.loss_and_grads(osd, names, items, mask, ocfg)
+    model.to('cuda:0').eval()
+    loss = model(items.to('cuda:0'), mask.to('cuda:0'), 0)
+    loss.backward()
+    tol_l, tol_g = (1e-4, 1e-4) if dtype == 'fp32' else (2e-2, 0.12)
+    assert abs(loss.item() - float(out['loss'].detach())) < tol_l
+    params = dict(model.named_parameters())
+    for n in names:
+        ref = grads[n].numpy()
+        np.testing.assert_allclose(params[n].grad.cpu().numpy(), ref, atol=1e-6 + tol_g * np.abs(ref).max(), rtol=0, err_msg=n)

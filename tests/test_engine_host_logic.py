@@ -98,3 +98,40 @@ def test_host_logic_bf16_mode(simulated, name):
         k = str(k)
         ref = grads[strip(k)].numpy()
         assert np.abs(params[k].grad.numpy() - ref).max() <= 0.12 * np.abs(ref).max() + 1e-9, k
+
+
+def build_lora_cpu(dtype='fp32'):
+    """LoRA has no reference fixture (loralib is absent): weights are seeded here and the oracle is the only checker."""
+    import adapter4rec_amd.inject as I
+    from adapter4rec_amd.model import BertBackbone, Model
+    from golden_util import load_variant
+    sd, cfg, fx, trainable, (items, mask), base = load_variant('finetune_all')       # un-adapted base weights
+    args = TG.make_args(compute_dtype=dtype, adapter_type='lora', bert_adapter_down_size=8, adapter_down_size=4)
+    model = Model(args, 200, True, BertBackbone(dict(TG.GEOM)))
+    model.load_state_dict({str(k): sd[strip(str(k))] for k in fx['all_keys']}, strict=True)
+    I.freeze_all(model)
+    torch.manual_seed(7)
+    model = I.inject_adapters(model, args)
+    with torch.no_grad():
+        for n, p in model.named_parameters():
+            if 'lora_B' in n:
+                p.normal_(std=0.05)                    # zeros would hide dA and half of the forward
+    model.eval()
+    osd = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    ocfg = dict(cfg, adapter_type='lora', lora_r_bert=8, lora_r_sasrec=4)
+    return model, args, osd, ocfg, items, mask
+
+
+def test_host_logic_lora(simulated):
+    from oracle import ref_cpu as R
+    model, args, osd, ocfg, items, mask = build_lora_cpu()
+    names = [n for n, p in model.named_parameters() if p.requires_grad]
+    assert any('lora_A' in n for n in names) and any(n.endswith('query.bias') for n in names)
+    out, grads = R.loss_and_grads(osd, names, items, mask, ocfg)
+    loss = model(items, mask, 'cpu')
+    loss.backward()
+    assert abs(loss.item() - float(out['loss'].detach())) < 1e-4
+    params = dict(model.named_parameters())
+    for n in names:
+        ref = grads[n].numpy()
+        np.testing.assert_allclose(params[n].grad.numpy(), ref, atol=1e-6 + 1e-4 * np.abs(ref).max(), rtol=0, err_msg=n)
