@@ -14,6 +14,7 @@ LIB_PATH = os.path.join(_HERE, 'liba4r_hip.so')
 
 BF16, F32 = 0, 1
 ACT_NONE, ACT_RELU, ACT_GELU, ACT_GELU_TANH, ACT_LEAKY = 0, 1, 2, 3, 4
+DACT_MUL = 15
 ACT_BY_NAME = {'none': 0, 'relu': 1, 'RELU': 1, 'gelu': 2, 'GELU': 2, 'gelu_new': 3, 'leaky_relu': 4}
 
 EXPORTS = [
@@ -31,7 +32,7 @@ class GemmArgs(C.Structure):
                 ('lda', C.c_int32), ('ldb', C.c_int32), ('ldc', C.c_int32), ('ldc2', C.c_int32),
                 ('ldr1', C.c_int32), ('ldr2', C.c_int32), ('ldpre', C.c_int32),
                 ('in_dtype', C.c_int32), ('out_dtype', C.c_int32), ('act', C.c_int32), ('dact', C.c_int32),
-                ('drop_first', C.c_int32), ('alpha', C.c_float), ('drop_p', C.c_float), ('drop_site', C.c_uint32), ('drop_seed', C.c_uint64)]
+                ('drop_first', C.c_int32), ('c2_mode', C.c_int32), ('alpha', C.c_float), ('drop_p', C.c_float), ('drop_site', C.c_uint32), ('drop_seed', C.c_uint64)]
 
 
 class AttnArgs(C.Structure):
@@ -98,7 +99,7 @@ def require_gpu(*tensors):
 
 # ------------------------------------------------------------------ wrappers
 def gemm_nt(A, B, Cout, bias=None, C2=None, R1=None, R2=None, Pre=None, act=0, dact=0, alpha=1.0,
-            drop_p=0.0, drop_site=0, drop_seed=0, M=None, drop_first=False):
+            drop_p=0.0, drop_site=0, drop_seed=0, M=None, drop_first=False, c2_deriv=False):
     require_gpu(A, B, Cout)
     g = GemmArgs()
     g.A, g.B, g.C, g.bias, g.C2, g.R1, g.R2, g.Pre = _p(A), _p(B), _p(Cout), _p(bias), _p(C2), _p(R1), _p(R2), _p(Pre)
@@ -115,7 +116,7 @@ def gemm_nt(A, B, Cout, bias=None, C2=None, R1=None, R2=None, Pre=None, act=0, d
     for t in (C2, R1, R2, Pre):
         assert t is None or _dt(t) == g.out_dtype
     assert bias is None or bias.dtype == torch.float32
-    g.act, g.dact, g.alpha, g.drop_first = act, dact, alpha, int(drop_first)
+    g.act, g.dact, g.alpha, g.drop_first, g.c2_mode = act, dact, alpha, int(drop_first), int(c2_deriv)
     g.drop_p, g.drop_site, g.drop_seed = drop_p, drop_site, drop_seed
     _check(lib().a4r_gemm_nt(_stream(), C.byref(g)), 'a4r_gemm_nt')
 

@@ -20,7 +20,7 @@ typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
 typedef __attribute__((ext_vector_type(4))) float f32x4_t;
 
 enum { A4R_BF16 = 0, A4R_F32 = 1 };
-enum { A4R_ACT_NONE = 0, A4R_ACT_RELU = 1, A4R_ACT_GELU = 2, A4R_ACT_GELU_TANH = 3, A4R_ACT_LEAKY = 4 };
+enum { A4R_ACT_NONE = 0, A4R_ACT_RELU = 1, A4R_ACT_GELU = 2, A4R_ACT_GELU_TANH = 3, A4R_ACT_LEAKY = 4, A4R_DACT_MUL_ = 15 };
 
 // ---------------------------------------------------------------- error codes (C ABI)
 #define A4R_OK 0
@@ -137,6 +137,13 @@ A4R_DEV float gelu_erf_bwd(float x) {      // Phi(x) + x * phi(x)
     const float z = x * 0.70710678118654752440f;
     const float e = __expf(-z * z);         // = exp(-x^2 / 2)
     return 0.5f * (1.f + erf_as(z, e)) + x * 0.3989422804014327f * e;
+}
+A4R_DEV void gelu_erf_both(float x, float& g, float& dg) {     // one exp, one rcp for value and derivative
+    const float z = x * 0.70710678118654752440f;
+    const float e = __expf(-z * z);
+    const float cdf = 0.5f * (1.f + erf_as(z, e));
+    g = x * cdf;
+    dg = cdf + x * 0.3989422804014327f * e;
 }
 A4R_DEV float act_fwd(float x, int act) {
     switch (act) {

@@ -19,8 +19,7 @@
 // residual / dropout run on 8 consecutive columns per thread and every global access is 16 B/lane.
 // Workgroup -> tile map is XCD-aware: blocks that share an XCD (blockIdx % 8) walk consecutive
 // N-tiles of the same 128-row A panel, which therefore stays in that XCD's L2.
-#include "a4r_common.h"
-#include "../../include/a4r.h"
+#include "a4r_gemm_epi.h"
 
 namespace {
 
@@ -92,20 +91,10 @@ __global__ void __launch_bounds__(256) gemm_nt_kernel(const a4r_gemm_t p, int nt
     const int Lt = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + j;
     const int tm = Lt / ntn, tn = Lt % ntn;
 
-    // copy the by-value argument's fields into registers (a captured struct would live in scratch)
-    const int lda = p.lda, ldb = p.ldb, ldc = p.ldc, ldc2 = p.ldc2, ldr1 = p.ldr1, ldr2 = p.ldr2, ldpre = p.ldpre;
-    const int Kdim = p.K, Ndim = p.N, act = p.act, dact = p.dact, drop_first = p.drop_first;
-    const float alpha = p.alpha;
-    const float* __restrict__ biasp = p.bias;
-    const uint64_t drop_seed = p.drop_seed;
-    const uint32_t drop_site = p.drop_site;
+    const int lda = p.lda, ldb = p.ldb;
+    const int Kdim = p.K;
     const TI* __restrict__ A = reinterpret_cast<const TI*>(p.A) + (size_t)tm * BM * lda;
     const TI* __restrict__ B = reinterpret_cast<const TI*>(p.B) + (size_t)tn * BN * ldb;
-    TO* __restrict__ C = reinterpret_cast<TO*>(p.C);
-    TO* __restrict__ C2 = reinterpret_cast<TO*>(p.C2);
-    const TO* __restrict__ R1 = reinterpret_cast<const TO*>(p.R1);
-    const TO* __restrict__ R2 = reinterpret_cast<const TO*>(p.R2);
-    const TO* __restrict__ Pre = reinterpret_cast<const TO*>(p.Pre);
 
     f32x4_t acc[4][NI];
 #pragma unroll
@@ -198,59 +187,22 @@ __global__ void __launch_bounds__(256) gemm_nt_kernel(const a4r_gemm_t p, int nt
     }
     __syncthreads();
     constexpr int TPR = BN / 8, RPP = 256 / TPR;
+    const GemmEpi<TO> epi = make_epi<TO>(p, thr16, keep_scale);
     const int c8 = (tid % TPR) * 8;
     const int gcol = tn * BN + c8;
     float bias[8];
 #pragma unroll
-    for (int e = 0; e < 8; ++e) bias[e] = biasp ? biasp[gcol + e] : 0.f;
+    for (int e = 0; e < 8; ++e) bias[e] = epi.bias ? epi.bias[gcol + e] : 0.f;
+#pragma unroll 1
     for (int pass = 0; pass < BM / RPP; ++pass) {
         const int row = pass * RPP + tid / TPR;
         const size_t grow = (size_t)tm * BM + row;
         const float* Cs = reinterpret_cast<const float*>(row < 64 ? lds0 : lds1) + (row & 63) * BN + c8;
         float v[8];
-        {
-            const float4 lo = *reinterpret_cast<const float4*>(Cs);
-            const float4 hi = *reinterpret_cast<const float4*>(Cs + 4);
-            v[0] = lo.x; v[1] = lo.y; v[2] = lo.z; v[3] = lo.w; v[4] = hi.x; v[5] = hi.y; v[6] = hi.z; v[7] = hi.w;
-        }
-#pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] = v[e] * alpha + bias[e];
-        if (C2) store_vec<TO, 8>(C2 + grow * ldc2 + gcol, v);
-        if (act != A4R_ACT_NONE) {
-#pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] = act_fwd(v[e], act);
-        }
-        if (dact != A4R_ACT_NONE) {
-            float pre[8];
-            load_vec<TO, 8>(Pre + grow * ldpre + gcol, pre);
-#pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] *= act_bwd(pre[e], dact);
-        }
-        auto dropout8 = [&]() {
-            const uint64_t e0 = (uint64_t)grow * (uint64_t)Ndim + (uint64_t)gcol;   // gcol % 8 == 0
-            const uint64_t h0 = a4r_hash64(drop_seed, drop_site, e0 >> 2);
-            const uint64_t h1 = a4r_hash64(drop_seed, drop_site, (e0 >> 2) + 1);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                v[e] = (((uint32_t)(h0 >> (16 * e)) & 0xffffu) >= thr16) ? v[e] * keep_scale : 0.f;
-                v[e + 4] = (((uint32_t)(h1 >> (16 * e)) & 0xffffu) >= thr16) ? v[e + 4] * keep_scale : 0.f;
-            }
-        };
-        if (thr16 && drop_first) dropout8();
-        if (R1) {
-            float t[8];
-            load_vec<TO, 8>(R1 + grow * ldr1 + gcol, t);
-#pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] += t[e];
-        }
-        if (R2) {
-            float t[8];
-            load_vec<TO, 8>(R2 + grow * ldr2 + gcol, t);
-#pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] += t[e];
-        }
-        if (thr16 && !drop_first) dropout8();
-        store_vec<TO, 8>(C + grow * ldc + gcol, v);
+        const float4 lo = *reinterpret_cast<const float4*>(Cs);
+        const float4 hi = *reinterpret_cast<const float4*>(Cs + 4);
+        v[0] = lo.x; v[1] = lo.y; v[2] = lo.z; v[3] = lo.w; v[4] = hi.x; v[5] = hi.y; v[6] = hi.z; v[7] = hi.w;
+        epilogue_n<TO, 8>(v, bias, grow, gcol, epi);
     }
 }
 
@@ -278,11 +230,11 @@ inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 
 
 }  // namespace
 
-int a4r_gemm_nt_256(hipStream_t s, const a4r_gemm_t& g, int sched);   // a4r_gemm256.hip
+int a4r_gemm_nt_256(hipStream_t s, const a4r_gemm_t& g);   // a4r_gemm256.hip
 
 extern "C" int a4r_gemm_variant(int v) {
     const int old = g_variant;
-    if (v >= 0 && v <= 4) g_variant = v;
+    if (v >= 0 && v <= 2) g_variant = v;
     return old;
 }
 
@@ -301,10 +253,12 @@ extern "C" int a4r_gemm_nt(void* stream, const a4r_gemm_t* gp) {
     if (g.R2 && (!aligned16(g.R2) || (g.ldr2 * osz) % 16 || g.ldr2 < g.N)) return A4R_EINVAL;
     if (g.dact != A4R_ACT_NONE && (!g.Pre || !aligned16(g.Pre) || (g.ldpre * osz) % 16 || g.ldpre < g.N)) return A4R_EINVAL;
     if (g.drop_p < 0.f || g.drop_p >= 1.f) return A4R_EINVAL;
+    if (g.dact == A4R_DACT_MUL_ && !g.Pre) return A4R_EINVAL;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-    if (g_variant >= 2 && g.M % 256 == 0 && g.N % 256 == 0 && g.K * isz >= 256 &&
-        (!g.bias || aligned16(g.bias)))
-        return a4r_gemm_nt_256(s, g, g_variant - 2);
+    if (g_variant >= 2 && g.M % 256 == 0 && g.N % 256 == 0 && g.K * isz >= 256) {
+        const int rc = a4r_gemm_nt_256(s, g);
+        if (rc != 1) return rc;              // 1 = this (dtype, act, dact) combination has no large-tile instantiation
+    }
     if (g.in_dtype == A4R_BF16 && g.out_dtype == A4R_BF16) return launch_bn<bf16_t, bf16_t>(s, g);
     if (g.in_dtype == A4R_F32 && g.out_dtype == A4R_F32) return launch_bn<float, float>(s, g);
     if (g.in_dtype == A4R_BF16 && g.out_dtype == A4R_F32) return launch_bn<bf16_t, float>(s, g);

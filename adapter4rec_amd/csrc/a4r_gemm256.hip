@@ -39,10 +39,11 @@ A4R_DEV void glds16(const void* base, uint32_t voff, uint32_t lds_dst) {
         : "memory");
 }
 
-template <typename TI, typename TO, bool PH2, bool STAG>
+template <typename TI, typename TO, int ACT, int DACT>
 __global__ void __launch_bounds__(512, 2) gemm_nt_256_kernel(const a4r_gemm_t p, int ntm, int ntn, uint32_t thr16, float keep_scale) {
     constexpr int ROWB = 128;
     constexpr int KT = ROWB / (int)sizeof(TI);
+    constexpr bool PH2 = false, STAG = false;   // schedule variants measured on MI355X and rejected
     __shared__ __attribute__((aligned(16))) char lds[8 * UNIT_BYTES];      // [buffer 2][unit 4][128 rows][128 B]
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -280,7 +281,7 @@ __global__ void __launch_bounds__(512, 2) gemm_nt_256_kernel(const a4r_gemm_t p,
             v_[r_] = __uint_as_float(sw_[0]);                                                                               \
             v_[4 + r_] = __uint_as_float(sw_[1]);                                                                           \
         }                                                                                                                   \
-        epilogue8<TO>(v_, bias8[pr_], grow0 + (mi_) * 16, gcolp + (pr_) * 32, epi);                                         \
+        epilogue_n<TO, 8, ACT, DACT>(v_, bias8[pr_], grow0 + (mi_) * 16, gcolp + (pr_) * 32, epi);                                         \
     }
 #define A4R_EPI_ROW(mi_) A4R_EPI_PAIR(mi_, 0) A4R_EPI_PAIR(mi_, 1)
     A4R_EPI_ROW(0) A4R_EPI_ROW(1) A4R_EPI_ROW(2) A4R_EPI_ROW(3) A4R_EPI_ROW(4) A4R_EPI_ROW(5) A4R_EPI_ROW(6) A4R_EPI_ROW(7)
@@ -297,7 +298,7 @@ __global__ void __launch_bounds__(512, 2) gemm_nt_256_kernel(const a4r_gemm_t p,
 #undef A4R_MFMA16
 }
 
-template <typename TI, typename TO, bool PH2, bool STAG>
+template <typename TI, typename TO, int ACT, int DACT>
 int launch256(hipStream_t s, const a4r_gemm_t& g) {
     const int ntm = g.M / 256, ntn = g.N / 256;
     static int n_cu = 0;
@@ -310,25 +311,30 @@ int launch256(hipStream_t s, const a4r_gemm_t& g) {
         if (n_cu < 8) n_cu = 8;
     }
     const int grid = ntm * ntn < n_cu ? ntm * ntn : n_cu;
-    hipLaunchKernelGGL((gemm_nt_256_kernel<TI, TO, PH2, STAG>), dim3(grid), dim3(512), 0, s, g, ntm, ntn,
+    hipLaunchKernelGGL((gemm_nt_256_kernel<TI, TO, ACT, DACT>), dim3(grid), dim3(512), 0, s, g, ntm, ntn,
                        a4r_thr16(g.drop_p), a4r_keep_scale(g.drop_p));
     return a4r_launch_status();
 }
 
-template <bool PH2, bool STAG>
-int dispatch256(hipStream_t s, const a4r_gemm_t& g) {
-    if (g.in_dtype == A4R_BF16 && g.out_dtype == A4R_BF16) return launch256<bf16_t, bf16_t, PH2, STAG>(s, g);
-    if (g.in_dtype == A4R_F32 && g.out_dtype == A4R_F32) return launch256<float, float, PH2, STAG>(s, g);
-    if (g.in_dtype == A4R_BF16 && g.out_dtype == A4R_F32) return launch256<bf16_t, float, PH2, STAG>(s, g);
-    return launch256<float, bf16_t, PH2, STAG>(s, g);
+template <typename T>
+int dispatch_same(hipStream_t s, const a4r_gemm_t& g) {   // in == out dtype: the activation forms the training step uses
+    if (g.act == A4R_ACT_NONE && g.dact == A4R_ACT_NONE) return launch256<T, T, A4R_ACT_NONE, A4R_ACT_NONE>(s, g);
+    if (g.act == A4R_ACT_GELU && g.dact == A4R_ACT_NONE) return launch256<T, T, A4R_ACT_GELU, A4R_ACT_NONE>(s, g);
+    if (g.act == A4R_ACT_RELU && g.dact == A4R_ACT_NONE) return launch256<T, T, A4R_ACT_RELU, A4R_ACT_NONE>(s, g);
+    if (g.act == A4R_ACT_NONE && g.dact == A4R_DACT_MUL_) return launch256<T, T, A4R_ACT_NONE, A4R_DACT_MUL_>(s, g);
+    if (g.act == A4R_ACT_NONE && g.dact == A4R_ACT_GELU) return launch256<T, T, A4R_ACT_NONE, A4R_ACT_GELU>(s, g);
+    if (g.act == A4R_ACT_NONE && g.dact == A4R_ACT_RELU) return launch256<T, T, A4R_ACT_NONE, A4R_ACT_RELU>(s, g);
+    return 1;
 }
 
 }  // namespace
 
-// called by a4r_gemm_nt (a4r_gemm.hip) after argument validation.  sched: 0 = 4 phases per K-tile, lockstep;
-// 1 = 2 phases per K-tile; 2 = 4 phases, SIMD partners staggered (DMA-first vs MFMA-first)
-int a4r_gemm_nt_256(hipStream_t s, const a4r_gemm_t& g, int sched) {
-    if (sched == 1) return dispatch256<true, false>(s, g);
-    if (sched == 2) return dispatch256<false, true>(s, g);
-    return dispatch256<false, false>(s, g);
+// called by a4r_gemm_nt (a4r_gemm.hip) after argument validation; returns 1 when the combination is not instantiated
+int a4r_gemm_nt_256(hipStream_t s, const a4r_gemm_t& g) {
+    if (g.bias && (reinterpret_cast<uintptr_t>(g.bias) & 3u)) return 1;
+    if (g.in_dtype == A4R_BF16 && g.out_dtype == A4R_BF16) return dispatch_same<bf16_t>(s, g);
+    if (g.in_dtype == A4R_F32 && g.out_dtype == A4R_F32) return dispatch_same<float>(s, g);
+    if (g.act != A4R_ACT_NONE || g.dact != A4R_ACT_NONE) return 1;
+    if (g.in_dtype == A4R_BF16) return launch256<bf16_t, float, A4R_ACT_NONE, A4R_ACT_NONE>(s, g);
+    return launch256<float, bf16_t, A4R_ACT_NONE, A4R_ACT_NONE>(s, g);
 }

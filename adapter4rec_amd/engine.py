@@ -509,7 +509,7 @@ class TransRecEngine:
         x1 = bufs['x1s'] if 'x1s' in bufs else x1
         self._sub_forward(blk, '1', ctx, blk.wo, blk.bo, x, blk.ln1, blk.ad1, blk.pl1, blk.lnn1, bufs, M, ph, blk.site + 1, seed, x1)
         u = self._buf('u', M, blk.F, T)
-        L.gemm_nt(x1, blk.wi, u, bias=blk.bi, C2=bufs['upre'], act=blk.ffn_act, M=M)
+        L.gemm_nt(x1, blk.wi, u, bias=blk.bi, C2=bufs['upre'], act=blk.ffn_act, c2_deriv=True, M=M)     # 'upre' holds act'(pre)
         self._sub_forward(blk, '2', u, blk.wo2, blk.bo2, x1, blk.ln2, blk.ad2, blk.pl2, blk.lnn2, bufs, M, ph, blk.site + 2, seed, x_out)
 
     # ------------------------------------------------------------------ one block, backward
@@ -612,7 +612,7 @@ class TransRecEngine:
             M = cls_rows
         dh2, dres2 = self._sub_backward(blk, '2', dx_out, blk.ln2, blk.ad2, blk.pl2, blk.lnn2, bufs, M, ph, blk.site + 2, seed)
         du = self._buf('du', M, F, T)
-        L.gemm_nt(dh2, blk.wo2T, du, Pre=bufs['upre'], dact=blk.ffn_act, M=M)
+        L.gemm_nt(dh2, blk.wo2T, du, Pre=bufs['upre'], dact=L.DACT_MUL, M=M)
         dx1 = self._buf('dx1', M, H, T)
         L.gemm_nt(du, blk.wiT, dx1, R1=dres2, M=M)
         dh1, dres1 = self._sub_backward(blk, '1', dx1, blk.ln1, blk.ad1, blk.pl1, blk.lnn1, bufs, M, ph, blk.site + 1, seed)

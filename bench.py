@@ -105,6 +105,14 @@ class GemmProbe:
             agg[key] = (f + 2.0 * M * N * K, t + e0.elapsed_time(e1) * 1e-3, n + 1)
         return agg
 
+    def by_shape(self):
+        out = {}
+        for da, dc, tile, M, N, K, e0, e1 in self.rec:
+            k = f'{tile}:{M}x{N}x{K}'
+            f, t, n = out.get(k, (0.0, 0.0, 0))
+            out[k] = (f + 2.0 * M * N * K, t + e0.elapsed_time(e1) * 1e-3, n + 1)
+        return {k: dict(launches=v[2], avg_us=round(v[1] / v[2] * 1e6, 1), tflops=round(v[0] / v[1] / 1e12, 1)) for k, v in out.items()}
+
 
 def host_threads():
     """Threads the CPU baseline may really use: CPU affinity, capped by the cgroup quota and by 32
@@ -217,6 +225,7 @@ def main():
             for i in range(2):
                 step(a.warmup + a.steps + i)
             agg = probe.summary()
+            shapes = probe.by_shape()
         tname = 'torch.bfloat16' if a.dtype == 'bf16' else 'torch.float32'
         key = max((k for k in agg if k[0] == tname and k[1] == tname), key=lambda k: agg[k][1])     # most GPU time
         f, t, n = agg[key]
@@ -228,6 +237,8 @@ def main():
                     kernel=(f'gemm_nt_256_kernel<{a.dtype},{a.dtype}>' if key[2] == 256 else f'gemm_nt_kernel<{a.dtype},{a.dtype},{key[2]}>'), launches_per_step=n // 2,
                     avg_launch_us=round(t / n * 1e6, 2), flop_per_launch=f / n,
                     all_gemm_tflops=round(total_f / total_t / 1e12, 2), gemm_time_share_of_step=round(total_t / 2 / (dt / a.steps), 3))
+        if os.environ.get('A4R_BENCH_SHAPES'):
+            print(json.dumps(shapes, indent=1), file=sys.stderr)
 
     cpu = None
     if rank == 0 and world == 1 and not a.no_cpu_baseline:

@@ -30,13 +30,14 @@ extern "C" {
 #define A4R_ACT_GELU 2       /* exact erf form (HF "gelu", nn.GELU) */
 #define A4R_ACT_GELU_TANH 3  /* HF "gelu_new" (compacter, model/modules.py:220) */
 #define A4R_ACT_LEAKY 4
+#define A4R_DACT_MUL 15       /* dact only: multiply by Pre itself (Pre holds a stored derivative, see c2_mode) */
 
 int a4r_version(void);
 
 /* C[M,N] = epilogue(alpha * A[M,K] . B[N,K]^T): every nn.Linear on the path (HF BertSelfAttention
  * q/k/v, BertSelfOutput.dense, BertIntermediate, BertOutput.dense; AdapterBlock fc_down/fc_up
  * model/modules.py:130-134; SASRec w_Q/w_K/w_V/fc/w_1/w_2 modules.py:23-28,63-74) and its dgrad.
- * epilogue, in order: + bias[N]; C2 = copy (saved pre-activation); act; * act'(Pre) if dact;
+ * epilogue, in order: + bias[N]; C2 = pre-activation (or its act' if c2_mode); act; * act'(Pre) if dact (* Pre if A4R_DACT_MUL);
  * [dropout if drop_first]; + R1 + R2 (residuals); [dropout if !drop_first]; store C.  The dropout mask is a
  * pure function of (seed, site, row * N + col), so backward regenerates it instead of reading it.
  * M % 128 == 0, N % 64 == 0, K % 64 == 0.  A,B have in_dtype; C,C2,R1,R2,Pre have out_dtype. */
@@ -48,6 +49,7 @@ typedef struct {
     int32_t in_dtype, out_dtype;
     int32_t act, dact;
     int32_t drop_first;   /* 0: dropout after the residual adds (backward form); 1: before them (forward form) */
+    int32_t c2_mode;      /* what C2 receives: 0 = the pre-activation, 1 = act'(pre-activation) (so that backward is one multiply) */
     float alpha;
     float drop_p; uint32_t drop_site; uint64_t drop_seed;
 } a4r_gemm_t;

@@ -13,6 +13,7 @@ from adapter4rec_amd import _lib as REAL
 
 BF16, F32 = REAL.BF16, REAL.F32
 ACT_NONE, ACT_RELU, ACT_GELU, ACT_GELU_TANH, ACT_LEAKY = 0, 1, 2, 3, 4
+DACT_MUL = 15
 ACT_BY_NAME = REAL.ACT_BY_NAME
 PackDesc = REAL.PackDesc
 
@@ -45,7 +46,7 @@ def _dact(pre, a):
 
 
 def gemm_nt(A, B, Cout, bias=None, C2=None, R1=None, R2=None, Pre=None, act=0, dact=0, alpha=1.0,
-            drop_p=0.0, drop_site=0, drop_seed=0, M=None, drop_first=False):
+            drop_p=0.0, drop_site=0, drop_seed=0, M=None, drop_first=False, c2_deriv=False):
     assert drop_p == 0.0
     M = A.shape[0] if M is None else M
     assert M % 128 == 0 and B.shape[0] % 64 == 0 and B.shape[1] % 64 == 0, (M, B.shape)
@@ -53,9 +54,11 @@ def gemm_nt(A, B, Cout, bias=None, C2=None, R1=None, R2=None, Pre=None, act=0, d
     if bias is not None:
         v = v + bias
     if C2 is not None:
-        C2[:M] = v.to(C2.dtype)
+        C2[:M] = (_dact(v, act) if c2_deriv else v).to(C2.dtype)
     v = _act(v, act)
-    if dact:
+    if dact == 15:
+        v = v * Pre[:M].float()
+    elif dact:
         v = v * _dact(Pre[:M].float(), dact)
     if R1 is not None:
         v = v + R1[:M].float()

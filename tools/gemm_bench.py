@@ -18,7 +18,7 @@ def main():
         C = torch.zeros(M, N, dtype=torch.bfloat16, device=dev)
         bias = torch.zeros(N, device=dev)
         for rnd in range(3):
-            for v in (2, 4):
+            for v in (1, 2):
                 L.gemm_variant(v)
                 for _ in range(3):
                     L.gemm_nt(A, B, C, bias=bias)
