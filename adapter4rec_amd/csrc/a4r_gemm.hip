@@ -255,7 +255,7 @@ extern "C" int a4r_gemm_nt(void* stream, const a4r_gemm_t* gp) {
     if (g.drop_p < 0.f || g.drop_p >= 1.f) return A4R_EINVAL;
     if (g.dact == A4R_DACT_MUL_ && !g.Pre) return A4R_EINVAL;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-    if (g_variant >= 2 && g.M % 256 == 0 && g.N % 256 == 0 && g.K * isz >= 256) {
+    if (g_variant >= 2 && g.M % 256 == 0 && g.N % 256 == 0 && (g.K * isz) % 128 == 0) {
         const int rc = a4r_gemm_nt_256(s, g);
         if (rc != 1) return rc;              // 1 = this (dtype, act, dact) combination has no large-tile instantiation
     }

@@ -1,4 +1,4 @@
-// gemm_nt_256_kernel: the large-tile path of a4r_gemm_nt (M % 256 == 0, N % 256 == 0, K >= 2 K-tiles).
+// gemm_nt_256_kernel: the large-tile path of a4r_gemm_nt (M % 256 == 0, N % 256 == 0, K a multiple of one 128-byte K-tile).
 //
 // 256 x 256 output tile, 512 threads = 8 waves laid out 2 (M) x 4 (N); each wave owns 128 x 64 = 8 x 4 MFMA 16x16 tiles
 // (128 accumulator registers).  One workgroup per CU, two waves per SIMD.  Twice the flop per L2->LDS byte of the
@@ -145,8 +145,8 @@ __global__ void __launch_bounds__(512, 2) gemm_nt_256_kernel(const a4r_gemm_t p,
     A4R_ISSUE(U_BLO, 1, Bbase, offB_lo)         \
     A4R_ISSUE(U_BHI, 1, Bbase, offB_hi)
     A4R_PROLOGUE()
-    if constexpr (PH2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");    // A_lo(0), B_lo(0), B_hi(0) of the first tile have landed
-    else asm volatile("s_waitcnt vmcnt(10)" ::: "memory");                // A_lo(0), B_lo(0)
+    if (nk >= 2) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");        // 7 units issued: A_lo(0), B_lo(0) have landed
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                  // single K-tile (adapter up-projection, K = 64): 4 units
     const GemmEpi<TO> epi = make_epi<TO>(p, thr16, keep_scale);
 
   for (;;) {                                              // ---- tiles of this workgroup

@@ -143,14 +143,14 @@ __global__ void __launch_bounds__(256) ln_fwd_kernel(const T* __restrict__ vin, 
 // dv = rstd * (dxhat - mean(dxhat) - xhat * mean(dxhat * xhat)), dxhat = dy * gamma (dy first goes back through
 // the forward's dropout mask).  Column sums (dgamma, dbeta, dbias = sum dv) are kept per lane over the rows a
 // wave visits, reduced over the block's 4 waves in LDS, and flushed with one atomic per column per block.
-template <typename T>
+template <typename T, bool WGB, bool WDB>     // WGB: accumulate dgamma/dbeta; WDB: accumulate dbias (unused sums cost 16-32 VGPRs each)
 __global__ void __launch_bounds__(256) ln_bwd_kernel(const T* __restrict__ dy, int lddy, const T* __restrict__ vin, int ldv,
                                                      const float* __restrict__ add, int add_rows, const float* __restrict__ stats,
                                                      const float* __restrict__ gamma, const T* __restrict__ dres, int lddres,
                                                      T* __restrict__ dv, int lddv,
                                                      float* __restrict__ dgamma, float* __restrict__ dbeta, float* __restrict__ dbias,
                                                      int M, int H, uint64_t seed, uint32_t site, uint32_t thr16, float scale) {
-    __shared__ float red[3][4][1024];
+    __shared__ float red[(WGB ? 2 : 0) + (WDB ? 1 : 0) + 1][4][1024];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int ng = H / 8;
     float ga[MAXG][8];
@@ -181,8 +181,10 @@ __global__ void __launch_bounds__(256) ln_bwd_kernel(const T* __restrict__ dy, i
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
                     const float xh = (v[g][e] - mean) * rstd;
-                    sg[g][e] += d[g][e] * xh;
-                    sb[g][e] += d[g][e];
+                    if constexpr (WGB) {
+                        sg[g][e] += d[g][e] * xh;
+                        sb[g][e] += d[g][e];
+                    }
                     const float dx = d[g][e] * ga[g][e];
                     v[g][e] = xh;
                     d[g][e] = dx;
@@ -199,7 +201,7 @@ __global__ void __launch_bounds__(256) ln_bwd_kernel(const T* __restrict__ dy, i
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
                     d[g][e] = rstd * (d[g][e] - c1 - v[g][e] * c2);
-                    sv[g][e] += d[g][e];
+                    if constexpr (WDB) sv[g][e] += d[g][e];
                 }
             }
         }
@@ -213,24 +215,29 @@ __global__ void __launch_bounds__(256) ln_bwd_kernel(const T* __restrict__ dy, i
         }
         row_store<T>(dv + (size_t)row * lddv, ng, lane, d);
     }
-    if (!dgamma && !dbeta && !dbias) return;      // uniform across the block
+    if constexpr (!WGB && !WDB) return;
+    constexpr int SV = WGB ? 2 : 0;
 #pragma unroll
     for (int g = 0; g < MAXG; ++g) {
         const int gi = lane + 64 * g;
         if (gi < ng) {
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
-                red[0][wave][gi * 8 + e] = sg[g][e];
-                red[1][wave][gi * 8 + e] = sb[g][e];
-                red[2][wave][gi * 8 + e] = sv[g][e];
+                if constexpr (WGB) {
+                    red[0][wave][gi * 8 + e] = sg[g][e];
+                    red[1][wave][gi * 8 + e] = sb[g][e];
+                }
+                if constexpr (WDB) red[SV][wave][gi * 8 + e] = sv[g][e];
             }
         }
     }
     __syncthreads();
     for (int c = threadIdx.x; c < H; c += 256) {
-        if (dgamma) atomicAdd(dgamma + c, red[0][0][c] + red[0][1][c] + red[0][2][c] + red[0][3][c]);
-        if (dbeta) atomicAdd(dbeta + c, red[1][0][c] + red[1][1][c] + red[1][2][c] + red[1][3][c]);
-        if (dbias) atomicAdd(dbias + c, red[2][0][c] + red[2][1][c] + red[2][2][c] + red[2][3][c]);
+        if constexpr (WGB) {
+            if (dgamma) atomicAdd(dgamma + c, red[0][0][c] + red[0][1][c] + red[0][2][c] + red[0][3][c]);
+            if (dbeta) atomicAdd(dbeta + c, red[1][0][c] + red[1][1][c] + red[1][2][c] + red[1][3][c]);
+        }
+        if constexpr (WDB) atomicAdd(dbias + c, red[SV][0][c] + red[SV][1][c] + red[SV][2][c] + red[SV][3][c]);
     }
 }
 
@@ -340,13 +347,20 @@ extern "C" int a4r_ln_bwd(void* stream, const void* dy, int lddy, const void* v,
     const uint32_t thr = a4r_thr16(drop_p);
     const float sc = a4r_keep_scale(drop_p);
     int grid = row_grid(M);
-    if (grid > 512) grid = 512;      // bounds the column-sum atomics: 512 blocks x H per accumulator
-    if (dtype == A4R_BF16)
-        hipLaunchKernelGGL(ln_bwd_kernel<bf16_t>, dim3(grid), dim3(256), 0, s, (const bf16_t*)dy, lddy, (const bf16_t*)v, ldv, add, add_rows,
-                           stats, gamma, (const bf16_t*)dres, lddres, (bf16_t*)dv, lddv, dgamma, dbeta, dbias, M, H, drop_seed, drop_site, thr, sc);
-    else
-        hipLaunchKernelGGL(ln_bwd_kernel<float>, dim3(grid), dim3(256), 0, s, (const float*)dy, lddy, (const float*)v, ldv, add, add_rows,
-                           stats, gamma, (const float*)dres, lddres, (float*)dv, lddv, dgamma, dbeta, dbias, M, H, drop_seed, drop_site, thr, sc);
+    if (grid > 1024) grid = 1024;    // 3-4 blocks per CU (VGPR-limited); bounds the column-sum atomics to 1024 x H per accumulator
+    const bool wgb = dgamma || dbeta, wdb = dbias != nullptr;
+#define A4R_LNB(T_, G_, B_)                                                                                                   \
+    hipLaunchKernelGGL((ln_bwd_kernel<T_, G_, B_>), dim3(grid), dim3(256), 0, s, (const T_*)dy, lddy, (const T_*)v, ldv, add,    \
+                       add_rows, stats, gamma, (const T_*)dres, lddres, (T_*)dv, lddv, dgamma, dbeta, dbias, M, H, drop_seed,  \
+                       drop_site, thr, sc)
+    if (dtype == A4R_BF16) {
+        if (wgb && wdb) A4R_LNB(bf16_t, true, true); else if (wgb) A4R_LNB(bf16_t, true, false);
+        else if (wdb) A4R_LNB(bf16_t, false, true); else A4R_LNB(bf16_t, false, false);
+    } else {
+        if (wgb && wdb) A4R_LNB(float, true, true); else if (wgb) A4R_LNB(float, true, false);
+        else if (wdb) A4R_LNB(float, false, true); else A4R_LNB(float, false, false);
+    }
+#undef A4R_LNB
     return a4r_launch_status();
 }
 

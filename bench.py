@@ -88,7 +88,7 @@ class GemmProbe:
             self.real(A, B, Cout, *a, **k)
             e1.record()
             N, K = B.shape[0], B.shape[1]
-            big = M % 256 == 0 and N % 256 == 0 and K * A.element_size() >= 256      # a4r_gemm_nt's dispatch rule
+            big = M % 256 == 0 and N % 256 == 0 and (K * A.element_size()) % 128 == 0      # a4r_gemm_nt's dispatch rule
             self.rec.append((str(A.dtype), str(Cout.dtype), 256 if big else (128 if N % 128 == 0 else 64), M, N, K, e0, e1))
         self.L.gemm_nt = wrapped
         return self
