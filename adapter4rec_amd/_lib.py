@@ -21,7 +21,7 @@ EXPORTS = [
     'a4r_version', 'a4r_gemm_nt', 'a4r_gemm_tn', 'a4r_colsum', 'a4r_attn_fwd', 'a4r_attn_bwd', 'a4r_embed_ln',
     'a4r_ln_fwd', 'a4r_ln_bwd', 'a4r_gather_rows', 'a4r_scatter_rows', 'a4r_act_bwd_f32', 'a4r_score_bce_fwd',
     'a4r_score_bce_bwd', 'a4r_emb_grad_add_inputs', 'a4r_take_inputs', 'a4r_adam_step', 'a4r_pack_matrices',
-    'a4r_eval_rank', 'a4r_dropout_apply', 'a4r_gemm_variant',
+    'a4r_eval_rank', 'a4r_dropout_apply', 'a4r_gemm_variant', 'a4r_adapter_fwd',
 ]
 
 
@@ -123,6 +123,15 @@ def gemm_nt(A, B, Cout, bias=None, C2=None, R1=None, R2=None, Pre=None, act=0, d
 
 def gemm_variant(v):
     return lib().a4r_gemm_variant(C.c_int(v))
+
+
+def adapter_fwd(h, x, Wd, bd, Wu, bu, gamma, beta, eps, act, inner_residual, zp, z, v, y, stats, M=None):
+    require_gpu(h, x, v, y)
+    M = h.shape[0] if M is None else M
+    _check(lib().a4r_adapter_fwd(_stream(), _p(h), C.c_int(_ld(h)), _p(x), C.c_int(_ld(x)), _p(Wd), _p(bd), _p(Wu), _p(bu),
+                                 _p(gamma), _p(beta), C.c_float(eps), C.c_int(act), C.c_int(int(inner_residual)),
+                                 _p(zp), _p(z), _p(v), C.c_int(_ld(v)), _p(y), C.c_int(_ld(y)), _p(stats),
+                                 C.c_int(M), C.c_int(h.shape[1]), C.c_int(Wd.shape[0]), C.c_int(_dt(h))), 'a4r_adapter_fwd')
 
 
 def gemm_tn(X, Y, Cacc, M=None):

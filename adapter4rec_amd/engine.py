@@ -329,6 +329,7 @@ class TransRecEngine:
         if emb.LayerNorm.weight.requires_grad:
             raise NotImplementedError('training the embedding LayerNorm (--finetune_layernorm) is not wired yet')
         self.cls_only = bool(getattr(self.args, 'cls_only_last', True))
+        self.fuse_adapters = bool(getattr(self.args, 'fuse_adapters', True))
         self.roberta = g['model_type'] == 'roberta'
         self.pad_id = int(g['pad_token_id'])
         self.p_hidden = float(g['hidden_dropout_prob'])
@@ -481,6 +482,11 @@ class TransRecEngine:
             L.ln_fwd(v, ln.gamma, ln.beta, ln.eps, out, st, M=M)
             return
         L.gemm_nt(dense_in, w, h, bias=bias, drop_p=p_drop, drop_site=site, drop_seed=seed, M=M)
+        if blk.T == torch.bfloat16 and ad.dp == 64 and blk.H in (128, 256, 512, 768, 1024) and self.fuse_adapters:
+            # one pass: down-projection, activation, up-projection, residual(s), LayerNorm (a4r_adapter.hip)
+            L.adapter_fwd(h, resid, ad.wd, ad.bd, ad.wu, ad.bu, ln.gamma, ln.beta, ln.eps, ad.act, ad.kind != 'compacter',
+                          zp, z, v, out, st, M=M)
+            return
         L.gemm_nt(h, ad.wd, z, bias=ad.bd, C2=zp, act=ad.act, M=M)
         if ad.kind == 'compacter':    # no inner residual (modules.py:248-252)
             L.gemm_nt(z, ad.wu, v, bias=ad.bu, R1=resid, M=M)

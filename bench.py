@@ -83,13 +83,14 @@ class GemmProbe:
     def __enter__(self):
         def wrapped(A, B, Cout, *a, **k):
             M = k.get('M') or A.shape[0]
+            ad = (k.get('act', 0), k.get('dact', 0))
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
             self.real(A, B, Cout, *a, **k)
             e1.record()
             N, K = B.shape[0], B.shape[1]
             big = M % 256 == 0 and N % 256 == 0 and (K * A.element_size()) % 128 == 0      # a4r_gemm_nt's dispatch rule
-            self.rec.append((str(A.dtype), str(Cout.dtype), 256 if big else (128 if N % 128 == 0 else 64), M, N, K, e0, e1))
+            self.rec.append((str(A.dtype), str(Cout.dtype), (256 if big else (128 if N % 128 == 0 else 64),) + (ad if big else ()), M, N, K, e0, e1))
         self.L.gemm_nt = wrapped
         return self
 
@@ -108,7 +109,7 @@ class GemmProbe:
     def by_shape(self):
         out = {}
         for da, dc, tile, M, N, K, e0, e1 in self.rec:
-            k = f'{tile}:{M}x{N}x{K}'
+            k = f'{tile[0]}:{M}x{N}x{K}'
             f, t, n = out.get(k, (0.0, 0.0, 0))
             out[k] = (f + 2.0 * M * N * K, t + e0.elapsed_time(e1) * 1e-3, n + 1)
         return {k: dict(launches=v[2], avg_us=round(v[1] / v[2] * 1e6, 1), tflops=round(v[0] / v[1] / 1e12, 1)) for k, v in out.items()}
@@ -234,7 +235,7 @@ def main():
         total_t = sum(v[1] for v in agg.values())
         peak = MFMA_BF16_PEAK_TFLOPS if a.dtype == 'bf16' else 157.3
         roof = dict(bound='mfma', achieved=round(ach, 2), peak=peak, unit='TFLOP/s', frac=round(ach / peak, 4), traffic=None,
-                    kernel=(f'gemm_nt_256_kernel<{a.dtype},{a.dtype}>' if key[2] == 256 else f'gemm_nt_kernel<{a.dtype},{a.dtype},{key[2]}>'), launches_per_step=n // 2,
+                    kernel=(f'gemm_nt_256_kernel<{a.dtype},{a.dtype},act={key[2][1]},dact={key[2][2]}>' if key[2][0] == 256 else f'gemm_nt_kernel<{a.dtype},{a.dtype},{key[2][0]}>'), launches_per_step=n // 2,
                     avg_launch_us=round(t / n * 1e6, 2), flop_per_launch=f / n,
                     all_gemm_tflops=round(total_f / total_t / 1e12, 2), gemm_time_share_of_step=round(total_t / 2 / (dt / a.steps), 3))
         if os.environ.get('A4R_BENCH_SHAPES'):

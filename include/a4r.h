@@ -69,6 +69,16 @@ int a4r_gemm_tn(void* stream, const void* X, int ldx, const void* Y, int ldy, fl
 /* colsum[N] (fp32, +=) = sum over rows of X[M,N]: bias gradients. N % 8 == 0. */
 int a4r_colsum(void* stream, const void* X, int ldx, float* out, int M, int N, int dtype);
 
+/* Fused adapter bottleneck + residual + LayerNorm, forward (bf16 only; H in {128,256,512,768,1024}; dp = 64 padded):
+ *   zp = h Wd^T + bd ; z = act(zp) ; v = z Wu^T + bu (+ h if inner_residual) + x ; y = LayerNorm(v) * gamma + beta
+ * = BertAdaptedSelfOutput.forward (model/model.py:292-297) after its dense+dropout, with AdapterBlock (modules.py:130-134,
+ * inner_residual = 1) or HyperComplexAdapterBlock (modules.py:248-252, inner_residual = 0, effective PHM matrices).
+ * Wd [dp, H], Wu [H, dp] row-major bf16; zp, z [M, dp]; v, y [M, ldv/ldy]; stats [M, 2] (mean, rstd). M % 128 == 0. */
+int a4r_adapter_fwd(void* stream, const void* h, int ldh, const void* x, int ldx, const void* Wd, const float* bd,
+                    const void* Wu, const float* bu, const float* gamma, const float* beta, float eps, int act,
+                    int inner_residual, void* zp, void* z, void* v, int ldv, void* y, int ldy, float* stats,
+                    int M, int H, int dp, int dtype);
+
 /* Short-sequence self-attention, one wave per (item, head), S <= 32, dh in {32, 64}.
  * BERT layer: HF BertSelfAttention (called from model/encoders.py:53); SASRec: SelfAttention
  * model/modules.py:31-42 with the mask of model/encoders.py:24-28.

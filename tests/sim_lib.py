@@ -67,6 +67,23 @@ def gemm_nt(A, B, Cout, bias=None, C2=None, R1=None, R2=None, Pre=None, act=0, d
     Cout[:M] = v.to(Cout.dtype)
 
 
+def adapter_fwd(h, x, Wd, bd, Wu, bu, gamma, beta, eps, act, inner_residual, zp, z, v, y, stats, M=None):
+    M = h.shape[0] if M is None else M
+    assert h.dtype == torch.bfloat16 and Wd.shape[0] == 64 and M % 128 == 0
+    p = h[:M].float() @ Wd.float().t() + bd
+    zp[:M] = p.to(zp.dtype)
+    zz = _act(p, act).to(z.dtype)
+    z[:M] = zz
+    vv = zz.float() @ Wu.float().t() + bu + x[:M].float() + (h[:M].float() if inner_residual else 0)
+    v[:M] = vv.to(v.dtype)
+    vq = v[:M].float()
+    mu = vq.mean(-1, keepdim=True)
+    rstd = torch.rsqrt(((vq - mu) ** 2).mean(-1, keepdim=True) + eps)
+    stats[:M, 0] = mu[:, 0]
+    stats[:M, 1] = rstd[:, 0]
+    y[:M] = ((vq - mu) * rstd * gamma + beta).to(y.dtype)
+
+
 def gemm_tn(X, Y, Cacc, M=None):
     M = X.shape[0] if M is None else M
     assert M % 64 == 0 and X.shape[1] % 64 == 0 and Y.shape[1] % 64 == 0

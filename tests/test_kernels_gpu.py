@@ -462,3 +462,30 @@ def test_eval_rank():
         ref.append(int((s[1:] > tsc).sum()) + 1)
     got = rank.cpu().tolist()
     assert sum(abs(a - b) for a, b in zip(got, ref)) <= 1, (got, ref)     # fp32 vs fp64 near-ties
+
+
+# ------------------------------------------------------------------ fused adapter forward
+@pytest.mark.parametrize('H', [128, 768])
+@pytest.mark.parametrize('act,inner', [(1, 1), (2, 1), (3, 0)])
+def test_adapter_fwd_fused(H, act, inner):
+    from adapter4rec_amd import _lib as L
+    M, dp, t = 384, 64, torch.bfloat16
+    h, x = rnd(M, H, dtype=t, seed=91), rnd(M, H, dtype=t, seed=92)
+    Wd, Wu = rnd(dp, H, dtype=t, scale=0.05, seed=93), rnd(H, dp, dtype=t, scale=0.05, seed=94)
+    bd, bu = rnd(dp, seed=95) * 0.1, rnd(H, seed=96) * 0.1
+    gamma, beta = rnd(H, seed=97) * 0.1 + 1, rnd(H, seed=98) * 0.1
+    zp = torch.zeros(M, dp, dtype=t, device=dev()); z = torch.zeros_like(zp)
+    v = torch.zeros(M, H, dtype=t, device=dev()); y = torch.zeros_like(v)
+    stats = torch.zeros(M, 2, device=dev())
+    L.adapter_fwd(h, x, Wd, bd, Wu, bu, gamma, beta, 1e-12, act, inner, zp, z, v, y, stats)
+    zp_r = h.float() @ Wd.float().t() + bd
+    z_r = act_ref(zp_r, act)
+    zq = z_r.to(t).float()                                   # the kernel feeds the bf16-rounded z into the up projection
+    v_r = zq @ Wu.float().t() + bu + x.float() + (h.float() if inner else 0)
+    y_r = torch.nn.functional.layer_norm(v_r, (H,), gamma, beta, 1e-12)
+    close(zp, zp_r, t, 'adapter zp')
+    close(z, z_r, t, 'adapter z')
+    close(v, v_r, t, 'adapter v')
+    close(y, y_r, t, 'adapter y')
+    close(stats[:, 0], v_r.mean(-1), torch.float32, 'adapter mean', atol32=2e-3, rtol32=1e-3)
+    close(stats[:, 1], torch.rsqrt(v_r.var(-1, unbiased=False) + 1e-12), torch.float32, 'adapter rstd', atol32=2e-3, rtol32=2e-3)
