@@ -43,7 +43,7 @@ template <typename TI, typename TO, int ACT, int DACT>
 __global__ void __launch_bounds__(512, 2) gemm_nt_256_kernel(const a4r_gemm_t p, int ntm, int ntn, uint32_t thr16, float keep_scale) {
     constexpr int ROWB = 128;
     constexpr int KT = ROWB / (int)sizeof(TI);
-    constexpr bool PH2 = false, STAG = false;   // schedule variants measured on MI355X and rejected
+    constexpr bool PH2 = false, STAG = false, PIPE = true;   // schedule variants measured on MI355X and rejected
     __shared__ __attribute__((aligned(16))) char lds[8 * UNIT_BYTES];      // [buffer 2][unit 4][128 rows][128 B]
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -103,17 +103,37 @@ __global__ void __launch_bounds__(512, 2) gemm_nt_256_kernel(const a4r_gemm_t p,
     // run them in OPPOSITE order (STAG): while one wave spends ~200 cycles issuing DMA the other owns the matrix pipe,
     // then they swap -- lockstep partners otherwise issue DMA together and fight for the pipe together.
     const bool mfma_first = STAG && wave >= 4;
-#define A4R_MFMA16(bx_, m0_, n0_)                                                                     \
+#define A4R_MFMA16(ax_, bx_, m0_, n0_)                                                                \
     _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                                  \
         _Pragma("unroll") for (int mi = 0; mi < 4; ++mi)                                              \
             _Pragma("unroll") for (int ni = 0; ni < 2; ++ni)                                          \
-                Mma<TI>::mma(bx_[ni][ks], af[mi][ks], acc[(m0_) + mi][(n0_) + ni]);
+                Mma<TI>::mma(bx_[ni][ks], ax_[mi][ks], acc[(m0_) + mi][(n0_) + ni]);
 #define A4R_PHASE_BODY(issue_, bx_, m0_, n0_)                                                         \
     if (!mfma_first) { issue_ }                                                                       \
     __builtin_amdgcn_sched_barrier(0);                                                                \
-    A4R_MFMA16(bx_, m0_, n0_)                                                                         \
+    A4R_MFMA16(af, bx_, m0_, n0_)                                                                     \
     __builtin_amdgcn_sched_barrier(0);                                                                \
     if (mfma_first) { issue_ }
+    // Software-pipelined phase (PIPE): the fragments of phase k+1 are requested right after barrier k -- which is what
+    // makes them readable -- and arrive while the 16 MFMAs of phase k run on operands read one phase earlier.
+#define A4R_RD_A(dst_, buf_, unit_)                                                                   \
+    _Pragma("unroll") for (int mi = 0; mi < 4; ++mi)                                                  \
+        _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                              \
+            dst_[mi][ks] = *reinterpret_cast<const uint4*>(lds + ((buf_) * 4 + (unit_)) * UNIT_BYTES + a_off[mi][ks]);
+#define A4R_RD_B(dst_, buf_, unit_)                                                                   \
+    _Pragma("unroll") for (int ni = 0; ni < 2; ++ni)                                                  \
+        _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                              \
+            dst_[ni][ks] = *reinterpret_cast<const uint4*>(lds + ((buf_) * 4 + (unit_)) * UNIT_BYTES + b_off[ni][ks]);
+#ifndef A4R_ABL
+#define A4R_ABL 0
+#endif
+#define A4R_PIPE_PHASE(steady_, issue_, reads_, ax_, bx_, m0_, n0_)                                   \
+    A4R_WAIT_BARRIER(steady_)                                                                         \
+    if (!(A4R_ABL & 1)) { issue_ }                                                                    \
+    if (!(A4R_ABL & 4)) { reads_ }                                                                    \
+    __builtin_amdgcn_sched_barrier(0);                                                                \
+    if (!(A4R_ABL & 2)) { A4R_MFMA16(ax_, bx_, m0_, n0_) }                                            \
+    __builtin_amdgcn_sched_barrier(0);
 
     f32x4_t acc[8][4];
 
@@ -142,8 +162,13 @@ __global__ void __launch_bounds__(512, 2) gemm_nt_256_kernel(const a4r_gemm_t p,
     A4R_ISSUE(U_BHI, 0, Bbase, offB_hi)         \
     A4R_ISSUE(U_AHI, 0, Abase, offA_hi)         \
     A4R_ISSUE(U_ALO, 1, Abase, offA_lo)         \
-    A4R_ISSUE(U_BLO, 1, Bbase, offB_lo)         \
-    A4R_ISSUE(U_BHI, 1, Bbase, offB_hi)
+    if constexpr (PIPE) {                       \
+        A4R_ISSUE(U_BHI, 1, Bbase, offB_hi)     \
+        A4R_ISSUE(U_BLO, 1, Bbase, offB_lo)     \
+    } else {                                    \
+        A4R_ISSUE(U_BLO, 1, Bbase, offB_lo)     \
+        A4R_ISSUE(U_BHI, 1, Bbase, offB_hi)     \
+    }
     A4R_PROLOGUE()
     if (nk >= 2) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");        // 7 units issued: A_lo(0), B_lo(0) have landed
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                  // single K-tile (adapter up-projection, K = 64): 4 units
@@ -158,7 +183,30 @@ __global__ void __launch_bounds__(512, 2) gemm_nt_256_kernel(const a4r_gemm_t p,
         for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
     uint4 af[4][2], b0[2][2], b1[2][2];
-    if constexpr (PH2) {
+    if constexpr (PIPE) {
+      // Odd K-tiles walk their quadrants with the roles of B_lo / B_hi swapped (and are streamed in that order), so the
+      // operands of the next phase always land in registers no MFMA of the current phase reads:
+      //   even: (A_lo,B_lo) (A_lo,B_hi) (A_hi,B_hi) (A_hi,B_lo)      odd: (A_lo,B_hi) (A_lo,B_lo) (A_hi,B_lo) (A_hi,B_hi)
+      uint4 a1[4][2];
+      A4R_RD_A(af, 0, U_ALO)
+      A4R_RD_B(b0, 0, U_BLO)
+      for (int u = 0; u < nk; u += 2) {
+        {
+            const bool steady = (u + 2 < nk), nxt = (u + 1 < nk);
+            A4R_PIPE_PHASE(steady, A4R_ISSUE(U_AHI, u + 1, Abase, offA_hi), A4R_RD_B(b1, 0, U_BHI), af, b0, 0, 0)
+            A4R_PIPE_PHASE(steady, A4R_ISSUE(U_ALO, u + 2, Abase, offA_lo), A4R_RD_A(a1, 0, U_AHI), af, b1, 0, 2)
+            A4R_PIPE_PHASE(steady, A4R_ISSUE(U_BLO, u + 2, Bbase, offB_lo), if (nxt) { A4R_RD_A(af, 1, U_ALO) }, a1, b1, 4, 2)
+            A4R_PIPE_PHASE(steady, A4R_ISSUE(U_BHI, u + 2, Bbase, offB_hi), if (nxt) { A4R_RD_B(b1, 1, U_BHI) }, a1, b0, 4, 0)
+        }
+        if (u + 1 < nk) {
+            const bool steady = (u + 3 < nk), nxt = (u + 2 < nk);
+            A4R_PIPE_PHASE(steady, A4R_ISSUE(U_AHI, u + 2, Abase, offA_hi), A4R_RD_B(b0, 1, U_BLO), af, b1, 0, 2)
+            A4R_PIPE_PHASE(steady, A4R_ISSUE(U_ALO, u + 3, Abase, offA_lo), A4R_RD_A(a1, 1, U_AHI), af, b0, 0, 0)
+            A4R_PIPE_PHASE(steady, A4R_ISSUE(U_BHI, u + 3, Bbase, offB_hi), if (nxt) { A4R_RD_A(af, 0, U_ALO) }, a1, b0, 4, 0)
+            A4R_PIPE_PHASE(steady, A4R_ISSUE(U_BLO, u + 3, Bbase, offB_lo), if (nxt) { A4R_RD_B(b0, 0, U_BLO) }, a1, b1, 4, 2)
+        }
+      }
+    } else if constexpr (PH2) {
       // Two phases of 32 MFMAs per K-tile (half the barriers of the 4-phase form):
       //   phase A: read A_lo, B_lo, B_hi | wait | barrier | issue A_hi(u+1)                      | quadrants (0,0), (0,1)
       //   phase B: read A_hi             | wait | barrier | issue A_lo, B_lo, B_hi of tile u+2   | quadrants (1,1), (1,0)
@@ -296,6 +344,9 @@ __global__ void __launch_bounds__(512, 2) gemm_nt_256_kernel(const a4r_gemm_t p,
 #undef A4R_WAIT_BARRIER_N
 #undef A4R_PHASE_BODY
 #undef A4R_MFMA16
+#undef A4R_RD_A
+#undef A4R_RD_B
+#undef A4R_PIPE_PHASE
 }
 
 template <typename TI, typename TO, int ACT, int DACT>

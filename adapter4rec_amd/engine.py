@@ -329,7 +329,7 @@ class TransRecEngine:
         if emb.LayerNorm.weight.requires_grad:
             raise NotImplementedError('training the embedding LayerNorm (--finetune_layernorm) is not wired yet')
         self.cls_only = bool(getattr(self.args, 'cls_only_last', True))
-        self.fuse_adapters = bool(getattr(self.args, 'fuse_adapters', True))
+        self.fuse_adapters = bool(getattr(self.args, 'fuse_adapters', False))
         self.roberta = g['model_type'] == 'roberta'
         self.pad_id = int(g['pad_token_id'])
         self.p_hidden = float(g['hidden_dropout_prob'])

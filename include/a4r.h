@@ -73,7 +73,7 @@ int a4r_colsum(void* stream, const void* X, int ldx, float* out, int M, int N, i
  *   zp = h Wd^T + bd ; z = act(zp) ; v = z Wu^T + bu (+ h if inner_residual) + x ; y = LayerNorm(v) * gamma + beta
  * = BertAdaptedSelfOutput.forward (model/model.py:292-297) after its dense+dropout, with AdapterBlock (modules.py:130-134,
  * inner_residual = 1) or HyperComplexAdapterBlock (modules.py:248-252, inner_residual = 0, effective PHM matrices).
- * Wd [dp, H], Wu [H, dp] row-major bf16; zp, z [M, dp]; v, y [M, ldv/ldy]; stats [M, 2] (mean, rstd). M % 128 == 0. */
+ * Wd [dp, H], Wu [H, dp] row-major bf16; zp, z [M, dp]; v, y [M, ldv/ldy]; stats [M, 2] (mean, rstd). M % 64 == 0. */
 int a4r_adapter_fwd(void* stream, const void* h, int ldh, const void* x, int ldx, const void* Wd, const float* bd,
                     const void* Wu, const float* bu, const float* gamma, const float* beta, float eps, int act,
                     int inner_residual, void* zp, void* z, void* v, int ldv, void* y, int ldy, float* stats,

@@ -69,7 +69,7 @@ def gemm_nt(A, B, Cout, bias=None, C2=None, R1=None, R2=None, Pre=None, act=0, d
 
 def adapter_fwd(h, x, Wd, bd, Wu, bu, gamma, beta, eps, act, inner_residual, zp, z, v, y, stats, M=None):
     M = h.shape[0] if M is None else M
-    assert h.dtype == torch.bfloat16 and Wd.shape[0] == 64 and M % 128 == 0
+    assert h.dtype == torch.bfloat16 and Wd.shape[0] == 64 and M % 64 == 0
     p = h[:M].float() @ Wd.float().t() + bd
     zp[:M] = p.to(zp.dtype)
     zz = _act(p, act).to(z.dtype)
