@@ -21,7 +21,7 @@ EXPORTS = [
     'a4r_version', 'a4r_gemm_nt', 'a4r_gemm_tn', 'a4r_colsum', 'a4r_attn_fwd', 'a4r_attn_bwd', 'a4r_embed_ln',
     'a4r_ln_fwd', 'a4r_ln_bwd', 'a4r_gather_rows', 'a4r_scatter_rows', 'a4r_act_bwd_f32', 'a4r_score_bce_fwd',
     'a4r_score_bce_bwd', 'a4r_emb_grad_add_inputs', 'a4r_take_inputs', 'a4r_adam_step', 'a4r_pack_matrices',
-    'a4r_eval_rank', 'a4r_dropout_apply', 'a4r_gemm_variant', 'a4r_adapter_fwd',
+    'a4r_eval_rank', 'a4r_dropout_apply', 'a4r_gemm_variant', 'a4r_adapter_fwd', 'a4r_attn_long_fwd', 'a4r_attn_long_bwd',
 ]
 
 
@@ -173,6 +173,22 @@ def attn_bwd(qkv, dout, dqkv, key_mask, n_items, S, n_heads, dh, q_off, k_off, v
     a = _attn_args(qkv, q_off, k_off, v_off, key_mask, n_items, S, n_heads, dh, causal, scale, mask_neg, drop_p, drop_site, drop_seed)
     a.dout, a.ldo, a.dqkv = _p(dout), _ld(dout), _p(dqkv)
     _check(lib().a4r_attn_bwd(_stream(), C.byref(a)), 'a4r_attn_bwd')
+
+
+def attn_long_fwd(qkv, out, lse, n_items, S, n_heads, dh, q_off, k_off, v_off, scale):
+    require_gpu(qkv, out, lse)
+    assert lse.dtype == torch.float32 and lse.numel() >= n_items * n_heads * S
+    a = _attn_args(qkv, q_off, k_off, v_off, None, n_items, S, n_heads, dh, False, scale, 0.0, 0.0, 0, 0)
+    a.out, a.ldo = _p(out), _ld(out)
+    _check(lib().a4r_attn_long_fwd(_stream(), C.byref(a), _p(lse)), 'a4r_attn_long_fwd')
+
+
+def attn_long_bwd(qkv, dout, dqkv, lse, delta_ws, n_items, S, n_heads, dh, q_off, k_off, v_off, scale):
+    require_gpu(qkv, dout, dqkv, lse, delta_ws)
+    assert _ld(dqkv) == _ld(qkv) and delta_ws.dtype == torch.float32 and delta_ws.numel() >= n_items * n_heads * S
+    a = _attn_args(qkv, q_off, k_off, v_off, None, n_items, S, n_heads, dh, False, scale, 0.0, 0.0, 0, 0)
+    a.dout, a.ldo, a.dqkv = _p(dout), _ld(dout), _p(dqkv)
+    _check(lib().a4r_attn_long_bwd(_stream(), C.byref(a), _p(lse), _p(delta_ws)), 'a4r_attn_long_bwd')
 
 
 def embed_ln(ids, word, pos, type0, gamma, beta, eps, out, n_items, S, roberta=False, pad_id=0,

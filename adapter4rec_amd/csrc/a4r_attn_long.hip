@@ -1,0 +1,398 @@
+// a4r_attn_long_fwd / a4r_attn_long_bwd: un-masked multi-head attention for 32 < S <= 256 tokens per item, head width 64
+// -- the ViT / MAE item tower (S = 197 / 50; HF ViTSelfAttention as called from Downstream/CV/model/encoders.py:21-32).
+// The S <= 32 kernels of a4r_attn.hip keep a whole score matrix in one wave; here one workgroup (4 waves) owns one
+// (item, head) pair, stages the key-side matrices of that pair in LDS and never writes anything S x S to HBM.
+//
+// Everything is the 16x16 "chunk" primitive of a4r_common.h (so the bf16 and exact-fp32 instantiations share all
+// addressing).  A score tile is produced TRANSPOSED (key-side fragment first): lane (c = l & 15, kg = l >> 4) then holds,
+// for ONE query column c, the 4 consecutive keys 16*kt + 4*kg + r.  The whole key range of a 16-query block lives in
+// registers (<= 16 tiles), so the softmax is plain register arithmetic + two cross-lane steps (l ^ 16, l ^ 32), and the
+// probabilities feed the next product as an MFMA operand WITHOUT any re-layout by permuting the contraction index:
+//     k-slot (kg, j) of chunk step st  <->  key  KSTEP*st + (j >> 2)*16 + 4*kg + (j & 3)
+// (two score tiles per step for bf16, one for fp32).  The other operand of such a product needs, per lane, 4 + 4
+// consecutive KEYS at one head column -- i.e. a transposed copy of V (or K, Q, dO), which is written once per workgroup
+// when the matrix is staged ([64][S_pad + 8] elements: 8-byte reads, conflict-free per half wave).
+//
+// forward  (per 16-query block): S^T = K Q^T | softmax | O^T = V^T P^T         + lse = max + log(sum) per query (fp32)
+// backward, two launches (FlashAttention-2 split, no atomics):
+//   dq   (per 16-query block): S^T, dP^T = V dO^T, delta = sum_k P dP, dS = P (dP - delta) scale, dQ^T = K^T dS^T
+//   dkdv (per 16-key tile, a wave owns its key tiles): S = Q K^T, dP = dO V^T (tiles with the KEY on the lane),
+//        dV^T += dO^T P, dK^T += Q^T dS  over all query groups; lse and delta come from LDS.
+// HBM-bound in principle (fwd: reads 3 M H, writes M H); measured numbers are in DESIGN.md.
+#include "a4r_common.h"
+#include "../../include/a4r.h"
+
+namespace {
+
+template <typename T> A4R_DEV uint4 ldg16(const T* p) { return *reinterpret_cast<const uint4*>(p); }
+
+template <typename T> struct Geo {
+    static constexpr int PER = Elem<T>::PER16;              // elements per 16-byte chunk
+    static constexpr int KSTEP = Mma<T>::KSTEP;             // contraction length of one chunk step (32 / 16)
+    static constexpr int KS = 64 / KSTEP;                   // chunk steps over the head width (2 / 4)
+    static constexpr int CPR = 64 / PER;                    // chunks per row of a [*, 64] matrix (8 / 16)
+    static constexpr int ROWB = 64 * (int)sizeof(T);        // row bytes (128 / 256)
+    static constexpr int TPS = KSTEP / 16;                  // score tiles per chunk step (2 / 1)
+    static A4R_DEV int swz(int row) { return CPR == 8 ? ((row >> 1) & 7) : (row & 15); }
+};
+
+// [S][64] (global, row stride ld) -> LDS row-major [SP][64], 16-byte chunks XOR-swizzled; rows >= S are zero
+template <typename T> A4R_DEV void stage_rows(char* lds, const T* src, int ld, int S, int SP, int tid) {
+    using G = Geo<T>;
+    for (int id = tid; id < SP * G::CPR; id += 256) {
+        const int r = id / G::CPR, c = id % G::CPR;
+        const uint4 v = r < S ? ldg16(src + (size_t)r * ld + c * G::PER) : make_uint4(0, 0, 0, 0);
+        *reinterpret_cast<uint4*>(lds + r * G::ROWB + ((c ^ G::swz(r)) << 4)) = v;
+    }
+}
+// [S][64] -> LDS transposed [64][SPT] (SPT = SP + 8 elements); columns >= S are zero
+template <typename T> A4R_DEV void stage_cols(T* lds, const T* src, int ld, int S, int SP, int SPT, int tid) {
+    using G = Geo<T>;
+    for (int id = tid; id < SP * G::CPR; id += 256) {
+        const int c = id / SP, r = id % SP;                  // consecutive lanes -> consecutive rows: LDS stores spread over banks
+        const uint4 v = r < S ? ldg16(src + (size_t)r * ld + c * G::PER) : make_uint4(0, 0, 0, 0);
+        const T* e = reinterpret_cast<const T*>(&v);
+#pragma unroll
+        for (int j = 0; j < G::PER; ++j) lds[(c * G::PER + j) * SPT + r] = e[j];
+    }
+}
+// operand chunk from a row-major image: row `row`, chunk step ks
+template <typename T> A4R_DEV uint4 frag_rows(const char* lds, int row, int ks, int kg) {
+    using G = Geo<T>;
+    return *reinterpret_cast<const uint4*>(lds + row * G::ROWB + (((ks * 4 + kg) ^ G::swz(row)) << 4));
+}
+// operand chunk from a transposed image: head column d, chunk step st over the (permuted) key/query index
+template <typename T> A4R_DEV uint4 frag_cols(const T* lds, int SPT, int d, int st, int kg) {
+    using G = Geo<T>;
+    const T* p = lds + d * SPT + G::KSTEP * st + 4 * kg;
+    if constexpr (sizeof(T) == 2) {
+        const uint2 lo = *reinterpret_cast<const uint2*>(p), hi = *reinterpret_cast<const uint2*>(p + 16);
+        return make_uint4(lo.x, lo.y, hi.x, hi.y);
+    } else {
+        return *reinterpret_cast<const uint4*>(p);
+    }
+}
+// probabilities / score gradients of chunk step st as an operand chunk (see the k-slot permutation in the header)
+template <typename T, int NKT> A4R_DEV uint4 pack_step(const f32x4_t (&t)[NKT], int st) {
+    if constexpr (sizeof(T) == 2) {
+        const f32x4_t a = t[2 * st], b = t[2 * st + 1];
+        return make_uint4(f32_to_bf16_bits(a[0]) | (f32_to_bf16_bits(a[1]) << 16), f32_to_bf16_bits(a[2]) | (f32_to_bf16_bits(a[3]) << 16),
+                          f32_to_bf16_bits(b[0]) | (f32_to_bf16_bits(b[1]) << 16), f32_to_bf16_bits(b[2]) | (f32_to_bf16_bits(b[3]) << 16));
+    } else {
+        const f32x4_t a = t[st];
+        return make_uint4(__float_as_uint(a[0]), __float_as_uint(a[1]), __float_as_uint(a[2]), __float_as_uint(a[3]));
+    }
+}
+// 4 consecutive head columns of one row, fp32 registers -> global
+template <typename T> A4R_DEV void store4(T* p, const f32x4_t& v) {
+    if constexpr (sizeof(T) == 2)
+        *reinterpret_cast<uint2*>(p) = make_uint2(f32_to_bf16_bits(v[0]) | (f32_to_bf16_bits(v[1]) << 16),
+                                                  f32_to_bf16_bits(v[2]) | (f32_to_bf16_bits(v[3]) << 16));
+    else
+        *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
+}
+A4R_DEV float red4(float v, bool mx) {       // over the 4 lanes l, l^16, l^32, l^48 that share a column
+    const float a = __shfl_xor(v, 16, 64);
+    v = mx ? fmaxf(v, a) : v + a;
+    const float b = __shfl_xor(v, 32, 64);
+    return mx ? fmaxf(v, b) : v + b;
+}
+
+// transposed score tiles of one 16-query block: s[kt][r] = scale * q[query c] . k[key 16 kt + 4 kg + r]  (keys >= S: -inf)
+template <typename T, int NKT>
+A4R_DEV void scores_t(const char* Kr, const uint4 (&qf)[Geo<T>::KS], f32x4_t (&s)[NKT], int S, float scale, int fr, int kg) {
+    using G = Geo<T>;
+#pragma unroll
+    for (int kt = 0; kt < NKT; ++kt) {
+        f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < G::KS; ++ks) Mma<T>::mma(frag_rows<T>(Kr, kt * 16 + fr, ks, kg), qf[ks], acc);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[r] = (kt * 16 + kg * 4 + r < S) ? acc[r] * scale : -INFINITY;
+        s[kt] = acc;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ forward
+template <typename T, int NKT>
+__global__ void __launch_bounds__(256) attn_long_fwd_kernel(const T* __restrict__ qkv, int ld, int q_off, int k_off, int v_off,
+                                                            T* __restrict__ ctx, int ldo, float* __restrict__ lse,
+                                                            int S, int nh, float scale) {
+    using G = Geo<T>;
+    constexpr int SP = NKT * 16, SPT = SP + 8, NST = SP / G::KSTEP;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* Kr = smem;                                                  // [SP][64] row-major
+    T* Vt = reinterpret_cast<T*>(smem + SP * G::ROWB);                // [64][SPT] transposed
+    const int item = blockIdx.x / nh, h = blockIdx.x % nh;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, fr = lane & 15, kg = lane >> 4;
+    const T* base = qkv + (size_t)item * S * ld + h * 64;
+    stage_rows<T>(Kr, base + k_off, ld, S, SP, tid);
+    stage_cols<T>(Vt, base + v_off, ld, S, SP, SPT, tid);
+    __syncthreads();
+    const int nqb = (S + 15) >> 4;
+    for (int qb = wave; qb < nqb; qb += 4) {
+        const int rq = qb * 16 + fr;
+        const bool valid = rq < S;
+        uint4 qf[G::KS];
+#pragma unroll
+        for (int ks = 0; ks < G::KS; ++ks)
+            qf[ks] = valid ? ldg16(base + q_off + (size_t)rq * ld + (ks * 4 + kg) * G::PER) : make_uint4(0, 0, 0, 0);
+        f32x4_t s[NKT];
+        scores_t<T, NKT>(Kr, qf, s, S, scale, fr, kg);
+        float m = -INFINITY;
+#pragma unroll
+        for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) m = fmaxf(m, s[kt][r]);
+        m = red4(m, true);
+        float l = 0.f;
+#pragma unroll
+        for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { s[kt][r] = __expf(s[kt][r] - m); l += s[kt][r]; }
+        l = red4(l, false);
+        const float inv = 1.f / l;
+#pragma unroll
+        for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) s[kt][r] *= inv;
+        if (valid && kg == 0) lse[((size_t)item * nh + h) * S + rq] = m + __logf(l);
+        uint4 pf[NST];
+#pragma unroll
+        for (int st = 0; st < NST; ++st) pf[st] = pack_step<T, NKT>(s, st);
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) {
+            f32x4_t o = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int st = 0; st < NST; ++st) Mma<T>::mma(frag_cols<T>(Vt, SPT, dt * 16 + fr, st, kg), pf[st], o);
+            if (valid) store4<T>(ctx + ((size_t)item * S + rq) * ldo + h * 64 + dt * 16 + kg * 4, o);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ backward: dq + delta
+template <typename T, int NKT>
+__global__ void __launch_bounds__(256) attn_long_dq_kernel(const T* __restrict__ qkv, int ld, int q_off, int k_off, int v_off,
+                                                           const T* __restrict__ dctx, int ldo, const float* __restrict__ lse,
+                                                           float* __restrict__ delta, T* __restrict__ dqkv,
+                                                           int S, int nh, float scale) {
+    using G = Geo<T>;
+    constexpr int SP = NKT * 16, SPT = SP + 8, NST = SP / G::KSTEP;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* Kr = smem;
+    char* Vr = smem + SP * G::ROWB;
+    T* Kt = reinterpret_cast<T*>(smem + 2 * SP * G::ROWB);
+    const int item = blockIdx.x / nh, h = blockIdx.x % nh;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, fr = lane & 15, kg = lane >> 4;
+    const T* base = qkv + (size_t)item * S * ld + h * 64;
+    stage_rows<T>(Kr, base + k_off, ld, S, SP, tid);
+    stage_rows<T>(Vr, base + v_off, ld, S, SP, tid);
+    stage_cols<T>(Kt, base + k_off, ld, S, SP, SPT, tid);
+    __syncthreads();
+    const int nqb = (S + 15) >> 4;
+    for (int qb = wave; qb < nqb; qb += 4) {
+        const int rq = qb * 16 + fr;
+        const bool valid = rq < S;
+        const size_t grow = (size_t)item * S + rq;
+        uint4 qf[G::KS], dof[G::KS];
+#pragma unroll
+        for (int ks = 0; ks < G::KS; ++ks) {
+            qf[ks] = valid ? ldg16(base + q_off + (size_t)rq * ld + (ks * 4 + kg) * G::PER) : make_uint4(0, 0, 0, 0);
+            dof[ks] = valid ? ldg16(dctx + grow * ldo + h * 64 + (ks * 4 + kg) * G::PER) : make_uint4(0, 0, 0, 0);
+        }
+        const float lq = valid ? lse[((size_t)item * nh + h) * S + rq] : 0.f;
+        f32x4_t p[NKT];
+        scores_t<T, NKT>(Kr, qf, p, S, scale, fr, kg);
+        // pass 1: delta = sum_k P dP (dP tiles are not kept: holding P and dP for 16 tiles spilled); pass 2 recomputes each
+        // dP tile (2-4 MFMAs) and turns P into dS in place
+        float dsum = 0.f;
+#pragma unroll
+        for (int kt = 0; kt < NKT; ++kt) {
+            f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ks = 0; ks < G::KS; ++ks) Mma<T>::mma(frag_rows<T>(Vr, kt * 16 + fr, ks, kg), dof[ks], acc);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                p[kt][r] = __expf(p[kt][r] - lq);          // exp(-inf) = 0 for the padded keys
+                dsum += p[kt][r] * acc[r];
+            }
+        }
+        dsum = red4(dsum, false);
+        if (valid && kg == 0) delta[((size_t)item * nh + h) * S + rq] = dsum;
+#pragma unroll
+        for (int kt = 0; kt < NKT; ++kt) {
+            f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ks = 0; ks < G::KS; ++ks) Mma<T>::mma(frag_rows<T>(Vr, kt * 16 + fr, ks, kg), dof[ks], acc);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) p[kt][r] = p[kt][r] * (acc[r] - dsum) * scale;
+        }
+        uint4 dsf[NST];
+#pragma unroll
+        for (int st = 0; st < NST; ++st) dsf[st] = pack_step<T, NKT>(p, st);
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) {
+            f32x4_t o = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int st = 0; st < NST; ++st) Mma<T>::mma(frag_cols<T>(Kt, SPT, dt * 16 + fr, st, kg), dsf[st], o);
+            if (valid) store4<T>(dqkv + grow * ld + q_off + h * 64 + dt * 16 + kg * 4, o);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ backward: dk, dv
+template <typename T, int NKT>
+__global__ void __launch_bounds__(256) attn_long_dkdv_kernel(const T* __restrict__ qkv, int ld, int q_off, int k_off, int v_off,
+                                                             const T* __restrict__ dctx, int ldo, const float* __restrict__ lse,
+                                                             const float* __restrict__ delta, T* __restrict__ dqkv,
+                                                             int S, int nh, float scale) {
+    using G = Geo<T>;
+    constexpr int SP = NKT * 16, SPT = SP + 8, NG = SP / G::KSTEP;          // NG query groups of KSTEP queries
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* Qr = smem;
+    char* Or = smem + SP * G::ROWB;
+    T* Qt = reinterpret_cast<T*>(smem + 2 * SP * G::ROWB);
+    T* Ot = Qt + 64 * SPT;
+    float* lse_s = reinterpret_cast<float*>(Ot + 64 * SPT);
+    float* del_s = lse_s + SP;
+    const int item = blockIdx.x / nh, h = blockIdx.x % nh;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, fr = lane & 15, kg = lane >> 4;
+    const T* base = qkv + (size_t)item * S * ld + h * 64;
+    const T* dob = dctx + (size_t)item * S * ldo + h * 64;
+    stage_rows<T>(Qr, base + q_off, ld, S, SP, tid);
+    stage_rows<T>(Or, dob, ldo, S, SP, tid);
+    stage_cols<T>(Qt, base + q_off, ld, S, SP, SPT, tid);
+    stage_cols<T>(Ot, dob, ldo, S, SP, SPT, tid);
+    for (int i = tid; i < SP; i += 256) {
+        lse_s[i] = i < S ? lse[((size_t)item * nh + h) * S + i] : 0.f;
+        del_s[i] = i < S ? delta[((size_t)item * nh + h) * S + i] : 0.f;
+    }
+    __syncthreads();
+    const int nkt = (S + 15) >> 4;
+    for (int kt = wave; kt < nkt; kt += 4) {
+        const int rk = kt * 16 + fr;                          // this lane's key (column of every tile below)
+        const bool kvalid = rk < S;
+        uint4 kf[G::KS], vf[G::KS];
+#pragma unroll
+        for (int ks = 0; ks < G::KS; ++ks) {
+            kf[ks] = kvalid ? ldg16(base + k_off + (size_t)rk * ld + (ks * 4 + kg) * G::PER) : make_uint4(0, 0, 0, 0);
+            vf[ks] = kvalid ? ldg16(base + v_off + (size_t)rk * ld + (ks * 4 + kg) * G::PER) : make_uint4(0, 0, 0, 0);
+        }
+        f32x4_t dk[4], dv[4];
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) { dk[dt] = f32x4_t{0.f, 0.f, 0.f, 0.f}; dv[dt] = f32x4_t{0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll 1
+        for (int g = 0; g < NG; ++g) {
+            f32x4_t p[G::TPS], ds[G::TPS];
+#pragma unroll
+            for (int t = 0; t < G::TPS; ++t) {
+                const int q0 = g * G::KSTEP + t * 16;         // tile rows = queries q0 + 4 kg + r, column = key rk
+                f32x4_t sc = {0.f, 0.f, 0.f, 0.f}, dpt = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int ks = 0; ks < G::KS; ++ks) {
+                    Mma<T>::mma(frag_rows<T>(Qr, q0 + fr, ks, kg), kf[ks], sc);
+                    Mma<T>::mma(frag_rows<T>(Or, q0 + fr, ks, kg), vf[ks], dpt);
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int q = q0 + kg * 4 + r;
+                    const float pv = (kvalid && q < S) ? __expf(sc[r] * scale - lse_s[q]) : 0.f;
+                    p[t][r] = pv;
+                    ds[t][r] = pv * (dpt[r] - del_s[q]) * scale;
+                }
+            }
+            const uint4 pf = pack_step<T, G::TPS>(p, 0), dsf = pack_step<T, G::TPS>(ds, 0);
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) {
+                Mma<T>::mma(frag_cols<T>(Ot, SPT, dt * 16 + fr, g, kg), pf, dv[dt]);
+                Mma<T>::mma(frag_cols<T>(Qt, SPT, dt * 16 + fr, g, kg), dsf, dk[dt]);
+            }
+        }
+        if (kvalid) {
+            T* row = dqkv + ((size_t)item * S + rk) * ld + h * 64 + kg * 4;
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) {
+                store4<T>(row + k_off + dt * 16, dk[dt]);
+                store4<T>(row + v_off + dt * 16, dv[dt]);
+            }
+        }
+    }
+}
+
+template <typename T> int nkt_for(int S) { return S <= 32 ? 2 : S <= 64 ? 4 : S <= 128 ? 8 : S <= 224 ? 14 : 16; }
+
+template <typename T, int NKT> size_t lds_fwd() { return (size_t)NKT * 16 * Geo<T>::ROWB + 64 * (NKT * 16 + 8) * sizeof(T); }
+template <typename T, int NKT> size_t lds_dq() { return 2 * (size_t)NKT * 16 * Geo<T>::ROWB + 64 * (NKT * 16 + 8) * sizeof(T); }
+template <typename T, int NKT> size_t lds_dkdv() {
+    return 2 * (size_t)NKT * 16 * Geo<T>::ROWB + 2 * 64 * (NKT * 16 + 8) * sizeof(T) + 2 * NKT * 16 * sizeof(float);
+}
+constexpr size_t LDS_MAX = 160 * 1024;
+
+template <typename K> int set_lds(K kernel, size_t bytes) {
+    if (bytes > LDS_MAX) return A4R_EINVAL;
+    if (bytes > 48 * 1024 && hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) != hipSuccess)
+        return A4R_ELAUNCH;
+    return A4R_OK;
+}
+
+template <typename T, int NKT> int run_fwd(hipStream_t s, const a4r_attn_t* a, float* lse) {
+    const size_t lds = lds_fwd<T, NKT>();
+    if (int rc = set_lds(attn_long_fwd_kernel<T, NKT>, lds)) return rc;
+    hipLaunchKernelGGL((attn_long_fwd_kernel<T, NKT>), dim3(a->n_items * a->n_heads), dim3(256), lds, s, (const T*)a->qkv, a->ld, a->q_off,
+                       a->k_off, a->v_off, (T*)a->out, a->ldo, lse, a->S, a->n_heads, a->scale);
+    return a4r_launch_status();
+}
+template <typename T, int NKT> int run_bwd(hipStream_t s, const a4r_attn_t* a, const float* lse, float* delta) {
+    const size_t l1 = lds_dq<T, NKT>(), l2 = lds_dkdv<T, NKT>();
+    if (int rc = set_lds(attn_long_dq_kernel<T, NKT>, l1)) return rc;
+    if (int rc = set_lds(attn_long_dkdv_kernel<T, NKT>, l2)) return rc;
+    const dim3 grid(a->n_items * a->n_heads), block(256);
+    hipLaunchKernelGGL((attn_long_dq_kernel<T, NKT>), grid, block, l1, s, (const T*)a->qkv, a->ld, a->q_off, a->k_off, a->v_off,
+                       (const T*)a->dout, a->ldo, lse, delta, (T*)a->dqkv, a->S, a->n_heads, a->scale);
+    hipLaunchKernelGGL((attn_long_dkdv_kernel<T, NKT>), grid, block, l2, s, (const T*)a->qkv, a->ld, a->q_off, a->k_off, a->v_off,
+                       (const T*)a->dout, a->ldo, lse, (const float*)delta, (T*)a->dqkv, a->S, a->n_heads, a->scale);
+    return a4r_launch_status();
+}
+
+int check(const a4r_attn_t* a, bool bwd) {
+    if (!a || !a->qkv || a->n_items <= 0 || a->S <= 0 || a->S > 256 || a->dh != 64 || a->n_heads <= 0) return A4R_EINVAL;
+    if (a->key_mask || a->causal || a->drop_p != 0.f) return A4R_EINVAL;           // the ViT / MAE tower uses none of them
+    if (a->dtype != A4R_BF16 && a->dtype != A4R_F32) return A4R_EINVAL;
+    const int es = a->dtype == A4R_BF16 ? 2 : 4;
+    if ((a->ld * es) % 16 || (a->ldo * es) % 16 || (a->q_off * es) % 16 || (a->k_off * es) % 16 || (a->v_off * es) % 16) return A4R_EINVAL;
+    if (reinterpret_cast<uintptr_t>(a->qkv) & 15u) return A4R_EINVAL;
+    if (!bwd && (!a->out || (reinterpret_cast<uintptr_t>(a->out) & 15u))) return A4R_EINVAL;
+    if (bwd && (!a->dout || !a->dqkv || ((reinterpret_cast<uintptr_t>(a->dout) | reinterpret_cast<uintptr_t>(a->dqkv)) & 15u))) return A4R_EINVAL;
+    return A4R_OK;
+}
+
+#define A4R_NKT_SWITCH(T_, CALL_)                       \
+    switch (nkt_for<T_>(a->S)) {                        \
+        case 2: return CALL_(T_, 2);                    \
+        case 4: return CALL_(T_, 4);                    \
+        case 8: return CALL_(T_, 8);                    \
+        case 14: return CALL_(T_, 14);                  \
+        default: return CALL_(T_, 16);                  \
+    }
+
+}  // namespace
+
+extern "C" int a4r_attn_long_fwd(void* stream, const a4r_attn_t* a, float* lse) {
+    if (int rc = check(a, false)) return rc;
+    if (!lse) return A4R_EINVAL;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+#define A4R_F(T_, N_) run_fwd<T_, N_>(s, a, lse)
+    if (a->dtype == A4R_BF16) { A4R_NKT_SWITCH(bf16_t, A4R_F) }
+    A4R_NKT_SWITCH(float, A4R_F)
+#undef A4R_F
+}
+
+extern "C" int a4r_attn_long_bwd(void* stream, const a4r_attn_t* a, const float* lse, float* delta_ws) {
+    if (int rc = check(a, true)) return rc;
+    if (!lse || !delta_ws) return A4R_EINVAL;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+#define A4R_B(T_, N_) run_bwd<T_, N_>(s, a, lse, delta_ws)
+    if (a->dtype == A4R_BF16) { A4R_NKT_SWITCH(bf16_t, A4R_B) }
+    A4R_NKT_SWITCH(float, A4R_B)
+#undef A4R_B
+}

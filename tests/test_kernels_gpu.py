@@ -234,6 +234,53 @@ def test_attention_fwd_bwd(dt, name, S, nh, dh, causal, neg):
           atol16=4e-2 * float(qr.grad.abs().max()))
 
 
+LONG_CASES = [('f32', 33, 2), ('f32', 50, 12), ('f32', 64, 3), ('f32', 100, 2), ('f32', 128, 2),
+              ('bf16', 33, 2), ('bf16', 50, 12), ('bf16', 65, 3), ('bf16', 128, 2), ('bf16', 197, 12), ('bf16', 224, 2), ('bf16', 256, 2)]
+
+
+@pytest.mark.parametrize('dt,S,nh', LONG_CASES)
+def test_attention_long_fwd_bwd(dt, S, nh):
+    """a4r_attn_long_*: the un-masked ViT / MAE attention (S up to 256, dh 64) against fp32 torch softmax(QK^T/8)V."""
+    from adapter4rec_amd import _lib as L
+    t = DT[dt]
+    n_items, dh = 5, 64
+    Hd = nh * dh
+    Mp = ((n_items * S + 255) // 256) * 256
+    qkv = rnd(Mp, 3 * Hd, dtype=t, seed=31 + S)
+    scale = 1.0 / math.sqrt(dh)
+    offs = (0, Hd, 2 * Hd)
+    out = torch.zeros(Mp, Hd, dtype=t, device=dev())
+    lse = torch.zeros(n_items * nh * S, device=dev())
+    L.attn_long_fwd(qkv, out, lse, n_items, S, nh, dh, *offs, scale)
+    qr = qkv.float().clone().requires_grad_(True)
+    ref = attn_ref(qr, torch.ones(n_items, S, device=dev()), n_items, S, nh, dh, False, scale, 0.0, offs)
+    close(out[:n_items * S], ref.detach(), t, f'attn_long fwd S={S} {dt}', atol32=1e-4, rtol32=1e-4)
+    assert torch.count_nonzero(out[n_items * S:]) == 0
+    q, k = [qkv[:n_items * S, o:o + Hd].float().view(n_items, S, nh, dh).transpose(1, 2) for o in offs[:2]]
+    lse_ref = torch.logsumexp(q @ k.transpose(-1, -2) * scale, -1).reshape(-1)
+    close(lse, lse_ref, torch.float32, 'lse', atol32=1e-3 if t == torch.float32 else 2e-2, rtol32=1e-3)
+    dout = rnd(Mp, Hd, dtype=t, seed=32)
+    dout[n_items * S:] = 0
+    dqkv = torch.zeros_like(qkv)
+    ws = torch.zeros_like(lse)
+    L.attn_long_bwd(qkv, dout, dqkv, lse, ws, n_items, S, nh, dh, *offs, scale)
+    ref.backward(dout[:n_items * S].float())
+    close(dqkv[:n_items * S], qr.grad[:n_items * S], t, f'attn_long bwd S={S} {dt}', atol32=2e-4, rtol32=2e-4,
+          atol16=4e-2 * float(qr.grad.abs().max()))
+    assert torch.count_nonzero(dqkv[n_items * S:]) == 0
+
+
+def test_attention_long_rejects():
+    from adapter4rec_amd import _lib as L
+    qkv = torch.zeros(512, 192, device=dev())
+    out = torch.zeros(512, 64, device=dev())
+    lse = torch.zeros(512, device=dev())
+    with pytest.raises(RuntimeError):                                          # fp32 backward needs S <= 128 (LDS)
+        L.attn_long_bwd(qkv, out, torch.zeros_like(qkv), lse, torch.zeros_like(lse), 2, 200, 1, 64, 0, 64, 128, 0.125)
+    with pytest.raises(RuntimeError):
+        L.attn_long_fwd(qkv, out, lse, 1, 300, 1, 64, 0, 64, 128, 0.125)       # S > 256
+
+
 @pytest.mark.parametrize('dt', ['f32', 'bf16'])
 def test_attention_dropout_adjoint(dt):
     """With dropout on, out is linear in V: <out, dO> == <V, dV> iff fwd and bwd regenerate the same mask."""
