@@ -21,7 +21,7 @@ EXPORTS = [
     'a4r_version', 'a4r_gemm_nt', 'a4r_gemm_tn', 'a4r_colsum', 'a4r_attn_fwd', 'a4r_attn_bwd', 'a4r_embed_ln',
     'a4r_ln_fwd', 'a4r_ln_bwd', 'a4r_gather_rows', 'a4r_scatter_rows', 'a4r_act_bwd_f32', 'a4r_score_bce_fwd',
     'a4r_score_bce_bwd', 'a4r_emb_grad_add_inputs', 'a4r_take_inputs', 'a4r_adam_step', 'a4r_pack_matrices',
-    'a4r_eval_rank', 'a4r_dropout_apply', 'a4r_gemm_variant', 'a4r_adapter_fwd', 'a4r_attn_long_fwd', 'a4r_attn_long_bwd',
+    'a4r_eval_rank', 'a4r_dropout_apply', 'a4r_gemm_variant', 'a4r_adapter_fwd', 'a4r_attn_long_fwd', 'a4r_attn_long_bwd', 'a4r_patchify', 'a4r_vit_assemble',
 ]
 
 
@@ -189,6 +189,28 @@ def attn_long_bwd(qkv, dout, dqkv, lse, delta_ws, n_items, S, n_heads, dh, q_off
     a = _attn_args(qkv, q_off, k_off, v_off, None, n_items, S, n_heads, dh, False, scale, 0.0, 0.0, 0, 0)
     a.dout, a.ldo, a.dqkv = _p(dout), _ld(dout), _p(dqkv)
     _check(lib().a4r_attn_long_bwd(_stream(), C.byref(a), _p(lse), _p(delta_ws)), 'a4r_attn_long_bwd')
+
+
+def patchify(img, out, patch, keep_idx=None):
+    """img fp32 [n, C, H, W] (normalised) or uint8 [n, H, W, C] (raw) -> out [n * n_keep, >= C*patch*patch]."""
+    require_gpu(img, out)
+    assert img.is_contiguous()
+    if img.dtype == torch.uint8:
+        kind, (n, Hi, Wi, Cc) = 1, img.shape
+    else:
+        assert img.dtype == torch.float32
+        kind, (n, Cc, Hi, Wi) = 0, img.shape
+    n_keep = keep_idx.shape[1] if keep_idx is not None else (Hi // patch) * (Wi // patch)
+    assert keep_idx is None or (keep_idx.dtype == torch.int32 and keep_idx.is_contiguous() and keep_idx.shape[0] == n)
+    _check(lib().a4r_patchify(_stream(), _p(img), C.c_int(kind), _p(out), C.c_int(_ld(out)), _p(keep_idx), C.c_int(n_keep),
+                              C.c_int(n), C.c_int(Cc), C.c_int(Hi), C.c_int(Wi), C.c_int(patch), C.c_int(_dt(out))), 'a4r_patchify')
+
+
+def vit_assemble(patches, cls, pos, out, n_items, n_keep, keep_idx=None):
+    require_gpu(patches, out)
+    _check(lib().a4r_vit_assemble(_stream(), _p(patches), C.c_int(_ld(patches)), _p(cls), _p(pos), _p(keep_idx), _p(out),
+                                  C.c_int(_ld(out)), C.c_int(n_items), C.c_int(n_keep), C.c_int(cls.numel()), C.c_int(_dt(out))),
+           'a4r_vit_assemble')
 
 
 def embed_ln(ids, word, pos, type0, gamma, beta, eps, out, n_items, S, roberta=False, pad_id=0,

@@ -1,0 +1,111 @@
+// ViT / ViT-MAE input side (HF ViTEmbeddings / ViTMAEEmbeddings as used by Downstream/CV/model/encoders.py:21-32):
+//   a4r_patchify      image -> rows of flattened 16x16x3 patches (the im2col of the stride-16 patch convolution, so that
+//                     the projection is one call of the large-tile GEMM); also the on-GPU half of the image pipeline of
+//                     Downstream/CV/data_utils/dataset.py:77-81: uint8 HWC pixels -> ToTensor -> Normalize(0.5, 0.5),
+//                     i.e. (x / 255 - 0.5) / 0.5; with keep_idx only the patches ViT-MAE keeps are produced at all.
+//   a4r_vit_assemble  [cls + pos[0]] ++ [patch_j + pos[1 + idx_j]] -> token rows of the encoder input.
+// Both are pure data movement (HBM-bound): one thread per 16 bytes of output.
+#include "a4r_common.h"
+#include "../../include/a4r.h"
+
+namespace {
+
+template <typename T, bool U8>
+__global__ void __launch_bounds__(256) patchify_kernel(const void* __restrict__ img, T* __restrict__ out, int ldo,
+                                                       const int32_t* __restrict__ keep, int n_keep, int n_items, int C, int Hi, int Wi, int P) {
+    constexpr int PER = Elem<T>::PER16;
+    const int cols = C * P * P, cpr = cols / PER;                     // P % PER == 0: a chunk never leaves one patch row
+    const long total = (long)n_items * n_keep * cpr;
+    const int npw = Wi / P;
+    for (long id = (long)blockIdx.x * 256 + threadIdx.x; id < total; id += (long)gridDim.x * 256) {
+        const int ch = (int)(id % cpr);
+        const long row = id / cpr;
+        const int item = (int)(row / n_keep), j = (int)(row % n_keep);
+        const int patch = keep ? keep[(long)item * n_keep + j] : j;
+        const int py = patch / npw, px = patch % npw;
+        const int col = ch * PER;                                     // = c * P * P + ky * P + kx (Conv2d weight order)
+        const int c = col / (P * P), ky = (col / P) % P, kx = col % P;
+        const int y = py * P + ky, x = px * P + kx;
+        float v[PER];
+        if constexpr (U8) {                                           // [item][y][x][c] bytes
+            const unsigned char* s = reinterpret_cast<const unsigned char*>(img) + (((long)item * Hi + y) * Wi + x) * C + c;
+#pragma unroll
+            for (int e = 0; e < PER; ++e) v[e] = ((float)s[e * C] * (1.f / 255.f) - 0.5f) / 0.5f;
+        } else {                                                      // [item][c][y][x] fp32, already normalised
+            const float* s = reinterpret_cast<const float*>(img) + (((long)item * C + c) * Hi + y) * Wi + x;
+#pragma unroll
+            for (int e = 0; e < PER; ++e) v[e] = s[e];
+        }
+        *reinterpret_cast<uint4*>(out + row * ldo + col) = Elem<T>::pack(v);
+    }
+}
+
+template <typename T>
+__global__ void __launch_bounds__(256) vit_assemble_kernel(const T* __restrict__ patches, int ldp, const float* __restrict__ cls,
+                                                           const float* __restrict__ pos, const int32_t* __restrict__ keep,
+                                                           T* __restrict__ out, int ldo, int n_items, int n_keep, int H) {
+    constexpr int PER = Elem<T>::PER16;
+    const int cpr = H / PER, S = n_keep + 1;
+    const long total = (long)n_items * S * cpr;
+    for (long id = (long)blockIdx.x * 256 + threadIdx.x; id < total; id += (long)gridDim.x * 256) {
+        const int ch = (int)(id % cpr);
+        const long row = id / cpr;
+        const int item = (int)(row / S), t = (int)(row % S);
+        float v[PER], p[PER];
+        if (t == 0) {
+            load_vec<float, PER>(cls + ch * PER, v);
+            load_vec<float, PER>(pos + ch * PER, p);
+        } else {
+            const int patch = keep ? keep[(long)item * n_keep + t - 1] : t - 1;
+            load_vec<T, PER>(patches + ((long)item * n_keep + t - 1) * ldp + ch * PER, v);
+            load_vec<float, PER>(pos + (long)(1 + patch) * H + ch * PER, p);
+        }
+#pragma unroll
+        for (int e = 0; e < PER; ++e) v[e] += p[e];
+        store_vec<T, PER>(out + row * ldo + ch * PER, v);
+    }
+}
+
+int grid_for(long total) {
+    long g = (total + 255) / 256;
+    return (int)(g < 1 ? 1 : g > 65536 ? 65536 : g);
+}
+
+}  // namespace
+
+extern "C" int a4r_patchify(void* stream, const void* img, int src_kind, void* out, int ldo, const int32_t* keep_idx, int n_keep,
+                            int n_items, int C, int Himg, int Wimg, int patch, int dtype) {
+    if (!img || !out || n_items <= 0 || C <= 0 || patch <= 0 || Himg % patch || Wimg % patch || patch % 8) return A4R_EINVAL;
+    if (src_kind != 0 && src_kind != 1) return A4R_EINVAL;
+    const int np = (Himg / patch) * (Wimg / patch);
+    if (!keep_idx) n_keep = np;
+    if (n_keep <= 0 || n_keep > np || ldo < C * patch * patch) return A4R_EINVAL;
+    const int es = dtype == A4R_BF16 ? 2 : 4;
+    if ((dtype != A4R_BF16 && dtype != A4R_F32) || (ldo * es) % 16 || (reinterpret_cast<uintptr_t>(out) & 15u)) return A4R_EINVAL;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    const long total = (long)n_items * n_keep * (C * patch * patch / (16 / es));
+#define A4R_GO(T_, U8_) hipLaunchKernelGGL((patchify_kernel<T_, U8_>), dim3(grid_for(total)), dim3(256), 0, s, img, (T_*)out, ldo, keep_idx, \
+                                           n_keep, n_items, C, Himg, Wimg, patch)
+    if (dtype == A4R_BF16) { if (src_kind) A4R_GO(bf16_t, true); else A4R_GO(bf16_t, false); }
+    else { if (src_kind) A4R_GO(float, true); else A4R_GO(float, false); }
+#undef A4R_GO
+    return a4r_launch_status();
+}
+
+extern "C" int a4r_vit_assemble(void* stream, const void* patches, int ldp, const float* cls, const float* pos, const int32_t* keep_idx,
+                                void* out, int ldo, int n_items, int n_keep, int H, int dtype) {
+    if (!patches || !cls || !pos || !out || n_items <= 0 || n_keep <= 0 || H % 8) return A4R_EINVAL;
+    const int es = dtype == A4R_BF16 ? 2 : 4;
+    if ((dtype != A4R_BF16 && dtype != A4R_F32) || (ldp * es) % 16 || (ldo * es) % 16 || ldp < H || ldo < H) return A4R_EINVAL;
+    if ((reinterpret_cast<uintptr_t>(patches) | reinterpret_cast<uintptr_t>(out) | reinterpret_cast<uintptr_t>(cls) | reinterpret_cast<uintptr_t>(pos)) & 15u)
+        return A4R_EINVAL;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    const long total = (long)n_items * (n_keep + 1) * (H / (16 / es));
+    if (dtype == A4R_BF16)
+        hipLaunchKernelGGL(vit_assemble_kernel<bf16_t>, dim3(grid_for(total)), dim3(256), 0, s, (const bf16_t*)patches, ldp, cls, pos, keep_idx,
+                           (bf16_t*)out, ldo, n_items, n_keep, H);
+    else
+        hipLaunchKernelGGL(vit_assemble_kernel<float>, dim3(grid_for(total)), dim3(256), 0, s, (const float*)patches, ldp, cls, pos, keep_idx,
+                           (float*)out, ldo, n_items, n_keep, H);
+    return a4r_launch_status();
+}

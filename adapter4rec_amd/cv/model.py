@@ -1,0 +1,133 @@
+"""Model / ModelCPC, Vit_Encoder / MAE_Encoder and the ViT adapter wrappers with the constructor and call signatures of
+the reference's image path (Downstream/CV/model/model.py, encoders.py) -- the drop-in boundary for configs 3 and 5.
+
+    cv_model = ViTForImageClassification(...); cv_model.classifier = nn.Linear(768, args.embedding_dim)   # run_adapter.py:289-296
+    model = Model(args, item_num, use_modal, cv_model)                                                    # :338
+    layer.attention.output = VITAdaptedSelfOutput(layer.attention.output, args)                          # :428-434
+    loss = model(sample_items.view(-1, 3, R, R), log_mask, local_rank); loss.backward()                   # :582-594
+
+``sample_items`` may also be raw uint8 pixels [n, R, R, 3] (the LMDB record content, data_utils/dataset.py:17-27): the
+ToTensor + Normalize(0.5, 0.5) half of the reference's CPU transform then runs inside the patch kernel."""
+import torch
+from torch import nn
+from torch.nn.init import constant_, xavier_normal_
+
+from ..model.bert import _Container
+from ..model.encoders import User_Encoder
+from ..model.model import (_NativeLoss, CompacterModel, SASRecAdaptedSelfOutput, SASRecCompacterAdaptedSelfOutput,   # noqa: F401
+                           SASRecParallelAdaptedSelfOutput, SASRecPfeifferVer2AdaptedSelfOutput)
+from ..model.modules import AdapterBlock, HyperComplexAdapterBlock
+
+
+class Vit_Encoder(nn.Module):                    # encoders.py:25-32
+    def __init__(self, image_net):
+        super().__init__()
+        self.image_net = image_net
+        self.activate = nn.GELU()
+        self._owner = [None]
+
+    def forward(self, item_content):
+        """[n, 3, R, R] fp32 (or [n, R, R, 3] uint8) -> [n, E] item embeddings (inference; eval uses it, metrics.py)."""
+        return self._owner[0]._engine().encode_items(item_content)
+
+
+class MAE_Encoder(nn.Module):                    # encoders.py:8-22
+    def __init__(self, image_net, item_dim):
+        super().__init__()
+        self.item_dim, self.word_emb = item_dim, 768
+        self.image_net = image_net
+        self.activate = nn.GELU()
+        self.cv_proj = nn.Linear(image_net.config['hidden_size'] if isinstance(image_net.config, dict) else image_net.config.hidden_size,
+                                 item_dim)
+        xavier_normal_(self.cv_proj.weight.data)
+        constant_(self.cv_proj.bias.data, 0)
+        self._owner = [None]
+
+    def forward(self, item_content, noise=None):
+        return self._owner[0]._engine().encode_items(item_content, noise=noise)
+
+
+class _CVBase(nn.Module):
+    arch = 'sasrec'
+
+    def __init__(self, args, item_num, use_modal, image_net):
+        super().__init__()
+        if not use_modal:
+            raise NotImplementedError('ID tower (use_modal=False) is out of scope')
+        self.args = args
+        self.use_modal = use_modal
+        self.max_seq_len = args.max_seq_len
+        self.l2_weight = args.l2_weight / 2
+        self.user_encoder = User_Encoder(item_num=item_num, max_seq_len=args.max_seq_len, item_dim=args.embedding_dim,
+                                         num_attention_heads=args.num_attention_heads, dropout=args.drop_rate,
+                                         n_layers=args.transformer_block)
+        name = args.CV_model_load
+        if 'mae' in name:                        # model.py:29-30
+            self.cv_encoder = MAE_Encoder(image_net=image_net, item_dim=args.embedding_dim)
+        elif 'vit' in name:
+            self.cv_encoder = Vit_Encoder(image_net=image_net)
+        else:
+            raise NotImplementedError(f'--CV_model_load {name}: the native image tower covers ViT and ViT-MAE (resnet/beit/swin are not in the BASELINE configs)')
+        self.criterion = nn.BCEWithLogitsLoss()
+        self.cv_encoder._owner[0] = self
+        self.user_encoder._owner[0] = self
+        self._native = [None]
+        self._phm_owner = [None]
+        self.compute_dtype = getattr(args, 'compute_dtype', 'bf16')
+        self.register_load_state_dict_post_hook(lambda module, incompatible: module.invalidate_native())
+
+    def invalidate_native(self):
+        self._native[0] = None
+
+    def _engine(self):
+        if self._native[0] is None:
+            from ..engine_vit import ViTRecEngine
+            self._native[0] = ViTRecEngine(self, self.args, arch=self.arch, dtype=self.compute_dtype, phm_owner=self._phm_owner[0])
+        return self._native[0]
+
+    def _apply(self, fn, *a, **k):
+        self.invalidate_native()
+        return super()._apply(fn, *a, **k)
+
+    def forward(self, sample_items, log_mask, local_rank=None, noise=None):
+        eng = self._engine()
+        eng.next_noise = noise                   # ViT-MAE: explicit masking noise [n, n_patches] (parity runs); None = drawn on device
+        if torch.is_grad_enabled() and eng.n_trainable:
+            return _NativeLoss.apply(eng, sample_items, log_mask, *eng.trainable_params)
+        return eng.train_forward(sample_items, log_mask)
+
+
+class Model(_CVBase):                            # model.py:10-77
+    arch = 'sasrec'
+
+
+class ModelCPC(_CVBase):                         # model.py:80-146
+    arch = 'cpc'
+
+
+# ---------------------------------------------------------------- ViT-side wrappers (pre-LN: no LayerNorm inside)
+class VITAdaptedSelfOutput(_Container):          # model.py:182-195: adapter(dropout(dense(x)))          (residual added by ViTLayer)
+    placement, adds_input = 'serial', False
+
+    def __init__(self, self_output, args):
+        super().__init__()
+        self.self_output = self_output
+        # the reference hard-codes 768 (ViT-B); the dense layer's own width is the same number there and also serves small test geometries
+        self.adapter = AdapterBlock(args, self_output.dense.out_features, args.cv_adapter_down_size, args.adapter_dropout_rate)
+
+
+class VITAdaptedOutput(VITAdaptedSelfOutput):    # model.py:198-212: adapter(dropout(dense(x))) + input
+    adds_input = True
+
+
+class VITCompacterAdaptedSelfOutput(_Container):   # model.py:432-445
+    placement, adds_input = 'serial', False
+
+    def __init__(self, self_output, args):
+        super().__init__()
+        self.self_output = self_output
+        self.adapter = HyperComplexAdapterBlock(args, self_output.dense.out_features, args.cv_adapter_down_size)
+
+
+class VITCompacterAdaptedOutput(VITCompacterAdaptedSelfOutput):   # model.py:448-462
+    adds_input = True

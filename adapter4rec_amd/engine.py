@@ -96,17 +96,23 @@ class _Lora:
         self.mod, self.slot, self.width = mod, slot, width
         self.r, self.rp, self.scaling = mod.r, pad_to(mod.r, 64), float(mod.scaling)
         dev = eng.dev
+        self.g_bias = eng.grad_view(mod.bias) if mod.bias is not None else None
+        self.g_W = None
+        if self.r == 0:                  # loralib: r = 0 leaves a plain Linear whose weight stays trainable (CV run_adapter.py:394)
+            self.g_W = eng.grad_view(mod.weight)
+            return
         self.A = torch.zeros(self.rp, width, dtype=dt, device=dev)        # lora_A [r, in]        (NT operand of t = x A^T)
         self.BT = torch.zeros(self.rp, width, dtype=dt, device=dev)       # lora_B^T [r, out]     (NT operand of dt = dq B)
         eng.add_pack(mod.lora_A, self.A, False)
         eng.add_pack(mod.lora_B, self.BT, True)
         self.g_A, self.g_B = eng.grad_view(mod.lora_A), eng.grad_view(mod.lora_B)
-        self.g_bias = eng.grad_view(mod.bias) if mod.bias is not None else None
         self.s_A = torch.zeros(self.rp, width, dtype=torch.float32, device=dev)
         self.s_B = torch.zeros(width, self.rp, dtype=torch.float32, device=dev)
 
     def merged(self):
         m = self.mod
+        if self.r == 0:
+            return m.weight.detach()
         return m.weight.detach() + (m.lora_B.detach() @ m.lora_A.detach()) * self.scaling
 
 
@@ -125,19 +131,14 @@ class TransRecEngine:
         if dtype not in ('bf16', 'fp32'):
             raise ValueError("compute_dtype must be 'bf16' or 'fp32'")
         self.T = torch.bfloat16 if dtype == 'bf16' else torch.float32
-        self.S = args.num_words_title
+        self.S = getattr(args, 'num_words_title', 0)
         self.E = args.embedding_dim
         self.Lseq = args.max_seq_len + 1
         self.seed = int(getattr(args, 'dropout_seed', 0x5eed))
         self.step_count = 0
         self._packs_T, self._packs_b, self._virtual = [], [], []
         self._collect_trainables()
-        bert = model.bert_encoder.text_encoders['title'].bert_model
-        self.geo = backbone_geometry(bert)
-        if self.geo['hidden_act'] not in ('gelu',):
-            raise NotImplementedError(f"hidden_act {self.geo['hidden_act']}")
-        self._build_bert(bert)
-        self._build_head()
+        self._build_item_tower()
         self._build_sasrec()
         self._check_coverage()
         self._finalize_packs()
@@ -315,6 +316,14 @@ class TransRecEngine:
             ln_new = _LN(mod.LN, self) if hasattr(mod, 'LN') else None
             return so.dense, so.LayerNorm, self._adapter_of(mod, 'adapter', width, dt), placement, ln_new
         return mod.dense, mod.LayerNorm, None, None, None
+
+    def _build_item_tower(self):
+        bert = self.model.bert_encoder.text_encoders['title'].bert_model
+        self.geo = backbone_geometry(bert)
+        if self.geo['hidden_act'] not in ('gelu',):
+            raise NotImplementedError(f"hidden_act {self.geo['hidden_act']}")
+        self._build_bert(bert)
+        self._build_head()
 
     def _build_bert(self, bert):
         g = self.geo
@@ -572,6 +581,12 @@ class TransRecEngine:
     def _lora_backward(self, blk, lo, dqkv, x, M):
         H, T = blk.H, blk.T
         dq = dqkv[:, lo.slot * H:(lo.slot + 1) * H]
+        if lo.g_bias is not None:
+            L.colsum(dq, lo.g_bias(), M=M)
+        if lo.r == 0:
+            if lo.g_W is not None:
+                L.gemm_tn(dq, x, lo.g_W(), M=M)                  # dW = dq^T x
+            return
         t = self._buf('lora_t', M, lo.rp, T)
         dt = self._buf('lora_dt', M, lo.rp, T)
         L.gemm_nt(x, lo.A, t, M=M)                               # t  = x A^T
@@ -583,8 +598,6 @@ class TransRecEngine:
         if lo.g_B is not None:
             lo.g_B().add_(lo.s_B[:, :lo.r], alpha=lo.scaling)
             lo.g_A().add_(lo.s_A[:lo.r])
-        if lo.g_bias is not None:
-            L.colsum(dq, lo.g_bias(), M=M)
 
     def _adapter_wgrads(self, ad, dv, z, dzp, down_in, M):
         """dW_up = dv^T z, dW_down = dzp^T down_in, db_down = colsum(dzp)  (db_up comes from ln_bwd's dbias)."""
@@ -786,6 +799,22 @@ class TransRecEngine:
                  dgamma=gg(self.sas_ln0.g_gamma), dbeta=gg(self.sas_ln0.g_beta),
                  drop_p=self.p_sas if train else 0.0, drop_site=4000, drop_seed=seed)
         L.emb_grad_add_inputs(d_in, d_emb, B, self.Lseq, E)
+        self._items_backward(c, d_emb, Ip)
+        if self._virtual:
+            self._virtual_backward()
+        if into_flat_grad:
+            return None
+        if grad_out is not None:
+            target.mul_(grad_out.to(target.dtype))
+        out = target.clone()
+        ddp = getattr(self.model, '_a4r_ddp', None)
+        if ddp is not None:                                   # DDP semantics: gradients averaged over ranks (run.py:503,599)
+            ddp.average_(out)
+        return [out[o:o + n].view(p.shape) for p, (o, n) in ((p, self.offsets[id(p)]) for p in self.trainable_params)]
+
+    def _items_backward(self, c, d_emb, Ip):
+        """d_emb [Ip, E] fp32 -> item head, encoder layers last to first (writes the adapter gradients)."""
+        n_items, M, seed, train, E = c['n_items'], c['M'], c['seed'], c['train'], self.E
         # item head backward: GELU, fc dgrad, scatter to the CLS rows
         d_pre = self._buf('d_pre', Ip, E, torch.float32)
         L.act_bwd_f32(d_emb, c['pre'], d_pre, L.ACT_GELU)
@@ -805,17 +834,6 @@ class TransRecEngine:
             else:
                 self._block_backward(blk, dxb, c['key_mask'], n_items, M, c['saved_b'][i], train, seed, spare if blk.need_dx else None)
             dxb, spare = spare, dxb
-        if self._virtual:
-            self._virtual_backward()
-        if into_flat_grad:
-            return None
-        if grad_out is not None:
-            target.mul_(grad_out.to(target.dtype))
-        out = target.clone()
-        ddp = getattr(self.model, '_a4r_ddp', None)
-        if ddp is not None:                                   # DDP semantics: gradients averaged over ranks (run.py:503,599)
-            ddp.average_(out)
-        return [out[o:o + n].view(p.shape) for p, (o, n) in ((p, self.offsets[id(p)]) for p in self.trainable_params)]
 
     def _virtual_backward(self):
         """Compacter: chain the gradients of the effective matrices into (phm_rule, W_left, W_right) with autograd."""

@@ -1,0 +1,281 @@
+"""Image item tower on the MI355X-native engine: frozen ViT-B/16 (HF ViTForImageClassification) or ViT-MAE encoder with
+injected Houlsby / Compacter adapters or LoRA on q, v -> the same SASRec/CPC user encoder, head, backward, flat-gradient
+and Adam machinery as the text path (engine.py).
+
+Replaces, behind ``Model.forward`` / ``Vit_Encoder`` / ``MAE_Encoder`` (reference: Downstream/CV/model/model.py:54-77,
+encoders.py:8-32; HF transformers==4.20.1 modeling_vit.py / modeling_vit_mae.py, third party), per PRE-LN layer
+    x1 = x  + A1(dense(attn(LN_before(x))))          A1 = VITAdaptedSelfOutput (model.py:182-195)
+    x2 = x1 + A2(dense(gelu(dense(LN_after(x1)))))   A2 = VITAdaptedOutput     (model.py:198-212)
+with A(h) = fc_up(act(fc_down(h))) + h (Houlsby) or without the inner residual (Compacter, model.py:432-462), then
+``layernorm`` -> CLS -> classifier / cv_proj -> GELU.
+
+Launch sequence per layer (all C-ABI kernels of liba4r_hip.so; the residual adds ride in GEMM epilogues):
+    ln_fwd | gemm(qkv) | attn_long_fwd | gemm(o [+R1=x]) [| gemm(down) | gemm(up, R1=h, R2=x)] | ln_fwd | gemm(fc1, GELU)
+    | gemm(fc2 [+R1=x1]) [| gemm(down) | gemm(up, R1=h, R2=x1)]
+The input side is a4r_patchify (im2col + uint8 normalise; ViT-MAE: only the kept 25 % of the patches) -> one GEMM with
+the Conv2d weight -> a4r_vit_assemble (cls, position rows).  Hidden / attention dropout are 0 in the ViT configs the
+reference loads (google/vit-base-patch16-224, facebook/vit-mae-base) and are required to be 0 here.
+"""
+import math
+
+import torch
+
+from . import _lib as L
+from .engine import TransRecEngine, _Adapter, _Block, _LN, _Lora, pad_to
+from .cv.vit import vit_geometry
+from .model.modules import AdapterBlock, HyperComplexAdapterBlock
+
+
+class ViTRecEngine(TransRecEngine):
+    # ------------------------------------------------------------------ build
+    def _build_item_tower(self):
+        enc = self.model.cv_encoder
+        net = enc.image_net
+        self.mae = not hasattr(net, 'vit')
+        core = net if self.mae else net.vit
+        g = self.geo = vit_geometry(net)
+        H, nh = g['hidden_size'], g['num_attention_heads']
+        self.H, self.F = H, g['intermediate_size']
+        self.P, self.R, self.C = g['patch_size'], g['image_size'], g['num_channels']
+        if H % 64 or self.F % 64 or H // nh != 64 or self.P % 8 or (self.C * self.P * self.P) % 64:
+            raise NotImplementedError(f'ViT geometry H={H} F={self.F} heads={nh} patch={self.P}')
+        if g['hidden_act'] != 'gelu':
+            raise NotImplementedError(f"hidden_act {g['hidden_act']}")
+        if g['hidden_dropout_prob'] or g['attention_probs_dropout_prob']:
+            raise NotImplementedError('the image tower assumes the ViT configs the reference loads: dropout probabilities 0')
+        self.NP = (self.R // self.P) ** 2
+        self.n_keep = int(self.NP * (1 - g['mask_ratio'])) if self.mae else self.NP       # HF: int(seq_length * (1 - mask_ratio))
+        self.S = self.n_keep + 1
+        if self.S > 256:
+            raise NotImplementedError(f'{self.S} tokens per image (attention kernel: <= 256)')
+        emb = core.embeddings
+        proj = emb.patch_embeddings.projection
+        for p in (emb.cls_token, emb.position_embeddings, proj.weight, proj.bias):
+            if p.requires_grad:
+                raise NotImplementedError('training the ViT embeddings (--fine_tune_to all) is not wired natively')
+        self.patch_w = self._w(proj.weight.reshape(H, -1))                  # [H, C*P*P], Conv2d column order
+        self.patch_b = self._f32(proj.bias)
+        self.cls_tok = self._f32(emb.cls_token.reshape(H))
+        self.pos_tab = self._f32(emb.position_embeddings.reshape(self.NP + 1, H))
+        self.next_noise = None
+        self.bert_blocks = []
+        for i, layer in enumerate(core.encoder.layer):
+            b = _Block()
+            att = layer.attention.attention
+            b.lora = []
+            for slot, lin in enumerate((att.query, att.key, att.value)):
+                if type(lin).__name__ == 'LoRALinear':
+                    b.lora.append(_Lora(lin, H, self, self.T, slot))
+                elif type(lin).__name__ != 'Linear':
+                    raise NotImplementedError(f'projection module {type(lin).__name__}')
+            b.H, b.F, b.nh, b.dh, b.S = H, self.F, nh, 64, self.S
+            b.scale = 1.0 / math.sqrt(64)
+            b.wqkv = self._w(torch.cat([att.query.weight, att.key.weight, att.value.weight], 0))
+            b.wqkvT = b.wqkv.t().contiguous()
+            b.bqkv = self._f32(torch.cat([att.query.bias, att.key.bias, att.value.bias], 0))
+            d1, b.ad1 = self._vit_so(layer.attention.output)
+            d2, b.ad2 = self._vit_so(layer.output)
+            b.wo, b.woT, b.bo = self._w(d1.weight), self._wT(d1.weight), self._f32(d1.bias)
+            b.wi, b.wiT, b.bi = (self._w(layer.intermediate.dense.weight), self._wT(layer.intermediate.dense.weight),
+                                 self._f32(layer.intermediate.dense.bias))
+            b.wo2, b.wo2T, b.bo2 = self._w(d2.weight), self._wT(d2.weight), self._f32(d2.bias)
+            b.lnA, b.lnB = _LN(layer.layernorm_before, self), _LN(layer.layernorm_after, self)
+            b.need_dx = i > 0
+            b.T = self.T
+            self.bert_blocks.append(b)
+        self.vit_ln = _LN(core.layernorm, self)
+        fc = enc.cv_proj if self.mae else net.classifier
+        if fc.weight.requires_grad or self.E % 64 or fc.out_features != self.E:
+            raise NotImplementedError('item head: frozen classifier / cv_proj with embedding_dim % 64 == 0')
+        self.fc_w = self._w(fc.weight)
+        self.fc_wT32 = self._wT(fc.weight, torch.float32)
+        self.fc_b = self._f32(fc.bias)
+        self.cls_only = False
+
+    def _vit_so(self, mod):
+        """(dense Linear, adapter or None) of a plain or wrapped ViTSelfOutput / ViTOutput."""
+        if hasattr(mod, 'self_output'):
+            ad = getattr(mod, 'adapter', None)
+            if not isinstance(ad, (AdapterBlock, HyperComplexAdapterBlock)) or getattr(mod, 'placement', 'serial') != 'serial':
+                raise NotImplementedError(f'ViT adapter wrapper {type(mod).__name__}')
+            return mod.self_output.dense, _Adapter(ad, self.H, self, self.T)
+        return mod.dense, None
+
+    # ------------------------------------------------------------------ buffers
+    def _block_bufs(self, tag, blk, M, shared, Mc=None):
+        if not hasattr(blk, 'lnA'):
+            return super()._block_bufs(tag, blk, M, shared, Mc)
+        pre = tag if not shared else tag.split('.')[0] + '.shared'
+        T, H, F = blk.T, blk.H, blk.F
+        d = {}
+        if not shared:
+            d['x0'] = self._buf(pre + '.x0', M, H, T)                      # the layer input (LN_before backward needs it)
+        if blk.lora and not shared:
+            d['n1'] = self._buf(pre + '.n1', M, H, T)
+        d['sta'] = self._buf(pre + '.sta', M, 2, torch.float32)
+        d['qkv'] = self._buf(pre + '.qkv', M, 3 * H, T)
+        d['lse'] = self._buf(pre + '.lse', (M // blk.S + 1) * blk.nh * blk.S, 1, torch.float32)
+        d['x1'] = self._buf(pre + '.x1', M, H, T)
+        d['stb'] = self._buf(pre + '.stb', M, 2, torch.float32)
+        d['upre'] = self._buf(pre + '.upre', M, F, T)
+        for k, ad in (('1', blk.ad1), ('2', blk.ad2)):
+            if ad is not None:
+                d['h' + k] = self._buf(pre + '.h' + k, M, H, T)
+                d['zp' + k] = self._buf(pre + '.zp' + k, M, ad.dp, T)
+                d['z' + k] = self._buf(pre + '.z' + k, M, ad.dp, T)
+        return d
+
+    # ------------------------------------------------------------------ one pre-LN layer
+    def _vit_sub_forward(self, ad, dense_in, w, bias, resid, bufs, k, M, out):
+        if ad is None:
+            L.gemm_nt(dense_in, w, out, bias=bias, R1=resid, M=M)
+            return
+        h, zp, z = bufs['h' + k], bufs['zp' + k], bufs['z' + k]
+        L.gemm_nt(dense_in, w, h, bias=bias, M=M)
+        L.gemm_nt(h, ad.wd, z, bias=ad.bd, C2=zp, act=ad.act, M=M)
+        if ad.kind == 'compacter':            # no inner residual (Downstream/CV/model/modules.py HyperComplexAdapterBlock.forward)
+            L.gemm_nt(z, ad.wu, out, bias=ad.bu, R1=resid, M=M)
+        else:
+            L.gemm_nt(z, ad.wu, out, bias=ad.bu, R1=h, R2=resid, M=M)
+
+    def _vit_block_forward(self, blk, x, n_items, M, bufs, x_out):
+        T, H = blk.T, blk.H
+        n1 = bufs['n1'] if 'n1' in bufs else self._buf('n1', M, H, T)
+        L.ln_fwd(x, blk.lnA.gamma, blk.lnA.beta, blk.lnA.eps, n1, bufs['sta'], M=M)
+        L.gemm_nt(n1, blk.wqkv, bufs['qkv'], bias=blk.bqkv, M=M)
+        ctx = self._buf('ctx', M, H, T)
+        L.attn_long_fwd(bufs['qkv'], ctx, bufs['lse'], n_items, blk.S, blk.nh, blk.dh, 0, H, 2 * H, blk.scale)
+        self._vit_sub_forward(blk.ad1, ctx, blk.wo, blk.bo, x, bufs, '1', M, bufs['x1'])
+        n2 = self._buf('n2', M, H, T)
+        L.ln_fwd(bufs['x1'], blk.lnB.gamma, blk.lnB.beta, blk.lnB.eps, n2, bufs['stb'], M=M)
+        u = self._buf('u', M, blk.F, T)
+        L.gemm_nt(n2, blk.wi, u, bias=blk.bi, C2=bufs['upre'], act=L.ACT_GELU, c2_deriv=True, M=M)
+        self._vit_sub_forward(blk.ad2, u, blk.wo2, blk.bo2, bufs['x1'], bufs, '2', M, x_out)
+
+    def _vit_sub_backward(self, blk, ad, dy, bufs, k, M):
+        """dy: gradient of the sub-layer output before the residual add -> gradient of the dense output."""
+        if ad is None:
+            return dy
+        T, H = blk.T, blk.H
+        h, zp, z = bufs['h' + k], bufs['zp' + k], bufs['z' + k]
+        dzp = self._buf('dzp', M, ad.dp, T)
+        L.gemm_nt(dy, ad.wuT, dzp, Pre=zp, dact=ad.act, M=M)
+        dh = self._buf('dh' + k, M, H, T)
+        if ad.kind == 'compacter':
+            L.gemm_nt(dzp, ad.wdT, dh, M=M)
+        else:
+            L.gemm_nt(dzp, ad.wdT, dh, R1=dy, M=M)
+        self._adapter_wgrads(ad, dy, z, dzp, h, M)
+        if ad.g_bu is not None:
+            L.colsum(dy, ad.g_bu(), M=M)
+        return dh
+
+    def _vit_block_backward(self, blk, dx_out, n_items, M, bufs, dx_in):
+        T, H, F = blk.T, blk.H, blk.F
+        gg = lambda f: f() if f is not None else None
+        d_o = self._vit_sub_backward(blk, blk.ad2, dx_out, bufs, '2', M)
+        du = self._buf('du', M, F, T)
+        L.gemm_nt(d_o, blk.wo2T, du, Pre=bufs['upre'], dact=L.DACT_MUL, M=M)
+        dn2 = self._buf('dn', M, H, T)
+        L.gemm_nt(du, blk.wiT, dn2, M=M)
+        dx1 = self._buf('dx1', M, H, T)
+        L.ln_bwd(dn2, bufs['x1'], bufs['stb'], blk.lnB.gamma, dx1, M=M, dgamma=gg(blk.lnB.g_gamma), dbeta=gg(blk.lnB.g_beta), dres=dx_out)
+        da = self._vit_sub_backward(blk, blk.ad1, dx1, bufs, '1', M)
+        if dx_in is None and not blk.lora:
+            return
+        dctx = self._buf('dctx', M, H, T)
+        L.gemm_nt(da, blk.woT, dctx, M=M)
+        dqkv = self._buf('dqkv', M, 3 * H, T)
+        ws = self._buf('attn_ws', bufs['lse'].shape[0], 1, torch.float32)
+        L.attn_long_bwd(bufs['qkv'], dctx, dqkv, bufs['lse'], ws, n_items, blk.S, blk.nh, blk.dh, 0, H, 2 * H, blk.scale)
+        for lo in blk.lora:
+            self._lora_backward(blk, lo, dqkv, bufs['n1'], M)
+        if dx_in is not None:
+            dn1 = self._buf('dn', M, H, T)
+            L.gemm_nt(dqkv, blk.wqkvT, dn1, M=M)
+            L.ln_bwd(dn1, bufs['x0'], bufs['sta'], blk.lnA.gamma, dx_in, M=M, dgamma=gg(blk.lnA.g_gamma), dbeta=gg(blk.lnA.g_beta), dres=dx1)
+
+    # ------------------------------------------------------------------ item tower
+    def _keep_indices(self, n_items, noise):
+        """ViT-MAE random masking (HF ViTMAEEmbeddings.random_masking): keep the n_keep patches of smallest noise, in
+        argsort order.  noise None: drawn on the device (training); explicit noise: parity runs."""
+        if not self.mae:
+            return None
+        if noise is None:
+            noise = torch.rand(n_items, self.NP, device=self.dev)
+        L.require_gpu(noise)
+        return torch.argsort(noise.float(), dim=1)[:, :self.n_keep].to(torch.int32).contiguous()
+
+    def _encode(self, images, n_items, train, seed, saved):
+        S, H = self.S, self.H
+        M = pad_to(n_items * S, 256)
+        if images.dtype == torch.uint8:
+            if images.shape[1:] != (self.R, self.R, self.C):
+                raise ValueError(f'uint8 images must be [n, {self.R}, {self.R}, {self.C}] (HWC), got {tuple(images.shape)}')
+        else:
+            if images.shape[1:] != (self.C, self.R, self.R):
+                raise ValueError(f'images must be [n, {self.C}, {self.R}, {self.R}], got {tuple(images.shape)} (no in-engine resize)')
+            images = images.float()
+        images = images.contiguous()
+        keep = self._keep_indices(n_items, self.next_noise)
+        self.next_noise = None
+        Mp = pad_to(n_items * self.n_keep, 256)
+        cols = self.C * self.P * self.P
+        pat = self._buf('patches', Mp, cols, self.T)
+        L.patchify(images, pat, self.P, keep)
+        pe = self._buf('patch_emb', Mp, H, self.T)
+        L.gemm_nt(pat, self.patch_w, pe, bias=self.patch_b, M=Mp)
+        x = saved[0]['x0'] if saved is not None else self._buf('xa', M, H, self.T)
+        L.vit_assemble(pe, self.cls_tok, self.pos_tab, x, n_items, self.n_keep, keep)
+        other = self._buf('xb', M, H, self.T)
+        nb = len(self.bert_blocks)
+        xl = self._buf('x_last', M, H, self.T)
+        for i, blk in enumerate(self.bert_blocks):
+            if saved is not None:
+                out = saved[i + 1]['x0'] if i + 1 < nb else xl
+                self._vit_block_forward(blk, x, n_items, M, saved[i], out)
+                x = out
+            else:
+                bufs = self._block_bufs('vit.shared', blk, M, True)
+                out = xl if i + 1 == nb else other
+                self._vit_block_forward(blk, x, n_items, M, bufs, out)
+                x, other = out, (x if x is not xl else other)
+        Ip = pad_to(n_items, 128)
+        cls = self._buf('cls', Ip, H, self.T)
+        L.gather_rows(x, cls, n_items, S)
+        cln = self._buf('cls_n', Ip, H, self.T)
+        self._cls_st = self._buf('cls_st', Ip, 2, torch.float32)
+        L.ln_fwd(cls, self.vit_ln.gamma, self.vit_ln.beta, self.vit_ln.eps, cln, self._cls_st, M=Ip)
+        emb = self._buf('emb', Ip, self.E, torch.float32)
+        pre = self._buf('embpre', Ip, self.E, torch.float32)
+        L.gemm_nt(cln, self.fc_w, emb, bias=self.fc_b, C2=pre, act=L.ACT_GELU, M=Ip)
+        return emb, pre, None, M
+
+    def _items_backward(self, c, d_emb, Ip):
+        n_items, M, E, H = c['n_items'], c['M'], self.E, self.H
+        gg = lambda f: f() if f is not None else None
+        d_pre = self._buf('d_pre', Ip, E, torch.float32)
+        L.act_bwd_f32(d_emb, c['pre'], d_pre, L.ACT_GELU)
+        dcln = self._buf('dcls_n', Ip, H, self.T)
+        L.gemm_nt(d_pre, self.fc_wT32, dcln, M=Ip)
+        dcls = self._buf('dcls', Ip, H, self.T)
+        L.ln_bwd(dcln, self._buf('cls', Ip, H, self.T), self._cls_st, self.vit_ln.gamma, dcls, M=Ip,
+                 dgamma=gg(self.vit_ln.g_gamma), dbeta=gg(self.vit_ln.g_beta))
+        dxb = self._buf('dx_a', M, H, self.T)
+        dxb.zero_()
+        L.scatter_rows(dcls, dxb, n_items, self.S)
+        spare = self._buf('dx_b', M, H, self.T)
+        for i in range(len(self.bert_blocks) - 1, -1, -1):
+            blk = self.bert_blocks[i]
+            self._vit_block_backward(blk, dxb, n_items, M, c['saved_b'][i], spare if blk.need_dx else None)
+            dxb, spare = spare, dxb
+
+    # ------------------------------------------------------------------ public: inference
+    @torch.no_grad()
+    def encode_items(self, images, noise=None):
+        L.require_gpu(images)
+        n = images.shape[0]
+        self.next_noise = noise
+        self.pack_trainables()
+        emb, _, _, _ = self._encode(images, n, False, 0, None)
+        return emb[:n].clone()

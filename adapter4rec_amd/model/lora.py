@@ -18,7 +18,7 @@ class LoRALinear(_Container):
     def __init__(self, in_features, out_features, r=0, lora_alpha=1, bias=True):
         super().__init__()
         self.in_features, self.out_features, self.r = in_features, out_features, r
-        self.weight = nn.Parameter(torch.empty(out_features, in_features), requires_grad=False)
+        self.weight = nn.Parameter(torch.empty(out_features, in_features), requires_grad=(r == 0))   # loralib freezes it only when r > 0
         self.bias = nn.Parameter(torch.empty(out_features)) if bias else None
         nn.init.kaiming_uniform_(self.weight, a=math.sqrt(5))
         if self.bias is not None:

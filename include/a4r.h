@@ -106,6 +106,20 @@ int a4r_attn_bwd(void* stream, const a4r_attn_t* a);
 int a4r_attn_long_fwd(void* stream, const a4r_attn_t* a, float* lse);
 int a4r_attn_long_bwd(void* stream, const a4r_attn_t* a, const float* lse, float* delta_ws);
 
+/* ViT / ViT-MAE input side (HF ViTEmbeddings, ViTMAEEmbeddings under Downstream/CV/model/encoders.py:21-32).
+ * a4r_patchify: out[(item*n_keep + j), c*P*P + ky*P + kx] = pixel (c, py*P + ky, px*P + kx) of patch keep_idx[item][j]
+ * (keep_idx NULL: all patches in raster order, n_keep ignored) -- the im2col of the stride-P patch convolution in the
+ * Conv2d weight's own column order, so the projection is a4r_gemm_nt with conv.weight.view(H, C*P*P).
+ * src_kind 0: img fp32 [n, C, Himg, Wimg], already normalised (the tensor Build_Lmdb_Dataset hands over,
+ * data_utils/dataset.py:85-113).  src_kind 1: img uint8 [n, Himg, Wimg, C] raw pixels; ToTensor + Normalize(0.5, 0.5)
+ * of dataset.py:77-81 is applied here: (x / 255 - 0.5) / 0.5.  patch % 8 == 0.
+ * a4r_vit_assemble: out[item*(n_keep+1) + 0] = cls + pos[0]; out[.. + 1 + j] = patches[item*n_keep + j] + pos[1 + idx_j]
+ * (cls [H], pos [1 + n_patches, H] fp32). */
+int a4r_patchify(void* stream, const void* img, int src_kind, void* out, int ldo, const int32_t* keep_idx, int n_keep,
+                 int n_items, int C, int Himg, int Wimg, int patch, int dtype);
+int a4r_vit_assemble(void* stream, const void* patches, int ldp, const float* cls, const float* pos, const int32_t* keep_idx,
+                     void* out, int ldo, int n_items, int n_keep, int H, int dtype);
+
 /* HF BertEmbeddings / RobertaEmbeddings: word[id] + pos[pos_id] + type[0] -> LayerNorm -> dropout.
  * ids [n_items, S] int64 with row stride ld_ids (the reference hands over ids||mask rows of 2*S,
  * model/encoders.py:49-52).  roberta != 0: pos_id = cumsum(id != pad) * (id != pad) + pad. */

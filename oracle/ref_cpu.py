@@ -285,7 +285,8 @@ def score_loss(prec, tgt_pos, tgt_neg, log_mask, cfg):
 def model_forward(sd, sample_items, log_mask, cfg):
     """model/model.py:48-70 Model.forward / :113-135 ModelCPC.forward."""
     e = cfg['embedding_dim']
-    embs_all = text_encoder(sd, sample_items, cfg)
+    embs_all = image_encoder(sd, sample_items, cfg, noise=cfg.get('noise')) if cfg.get('tower', 'text') == 'image' \
+        else text_encoder(sd, sample_items, cfg)
     embs = embs_all.view(-1, cfg['max_seq_len'] + 1, 2, e)
     pos_e, neg_e = embs[:, :, 0], embs[:, :, 1]
     prec = user_encoder(sd, pos_e[:, :-1], log_mask, cfg)
@@ -301,6 +302,96 @@ def loss_and_grads(sd, trainable, sample_items, log_mask, cfg):
     out = model_forward(work, sample_items, log_mask, cfg)
     grads = torch.autograd.grad(out['loss'], [work[k] for k in trainable], allow_unused=True)
     return out, {k: (g if g is not None else torch.zeros_like(work[k])) for k, g in zip(trainable, grads)}
+
+
+# --------------------------------------------------------------------------- image tower
+# HF ViTForImageClassification / ViTMAEModel are third party (transformers==4.20.1, README.md:64); the reference reaches
+# them at Downstream/CV/model/encoders.py:21-32 and wraps their sub-modules at Downstream/CV/model/model.py:182-212,
+# 432-462.  The restatement follows 4.20.1's pre-LN layer algebra; it is pinned (tools/gen_golden_cv.py) against the
+# installed HF ViT / ViT-MAE forward for the un-adapted backbone and against the reference's own wrapper classes, Model
+# and User_Encoder for everything around it.
+def _vit_prefix(sd):
+    return 'cv_encoder.image_net.vit.' if 'cv_encoder.image_net.vit.layernorm.weight' in sd else 'cv_encoder.image_net.'
+
+
+def vit_sub_output(sd, p, h, cfg):
+    """(possibly wrapped) ViTSelfOutput / ViTOutput at prefix p: dense [-> adapter]; the residual is added by the caller
+    (ViTLayer for attention.output, the wrapper / ViTOutput itself for output -- same sum either way)."""
+    if p + 'self_output.dense.weight' in sd:
+        h = linear(h, sd[p + 'self_output.dense.weight'], sd[p + 'self_output.dense.bias'])
+        a = p + 'adapter.'
+        if a + 'down_sampler.W_left' in sd:          # model.py:432-462 (HyperComplexAdapterBlock: no inner residual)
+            return compacter_block(sd, a, h, cfg)
+        return houlsby_block(sd, a, h, cfg)          # model.py:182-212
+    return linear(h, sd[p + 'dense.weight'], sd[p + 'dense.bias'])
+
+
+def vit_embed(sd, images, cfg, noise=None):
+    """HF ViTEmbeddings / ViTMAEEmbeddings (4.20.1).  MAE: patches + pos[1:], keep the int(N (1 - ratio)) patches of
+    smallest noise in argsort order, prepend cls + pos[0]."""
+    p = _vit_prefix(sd) + 'embeddings.'
+    w, b = sd[p + 'patch_embeddings.projection.weight'], sd[p + 'patch_embeddings.projection.bias']
+    x = torch.nn.functional.conv2d(images, w, b, stride=w.shape[-1]).flatten(2).transpose(1, 2)
+    n = x.shape[0]
+    pos, cls = sd[p + 'position_embeddings'], sd[p + 'cls_token']
+    if cfg.get('mae'):
+        x = x + pos[:, 1:]
+        keep = torch.argsort(noise, dim=1)[:, :int(x.shape[1] * (1 - cfg.get('mask_ratio', 0.75)))]
+        x = torch.gather(x, 1, keep[:, :, None].expand(-1, -1, x.shape[2]))
+        return torch.cat([(cls + pos[:, :1]).expand(n, -1, -1), x], 1)
+    return torch.cat([cls.expand(n, -1, -1), x], 1) + pos
+
+
+def vit_layer(sd, lp, x, cfg):
+    """HF ViTLayer (pre-LN): x + attn(LN(x)); then + mlp(LN(.)).  q / v may be loralib Linears (run_adapter.py:384-388)."""
+    eps, nh = cfg.get('vit_ln_eps', 1e-12), cfg['vit_heads']
+    n, s, hdim = x.shape
+    n1 = layer_norm(x, sd[lp + 'layernorm_before.weight'], sd[lp + 'layernorm_before.bias'], eps)
+    a = lp + 'attention.attention.'
+    r = cfg.get('lora_r_vit', 0)
+    q, k, v = lora_linear(sd, a + 'query.', n1, r), linear(n1, sd[a + 'key.weight'], sd[a + 'key.bias']), lora_linear(sd, a + 'value.', n1, r)
+    sp = lambda t: t.view(n, s, nh, hdim // nh).transpose(1, 2)
+    pr = torch.softmax(sp(q) @ sp(k).transpose(-1, -2) / math.sqrt(hdim // nh), -1)
+    ctx = (pr @ sp(v)).transpose(1, 2).reshape(n, s, hdim)
+    x1 = vit_sub_output(sd, lp + 'attention.output.', ctx, cfg) + x
+    n2 = layer_norm(x1, sd[lp + 'layernorm_after.weight'], sd[lp + 'layernorm_after.bias'], eps)
+    u = gelu_erf(linear(n2, sd[lp + 'intermediate.dense.weight'], sd[lp + 'intermediate.dense.bias']))
+    return vit_sub_output(sd, lp + 'output.', u, cfg) + x1
+
+
+def vit_encode(sd, images, cfg, noise=None, return_all=False):
+    p = _vit_prefix(sd)
+    x = vit_embed(sd, images, cfg, noise)
+    hs = [x]
+    i = 0
+    while f'{p}encoder.layer.{i}.layernorm_before.weight' in sd:
+        x = vit_layer(sd, f'{p}encoder.layer.{i}.', x, cfg)
+        hs.append(x)
+        i += 1
+    x = layer_norm(x, sd[p + 'layernorm.weight'], sd[p + 'layernorm.bias'], cfg.get('vit_ln_eps', 1e-12))
+    return (x, hs) if return_all else x
+
+
+def image_encoder(sd, images, cfg, noise=None):
+    """Downstream/CV/model/encoders.py:21-22 (MAE_Encoder: GELU(cv_proj(last_hidden[:, 0]))) / :31-32 (Vit_Encoder:
+    GELU(classifier(layernorm(x)[:, 0])))."""
+    cls = vit_encode(sd, images, cfg, noise)[:, 0]
+    if cfg.get('mae'):
+        return gelu_erf(linear(cls, sd['cv_encoder.cv_proj.weight'], sd['cv_encoder.cv_proj.bias']))
+    return gelu_erf(linear(cls, sd['cv_encoder.image_net.classifier.weight'], sd['cv_encoder.image_net.classifier.bias']))
+
+
+def normalize_u8(img_u8_hwc):
+    """Downstream/CV/data_utils/dataset.py:77-81 without the Resize (source already R x R): ToTensor + Normalize(0.5, 0.5)."""
+    return ((img_u8_hwc.float() / 255.0 - 0.5) / 0.5).permute(0, 3, 1, 2).contiguous()
+
+
+def lr_group_cv(name, cfg_lrs):
+    """Downstream/CV/run_adapter.py:491-517."""
+    ad = 'adapter' in name
+    if 'image_net' in name and not ('fc' in name or 'classifier' in name or 'decoder_pred' in name):
+        return cfg_lrs['adapter_cv_lr'] if ad else cfg_lrs['fine_tune_lr']
+    return cfg_lrs['adapter_sasrec_lr'] if ad else cfg_lrs['lr']
 
 
 # --------------------------------------------------------------------------- optimiser
@@ -319,7 +410,7 @@ def adam_step(p, g, m, v, step, lr, b1=0.9, b2=0.999, eps=1e-8):
     p.sub_((lr / bc1) * m / (v.sqrt() / math.sqrt(bc2) + eps))
 
 
-def train_steps(sd, trainable, batches, cfg, lrs, n_steps):
+def train_steps(sd, trainable, batches, cfg, lrs, n_steps, group=None):
     """n Adam steps on the same restatement; returns the list of losses and the final trainable tensors."""
     sd = {k: v.detach().clone() for k, v in sd.items()}
     ms = {k: torch.zeros_like(sd[k]) for k in trainable}
@@ -330,7 +421,7 @@ def train_steps(sd, trainable, batches, cfg, lrs, n_steps):
         out, grads = loss_and_grads(sd, trainable, items, mask, cfg)
         losses.append(float(out['loss'].detach()))
         for k in trainable:
-            adam_step(sd[k], grads[k], ms[k], vs[k], s, lr_group(k, lrs))
+            adam_step(sd[k], grads[k], ms[k], vs[k], s, (group or lr_group)(k, lrs))
     return losses, {k: sd[k] for k in trainable}
 
 

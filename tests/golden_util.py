@@ -51,3 +51,35 @@ def load_variant(name):
     trainable = [strip(str(k)) for k in fx['trainable']]
     batch = (torch.from_numpy(base['sample_items']).view(-1, 60), torch.from_numpy(base['log_mask']))
     return sd, cfg, fx, trainable, batch, base
+
+
+# ---------------------------------------------------------------- image path fixtures (tools/gen_golden_cv.py)
+CV_VARIANT_CFG = {
+    'cv_vit_houlsby': dict(),
+    'cv_vit_houlsby_gelu_ln': dict(adapter_activation='GELU'),
+    'cv_vit_pfeiffer_ver2': dict(adapter_type='pfeiffer_ver2'),
+    'cv_vit_compacter': dict(adapter_type='compacter'),
+    'cv_vit_cpc': dict(arch='cpc'),
+    'cv_mae_houlsby': dict(mae=True),
+    'cv_vit_frozen': dict(adapter_type='none'),
+}
+CV_LRS = dict(fine_tune_lr=1e-5, lr=1e-3, adapter_cv_lr=5e-4, adapter_sasrec_lr=1e-4)
+
+
+def load_cv_variant(name):
+    """-> (sd, cfg, fixture, trainable names, (images [n,3,R,R], log_mask), noise)."""
+    from oracle.ref_cpu import DEFAULT_CFG
+    common = np.load(os.path.join(GOLDEN, 'cv_base.npz'))
+    base = np.load(os.path.join(GOLDEN, 'cv_base_mae.npz')) if 'mae' in name else common
+    fx = np.load(os.path.join(GOLDEN, name + '.npz'))
+    base_sd = {k[3:]: torch.from_numpy(base[k]) for k in base.files if k.startswith('sd/')}
+    sd = {}
+    for k in fx['all_keys']:
+        k = str(k)
+        sd[strip(k)] = torch.from_numpy(fx['sd/' + k]) if 'sd/' + k in fx.files else base_sd[base_name(k)]
+    cfg = dict(DEFAULT_CFG)
+    cfg.update(tower='image', vit_heads=2, noise=torch.from_numpy(common['noise']))
+    cfg.update(CV_VARIANT_CFG[name])
+    trainable = [strip(str(k)) for k in fx['trainable']]
+    batch = (torch.from_numpy(common['images']), torch.from_numpy(common['log_mask']))
+    return sd, cfg, fx, trainable, batch, cfg['noise']

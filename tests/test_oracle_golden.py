@@ -87,3 +87,41 @@ def test_eval_fixture():
         hr, nd = R.hit_ndcg(ranks)
         assert abs(hr - float(fx[tag + '_means'][0])) < 1e-3      # HR@10 / nDCG@10 within 1e-3
         assert abs(nd - float(fx[tag + '_means'][1])) < 1e-3
+
+
+# ------------------------------------------------------------------ image path (ViT / ViT-MAE tower)
+from golden_util import CV_LRS, CV_VARIANT_CFG, load_cv_variant  # noqa: E402
+
+
+@pytest.mark.parametrize('name', list(CV_VARIANT_CFG))
+def test_cv_forward_and_grads(name):
+    sd, cfg, fx, trainable, (images, mask), _ = load_cv_variant(name)
+    with torch.no_grad():
+        out = R.model_forward(sd, images, mask, cfg)
+    np.testing.assert_allclose(out['input_embs_all'].numpy(), fx['input_embs_all'], atol=TOL, rtol=0)
+    np.testing.assert_allclose(out['prec_vec'].numpy(), fx['prec_vec'], atol=TOL, rtol=0)
+    assert abs(float(out['loss']) - float(fx['loss'])) < TOL * max(1.0, float(fx['loss']))
+    gkeys = [k[5:] for k in fx.files if k.startswith('grad/')]
+    assert gkeys or name == 'cv_vit_frozen'
+    if gkeys:
+        _, grads = R.loss_and_grads(sd, [strip(k) for k in gkeys], images, mask, cfg)
+        for k in gkeys:
+            ref = fx['grad/' + k]
+            np.testing.assert_allclose(grads[strip(k)].numpy(), ref, atol=1e-5 + 1e-4 * np.abs(ref).max(), rtol=0, err_msg=k)
+
+
+@pytest.mark.parametrize('name', ['cv_vit_houlsby', 'cv_vit_compacter', 'cv_mae_houlsby'])
+def test_cv_adam_three_steps(name):
+    sd, cfg, fx, trainable, batch, _ = load_cv_variant(name)
+    # lr groups are decided on the module names incl. the CompacterModel 'model.' prefix (none of the tests here depends on it)
+    losses3, p3 = R.train_steps(sd, trainable, [batch], cfg, CV_LRS, 3, group=R.lr_group_cv)
+    np.testing.assert_allclose(losses3, fx['adam_losses'], atol=TOL * 20, rtol=0)
+    for k in fx['trainable']:
+        k = str(k)
+        np.testing.assert_allclose(p3[strip(k)].numpy(), fx['adam3/' + k], rtol=2e-4, atol=2e-7, err_msg=k)
+
+
+def test_cv_backbone_matches_installed_hf():
+    """The generator first checked its 4.20.1-shaped backbone against the installed HuggingFace ViT / ViT-MAE."""
+    d = np.load(GOLDEN + '/cv_base.npz')['hf_check']
+    assert d.max() < 2e-5
