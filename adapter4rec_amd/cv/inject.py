@@ -26,8 +26,9 @@ def inject_adapters(model, args):
         r_vit = int(getattr(args, 'lora_r', 12))
         r_q = int(getattr(args, 'lora_r_sasrec', 4))
         for lyr in layers:
-            lyr.attention.attention.query = LoRALinear(768, 768, r=r_vit)
-            lyr.attention.attention.value = LoRALinear(768, 768, r=r_vit)
+            h = lyr.attention.attention.query.in_features          # 768 in the reference (ViT-B)
+            lyr.attention.attention.query = LoRALinear(h, h, r=r_vit)
+            lyr.attention.attention.value = LoRALinear(h, h, r=r_vit)
         for blk in blocks:
             blk.multi_head_attention.w_Q = LoRALinear(args.embedding_dim, args.embedding_dim, r=r_q)
             blk.multi_head_attention.w_V = LoRALinear(args.embedding_dim, args.embedding_dim)      # r = 0: a plain trainable Linear

@@ -100,7 +100,8 @@ class ViTForImageClassification(_Container):
 
     def __init__(self, config=None, **overrides):
         super().__init__()
-        cfg = dict(VIT_BASE if config is None else config)
+        cfg = dict(VIT_BASE)
+        cfg.update(config or {})
         cfg.update(overrides)
         self.config = cfg
         self.vit = ViTModelParams(cfg)
@@ -130,7 +131,8 @@ class ViTMAEModel(_Container):
 
     def __init__(self, config=None, **overrides):
         super().__init__()
-        cfg = dict(VIT_BASE if config is None else config, model_type='vit_mae')
+        cfg = dict(VIT_BASE, model_type='vit_mae')
+        cfg.update(config or {})
         cfg.update(overrides)
         self.config = cfg
         self.embeddings = ViTEmbeddingsParams(cfg, learned_pos=False)

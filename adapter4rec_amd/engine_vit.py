@@ -181,7 +181,8 @@ class ViTRecEngine(TransRecEngine):
         dx1 = self._buf('dx1', M, H, T)
         L.ln_bwd(dn2, bufs['x1'], bufs['stb'], blk.lnB.gamma, dx1, M=M, dgamma=gg(blk.lnB.g_gamma), dbeta=gg(blk.lnB.g_beta), dres=dx_out)
         da = self._vit_sub_backward(blk, blk.ad1, dx1, bufs, '1', M)
-        if dx_in is None and not blk.lora:
+        ln_a = blk.lnA.g_gamma is not None           # --finetune_layernorm: layer 0 still owes its LN_before gradients
+        if dx_in is None and not blk.lora and not ln_a:
             return
         dctx = self._buf('dctx', M, H, T)
         L.gemm_nt(da, blk.woT, dctx, M=M)
@@ -190,7 +191,9 @@ class ViTRecEngine(TransRecEngine):
         L.attn_long_bwd(bufs['qkv'], dctx, dqkv, bufs['lse'], ws, n_items, blk.S, blk.nh, blk.dh, 0, H, 2 * H, blk.scale)
         for lo in blk.lora:
             self._lora_backward(blk, lo, dqkv, bufs['n1'], M)
-        if dx_in is not None:
+        if dx_in is not None or ln_a:
+            if dx_in is None:
+                dx_in = self._buf('dx_unused', M, H, T)
             dn1 = self._buf('dn', M, H, T)
             L.gemm_nt(dqkv, blk.wqkvT, dn1, M=M)
             L.ln_bwd(dn1, bufs['x0'], bufs['sta'], blk.lnA.gamma, dx_in, M=M, dgamma=gg(blk.lnA.g_gamma), dbeta=gg(blk.lnA.g_beta), dres=dx1)
@@ -229,17 +232,14 @@ class ViTRecEngine(TransRecEngine):
         L.vit_assemble(pe, self.cls_tok, self.pos_tab, x, n_items, self.n_keep, keep)
         other = self._buf('xb', M, H, self.T)
         nb = len(self.bert_blocks)
-        xl = self._buf('x_last', M, H, self.T)
         for i, blk in enumerate(self.bert_blocks):
-            if saved is not None:
-                out = saved[i + 1]['x0'] if i + 1 < nb else xl
+            if saved is not None:                 # training: layer i writes straight into layer i+1's saved input
+                out = saved[i + 1]['x0'] if i + 1 < nb else self._buf('x_last', M, H, self.T)
                 self._vit_block_forward(blk, x, n_items, M, saved[i], out)
                 x = out
-            else:
-                bufs = self._block_bufs('vit.shared', blk, M, True)
-                out = xl if i + 1 == nb else other
-                self._vit_block_forward(blk, x, n_items, M, bufs, out)
-                x, other = out, (x if x is not xl else other)
+            else:                                 # inference: one transient buffer set, two ping-pong activations
+                self._vit_block_forward(blk, x, n_items, M, self._block_bufs('vit.shared', blk, M, True), other)
+                x, other = other, x
         Ip = pad_to(n_items, 128)
         cls = self._buf('cls', Ip, H, self.T)
         L.gather_rows(x, cls, n_items, S)

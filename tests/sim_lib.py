@@ -122,6 +122,40 @@ def attn_bwd(qkv, dout, dqkv, key_mask, n_items, S, n_heads, dh, q_off, k_off, v
     dqkv[:n_items * S] = q.grad[:n_items * S].to(dqkv.dtype)
 
 
+def attn_long_fwd(qkv, out, lse, n_items, S, n_heads, dh, q_off, k_off, v_off, scale):
+    assert dh == 64 and S <= 256
+    Hd = n_heads * dh
+    x = qkv.float()
+    q, k = [x[:n_items * S, o:o + Hd].view(n_items, S, n_heads, dh).transpose(1, 2) for o in (q_off, k_off)]
+    lse.view(-1)[:n_items * n_heads * S] = torch.logsumexp(q @ k.transpose(-1, -2) * scale, -1).reshape(-1)
+    km = torch.ones(n_items, S)
+    out[:n_items * S] = _attn(x, km, n_items, S, n_heads, dh, (q_off, k_off, v_off), False, scale, 0.0).to(out.dtype)
+
+
+def attn_long_bwd(qkv, dout, dqkv, lse, delta_ws, n_items, S, n_heads, dh, q_off, k_off, v_off, scale):
+    attn_bwd(qkv, dout, dqkv, torch.ones(n_items, S), n_items, S, n_heads, dh, q_off, k_off, v_off, False, scale, 0.0)
+
+
+def patchify(img, out, patch, keep_idx=None):
+    if img.dtype == torch.uint8:
+        img = ((img.float() / 255.0 - 0.5) / 0.5).permute(0, 3, 1, 2)
+    n, C, Hi, Wi = img.shape
+    cols = torch.nn.functional.unfold(img.float(), kernel_size=patch, stride=patch).transpose(1, 2)     # [n, NP, C*P*P] in (c, ky, kx) order
+    if keep_idx is not None:
+        cols = torch.gather(cols, 1, keep_idx.long()[:, :, None].expand(-1, -1, cols.shape[2]))
+    rows = cols.reshape(-1, cols.shape[2])
+    out[:rows.shape[0], :rows.shape[1]] = rows.to(out.dtype)
+
+
+def vit_assemble(patches, cls, pos, out, n_items, n_keep, keep_idx=None):
+    H = cls.numel()
+    x = patches[:n_items * n_keep, :H].float().view(n_items, n_keep, H)
+    idx = keep_idx.long() if keep_idx is not None else torch.arange(n_keep)[None].expand(n_items, -1)
+    x = x + pos[1:][idx]
+    tok = torch.cat([(cls + pos[0])[None, None].expand(n_items, 1, H), x], 1)
+    out[:n_items * (n_keep + 1)] = tok.reshape(-1, H).to(out.dtype)
+
+
 def embed_ln(ids, word, pos, type0, gamma, beta, eps, out, n_items, S, roberta=False, pad_id=0,
              drop_p=0.0, drop_site=0, drop_seed=0):
     assert drop_p == 0.0
