@@ -30,7 +30,7 @@ __global__ void __launch_bounds__(256) patchify_kernel(const void* __restrict__ 
         if constexpr (U8) {                                           // [item][y][x][c] bytes
             const unsigned char* s = reinterpret_cast<const unsigned char*>(img) + (((long)item * Hi + y) * Wi + x) * C + c;
 #pragma unroll
-            for (int e = 0; e < PER; ++e) v[e] = ((float)s[e * C] * (1.f / 255.f) - 0.5f) / 0.5f;
+            for (int e = 0; e < PER; ++e) v[e] = ((float)s[e * C] / 255.f - 0.5f) / 0.5f;   // ToTensor (div 255) then Normalize (sub, div): same roundings
         } else {                                                      // [item][c][y][x] fp32, already normalised
             const float* s = reinterpret_cast<const float*>(img) + (((long)item * C + c) * Hi + y) * Wi + x;
 #pragma unroll

@@ -38,6 +38,61 @@ def make_args(batch, dtype):
         fine_tune_lr=5e-5, lr=1e-4, adapter_bert_lr=1.5e-4, adapter_sasrec_lr=1.5e-4)
 
 
+WORKLOADS = {
+    # name: (BASELINE.json config, default users/GPU, description, data)
+    'bert_houlsby': ('configs[1]', 32, 'MIND-shape SASRec+BERT-base+Houlsby adapter train step (fwd+bwd+allreduce+Adam), dropout on',
+                     'synthetic (seed 123456, 65536 items, 30-token titles, full 23-item histories; random-init BERT-base)'),
+    'roberta_pfeiffer_cpc': ('configs[3]', 32, 'Adressa-shape CPC+RoBERTa-base+Pfeiffer adapter (relu) train step, dropout on',
+                             'synthetic (seed 123456, 65536 items, 30-token titles, vocab 50265, pad id 1; random-init RoBERTa-base)'),
+    'vit_lora': ('configs[2]', 8, 'HM-shape SASRec+ViT-B/16+LoRA r=8 (q, v) train step from uint8 224x224 images resident in HBM',
+                 'synthetic (seed 123456, uint8 images U{0..255} [336, 224, 224, 3] per step; random-init ViT-B/16)'),
+    'mae_compacter': ('configs[4], bf16 instead of fp8', 8, 'Amazon-shape SASRec+ViT-MAE-base (75 % masked, 50 tokens)+Compacter train step from uint8 images',
+                      'synthetic (seed 123456, uint8 images, on-device masking noise; random-init ViT-MAE-base)'),
+}
+
+
+def make_cv_args(batch, dtype, workload):
+    a = argparse.Namespace(
+        max_seq_len=20, l2_weight=0, embedding_dim=64, num_attention_heads=2, drop_rate=0.1, transformer_block=2,
+        CV_model_load='vit-mae-base' if workload == 'mae_compacter' else 'vit-base-patch16-224', CV_resize=224,
+        cv_adapter_down_size=64, adapter_down_size=16, adapter_dropout_rate=0.1, adapter_activation='RELU',
+        hypercomplex_division=4, phm_init_range=1e-4, adapter_type='compacter' if workload == 'mae_compacter' else 'lora',
+        is_serial='True', adding_adapter_to='all', arch='sasrec', compute_dtype=dtype, batch_size=batch, lora_r=8, lora_r_sasrec=4,
+        fine_tune_lr=1e-5, lr=1e-3, adapter_cv_lr=5e-4, adapter_sasrec_lr=1e-4)
+    return a
+
+
+def build_cv_model(args, device):
+    from adapter4rec_amd.cv import Model, ViTForImageClassification, ViTMAEModel
+    from adapter4rec_amd.cv.inject import inject_adapters, optimizer_groups
+    from adapter4rec_amd.inject import freeze_all
+    from adapter4rec_amd.optim import FusedAdam
+    torch.manual_seed(SEED)
+    if 'mae' in args.CV_model_load:
+        net = ViTMAEModel()
+    else:
+        net = ViTForImageClassification(num_labels=args.embedding_dim)      # classifier swapped for Linear(768, 64), run_adapter.py:291-296
+        torch.nn.init.xavier_normal_(net.classifier.weight)
+    model = Model(args, 8192, True, net)
+    freeze_all(model)
+    model = inject_adapters(model, args)
+    model.to(device)
+    model.train()
+    opt = FusedAdam(optimizer_groups(model, args))
+    return model, opt
+
+
+def synth_image_batches(batch, n_batches, device, seed):
+    """uint8 HWC images, 21 + 21 slots per user; the last negative slot is never filled (dataset.py:94-105)."""
+    g = torch.Generator(device=device).manual_seed(seed)
+    out = []
+    for _ in range(n_batches):
+        img = torch.randint(0, 256, (batch, 21, 2, 224, 224, 3), generator=g, device=device, dtype=torch.uint8)
+        img[:, -1, 1] = 0
+        out.append((img.view(-1, 224, 224, 3), torch.ones(batch, 20, device=device)))
+    return out
+
+
 def synth_content(n_items, g):
     """item_content [n_items + 1, 60]: [101, t_1..t_28, 102] || ones; item 0 = zeros (SURVEY.md 8(d) canonical variant)."""
     c = torch.zeros(n_items + 1, 60, dtype=torch.int64)
@@ -60,12 +115,12 @@ def synth_batches(content, n_items, batch, n_batches, g):
     return out
 
 
-def build_model(args, device):
+def build_model(args, device, roberta=False):
     from adapter4rec_amd.inject import freeze_all, inject_adapters, optimizer_groups
-    from adapter4rec_amd.model import BERT_BASE, BertBackbone, Model
+    from adapter4rec_amd.model import BERT_BASE, ROBERTA_BASE, BertBackbone, Model, ModelCPC
     from adapter4rec_amd.optim import FusedAdam
     torch.manual_seed(SEED)
-    model = Model(args, 65536, True, BertBackbone(BERT_BASE))
+    model = (ModelCPC if args.arch == 'cpc' else Model)(args, 65536, True, BertBackbone(ROBERTA_BASE if roberta else BERT_BASE))
     freeze_all(model)
     model = inject_adapters(model, args)
     model.to(device)
@@ -159,7 +214,9 @@ def main():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=20)
     ap.add_argument('--warmup', type=int, default=5)
-    ap.add_argument('--batch', type=int, default=32, help='users per GPU per step (reference default: 32)')
+    ap.add_argument('--batch', type=int, default=0, help="users per GPU per step (default: the reference's 32 for text, 8 for images)")
+    ap.add_argument('--workload', default='bert_houlsby', choices=list(WORKLOADS),
+                    help="bert_houlsby = the configuration BASELINE.json's metric is quoted on; the others are its remaining configs")
     ap.add_argument('--dtype', default='bf16', choices=['bf16', 'fp32'])
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-roofline', action='store_true')
@@ -178,13 +235,28 @@ def main():
     assert world == a.gpus or world == 1, f'--gpus {a.gpus} but WORLD_SIZE={world}'
 
     from adapter4rec_amd import _lib as L
-    args = make_args(a.batch, a.dtype)
-    model, opt = build_model(args, device)
-    eng = model._engine()
-    g = torch.Generator().manual_seed(SEED + rank)            # users are sharded: every rank draws its own users
-    gc = torch.Generator().manual_seed(SEED)
-    content = synth_content(65536, gc)
-    batches = [(i.to(device), m.to(device)) for i, m in synth_batches(content, 65536, a.batch, 4, g)]
+    wl = a.workload
+    a.batch = a.batch or WORKLOADS[wl][1]
+    image = wl in ('vit_lora', 'mae_compacter')
+    if image:
+        args = make_cv_args(a.batch, a.dtype, wl)
+        model, opt = build_cv_model(args, device)
+        inner = getattr(model, 'model', model)
+        eng = inner._engine()
+        batches = synth_image_batches(a.batch, 2, device, SEED + rank)
+    else:
+        args = make_args(a.batch, a.dtype)
+        if wl == 'roberta_pfeiffer_cpc':
+            args.adapter_type, args.adapter_activation, args.arch, args.bert_model_load = 'pfeiffer', 'relu', 'cpc', 'roberta_base'
+        model, opt = build_model(args, device, roberta=(wl == 'roberta_pfeiffer_cpc'))
+        eng = model._engine()
+        g = torch.Generator().manual_seed(SEED + rank)            # users are sharded: every rank draws its own users
+        gc = torch.Generator().manual_seed(SEED)
+        content = synth_content(65536, gc)
+        if wl == 'roberta_pfeiffer_cpc':                           # <s> ... </s>, pad id 1
+            content[1:, 0], content[1:, 29] = 0, 2
+            content[1:, 1:29] = torch.randint(3, 50265, (65536, 28), generator=gc)
+        batches = [(i.to(device), m.to(device)) for i, m in synth_batches(content, 65536, a.batch, 4, g)]
     if world > 1:                                              # DDP constructor semantics: rank 0's trainables everywhere
         dist.broadcast(eng.flat_p, 0)
 
@@ -251,19 +323,21 @@ def main():
             print(json.dumps(shapes, indent=1), file=sys.stderr)
 
     cpu = None
-    if rank == 0 and world == 1 and not a.no_cpu_baseline:
+    if rank == 0 and world == 1 and not a.no_cpu_baseline and wl == 'bert_houlsby':
         cpu = cpu_baseline()
 
     if rank == 0:
         users = world * a.batch * a.steps
         out = {
-            'metric': 'user-sequences/sec, seq_len=23 BERT+SASRec+Adapter', 'value': round(users / dt, 2),
+            'metric': {'bert_houlsby': 'user-sequences/sec, seq_len=23 BERT+SASRec+Adapter', 'roberta_pfeiffer_cpc': 'user-sequences/sec, seq_len=23 RoBERTa+CPC+Pfeiffer',
+                       'vit_lora': 'user-sequences/sec, seq_len=23 ViT+SASRec+LoRA', 'mae_compacter': 'user-sequences/sec, seq_len=23 MAE+SASRec+Compacter'}[wl],
+            'value': round(users / dt, 2),
             'unit': 'user-sequences/sec', 'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup,
             'ms_per_step': round(dt / a.steps * 1e3, 3), 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
-            'dtype': a.dtype, 'data': 'synthetic (seed 123456, 65536 items, 30-token titles, full 23-item histories; random-init BERT-base)',
-            'config': {'workload': 'MIND-shape SASRec+BERT-base+Houlsby adapter train step (fwd+bwd+allreduce+Adam), dropout on',
-                       'users_per_gpu': a.batch, 'global_batch': world * a.batch, 'seq_len': 23, 'title_tokens': 30,
-                       'items_per_user': 42, 'parallelism': f'dp{world}'},
+            'dtype': a.dtype, 'data': WORKLOADS[wl][3],
+            'config': {'workload': WORKLOADS[wl][2], 'baseline_config': WORKLOADS[wl][0],
+                       'users_per_gpu': a.batch, 'global_batch': world * a.batch, 'seq_len': 23,
+                       'tokens_per_item': eng.S, 'items_per_user': 42, 'parallelism': f'dp{world}'},
             'loss': round(loss_val, 5), 'roofline': roof, 'cpu_baseline': cpu,
         }
         print(json.dumps(out))
