@@ -1,6 +1,6 @@
 // a4r_attn_long_fwd / a4r_attn_long_bwd: un-masked multi-head attention for 32 < S <= 256 tokens per item, head width 64
 // -- the ViT / MAE item tower (S = 197 / 50; HF ViTSelfAttention as called from Downstream/CV/model/encoders.py:21-32).
-// The S <= 32 kernels of a4r_attn.hip keep a whole score matrix in one wave; here one workgroup (4 waves) owns one
+// The S <= 32 kernels of a4r_attn.hip keep a whole score matrix in one wave; here one workgroup (8 waves) owns one
 // (item, head) pair, stages the key-side matrices of that pair in LDS and never writes anything S x S to HBM.
 //
 // Everything is the 16x16 "chunk" primitive of a4r_common.h (so the bf16 and exact-fp32 instantiations share all
@@ -26,6 +26,10 @@ namespace {
 
 template <typename T> A4R_DEV uint4 ldg16(const T* p) { return *reinterpret_cast<const uint4*>(p); }
 
+// 8 waves per (item, head) workgroup: two workgroups (114 KB of LDS at S = 197) give a CU 4 waves per SIMD to hide the
+// staging and Q / dO load latency behind; with 4-wave workgroups the chip sat at 0.4 waves per SIMD (PMC).
+constexpr int NTHR = 512, NWAVE = NTHR / 64;
+
 template <typename T> struct Geo {
     static constexpr int PER = Elem<T>::PER16;              // elements per 16-byte chunk
     static constexpr int KSTEP = Mma<T>::KSTEP;             // contraction length of one chunk step (32 / 16)
@@ -39,7 +43,7 @@ template <typename T> struct Geo {
 // [S][64] (global, row stride ld) -> LDS row-major [SP][64], 16-byte chunks XOR-swizzled; rows >= S are zero
 template <typename T> A4R_DEV void stage_rows(char* lds, const T* src, int ld, int S, int SP, int tid) {
     using G = Geo<T>;
-    for (int id = tid; id < SP * G::CPR; id += 256) {
+    for (int id = tid; id < SP * G::CPR; id += NTHR) {
         const int r = id / G::CPR, c = id % G::CPR;
         const uint4 v = r < S ? ldg16(src + (size_t)r * ld + c * G::PER) : make_uint4(0, 0, 0, 0);
         *reinterpret_cast<uint4*>(lds + r * G::ROWB + ((c ^ G::swz(r)) << 4)) = v;
@@ -48,7 +52,7 @@ template <typename T> A4R_DEV void stage_rows(char* lds, const T* src, int ld, i
 // [S][64] -> LDS transposed [64][SPT] (SPT = SP + 8 elements); columns >= S are zero
 template <typename T> A4R_DEV void stage_cols(T* lds, const T* src, int ld, int S, int SP, int SPT, int tid) {
     using G = Geo<T>;
-    for (int id = tid; id < SP * G::CPR; id += 256) {
+    for (int id = tid; id < SP * G::CPR; id += NTHR) {
         const int c = id / SP, r = id % SP;                  // consecutive lanes -> consecutive rows: LDS stores spread over banks
         const uint4 v = r < S ? ldg16(src + (size_t)r * ld + c * G::PER) : make_uint4(0, 0, 0, 0);
         const T* e = reinterpret_cast<const T*>(&v);
@@ -72,6 +76,28 @@ template <typename T> A4R_DEV uint4 frag_cols(const T* lds, int SPT, int d, int 
         return *reinterpret_cast<const uint4*>(p);
     }
 }
+// The same operand chunk for bf16 WITHOUT a transposed copy: ds_read_b64_tr_b16 gathers, per 16-lane group, a 4-row x 16-column
+// block of a ROW-major image and hands lane i the block's column i (4 consecutive rows) -- exactly the 4 + 4 keys the permuted
+// contraction index asks for.  Lane 4q + p of a group supplies the address of block row q, columns 4p .. 4p+3.  EXEC must be
+// all ones (every call site sits in wave-uniform control flow).
+typedef short v4s_t __attribute__((ext_vector_type(4)));
+A4R_DEV uint4 frag_tr(const char* lds, int d0, int st, int lane) {
+    const int kg = lane >> 4, q = (lane >> 2) & 3, p = lane & 3;
+    const int chunk = (d0 >> 3) + (p >> 1);
+    const int r0 = 32 * st + 4 * kg + q, r1 = r0 + 16;
+    const char* a0 = lds + r0 * 128 + ((chunk ^ ((r0 >> 1) & 7)) << 4) + 8 * (p & 1);
+    const char* a1 = lds + r1 * 128 + ((chunk ^ ((r1 >> 1) & 7)) << 4) + 8 * (p & 1);
+    const v4s_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) v4s_t*)(a0));
+    const v4s_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) v4s_t*)(a1));
+    const uint2 l2 = __builtin_bit_cast(uint2, lo), h2 = __builtin_bit_cast(uint2, hi);
+    return make_uint4(l2.x, l2.y, h2.x, h2.y);
+}
+// one accessor for both element types: bf16 reads the row-major image transposed, fp32 a transposed copy
+template <typename T> A4R_DEV uint4 frag_T(const void* img, int SPT, int d0, int st, int lane) {
+    if constexpr (sizeof(T) == 2) return frag_tr(reinterpret_cast<const char*>(img), d0, st, lane);
+    else return frag_cols<T>(reinterpret_cast<const T*>(img), SPT, d0 + (lane & 15), st, lane >> 4);
+}
+
 // probabilities / score gradients of chunk step st as an operand chunk (see the k-slot permutation in the header)
 template <typename T, int NKT> A4R_DEV uint4 pack_step(const f32x4_t (&t)[NKT], int st) {
     if constexpr (sizeof(T) == 2) {
@@ -110,27 +136,30 @@ A4R_DEV void scores_t(const char* Kr, const uint4 (&qf)[Geo<T>::KS], f32x4_t (&s
 #pragma unroll
         for (int r = 0; r < 4; ++r) acc[r] = (kt * 16 + kg * 4 + r < S) ? acc[r] * scale : -INFINITY;
         s[kt] = acc;
+        if ((kt & 1) == 1) __builtin_amdgcn_sched_barrier(0);      // keeps the scheduler from hoisting all 2 NKT fragment reads (spills)
     }
 }
 
 // ------------------------------------------------------------------------------------------------ forward
 template <typename T, int NKT>
-__global__ void __launch_bounds__(256) attn_long_fwd_kernel(const T* __restrict__ qkv, int ld, int q_off, int k_off, int v_off,
+__global__ void __launch_bounds__(NTHR, 4) attn_long_fwd_kernel(const T* __restrict__ qkv, int ld, int q_off, int k_off, int v_off,
                                                             T* __restrict__ ctx, int ldo, float* __restrict__ lse,
                                                             int S, int nh, float scale) {
     using G = Geo<T>;
     constexpr int SP = NKT * 16, SPT = SP + 8, NST = SP / G::KSTEP;
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr bool TR = sizeof(T) == 2;
     char* Kr = smem;                                                  // [SP][64] row-major
-    T* Vt = reinterpret_cast<T*>(smem + SP * G::ROWB);                // [64][SPT] transposed
+    char* Vimg = smem + SP * G::ROWB;                                 // bf16: [SP][64] row-major (read transposed); fp32: [64][SPT]
     const int item = blockIdx.x / nh, h = blockIdx.x % nh;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, fr = lane & 15, kg = lane >> 4;
     const T* base = qkv + (size_t)item * S * ld + h * 64;
     stage_rows<T>(Kr, base + k_off, ld, S, SP, tid);
-    stage_cols<T>(Vt, base + v_off, ld, S, SP, SPT, tid);
+    if constexpr (TR) stage_rows<T>(Vimg, base + v_off, ld, S, SP, tid);
+    else stage_cols<T>(reinterpret_cast<T*>(Vimg), base + v_off, ld, S, SP, SPT, tid);
     __syncthreads();
     const int nqb = (S + 15) >> 4;
-    for (int qb = wave; qb < nqb; qb += 4) {
+    for (int qb = wave; qb < nqb; qb += NWAVE) {
         const int rq = qb * 16 + fr;
         const bool valid = rq < S;
         uint4 qf[G::KS];
@@ -157,40 +186,45 @@ __global__ void __launch_bounds__(256) attn_long_fwd_kernel(const T* __restrict_
 #pragma unroll
             for (int r = 0; r < 4; ++r) s[kt][r] *= inv;
         if (valid && kg == 0) lse[((size_t)item * nh + h) * S + rq] = m + __logf(l);
-        uint4 pf[NST];
+        f32x4_t o[4];
 #pragma unroll
-        for (int st = 0; st < NST; ++st) pf[st] = pack_step<T, NKT>(s, st);
+        for (int dt = 0; dt < 4; ++dt) o[dt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int dt = 0; dt < 4; ++dt) {
-            f32x4_t o = {0.f, 0.f, 0.f, 0.f};
+        for (int st = 0; st < NST; ++st) {                   // probabilities are packed step by step (keeping all NST chunks spilled)
+            const uint4 pf = pack_step<T, NKT>(s, st);
 #pragma unroll
-            for (int st = 0; st < NST; ++st) Mma<T>::mma(frag_cols<T>(Vt, SPT, dt * 16 + fr, st, kg), pf[st], o);
-            if (valid) store4<T>(ctx + ((size_t)item * S + rq) * ldo + h * 64 + dt * 16 + kg * 4, o);
+            for (int dt = 0; dt < 4; ++dt) Mma<T>::mma(frag_T<T>(Vimg, SPT, dt * 16, st, lane), pf, o[dt]);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (valid) {
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) store4<T>(ctx + ((size_t)item * S + rq) * ldo + h * 64 + dt * 16 + kg * 4, o[dt]);
         }
     }
 }
 
 // ------------------------------------------------------------------------------------------------ backward: dq + delta
 template <typename T, int NKT>
-__global__ void __launch_bounds__(256) attn_long_dq_kernel(const T* __restrict__ qkv, int ld, int q_off, int k_off, int v_off,
+__global__ void __launch_bounds__(NTHR, 4) attn_long_dq_kernel(const T* __restrict__ qkv, int ld, int q_off, int k_off, int v_off,
                                                            const T* __restrict__ dctx, int ldo, const float* __restrict__ lse,
                                                            float* __restrict__ delta, T* __restrict__ dqkv,
                                                            int S, int nh, float scale) {
     using G = Geo<T>;
     constexpr int SP = NKT * 16, SPT = SP + 8, NST = SP / G::KSTEP;
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr bool TR = sizeof(T) == 2;
     char* Kr = smem;
     char* Vr = smem + SP * G::ROWB;
-    T* Kt = reinterpret_cast<T*>(smem + 2 * SP * G::ROWB);
+    char* Kimg = TR ? Kr : smem + 2 * SP * G::ROWB;                   // bf16: K's row-major image doubles as the transposed operand
     const int item = blockIdx.x / nh, h = blockIdx.x % nh;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, fr = lane & 15, kg = lane >> 4;
     const T* base = qkv + (size_t)item * S * ld + h * 64;
     stage_rows<T>(Kr, base + k_off, ld, S, SP, tid);
     stage_rows<T>(Vr, base + v_off, ld, S, SP, tid);
-    stage_cols<T>(Kt, base + k_off, ld, S, SP, SPT, tid);
+    if constexpr (!TR) stage_cols<T>(reinterpret_cast<T*>(Kimg), base + k_off, ld, S, SP, SPT, tid);
     __syncthreads();
     const int nqb = (S + 15) >> 4;
-    for (int qb = wave; qb < nqb; qb += 4) {
+    for (int qb = wave; qb < nqb; qb += NWAVE) {
         const int rq = qb * 16 + fr;
         const bool valid = rq < S;
         const size_t grow = (size_t)item * S + rq;
@@ -216,6 +250,7 @@ __global__ void __launch_bounds__(256) attn_long_dq_kernel(const T* __restrict__
                 p[kt][r] = __expf(p[kt][r] - lq);          // exp(-inf) = 0 for the padded keys
                 dsum += p[kt][r] * acc[r];
             }
+            if ((kt & 1) == 1) __builtin_amdgcn_sched_barrier(0);
         }
         dsum = red4(dsum, false);
         if (valid && kg == 0) delta[((size_t)item * nh + h) * S + rq] = dsum;
@@ -226,34 +261,40 @@ __global__ void __launch_bounds__(256) attn_long_dq_kernel(const T* __restrict__
             for (int ks = 0; ks < G::KS; ++ks) Mma<T>::mma(frag_rows<T>(Vr, kt * 16 + fr, ks, kg), dof[ks], acc);
 #pragma unroll
             for (int r = 0; r < 4; ++r) p[kt][r] = p[kt][r] * (acc[r] - dsum) * scale;
+            if ((kt & 1) == 1) __builtin_amdgcn_sched_barrier(0);
         }
-        uint4 dsf[NST];
+        f32x4_t o[4];
 #pragma unroll
-        for (int st = 0; st < NST; ++st) dsf[st] = pack_step<T, NKT>(p, st);
+        for (int dt = 0; dt < 4; ++dt) o[dt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int dt = 0; dt < 4; ++dt) {
-            f32x4_t o = {0.f, 0.f, 0.f, 0.f};
+        for (int st = 0; st < NST; ++st) {
+            const uint4 dsf = pack_step<T, NKT>(p, st);
 #pragma unroll
-            for (int st = 0; st < NST; ++st) Mma<T>::mma(frag_cols<T>(Kt, SPT, dt * 16 + fr, st, kg), dsf[st], o);
-            if (valid) store4<T>(dqkv + grow * ld + q_off + h * 64 + dt * 16 + kg * 4, o);
+            for (int dt = 0; dt < 4; ++dt) Mma<T>::mma(frag_T<T>(Kimg, SPT, dt * 16, st, lane), dsf, o[dt]);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (valid) {
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) store4<T>(dqkv + grow * ld + q_off + h * 64 + dt * 16 + kg * 4, o[dt]);
         }
     }
 }
 
 // ------------------------------------------------------------------------------------------------ backward: dk, dv
 template <typename T, int NKT>
-__global__ void __launch_bounds__(256) attn_long_dkdv_kernel(const T* __restrict__ qkv, int ld, int q_off, int k_off, int v_off,
+__global__ void __launch_bounds__(NTHR, 4) attn_long_dkdv_kernel(const T* __restrict__ qkv, int ld, int q_off, int k_off, int v_off,
                                                              const T* __restrict__ dctx, int ldo, const float* __restrict__ lse,
                                                              const float* __restrict__ delta, T* __restrict__ dqkv,
                                                              int S, int nh, float scale) {
     using G = Geo<T>;
     constexpr int SP = NKT * 16, SPT = SP + 8, NG = SP / G::KSTEP;          // NG query groups of KSTEP queries
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr bool TR = sizeof(T) == 2;
     char* Qr = smem;
     char* Or = smem + SP * G::ROWB;
-    T* Qt = reinterpret_cast<T*>(smem + 2 * SP * G::ROWB);
-    T* Ot = Qt + 64 * SPT;
-    float* lse_s = reinterpret_cast<float*>(Ot + 64 * SPT);
+    char* Qimg = TR ? Qr : smem + 2 * SP * G::ROWB;
+    char* Oimg = TR ? Or : Qimg + 64 * SPT * sizeof(T);
+    float* lse_s = reinterpret_cast<float*>(TR ? smem + 2 * SP * G::ROWB : Oimg + 64 * SPT * sizeof(T));
     float* del_s = lse_s + SP;
     const int item = blockIdx.x / nh, h = blockIdx.x % nh;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, fr = lane & 15, kg = lane >> 4;
@@ -261,15 +302,17 @@ __global__ void __launch_bounds__(256) attn_long_dkdv_kernel(const T* __restrict
     const T* dob = dctx + (size_t)item * S * ldo + h * 64;
     stage_rows<T>(Qr, base + q_off, ld, S, SP, tid);
     stage_rows<T>(Or, dob, ldo, S, SP, tid);
-    stage_cols<T>(Qt, base + q_off, ld, S, SP, SPT, tid);
-    stage_cols<T>(Ot, dob, ldo, S, SP, SPT, tid);
-    for (int i = tid; i < SP; i += 256) {
+    if constexpr (!TR) {
+        stage_cols<T>(reinterpret_cast<T*>(Qimg), base + q_off, ld, S, SP, SPT, tid);
+        stage_cols<T>(reinterpret_cast<T*>(Oimg), dob, ldo, S, SP, SPT, tid);
+    }
+    for (int i = tid; i < SP; i += NTHR) {
         lse_s[i] = i < S ? lse[((size_t)item * nh + h) * S + i] : 0.f;
         del_s[i] = i < S ? delta[((size_t)item * nh + h) * S + i] : 0.f;
     }
     __syncthreads();
     const int nkt = (S + 15) >> 4;
-    for (int kt = wave; kt < nkt; kt += 4) {
+    for (int kt = wave; kt < nkt; kt += NWAVE) {
         const int rk = kt * 16 + fr;                          // this lane's key (column of every tile below)
         const bool kvalid = rk < S;
         uint4 kf[G::KS], vf[G::KS];
@@ -304,8 +347,8 @@ __global__ void __launch_bounds__(256) attn_long_dkdv_kernel(const T* __restrict
             const uint4 pf = pack_step<T, G::TPS>(p, 0), dsf = pack_step<T, G::TPS>(ds, 0);
 #pragma unroll
             for (int dt = 0; dt < 4; ++dt) {
-                Mma<T>::mma(frag_cols<T>(Ot, SPT, dt * 16 + fr, g, kg), pf, dv[dt]);
-                Mma<T>::mma(frag_cols<T>(Qt, SPT, dt * 16 + fr, g, kg), dsf, dk[dt]);
+                Mma<T>::mma(frag_T<T>(Oimg, SPT, dt * 16, g, lane), pf, dv[dt]);
+                Mma<T>::mma(frag_T<T>(Qimg, SPT, dt * 16, g, lane), dsf, dk[dt]);
             }
         }
         if (kvalid) {
@@ -321,11 +364,10 @@ __global__ void __launch_bounds__(256) attn_long_dkdv_kernel(const T* __restrict
 
 template <typename T> int nkt_for(int S) { return S <= 32 ? 2 : S <= 64 ? 4 : S <= 128 ? 8 : S <= 224 ? 14 : 16; }
 
-template <typename T, int NKT> size_t lds_fwd() { return (size_t)NKT * 16 * Geo<T>::ROWB + 64 * (NKT * 16 + 8) * sizeof(T); }
-template <typename T, int NKT> size_t lds_dq() { return 2 * (size_t)NKT * 16 * Geo<T>::ROWB + 64 * (NKT * 16 + 8) * sizeof(T); }
-template <typename T, int NKT> size_t lds_dkdv() {
-    return 2 * (size_t)NKT * 16 * Geo<T>::ROWB + 2 * 64 * (NKT * 16 + 8) * sizeof(T) + 2 * NKT * 16 * sizeof(float);
-}
+template <typename T, int NKT> constexpr size_t img_t() { return sizeof(T) == 2 ? 0 : 64 * (NKT * 16 + 8) * sizeof(T); }   // transposed copy (fp32 only)
+template <typename T, int NKT> size_t lds_fwd() { return (size_t)NKT * 16 * Geo<T>::ROWB + (sizeof(T) == 2 ? (size_t)NKT * 16 * Geo<T>::ROWB : img_t<T, NKT>()); }
+template <typename T, int NKT> size_t lds_dq() { return 2 * (size_t)NKT * 16 * Geo<T>::ROWB + img_t<T, NKT>(); }
+template <typename T, int NKT> size_t lds_dkdv() { return 2 * (size_t)NKT * 16 * Geo<T>::ROWB + 2 * img_t<T, NKT>() + 2 * NKT * 16 * sizeof(float); }
 constexpr size_t LDS_MAX = 160 * 1024;
 
 template <typename K> int set_lds(K kernel, size_t bytes) {
@@ -338,7 +380,7 @@ template <typename K> int set_lds(K kernel, size_t bytes) {
 template <typename T, int NKT> int run_fwd(hipStream_t s, const a4r_attn_t* a, float* lse) {
     const size_t lds = lds_fwd<T, NKT>();
     if (int rc = set_lds(attn_long_fwd_kernel<T, NKT>, lds)) return rc;
-    hipLaunchKernelGGL((attn_long_fwd_kernel<T, NKT>), dim3(a->n_items * a->n_heads), dim3(256), lds, s, (const T*)a->qkv, a->ld, a->q_off,
+    hipLaunchKernelGGL((attn_long_fwd_kernel<T, NKT>), dim3(a->n_items * a->n_heads), dim3(NTHR), lds, s, (const T*)a->qkv, a->ld, a->q_off,
                        a->k_off, a->v_off, (T*)a->out, a->ldo, lse, a->S, a->n_heads, a->scale);
     return a4r_launch_status();
 }
@@ -346,7 +388,7 @@ template <typename T, int NKT> int run_bwd(hipStream_t s, const a4r_attn_t* a, c
     const size_t l1 = lds_dq<T, NKT>(), l2 = lds_dkdv<T, NKT>();
     if (int rc = set_lds(attn_long_dq_kernel<T, NKT>, l1)) return rc;
     if (int rc = set_lds(attn_long_dkdv_kernel<T, NKT>, l2)) return rc;
-    const dim3 grid(a->n_items * a->n_heads), block(256);
+    const dim3 grid(a->n_items * a->n_heads), block(NTHR);
     hipLaunchKernelGGL((attn_long_dq_kernel<T, NKT>), grid, block, l1, s, (const T*)a->qkv, a->ld, a->q_off, a->k_off, a->v_off,
                        (const T*)a->dout, a->ldo, lse, delta, (T*)a->dqkv, a->S, a->n_heads, a->scale);
     hipLaunchKernelGGL((attn_long_dkdv_kernel<T, NKT>), grid, block, l2, s, (const T*)a->qkv, a->ld, a->q_off, a->k_off, a->v_off,
