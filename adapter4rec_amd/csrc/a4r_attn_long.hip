@@ -28,7 +28,7 @@ template <typename T> A4R_DEV uint4 ldg16(const T* p) { return *reinterpret_cast
 
 // 8 waves per (item, head) workgroup: two workgroups (114 KB of LDS at S = 197) give a CU 4 waves per SIMD to hide the
 // staging and Q / dO load latency behind; with 4-wave workgroups the chip sat at 0.4 waves per SIMD (PMC).
-constexpr int NTHR = 512, NWAVE = NTHR / 64;
+template <int NKT> struct WG { static constexpr int NWAVE = NKT <= 4 ? 4 : 8, NTHR = NWAVE * 64; };   // short sequences have <= 4 query blocks
 
 template <typename T> struct Geo {
     static constexpr int PER = Elem<T>::PER16;              // elements per 16-byte chunk
@@ -41,7 +41,7 @@ template <typename T> struct Geo {
 };
 
 // [S][64] (global, row stride ld) -> LDS row-major [SP][64], 16-byte chunks XOR-swizzled; rows >= S are zero
-template <typename T> A4R_DEV void stage_rows(char* lds, const T* src, int ld, int S, int SP, int tid) {
+template <typename T> A4R_DEV void stage_rows(char* lds, const T* src, int ld, int S, int SP, int tid, int NTHR) {
     using G = Geo<T>;
     for (int id = tid; id < SP * G::CPR; id += NTHR) {
         const int r = id / G::CPR, c = id % G::CPR;
@@ -50,7 +50,7 @@ template <typename T> A4R_DEV void stage_rows(char* lds, const T* src, int ld, i
     }
 }
 // [S][64] -> LDS transposed [64][SPT] (SPT = SP + 8 elements); columns >= S are zero
-template <typename T> A4R_DEV void stage_cols(T* lds, const T* src, int ld, int S, int SP, int SPT, int tid) {
+template <typename T> A4R_DEV void stage_cols(T* lds, const T* src, int ld, int S, int SP, int SPT, int tid, int NTHR) {
     using G = Geo<T>;
     for (int id = tid; id < SP * G::CPR; id += NTHR) {
         const int c = id / SP, r = id % SP;                  // consecutive lanes -> consecutive rows: LDS stores spread over banks
@@ -142,10 +142,11 @@ A4R_DEV void scores_t(const char* Kr, const uint4 (&qf)[Geo<T>::KS], f32x4_t (&s
 
 // ------------------------------------------------------------------------------------------------ forward
 template <typename T, int NKT>
-__global__ void __launch_bounds__(NTHR, 4) attn_long_fwd_kernel(const T* __restrict__ qkv, int ld, int q_off, int k_off, int v_off,
+__global__ void __launch_bounds__(WG<NKT>::NTHR, 4) attn_long_fwd_kernel(const T* __restrict__ qkv, int ld, int q_off, int k_off, int v_off,
                                                             T* __restrict__ ctx, int ldo, float* __restrict__ lse,
                                                             int S, int nh, float scale) {
     using G = Geo<T>;
+    constexpr int NTHR = WG<NKT>::NTHR, NWAVE = WG<NKT>::NWAVE;
     constexpr int SP = NKT * 16, SPT = SP + 8, NST = SP / G::KSTEP;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr bool TR = sizeof(T) == 2;
@@ -154,9 +155,9 @@ __global__ void __launch_bounds__(NTHR, 4) attn_long_fwd_kernel(const T* __restr
     const int item = blockIdx.x / nh, h = blockIdx.x % nh;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, fr = lane & 15, kg = lane >> 4;
     const T* base = qkv + (size_t)item * S * ld + h * 64;
-    stage_rows<T>(Kr, base + k_off, ld, S, SP, tid);
-    if constexpr (TR) stage_rows<T>(Vimg, base + v_off, ld, S, SP, tid);
-    else stage_cols<T>(reinterpret_cast<T*>(Vimg), base + v_off, ld, S, SP, SPT, tid);
+    stage_rows<T>(Kr, base + k_off, ld, S, SP, tid, NTHR);
+    if constexpr (TR) stage_rows<T>(Vimg, base + v_off, ld, S, SP, tid, NTHR);
+    else stage_cols<T>(reinterpret_cast<T*>(Vimg), base + v_off, ld, S, SP, SPT, tid, NTHR);
     __syncthreads();
     const int nqb = (S + 15) >> 4;
     for (int qb = wave; qb < nqb; qb += NWAVE) {
@@ -205,11 +206,12 @@ __global__ void __launch_bounds__(NTHR, 4) attn_long_fwd_kernel(const T* __restr
 
 // ------------------------------------------------------------------------------------------------ backward: dq + delta
 template <typename T, int NKT>
-__global__ void __launch_bounds__(NTHR, 4) attn_long_dq_kernel(const T* __restrict__ qkv, int ld, int q_off, int k_off, int v_off,
+__global__ void __launch_bounds__(WG<NKT>::NTHR, 4) attn_long_dq_kernel(const T* __restrict__ qkv, int ld, int q_off, int k_off, int v_off,
                                                            const T* __restrict__ dctx, int ldo, const float* __restrict__ lse,
                                                            float* __restrict__ delta, T* __restrict__ dqkv,
                                                            int S, int nh, float scale) {
     using G = Geo<T>;
+    constexpr int NTHR = WG<NKT>::NTHR, NWAVE = WG<NKT>::NWAVE;
     constexpr int SP = NKT * 16, SPT = SP + 8, NST = SP / G::KSTEP;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr bool TR = sizeof(T) == 2;
@@ -219,9 +221,9 @@ __global__ void __launch_bounds__(NTHR, 4) attn_long_dq_kernel(const T* __restri
     const int item = blockIdx.x / nh, h = blockIdx.x % nh;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, fr = lane & 15, kg = lane >> 4;
     const T* base = qkv + (size_t)item * S * ld + h * 64;
-    stage_rows<T>(Kr, base + k_off, ld, S, SP, tid);
-    stage_rows<T>(Vr, base + v_off, ld, S, SP, tid);
-    if constexpr (!TR) stage_cols<T>(reinterpret_cast<T*>(Kimg), base + k_off, ld, S, SP, SPT, tid);
+    stage_rows<T>(Kr, base + k_off, ld, S, SP, tid, NTHR);
+    stage_rows<T>(Vr, base + v_off, ld, S, SP, tid, NTHR);
+    if constexpr (!TR) stage_cols<T>(reinterpret_cast<T*>(Kimg), base + k_off, ld, S, SP, SPT, tid, NTHR);
     __syncthreads();
     const int nqb = (S + 15) >> 4;
     for (int qb = wave; qb < nqb; qb += NWAVE) {
@@ -282,11 +284,12 @@ __global__ void __launch_bounds__(NTHR, 4) attn_long_dq_kernel(const T* __restri
 
 // ------------------------------------------------------------------------------------------------ backward: dk, dv
 template <typename T, int NKT>
-__global__ void __launch_bounds__(NTHR, 4) attn_long_dkdv_kernel(const T* __restrict__ qkv, int ld, int q_off, int k_off, int v_off,
+__global__ void __launch_bounds__(WG<NKT>::NTHR, 4) attn_long_dkdv_kernel(const T* __restrict__ qkv, int ld, int q_off, int k_off, int v_off,
                                                              const T* __restrict__ dctx, int ldo, const float* __restrict__ lse,
                                                              const float* __restrict__ delta, T* __restrict__ dqkv,
                                                              int S, int nh, float scale) {
     using G = Geo<T>;
+    constexpr int NTHR = WG<NKT>::NTHR, NWAVE = WG<NKT>::NWAVE;
     constexpr int SP = NKT * 16, SPT = SP + 8, NG = SP / G::KSTEP;          // NG query groups of KSTEP queries
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr bool TR = sizeof(T) == 2;
@@ -300,11 +303,11 @@ __global__ void __launch_bounds__(NTHR, 4) attn_long_dkdv_kernel(const T* __rest
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, fr = lane & 15, kg = lane >> 4;
     const T* base = qkv + (size_t)item * S * ld + h * 64;
     const T* dob = dctx + (size_t)item * S * ldo + h * 64;
-    stage_rows<T>(Qr, base + q_off, ld, S, SP, tid);
-    stage_rows<T>(Or, dob, ldo, S, SP, tid);
+    stage_rows<T>(Qr, base + q_off, ld, S, SP, tid, NTHR);
+    stage_rows<T>(Or, dob, ldo, S, SP, tid, NTHR);
     if constexpr (!TR) {
-        stage_cols<T>(reinterpret_cast<T*>(Qimg), base + q_off, ld, S, SP, SPT, tid);
-        stage_cols<T>(reinterpret_cast<T*>(Oimg), dob, ldo, S, SP, SPT, tid);
+        stage_cols<T>(reinterpret_cast<T*>(Qimg), base + q_off, ld, S, SP, SPT, tid, NTHR);
+        stage_cols<T>(reinterpret_cast<T*>(Oimg), dob, ldo, S, SP, SPT, tid, NTHR);
     }
     for (int i = tid; i < SP; i += NTHR) {
         lse_s[i] = i < S ? lse[((size_t)item * nh + h) * S + i] : 0.f;
@@ -380,7 +383,7 @@ template <typename K> int set_lds(K kernel, size_t bytes) {
 template <typename T, int NKT> int run_fwd(hipStream_t s, const a4r_attn_t* a, float* lse) {
     const size_t lds = lds_fwd<T, NKT>();
     if (int rc = set_lds(attn_long_fwd_kernel<T, NKT>, lds)) return rc;
-    hipLaunchKernelGGL((attn_long_fwd_kernel<T, NKT>), dim3(a->n_items * a->n_heads), dim3(NTHR), lds, s, (const T*)a->qkv, a->ld, a->q_off,
+    hipLaunchKernelGGL((attn_long_fwd_kernel<T, NKT>), dim3(a->n_items * a->n_heads), dim3(WG<NKT>::NTHR), lds, s, (const T*)a->qkv, a->ld, a->q_off,
                        a->k_off, a->v_off, (T*)a->out, a->ldo, lse, a->S, a->n_heads, a->scale);
     return a4r_launch_status();
 }
@@ -388,7 +391,7 @@ template <typename T, int NKT> int run_bwd(hipStream_t s, const a4r_attn_t* a, c
     const size_t l1 = lds_dq<T, NKT>(), l2 = lds_dkdv<T, NKT>();
     if (int rc = set_lds(attn_long_dq_kernel<T, NKT>, l1)) return rc;
     if (int rc = set_lds(attn_long_dkdv_kernel<T, NKT>, l2)) return rc;
-    const dim3 grid(a->n_items * a->n_heads), block(NTHR);
+    const dim3 grid(a->n_items * a->n_heads), block(WG<NKT>::NTHR);
     hipLaunchKernelGGL((attn_long_dq_kernel<T, NKT>), grid, block, l1, s, (const T*)a->qkv, a->ld, a->q_off, a->k_off, a->v_off,
                        (const T*)a->dout, a->ldo, lse, delta, (T*)a->dqkv, a->S, a->n_heads, a->scale);
     hipLaunchKernelGGL((attn_long_dkdv_kernel<T, NKT>), grid, block, l2, s, (const T*)a->qkv, a->ld, a->q_off, a->k_off, a->v_off,
