@@ -90,7 +90,7 @@ class ViTRecEngine(TransRecEngine):
         self.fc_w = self._w(fc.weight)
         self.fc_wT32 = self._wT(fc.weight, torch.float32)
         self.fc_b = self._f32(fc.bias)
-        self.cls_only = False
+        self.cls_only = bool(getattr(self.args, 'cls_only_last', True))      # last layer: only the CLS rows go past attention
 
     def _vit_so(self, mod):
         """(dense Linear, adapter or None) of a plain or wrapped ViTSelfOutput / ViTOutput."""
@@ -115,6 +115,8 @@ class ViTRecEngine(TransRecEngine):
         d['sta'] = self._buf(pre + '.sta', M, 2, torch.float32)
         d['qkv'] = self._buf(pre + '.qkv', M, 3 * H, T)
         d['lse'] = self._buf(pre + '.lse', (M // blk.S + 1) * blk.nh * blk.S, 1, torch.float32)
+        if Mc is not None:                   # last layer in CLS-only mode: everything after attention has Mc rows
+            pre, M = pre + '.cls', Mc
         d['x1'] = self._buf(pre + '.x1', M, H, T)
         d['stb'] = self._buf(pre + '.stb', M, 2, torch.float32)
         d['upre'] = self._buf(pre + '.upre', M, F, T)
@@ -138,13 +140,20 @@ class ViTRecEngine(TransRecEngine):
         else:
             L.gemm_nt(z, ad.wu, out, bias=ad.bu, R1=h, R2=resid, M=M)
 
-    def _vit_block_forward(self, blk, x, n_items, M, bufs, x_out):
+    def _vit_block_forward(self, blk, x, n_items, M, bufs, x_out, cls_rows=None):
+        """cls_rows = Ip: after attention only token 0 of every image (all the head reads, encoders.py:22,32) is carried on:
+        x_out is then [Ip, H].  Results-neutral: the other rows of the last layer's output are never consumed."""
         T, H = blk.T, blk.H
         n1 = bufs['n1'] if 'n1' in bufs else self._buf('n1', M, H, T)
         L.ln_fwd(x, blk.lnA.gamma, blk.lnA.beta, blk.lnA.eps, n1, bufs['sta'], M=M)
         L.gemm_nt(n1, blk.wqkv, bufs['qkv'], bias=blk.bqkv, M=M)
         ctx = self._buf('ctx', M, H, T)
         L.attn_long_fwd(bufs['qkv'], ctx, bufs['lse'], n_items, blk.S, blk.nh, blk.dh, 0, H, 2 * H, blk.scale)
+        if cls_rows is not None:
+            ctx_c, x_c = self._buf('ctx_c', cls_rows, H, T), self._buf('x_c', cls_rows, H, T)
+            L.gather_rows(ctx, ctx_c, n_items, blk.S)
+            L.gather_rows(x, x_c, n_items, blk.S)
+            ctx, x, M = ctx_c, x_c, cls_rows
         self._vit_sub_forward(blk.ad1, ctx, blk.wo, blk.bo, x, bufs, '1', M, bufs['x1'])
         n2 = self._buf('n2', M, H, T)
         L.ln_fwd(bufs['x1'], blk.lnB.gamma, blk.lnB.beta, blk.lnB.eps, n2, bufs['stb'], M=M)
@@ -170,9 +179,12 @@ class ViTRecEngine(TransRecEngine):
             L.colsum(dy, ad.g_bu(), M=M)
         return dh
 
-    def _vit_block_backward(self, blk, dx_out, n_items, M, bufs, dx_in):
+    def _vit_block_backward(self, blk, dx_out, n_items, M, bufs, dx_in, cls_rows=None):
         T, H, F = blk.T, blk.H, blk.F
         gg = lambda f: f() if f is not None else None
+        M_full = M
+        if cls_rows is not None:
+            M = cls_rows
         d_o = self._vit_sub_backward(blk, blk.ad2, dx_out, bufs, '2', M)
         du = self._buf('du', M, F, T)
         L.gemm_nt(d_o, blk.wo2T, du, Pre=bufs['upre'], dact=L.DACT_MUL, M=M)
@@ -184,8 +196,18 @@ class ViTRecEngine(TransRecEngine):
         ln_a = blk.lnA.g_gamma is not None           # --finetune_layernorm: layer 0 still owes its LN_before gradients
         if dx_in is None and not blk.lora and not ln_a:
             return
-        dctx = self._buf('dctx', M, H, T)
+        dctx = self._buf('dctx_c' if cls_rows is not None else 'dctx', M, H, T)
         L.gemm_nt(da, blk.woT, dctx, M=M)
+        if cls_rows is not None:             # back to token rows: the gradients live on the CLS rows only
+            M = M_full
+            full = self._buf('dctx', M, H, T)
+            full.zero_()
+            L.scatter_rows(dctx, full, n_items, blk.S)
+            dctx = full
+            rfull = self._buf('dres_full', M, H, T)
+            rfull.zero_()
+            L.scatter_rows(dx1, rfull, n_items, blk.S)
+            dx1 = rfull
         dqkv = self._buf('dqkv', M, 3 * H, T)
         ws = self._buf('attn_ws', bufs['lse'].shape[0], 1, torch.float32)
         L.attn_long_bwd(bufs['qkv'], dctx, dqkv, bufs['lse'], ws, n_items, blk.S, blk.nh, blk.dh, 0, H, 2 * H, blk.scale)
@@ -232,17 +254,20 @@ class ViTRecEngine(TransRecEngine):
         L.vit_assemble(pe, self.cls_tok, self.pos_tab, x, n_items, self.n_keep, keep)
         other = self._buf('xb', M, H, self.T)
         nb = len(self.bert_blocks)
-        for i, blk in enumerate(self.bert_blocks):
-            if saved is not None:                 # training: layer i writes straight into layer i+1's saved input
-                out = saved[i + 1]['x0'] if i + 1 < nb else self._buf('x_last', M, H, self.T)
-                self._vit_block_forward(blk, x, n_items, M, saved[i], out)
-                x = out
-            else:                                 # inference: one transient buffer set, two ping-pong activations
-                self._vit_block_forward(blk, x, n_items, M, self._block_bufs('vit.shared', blk, M, True), other)
-                x, other = other, x
         Ip = pad_to(n_items, 128)
         cls = self._buf('cls', Ip, H, self.T)
-        L.gather_rows(x, cls, n_items, S)
+        for i, blk in enumerate(self.bert_blocks):
+            cmode = self.cls_only and i + 1 == nb
+            if saved is not None:                 # training: layer i writes straight into layer i+1's saved input
+                out = saved[i + 1]['x0'] if i + 1 < nb else (cls if cmode else self._buf('x_last', M, H, self.T))
+                self._vit_block_forward(blk, x, n_items, M, saved[i], out, cls_rows=Ip if cmode else None)
+                x = out
+            else:                                 # inference: one transient buffer set, two ping-pong activations
+                bufs = self._block_bufs('vit.shared', blk, M, True, Mc=Ip if cmode else None)
+                self._vit_block_forward(blk, x, n_items, M, bufs, cls if cmode else other, cls_rows=Ip if cmode else None)
+                x, other = (cls, other) if cmode else (other, x)
+        if not self.cls_only:
+            L.gather_rows(x, cls, n_items, S)
         cln = self._buf('cls_n', Ip, H, self.T)
         self._cls_st = self._buf('cls_st', Ip, 2, torch.float32)
         L.ln_fwd(cls, self.vit_ln.gamma, self.vit_ln.beta, self.vit_ln.eps, cln, self._cls_st, M=Ip)
@@ -262,12 +287,17 @@ class ViTRecEngine(TransRecEngine):
         L.ln_bwd(dcln, self._buf('cls', Ip, H, self.T), self._cls_st, self.vit_ln.gamma, dcls, M=Ip,
                  dgamma=gg(self.vit_ln.g_gamma), dbeta=gg(self.vit_ln.g_beta))
         dxb = self._buf('dx_a', M, H, self.T)
-        dxb.zero_()
-        L.scatter_rows(dcls, dxb, n_items, self.S)
+        if not self.cls_only:
+            dxb.zero_()
+            L.scatter_rows(dcls, dxb, n_items, self.S)
         spare = self._buf('dx_b', M, H, self.T)
-        for i in range(len(self.bert_blocks) - 1, -1, -1):
+        last = len(self.bert_blocks) - 1
+        for i in range(last, -1, -1):
             blk = self.bert_blocks[i]
-            self._vit_block_backward(blk, dxb, n_items, M, c['saved_b'][i], spare if blk.need_dx else None)
+            if self.cls_only and i == last:
+                self._vit_block_backward(blk, dcls, n_items, M, c['saved_b'][i], spare if blk.need_dx else None, cls_rows=Ip)
+            else:
+                self._vit_block_backward(blk, dxb, n_items, M, c['saved_b'][i], spare if blk.need_dx else None)
             dxb, spare = spare, dxb
 
     # ------------------------------------------------------------------ public: inference
