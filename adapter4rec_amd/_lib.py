@@ -21,7 +21,7 @@ EXPORTS = [
     'a4r_version', 'a4r_gemm_nt', 'a4r_gemm_tn', 'a4r_colsum', 'a4r_attn_fwd', 'a4r_attn_bwd', 'a4r_embed_ln',
     'a4r_ln_fwd', 'a4r_ln_bwd', 'a4r_gather_rows', 'a4r_scatter_rows', 'a4r_act_bwd_f32', 'a4r_score_bce_fwd',
     'a4r_score_bce_bwd', 'a4r_emb_grad_add_inputs', 'a4r_take_inputs', 'a4r_adam_step', 'a4r_pack_matrices',
-    'a4r_eval_rank', 'a4r_dropout_apply', 'a4r_gemm_variant', 'a4r_adapter_fwd', 'a4r_attn_long_fwd', 'a4r_attn_long_bwd', 'a4r_patchify', 'a4r_vit_assemble',
+    'a4r_eval_rank', 'a4r_dropout_apply', 'a4r_gemm_variant', 'a4r_adapter_fwd', 'a4r_attn_long_fwd', 'a4r_attn_long_bwd', 'a4r_patchify', 'a4r_vit_assemble', 'a4r_resample_u8',
 ]
 
 
@@ -204,6 +204,14 @@ def patchify(img, out, patch, keep_idx=None):
     assert keep_idx is None or (keep_idx.dtype == torch.int32 and keep_idx.is_contiguous() and keep_idx.shape[0] == n)
     _check(lib().a4r_patchify(_stream(), _p(img), C.c_int(kind), _p(out), C.c_int(_ld(out)), _p(keep_idx), C.c_int(n_keep),
                               C.c_int(n), C.c_int(Cc), C.c_int(Hi), C.c_int(Wi), C.c_int(patch), C.c_int(_dt(out))), 'a4r_patchify')
+
+
+def resample_u8(src, dst, bounds, kk, n_outer, in_len, out_len, inner):
+    require_gpu(src, dst, bounds, kk)
+    assert src.dtype == torch.uint8 and dst.dtype == torch.uint8 and bounds.dtype == torch.int32 and kk.dtype == torch.int32
+    assert src.is_contiguous() and dst.is_contiguous() and src.numel() == n_outer * in_len * inner and dst.numel() == n_outer * out_len * inner
+    _check(lib().a4r_resample_u8(_stream(), _p(src), _p(dst), _p(bounds), _p(kk), C.c_int(kk.shape[1]), C.c_long(n_outer),
+                                 C.c_int(in_len), C.c_int(out_len), C.c_long(inner)), 'a4r_resample_u8')
 
 
 def vit_assemble(patches, cls, pos, out, n_items, n_keep, keep_idx=None):

@@ -109,3 +109,40 @@ extern "C" int a4r_vit_assemble(void* stream, const void* patches, int ldp, cons
                            (float*)out, ldo, n_items, n_keep, H);
     return a4r_launch_status();
 }
+
+// ---------------------------------------------------------------------------------------------------------------------
+// a4r_resample_u8: one pass of Pillow's fixed-point separable resampler (third party: Pillow src/libImaging/Resample.c,
+// ImagingResampleHorizontal_8bpc / Vertical_8bpc), which is what torchvision's Resize((R, R)) runs on the PIL image at
+// Downstream/CV/data_utils/dataset.py:77-81.  The coefficient tables come from the host (adapter4rec_amd/cv/image_io.py:
+// double-precision triangle weights -> 22-bit fixed point exactly as precompute_coeffs / normalize_coeffs_8bpc).
+// out = clip8((2^21 + sum_x in[x0 + x] * kk[x]) >> 22); two passes (horizontal, then vertical on the 8-bit intermediate)
+// reproduce Image.resize(..., BILINEAR) bit for bit.  One thread per output byte; HBM-bound.
+namespace {
+__global__ void __launch_bounds__(256) resample_u8_kernel(const unsigned char* __restrict__ src, unsigned char* __restrict__ dst,
+                                                          const int32_t* __restrict__ bounds, const int32_t* __restrict__ kk, int ksize,
+                                                          long n_outer, int in_len, int out_len, long inner) {
+    // src [n_outer][in_len][inner] -> dst [n_outer][out_len][inner]   (horizontal pass: inner = C; vertical: inner = W * C)
+    const long total = n_outer * out_len * inner;
+    for (long id = (long)blockIdx.x * 256 + threadIdx.x; id < total; id += (long)gridDim.x * 256) {
+        const long i = id % inner;
+        const int xx = (int)((id / inner) % out_len);
+        const long o = id / (inner * out_len);
+        const int x0 = bounds[2 * xx], cnt = bounds[2 * xx + 1];
+        const unsigned char* s = src + (o * in_len + x0) * inner + i;
+        const int32_t* k = kk + (long)xx * ksize;
+        int acc = 1 << 21;
+        for (int x = 0; x < cnt; ++x) acc += (int)s[(long)x * inner] * k[x];
+        acc >>= 22;
+        dst[id] = (unsigned char)(acc < 0 ? 0 : acc > 255 ? 255 : acc);
+    }
+}
+}  // namespace
+
+extern "C" int a4r_resample_u8(void* stream, const void* src, void* dst, const int32_t* bounds, const int32_t* kk, int ksize,
+                               long n_outer, int in_len, int out_len, long inner) {
+    if (!src || !dst || !bounds || !kk || ksize <= 0 || n_outer <= 0 || in_len <= 0 || out_len <= 0 || inner <= 0) return A4R_EINVAL;
+    const long total = n_outer * out_len * inner;
+    hipLaunchKernelGGL(resample_u8_kernel, dim3(grid_for(total)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
+                       (const unsigned char*)src, (unsigned char*)dst, bounds, kk, ksize, n_outer, in_len, out_len, inner);
+    return a4r_launch_status();
+}

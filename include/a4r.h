@@ -120,6 +120,14 @@ int a4r_patchify(void* stream, const void* img, int src_kind, void* out, int ldo
 int a4r_vit_assemble(void* stream, const void* patches, int ldp, const float* cls, const float* pos, const int32_t* keep_idx,
                      void* out, int ldo, int n_items, int n_keep, int H, int dtype);
 
+/* One pass of Pillow's 8-bit separable resampler (third party; what torchvision's Resize((R, R)) executes on the PIL image
+ * at Downstream/CV/data_utils/dataset.py:77-81): src uint8 [n_outer, in_len, inner] -> dst uint8 [n_outer, out_len, inner],
+ * dst = clip8((2^21 + sum_{x < bounds[2*o+1]} src[bounds[2*o] + x] * kk[o*ksize + x]) >> 22).  Horizontal pass of a batch of
+ * [n, H, W, C] images: n_outer = n*H, in_len = W, inner = C; vertical pass: n_outer = n, in_len = H, inner = W*C.
+ * bounds / kk (device, int32) come from the caller (adapter4rec_amd/cv/image_io.py: resample_tables). */
+int a4r_resample_u8(void* stream, const void* src, void* dst, const int32_t* bounds, const int32_t* kk, int ksize,
+                    long n_outer, int in_len, int out_len, long inner);
+
 /* HF BertEmbeddings / RobertaEmbeddings: word[id] + pos[pos_id] + type[0] -> LayerNorm -> dropout.
  * ids [n_items, S] int64 with row stride ld_ids (the reference hands over ids||mask rows of 2*S,
  * model/encoders.py:49-52).  roberta != 0: pos_id = cumsum(id != pad) * (id != pad) + pad. */

@@ -147,6 +147,18 @@ def patchify(img, out, patch, keep_idx=None):
     out[:rows.shape[0], :rows.shape[1]] = rows.to(out.dtype)
 
 
+def resample_u8(src, dst, bounds, kk, n_outer, in_len, out_len, inner):
+    s = src.reshape(n_outer, in_len, inner).long()
+    out = torch.zeros(n_outer, out_len, inner, dtype=torch.long)
+    for xx in range(out_len):
+        x0, cnt = int(bounds[xx, 0]), int(bounds[xx, 1])
+        acc = torch.full((n_outer, inner), 1 << 21, dtype=torch.long)
+        for x in range(cnt):
+            acc += s[:, x0 + x] * int(kk[xx, x])
+        out[:, xx] = (acc >> 22).clamp(0, 255)
+    dst.view(-1)[:] = out.reshape(-1).to(torch.uint8)
+
+
 def vit_assemble(patches, cls, pos, out, n_items, n_keep, keep_idx=None):
     H = cls.numel()
     x = patches[:n_items * n_keep, :H].float().view(n_items, n_keep, H)
