@@ -21,7 +21,7 @@ EXPORTS = [
     'a4r_version', 'a4r_gemm_nt', 'a4r_gemm_tn', 'a4r_colsum', 'a4r_attn_fwd', 'a4r_attn_bwd', 'a4r_embed_ln',
     'a4r_ln_fwd', 'a4r_ln_bwd', 'a4r_gather_rows', 'a4r_scatter_rows', 'a4r_act_bwd_f32', 'a4r_score_bce_fwd',
     'a4r_score_bce_bwd', 'a4r_emb_grad_add_inputs', 'a4r_take_inputs', 'a4r_adam_step', 'a4r_pack_matrices',
-    'a4r_eval_rank', 'a4r_dropout_apply', 'a4r_gemm_variant', 'a4r_adapter_fwd', 'a4r_attn_long_fwd', 'a4r_attn_long_bwd', 'a4r_patchify', 'a4r_vit_assemble', 'a4r_resample_u8',
+    'a4r_eval_rank', 'a4r_dropout_apply', 'a4r_gemm_variant', 'a4r_adapter_fwd', 'a4r_attn_long_fwd', 'a4r_attn_long_bwd', 'a4r_patchify', 'a4r_vit_assemble', 'a4r_resample_u8', 'a4r_embed_bwd',
 ]
 
 
@@ -45,7 +45,7 @@ class AttnArgs(C.Structure):
 
 class PackDesc(C.Structure):
     _fields_ = [('src_off', C.c_int64), ('dst', C.c_void_p), ('rows', C.c_int32), ('cols', C.c_int32),
-                ('rows_pad', C.c_int32), ('cols_pad', C.c_int32), ('transpose', C.c_int32), ('pad_', C.c_int32)]
+                ('rows_pad', C.c_int32), ('cols_pad', C.c_int32), ('transpose', C.c_int32), ('dst_ld', C.c_int32)]
 
 
 _lib = None
@@ -221,14 +221,21 @@ def vit_assemble(patches, cls, pos, out, n_items, n_keep, keep_idx=None):
            'a4r_vit_assemble')
 
 
+def embed_bwd(ids, dpre, dword, dpos, n_items, S, roberta=False, pad_id=0):
+    require_gpu(ids, dpre)
+    _check(lib().a4r_embed_bwd(_stream(), _p(ids), C.c_int(ids.stride(0)), _p(dpre), C.c_int(_ld(dpre)), _p(dword), _p(dpos),
+                               C.c_int(n_items), C.c_int(S), C.c_int(dpre.shape[1]), C.c_int(int(roberta)), C.c_int(pad_id),
+                               C.c_int(_dt(dpre))), 'a4r_embed_bwd')
+
+
 def embed_ln(ids, word, pos, type0, gamma, beta, eps, out, n_items, S, roberta=False, pad_id=0,
-             drop_p=0.0, drop_site=0, drop_seed=0):
+             drop_p=0.0, drop_site=0, drop_seed=0, pre_out=None, stats_out=None):
     require_gpu(ids, word, out)
     assert ids.dtype == torch.int64 and ids.stride(1) == 1
     _check(lib().a4r_embed_ln(_stream(), _p(ids), C.c_int(ids.stride(0)), _p(word), _p(pos), _p(type0), _p(gamma), _p(beta),
                               C.c_float(eps), _p(out), C.c_int(_ld(out)), C.c_int(n_items), C.c_int(S), C.c_int(word.shape[1]),
                               C.c_int(int(roberta)), C.c_int(pad_id), C.c_int(_dt(out)),
-                              C.c_float(drop_p), C.c_uint32(drop_site), C.c_uint64(drop_seed)), 'a4r_embed_ln')
+                              C.c_float(drop_p), C.c_uint32(drop_site), C.c_uint64(drop_seed), _p(pre_out), _p(stats_out)), 'a4r_embed_ln')
 
 
 def ln_fwd(v, gamma, beta, eps, y, stats, M=None, add=None, drop_p=0.0, drop_site=0, drop_seed=0):

@@ -114,19 +114,20 @@ __global__ void __launch_bounds__(256) adam_kernel(float* __restrict__ p, const 
 }
 
 struct PackDesc {   // mirrors a4r_pack_desc_t
-    int64_t src_off; void* dst; int32_t rows, cols, rows_pad, cols_pad, transpose, pad_;
+    int64_t src_off; void* dst; int32_t rows, cols, rows_pad, cols_pad, transpose, dst_ld;
 };
 template <typename T>
 __global__ void __launch_bounds__(256) pack_kernel(const float* __restrict__ flat, const PackDesc* __restrict__ desc) {
     const PackDesc d = desc[blockIdx.y];
     T* dst = reinterpret_cast<T*>(d.dst);
     const int total = d.rows_pad * d.cols_pad;
+    const int ld = d.dst_ld ? d.dst_ld : d.cols_pad;          // dst may be a column block of a wider matrix (fused q|k|v operand)
     for (int i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
         const int r = i / d.cols_pad, c = i % d.cols_pad;     // destination coordinates
         const int sr = d.transpose ? c : r, sc = d.transpose ? r : c;
         float val = 0.f;
         if (sr < d.rows && sc < d.cols) val = flat[d.src_off + (int64_t)sr * d.cols + sc];
-        Elem<T>::st(dst + i, val);
+        Elem<T>::st(dst + (size_t)r * ld + c, val);
     }
 }
 
@@ -182,7 +183,7 @@ extern "C" int a4r_adam_step(void* stream, float* p, const float* g, float* m, f
 
 extern "C" int a4r_pack_matrices(void* stream, const float* flat, const a4r_pack_desc_t* desc_dev, int n_desc, int max_elems, int dtype) {
     if (!flat || !desc_dev || n_desc <= 0 || max_elems <= 0 || (dtype != A4R_BF16 && dtype != A4R_F32)) return A4R_EINVAL;
-    int gx = (max_elems + 255) / 256; if (gx > 64) gx = 64;
+    int gx = (max_elems + 255) / 256; if (gx > 256) gx = 256;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     const PackDesc* d = reinterpret_cast<const PackDesc*>(desc_dev);
     if (dtype == A4R_BF16) hipLaunchKernelGGL(pack_kernel<bf16_t>, dim3(gx, n_desc), dim3(256), 0, s, flat, d);

@@ -71,7 +71,8 @@ __global__ void __launch_bounds__(256) embed_ln_kernel(const int64_t* __restrict
                                                        const float* __restrict__ pos, const float* __restrict__ type0,
                                                        const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
                                                        T* __restrict__ out, int ldo, int n_rows, int S, int H, int roberta, int pad_id,
-                                                       uint64_t seed, uint32_t site, uint32_t thr16, float scale) {
+                                                       uint64_t seed, uint32_t site, uint32_t thr16, float scale,
+                                                       T* __restrict__ pre_out, float* __restrict__ stats_out) {
     const int lane = threadIdx.x & 63;
     const int ng = H / 8;
     for (int row = blockIdx.x * 4 + (threadIdx.x >> 6); row < n_rows; row += gridDim.x * 4) {
@@ -92,8 +93,10 @@ __global__ void __launch_bounds__(256) embed_ln_kernel(const int64_t* __restrict
         for (int g = 0; g < MAXG; ++g)
 #pragma unroll
             for (int e = 0; e < 8; ++e) v[g][e] += a[g][e] + b[g][e];
+        if (pre_out) row_store<T>(pre_out + (size_t)row * ldo, ng, lane, v);    // training the embedding side: what ln_bwd needs
         float mean, rstd;
         row_stats(v, ng, lane, H, eps, mean, rstd);
+        if (stats_out && lane == 0) { stats_out[2 * (size_t)row] = mean; stats_out[2 * (size_t)row + 1] = rstd; }
         row_load<float>(gamma, ng, lane, a);
         row_load<float>(beta, ng, lane, b);
 #pragma unroll
@@ -102,6 +105,31 @@ __global__ void __launch_bounds__(256) embed_ln_kernel(const int64_t* __restrict
             for (int e = 0; e < 8; ++e) v[g][e] = (v[g][e] - mean) * rstd * a[g][e] + b[g][e];
         if (thr16) row_dropout(v, ng, lane, row, H, seed, site, thr16, scale);
         row_store<T>(out + (size_t)row * ldo, ng, lane, v);
+    }
+}
+
+// gradient of the embedding sum: every token row of dpre is added into the rows of the word / position tables it read
+// (--fine_tune_to all, Pretraining; the reference gets this from nn.Embedding's backward).  fp32 atomics.
+template <typename T>
+__global__ void __launch_bounds__(256) embed_bwd_kernel(const int64_t* __restrict__ ids, int ld_ids, const T* __restrict__ dpre, int ldd,
+                                                        float* __restrict__ dword, float* __restrict__ dpos, int n_rows, int S, int H,
+                                                        int roberta, int pad_id) {
+    const int lane = threadIdx.x & 63;
+    for (int row = blockIdx.x * 4 + (threadIdx.x >> 6); row < n_rows; row += gridDim.x * 4) {
+        const int item = row / S, s = row % S;
+        const int64_t* idr = ids + (size_t)item * ld_ids;
+        const int64_t id = idr[s];
+        int pid = s;
+        if (roberta) {
+            int c = 0;
+            for (int t = 0; t <= s; ++t) c += (idr[t] != pad_id);
+            pid = (id != pad_id) ? c + pad_id : pad_id;
+        }
+        for (int c = lane; c < H; c += 64) {
+            const float g = Elem<T>::ld(dpre + (size_t)row * ldd + c);
+            if (dword) atomicAdd(dword + (size_t)id * H + c, g);
+            if (dpos) atomicAdd(dpos + (size_t)pid * H + c, g);
+        }
     }
 }
 
@@ -292,8 +320,9 @@ inline int row_grid(int rows) { int g = (rows + 3) / 4; return g > 2048 ? 2048 :
 extern "C" int a4r_embed_ln(void* stream, const int64_t* ids, int ld_ids, const float* word, const float* pos,
                             const float* type0, const float* gamma, const float* beta, float eps,
                             void* out, int ldo, int n_items, int S, int H, int roberta, int pad_id, int dtype,
-                            float drop_p, uint32_t drop_site, uint64_t drop_seed) {
+                            float drop_p, uint32_t drop_site, uint64_t drop_seed, void* pre_out, float* stats_out) {
     if (!ids || !word || !pos || !type0 || !gamma || !beta || !out) return A4R_EINVAL;
+    if (pre_out && misaligned(pre_out)) return A4R_EINVAL;
     if (bad_dtype(dtype) || n_items <= 0 || S <= 0 || H <= 0 || H % 8 || H > 1024 || ld_ids < S) return A4R_EINVAL;
     const int esz = dtype == A4R_F32 ? 4 : 2;
     if ((ldo * esz) % 16 || ldo < H || misaligned(out) || misaligned(word) || misaligned(pos) || misaligned(type0)) return A4R_EINVAL;
@@ -304,10 +333,24 @@ extern "C" int a4r_embed_ln(void* stream, const int64_t* ids, int ld_ids, const 
     const float sc = a4r_keep_scale(drop_p);
     if (dtype == A4R_BF16)
         hipLaunchKernelGGL(embed_ln_kernel<bf16_t>, dim3(row_grid(rows)), dim3(256), 0, s, ids, ld_ids, word, pos, type0, gamma, beta, eps,
-                           (bf16_t*)out, ldo, rows, S, H, roberta, pad_id, drop_seed, drop_site, thr, sc);
+                           (bf16_t*)out, ldo, rows, S, H, roberta, pad_id, drop_seed, drop_site, thr, sc, (bf16_t*)pre_out, stats_out);
     else
         hipLaunchKernelGGL(embed_ln_kernel<float>, dim3(row_grid(rows)), dim3(256), 0, s, ids, ld_ids, word, pos, type0, gamma, beta, eps,
-                           (float*)out, ldo, rows, S, H, roberta, pad_id, drop_seed, drop_site, thr, sc);
+                           (float*)out, ldo, rows, S, H, roberta, pad_id, drop_seed, drop_site, thr, sc, (float*)pre_out, stats_out);
+    return a4r_launch_status();
+}
+
+extern "C" int a4r_embed_bwd(void* stream, const int64_t* ids, int ld_ids, const void* dpre, int ldd, float* dword, float* dpos,
+                             int n_items, int S, int H, int roberta, int pad_id, int dtype) {
+    if (!ids || !dpre || (!dword && !dpos) || bad_dtype(dtype) || n_items <= 0 || S <= 0 || H <= 0 || ld_ids < S || ldd < H) return A4R_EINVAL;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    const int rows = n_items * S;
+    if (dtype == A4R_BF16)
+        hipLaunchKernelGGL(embed_bwd_kernel<bf16_t>, dim3(row_grid(rows)), dim3(256), 0, s, ids, ld_ids, (const bf16_t*)dpre, ldd, dword, dpos,
+                           rows, S, H, roberta, pad_id);
+    else
+        hipLaunchKernelGGL(embed_bwd_kernel<float>, dim3(row_grid(rows)), dim3(256), 0, s, ids, ld_ids, (const float*)dpre, ldd, dword, dpos,
+                           rows, S, H, roberta, pad_id);
     return a4r_launch_status();
 }
 

@@ -118,7 +118,39 @@ class _Lora:
 
 class _Block:
     """One post-LN transformer block (BERT layer or SASRec block) with optional adapters."""
-    pass
+    train_dense = False          # any backbone Linear of the block trainable (--fine_tune_to all)
+    qkv = (None, None, None)
+    d_o = d_i = d_o2 = None
+
+
+class _Dense:
+    """One Linear of the backbone: compute-dtype copies W [out, in] (NT operand) and W^T (dgrad operand).  Frozen: filled once.
+    Trainable (--fine_tune_to all, Pretraining/): the copies are re-packed from the flat fp32 master every step and g_w / g_b
+    receive dW = dY^T X (a4r_gemm_tn) and db = column sums of dY (a4r_colsum)."""
+
+    def __init__(self, eng, weight, bias, dt, w_dst=None, wT_dst=None, b_dst=None):
+        out_f, in_f = weight.shape
+        self.w = w_dst if w_dst is not None else torch.zeros(out_f, in_f, dtype=dt, device=eng.dev)
+        self.wT = wT_dst if wT_dst is not None else torch.zeros(in_f, out_f, dtype=dt, device=eng.dev)
+        if weight.requires_grad:
+            eng.add_pack(weight, self.w, False)
+            eng.add_pack(weight, self.wT, True)
+        else:
+            self.w.copy_(weight.detach().to(dt))
+            self.wT.copy_(weight.detach().t().to(dt))
+        self.g_w = eng.grad_view(weight)
+        self.b = self.g_b = None
+        if bias is not None:
+            if b_dst is not None:
+                self.b = b_dst
+                if bias.requires_grad:
+                    eng.add_pack_bias(bias, b_dst)
+                else:
+                    b_dst.copy_(bias.detach().float())
+            else:
+                self.b = bias.data if bias.requires_grad else eng._f32(bias)     # trainable: the fp32 master (a flat_p view) itself
+            self.g_b = eng.grad_view(bias)
+        self.trainable = self.g_w is not None or self.g_b is not None
 
 
 class TransRecEngine:
@@ -217,7 +249,8 @@ class TransRecEngine:
                 rows, cols = (p.shape[0], p.shape[1]) if p.dim() == 2 else (1, p.shape[0])
                 rp, cp = (dst.shape[0], dst.shape[1]) if dst.dim() == 2 else (1, dst.shape[0])
                 off = self.offsets[id(p)][0] if frozen_src is None else frozen_src[i]
-                arr[i] = L.PackDesc(off, dst.data_ptr(), rows, cols, rp, cp, int(tr), 0)
+                ld = dst.stride(0) if dst.dim() == 2 and dst.stride(0) != cp else 0      # column block of a fused operand
+                arr[i] = L.PackDesc(off, dst.data_ptr(), rows, cols, rp, cp, int(tr), ld)
                 mx = max(mx, rp * cp)
             return torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(self.dev), len(entries), mx
         code = lambda t: L.BF16 if t.dtype == torch.bfloat16 else L.F32
@@ -332,11 +365,18 @@ class TransRecEngine:
         if H % 64 or self.F % 64 or (H // nh) not in (32, 64) or self.S > 32:
             raise NotImplementedError(f'encoder geometry H={H} F={self.F} heads={nh} S={self.S}')
         emb = bert.embeddings
-        self.emb_word, self.emb_pos = self._f32(emb.word_embeddings.weight), self._f32(emb.position_embeddings.weight)
-        self.emb_type0 = self._f32(emb.token_type_embeddings.weight[0])
+        tab = lambda p: p.data if p.requires_grad else self._f32(p)        # trainable tables are read from the flat fp32 master
+        self.emb_word, self.emb_pos = tab(emb.word_embeddings.weight), tab(emb.position_embeddings.weight)
+        self.emb_type = tab(emb.token_type_embeddings.weight)
+        self.emb_type0 = self.emb_type[0]
         self.emb_ln = _LN(emb.LayerNorm, self)
-        if emb.LayerNorm.weight.requires_grad:
-            raise NotImplementedError('training the embedding LayerNorm (--finetune_layernorm) is not wired yet')
+        self.g_word, self.g_pos = self.grad_view(emb.word_embeddings.weight), self.grad_view(emb.position_embeddings.weight)
+        self.g_type = self.grad_view(emb.token_type_embeddings.weight)
+        # --finetune_layernorm (run.py:496-501) / --fine_tune_to all: the embedding side needs its input gradient
+        self.train_emb = any(f is not None for f in (self.g_word, self.g_pos, self.g_type, self.emb_ln.g_gamma, self.emb_ln.g_beta))
+        if getattr(bert, 'pooler', None) is not None:                       # never on the forward path ([0][:, 0], encoders.py:55): zero gradient
+            for p in bert.pooler.parameters():
+                self.grad_view(p)
         self.cls_only = bool(getattr(self.args, 'cls_only_last', True))
         self.fuse_adapters = bool(getattr(self.args, 'fuse_adapters', False))
         self.roberta = g['model_type'] == 'roberta'
@@ -357,17 +397,25 @@ class TransRecEngine:
             b.causal, b.mask_neg, b.scale = False, FMIN, 1.0 / math.sqrt(H // nh)
             b.ffn_act = L.ACT_GELU
             b.p_hidden, b.p_attn, b.site = self.p_hidden, self.p_attn, 16 * i
-            b.wqkv = self._w(torch.cat([att.query.weight, att.key.weight, att.value.weight], 0))
-            b.wqkvT = b.wqkv.t().contiguous()
-            b.bqkv = self._f32(torch.cat([att.query.bias, att.key.bias, att.value.bias], 0))
+            b.wqkv = torch.zeros(3 * H, H, dtype=self.T, device=self.dev)
+            b.wqkvT = torch.zeros(H, 3 * H, dtype=self.T, device=self.dev)
+            b.bqkv = torch.zeros(3 * H, dtype=torch.float32, device=self.dev)
+            b.qkv = tuple(None if type(lin).__name__ == 'LoRALinear' else          # LoRA slots are merged in pack_trainables
+                          _Dense(self, lin.weight, lin.bias, self.T, b.wqkv[sl * H:(sl + 1) * H], b.wqkvT[:, sl * H:(sl + 1) * H],
+                                 b.bqkv[sl * H:(sl + 1) * H])
+                          for sl, lin in enumerate((att.query, att.key, att.value)))
             d1, ln1, ad1, pl1, lnn1 = self._so(layer.attention.output, H, self.T)
             d2, ln2, ad2, pl2, lnn2 = self._so(layer.output, H, self.T)
-            b.wo, b.woT, b.bo = self._w(d1.weight), self._wT(d1.weight), self._f32(d1.bias)
-            b.wi, b.wiT, b.bi = self._w(layer.intermediate.dense.weight), self._wT(layer.intermediate.dense.weight), self._f32(layer.intermediate.dense.bias)
-            b.wo2, b.wo2T, b.bo2 = self._w(d2.weight), self._wT(d2.weight), self._f32(d2.bias)
+            b.d_o = _Dense(self, d1.weight, d1.bias, self.T)
+            b.d_i = _Dense(self, layer.intermediate.dense.weight, layer.intermediate.dense.bias, self.T)
+            b.d_o2 = _Dense(self, d2.weight, d2.bias, self.T)
+            b.wo, b.woT, b.bo = b.d_o.w, b.d_o.wT, b.d_o.b
+            b.wi, b.wiT, b.bi = b.d_i.w, b.d_i.wT, b.d_i.b
+            b.wo2, b.wo2T, b.bo2 = b.d_o2.w, b.d_o2.wT, b.d_o2.b
+            b.train_dense = any(d is not None and d.trainable for d in b.qkv + (b.d_o, b.d_i, b.d_o2))
             b.ln1, b.ln2 = _LN(ln1, self), _LN(ln2, self)
             b.ad1, b.ad2, b.pl1, b.pl2, b.lnn1, b.lnn2 = ad1, ad2, pl1, pl2, lnn1, lnn2
-            b.need_dx = i > 0
+            b.need_dx = i > 0 or self.train_emb
             b.T = self.T
             self.bert_blocks.append(b)
         lastb = self.bert_blocks[-1]
@@ -376,18 +424,24 @@ class TransRecEngine:
 
     def _build_head(self):
         fc = self.model.bert_encoder.text_encoders['title'].fc
-        self.fc_w = self._w(fc.weight)                         # [E, H] compute dtype (forward operand)
-        self.fc_wT32 = self._wT(fc.weight, torch.float32)      # [H, E] fp32 (dgrad operand: d_pre is fp32)
-        self.fc_b = self._f32(fc.bias)
-        if fc.weight.requires_grad or self.E % 64:
-            raise NotImplementedError('item head: frozen fc with embedding_dim % 64 == 0')
+        self.d_fc = _Dense(self, fc.weight, fc.bias, self.T)
+        self.fc_w, self.fc_b = self.d_fc.w, self.d_fc.b        # [E, H] compute dtype (forward operand)
+        self.fc_wT32 = torch.zeros(fc.in_features, fc.out_features, dtype=torch.float32, device=self.dev)   # [H, E] fp32 (dgrad operand: d_pre is fp32)
+        if fc.weight.requires_grad:
+            self.add_pack(fc.weight, self.fc_wT32, True)
+        else:
+            self.fc_wT32.copy_(fc.weight.detach().t().float())
+        if self.E % 64:
+            raise NotImplementedError('item head: embedding_dim % 64 == 0')
 
     def _build_sasrec(self):
         te = self.model.user_encoder.transformer_encoder
         E, nh = self.E, self.args.num_attention_heads
         if (E // nh) not in (32, 64) or self.Lseq - 1 > 32:
             raise NotImplementedError(f'SASRec geometry E={E} heads={nh} T={self.Lseq - 1}')
-        self.pos_emb = self._f32(te.position_embedding.weight)
+        pe = te.position_embedding.weight
+        self.pos_emb = pe.data if pe.requires_grad else self._f32(pe)
+        self.g_pos_emb = self.grad_view(pe)
         self.sas_ln0 = _LN(te.layer_norm, self)
         self.p_sas = float(self.args.drop_rate)
         f32 = torch.float32
@@ -406,12 +460,19 @@ class TransRecEngine:
             b.causal, b.mask_neg, b.scale = True, -1e9, 1.0 / math.sqrt(E // nh)
             b.ffn_act = L.ACT_RELU
             b.p_hidden, b.p_attn, b.site = self.p_sas, self.p_sas, 4096 + 16 * j
-            b.wqkv = self._w(torch.cat([mha.w_Q.weight, mha.w_K.weight, mha.w_V.weight], 0), f32)
-            b.wqkvT = b.wqkv.t().contiguous()
+            b.wqkv = torch.zeros(3 * E, E, dtype=f32, device=self.dev)
+            b.wqkvT = torch.zeros(E, 3 * E, dtype=f32, device=self.dev)
             b.bqkv = torch.zeros(3 * E, dtype=f32, device=self.dev) if b.lora else None       # lora.Linear carries a bias
-            b.wo, b.woT, b.bo = self._w(mha.fc.weight, f32), self._wT(mha.fc.weight, f32), None
-            b.wi, b.wiT, b.bi = self._w(ff.w_1.weight, f32), self._wT(ff.w_1.weight, f32), self._f32(ff.w_1.bias)
-            b.wo2, b.wo2T, b.bo2 = self._w(ff.w_2.weight, f32), self._wT(ff.w_2.weight, f32), self._f32(ff.w_2.bias)
+            b.qkv = tuple(None if type(lin).__name__ == 'LoRALinear' else
+                          _Dense(self, lin.weight, None, f32, b.wqkv[sl * E:(sl + 1) * E], b.wqkvT[:, sl * E:(sl + 1) * E])
+                          for sl, lin in enumerate((mha.w_Q, mha.w_K, mha.w_V)))
+            b.d_o = _Dense(self, mha.fc.weight, None, f32)
+            b.d_i = _Dense(self, ff.w_1.weight, ff.w_1.bias, f32)
+            b.d_o2 = _Dense(self, ff.w_2.weight, ff.w_2.bias, f32)
+            b.wo, b.woT, b.bo = b.d_o.w, b.d_o.wT, None
+            b.wi, b.wiT, b.bi = b.d_i.w, b.d_i.wT, b.d_i.b
+            b.wo2, b.wo2T, b.bo2 = b.d_o2.w, b.d_o2.wT, b.d_o2.b
+            b.train_dense = any(d is not None and d.trainable for d in b.qkv + (b.d_o, b.d_i, b.d_o2))
             b.ln1, b.ln2 = _LN(mha.layer_norm, self), _LN(ff.layer_norm, self)
             placement = getattr(blk, 'placement', None) if blk is not tb else None
             b.ad1 = b.ad2 = b.lnn1 = b.lnn2 = None
@@ -446,10 +507,13 @@ class TransRecEngine:
         d['qkv'] = self._buf(pre + '.qkv', M, 3 * H, T)
         if Mc is not None:
             pre, M = pre + '.cls', Mc
-        if (blk.lora or blk.pl1 == 'parallel') and not shared:
+        if (blk.lora or blk.pl1 == 'parallel' or blk.train_dense) and not shared:
             d['xin'] = self._buf(pre + '.xin', d['qkv'].shape[0], H, T)
-        if blk.pl2 == 'parallel' and not shared:
+        if (blk.pl2 == 'parallel' or blk.train_dense) and not shared:
             d['x1s'] = self._buf(pre + '.x1s', M, H, T)
+        if blk.train_dense and not shared:           # inputs of attention.output.dense and output.dense (weight gradients)
+            d['ctx_s'] = self._buf(pre + '.ctx_s', M, H, T)
+            d['u_s'] = self._buf(pre + '.u_s', M, F, T)
         d['h1'] = self._buf(pre + '.h1', M, H, T)
         d['v1'] = self._buf(pre + '.v1', M, H, T)
         d['st1'] = self._buf(pre + '.st1', M, 2, torch.float32)
@@ -520,10 +584,12 @@ class TransRecEngine:
             L.gather_rows(ctx, ctx_c, n_items, blk.S)
             L.gather_rows(x, x_c, n_items, blk.S)
             ctx, x, M = ctx_c, x_c, cls_rows
+        if 'ctx_s' in bufs:
+            bufs['ctx_s'][:M].copy_(ctx[:M])
         x1 = self._buf('x1', M, H, T)
         x1 = bufs['x1s'] if 'x1s' in bufs else x1
         self._sub_forward(blk, '1', ctx, blk.wo, blk.bo, x, blk.ln1, blk.ad1, blk.pl1, blk.lnn1, bufs, M, ph, blk.site + 1, seed, x1)
-        u = self._buf('u', M, blk.F, T)
+        u = bufs['u_s'] if 'u_s' in bufs else self._buf('u', M, blk.F, T)
         L.gemm_nt(x1, blk.wi, u, bias=blk.bi, C2=bufs['upre'], act=blk.ffn_act, c2_deriv=True, M=M)     # 'upre' holds act'(pre)
         self._sub_forward(blk, '2', u, blk.wo2, blk.bo2, x1, blk.ln2, blk.ad2, blk.pl2, blk.lnn2, bufs, M, ph, blk.site + 2, seed, x_out)
 
@@ -630,12 +696,16 @@ class TransRecEngine:
         if cls_rows is not None:
             M = cls_rows
         dh2, dres2 = self._sub_backward(blk, '2', dx_out, blk.ln2, blk.ad2, blk.pl2, blk.lnn2, bufs, M, ph, blk.site + 2, seed)
+        self._dense_wgrad(blk.d_o2, dh2, bufs.get('u_s'), M)
         du = self._buf('du', M, F, T)
         L.gemm_nt(dh2, blk.wo2T, du, Pre=bufs['upre'], dact=L.DACT_MUL, M=M)
+        self._dense_wgrad(blk.d_i, du, bufs.get('x1s'), M)
         dx1 = self._buf('dx1', M, H, T)
         L.gemm_nt(du, blk.wiT, dx1, R1=dres2, M=M)
         dh1, dres1 = self._sub_backward(blk, '1', dx1, blk.ln1, blk.ad1, blk.pl1, blk.lnn1, bufs, M, ph, blk.site + 1, seed)
-        if dx_in is None and not blk.lora:      # first encoder layer: nothing trainable sits below its attention
+        self._dense_wgrad(blk.d_o, dh1, bufs.get('ctx_s'), M)
+        qkv_train = any(d is not None and d.trainable for d in blk.qkv)
+        if dx_in is None and not blk.lora and not qkv_train:      # first encoder layer: nothing trainable sits below its attention
             return
         dctx = self._buf('dctx_c' if cls_rows is not None else 'dctx', M, H, T)
         L.gemm_nt(dh1, blk.woT, dctx, M=M)
@@ -654,8 +724,19 @@ class TransRecEngine:
                    drop_p=pa, drop_site=blk.site, drop_seed=seed)
         for lo in blk.lora:
             self._lora_backward(blk, lo, dqkv, bufs['xin'], M)
+        for sl, d in enumerate(blk.qkv):
+            self._dense_wgrad(d, dqkv[:, sl * H:(sl + 1) * H], bufs.get('xin'), M)
         if dx_in is not None:
             L.gemm_nt(dqkv, blk.wqkvT, dx_in, R1=dres1, M=M)
+
+    def _dense_wgrad(self, d, dy, x, M):
+        """dW += dy^T x, db += column sums of dy for a trainable backbone Linear (--fine_tune_to all)."""
+        if d is None or not d.trainable:
+            return
+        if d.g_w is not None:
+            L.gemm_tn(dy, x, d.g_w(), M=M)
+        if d.g_b is not None:
+            L.colsum(dy, d.g_b(), M=M)
 
     # ------------------------------------------------------------------ item tower / user tower
     def _encode(self, news, n_items, train, seed, saved):
@@ -665,9 +746,13 @@ class TransRecEngine:
         key_mask = self._buf('kmask', n_items, S, torch.float32)
         key_mask.copy_(news[:, S:2 * S])
         x = self._buf('xa', M, H, self.T)
+        keep = self.train_emb and saved is not None
         L.embed_ln(news, self.emb_word, self.emb_pos, self.emb_type0, self.emb_ln.gamma, self.emb_ln.beta, self.emb_ln.eps,
                    x, n_items, S, roberta=self.roberta, pad_id=self.pad_id,
-                   drop_p=self.p_hidden if train else 0.0, drop_site=999, drop_seed=seed)
+                   drop_p=self.p_hidden if train else 0.0, drop_site=999, drop_seed=seed,
+                   pre_out=self._buf('emb_pre', M, H, self.T) if keep else None,
+                   stats_out=self._buf('emb_st', M, 2, torch.float32) if keep else None)
+        self._news = news
         other = self._buf('xb', M, H, self.T)
         Ip = pad_to(n_items, 128)
         cls = self._buf('cls', Ip, H, self.T)
@@ -798,6 +883,8 @@ class TransRecEngine:
         L.ln_bwd(dx, c['xin'], st0, self.sas_ln0.gamma, d_in, M=Mu, add=self.pos_emb[:Tn],
                  dgamma=gg(self.sas_ln0.g_gamma), dbeta=gg(self.sas_ln0.g_beta),
                  drop_p=self.p_sas if train else 0.0, drop_site=4000, drop_seed=seed)
+        if self.g_pos_emb is not None:             # nn.Embedding(position) backward: the same rows are read by every user
+            self.g_pos_emb()[:Tn].add_(d_in[:B * Tn].view(B, Tn, E).sum(0))
         L.emb_grad_add_inputs(d_in, d_emb, B, self.Lseq, E)
         self._items_backward(c, d_emb, Ip)
         if self._virtual:
@@ -820,6 +907,11 @@ class TransRecEngine:
         L.act_bwd_f32(d_emb, c['pre'], d_pre, L.ACT_GELU)
         dcls = self._buf('dcls', Ip, self.H, self.T)
         L.gemm_nt(d_pre, self.fc_wT32, dcls, M=Ip)
+        if self.d_fc.trainable:                    # item head fc (encoders.py:44,56) under --fine_tune_to all
+            if self.d_fc.g_w is not None:
+                L.gemm_tn(d_pre if self.T == torch.float32 else d_pre.to(self.T), self._buf('cls', Ip, self.H, self.T), self.d_fc.g_w(), M=Ip)
+            if self.d_fc.g_b is not None:
+                L.colsum(d_pre, self.d_fc.g_b(), M=Ip)
         dxb = self._buf('dx_a', M, self.H, self.T)
         if not self.cls_only:
             dxb.zero_()
@@ -834,6 +926,16 @@ class TransRecEngine:
             else:
                 self._block_backward(blk, dxb, c['key_mask'], n_items, M, c['saved_b'][i], train, seed, spare if blk.need_dx else None)
             dxb, spare = spare, dxb
+        if self.train_emb:                         # HF BertEmbeddings backward: LayerNorm (through its dropout mask), then the three tables
+            gg = lambda f: f() if f is not None else None
+            dpre = spare
+            L.ln_bwd(dxb, self._buf('emb_pre', M, self.H, self.T), self._buf('emb_st', M, 2, torch.float32), self.emb_ln.gamma, dpre, M=M,
+                     dgamma=gg(self.emb_ln.g_gamma), dbeta=gg(self.emb_ln.g_beta),
+                     drop_p=self.p_hidden if train else 0.0, drop_site=999, drop_seed=seed)
+            if self.g_word is not None or self.g_pos is not None:
+                L.embed_bwd(self._news, dpre, gg(self.g_word), gg(self.g_pos), n_items, self.S, roberta=self.roberta, pad_id=self.pad_id)
+            if self.g_type is not None:
+                L.colsum(dpre, self.g_type()[0], M=M)
 
     def _virtual_backward(self):
         """Compacter: chain the gradients of the effective matrices into (phm_rule, W_left, W_right) with autograd."""

@@ -134,7 +134,12 @@ int a4r_resample_u8(void* stream, const void* src, void* dst, const int32_t* bou
 int a4r_embed_ln(void* stream, const int64_t* ids, int ld_ids, const float* word, const float* pos,
                  const float* type0, const float* gamma, const float* beta, float eps,
                  void* out, int ldo, int n_items, int S, int H, int roberta, int pad_id, int dtype,
-                 float drop_p, uint32_t drop_site, uint64_t drop_seed);
+                 float drop_p, uint32_t drop_site, uint64_t drop_seed, void* pre_out, float* stats_out);
+/* pre_out (optional, same dtype / ld as out): the embedding sum before the LayerNorm; stats_out (optional, fp32 [rows, 2]):
+ * mean, rstd -- what a4r_ln_bwd needs when the embedding LayerNorm or tables are trained (--finetune_layernorm, --fine_tune_to all).
+ * a4r_embed_bwd: the nn.Embedding backward: dword[id] += dpre[row], dpos[pos_id] += dpre[row] (either table may be NULL). */
+int a4r_embed_bwd(void* stream, const int64_t* ids, int ld_ids, const void* dpre, int ldd, float* dword, float* dpos,
+                  int n_items, int S, int H, int roberta, int pad_id, int dtype);
 
 /* y = LayerNorm(v) * gamma + beta over rows of width H (H % 8 == 0, H <= 1024);
  * stats[2*row] = mean, stats[2*row+1] = rstd (fp32) saved for backward.  add (optional, fp32 [add_rows, H])
@@ -189,7 +194,7 @@ int a4r_adam_step(void* stream, float* p, const float* g, float* m, float* v, in
 /* Refresh the kernel-side copies of trainable matrices after an optimiser step:
  * dst[rows_pad, cols_pad] (dtype) = src (fp32 [rows, cols] at flat + src_off) or its transpose, zero padded. */
 typedef struct {
-    int64_t src_off; void* dst; int32_t rows, cols, rows_pad, cols_pad, transpose, pad_;
+    int64_t src_off; void* dst; int32_t rows, cols, rows_pad, cols_pad, transpose, dst_ld;   /* dst_ld 0 = cols_pad */
 } a4r_pack_desc_t;
 int a4r_pack_matrices(void* stream, const float* flat, const a4r_pack_desc_t* desc_dev, int n_desc, int max_elems, int dtype);
 

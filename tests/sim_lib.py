@@ -168,16 +168,34 @@ def vit_assemble(patches, cls, pos, out, n_items, n_keep, keep_idx=None):
     out[:n_items * (n_keep + 1)] = tok.reshape(-1, H).to(out.dtype)
 
 
-def embed_ln(ids, word, pos, type0, gamma, beta, eps, out, n_items, S, roberta=False, pad_id=0,
-             drop_p=0.0, drop_site=0, drop_seed=0):
-    assert drop_p == 0.0
+def _pos_ids(ids, n_items, S, roberta, pad_id):
     idv = ids[:, :S]
     if roberta:
         m = (idv != pad_id).long()
-        pid = torch.cumsum(m, 1) * m + pad_id
-    else:
-        pid = torch.arange(S).expand(n_items, S)
+        return idv, torch.cumsum(m, 1) * m + pad_id
+    return idv, torch.arange(S).expand(n_items, S)
+
+
+def embed_bwd(ids, dpre, dword, dpos, n_items, S, roberta=False, pad_id=0):
+    idv, pid = _pos_ids(ids, n_items, S, roberta, pad_id)
+    g = dpre[:n_items * S].float()
+    if dword is not None:
+        dword.index_add_(0, idv.reshape(-1), g)
+    if dpos is not None:
+        dpos.index_add_(0, pid.reshape(-1), g)
+
+
+def embed_ln(ids, word, pos, type0, gamma, beta, eps, out, n_items, S, roberta=False, pad_id=0,
+             drop_p=0.0, drop_site=0, drop_seed=0, pre_out=None, stats_out=None):
+    assert drop_p == 0.0
+    idv, pid = _pos_ids(ids, n_items, S, roberta, pad_id)
     x = word[idv] + pos[pid] + type0
+    if pre_out is not None:
+        pre_out[:n_items * S] = x.view(n_items * S, -1).to(pre_out.dtype)
+    if stats_out is not None:
+        xf = x.view(n_items * S, -1)
+        stats_out[:n_items * S, 0] = xf.mean(-1)
+        stats_out[:n_items * S, 1] = torch.rsqrt(xf.var(-1, unbiased=False) + eps)
     out[:n_items * S] = torch.nn.functional.layer_norm(x, (x.shape[-1],), gamma, beta, eps).view(n_items * S, -1).to(out.dtype)
 
 
@@ -300,9 +318,10 @@ def pack_matrices(flat, desc_dev, n_desc, max_elems, dtype):
         src = flat[d.src_off:d.src_off + d.rows * d.cols].view(d.rows, d.cols)
         if d.transpose:
             src = src.t()
-        n = d.rows_pad * d.cols_pad
+        ld = d.dst_ld or d.cols_pad
+        n = (d.rows_pad - 1) * ld + d.cols_pad
         buf = (ctypes.c_char * (n * (2 if dtype == BF16 else 4))).from_address(d.dst)
-        dst = torch.frombuffer(buf, dtype=tdt).view(d.rows_pad, d.cols_pad)
+        dst = torch.frombuffer(buf, dtype=tdt).as_strided((d.rows_pad, d.cols_pad), (ld, 1))
         dst.zero_()
         dst[:src.shape[0], :src.shape[1]] = src.to(tdt)
 

@@ -273,3 +273,33 @@ def test_lora_vs_oracle(dtype):
     for n in names:
         ref = grads[n].numpy()
         np.testing.assert_allclose(params[n].grad.cpu().numpy(), ref, atol=1e-6 + tol_g * np.abs(ref).max(), rtol=0, err_msg=n)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('ln_only', [False, True])
+def test_finetune_all_fp32_vs_oracle_and_fixture(ln_only):
+    """--fine_tune_to all (every backbone weight, the embedding tables, the item head and the SASRec weights trainable) and
+    --finetune_layernorm without adapters, through the C ABI: every gradient vs the oracle's autograd and the reference fixture."""
+    import test_engine_host_logic as TH
+    from oracle import ref_cpu as R
+    model, args, sd, cfg, fx, items, mask = TH.build_finetune_all(device='cuda:0', ln_only=ln_only)
+    names = [n for n, p in model.named_parameters() if p.requires_grad]
+    out, grads = R.loss_and_grads(sd, names, items.cpu(), mask.cpu(), cfg)
+    loss = model(items, mask, 'cuda:0')
+    loss.backward()
+    assert abs(loss.item() - float(fx['loss'])) < 1e-4
+    params = dict(model.named_parameters())
+    for n in names:
+        ref = grads[n].numpy()
+        np.testing.assert_allclose(params[n].grad.cpu().numpy(), ref, atol=1e-6 + 1e-4 * np.abs(ref).max(), rtol=0, err_msg=n)
+    if not ln_only:
+        from adapter4rec_amd.inject import optimizer_groups
+        from adapter4rec_amd.optim import FusedAdam
+        opt = FusedAdam(optimizer_groups(model, args))
+        l0 = loss.item()
+        for _ in range(3):
+            opt.zero_grad()
+            l_ = model(items, mask, 'cuda:0')
+            l_.backward()
+            opt.step()
+        assert model(items, mask, 'cuda:0').item() < l0          # three Adam steps on one batch must lower its loss

@@ -135,3 +135,41 @@ def test_host_logic_lora(simulated):
     for n in names:
         ref = grads[n].numpy()
         np.testing.assert_allclose(params[n].grad.numpy(), ref, atol=1e-6 + 1e-4 * np.abs(ref).max(), rtol=0, err_msg=n)
+
+
+def build_finetune_all(device='cpu', dtype='fp32', ln_only=False):
+    """--fine_tune_to all (run.py:366-371: nothing frozen, no adapters) -- the Pretraining/ configuration -- or, with ln_only,
+    adapters off + --finetune_layernorm (every LayerNorm incl. the embedding one trainable)."""
+    from adapter4rec_amd.model import BertBackbone, Model
+    from golden_util import load_variant
+    sd, cfg, fx, trainable, (items, mask), base = load_variant('finetune_all')
+    args = TG.make_args(compute_dtype=dtype, adapter_type='none', adding_adapter_to='None')
+    model = Model(args, 200, True, BertBackbone(dict(TG.GEOM)))
+    model.load_state_dict({str(k): sd[strip(str(k))] for k in fx['all_keys']}, strict=True)
+    for n, p in model.named_parameters():
+        if ln_only:
+            p.requires_grad = ('LayerNorm' in n or 'layer_norm' in n)
+        else:
+            p.requires_grad = 'pooler' not in n            # as the fixture generator (pooler never receives a gradient)
+    model.eval()
+    return model.to(device), args, sd, cfg, fx, items.to(device), mask.to(device)
+
+
+@pytest.mark.parametrize('ln_only', [False, True])
+def test_host_logic_finetune_all(simulated, ln_only):
+    from oracle import ref_cpu as R
+    model, args, sd, cfg, fx, items, mask = build_finetune_all(ln_only=ln_only)
+    names = [n for n, p in model.named_parameters() if p.requires_grad]
+    out, grads = R.loss_and_grads(sd, names, items, mask, cfg)
+    loss = model(items, mask, 'cpu')
+    loss.backward()
+    assert abs(loss.item() - float(fx['loss'])) < 1e-4
+    params = dict(model.named_parameters())
+    for n in names:                                           # every tensor against the oracle's autograd ...
+        ref = grads[n].numpy()
+        np.testing.assert_allclose(params[n].grad.numpy(), ref, atol=1e-6 + 1e-4 * np.abs(ref).max(), rtol=0, err_msg=n)
+    if not ln_only:
+        for k in fx.files:                                    # ... and the ones the reference itself recorded
+            if k.startswith('grad/'):
+                ref = fx[k]
+                np.testing.assert_allclose(params[k[5:]].grad.numpy(), ref, atol=1e-6 + 1e-4 * np.abs(ref).max(), rtol=0, err_msg=k)
