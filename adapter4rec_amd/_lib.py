@@ -32,7 +32,8 @@ class GemmArgs(C.Structure):
                 ('lda', C.c_int32), ('ldb', C.c_int32), ('ldc', C.c_int32), ('ldc2', C.c_int32),
                 ('ldr1', C.c_int32), ('ldr2', C.c_int32), ('ldpre', C.c_int32),
                 ('in_dtype', C.c_int32), ('out_dtype', C.c_int32), ('act', C.c_int32), ('dact', C.c_int32),
-                ('drop_first', C.c_int32), ('c2_mode', C.c_int32), ('alpha', C.c_float), ('drop_p', C.c_float), ('drop_site', C.c_uint32), ('drop_seed', C.c_uint64)]
+                ('drop_first', C.c_int32), ('c2_mode', C.c_int32), ('alpha', C.c_float), ('drop_p', C.c_float), ('drop_site', C.c_uint32), ('drop_seed', C.c_uint64),
+                ('drop_row0', C.c_int64)]
 
 
 class AttnArgs(C.Structure):

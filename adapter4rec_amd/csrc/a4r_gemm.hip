@@ -231,6 +231,7 @@ inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 
 }  // namespace
 
 int a4r_gemm_nt_256(hipStream_t s, const a4r_gemm_t& g);   // a4r_gemm256.hip
+int a4r_cu_count();                                          // a4r_gemm256.hip: CU count rounded down to a multiple of 8
 
 extern "C" int a4r_gemm_variant(int v) {
     const int old = g_variant;
@@ -256,8 +257,36 @@ extern "C" int a4r_gemm_nt(void* stream, const a4r_gemm_t* gp) {
     if (g.dact == A4R_DACT_MUL_ && !g.Pre) return A4R_EINVAL;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     if (g_variant >= 2 && g.M % 256 == 0 && g.N % 256 == 0 && (g.K * isz) % 128 == 0) {
-        const int rc = a4r_gemm_nt_256(s, g);
-        if (rc != 1) return rc;              // 1 = this (dtype, act, dact) combination has no large-tile instantiation
+        // Tile quantisation: the persistent 256-tile grid runs ceil(tiles / CUs) rounds.  When the last round would hold only a
+        // few whole row panels (ViT-B/16 at 8 users: 777 tiles = 3 rounds + 9 tiles), those panels go to the 128-tile kernel as
+        // a second launch instead of costing a full round (N = 768, K = 3072: 4 -> 3 rounds + ~1/4).
+        const int ntm = g.M / 256, ntn = g.N / 256, tiles = ntm * ntn, ncu = a4r_cu_count();
+        const int rem = tiles % ncu;
+        if (tiles > ncu && rem > 0 && rem * 4 <= ncu && rem % ntn == 0) {
+            const int64_t head_rows = (int64_t)(ntm - rem / ntn) * 256;
+            a4r_gemm_t g1 = g, g2 = g;
+            g1.M = (int)head_rows;
+            g2.M = g.M - (int)head_rows;
+            g2.drop_row0 = g.drop_row0 + head_rows;
+            auto adv = [&](const void* p, int ld, int sz) { return p ? (const void*)((const char*)p + head_rows * ld * sz) : nullptr; };
+            g2.A = adv(g.A, g.lda, isz);
+            g2.C = const_cast<void*>(adv(g.C, g.ldc, osz));
+            g2.C2 = const_cast<void*>(adv(g.C2, g.ldc2, osz));
+            g2.R1 = adv(g.R1, g.ldr1, osz);
+            g2.R2 = adv(g.R2, g.ldr2, osz);
+            g2.Pre = adv(g.Pre, g.ldpre, osz);
+            const int rc = a4r_gemm_nt_256(s, g1);
+            if (rc == 0) {
+                if (g.in_dtype == A4R_BF16 && g.out_dtype == A4R_BF16) return launch_bn<bf16_t, bf16_t>(s, g2);
+                if (g.in_dtype == A4R_F32 && g.out_dtype == A4R_F32) return launch_bn<float, float>(s, g2);
+                if (g.in_dtype == A4R_BF16 && g.out_dtype == A4R_F32) return launch_bn<bf16_t, float>(s, g2);
+                return launch_bn<float, bf16_t>(s, g2);
+            }
+            if (rc != 1) return rc;
+        } else {
+            const int rc = a4r_gemm_nt_256(s, g);
+            if (rc != 1) return rc;              // 1 = this (dtype, act, dact) combination has no large-tile instantiation
+        }
     }
     if (g.in_dtype == A4R_BF16 && g.out_dtype == A4R_BF16) return launch_bn<bf16_t, bf16_t>(s, g);
     if (g.in_dtype == A4R_F32 && g.out_dtype == A4R_F32) return launch_bn<float, float>(s, g);

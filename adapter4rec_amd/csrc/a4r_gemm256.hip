@@ -349,9 +349,9 @@ __global__ void __launch_bounds__(512, 2) gemm_nt_256_kernel(const a4r_gemm_t p,
 #undef A4R_PIPE_PHASE
 }
 
-template <typename TI, typename TO, int ACT, int DACT>
-int launch256(hipStream_t s, const a4r_gemm_t& g) {
-    const int ntm = g.M / 256, ntn = g.N / 256;
+}  // namespace
+
+int a4r_cu_count() {
     static int n_cu = 0;
     if (n_cu == 0) {
         int dev = 0;
@@ -361,6 +361,15 @@ int launch256(hipStream_t s, const a4r_gemm_t& g) {
         n_cu &= ~7;                                        // multiple of 8: a workgroup stays on one XCD group
         if (n_cu < 8) n_cu = 8;
     }
+    return n_cu;
+}
+
+namespace {
+
+template <typename TI, typename TO, int ACT, int DACT>
+int launch256(hipStream_t s, const a4r_gemm_t& g) {
+    const int ntm = g.M / 256, ntn = g.N / 256;
+    const int n_cu = a4r_cu_count();
     const int grid = ntm * ntn < n_cu ? ntm * ntn : n_cu;
     hipLaunchKernelGGL((gemm_nt_256_kernel<TI, TO, ACT, DACT>), dim3(grid), dim3(512), 0, s, g, ntm, ntn,
                        a4r_thr16(g.drop_p), a4r_keep_scale(g.drop_p));

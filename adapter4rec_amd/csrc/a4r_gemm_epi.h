@@ -12,7 +12,7 @@ struct GemmEpi {
     int ldc, ldc2, ldr1, ldr2, ldpre, N, act, dact, drop_first, c2_mode;
     float alpha, keep_scale;
     uint32_t thr16, drop_site;
-    uint64_t drop_seed;
+    uint64_t drop_seed, row0;
 };
 
 template <typename TO>
@@ -24,6 +24,7 @@ A4R_DEV GemmEpi<TO> make_epi(const a4r_gemm_t& p, uint32_t thr16, float keep_sca
     e.ldc = p.ldc; e.ldc2 = p.ldc2; e.ldr1 = p.ldr1; e.ldr2 = p.ldr2; e.ldpre = p.ldpre; e.N = p.N;
     e.act = p.act; e.dact = p.dact; e.drop_first = p.drop_first; e.c2_mode = p.c2_mode;
     e.alpha = p.alpha; e.keep_scale = keep_scale; e.thr16 = thr16; e.drop_site = p.drop_site; e.drop_seed = p.drop_seed;
+    e.row0 = (uint64_t)p.drop_row0;
     return e;
 }
 
@@ -93,7 +94,7 @@ A4R_DEV void epilogue_n(float (&v)[NC], const float* bias, size_t grow, int gcol
             for (int i = 0; i < NC; ++i) v[i] *= act_bwd(pre[i], dact);
         }
     }
-    const uint64_t e0 = (uint64_t)grow * (uint64_t)e.N + (uint64_t)gcol;
+    const uint64_t e0 = ((uint64_t)grow + e.row0) * (uint64_t)e.N + (uint64_t)gcol;
     if (e.thr16 && e.drop_first) epi_dropout<NC>(v, e0, e.drop_seed, e.drop_site, e.thr16, e.keep_scale);
     if (e.R1) {
         float t[NC];

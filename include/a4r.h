@@ -52,6 +52,8 @@ typedef struct {
     int32_t c2_mode;      /* what C2 receives: 0 = the pre-activation, 1 = act'(pre-activation) (so that backward is one multiply) */
     float alpha;
     float drop_p; uint32_t drop_site; uint64_t drop_seed;
+    int64_t drop_row0;    /* row index of A's first row inside the logical matrix the dropout mask is defined on (0 unless the
+                           * caller splits one GEMM into several launches: the mask index is (drop_row0 + row) * N + col) */
 } a4r_gemm_t;
 int a4r_gemm_nt(void* stream, const a4r_gemm_t* g);
 /* tuning knob for A/B measurements: 0 = 128x128 tile, register-staged K pipeline; 1 = 128x128 tile, direct-to-LDS

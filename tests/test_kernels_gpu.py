@@ -536,3 +536,27 @@ def test_adapter_fwd_fused(H, act, inner):
     close(y, y_r, t, 'adapter y')
     close(stats[:, 0], v_r.mean(-1), torch.float32, 'adapter mean', atol32=2e-3, rtol32=1e-3)
     close(stats[:, 1], torch.rsqrt(v_r.var(-1, unbiased=False) + 1e-12), torch.float32, 'adapter rstd', atol32=2e-3, rtol32=2e-3)
+
+
+def test_gemm_tail_panels_split_launch():
+    """777 tiles on 256 CUs: the last 3 row panels are launched on the 128-tile kernel (a4r_gemm.hip); results and the dropout
+    mask (drop_row0) must equal the single-kernel launch."""
+    from adapter4rec_amd import _lib as L
+    M, N, K = 259 * 256, 768, 768
+    A = rnd(M, K, dtype=torch.bfloat16, seed=71)
+    B = rnd(N, K, dtype=torch.bfloat16, scale=0.05, seed=72)
+    R1 = rnd(M, N, dtype=torch.bfloat16, seed=73)
+    bias = rnd(N, seed=74)
+    outs = []
+    for v in (2, 1):
+        L.gemm_variant(v)
+        C = torch.zeros(M, N, dtype=torch.bfloat16, device=dev())
+        C2 = torch.zeros_like(C)
+        L.gemm_nt(A, B, C, bias=bias, R1=R1, C2=C2, act=2, drop_p=0.25, drop_site=5, drop_seed=99, drop_first=True)
+        outs.append((C, C2))
+    L.gemm_variant(2)
+    (c_a, c2_a), (c_b, c2_b) = outs
+    assert torch.equal((c_a == R1), (c_b == R1))                      # identical dropout pattern, tail rows included
+    close(c_a, c_b, torch.bfloat16, 'split vs single launch', rtol16=2e-2, atol16=2e-2)
+    close(c2_a[-768:], c2_b[-768:], torch.bfloat16, 'tail C2', rtol16=2e-2, atol16=2e-2)
+    assert float((c_a[-768:] != R1[-768:]).float().mean()) > 0.5     # the tail was really written
