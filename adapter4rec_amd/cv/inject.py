@@ -3,7 +3,9 @@
 from ..model.lora import LoRALinear
 from ..model.model import (CompacterModel, SASRecAdaptedSelfOutput, SASRecCompacterAdaptedSelfOutput,
                            SASRecPfeifferVer2AdaptedSelfOutput)
-from .model import VITAdaptedOutput, VITAdaptedSelfOutput, VITCompacterAdaptedOutput, VITCompacterAdaptedSelfOutput
+from ..model.model import SASRecParallelAdaptedSelfOutput
+from .model import (VITAdaptedOutput, VITAdaptedParallelOutput, VITAdaptedSelfOutput, VITCompacterAdaptedOutput,
+                    VITCompacterAdaptedSelfOutput)
 
 
 def vit_layers(model):
@@ -45,9 +47,13 @@ def inject_adapters(model, args):
             lyr.output = VITAdaptedOutput(lyr.output, args)
         for i, blk in enumerate(blocks):
             blocks[i] = SASRecAdaptedSelfOutput(blk, args)
+    elif 'houslby' in t:                             # :448-460 --is_serial None: parallel adapter at layer.output only
+        for lyr in layers:
+            lyr.output = VITAdaptedParallelOutput(lyr.output, args)
+        for i, blk in enumerate(blocks):
+            blocks[i] = SASRecParallelAdaptedSelfOutput(blk, args)
     else:
-        raise NotImplementedError(f'--adapter_type {t} (is_serial={args.is_serial}) on the image tower: K-Adapter, soft prompt and '
-                                  'the parallel form are not wired natively yet')
+        raise NotImplementedError(f'--adapter_type {t} on the image tower: K-Adapter and soft prompt are not wired natively')
     getattr(model, 'model', model).invalidate_native()
     return model
 

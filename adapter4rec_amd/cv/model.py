@@ -120,6 +120,10 @@ class VITAdaptedOutput(VITAdaptedSelfOutput):    # model.py:198-212: adapter(dro
     adds_input = True
 
 
+class VITAdaptedParallelOutput(VITAdaptedSelfOutput):   # model.py:165-179: dense(x) + input + adapter(input) (adapter keeps its inner residual)
+    placement, adds_input = 'parallel', True
+
+
 class VITCompacterAdaptedSelfOutput(_Container):   # model.py:432-445
     placement, adds_input = 'serial', False
 

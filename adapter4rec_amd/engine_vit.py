@@ -96,9 +96,12 @@ class ViTRecEngine(TransRecEngine):
         """(dense Linear, adapter or None) of a plain or wrapped ViTSelfOutput / ViTOutput."""
         if hasattr(mod, 'self_output'):
             ad = getattr(mod, 'adapter', None)
-            if not isinstance(ad, (AdapterBlock, HyperComplexAdapterBlock)) or getattr(mod, 'placement', 'serial') != 'serial':
+            pl = getattr(mod, 'placement', 'serial')
+            if not isinstance(ad, (AdapterBlock, HyperComplexAdapterBlock)) or pl not in ('serial', 'parallel'):
                 raise NotImplementedError(f'ViT adapter wrapper {type(mod).__name__}')
-            return mod.self_output.dense, _Adapter(ad, self.H, self, self.T)
+            a = _Adapter(ad, self.H, self, self.T)
+            a.parallel = pl == 'parallel'
+            return mod.self_output.dense, a
         return mod.dense, None
 
     # ------------------------------------------------------------------ buffers
@@ -133,6 +136,11 @@ class ViTRecEngine(TransRecEngine):
             L.gemm_nt(dense_in, w, out, bias=bias, R1=resid, M=M)
             return
         h, zp, z = bufs['h' + k], bufs['zp' + k], bufs['z' + k]
+        if getattr(ad, 'parallel', False):    # model.py:165-179: dense(u) + x + [fc_up(act(fc_down(x))) + x], the adapter reads the sub-layer INPUT x
+            L.gemm_nt(resid, ad.wd, z, bias=ad.bd, C2=zp, act=ad.act, M=M)
+            L.gemm_nt(z, ad.wu, h, bias=ad.bu, R1=resid, R2=resid, M=M)
+            L.gemm_nt(dense_in, w, out, bias=bias, R1=h, M=M)
+            return
         L.gemm_nt(dense_in, w, h, bias=bias, M=M)
         L.gemm_nt(h, ad.wd, z, bias=ad.bd, C2=zp, act=ad.act, M=M)
         if ad.kind == 'compacter':            # no inner residual (Downstream/CV/model/modules.py HyperComplexAdapterBlock.forward)
@@ -161,15 +169,22 @@ class ViTRecEngine(TransRecEngine):
         L.gemm_nt(n2, blk.wi, u, bias=blk.bi, C2=bufs['upre'], act=L.ACT_GELU, c2_deriv=True, M=M)
         self._vit_sub_forward(blk.ad2, u, blk.wo2, blk.bo2, bufs['x1'], bufs, '2', M, x_out)
 
-    def _vit_sub_backward(self, blk, ad, dy, bufs, k, M):
-        """dy: gradient of the sub-layer output before the residual add -> gradient of the dense output."""
+    def _vit_sub_backward(self, blk, ad, dy, bufs, k, M, x_in=None):
+        """dy: gradient of the sub-layer output before the residual add -> (gradient of the dense output, gradient that goes to
+        the residual stream: dy itself, or 2 dy + dzp Wd for the parallel form whose adapter reads the sub-layer input x_in)."""
         if ad is None:
-            return dy
+            return dy, dy
         T, H = blk.T, blk.H
         h, zp, z = bufs['h' + k], bufs['zp' + k], bufs['z' + k]
         dzp = self._buf('dzp', M, ad.dp, T)
         L.gemm_nt(dy, ad.wuT, dzp, Pre=zp, dact=ad.act, M=M)
         dh = self._buf('dh' + k, M, H, T)
+        if getattr(ad, 'parallel', False):
+            L.gemm_nt(dzp, ad.wdT, dh, R1=dy, R2=dy, M=M)
+            self._adapter_wgrads(ad, dy, z, dzp, x_in, M)
+            if ad.g_bu is not None:
+                L.colsum(dy, ad.g_bu(), M=M)
+            return dy, dh
         if ad.kind == 'compacter':
             L.gemm_nt(dzp, ad.wdT, dh, M=M)
         else:
@@ -177,7 +192,7 @@ class ViTRecEngine(TransRecEngine):
         self._adapter_wgrads(ad, dy, z, dzp, h, M)
         if ad.g_bu is not None:
             L.colsum(dy, ad.g_bu(), M=M)
-        return dh
+        return dh, dy
 
     def _vit_block_backward(self, blk, dx_out, n_items, M, bufs, dx_in, cls_rows=None):
         T, H, F = blk.T, blk.H, blk.F
@@ -185,14 +200,15 @@ class ViTRecEngine(TransRecEngine):
         M_full = M
         if cls_rows is not None:
             M = cls_rows
-        d_o = self._vit_sub_backward(blk, blk.ad2, dx_out, bufs, '2', M)
+        d_o, dres2 = self._vit_sub_backward(blk, blk.ad2, dx_out, bufs, '2', M, x_in=bufs['x1'])
         du = self._buf('du', M, F, T)
         L.gemm_nt(d_o, blk.wo2T, du, Pre=bufs['upre'], dact=L.DACT_MUL, M=M)
         dn2 = self._buf('dn', M, H, T)
         L.gemm_nt(du, blk.wiT, dn2, M=M)
         dx1 = self._buf('dx1', M, H, T)
-        L.ln_bwd(dn2, bufs['x1'], bufs['stb'], blk.lnB.gamma, dx1, M=M, dgamma=gg(blk.lnB.g_gamma), dbeta=gg(blk.lnB.g_beta), dres=dx_out)
-        da = self._vit_sub_backward(blk, blk.ad1, dx1, bufs, '1', M)
+        L.ln_bwd(dn2, bufs['x1'], bufs['stb'], blk.lnB.gamma, dx1, M=M, dgamma=gg(blk.lnB.g_gamma), dbeta=gg(blk.lnB.g_beta), dres=dres2)
+        da, dres1 = self._vit_sub_backward(blk, blk.ad1, dx1, bufs, '1', M)
+        assert dres1 is dx1              # the parallel form exists at layer.output only (run_adapter.py:448-453)
         ln_a = blk.lnA.g_gamma is not None           # --finetune_layernorm: layer 0 still owes its LN_before gradients
         if dx_in is None and not blk.lora and not ln_a:
             return

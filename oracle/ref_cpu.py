@@ -314,12 +314,14 @@ def _vit_prefix(sd):
     return 'cv_encoder.image_net.vit.' if 'cv_encoder.image_net.vit.layernorm.weight' in sd else 'cv_encoder.image_net.'
 
 
-def vit_sub_output(sd, p, h, cfg):
+def vit_sub_output(sd, p, h, cfg, inp=None):
     """(possibly wrapped) ViTSelfOutput / ViTOutput at prefix p: dense [-> adapter]; the residual is added by the caller
     (ViTLayer for attention.output, the wrapper / ViTOutput itself for output -- same sum either way)."""
     if p + 'self_output.dense.weight' in sd:
         h = linear(h, sd[p + 'self_output.dense.weight'], sd[p + 'self_output.dense.bias'])
         a = p + 'adapter.'
+        if cfg.get('is_serial', 'True') == 'None' and cfg.get('adapter_type', 'houslby') == 'houslby':
+            return h + houlsby_block(sd, a, inp, cfg)      # model.py:165-179 VITAdaptedParallelOutput: + adapter(input_tensor)
         if a + 'down_sampler.W_left' in sd:          # model.py:432-462 (HyperComplexAdapterBlock: no inner residual)
             return compacter_block(sd, a, h, cfg)
         return houlsby_block(sd, a, h, cfg)          # model.py:182-212
@@ -356,7 +358,7 @@ def vit_layer(sd, lp, x, cfg):
     x1 = vit_sub_output(sd, lp + 'attention.output.', ctx, cfg) + x
     n2 = layer_norm(x1, sd[lp + 'layernorm_after.weight'], sd[lp + 'layernorm_after.bias'], eps)
     u = gelu_erf(linear(n2, sd[lp + 'intermediate.dense.weight'], sd[lp + 'intermediate.dense.bias']))
-    return vit_sub_output(sd, lp + 'output.', u, cfg) + x1
+    return vit_sub_output(sd, lp + 'output.', u, cfg, inp=x1) + x1
 
 
 def vit_encode(sd, images, cfg, noise=None, return_all=False):

@@ -60,6 +60,7 @@ CV_VARIANT_CFG = {
     'cv_vit_pfeiffer_ver2': dict(adapter_type='pfeiffer_ver2'),
     'cv_vit_compacter': dict(adapter_type='compacter'),
     'cv_vit_cpc': dict(arch='cpc'),
+    'cv_vit_parallel': dict(is_serial='None'),
     'cv_mae_houlsby': dict(mae=True),
     'cv_vit_frozen': dict(adapter_type='none'),
 }

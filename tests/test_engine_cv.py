@@ -17,6 +17,7 @@ ARGS = {
     'cv_vit_pfeiffer_ver2': dict(adapter_type='pfeiffer_ver2'),
     'cv_vit_compacter': dict(adapter_type='compacter'),
     'cv_vit_cpc': dict(arch='cpc'),
+    'cv_vit_parallel': dict(is_serial='None'),
     'cv_mae_houlsby': dict(CV_model_load='vit-mae-base'),
     'cv_vit_frozen': dict(adding_adapter_to='None'),
 }

@@ -25,7 +25,7 @@ OUT = os.path.join(os.path.dirname(os.path.abspath(__file__)), '..', 'tests', 'g
 
 import model as refm  # noqa: E402
 from model import Model, ModelCPC  # noqa: E402
-from model.model import (VITAdaptedSelfOutput, VITAdaptedOutput, VITCompacterAdaptedSelfOutput, VITCompacterAdaptedOutput,  # noqa: E402
+from model.model import (VITAdaptedParallelOutput, SASRecParallelAdaptedSelfOutput, VITAdaptedSelfOutput, VITAdaptedOutput, VITCompacterAdaptedSelfOutput, VITCompacterAdaptedOutput,  # noqa: E402
                          SASRecAdaptedSelfOutput, SASRecPfeifferV2AdaptedSelfOutput, SASRecCompacterAdaptedSelfOutput)
 from model.modules import AdapterBlock, HyperComplexAdapterBlock  # noqa: E402
 from model.layers import PHMLinear  # noqa: E402
@@ -236,6 +236,11 @@ def inject(m, args):                   # Downstream/CV/run_adapter.py:369-447 at
         for i, blk in enumerate(blocks):
             blocks[i] = SASRecCompacterAdaptedSelfOutput(blk, args)
         m = CompacterModel(args, m)
+    elif 'houslby' in t and 'None' in args.is_serial:      # run_adapter.py:448-460
+        for lyr in layers_of(m):
+            lyr.output = wrap(VITAdaptedParallelOutput, lyr.output, AdapterBlock)
+        for i, blk in enumerate(blocks):
+            blocks[i] = SASRecParallelAdaptedSelfOutput(blk, args)
     elif 'houslby' in t:
         for lyr in layers_of(m):
             lyr.attention.output = wrap(VITAdaptedSelfOutput, lyr.attention.output, AdapterBlock)
@@ -367,9 +372,13 @@ def main():
     base_mae.eval()
     d1, d2 = check_against_installed_hf(vit, mae_net, images[:6], noise[:6])
 
-    np.savez_compressed(os.path.join(OUT, 'cv_base.npz'), images=images.numpy(), log_mask=masks.numpy(), noise=noise.numpy(),
+    if not (len(sys.argv) > 1 and sys.argv[1] == '--parallel-only'):
+      np.savez_compressed(os.path.join(OUT, 'cv_base.npz'), images=images.numpy(), log_mask=masks.numpy(), noise=noise.numpy(),
                         hf_check=np.array([d1, d2]), **{'sd/' + k: v.numpy() for k, v in base.state_dict().items()})
-    np.savez_compressed(os.path.join(OUT, 'cv_base_mae.npz'), **{'sd/' + k: v.numpy() for k, v in base_mae.state_dict().items()})
+      np.savez_compressed(os.path.join(OUT, 'cv_base_mae.npz'), **{'sd/' + k: v.numpy() for k, v in base_mae.state_dict().items()})
+    if len(sys.argv) > 1 and sys.argv[1] == '--parallel-only':      # added later: leaves the other fixtures untouched
+        run_variant('cv_vit_parallel', base, images, masks, noise, make_args(is_serial='None'))
+        return
     run_variant('cv_vit_houlsby', base, images, masks, noise, make_args())
     run_variant('cv_vit_houlsby_gelu_ln', base, images, masks, noise, make_args(adapter_activation='GELU'), layernorm=True)
     run_variant('cv_vit_pfeiffer_ver2', base, images, masks, noise, make_args(adapter_type='pfeiffer_ver2'))
