@@ -43,7 +43,7 @@ template <typename TI, typename TO, int ACT, int DACT>
 __global__ void __launch_bounds__(512, 2) gemm_nt_256_kernel(const a4r_gemm_t p, int ntm, int ntn, uint32_t thr16, float keep_scale) {
     constexpr int ROWB = 128;
     constexpr int KT = ROWB / (int)sizeof(TI);
-    constexpr bool PH2 = false, STAG = false, PIPE = true;   // schedule variants measured on MI355X and rejected
+    constexpr bool PH2 = false, STAG = false, PIPE = true, INTER = true;   // schedule variants measured on MI355X and rejected
     __shared__ __attribute__((aligned(16))) char lds[8 * UNIT_BYTES];      // [buffer 2][unit 4][128 rows][128 B]
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -124,6 +124,30 @@ __global__ void __launch_bounds__(512, 2) gemm_nt_256_kernel(const a4r_gemm_t p,
     _Pragma("unroll") for (int ni = 0; ni < 2; ++ni)                                                  \
         _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                              \
             dst_[ni][ks] = *reinterpret_cast<const uint4*>(lds + ((buf_) * 4 + (unit_)) * UNIT_BYTES + b_off[ni][ks]);
+    // INTER: the same phase with the LDS reads spread between the MFMAs (one read per MFMA pair, order pinned by sched_barrier):
+    // an MFMA holds the vector issue port for 8 of its 16 cycles, so the reads issue in its shadow instead of in front of it.
+#define A4R_MFMA_J(ax_, bx_, m0_, n0_, j_) \
+    Mma<TI>::mma(bx_[(j_) & 1][(j_) >> 3], ax_[((j_) >> 1) & 3][(j_) >> 3], acc[(m0_) + (((j_) >> 1) & 3)][(n0_) + ((j_) & 1)]);
+#define A4R_RD_I(dst_, off_, buf_, unit_, r_) \
+    dst_[(r_) >> 1][(r_) & 1] = *reinterpret_cast<const uint4*>(lds + ((buf_) * 4 + (unit_)) * UNIT_BYTES + off_[(r_) >> 1][(r_) & 1]);
+#define A4R_PHASE_I(steady_, issue_, nr_, dst_, off_, buf_, unit_, ax_, bx_, m0_, n0_)                 \
+    A4R_WAIT_BARRIER(steady_)                                                                         \
+    _Pragma("unroll") for (int k_ = 0; k_ < 8; ++k_) {                                                \
+        A4R_MFMA_J(ax_, bx_, m0_, n0_, 2 * k_)                                                        \
+        A4R_MFMA_J(ax_, bx_, m0_, n0_, 2 * k_ + 1)                                                    \
+        if (k_ == 0) { issue_ }                     /* the two LDS-DMA of this phase, behind the first MFMA pair */ \
+        if (k_ >= 1 && k_ <= 4) {                   /* all reads in the first half: the last 6 MFMAs cover their latency */ \
+            if ((nr_) == 8) { A4R_RD_I(dst_, off_, buf_, unit_, 2 * (k_ - 1)) A4R_RD_I(dst_, off_, buf_, unit_, 2 * (k_ - 1) + 1) } \
+            else { A4R_RD_I(dst_, off_, buf_, unit_, k_ - 1) }                                        \
+        }                                                                                             \
+        __builtin_amdgcn_sched_barrier(0);                                                            \
+    }
+    // cond_ (is there a next K-tile?) is deliberately ignored: on the last K-tile the reads fetch stale LDS bytes into registers
+    // that the next output tile re-reads anyway -- harmless, and it keeps ONE copy of each phase (two copies spilled).
+#define A4R_PHASE_I_A(steady_, issue_, cond_, dst_, buf_, unit_, ax_, bx_, m0_, n0_)                   \
+    A4R_PHASE_I(steady_, issue_, 8, dst_, a_off, buf_, unit_, ax_, bx_, m0_, n0_)
+#define A4R_PHASE_I_B(steady_, issue_, cond_, dst_, buf_, unit_, ax_, bx_, m0_, n0_)                   \
+    A4R_PHASE_I(steady_, issue_, 4, dst_, b_off, buf_, unit_, ax_, bx_, m0_, n0_)
 #ifndef A4R_ABL
 #define A4R_ABL 0
 #endif
@@ -190,6 +214,24 @@ __global__ void __launch_bounds__(512, 2) gemm_nt_256_kernel(const a4r_gemm_t p,
       uint4 a1[4][2];
       A4R_RD_A(af, 0, U_ALO)
       A4R_RD_B(b0, 0, U_BLO)
+      if constexpr (INTER) {
+      for (int u = 0; u < nk; u += 2) {
+        {
+            const bool steady = (u + 2 < nk);
+            A4R_PHASE_I_B(steady, A4R_ISSUE(U_AHI, u + 1, Abase, offA_hi), true, b1, 0, U_BHI, af, b0, 0, 0)
+            A4R_PHASE_I_A(steady, A4R_ISSUE(U_ALO, u + 2, Abase, offA_lo), true, a1, 0, U_AHI, af, b1, 0, 2)
+            A4R_PHASE_I_A(steady, A4R_ISSUE(U_BLO, u + 2, Bbase, offB_lo), true, af, 1, U_ALO, a1, b1, 4, 2)
+            A4R_PHASE_I_B(steady, A4R_ISSUE(U_BHI, u + 2, Bbase, offB_hi), true, b1, 1, U_BHI, a1, b0, 4, 0)
+        }
+        if (u + 1 < nk) {
+            const bool steady = (u + 3 < nk);
+            A4R_PHASE_I_B(steady, A4R_ISSUE(U_AHI, u + 2, Abase, offA_hi), true, b0, 1, U_BLO, af, b1, 0, 2)
+            A4R_PHASE_I_A(steady, A4R_ISSUE(U_ALO, u + 3, Abase, offA_lo), true, a1, 1, U_AHI, af, b0, 0, 0)
+            A4R_PHASE_I_A(steady, A4R_ISSUE(U_BHI, u + 3, Bbase, offB_hi), true, af, 0, U_ALO, a1, b0, 4, 0)
+            A4R_PHASE_I_B(steady, A4R_ISSUE(U_BLO, u + 3, Bbase, offB_lo), true, b0, 0, U_BLO, a1, b1, 4, 2)
+        }
+      }
+      } else
       for (int u = 0; u < nk; u += 2) {
         {
             const bool steady = (u + 2 < nk), nxt = (u + 1 < nk);
@@ -347,6 +389,11 @@ __global__ void __launch_bounds__(512, 2) gemm_nt_256_kernel(const a4r_gemm_t p,
 #undef A4R_RD_A
 #undef A4R_RD_B
 #undef A4R_PIPE_PHASE
+#undef A4R_PHASE_I
+#undef A4R_PHASE_I_A
+#undef A4R_PHASE_I_B
+#undef A4R_MFMA_J
+#undef A4R_RD_I
 }
 
 }  // namespace
