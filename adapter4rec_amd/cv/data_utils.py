@@ -7,7 +7,7 @@ import pickle
 import numpy as np
 import torch
 
-from ..data_utils.metrics import _inner, eval_model, eval_ranks       # noqa: F401
+from ..data_utils.metrics import _gather_shards, _inner, _my_shard, eval_model, eval_ranks       # noqa: F401
 from .image_io import RecordStore, decode_record, resize_to_square
 
 
@@ -87,9 +87,10 @@ def get_itemLMDB_embeddings(model, item_num, item_id_to_keys, test_batch_size, a
     dev = next(model.parameters()).device
     R = args.CV_resize
     out = []
+    lo, hi, chunk, world = _my_shard(item_num + 1)         # the sweep is sharded over the data-parallel ranks and all-gathered
     with torch.no_grad():
-        for s in range(0, item_num + 1, test_batch_size):
-            ids = list(range(s, min(s + test_batch_size, item_num + 1)))
+        for s in range(lo, hi, test_batch_size):
+            ids = list(range(s, min(s + test_batch_size, hi)))
             batch = torch.zeros(len(ids), R, R, 3, dtype=torch.uint8, device=dev)
             groups = {}
             for j, i in enumerate(ids):
@@ -106,4 +107,5 @@ def get_itemLMDB_embeddings(model, item_num, item_id_to_keys, test_batch_size, a
                 out.append(enc(f))
             else:
                 out.append(enc(batch))
-    return torch.cat(out, 0)
+    mine = torch.cat(out, 0) if out else torch.zeros(0, int(args.embedding_dim), device=dev)
+    return _gather_shards(mine, item_num + 1, chunk, world)

@@ -30,11 +30,35 @@ def get_item_embeddings(model, item_content, test_batch_size, args, use_modal, l
     enc = _inner(model, args).bert_encoder
     dev = next(model.parameters()).device
     content = torch.as_tensor(np.asarray(item_content)).long()
+    lo, hi, chunk, world = _my_shard(content.shape[0])
     out = []
     with torch.no_grad():
-        for i in range(0, content.shape[0], test_batch_size):
-            out.append(enc(content[i:i + test_batch_size].to(dev)))
-    return torch.cat(out, 0)
+        for i in range(lo, hi, test_batch_size):
+            out.append(enc(content[i:min(i + test_batch_size, hi)].to(dev)))
+    return _gather_shards(torch.cat(out, 0) if out else torch.zeros(0, enc_dim(model, args), device=dev), content.shape[0], chunk, world)
+
+
+def enc_dim(model, args):
+    return int(args.embedding_dim)
+
+
+def _my_shard(n):
+    """The item sweep is sharded over the data-parallel ranks (the reference encodes all N + 1 items on EVERY rank,
+    metrics.py:62-79): rank r takes rows [r * chunk, (r + 1) * chunk) and the table is all-gathered."""
+    world = dist.get_world_size() if dist.is_initialized() else 1
+    r = dist.get_rank() if dist.is_initialized() else 0
+    chunk = (n + world - 1) // world
+    return min(r * chunk, n), min((r + 1) * chunk, n), chunk, world
+
+
+def _gather_shards(mine, n, chunk, world):
+    if world == 1:
+        return mine
+    pad = torch.zeros(chunk, mine.shape[1], dtype=mine.dtype, device=mine.device)
+    pad[:mine.shape[0]] = mine
+    parts = [torch.zeros_like(pad) for _ in range(world)]
+    dist.all_gather(parts, pad)
+    return torch.cat(parts, 0)[:n].contiguous()
 
 
 def eval_ranks(model, user_history, eval_seq, item_embeddings, test_batch_size, args, user_ids):

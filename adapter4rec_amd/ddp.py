@@ -26,7 +26,9 @@ class FlatDDP(nn.Module):
             if hasattr(inner, 'invalidate_native'):
                 inner.invalidate_native()
         inner = getattr(module, 'model', module)               # CompacterModel keeps the TransRec model in .model
-        inner._a4r_ddp = self if self.world > 1 else None
+        # plain attribute, NOT a registered sub-module: nn.Module.__setattr__ would make module <-> wrapper a cycle and
+        # .train() / .eval() / .named_parameters() recurse forever on world > 1
+        object.__setattr__(inner, '_a4r_ddp', self if self.world > 1 else None)
 
     def average_(self, flat):
         """In-place mean over ranks of one flat gradient buffer (a single RCCL all-reduce)."""

@@ -21,8 +21,10 @@ def _worker(rank, world, port, out_dir):
     import sim_lib
     import adapter4rec_amd.engine as E
     import adapter4rec_amd.optim as O
+    import adapter4rec_amd.data_utils.metrics as MT
     E.L = sim_lib
     O.L = sim_lib
+    MT.L = sim_lib
     E.TransRecEngine._require_device = lambda self, p0: None
     from test_engine_host_logic import build_cpu
     from adapter4rec_amd.ddp import FlatDDP
@@ -46,8 +48,26 @@ def _worker(rank, world, port, out_dir):
     grads = {n: p.grad.clone() for n, p in model.named_parameters() if p.requires_grad}
     opt.step()
     params = {n: p.detach().clone() for n, p in model.named_parameters() if p.requires_grad}
-    torch.save(dict(loss=loss.item(), grads=grads, params=params), os.path.join(out_dir, f'r{rank}.pt'))
+    # eval: the item sweep is sharded over the two ranks and all-gathered; 101 rows = uneven shards
+    from adapter4rec_amd.data_utils.metrics import get_item_embeddings
+    g = torch.Generator().manual_seed(3)
+    content = items[torch.randint(0, items.shape[0], (101,), generator=g)]
+    table = get_item_embeddings(model, content.numpy(), 16, args, True, 'cpu')
+    import logging
+    from adapter4rec_amd.data_utils.metrics import eval_model
+    eval_seq, hist = _eval_users()
+    hit = eval_model(model, hist, eval_seq, table, 4, args, 100, logging.getLogger('ddp-test'), 'valid', 'cpu')
+    torch.save(dict(loss=loss.item(), grads=grads, params=params, table=table, content=content, hit=hit), os.path.join(out_dir, f'r{rank}.pt'))
     dist.destroy_process_group()
+
+
+def _eval_users():
+    rng = np.random.default_rng(4)
+    eval_seq, hist = {}, {}
+    for u in range(7):                                   # 7 users on 2 ranks x batch 4: SequentialDistributedSampler pads the tail
+        seq = [int(x) for x in rng.choice(np.arange(1, 101), size=int(rng.integers(3, 22)), replace=False)]
+        eval_seq[u], hist[u] = seq, torch.LongTensor(seq[:-1])
+    return eval_seq, hist
 
 
 def test_two_rank_gradient_average(tmp_path):
@@ -55,6 +75,8 @@ def test_two_rank_gradient_average(tmp_path):
     mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
     r0 = torch.load(tmp_path / 'r0.pt')
     r1 = torch.load(tmp_path / 'r1.pt')
+    assert r0['table'].shape == (101, 64)
+    torch.testing.assert_close(r0['table'], r1['table'], rtol=0, atol=0)                 # both ranks hold the whole gathered table
     for k in r0['grads']:
         torch.testing.assert_close(r0['grads'][k], r1['grads'][k], rtol=0, atol=0)       # identical averaged gradients
         torch.testing.assert_close(r0['params'][k], r1['params'][k], rtol=0, atol=0)     # replicas stay in lock-step
@@ -62,9 +84,11 @@ def test_two_rank_gradient_average(tmp_path):
     sys.path.insert(0, HERE)
     import sim_lib
     import adapter4rec_amd.engine as E
+    import adapter4rec_amd.data_utils.metrics as MT
     real_L, real_req = E.L, E.TransRecEngine._require_device
     try:
         E.L = sim_lib
+        MT.L = sim_lib
         E.TransRecEngine._require_device = lambda self, p0: None
         from test_engine_host_logic import build_cpu
         acc = None
@@ -79,5 +103,20 @@ def test_two_rank_gradient_average(tmp_path):
             acc = g if acc is None else {k: acc[k] + g[k] for k in g}
         for k in acc:
             np.testing.assert_allclose(r0['grads'][k].numpy(), (acc[k] / 2).numpy(), rtol=1e-5, atol=1e-7, err_msg=k)
+        # the sharded + gathered item table == a single-process sweep with the (identical, post-step) adapter weights
+        root, args, fx, items, mask = build_cpu('houlsby')
+        sd = root.state_dict()
+        for k, v in r0['params'].items():
+            sd[k[len('module.'):]] = v
+        root.load_state_dict(sd)
+        from adapter4rec_amd.data_utils.metrics import get_item_embeddings
+        full = get_item_embeddings(root, r0['content'].numpy(), 16, args, True, 'cpu')
+        np.testing.assert_allclose(r0['table'].numpy(), full.numpy(), rtol=0, atol=1e-6)
+        import logging
+        from adapter4rec_amd.data_utils.metrics import eval_model
+        eval_seq, hist = _eval_users()
+        hit1 = eval_model(root, hist, eval_seq, full, 4, args, 100, logging.getLogger('ddp-test'), 'valid', 'cpu')
+        assert r0['hit'] == r1['hit'] == hit1            # users sharded over ranks, Hit/nDCG gathered: same mean as one process
     finally:
         E.L, E.TransRecEngine._require_device = real_L, real_req
+        MT.L = real_L
