@@ -43,9 +43,16 @@ def load_backbone(args, Log_file):
     else:
         Log_file.info(f'{path} holds no weights: random-init {family} backbone from config.json')
         model = BertBackbone.from_config_json(os.path.join(path, 'config.json'))
+    pooler_para = []
     for key, dim in DIMS.items():
         if key in args.bert_model_load:
             args.word_embedding_dim = dim
+            n_layers = {'tiny': 2, 'mini': 4, 'medium': 8, 'base': 12, 'large': 24}[key]
+            pooler_para = [5 + 16 * n_layers, 6 + 16 * n_layers]          # run.py:302-316: [37,38] tiny ... [197,198] base
+    # run.py:317-319: the first --freeze_paras_before backbone tensors (and the pooler) never train, whatever --fine_tune_to says
+    for index, (_, p) in enumerate(model.named_parameters()):
+        if index < args.freeze_paras_before or index in pooler_para:
+            p.requires_grad = False
     return tok, model
 
 
