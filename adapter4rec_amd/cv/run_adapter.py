@@ -62,8 +62,8 @@ def build_model(args, item_num, use_modal, cv_model, local_rank, Log_file, model
     if 'None' not in args.pretrained_recsys_model:                    # :341-350
         ckpt = torch.load(get_checkpoint('../pretrained_models/', args.pretrained_recsys_model), map_location='cpu')
         model.load_state_dict(ckpt['model_state_dict'])
-    if 'all' in args.fine_tune_to:
-        raise NotImplementedError('--fine_tune_to all on the image tower is not wired natively (text tower only)')
+    if 'all' in args.fine_tune_to:                                    # Downstream/CV/run.py: end-to-end fine-tuning (ViT, not ViT-MAE)
+        pass
     elif 'None' in args.fine_tune_to:
         freeze_all(model)
     else:

@@ -128,16 +128,18 @@ class _Dense:
     Trainable (--fine_tune_to all, Pretraining/): the copies are re-packed from the flat fp32 master every step and g_w / g_b
     receive dW = dY^T X (a4r_gemm_tn) and db = column sums of dY (a4r_colsum)."""
 
-    def __init__(self, eng, weight, bias, dt, w_dst=None, wT_dst=None, b_dst=None):
-        out_f, in_f = weight.shape
+    def __init__(self, eng, weight, bias, dt, w_dst=None, wT_dst=None, b_dst=None, view2d=None):
+        out_f, in_f = view2d if view2d is not None else weight.shape          # view2d: a Conv2d weight seen as [out, C*kh*kw]
+        self.view2d = view2d
         self.w = w_dst if w_dst is not None else torch.zeros(out_f, in_f, dtype=dt, device=eng.dev)
         self.wT = wT_dst if wT_dst is not None else torch.zeros(in_f, out_f, dtype=dt, device=eng.dev)
         if weight.requires_grad:
             eng.add_pack(weight, self.w, False)
             eng.add_pack(weight, self.wT, True)
         else:
-            self.w.copy_(weight.detach().to(dt))
-            self.wT.copy_(weight.detach().t().to(dt))
+            w2 = weight.detach().reshape(out_f, in_f)
+            self.w.copy_(w2.to(dt))
+            self.wT.copy_(w2.t().to(dt))
         self.g_w = eng.grad_view(weight)
         self.b = self.g_b = None
         if bias is not None:
@@ -246,7 +248,7 @@ class TransRecEngine:
             arr = (L.PackDesc * len(entries))()
             mx = 0
             for i, (p, dst, tr) in enumerate(entries):
-                rows, cols = (p.shape[0], p.shape[1]) if p.dim() == 2 else (1, p.shape[0])
+                rows, cols = (p.shape[0], p[0].numel()) if p.dim() >= 2 else (1, p.shape[0])
                 rp, cp = (dst.shape[0], dst.shape[1]) if dst.dim() == 2 else (1, dst.shape[0])
                 off = self.offsets[id(p)][0] if frozen_src is None else frozen_src[i]
                 ld = dst.stride(0) if dst.dim() == 2 and dst.stride(0) != cp else 0      # column block of a fused operand

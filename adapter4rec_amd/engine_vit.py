@@ -21,7 +21,7 @@ import math
 import torch
 
 from . import _lib as L
-from .engine import TransRecEngine, _Adapter, _Block, _LN, _Lora, pad_to
+from .engine import TransRecEngine, _Adapter, _Block, _Dense, _LN, _Lora, pad_to
 from .cv.vit import vit_geometry
 from .model.modules import AdapterBlock, HyperComplexAdapterBlock
 
@@ -50,13 +50,16 @@ class ViTRecEngine(TransRecEngine):
             raise NotImplementedError(f'{self.S} tokens per image (attention kernel: <= 256)')
         emb = core.embeddings
         proj = emb.patch_embeddings.projection
-        for p in (emb.cls_token, emb.position_embeddings, proj.weight, proj.bias):
-            if p.requires_grad:
-                raise NotImplementedError('training the ViT embeddings (--fine_tune_to all) is not wired natively')
-        self.patch_w = self._w(proj.weight.reshape(H, -1))                  # [H, C*P*P], Conv2d column order
-        self.patch_b = self._f32(proj.bias)
-        self.cls_tok = self._f32(emb.cls_token.reshape(H))
-        self.pos_tab = self._f32(emb.position_embeddings.reshape(self.NP + 1, H))
+        # Conv2d weight [H, C, P, P] is [H, C*P*P] in memory: the flat fp32 master is packed as that matrix when trainable
+        self.d_patch = _Dense(self, proj.weight, proj.bias, self.T, view2d=(H, self.C * self.P * self.P))
+        self.patch_w, self.patch_b = self.d_patch.w, self.d_patch.b
+        tab = lambda p: p.data if p.requires_grad else self._f32(p)
+        self.cls_tok = tab(emb.cls_token).reshape(H)
+        self.pos_tab = tab(emb.position_embeddings).reshape(self.NP + 1, H)
+        self.g_cls, self.g_postab = self.grad_view(emb.cls_token), self.grad_view(emb.position_embeddings)
+        self.train_emb = self.d_patch.trainable or self.g_cls is not None or self.g_postab is not None
+        if self.train_emb and self.mae:
+            raise NotImplementedError('training the ViT-MAE embedding side (--fine_tune_to all) is not wired natively')
         self.next_noise = None
         self.bert_blocks = []
         for i, layer in enumerate(core.encoder.layer):
@@ -70,26 +73,37 @@ class ViTRecEngine(TransRecEngine):
                     raise NotImplementedError(f'projection module {type(lin).__name__}')
             b.H, b.F, b.nh, b.dh, b.S = H, self.F, nh, 64, self.S
             b.scale = 1.0 / math.sqrt(64)
-            b.wqkv = self._w(torch.cat([att.query.weight, att.key.weight, att.value.weight], 0))
-            b.wqkvT = b.wqkv.t().contiguous()
-            b.bqkv = self._f32(torch.cat([att.query.bias, att.key.bias, att.value.bias], 0))
+            b.wqkv = torch.zeros(3 * H, H, dtype=self.T, device=self.dev)
+            b.wqkvT = torch.zeros(H, 3 * H, dtype=self.T, device=self.dev)
+            b.bqkv = torch.zeros(3 * H, dtype=torch.float32, device=self.dev)
+            b.qkv = tuple(None if type(lin).__name__ == 'LoRALinear' else
+                          _Dense(self, lin.weight, lin.bias, self.T, b.wqkv[sl * H:(sl + 1) * H], b.wqkvT[:, sl * H:(sl + 1) * H],
+                                 b.bqkv[sl * H:(sl + 1) * H])
+                          for sl, lin in enumerate((att.query, att.key, att.value)))
             d1, b.ad1 = self._vit_so(layer.attention.output)
             d2, b.ad2 = self._vit_so(layer.output)
-            b.wo, b.woT, b.bo = self._w(d1.weight), self._wT(d1.weight), self._f32(d1.bias)
-            b.wi, b.wiT, b.bi = (self._w(layer.intermediate.dense.weight), self._wT(layer.intermediate.dense.weight),
-                                 self._f32(layer.intermediate.dense.bias))
-            b.wo2, b.wo2T, b.bo2 = self._w(d2.weight), self._wT(d2.weight), self._f32(d2.bias)
+            b.d_o = _Dense(self, d1.weight, d1.bias, self.T)
+            b.d_i = _Dense(self, layer.intermediate.dense.weight, layer.intermediate.dense.bias, self.T)
+            b.d_o2 = _Dense(self, d2.weight, d2.bias, self.T)
+            b.wo, b.woT, b.bo = b.d_o.w, b.d_o.wT, b.d_o.b
+            b.wi, b.wiT, b.bi = b.d_i.w, b.d_i.wT, b.d_i.b
+            b.wo2, b.wo2T, b.bo2 = b.d_o2.w, b.d_o2.wT, b.d_o2.b
+            b.train_dense = any(d is not None and d.trainable for d in b.qkv + (b.d_o, b.d_i, b.d_o2))
             b.lnA, b.lnB = _LN(layer.layernorm_before, self), _LN(layer.layernorm_after, self)
-            b.need_dx = i > 0
+            b.need_dx = i > 0 or self.train_emb
             b.T = self.T
             self.bert_blocks.append(b)
         self.vit_ln = _LN(core.layernorm, self)
         fc = enc.cv_proj if self.mae else net.classifier
-        if fc.weight.requires_grad or self.E % 64 or fc.out_features != self.E:
-            raise NotImplementedError('item head: frozen classifier / cv_proj with embedding_dim % 64 == 0')
-        self.fc_w = self._w(fc.weight)
-        self.fc_wT32 = self._wT(fc.weight, torch.float32)
-        self.fc_b = self._f32(fc.bias)
+        if self.E % 64 or fc.out_features != self.E:
+            raise NotImplementedError('item head: classifier / cv_proj with embedding_dim % 64 == 0')
+        self.d_fc = _Dense(self, fc.weight, fc.bias, self.T)
+        self.fc_w, self.fc_b = self.d_fc.w, self.d_fc.b
+        self.fc_wT32 = torch.zeros(fc.in_features, fc.out_features, dtype=torch.float32, device=self.dev)
+        if fc.weight.requires_grad:
+            self.add_pack(fc.weight, self.fc_wT32, True)
+        else:
+            self.fc_wT32.copy_(fc.weight.detach().t().float())
         self.cls_only = bool(getattr(self.args, 'cls_only_last', True))      # last layer: only the CLS rows go past attention
 
     def _vit_so(self, mod):
@@ -113,7 +127,7 @@ class ViTRecEngine(TransRecEngine):
         d = {}
         if not shared:
             d['x0'] = self._buf(pre + '.x0', M, H, T)                      # the layer input (LN_before backward needs it)
-        if blk.lora and not shared:
+        if (blk.lora or blk.train_dense) and not shared:
             d['n1'] = self._buf(pre + '.n1', M, H, T)
         d['sta'] = self._buf(pre + '.sta', M, 2, torch.float32)
         d['qkv'] = self._buf(pre + '.qkv', M, 3 * H, T)
@@ -121,6 +135,10 @@ class ViTRecEngine(TransRecEngine):
         if Mc is not None:                   # last layer in CLS-only mode: everything after attention has Mc rows
             pre, M = pre + '.cls', Mc
         d['x1'] = self._buf(pre + '.x1', M, H, T)
+        if blk.train_dense and not shared:       # inputs of the trainable Linears (weight gradients, --fine_tune_to all)
+            d['ctx_s'] = self._buf(pre + '.ctx_s', M, H, T)
+            d['n2_s'] = self._buf(pre + '.n2_s', M, H, T)
+            d['u_s'] = self._buf(pre + '.u_s', M, F, T)
         d['stb'] = self._buf(pre + '.stb', M, 2, torch.float32)
         d['upre'] = self._buf(pre + '.upre', M, F, T)
         for k, ad in (('1', blk.ad1), ('2', blk.ad2)):
@@ -162,10 +180,12 @@ class ViTRecEngine(TransRecEngine):
             L.gather_rows(ctx, ctx_c, n_items, blk.S)
             L.gather_rows(x, x_c, n_items, blk.S)
             ctx, x, M = ctx_c, x_c, cls_rows
+        if 'ctx_s' in bufs:
+            bufs['ctx_s'][:M].copy_(ctx[:M])
         self._vit_sub_forward(blk.ad1, ctx, blk.wo, blk.bo, x, bufs, '1', M, bufs['x1'])
-        n2 = self._buf('n2', M, H, T)
+        n2 = bufs['n2_s'] if 'n2_s' in bufs else self._buf('n2', M, H, T)
         L.ln_fwd(bufs['x1'], blk.lnB.gamma, blk.lnB.beta, blk.lnB.eps, n2, bufs['stb'], M=M)
-        u = self._buf('u', M, blk.F, T)
+        u = bufs['u_s'] if 'u_s' in bufs else self._buf('u', M, blk.F, T)
         L.gemm_nt(n2, blk.wi, u, bias=blk.bi, C2=bufs['upre'], act=L.ACT_GELU, c2_deriv=True, M=M)
         self._vit_sub_forward(blk.ad2, u, blk.wo2, blk.bo2, bufs['x1'], bufs, '2', M, x_out)
 
@@ -201,16 +221,20 @@ class ViTRecEngine(TransRecEngine):
         if cls_rows is not None:
             M = cls_rows
         d_o, dres2 = self._vit_sub_backward(blk, blk.ad2, dx_out, bufs, '2', M, x_in=bufs['x1'])
+        self._dense_wgrad(blk.d_o2, d_o, bufs.get('u_s'), M)
         du = self._buf('du', M, F, T)
         L.gemm_nt(d_o, blk.wo2T, du, Pre=bufs['upre'], dact=L.DACT_MUL, M=M)
+        self._dense_wgrad(blk.d_i, du, bufs.get('n2_s'), M)
         dn2 = self._buf('dn', M, H, T)
         L.gemm_nt(du, blk.wiT, dn2, M=M)
         dx1 = self._buf('dx1', M, H, T)
         L.ln_bwd(dn2, bufs['x1'], bufs['stb'], blk.lnB.gamma, dx1, M=M, dgamma=gg(blk.lnB.g_gamma), dbeta=gg(blk.lnB.g_beta), dres=dres2)
         da, dres1 = self._vit_sub_backward(blk, blk.ad1, dx1, bufs, '1', M)
         assert dres1 is dx1              # the parallel form exists at layer.output only (run_adapter.py:448-453)
+        self._dense_wgrad(blk.d_o, da, bufs.get('ctx_s'), M)
         ln_a = blk.lnA.g_gamma is not None           # --finetune_layernorm: layer 0 still owes its LN_before gradients
-        if dx_in is None and not blk.lora and not ln_a:
+        qkv_train = any(d is not None and d.trainable for d in blk.qkv)
+        if dx_in is None and not blk.lora and not ln_a and not qkv_train:
             return
         dctx = self._buf('dctx_c' if cls_rows is not None else 'dctx', M, H, T)
         L.gemm_nt(da, blk.woT, dctx, M=M)
@@ -229,6 +253,8 @@ class ViTRecEngine(TransRecEngine):
         L.attn_long_bwd(bufs['qkv'], dctx, dqkv, bufs['lse'], ws, n_items, blk.S, blk.nh, blk.dh, 0, H, 2 * H, blk.scale)
         for lo in blk.lora:
             self._lora_backward(blk, lo, dqkv, bufs['n1'], M)
+        for sl, d in enumerate(blk.qkv):
+            self._dense_wgrad(d, dqkv[:, sl * H:(sl + 1) * H], bufs.get('n1'), M)
         if dx_in is not None or ln_a:
             if dx_in is None:
                 dx_in = self._buf('dx_unused', M, H, T)
@@ -299,6 +325,11 @@ class ViTRecEngine(TransRecEngine):
         L.act_bwd_f32(d_emb, c['pre'], d_pre, L.ACT_GELU)
         dcln = self._buf('dcls_n', Ip, H, self.T)
         L.gemm_nt(d_pre, self.fc_wT32, dcln, M=Ip)
+        if self.d_fc.trainable:
+            if self.d_fc.g_w is not None:
+                L.gemm_tn(d_pre if self.T == torch.float32 else d_pre.to(self.T), self._buf('cls_n', Ip, H, self.T), self.d_fc.g_w(), M=Ip)
+            if self.d_fc.g_b is not None:
+                L.colsum(d_pre, self.d_fc.g_b(), M=Ip)
         dcls = self._buf('dcls', Ip, H, self.T)
         L.ln_bwd(dcln, self._buf('cls', Ip, H, self.T), self._cls_st, self.vit_ln.gamma, dcls, M=Ip,
                  dgamma=gg(self.vit_ln.g_gamma), dbeta=gg(self.vit_ln.g_beta))
@@ -315,6 +346,22 @@ class ViTRecEngine(TransRecEngine):
             else:
                 self._vit_block_backward(blk, dxb, n_items, M, c['saved_b'][i], spare if blk.need_dx else None)
             dxb, spare = spare, dxb
+        if self.train_emb:                       # ViTEmbeddings backward: token 0 -> cls + pos[0]; token 1 + j -> patch projection + pos[1 + j]
+            S, NP = self.S, self.NP
+            d3 = dxb[:n_items * S].view(n_items, S, H)
+            if self.g_postab is not None:
+                self.g_postab().view(NP + 1, H).add_(d3.float().sum(0))
+            if self.g_cls is not None:
+                self.g_cls().view(H).add_(d3[:, 0].float().sum(0))
+            if self.d_patch.trainable:
+                Mp = pad_to(n_items * NP, 256)
+                dpe = self._buf('d_patch_emb', Mp, H, self.T)
+                dpe[:n_items * NP].copy_(d3[:, 1:].reshape(n_items * NP, H))
+                dpe[n_items * NP:].zero_()
+                if self.d_patch.g_w is not None:
+                    L.gemm_tn(dpe, self._buf('patches', Mp, self.C * self.P * self.P, self.T), self.d_patch.g_w().view(H, -1), M=Mp)
+                if self.d_patch.g_b is not None:
+                    L.colsum(dpe, self.d_patch.g_b(), M=Mp)
 
     # ------------------------------------------------------------------ public: inference
     @torch.no_grad()

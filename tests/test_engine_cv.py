@@ -197,3 +197,39 @@ def test_cv_patchify_u8_matches_float():
         refk = torch.nn.functional.unfold(f, 8, stride=8).transpose(1, 2)
         refk = torch.gather(refk, 1, keep.long()[:, :, None].expand(-1, -1, 192)).reshape(-1, 192)
         torch.testing.assert_close(c[:20].float().cpu(), refk.to(dt).float(), atol=0, rtol=0)
+
+
+def build_cv_finetune_all(device='cpu', dtype='fp32'):
+    """--fine_tune_to all on the image path (Downstream/CV/run.py: the end-to-end fine-tuning baseline): nothing frozen."""
+    from adapter4rec_amd.cv import Model, ViTForImageClassification
+    sd, cfg, fx, _, (images, mask), _ = load_cv_variant('cv_vit_frozen')
+    args = make_args(compute_dtype=dtype, adding_adapter_to='None')
+    model = Model(args, 60, True, ViTForImageClassification(GEOM))
+    model.load_state_dict({str(k): sd[strip(str(k))] for k in fx['all_keys']}, strict=True)
+    for p in model.parameters():
+        p.requires_grad = True
+    model.eval()
+    return model.to(device), sd, dict(cfg, adapter_type='none'), images.to(device), mask.to(device)
+
+
+def _check_all_grads(model, sd, cfg, images, mask, dev):
+    from oracle import ref_cpu as R
+    names = [n for n, p in model.named_parameters() if p.requires_grad]
+    assert any('patch_embeddings.projection.weight' in n for n in names) and any('position_embeddings' in n for n in names)
+    out, grads = R.loss_and_grads(sd, names, images.cpu(), mask.cpu(), cfg)
+    loss = model(images, mask, dev)
+    loss.backward()
+    assert abs(loss.item() - float(out['loss'].detach())) < 1e-4 * max(1.0, float(out['loss'].detach()))
+    params = dict(model.named_parameters())
+    for n in names:
+        ref = grads[n].numpy()
+        np.testing.assert_allclose(params[n].grad.cpu().numpy(), ref, atol=1e-6 + 1e-4 * np.abs(ref).max(), rtol=0, err_msg=n)
+
+
+def test_cv_host_logic_finetune_all(simulated):
+    _check_all_grads(*build_cv_finetune_all(), 'cpu')
+
+
+@pytest.mark.gpu
+def test_cv_finetune_all_fp32_vs_oracle():
+    _check_all_grads(*build_cv_finetune_all(device='cuda:0'), 'cuda:0')
