@@ -368,14 +368,30 @@ class TransRecEngine:
             raise NotImplementedError(f'encoder geometry H={H} F={self.F} heads={nh} S={self.S}')
         emb = bert.embeddings
         tab = lambda p: p.data if p.requires_grad else self._f32(p)        # trainable tables are read from the flat fp32 master
-        self.emb_word, self.emb_pos = tab(emb.word_embeddings.weight), tab(emb.position_embeddings.weight)
+        wemb = emb.word_embeddings
+        self.prompt_n, self.g_prompt = 0, None
+        if type(wemb).__name__ == 'SoftEmbedding':      # soft prompt (model.py:586-630): rows V .. V+n-1 of an extended table hold the
+            if g['model_type'] == 'roberta':            # learned vectors and the first n ids of every title are redirected to them
+                raise NotImplementedError('soft prompt on RoBERTa (position ids are derived from the replaced token ids)')
+            self.prompt_n = int(wemb.n_tokens)
+            if self.prompt_n > self.S:
+                raise ValueError(f'--n_tokens {self.prompt_n} exceeds the title length {self.S}')
+            self.prompt_param = wemb.learned_embedding
+            self.g_prompt = self.grad_view(wemb.learned_embedding)
+            wemb = wemb.wte
+            if wemb.weight.requires_grad:
+                raise NotImplementedError('soft prompt together with a trainable vocabulary table')
+            V = wemb.weight.shape[0]
+            self.prompt_V = V
+            self.emb_word_ext = torch.cat([self._f32(wemb.weight), torch.zeros(self.prompt_n, H, device=self.dev)], 0)
+        self.emb_word, self.emb_pos = tab(wemb.weight), tab(emb.position_embeddings.weight)
         self.emb_type = tab(emb.token_type_embeddings.weight)
         self.emb_type0 = self.emb_type[0]
         self.emb_ln = _LN(emb.LayerNorm, self)
-        self.g_word, self.g_pos = self.grad_view(emb.word_embeddings.weight), self.grad_view(emb.position_embeddings.weight)
+        self.g_word, self.g_pos = self.grad_view(wemb.weight), self.grad_view(emb.position_embeddings.weight)
         self.g_type = self.grad_view(emb.token_type_embeddings.weight)
-        # --finetune_layernorm (run.py:496-501) / --fine_tune_to all: the embedding side needs its input gradient
-        self.train_emb = any(f is not None for f in (self.g_word, self.g_pos, self.g_type, self.emb_ln.g_gamma, self.emb_ln.g_beta))
+        # --finetune_layernorm (run.py:496-501) / --fine_tune_to all / soft prompt: the embedding side needs its input gradient
+        self.train_emb = any(f is not None for f in (self.g_word, self.g_pos, self.g_type, self.emb_ln.g_gamma, self.emb_ln.g_beta, self.g_prompt))
         if getattr(bert, 'pooler', None) is not None:                       # never on the forward path ([0][:, 0], encoders.py:55): zero gradient
             for p in bert.pooler.parameters():
                 self.grad_view(p)
@@ -749,7 +765,14 @@ class TransRecEngine:
         key_mask.copy_(news[:, S:2 * S])
         x = self._buf('xa', M, H, self.T)
         keep = self.train_emb and saved is not None
-        L.embed_ln(news, self.emb_word, self.emb_pos, self.emb_type0, self.emb_ln.gamma, self.emb_ln.beta, self.emb_ln.eps,
+        word = self.emb_word
+        if self.prompt_n:                          # refresh the learned rows, point the first n ids of every title at them
+            n, V = self.prompt_n, self.prompt_V
+            word = self.emb_word_ext
+            word[V:V + n].copy_(self.prompt_param.detach())
+            news = news.clone()
+            news[:, :n] = torch.arange(V, V + n, device=news.device)
+        L.embed_ln(news, word, self.emb_pos, self.emb_type0, self.emb_ln.gamma, self.emb_ln.beta, self.emb_ln.eps,
                    x, n_items, S, roberta=self.roberta, pad_id=self.pad_id,
                    drop_p=self.p_hidden if train else 0.0, drop_site=999, drop_seed=seed,
                    pre_out=self._buf('emb_pre', M, H, self.T) if keep else None,
@@ -934,6 +957,8 @@ class TransRecEngine:
             L.ln_bwd(dxb, self._buf('emb_pre', M, self.H, self.T), self._buf('emb_st', M, 2, torch.float32), self.emb_ln.gamma, dpre, M=M,
                      dgamma=gg(self.emb_ln.g_gamma), dbeta=gg(self.emb_ln.g_beta),
                      drop_p=self.p_hidden if train else 0.0, drop_site=999, drop_seed=seed)
+            if self.g_prompt is not None:          # d learned_embedding[t] = sum over items of the token-t rows
+                self.g_prompt().add_(dpre[:n_items * self.S].view(n_items, self.S, self.H)[:, :self.prompt_n].float().sum(0))
             if self.g_word is not None or self.g_pos is not None:
                 L.embed_bwd(self._news, dpre, gg(self.g_word), gg(self.g_pos), n_items, self.S, roberta=self.roberta, pad_id=self.pad_id)
             if self.g_type is not None:

@@ -30,8 +30,13 @@ def inject_adapters(model, args):
             lyr.output = BertPfeifferAdaptedSelfOutput(lyr.output, args)
         for i, blk in enumerate(blocks):
             blocks[i] = SASRecPfeifferAdaptedSelfOutput(blk, args)
-    elif 'kadapter' in t or 'prompt' in t:
-        raise NotImplementedError(f'--adapter_type {t}: K-Adapter / soft prompt are outside the BASELINE configs (SURVEY.md 2.1 rows 13-14)')
+    elif 'kadapter' in t:
+        raise NotImplementedError(f'--adapter_type {t}: K-Adapter is not wired natively (its 2-block transformers run at head widths 16 / 8, '
+                                  'which the attention kernels do not cover)')
+    elif 'prompt' in t:                                 # run.py:429-434
+        from .model.model import SoftEmbedding
+        bm = model.bert_encoder.text_encoders['title'].bert_model
+        bm.set_input_embeddings(SoftEmbedding(bm.get_input_embeddings(), n_tokens=args.n_tokens, initialize_from_vocab=True))
     elif 'lora' in t:                                   # run.py:414-428: fresh lora.Linear modules replace q, v / w_Q, w_V
         from .model.lora import LoRALinear
         h = model.bert_encoder.text_encoders['title'].fc.in_features

@@ -3,7 +3,7 @@ from .encoders import Bert_Encoder, Text_Encoder, User_Encoder
 from .model import (Model, ModelCPC, CompacterModel, BertAdaptedSelfOutput, BertAdaptedParallelSelfOutput,
                     BertPfeifferAdaptedSelfOutput, BertCompacterAdaptedSelfOutput, SASRecAdaptedSelfOutput,
                     SASRecParallelAdaptedSelfOutput, SASRecPfeifferAdaptedSelfOutput,
-                    SASRecPfeifferVer2AdaptedSelfOutput, SASRecCompacterAdaptedSelfOutput)
+                    SASRecPfeifferVer2AdaptedSelfOutput, SASRecCompacterAdaptedSelfOutput, SoftEmbedding)
 from .modules import (AdapterBlock, AdapterPfeifferBlock, HyperComplexAdapterBlock, PHMLinear, TransformerBlock,
                       TransformerEncoder, MultiHeadedAttention, PositionwiseFeedForward)
 from .lora import LoRALinear

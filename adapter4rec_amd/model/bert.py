@@ -110,6 +110,12 @@ class BertBackbone(_Container):
                     with torch.no_grad():
                         m.weight[m.padding_idx].zero_()
 
+    def get_input_embeddings(self):              # HF API used by the soft-prompt injection (run.py:429-434)
+        return self.embeddings.word_embeddings
+
+    def set_input_embeddings(self, value):
+        self.embeddings.word_embeddings = value
+
     @classmethod
     def from_config_json(cls, path):
         import json

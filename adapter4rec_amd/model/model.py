@@ -110,6 +110,20 @@ class CompacterModel(nn.Module):        # Downstream/Text/run.py:70-83
         return self.model(sample_items, log_mask, local_rank)
 
 
+class SoftEmbedding(_Container):                # model.py:586-630 (soft prompt)
+    """Replaces the backbone's word embedding: the first ``n_tokens`` word vectors of every title are the rows of
+    ``learned_embedding`` (initialised from the first vocabulary rows), the rest are ``wte`` look-ups of tokens[:, n_tokens:]."""
+
+    def __init__(self, wte, n_tokens=100, random_range=0.5, initialize_from_vocab=True):
+        super().__init__()
+        self.wte, self.n_tokens = wte, n_tokens
+        if initialize_from_vocab:
+            init = wte.weight[:n_tokens].clone().detach()
+        else:
+            init = torch.empty(n_tokens, wte.weight.size(1)).uniform_(-random_range, random_range)
+        self.learned_embedding = nn.Parameter(init)
+
+
 # ---------------------------------------------------------------- BERT-side wrappers
 class BertAdaptedSelfOutput(_Container):            # model.py:273-297 (Houlsby, serial)
     placement = 'serial'

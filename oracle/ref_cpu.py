@@ -126,7 +126,13 @@ def position_ids(ids, cfg):
 
 def bert_embed(sd, ids, cfg):
     e = BERT + 'embeddings.'
-    x = sd[e + 'word_embeddings.weight'][ids] + sd[e + 'position_embeddings.weight'][position_ids(ids, cfg)] \
+    if e + 'word_embeddings.learned_embedding' in sd:      # soft prompt, model/model.py:586-630 SoftEmbedding: the first n_tokens
+        le = sd[e + 'word_embeddings.learned_embedding']    # word vectors of every title are REPLACED by the learned rows
+        n = le.shape[0]
+        w = torch.cat([le.unsqueeze(0).expand(ids.shape[0], -1, -1), sd[e + 'word_embeddings.wte.weight'][ids[:, n:]]], 1)
+    else:
+        w = sd[e + 'word_embeddings.weight'][ids]
+    x = w + sd[e + 'position_embeddings.weight'][position_ids(ids, cfg)] \
         + sd[e + 'token_type_embeddings.weight'][0]
     return layer_norm(x, sd[e + 'LayerNorm.weight'], sd[e + 'LayerNorm.bias'], cfg['bert_ln_eps'])
 

@@ -75,6 +75,10 @@ def inject(model, args):
     t = args.adapter_type
     if t == 'none':
         return model
+    if 'prompt' in t:                       # run.py:429-434
+        bm = model.bert_encoder.text_encoders.title.bert_model
+        bm.set_input_embeddings(refm.model.SoftEmbedding(bm.get_input_embeddings(), n_tokens=args.n_tokens, initialize_from_vocab=True))
+        return model
     if 'pfeiffer_ver2' in t:
         for lyr in layers:
             lyr.attention.output = BertAdaptedSelfOutput(lyr.attention.output, args)
@@ -112,7 +116,7 @@ def base_name(k):
     """adapted state_dict key -> key of the un-adapted model that holds the same tensor."""
     if k.startswith('model.'):
         k = k[len('model.'):]
-    return k.replace('.self_output.', '.').replace('.transformer_block.', '.')
+    return k.replace('.self_output.', '.').replace('.transformer_block.', '.').replace('.word_embeddings.wte.', '.word_embeddings.')
 
 
 def make_content(rng, n_items, roberta=False):
@@ -182,7 +186,7 @@ def run_variant(name, base_model, content, items, masks, args, hidden_dump=False
     # every trainable tensor has a non-trivial value and gradient.
     with torch.no_grad():
         for n_, p in m.named_parameters():
-            if p.requires_grad and ('adapter' in n_ or n_.endswith('phm_rule') or n_.startswith('LN') or '.LN.' in n_):
+            if p.requires_grad and ('adapter' in n_ or n_.endswith('phm_rule') or n_.startswith('LN') or '.LN.' in n_ or 'learned_embedding' in n_):
                 p.add_(0.05 * torch.randn_like(p))
     m.eval()
     inner = m.model if isinstance(m, CompacterModel) else m
@@ -313,6 +317,14 @@ def main():
                      intermediate_size=FFN, max_position_embeddings=MAXPOS, attn_implementation='eager')
     args = make_args()
     base = Model(args, ITEM_NUM, True, BertModel(cfg))
+    if len(sys.argv) > 2 and sys.argv[1] == '--only':        # later additions: rebuild the base from base.npz, write ONE new fixture
+        fx = np.load(os.path.join(OUT, 'base.npz'))
+        base.load_state_dict({k[3:]: torch.from_numpy(fx[k]) for k in fx.files if k.startswith('sd/')})
+        base.eval()
+        items, masks = torch.from_numpy(fx['sample_items']), torch.from_numpy(fx['log_mask'])
+        if sys.argv[2] == 'prompt':
+            run_variant('prompt', base, fx['item_content'], items, masks, make_args(adapter_type='prompt', n_tokens=8))
+        return
     # HF inits LayerNorm to (1, 0) and biases to 0; jitter so that those terms are exercised
     with torch.no_grad():
         for n_, p in base.named_parameters():
