@@ -36,6 +36,43 @@ class BuildTrainDataset(Dataset):
         return torch.LongTensor(ids), torch.FloatTensor(log_mask)
 
 
+class DeviceTrainSampler:
+    """Device-side replacement of BuildTrainDataset + DataLoader for throughput runs ("a device-side sampler may
+    replace it -- distribution pinned, not bit-pinned"): all user sequences live on the GPU as one left-padded [U, L] table, a batch
+    is a gather + one vectorised rejection loop.  Same distribution as dataset.py:24-49: one negative per real position, uniform over
+    1..item_num minus the user's own sequence; negatives row = [0]*pad + negs + [0]; log_mask = [0]*pad + [1]*(len - 1).
+    ``sample(user_ids)`` -> (item_content[ids] [B*L*2, 2*words] int64, log_mask [B, L-1] fp32), both on the device."""
+
+    def __init__(self, u2seq, item_content, item_num, max_seq_len, device, seed=0):
+        self.L, self.item_num, self.device = max_seq_len + 1, item_num, torch.device(device)
+        users = sorted(u2seq)
+        tab = np.zeros((len(users), self.L), dtype=np.int64)
+        for r, u in enumerate(users):
+            seq = list(u2seq[u])
+            tab[r, self.L - len(seq):] = seq
+        self.row_of = {u: r for r, u in enumerate(users)}
+        self.seqs = torch.from_numpy(tab).to(self.device)
+        self.content = torch.as_tensor(np.asarray(item_content)).long().to(self.device)
+        self.gen = torch.Generator(device=self.device)
+        self.gen.manual_seed(seed)
+
+    def sample(self, user_ids):
+        rows = torch.as_tensor([self.row_of[int(u)] for u in user_ids], device=self.device)
+        seq = self.seqs[rows]                                              # [B, L], 0 = pad
+        valid = seq != 0
+        log_mask = (valid[:, :-1] & valid[:, 1:]).float()                 # positions that have an input AND a target
+        need = torch.cat([valid[:, 1:], torch.zeros_like(valid[:, :1])], 1) & valid        # every real slot except the last one
+        neg = torch.randint(1, self.item_num + 1, seq.shape, device=self.device, generator=self.gen)
+        for _ in range(64):                                                # rejection: redraw the slots that hit the user's own items
+            clash = (neg.unsqueeze(2) == seq.unsqueeze(1)).any(2) & need
+            if not bool(clash.any()):
+                break
+            neg = torch.where(clash, torch.randint(1, self.item_num + 1, seq.shape, device=self.device, generator=self.gen), neg)
+        neg = torch.where(need, neg, torch.zeros_like(neg))
+        ids = torch.stack([seq, neg], 2).reshape(-1)                       # [B, L, 2] -> rows (b, l, pos|neg)
+        return self.content[ids].contiguous(), log_mask
+
+
 class BuildEvalDataset(Dataset):
     """dataset.py:52-78 (kept for interface parity; the native eval path does not materialise one-hot labels)."""
 

@@ -110,3 +110,41 @@ def test_eval_entry_points_vs_reference_fixture(simulated):
         np.testing.assert_array_equal((ranks <= 10).astype(np.float32), per_user[:, 0])
         nd = np.where(ranks <= 10, 1.0 / np.log2(ranks + 1.0), 0.0)
         assert abs(nd.mean() - float(fx[tag + '_means'][1])) < 1e-3
+
+
+def test_device_train_sampler_matches_dataset_distribution():
+    """DeviceTrainSampler == BuildTrainDataset in everything that is deterministic (positives, pad layout, log_mask, the empty last
+    negative) and in distribution for the negatives (uniform over the items outside the user's own sequence)."""
+    import random
+    from adapter4rec_amd.data_utils import BuildTrainDataset, DeviceTrainSampler
+    rng = np.random.default_rng(0)
+    item_num, L = 40, 21
+    content = rng.integers(1, 100, size=(item_num + 1, 6)).astype(np.int64)
+    content[0] = 0
+    u2seq = {0: [int(x) for x in rng.choice(np.arange(1, item_num + 1), 21, replace=False)],
+             1: [int(x) for x in rng.choice(np.arange(1, item_num + 1), 5, replace=False)],
+             2: [int(x) for x in rng.choice(np.arange(1, item_num + 1), 12, replace=False)]}
+    ds = BuildTrainDataset(u2seq, content, item_num, 20, True)
+    sm = DeviceTrainSampler(u2seq, content, item_num, 20, 'cpu', seed=1)
+    counts = np.zeros((3, item_num + 1))
+    for it in range(400):
+        items, mask = sm.sample([0, 1, 2])
+        items = items.view(3, L, 2, 6)
+        for u in range(3):
+            random.seed(it)
+            ref_items, ref_mask = ds[u]
+            np.testing.assert_array_equal(items[u, :, 0].numpy(), ref_items[:, 0].numpy())          # positives + left padding
+            np.testing.assert_array_equal(mask[u].numpy(), ref_mask.numpy())
+            pad = L - len(u2seq[u])
+            negs = items[u, :, 1]
+            assert (negs[:pad] == 0).all() and (negs[-1] == 0).all()
+            # recover the negative ids from their content rows (rows are unique with overwhelming probability)
+            for t in range(pad, L - 1):
+                match = np.where((content == negs[t].numpy()).all(1))[0]
+                assert len(match) >= 1 and match[0] not in u2seq[u] and match[0] != 0
+                counts[u, match[0]] += 1
+    for u in range(3):
+        allowed = [i for i in range(1, item_num + 1) if i not in u2seq[u]]
+        c = counts[u, allowed]
+        exp = c.sum() / len(allowed)
+        assert counts[u].sum() == c.sum() and (np.abs(c - exp) < 6 * np.sqrt(exp) + 1).all()        # uniform over the allowed items
