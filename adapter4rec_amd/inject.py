@@ -31,8 +31,8 @@ def inject_adapters(model, args):
         for i, blk in enumerate(blocks):
             blocks[i] = SASRecPfeifferAdaptedSelfOutput(blk, args)
     elif 'kadapter' in t:
-        raise NotImplementedError(f'--adapter_type {t}: K-Adapter is not wired natively (its 2-block transformers run at head widths 16 / 8, '
-                                  'which the attention kernels do not cover)')
+        raise NotImplementedError(f'--adapter_type {t}: K-Adapter is not wired natively: its SASRec-side transformer blocks are 16 wide '
+                                  '(the GEMM kernels need multiples of 64); the narrow-head attention it needs exists (a4r_attn_small.hip)')
     elif 'prompt' in t:                                 # run.py:429-434
         from .model.model import SoftEmbedding
         bm = model.bert_encoder.text_encoders['title'].bert_model

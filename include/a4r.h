@@ -86,7 +86,9 @@ int a4r_adapter_fwd(void* stream, const void* h, int ldh, const void* x, int ldx
  * model/modules.py:31-42 with the mask of model/encoders.py:24-28.
  * qkv [n_items*S, ld]: q at column q_off, k at k_off, v at v_off, head h at +h*dh.
  * score = q.k * scale + (allowed ? 0 : mask_neg), allowed = key_mask[item][key] != 0 and
- * (!causal or key <= query); softmax over the S keys; attention-prob dropout; . V. */
+ * (!causal or key <= query); softmax over the S keys; attention-prob dropout; . V.
+ * S <= 32; dh 32 or 64 (MFMA kernels) or dh <= 16 (scalar kernels for the narrow heads inside a K-Adapter,
+ * Downstream/Text/model/modules.py:161-206; their dropout lots are indexed differently, fwd and bwd agree). */
 typedef struct {
     const void* qkv; int32_t ld; int32_t q_off, k_off, v_off;
     void* out; int32_t ldo;              /* fwd: ctx [n_items*S, ldo], head h at column h*dh */

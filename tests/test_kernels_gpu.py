@@ -201,7 +201,8 @@ def attn_ref(qkv, key_mask, n_items, S, nh, dh, causal, scale, mask_neg, offs):
 
 
 ATTN_CASES = [('bert', 30, 12, 64, False, torch.finfo(torch.float32).min), ('bert2', 30, 2, 64, False, torch.finfo(torch.float32).min),
-              ('sasrec', 20, 2, 32, True, -1e9), ('full32', 32, 3, 64, True, -1e9)]
+              ('sasrec', 20, 2, 32, True, -1e9), ('full32', 32, 3, 64, True, -1e9),
+              ('kad_bert', 30, 12, 16, False, -10000.0), ('kad_sas', 20, 2, 8, True, -1e9), ('kad_odd', 7, 3, 8, False, -1e9)]
 
 
 @pytest.mark.parametrize('dt', ['f32', 'bf16'])
@@ -282,11 +283,12 @@ def test_attention_long_rejects():
 
 
 @pytest.mark.parametrize('dt', ['f32', 'bf16'])
-def test_attention_dropout_adjoint(dt):
+@pytest.mark.parametrize('dh', [64, 8])
+def test_attention_dropout_adjoint(dt, dh):
     """With dropout on, out is linear in V: <out, dO> == <V, dV> iff fwd and bwd regenerate the same mask."""
     from adapter4rec_amd import _lib as L
     t = DT[dt]
-    n_items, S, nh, dh = 9, 30, 4, 64
+    n_items, S, nh = 9, 30, 4
     Hd = nh * dh
     Mp = 384
     qkv = rnd(Mp, 3 * Hd, dtype=t, seed=23)
