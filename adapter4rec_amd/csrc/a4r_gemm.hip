@@ -231,11 +231,21 @@ inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 
 }  // namespace
 
 int a4r_gemm_nt_256(hipStream_t s, const a4r_gemm_t& g);   // a4r_gemm256.hip
+int a4r_gemm_nt_256w4(hipStream_t s, const a4r_gemm_t& g); // a4r_gemm256w4.hip (variant 3: four waves of 128 x 128)
+static int run_256(hipStream_t s, const a4r_gemm_t& g);
 int a4r_cu_count();                                          // a4r_gemm256.hip: CU count rounded down to a multiple of 8
+
+static int run_256(hipStream_t s, const a4r_gemm_t& g) {
+    if (g_variant >= 3) {
+        const int rc = a4r_gemm_nt_256w4(s, g);
+        if (rc != 1) return rc;
+    }
+    return a4r_gemm_nt_256(s, g);
+}
 
 extern "C" int a4r_gemm_variant(int v) {
     const int old = g_variant;
-    if (v >= 0 && v <= 2) g_variant = v;
+    if (v >= 0 && v <= 3) g_variant = v;
     return old;
 }
 
@@ -275,7 +285,7 @@ extern "C" int a4r_gemm_nt(void* stream, const a4r_gemm_t* gp) {
             g2.R1 = adv(g.R1, g.ldr1, osz);
             g2.R2 = adv(g.R2, g.ldr2, osz);
             g2.Pre = adv(g.Pre, g.ldpre, osz);
-            const int rc = a4r_gemm_nt_256(s, g1);
+            const int rc = run_256(s, g1);
             if (rc == 0) {
                 if (g.in_dtype == A4R_BF16 && g.out_dtype == A4R_BF16) return launch_bn<bf16_t, bf16_t>(s, g2);
                 if (g.in_dtype == A4R_F32 && g.out_dtype == A4R_F32) return launch_bn<float, float>(s, g2);
@@ -284,7 +294,7 @@ extern "C" int a4r_gemm_nt(void* stream, const a4r_gemm_t* gp) {
             }
             if (rc != 1) return rc;
         } else {
-            const int rc = a4r_gemm_nt_256(s, g);
+            const int rc = run_256(s, g);
             if (rc != 1) return rc;              // 1 = this (dtype, act, dact) combination has no large-tile instantiation
         }
     }
