@@ -96,7 +96,7 @@ __global__ void __launch_bounds__(512, 2) gemm_nt_256_kernel(const a4r_gemm_t p,
 #define A4R_WAIT_BARRIER_N(steady_, n_)                                                                              \
     if (steady_) asm volatile("s_waitcnt vmcnt(" #n_ ") lgkmcnt(0)" ::: "memory");                                   \
     else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");                                                 \
-    __builtin_amdgcn_s_barrier();                                                                                    \
+    if (!(A4R_ABL_ & 8)) __builtin_amdgcn_s_barrier();                                                               \
     asm volatile("" ::: "memory");
 
     // A phase after its barrier = {issue one unit's LDS-DMA} + {16 MFMAs}.  The two waves that share a SIMD (w and w + 4)
@@ -133,10 +133,9 @@ __global__ void __launch_bounds__(512, 2) gemm_nt_256_kernel(const a4r_gemm_t p,
 #define A4R_PHASE_I(steady_, issue_, nr_, dst_, off_, buf_, unit_, ax_, bx_, m0_, n0_)                 \
     A4R_WAIT_BARRIER(steady_)                                                                         \
     _Pragma("unroll") for (int k_ = 0; k_ < 8; ++k_) {                                                \
-        A4R_MFMA_J(ax_, bx_, m0_, n0_, 2 * k_)                                                        \
-        A4R_MFMA_J(ax_, bx_, m0_, n0_, 2 * k_ + 1)                                                    \
-        if (k_ == 0) { issue_ }                     /* the two LDS-DMA of this phase, behind the first MFMA pair */ \
-        if (k_ >= 1 && k_ <= 4) {                   /* all reads in the first half: the last 6 MFMAs cover their latency */ \
+        if (!(A4R_ABL & 2)) { A4R_MFMA_J(ax_, bx_, m0_, n0_, 2 * k_) A4R_MFMA_J(ax_, bx_, m0_, n0_, 2 * k_ + 1) } \
+        if (k_ == 0 && !(A4R_ABL & 1)) { issue_ }   /* the two LDS-DMA of this phase, behind the first MFMA pair */ \
+        if (k_ >= 1 && k_ <= 4 && !(A4R_ABL & 4)) { /* all reads in the first half: the last 6 MFMAs cover their latency */ \
             if ((nr_) == 8) { A4R_RD_I(dst_, off_, buf_, unit_, 2 * (k_ - 1)) A4R_RD_I(dst_, off_, buf_, unit_, 2 * (k_ - 1) + 1) } \
             else { A4R_RD_I(dst_, off_, buf_, unit_, k_ - 1) }                                        \
         }                                                                                             \
@@ -151,6 +150,7 @@ __global__ void __launch_bounds__(512, 2) gemm_nt_256_kernel(const a4r_gemm_t p,
 #ifndef A4R_ABL
 #define A4R_ABL 0
 #endif
+#define A4R_ABL_ A4R_ABL
 #define A4R_PIPE_PHASE(steady_, issue_, reads_, ax_, bx_, m0_, n0_)                                   \
     A4R_WAIT_BARRIER(steady_)                                                                         \
     if (!(A4R_ABL & 1)) { issue_ }                                                                    \
