@@ -272,6 +272,7 @@ extern "C" int a4r_gemm_nt(void* stream, const a4r_gemm_t* gp) {
         // a second launch instead of costing a full round (N = 768, K = 3072: 4 -> 3 rounds + ~1/4).
         const int ntm = g.M / 256, ntn = g.N / 256, tiles = ntm * ntn, ncu = a4r_cu_count();
         const int rem = tiles % ncu;
+        // (measured on the ViT step: 194 vs 190 user-seq/s with the split applied at every K against long K only)
         if (tiles > ncu && rem > 0 && rem * 4 <= ncu && rem % ntn == 0) {
             const int64_t head_rows = (int64_t)(ntm - rem / ntn) * 256;
             a4r_gemm_t g1 = g, g2 = g;

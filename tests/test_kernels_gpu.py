@@ -544,7 +544,7 @@ def test_gemm_tail_panels_split_launch():
     """777 tiles on 256 CUs: the last 3 row panels are launched on the 128-tile kernel (a4r_gemm.hip); results and the dropout
     mask (drop_row0) must equal the single-kernel launch."""
     from adapter4rec_amd import _lib as L
-    M, N, K = 259 * 256, 768, 768
+    M, N, K = 259 * 256, 768, 2304
     A = rnd(M, K, dtype=torch.bfloat16, seed=71)
     B = rnd(N, K, dtype=torch.bfloat16, scale=0.05, seed=72)
     R1 = rnd(M, N, dtype=torch.bfloat16, seed=73)
