@@ -215,11 +215,11 @@ def resample_u8(src, dst, bounds, kk, n_outer, in_len, out_len, inner):
                                  C.c_int(in_len), C.c_int(out_len), C.c_long(inner)), 'a4r_resample_u8')
 
 
-def vit_assemble(patches, cls, pos, out, n_items, n_keep, keep_idx=None):
+def vit_assemble(patches, cls, pos, out, n_items, n_keep, keep_idx=None, tokens_out=0):
     require_gpu(patches, out)
     _check(lib().a4r_vit_assemble(_stream(), _p(patches), C.c_int(_ld(patches)), _p(cls), _p(pos), _p(keep_idx), _p(out),
-                                  C.c_int(_ld(out)), C.c_int(n_items), C.c_int(n_keep), C.c_int(cls.numel()), C.c_int(_dt(out))),
-           'a4r_vit_assemble')
+                                  C.c_int(_ld(out)), C.c_int(n_items), C.c_int(n_keep), C.c_int(cls.numel()), C.c_int(_dt(out)),
+                                  C.c_int(tokens_out)), 'a4r_vit_assemble')
 
 
 def embed_bwd(ids, dpre, dword, dpos, n_items, S, roberta=False, pad_id=0):

@@ -43,14 +43,15 @@ __global__ void __launch_bounds__(256) patchify_kernel(const void* __restrict__ 
 template <typename T>
 __global__ void __launch_bounds__(256) vit_assemble_kernel(const T* __restrict__ patches, int ldp, const float* __restrict__ cls,
                                                            const float* __restrict__ pos, const int32_t* __restrict__ keep,
-                                                           T* __restrict__ out, int ldo, int n_items, int n_keep, int H) {
+                                                           T* __restrict__ out, int ldo, int n_items, int n_keep, int H, int S_out) {
     constexpr int PER = Elem<T>::PER16;
     const int cpr = H / PER, S = n_keep + 1;
     const long total = (long)n_items * S * cpr;
     for (long id = (long)blockIdx.x * 256 + threadIdx.x; id < total; id += (long)gridDim.x * 256) {
         const int ch = (int)(id % cpr);
-        const long row = id / cpr;
-        const int item = (int)(row / S), t = (int)(row % S);
+        const long irow = id / cpr;
+        const int item = (int)(irow / S), t = (int)(irow % S);
+        const long row = (long)item * S_out + t;                     // S_out > S leaves room for appended prompt tokens
         float v[PER], p[PER];
         if (t == 0) {
             load_vec<float, PER>(cls + ch * PER, v);
@@ -93,8 +94,10 @@ extern "C" int a4r_patchify(void* stream, const void* img, int src_kind, void* o
 }
 
 extern "C" int a4r_vit_assemble(void* stream, const void* patches, int ldp, const float* cls, const float* pos, const int32_t* keep_idx,
-                                void* out, int ldo, int n_items, int n_keep, int H, int dtype) {
+                                void* out, int ldo, int n_items, int n_keep, int H, int dtype, int tokens_out) {
     if (!patches || !cls || !pos || !out || n_items <= 0 || n_keep <= 0 || H % 8) return A4R_EINVAL;
+    if (tokens_out == 0) tokens_out = n_keep + 1;
+    if (tokens_out < n_keep + 1) return A4R_EINVAL;
     const int es = dtype == A4R_BF16 ? 2 : 4;
     if ((dtype != A4R_BF16 && dtype != A4R_F32) || (ldp * es) % 16 || (ldo * es) % 16 || ldp < H || ldo < H) return A4R_EINVAL;
     if ((reinterpret_cast<uintptr_t>(patches) | reinterpret_cast<uintptr_t>(out) | reinterpret_cast<uintptr_t>(cls) | reinterpret_cast<uintptr_t>(pos)) & 15u)
@@ -103,10 +106,10 @@ extern "C" int a4r_vit_assemble(void* stream, const void* patches, int ldp, cons
     const long total = (long)n_items * (n_keep + 1) * (H / (16 / es));
     if (dtype == A4R_BF16)
         hipLaunchKernelGGL(vit_assemble_kernel<bf16_t>, dim3(grid_for(total)), dim3(256), 0, s, (const bf16_t*)patches, ldp, cls, pos, keep_idx,
-                           (bf16_t*)out, ldo, n_items, n_keep, H);
+                           (bf16_t*)out, ldo, n_items, n_keep, H, tokens_out);
     else
         hipLaunchKernelGGL(vit_assemble_kernel<float>, dim3(grid_for(total)), dim3(256), 0, s, (const float*)patches, ldp, cls, pos, keep_idx,
-                           (float*)out, ldo, n_items, n_keep, H);
+                           (float*)out, ldo, n_items, n_keep, H, tokens_out);
     return a4r_launch_status();
 }
 

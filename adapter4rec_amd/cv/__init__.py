@@ -1,3 +1,3 @@
 from .model import (Model, ModelCPC, Vit_Encoder, MAE_Encoder, VITAdaptedSelfOutput, VITAdaptedOutput,   # noqa: F401
-                    VITCompacterAdaptedSelfOutput, VITCompacterAdaptedOutput, VITAdaptedParallelOutput)
+                    VITCompacterAdaptedSelfOutput, VITCompacterAdaptedOutput, VITAdaptedParallelOutput, SoftPrompt)
 from .vit import ViTForImageClassification, ViTMAEModel                                                  # noqa: F401

@@ -41,6 +41,16 @@ def inject_adapters(model, args):
         for i, blk in enumerate(blocks):
             blocks[i] = SASRecCompacterAdaptedSelfOutput(blk, args)
         model = CompacterModel(args, model)
+    elif 'prompt' in t:                              # :413-422: shallow prompt on the ViT + trainable classifier; SASRec untouched
+        from .model import SoftPrompt
+        net = model.cv_encoder.image_net
+        if not hasattr(net, 'vit'):
+            raise NotImplementedError('soft prompt on ViT-MAE (the reference wires it for ViTForImageClassification only)')
+        h = net.vit.embeddings.cls_token.shape[-1]
+        net.vit.embeddings = SoftPrompt(net.vit.embeddings, n_tokens=args.n_tokens, embed_dim=h)
+        for name, p in model.named_parameters():
+            if 'cv_encoder.image_net.classifier' in name:
+                p.requires_grad = True
     elif 'houslby' in t and 'None' not in args.is_serial:      # :425-447
         for lyr in layers:
             lyr.attention.output = VITAdaptedSelfOutput(lyr.attention.output, args)

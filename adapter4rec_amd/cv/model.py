@@ -105,6 +105,15 @@ class ModelCPC(_CVBase):                         # model.py:80-146
     arch = 'cpc'
 
 
+class SoftPrompt(_Container):                    # model.py:512-535: n_tokens learned rows appended AFTER cls + patches (no position term)
+    def __init__(self, wte, n_tokens=10, embed_dim=768):
+        super().__init__()
+        self.wte = wte
+        self.patch_embeddings = wte.patch_embeddings
+        self.n_tokens = n_tokens
+        self.Prompt_Tokens = nn.Parameter(torch.zeros(1, n_tokens, embed_dim))
+
+
 # ---------------------------------------------------------------- ViT-side wrappers (pre-LN: no LayerNorm inside)
 class VITAdaptedSelfOutput(_Container):          # model.py:182-195: adapter(dropout(dense(x)))          (residual added by ViTLayer)
     placement, adds_input = 'serial', False

@@ -45,10 +45,16 @@ class ViTRecEngine(TransRecEngine):
             raise NotImplementedError('the image tower assumes the ViT configs the reference loads: dropout probabilities 0')
         self.NP = (self.R // self.P) ** 2
         self.n_keep = int(self.NP * (1 - g['mask_ratio'])) if self.mae else self.NP       # HF: int(seq_length * (1 - mask_ratio))
-        self.S = self.n_keep + 1
+        emb = core.embeddings
+        self.n_prompt, self.g_prompt = 0, None
+        if type(emb).__name__ == 'SoftPrompt':       # model.py:512-535: learned tokens appended after cls + patches
+            self.prompt_param = emb.Prompt_Tokens
+            self.n_prompt = int(emb.n_tokens)
+            self.g_prompt = self.grad_view(emb.Prompt_Tokens)
+            emb = emb.wte
+        self.S = self.n_keep + 1 + self.n_prompt
         if self.S > 256:
             raise NotImplementedError(f'{self.S} tokens per image (attention kernel: <= 256)')
-        emb = core.embeddings
         proj = emb.patch_embeddings.projection
         # Conv2d weight [H, C, P, P] is [H, C*P*P] in memory: the flat fp32 master is packed as that matrix when trainable
         self.d_patch = _Dense(self, proj.weight, proj.bias, self.T, view2d=(H, self.C * self.P * self.P))
@@ -57,7 +63,7 @@ class ViTRecEngine(TransRecEngine):
         self.cls_tok = tab(emb.cls_token).reshape(H)
         self.pos_tab = tab(emb.position_embeddings).reshape(self.NP + 1, H)
         self.g_cls, self.g_postab = self.grad_view(emb.cls_token), self.grad_view(emb.position_embeddings)
-        self.train_emb = self.d_patch.trainable or self.g_cls is not None or self.g_postab is not None
+        self.train_emb = self.d_patch.trainable or self.g_cls is not None or self.g_postab is not None or self.g_prompt is not None
         if self.train_emb and self.mae:
             raise NotImplementedError('training the ViT-MAE embedding side (--fine_tune_to all) is not wired natively')
         self.next_noise = None
@@ -293,7 +299,9 @@ class ViTRecEngine(TransRecEngine):
         pe = self._buf('patch_emb', Mp, H, self.T)
         L.gemm_nt(pat, self.patch_w, pe, bias=self.patch_b, M=Mp)
         x = saved[0]['x0'] if saved is not None else self._buf('xa', M, H, self.T)
-        L.vit_assemble(pe, self.cls_tok, self.pos_tab, x, n_items, self.n_keep, keep)
+        L.vit_assemble(pe, self.cls_tok, self.pos_tab, x, n_items, self.n_keep, keep, tokens_out=S)
+        if self.n_prompt:
+            x[:n_items * S].view(n_items, S, H)[:, S - self.n_prompt:] = self.prompt_param.detach().to(self.T)
         other = self._buf('xb', M, H, self.T)
         nb = len(self.bert_blocks)
         Ip = pad_to(n_items, 128)
@@ -349,6 +357,9 @@ class ViTRecEngine(TransRecEngine):
         if self.train_emb:                       # ViTEmbeddings backward: token 0 -> cls + pos[0]; token 1 + j -> patch projection + pos[1 + j]
             S, NP = self.S, self.NP
             d3 = dxb[:n_items * S].view(n_items, S, H)
+            if self.g_prompt is not None:
+                self.g_prompt().view(self.n_prompt, H).add_(d3[:, S - self.n_prompt:].float().sum(0))
+                d3 = d3[:, :S - self.n_prompt]
             if self.g_postab is not None:
                 self.g_postab().view(NP + 1, H).add_(d3.float().sum(0))
             if self.g_cls is not None:

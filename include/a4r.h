@@ -118,11 +118,12 @@ int a4r_attn_long_bwd(void* stream, const a4r_attn_t* a, const float* lse, float
  * data_utils/dataset.py:85-113).  src_kind 1: img uint8 [n, Himg, Wimg, C] raw pixels; ToTensor + Normalize(0.5, 0.5)
  * of dataset.py:77-81 is applied here: (x / 255 - 0.5) / 0.5.  patch % 8 == 0.
  * a4r_vit_assemble: out[item*(n_keep+1) + 0] = cls + pos[0]; out[.. + 1 + j] = patches[item*n_keep + j] + pos[1 + idx_j]
- * (cls [H], pos [1 + n_patches, H] fp32). */
+ * (cls [H], pos [1 + n_patches, H] fp32).  tokens_out (0 = n_keep + 1): rows per item in `out`; a larger value leaves rows
+ * n_keep + 1 .. tokens_out - 1 of every item untouched (soft-prompt tokens appended by the caller, Downstream/CV/model/model.py:512-535). */
 int a4r_patchify(void* stream, const void* img, int src_kind, void* out, int ldo, const int32_t* keep_idx, int n_keep,
                  int n_items, int C, int Himg, int Wimg, int patch, int dtype);
 int a4r_vit_assemble(void* stream, const void* patches, int ldp, const float* cls, const float* pos, const int32_t* keep_idx,
-                     void* out, int ldo, int n_items, int n_keep, int H, int dtype);
+                     void* out, int ldo, int n_items, int n_keep, int H, int dtype, int tokens_out);
 
 /* One pass of Pillow's 8-bit separable resampler (third party; what torchvision's Resize((R, R)) executes on the PIL image
  * at Downstream/CV/data_utils/dataset.py:77-81): src uint8 [n_outer, in_len, inner] -> dst uint8 [n_outer, out_len, inner],

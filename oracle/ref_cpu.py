@@ -338,6 +338,10 @@ def vit_embed(sd, images, cfg, noise=None):
     """HF ViTEmbeddings / ViTMAEEmbeddings (4.20.1).  MAE: patches + pos[1:], keep the int(N (1 - ratio)) patches of
     smallest noise in argsort order, prepend cls + pos[0]."""
     p = _vit_prefix(sd) + 'embeddings.'
+    if p + 'Prompt_Tokens' in sd:                     # Downstream/CV/model/model.py:512-535 SoftPrompt: tokens appended after cls + patches
+        base = vit_embed({k.replace('embeddings.wte.', 'embeddings.'): v for k, v in sd.items() if 'Prompt_Tokens' not in k and '.embeddings.patch_embeddings.' not in k},
+                         images, cfg, noise)
+        return torch.cat([base, sd[p + 'Prompt_Tokens'].expand(base.shape[0], -1, -1)], 1)
     w, b = sd[p + 'patch_embeddings.projection.weight'], sd[p + 'patch_embeddings.projection.bias']
     x = torch.nn.functional.conv2d(images, w, b, stride=w.shape[-1]).flatten(2).transpose(1, 2)
     n = x.shape[0]

@@ -62,6 +62,7 @@ CV_VARIANT_CFG = {
     'cv_vit_compacter': dict(adapter_type='compacter'),
     'cv_vit_cpc': dict(arch='cpc'),
     'cv_vit_parallel': dict(is_serial='None'),
+    'cv_vit_prompt': dict(adapter_type='prompt'),
     'cv_mae_houlsby': dict(mae=True),
     'cv_vit_frozen': dict(adapter_type='none'),
 }

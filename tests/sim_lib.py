@@ -159,13 +159,14 @@ def resample_u8(src, dst, bounds, kk, n_outer, in_len, out_len, inner):
     dst.view(-1)[:] = out.reshape(-1).to(torch.uint8)
 
 
-def vit_assemble(patches, cls, pos, out, n_items, n_keep, keep_idx=None):
+def vit_assemble(patches, cls, pos, out, n_items, n_keep, keep_idx=None, tokens_out=0):
     H = cls.numel()
+    S_out = tokens_out or n_keep + 1
     x = patches[:n_items * n_keep, :H].float().view(n_items, n_keep, H)
     idx = keep_idx.long() if keep_idx is not None else torch.arange(n_keep)[None].expand(n_items, -1)
     x = x + pos[1:][idx]
     tok = torch.cat([(cls + pos[0])[None, None].expand(n_items, 1, H), x], 1)
-    out[:n_items * (n_keep + 1)] = tok.reshape(-1, H).to(out.dtype)
+    out[:n_items * S_out].view(n_items, S_out, -1)[:, :n_keep + 1] = tok.to(out.dtype)
 
 
 def _pos_ids(ids, n_items, S, roberta, pad_id):

@@ -18,6 +18,7 @@ ARGS = {
     'cv_vit_compacter': dict(adapter_type='compacter'),
     'cv_vit_cpc': dict(arch='cpc'),
     'cv_vit_parallel': dict(is_serial='None'),
+    'cv_vit_prompt': dict(adapter_type='prompt', n_tokens=5),
     'cv_mae_houlsby': dict(CV_model_load='vit-mae-base'),
     'cv_vit_frozen': dict(adding_adapter_to='None'),
 }

@@ -25,7 +25,7 @@ OUT = os.path.join(os.path.dirname(os.path.abspath(__file__)), '..', 'tests', 'g
 
 import model as refm  # noqa: E402
 from model import Model, ModelCPC  # noqa: E402
-from model.model import (VITAdaptedParallelOutput, SASRecParallelAdaptedSelfOutput, VITAdaptedSelfOutput, VITAdaptedOutput, VITCompacterAdaptedSelfOutput, VITCompacterAdaptedOutput,  # noqa: E402
+from model.model import (SoftPrompt, VITAdaptedParallelOutput, SASRecParallelAdaptedSelfOutput, VITAdaptedSelfOutput, VITAdaptedOutput, VITCompacterAdaptedSelfOutput, VITCompacterAdaptedOutput,  # noqa: E402
                          SASRecAdaptedSelfOutput, SASRecPfeifferV2AdaptedSelfOutput, SASRecCompacterAdaptedSelfOutput)
 from model.modules import AdapterBlock, HyperComplexAdapterBlock  # noqa: E402
 from model.layers import PHMLinear  # noqa: E402
@@ -224,6 +224,13 @@ def inject(m, args):                   # Downstream/CV/run_adapter.py:369-447 at
         w.adapter = block_cls(args, HID, args.cv_adapter_down_size) if block_cls is HyperComplexAdapterBlock else \
             block_cls(args, HID, args.cv_adapter_down_size, args.adapter_dropout_rate)
         return w
+    if 'prompt' in t:                       # run_adapter.py:413-422
+        net = m.cv_encoder.image_net
+        net.vit.embeddings = SoftPrompt(net.vit.embeddings, n_tokens=args.n_tokens, embed_dim=HID)
+        for n_, p in m.named_parameters():
+            if 'cv_encoder.image_net.classifier' in n_:
+                p.requires_grad = True
+        return m
     if 'pfeiffer_ver2' in t:
         for lyr in layers_of(m):
             lyr.attention.output = wrap(VITAdaptedSelfOutput, lyr.attention.output, AdapterBlock)
@@ -286,12 +293,12 @@ def run_variant(name, base_model, images, masks, noise, args, layernorm=False):
                 p.requires_grad = True
     with torch.no_grad():
         for n_, p in m.named_parameters():
-            if p.requires_grad and ('adapter' in n_ or n_.endswith('phm_rule')):
+            if p.requires_grad and ('adapter' in n_ or n_.endswith('phm_rule') or 'Prompt_Tokens' in n_):
                 p.add_(0.05 * torch.randn_like(p))
     m.eval()
     inner = m.model if isinstance(m, CompacterModel) else m
     emb_mod = inner.cv_encoder.image_net.embeddings if 'mae' in args.CV_model_load else inner.cv_encoder.image_net.vit.embeddings
-    emb_mod.noise = noise
+    getattr(emb_mod, 'wte', emb_mod).noise = noise
     out = {}
     sd = {k: v.detach().clone() for k, v in m.state_dict().items()}
     base_sd = base_model.state_dict()
@@ -372,12 +379,15 @@ def main():
     base_mae.eval()
     d1, d2 = check_against_installed_hf(vit, mae_net, images[:6], noise[:6])
 
-    if not (len(sys.argv) > 1 and sys.argv[1] == '--parallel-only'):
+    if not (len(sys.argv) > 1 and sys.argv[1] in ('--parallel-only', '--prompt-only')):
       np.savez_compressed(os.path.join(OUT, 'cv_base.npz'), images=images.numpy(), log_mask=masks.numpy(), noise=noise.numpy(),
                         hf_check=np.array([d1, d2]), **{'sd/' + k: v.numpy() for k, v in base.state_dict().items()})
       np.savez_compressed(os.path.join(OUT, 'cv_base_mae.npz'), **{'sd/' + k: v.numpy() for k, v in base_mae.state_dict().items()})
     if len(sys.argv) > 1 and sys.argv[1] == '--parallel-only':      # added later: leaves the other fixtures untouched
         run_variant('cv_vit_parallel', base, images, masks, noise, make_args(is_serial='None'))
+        return
+    if len(sys.argv) > 1 and sys.argv[1] == '--prompt-only':
+        run_variant('cv_vit_prompt', base, images, masks, noise, make_args(adapter_type='prompt', n_tokens=5))
         return
     run_variant('cv_vit_houlsby', base, images, masks, noise, make_args())
     run_variant('cv_vit_houlsby_gelu_ln', base, images, masks, noise, make_args(adapter_activation='GELU'), layernorm=True)
