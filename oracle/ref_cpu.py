@@ -199,10 +199,30 @@ def text_encoder(sd, news, cfg, return_all=False):
     """model/encoders.py:48-57,89-99: ids || mask -> BERT -> fc(CLS) -> GELU."""
     nw = cfg['num_words_title']
     ids, mask = news[:, :nw], news[:, nw:2 * nw]
+    if BERT + 'com_dense.weight' in sd:          # K-Adapter, model/model.py:523-559 BertKAdaptedBertModel wraps the backbone
+        inner = {(BERT + k[len(BERT + 'bert_model.'):] if k.startswith(BERT + 'bert_model.') else k): v for k, v in sd.items()}
+        hs = bert_encode(inner, ids, mask, cfg, return_all=True)
+        ks = [int(i) + 1 for i in str(cfg['k_adapter_bert_list']).split(',')]
+        last = 0
+        for j, k in enumerate(ks):                # hidden_states[k] = output of layer k-1, chained through the adapters
+            last = kadapter_block(sd, BERT + f'bert_adapter_list.{j}.', hs[k] + last, cfg['num_adapter_heads_bert'], cfg)
+        out = linear(torch.cat([hs[-1], last], -1), sd[BERT + 'com_dense.weight'], sd[BERT + 'com_dense.bias'])
+        emb = gelu_erf(linear(out[:, 0], sd[FC + 'weight'], sd[FC + 'bias']))
+        return (emb, hs) if return_all else emb
     hs = bert_encode(sd, ids, mask, cfg, return_all=return_all)
     last = hs[-1] if return_all else hs
     emb = gelu_erf(linear(last[:, 0], sd[FC + 'weight'], sd[FC + 'bias']))
     return (emb, hs) if return_all else emb
+
+
+def kadapter_block(sd, p, x, n_heads, cfg):
+    """model/modules.py:161-206 KAdapterBlock: down_project -> 2 plain post-LN TransformerBlocks under an all-zero additive mask (no
+    key mask, NOT causal) -> up_project, + input."""
+    h = linear(x, sd[p + 'down_project.weight'], sd[p + 'down_project.bias'])
+    c = dict(cfg, sasrec_heads=n_heads, lora_r_sasrec=0, is_serial='True')
+    for j in range(2):
+        h = sasrec_block(sd, p + f'transformer_blocks.{j}.', h, torch.zeros(()), c)
+    return x + linear(h, sd[p + 'up_project.weight'], sd[p + 'up_project.bias'])
 
 
 # --------------------------------------------------------------------------- SASRec user encoder
@@ -262,6 +282,13 @@ def user_encoder(sd, input_embs, log_mask, cfg):
     x = layer_norm(input_embs + sd[UE + 'position_embedding.weight'][:t],
                    sd[UE + 'layer_norm.weight'], sd[UE + 'layer_norm.bias'], 1e-6)
     i = 0
+    if UE + 'transformer_blocks.com_dense2.weight' in sd:      # K-Adapter, model/model.py:562-583 SASRecKAdaptedTransformerBlocks
+        last = 0
+        while UE + f'transformer_blocks.adapter_list.{i}.down_project.weight' in sd:
+            last = kadapter_block(sd, UE + f'transformer_blocks.adapter_list.{i}.', x + last, cfg['num_adapter_heads_sasrec'], cfg)
+            x = sasrec_block(sd, UE + f'transformer_blocks.transformer_blocks.{i}.', x, add_mask, cfg)
+            i += 1
+        return linear(torch.cat([x, last], -1), sd[UE + 'transformer_blocks.com_dense2.weight'], sd[UE + 'transformer_blocks.com_dense2.bias'])
     while True:
         bp = UE + f'transformer_blocks.{i}.'
         if not any(k.startswith(bp) for k in sd):

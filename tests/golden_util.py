@@ -16,6 +16,7 @@ VARIANT_CFG = {
     'houlsby_cpc': dict(arch='cpc'),
     'finetune_all': dict(adapter_type='none'),
     'prompt': dict(adapter_type='prompt', n_tokens=8),
+    'kadapter': dict(adapter_type='kadapter', k_adapter_bert_list='0,1', num_adapter_heads_bert=4, num_adapter_heads_sasrec=2),
     'roberta_cpc_pfeiffer': dict(adapter_type='pfeiffer', adapter_activation='relu', arch='cpc',
                                  encoder='roberta', bert_ln_eps=1e-5, pad_token_id=1),
 }
@@ -25,7 +26,8 @@ LRS = dict(fine_tune_lr=5e-5, lr=1e-4, adapter_bert_lr=1.5e-4, adapter_sasrec_lr
 def base_name(k):
     if k.startswith('model.'):
         k = k[len('model.'):]
-    return k.replace('.self_output.', '.').replace('.transformer_block.', '.').replace('.word_embeddings.wte.', '.word_embeddings.')
+    return k.replace('.self_output.', '.').replace('.transformer_block.', '.').replace('.word_embeddings.wte.', '.word_embeddings.') \
+        .replace('.bert_model.bert_model.', '.bert_model.').replace('.transformer_blocks.transformer_blocks.', '.transformer_blocks.')
 
 
 def strip(k):

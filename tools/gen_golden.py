@@ -75,6 +75,12 @@ def inject(model, args):
     t = args.adapter_type
     if t == 'none':
         return model
+    if 'kadapter' in t:                     # run.py:409-413
+        te = model.bert_encoder.text_encoders.title
+        te.bert_model = refm.model.BertKAdaptedBertModel(te.bert_model, args)
+        ue = model.user_encoder.transformer_encoder
+        ue.transformer_blocks = refm.model.SASRecKAdaptedTransformerBlocks(ue.transformer_blocks, args)
+        return model
     if 'prompt' in t:                       # run.py:429-434
         bm = model.bert_encoder.text_encoders.title.bert_model
         bm.set_input_embeddings(refm.model.SoftEmbedding(bm.get_input_embeddings(), n_tokens=args.n_tokens, initialize_from_vocab=True))
@@ -116,7 +122,8 @@ def base_name(k):
     """adapted state_dict key -> key of the un-adapted model that holds the same tensor."""
     if k.startswith('model.'):
         k = k[len('model.'):]
-    return k.replace('.self_output.', '.').replace('.transformer_block.', '.').replace('.word_embeddings.wte.', '.word_embeddings.')
+    return k.replace('.self_output.', '.').replace('.transformer_block.', '.').replace('.word_embeddings.wte.', '.word_embeddings.') \
+        .replace('.bert_model.bert_model.', '.bert_model.').replace('.transformer_blocks.transformer_blocks.', '.transformer_blocks.')
 
 
 def make_content(rng, n_items, roberta=False):
@@ -186,7 +193,7 @@ def run_variant(name, base_model, content, items, masks, args, hidden_dump=False
     # every trainable tensor has a non-trivial value and gradient.
     with torch.no_grad():
         for n_, p in m.named_parameters():
-            if p.requires_grad and ('adapter' in n_ or n_.endswith('phm_rule') or n_.startswith('LN') or '.LN.' in n_ or 'learned_embedding' in n_):
+            if p.requires_grad and ('adapter' in n_ or n_.endswith('phm_rule') or n_.startswith('LN') or '.LN.' in n_ or 'learned_embedding' in n_ or 'com_dense' in n_):
                 p.add_(0.05 * torch.randn_like(p))
     m.eval()
     inner = m.model if isinstance(m, CompacterModel) else m
@@ -314,7 +321,8 @@ def main():
     rng = np.random.default_rng(123456)
     torch.manual_seed(123456)
     cfg = BertConfig(vocab_size=VOCAB, hidden_size=HID, num_hidden_layers=LAYERS, num_attention_heads=HEADS,
-                     intermediate_size=FFN, max_position_embeddings=MAXPOS, attn_implementation='eager')
+                     intermediate_size=FFN, max_position_embeddings=MAXPOS, attn_implementation='eager',
+                     output_hidden_states=(len(sys.argv) > 2 and sys.argv[2] == 'kadapter'))
     args = make_args()
     base = Model(args, ITEM_NUM, True, BertModel(cfg))
     if len(sys.argv) > 2 and sys.argv[1] == '--only':        # later additions: rebuild the base from base.npz, write ONE new fixture
@@ -324,6 +332,10 @@ def main():
         items, masks = torch.from_numpy(fx['sample_items']), torch.from_numpy(fx['log_mask'])
         if sys.argv[2] == 'prompt':
             run_variant('prompt', base, fx['item_content'], items, masks, make_args(adapter_type='prompt', n_tokens=8))
+        if sys.argv[2] == 'kadapter':
+            run_variant('kadapter', base, fx['item_content'], items, masks,
+                        make_args(adapter_type='kadapter', k_adapter_bert_list='0,1', k_adapter_bert_hidden_dim=64, num_adapter_heads_bert=4,
+                                  num_adapter_heads_sasrec=2))
         return
     # HF inits LayerNorm to (1, 0) and biases to 0; jitter so that those terms are exercised
     with torch.no_grad():
