@@ -128,31 +128,44 @@ class _Dense:
     Trainable (--fine_tune_to all, Pretraining/): the copies are re-packed from the flat fp32 master every step and g_w / g_b
     receive dW = dY^T X (a4r_gemm_tn) and db = column sums of dY (a4r_colsum)."""
 
-    def __init__(self, eng, weight, bias, dt, w_dst=None, wT_dst=None, b_dst=None, view2d=None):
+    def __init__(self, eng, weight, bias, dt, w_dst=None, wT_dst=None, b_dst=None, view2d=None, pad=None):
         out_f, in_f = view2d if view2d is not None else weight.shape          # view2d: a Conv2d weight seen as [out, C*kh*kw]
-        self.view2d = view2d
-        self.w = w_dst if w_dst is not None else torch.zeros(out_f, in_f, dtype=dt, device=eng.dev)
-        self.wT = wT_dst if wT_dst is not None else torch.zeros(in_f, out_f, dtype=dt, device=eng.dev)
+        op, ip = pad if pad is not None else (out_f, in_f)                     # pad: zero-padded storage (K-Adapter blocks 16 -> 64 wide)
+        self.view2d, self.out_f, self.in_f = view2d, out_f, in_f
+        self.w = w_dst if w_dst is not None else torch.zeros(op, ip, dtype=dt, device=eng.dev)
+        self.wT = wT_dst if wT_dst is not None else torch.zeros(ip, op, dtype=dt, device=eng.dev)
+        padded = tuple(self.w.shape) != (out_f, in_f)
         if weight.requires_grad:
             eng.add_pack(weight, self.w, False)
             eng.add_pack(weight, self.wT, True)
         else:
             w2 = weight.detach().reshape(out_f, in_f)
-            self.w.copy_(w2.to(dt))
-            self.wT.copy_(w2.t().to(dt))
+            self.w[:out_f, :in_f].copy_(w2.to(dt))
+            self.wT[:in_f, :out_f].copy_(w2.t().to(dt))
         self.g_w = eng.grad_view(weight)
-        self.b = self.g_b = None
+        self.s_w = torch.zeros(self.w.shape, dtype=torch.float32, device=eng.dev) if (padded and self.g_w is not None) else None
+        self.b = self.g_b = self.s_b = None
         if bias is not None:
+            if b_dst is None and padded:
+                b_dst = torch.zeros(self.w.shape[0], dtype=torch.float32, device=eng.dev)
             if b_dst is not None:
                 self.b = b_dst
                 if bias.requires_grad:
-                    eng.add_pack_bias(bias, b_dst)
+                    eng.add_pack_bias(bias, b_dst[:out_f])
                 else:
-                    b_dst.copy_(bias.detach().float())
+                    b_dst[:out_f].copy_(bias.detach().float())
             else:
                 self.b = bias.data if bias.requires_grad else eng._f32(bias)     # trainable: the fp32 master (a flat_p view) itself
             self.g_b = eng.grad_view(bias)
+            if padded and self.g_b is not None:
+                self.s_b = torch.zeros(self.w.shape[0], dtype=torch.float32, device=eng.dev)
         self.trainable = self.g_w is not None or self.g_b is not None
+
+
+class _KAdapter:
+    """Engine side of one KAdapterBlock (modules.py:161-206): down (trainable Linear) -> two plain post-LN blocks (all weights
+    trainable, no mask, not causal) -> up, + input."""
+    pass
 
 
 class TransRecEngine:
@@ -354,11 +367,24 @@ class TransRecEngine:
 
     def _build_item_tower(self):
         bert = self.model.bert_encoder.text_encoders['title'].bert_model
+        kmod = None
+        if type(bert).__name__ == 'BertKAdaptedBertModel':       # K-Adapter wraps the backbone (model.py:523-559)
+            kmod, bert = bert, bert.bert_model
         self.geo = backbone_geometry(bert)
         if self.geo['hidden_act'] not in ('gelu',):
             raise NotImplementedError(f"hidden_act {self.geo['hidden_act']}")
         self._build_bert(bert)
         self._build_head()
+        self.bert_trains = any(p.requires_grad for p in bert.parameters())
+        self.bert_kads, self.bert_klist, self.d_com = [], [], None
+        if kmod is not None:
+            nb = len(self.bert_blocks)
+            self.bert_klist = [int(k) for k in kmod.k_adapter_num_list]
+            if any(k < 1 or k > nb for k in self.bert_klist):
+                raise ValueError(f'--k_adapter_bert_list {self.bert_klist} outside 1..{nb}')
+            self.bert_kads = [self._make_kadapter(a, self.H, self.S, self.T, 6000 + 64 * j) for j, a in enumerate(kmod.bert_adapter_list)]
+            self.d_com = _Dense(self, kmod.com_dense.weight, kmod.com_dense.bias, self.T)
+            self.cls_only = False                      # the adapters attend over all tokens of the last layer's output
 
     def _build_bert(self, bert):
         g = self.geo
@@ -464,37 +490,12 @@ class TransRecEngine:
         self.p_sas = float(self.args.drop_rate)
         f32 = torch.float32
         self.sas_blocks = []
-        for j, blk in enumerate(te.transformer_blocks):
+        kad = type(te.transformer_blocks).__name__ == 'SASRecKAdaptedTransformerBlocks'       # model.py:562-583
+        block_list = te.transformer_blocks.transformer_blocks if kad else te.transformer_blocks
+        for j, blk in enumerate(block_list):
             tb = blk.transformer_block if hasattr(blk, 'transformer_block') else blk
-            mha, ff = tb.multi_head_attention, tb.feed_forward
-            b = _Block()
-            b.lora = []
-            for slot, lin in enumerate((mha.w_Q, mha.w_K, mha.w_V)):
-                if type(lin).__name__ == 'LoRALinear':
-                    b.lora.append(_Lora(lin, E, self, f32, slot))
-                elif type(lin).__name__ != 'Linear':
-                    raise NotImplementedError(f'projection module {type(lin).__name__}')
-            b.H, b.F, b.nh, b.dh, b.S = E, ff.w_1.out_features, nh, E // nh, self.Lseq - 1
-            b.causal, b.mask_neg, b.scale = True, -1e9, 1.0 / math.sqrt(E // nh)
-            b.ffn_act = L.ACT_RELU
-            b.p_hidden, b.p_attn, b.site = self.p_sas, self.p_sas, 4096 + 16 * j
-            b.wqkv = torch.zeros(3 * E, E, dtype=f32, device=self.dev)
-            b.wqkvT = torch.zeros(E, 3 * E, dtype=f32, device=self.dev)
-            b.bqkv = torch.zeros(3 * E, dtype=f32, device=self.dev) if b.lora else None       # lora.Linear carries a bias
-            b.qkv = tuple(None if type(lin).__name__ == 'LoRALinear' else
-                          _Dense(self, lin.weight, None, f32, b.wqkv[sl * E:(sl + 1) * E], b.wqkvT[:, sl * E:(sl + 1) * E])
-                          for sl, lin in enumerate((mha.w_Q, mha.w_K, mha.w_V)))
-            b.d_o = _Dense(self, mha.fc.weight, None, f32)
-            b.d_i = _Dense(self, ff.w_1.weight, ff.w_1.bias, f32)
-            b.d_o2 = _Dense(self, ff.w_2.weight, ff.w_2.bias, f32)
-            b.wo, b.woT, b.bo = b.d_o.w, b.d_o.wT, None
-            b.wi, b.wiT, b.bi = b.d_i.w, b.d_i.wT, b.d_i.b
-            b.wo2, b.wo2T, b.bo2 = b.d_o2.w, b.d_o2.wT, b.d_o2.b
-            b.train_dense = any(d is not None and d.trainable for d in b.qkv + (b.d_o, b.d_i, b.d_o2))
-            b.ln1, b.ln2 = _LN(mha.layer_norm, self), _LN(ff.layer_norm, self)
+            b = self._make_block(tb, E, nh, self.Lseq - 1, f32, True, -1e9, self.p_sas, 4096 + 16 * j)
             placement = getattr(blk, 'placement', None) if blk is not tb else None
-            b.ad1 = b.ad2 = b.lnn1 = b.lnn2 = None
-            b.pl1 = b.pl2 = None
             if blk is not tb:
                 if placement == 'pfeiffer':
                     b.ad2, b.pl2, b.lnn2 = self._adapter_of(blk, 'adapter', E, f32), 'pfeiffer', _LN(blk.LN, self)
@@ -503,9 +504,99 @@ class TransRecEngine:
                     b.ad2 = self._adapter_of(blk, 'adapter2', E, f32)
                     b.pl1 = (placement or 'serial') if b.ad1 else None
                     b.pl2 = (placement or 'serial') if b.ad2 else None
-            b.need_dx = True
-            b.T = f32
             self.sas_blocks.append(b)
+        self.sas_kads, self.d_com2 = [], None
+        if kad:
+            tbs = te.transformer_blocks
+            self.sas_kads = [self._make_kadapter(m, E, self.Lseq - 1, f32, 5000 + 64 * j) for j, m in enumerate(tbs.adapter_list)]
+            self.d_com2 = _Dense(self, tbs.com_dense2.weight, tbs.com_dense2.bias, f32)
+
+    def _make_block(self, tb, Hv, nh, S, dt, causal, mask_neg, p_drop, site):
+        """A plain post-LN TransformerBlock (modules.py:16-87: bias-free w_Q / w_K / w_V / fc, ReLU FFN with biases, LayerNorm eps
+        1e-6) as an engine _Block.  Widths that are not multiples of 64 (K-Adapter blocks: 16) are stored zero-padded to 64; the
+        LayerNorms run on the valid columns only (b.Hv)."""
+        mha, ff = tb.multi_head_attention, tb.feed_forward
+        H = pad_to(Hv, 64)
+        Fv = ff.w_1.out_features
+        F = pad_to(Fv, 64)
+        dh = Hv // nh
+        if dh not in (32, 64) and not (0 < dh <= 16) or S > 32:
+            raise NotImplementedError(f'transformer block geometry width={Hv} heads={nh} S={S}')
+        b = _Block()
+        b.lora = []
+        for slot, lin in enumerate((mha.w_Q, mha.w_K, mha.w_V)):
+            if type(lin).__name__ == 'LoRALinear':
+                b.lora.append(_Lora(lin, Hv, self, dt, slot))
+            elif type(lin).__name__ != 'Linear':
+                raise NotImplementedError(f'projection module {type(lin).__name__}')
+        if b.lora and H != Hv:
+            raise NotImplementedError('LoRA on a zero-padded block')
+        b.H, b.Hv, b.F, b.nh, b.dh, b.S = H, Hv, F, nh, dh, S
+        b.causal, b.mask_neg, b.scale = causal, mask_neg, 1.0 / math.sqrt(dh)
+        b.ffn_act = L.ACT_RELU
+        b.p_hidden, b.p_attn, b.site = p_drop, p_drop, site
+        b.wqkv = torch.zeros(3 * H, H, dtype=dt, device=self.dev)
+        b.wqkvT = torch.zeros(H, 3 * H, dtype=dt, device=self.dev)
+        b.bqkv = torch.zeros(3 * H, dtype=torch.float32, device=self.dev) if b.lora else None       # lora.Linear carries a bias
+        b.qkv = tuple(None if type(lin).__name__ == 'LoRALinear' else
+                      _Dense(self, lin.weight, None, dt, b.wqkv[sl * H:(sl + 1) * H], b.wqkvT[:, sl * H:(sl + 1) * H])
+                      for sl, lin in enumerate((mha.w_Q, mha.w_K, mha.w_V)))
+        b.d_o = _Dense(self, mha.fc.weight, None, dt, pad=(H, H))
+        b.d_i = _Dense(self, ff.w_1.weight, ff.w_1.bias, dt, pad=(F, H))
+        b.d_o2 = _Dense(self, ff.w_2.weight, ff.w_2.bias, dt, pad=(H, F))
+        b.wo, b.woT, b.bo = b.d_o.w, b.d_o.wT, None
+        b.wi, b.wiT, b.bi = b.d_i.w, b.d_i.wT, b.d_i.b
+        b.wo2, b.wo2T, b.bo2 = b.d_o2.w, b.d_o2.wT, b.d_o2.b
+        b.train_dense = any(d is not None and d.trainable for d in b.qkv + (b.d_o, b.d_i, b.d_o2))
+        b.ln1, b.ln2 = _LN(mha.layer_norm, self), _LN(ff.layer_norm, self)
+        b.ad1 = b.ad2 = b.lnn1 = b.lnn2 = None
+        b.pl1 = b.pl2 = None
+        b.need_dx = True
+        b.T = dt
+        return b
+
+    def _make_kadapter(self, mod, width, S, dt, site):
+        k = _KAdapter()
+        d = mod.down_project.out_features
+        dp = pad_to(d, 64)
+        k.width, k.d, k.dp, k.T = width, d, dp, dt
+        k.down = _Dense(self, mod.down_project.weight, mod.down_project.bias, dt, pad=(dp, width))
+        k.up = _Dense(self, mod.up_project.weight, mod.up_project.bias, dt, pad=(width, dp))
+        p_drop = float(mod.transformer_blocks[0].multi_head_attention.dropout.p)
+        k.blocks = [self._make_block(tb, d, mod.num_head, S, dt, False, 0.0, p_drop, site + 16 * j)
+                    for j, tb in enumerate(mod.transformer_blocks)]
+        k.tag = f'kad{site}'
+        return k
+
+    def _kad_forward(self, k, fus, n_seq, M, train, seed, out, saved):
+        """out = fus + up(block2(block1(down(fus))));  saved: per-adapter buffer dict (training) or None."""
+        T, dp = k.T, k.dp
+        dn = self._buf(k.tag + '.dn', M, dp, T)
+        L.gemm_nt(fus, k.down.w, dn, bias=k.down.b, M=M)
+        x = dn
+        for j, blk in enumerate(k.blocks):
+            bufs = saved['blk'][j] if saved is not None else self._block_bufs(k.tag + f'.b{j}.shared', blk, M, True)
+            nxt = (saved['bo'] if (saved is not None and j == len(k.blocks) - 1) else self._buf(k.tag + f'.o{j}', M, dp, T))
+            self._block_forward(blk, x, None, n_seq, M, bufs, train, seed, nxt)
+            x = nxt
+        L.gemm_nt(x, k.up.w, out, bias=k.up.b, R1=fus, M=M)
+
+    def _kad_bufs(self, k, M):
+        return dict(blk=[self._block_bufs(k.tag + f'.b{j}', blk, M, False) for j, blk in enumerate(k.blocks)],
+                    bo=self._buf(k.tag + '.bo', M, k.dp, k.T), fus=self._buf(k.tag + '.fus', M, k.width, k.T))
+
+    def _kad_backward(self, k, d_out, n_seq, M, train, seed, d_fus, saved):
+        """d_fus = d_out + down^T(blocks^T(up^T d_out)); accumulates the weight gradients of down / up / the two blocks."""
+        T, dp = k.T, k.dp
+        self._dense_wgrad(k.up, d_out, saved['bo'], M)
+        dx = self._buf(k.tag + '.dbo', M, dp, T)
+        L.gemm_nt(d_out, k.up.wT, dx, M=M)
+        for j in range(len(k.blocks) - 1, -1, -1):
+            dprev = self._buf(k.tag + f'.dx{j}', M, dp, T)
+            self._block_backward(k.blocks[j], dx, None, n_seq, M, saved['blk'][j], train, seed, dprev)
+            dx = dprev
+        self._dense_wgrad(k.down, dx, saved['fus'], M)
+        L.gemm_nt(dx, k.down.wT, d_fus, R1=d_out, M=M)
 
     # ------------------------------------------------------------------ buffers
     def _buf(self, name, rows, cols, dt):
@@ -549,13 +640,19 @@ class TransRecEngine:
                     d['sta' + k] = self._buf(pre + '.sta' + k, M, 2, torch.float32)
         return d
 
+    @staticmethod
+    def _vc(blk, t):
+        """The valid columns of a zero-padded block's activation (LayerNorm width), the tensor itself otherwise."""
+        hv = getattr(blk, 'Hv', blk.H)
+        return t if hv == t.shape[1] else t[:, :hv]
+
     # ------------------------------------------------------------------ one block, forward
     def _sub_forward(self, blk, which, dense_in, w, bias, resid, ln, ad, pl, lnn, bufs, M, p_drop, site, seed, out):
         """dense -> dropout -> [adapter] -> LN(residual + .)  for the attention-output (which='1') or FFN-output ('2') half."""
         h, v, st = bufs['h' + which], bufs['v' + which], bufs['st' + which]
         if ad is None:
             L.gemm_nt(dense_in, w, v, bias=bias, R1=resid, drop_p=p_drop, drop_site=site, drop_seed=seed, drop_first=True, M=M)
-            L.ln_fwd(v, ln.gamma, ln.beta, ln.eps, out, st, M=M)
+            L.ln_fwd(self._vc(blk, v), ln.gamma, ln.beta, ln.eps, self._vc(blk, out), st, M=M)
             return
         zp, z = bufs['zp' + which], bufs['z' + which]
         if pl == 'pfeiffer':          # model.py:321-329 / :458-471
@@ -620,7 +717,7 @@ class TransRecEngine:
         gg = lambda f: f() if f is not None else None
         if ad is None:
             dv = self._buf('dv' + which, M, H, T)
-            L.ln_bwd(dy, v, st, ln.gamma, dv, M=M, dgamma=gg(ln.g_gamma), dbeta=gg(ln.g_beta))
+            L.ln_bwd(self._vc(blk, dy), self._vc(blk, v), st, ln.gamma, self._vc(blk, dv), M=M, dgamma=gg(ln.g_gamma), dbeta=gg(ln.g_beta))
             if p_drop > 0:
                 dh = self._buf('dh' + which, M, H, T)
                 L.dropout_apply(dv, dh, p_drop, site, seed, M=M)
@@ -752,9 +849,63 @@ class TransRecEngine:
         if d is None or not d.trainable:
             return
         if d.g_w is not None:
-            L.gemm_tn(dy, x, d.g_w(), M=M)
+            if d.s_w is None:
+                L.gemm_tn(dy, x, d.g_w().view(d.out_f, d.in_f), M=M)
+            else:                                   # zero-padded storage: accumulate into a scratch, add the valid corner
+                d.s_w.zero_()
+                L.gemm_tn(dy, x, d.s_w, M=M)
+                d.g_w().view(d.out_f, d.in_f).add_(d.s_w[:d.out_f, :d.in_f])
         if d.g_b is not None:
-            L.colsum(dy, d.g_b(), M=M)
+            if d.s_b is None:
+                L.colsum(dy, d.g_b(), M=M)
+            else:
+                d.s_b.zero_()
+                L.colsum(dy, d.s_b, M=M)
+                d.g_b().add_(d.s_b[:d.out_f])
+
+    # ------------------------------------------------------------------ K-Adapter chains
+    def _kad_chain_forward(self, x_last, n_items, M, Ip, train, seed, cls, keep):
+        """model.py:546-559: last = 0; for each listed hidden state: last = adapter(hidden + last); cls rows of
+        com_dense([last_hidden ; last]) -> `cls`."""
+        H, T, nb = self.H, self.T, len(self.bert_blocks)
+        if keep and (getattr(self, '_kad_saved_b', None) is None or self._kad_saved_M != M):
+            self._kad_saved_b = [self._kad_bufs(k, M) for k in self.bert_kads]
+            self._kad_saved_M = M
+        last = None
+        for j, (kk, kad) in enumerate(zip(self.bert_klist, self.bert_kads)):
+            sv = self._kad_saved_b[j] if keep else None
+            fus = sv['fus'] if sv is not None else self._buf(kad.tag + '.fus', M, H, T)
+            fus.copy_(x_last if kk == nb else self._buf(f'khs{kk}', M, H, T))
+            if last is not None:
+                fus.add_(last)
+            out = self._buf(kad.tag + '.out', M, H, T)
+            self._kad_forward(kad, fus, n_items, M, train, seed, out, sv)
+            last = out
+        cat = self._buf('kcat', Ip, 2 * H, T)
+        L.gather_rows(x_last, cat[:, :H], n_items, self.S)
+        L.gather_rows(last, cat[:, H:], n_items, self.S)
+        L.gemm_nt(cat, self.d_com.w, cls, bias=self.d_com.b, M=Ip)
+
+    def _kad_chain_backward(self, dcls, n_items, M, Ip, train, seed, dxb):
+        """-> {hidden-state index: gradient buffer} for the backbone (only used when something inside it trains); dxb receives
+        the gradient of the last hidden state that came through com_dense."""
+        H, T, S = self.H, self.T, self.S
+        self._dense_wgrad(self.d_com, dcls, self._buf('kcat', Ip, 2 * H, T), Ip)
+        dcat = self._buf('dkcat', Ip, 2 * H, T)
+        L.gemm_nt(dcls, self.d_com.wT, dcat, M=Ip)
+        dxb.zero_()
+        L.scatter_rows(dcat[:, :H], dxb, n_items, S)
+        dlast = self._buf('kd_last', M, H, T)
+        dlast.zero_()
+        L.scatter_rows(dcat[:, H:], dlast, n_items, S)
+        d_hs = {}
+        for j in range(len(self.bert_kads) - 1, -1, -1):
+            kad, kk = self.bert_kads[j], self.bert_klist[j]
+            d_fus = self._buf(kad.tag + '.dfus', M, H, T)
+            self._kad_backward(kad, dlast, n_items, M, train, seed, d_fus, self._kad_saved_b[j])
+            d_hs[kk] = d_fus if kk not in d_hs else d_hs[kk].add_(d_fus)
+            dlast = d_fus
+        return d_hs
 
     # ------------------------------------------------------------------ item tower / user tower
     def _encode(self, news, n_items, train, seed, saved):
@@ -790,7 +941,11 @@ class TransRecEngine:
             else:
                 self._block_forward(blk, x, key_mask, n_items, M, bufs, train, seed, other)
                 x, other = other, x
-        if not self.cls_only:
+                if (i + 1) in self.bert_klist and i != last:
+                    self._buf(f'khs{i + 1}', M, H, self.T).copy_(x)      # hidden_states[i + 1], read by a K-Adapter below
+        if self.bert_kads:
+            self._kad_chain_forward(x, n_items, M, Ip, train, seed, cls, saved is not None)
+        elif not self.cls_only:
             L.gather_rows(x, cls, n_items, S)
         emb = self._buf('emb', Ip, self.E, torch.float32)
         pre = self._buf('embpre', Ip, self.E, torch.float32)
@@ -806,10 +961,32 @@ class TransRecEngine:
         L.ln_fwd(xin, self.sas_ln0.gamma, self.sas_ln0.beta, self.sas_ln0.eps, x, st0, M=Mu, add=self.pos_emb[:Tn],
                  drop_p=self.p_sas if train else 0.0, drop_site=4000, drop_seed=seed)
         other = self._buf('sx_b', Mu, E, torch.float32)
+        keep = saved is not None
+        if self.sas_kads and keep and (getattr(self, '_kad_saved_s', None) is None or self._kad_saved_Mu != Mu):
+            self._kad_saved_s = [self._kad_bufs(k, Mu) for k in self.sas_kads]
+            self._kad_saved_Mu = Mu
+        last = None
         for j, blk in enumerate(self.sas_blocks):
+            if self.sas_kads:                      # model.py:573-583: the adapter reads (block input + previous adapter output)
+                kad = self.sas_kads[j]
+                sv = self._kad_saved_s[j] if keep else None
+                fus = sv['fus'] if sv is not None else self._buf(kad.tag + '.fus', Mu, E, torch.float32)
+                fus.copy_(x)
+                if last is not None:
+                    fus.add_(last)
+                out = self._buf(kad.tag + '.out', Mu, E, torch.float32)
+                self._kad_forward(kad, fus, B, Mu, train, seed, out, sv)
+                last = out
             bufs = saved[j] if saved is not None else self._block_bufs('sas.shared', blk, Mu, True)
             self._block_forward(blk, x, log_mask, B, Mu, bufs, train, seed, other)
             x, other = other, x
+        if self.sas_kads:
+            cat = self._buf('skcat', Mu, 2 * E, torch.float32)
+            cat[:, :E].copy_(x)
+            cat[:, E:].copy_(last)
+            y = self._buf('sk_y', Mu, E, torch.float32)
+            L.gemm_nt(cat, self.d_com2.w, y, bias=self.d_com2.b, M=Mu)
+            x = y
         return x, Mu
 
     # ------------------------------------------------------------------ public: inference entry points
@@ -898,10 +1075,25 @@ class TransRecEngine:
         L.score_bce_bwd(c['emb'], c['prec'], c['lm'], c['pos'], c['neg'], c['ws'], 1.0, d_prec, d_emb, B, self.Lseq, E, self.arch == 'cpc')
         # SASRec blocks, last to first
         dx = d_prec
+        dlast = None
+        if self.sas_kads:                          # com_dense2 backward: [d block-chain output ; d last adapter output]
+            self._dense_wgrad(self.d_com2, d_prec, self._buf('skcat', Mu, 2 * E, torch.float32), Mu)
+            dcat = self._buf('sk_dcat', Mu, 2 * E, torch.float32)
+            L.gemm_nt(d_prec, self.d_com2.wT, dcat, M=Mu)
+            dx = self._buf('sk_dx', Mu, E, torch.float32)
+            dx.copy_(dcat[:, :E])
+            dlast = self._buf('sk_dlast', Mu, E, torch.float32)
+            dlast.copy_(dcat[:, E:])
         pp = [self._buf('sdx_a', Mu, E, torch.float32), self._buf('sdx_b', Mu, E, torch.float32)]
         for k, j in enumerate(range(len(self.sas_blocks) - 1, -1, -1)):
             self._block_backward(self.sas_blocks[j], dx, c['lm'], B, Mu, c['saved_s'][j], train, seed, pp[k % 2])
             dx = pp[k % 2]
+            if self.sas_kads:
+                kad = self.sas_kads[j]
+                d_fus = self._buf(kad.tag + '.dfus', Mu, E, torch.float32)
+                self._kad_backward(kad, dlast, B, Mu, train, seed, d_fus, self._kad_saved_s[j])
+                dx.add_(d_fus)
+                dlast = d_fus
         d_in = self._buf('sd_in', Mu, E, torch.float32)
         st0 = self._buf('sst0', Mu, 2, torch.float32)
         gg = lambda f: f() if f is not None else None
@@ -938,13 +1130,20 @@ class TransRecEngine:
             if self.d_fc.g_b is not None:
                 L.colsum(d_pre, self.d_fc.g_b(), M=Ip)
         dxb = self._buf('dx_a', M, self.H, self.T)
-        if not self.cls_only:
+        d_hs = {}
+        if self.bert_kads:
+            d_hs = self._kad_chain_backward(dcls, n_items, M, Ip, train, seed, dxb)
+            if not (self.bert_trains or self.train_emb):
+                return                             # frozen backbone: nothing trainable lies upstream of its activations
+        elif not self.cls_only:
             dxb.zero_()
             L.scatter_rows(dcls, dxb, n_items, self.S)
         spare = self._buf('dx_b', M, self.H, self.T)
         last = len(self.bert_blocks) - 1
         for i in range(last, -1, -1):
             blk = self.bert_blocks[i]
+            if (i + 1) in d_hs:
+                dxb.add_(d_hs[i + 1])              # hidden_states[i + 1] also fed a K-Adapter
             if self.cls_only and i == last:
                 self._block_backward(blk, dcls, c['key_mask'], n_items, M, c['saved_b'][i], train, seed,
                                      spare if blk.need_dx else None, cls_rows=Ip)

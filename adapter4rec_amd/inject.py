@@ -17,9 +17,9 @@ def inject_adapters(model, args):
     """Returns the (possibly wrapped: CompacterModel) model with adapters attached."""
     if 'None' in args.adding_adapter_to:
         return model
+    t = args.adapter_type
     layers = model.bert_encoder.text_encoders['title'].bert_model.encoder.layer
     blocks = model.user_encoder.transformer_encoder.transformer_blocks
-    t = args.adapter_type
     if 'pfeiffer_ver2' in t:
         for lyr in layers:
             lyr.attention.output = BertAdaptedSelfOutput(lyr.attention.output, args)
@@ -30,9 +30,12 @@ def inject_adapters(model, args):
             lyr.output = BertPfeifferAdaptedSelfOutput(lyr.output, args)
         for i, blk in enumerate(blocks):
             blocks[i] = SASRecPfeifferAdaptedSelfOutput(blk, args)
-    elif 'kadapter' in t:
-        raise NotImplementedError(f'--adapter_type {t}: K-Adapter is not wired natively: its SASRec-side transformer blocks are 16 wide '
-                                  '(the GEMM kernels need multiples of 64); the narrow-head attention it needs exists (a4r_attn_small.hip)')
+    elif 'kadapter' in t:                               # run.py:409-413
+        from .model.model import BertKAdaptedBertModel, SASRecKAdaptedTransformerBlocks
+        te = model.bert_encoder.text_encoders['title']
+        te.bert_model = BertKAdaptedBertModel(te.bert_model, args)
+        ue = model.user_encoder.transformer_encoder
+        ue.transformer_blocks = SASRecKAdaptedTransformerBlocks(ue.transformer_blocks, args)
     elif 'prompt' in t:                                 # run.py:429-434
         from .model.model import SoftEmbedding
         bm = model.bert_encoder.text_encoders['title'].bert_model

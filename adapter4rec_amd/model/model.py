@@ -15,7 +15,7 @@ from torch.nn.init import xavier_normal_
 
 from .bert import _Container
 from .encoders import Bert_Encoder, User_Encoder
-from .modules import AdapterBlock, AdapterPfeifferBlock, HyperComplexAdapterBlock, PHMLinear
+from .modules import AdapterBlock, AdapterPfeifferBlock, HyperComplexAdapterBlock, KAdapterBlock, PHMLinear
 
 
 def _bert_dim(args):
@@ -108,6 +108,37 @@ class CompacterModel(nn.Module):        # Downstream/Text/run.py:70-83
 
     def forward(self, sample_items, log_mask, local_rank=None):
         return self.model(sample_items, log_mask, local_rank)
+
+
+class BertKAdaptedBertModel(_Container):        # model.py:523-559
+    """Wraps the backbone: K-Adapter blocks read hidden_states[i + 1] for i in --k_adapter_bert_list (chained: each adds the previous
+    adapter's output to its input), com_dense fuses [last_hidden ; last adapter output] back to the hidden width."""
+
+    def __init__(self, bert_model, args):
+        super().__init__()
+        dim = _bert_dim(args)
+        self.bert_model = bert_model
+        self.k_adapter_num_list = [int(i) + 1 for i in str(args.k_adapter_bert_list).split(',')]
+        self.bert_adapter_list = nn.ModuleList([KAdapterBlock(args, args.num_adapter_heads_bert, dim, args.k_adapter_bert_hidden_dim,
+                                                              args.adapter_dropout_rate) for _ in self.k_adapter_num_list])
+        self.com_dense = nn.Linear(dim * 2, dim)
+
+    @property
+    def config(self):
+        return self.bert_model.config
+
+
+class SASRecKAdaptedTransformerBlocks(_Container):   # model.py:562-583
+    """Replaces the ModuleList of SASRec blocks: adapter i reads (block input i + previous adapter output); com_dense2 fuses
+    [last block output ; last adapter output]."""
+
+    def __init__(self, transformer_blocks, args):
+        super().__init__()
+        self.transformer_blocks = transformer_blocks
+        self.len_transformer_blocks = len(transformer_blocks)
+        self.adapter_list = nn.ModuleList([KAdapterBlock(args, args.num_adapter_heads_sasrec, args.embedding_dim, args.adapter_down_size,
+                                                         args.drop_rate) for _ in range(self.len_transformer_blocks)])
+        self.com_dense2 = nn.Linear(args.embedding_dim * 2, args.embedding_dim)
 
 
 class SoftEmbedding(_Container):                # model.py:586-630 (soft prompt)

@@ -77,6 +77,19 @@ class AdapterPfeifferBlock(_Container):         # modules.py:137-158 (no inner r
         self.dropout = nn.Dropout(dropout)
 
 
+class KAdapterBlock(_Container):                # modules.py:161-206 (K-Adapter: down -> 2 plain transformer blocks -> up, + input)
+    def __init__(self, args, num_head, input_size, down_size, dropout=0.1):
+        super().__init__()
+        self.num_head = num_head
+        self.down_project = nn.Linear(input_size, down_size)
+        self.up_project = nn.Linear(down_size, input_size)
+        for lin in (self.down_project, self.up_project):
+            nn.init.normal_(lin.weight, mean=0.0, std=2e-4)
+            nn.init.zeros_(lin.bias)
+        self.transformer_blocks = nn.ModuleList(
+            [TransformerBlock(d_model=down_size, n_heads=num_head, d_inner=down_size * 4, dropout=dropout) for _ in range(2)])
+
+
 class PHMLinear(_Container):                    # layers.py:25-166 in the configuration modules.py:220-249 uses
     def __init__(self, in_features, out_features, phm_dim):
         super().__init__()

@@ -99,6 +99,8 @@ def _attn(qkv, key_mask, n_items, S, nh, dh, offs, causal, scale, mask_neg):
     Hd = nh * dh
     q, k, v = [qkv[:n_items * S, o:o + Hd].view(n_items, S, nh, dh).transpose(1, 2) for o in offs]
     sc = q @ k.transpose(-1, -2) * scale
+    if key_mask is None:
+        key_mask = torch.ones(n_items, S)
     allowed = (key_mask != 0)[:, None, None, :].expand(n_items, 1, S, S)
     if causal:
         allowed = torch.tril(allowed)
@@ -109,7 +111,7 @@ def _attn(qkv, key_mask, n_items, S, nh, dh, offs, causal, scale, mask_neg):
 def attn_fwd(qkv, out, key_mask, n_items, S, n_heads, dh, q_off, k_off, v_off, causal, scale, mask_neg,
              drop_p=0.0, drop_site=0, drop_seed=0):
     assert drop_p == 0.0
-    out[:n_items * S] = _attn(qkv.float(), key_mask, n_items, S, n_heads, dh, (q_off, k_off, v_off), causal, scale, mask_neg).to(out.dtype)
+    out[:n_items * S, :n_heads * dh] = _attn(qkv.float(), key_mask, n_items, S, n_heads, dh, (q_off, k_off, v_off), causal, scale, mask_neg).to(out.dtype)
 
 
 def attn_bwd(qkv, dout, dqkv, key_mask, n_items, S, n_heads, dh, q_off, k_off, v_off, causal, scale, mask_neg,
@@ -118,8 +120,9 @@ def attn_bwd(qkv, dout, dqkv, key_mask, n_items, S, n_heads, dh, q_off, k_off, v
     with torch.enable_grad():
         q = qkv.float().clone().requires_grad_(True)
         o = _attn(q, key_mask, n_items, S, n_heads, dh, (q_off, k_off, v_off), causal, scale, mask_neg)
-        o.backward(dout[:n_items * S].float())
-    dqkv[:n_items * S] = q.grad[:n_items * S].to(dqkv.dtype)
+        o.backward(dout[:n_items * S, :n_heads * dh].float())
+    for off in (q_off, k_off, v_off):            # like the kernels: only the columns of the heads are written
+        dqkv[:n_items * S, off:off + n_heads * dh] = q.grad[:n_items * S, off:off + n_heads * dh].to(dqkv.dtype)
 
 
 def attn_long_fwd(qkv, out, lse, n_items, S, n_heads, dh, q_off, k_off, v_off, scale):

@@ -20,6 +20,8 @@ GEOM = dict(vocab_size=120, hidden_size=128, num_hidden_layers=2, num_attention_
 ARGS = dict(houlsby=dict(), houlsby_gelu=dict(adapter_activation='GELU'), houlsby_parallel=dict(is_serial='None'),
             pfeiffer=dict(adapter_type='pfeiffer', adapter_activation='relu'), pfeiffer_ver2=dict(adapter_type='pfeiffer_ver2'),
             compacter=dict(adapter_type='compacter'), houlsby_cpc=dict(arch='cpc'), prompt=dict(adapter_type='prompt', n_tokens=8),
+            kadapter=dict(adapter_type='kadapter', k_adapter_bert_list='0,1', k_adapter_bert_hidden_dim=64, num_adapter_heads_bert=4,
+                          num_adapter_heads_sasrec=2),
             roberta_cpc_pfeiffer=dict(adapter_type='pfeiffer', adapter_activation='relu', arch='cpc', bert_model_load='roberta_tiny'))
 
 
