@@ -15,7 +15,8 @@
 //
 // forward  (per 16-query block): S^T = K Q^T | softmax | O^T = V^T P^T         + lse = max + log(sum) per query (fp32)
 // backward, two launches (FlashAttention-2 split, no atomics):
-//   dq   (per 16-query block): S^T, dP^T = V dO^T, delta = sum_k P dP, dS = P (dP - delta) scale, dQ^T = K^T dS^T
+//   dq   (per 16-query block): delta = dO . O (forward output), then per chunk step of keys S^T, dP^T = V dO^T,
+//        dS = P (dP - delta) scale, dQ^T += K^T dS^T  (nothing held for the whole key range)
 //   dkdv (per 16-key tile, a wave owns its key tiles): S = Q K^T, dP = dO V^T (tiles with the KEY on the lane),
 //        dV^T += dO^T P, dK^T += Q^T dS  over all query groups; lse and delta come from LDS.
 // HBM-bound in principle (fwd: reads 3 M H, writes M H); measured numbers are in DESIGN.md.
@@ -207,9 +208,9 @@ __global__ void __launch_bounds__(WG<NKT>::NTHR, 4) attn_long_fwd_kernel(const T
 // ------------------------------------------------------------------------------------------------ backward: dq + delta
 template <typename T, int NKT>
 __global__ void __launch_bounds__(WG<NKT>::NTHR, 4) attn_long_dq_kernel(const T* __restrict__ qkv, int ld, int q_off, int k_off, int v_off,
-                                                           const T* __restrict__ dctx, int ldo, const float* __restrict__ lse,
-                                                           float* __restrict__ delta, T* __restrict__ dqkv,
-                                                           int S, int nh, float scale) {
+                                                           const T* __restrict__ dctx, int ldo, const T* __restrict__ octx,
+                                                           const float* __restrict__ lse, float* __restrict__ delta,
+                                                           T* __restrict__ dqkv, int S, int nh, float scale) {
     using G = Geo<T>;
     constexpr int NTHR = WG<NKT>::NTHR, NWAVE = WG<NKT>::NWAVE;
     constexpr int SP = NKT * 16, SPT = SP + 8, NST = SP / G::KSTEP;
@@ -237,40 +238,42 @@ __global__ void __launch_bounds__(WG<NKT>::NTHR, 4) attn_long_dq_kernel(const T*
             dof[ks] = valid ? ldg16(dctx + grow * ldo + h * 64 + (ks * 4 + kg) * G::PER) : make_uint4(0, 0, 0, 0);
         }
         const float lq = valid ? lse[((size_t)item * nh + h) * S + rq] : 0.f;
-        f32x4_t p[NKT];
-        scores_t<T, NKT>(Kr, qf, p, S, scale, fr, kg);
-        // pass 1: delta = sum_k P dP (dP tiles are not kept: holding P and dP for 16 tiles spilled); pass 2 recomputes each
-        // dP tile (2-4 MFMAs) and turns P into dS in place
+        // delta = sum_k P dP = dO . O (the forward output): one dot product per query instead of a pass over all key tiles,
+        // so P, dP and dS are produced and consumed one chunk step (32 / 16 keys) at a time and never held for the whole row
         float dsum = 0.f;
 #pragma unroll
-        for (int kt = 0; kt < NKT; ++kt) {
-            f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
+        for (int ks = 0; ks < G::KS; ++ks) {
+            const uint4 of = valid ? ldg16(octx + grow * ldo + h * 64 + (ks * 4 + kg) * G::PER) : make_uint4(0, 0, 0, 0);
+            float a8[G::PER], b8[G::PER];
+            Elem<T>::unpack(of, a8);
+            Elem<T>::unpack(dof[ks], b8);
 #pragma unroll
-            for (int ks = 0; ks < G::KS; ++ks) Mma<T>::mma(frag_rows<T>(Vr, kt * 16 + fr, ks, kg), dof[ks], acc);
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                p[kt][r] = __expf(p[kt][r] - lq);          // exp(-inf) = 0 for the padded keys
-                dsum += p[kt][r] * acc[r];
-            }
-            if ((kt & 1) == 1) __builtin_amdgcn_sched_barrier(0);
+            for (int e = 0; e < G::PER; ++e) dsum += a8[e] * b8[e];
         }
         dsum = red4(dsum, false);
         if (valid && kg == 0) delta[((size_t)item * nh + h) * S + rq] = dsum;
-#pragma unroll
-        for (int kt = 0; kt < NKT; ++kt) {
-            f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int ks = 0; ks < G::KS; ++ks) Mma<T>::mma(frag_rows<T>(Vr, kt * 16 + fr, ks, kg), dof[ks], acc);
-#pragma unroll
-            for (int r = 0; r < 4; ++r) p[kt][r] = p[kt][r] * (acc[r] - dsum) * scale;
-            if ((kt & 1) == 1) __builtin_amdgcn_sched_barrier(0);
-        }
         f32x4_t o[4];
 #pragma unroll
         for (int dt = 0; dt < 4; ++dt) o[dt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int st = 0; st < NST; ++st) {
-            const uint4 dsf = pack_step<T, NKT>(p, st);
+            f32x4_t ds[G::TPS];
+#pragma unroll
+            for (int t = 0; t < G::TPS; ++t) {
+                const int kt = st * G::TPS + t;
+                f32x4_t sc = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int ks = 0; ks < G::KS; ++ks) {
+                    Mma<T>::mma(frag_rows<T>(Kr, kt * 16 + fr, ks, kg), qf[ks], sc);
+                    Mma<T>::mma(frag_rows<T>(Vr, kt * 16 + fr, ks, kg), dof[ks], dp);
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float pv = (kt * 16 + kg * 4 + r < S) ? __expf(sc[r] * scale - lq) : 0.f;
+                    ds[t][r] = pv * (dp[r] - dsum) * scale;
+                }
+            }
+            const uint4 dsf = pack_step<T, G::TPS>(ds, 0);
 #pragma unroll
             for (int dt = 0; dt < 4; ++dt) Mma<T>::mma(frag_T<T>(Kimg, SPT, dt * 16, st, lane), dsf, o[dt]);
             __builtin_amdgcn_sched_barrier(0);
@@ -393,7 +396,7 @@ template <typename T, int NKT> int run_bwd(hipStream_t s, const a4r_attn_t* a, c
     if (int rc = set_lds(attn_long_dkdv_kernel<T, NKT>, l2)) return rc;
     const dim3 grid(a->n_items * a->n_heads), block(WG<NKT>::NTHR);
     hipLaunchKernelGGL((attn_long_dq_kernel<T, NKT>), grid, block, l1, s, (const T*)a->qkv, a->ld, a->q_off, a->k_off, a->v_off,
-                       (const T*)a->dout, a->ldo, lse, delta, (T*)a->dqkv, a->S, a->n_heads, a->scale);
+                       (const T*)a->dout, a->ldo, (const T*)a->out, lse, delta, (T*)a->dqkv, a->S, a->n_heads, a->scale);
     hipLaunchKernelGGL((attn_long_dkdv_kernel<T, NKT>), grid, block, l2, s, (const T*)a->qkv, a->ld, a->q_off, a->k_off, a->v_off,
                        (const T*)a->dout, a->ldo, lse, (const float*)delta, (T*)a->dqkv, a->S, a->n_heads, a->scale);
     return a4r_launch_status();
@@ -407,7 +410,8 @@ int check(const a4r_attn_t* a, bool bwd) {
     if ((a->ld * es) % 16 || (a->ldo * es) % 16 || (a->q_off * es) % 16 || (a->k_off * es) % 16 || (a->v_off * es) % 16) return A4R_EINVAL;
     if (reinterpret_cast<uintptr_t>(a->qkv) & 15u) return A4R_EINVAL;
     if (!bwd && (!a->out || (reinterpret_cast<uintptr_t>(a->out) & 15u))) return A4R_EINVAL;
-    if (bwd && (!a->dout || !a->dqkv || ((reinterpret_cast<uintptr_t>(a->dout) | reinterpret_cast<uintptr_t>(a->dqkv)) & 15u))) return A4R_EINVAL;
+    if (bwd && (!a->dout || !a->dqkv || !a->out || ((reinterpret_cast<uintptr_t>(a->dout) | reinterpret_cast<uintptr_t>(a->dqkv) | reinterpret_cast<uintptr_t>(a->out)) & 15u)))
+        return A4R_EINVAL;                                                         // bwd reads the forward output too (a->out, same ldo)
     return A4R_OK;
 }
 

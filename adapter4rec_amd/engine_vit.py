@@ -138,6 +138,8 @@ class ViTRecEngine(TransRecEngine):
         d['sta'] = self._buf(pre + '.sta', M, 2, torch.float32)
         d['qkv'] = self._buf(pre + '.qkv', M, 3 * H, T)
         d['lse'] = self._buf(pre + '.lse', (M // blk.S + 1) * blk.nh * blk.S, 1, torch.float32)
+        if not shared:
+            d['ctx_o'] = self._buf(pre + '.ctx_o', M, H, T)                # the attention output: its backward takes delta = dO . O from it
         if Mc is not None:                   # last layer in CLS-only mode: everything after attention has Mc rows
             pre, M = pre + '.cls', Mc
         d['x1'] = self._buf(pre + '.x1', M, H, T)
@@ -179,7 +181,7 @@ class ViTRecEngine(TransRecEngine):
         n1 = bufs['n1'] if 'n1' in bufs else self._buf('n1', M, H, T)
         L.ln_fwd(x, blk.lnA.gamma, blk.lnA.beta, blk.lnA.eps, n1, bufs['sta'], M=M)
         L.gemm_nt(n1, blk.wqkv, bufs['qkv'], bias=blk.bqkv, M=M)
-        ctx = self._buf('ctx', M, H, T)
+        ctx = bufs['ctx_o'] if 'ctx_o' in bufs else self._buf('ctx', M, H, T)
         L.attn_long_fwd(bufs['qkv'], ctx, bufs['lse'], n_items, blk.S, blk.nh, blk.dh, 0, H, 2 * H, blk.scale)
         if cls_rows is not None:
             ctx_c, x_c = self._buf('ctx_c', cls_rows, H, T), self._buf('x_c', cls_rows, H, T)
@@ -256,7 +258,7 @@ class ViTRecEngine(TransRecEngine):
             dx1 = rfull
         dqkv = self._buf('dqkv', M, 3 * H, T)
         ws = self._buf('attn_ws', bufs['lse'].shape[0], 1, torch.float32)
-        L.attn_long_bwd(bufs['qkv'], dctx, dqkv, bufs['lse'], ws, n_items, blk.S, blk.nh, blk.dh, 0, H, 2 * H, blk.scale)
+        L.attn_long_bwd(bufs['qkv'], bufs['ctx_o'], dctx, dqkv, bufs['lse'], ws, n_items, blk.S, blk.nh, blk.dh, 0, H, 2 * H, blk.scale)
         for lo in blk.lora:
             self._lora_backward(blk, lo, dqkv, bufs['n1'], M)
         for sl, d in enumerate(blk.qkv):

@@ -105,8 +105,8 @@ int a4r_attn_bwd(void* stream, const a4r_attn_t* a);
  * causal 0, drop_p 0, else A4R_EINVAL): the ViT / ViT-MAE item tower (HF ViTSelfAttention under
  * Downstream/CV/model/encoders.py:21-32; S = 197 / 50).  One workgroup per (item, head); nothing S x S reaches HBM.
  * fwd also writes lse [n_items, n_heads, S] fp32 (row max + log row sum of the scaled scores), which bwd reads;
- * bwd needs delta_ws [n_items, n_heads, S] fp32 scratch (sum_k P dP, produced by its dq launch, consumed by its
- * dk/dv launch).  fp32 instantiation: backward needs S <= 128 (LDS). */
+ * bwd reads a->out = the ctx fwd wrote (ldo), a->dout = d ctx, and needs delta_ws [n_items, n_heads, S] fp32 scratch
+ * (dO . O per query, produced by its dq launch, consumed by its dk/dv launch).  fp32 instantiation: backward needs S <= 128 (LDS). */
 int a4r_attn_long_fwd(void* stream, const a4r_attn_t* a, float* lse);
 int a4r_attn_long_bwd(void* stream, const a4r_attn_t* a, const float* lse, float* delta_ws);
 

@@ -135,7 +135,7 @@ def attn_long_fwd(qkv, out, lse, n_items, S, n_heads, dh, q_off, k_off, v_off, s
     out[:n_items * S] = _attn(x, km, n_items, S, n_heads, dh, (q_off, k_off, v_off), False, scale, 0.0).to(out.dtype)
 
 
-def attn_long_bwd(qkv, dout, dqkv, lse, delta_ws, n_items, S, n_heads, dh, q_off, k_off, v_off, scale):
+def attn_long_bwd(qkv, out, dout, dqkv, lse, delta_ws, n_items, S, n_heads, dh, q_off, k_off, v_off, scale):
     attn_bwd(qkv, dout, dqkv, torch.ones(n_items, S), n_items, S, n_heads, dh, q_off, k_off, v_off, False, scale, 0.0)
 
 

@@ -264,7 +264,7 @@ def test_attention_long_fwd_bwd(dt, S, nh):
     dout[n_items * S:] = 0
     dqkv = torch.zeros_like(qkv)
     ws = torch.zeros_like(lse)
-    L.attn_long_bwd(qkv, dout, dqkv, lse, ws, n_items, S, nh, dh, *offs, scale)
+    L.attn_long_bwd(qkv, out, dout, dqkv, lse, ws, n_items, S, nh, dh, *offs, scale)
     ref.backward(dout[:n_items * S].float())
     close(dqkv[:n_items * S], qr.grad[:n_items * S], t, f'attn_long bwd S={S} {dt}', atol32=2e-4, rtol32=2e-4,
           atol16=4e-2 * float(qr.grad.abs().max()))
@@ -277,7 +277,7 @@ def test_attention_long_rejects():
     out = torch.zeros(512, 64, device=dev())
     lse = torch.zeros(512, device=dev())
     with pytest.raises(RuntimeError):                                          # fp32 backward needs S <= 128 (LDS)
-        L.attn_long_bwd(qkv, out, torch.zeros_like(qkv), lse, torch.zeros_like(lse), 2, 200, 1, 64, 0, 64, 128, 0.125)
+        L.attn_long_bwd(qkv, out, out, torch.zeros_like(qkv), lse, torch.zeros_like(lse), 2, 200, 1, 64, 0, 64, 128, 0.125)
     with pytest.raises(RuntimeError):
         L.attn_long_fwd(qkv, out, lse, 1, 300, 1, 64, 0, 64, 128, 0.125)       # S > 256
 

@@ -25,7 +25,7 @@ for n_items, S in ((336, 197), (336, 50)):
     lse = torch.zeros(n_items * nh * S, device=dev); ws = torch.zeros_like(lse)
     sc = 1 / math.sqrt(dh)
     tf = t_us(lambda: L.attn_long_fwd(qkv, out, lse, n_items, S, nh, dh, 0, H, 2 * H, sc))
-    tb = t_us(lambda: L.attn_long_bwd(qkv, dout, dqkv, lse, ws, n_items, S, nh, dh, 0, H, 2 * H, sc))
+    tb = t_us(lambda: L.attn_long_bwd(qkv, out, dout, dqkv, lse, ws, n_items, S, nh, dh, 0, H, 2 * H, sc))
     fl = 4.0 * n_items * nh * S * S * dh
     by = 4.0 * n_items * S * H * 2
     print(f'S={S} items={n_items}: fwd {tf:.1f} us ({fl/tf/1e6:.1f} TF/s, {by/tf/1e6:.2f} TB/s)  bwd {tb:.1f} us ({2.5*fl/tb/1e6:.1f} TF/s, {2*by/tb/1e6:.2f} TB/s)')
