@@ -52,7 +52,11 @@ def test_cv_run_adapter_one_epoch(tmp_path, monkeypatch):
     root = str(tmp_path)
     _write_dataset(root)
     monkeypatch.chdir(tmp_path)
-    for k, v in dict(MASTER_ADDR='127.0.0.1', MASTER_PORT='29517', WORLD_SIZE='1', RANK='0', LOCAL_RANK='0').items():
+    import socket
+    with socket.socket() as sk:                       # a free rendezvous port
+        sk.bind(('127.0.0.1', 0))
+        port = sk.getsockname()[1]
+    for k, v in dict(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), WORLD_SIZE='1', RANK='0', LOCAL_RANK='0').items():
         monkeypatch.setenv(k, v)
     try:
         run_adapter.main(['--root_data_dir', root, '--dataset', 'toy', '--lmdb_data', 'image.pkl', '--CV_model_load', 'vit-base-patch16-224',
