@@ -245,7 +245,7 @@ static int run_256(hipStream_t s, const a4r_gemm_t& g) {
 
 extern "C" int a4r_gemm_variant(int v) {
     const int old = g_variant;
-    if (v >= 0 && v <= 3) g_variant = v;
+    if (v >= 0 && v <= 4) g_variant = v;     // 0/1: 128-tile kernels, 2: automatic (default), 3: four-wave 256 tile, 4: eight-wave 256 tile forced
     return old;
 }
 
@@ -272,8 +272,11 @@ extern "C" int a4r_gemm_nt(void* stream, const a4r_gemm_t* gp) {
         // a second launch instead of costing a full round (N = 768, K = 3072: 4 -> 3 rounds + ~1/4).
         const int ntm = g.M / 256, ntn = g.N / 256, tiles = ntm * ntn, ncu = a4r_cu_count();
         const int rem = tiles % ncu;
+        // fewer 256-tiles than half the CUs (8 users: 120 tiles at N = 768): the 128-tile kernel fills the chip better
+        // (measured 505 vs 454, 735 vs 624, 774 vs 637 TF/s at M = 10240; the large tile wins from 198 tiles on)
+        if (tiles * 2 <= ncu && g_variant == 2) goto small_tiles;
         // (measured on the ViT step: 194 vs 190 user-seq/s with the split applied at every K against long K only)
-        if (tiles > ncu && rem > 0 && rem * 4 <= ncu && rem % ntn == 0) {
+        if (tiles > ncu && rem > 0 && rem * 4 <= ncu && rem % ntn == 0 && g_variant != 4) {
             const int64_t head_rows = (int64_t)(ntm - rem / ntn) * 256;
             a4r_gemm_t g1 = g, g2 = g;
             g1.M = (int)head_rows;
@@ -299,6 +302,7 @@ extern "C" int a4r_gemm_nt(void* stream, const a4r_gemm_t* gp) {
             if (rc != 1) return rc;              // 1 = this (dtype, act, dact) combination has no large-tile instantiation
         }
     }
+small_tiles:
     if (g.in_dtype == A4R_BF16 && g.out_dtype == A4R_BF16) return launch_bn<bf16_t, bf16_t>(s, g);
     if (g.in_dtype == A4R_F32 && g.out_dtype == A4R_F32) return launch_bn<float, float>(s, g);
     if (g.in_dtype == A4R_BF16 && g.out_dtype == A4R_F32) return launch_bn<bf16_t, float>(s, g);

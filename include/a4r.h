@@ -58,7 +58,9 @@ typedef struct {
 int a4r_gemm_nt(void* stream, const a4r_gemm_t* g);
 /* tuning knob for A/B measurements: 0 = 128x128 tile, register-staged K pipeline; 1 = 128x128 tile, direct-to-LDS
  * (global_load_lds) pipeline; 2 (default) = 256x256 tile with a 2-deep LDS-DMA ring kept in flight across barriers
- * wherever M % 256 == 0, N % 256 == 0 and K spans >= 2 stages, variant 1 elsewhere.  Results agree to fp32
+ * wherever M % 256 == 0, N % 256 == 0 (variant 1 elsewhere), chosen automatically: fewer 256-tiles than half the CUs -> the
+ * 128-tile kernel; a last round of only a few whole row panels -> those panels on the 128-tile kernel; 3 = the four-wave
+ * form of the 256 tile (measured slower); 4 = the eight-wave 256 tile forced (tests).  Results agree to fp32
  * summation order; returns the previous setting (any other v only queries). */
 int a4r_gemm_variant(int v);
 

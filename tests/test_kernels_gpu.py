@@ -53,7 +53,7 @@ def act_ref(x, act):
 
 
 # ------------------------------------------------------------------ GEMM NT
-@pytest.fixture(params=[3, 2, 1, 0], ids=['tile256w4', 'tile256', 'glds', 'regstage'])
+@pytest.fixture(params=[4, 3, 2, 1, 0], ids=['tile256', 'tile256w4', 'auto', 'glds', 'regstage'])
 def gemm_variant(request):
     from adapter4rec_amd import _lib as L
     old = L.gemm_variant(request.param)

@@ -18,7 +18,7 @@ def main():
         C = torch.zeros(M, N, dtype=torch.bfloat16, device=dev)
         bias = torch.zeros(N, device=dev)
         for rnd in range(3):
-            for v in (2, 3):
+            for v in ([int(x) for x in os.environ['A4R_VARIANTS'].split(',')] if 'A4R_VARIANTS' in os.environ else (2, 3)):
                 L.gemm_variant(v)
                 for _ in range(3):
                     L.gemm_nt(A, B, C, bias=bias)
