@@ -311,14 +311,14 @@ def main():
                     avg_launch_us=round(t / n * 1e6, 2), flop_per_launch=f / n,
                     all_gemm_tflops=round(total_f / total_t / 1e12, 2), gemm_time_share_of_step=round(total_t / 2 / (dt / a.steps), 3))
         # fabric/HBM bytes per launch of that kernel: not measurable from inside the process -- taken from the committed
-        # rocprofv3 PMC passes over this same command (profiles/r01_e_pmc_hbm_traffic.json says how), B=32 bf16 only.
-        pmc = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles', 'r01_e_pmc_hbm_traffic.json')
+        # rocprofv3 PMC passes over this same command (profiles/r01_f_pmc_hbm_traffic.json says how), B=32 bf16 only.
+        pmc = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles', 'r01_f_pmc_hbm_traffic.json')
         if key[2][0] == 256 and a.dtype == 'bf16' and a.batch == 32 and os.path.exists(pmc):
             mangled = f'gemm_nt_256_kernelIDF16bDF16bLi{key[2][1]}ELi{key[2][2]}E'
             for kname, rec in json.load(open(pmc))['kernels'].items():
                 if mangled in kname:
                     roof['traffic'] = rec['traffic_bytes_per_launch']
-                    roof['traffic_source'] = 'profiles/r01_e_pmc_hbm_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, 2 x FETCH correction)'
+                    roof['traffic_source'] = 'profiles/r01_f_pmc_hbm_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, 2 x FETCH correction)'
         if os.environ.get('A4R_BENCH_SHAPES'):
             print(json.dumps(shapes, indent=1), file=sys.stderr)
 
