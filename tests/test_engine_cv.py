@@ -285,3 +285,50 @@ def test_cv_host_logic_other_geometry(simulated):
 @pytest.mark.gpu
 def test_cv_other_geometry_gpu():
     _check_other_geometry('cuda:0')
+
+
+def _cv_eval_case(dev):
+    """Image path eval: item sweep from a record store (pad item 0 = all-zero float image, dataset.py:163-166) + user ranks,
+    against the oracle's image_encoder / eval_ranks."""
+    import logging
+    from adapter4rec_amd.cv.data_utils import eval_model, get_itemLMDB_embeddings
+    from adapter4rec_amd.cv.image_io import RecordStore
+    from adapter4rec_amd.data_utils.metrics import eval_ranks
+    from oracle import ref_cpu as R
+    root, args, sd, cfg, fx, images, mask, noise = build('cv_vit_houlsby', device=dev)
+    rng = np.random.default_rng(21)
+    n_items = 40
+    st, keys, raw = RecordStore(), {}, [np.zeros((32, 32, 3), np.uint8)]
+    for i in range(1, n_items + 1):
+        a = rng.integers(0, 256, (32, 32, 3), dtype=np.uint8)
+        keys[i] = f'i{i}'.encode()
+        st.add(keys[i], a, i)
+        raw.append(a)
+    emb = get_itemLMDB_embeddings(root, n_items, keys, 16, args, dev, db=st)
+    ref_in = R.normalize_u8(torch.from_numpy(np.stack(raw)))
+    ref_in[0] = 0
+    with torch.no_grad():
+        ref = R.image_encoder(sd, ref_in, cfg)
+    np.testing.assert_allclose(emb.cpu().numpy(), ref.numpy(), atol=1e-4, rtol=0)
+    eval_seq, hist = {}, {}
+    for u in range(9):
+        seq = [int(x) for x in rng.choice(np.arange(1, n_items + 1), size=int(rng.integers(3, 22)), replace=False)]
+        eval_seq[u], hist[u] = seq, torch.LongTensor(seq[:-1])
+    ranks = eval_ranks(root, hist, eval_seq, emb, 4, args, list(range(9))).cpu().numpy()
+    _, oranks = R.eval_ranks(sd, ref, eval_seq, hist, cfg)
+    assert (np.abs(ranks - oranks) <= 1).all() and (ranks == oranks).mean() >= 0.8       # equal up to an fp32 near-tie
+    hit = eval_model(root, hist, eval_seq, emb, 4, args, n_items, logging.getLogger('cv-eval'), 'valid', dev)
+    assert abs(hit - R.hit_ndcg(oranks)[0]) <= 1.0 / 9 + 1e-6
+
+
+def test_cv_host_logic_eval(simulated, monkeypatch):
+    import adapter4rec_amd.data_utils.metrics as MT
+    import adapter4rec_amd.cv.image_io as IO
+    monkeypatch.setattr(MT, 'L', sim_lib)
+    monkeypatch.setattr(IO, 'L', sim_lib)
+    _cv_eval_case('cpu')
+
+
+@pytest.mark.gpu
+def test_cv_eval_gpu():
+    _cv_eval_case('cuda:0')
