@@ -232,11 +232,16 @@ inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 
 
 int a4r_gemm_nt_256(hipStream_t s, const a4r_gemm_t& g);   // a4r_gemm256.hip
 int a4r_gemm_nt_256w4(hipStream_t s, const a4r_gemm_t& g); // a4r_gemm256w4.hip (variant 3: four waves of 128 x 128)
+int a4r_gemm_nt_256s(hipStream_t s, const a4r_gemm_t& g);  // a4r_gemm256s.hip (variant 5: four waves, K-tile double buffer, spread DMA stream)
 static int run_256(hipStream_t s, const a4r_gemm_t& g);
 int a4r_cu_count();                                          // a4r_gemm256.hip: CU count rounded down to a multiple of 8
 
 static int run_256(hipStream_t s, const a4r_gemm_t& g) {
-    if (g_variant >= 3) {
+    if (g_variant == 5) {
+        const int rc = a4r_gemm_nt_256s(s, g);
+        if (rc != 1) return rc;
+    }
+    if (g_variant == 3) {
         const int rc = a4r_gemm_nt_256w4(s, g);
         if (rc != 1) return rc;
     }
@@ -245,7 +250,7 @@ static int run_256(hipStream_t s, const a4r_gemm_t& g) {
 
 extern "C" int a4r_gemm_variant(int v) {
     const int old = g_variant;
-    if (v >= 0 && v <= 4) g_variant = v;     // 0/1: 128-tile kernels, 2: automatic (default), 3: four-wave 256 tile, 4: eight-wave 256 tile forced
+    if (v >= 0 && v <= 5) g_variant = v;     // 0/1: 128-tile kernels, 2: automatic (default), 3: four-wave 256 tile, 4: eight-wave 256 tile forced, 5: four-wave stream kernel forced
     return old;
 }
 
@@ -276,7 +281,7 @@ extern "C" int a4r_gemm_nt(void* stream, const a4r_gemm_t* gp) {
         // (measured 505 vs 454, 735 vs 624, 774 vs 637 TF/s at M = 10240; the large tile wins from 198 tiles on)
         if (tiles * 2 <= ncu && g_variant == 2) goto small_tiles;
         // (measured on the ViT step: 194 vs 190 user-seq/s with the split applied at every K against long K only)
-        if (tiles > ncu && rem > 0 && rem * 4 <= ncu && rem % ntn == 0 && g_variant != 4) {
+        if (tiles > ncu && rem > 0 && rem * 4 <= ncu && rem % ntn == 0 && g_variant < 4) {
             const int64_t head_rows = (int64_t)(ntm - rem / ntn) * 256;
             a4r_gemm_t g1 = g, g2 = g;
             g1.M = (int)head_rows;

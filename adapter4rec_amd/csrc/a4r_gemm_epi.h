@@ -111,3 +111,94 @@ A4R_DEV void epilogue_n(float (&v)[NC], const float* bias, size_t grow, int gcol
     if (e.thr16 && !e.drop_first) epi_dropout<NC>(v, e0, e.drop_seed, e.drop_site, e.thr16, e.keep_scale);
     store_n<TO, NC>(e.C + grow * e.ldc + gcol, v);
 }
+
+// ---- two-stage form of the same epilogue: the loads of a group (Pre, R1, R2: 16 B per operand for bf16, 32 B for fp32) are issued
+// by epi_issue() and consumed by epi_finish().  A caller that issues row mi + 1 BEFORE it finishes row mi keeps a row of loads in
+// flight behind the stores; with the single-stage epilogue_n() every group waited for its own loads (they cannot be hoisted above
+// the previous group's store: C may alias R1 for all the compiler knows), i.e. one L2 round trip per group.
+template <typename TO>
+struct EpiLoads {
+    static constexpr int S = (int)sizeof(TO) / 2;       // uint4 per 8 elements
+    uint4 pre[S], r1[S], r2[S];
+};
+
+template <typename TO, int DACT = -1>
+A4R_DEV void epi_issue(EpiLoads<TO>& L, size_t grow, int gcol, const GemmEpi<TO>& e) {
+    constexpr int S = EpiLoads<TO>::S, PER = 16 / (int)sizeof(TO);
+    const int dact = DACT >= 0 ? DACT : e.dact;
+    if (dact != A4R_ACT_NONE) {
+#pragma unroll
+        for (int s = 0; s < S; ++s) L.pre[s] = *reinterpret_cast<const uint4*>(e.Pre + grow * e.ldpre + gcol + s * PER);
+    }
+    if (e.R1) {
+#pragma unroll
+        for (int s = 0; s < S; ++s) L.r1[s] = *reinterpret_cast<const uint4*>(e.R1 + grow * e.ldr1 + gcol + s * PER);
+    }
+    if (e.R2) {
+#pragma unroll
+        for (int s = 0; s < S; ++s) L.r2[s] = *reinterpret_cast<const uint4*>(e.R2 + grow * e.ldr2 + gcol + s * PER);
+    }
+}
+
+template <typename TO>
+A4R_DEV void epi_unpack8(const uint4* q, float* o) {
+#pragma unroll
+    for (int s = 0; s < EpiLoads<TO>::S; ++s) Elem<TO>::unpack(q[s], o + s * Elem<TO>::PER16);
+}
+
+template <typename TO, int ACT = -1, int DACT = -1>
+A4R_DEV void epi_finish(float (&v)[8], const float* bias, const EpiLoads<TO>& L, size_t grow, int gcol, const GemmEpi<TO>& e) {
+    constexpr int NC = 8;
+    const int act = ACT >= 0 ? ACT : e.act;
+    const int dact = DACT >= 0 ? DACT : e.dact;
+#pragma unroll
+    for (int i = 0; i < NC; ++i) v[i] = v[i] * e.alpha + bias[i];
+    if (act == A4R_ACT_GELU && e.C2 && e.c2_mode) {          // value and derivative from one exp + one rcp
+        float d[NC];
+#pragma unroll
+        for (int i = 0; i < NC; ++i) gelu_erf_both(v[i], v[i], d[i]);
+        store_n<TO, NC>(e.C2 + grow * e.ldc2 + gcol, d);
+    } else {
+        if (e.C2) {
+            if (e.c2_mode) {
+                float d[NC];
+#pragma unroll
+                for (int i = 0; i < NC; ++i) d[i] = act_bwd(v[i], act);
+                store_n<TO, NC>(e.C2 + grow * e.ldc2 + gcol, d);
+            } else {
+                store_n<TO, NC>(e.C2 + grow * e.ldc2 + gcol, v);
+            }
+        }
+        if (act != A4R_ACT_NONE) {
+#pragma unroll
+            for (int i = 0; i < NC; ++i) v[i] = act_fwd(v[i], act);
+        }
+    }
+    if (dact != A4R_ACT_NONE) {
+        float pre[NC];
+        epi_unpack8<TO>(L.pre, pre);
+        if (dact == A4R_DACT_MUL_) {
+#pragma unroll
+            for (int i = 0; i < NC; ++i) v[i] *= pre[i];
+        } else {
+#pragma unroll
+            for (int i = 0; i < NC; ++i) v[i] *= act_bwd(pre[i], dact);
+        }
+    }
+    const uint64_t e0 = ((uint64_t)grow + e.row0) * (uint64_t)e.N + (uint64_t)gcol;
+    if (e.thr16 && e.drop_first) epi_dropout<NC>(v, e0, e.drop_seed, e.drop_site, e.thr16, e.keep_scale);
+    if (e.R1) {
+        float t[NC];
+        epi_unpack8<TO>(L.r1, t);
+#pragma unroll
+        for (int i = 0; i < NC; ++i) v[i] += t[i];
+    }
+    if (e.R2) {
+        float t[NC];
+        epi_unpack8<TO>(L.r2, t);
+#pragma unroll
+        for (int i = 0; i < NC; ++i) v[i] += t[i];
+    }
+    if (e.thr16 && !e.drop_first) epi_dropout<NC>(v, e0, e.drop_seed, e.drop_site, e.thr16, e.keep_scale);
+    store_n<TO, NC>(e.C + grow * e.ldc + gcol, v);
+}

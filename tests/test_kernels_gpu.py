@@ -53,7 +53,7 @@ def act_ref(x, act):
 
 
 # ------------------------------------------------------------------ GEMM NT
-@pytest.fixture(params=[4, 3, 2, 1, 0], ids=['tile256', 'tile256w4', 'auto', 'glds', 'regstage'])
+@pytest.fixture(params=[5, 4, 3, 2, 1, 0], ids=['tile256s', 'tile256', 'tile256w4', 'auto', 'glds', 'regstage'])
 def gemm_variant(request):
     from adapter4rec_amd import _lib as L
     old = L.gemm_variant(request.param)
@@ -538,6 +538,35 @@ def test_adapter_fwd_fused(H, act, inner):
     close(y, y_r, t, 'adapter y')
     close(stats[:, 0], v_r.mean(-1), torch.float32, 'adapter mean', atol32=2e-3, rtol32=1e-3)
     close(stats[:, 1], torch.rsqrt(v_r.var(-1, unbiased=False) + 1e-12), torch.float32, 'adapter rstd', atol32=2e-3, rtol32=2e-3)
+
+
+@pytest.mark.parametrize('N,K', [(768, 768), (768, 64), (256, 3072), (1024, 192)])
+def test_gemm_stream_kernel_many_tiles(N, K):
+    """Four-wave stream kernel (variant 5) with more output tiles than CUs: the LDS-DMA stream runs on across output-tile
+    boundaries (the last two K-tiles of a tile fetch the first two of the workgroup's next tile), odd and even K-tile counts,
+    a single K-tile (K = 64), residual + bias + dropout epilogue; compared with torch and with the eight-wave kernel."""
+    from adapter4rec_amd import _lib as L
+    M = 256 * 301                                             # 301 row panels: 903 / 301 / 1204 tiles on 256 CUs
+    A = rnd(M, K, dtype=torch.bfloat16, seed=81)
+    B = rnd(N, K, dtype=torch.bfloat16, scale=0.05, seed=82)
+    R1 = rnd(M, N, dtype=torch.bfloat16, seed=83)
+    bias = rnd(N, seed=84)
+    outs = []
+    for v in (5, 4):
+        L.gemm_variant(v)
+        C = torch.zeros(M, N, dtype=torch.bfloat16, device=dev())
+        L.gemm_nt(A, B, C, bias=bias, R1=R1, drop_p=0.25, drop_site=6, drop_seed=77, drop_first=True)
+        P = torch.zeros(M, N, dtype=torch.bfloat16, device=dev())
+        L.gemm_nt(A, B, P)
+        outs.append((C, P))
+    L.gemm_variant(2)
+    (c_s, p_s), (c_8, p_8) = outs
+    ref = A[:4096].float() @ B.float().t()
+    close(p_s[:4096], ref, torch.bfloat16, 'stream kernel head rows')
+    ref = A[-4096:].float() @ B.float().t()
+    close(p_s[-4096:], ref, torch.bfloat16, 'stream kernel tail rows')
+    assert torch.equal(p_s, p_8), 'same MFMA order per output element: the two kernels must agree bit for bit'
+    assert torch.equal(c_s, c_8)
 
 
 def test_gemm_tail_panels_split_launch():
