@@ -220,6 +220,7 @@ def main():
     ap.add_argument('--dtype', default='bf16', choices=['bf16', 'fp32'])
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-roofline', action='store_true')
+    ap.add_argument('--gemm-variant', type=int, default=-1, help='A/B knob of a4r_gemm_variant (include/a4r.h); default: the library default')
     a = ap.parse_args()
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -235,6 +236,8 @@ def main():
     assert world == a.gpus or world == 1, f'--gpus {a.gpus} but WORLD_SIZE={world}'
 
     from adapter4rec_amd import _lib as L
+    if a.gemm_variant >= 0:
+        L.gemm_variant(a.gemm_variant)
     wl = a.workload
     a.batch = a.batch or WORKLOADS[wl][1]
     image = wl in ('vit_lora', 'mae_compacter')

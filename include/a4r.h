@@ -60,8 +60,10 @@ int a4r_gemm_nt(void* stream, const a4r_gemm_t* g);
  * (global_load_lds) pipeline; 2 (default) = 256x256 tile with a 2-deep LDS-DMA ring kept in flight across barriers
  * wherever M % 256 == 0, N % 256 == 0 (variant 1 elsewhere), chosen automatically: fewer 256-tiles than half the CUs -> the
  * 128-tile kernel; a last round of only a few whole row panels -> those panels on the 128-tile kernel; 3 = the four-wave
- * form of the 256 tile (measured slower); 4 = the eight-wave 256 tile forced (tests).  Results agree to fp32
- * summation order; returns the previous setting (any other v only queries). */
+ * form of the 256 tile (measured slower); 4 = the eight-wave 256 tile forced (tests); 5 = the four-wave stream kernel
+ * (a4r_gemm256s.hip: K-tile double buffer, one LDS-DMA stream across output tiles; bf16, within 10 % of variant 4 either way
+ * depending on the epilogue) forced.  Results of 2 / 4 / 5 agree bit for bit (same MFMA order per output element), the others
+ * to fp32 summation order; returns the previous setting (any other v only queries). */
 int a4r_gemm_variant(int v);
 
 /* C[P,Q] (fp32, +=) = X[M,P]^T . Y[M,Q]: weight gradients of the trainable adapter matrices
