@@ -362,6 +362,15 @@ __global__ void __launch_bounds__(512, 2) gemm_nt_256_kernel(const a4r_gemm_t p,
     for (int pr = 0; pr < 2; ++pr)
 #pragma unroll
         for (int e = 0; e < 8; ++e) bias8[pr][e] = epi.bias ? epi.bias[gcolp + pr * 32 + e] : 0.f;
+    // DACT instantiations (dgrad through an activation: C = acc * act'(Pre)): the Pre operand of row mi + 1 is requested before
+    // row mi is finished and stored -- a load waited for where it is issued costs an L2 / HBM round trip per group, and it cannot
+    // be hoisted above the previous group's store by the compiler (C may alias Pre for all it knows).
+    constexpr int PS = DACT != A4R_ACT_NONE ? 8 * (int)sizeof(TO) / 16 : 1;
+    uint4 pre_ld[2][2][PS];
+    if constexpr (DACT != A4R_ACT_NONE) {
+        load_pre_n<TO, 8>(pre_ld[0][0], grow0, gcolp, epi);
+        load_pre_n<TO, 8>(pre_ld[0][1], grow0, gcolp + 32, epi);
+    }
 #define A4R_EPI_PAIR(mi_, pr_)                                                                                              \
     {                                                                                                                       \
         float v_[8];                                                                                                        \
@@ -371,9 +380,15 @@ __global__ void __launch_bounds__(512, 2) gemm_nt_256_kernel(const a4r_gemm_t p,
             v_[r_] = __uint_as_float(sw_[0]);                                                                               \
             v_[4 + r_] = __uint_as_float(sw_[1]);                                                                           \
         }                                                                                                                   \
-        epilogue_n<TO, 8, ACT, DACT>(v_, bias8[pr_], grow0 + (mi_) * 16, gcolp + (pr_) * 32, epi);                                         \
+        epilogue_n<TO, 8, ACT, DACT>(v_, bias8[pr_], grow0 + (mi_) * 16, gcolp + (pr_) * 32, epi,                           \
+                                     DACT != A4R_ACT_NONE ? pre_ld[(mi_) & 1][pr_] : nullptr);                              \
     }
-#define A4R_EPI_ROW(mi_) A4R_EPI_PAIR(mi_, 0) A4R_EPI_PAIR(mi_, 1)
+#define A4R_EPI_ROW(mi_)                                                                                                    \
+    if constexpr (DACT != A4R_ACT_NONE && (mi_) < 7) {                                                                      \
+        load_pre_n<TO, 8>(pre_ld[((mi_) + 1) & 1][0], grow0 + ((mi_) + 1) * 16, gcolp, epi);                                \
+        load_pre_n<TO, 8>(pre_ld[((mi_) + 1) & 1][1], grow0 + ((mi_) + 1) * 16, gcolp + 32, epi);                           \
+    }                                                                                                                       \
+    A4R_EPI_PAIR(mi_, 0) A4R_EPI_PAIR(mi_, 1)
     A4R_EPI_ROW(0) A4R_EPI_ROW(1) A4R_EPI_ROW(2) A4R_EPI_ROW(3) A4R_EPI_ROW(4) A4R_EPI_ROW(5) A4R_EPI_ROW(6) A4R_EPI_ROW(7)
 #undef A4R_EPI_ROW
 #undef A4R_EPI_PAIR

@@ -56,8 +56,15 @@ A4R_DEV void epi_dropout(float (&v)[NC], uint64_t e0, uint64_t seed, uint32_t si
     }
 }
 
+// pre_ld != nullptr: the NC elements of Pre were requested earlier by the caller (16-byte pieces; see load_pre_n)
+template <typename TO, int NC> A4R_DEV void load_pre_n(uint4* q, size_t grow, int gcol, const GemmEpi<TO>& e) {
+#pragma unroll
+    for (int s = 0; s < NC * (int)sizeof(TO) / 16; ++s)
+        q[s] = *reinterpret_cast<const uint4*>(e.Pre + grow * e.ldpre + gcol + s * (16 / (int)sizeof(TO)));
+}
+
 template <typename TO, int NC, int ACT = -1, int DACT = -1>
-A4R_DEV void epilogue_n(float (&v)[NC], const float* bias, size_t grow, int gcol, const GemmEpi<TO>& e) {
+A4R_DEV void epilogue_n(float (&v)[NC], const float* bias, size_t grow, int gcol, const GemmEpi<TO>& e, const uint4* pre_ld = nullptr) {
     const int act = ACT >= 0 ? ACT : e.act;
     const int dact = DACT >= 0 ? DACT : e.dact;
 #pragma unroll
@@ -85,7 +92,12 @@ A4R_DEV void epilogue_n(float (&v)[NC], const float* bias, size_t grow, int gcol
     }
     if (dact != A4R_ACT_NONE) {
         float pre[NC];
-        load_n<TO, NC>(e.Pre + grow * e.ldpre + gcol, pre);
+        if (pre_ld) {
+#pragma unroll
+            for (int s = 0; s < NC / Elem<TO>::PER16; ++s) Elem<TO>::unpack(pre_ld[s], pre + s * Elem<TO>::PER16);
+        } else {
+            load_n<TO, NC>(e.Pre + grow * e.ldpre + gcol, pre);
+        }
         if (dact == A4R_DACT_MUL_) {
 #pragma unroll
             for (int i = 0; i < NC; ++i) v[i] *= pre[i];
