@@ -232,6 +232,7 @@ inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 
 
 int a4r_gemm_nt_256(hipStream_t s, const a4r_gemm_t& g);   // a4r_gemm256.hip
 int a4r_gemm_nt_256w4(hipStream_t s, const a4r_gemm_t& g); // a4r_gemm256w4.hip (variant 3: four waves of 128 x 128)
+int a4r_gemm_nt_skinny64(hipStream_t s, const a4r_gemm_t& g); // a4r_gemm_skinny.hip (N == 64, bf16 in: the adapter down-projections)
 int a4r_gemm_nt_256s(hipStream_t s, const a4r_gemm_t& g);  // a4r_gemm256s.hip (variant 5: four waves, K-tile double buffer, spread DMA stream)
 static int run_256(hipStream_t s, const a4r_gemm_t& g);
 int a4r_cu_count();                                          // a4r_gemm256.hip: CU count rounded down to a multiple of 8
@@ -308,6 +309,10 @@ extern "C" int a4r_gemm_nt(void* stream, const a4r_gemm_t* gp) {
         }
     }
 small_tiles:
+    if (g.N == 64 && g_variant >= 2) {
+        const int rc = a4r_gemm_nt_skinny64(s, g);
+        if (rc != 1) return rc;
+    }
     if (g.in_dtype == A4R_BF16 && g.out_dtype == A4R_BF16) return launch_bn<bf16_t, bf16_t>(s, g);
     if (g.in_dtype == A4R_F32 && g.out_dtype == A4R_F32) return launch_bn<float, float>(s, g);
     if (g.in_dtype == A4R_BF16 && g.out_dtype == A4R_F32) return launch_bn<bf16_t, float>(s, g);

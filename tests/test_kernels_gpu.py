@@ -117,6 +117,37 @@ def test_gemm_epilogue_full(dt, gemm_variant):
         close(Cc, ref, t, f'gemm epilogue act={act} dact={dact}')
 
 
+@pytest.mark.parametrize('to', ['bf16', 'f32'])
+def test_gemm_skinny64_epilogue(to):
+    """N = 64 with bf16 operands goes to skinny64_kernel (a4r_gemm_skinny.hip): every epilogue form the adapter down-projections use
+    (bias + ReLU/GELU + pre-activation or derivative in C2, residual, alpha, dropout) against torch and against the 128-tile kernel."""
+    from adapter4rec_amd import _lib as L
+    tO = DT[to]
+    for M, K in ((128, 64), (384, 768), (4096 + 128, 320)):          # (the 128-tile comparison kernel needs M % 128 == 0)
+        A, B = rnd(M, K, dtype=torch.bfloat16, seed=31), rnd(64, K, dtype=torch.bfloat16, scale=0.1, seed=32)
+        bias, R1 = rnd(64, seed=33), rnd(M, 64, dtype=tO, seed=34)
+        for act, c2d in ((1, 0), (1, 1), (2, 1), (0, 0)):
+            outs = []
+            for v in (2, 1):
+                old = L.gemm_variant(v)
+                Cc = torch.zeros(M, 64, dtype=tO, device=dev()); C2 = torch.zeros_like(Cc)
+                L.gemm_nt(A, B, Cc, bias=bias, C2=C2, R1=R1, act=act, alpha=0.5, c2_deriv=bool(c2d))
+                D = torch.zeros_like(Cc)
+                L.gemm_nt(A, B, D, bias=bias, drop_p=0.2, drop_site=9, drop_seed=4321)
+                L.gemm_variant(old)
+                outs.append((Cc, C2, D))
+            pre = 0.5 * (A.float() @ B.float().t()) + bias
+            close(outs[0][0], act_ref(pre, act) + R1.float(), tO, f'skinny C act={act}')
+            if c2d:
+                q = pre.clone().requires_grad_(True)
+                act_ref(q, act).sum().backward()
+                close(outs[0][1], q.grad, tO, 'skinny C2 derivative')
+            else:
+                close(outs[0][1], pre, tO, 'skinny C2 pre-activation')
+            close(outs[0][0], outs[1][0], tO, 'skinny vs 128-tile kernel', atol32=1e-5, rtol32=1e-5, atol16=1e-2, rtol16=1e-2)
+            assert torch.equal(outs[0][2] == 0, outs[1][2] == 0), 'same dropout mask from both kernels'
+
+
 def test_gemm_mixed_dtypes_and_views():
     from adapter4rec_amd import _lib as L
     M, N, K = 128, 64, 768
