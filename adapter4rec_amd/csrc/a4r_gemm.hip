@@ -233,6 +233,7 @@ inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 
 int a4r_gemm_nt_256(hipStream_t s, const a4r_gemm_t& g);   // a4r_gemm256.hip
 int a4r_gemm_nt_256w4(hipStream_t s, const a4r_gemm_t& g); // a4r_gemm256w4.hip (variant 3: four waves of 128 x 128)
 int a4r_gemm_nt_skinny64(hipStream_t s, const a4r_gemm_t& g); // a4r_gemm_skinny.hip (N == 64, bf16 in: the adapter down-projections)
+int a4r_gemm_nt_skinnyk(hipStream_t s, const a4r_gemm_t& g);  // a4r_gemm_skinny.hip (K == 64, bf16: the adapter up-projections)
 int a4r_gemm_nt_256s(hipStream_t s, const a4r_gemm_t& g);  // a4r_gemm256s.hip (variant 5: four waves, K-tile double buffer, spread DMA stream)
 static int run_256(hipStream_t s, const a4r_gemm_t& g);
 int a4r_cu_count();                                          // a4r_gemm256.hip: CU count rounded down to a multiple of 8
@@ -272,6 +273,10 @@ extern "C" int a4r_gemm_nt(void* stream, const a4r_gemm_t* gp) {
     if (g.drop_p < 0.f || g.drop_p >= 1.f) return A4R_EINVAL;
     if (g.dact == A4R_DACT_MUL_ && !g.Pre) return A4R_EINVAL;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    if (g_variant == 2 && g.K == 64 && g.N >= 256) {
+        const int rc = a4r_gemm_nt_skinnyk(s, g);
+        if (rc != 1) return rc;
+    }
     if (g_variant >= 2 && g.M % 256 == 0 && g.N % 256 == 0 && (g.K * isz) % 128 == 0) {
         // Tile quantisation: the persistent 256-tile grid runs ceil(tiles / CUs) rounds.  When the last round would hold only a
         // few whole row panels (ViT-B/16 at 8 users: 777 tiles = 3 rounds + 9 tiles), those panels go to the 128-tile kernel as

@@ -64,7 +64,8 @@ template <typename TO, int NC> A4R_DEV void load_pre_n(uint4* q, size_t grow, in
 }
 
 template <typename TO, int NC, int ACT = -1, int DACT = -1>
-A4R_DEV void epilogue_n(float (&v)[NC], const float* bias, size_t grow, int gcol, const GemmEpi<TO>& e, const uint4* pre_ld = nullptr) {
+A4R_DEV void epilogue_n(float (&v)[NC], const float* bias, size_t grow, int gcol, const GemmEpi<TO>& e, const uint4* pre_ld = nullptr,
+                        const uint4* r1_ld = nullptr, const uint4* r2_ld = nullptr) {
     const int act = ACT >= 0 ? ACT : e.act;
     const int dact = DACT >= 0 ? DACT : e.dact;
 #pragma unroll
@@ -110,18 +111,34 @@ A4R_DEV void epilogue_n(float (&v)[NC], const float* bias, size_t grow, int gcol
     if (e.thr16 && e.drop_first) epi_dropout<NC>(v, e0, e.drop_seed, e.drop_site, e.thr16, e.keep_scale);
     if (e.R1) {
         float t[NC];
-        load_n<TO, NC>(e.R1 + grow * e.ldr1 + gcol, t);
+        if (r1_ld) {
+#pragma unroll
+            for (int s = 0; s < NC / Elem<TO>::PER16; ++s) Elem<TO>::unpack(r1_ld[s], t + s * Elem<TO>::PER16);
+        } else {
+            load_n<TO, NC>(e.R1 + grow * e.ldr1 + gcol, t);
+        }
 #pragma unroll
         for (int i = 0; i < NC; ++i) v[i] += t[i];
     }
     if (e.R2) {
         float t[NC];
-        load_n<TO, NC>(e.R2 + grow * e.ldr2 + gcol, t);
+        if (r2_ld) {
+#pragma unroll
+            for (int s = 0; s < NC / Elem<TO>::PER16; ++s) Elem<TO>::unpack(r2_ld[s], t + s * Elem<TO>::PER16);
+        } else {
+            load_n<TO, NC>(e.R2 + grow * e.ldr2 + gcol, t);
+        }
 #pragma unroll
         for (int i = 0; i < NC; ++i) v[i] += t[i];
     }
     if (e.thr16 && !e.drop_first) epi_dropout<NC>(v, e0, e.drop_seed, e.drop_site, e.thr16, e.keep_scale);
     store_n<TO, NC>(e.C + grow * e.ldc + gcol, v);
+}
+// the NC elements of a residual operand as 16-byte pieces, for a caller that requests them ahead of use (r1_ld / r2_ld above)
+template <typename TO, int NC> A4R_DEV void load_res_n(uint4* q, const TO* R, int ldr, size_t grow, int gcol) {
+#pragma unroll
+    for (int s = 0; s < NC * (int)sizeof(TO) / 16; ++s)
+        q[s] = *reinterpret_cast<const uint4*>(R + grow * ldr + gcol + s * (16 / (int)sizeof(TO)));
 }
 
 // ---- two-stage form of the same epilogue: the loads of a group (Pre, R1, R2: 16 B per operand for bf16, 32 B for fp32) are issued

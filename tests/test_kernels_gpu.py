@@ -148,6 +148,33 @@ def test_gemm_skinny64_epilogue(to):
             assert torch.equal(outs[0][2] == 0, outs[1][2] == 0), 'same dropout mask from both kernels'
 
 
+def test_gemm_skinnyk_epilogue():
+    """K = 64 (one K-tile) with bf16 operands goes to skinnyk_kernel (a4r_gemm_skinny.hip): bias, two residuals, alpha, ReLU, C2,
+    dropout before / after the residual, in-place residual (C is R1); against torch and the 256-tile kernel (variant 4)."""
+    from adapter4rec_amd import _lib as L
+    t = torch.bfloat16
+    for M, N in ((256, 256), (1024 + 256, 768), (512, 3072)):
+        A, B = rnd(M, 64, dtype=t, seed=41), rnd(N, 64, dtype=t, scale=0.1, seed=42)
+        bias, R1, R2 = rnd(N, seed=43), rnd(M, N, dtype=t, seed=44), rnd(M, N, dtype=t, seed=45)
+        outs = []
+        for v in (2, 4):
+            old = L.gemm_variant(v)
+            Cc = torch.zeros(M, N, dtype=t, device=dev()); C2 = torch.zeros_like(Cc)
+            L.gemm_nt(A, B, Cc, bias=bias, C2=C2, R1=R1, R2=R2, act=1, alpha=0.5)
+            D = torch.zeros_like(Cc)
+            L.gemm_nt(A, B, D, bias=bias, R1=R1, drop_p=0.2, drop_site=9, drop_seed=4321, drop_first=True)
+            E = R1.clone()
+            L.gemm_nt(A, B, E, bias=bias, R1=E, R2=R2)                       # in place over R1
+            L.gemm_variant(old)
+            outs.append((Cc, C2, D, E))
+        pre = 0.5 * (A.float() @ B.float().t()) + bias
+        close(outs[0][0], torch.relu(pre) + R1.float() + R2.float(), t, 'skinnyk C')
+        close(outs[0][1], pre, t, 'skinnyk C2')
+        close(outs[0][3], (A.float() @ B.float().t()) + bias + R1.float() + R2.float(), t, 'skinnyk in place')
+        for a, b in zip(outs[0], outs[1]):
+            assert torch.equal(a, b), 'same MFMA order and epilogue as the 256-tile kernel: bit-equal'
+
+
 def test_gemm_mixed_dtypes_and_views():
     from adapter4rec_amd import _lib as L
     M, N, K = 128, 64, 768
