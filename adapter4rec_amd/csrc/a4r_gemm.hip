@@ -250,8 +250,11 @@ static int run_256(hipStream_t s, const a4r_gemm_t& g) {
     return a4r_gemm_nt_256(s, g);
 }
 
+extern int g_tn_variant;                                     // a4r_gemm_tn.hip: 0 = register-staged weight-gradient kernel for bf16 too
+
 extern "C" int a4r_gemm_variant(int v) {
     const int old = g_variant;
+    if (v >= 0 && v <= 5) g_tn_variant = v != 0;
     if (v >= 0 && v <= 5) g_variant = v;     // 0/1: 128-tile kernels, 2: automatic (default), 3: four-wave 256 tile, 4: eight-wave 256 tile forced, 5: four-wave stream kernel forced
     return old;
 }

@@ -92,6 +92,96 @@ __global__ void __launch_bounds__(256) gemm_tn_kernel(const T* __restrict__ X, i
     }
 }
 
+// ---- bf16 form: LDS-DMA ring + hardware-transposed fragment reads.
+// The kernel above stages through registers one 64-token stage at a time (load -> barrier -> ds_write -> barrier -> gather with 64
+// ds_read_u16 per wave -> 8 MFMA): nothing is in flight while it computes, 24.5 us for the 67 MB of a 40448 x (768 | 64) pair.
+// Here a stage (64 tokens x 64 columns of X and of Y, 8 KiB each, 128-byte rows with the chunk swizzle c ^ ((row >> 1) & 7)
+// applied on the DMA source address) is written by global_load_lds_dwordx4 into a 3-deep ring that stays in flight across the
+// ONE barrier per stage, and the operands -- contraction index running DOWN the rows -- come from ds_read_b64_tr_b16: a lane
+// gets tokens {4kg .. 4kg+3} and {16 + 4kg .. +3} of its column, the same permutation of the contraction index for both
+// operands.  48 KiB of LDS: three workgroups per CU, ~96 KiB in flight per CU.
+typedef short tn_v4s_t __attribute__((ext_vector_type(4)));
+A4R_DEV uint4 tn_frag_tr(const char* img, int d0, int st, int lane) {
+    const int kg = lane >> 4, q = (lane >> 2) & 3, pp = lane & 3;
+    const int chunk = (d0 >> 3) + (pp >> 1);
+    const int r0 = 32 * st + 4 * kg + q, r1 = r0 + 16;
+    const char* a0 = img + r0 * 128 + ((chunk ^ ((r0 >> 1) & 7)) << 4) + 8 * (pp & 1);
+    const char* a1 = img + r1 * 128 + ((chunk ^ ((r1 >> 1) & 7)) << 4) + 8 * (pp & 1);
+    const tn_v4s_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) tn_v4s_t*)(a0));
+    const tn_v4s_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) tn_v4s_t*)(a1));
+    const uint2 l2 = __builtin_bit_cast(uint2, lo), h2 = __builtin_bit_cast(uint2, hi);
+    return make_uint4(l2.x, l2.y, h2.x, h2.y);
+}
+A4R_DEV void tn_glds16(const void* base, uint32_t voff, uint32_t lds_dst) {
+    asm volatile("s_mov_b32 m0, %2\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(base), "s"(lds_dst) : "memory");
+}
+
+__global__ void __launch_bounds__(256) gemm_tn_glds_kernel(const bf16_t* __restrict__ X, int ldx, const bf16_t* __restrict__ Y, int ldy,
+                                                           float* __restrict__ C, int ldc, int M, int ntq, int rows_per_split) {
+    constexpr int NST = 3, STAGE = 16384;
+    __shared__ __attribute__((aligned(16))) char lds[NST * STAGE];        // [stage][X 64 tokens | Y 64 tokens][128 B]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wp = wave >> 1, wq = wave & 1;
+    const int tile = blockIdx.x, split = blockIdx.y;
+    const int p0 = (tile / ntq) * 64, q0 = (tile % ntq) * 64;
+    const int m_begin = split * rows_per_split;
+    const int m_end = min(M, m_begin + rows_per_split);
+    const int ns = (m_end - m_begin) / 64;
+    const char* Xb = reinterpret_cast<const char*>(X + (size_t)m_begin * ldx + p0);
+    const char* Yb = reinterpret_cast<const char*>(Y + (size_t)m_begin * ldy + q0);
+    const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)lds;
+    uint32_t voffX[2], voffY[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {                                          // wave w stages tokens 16w .. 16w+15 of both operands
+        const int ul = 8 * (2 * wave + i) + (lane >> 3);
+        const int c = (lane & 7) ^ ((ul >> 1) & 7);
+        voffX[i] = (uint32_t)(ul * ldx * 2 + c * 16);
+        voffY[i] = (uint32_t)(ul * ldy * 2 + c * 16);
+    }
+    const uint32_t dst0 = lds0 + (uint32_t)(2 * wave) * 1024u;
+    auto issue = [&](int t) {
+        if (t < ns) {
+            const uint32_t d = dst0 + (uint32_t)(t % NST) * STAGE;
+            const char* x = Xb + (size_t)t * 64 * ldx * 2;
+            const char* y = Yb + (size_t)t * 64 * ldy * 2;
+            tn_glds16(x, voffX[0], d);
+            tn_glds16(x, voffX[1], d + 1024u);
+            tn_glds16(y, voffY[0], d + 8192u);
+            tn_glds16(y, voffY[1], d + 8192u + 1024u);
+        }
+    };
+    issue(0);
+    issue(1);
+    f32x4_t acc00 = {0.f, 0.f, 0.f, 0.f}, acc01 = acc00, acc10 = acc00, acc11 = acc00;
+    for (int t = 0; t < ns; ++t) {
+        if (t + 1 < ns) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        issue(t + 2);
+        const char* xs = lds + (t % NST) * STAGE;
+        const char* ys = xs + 8192;
+#pragma unroll
+        for (int st = 0; st < 2; ++st) {
+            const uint4 a0 = tn_frag_tr(xs, wp * 32, st, lane), a1 = tn_frag_tr(xs, wp * 32 + 16, st, lane);
+            const uint4 b0 = tn_frag_tr(ys, wq * 32, st, lane), b1 = tn_frag_tr(ys, wq * 32 + 16, st, lane);
+            Mma<bf16_t>::mma(a0, b0, acc00);
+            Mma<bf16_t>::mma(a0, b1, acc01);
+            Mma<bf16_t>::mma(a1, b0, acc10);
+            Mma<bf16_t>::mma(a1, b1, acc11);
+        }
+    }
+    const int prow = p0 + wp * 32 + (lane >> 4) * 4, qcol = q0 + wq * 32 + (lane & 15);
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr) {
+        atomicAdd(C + (size_t)(prow + rr) * ldc + qcol, acc00[rr]);
+        atomicAdd(C + (size_t)(prow + rr) * ldc + qcol + 16, acc01[rr]);
+        atomicAdd(C + (size_t)(prow + 16 + rr) * ldc + qcol, acc10[rr]);
+        atomicAdd(C + (size_t)(prow + 16 + rr) * ldc + qcol + 16, acc11[rr]);
+    }
+}
+
 // block = NCG column groups (8 columns each, NCG = min(N/8, 32)) x 256/NCG row lanes; grid.y strides the rows.
 // Row lanes are reduced through LDS so that a block issues ONE atomic per column (all blocks hit the same
 // N addresses: per-thread atomics there ran at the contended-atomic rate, 0.8 ms for a 40k x 64 input).
@@ -126,6 +216,8 @@ __global__ void __launch_bounds__(256) colsum_kernel(const T* __restrict__ X, in
 
 }  // namespace
 
+int g_tn_variant = 1;          // 0: register-staged kernel for bf16 too (tests / A-B via a4r_gemm_variant(0))
+
 extern "C" int a4r_gemm_tn(void* stream, const void* X, int ldx, const void* Y, int ldy, float* C, int ldc,
                            int M, int P, int Q, int dtype) {
     if (!X || !Y || !C || M <= 0 || P <= 0 || Q <= 0 || M % 64 || P % 64 || Q % 64) return A4R_EINVAL;
@@ -133,13 +225,17 @@ extern "C" int a4r_gemm_tn(void* stream, const void* X, int ldx, const void* Y, 
     if ((dtype != A4R_F32 && dtype != A4R_BF16) || (ldx * esz) % 16 || (ldy * esz) % 16 || ldx < P || ldy < Q || ldc < Q) return A4R_EINVAL;
     if ((reinterpret_cast<uintptr_t>(X) | reinterpret_cast<uintptr_t>(Y)) & 15u) return A4R_EINVAL;
     const int ntp = P / 64, ntq = Q / 64, tiles = ntp * ntq;
-    int splits = (512 + tiles - 1) / tiles;                 // ~2 workgroups per CU
+    const bool glds = dtype == A4R_BF16 && g_tn_variant != 0;
+    int splits = ((glds ? 768 : 512) + tiles - 1) / tiles;  // one round of three (two) workgroups per CU
     const int stages = M / 64;
     if (splits > stages) splits = stages;
     const int rows_per_split = ((stages + splits - 1) / splits) * 64;
     splits = (M + rows_per_split - 1) / rows_per_split;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-    if (dtype == A4R_BF16)
+    if (glds)
+        hipLaunchKernelGGL(gemm_tn_glds_kernel, dim3(tiles, splits), dim3(256), 0, s, (const bf16_t*)X, ldx, (const bf16_t*)Y, ldy,
+                           C, ldc, M, ntq, rows_per_split);
+    else if (dtype == A4R_BF16)
         hipLaunchKernelGGL(gemm_tn_kernel<bf16_t>, dim3(tiles, splits), dim3(256), 0, s, (const bf16_t*)X, ldx, (const bf16_t*)Y, ldy,
                            C, ldc, M, ntq, rows_per_split);
     else

@@ -234,6 +234,27 @@ def test_gemm_tn(dt, M, P, Q):
     close(Cc, ref, torch.float32, f'gemm_tn {dt}', atol32=2e-3 if dt == 'f32' else 2e-2, rtol32=1e-3)
 
 
+@pytest.mark.parametrize('M,P,Q', [(40448, 768, 64), (40448, 64, 768), (64 * 37, 128, 192), (64, 64, 64), (128, 64, 64)])
+def test_gemm_tn_glds_bf16(M, P, Q):
+    """bf16 weight-gradient kernel (LDS-DMA ring + ds_read_b64_tr_b16): many splits, ragged last split, 1 and 2 stages; small-integer
+    operands make the token sum exact, so it must equal torch AND the register-staged kernel bit for bit, views (ld > width) included."""
+    from adapter4rec_amd import _lib as L
+    g = torch.Generator().manual_seed(17)
+    Xb = torch.randint(-3, 4, (M, P + 64), generator=g).to(torch.bfloat16).to(dev())
+    Yb = torch.randint(-2, 3, (M, Q + 128), generator=g).to(torch.bfloat16).to(dev())
+    X, Y = Xb[:, 64:], Yb[:, :Q]
+    outs = []
+    for v in (2, 0):
+        old = L.gemm_variant(v)
+        Cc = torch.full((P, Q), 3.0, device=dev())
+        L.gemm_tn(X, Y, Cc)
+        L.gemm_variant(old)
+        outs.append(Cc)
+    ref = 3.0 + X.float().t() @ Y.float()
+    assert torch.equal(outs[0], ref), float((outs[0] - ref).abs().max())
+    assert torch.equal(outs[0], outs[1])
+
+
 @pytest.mark.parametrize('dt', ['f32', 'bf16'])
 def test_colsum(dt):
     from adapter4rec_amd import _lib as L
