@@ -20,6 +20,17 @@
 //   "all but the newest 4 units have landed" (vmcnt(8)) before barrier k makes exactly the data of phase k+1 readable.
 #include "a4r_gemm_epi.h"
 
+#ifdef A4R_STAMP
+// diagnostic build only (-DA4R_STAMP): s_memtime stamps of workgroup phases, first two tiles of every workgroup; never read by the kernel
+__device__ unsigned long long g_a4r_stamps[1024 * 8];
+extern "C" int a4r_debug_stamps(unsigned long long* host_out) {
+    return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_a4r_stamps), sizeof(g_a4r_stamps)) == hipSuccess ? 0 : -2;
+}
+#define A4R_STAMP_AT(i_) if (stamp_iter < 2 && tid == 0) g_a4r_stamps[blockIdx.x * 8 + (i_)] = __builtin_amdgcn_s_memtime();
+#else
+#define A4R_STAMP_AT(i_)
+#endif
+
 namespace {
 
 constexpr int UNIT_BYTES = 16384;
@@ -198,9 +209,16 @@ __global__ void __launch_bounds__(512, 2) gemm_nt_256_kernel(const a4r_gemm_t p,
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                  // single K-tile (adapter up-projection, K = 64): 4 units
     const GemmEpi<TO> epi = make_epi<TO>(p, thr16, keep_scale);
 
+#ifdef A4R_STAMP
+  int stamp_iter = 0;
+  A4R_STAMP_AT(0)
+#endif
   for (;;) {                                              // ---- tiles of this workgroup
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
+#ifdef A4R_STAMP
+    if (stamp_iter == 1) { A4R_STAMP_AT(4) }
+#endif
 #pragma unroll
     for (int mi = 0; mi < 8; ++mi)
 #pragma unroll
@@ -339,6 +357,9 @@ __global__ void __launch_bounds__(512, 2) gemm_nt_256_kernel(const a4r_gemm_t p,
     // tile with one workgroup per CU).
     // every LDS read of this tile completed before the last barrier: the ring is free, so the NEXT tile's first units
     // are put in flight now and land while this tile's accumulators are being written out.
+#ifdef A4R_STAMP
+    if (stamp_iter == 0) { A4R_STAMP_AT(1) } else { A4R_STAMP_AT(5) }
+#endif
     const int tm_done = tm, tn_done = tn;
     vb += gridDim.x;
     const bool more = vb < nt;
@@ -392,8 +413,15 @@ __global__ void __launch_bounds__(512, 2) gemm_nt_256_kernel(const a4r_gemm_t p,
     A4R_EPI_ROW(0) A4R_EPI_ROW(1) A4R_EPI_ROW(2) A4R_EPI_ROW(3) A4R_EPI_ROW(4) A4R_EPI_ROW(5) A4R_EPI_ROW(6) A4R_EPI_ROW(7)
 #undef A4R_EPI_ROW
 #undef A4R_EPI_PAIR
+#ifdef A4R_STAMP
+    if (stamp_iter == 0) { A4R_STAMP_AT(2) } else { A4R_STAMP_AT(6) }
+#endif
     if (!more) break;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // stores of this tile + prologue loads of the next (vmcnt counts both)
+#ifdef A4R_STAMP
+    if (stamp_iter == 0) { A4R_STAMP_AT(3) }
+    ++stamp_iter;
+#endif
   }
 #undef A4R_PROLOGUE
 #undef A4R_ISSUE
