@@ -285,7 +285,9 @@ int dispatch_same(hipStream_t s, const a4r_gemm_t& g) {
 
 }  // namespace
 
-extern "C" int a4r_gemm_sched(int v) { const int o = g_sched; g_sched = v; return o; }   // schedule sweep (diagnostic builds)
+#ifdef A4R_SCHED_SWEEP
+extern "C" int a4r_gemm_sched(int v) { const int o = g_sched; g_sched = v; return o; }   // schedule sweep (diagnostic builds only)
+#endif
 
 // bf16 in / bf16 out only (the training step's big GEMMs); returns 1 when the combination is not instantiated
 int a4r_gemm_nt_256s(hipStream_t s, const a4r_gemm_t& g) {

@@ -144,8 +144,17 @@ class GemmProbe:
             self.real(A, B, Cout, *a, **k)
             e1.record()
             N, K = B.shape[0], B.shape[1]
-            big = M % 256 == 0 and N % 256 == 0 and (K * A.element_size()) % 128 == 0      # a4r_gemm_nt's dispatch rule
-            self.rec.append((str(A.dtype), str(Cout.dtype), (256 if big else (128 if N % 128 == 0 else 64),) + (ad if big else ()), M, N, K, e0, e1))
+            # mirror of a4r_gemm_nt's dispatch (a4r_gemm.hip): one-K-tile products and N = 64 have their own streaming kernels
+            bf16_in = A.dtype == torch.bfloat16
+            if bf16_in and K == 64 and N >= 256 and N % 128 == 0 and M % 64 == 0 and Cout.dtype == torch.bfloat16 and not ad[1]:
+                tile = ('skinnyk',)
+            elif bf16_in and N == 64 and M % 64 == 0:
+                tile = ('skinny64',)
+            elif M % 256 == 0 and N % 256 == 0 and (K * A.element_size()) % 128 == 0:
+                tile = (256,) + ad
+            else:
+                tile = (128 if N % 128 == 0 else 64,)
+            self.rec.append((str(A.dtype), str(Cout.dtype), tile, M, N, K, e0, e1))
         self.L.gemm_nt = wrapped
         return self
 
@@ -310,18 +319,18 @@ def main():
         total_t = sum(v[1] for v in agg.values())
         peak = MFMA_BF16_PEAK_TFLOPS if a.dtype == 'bf16' else 157.3
         roof = dict(bound='mfma', achieved=round(ach, 2), peak=peak, unit='TFLOP/s', frac=round(ach / peak, 4), traffic=None,
-                    kernel=(f'gemm_nt_256_kernel<{a.dtype},{a.dtype},act={key[2][1]},dact={key[2][2]}>' if key[2][0] == 256 else f'gemm_nt_kernel<{a.dtype},{a.dtype},{key[2][0]}>'), launches_per_step=n // 2,
+                    kernel=(f'gemm_nt_256_kernel<{a.dtype},{a.dtype},act={key[2][1]},dact={key[2][2]}>' if key[2][0] == 256 else (f'{key[2][0]}_kernel<{a.dtype},{a.dtype}>' if isinstance(key[2][0], str) else f'gemm_nt_kernel<{a.dtype},{a.dtype},{key[2][0]}>')), launches_per_step=n // 2,
                     avg_launch_us=round(t / n * 1e6, 2), flop_per_launch=f / n,
                     all_gemm_tflops=round(total_f / total_t / 1e12, 2), gemm_time_share_of_step=round(total_t / 2 / (dt / a.steps), 3))
         # fabric/HBM bytes per launch of that kernel: not measurable from inside the process -- taken from the committed
-        # rocprofv3 PMC passes over this same command (profiles/r01_f_pmc_hbm_traffic.json says how), B=32 bf16 only.
-        pmc = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles', 'r01_f_pmc_hbm_traffic.json')
+        # rocprofv3 PMC passes over this same command (profiles/r01_g_pmc_hbm_traffic.json says how), B=32 bf16 only.
+        pmc = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles', 'r01_g_pmc_hbm_traffic.json')
         if key[2][0] == 256 and a.dtype == 'bf16' and a.batch == 32 and os.path.exists(pmc):
             mangled = f'gemm_nt_256_kernelIDF16bDF16bLi{key[2][1]}ELi{key[2][2]}E'
             for kname, rec in json.load(open(pmc))['kernels'].items():
                 if mangled in kname:
                     roof['traffic'] = rec['traffic_bytes_per_launch']
-                    roof['traffic_source'] = 'profiles/r01_f_pmc_hbm_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, 2 x FETCH correction)'
+                    roof['traffic_source'] = 'profiles/r01_g_pmc_hbm_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, 2 x FETCH correction)'
         if os.environ.get('A4R_BENCH_SHAPES'):
             print(json.dumps(shapes, indent=1), file=sys.stderr)
 
