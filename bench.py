@@ -237,11 +237,12 @@ def main():
     local = int(os.environ.get('LOCAL_RANK', '0'))
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs an MI355X (no CPU fallback)')
+    local = local % torch.cuda.device_count()                  # (one rank per GPU in real runs; lets the N > 1 control flow be exercised on one GPU)
     torch.cuda.set_device(local)
     device = torch.device('cuda', local)
     import torch.distributed as dist
     if world > 1:
-        dist.init_process_group('nccl', init_method='env://')
+        dist.init_process_group(os.environ.get('A4R_BENCH_BACKEND', 'nccl'), init_method='env://')     # 'nccl' is RCCL on ROCm; gloo only for the control-flow test
     assert world == a.gpus or world == 1, f'--gpus {a.gpus} but WORLD_SIZE={world}'
 
     from adapter4rec_amd import _lib as L
@@ -272,12 +273,12 @@ def main():
     if world > 1:                                              # DDP constructor semantics: rank 0's trainables everywhere
         dist.broadcast(eng.flat_p, 0)
 
-    def step(i):
+    def step(i, exchange=True):
         items, mask = batches[i % len(batches)]
         eng.flat_g.zero_()
         loss = eng.train_forward(items, mask)
         eng.train_backward(into_flat_grad=True)
-        if world > 1:
+        if world > 1 and exchange:
             dist.all_reduce(eng.flat_g)
         opt.step(grad_scale=1.0 / world)
         return loss
@@ -307,8 +308,8 @@ def main():
     if rank == 0 and not a.no_roofline:
         import adapter4rec_amd.engine as E
         with GemmProbe(E.L) as probe:
-            for i in range(2):
-                step(a.warmup + a.steps + i)
+            for i in range(2):                                   # rank 0 only: NO collective in here (the other ranks have moved on)
+                step(a.warmup + a.steps + i, exchange=False)
             agg = probe.summary()
             shapes = probe.by_shape()
         tname = 'torch.bfloat16' if a.dtype == 'bf16' else 'torch.float32'
@@ -354,6 +355,7 @@ def main():
         }
         print(json.dumps(out))
     if world > 1:
+        dist.barrier()                 # rank 0 ran its instrumented pass alone: leave the group together
         dist.destroy_process_group()
 
 
