@@ -78,12 +78,15 @@ __global__ void __launch_bounds__(256) embed_ln_kernel(const int64_t* __restrict
     for (int row = blockIdx.x * 4 + (threadIdx.x >> 6); row < n_rows; row += gridDim.x * 4) {
         const int item = row / S, s = row % S;
         const int64_t* idr = ids + (size_t)item * ld_ids;
-        const int64_t id = idr[s];
+        // a NEGATIVE id -(r + 1) reads word row r but counts as a pad token for the position ids: a soft prompt replaces the word
+        // vector of a title's first tokens, RoBERTa's positions still follow the ORIGINAL ids (pads inside a short title's prompt)
+        const int64_t idraw = idr[s];
+        const int64_t id = idraw < 0 ? -idraw - 1 : idraw;
         int pid = s;
         if (roberta) {        // cumsum(id != pad) * (id != pad) + pad
             int c = 0;
-            for (int t = 0; t <= s; ++t) c += (idr[t] != pad_id);
-            pid = (id != pad_id) ? c + pad_id : pad_id;
+            for (int t = 0; t <= s; ++t) c += (idr[t] != pad_id && idr[t] >= 0);
+            pid = (idraw != pad_id && idraw >= 0) ? c + pad_id : pad_id;
         }
         float v[MAXG][8], a[MAXG][8], b[MAXG][8];
         row_load<float>(word + (size_t)id * H, ng, lane, v);
@@ -118,12 +121,13 @@ __global__ void __launch_bounds__(256) embed_bwd_kernel(const int64_t* __restric
     for (int row = blockIdx.x * 4 + (threadIdx.x >> 6); row < n_rows; row += gridDim.x * 4) {
         const int item = row / S, s = row % S;
         const int64_t* idr = ids + (size_t)item * ld_ids;
-        const int64_t id = idr[s];
+        const int64_t idraw = idr[s];
+        const int64_t id = idraw < 0 ? -idraw - 1 : idraw;     // (negative ids: see embed_ln_kernel)
         int pid = s;
         if (roberta) {
             int c = 0;
-            for (int t = 0; t <= s; ++t) c += (idr[t] != pad_id);
-            pid = (id != pad_id) ? c + pad_id : pad_id;
+            for (int t = 0; t <= s; ++t) c += (idr[t] != pad_id && idr[t] >= 0);
+            pid = (idraw != pad_id && idraw >= 0) ? c + pad_id : pad_id;
         }
         for (int c = lane; c < H; c += 64) {
             const float g = Elem<T>::ld(dpre + (size_t)row * ldd + c);

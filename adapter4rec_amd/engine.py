@@ -397,9 +397,7 @@ class TransRecEngine:
         wemb = emb.word_embeddings
         self.prompt_n, self.g_prompt = 0, None
         if type(wemb).__name__ == 'SoftEmbedding':      # soft prompt (model.py:586-630): rows V .. V+n-1 of an extended table hold the
-            if g['model_type'] == 'roberta':            # learned vectors and the first n ids of every title are redirected to them
-                raise NotImplementedError('soft prompt on RoBERTa (position ids are derived from the replaced token ids)')
-            self.prompt_n = int(wemb.n_tokens)
+            self.prompt_n = int(wemb.n_tokens)          # learned vectors and the first n ids of every title are redirected to them
             if self.prompt_n > self.S:
                 raise ValueError(f'--n_tokens {self.prompt_n} exceeds the title length {self.S}')
             self.prompt_param = wemb.learned_embedding
@@ -922,7 +920,10 @@ class TransRecEngine:
             word = self.emb_word_ext
             word[V:V + n].copy_(self.prompt_param.detach())
             news = news.clone()
-            news[:, :n] = torch.arange(V, V + n, device=news.device)
+            red = torch.arange(V, V + n, device=news.device).expand(news.shape[0], n)
+            if self.roberta:                       # RoBERTa derives the position ids from the ORIGINAL ids: a redirected pad stays a pad
+                red = torch.where(news[:, :n] == self.pad_id, -red - 1, red)      # (a4r_embed_ln: negative id = row -(id + 1), counted as pad)
+            news[:, :n] = red
         L.embed_ln(news, word, self.emb_pos, self.emb_type0, self.emb_ln.gamma, self.emb_ln.beta, self.emb_ln.eps,
                    x, n_items, S, roberta=self.roberta, pad_id=self.pad_id,
                    drop_p=self.p_hidden if train else 0.0, drop_site=999, drop_seed=seed,

@@ -139,7 +139,9 @@ int a4r_resample_u8(void* stream, const void* src, void* dst, const int32_t* bou
 
 /* HF BertEmbeddings / RobertaEmbeddings: word[id] + pos[pos_id] + type[0] -> LayerNorm -> dropout.
  * ids [n_items, S] int64 with row stride ld_ids (the reference hands over ids||mask rows of 2*S,
- * model/encoders.py:49-52).  roberta != 0: pos_id = cumsum(id != pad) * (id != pad) + pad. */
+ * model/encoders.py:49-52).  roberta != 0: pos_id = cumsum(id != pad) * (id != pad) + pad.  A negative id -(r + 1) reads word
+ * row r and counts as a pad for the position ids (soft prompt, model/model.py:586-630: the first n_tokens word vectors are
+ * replaced, the positions still follow the original ids). */
 int a4r_embed_ln(void* stream, const int64_t* ids, int ld_ids, const float* word, const float* pos,
                  const float* type0, const float* gamma, const float* beta, float eps,
                  void* out, int ldo, int n_items, int S, int H, int roberta, int pad_id, int dtype,

@@ -19,6 +19,7 @@ VARIANT_CFG = {
     'kadapter': dict(adapter_type='kadapter', k_adapter_bert_list='0,1', num_adapter_heads_bert=4, num_adapter_heads_sasrec=2),
     'roberta_cpc_pfeiffer': dict(adapter_type='pfeiffer', adapter_activation='relu', arch='cpc',
                                  encoder='roberta', bert_ln_eps=1e-5, pad_token_id=1),
+    'roberta_prompt': dict(adapter_type='prompt', n_tokens=8, arch='cpc', encoder='roberta', bert_ln_eps=1e-5, pad_token_id=1),
 }
 LRS = dict(fine_tune_lr=5e-5, lr=1e-4, adapter_bert_lr=1.5e-4, adapter_sasrec_lr=1.5e-4)
 

@@ -22,7 +22,8 @@ ARGS = dict(houlsby=dict(), houlsby_gelu=dict(adapter_activation='GELU'), houlsb
             compacter=dict(adapter_type='compacter'), houlsby_cpc=dict(arch='cpc'), prompt=dict(adapter_type='prompt', n_tokens=8),
             kadapter=dict(adapter_type='kadapter', k_adapter_bert_list='0,1', k_adapter_bert_hidden_dim=64, num_adapter_heads_bert=4,
                           num_adapter_heads_sasrec=2),
-            roberta_cpc_pfeiffer=dict(adapter_type='pfeiffer', adapter_activation='relu', arch='cpc', bert_model_load='roberta_tiny'))
+            roberta_cpc_pfeiffer=dict(adapter_type='pfeiffer', adapter_activation='relu', arch='cpc', bert_model_load='roberta_tiny'),
+            roberta_prompt=dict(adapter_type='prompt', n_tokens=8, arch='cpc', bert_model_load='roberta_tiny'))
 
 
 def make_args(**kw):

@@ -325,6 +325,18 @@ def main():
                      output_hidden_states=(len(sys.argv) > 2 and sys.argv[2] == 'kadapter'))
     args = make_args()
     base = Model(args, ITEM_NUM, True, BertModel(cfg))
+    if len(sys.argv) > 2 and sys.argv[1] == '--only' and sys.argv[2] == 'roberta_prompt':
+        # soft prompt on RoBERTa: the position ids still come from the ORIGINAL token ids (titles shorter than n_tokens have pads inside the prompt)
+        rcfg = RobertaConfig(vocab_size=VOCAB, hidden_size=HID, num_hidden_layers=LAYERS, num_attention_heads=HEADS,
+                             intermediate_size=FFN, max_position_embeddings=MAXPOS + 2, type_vocab_size=1,
+                             layer_norm_eps=1e-5, pad_token_id=1, attn_implementation='eager')
+        rargs = make_args(adapter_type='prompt', n_tokens=8, arch='cpc', bert_model_load='roberta_tiny')
+        rbase = Model(rargs, ITEM_NUM, True, RobertaModel(rcfg))
+        fx = np.load(os.path.join(OUT, 'base_roberta.npz'))
+        rbase.load_state_dict({k[3:]: torch.from_numpy(fx[k]) for k in fx.files if k.startswith('sd/')})
+        rbase.eval()
+        run_variant('roberta_prompt', rbase, fx['item_content'], torch.from_numpy(fx['sample_items']), torch.from_numpy(fx['log_mask']), rargs)
+        return
     if len(sys.argv) > 2 and sys.argv[1] == '--only':        # later additions: rebuild the base from base.npz, write ONE new fixture
         fx = np.load(os.path.join(OUT, 'base.npz'))
         base.load_state_dict({k[3:]: torch.from_numpy(fx[k]) for k in fx.files if k.startswith('sd/')})
