@@ -30,6 +30,9 @@ def pad_to(n, m):
     return (n + m - 1) // m * m
 
 
+import os as _os
+WGRAD_STREAM = bool(int(_os.environ.get('A4R_WGRAD_STREAM', '1')))     # adapter weight gradients on a side stream (see _adapter_wgrads); 0 = single stream
+
 class _LN:
     """LayerNorm parameters (fp32) + optional gradient sinks."""
 
@@ -193,6 +196,7 @@ class TransRecEngine:
         self.cap_users = 0
         self._bufs, self._saved_bert, self._saved_sas = {}, None, None
         self._ctx = None
+        self._wstream, self._wdone, self._wev = None, None, None     # optional side stream for the adapter weight gradients (A4R_WGRAD_STREAM)
         self._saved_M = self._saved_Mu = 0
 
     def _require_device(self, p0):
@@ -713,6 +717,7 @@ class TransRecEngine:
         T, H = blk.T, blk.H
         v, st = bufs['v' + which], bufs['st' + which]
         gg = lambda f: f() if f is not None else None
+        self._wgrad_join()                               # dzp / dv are about to be overwritten
         if ad is None:
             dv = self._buf('dv' + which, M, H, T)
             L.ln_bwd(self._vc(blk, dy), self._vc(blk, v), st, ln.gamma, self._vc(blk, dv), M=M, dgamma=gg(ln.g_gamma), dbeta=gg(ln.g_beta))
@@ -778,10 +783,41 @@ class TransRecEngine:
             lo.g_B().add_(lo.s_B[:, :lo.r], alpha=lo.scaling)
             lo.g_A().add_(lo.s_A[:lo.r])
 
+    WGRAD_SIDE_OK = True            # the text tower's backward joins the side stream before dv / dzp are reused (_sub_backward)
+
+    def _wgrad_join(self):
+        """Main stream waits for the weight-gradient kernels that were put on the side stream (no-op without one)."""
+        if self._wdone is not None:
+            torch.cuda.current_stream().wait_event(self._wdone)
+            self._wdone = None
+
     def _adapter_wgrads(self, ad, dv, z, dzp, down_in, M):
-        """dW_up = dv^T z, dW_down = dzp^T down_in, db_down = colsum(dzp)  (db_up comes from ln_bwd's dbias)."""
+        """dW_up = dv^T z, dW_down = dzp^T down_in, db_down = colsum(dzp)  (db_up comes from ln_bwd's dbias).
+        A4R_WGRAD_STREAM=1: on a side stream, to run in the tail rounds of the dgrad GEMMs that follow (nothing on the
+        dgrad chain reads these results); joined before dv / dzp are reused and at the end of the backward pass."""
         if ad.virtual is None and ad.g_wu is None:
             return                       # frozen adapter: nothing to accumulate
+        if WGRAD_STREAM and self.WGRAD_SIDE_OK and ad.s_wu is None and ad.virtual is None and torch.device(self.dev).type == 'cuda':
+            if self._wstream is None:
+                self._wstream = torch.cuda.Stream(device=self.dev)
+                self._wev = [torch.cuda.Event(), torch.cuda.Event()]
+            ev = self._wev[0]
+            ev.record()
+            with torch.cuda.stream(self._wstream):
+                self._wstream.wait_event(ev)
+                L.gemm_tn(dv, z, ad.g_wu(), M=M)
+                L.gemm_tn(dzp, down_in, ad.g_wd(), M=M)
+                if ad.g_bd is not None and ad.s_bd is None:
+                    L.colsum(dzp, ad.g_bd(), M=M)
+                self._wev[1].record()
+            self._wdone = self._wev[1]
+            self._wev.reverse()
+            if ad.g_bd is not None and ad.s_bd is not None:
+                self._wgrad_join()
+                ad.s_bd.zero_()
+                L.colsum(dzp, ad.s_bd, M=M)
+                ad.g_bd().add_(ad.s_bd[:ad.d])
+            return
         if ad.s_wu is None:
             L.gemm_tn(dv, z, ad.g_wu(), M=M)
             L.gemm_tn(dzp, down_in, ad.g_wd(), M=M)
@@ -1105,6 +1141,7 @@ class TransRecEngine:
             self.g_pos_emb()[:Tn].add_(d_in[:B * Tn].view(B, Tn, E).sum(0))
         L.emb_grad_add_inputs(d_in, d_emb, B, self.Lseq, E)
         self._items_backward(c, d_emb, Ip)
+        self._wgrad_join()
         if self._virtual:
             self._virtual_backward()
         if into_flat_grad:

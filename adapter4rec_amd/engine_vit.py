@@ -27,6 +27,8 @@ from .model.modules import AdapterBlock, HyperComplexAdapterBlock
 
 
 class ViTRecEngine(TransRecEngine):
+    WGRAD_SIDE_OK = False           # the image tower's gradient buffers ping-pong: its weight gradients stay on the main stream
+
     # ------------------------------------------------------------------ build
     def _build_item_tower(self):
         enc = self.model.cv_encoder
