@@ -27,8 +27,18 @@ extern "C" int a4r_debug_stamps(unsigned long long* host_out) {
     return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_a4r_stamps), sizeof(g_a4r_stamps)) == hipSuccess ? 0 : -2;
 }
 #define A4R_STAMP_AT(i_) if (stamp_iter < 2 && tid == 0) g_a4r_stamps[blockIdx.x * 8 + (i_)] = __builtin_amdgcn_s_memtime();
+#ifdef A4R_STAMP2
+__device__ unsigned long long g_a4r_barstamps[256 * 16 * 8 * 3];
+extern "C" int a4r_debug_barstamps(unsigned long long* host_out) {
+    return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_a4r_barstamps), sizeof(g_a4r_barstamps)) == hipSuccess ? 0 : -2;
+}
+#define A4R_BAR_INC ++bar_idx_;
+#else
+#define A4R_BAR_INC
+#endif
 #else
 #define A4R_STAMP_AT(i_)
+#define A4R_BAR_INC
 #endif
 
 namespace {
@@ -104,11 +114,24 @@ __global__ void __launch_bounds__(512, 2) gemm_nt_256_kernel(const a4r_gemm_t p,
         glds16(src_, off_[1], dst_ + 1024u);                                                                         \
     }
 #define A4R_WAIT_BARRIER(steady_) A4R_WAIT_BARRIER_N(steady_, 8)
+#ifdef A4R_STAMP2
+    // diagnostic: per-wave s_memtime at [before the waitcnt | before s_barrier | after it] of 16 consecutive barriers of the second tile
+    int bar_idx_ = 0;
+#define A4R_BAR_STAMP(k_)                                                                                             \
+    if (stamp_iter == 1 && bar_idx_ >= 64 && bar_idx_ < 80 && lane == 0)                                             \
+        g_a4r_barstamps[((blockIdx.x * 16 + (bar_idx_ - 64)) * 8 + wave) * 3 + (k_)] = __builtin_amdgcn_s_memtime();
+#else
+#define A4R_BAR_STAMP(k_)
+#endif
 #define A4R_WAIT_BARRIER_N(steady_, n_)                                                                              \
+    A4R_BAR_STAMP(0)                                                                                                 \
     if (steady_) asm volatile("s_waitcnt vmcnt(" #n_ ") lgkmcnt(0)" ::: "memory");                                   \
     else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");                                                 \
+    A4R_BAR_STAMP(1)                                                                                                 \
     if (!(A4R_ABL_ & 8)) __builtin_amdgcn_s_barrier();                                                               \
-    asm volatile("" ::: "memory");
+    asm volatile("" ::: "memory");                                                                                   \
+    A4R_BAR_STAMP(2)                                                                                                 \
+    A4R_BAR_INC
 
     // A phase after its barrier = {issue one unit's LDS-DMA} + {16 MFMAs}.  The two waves that share a SIMD (w and w + 4)
     // run them in OPPOSITE order (STAG): while one wave spends ~200 cycles issuing DMA the other owns the matrix pipe,
@@ -218,6 +241,9 @@ __global__ void __launch_bounds__(512, 2) gemm_nt_256_kernel(const a4r_gemm_t p,
     asm volatile("" ::: "memory");
 #ifdef A4R_STAMP
     if (stamp_iter == 1) { A4R_STAMP_AT(4) }
+#endif
+#ifdef A4R_STAMP2
+    bar_idx_ = 0;
 #endif
 #pragma unroll
     for (int mi = 0; mi < 8; ++mi)
