@@ -57,14 +57,14 @@ A4R_DEV void epi_dropout(float (&v)[NC], uint64_t e0, uint64_t seed, uint32_t si
 }
 
 // pre_ld != nullptr: the NC elements of Pre were requested earlier by the caller (16-byte pieces; see load_pre_n)
-template <typename TO, int NC> A4R_DEV void load_pre_n(uint4* q, size_t grow, int gcol, const GemmEpi<TO>& e) {
+template <typename TO, int NC> A4R_DEV void load_pre_n(uint4* q, uint32_t grow, int gcol, const GemmEpi<TO>& e) {
 #pragma unroll
     for (int s = 0; s < NC * (int)sizeof(TO) / 16; ++s)
-        q[s] = *reinterpret_cast<const uint4*>(e.Pre + grow * e.ldpre + gcol + s * (16 / (int)sizeof(TO)));
+        q[s] = *reinterpret_cast<const uint4*>(e.Pre + (size_t)grow * (uint32_t)e.ldpre + gcol + s * (16 / (int)sizeof(TO)));
 }
 
 template <typename TO, int NC, int ACT = -1, int DACT = -1>
-A4R_DEV void epilogue_n(float (&v)[NC], const float* bias, size_t grow, int gcol, const GemmEpi<TO>& e, const uint4* pre_ld = nullptr,
+A4R_DEV void epilogue_n(float (&v)[NC], const float* bias, uint32_t grow, int gcol, const GemmEpi<TO>& e, const uint4* pre_ld = nullptr,
                         const uint4* r1_ld = nullptr, const uint4* r2_ld = nullptr) {
     const int act = ACT >= 0 ? ACT : e.act;
     const int dact = DACT >= 0 ? DACT : e.dact;
@@ -74,16 +74,16 @@ A4R_DEV void epilogue_n(float (&v)[NC], const float* bias, size_t grow, int gcol
         float d[NC];
 #pragma unroll
         for (int i = 0; i < NC; ++i) gelu_erf_both(v[i], v[i], d[i]);
-        store_n<TO, NC>(e.C2 + grow * e.ldc2 + gcol, d);
+        store_n<TO, NC>(e.C2 + (size_t)grow * (uint32_t)e.ldc2 + gcol, d);
     } else {
         if (e.C2) {
             if (e.c2_mode) {
                 float d[NC];
 #pragma unroll
                 for (int i = 0; i < NC; ++i) d[i] = act_bwd(v[i], act);
-                store_n<TO, NC>(e.C2 + grow * e.ldc2 + gcol, d);
+                store_n<TO, NC>(e.C2 + (size_t)grow * (uint32_t)e.ldc2 + gcol, d);
             } else {
-                store_n<TO, NC>(e.C2 + grow * e.ldc2 + gcol, v);
+                store_n<TO, NC>(e.C2 + (size_t)grow * (uint32_t)e.ldc2 + gcol, v);
             }
         }
         if (act != A4R_ACT_NONE) {
@@ -97,7 +97,7 @@ A4R_DEV void epilogue_n(float (&v)[NC], const float* bias, size_t grow, int gcol
 #pragma unroll
             for (int s = 0; s < NC / Elem<TO>::PER16; ++s) Elem<TO>::unpack(pre_ld[s], pre + s * Elem<TO>::PER16);
         } else {
-            load_n<TO, NC>(e.Pre + grow * e.ldpre + gcol, pre);
+            load_n<TO, NC>(e.Pre + (size_t)grow * (uint32_t)e.ldpre + gcol, pre);
         }
         if (dact == A4R_DACT_MUL_) {
 #pragma unroll
@@ -107,15 +107,16 @@ A4R_DEV void epilogue_n(float (&v)[NC], const float* bias, size_t grow, int gcol
             for (int i = 0; i < NC; ++i) v[i] *= act_bwd(pre[i], dact);
         }
     }
-    const uint64_t e0 = ((uint64_t)grow + e.row0) * (uint64_t)e.N + (uint64_t)gcol;
-    if (e.thr16 && e.drop_first) epi_dropout<NC>(v, e0, e.drop_seed, e.drop_site, e.thr16, e.keep_scale);
+    // (the element index of the dropout mask is only formed when a mask is drawn: it is 64-bit arithmetic per group)
+    if (e.thr16 && e.drop_first)
+        epi_dropout<NC>(v, ((uint64_t)grow + e.row0) * (uint64_t)e.N + (uint64_t)gcol, e.drop_seed, e.drop_site, e.thr16, e.keep_scale);
     if (e.R1) {
         float t[NC];
         if (r1_ld) {
 #pragma unroll
             for (int s = 0; s < NC / Elem<TO>::PER16; ++s) Elem<TO>::unpack(r1_ld[s], t + s * Elem<TO>::PER16);
         } else {
-            load_n<TO, NC>(e.R1 + grow * e.ldr1 + gcol, t);
+            load_n<TO, NC>(e.R1 + (size_t)grow * (uint32_t)e.ldr1 + gcol, t);
         }
 #pragma unroll
         for (int i = 0; i < NC; ++i) v[i] += t[i];
@@ -126,13 +127,14 @@ A4R_DEV void epilogue_n(float (&v)[NC], const float* bias, size_t grow, int gcol
 #pragma unroll
             for (int s = 0; s < NC / Elem<TO>::PER16; ++s) Elem<TO>::unpack(r2_ld[s], t + s * Elem<TO>::PER16);
         } else {
-            load_n<TO, NC>(e.R2 + grow * e.ldr2 + gcol, t);
+            load_n<TO, NC>(e.R2 + (size_t)grow * (uint32_t)e.ldr2 + gcol, t);
         }
 #pragma unroll
         for (int i = 0; i < NC; ++i) v[i] += t[i];
     }
-    if (e.thr16 && !e.drop_first) epi_dropout<NC>(v, e0, e.drop_seed, e.drop_site, e.thr16, e.keep_scale);
-    store_n<TO, NC>(e.C + grow * e.ldc + gcol, v);
+    if (e.thr16 && !e.drop_first)
+        epi_dropout<NC>(v, ((uint64_t)grow + e.row0) * (uint64_t)e.N + (uint64_t)gcol, e.drop_seed, e.drop_site, e.thr16, e.keep_scale);
+    store_n<TO, NC>(e.C + (size_t)grow * (uint32_t)e.ldc + gcol, v);
 }
 // the NC elements of a residual operand as 16-byte pieces, for a caller that requests them ahead of use (r1_ld / r2_ld above)
 template <typename TO, int NC> A4R_DEV void load_res_n(uint4* q, const TO* R, int ldr, size_t grow, int gcol) {
