@@ -307,11 +307,13 @@ def main():
     roof = None
     if rank == 0 and not a.no_roofline:
         import adapter4rec_amd.engine as E
-        with GemmProbe(E.L) as probe:
+        side, E.WGRAD_STREAM = E.WGRAD_STREAM, False             # single stream here: an event pair would also time the wait for CUs that
+        with GemmProbe(E.L) as probe:                            # side-stream weight-gradient kernels still hold when a GEMM is launched
             for i in range(2):                                   # rank 0 only: NO collective in here (the other ranks have moved on)
                 step(a.warmup + a.steps + i, exchange=False)
             agg = probe.summary()
             shapes = probe.by_shape()
+        E.WGRAD_STREAM = side
         tname = 'torch.bfloat16' if a.dtype == 'bf16' else 'torch.float32'
         key = max((k for k in agg if k[0] == tname and k[1] == tname), key=lambda k: agg[k][1])     # most GPU time
         f, t, n = agg[key]
