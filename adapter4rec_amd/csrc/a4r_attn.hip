@@ -246,43 +246,54 @@ __global__ void __launch_bounds__(WAVES * 64) attn_bwd_kernel(const T* __restric
     const T* dbase = dout + (size_t)item * S * ldo + head * DH;
     T* gbase = dqkv + (size_t)item * S * ld + head * DH;
 
-    // stage Q, K, dO (rows >= S zero)
+    // Every global read of the pair is requested BEFORE anything is consumed: the staged copies of Q, K, dO (contraction down the
+    // rows) and the row-major operand fragments of Q K^T and dO V^T (the second touch of Q, K, dO hits L2).  Issued phase by phase
+    // (stage -> wait -> scores -> wait -> dP) a wave had ~5 KB in flight three times over; with 8 waves per CU (LDS-bound) that was 2.8 TB/s.
+    uint4 sq[C::NLD], sk[C::NLD], sd[C::NLD];
 #pragma unroll
     for (int i = 0; i < C::NLD; ++i) {
         const int id = lane + 64 * i, row = id / C::CPR, ch = id % C::CPR;
-        uint4 q = make_uint4(0u, 0u, 0u, 0u), k = q, d = q;
+        sq[i] = make_uint4(0u, 0u, 0u, 0u); sk[i] = sq[i]; sd[i] = sq[i];
         if (row < S) {
-            q = ldg16(base + (size_t)row * ld + q_off + ch * C::PER);
-            k = ldg16(base + (size_t)row * ld + k_off + ch * C::PER);
-            d = ldg16(dbase + (size_t)row * ldo + ch * C::PER);
+            sq[i] = ldg16(base + (size_t)row * ld + q_off + ch * C::PER);
+            sk[i] = ldg16(base + (size_t)row * ld + k_off + ch * C::PER);
+            sd[i] = ldg16(dbase + (size_t)row * ldo + ch * C::PER);
         }
-        lds_put16<T, C::GSTRIDE>(Qs, row, ch, q);
-        lds_put16<T, C::GSTRIDE>(Ks, row, ch, k);
-        lds_put16<T, C::GSTRIDE>(dOs, row, ch, d);
+    }
+    uint4 fq[C::KSD][2], fk[C::KSD][2], fd[C::KSD][2], fv[C::KSD][2];
+#pragma unroll
+    for (int ks = 0; ks < C::KSD; ++ks)
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const int row = t * 16 + r16, rc = min(row, S - 1);
+            fq[ks][t] = ldg16(base + (size_t)rc * ld + q_off + (ks * 4 + kg) * C::PER);
+            fk[ks][t] = ldg16(base + (size_t)rc * ld + k_off + (ks * 4 + kg) * C::PER);
+            fv[ks][t] = ldg16(base + (size_t)rc * ld + v_off + (ks * 4 + kg) * C::PER);
+            fd[ks][t] = make_uint4(0u, 0u, 0u, 0u);
+            if (row < S) fd[ks][t] = ldg16(dbase + (size_t)row * ldo + (ks * 4 + kg) * C::PER);
+        }
+#pragma unroll
+    for (int i = 0; i < C::NLD; ++i) {
+        const int id = lane + 64 * i, row = id / C::CPR, ch = id % C::CPR;
+        lds_put16<T, C::GSTRIDE>(Qs, row, ch, sq[i]);
+        lds_put16<T, C::GSTRIDE>(Ks, row, ch, sk[i]);
+        lds_put16<T, C::GSTRIDE>(dOs, row, ch, sd[i]);
     }
 
     f32x4_t sc[2][2], dp[2][2];
-    qk_scores<T, DH>(base, ld, q_off, k_off, S, lane, sc);
-    // dP' = dO . V^T  (dO rows >= S are zero, so dS rows >= S vanish)
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
-        for (int nt = 0; nt < 2; ++nt) dp[mt][nt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+        for (int nt = 0; nt < 2; ++nt) { sc[mt][nt] = f32x4_t{0.f, 0.f, 0.f, 0.f}; dp[mt][nt] = sc[mt][nt]; }
 #pragma unroll
-    for (int ks = 0; ks < C::KSD; ++ks) {
-        uint4 da[2], vb[2];
-#pragma unroll
-        for (int t = 0; t < 2; ++t) {
-            const int row = t * 16 + r16;
-            da[t] = make_uint4(0u, 0u, 0u, 0u);
-            if (row < S) da[t] = ldg16(dbase + (size_t)row * ldo + (ks * 4 + kg) * C::PER);
-            vb[t] = ldg16(base + (size_t)min(row, S - 1) * ld + v_off + (ks * 4 + kg) * C::PER);
-        }
+    for (int ks = 0; ks < C::KSD; ++ks)
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
-            for (int nt = 0; nt < 2; ++nt) Mma<T>::mma(da[mt], vb[nt], dp[mt][nt]);
-    }
+            for (int nt = 0; nt < 2; ++nt) {
+                Mma<T>::mma(fq[ks][mt], fk[ks][nt], sc[mt][nt]);
+                Mma<T>::mma(fd[ks][mt], fv[ks][nt], dp[mt][nt]);      // dP' = dO . V^T  (dO rows >= S are zero, so dS rows >= S vanish)
+            }
 
     float km[2];
 #pragma unroll
