@@ -97,6 +97,14 @@ __global__ void __launch_bounds__(WAVES * 64) attn_fwd_kernel(const T* __restric
     const int item = gw / n_heads, head = gw % n_heads;
     const T* base = qkv + (size_t)item * S * ld + head * DH;
 
+    // V is requested before the scores are computed (its loads used to be issued only after Q K^T had waited for Q and K)
+    uint4 sv[C::NLD];
+#pragma unroll
+    for (int i = 0; i < C::NLD; ++i) {
+        const int id = lane + 64 * i, row = id / C::CPR, ch = id % C::CPR;
+        sv[i] = make_uint4(0u, 0u, 0u, 0u);
+        if (row < S) sv[i] = ldg16(base + (size_t)row * ld + v_off + ch * C::PER);
+    }
     f32x4_t sc[2][2];
     qk_scores<T, DH>(base, ld, q_off, k_off, S, lane, sc);
 
@@ -104,9 +112,7 @@ __global__ void __launch_bounds__(WAVES * 64) attn_fwd_kernel(const T* __restric
 #pragma unroll
     for (int i = 0; i < C::NLD; ++i) {
         const int id = lane + 64 * i, row = id / C::CPR, ch = id % C::CPR;
-        uint4 v = make_uint4(0u, 0u, 0u, 0u);
-        if (row < S) v = ldg16(base + (size_t)row * ld + v_off + ch * C::PER);
-        lds_put16<T, C::GSTRIDE>(Vs, row, ch, v);
+        lds_put16<T, C::GSTRIDE>(Vs, row, ch, sv[i]);
     }
 
     float km[2];
