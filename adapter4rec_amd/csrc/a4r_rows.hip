@@ -193,6 +193,7 @@ __global__ void __launch_bounds__(256) ln_bwd_kernel(const T* __restrict__ dy, i
 #pragma unroll
         for (int e = 0; e < 8; ++e) { sg[g][e] = 0.f; sb[g][e] = 0.f; sv[g][e] = 0.f; }
     for (int row = blockIdx.x * 4 + wave; row < M; row += gridDim.x * 4) {
+        const float mean = stats[2 * (size_t)row], rstd = stats[2 * (size_t)row + 1];      // requested with the row, not after the dropout mask
         float v[MAXG][8], d[MAXG][8];
         row_load<T>(vin + (size_t)row * ldv, ng, lane, v);
         row_load<T>(dy + (size_t)row * lddy, ng, lane, d);
@@ -205,7 +206,6 @@ __global__ void __launch_bounds__(256) ln_bwd_kernel(const T* __restrict__ dy, i
                 for (int e = 0; e < 8; ++e) v[g][e] += a[g][e];
         }
         if (thr16) row_dropout(d, ng, lane, row, H, seed, site, thr16, scale);
-        const float mean = stats[2 * (size_t)row], rstd = stats[2 * (size_t)row + 1];
         float c1 = 0.f, c2 = 0.f;
 #pragma unroll
         for (int g = 0; g < MAXG; ++g) {
