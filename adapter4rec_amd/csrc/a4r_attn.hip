@@ -97,6 +97,13 @@ __global__ void __launch_bounds__(WAVES * 64) attn_fwd_kernel(const T* __restric
     const int item = gw / n_heads, head = gw % n_heads;
     const T* base = qkv + (size_t)item * S * ld + head * DH;
 
+    // (the key mask too: it used to be the third serial round trip of the wave)
+    float km[2];
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+        const int key = nt * 16 + r16;
+        km[nt] = (key < S) ? (key_mask ? key_mask[(size_t)item * S + key] : 1.f) : 0.f;
+    }
     // V is requested before the scores are computed (its loads used to be issued only after Q K^T had waited for Q and K)
     uint4 sv[C::NLD];
 #pragma unroll
@@ -115,12 +122,6 @@ __global__ void __launch_bounds__(WAVES * 64) attn_fwd_kernel(const T* __restric
         lds_put16<T, C::GSTRIDE>(Vs, row, ch, sv[i]);
     }
 
-    float km[2];
-#pragma unroll
-    for (int nt = 0; nt < 2; ++nt) {
-        const int key = nt * 16 + r16;
-        km[nt] = (key < S) ? (key_mask ? key_mask[(size_t)item * S + key] : 1.f) : 0.f;
-    }
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
@@ -252,6 +253,12 @@ __global__ void __launch_bounds__(WAVES * 64) attn_bwd_kernel(const T* __restric
     const T* dbase = dout + (size_t)item * S * ldo + head * DH;
     T* gbase = dqkv + (size_t)item * S * ld + head * DH;
 
+    float km[2];
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+        const int key = nt * 16 + r16;
+        km[nt] = (key < S) ? (key_mask ? key_mask[(size_t)item * S + key] : 1.f) : 0.f;
+    }
     // Every global read of the pair is requested BEFORE anything is consumed: the staged copies of Q, K, dO (contraction down the
     // rows) and the row-major operand fragments of Q K^T and dO V^T (the second touch of Q, K, dO hits L2).  Issued phase by phase
     // (stage -> wait -> scores -> wait -> dP) a wave had ~5 KB in flight three times over; with 8 waves per CU (LDS-bound) that was 2.8 TB/s.
@@ -301,12 +308,6 @@ __global__ void __launch_bounds__(WAVES * 64) attn_bwd_kernel(const T* __restric
                 Mma<T>::mma(fd[ks][mt], fv[ks][nt], dp[mt][nt]);      // dP' = dO . V^T  (dO rows >= S are zero, so dS rows >= S vanish)
             }
 
-    float km[2];
-#pragma unroll
-    for (int nt = 0; nt < 2; ++nt) {
-        const int key = nt * 16 + r16;
-        km[nt] = (key < S) ? (key_mask ? key_mask[(size_t)item * S + key] : 1.f) : 0.f;
-    }
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
