@@ -57,6 +57,22 @@ __global__ void __launch_bounds__(256) skinny64_kernel(const a4r_gemm_t p, uint3
     issue(1);
 
     const int fr = lane & 15, kg = lane >> 4;
+    // bias and the Pre operand of the dgrad form (dz = dy . W_up * act'(zpre)) are requested now, not in the epilogue
+    const GemmEpi<TO> epi = make_epi<TO>(p, thr16, keep_scale);
+    const size_t grow = (size_t)blockIdx.x * 64 + 16 * wave + fr;
+    const int gcolp = (kg & 1) * 16 + (kg >> 1) * 8;                       // + pair * 32
+    float b8[2][8];
+#pragma unroll
+    for (int pr = 0; pr < 2; ++pr)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) b8[pr][e] = epi.bias ? epi.bias[gcolp + pr * 32 + e] : 0.f;
+    constexpr int PS = 8 * (int)sizeof(TO) / 16;
+    uint4 pre_ld[2][PS];
+    const bool has_pre = epi.dact != A4R_ACT_NONE;
+    if (has_pre) {
+        load_pre_n<TO, 8>(pre_ld[0], grow, gcolp, epi);
+        load_pre_n<TO, 8>(pre_ld[1], grow, gcolp + 32, epi);
+    }
     int a_off[2], b_off[2];
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
@@ -89,21 +105,16 @@ __global__ void __launch_bounds__(256) skinny64_kernel(const a4r_gemm_t p, uint3
     }
 
     // ---- epilogue from the (transposed) accumulators: lane (fr, kg) holds row fr, columns ni*16 + kg*4 .. +3 of tile ni
-    const GemmEpi<TO> epi = make_epi<TO>(p, thr16, keep_scale);
-    const size_t grow = (size_t)blockIdx.x * 64 + 16 * wave + fr;
-    const int gcolp = (kg & 1) * 16 + (kg >> 1) * 8;                       // + pair * 32
 #pragma unroll
     for (int pr = 0; pr < 2; ++pr) {
-        float v[8], b8[8];
+        float v[8];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const auto sw = __builtin_amdgcn_permlane16_swap(__float_as_uint(acc[2 * pr][r]), __float_as_uint(acc[2 * pr + 1][r]), false, false);
             v[r] = __uint_as_float(sw[0]);
             v[4 + r] = __uint_as_float(sw[1]);
         }
-#pragma unroll
-        for (int e = 0; e < 8; ++e) b8[e] = epi.bias ? epi.bias[gcolp + pr * 32 + e] : 0.f;
-        epilogue_n<TO, 8>(v, b8, grow, gcolp + pr * 32, epi);
+        epilogue_n<TO, 8>(v, b8[pr], grow, gcolp + pr * 32, epi, has_pre ? pre_ld[pr] : nullptr);
     }
 }
 
