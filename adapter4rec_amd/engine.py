@@ -195,6 +195,7 @@ class TransRecEngine:
         self.cap_items = 0
         self.cap_users = 0
         self._bufs, self._saved_bert, self._saved_sas = {}, None, None
+        self._dirty = {}            # (_buf key) -> rows a partial-row producer has written (see _buf_tail0)
         self._ctx = None
         self._wstream, self._wdone, self._wev = None, None, None     # optional side stream for the adapter weight gradients (A4R_WGRAD_STREAM)
         self._saved_M = self._saved_Mu = 0
@@ -609,6 +610,21 @@ class TransRecEngine:
             self._bufs[key] = t
         return t[:rows]
 
+    def _buf_tail0(self, name, rows, cols, dt, real):
+        """_buf for a gradient buffer whose producer writes only the first `real` rows while its consumers (dgrad GEMMs, ln_bwd
+        column sums, gemm_tn weight gradients) run over all `rows` padded rows: rows [real, rows) must be EXACT zeros or a smaller
+        batch that follows a larger one (run.py's DataLoader has no drop_last) sums the previous batch's rows into the adapter
+        gradients.  A fresh buffer is zero; afterwards only what an earlier, larger call wrote has to be cleared, so the steady
+        state (same batch size every step) costs no launch."""
+        t = self._buf(name, rows, cols, dt)
+        key = (name, cols, dt)
+        hw = self._dirty.get(key, 0)
+        if hw > real:
+            full = self._bufs[key]
+            full[real:min(hw, full.shape[0])].zero_()
+        self._dirty[key] = real
+        return t
+
     def _block_bufs(self, tag, blk, M, shared, Mc=None):
         """Activation buffers of one block: `shared` => transient set reused by every block (inference).
         Mc: row count of everything AFTER attention when only the CLS rows are carried on (last encoder layer)."""
@@ -868,7 +884,7 @@ class TransRecEngine:
             rfull.zero_()
             L.scatter_rows(dres1, rfull, n_items, blk.S)
             dres1 = rfull
-        dqkv = self._buf('dqkv', M, 3 * H, T)
+        dqkv = self._buf_tail0('dqkv', M, 3 * H, T, n_items * blk.S)       # attn_bwd writes the real token rows only
         L.attn_bwd(bufs['qkv'], dctx, dqkv, key_mask, n_items, blk.S, blk.nh, blk.dh, 0, H, 2 * H, blk.causal, blk.scale, blk.mask_neg,
                    drop_p=pa, drop_site=blk.site, drop_seed=seed)
         for lo in blk.lora:
@@ -1107,8 +1123,8 @@ class TransRecEngine:
         E, Tn = self.E, self.Lseq - 1
         train = c['train']
         Ip = pad_to(n_items, 128)
-        d_prec = self._buf('d_prec', Mu, E, torch.float32)
-        d_emb = self._buf('d_emb', Ip, E, torch.float32)
+        d_prec = self._buf_tail0('d_prec', Mu, E, torch.float32, B * Tn)     # score_bce_bwd writes the real rows only
+        d_emb = self._buf_tail0('d_emb', Ip, E, torch.float32, n_items)
         L.score_bce_bwd(c['emb'], c['prec'], c['lm'], c['pos'], c['neg'], c['ws'], 1.0, d_prec, d_emb, B, self.Lseq, E, self.arch == 'cpc')
         # SASRec blocks, last to first
         dx = d_prec

@@ -258,7 +258,7 @@ class ViTRecEngine(TransRecEngine):
             rfull.zero_()
             L.scatter_rows(dx1, rfull, n_items, blk.S)
             dx1 = rfull
-        dqkv = self._buf('dqkv', M, 3 * H, T)
+        dqkv = self._buf_tail0('dqkv', M, 3 * H, T, n_items * blk.S)       # attn_long_bwd writes the real token rows only
         ws = self._buf('attn_ws', bufs['lse'].shape[0], 1, torch.float32)
         L.attn_long_bwd(bufs['qkv'], bufs['ctx_o'], dctx, dqkv, bufs['lse'], ws, n_items, blk.S, blk.nh, blk.dh, 0, H, 2 * H, blk.scale)
         for lo in blk.lora:

@@ -101,3 +101,37 @@ def test_shapes_host_logic(simulated, case):
 @pytest.mark.parametrize('case', list(CASES))
 def test_shapes_gpu(case):
     check(case, 'cuda:0')
+
+
+def large_then_small(case, device):
+    """A smaller batch after a larger one on the SAME engine (the last batch of every epoch: run.py's DataLoader has no
+    drop_last, Downstream/Text/run.py:356) must give the gradients of a fresh engine: the cached work buffers are sliced to a
+    padded row count and the padding rows of the gradient buffers have to be exact zeros again."""
+    c = CASES[case]
+    L2 = 2 * (c['T'] + 1)
+
+    def grads(model, items, mask):
+        model.zero_grad()
+        loss = model(items, mask, device)
+        loss.backward()
+        return loss.item(), {n: p.grad.detach().cpu().clone() for n, p in model.named_parameters() if p.requires_grad}
+
+    model, args, geom, items, mask = make(case, device)
+    grads(model, items, mask)                                   # B users
+    l_small, g_small = grads(model, items[:L2], mask[:1])       # then 1 user on the same buffers
+    fresh, *_ = make(case, device)
+    l_ref, g_ref = grads(fresh, items[:L2], mask[:1])
+    assert abs(l_small - l_ref) < 1e-6 * max(1.0, abs(l_ref))
+    for n, ref in g_ref.items():
+        np.testing.assert_allclose(g_small[n].numpy(), ref.numpy(), atol=1e-7 + 2e-6 * ref.abs().max().item(), rtol=0, err_msg=n)
+
+
+@pytest.mark.parametrize('case', ['short_titles', 'five_users_cpc'])
+def test_large_then_small_batch_host_logic(simulated, case):
+    large_then_small(case, 'cpu')
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('case', ['short_titles', 'five_users_cpc', 'long_history_32'])
+def test_large_then_small_batch_gpu(case):
+    large_then_small(case, 'cuda:0')
