@@ -15,6 +15,7 @@ LIB_PATH = os.environ.get('A4R_LIB_PATH') or os.path.join(_HERE, 'liba4r_hip.so'
 BF16, F32 = 0, 1
 ACT_NONE, ACT_RELU, ACT_GELU, ACT_GELU_TANH, ACT_LEAKY = 0, 1, 2, 3, 4
 DACT_MUL = 15
+EVAL_MAX_HISTORY = 64          # A4R_EVAL_MAX_HISTORY (include/a4r.h)
 ACT_BY_NAME = {'none': 0, 'relu': 1, 'RELU': 1, 'gelu': 2, 'GELU': 2, 'gelu_new': 3, 'leaky_relu': 4}
 
 EXPORTS = [

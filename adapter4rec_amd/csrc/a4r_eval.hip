@@ -14,7 +14,7 @@
 
 namespace {
 
-constexpr int MAXH = 32;   // history ids per user kept in LDS (reference keeps <= max_seq_len + 2 = 22)
+constexpr int MAXH = A4R_EVAL_MAX_HISTORY;   // history ids per user kept in LDS (reference keeps <= max_seq_len + 2 = 22; the engine allows max_seq_len <= 32)
 
 template <int E>
 __global__ void __launch_bounds__(256) eval_rank_kernel(const float* __restrict__ prec, const float* __restrict__ item_emb,

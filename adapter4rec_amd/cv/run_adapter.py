@@ -137,6 +137,8 @@ def train(args, use_modal, local_rank, Log_file, Log_screen, model_dir, start_ti
                 Log_file.info('cnt: {}, Ed: {}, batch loss: {:.5f}, sum loss: {:.5f}'.format(
                     batch_index, batch_index * args.batch_size, loss.item() / batch_index, loss.item()))
             batch_index += 1
+        if not need_break and bool(torch.isnan(loss)):                 # a NaN after the last log step: never evaluate / save NaN weights
+            need_break = True
         if not need_break:
             hit10 = run_eval_once(model, db, item_id_to_keys, hist_valid, users_valid, 256, item_num, 'valid', local_rank, args, Log_file)
             if hit10 > max_eval:

@@ -82,7 +82,10 @@ def eval_ranks(model, user_history, eval_seq, item_embeddings, test_batch_size, 
                 ids[r, pad:] = toks
                 mask[r, pad:] = 1.0
                 target.append(seq[-1])
-                h = [int(x) for x in np.asarray(user_history[u]).reshape(-1)][-32:]
+                h = [int(x) for x in np.asarray(user_history[u]).reshape(-1)]
+                if len(h) > L.EVAL_MAX_HISTORY:        # never truncate: an unmasked history item changes ranks silently
+                    raise ValueError(f'user {u}: history of {len(h)} items exceeds A4R_EVAL_MAX_HISTORY = {L.EVAL_MAX_HISTORY} '
+                                     f'(the reference keeps max_seq_len + 2 = {args.max_seq_len + 2})')
                 hist += h
                 ptr.append(len(hist))
             ids_t = torch.from_numpy(ids).to(dev)

@@ -145,6 +145,8 @@ def train(args, use_modal, local_rank, Log_file, Log_screen, model_dir, start_ti
                 Log_file.info('cnt: {}, Ed: {}, batch loss: {:.5f}, sum loss: {:.5f}'.format(
                     batch_index, batch_index * args.batch_size, loss.item() / batch_index, loss.item()))
             batch_index += 1
+        if not need_break and bool(torch.isnan(loss)):                 # a NaN after the last log step of the epoch: the reference checks
+            need_break = True                                          # every batch (run.py:601-603); never evaluate / save NaN weights
         if not need_break:
             hit10 = run_eval_once(model, item_content, hist_valid, users_valid, 512, item_num, use_modal, 'valid', local_rank, args, Log_file)
             if hit10 > max_eval:

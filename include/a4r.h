@@ -211,7 +211,11 @@ int a4r_pack_matrices(void* stream, const float* flat, const a4r_pack_desc_t* de
 
 /* Eval (data_utils/metrics.py:82-116): for user u with vector prec[u] (fp32 [U,E]) and item table
  * item_emb (fp32 [N1,E], row 0 = pad item): rank[u] = 1 + #{i in 1..N1-1, i not in hist(u),
- * score_i > score_target(u)} without materialising [U,N1].  hist in CSR form (hist_ptr [U+1], hist_idx). */
+ * score_i > score_target(u)} without materialising [U,N1].  hist in CSR form (hist_ptr [U+1], hist_idx); a user's
+ * history may hold at most A4R_EVAL_MAX_HISTORY ids (the reference keeps max_seq_len + 2, preprocess.py:51-59) --
+ * the caller checks this (the host cannot read hist_ptr without a sync); longer lists are NOT silently truncated by
+ * the Python mirror (data_utils/metrics.py raises). */
+#define A4R_EVAL_MAX_HISTORY 64
 int a4r_eval_rank(void* stream, const float* prec, const float* item_emb, const int32_t* target,
                   const int32_t* hist_ptr, const int32_t* hist_idx, int32_t* rank, int U, int N1, int E);
 

@@ -14,6 +14,7 @@ from adapter4rec_amd import _lib as REAL
 BF16, F32 = REAL.BF16, REAL.F32
 ACT_NONE, ACT_RELU, ACT_GELU, ACT_GELU_TANH, ACT_LEAKY = 0, 1, 2, 3, 4
 DACT_MUL = 15
+EVAL_MAX_HISTORY = REAL.EVAL_MAX_HISTORY
 ACT_BY_NAME = REAL.ACT_BY_NAME
 PackDesc = REAL.PackDesc
 
