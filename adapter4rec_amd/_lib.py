@@ -301,9 +301,10 @@ def score_bce_fwd(emb, prec, log_mask, pos, neg, loss_ws, B, L, E, cpc):
                                    C.c_int(B), C.c_int(L), C.c_int(E), C.c_int(int(cpc))), 'a4r_score_bce_fwd')
 
 
-def score_bce_bwd(emb, prec, log_mask, pos, neg, loss_ws, loss_scale, d_prec, d_emb, B, L, E, cpc):
-    require_gpu(emb, prec)
-    _check(lib().a4r_score_bce_bwd(_stream(), _p(emb), _p(prec), _p(log_mask), _p(pos), _p(neg), _p(loss_ws), C.c_float(loss_scale),
+def score_bce_bwd(emb, prec, log_mask, pos, neg, loss_ws, loss_scale, d_prec, d_emb, B, L, E, cpc, scale_dev=None):
+    require_gpu(emb, prec, scale_dev)
+    assert scale_dev is None or (scale_dev.dtype == torch.float32 and scale_dev.numel() == 1)
+    _check(lib().a4r_score_bce_bwd(_stream(), _p(emb), _p(prec), _p(log_mask), _p(pos), _p(neg), _p(loss_ws), C.c_float(loss_scale), _p(scale_dev),
                                    _p(d_prec), _p(d_emb), C.c_int(B), C.c_int(L), C.c_int(E), C.c_int(int(cpc))), 'a4r_score_bce_bwd')
 
 

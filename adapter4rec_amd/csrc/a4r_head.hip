@@ -40,10 +40,10 @@ __global__ void loss_finalize_kernel(float* ws) { ws[0] = ws[1] / ws[2]; }
 __global__ void __launch_bounds__(256) score_bwd_kernel(const float* __restrict__ emb, const float* __restrict__ prec,
                                                         const float* __restrict__ log_mask, const float* __restrict__ pos,
                                                         const float* __restrict__ neg, const float* __restrict__ ws, float loss_scale,
-                                                        float* __restrict__ d_prec, float* __restrict__ d_emb, int B, int L, int E, int cpc) {
+                                                        const float* __restrict__ loss_scale_dev, float* __restrict__ d_prec, float* __restrict__ d_emb, int B, int L, int E, int cpc) {
     const int lane = threadIdx.x & 63;
     const int T = L - 1;
-    const float g = loss_scale / ws[2];
+    const float g = loss_scale * (loss_scale_dev ? loss_scale_dev[0] : 1.f) / ws[2];
     for (int r = blockIdx.x * 4 + (threadIdx.x >> 6); r < B * L; r += gridDim.x * 4) {
         const int b = r / L, l = r % L;
         float dpos_prev = 0.f, dneg_here = 0.f, dpos_here = 0.f;
@@ -144,12 +144,12 @@ extern "C" int a4r_score_bce_fwd(void* stream, const float* emb, const float* pr
 }
 
 extern "C" int a4r_score_bce_bwd(void* stream, const float* emb, const float* prec, const float* log_mask,
-                                 const float* pos, const float* neg, const float* loss_ws, float loss_scale,
+                                 const float* pos, const float* neg, const float* loss_ws, float loss_scale, const float* loss_scale_dev,
                                  float* d_prec, float* d_emb, int B, int L, int E, int cpc) {
     if (!emb || !prec || !log_mask || !pos || !neg || !loss_ws || !d_prec || !d_emb || B <= 0 || L < 2 || E <= 0) return A4R_EINVAL;
     int grid = (B * L + 3) / 4; if (grid > 1024) grid = 1024;
     hipLaunchKernelGGL(score_bwd_kernel, dim3(grid), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), emb, prec, log_mask, pos, neg,
-                       loss_ws, loss_scale, d_prec, d_emb, B, L, E, cpc);
+                       loss_ws, loss_scale, loss_scale_dev, d_prec, d_emb, B, L, E, cpc);
     return a4r_launch_status();
 }
 

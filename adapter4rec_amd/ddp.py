@@ -18,6 +18,7 @@ class FlatDDP(nn.Module):
         self.module = module
         self.process_group = process_group
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
+        self._avg = dist.is_initialized() and dist.get_backend(process_group) == 'nccl'
         if self.world > 1 and broadcast:                       # DDP constructor semantics: rank 0's state everywhere
             with torch.no_grad():
                 for t in list(module.parameters()) + list(module.buffers()):
@@ -32,8 +33,11 @@ class FlatDDP(nn.Module):
 
     def average_(self, flat):
         """In-place mean over ranks of one flat gradient buffer (a single RCCL all-reduce)."""
-        dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.process_group)
-        flat.mul_(1.0 / self.world)
+        if self._avg:                                          # RCCL averages inside the collective: one launch
+            dist.all_reduce(flat, op=dist.ReduceOp.AVG, group=self.process_group)
+        else:                                                  # gloo (CPU tests) has no AVG
+            dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.process_group)
+            flat.mul_(1.0 / self.world)
         return flat
 
     def forward(self, *args, **kwargs):

@@ -195,6 +195,8 @@ class TransRecEngine:
         self.cap_items = 0
         self.cap_users = 0
         self._bufs, self._saved_bert, self._saved_sas = {}, None, None
+        self._fused_opt = None      # FusedAdam once it is bound: p.grad are views of flat_g (see backward_bound)
+        self._flat_clean = False    # flat_g was zeroed by optimizer.zero_grad() and nothing has been accumulated since
         self._dirty = {}            # (_buf key) -> rows a partial-row producer has written (see _buf_tail0)
         self._ctx = None
         self._wstream, self._wdone, self._wev = None, None, None     # optional side stream for the adapter weight gradients (A4R_WGRAD_STREAM)
@@ -1108,9 +1110,27 @@ class TransRecEngine:
         c = self._ctx
         return c['pos'].clone(), c['neg'].clone()
 
-    def train_backward(self, grad_out=None, into_flat_grad=False):
+    def backward_bound(self, grad_out):
+        """Backward of the public path (loss.backward(), run.py:599) once FusedAdam owns the flat buffers: every p.grad IS a view
+        of flat_g, so the kernels accumulate straight into it (no per-parameter gradient list, no AccumulateGrad adds) and the
+        data-parallel exchange is ONE all-reduce of flat_g.  After optimizer.zero_grad() flat_g is known to be zero and is the
+        kernels' target; otherwise (gradient accumulation) the step goes to the scratch buffer and is added."""
+        ddp = getattr(self.model, '_a4r_ddp', None)
+        if self._flat_clean:
+            self._flat_clean = False
+            self.train_backward(grad_out, into_flat_grad=True)
+            if ddp is not None:                                   # DDP semantics: gradients averaged over ranks (run.py:503,599)
+                ddp.average_(self.flat_g)
+            return
+        self.train_backward(grad_out, into_flat_grad=False, as_list=False)
+        if ddp is not None:
+            ddp.average_(self.flat_gs)
+        self.flat_g.add_(self.flat_gs)
+
+    def train_backward(self, grad_out=None, into_flat_grad=False, as_list=True):
         """Native backward of the last train_forward.  into_flat_grad: accumulate straight into the flat
-        gradient buffer (fused path); else return per-parameter gradients for autograd to accumulate."""
+        gradient buffer (fused path); else into the scratch buffer, returned as per-parameter gradients for autograd to
+        accumulate (as_list).  grad_out: d(loss) as a 0-d fp32 DEVICE tensor (read by the head kernel, no host sync)."""
         c = self._ctx
         if c is None:
             raise RuntimeError('train_backward without train_forward')
@@ -1119,13 +1139,16 @@ class TransRecEngine:
         if not into_flat_grad:
             target.zero_()
         self._grad_target = target
+        if grad_out is not None:
+            grad_out = grad_out.detach().to(torch.float32).reshape(1)
         B, n_items, M, Mu, seed = c['B'], c['n_items'], c['M'], c['Mu'], c['seed']
         E, Tn = self.E, self.Lseq - 1
         train = c['train']
         Ip = pad_to(n_items, 128)
         d_prec = self._buf_tail0('d_prec', Mu, E, torch.float32, B * Tn)     # score_bce_bwd writes the real rows only
         d_emb = self._buf_tail0('d_emb', Ip, E, torch.float32, n_items)
-        L.score_bce_bwd(c['emb'], c['prec'], c['lm'], c['pos'], c['neg'], c['ws'], 1.0, d_prec, d_emb, B, self.Lseq, E, self.arch == 'cpc')
+        L.score_bce_bwd(c['emb'], c['prec'], c['lm'], c['pos'], c['neg'], c['ws'], 1.0, d_prec, d_emb, B, self.Lseq, E, self.arch == 'cpc',
+                        scale_dev=grad_out)
         # SASRec blocks, last to first
         dx = d_prec
         dlast = None
@@ -1160,10 +1183,8 @@ class TransRecEngine:
         self._wgrad_join()
         if self._virtual:
             self._virtual_backward()
-        if into_flat_grad:
+        if into_flat_grad or not as_list:
             return None
-        if grad_out is not None:
-            target.mul_(grad_out.to(target.dtype))
         out = target.clone()
         ddp = getattr(self.model, '_a4r_ddp', None)
         if ddp is not None:                                   # DDP semantics: gradients averaged over ranks (run.py:503,599)

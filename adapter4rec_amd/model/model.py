@@ -37,7 +37,11 @@ class _NativeLoss(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, grad_out):
-        grads = ctx.engine.train_backward(grad_out)
+        eng = ctx.engine
+        if eng._fused_opt is not None:           # FusedAdam bound: p.grad are views of the flat gradient buffer, filled in place
+            eng.backward_bound(grad_out)
+            return (None, None, None) + (None,) * ctx.n
+        grads = eng.train_backward(grad_out)
         return (None, None, None) + tuple(grads)
 
 

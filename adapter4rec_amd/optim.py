@@ -41,6 +41,7 @@ class FusedAdam(torch.optim.Optimizer):
         if covered != sum(n for _, n in eng.offsets.values()):
             raise RuntimeError('FusedAdam must own every trainable parameter of the engine (the flat buffer is updated as a whole)')
         self._bound = eng
+        eng._fused_opt = self
         self._attach_grads()
         self._apply_pending()
 
@@ -59,6 +60,7 @@ class FusedAdam(torch.optim.Optimizer):
         if self._bound is None:
             return super().zero_grad(set_to_none=True)
         self._bound.flat_g.zero_()
+        self._bound._flat_clean = True          # the next backward writes straight into flat_g (engine.backward_bound)
         self._attach_grads()
 
     @torch.no_grad()
@@ -66,6 +68,10 @@ class FusedAdam(torch.optim.Optimizer):
         if closure is not None:
             raise NotImplementedError('closure')
         if self._bound is None:
+            self._bind()
+        elif next(p for g in self.param_groups for p in g['params'])._a4r_flat[0] is not self._bound:
+            # the model rebuilt its engine (.to(device) / load_state_dict): move the moments over to the new flat buffers
+            self._pending = dict(step=self._step, m=self._m, v=self._v)
             self._bind()
         else:
             self._attach_grads()

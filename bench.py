@@ -8,7 +8,15 @@ buffer per step when --gpus > 1.  Synthetic data per SURVEY.md section 8(d): see
 canonical dense titles (30 tokens), every user a full 23-item history.  Random-init weights of the
 BERT-base geometry (no checkpoints in the image).
 
-A "step" = forward + backward + gradient all-reduce + Adam on one batch already resident in HBM.
+A "step" = the PUBLIC path of the drop-in boundary, exactly what adapter4rec_amd/run.py's loop executes (reference:
+Downstream/Text/run.py:595-600): optimizer.zero_grad(); loss = model(sample_items, log_mask, local_rank) through FlatDDP;
+loss.backward() (native backward straight into the flat gradient buffer + ONE RCCL all-reduce of it); optimizer.step()
+(FusedAdam) -- on one batch already resident in HBM.
+
+`--gpus N` with N > 1 and no launcher environment starts N ranks itself (one process per GPU, torch.distributed.run on
+127.0.0.1) BEFORE anything touches the GPU; under a launcher (WORLD_SIZE set) it is one of the ranks.  It exits non-zero if
+it ends up with a rank count other than N.  The JSON line carries `rccl_ranks` (the result of an actual all-reduce of ones),
+the all-reduce payload and its measured time.
 Prints ONE JSON line (rank 0).  `roofline` is for the dominant kernel (the bf16 MFMA GEMM), measured with HIP events
 in an instrumented pass run after the timed region; `cpu_baseline` times the CPU oracle (oracle/ref_cpu.py) on a
 bounded sample of the same workload on the host cores.
@@ -25,6 +33,8 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 MFMA_BF16_PEAK_TFLOPS = 2500.0      # dense bf16, /opt/skills/guides/MI355X_MICROARCH.md
+# algorithmic GFLOP per user-sequence (12 S 42 [2 x 14 155 776 + 3 (4SH + f_ad)], + patch embedding for images)
+GFLOP_PER_USER = {'bert_houlsby': 450.1, 'roberta_pfeiffer_cpc': 441.2, 'vit_lora': 3005.9 + 9.7, 'mae_compacter': 754.8 + 9.7}
 SEED = 123456
 
 
@@ -192,18 +202,24 @@ def host_threads():
     return max(1, min(n, 32))
 
 
-def cpu_baseline(sample_users=16):
-    """The CPU oracle on a bounded sample: one training step (fwd + bwd + Adam), BERT-base + Houlsby, fp32."""
+def cpu_baseline(device, sample_users=8):
+    """BASELINE.json configs[0] (B = 8, BERT-base + Houlsby, fp32, dropout off): one training step (fwd + bwd + Adam) of the CPU
+    oracle on the host cores, timed; then THE SAME batch and weights through the HIP path in its fp32 and bf16 modes and the
+    max-abs differences of loss / scores / adapter gradients against the oracle.  The oracle is the checker and
+    the reported baseline here, never the thing measured as `value`."""
     from oracle import ref_cpu as R
     from adapter4rec_amd.inject import freeze_all, inject_adapters
     from adapter4rec_amd.model import BERT_BASE, BertBackbone, Model
     torch.set_num_threads(host_threads())
-    args = make_args(sample_users, 'fp32')
-    torch.manual_seed(SEED)
-    model = Model(args, 65536, True, BertBackbone(BERT_BASE))
-    freeze_all(model)
-    model = inject_adapters(model, args)
-    sd = {k: v.detach() for k, v in model.state_dict().items()}
+
+    def fresh(dtype):
+        args = make_args(sample_users, dtype)
+        torch.manual_seed(SEED)
+        model = Model(args, 65536, True, BertBackbone(BERT_BASE))
+        freeze_all(model)
+        return inject_adapters(model, args)
+    model = fresh('fp32')
+    sd = {k: v.detach().clone() for k, v in model.state_dict().items()}
     trainable = [n for n, p in model.named_parameters() if p.requires_grad]
     g = torch.Generator().manual_seed(SEED)
     content = synth_content(4096, g)
@@ -211,11 +227,74 @@ def cpu_baseline(sample_users=16):
     cfg = dict(R.DEFAULT_CFG)
     lrs = dict(fine_tune_lr=5e-5, lr=1e-4, adapter_bert_lr=1.5e-4, adapter_sasrec_lr=1.5e-4)
     t0 = time.perf_counter()
-    R.train_steps(sd, trainable, [(items, mask)], cfg, lrs, 1)
+    out, grads = R.loss_and_grads(sd, trainable, items, mask, cfg)
+    for k in trainable:                                         # Adam, 4 lr groups (run.py:505-529)
+        p = sd[k].clone()
+        R.adam_step(p, grads[k], torch.zeros_like(p), torch.zeros_like(p), 1, R.lr_group(k, lrs))
     dt = time.perf_counter() - t0
+    ref_loss = float(out['loss'].detach())
+    diff = {}
+    for dtype in ('fp32', 'bf16'):
+        m = fresh(dtype).to(device)
+        m.eval()                                                # dropout off, like the oracle
+        loss = m(items.to(device), mask.to(device), device)
+        pos, neg = m._engine().scores()
+        loss.backward()
+        gerr, worst = 0.0, ''
+        for n, p in m.named_parameters():
+            if p.requires_grad:
+                r = grads[n]
+                e = float((p.grad.detach().cpu() - r).abs().max() / r.abs().max().clamp_min(1e-30))
+                if e > gerr:
+                    gerr, worst = e, n
+        diff[dtype] = dict(loss_abs=abs(float(loss) - ref_loss),
+                           scores_max_abs=float(max((pos.cpu() - out['pos_score'].detach()).abs().max(), (neg.cpu() - out['neg_score'].detach()).abs().max())),
+                           grad_max_err_rel_to_tensor_max=gerr, worst_grad=worst)
+        del m
+    torch.cuda.empty_cache()
     return dict(value=sample_users / dt, unit='user-sequences/sec', cores=torch.get_num_threads(), kind='port',
                 sample=f'1 train step (fwd+bwd+Adam) of oracle/ref_cpu.py, B={sample_users} users ({sample_users * 42} items x 30 tokens), '
-                       f'BERT-base+Houlsby fp32, dropout off, {dt:.1f} s')
+                       f'BERT-base+Houlsby fp32, dropout off (BASELINE.json configs[0]), {dt:.1f} s',
+                loss=ref_loss, diff=diff,
+                diff_note='HIP path vs the CPU oracle on the identical B=8 batch and weights (random-init BERT-base, dropout off): '
+                          '|loss| difference, max |pos/neg score| difference, worst max|dg|/max|g| over the adapter gradients')
+
+
+def self_launch(a, argv):
+    """--gpus N > 1 without a launcher: become N ranks (the reference starts one process per GPU,
+    Downstream/Text/script/adapter_houlsby.py:58-59, run.py:685).  This parent never touches the GPU: it starts
+    `python -m torch.distributed.run` on 127.0.0.1 as a CHILD process and exits with its code."""
+    import socket
+    import subprocess
+    if not os.environ.get('A4R_BENCH_CONTROL_ONLY') and torch.cuda.device_count() < a.gpus:
+        raise SystemExit(f'bench.py --gpus {a.gpus}: only {torch.cuda.device_count()} GPU(s) visible')
+    with socket.socket() as sk:
+        sk.bind(('127.0.0.1', 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={a.gpus}', '--master-addr', '127.0.0.1',
+           '--master-port', str(port), os.path.abspath(__file__)] + list(argv)
+    raise SystemExit(subprocess.run(cmd, env=env).returncode)
+
+
+def control_only(a, world, rank):
+    """A4R_BENCH_CONTROL_ONLY=1 (tests/test_bench_launch.py, no GPU): the launch / rendezvous / rank-accounting control flow of
+    this file with the gloo backend and no compute -- rank 0 prints the JSON skeleton with value null."""
+    import torch.distributed as dist
+    t = torch.ones(1)
+    if world > 1:
+        dist.all_reduce(t)
+    ranks = int(t.item())
+    if ranks != a.gpus:
+        raise SystemExit(f'--gpus {a.gpus} but the all-reduce saw {ranks} rank(s)')
+    if rank == 0:
+        print(json.dumps({'metric': 'user-sequences/sec, seq_len=23 BERT+SASRec+Adapter', 'value': None, 'unit': 'user-sequences/sec',
+                          'n_gpus': world, 'rccl_ranks': ranks, 'backend': os.environ.get('A4R_BENCH_BACKEND', 'nccl'),
+                          'control_only': True}))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
 
 
 def main():
@@ -232,18 +311,35 @@ def main():
     ap.add_argument('--gemm-variant', type=int, default=-1, help='A/B knob of a4r_gemm_variant (include/a4r.h); default: the library default')
     a = ap.parse_args()
 
+    if a.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        self_launch(a, sys.argv[1:])                           # never returns
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local = int(os.environ.get('LOCAL_RANK', '0'))
+    if world != a.gpus:
+        raise SystemExit(f'bench.py --gpus {a.gpus} but WORLD_SIZE={world}: refusing to report a rank count that did not run')
+    import torch.distributed as dist
+    control = bool(os.environ.get('A4R_BENCH_CONTROL_ONLY'))
+    backend = os.environ.get('A4R_BENCH_BACKEND', 'nccl')      # 'nccl' is RCCL on ROCm; gloo only for the control-flow test
+    if control:
+        if world > 1:
+            dist.init_process_group(backend, init_method='env://')
+        return control_only(a, world, rank)
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs an MI355X (no CPU fallback)')
-    local = local % torch.cuda.device_count()                  # (one rank per GPU in real runs; lets the N > 1 control flow be exercised on one GPU)
+    if world > torch.cuda.device_count():
+        raise SystemExit(f'{world} ranks but {torch.cuda.device_count()} GPU(s): one process per GPU')
     torch.cuda.set_device(local)
     device = torch.device('cuda', local)
-    import torch.distributed as dist
     if world > 1:
-        dist.init_process_group(os.environ.get('A4R_BENCH_BACKEND', 'nccl'), init_method='env://')     # 'nccl' is RCCL on ROCm; gloo only for the control-flow test
-    assert world == a.gpus or world == 1, f'--gpus {a.gpus} but WORLD_SIZE={world}'
+        dist.init_process_group(backend, init_method='env://', device_id=device)
+    rccl_ranks = 1
+    if world > 1:                                              # an actual collective over the group: the rank count RCCL sees
+        t = torch.ones(1, device=device)
+        dist.all_reduce(t)
+        rccl_ranks = int(t.item())
+        if rccl_ranks != a.gpus:
+            raise SystemExit(f'--gpus {a.gpus} but the all-reduce saw {rccl_ranks} rank(s)')
 
     from adapter4rec_amd import _lib as L
     if a.gemm_variant >= 0:
@@ -254,15 +350,12 @@ def main():
     if image:
         args = make_cv_args(a.batch, a.dtype, wl)
         model, opt = build_cv_model(args, device)
-        inner = getattr(model, 'model', model)
-        eng = inner._engine()
         batches = synth_image_batches(a.batch, 2, device, SEED + rank)
     else:
         args = make_args(a.batch, a.dtype)
         if wl == 'roberta_pfeiffer_cpc':
             args.adapter_type, args.adapter_activation, args.arch, args.bert_model_load = 'pfeiffer', 'relu', 'cpc', 'roberta_base'
         model, opt = build_model(args, device, roberta=(wl == 'roberta_pfeiffer_cpc'))
-        eng = model._engine()
         g = torch.Generator().manual_seed(SEED + rank)            # users are sharded: every rank draws its own users
         gc = torch.Generator().manual_seed(SEED)
         content = synth_content(65536, gc)
@@ -270,17 +363,23 @@ def main():
             content[1:, 0], content[1:, 29] = 0, 2
             content[1:, 1:29] = torch.randint(3, 50265, (65536, 28), generator=gc)
         batches = [(i.to(device), m.to(device)) for i, m in synth_batches(content, 65536, a.batch, 4, g)]
-    if world > 1:                                              # DDP constructor semantics: rank 0's trainables everywhere
-        dist.broadcast(eng.flat_p, 0)
+    from adapter4rec_amd.ddp import FlatDDP
+    ddp = FlatDDP(model, device_ids=[local], output_device=local)     # broadcasts rank 0's state once (run.py:503); frozen weights never move again
+    inner = getattr(model, 'model', model)
+    eng = inner._engine()                                      # (FlatDDP's broadcast invalidates the packed copies: this is the engine that runs)
 
-    def step(i, exchange=True):
+    def step(i, api=False):
         items, mask = batches[i % len(batches)]
-        eng.flat_g.zero_()
-        loss = eng.train_forward(items, mask)
-        eng.train_backward(into_flat_grad=True)
-        if world > 1 and exchange:
-            dist.all_reduce(eng.flat_g)
-        opt.step(grad_scale=1.0 / world)
+        if api:                                                # the engine API underneath (instrumented pass on rank 0: no collective)
+            eng.flat_g.zero_()
+            loss = eng.train_forward(items, mask)
+            eng.train_backward(into_flat_grad=True)
+            opt.step()
+            return loss
+        opt.zero_grad()
+        loss = ddp(items, mask, local)                         # run.py:597-600
+        loss.backward()
+        opt.step()
         return loss
 
     for i in range(a.warmup):
@@ -304,13 +403,30 @@ def main():
     loss_val = float(loss)
     assert loss_val == loss_val, 'NaN loss'
 
+    ar_us = None
+    if world > 1:                                              # the exchange step on its own: 20 all-reduces of the flat gradient buffer
+        scratch = torch.zeros_like(eng.flat_g)
+        for _ in range(3):
+            ddp.average_(scratch)
+        torch.cuda.synchronize()
+        dist.barrier()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(20):
+            ddp.average_(scratch)
+        e1.record()
+        torch.cuda.synchronize()
+        t = torch.tensor([e0.elapsed_time(e1) / 20 * 1e3], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        ar_us = round(float(t.item()), 1)
+
     roof = None
     if rank == 0 and not a.no_roofline:
         import adapter4rec_amd.engine as E
         side, E.WGRAD_STREAM = E.WGRAD_STREAM, False             # single stream here: an event pair would also time the wait for CUs that
         with GemmProbe(E.L) as probe:                            # side-stream weight-gradient kernels still hold when a GEMM is launched
             for i in range(2):                                   # rank 0 only: NO collective in here (the other ranks have moved on)
-                step(a.warmup + a.steps + i, exchange=False)
+                step(a.warmup + a.steps + i, api=True)
             agg = probe.summary()
             shapes = probe.by_shape()
         E.WGRAD_STREAM = side
@@ -324,7 +440,9 @@ def main():
         roof = dict(bound='mfma', achieved=round(ach, 2), peak=peak, unit='TFLOP/s', frac=round(ach / peak, 4), traffic=None,
                     kernel=(f'gemm_nt_256_kernel<{a.dtype},{a.dtype},act={key[2][1]},dact={key[2][2]}>' if key[2][0] == 256 else (f'{key[2][0]}_kernel<{a.dtype},{a.dtype}>' if isinstance(key[2][0], str) else f'gemm_nt_kernel<{a.dtype},{a.dtype},{key[2][0]}>')), launches_per_step=n // 2,
                     avg_launch_us=round(t / n * 1e6, 2), flop_per_launch=f / n,
-                    all_gemm_tflops=round(total_f / total_t / 1e12, 2), gemm_time_share_of_step=round(total_t / 2 / (dt / a.steps), 3))
+                    all_gemm_tflops=round(total_f / total_t / 1e12, 2), gemm_time_share_of_step=round(total_t / 2 / (dt / a.steps), 3),
+                    step_tflops_per_gpu=round(a.batch * a.steps / dt * GFLOP_PER_USER[wl] / 1e3, 1),
+                    step_frac_of_peak=round(a.batch * a.steps / dt * GFLOP_PER_USER[wl] / 1e3 / peak, 4))
         # fabric/HBM bytes per launch of that kernel: not measurable from inside the process -- taken from the committed
         # rocprofv3 PMC passes over this same command (profiles/r01_g_pmc_hbm_traffic.json says how), B=32 bf16 only.
         pmc = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles', 'r01_g_pmc_hbm_traffic.json')
@@ -339,7 +457,7 @@ def main():
 
     cpu = None
     if rank == 0 and world == 1 and not a.no_cpu_baseline and wl == 'bert_houlsby':
-        cpu = cpu_baseline()
+        cpu = cpu_baseline(device)
 
     if rank == 0:
         users = world * a.batch * a.steps
@@ -352,7 +470,9 @@ def main():
             'dtype': a.dtype, 'data': WORKLOADS[wl][3],
             'config': {'workload': WORKLOADS[wl][2], 'baseline_config': WORKLOADS[wl][0],
                        'users_per_gpu': a.batch, 'global_batch': world * a.batch, 'seq_len': 23,
-                       'tokens_per_item': eng.S, 'items_per_user': 42, 'parallelism': f'dp{world}'},
+                       'tokens_per_item': eng.S, 'items_per_user': 42, 'parallelism': f'dp{world}',
+                       'path': 'public: optimizer.zero_grad(); FlatDDP(model)(items, mask); loss.backward(); FusedAdam.step()'},
+            'rccl_ranks': rccl_ranks, 'allreduce_bytes_per_step': int(eng.flat_g.numel() * 4) if world > 1 else 0, 'allreduce_us': ar_us,
             'loss': round(loss_val, 5), 'roofline': roof, 'cpu_baseline': cpu,
         }
         print(json.dumps(out))

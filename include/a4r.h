@@ -184,11 +184,13 @@ int a4r_act_bwd_f32(void* stream, const float* dy, const float* pre, float* dx, 
  * emb [B, L, 2, E] fp32 item embeddings (L = max_seq_len + 1), prec [B, L-1, E] user-encoder output,
  * log_mask [B, L-1].  fwd: pos/neg scores [B, L-1]; loss_ws = 4 floats zeroed by the caller:
  * [0] loss (mean over valid positions of softplus(-pos) + softplus(neg)), [1] sum, [2] valid count.
- * bwd: d_prec [B, L-1, E] and d_emb [B, L, 2, E] (the target-side part; the caller adds the input side). */
+ * bwd: d_prec [B, L-1, E] and d_emb [B, L, 2, E] (the target-side part; the caller adds the input side); the incoming
+ * gradient of the loss is loss_scale x (*loss_scale_dev if that device pointer is non-null: autograd's grad_output of
+ * loss.backward(), run.py:599, stays on the device). */
 int a4r_score_bce_fwd(void* stream, const float* emb, const float* prec, const float* log_mask,
                       float* pos, float* neg, float* loss_ws, int B, int L, int E, int cpc);
 int a4r_score_bce_bwd(void* stream, const float* emb, const float* prec, const float* log_mask,
-                      const float* pos, const float* neg, const float* loss_ws, float loss_scale,
+                      const float* pos, const float* neg, const float* loss_ws, float loss_scale, const float* loss_scale_dev,
                       float* d_prec, float* d_emb, int B, int L, int E, int cpc);
 /* d_emb[b, l, 0, :] += d_in[b*(L-1) + l, :] for l < L-1 (gradient wrt the user-encoder input, model.py:57). */
 int a4r_emb_grad_add_inputs(void* stream, const float* d_in, int ldi, float* d_emb, int B, int L, int E);

@@ -280,7 +280,9 @@ def score_bce_fwd(emb, prec, log_mask, pos, neg, loss_ws, B, L, E, cpc):
     loss_ws.view(-1)[0] = s / m.sum()
 
 
-def score_bce_bwd(emb, prec, log_mask, pos, neg, loss_ws, loss_scale, d_prec, d_emb, B, L, E, cpc):
+def score_bce_bwd(emb, prec, log_mask, pos, neg, loss_ws, loss_scale, d_prec, d_emb, B, L, E, cpc, scale_dev=None):
+    if scale_dev is not None:
+        loss_scale = loss_scale * float(scale_dev)
     T = L - 1
     with torch.enable_grad():
         e = emb[:B * L * 2].view(B, L, 2, E).clone().requires_grad_(True)

@@ -173,3 +173,29 @@ def test_host_logic_finetune_all(simulated, ln_only):
             if k.startswith('grad/'):
                 ref = fx[k]
                 np.testing.assert_allclose(params[k[5:]].grad.numpy(), ref, atol=1e-6 + 1e-4 * np.abs(ref).max(), rtol=0, err_msg=k)
+
+
+def test_host_logic_bound_backward_path(simulated):
+    """The public path once FusedAdam is bound (engine.backward_bound): p.grad are views of the flat gradient buffer and are
+    filled in place -- same numbers as the per-parameter autograd path, a scaled loss scales them (grad_output stays a device
+    scalar read by the head kernel), and a second backward without zero_grad accumulates."""
+    from adapter4rec_amd.inject import optimizer_groups
+    from adapter4rec_amd.optim import FusedAdam
+    root, args, fx, items, mask = build_cpu('houlsby')
+    params = dict(root.named_parameters())
+    root(items, mask, 'cpu').backward()                              # unbound: per-parameter gradients through autograd
+    ref = {k: params[k].grad.detach().clone() for k in map(str, fx['trainable'])}
+    opt = FusedAdam(optimizer_groups(root, args), lr=0.0)
+    for g in opt.param_groups:
+        g['lr'] = 0.0
+    opt.step()                                                       # binds (lr 0: parameters unchanged)
+    eng = getattr(root, 'model', root)._engine()
+    assert eng._fused_opt is opt
+    opt.zero_grad()
+    (0.5 * root(items, mask, 'cpu')).backward()
+    for k, r in ref.items():
+        assert params[k].grad.data_ptr() == eng.flat_g[eng.offsets[id(params[k])][0]:].data_ptr()
+        np.testing.assert_allclose(params[k].grad.numpy(), 0.5 * r.numpy(), atol=1e-7 + 1e-5 * r.abs().max().item(), rtol=0, err_msg=k)
+    root(items, mask, 'cpu').backward()                              # accumulation: 0.5 g + g
+    for k, r in ref.items():
+        np.testing.assert_allclose(params[k].grad.numpy(), 1.5 * r.numpy(), atol=1e-7 + 1e-5 * r.abs().max().item(), rtol=0, err_msg=k)
