@@ -84,6 +84,9 @@ def get_itemLMDB_embeddings(model, item_num, item_id_to_keys, test_batch_size, a
     model.eval()
     db = db if db is not None else open_image_db(os.path.join(args.root_data_dir, args.dataset, args.lmdb_data))
     enc = _inner(model, args).cv_encoder
+    ed = getattr(args, 'eval_compute_dtype', None)
+    if ed and ed != _inner(model, args).compute_dtype:
+        enc = _inner(model, args).item_encoder_in(ed)
     dev = next(model.parameters()).device
     R = args.CV_resize
     out = []

@@ -55,6 +55,8 @@ def parse_args(argv=None):
     p.add_argument('--hypercomplex_division', type=int, default=4)
     p.add_argument('--phm_init_range', type=float, default=0.0001)
     p.add_argument('--compute_dtype', type=str, default=None, choices=[None, 'bf16', 'fp32'])
+    p.add_argument('--eval_compute_dtype', type=str, default=None, choices=[None, 'bf16', 'fp32'],
+                   help="dtype of eval's item sweep; None = --compute_dtype (the reference evaluates under the same AMP setting it trains with)")
     p.add_argument('--lora_r', type=int, default=12)              # run_adapter.py:386-387 hard-codes 12
     p.add_argument('--lora_r_sasrec', type=int, default=4)        # :393 hard-codes 4
     args = p.parse_args(argv)

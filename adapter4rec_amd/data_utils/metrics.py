@@ -27,7 +27,11 @@ def _inner(model, args):
 def get_item_embeddings(model, item_content, test_batch_size, args, use_modal, local_rank):
     """metrics.py:62-79 -> fp32 [N + 1, E] (on the device; the reference returns it on the CPU and moves it back)."""
     model.eval()
-    enc = _inner(model, args).bert_encoder
+    inner = _inner(model, args)
+    enc = inner.bert_encoder
+    ed = getattr(args, 'eval_compute_dtype', None)
+    if ed and ed != inner.compute_dtype:       # e.g. the item sweep in fp32 (the reference's eval precision) under bf16 training
+        enc = inner.item_encoder_in(ed)
     dev = next(model.parameters()).device
     content = torch.as_tensor(np.asarray(item_content)).long()
     lo, hi, chunk, world = _my_shard(content.shape[0])

@@ -202,6 +202,21 @@ class TransRecEngine:
         self._wstream, self._wdone, self._wev = None, None, None     # optional side stream for the adapter weight gradients (A4R_WGRAD_STREAM)
         self._saved_M = self._saved_Mu = 0
 
+    @classmethod
+    def inference_snapshot(cls, model, args, arch, dtype, phm_owner=None):
+        """A forward-only engine over the CURRENT parameter values in another compute dtype (the fp32 item sweep of eval,
+        --eval_compute_dtype): every tensor is packed once as frozen, nothing is re-viewed, so the training engine that owns the
+        parameters' flat buffer is not disturbed.  Build, use, drop (the copies go stale at the next optimizer step)."""
+        root = phm_owner if phm_owner is not None else model
+        flags = [(p, p.requires_grad) for p in root.parameters()]
+        try:
+            for p, _ in flags:
+                p.requires_grad_(False)
+            return cls(model, args, arch=arch, dtype=dtype, phm_owner=phm_owner)
+        finally:
+            for p, f in flags:
+                p.requires_grad_(f)
+
     def _require_device(self, p0):
         if not p0.is_cuda:
             raise RuntimeError('adapter4rec_amd runs on an MI355X only: move the model to a cuda device first '

@@ -79,6 +79,15 @@ class _TransRecBase(nn.Module):
                                              phm_owner=self._phm_owner[0])
         return self._native[0]
 
+    def item_encoder_in(self, dtype):
+        """items -> embeddings computed in `dtype` on the current weights (a forward-only snapshot engine; eval's item sweep in
+        fp32 while training runs in bf16: data_utils/metrics.py get_item_embeddings, --eval_compute_dtype)."""
+        if dtype == self.compute_dtype:
+            return self._engine().encode_items
+        from ..engine import TransRecEngine
+        snap = TransRecEngine.inference_snapshot(self, self.args, self.arch, dtype, self._phm_owner[0])
+        return snap.encode_items
+
     def _apply(self, fn, *a, **k):      # .to(device) / .cuda() move tensors => rebuild the packed copies
         self.invalidate_native()
         return super()._apply(fn, *a, **k)

@@ -400,7 +400,7 @@ def main():
         t = torch.tensor([dt], device=device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
-    loss_val = float(loss)
+    loss_val = float(loss.detach())
     assert loss_val == loss_val, 'NaN loss'
 
     ar_us = None

@@ -199,3 +199,30 @@ def test_host_logic_bound_backward_path(simulated):
     root(items, mask, 'cpu').backward()                              # accumulation: 0.5 g + g
     for k, r in ref.items():
         np.testing.assert_allclose(params[k].grad.numpy(), 1.5 * r.numpy(), atol=1e-7 + 1e-5 * r.abs().max().item(), rtol=0, err_msg=k)
+
+
+def test_host_logic_eval_item_sweep_in_fp32_snapshot(simulated):
+    """--eval_compute_dtype fp32 under bf16 training: the item sweep runs on a forward-only fp32 snapshot engine of the CURRENT
+    weights; it equals the fp32 engine's embeddings and leaves the training engine (which owns the parameters' flat buffer) alone."""
+    root, args, fx, items, mask = build_cpu('houlsby')
+    inner = getattr(root, 'model', root)
+    ref = inner.bert_encoder(items).clone()                          # fp32 engine
+    inner.compute_dtype = 'bf16'
+    inner.invalidate_native()
+    eng = inner._engine()
+    flat = eng.flat_p
+    with torch.no_grad():
+        for p in eng.trainable_params:                               # "training" moved the weights: the snapshot must see the new values
+            p.mul_(1.5)
+    inner.compute_dtype = 'fp32'
+    inner.invalidate_native()
+    ref2 = inner.bert_encoder(items).clone()
+    assert (ref2 - ref).abs().max() > 1e-4
+    inner.compute_dtype = 'bf16'
+    inner.invalidate_native()
+    eng = inner._engine()
+    got = inner.item_encoder_in('fp32')(items)
+    np.testing.assert_allclose(got.numpy(), ref2.numpy(), atol=1e-6, rtol=0)
+    assert inner._engine() is eng and all(p.requires_grad for p in eng.trainable_params)
+    bf = inner.bert_encoder(items)
+    assert 0 < (bf - ref2).abs().max() < 5e-2                        # the bf16 engine itself still answers, in bf16
