@@ -22,7 +22,7 @@ EXPORTS = [
     'a4r_version', 'a4r_gemm_nt', 'a4r_gemm_tn', 'a4r_colsum', 'a4r_attn_fwd', 'a4r_attn_bwd', 'a4r_embed_ln',
     'a4r_ln_fwd', 'a4r_ln_bwd', 'a4r_gather_rows', 'a4r_scatter_rows', 'a4r_act_bwd_f32', 'a4r_score_bce_fwd',
     'a4r_score_bce_bwd', 'a4r_emb_grad_add_inputs', 'a4r_take_inputs', 'a4r_adam_step', 'a4r_pack_matrices',
-    'a4r_eval_rank', 'a4r_dropout_apply', 'a4r_gemm_variant', 'a4r_adapter_fwd', 'a4r_attn_long_fwd', 'a4r_attn_long_bwd', 'a4r_patchify', 'a4r_vit_assemble', 'a4r_resample_u8', 'a4r_embed_bwd',
+    'a4r_eval_rank', 'a4r_dropout_apply', 'a4r_gemm_variant', 'a4r_adapter_ln_fwd', 'a4r_adapter_ln_bwd', 'a4r_attn_long_fwd', 'a4r_attn_long_bwd', 'a4r_patchify', 'a4r_vit_assemble', 'a4r_resample_u8', 'a4r_embed_bwd',
 ]
 
 
@@ -137,13 +137,29 @@ def gemm_variant(v):
     return lib().a4r_gemm_variant(C.c_int(v))
 
 
-def adapter_fwd(h, x, Wd, bd, Wu, bu, gamma, beta, eps, act, inner_residual, zp, z, v, y, stats, M=None):
-    require_gpu(h, x, v, y)
-    M = h.shape[0] if M is None else M
-    _check(lib().a4r_adapter_fwd(_stream(), _p(h), C.c_int(_ld(h)), _p(x), C.c_int(_ld(x)), _p(Wd), _p(bd), _p(Wu), _p(bu),
-                                 _p(gamma), _p(beta), C.c_float(eps), C.c_int(act), C.c_int(int(inner_residual)),
-                                 _p(zp), _p(z), _p(v), C.c_int(_ld(v)), _p(y), C.c_int(_ld(y)), _p(stats),
-                                 C.c_int(M), C.c_int(h.shape[1]), C.c_int(Wd.shape[0]), C.c_int(_dt(h))), 'a4r_adapter_fwd')
+def adapter_ln_ok(A, d):
+    """Shapes the one-launch adapter kernels (a4r_adapter_ln_fwd / _bwd) are instantiated for."""
+    return A.dtype == torch.bfloat16 and d == 64 and A.shape[1] in (128, 256, 512, 768, 1024)
+
+
+def adapter_ln_fwd(A, R1, R2, Wd, bd, Wu, bu, gamma, beta, eps, act, zp, z, v, y, stats, M=None):
+    require_gpu(A, R1, R2, v, y)
+    M = A.shape[0] if M is None else M
+    _check(lib().a4r_adapter_ln_fwd(_stream(), _p(A), C.c_int(_ld(A)), _p(R1), C.c_int(_ld(R1)), _p(R2), C.c_int(_ld(R2) if R2 is not None else 0),
+                                    _p(Wd), _p(bd), _p(Wu), _p(bu), _p(gamma), _p(beta), C.c_float(eps), C.c_int(act),
+                                    _p(zp), _p(z), _p(v), C.c_int(_ld(v)), _p(y), C.c_int(_ld(y)), _p(stats),
+                                    C.c_int(M), C.c_int(A.shape[1]), C.c_int(Wd.shape[0]), C.c_int(_dt(A))), 'a4r_adapter_ln_fwd')
+
+
+def adapter_ln_bwd(dy, v, stats, gamma, dres, zp, act, WuT, WdT, inner_res, dv, dzp, dh, dgamma=None, dbeta=None, dbias=None, M=None,
+                   drop_p=0.0, drop_site=0, drop_seed=0):
+    require_gpu(dy, v, dv, dh)
+    M = dy.shape[0] if M is None else M
+    _check(lib().a4r_adapter_ln_bwd(_stream(), _p(dy), C.c_int(_ld(dy)), _p(v), C.c_int(_ld(v)), _p(stats), _p(gamma),
+                                    _p(dres), C.c_int(_ld(dres) if dres is not None else 0), _p(zp), C.c_int(act), _p(WuT), _p(WdT),
+                                    C.c_int(int(inner_res)), _p(dv), C.c_int(_ld(dv)), _p(dzp), _p(dh), C.c_int(_ld(dh)),
+                                    _p(dgamma), _p(dbeta), _p(dbias), C.c_int(M), C.c_int(dy.shape[1]), C.c_int(WuT.shape[0]), C.c_int(_dt(dy)),
+                                    C.c_float(drop_p), C.c_uint32(drop_site), C.c_uint64(drop_seed)), 'a4r_adapter_ln_bwd')
 
 
 def gemm_tn(X, Y, Cacc, M=None):

@@ -1,0 +1,523 @@
+// Fused bottleneck adapter + residual(s) + LayerNorm, forward and backward, bf16 (the north_star's "LDS-staged adapter
+// bottleneck down/up projections fused with residual + LayerNorm").
+//
+// Replaces, per adapter, the launch sequences
+//   forward : skinny64 (zp = A Wd^T + bd, z = act(zp)) | skinnyk (v = z Wu^T + bu + residuals) | ln_fwd (y = LN(v))
+//   backward: ln_bwd (dv) | skinny64 (dzp = (dv Wu) * act'(zp)) | skinnyk (dh = dzp Wd + dv, dropout)
+// of BertAdaptedSelfOutput.forward / AdapterBlock.forward (Downstream/Text/model/model.py:292-297, modules.py:116-134; the
+// Compacter form model.py:696-720 without the inner residual; the Pfeiffer form model.py:321-329 with A = LN(h + input))
+// by ONE launch each: every activation row is read once and written once.  Algorithmic HBM bytes per launch, bf16:
+//   forward  read A, O (2 M H) | write v, y (2 M H) | zp, z (2 M 64)                      = (4 H + 128) 2 M  bytes
+//   backward read dy, v (2 M H) [+ dres] | write dv, dh (2 M H) | zp in, dzp out (2 M 64) = (4 H + 128) 2 M  bytes
+// against ~7 M H x 2 for the three-launch forms (h / dv re-read by two kernels, v re-read by ln_fwd).
+//
+// Structure.  One workgroup of NW waves per CU (persistent over 16-row tiles); wave w owns columns [w CW, (w+1) CW) of the
+// width H = NW x CW for every row of the tile.  Both weight matrices stay ON THE CU for the whole launch as MFMA operand
+// fragments (forward: both in registers, 48 + 48 VGPRs at CW = 96; backward: Wu in registers, Wd as a fragment-ordered LDS
+// image, its registers go to the column sums): the 192 KB of weights are read once per CU, not once per tile -- streaming
+// them per 16 rows is what made the first fused kernel (round 1) slower than the un-fused launches.
+//   * a lane holds, of row (lane & 15), the 16-byte pieces at columns c0 + 32 s + 8 (lane >> 4) + [0, 8), s < CW / 32:
+//     exactly the MFMA operand of the down-projection (contraction over H: the wave's CW columns are K-steps), so a
+//     global_load_dwordx4 is an operand with no LDS round trip;
+//   * the [16, 64] partial products of the NW waves are summed through LDS (34 KB), bias + activation applied once, the
+//     bottleneck z goes back to LDS as the bf16 operand of the up-projection (K = 64: two MFMA steps);
+//   * the up-projection's weight rows are PERMUTED when the fragments are loaded so that accumulator register (tile 2s+h, r)
+//     of a lane is column c0 + 32 s + 8 (lane >> 4) + 4 h + r -- the very columns of the pieces the lane loaded: residual
+//     adds, LayerNorm and the 16-byte stores happen in registers in the load layout;
+//   * row statistics: per-wave (mean, centred sum of squares) over its CW columns, combined across waves exactly (Chan);
+//   * the next tile's rows are requested before the current tile is processed (static vmcnt schedule: the last tile
+//     re-requests itself instead of branching).
+// Three workgroup barriers per tile.  The kernels are HBM-bound: 24 MFMAs per wave per 96 KB of traffic.
+#include "a4r_common.h"
+#include "../../include/a4r.h"
+
+namespace {
+
+constexpr int ZLD = 68;            // floats per row of a wave's partial [16][64] tile in LDS (272-byte rows: bank spread)
+
+#define A4R_LDS_BARRIER()                                    \
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       \
+    __builtin_amdgcn_s_barrier();                            \
+    asm volatile("" ::: "memory")
+
+A4R_DEV float kg_sum(float v) {    // over the 4 lanes (lane & 15 fixed) that hold one row
+    v += __shfl_xor(v, 16, 64);
+    v += __shfl_xor(v, 32, 64);
+    return v;
+}
+A4R_DEV float bf16_round(float x) { return bf16_bits_to_f32(f32_to_bf16_bits(x)); }
+
+struct AdFwdArgs {
+    const bf16_t* A; const bf16_t* O; int lda, ldo, a_in_resid;
+    const bf16_t* Wd; const bf16_t* Wu; const float* bd; const float* bu; const float* gamma; const float* beta;
+    float eps; int act;
+    bf16_t* zp; bf16_t* z; bf16_t* v; bf16_t* y; int ldv, ldy; float* stats; int M;
+};
+
+// sum of the NW partial [16][64] tiles for EPT consecutive bottleneck columns of one row (thread t: element t * EPT)
+template <int NW, int EPT>
+A4R_DEV void reduce_partials(const float (*zpart)[16][ZLD], int row, int zd, float (&s)[EPT]) {
+#pragma unroll
+    for (int i = 0; i < EPT; ++i) s[i] = 0.f;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) {
+        if constexpr (EPT == 2) {
+            const float2 q = *reinterpret_cast<const float2*>(&zpart[w][row][zd]);
+            s[0] += q.x; s[1] += q.y;
+        } else {
+            const float4 q = *reinterpret_cast<const float4*>(&zpart[w][row][zd]);
+            s[0] += q.x; s[1] += q.y; s[2] += q.z; s[3] += q.w;
+        }
+    }
+}
+template <int EPT>
+A4R_DEV void store_bf16_n(bf16_t* dst, const float (&v)[EPT]) {
+    if constexpr (EPT == 2) *reinterpret_cast<uint32_t*>(dst) = f32_to_bf16_bits(v[0]) | (f32_to_bf16_bits(v[1]) << 16);
+    else *reinterpret_cast<uint2*>(dst) = make_uint2(f32_to_bf16_bits(v[0]) | (f32_to_bf16_bits(v[1]) << 16),
+                                                      f32_to_bf16_bits(v[2]) | (f32_to_bf16_bits(v[3]) << 16));
+}
+// byte offset of bottleneck column zd of row r in the swizzled bf16 [16][64] operand image (16-byte chunk c at c ^ ((r >> 1) & 7))
+A4R_DEV int zbf_off(int r, int zd) { return r * 128 + ((((zd >> 3) ^ ((r >> 1) & 7))) << 4) + (zd & 7) * 2; }
+
+template <int CW, int NW>
+__global__ void __launch_bounds__(NW * 64) adapter_ln_fwd_kernel(const AdFwdArgs p) {
+    constexpr int KS = CW / 32, H = CW * NW, NT = NW * 64, EPT = 1024 / NT;
+    __shared__ __attribute__((aligned(16))) float zpart[NW][16][ZLD];
+    __shared__ __attribute__((aligned(16))) char zbf[16 * 128];
+    __shared__ float red[NW][16][2];
+    __shared__ __attribute__((aligned(16))) float par[3][H];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int fr = lane & 15, kg = lane >> 4;
+    const int c0 = wave * CW;
+    const int cl = c0 + kg * 8;                              // + 32 s: first column of the lane's piece s
+    for (int c = tid; c < H; c += NT) { par[0][c] = p.bu[c]; par[1][c] = p.gamma[c]; par[2][c] = p.beta[c]; }
+
+    // weight fragments (W side of the MFMA: a lane supplies weight row (lane & 15), 8 contraction elements at lane >> 4)
+    uint4 wd[KS][4], wu[2 * KS][2];
+#pragma unroll
+    for (int s = 0; s < KS; ++s)
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt)
+            wd[s][nt] = *reinterpret_cast<const uint4*>(p.Wd + (size_t)(nt * 16 + fr) * H + cl + s * 32);
+#pragma unroll
+    for (int s = 0; s < KS; ++s)
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)      // accumulator register (kg', r) of tile 2s+h <- weight row c0 + 32 s + 8 kg' + 4 h + r
+                wu[2 * s + h][ks] = *reinterpret_cast<const uint4*>(p.Wu + (size_t)(c0 + s * 32 + (fr >> 2) * 8 + h * 4 + (fr & 3)) * 64 + ks * 32 + kg * 8);
+
+    const int e0 = tid * EPT, rrow = e0 >> 6, rzd = e0 & 63;  // this thread's share of the [16][64] reduction
+    float bd_r[EPT];
+#pragma unroll
+    for (int i = 0; i < EPT; ++i) bd_r[i] = p.bd[rzd + i];
+
+    const int ntiles = p.M / 16;
+    uint4 a_cur[KS], o_cur[KS], a_nxt[KS], o_nxt[KS];
+    {
+        const size_t row = (size_t)blockIdx.x * 16 + fr;
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            a_cur[s] = *reinterpret_cast<const uint4*>(p.A + row * p.lda + cl + s * 32);
+            o_cur[s] = *reinterpret_cast<const uint4*>(p.O + row * p.ldo + cl + s * 32);
+        }
+    }
+    A4R_LDS_BARRIER();                                       // par[] visible
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        {   // request the next tile's rows now (the last tile re-requests itself: the vmcnt schedule stays static)
+            const int tn = tile + (int)gridDim.x < ntiles ? tile + (int)gridDim.x : tile;
+            const size_t row = (size_t)tn * 16 + fr;
+#pragma unroll
+            for (int s = 0; s < KS; ++s) {
+                a_nxt[s] = *reinterpret_cast<const uint4*>(p.A + row * p.lda + cl + s * 32);
+                o_nxt[s] = *reinterpret_cast<const uint4*>(p.O + row * p.ldo + cl + s * 32);
+            }
+        }
+        const size_t row = (size_t)tile * 16 + fr;
+        // ---- down-projection: partial over this wave's CW columns
+        f32x4_t zacc[4];
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) zacc[nt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int s = 0; s < KS; ++s)
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) Mma<bf16_t>::mma(wd[s][nt], a_cur[s], zacc[nt]);
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) *reinterpret_cast<f32x4_t*>(&zpart[wave][fr][nt * 16 + kg * 4]) = zacc[nt];
+        A4R_LDS_BARRIER();
+        // ---- sum over waves, bias, activation: zp (pre-activation) and z to HBM, z as the next MFMA's operand to LDS
+        {
+            float s_[EPT], a_[EPT];
+            reduce_partials<NW, EPT>(zpart, rrow, rzd, s_);
+#pragma unroll
+            for (int i = 0; i < EPT; ++i) { s_[i] += bd_r[i]; a_[i] = act_fwd(s_[i], p.act); }
+            const size_t g = ((size_t)tile * 16 + rrow) * 64 + rzd;
+            store_bf16_n<EPT>(p.zp + g, s_);
+            store_bf16_n<EPT>(p.z + g, a_);
+            store_bf16_n<EPT>(reinterpret_cast<bf16_t*>(zbf + zbf_off(rrow, rzd)), a_);
+        }
+        A4R_LDS_BARRIER();
+        // ---- up-projection (K = 64) into the load layout
+        uint4 zf[2];
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) zf[ks] = *reinterpret_cast<const uint4*>(zbf + fr * 128 + (((ks * 4 + kg) ^ ((fr >> 1) & 7)) << 4));
+        f32x4_t acc[2 * KS];
+#pragma unroll
+        for (int t = 0; t < 2 * KS; ++t) {
+            acc[t] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) Mma<bf16_t>::mma(wu[t][ks], zf[ks], acc[t]);
+        }
+        // ---- v = up + bias + residual(s), rounded to its bf16 storage (LayerNorm runs on what backward will re-read)
+        float vv[KS][8];
+        float s1 = 0.f;
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            float af[8], of[8], bu8[8];
+            Elem<bf16_t>::unpack(a_cur[s], af);
+            Elem<bf16_t>::unpack(o_cur[s], of);
+            *reinterpret_cast<float4*>(bu8) = *reinterpret_cast<const float4*>(&par[0][cl + s * 32]);
+            *reinterpret_cast<float4*>(bu8 + 4) = *reinterpret_cast<const float4*>(&par[0][cl + s * 32 + 4]);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                float x = acc[2 * s + (j >> 2)][j & 3] + bu8[j] + of[j];
+                if (p.a_in_resid) x += af[j];
+                vv[s][j] = x;
+            }
+            const uint4 pk = Elem<bf16_t>::pack(vv[s]);
+            *reinterpret_cast<uint4*>(p.v + row * p.ldv + cl + s * 32) = pk;
+            Elem<bf16_t>::unpack(pk, vv[s]);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) s1 += vv[s][j];
+        }
+        // ---- row statistics: this wave's (mean, centred sum of squares) over CW columns; exact combination across waves
+        const float mean_w = kg_sum(s1) * (1.f / CW);
+        float q = 0.f;
+#pragma unroll
+        for (int s = 0; s < KS; ++s)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { const float d = vv[s][j] - mean_w; q += d * d; }
+        q = kg_sum(q);
+        if (kg == 0) { red[wave][fr][0] = mean_w; red[wave][fr][1] = q; }
+        A4R_LDS_BARRIER();
+        float mean = 0.f;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) mean += red[w][fr][0];
+        mean *= (1.f / NW);
+        float m2 = 0.f;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) { const float d = red[w][fr][0] - mean; m2 += red[w][fr][1] + (float)CW * d * d; }
+        const float rstd = rsqrtf(m2 * (1.f / H) + p.eps);
+        if (wave == 0 && kg == 0) { p.stats[2 * row] = mean; p.stats[2 * row + 1] = rstd; }
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            float g8[8], b8[8], y8[8];
+            *reinterpret_cast<float4*>(g8) = *reinterpret_cast<const float4*>(&par[1][cl + s * 32]);
+            *reinterpret_cast<float4*>(g8 + 4) = *reinterpret_cast<const float4*>(&par[1][cl + s * 32 + 4]);
+            *reinterpret_cast<float4*>(b8) = *reinterpret_cast<const float4*>(&par[2][cl + s * 32]);
+            *reinterpret_cast<float4*>(b8 + 4) = *reinterpret_cast<const float4*>(&par[2][cl + s * 32 + 4]);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) y8[j] = (vv[s][j] - mean) * rstd * g8[j] + b8[j];
+            *reinterpret_cast<uint4*>(p.y + row * p.ldy + cl + s * 32) = Elem<bf16_t>::pack(y8);
+        }
+#pragma unroll
+        for (int s = 0; s < KS; ++s) { a_cur[s] = a_nxt[s]; o_cur[s] = o_nxt[s]; }
+    }
+}
+
+struct AdBwdArgs {
+    const bf16_t* dy; const bf16_t* v; const bf16_t* dres; int lddy, ldv, lddres;
+    const float* stats; const float* gamma;
+    const bf16_t* zp; int act;
+    const bf16_t* WuT; const bf16_t* WdT; int inner_res;
+    bf16_t* dv; bf16_t* dzp; bf16_t* dh; int lddv, lddh;
+    float* dgamma; float* dbeta; float* dbias;
+    int M;
+    uint64_t seed; uint32_t site, thr16; float keep_scale;
+};
+
+// WGB: accumulate dgamma / dbeta (trainable LayerNorm: Pfeiffer's LN_new, --finetune_layernorm); WDB: dbias = column sums of dv
+// BEFORE dres is added (the up-projection bias sits inside the LayerNorm input).
+template <int CW, int NW, bool WGB, bool WDB>
+__global__ void __launch_bounds__(NW * 64) adapter_ln_bwd_kernel(const AdBwdArgs p) {
+    constexpr int KS = CW / 32, H = CW * NW, NT = NW * 64, EPT = 1024 / NT;
+    __shared__ __attribute__((aligned(16))) float zpart[NW][16][ZLD];
+    __shared__ __attribute__((aligned(16))) char zbf[16 * 128];
+    __shared__ float red[NW][16][2];
+    __shared__ __attribute__((aligned(16))) float par[H];                 // gamma; re-used for the column sums at the end
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int fr = lane & 15, kg = lane >> 4;
+    const int c0 = wave * CW;
+    const int cl = c0 + kg * 8;
+    for (int c = tid; c < H; c += NT) par[c] = p.gamma[c];
+
+    // dz = dv . Wu (contraction over H: WuT [64, H]) keeps its fragments in registers; dh = dzp . Wd (contraction over 64:
+    // WdT [H, 64]) keeps them in LDS in fragment order (a wave's private 2 KS x 2 KiB, read back as conflict-free
+    // ds_read_b128: 12 reads per lane per tile) -- the column-sum accumulators need the 48 registers more.
+    __shared__ __attribute__((aligned(16))) uint4 wdl[NW][2 * KS][2][64];
+    uint4 wu[KS][4];
+#pragma unroll
+    for (int s = 0; s < KS; ++s)
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt)
+            wu[s][nt] = *reinterpret_cast<const uint4*>(p.WuT + (size_t)(nt * 16 + fr) * H + cl + s * 32);
+#pragma unroll
+    for (int s = 0; s < KS; ++s)
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+                wdl[wave][2 * s + h][ks][lane] =
+                    *reinterpret_cast<const uint4*>(p.WdT + (size_t)(c0 + s * 32 + (fr >> 2) * 8 + h * 4 + (fr & 3)) * 64 + ks * 32 + kg * 8);
+
+    const int e0 = tid * EPT, rrow = e0 >> 6, rzd = e0 & 63;
+    float sg[KS][8], sb[KS][8], sv[KS][8];
+#pragma unroll
+    for (int s = 0; s < KS; ++s)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { sg[s][j] = 0.f; sb[s][j] = 0.f; sv[s][j] = 0.f; }
+
+    const int ntiles = p.M / 16;
+    uint4 d_cur[KS], v_cur[KS], d_nxt[KS], v_nxt[KS];
+    float2 st_cur, st_nxt;
+    {
+        const size_t row = (size_t)blockIdx.x * 16 + fr;
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            d_cur[s] = *reinterpret_cast<const uint4*>(p.dy + row * p.lddy + cl + s * 32);
+            v_cur[s] = *reinterpret_cast<const uint4*>(p.v + row * p.ldv + cl + s * 32);
+        }
+        st_cur = *reinterpret_cast<const float2*>(p.stats + 2 * row);
+    }
+    A4R_LDS_BARRIER();
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        {
+            const int tn = tile + (int)gridDim.x < ntiles ? tile + (int)gridDim.x : tile;
+            const size_t row = (size_t)tn * 16 + fr;
+#pragma unroll
+            for (int s = 0; s < KS; ++s) {
+                d_nxt[s] = *reinterpret_cast<const uint4*>(p.dy + row * p.lddy + cl + s * 32);
+                v_nxt[s] = *reinterpret_cast<const uint4*>(p.v + row * p.ldv + cl + s * 32);
+            }
+            st_nxt = *reinterpret_cast<const float2*>(p.stats + 2 * row);
+        }
+        const size_t row = (size_t)tile * 16 + fr;
+        const float mean = st_cur.x, rstd = st_cur.y;
+        // ---- LayerNorm backward, part 1: xhat, g = dy * gamma, the two row means
+        float xh[KS][8], g[KS][8];
+        float c1 = 0.f, c2 = 0.f;
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            float d8[8], ga8[8];
+            Elem<bf16_t>::unpack(d_cur[s], d8);
+            Elem<bf16_t>::unpack(v_cur[s], xh[s]);
+            *reinterpret_cast<float4*>(ga8) = *reinterpret_cast<const float4*>(&par[cl + s * 32]);
+            *reinterpret_cast<float4*>(ga8 + 4) = *reinterpret_cast<const float4*>(&par[cl + s * 32 + 4]);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float x = (xh[s][j] - mean) * rstd;
+                if constexpr (WGB) { sg[s][j] += d8[j] * x; sb[s][j] += d8[j]; }
+                const float gg = d8[j] * ga8[j];
+                xh[s][j] = x;
+                g[s][j] = gg;
+                c1 += gg;
+                c2 += gg * x;
+            }
+        }
+        c1 = kg_sum(c1);
+        c2 = kg_sum(c2);
+        if (kg == 0) { red[wave][fr][0] = c1; red[wave][fr][1] = c2; }
+        A4R_LDS_BARRIER();
+        c1 = 0.f; c2 = 0.f;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) { c1 += red[w][fr][0]; c2 += red[w][fr][1]; }
+        c1 *= (1.f / H);
+        c2 *= (1.f / H);
+        // ---- part 2: dv (+ dres), rounded to its bf16 storage = the operand of dz = dv . Wu
+        uint4 dvp[KS];
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            float d8[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                d8[j] = rstd * (g[s][j] - c1 - xh[s][j] * c2);
+                if constexpr (WDB) sv[s][j] += d8[j];
+            }
+            if (p.dres) {
+                float r8[8];
+                Elem<bf16_t>::unpack(*reinterpret_cast<const uint4*>(p.dres + row * p.lddres + cl + s * 32), r8);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) d8[j] += r8[j];
+            }
+            dvp[s] = Elem<bf16_t>::pack(d8);
+            *reinterpret_cast<uint4*>(p.dv + row * p.lddv + cl + s * 32) = dvp[s];
+        }
+        // ---- dz partial over this wave's columns, summed through LDS; dzp = dz * act'(zp)
+        f32x4_t zacc[4];
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) zacc[nt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int s = 0; s < KS; ++s)
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) Mma<bf16_t>::mma(wu[s][nt], dvp[s], zacc[nt]);
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) *reinterpret_cast<f32x4_t*>(&zpart[wave][fr][nt * 16 + kg * 4]) = zacc[nt];
+        A4R_LDS_BARRIER();
+        {
+            float s_[EPT];
+            reduce_partials<NW, EPT>(zpart, rrow, rzd, s_);
+            const size_t gi = ((size_t)tile * 16 + rrow) * 64 + rzd;
+            float pre[EPT];
+            if constexpr (EPT == 2) {
+                const uint32_t u = *reinterpret_cast<const uint32_t*>(p.zp + gi);
+                pre[0] = bf16_bits_to_f32(u & 0xffffu); pre[1] = bf16_bits_to_f32(u >> 16);
+            } else {
+                const uint2 u = *reinterpret_cast<const uint2*>(p.zp + gi);
+                pre[0] = bf16_bits_to_f32(u.x & 0xffffu); pre[1] = bf16_bits_to_f32(u.x >> 16);
+                pre[2] = bf16_bits_to_f32(u.y & 0xffffu); pre[3] = bf16_bits_to_f32(u.y >> 16);
+            }
+#pragma unroll
+            for (int i = 0; i < EPT; ++i) s_[i] *= act_bwd(pre[i], p.act);
+            store_bf16_n<EPT>(p.dzp + gi, s_);
+            store_bf16_n<EPT>(reinterpret_cast<bf16_t*>(zbf + zbf_off(rrow, rzd)), s_);
+        }
+        A4R_LDS_BARRIER();
+        // ---- dh = dzp . Wd (+ dv: the adapter's inner residual), through the dense output's dropout mask
+        uint4 zf[2];
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) zf[ks] = *reinterpret_cast<const uint4*>(zbf + fr * 128 + (((ks * 4 + kg) ^ ((fr >> 1) & 7)) << 4));
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            f32x4_t acc[2];
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                acc[h] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) Mma<bf16_t>::mma(wdl[wave][2 * s + h][ks][lane], zf[ks], acc[h]);
+            }
+            float o8[8], dv8[8];
+            Elem<bf16_t>::unpack(dvp[s], dv8);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) o8[j] = acc[j >> 2][j & 3] + (p.inner_res ? dv8[j] : 0.f);
+            if (p.thr16) {
+                const uint64_t el = (uint64_t)row * (uint64_t)H + (uint64_t)(cl + s * 32);
+                const uint64_t h0 = a4r_hash64(p.seed, p.site, el >> 2), h1 = a4r_hash64(p.seed, p.site, (el >> 2) + 1);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    o8[e] = (((uint32_t)(h0 >> (16 * e)) & 0xffffu) >= p.thr16) ? o8[e] * p.keep_scale : 0.f;
+                    o8[e + 4] = (((uint32_t)(h1 >> (16 * e)) & 0xffffu) >= p.thr16) ? o8[e + 4] * p.keep_scale : 0.f;
+                }
+            }
+            *reinterpret_cast<uint4*>(p.dh + row * p.lddh + cl + s * 32) = Elem<bf16_t>::pack(o8);
+        }
+#pragma unroll
+        for (int s = 0; s < KS; ++s) { d_cur[s] = d_nxt[s]; v_cur[s] = v_nxt[s]; }
+        st_cur = st_nxt;
+    }
+    // ---- column sums: over the 16 rows a lane group holds (lane & 15), then one atomic per column per workgroup
+    if constexpr (WGB || WDB) {
+        auto flush = [&](float (&acc)[KS][8], float* dst) {
+            A4R_LDS_BARRIER();                                            // par[] free (gamma no longer read / previous flush done)
+#pragma unroll
+            for (int s = 0; s < KS; ++s)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const float t = group16_sum(acc[s][j]);
+                    if (fr == 0) par[cl + s * 32 + j] = t;
+                }
+            A4R_LDS_BARRIER();
+            if (dst)
+                for (int c = tid; c < H; c += NT) atomicAdd(dst + c, par[c]);
+        };
+        if constexpr (WGB) { flush(sg, p.dgamma); flush(sb, p.dbeta); }
+        if constexpr (WDB) flush(sv, p.dbias);
+    }
+}
+
+inline bool misaligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) != 0; }
+
+template <int CW, int NW>
+int launch_fwd(hipStream_t s, const AdFwdArgs& a, int grid) {
+    hipLaunchKernelGGL((adapter_ln_fwd_kernel<CW, NW>), dim3(grid), dim3(NW * 64), 0, s, a);
+    return a4r_launch_status();
+}
+template <int CW, int NW>
+int launch_bwd(hipStream_t s, const AdBwdArgs& a, int grid) {
+    const bool wgb = a.dgamma || a.dbeta, wdb = a.dbias != nullptr;
+    if (wgb && wdb) hipLaunchKernelGGL((adapter_ln_bwd_kernel<CW, NW, true, true>), dim3(grid), dim3(NW * 64), 0, s, a);
+    else if (wgb) hipLaunchKernelGGL((adapter_ln_bwd_kernel<CW, NW, true, false>), dim3(grid), dim3(NW * 64), 0, s, a);
+    else if (wdb) hipLaunchKernelGGL((adapter_ln_bwd_kernel<CW, NW, false, true>), dim3(grid), dim3(NW * 64), 0, s, a);
+    else hipLaunchKernelGGL((adapter_ln_bwd_kernel<CW, NW, false, false>), dim3(grid), dim3(NW * 64), 0, s, a);
+    return a4r_launch_status();
+}
+
+}  // namespace
+
+int a4r_cu_count();       // a4r_gemm256.hip
+
+extern "C" int a4r_adapter_ln_fwd(void* stream, const void* A, int lda, const void* R1, int ldr1, const void* R2, int ldr2,
+                                  const void* Wd, const float* bd, const void* Wu, const float* bu,
+                                  const float* gamma, const float* beta, float eps, int act,
+                                  void* zp, void* z, void* v, int ldv, void* y, int ldy, float* stats, int M, int H, int d, int dtype) {
+    if (!A || !R1 || !Wd || !bd || !Wu || !bu || !gamma || !beta || !zp || !z || !v || !y || !stats) return A4R_EINVAL;
+    if (dtype != A4R_BF16 || d != 64 || M <= 0 || M % 16) return A4R_EINVAL;
+    if (lda % 8 || ldr1 % 8 || (R2 && ldr2 % 8) || ldv % 8 || ldy % 8) return A4R_EINVAL;
+    if (misaligned16(A) || misaligned16(R1) || misaligned16(R2) || misaligned16(Wd) || misaligned16(Wu) || misaligned16(v) || misaligned16(y) ||
+        misaligned16(zp) || misaligned16(z) || (reinterpret_cast<uintptr_t>(stats) & 7u))
+        return A4R_EINVAL;
+    // the residual sum is R1 + R2; the kernel streams TWO tensors: the down-projection input A and one other
+    AdFwdArgs a{};
+    a.A = reinterpret_cast<const bf16_t*>(A); a.lda = lda;
+    if (R1 == A && ldr1 == lda && R2) { a.O = reinterpret_cast<const bf16_t*>(R2); a.ldo = ldr2; a.a_in_resid = 1; }          // Houlsby: up + h + input
+    else if (R2 == A && ldr2 == lda) { a.O = reinterpret_cast<const bf16_t*>(R1); a.ldo = ldr1; a.a_in_resid = 1; }             // parallel form
+    else if (!R2 && R1 != A) { a.O = reinterpret_cast<const bf16_t*>(R1); a.ldo = ldr1; a.a_in_resid = 0; }                     // Compacter / Pfeiffer
+    else return A4R_EINVAL;
+    a.Wd = reinterpret_cast<const bf16_t*>(Wd); a.Wu = reinterpret_cast<const bf16_t*>(Wu); a.bd = bd; a.bu = bu;
+    a.gamma = gamma; a.beta = beta; a.eps = eps; a.act = act;
+    a.zp = reinterpret_cast<bf16_t*>(zp); a.z = reinterpret_cast<bf16_t*>(z); a.v = reinterpret_cast<bf16_t*>(v); a.y = reinterpret_cast<bf16_t*>(y);
+    a.ldv = ldv; a.ldy = ldy; a.stats = stats; a.M = M;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    const int ntiles = M / 16, ncu = a4r_cu_count();
+    const int grid = ntiles < ncu ? ntiles : ncu;
+    switch (H) {
+        case 128: return launch_fwd<32, 4>(s, a, grid);
+        case 256: return launch_fwd<32, 8>(s, a, grid);
+        case 512: return launch_fwd<64, 8>(s, a, grid);
+        case 768: return launch_fwd<96, 8>(s, a, grid);
+        case 1024: return launch_fwd<128, 8>(s, a, grid);
+        default: return A4R_EINVAL;
+    }
+}
+
+extern "C" int a4r_adapter_ln_bwd(void* stream, const void* dy, int lddy, const void* v, int ldv, const float* stats, const float* gamma,
+                                  const void* dres, int lddres, const void* zp, int act, const void* WuT, const void* WdT, int inner_res,
+                                  void* dv, int lddv, void* dzp, void* dh, int lddh, float* dgamma, float* dbeta, float* dbias,
+                                  int M, int H, int d, int dtype, float drop_p, uint32_t drop_site, uint64_t drop_seed) {
+    if (!dy || !v || !stats || !gamma || !zp || !WuT || !WdT || !dv || !dzp || !dh) return A4R_EINVAL;
+    if (dtype != A4R_BF16 || d != 64 || M <= 0 || M % 16) return A4R_EINVAL;
+    if (lddy % 8 || ldv % 8 || (dres && lddres % 8) || lddv % 8 || lddh % 8) return A4R_EINVAL;
+    if (misaligned16(dy) || misaligned16(v) || misaligned16(dres) || misaligned16(WuT) || misaligned16(WdT) || misaligned16(dv) || misaligned16(dh) ||
+        misaligned16(zp) || misaligned16(dzp) || (reinterpret_cast<uintptr_t>(stats) & 7u))
+        return A4R_EINVAL;
+    AdBwdArgs a{};
+    a.dy = reinterpret_cast<const bf16_t*>(dy); a.v = reinterpret_cast<const bf16_t*>(v); a.dres = reinterpret_cast<const bf16_t*>(dres);
+    a.lddy = lddy; a.ldv = ldv; a.lddres = lddres; a.stats = stats; a.gamma = gamma;
+    a.zp = reinterpret_cast<const bf16_t*>(zp); a.act = act;
+    a.WuT = reinterpret_cast<const bf16_t*>(WuT); a.WdT = reinterpret_cast<const bf16_t*>(WdT); a.inner_res = inner_res;
+    a.dv = reinterpret_cast<bf16_t*>(dv); a.dzp = reinterpret_cast<bf16_t*>(dzp); a.dh = reinterpret_cast<bf16_t*>(dh);
+    a.lddv = lddv; a.lddh = lddh; a.dgamma = dgamma; a.dbeta = dbeta; a.dbias = dbias; a.M = M;
+    a.seed = drop_seed; a.site = drop_site; a.thr16 = a4r_thr16(drop_p); a.keep_scale = a4r_keep_scale(drop_p);
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    const int ntiles = M / 16, ncu = a4r_cu_count();
+    const int grid = ntiles < ncu ? ntiles : ncu;
+    switch (H) {
+        case 128: return launch_bwd<32, 4>(s, a, grid);
+        case 256: return launch_bwd<32, 8>(s, a, grid);
+        case 512: return launch_bwd<64, 8>(s, a, grid);
+        case 768: return launch_bwd<96, 8>(s, a, grid);
+        // H = 1024: the fragment image of Wd (128 KB) + the partial tiles exceed the 160 KB of LDS -> the three-launch form
+        default: return A4R_EINVAL;
+    }
+}

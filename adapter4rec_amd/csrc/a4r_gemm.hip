@@ -231,31 +231,20 @@ inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 
 }  // namespace
 
 int a4r_gemm_nt_256(hipStream_t s, const a4r_gemm_t& g);   // a4r_gemm256.hip
-int a4r_gemm_nt_256w4(hipStream_t s, const a4r_gemm_t& g); // a4r_gemm256w4.hip (variant 3: four waves of 128 x 128)
 int a4r_gemm_nt_skinny64(hipStream_t s, const a4r_gemm_t& g); // a4r_gemm_skinny.hip (N == 64, bf16 in: the adapter down-projections)
 int a4r_gemm_nt_skinnyk(hipStream_t s, const a4r_gemm_t& g);  // a4r_gemm_skinny.hip (K == 64, bf16: the adapter up-projections)
-int a4r_gemm_nt_256s(hipStream_t s, const a4r_gemm_t& g);  // a4r_gemm256s.hip (variant 5: four waves, K-tile double buffer, spread DMA stream)
 static int run_256(hipStream_t s, const a4r_gemm_t& g);
 int a4r_cu_count();                                          // a4r_gemm256.hip: CU count rounded down to a multiple of 8
 
-static int run_256(hipStream_t s, const a4r_gemm_t& g) {
-    if (g_variant == 5) {
-        const int rc = a4r_gemm_nt_256s(s, g);
-        if (rc != 1) return rc;
-    }
-    if (g_variant == 3) {
-        const int rc = a4r_gemm_nt_256w4(s, g);
-        if (rc != 1) return rc;
-    }
-    return a4r_gemm_nt_256(s, g);
-}
+static int run_256(hipStream_t s, const a4r_gemm_t& g) { return a4r_gemm_nt_256(s, g); }
 
 extern int g_tn_variant;                                     // a4r_gemm_tn.hip: 0 = register-staged weight-gradient kernel for bf16 too
 
 extern "C" int a4r_gemm_variant(int v) {
     const int old = g_variant;
-    if (v >= 0 && v <= 5) g_tn_variant = v != 0;
-    if (v >= 0 && v <= 5) g_variant = v;     // 0/1: 128-tile kernels, 2: automatic (default), 3: four-wave 256 tile, 4: eight-wave 256 tile forced, 5: four-wave stream kernel forced
+    if (v == 3 || v == 5) return -1;         // the four-wave forms were measured slower and are no longer part of the library (tools/rejected_kernels/)
+    if (v >= 0 && v <= 4) g_tn_variant = v != 0;
+    if (v >= 0 && v <= 4) g_variant = v;     // 0/1: 128-tile kernels, 2: automatic (default), 4: eight-wave 256 tile forced
     return old;
 }
 

@@ -187,6 +187,8 @@ class TransRecEngine:
         self.seed = int(getattr(args, 'dropout_seed', 0x5eed))
         self.step_count = 0
         self._packs_T, self._packs_b, self._virtual = [], [], []
+        # one-launch adapter + residual + LayerNorm kernels (a4r_adapter_fused.hip); A4R_FUSE_ADAPTERS=0: the three-launch forms (A/B runs, tests)
+        self.fuse_adapters = bool(int(_os.environ.get('A4R_FUSE_ADAPTERS', '1'))) and bool(getattr(args, 'fuse_adapters', True))
         self._collect_trainables()
         self._build_item_tower()
         self._build_sasrec()
@@ -442,7 +444,6 @@ class TransRecEngine:
             for p in bert.pooler.parameters():
                 self.grad_view(p)
         self.cls_only = bool(getattr(self.args, 'cls_only_last', True))
-        self.fuse_adapters = bool(getattr(self.args, 'fuse_adapters', False))
         self.roberta = g['model_type'] == 'roberta'
         self.pad_id = int(g['pad_token_id'])
         self.p_hidden = float(g['hidden_dropout_prob'])
@@ -694,6 +695,9 @@ class TransRecEngine:
             va, t, sta = bufs['va' + which], bufs['t' + which], bufs['sta' + which]
             L.gemm_nt(dense_in, w, va, bias=bias, R1=resid, drop_p=p_drop, drop_site=site, drop_seed=seed, drop_first=True, M=M)   # h + input
             L.ln_fwd(va, ln.gamma, ln.beta, ln.eps, t, sta, M=M)
+            if self._fuse(blk, ad, t):
+                L.adapter_ln_fwd(t, va, None, ad.wd, ad.bd, ad.wu, ad.bu, lnn.gamma, lnn.beta, lnn.eps, ad.act, zp, z, v, out, st, M=M)
+                return
             L.gemm_nt(t, ad.wd, z, bias=ad.bd, C2=zp, act=ad.act, M=M)
             L.gemm_nt(z, ad.wu, v, bias=ad.bu, R1=va, M=M)                   # adapter(t) + h + input
             L.ln_fwd(v, lnn.gamma, lnn.beta, lnn.eps, out, st, M=M)
@@ -705,17 +709,24 @@ class TransRecEngine:
             L.ln_fwd(v, ln.gamma, ln.beta, ln.eps, out, st, M=M)
             return
         L.gemm_nt(dense_in, w, h, bias=bias, drop_p=p_drop, drop_site=site, drop_seed=seed, M=M)
-        if blk.T == torch.bfloat16 and ad.dp == 64 and blk.H in (128, 256, 512, 768, 1024) and self.fuse_adapters:
-            # one pass: down-projection, activation, up-projection, residual(s), LayerNorm (a4r_adapter.hip)
-            L.adapter_fwd(h, resid, ad.wd, ad.bd, ad.wu, ad.bu, ln.gamma, ln.beta, ln.eps, ad.act, ad.kind != 'compacter',
-                          zp, z, v, out, st, M=M)
+        comp = ad.kind == 'compacter'  # no inner residual (modules.py:248-252); Houlsby: fc_up(act(fc_down(h))) + h, then + input (model.py:292-297)
+        if self._fuse(blk, ad, h):     # ONE launch: down-projection, activation, up-projection, residual(s), LayerNorm (a4r_adapter_fused.hip)
+            L.adapter_ln_fwd(h, resid if comp else h, None if comp else resid, ad.wd, ad.bd, ad.wu, ad.bu, ln.gamma, ln.beta, ln.eps, ad.act,
+                             zp, z, v, out, st, M=M)
             return
         L.gemm_nt(h, ad.wd, z, bias=ad.bd, C2=zp, act=ad.act, M=M)
-        if ad.kind == 'compacter':    # no inner residual (modules.py:248-252)
+        if comp:
             L.gemm_nt(z, ad.wu, v, bias=ad.bu, R1=resid, M=M)
-        else:                         # Houlsby: fc_up(act(fc_down(h))) + h, then + input (model.py:292-297)
+        else:
             L.gemm_nt(z, ad.wu, v, bias=ad.bu, R1=h, R2=resid, M=M)
         L.ln_fwd(v, ln.gamma, ln.beta, ln.eps, out, st, M=M)
+
+    def _fuse_bwd(self, blk, ad, t):
+        return self._fuse(blk, ad, t) and blk.H != 1024          # (the backward kernel's LDS image of Wd does not fit at H = 1024)
+
+    def _fuse(self, blk, ad, t):
+        """The one-launch adapter kernels apply (bf16, bottleneck 64, a width they are instantiated for, no zero-padded block)."""
+        return self.fuse_adapters and getattr(blk, 'Hv', blk.H) == blk.H and L.adapter_ln_ok(t, ad.dp)
 
     def _block_forward(self, blk, x, key_mask, n_items, M, bufs, train, seed, x_out, cls_rows=None):
         """cls_rows = Ip: after attention only row 0 of every item (the CLS token, all the item head reads,
@@ -765,10 +776,14 @@ class TransRecEngine:
         dh = self._buf('dh' + which, M, H, T)
         if pl == 'pfeiffer':
             va, t, sta = bufs['va' + which], bufs['t' + which], bufs['sta' + which]
-            L.ln_bwd(dy, v, st, lnn.gamma, dv, M=M, dgamma=gg(lnn.g_gamma), dbeta=gg(lnn.g_beta), dbias=gg(ad.g_bu))
-            L.gemm_nt(dv, ad.wuT, dzp, Pre=zp, dact=ad.act, M=M)
             dt = self._buf('dt', M, H, T)
-            L.gemm_nt(dzp, ad.wdT, dt, M=M)
+            if self._fuse_bwd(blk, ad, dy):
+                L.adapter_ln_bwd(dy, v, st, lnn.gamma, None, zp, ad.act, ad.wuT, ad.wdT, False, dv, dzp, dt,
+                                 dgamma=gg(lnn.g_gamma), dbeta=gg(lnn.g_beta), dbias=gg(ad.g_bu), M=M)
+            else:
+                L.ln_bwd(dy, v, st, lnn.gamma, dv, M=M, dgamma=gg(lnn.g_gamma), dbeta=gg(lnn.g_beta), dbias=gg(ad.g_bu))
+                L.gemm_nt(dv, ad.wuT, dzp, Pre=zp, dact=ad.act, M=M)
+                L.gemm_nt(dzp, ad.wdT, dt, M=M)
             self._adapter_wgrads(ad, dv, z, dzp, t, M)
             dva = self._buf('dva', M, H, T)
             L.ln_bwd(dt, va, sta, ln.gamma, dva, M=M, dgamma=gg(ln.g_gamma), dbeta=gg(ln.g_beta), dres=dv)
@@ -777,6 +792,13 @@ class TransRecEngine:
                 return dh, dva
             return dva, dva
         h = bufs['h' + which]
+        if pl != 'parallel' and self._fuse_bwd(blk, ad, dy):
+            # ONE launch: LayerNorm backward, dzp = (dv Wu) * act'(zp), dh = mask * (dzp Wd [+ dv]) (a4r_adapter_fused.hip)
+            L.adapter_ln_bwd(dy, v, st, ln.gamma, None, zp, ad.act, ad.wuT, ad.wdT, ad.kind != 'compacter', dv, dzp, dh,
+                             dgamma=gg(ln.g_gamma), dbeta=gg(ln.g_beta), dbias=gg(ad.g_bu), M=M,
+                             drop_p=p_drop, drop_site=site, drop_seed=seed)
+            self._adapter_wgrads(ad, dv, z, dzp, h, M)
+            return dh, dv
         L.ln_bwd(dy, v, st, ln.gamma, dv, M=M, dgamma=gg(ln.g_gamma), dbeta=gg(ln.g_beta), dbias=gg(ad.g_bu))
         L.gemm_nt(dv, ad.wuT, dzp, Pre=zp, dact=ad.act, M=M)
         if pl == 'parallel':

@@ -56,14 +56,12 @@ typedef struct {
                            * caller splits one GEMM into several launches: the mask index is (drop_row0 + row) * N + col) */
 } a4r_gemm_t;
 int a4r_gemm_nt(void* stream, const a4r_gemm_t* g);
-/* tuning knob for A/B measurements: 0 = 128x128 tile, register-staged K pipeline; 1 = 128x128 tile, direct-to-LDS
+/* tuning knob for A/B measurements and tests: 0 = 128x128 tile, register-staged K pipeline; 1 = 128x128 tile, direct-to-LDS
  * (global_load_lds) pipeline; 2 (default) = 256x256 tile with a 2-deep LDS-DMA ring kept in flight across barriers
  * wherever M % 256 == 0, N % 256 == 0 (variant 1 elsewhere), chosen automatically: fewer 256-tiles than half the CUs -> the
- * 128-tile kernel; a last round of only a few whole row panels -> those panels on the 128-tile kernel; 3 = the four-wave
- * form of the 256 tile (measured slower); 4 = the eight-wave 256 tile forced (tests); 5 = the four-wave stream kernel
- * (a4r_gemm256s.hip: K-tile double buffer, one LDS-DMA stream across output tiles; bf16, within 10 % of variant 4 either way
- * depending on the epilogue) forced.  Results of 2 / 4 / 5 agree bit for bit (same MFMA order per output element), the others
- * to fp32 summation order; returns the previous setting (any other v only queries). */
+ * 128-tile kernel; a last round of only a few whole row panels -> those panels on the 128-tile kernel; 4 = the 256 tile
+ * forced (tests).  Results of 2 / 4 agree bit for bit, the others to fp32 summation order; returns the previous setting
+ * (-1 for the retired variants 3 and 5, any other v only queries). */
 int a4r_gemm_variant(int v);
 
 /* C[P,Q] (fp32, +=) = X[M,P]^T . Y[M,Q]: weight gradients of the trainable adapter matrices
@@ -75,15 +73,27 @@ int a4r_gemm_tn(void* stream, const void* X, int ldx, const void* Y, int ldy, fl
 /* colsum[N] (fp32, +=) = sum over rows of X[M,N]: bias gradients. N % 8 == 0. */
 int a4r_colsum(void* stream, const void* X, int ldx, float* out, int M, int N, int dtype);
 
-/* Fused adapter bottleneck + residual + LayerNorm, forward (bf16 only; H in {128,256,512,768,1024}; dp = 64 padded):
- *   zp = h Wd^T + bd ; z = act(zp) ; v = z Wu^T + bu (+ h if inner_residual) + x ; y = LayerNorm(v) * gamma + beta
- * = BertAdaptedSelfOutput.forward (model/model.py:292-297) after its dense+dropout, with AdapterBlock (modules.py:130-134,
- * inner_residual = 1) or HyperComplexAdapterBlock (modules.py:248-252, inner_residual = 0, effective PHM matrices).
- * Wd [dp, H], Wu [H, dp] row-major bf16; zp, z [M, dp]; v, y [M, ldv/ldy]; stats [M, 2] (mean, rstd). M % 64 == 0. */
-int a4r_adapter_fwd(void* stream, const void* h, int ldh, const void* x, int ldx, const void* Wd, const float* bd,
-                    const void* Wu, const float* bu, const float* gamma, const float* beta, float eps, int act,
-                    int inner_residual, void* zp, void* z, void* v, int ldv, void* y, int ldy, float* stats,
-                    int M, int H, int dp, int dtype);
+/* Fused bottleneck adapter + residual(s) + LayerNorm, ONE launch per direction (bf16; H in {128,256,512,768,1024}; the
+ * bottleneck width padded to d = 64; M % 16 == 0).  Replaces BertAdaptedSelfOutput.forward after its dense + dropout
+ * (model/model.py:292-297) with AdapterBlock (modules.py:116-134), HyperComplexAdapterBlock (modules.py:209-252, effective
+ * PHM matrices, no inner residual) or the adapter half of BertPfeifferAdaptedSelfOutput (model.py:321-329):
+ *   forward : zp = A Wd^T + bd ; z = act(zp) ; v = z Wu^T + bu + R1 + R2 ; y = LayerNorm(v) gamma + beta
+ *             A must be R1 or R2 (Houlsby: A = R1 = dense output, R2 = sub-layer input; parallel form: A = R2) or R2 must be
+ *             null (Compacter: A = dense output, R1 = input; Pfeiffer: A = LN(h + input), R1 = h + input): two tensors streamed.
+ *             Wd [64, H], Wu [H, 64] row-major bf16; outputs zp, z [M, 64], v, y [M, H], stats [M, 2] (mean, rstd).
+ *   backward: dv = LayerNorm'(dy; v, stats, gamma) [+ dres]; dzp = (dv Wu) * act'(zp); dh = dropout_mask * (dzp Wd [+ dv if
+ *             inner_res]); column sums dgamma += sum dy xhat, dbeta += sum dy, dbias += sum dv (each optional, fp32 atomics).
+ *             WuT [64, H] = Wu^T, WdT [H, 64] = Wd^T; the dropout mask is the dense output's (index row * H + col).
+ * Returns A4R_EINVAL for anything else: the caller then uses the three-launch form (a4r_gemm_nt x 2 + a4r_ln_fwd / a4r_ln_bwd).
+ * HBM bytes per launch: (4 H + 128) * 2 * M against ~7 H * 2 * M for the three launches. */
+int a4r_adapter_ln_fwd(void* stream, const void* A, int lda, const void* R1, int ldr1, const void* R2, int ldr2,
+                       const void* Wd, const float* bd, const void* Wu, const float* bu,
+                       const float* gamma, const float* beta, float eps, int act,
+                       void* zp, void* z, void* v, int ldv, void* y, int ldy, float* stats, int M, int H, int d, int dtype);
+int a4r_adapter_ln_bwd(void* stream, const void* dy, int lddy, const void* v, int ldv, const float* stats, const float* gamma,
+                       const void* dres, int lddres, const void* zp, int act, const void* WuT, const void* WdT, int inner_res,
+                       void* dv, int lddv, void* dzp, void* dh, int lddh, float* dgamma, float* dbeta, float* dbias,
+                       int M, int H, int d, int dtype, float drop_p, uint32_t drop_site, uint64_t drop_seed);
 
 /* Short-sequence self-attention, one wave per (item, head), S <= 32, dh in {32, 64}.
  * BERT layer: HF BertSelfAttention (called from model/encoders.py:53); SASRec: SelfAttention

@@ -68,14 +68,21 @@ def gemm_nt(A, B, Cout, bias=None, C2=None, R1=None, R2=None, Pre=None, act=0, d
     Cout[:M] = v.to(Cout.dtype)
 
 
-def adapter_fwd(h, x, Wd, bd, Wu, bu, gamma, beta, eps, act, inner_residual, zp, z, v, y, stats, M=None):
-    M = h.shape[0] if M is None else M
-    assert h.dtype == torch.bfloat16 and Wd.shape[0] == 64 and M % 64 == 0
-    p = h[:M].float() @ Wd.float().t() + bd
+def adapter_ln_ok(A, d):
+    return REAL.adapter_ln_ok(A, d)
+
+
+def adapter_ln_fwd(A, R1, R2, Wd, bd, Wu, bu, gamma, beta, eps, act, zp, z, v, y, stats, M=None):
+    """a4r_adapter_ln_fwd: zp = A Wd^T + bd; z = act(zp); v = z Wu^T + bu + R1 + R2; y = LN(v) (bf16 storage points as the kernel's)."""
+    M = A.shape[0] if M is None else M
+    assert A.dtype == torch.bfloat16 and Wd.shape[0] == 64 and M % 16 == 0
+    assert (R1 is A and R2 is not None) or (R2 is A) or (R2 is None and R1 is not A) or \
+        (R1.data_ptr() == A.data_ptr() and R2 is not None) or (R2 is not None and R2.data_ptr() == A.data_ptr())
+    p = A[:M].float() @ Wd.float().t() + bd
     zp[:M] = p.to(zp.dtype)
     zz = _act(p, act).to(z.dtype)
     z[:M] = zz
-    vv = zz.float() @ Wu.float().t() + bu + x[:M].float() + (h[:M].float() if inner_residual else 0)
+    vv = zz.float() @ Wu.float().t() + bu + R1[:M].float() + (R2[:M].float() if R2 is not None else 0)
     v[:M] = vv.to(v.dtype)
     vq = v[:M].float()
     mu = vq.mean(-1, keepdim=True)
@@ -83,6 +90,21 @@ def adapter_fwd(h, x, Wd, bd, Wu, bu, gamma, beta, eps, act, inner_residual, zp,
     stats[:M, 0] = mu[:, 0]
     stats[:M, 1] = rstd[:, 0]
     y[:M] = ((vq - mu) * rstd * gamma + beta).to(y.dtype)
+
+
+def adapter_ln_bwd(dy, v, stats, gamma, dres, zp, act, WuT, WdT, inner_res, dv, dzp, dh, dgamma=None, dbeta=None, dbias=None, M=None,
+                   drop_p=0.0, drop_site=0, drop_seed=0):
+    """a4r_adapter_ln_bwd = ln_bwd | (dv Wu) * act'(zp) | dzp Wd (+ dv), with the kernel's bf16 storage points."""
+    assert drop_p == 0.0
+    M = dy.shape[0] if M is None else M
+    ln_bwd(dy, v, stats, gamma, dv, M=M, dgamma=dgamma, dbeta=dbeta, dbias=dbias, dres=dres)
+    dq = dv[:M].float()
+    dz = (dq @ WuT.float().t()) * _dact(zp[:M].float(), act)
+    dzp[:M] = dz.to(dzp.dtype)
+    o = dzp[:M].float() @ WdT.float().t()
+    if inner_res:
+        o = o + dq
+    dh[:M] = o.to(dh.dtype)
 
 
 def gemm_tn(X, Y, Cacc, M=None):

@@ -53,7 +53,7 @@ def act_ref(x, act):
 
 
 # ------------------------------------------------------------------ GEMM NT
-@pytest.fixture(params=[5, 4, 3, 2, 1, 0], ids=['tile256s', 'tile256', 'tile256w4', 'auto', 'glds', 'regstage'])
+@pytest.fixture(params=[4, 2, 1, 0], ids=['tile256', 'auto', 'glds', 'regstage'])
 def gemm_variant(request):
     from adapter4rec_amd import _lib as L
     old = L.gemm_variant(request.param)
@@ -592,60 +592,131 @@ def test_eval_rank():
     assert sum(abs(a - b) for a, b in zip(got, ref)) <= 1, (got, ref)     # fp32 vs fp64 near-ties
 
 
-# ------------------------------------------------------------------ fused adapter forward
-@pytest.mark.parametrize('H', [128, 768])
-@pytest.mark.parametrize('act,inner', [(1, 1), (2, 1), (3, 0)])
-def test_adapter_fwd_fused(H, act, inner):
+# ------------------------------------------------------------------ one-launch adapter + residual(s) + LayerNorm
+AD_MODES = {'houlsby': (1, True), 'houlsby_gelu': (2, True), 'compacter': (3, False), 'pfeiffer': (1, False), 'parallel': (1, True)}
+
+
+def _adapter_case(H, M, seed=90):
+    t, dp = torch.bfloat16, 64
+    a, o = rnd(M, H, dtype=t, seed=seed + 1), rnd(M, H, dtype=t, seed=seed + 2)
+    Wd, Wu = rnd(dp, H, dtype=t, scale=0.05, seed=seed + 3), rnd(H, dp, dtype=t, scale=0.05, seed=seed + 4)
+    bd, bu = rnd(dp, seed=seed + 5) * 0.1, rnd(H, seed=seed + 6) * 0.1
+    gamma, beta = rnd(H, seed=seed + 7) * 0.1 + 1, rnd(H, seed=seed + 8) * 0.1
+    return a, o, Wd, Wu, bd, bu, gamma, beta
+
+
+@pytest.mark.parametrize('H', [128, 256, 512, 768, 1024])
+@pytest.mark.parametrize('mode', list(AD_MODES))
+def test_adapter_ln_fwd(H, mode):
+    """a4r_adapter_ln_fwd vs torch fp32 and vs the three-launch form (a4r_gemm_nt x 2 + a4r_ln_fwd) it replaces; M = 16 x 301
+    rows: more tiles than workgroups, a ragged last round, every wave-to-column mapping (H / 8 columns per wave)."""
     from adapter4rec_amd import _lib as L
-    M, dp, t = 384, 64, torch.bfloat16
-    h, x = rnd(M, H, dtype=t, seed=91), rnd(M, H, dtype=t, seed=92)
-    Wd, Wu = rnd(dp, H, dtype=t, scale=0.05, seed=93), rnd(H, dp, dtype=t, scale=0.05, seed=94)
-    bd, bu = rnd(dp, seed=95) * 0.1, rnd(H, seed=96) * 0.1
-    gamma, beta = rnd(H, seed=97) * 0.1 + 1, rnd(H, seed=98) * 0.1
-    zp = torch.zeros(M, dp, dtype=t, device=dev()); z = torch.zeros_like(zp)
-    v = torch.zeros(M, H, dtype=t, device=dev()); y = torch.zeros_like(v)
-    stats = torch.zeros(M, 2, device=dev())
-    L.adapter_fwd(h, x, Wd, bd, Wu, bu, gamma, beta, 1e-12, act, inner, zp, z, v, y, stats)
-    zp_r = h.float() @ Wd.float().t() + bd
+    act, inner = AD_MODES[mode]
+    M, dp, t = 16 * 301, 64, torch.bfloat16
+    a, o, Wd, Wu, bd, bu, gamma, beta = _adapter_case(H, M)
+    mk = lambda c: torch.zeros(M, c, dtype=t, device=dev())
+    zp, z, v, y, stats = mk(dp), mk(dp), mk(H), mk(H), torch.zeros(M, 2, device=dev())
+    if mode == 'parallel':
+        R1, R2 = o, a                                          # up + (dense + input) + input: the adapter reads the sub-layer input
+    else:
+        R1, R2 = (a, o) if inner else (o, None)
+    L.adapter_ln_fwd(a, R1, R2, Wd, bd, Wu, bu, gamma, beta, 1e-12, act, zp, z, v, y, stats)
+    zp_r = a.float() @ Wd.float().t() + bd
     z_r = act_ref(zp_r, act)
-    zq = z_r.to(t).float()                                   # the kernel feeds the bf16-rounded z into the up projection
-    v_r = zq @ Wu.float().t() + bu + x.float() + (h.float() if inner else 0)
-    y_r = torch.nn.functional.layer_norm(v_r, (H,), gamma, beta, 1e-12)
-    close(zp, zp_r, t, 'adapter zp')
-    close(z, z_r, t, 'adapter z')
-    close(v, v_r, t, 'adapter v')
-    close(y, y_r, t, 'adapter y')
-    close(stats[:, 0], v_r.mean(-1), torch.float32, 'adapter mean', atol32=2e-3, rtol32=1e-3)
-    close(stats[:, 1], torch.rsqrt(v_r.var(-1, unbiased=False) + 1e-12), torch.float32, 'adapter rstd', atol32=2e-3, rtol32=2e-3)
+    v_r = z_r.to(t).float() @ Wu.float().t() + bu + R1.float() + (R2.float() if R2 is not None else 0)
+    vq = v_r.to(t).float()                                    # LayerNorm runs on the stored (bf16) v
+    y_r = torch.nn.functional.layer_norm(vq, (H,), gamma, beta, 1e-12)
+    close(zp, zp_r, t, 'zp')
+    close(z, z_r, t, 'z')
+    close(v, v_r, t, 'v')
+    close(y, y_r, t, 'y')
+    close(stats[:, 0], vq.mean(-1), torch.float32, 'mean', atol32=2e-3, rtol32=1e-3)
+    close(stats[:, 1], torch.rsqrt(vq.var(-1, unbiased=False) + 1e-12), torch.float32, 'rstd', atol32=2e-3, rtol32=2e-3)
+    # the launches it replaces, same inputs: outputs agree to bf16 rounding of the stored intermediates
+    Mp = 16 * 304                                             # (a4r_gemm_nt wants M % 128 == 0: padded copies)
+    pad = lambda x: torch.cat([x, torch.zeros(Mp - M, x.shape[1], dtype=x.dtype, device=dev())])
+    a2, r1, r2 = pad(a), pad(R1), (pad(R2) if R2 is not None else None)
+    if R1 is a:
+        r1 = a2
+    if R2 is a:
+        r2 = a2
+    mk2 = lambda c: torch.zeros(Mp, c, dtype=t, device=dev())
+    zp2, z2, v2, y2, st2 = mk2(dp), mk2(dp), mk2(H), mk2(H), torch.zeros(Mp, 2, device=dev())
+    L.gemm_nt(a2, Wd, z2, bias=bd, C2=zp2, act=act)
+    L.gemm_nt(z2, Wu, v2, bias=bu, R1=r1, R2=r2)
+    L.ln_fwd(v2, gamma, beta, 1e-12, y2, st2)
+    close(zp, zp2[:M], t, 'zp vs 3 launches', rtol16=1e-2, atol16=1e-2)
+    close(v, v2[:M], t, 'v vs 3 launches', rtol16=1e-2, atol16=2e-2)
+    close(y, y2[:M], t, 'y vs 3 launches', rtol16=1e-2, atol16=3e-2)
 
 
-@pytest.mark.parametrize('N,K', [(768, 768), (768, 64), (256, 3072), (1024, 192)])
-def test_gemm_stream_kernel_many_tiles(N, K):
-    """Four-wave stream kernel (variant 5) with more output tiles than CUs: the LDS-DMA stream runs on across output-tile
-    boundaries (the last two K-tiles of a tile fetch the first two of the workgroup's next tile), odd and even K-tile counts,
-    a single K-tile (K = 64), residual + bias + dropout epilogue; compared with torch and with the eight-wave kernel."""
+@pytest.mark.parametrize('H', [128, 256, 512, 768])
+@pytest.mark.parametrize('act,inner,sums,drop', [(1, True, 'b', 0.1), (2, True, 'gb', 0.0), (3, False, 'b', 0.25), (1, False, 'gb', 0.0), (1, True, '', 0.1)])
+def test_adapter_ln_bwd(H, act, inner, sums, drop):
+    """a4r_adapter_ln_bwd vs the three launches it replaces (a4r_ln_bwd | a4r_gemm_nt dact | a4r_gemm_nt + residual + dropout: SAME
+    dropout mask, regenerated from (seed, site, row * H + col)) and vs torch fp32; column sums dgamma / dbeta / dbias."""
     from adapter4rec_amd import _lib as L
-    M = 256 * 301                                             # 301 row panels: 903 / 301 / 1204 tiles on 256 CUs
-    A = rnd(M, K, dtype=torch.bfloat16, seed=81)
-    B = rnd(N, K, dtype=torch.bfloat16, scale=0.05, seed=82)
-    R1 = rnd(M, N, dtype=torch.bfloat16, seed=83)
-    bias = rnd(N, seed=84)
-    outs = []
-    for v in (5, 4):
-        L.gemm_variant(v)
-        C = torch.zeros(M, N, dtype=torch.bfloat16, device=dev())
-        L.gemm_nt(A, B, C, bias=bias, R1=R1, drop_p=0.25, drop_site=6, drop_seed=77, drop_first=True)
-        P = torch.zeros(M, N, dtype=torch.bfloat16, device=dev())
-        L.gemm_nt(A, B, P)
-        outs.append((C, P))
-    L.gemm_variant(2)
-    (c_s, p_s), (c_8, p_8) = outs
-    ref = A[:4096].float() @ B.float().t()
-    close(p_s[:4096], ref, torch.bfloat16, 'stream kernel head rows')
-    ref = A[-4096:].float() @ B.float().t()
-    close(p_s[-4096:], ref, torch.bfloat16, 'stream kernel tail rows')
-    assert torch.equal(p_s, p_8), 'same MFMA order per output element: the two kernels must agree bit for bit'
-    assert torch.equal(c_s, c_8)
+    M, Mp, dp, t = 16 * 301, 16 * 304, 64, torch.bfloat16
+    _, _, Wd, Wu, bd, bu, gamma, beta = _adapter_case(H, Mp, seed=120)
+    dy, v = rnd(Mp, H, dtype=t, seed=131), rnd(Mp, H, dtype=t, scale=1.5, seed=132)
+    zp = rnd(Mp, dp, dtype=t, seed=133)
+    WuT, WdT = Wu.t().contiguous(), Wd.t().contiguous()
+    vf = v.float()
+    mean = vf.mean(-1)
+    rstd = torch.rsqrt(vf.var(-1, unbiased=False) + 1e-12)
+    stats = torch.stack([mean, rstd], 1).contiguous()
+    mk = lambda c: torch.zeros(Mp, c, dtype=t, device=dev())
+    vec = lambda: torch.zeros(H, device=dev())
+    dv, dzp, dh = mk(H), mk(dp), mk(H)
+    dg, db, dbi = (vec() if 'g' in sums else None), (vec() if 'g' in sums else None), (vec() if 'b' in sums else None)
+    L.adapter_ln_bwd(dy, v, stats, gamma, None, zp, act, WuT, WdT, inner, dv, dzp, dh, dgamma=dg, dbeta=db, dbias=dbi, M=M,
+                     drop_p=drop, drop_site=9, drop_seed=4242)
+    assert float(dv[M:].abs().max()) == 0 and float(dh[M:].abs().max()) == 0        # rows >= M untouched
+    # the three launches
+    dv2, dzp2, dh2 = mk(H), mk(dp), mk(H)
+    dg2, db2, dbi2 = (vec() if 'g' in sums else None), (vec() if 'g' in sums else None), (vec() if 'b' in sums else None)
+    L.ln_bwd(dy, v, stats, gamma, dv2, dgamma=dg2, dbeta=db2, dbias=dbi2, M=M)
+    L.gemm_nt(dv2, WuT, dzp2, Pre=zp, dact=act)
+    L.gemm_nt(dzp2, WdT, dh2, R1=dv2 if inner else None, drop_p=drop, drop_site=9, drop_seed=4242)
+    close(dv[:M], dv2[:M], t, 'dv vs ln_bwd', rtol16=1e-2, atol16=1e-2)
+    close(dzp[:M], dzp2[:M], t, 'dzp vs 3 launches', rtol16=2e-2, atol16=2e-2)
+    if drop:
+        assert torch.equal(dh[:M] == 0, dh2[:M] == 0), 'dropout mask differs from the GEMM epilogue\'s'
+        assert 0.5 * drop < float((dh[:M] == 0).float().mean()) < 1.5 * drop
+    close(dh[:M], dh2[:M], t, 'dh vs 3 launches', rtol16=2e-2, atol16=3e-2)
+    for got, ref, nm in ((dg, dg2, 'dgamma'), (db, db2, 'dbeta'), (dbi, dbi2, 'dbias')):
+        if got is not None:
+            close(got, ref, torch.float32, nm, atol32=2e-2 * max(1.0, float(ref.abs().max())), rtol32=1e-2)
+    # torch fp32 on the same (bf16) inputs
+    xh = (vf[:M] - mean[:M, None]) * rstd[:M, None]
+    gq = dy[:M].float() * gamma
+    dv_r = rstd[:M, None] * (gq - gq.mean(-1, keepdim=True) - xh * (gq * xh).mean(-1, keepdim=True))
+    close(dv[:M], dv_r, t, 'dv vs torch')
+    pre = zp[:M].float().requires_grad_(True)
+    act_ref(pre, act).sum().backward()
+    dzp_r = (dv[:M].float() @ Wu.float()) * pre.grad
+    close(dzp[:M], dzp_r, t, 'dzp vs torch')
+    dh_r = dzp[:M].float() @ Wd.float() + (dv[:M].float() if inner else 0)
+    keep = dh[:M] != 0
+    scale = 1.0 / (1.0 - round(drop * 65536) / 65536) if drop else 1.0
+    close(dh[:M][keep], (dh_r * scale)[keep], t, 'dh vs torch')
+    if dbi is not None:
+        close(dbi, dv_r.sum(0), torch.float32, 'dbias vs torch', atol32=3e-2 * max(1.0, float(dv_r.sum(0).abs().max())), rtol32=2e-2)
+    if dg is not None:
+        close(dg, (dy[:M].float() * xh).sum(0), torch.float32, 'dgamma vs torch', atol32=1e-2 * float((dy[:M].float() * xh).sum(0).abs().max()), rtol32=1e-2)
+
+
+def test_adapter_ln_rejects():
+    from adapter4rec_amd import _lib as L
+    t = torch.bfloat16
+    a, o, Wd, Wu, bd, bu, gamma, beta = _adapter_case(192, 64)             # width without an instantiation
+    mk = lambda c: torch.zeros(64, c, dtype=t, device=dev())
+    with pytest.raises(RuntimeError):
+        L.adapter_ln_fwd(a, a, o, Wd, bd, Wu, bu, gamma, beta, 1e-12, 1, mk(64), mk(64), mk(192), mk(192), torch.zeros(64, 2, device=dev()))
+    a, o, Wd, Wu, bd, bu, gamma, beta = _adapter_case(128, 64)
+    third = mk(128)
+    with pytest.raises(RuntimeError):                                      # three distinct streamed tensors
+        L.adapter_ln_fwd(a, o, third, Wd, bd, Wu, bu, gamma, beta, 1e-12, 1, mk(64), mk(64), mk(128), mk(128), torch.zeros(64, 2, device=dev()))
 
 
 def test_gemm_tail_panels_split_launch():

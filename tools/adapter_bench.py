@@ -1,32 +1,63 @@
-"""Time a4r_adapter_fwd against the unfused sequence (down GEMM, up GEMM + residuals, LayerNorm) on one GPU."""
-import sys, torch
-sys.path.insert(0, '.')
+"""Time a4r_adapter_ln_fwd / _bwd against the three-launch forms they replace, at the training step's shape
+(M = 40 448 rows x H = 768, bottleneck 64, bf16), back to back on one GPU.  Prints us per launch and achieved TB/s on the
+algorithmic bytes ((4 H + 128) * 2 * M).  usage: python tools/adapter_bench.py [M] [H]"""
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from adapter4rec_amd import _lib as L
 
-def timeit(fn, n=30):
-    for _ in range(5): fn()
-    torch.cuda.synchronize()
-    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    a.record()
-    for _ in range(n): fn()
-    b.record(); torch.cuda.synchronize()
-    return a.elapsed_time(b) / n * 1e3
+M = int(sys.argv[1]) if len(sys.argv) > 1 else 40448
+H = int(sys.argv[2]) if len(sys.argv) > 2 else 768
+dev, t = 'cuda:0', torch.bfloat16
+g = torch.Generator(device=dev).manual_seed(1)
+r = lambda *s, sc=1.0: (torch.randn(*s, device=dev, generator=g) * sc)
+h, x = r(M, H).to(t), r(M, H).to(t)
+Wd, Wu = r(64, H, sc=0.05).to(t), r(H, 64, sc=0.05).to(t)
+WuT, WdT = Wu.t().contiguous(), Wd.t().contiguous()
+bd, bu, gam, bet = r(64, sc=0.1), r(H, sc=0.1), 1 + r(H, sc=0.1), r(H, sc=0.1)
+mk = lambda c: torch.zeros(M, c, dtype=t, device=dev)
+zp, z, v, y, st = mk(64), mk(64), mk(H), mk(H), torch.zeros(M, 2, device=dev)
+dy, dv, dzp, dh, dbias = r(M, H).to(t), mk(H), mk(64), mk(H), torch.zeros(H, device=dev)
 
-M, H = int(sys.argv[1]) if len(sys.argv) > 1 else 40448, 768
-d = 'cuda'
-g = torch.Generator(device=d).manual_seed(0)
-bf = torch.bfloat16
-h = torch.randn(M, H, device=d, generator=g).to(bf); x = torch.randn(M, H, device=d, generator=g).to(bf)
-Wd = (torch.randn(64, H, device=d, generator=g) * .05).to(bf); Wu = (torch.randn(H, 64, device=d, generator=g) * .05).to(bf)
-bd = torch.randn(64, device=d) * .1; bu = torch.randn(H, device=d) * .1
-gam = torch.rand(H, device=d) + .5; bet = torch.randn(H, device=d) * .1
-zp = torch.empty(M, 64, device=d, dtype=bf); z = torch.empty_like(zp)
-v = torch.empty(M, H, device=d, dtype=bf); y = torch.empty_like(v); st = torch.empty(M, 2, device=d)
-def fused(): L.adapter_fwd(h, x, Wd, bd, Wu, bu, gam, bet, 1e-12, 1, True, zp, z, v, y, st)
-def unfused():
+
+def fwd_fused():
+    L.adapter_ln_fwd(h, h, x, Wd, bd, Wu, bu, gam, bet, 1e-12, 1, zp, z, v, y, st)
+
+
+def fwd_three():
     L.gemm_nt(h, Wd, z, bias=bd, C2=zp, act=1)
     L.gemm_nt(z, Wu, v, bias=bu, R1=h, R2=x)
     L.ln_fwd(v, gam, bet, 1e-12, y, st)
-tf, tu = timeit(fused), timeit(unfused)
-byt = 4 * M * H * 2
-print(f"M={M} fused {tf:.1f} us ({byt / tf / 1e6:.2f} TB/s algorithmic)  unfused {tu:.1f} us")
+
+
+def bwd_fused():
+    L.adapter_ln_bwd(dy, v, st, gam, None, zp, 1, WuT, WdT, True, dv, dzp, dh, dbias=dbias, drop_p=0.1, drop_site=3, drop_seed=7)
+
+
+def bwd_three():
+    L.ln_bwd(dy, v, st, gam, dv, dbias=dbias)
+    L.gemm_nt(dv, WuT, dzp, Pre=zp, dact=1)
+    L.gemm_nt(dzp, WdT, dh, R1=dv, drop_p=0.1, drop_site=3, drop_seed=7)
+
+
+def timeit(f, n=50):
+    for _ in range(5):
+        f()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(n):
+        f()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / n * 1e3
+
+
+fwd_three()
+alg = (4 * H + 128) * 2 * M
+for name, f in (('fwd fused', fwd_fused), ('fwd 3 launches', fwd_three), ('bwd fused', bwd_fused), ('bwd 3 launches', bwd_three)):
+    us = timeit(f)
+    print(f'{name:16s} {us:8.1f} us   {alg / us / 1e6:6.2f} TB/s on the fused form\'s algorithmic bytes ({alg / 1e6:.0f} MB)')
