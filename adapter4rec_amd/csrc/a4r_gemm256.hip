@@ -18,6 +18,7 @@
 // Unit order in the instruction stream: A_lo(t), B_lo(t), B_hi(t), A_hi(t), A_lo(t+1), ...  (2 DMA instr each):
 //   phase 0 of tile u issues A_hi(u+1), phase 1 A_lo(u+2), phase 2 B_lo(u+2), phase 3 B_hi(u+2);
 //   "all but the newest 4 units have landed" (vmcnt(8)) before barrier k makes exactly the data of phase k+1 readable.
+#include <stdlib.h>
 #include "a4r_gemm_epi.h"
 
 #ifdef A4R_STAMP
@@ -61,7 +62,7 @@ A4R_DEV void glds16(const void* base, uint32_t voff, uint32_t lds_dst) {
 }
 
 template <typename TI, typename TO, int ACT, int DACT>
-__global__ void __launch_bounds__(512, 2) gemm_nt_256_kernel(const a4r_gemm_t p, int ntm, int ntn, uint32_t thr16, float keep_scale) {
+__global__ void __launch_bounds__(512, 2) gemm_nt_256_kernel(const a4r_gemm_t p, int ntm, int ntn, int gn, uint32_t thr16, float keep_scale) {
     constexpr int ROWB = 128;
     constexpr int KT = ROWB / (int)sizeof(TI);
     constexpr bool PH2 = false, STAG = false, PIPE = true, INTER = true;   // schedule variants measured on MI355X and rejected
@@ -70,18 +71,40 @@ __global__ void __launch_bounds__(512, 2) gemm_nt_256_kernel(const a4r_gemm_t p,
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 2, wn = wave & 3;
 
-    // persistent workgroups: virtual block id vb = blockIdx.x + i * gridDim.x (gridDim.x is a multiple of 8 whenever the
-    // grid is smaller than the tile count, so vb & 7 -- the XCD group -- is the same for every tile a workgroup visits);
-    // bijective XCD-aware remap: workgroups that share an XCD walk consecutive N-tiles of one 256-row A panel.
+    // persistent workgroups: virtual block id vb = blockIdx.x + i * gridDim.x; gridDim.x is a multiple of 8, so vb & 7 -- the XCD
+    // group under round-robin placement (speed only) -- is the same for every tile a workgroup visits, and t = vb >> 3 counts the
+    // tiles of that XCD.  Two bijective tile maps:
+    //   gn == 0: XCD x owns a contiguous chunk of the panel-major order (tile = tm * ntn + tn): its 32 workgroups walk all
+    //            N-tiles of ~32 / ntn row panels together;
+    //   gn  > 0: XCD x owns whole row panels (ntm / 8, the first ntm % 8 XCDs one more) and walks them in BANDS of gn N-tiles:
+    //            band, then panel, then N-tile inside the band.  The B tiles of a band (gn x 256 x K) stay in the XCD's 4 MiB
+    //            L2 for all its panels and every A panel is fetched by ONE XCD (once per band): for N = 3072, K = 768 the
+    //            un-banded map re-fetched the 4.7 MB of weights every round (PMC: 449 MB read per launch against 67).
     const int nt = ntm * ntn;
     const int q8 = nt >> 3, r8 = nt & 7;
-    auto tile_of = [&](int vb) {
-        const int xcd = vb & 7, j = vb >> 3;
-        return (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + j;
+    const int xcd = blockIdx.x & 7;
+    const int pq = ntm >> 3, pr = ntm & 7;
+    const int np_x = pq + (xcd < pr ? 1 : 0), p0_x = xcd * pq + (xcd < pr ? xcd : pr);      // banded map: this XCD's panels
+    const int len_x = gn > 0 ? np_x * ntn : (q8 + (xcd < r8 ? 1 : 0));                       // tiles of this XCD
+    const int base_x = xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8;
+    auto tile_of = [&](int t, int& tm_, int& tn_) {
+        if (gn > 0) {
+            const int nfull = ntn / gn, per_band = np_x * gn;               // full bands first, then the narrower last band
+            const int b = t / per_band < nfull ? t / per_band : nfull;
+            const int w = b < nfull ? gn : ntn - nfull * gn;
+            const int r = t - b * per_band;
+            tm_ = p0_x + r / w;
+            tn_ = b * gn + r % w;
+        } else {
+            const int Lt_ = base_x + t;
+            tm_ = Lt_ / ntn;
+            tn_ = Lt_ % ntn;
+        }
     };
-    int vb = blockIdx.x;
-    int Lt = tile_of(vb);
-    int tm = Lt / ntn, tn = Lt % ntn;
+    int t_loc = blockIdx.x >> 3;
+    if (t_loc >= len_x) return;
+    int tm, tn;
+    tile_of(t_loc, tm, tn);
 
     const int lda = p.lda, ldb = p.ldb;
     const int nk = p.K / KT;
@@ -387,12 +410,10 @@ __global__ void __launch_bounds__(512, 2) gemm_nt_256_kernel(const a4r_gemm_t p,
     if (stamp_iter == 0) { A4R_STAMP_AT(1) } else { A4R_STAMP_AT(5) }
 #endif
     const int tm_done = tm, tn_done = tn;
-    vb += gridDim.x;
-    const bool more = vb < nt;
+    t_loc += gridDim.x >> 3;
+    const bool more = t_loc < len_x;
     if (more) {
-        Lt = tile_of(vb);
-        tm = Lt / ntn;
-        tn = Lt % ntn;
+        tile_of(t_loc, tm, tn);
         Abase = reinterpret_cast<const char*>(Ap + (size_t)tm * 256 * lda);
         Bbase = reinterpret_cast<const char*>(Bp + (size_t)tn * 256 * ldb);
         A4R_PROLOGUE()
@@ -482,12 +503,36 @@ int a4r_cu_count() {
 
 namespace {
 
+int g_band = -1;        // A4R_GEMM_BAND: -1 = automatic, 0 = panel-major map always, n > 0 = bands of n N-tiles wherever the banded map applies
+
+// Band width of the banded tile map, or 0 for the panel-major map.  Banding needs whole panels per XCD without costing a round:
+// the slowest XCD must not run more rounds than the balanced map would.
+static int band_for(const a4r_gemm_t& g, int ntm, int ntn, int grid, int isz) {
+    if (g_band < 0) {
+        const char* e = getenv("A4R_GEMM_BAND");
+        g_band = e ? atoi(e) + 1000 : 999;                 // 999 = automatic (resolved per shape below)
+    }
+    if (g_band == 1000 || grid % 8) return 0;
+    const int wg_x = grid / 8;
+    const int max_len = (ntm / 8 + (ntm % 8 ? 1 : 0)) * ntn;
+    const int rounds_bal = (ntm * ntn + grid - 1) / grid, rounds_band = (max_len + wg_x - 1) / wg_x;
+    if (ntm < 8 || rounds_band > rounds_bal) return 0;
+    if (g_band > 1000) return g_band - 1000 < ntn ? g_band - 1000 : ntn;
+    // automatic: band only when the whole B operand does not sit in an XCD's L2 next to the streaming A panels
+    const double b_tile = 256.0 * g.K * isz;
+    if (b_tile * ntn <= 2.5e6) return 0;
+    int gn = (int)(2.5e6 / b_tile);
+    if (gn < 1) return 0;                                   // one B tile alone is too large: panel-major (A read once) is the better map
+    return gn < ntn ? gn : ntn;
+}
+
 template <typename TI, typename TO, int ACT, int DACT>
 int launch256(hipStream_t s, const a4r_gemm_t& g) {
     const int ntm = g.M / 256, ntn = g.N / 256;
     const int n_cu = a4r_cu_count();
-    const int grid = ntm * ntn < n_cu ? ntm * ntn : n_cu;
-    hipLaunchKernelGGL((gemm_nt_256_kernel<TI, TO, ACT, DACT>), dim3(grid), dim3(512), 0, s, g, ntm, ntn,
+    int grid = ntm * ntn < n_cu ? ((ntm * ntn + 7) & ~7) : n_cu;       // a multiple of 8 (workgroups past an XCD's tile count exit at once)
+    const int gn = band_for(g, ntm, ntn, grid, (int)sizeof(TI));
+    hipLaunchKernelGGL((gemm_nt_256_kernel<TI, TO, ACT, DACT>), dim3(grid), dim3(512), 0, s, g, ntm, ntn, gn,
                        a4r_thr16(g.drop_p), a4r_keep_scale(g.drop_p));
     return a4r_launch_status();
 }

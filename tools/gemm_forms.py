@@ -1,0 +1,54 @@
+#!/usr/bin/env python
+"""a4r_gemm_nt on the training step's shapes WITH the epilogue forms the step uses (plain + bias, residual + dropout,
+GELU + derivative output, * saved derivative), us and TF/s per launch; `vendor` = torch.nn.functional.linear (hipBLASLt) on the
+plain form for orientation (measurement only: the product never calls it).  A4R_GEMM_BAND=0 / n selects the tile map.
+usage: python tools/gemm_forms.py [M=40448]"""
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from adapter4rec_amd import _lib as L
+
+dev = torch.device('cuda:0')
+M = int(sys.argv[1]) if len(sys.argv) > 1 else 40448
+t = torch.bfloat16
+
+
+def t_us(fn, n=20):
+    for _ in range(5):
+        fn()
+    torch.cuda.synchronize()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(n):
+        fn()
+    b.record()
+    torch.cuda.synchronize()
+    return a.elapsed_time(b) / n * 1e3
+
+
+g = torch.Generator(device=dev).manual_seed(3)
+R = lambda *s, sc=1.0: (torch.randn(*s, device=dev, generator=g) * sc).to(t)
+rows = []
+for name, N, K, form in (('qkv', 2304, 768, 'plain'), ('attn-out', 768, 768, 'drop'), ('ffn-up', 3072, 768, 'gelu'), ('ffn-down', 768, 3072, 'drop'),
+                         ('d ffn-down', 3072, 768, 'dmul'), ('d ffn-up', 768, 3072, 'res'), ('d attn-out', 768, 768, 'plain'), ('d qkv', 768, 2304, 'res')):
+    A, B = R(M, K), R(N, K, sc=0.05)
+    C, C2, R1, Pre = (torch.empty(M, N, device=dev, dtype=t) for _ in range(4))
+    R1.normal_(); Pre.normal_()
+    bias = torch.zeros(N, device=dev)
+    if form == 'plain':
+        f = lambda: L.gemm_nt(A, B, C, bias=bias)
+    elif form == 'drop':
+        f = lambda: L.gemm_nt(A, B, C, bias=bias, drop_p=0.1, drop_site=3, drop_seed=11)
+    elif form == 'gelu':
+        f = lambda: L.gemm_nt(A, B, C, bias=bias, C2=C2, act=L.ACT_GELU, c2_deriv=True)
+    elif form == 'dmul':
+        f = lambda: L.gemm_nt(A, B, C, Pre=Pre, dact=L.DACT_MUL)
+    else:
+        f = lambda: L.gemm_nt(A, B, C, R1=R1)
+    ta = t_us(f)
+    bb = bias.to(t)
+    tv = t_us(lambda: torch.nn.functional.linear(A, B, bb))
+    fl = 2.0 * M * N * K
+    print(f'{name:11s} M={M} N={N:4d} K={K:4d} {form:5s}: a4r {ta:7.1f} us {fl / ta / 1e6:7.1f} TF/s | vendor plain {tv:7.1f} us {fl / tv / 1e6:7.1f} TF/s')
