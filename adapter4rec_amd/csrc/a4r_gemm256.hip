@@ -1,46 +1,54 @@
 // gemm_nt_256_kernel: the large-tile path of a4r_gemm_nt (M % 256 == 0, N % 256 == 0, K a multiple of one 128-byte K-tile).
 //
 // 256 x 256 output tile, 512 threads = 8 waves laid out 2 (M) x 4 (N); each wave owns 128 x 64 = 8 x 4 MFMA 16x16 tiles
-// (128 accumulator registers).  One workgroup per CU, two waves per SIMD.  Twice the flop per L2->LDS byte of the
-// 128 x 128 kernel, 64 MFMAs per 24 ds_read_b128 (was 32 per 16), and -- the point -- global loads stay IN FLIGHT ACROSS
-// BARRIERS: a K-tile (128 B of K per row) is cut into four 16 KiB "units"
-//     A_lo = tile rows {0-63, 128-191}   (what the two M-halves of waves read in phase 0)
-//     B_lo = B rows 64w + [0,32)         (phase 0)          B_hi = 64w + [32,64)   (phase 1)
-//     A_hi = tile rows {64-127, 192-255} (phase 2)
-// held in a 2-deep ring (2 x 64 KiB of LDS).  Each of the 4 phases of a K-tile is
-//     ds_read this phase's fragments | s_waitcnt vmcnt(8) lgkmcnt(0) | s_barrier | issue ONE unit (2 LDS-DMA per wave) | 16 MFMAs
-// The unit issued in a phase overwrites data whose last reader finished before the barrier just passed (WAR), and is
-// first read five phases later, after a counted wait + barrier has retired it (RAW): every unit has ~5 phases
-// (~1.5 us) to arrive and the matrix pipe never waits for memory in steady state.
-// LDS-DMA is issued through inline asm so that hipcc neither counts it nor inserts vmcnt(0) in front of the ds_reads
-// (it cannot prove the DMA target and the fragment reads disjoint inside one array); all vmcnt waits are explicit.
+// (128 accumulator registers).  One workgroup per CU, two waves per SIMD (wave w and w + 4).
 //
-// Unit order in the instruction stream: A_lo(t), B_lo(t), B_hi(t), A_hi(t), A_lo(t+1), ...  (2 DMA instr each):
-//   phase 0 of tile u issues A_hi(u+1), phase 1 A_lo(u+2), phase 2 B_lo(u+2), phase 3 B_hi(u+2);
-//   "all but the newest 4 units have landed" (vmcnt(8)) before barrier k makes exactly the data of phase k+1 readable.
+// Data movement.  A K-tile (128 B of K per row) is cut into four 16 KiB "units"
+//     A_lo = tile rows {0-63, 128-191}   (the upper 64 rows of both M-halves of waves)      A_hi = rows {64-127, 192-255}
+//     B_lo = B rows 64w + [0,32)                                                             B_hi = 64w + [32,64)
+// held in a 2-deep ring (2 x 64 KiB of LDS) filled by LDS-DMA (global_load_lds_dwordx4 through inline asm: hipcc neither counts
+// it nor drains it) that stays IN FLIGHT ACROSS BARRIERS: every phase issues ONE unit (2 DMA per wave) and waits with a COUNTED
+// vmcnt(8) -- all but the newest four units have landed -- so a unit has ~5 phases (>1 K-tile) to arrive.  Stream order
+// A_lo(t), B_lo(t), B_hi(t), A_hi(t), A_lo(t+1), ...; the XOR swizzle c ^ ((r >> 1) & 7) is applied on the DMA SOURCE address and
+// on the fragment read (the LDS image itself is lane-linear), which makes the ds_read_b128 of the fragments conflict-free.
+//
+// Schedule: a PING-PONG between the two waves of every SIMD.  A K-tile is four phases, one output quadrant of the wave each:
+//     (A_lo,B_lo) (A_lo,B_hi) (A_hi,B_hi) (A_hi,B_lo)
+// and a phase is, for every wave, the same straight code
+//     LOAD segment : ds_read this phase's new fragments (12 / 4 / 8 / 0 reads) | issue one unit's DMA | s_waitcnt vmcnt(8)
+//     s_barrier | s_waitcnt lgkmcnt(0) | s_setprio 1 | 16 MFMA | s_setprio 0 | s_barrier
+// Waves 4-7 execute ONE extra s_barrier before the loop (waves 0-3 one after it), so the two halves run exactly one barrier
+// apart: while waves 0-3 are in their MFMA segment, waves 4-7 are in their LOAD segment and vice versa.  Each SIMD's matrix
+// pipe therefore always has exactly ONE wave issuing MFMAs back to back (no arbitration between lock-step partners, which
+// cost the previous all-waves-in-phase schedule half of the pipe: 46 % MFMA duty), and a wave's LDS latency is covered by
+// its PARTNER's MFMAs, so fragments need no second register set (64 instead of 96 fragment registers).
+// Hazards (reads of phase p are issued in LOAD_p; the other half runs one barrier later):
+//   RAW  a unit read in phase p is retired by every wave's counted wait in LOAD_(p-1): both halves execute that wait before a
+//        barrier the reader passes before LOAD_p.  Phase 0 reads A_lo, B_lo (retired in phase 3 of the previous K-tile),
+//        phase 1 B_hi (phase 0), phase 2 A_hi (phase 1).
+//   WAR  a slot is re-filled no earlier than two phases after its last read: phase 0 issues B_hi(t+1) (slot last read in phase 1
+//        of t-1), phase 1 A_hi(t+1) (phase 2 of t-1), phase 2 A_lo(t+2) (phase 0 of t), phase 3 B_lo(t+2) (phase 0 of t).
 #include <stdlib.h>
 #include "a4r_gemm_epi.h"
 
 #ifdef A4R_STAMP
-// diagnostic build only (-DA4R_STAMP): s_memtime stamps of workgroup phases, first two tiles of every workgroup; never read by the kernel
-__device__ unsigned long long g_a4r_stamps[1024 * 8];
+// diagnostic build only (-DA4R_STAMP, tools/gemm_stamps.py): (s_memtime, s_memrealtime) of wave 0 of every workgroup at the start and the
+// end of the K loop of its first four output tiles -> shader cycles per K loop and the clock the chip holds (cycles / (realtime ticks / 100 MHz)).
+// Written to a buffer of its own, never read by the kernel.
+__device__ unsigned long long g_a4r_stamps[256 * 4 * 4];
 extern "C" int a4r_debug_stamps(unsigned long long* host_out) {
     return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_a4r_stamps), sizeof(g_a4r_stamps)) == hipSuccess ? 0 : -2;
 }
-#define A4R_STAMP_AT(i_) if (stamp_iter < 2 && tid == 0) g_a4r_stamps[blockIdx.x * 8 + (i_)] = __builtin_amdgcn_s_memtime();
-#ifdef A4R_STAMP2
-__device__ unsigned long long g_a4r_barstamps[256 * 16 * 8 * 3];
-extern "C" int a4r_debug_barstamps(unsigned long long* host_out) {
-    return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_a4r_barstamps), sizeof(g_a4r_barstamps)) == hipSuccess ? 0 : -2;
-}
-#define A4R_BAR_INC ++bar_idx_;
+#define A4R_LOOP_STAMP(k_)                                                                                                   \
+    if (tid == 0 && tile_no_ < 4 && blockIdx.x < 256) {                                                                     \
+        g_a4r_stamps[(blockIdx.x * 4 + tile_no_) * 4 + 2 * (k_)] = __builtin_amdgcn_s_memtime();                             \
+        g_a4r_stamps[(blockIdx.x * 4 + tile_no_) * 4 + 2 * (k_) + 1] = __builtin_amdgcn_s_memrealtime();                     \
+    }
 #else
-#define A4R_BAR_INC
+#define A4R_LOOP_STAMP(k_)
 #endif
-#else
-#define A4R_STAMP_AT(i_)
-#define A4R_BAR_INC
-#endif
+#define A4R_ST(k_)
+#define A4R_ST_NEXT
 
 namespace {
 
@@ -65,7 +73,6 @@ template <typename TI, typename TO, int ACT, int DACT>
 __global__ void __launch_bounds__(512, 2) gemm_nt_256_kernel(const a4r_gemm_t p, int ntm, int ntn, int gn, uint32_t thr16, float keep_scale) {
     constexpr int ROWB = 128;
     constexpr int KT = ROWB / (int)sizeof(TI);
-    constexpr bool PH2 = false, STAG = false, PIPE = true, INTER = true;   // schedule variants measured on MI355X and rejected
     __shared__ __attribute__((aligned(16))) char lds[8 * UNIT_BYTES];      // [buffer 2][unit 4][128 rows][128 B]
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -136,43 +143,7 @@ __global__ void __launch_bounds__(512, 2) gemm_nt_256_kernel(const a4r_gemm_t p,
         glds16(src_, off_[0], dst_);                                                                                 \
         glds16(src_, off_[1], dst_ + 1024u);                                                                         \
     }
-#define A4R_WAIT_BARRIER(steady_) A4R_WAIT_BARRIER_N(steady_, 8)
-#ifdef A4R_STAMP2
-    // diagnostic: per-wave s_memtime at [before the waitcnt | before s_barrier | after it] of 16 consecutive barriers of the second tile
-    int bar_idx_ = 0;
-#define A4R_BAR_STAMP(k_)                                                                                             \
-    if (stamp_iter == 1 && bar_idx_ >= 64 && bar_idx_ < 80 && lane == 0)                                             \
-        g_a4r_barstamps[((blockIdx.x * 16 + (bar_idx_ - 64)) * 8 + wave) * 3 + (k_)] = __builtin_amdgcn_s_memtime();
-#else
-#define A4R_BAR_STAMP(k_)
-#endif
-#define A4R_WAIT_BARRIER_N(steady_, n_)                                                                              \
-    A4R_BAR_STAMP(0)                                                                                                 \
-    if (steady_) asm volatile("s_waitcnt vmcnt(" #n_ ") lgkmcnt(0)" ::: "memory");                                   \
-    else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");                                                 \
-    A4R_BAR_STAMP(1)                                                                                                 \
-    if (!(A4R_ABL_ & 8)) __builtin_amdgcn_s_barrier();                                                               \
-    asm volatile("" ::: "memory");                                                                                   \
-    A4R_BAR_STAMP(2)                                                                                                 \
-    A4R_BAR_INC
-
-    // A phase after its barrier = {issue one unit's LDS-DMA} + {16 MFMAs}.  The two waves that share a SIMD (w and w + 4)
-    // run them in OPPOSITE order (STAG): while one wave spends ~200 cycles issuing DMA the other owns the matrix pipe,
-    // then they swap -- lockstep partners otherwise issue DMA together and fight for the pipe together.
-    const bool mfma_first = STAG && wave >= 4;
-#define A4R_MFMA16(ax_, bx_, m0_, n0_)                                                                \
-    _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                                  \
-        _Pragma("unroll") for (int mi = 0; mi < 4; ++mi)                                              \
-            _Pragma("unroll") for (int ni = 0; ni < 2; ++ni)                                          \
-                Mma<TI>::mma(bx_[ni][ks], ax_[mi][ks], acc[(m0_) + mi][(n0_) + ni]);
-#define A4R_PHASE_BODY(issue_, bx_, m0_, n0_)                                                         \
-    if (!mfma_first) { issue_ }                                                                       \
-    __builtin_amdgcn_sched_barrier(0);                                                                \
-    A4R_MFMA16(af, bx_, m0_, n0_)                                                                     \
-    __builtin_amdgcn_sched_barrier(0);                                                                \
-    if (mfma_first) { issue_ }
-    // Software-pipelined phase (PIPE): the fragments of phase k+1 are requested right after barrier k -- which is what
-    // makes them readable -- and arrive while the 16 MFMAs of phase k run on operands read one phase earlier.
+    // LOAD-segment pieces and the MFMA segment of a phase (see the header).  sched_barrier(0) pins the order hipcc emits.
 #define A4R_RD_A(dst_, buf_, unit_)                                                                   \
     _Pragma("unroll") for (int mi = 0; mi < 4; ++mi)                                                  \
         _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                              \
@@ -181,40 +152,50 @@ __global__ void __launch_bounds__(512, 2) gemm_nt_256_kernel(const a4r_gemm_t p,
     _Pragma("unroll") for (int ni = 0; ni < 2; ++ni)                                                  \
         _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                              \
             dst_[ni][ks] = *reinterpret_cast<const uint4*>(lds + ((buf_) * 4 + (unit_)) * UNIT_BYTES + b_off[ni][ks]);
-    // INTER: the same phase with the LDS reads spread between the MFMAs (one read per MFMA pair, order pinned by sched_barrier):
-    // an MFMA holds the vector issue port for 8 of its 16 cycles, so the reads issue in its shadow instead of in front of it.
-#define A4R_MFMA_J(ax_, bx_, m0_, n0_, j_) \
-    Mma<TI>::mma(bx_[(j_) & 1][(j_) >> 3], ax_[((j_) >> 1) & 3][(j_) >> 3], acc[(m0_) + (((j_) >> 1) & 3)][(n0_) + ((j_) & 1)]);
-#define A4R_RD_I(dst_, off_, buf_, unit_, r_) \
-    dst_[(r_) >> 1][(r_) & 1] = *reinterpret_cast<const uint4*>(lds + ((buf_) * 4 + (unit_)) * UNIT_BYTES + off_[(r_) >> 1][(r_) & 1]);
-#define A4R_PHASE_I(steady_, issue_, nr_, dst_, off_, buf_, unit_, ax_, bx_, m0_, n0_)                 \
-    A4R_WAIT_BARRIER(steady_)                                                                         \
-    _Pragma("unroll") for (int k_ = 0; k_ < 8; ++k_) {                                                \
-        if (!(A4R_ABL & 2)) { A4R_MFMA_J(ax_, bx_, m0_, n0_, 2 * k_) A4R_MFMA_J(ax_, bx_, m0_, n0_, 2 * k_ + 1) } \
-        if (k_ == 0 && !(A4R_ABL & 1)) { issue_ }   /* the two LDS-DMA of this phase, behind the first MFMA pair */ \
-        if (k_ >= 1 && k_ <= 4 && !(A4R_ABL & 4)) { /* all reads in the first half: the last 6 MFMAs cover their latency */ \
-            if ((nr_) == 8) { A4R_RD_I(dst_, off_, buf_, unit_, 2 * (k_ - 1)) A4R_RD_I(dst_, off_, buf_, unit_, 2 * (k_ - 1) + 1) } \
-            else { A4R_RD_I(dst_, off_, buf_, unit_, k_ - 1) }                                        \
-        }                                                                                             \
-        __builtin_amdgcn_sched_barrier(0);                                                            \
-    }
-    // cond_ (is there a next K-tile?) is deliberately ignored: on the last K-tile the reads fetch stale LDS bytes into registers
-    // that the next output tile re-reads anyway -- harmless, and it keeps ONE copy of each phase (two copies spilled).
-#define A4R_PHASE_I_A(steady_, issue_, cond_, dst_, buf_, unit_, ax_, bx_, m0_, n0_)                   \
-    A4R_PHASE_I(steady_, issue_, 8, dst_, a_off, buf_, unit_, ax_, bx_, m0_, n0_)
-#define A4R_PHASE_I_B(steady_, issue_, cond_, dst_, buf_, unit_, ax_, bx_, m0_, n0_)                   \
-    A4R_PHASE_I(steady_, issue_, 4, dst_, b_off, buf_, unit_, ax_, bx_, m0_, n0_)
+#define A4R_MFMA16(ax_, bx_, m0_, n0_)                                                                \
+    _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                                  \
+        _Pragma("unroll") for (int mi = 0; mi < 4; ++mi)                                              \
+            _Pragma("unroll") for (int ni = 0; ni < 2; ++ni)                                          \
+                Mma<TI>::mma(bx_[ni][ks], ax_[mi][ks], acc[(m0_) + mi][(n0_) + ni]);
+    // full_: the units this phase's counted wait leaves in flight were all issued -> vmcnt(8) (four units may stay in flight);
+    // else the shorter count tail_ of the end of the K range.  ONE copy of every phase (duplicated phase bodies spill).
 #ifndef A4R_ABL
-#define A4R_ABL 0
+#define A4R_ABL 0          /* timing-only diagnostic builds (tools/gemm_abl.sh): 1 no DMA, 2 no MFMA, 4 no fragment reads, 8 no barriers, 16 no setprio */
 #endif
-#define A4R_ABL_ A4R_ABL
-#define A4R_PIPE_PHASE(steady_, issue_, reads_, ax_, bx_, m0_, n0_)                                   \
-    A4R_WAIT_BARRIER(steady_)                                                                         \
-    if (!(A4R_ABL & 1)) { issue_ }                                                                    \
+#define A4R_PHASE(reads_, issue_, full_, tail_, ax_, bx_, m0_, n0_)                                    \
+    A4R_ST(0)                                                                                         \
     if (!(A4R_ABL & 4)) { reads_ }                                                                    \
+    if (!(A4R_ABL & 1)) { issue_ }                                                                    \
     __builtin_amdgcn_sched_barrier(0);                                                                \
+    A4R_ST(1)                                                                                         \
+    if (full_) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");                                       \
+    else asm volatile("s_waitcnt vmcnt(" tail_ ")" ::: "memory");                                     \
+    A4R_ST(2)                                                                                         \
+    if (!(A4R_ABL & 8)) __builtin_amdgcn_s_barrier();                                                 \
+    asm volatile("" ::: "memory");                                                                    \
+    __builtin_amdgcn_sched_barrier(0);                                                                \
+    A4R_ST(3)                                                                                         \
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                \
+    __builtin_amdgcn_sched_barrier(0);                                                                \
+    A4R_ST(4)                                                                                         \
+    if (!(A4R_ABL & 16)) __builtin_amdgcn_s_setprio(1);                                               \
     if (!(A4R_ABL & 2)) { A4R_MFMA16(ax_, bx_, m0_, n0_) }                                            \
-    __builtin_amdgcn_sched_barrier(0);
+    if (!(A4R_ABL & 16)) __builtin_amdgcn_s_setprio(0);                                               \
+    __builtin_amdgcn_sched_barrier(0);                                                                \
+    A4R_ST(5)                                                                                         \
+    if (!(A4R_ABL & 8)) __builtin_amdgcn_s_barrier();                                                 \
+    asm volatile("" ::: "memory");                                                                    \
+    A4R_ST(6)                                                                                         \
+    A4R_ST_NEXT
+    // K-tile u from ring buffer buf_ (compile-time).  n1 = a K-tile u+1 exists, n2 = u+2 exists (A4R_ISSUE skips what does not).
+#define A4R_KTILE(u_, buf_)                                                                                                         \
+    {                                                                                                                               \
+        const bool n1 = (u_) + 1 < nk, n2 = (u_) + 2 < nk;                                                                          \
+        A4R_PHASE(A4R_RD_B(b0, buf_, U_BLO) A4R_RD_A(af, buf_, U_ALO), A4R_ISSUE(U_BHI, (u_) + 1, Bbase, offB_hi), n1, "2", af, b0, 0, 0) \
+        A4R_PHASE(A4R_RD_B(b1, buf_, U_BHI), A4R_ISSUE(U_AHI, (u_) + 1, Abase, offA_hi), n1, "0", af, b1, 0, 2)                     \
+        A4R_PHASE(A4R_RD_A(af, buf_, U_AHI), A4R_ISSUE(U_ALO, (u_) + 2, Abase, offA_lo), n2, "4", af, b1, 4, 2)                     \
+        A4R_PHASE(, A4R_ISSUE(U_BLO, (u_) + 2, Bbase, offB_lo), n2, "4", af, b0, 4, 0)                                              \
+    }
 
     f32x4_t acc[8][4];
 
@@ -236,167 +217,42 @@ __global__ void __launch_bounds__(512, 2) gemm_nt_256_kernel(const a4r_gemm_t p,
             b_off[ni][ks] = row * ROWB + ((ch ^ ((row >> 1) & 7)) << 4);
         }
 
-    // ---- prologue of a tile: 7 units in stream order (tiles 0 and 1 of the ring)
+    // ---- prologue of a tile: the first 6 units in stream order (K-tile 0 and A_lo, B_lo of K-tile 1)
 #define A4R_PROLOGUE()                          \
     A4R_ISSUE(U_ALO, 0, Abase, offA_lo)         \
     A4R_ISSUE(U_BLO, 0, Bbase, offB_lo)         \
     A4R_ISSUE(U_BHI, 0, Bbase, offB_hi)         \
     A4R_ISSUE(U_AHI, 0, Abase, offA_hi)         \
     A4R_ISSUE(U_ALO, 1, Abase, offA_lo)         \
-    if constexpr (PIPE) {                       \
-        A4R_ISSUE(U_BHI, 1, Bbase, offB_hi)     \
-        A4R_ISSUE(U_BLO, 1, Bbase, offB_lo)     \
-    } else {                                    \
-        A4R_ISSUE(U_BLO, 1, Bbase, offB_lo)     \
-        A4R_ISSUE(U_BHI, 1, Bbase, offB_hi)     \
-    }
+    A4R_ISSUE(U_BLO, 1, Bbase, offB_lo)
     A4R_PROLOGUE()
-    if (nk >= 2) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");        // 7 units issued: A_lo(0), B_lo(0) have landed
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                  // single K-tile (adapter up-projection, K = 64): 4 units
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     const GemmEpi<TO> epi = make_epi<TO>(p, thr16, keep_scale);
 
 #ifdef A4R_STAMP
-  int stamp_iter = 0;
-  A4R_STAMP_AT(0)
+  int tile_no_ = 0;
 #endif
   for (;;) {                                              // ---- tiles of this workgroup
-    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_s_barrier();                         // every wave's prologue units have landed (vmcnt(0) above / below)
     asm volatile("" ::: "memory");
-#ifdef A4R_STAMP
-    if (stamp_iter == 1) { A4R_STAMP_AT(4) }
-#endif
-#ifdef A4R_STAMP2
-    bar_idx_ = 0;
-#endif
 #pragma unroll
     for (int mi = 0; mi < 8; ++mi)
 #pragma unroll
         for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
     uint4 af[4][2], b0[2][2], b1[2][2];
-    if constexpr (PIPE) {
-      // Odd K-tiles walk their quadrants with the roles of B_lo / B_hi swapped (and are streamed in that order), so the
-      // operands of the next phase always land in registers no MFMA of the current phase reads:
-      //   even: (A_lo,B_lo) (A_lo,B_hi) (A_hi,B_hi) (A_hi,B_lo)      odd: (A_lo,B_hi) (A_lo,B_lo) (A_hi,B_lo) (A_hi,B_hi)
-      uint4 a1[4][2];
-      A4R_RD_A(af, 0, U_ALO)
-      A4R_RD_B(b0, 0, U_BLO)
-      if constexpr (INTER) {
-      for (int u = 0; u < nk; u += 2) {
-        {
-            const bool steady = (u + 2 < nk);
-            A4R_PHASE_I_B(steady, A4R_ISSUE(U_AHI, u + 1, Abase, offA_hi), true, b1, 0, U_BHI, af, b0, 0, 0)
-            A4R_PHASE_I_A(steady, A4R_ISSUE(U_ALO, u + 2, Abase, offA_lo), true, a1, 0, U_AHI, af, b1, 0, 2)
-            A4R_PHASE_I_A(steady, A4R_ISSUE(U_BLO, u + 2, Bbase, offB_lo), true, af, 1, U_ALO, a1, b1, 4, 2)
-            A4R_PHASE_I_B(steady, A4R_ISSUE(U_BHI, u + 2, Bbase, offB_hi), true, b1, 1, U_BHI, a1, b0, 4, 0)
-        }
-        if (u + 1 < nk) {
-            const bool steady = (u + 3 < nk);
-            A4R_PHASE_I_B(steady, A4R_ISSUE(U_AHI, u + 2, Abase, offA_hi), true, b0, 1, U_BLO, af, b1, 0, 2)
-            A4R_PHASE_I_A(steady, A4R_ISSUE(U_ALO, u + 3, Abase, offA_lo), true, a1, 1, U_AHI, af, b0, 0, 0)
-            A4R_PHASE_I_A(steady, A4R_ISSUE(U_BHI, u + 3, Bbase, offB_hi), true, af, 0, U_ALO, a1, b0, 4, 0)
-            A4R_PHASE_I_B(steady, A4R_ISSUE(U_BLO, u + 3, Bbase, offB_lo), true, b0, 0, U_BLO, a1, b1, 4, 2)
-        }
-      }
-      } else
-      for (int u = 0; u < nk; u += 2) {
-        {
-            const bool steady = (u + 2 < nk), nxt = (u + 1 < nk);
-            A4R_PIPE_PHASE(steady, A4R_ISSUE(U_AHI, u + 1, Abase, offA_hi), A4R_RD_B(b1, 0, U_BHI), af, b0, 0, 0)
-            A4R_PIPE_PHASE(steady, A4R_ISSUE(U_ALO, u + 2, Abase, offA_lo), A4R_RD_A(a1, 0, U_AHI), af, b1, 0, 2)
-            A4R_PIPE_PHASE(steady, A4R_ISSUE(U_BLO, u + 2, Bbase, offB_lo), if (nxt) { A4R_RD_A(af, 1, U_ALO) }, a1, b1, 4, 2)
-            A4R_PIPE_PHASE(steady, A4R_ISSUE(U_BHI, u + 2, Bbase, offB_hi), if (nxt) { A4R_RD_B(b1, 1, U_BHI) }, a1, b0, 4, 0)
-        }
-        if (u + 1 < nk) {
-            const bool steady = (u + 3 < nk), nxt = (u + 2 < nk);
-            A4R_PIPE_PHASE(steady, A4R_ISSUE(U_AHI, u + 2, Abase, offA_hi), A4R_RD_B(b0, 1, U_BLO), af, b1, 0, 2)
-            A4R_PIPE_PHASE(steady, A4R_ISSUE(U_ALO, u + 3, Abase, offA_lo), A4R_RD_A(a1, 1, U_AHI), af, b0, 0, 0)
-            A4R_PIPE_PHASE(steady, A4R_ISSUE(U_BHI, u + 3, Bbase, offB_hi), if (nxt) { A4R_RD_A(af, 0, U_ALO) }, a1, b0, 4, 0)
-            A4R_PIPE_PHASE(steady, A4R_ISSUE(U_BLO, u + 3, Bbase, offB_lo), if (nxt) { A4R_RD_B(b0, 0, U_BLO) }, a1, b1, 4, 2)
-        }
-      }
-    } else if constexpr (PH2) {
-      // Two phases of 32 MFMAs per K-tile (half the barriers of the 4-phase form):
-      //   phase A: read A_lo, B_lo, B_hi | wait | barrier | issue A_hi(u+1)                      | quadrants (0,0), (0,1)
-      //   phase B: read A_hi             | wait | barrier | issue A_lo, B_lo, B_hi of tile u+2   | quadrants (1,1), (1,0)
-      // stream order ... A_hi(u) | A_lo B_lo B_hi (u+1) | A_hi(u+1) | ...: phase A needs A_hi(u) => the 3 newest units may
-      // be in flight (vmcnt(6)); phase B needs the three units of tile u+1 => only A_hi(u+1) may be (vmcnt(2)).
-      for (int u = 0; u < nk; ++u) {
-        const char* buf = lds + (u & 1) * 4 * UNIT_BYTES;
-        const bool steady = (u + 1 < nk);
-#pragma unroll
-        for (int mi = 0; mi < 4; ++mi)
-#pragma unroll
-            for (int ks = 0; ks < 2; ++ks) af[mi][ks] = *reinterpret_cast<const uint4*>(buf + U_ALO * UNIT_BYTES + a_off[mi][ks]);
-#pragma unroll
-        for (int ni = 0; ni < 2; ++ni)
-#pragma unroll
-            for (int ks = 0; ks < 2; ++ks) {
-                b0[ni][ks] = *reinterpret_cast<const uint4*>(buf + U_BLO * UNIT_BYTES + b_off[ni][ks]);
-                b1[ni][ks] = *reinterpret_cast<const uint4*>(buf + U_BHI * UNIT_BYTES + b_off[ni][ks]);
-            }
-        A4R_WAIT_BARRIER_N(steady, 6)
-        A4R_ISSUE(U_AHI, u + 1, Abase, offA_hi)
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-            for (int mi = 0; mi < 4; ++mi)
-#pragma unroll
-                for (int ni = 0; ni < 2; ++ni) {
-                    Mma<TI>::mma(b0[ni][ks], af[mi][ks], acc[mi][ni]);
-                    Mma<TI>::mma(b1[ni][ks], af[mi][ks], acc[mi][2 + ni]);
-                }
-#pragma unroll
-        for (int mi = 0; mi < 4; ++mi)
-#pragma unroll
-            for (int ks = 0; ks < 2; ++ks) af[mi][ks] = *reinterpret_cast<const uint4*>(buf + U_AHI * UNIT_BYTES + a_off[mi][ks]);
-        A4R_WAIT_BARRIER_N(steady, 2)
-        A4R_ISSUE(U_ALO, u + 2, Abase, offA_lo)
-        A4R_ISSUE(U_BLO, u + 2, Bbase, offB_lo)
-        A4R_ISSUE(U_BHI, u + 2, Bbase, offB_hi)
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-            for (int mi = 0; mi < 4; ++mi)
-#pragma unroll
-                for (int ni = 0; ni < 2; ++ni) {
-                    Mma<TI>::mma(b1[ni][ks], af[mi][ks], acc[4 + mi][2 + ni]);
-                    Mma<TI>::mma(b0[ni][ks], af[mi][ks], acc[4 + mi][ni]);
-                }
-      }
-    } else
-    for (int u = 0; u < nk; ++u) {
-        const char* buf = lds + (u & 1) * 4 * UNIT_BYTES;
-        const bool steady = (u + 2 < nk);
-        // ---------------- phase 0: quadrant (rows 0-63, cols 0-31)
-#pragma unroll
-        for (int mi = 0; mi < 4; ++mi)
-#pragma unroll
-            for (int ks = 0; ks < 2; ++ks) af[mi][ks] = *reinterpret_cast<const uint4*>(buf + U_ALO * UNIT_BYTES + a_off[mi][ks]);
-#pragma unroll
-        for (int ni = 0; ni < 2; ++ni)
-#pragma unroll
-            for (int ks = 0; ks < 2; ++ks) b0[ni][ks] = *reinterpret_cast<const uint4*>(buf + U_BLO * UNIT_BYTES + b_off[ni][ks]);
-        A4R_WAIT_BARRIER(steady)
-        A4R_PHASE_BODY(A4R_ISSUE(U_AHI, u + 1, Abase, offA_hi), b0, 0, 0)
-        // ---------------- phase 1: (rows 0-63, cols 32-63)
-#pragma unroll
-        for (int ni = 0; ni < 2; ++ni)
-#pragma unroll
-            for (int ks = 0; ks < 2; ++ks) b1[ni][ks] = *reinterpret_cast<const uint4*>(buf + U_BHI * UNIT_BYTES + b_off[ni][ks]);
-        A4R_WAIT_BARRIER(steady)
-        A4R_PHASE_BODY(A4R_ISSUE(U_ALO, u + 2, Abase, offA_lo), b1, 0, 2)
-        // ---------------- phase 2: (rows 64-127, cols 32-63)
-#pragma unroll
-        for (int mi = 0; mi < 4; ++mi)
-#pragma unroll
-            for (int ks = 0; ks < 2; ++ks) af[mi][ks] = *reinterpret_cast<const uint4*>(buf + U_AHI * UNIT_BYTES + a_off[mi][ks]);
-        A4R_WAIT_BARRIER(steady)
-        A4R_PHASE_BODY(A4R_ISSUE(U_BLO, u + 2, Bbase, offB_lo), b1, 4, 2)
-        // ---------------- phase 3: (rows 64-127, cols 0-31), operands already in registers
-        A4R_WAIT_BARRIER(steady)
-        A4R_PHASE_BODY(A4R_ISSUE(U_BHI, u + 2, Bbase, offB_hi), b0, 4, 0)
+    A4R_LOOP_STAMP(0)
+    if (wave >= 4 && !(A4R_ABL & 8)) __builtin_amdgcn_s_barrier();          // waves 4-7 run one barrier behind waves 0-3 from here on
+    for (int u = 0; u < nk; u += 2) {
+        A4R_KTILE(u, 0)
+        if (u + 1 < nk) A4R_KTILE(u + 1, 1)
     }
+    if (wave < 4 && !(A4R_ABL & 8)) __builtin_amdgcn_s_barrier();           // re-align: all LDS reads of this tile are complete, the ring is free
+    asm volatile("" ::: "memory");
+    A4R_LOOP_STAMP(1)
+#ifdef A4R_STAMP
+    ++tile_no_;
+#endif
 
     // ---- epilogue straight from the accumulators.  The MFMA operands are swapped (B fragment first), so the tile is
     // produced transposed: a lane's 4 registers of tile (mi, ni) are 4 CONSECUTIVE COLUMNS of one output row,
@@ -406,9 +262,6 @@ __global__ void __launch_bounds__(512, 2) gemm_nt_256_kernel(const a4r_gemm_t p,
     // tile with one workgroup per CU).
     // every LDS read of this tile completed before the last barrier: the ring is free, so the NEXT tile's first units
     // are put in flight now and land while this tile's accumulators are being written out.
-#ifdef A4R_STAMP
-    if (stamp_iter == 0) { A4R_STAMP_AT(1) } else { A4R_STAMP_AT(5) }
-#endif
     const int tm_done = tm, tn_done = tn;
     t_loc += gridDim.x >> 3;
     const bool more = t_loc < len_x;
@@ -460,30 +313,16 @@ __global__ void __launch_bounds__(512, 2) gemm_nt_256_kernel(const a4r_gemm_t p,
     A4R_EPI_ROW(0) A4R_EPI_ROW(1) A4R_EPI_ROW(2) A4R_EPI_ROW(3) A4R_EPI_ROW(4) A4R_EPI_ROW(5) A4R_EPI_ROW(6) A4R_EPI_ROW(7)
 #undef A4R_EPI_ROW
 #undef A4R_EPI_PAIR
-#ifdef A4R_STAMP
-    if (stamp_iter == 0) { A4R_STAMP_AT(2) } else { A4R_STAMP_AT(6) }
-#endif
     if (!more) break;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // stores of this tile + prologue loads of the next (vmcnt counts both)
-#ifdef A4R_STAMP
-    if (stamp_iter == 0) { A4R_STAMP_AT(3) }
-    ++stamp_iter;
-#endif
   }
 #undef A4R_PROLOGUE
 #undef A4R_ISSUE
-#undef A4R_WAIT_BARRIER
-#undef A4R_WAIT_BARRIER_N
-#undef A4R_PHASE_BODY
-#undef A4R_MFMA16
 #undef A4R_RD_A
 #undef A4R_RD_B
-#undef A4R_PIPE_PHASE
-#undef A4R_PHASE_I
-#undef A4R_PHASE_I_A
-#undef A4R_PHASE_I_B
-#undef A4R_MFMA_J
-#undef A4R_RD_I
+#undef A4R_MFMA16
+#undef A4R_PHASE
+#undef A4R_KTILE
 }
 
 }  // namespace

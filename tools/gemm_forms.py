@@ -12,6 +12,7 @@ from adapter4rec_amd import _lib as L
 
 dev = torch.device('cuda:0')
 M = int(sys.argv[1]) if len(sys.argv) > 1 else 40448
+PLAIN = len(sys.argv) > 2          # ablation runs: plain epilogue on three shapes, no vendor column
 t = torch.bfloat16
 
 
@@ -31,8 +32,11 @@ def t_us(fn, n=20):
 g = torch.Generator(device=dev).manual_seed(3)
 R = lambda *s, sc=1.0: (torch.randn(*s, device=dev, generator=g) * sc).to(t)
 rows = []
-for name, N, K, form in (('qkv', 2304, 768, 'plain'), ('attn-out', 768, 768, 'drop'), ('ffn-up', 3072, 768, 'gelu'), ('ffn-down', 768, 3072, 'drop'),
-                         ('d ffn-down', 3072, 768, 'dmul'), ('d ffn-up', 768, 3072, 'res'), ('d attn-out', 768, 768, 'plain'), ('d qkv', 768, 2304, 'res')):
+CASES = (('qkv', 2304, 768, 'plain'), ('attn-out', 768, 768, 'drop'), ('ffn-up', 3072, 768, 'gelu'), ('ffn-down', 768, 3072, 'drop'),
+                         ('d ffn-down', 3072, 768, 'dmul'), ('d ffn-up', 768, 3072, 'res'), ('d attn-out', 768, 768, 'plain'), ('d qkv', 768, 2304, 'res'))
+if PLAIN:
+    CASES = (('k768', 768, 768, 'plain'), ('k3072', 768, 3072, 'plain'), ('n3072', 3072, 768, 'plain'))
+for name, N, K, form in CASES:
     A, B = R(M, K), R(N, K, sc=0.05)
     C, C2, R1, Pre = (torch.empty(M, N, device=dev, dtype=t) for _ in range(4))
     R1.normal_(); Pre.normal_()
@@ -49,6 +53,6 @@ for name, N, K, form in (('qkv', 2304, 768, 'plain'), ('attn-out', 768, 768, 'dr
         f = lambda: L.gemm_nt(A, B, C, R1=R1)
     ta = t_us(f)
     bb = bias.to(t)
-    tv = t_us(lambda: torch.nn.functional.linear(A, B, bb))
+    tv = t_us(lambda: torch.nn.functional.linear(A, B, bb)) if not PLAIN else float('nan')
     fl = 2.0 * M * N * K
     print(f'{name:11s} M={M} N={N:4d} K={K:4d} {form:5s}: a4r {ta:7.1f} us {fl / ta / 1e6:7.1f} TF/s | vendor plain {tv:7.1f} us {fl / tv / 1e6:7.1f} TF/s')
