@@ -259,20 +259,11 @@ __global__ void __launch_bounds__(WAVES * 64) attn_bwd_kernel(const T* __restric
         const int key = nt * 16 + r16;
         km[nt] = (key < S) ? (key_mask ? key_mask[(size_t)item * S + key] : 1.f) : 0.f;
     }
-    // Every global read of the pair is requested BEFORE anything is consumed: the staged copies of Q, K, dO (contraction down the
-    // rows) and the row-major operand fragments of Q K^T and dO V^T (the second touch of Q, K, dO hits L2).  Issued phase by phase
-    // (stage -> wait -> scores -> wait -> dP) a wave had ~5 KB in flight three times over; with 8 waves per CU (LDS-bound) that was 2.8 TB/s.
-    uint4 sq[C::NLD], sk[C::NLD], sd[C::NLD];
-#pragma unroll
-    for (int i = 0; i < C::NLD; ++i) {
-        const int id = lane + 64 * i, row = id / C::CPR, ch = id % C::CPR;
-        sq[i] = make_uint4(0u, 0u, 0u, 0u); sk[i] = sq[i]; sd[i] = sq[i];
-        if (row < S) {
-            sq[i] = ldg16(base + (size_t)row * ld + q_off + ch * C::PER);
-            sk[i] = ldg16(base + (size_t)row * ld + k_off + ch * C::PER);
-            sd[i] = ldg16(dbase + (size_t)row * ldo + ch * C::PER);
-        }
-    }
+    // Every global read of the pair is requested BEFORE anything is consumed, and every byte ONCE: the row-major operand fragments
+    // of Q K^T and dO V^T (lane (r16, kg) holds the 16-byte chunk ks * 4 + kg of rows r16 and 16 + r16) are exactly the chunks the
+    // staged copies of Q, K, dO are made of, so the same registers fill the LDS tiles (they used to be loaded a second time in
+    // row-chunk order: 28 loads per lane instead of 16).  Rows >= S: Q, K, V clamp to row S - 1 (finite values; their scores are
+    // masked / their dS rows are zero because dO is zero there), dO is zero.
     uint4 fq[C::KSD][2], fk[C::KSD][2], fd[C::KSD][2], fv[C::KSD][2];
 #pragma unroll
     for (int ks = 0; ks < C::KSD; ++ks)
@@ -286,12 +277,16 @@ __global__ void __launch_bounds__(WAVES * 64) attn_bwd_kernel(const T* __restric
             if (row < S) fd[ks][t] = ldg16(dbase + (size_t)row * ldo + (ks * 4 + kg) * C::PER);
         }
 #pragma unroll
-    for (int i = 0; i < C::NLD; ++i) {
-        const int id = lane + 64 * i, row = id / C::CPR, ch = id % C::CPR;
-        lds_put16<T, C::GSTRIDE>(Qs, row, ch, sq[i]);
-        lds_put16<T, C::GSTRIDE>(Ks, row, ch, sk[i]);
-        lds_put16<T, C::GSTRIDE>(dOs, row, ch, sd[i]);
-    }
+    for (int ks = 0; ks < C::KSD; ++ks)
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const int row = t * 16 + r16, ch = ks * 4 + kg;
+            const bool in = row < S;                       // staged rows >= S are ZERO (they are contraction terms of dK, dV / dQ)
+            const uint4 z = make_uint4(0u, 0u, 0u, 0u);
+            lds_put16<T, C::GSTRIDE>(Qs, row, ch, in ? fq[ks][t] : z);
+            lds_put16<T, C::GSTRIDE>(Ks, row, ch, in ? fk[ks][t] : z);
+            lds_put16<T, C::GSTRIDE>(dOs, row, ch, fd[ks][t]);
+        }
 
     f32x4_t sc[2][2], dp[2][2];
 #pragma unroll
