@@ -12,7 +12,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('A4R_LIB_PATH') or os.path.join(_HERE, 'liba4r_hip.so')    # A4R_LIB_PATH: A/B builds (tools/), same C ABI
 
-BF16, F32 = 0, 1
+BF16, F32, FP8 = 0, 1, 2
 ACT_NONE, ACT_RELU, ACT_GELU, ACT_GELU_TANH, ACT_LEAKY = 0, 1, 2, 3, 4
 DACT_MUL = 15
 EVAL_MAX_HISTORY = 64          # A4R_EVAL_MAX_HISTORY (include/a4r.h)
@@ -22,7 +22,7 @@ EXPORTS = [
     'a4r_version', 'a4r_gemm_nt', 'a4r_gemm_tn', 'a4r_colsum', 'a4r_attn_fwd', 'a4r_attn_bwd', 'a4r_embed_ln',
     'a4r_ln_fwd', 'a4r_ln_bwd', 'a4r_gather_rows', 'a4r_scatter_rows', 'a4r_act_bwd_f32', 'a4r_score_bce_fwd',
     'a4r_score_bce_bwd', 'a4r_emb_grad_add_inputs', 'a4r_take_inputs', 'a4r_adam_step', 'a4r_pack_matrices',
-    'a4r_eval_rank', 'a4r_dropout_apply', 'a4r_gemm_variant', 'a4r_adapter_ln_fwd', 'a4r_adapter_ln_bwd', 'a4r_attn_long_fwd', 'a4r_attn_long_bwd', 'a4r_patchify', 'a4r_vit_assemble', 'a4r_resample_u8', 'a4r_embed_bwd',
+    'a4r_eval_rank', 'a4r_dropout_apply', 'a4r_gemm_variant', 'a4r_adapter_ln_fwd', 'a4r_adapter_ln_bwd', 'a4r_ln_fwd_fp8', 'a4r_quant_rows_fp8', 'a4r_attn_long_fwd', 'a4r_attn_long_bwd', 'a4r_patchify', 'a4r_vit_assemble', 'a4r_resample_u8', 'a4r_embed_bwd',
 ]
 
 
@@ -34,7 +34,7 @@ class GemmArgs(C.Structure):
                 ('ldr1', C.c_int32), ('ldr2', C.c_int32), ('ldpre', C.c_int32),
                 ('in_dtype', C.c_int32), ('out_dtype', C.c_int32), ('act', C.c_int32), ('dact', C.c_int32),
                 ('drop_first', C.c_int32), ('c2_mode', C.c_int32), ('alpha', C.c_float), ('drop_p', C.c_float), ('drop_site', C.c_uint32), ('drop_seed', C.c_uint64),
-                ('drop_row0', C.c_int64)]
+                ('drop_row0', C.c_int64), ('scale_a', C.c_void_p), ('scale_b', C.c_void_p)]
 
 
 class AttnArgs(C.Structure):
@@ -98,6 +98,8 @@ def _dt(t):
         return BF16
     if t.dtype == torch.float32:
         return F32
+    if t.dtype == torch.uint8:           # e4m3 bit patterns (a4r_quant_rows_fp8 / a4r_ln_fwd_fp8 / quantize_weight_fp8)
+        return FP8
     raise TypeError(f'unsupported dtype {t.dtype}')
 
 
@@ -114,7 +116,7 @@ def require_gpu(*tensors):
 
 # ------------------------------------------------------------------ wrappers
 def gemm_nt(A, B, Cout, bias=None, C2=None, R1=None, R2=None, Pre=None, act=0, dact=0, alpha=1.0,
-            drop_p=0.0, drop_site=0, drop_seed=0, M=None, drop_first=False, c2_deriv=False):
+            drop_p=0.0, drop_site=0, drop_seed=0, M=None, drop_first=False, c2_deriv=False, scale_a=None, scale_b=None):
     if not (A.is_cuda and B.is_cuda and Cout.is_cuda):
         require_gpu(A, B, Cout)
     N, K = B.shape
@@ -129,7 +131,7 @@ def gemm_nt(A, B, Cout, bias=None, C2=None, R1=None, R2=None, Pre=None, act=0, d
                  A.shape[0] if M is None else M, N, K, _ld(A), _ld(B), _ld(Cout),
                  _ld(C2) if C2 is not None else 0, _ld(R1) if R1 is not None else 0, _ld(R2) if R2 is not None else 0,
                  _ld(Pre) if Pre is not None else 0, din, dout, act, dact, int(drop_first), int(c2_deriv), alpha, drop_p, drop_site,
-                 drop_seed, 0)
+                 drop_seed, 0, _pi(scale_a), _pi(scale_b))
     _check(lib().a4r_gemm_nt(_stream(), C.byref(g)), 'a4r_gemm_nt')
 
 
@@ -268,9 +270,32 @@ def embed_ln(ids, word, pos, type0, gamma, beta, eps, out, n_items, S, roberta=F
                               C.c_float(drop_p), C.c_uint32(drop_site), C.c_uint64(drop_seed), _p(pre_out), _p(stats_out)), 'a4r_embed_ln')
 
 
-def ln_fwd(v, gamma, beta, eps, y, stats, M=None, add=None, drop_p=0.0, drop_site=0, drop_seed=0):
-    require_gpu(v, y)
+def quantize_weight_fp8(w):
+    """Frozen weight [out, in] -> (e4m3 bit patterns uint8 [out, in], fp32 scale [out]): per-output-channel absmax scaling, the B
+    operand form of the fp8 a4r_gemm_nt.  Build-time only (once per frozen matrix)."""
+    wf = w.detach().float()
+    amax = wf.abs().amax(1).clamp_min(1e-30)
+    q = (wf * (448.0 / amax)[:, None]).to(torch.float8_e4m3fn).view(torch.uint8).contiguous()
+    return q, (amax / 448.0).contiguous()
+
+
+def quant_rows_fp8(x, q, scale, M=None):
+    require_gpu(x, q, scale)
+    M = x.shape[0] if M is None else M
+    assert q.dtype == torch.uint8 and scale.dtype == torch.float32
+    _check(lib().a4r_quant_rows_fp8(_stream(), _p(x), C.c_int(_ld(x)), _p(q), C.c_int(_ld(q)), _p(scale), C.c_int(M), C.c_int(x.shape[1]),
+                                    C.c_int(_dt(x))), 'a4r_quant_rows_fp8')
+
+
+def ln_fwd(v, gamma, beta, eps, y, stats, M=None, add=None, drop_p=0.0, drop_site=0, drop_seed=0, y8=None, ys=None):
+    require_gpu(v, y, y8)
     M = v.shape[0] if M is None else M
+    if y8 is not None:                    # also emit the row as e4m3 + per-row scale (y may be None)
+        assert drop_p == 0.0 and y8.dtype == torch.uint8 and ys.dtype == torch.float32
+        _check(lib().a4r_ln_fwd_fp8(_stream(), _p(v), C.c_int(_ld(v)), _p(add), C.c_int(add.shape[0] if add is not None else 0),
+                                    _p(gamma), _p(beta), C.c_float(eps), _p(y), C.c_int(_ld(y) if y is not None else 0), _p(y8), C.c_int(_ld(y8)),
+                                    _p(ys), _p(stats), C.c_int(M), C.c_int(v.shape[1]), C.c_int(_dt(v))), 'a4r_ln_fwd_fp8')
+        return
     _check(lib().a4r_ln_fwd(_stream(), _p(v), C.c_int(_ld(v)), _p(add), C.c_int(add.shape[0] if add is not None else 0),
                             _p(gamma), _p(beta), C.c_float(eps), _p(y), C.c_int(_ld(y)), _p(stats), C.c_int(M),
                             C.c_int(v.shape[1]), C.c_int(_dt(v)), C.c_float(drop_p), C.c_uint32(drop_site), C.c_uint64(drop_seed)),

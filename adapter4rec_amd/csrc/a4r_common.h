@@ -16,10 +16,11 @@
 #define A4R_DEV __device__ __forceinline__
 
 typedef __bf16 bf16_t;
+struct fp8_t { unsigned char v; };      // OCP e4m3fn (gfx950's fp8; NOT MI300's fnuz), storage tag for the fp8 GEMM operands
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
 typedef __attribute__((ext_vector_type(4))) float f32x4_t;
 
-enum { A4R_BF16 = 0, A4R_F32 = 1 };
+enum { A4R_BF16 = 0, A4R_F32 = 1, A4R_FP8 = 2 };      // A4R_FP8: OCP e4m3fn operands of a4r_gemm_nt (one byte per element)
 enum { A4R_ACT_NONE = 0, A4R_ACT_RELU = 1, A4R_ACT_GELU = 2, A4R_ACT_GELU_TANH = 3, A4R_ACT_LEAKY = 4, A4R_DACT_MUL_ = 15 };
 
 // ---------------------------------------------------------------- error codes (C ABI)
@@ -94,6 +95,17 @@ template <> struct Mma<float> {
         c = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.y), __uint_as_float(b.y), c, 0, 0, 0);
         c = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.z), __uint_as_float(b.z), c, 0, 0, 0);
         c = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.w), __uint_as_float(b.w), c, 0, 0, 0);
+    }
+};
+
+template <> struct Mma<fp8_t> {
+    // a 16-byte chunk holds 16 e4m3 elements: two v_mfma_f32_16x16x32_fp8_fp8 (8 bytes per lane each, K = 32) cover K = 64.  Both
+    // operands use the same byte -> contraction-slot map, so the products pair the right elements whatever the slot order.  Same
+    // cycles per instruction as the bf16 form: twice the flops per LDS / DMA byte, the same flops per MFMA cycle.
+    static constexpr int KSTEP = 64;
+    static A4R_DEV void mma(const uint4& a, const uint4& b, f32x4_t& c) {
+        c = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8((long)(((unsigned long)a.y << 32) | a.x), (long)(((unsigned long)b.y << 32) | b.x), c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8((long)(((unsigned long)a.w << 32) | a.z), (long)(((unsigned long)b.w << 32) | b.z), c, 0, 0, 0);
     }
 };
 

@@ -253,8 +253,17 @@ extern "C" int a4r_gemm_nt(void* stream, const a4r_gemm_t* gp) {
     const a4r_gemm_t& g = *gp;
     if (!g.A || !g.B || !g.C) return A4R_EINVAL;
     if (g.M <= 0 || g.N <= 0 || g.K <= 0 || g.M % 128 || g.N % 64 || g.K % 64) return A4R_EINVAL;
-    const int isz = g.in_dtype == A4R_F32 ? 4 : 2, osz = g.out_dtype == A4R_F32 ? 4 : 2;
-    if ((g.in_dtype != A4R_F32 && g.in_dtype != A4R_BF16) || (g.out_dtype != A4R_F32 && g.out_dtype != A4R_BF16)) return A4R_EINVAL;
+    const int isz = g.in_dtype == A4R_F32 ? 4 : (g.in_dtype == A4R_FP8 ? 1 : 2), osz = g.out_dtype == A4R_F32 ? 4 : 2;
+    if ((g.in_dtype != A4R_F32 && g.in_dtype != A4R_BF16 && g.in_dtype != A4R_FP8) || (g.out_dtype != A4R_F32 && g.out_dtype != A4R_BF16)) return A4R_EINVAL;
+    if (g.in_dtype == A4R_FP8) {          // e4m3 operands: the 256-tile kernel only, scales required
+        if (g.M % 256 || g.N % 256 || g.K % 128 || g.out_dtype != A4R_BF16 || !g.scale_a || !g.scale_b) return A4R_EINVAL;
+        if (g.lda < g.K || g.ldb < g.K || g.ldc < g.N || g.lda % 16 || g.ldb % 16 || (g.ldc * osz) % 16) return A4R_EINVAL;
+        if (!aligned16(g.A) || !aligned16(g.B) || !aligned16(g.C) || (g.C2 && (!aligned16(g.C2) || (g.ldc2 * osz) % 16 || g.ldc2 < g.N))) return A4R_EINVAL;
+        if ((g.R1 && (!aligned16(g.R1) || (g.ldr1 * osz) % 16)) || (g.R2 && (!aligned16(g.R2) || (g.ldr2 * osz) % 16))) return A4R_EINVAL;
+        if (g.drop_p < 0.f || g.drop_p >= 1.f) return A4R_EINVAL;
+        const int rc = a4r_gemm_nt_256(reinterpret_cast<hipStream_t>(stream), g);
+        return rc == 1 ? A4R_EINVAL : rc;
+    }
     if (g.lda < g.K || g.ldb < g.K || g.ldc < g.N) return A4R_EINVAL;
     if ((g.lda * isz) % 16 || (g.ldb * isz) % 16 || (g.ldc * osz) % 16) return A4R_EINVAL;
     if (!aligned16(g.A) || !aligned16(g.B) || !aligned16(g.C)) return A4R_EINVAL;

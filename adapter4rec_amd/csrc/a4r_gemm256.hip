@@ -283,6 +283,17 @@ __global__ void __launch_bounds__(512, 2) gemm_nt_256_kernel(const a4r_gemm_t p,
     for (int pr = 0; pr < 2; ++pr)
 #pragma unroll
         for (int e = 0; e < 8; ++e) bias8[pr][e] = epi.bias ? epi.bias[gcolp + pr * 32 + e] : 0.f;
+    // fp8 operands: per-row scale of A (token) x per-row scale of B (output channel), applied to the raw accumulator
+    constexpr bool SCALED = sizeof(TI) == 1;
+    float sb8[2][8], sa8[8];
+    if constexpr (SCALED) {
+#pragma unroll
+        for (int pr = 0; pr < 2; ++pr)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) sb8[pr][e] = p.scale_b[gcolp + pr * 32 + e];
+#pragma unroll
+        for (int mi = 0; mi < 8; ++mi) sa8[mi] = p.scale_a[grow0 + mi * 16];
+    }
     // DACT instantiations (dgrad through an activation: C = acc * act'(Pre)): the Pre operand of row mi + 1 is requested before
     // row mi is finished and stored -- a load waited for where it is issued costs an L2 / HBM round trip per group, and it cannot
     // be hoisted above the previous group's store by the compiler (C may alias Pre for all it knows).
@@ -300,6 +311,9 @@ __global__ void __launch_bounds__(512, 2) gemm_nt_256_kernel(const a4r_gemm_t p,
                                                               __float_as_uint(acc[mi_][2 * (pr_) + 1][r_]), false, false);  \
             v_[r_] = __uint_as_float(sw_[0]);                                                                               \
             v_[4 + r_] = __uint_as_float(sw_[1]);                                                                           \
+        }                                                                                                                   \
+        if constexpr (SCALED) {                                                                                             \
+            _Pragma("unroll") for (int e_ = 0; e_ < 8; ++e_) v_[e_] *= sa8[mi_] * sb8[pr_][e_];                             \
         }                                                                                                                   \
         epilogue_n<TO, 8, ACT, DACT>(v_, bias8[pr_], grow0 + (mi_) * 16, gcolp + (pr_) * 32, epi,                           \
                                      DACT != A4R_ACT_NONE ? pre_ld[(mi_) & 1][pr_] : nullptr);                              \
@@ -392,6 +406,12 @@ int dispatch_same(hipStream_t s, const a4r_gemm_t& g) {   // in == out dtype: th
 // called by a4r_gemm_nt (a4r_gemm.hip) after argument validation; returns 1 when the combination is not instantiated
 int a4r_gemm_nt_256(hipStream_t s, const a4r_gemm_t& g) {
     if (g.bias && (reinterpret_cast<uintptr_t>(g.bias) & 3u)) return 1;
+    if (g.in_dtype == A4R_FP8) {                      // e4m3 operands (frozen-backbone forward GEMMs): plain and GELU (+ derivative) epilogues
+        if (g.out_dtype != A4R_BF16 || !g.scale_a || !g.scale_b || g.dact != A4R_ACT_NONE) return 1;
+        if (g.act == A4R_ACT_NONE) return launch256<fp8_t, bf16_t, A4R_ACT_NONE, A4R_ACT_NONE>(s, g);
+        if (g.act == A4R_ACT_GELU) return launch256<fp8_t, bf16_t, A4R_ACT_GELU, A4R_ACT_NONE>(s, g);
+        return 1;
+    }
     if (g.in_dtype == A4R_BF16 && g.out_dtype == A4R_BF16) return dispatch_same<bf16_t>(s, g);
     if (g.in_dtype == A4R_F32 && g.out_dtype == A4R_F32) return dispatch_same<float>(s, g);
     if (g.act != A4R_ACT_NONE || g.dact != A4R_ACT_NONE) return 1;

@@ -137,12 +137,72 @@ __global__ void __launch_bounds__(256) embed_bwd_kernel(const int64_t* __restric
     }
 }
 
+// ------------------------------------------------------------------ fp8 (OCP e4m3fn) row quantisation
+// x8[row] = e4m3(x[row] * 448 / amax(row)), scale[row] = amax(row) / 448: one scale per row (token), the A operand form of the
+// fp8 a4r_gemm_nt.  v_cvt_pk_fp8_f32 rounds to nearest even; |x * 448 / amax| <= 448 = the e4m3 maximum, so nothing overflows.
+A4R_DEV uint2 f32x8_to_fp8(const float (&v)[8]) {
+    int lo = 0, hi = 0;
+    lo = __builtin_amdgcn_cvt_pk_fp8_f32(v[0], v[1], lo, false);
+    lo = __builtin_amdgcn_cvt_pk_fp8_f32(v[2], v[3], lo, true);
+    hi = __builtin_amdgcn_cvt_pk_fp8_f32(v[4], v[5], hi, false);
+    hi = __builtin_amdgcn_cvt_pk_fp8_f32(v[6], v[7], hi, true);
+    return make_uint2((unsigned)lo, (unsigned)hi);
+}
+A4R_DEV float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+template <int NG>
+A4R_DEV void row_quant_store(const float (&v)[NG][8], int ng, int lane, unsigned char* q, float* scale_out) {
+    float am = 0.f;
+#pragma unroll
+    for (int g = 0; g < NG; ++g)
+        if (lane + 64 * g < ng) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) am = fmaxf(am, fabsf(v[g][e]));
+        }
+    am = wave_max(am);
+    const float inv = am > 0.f ? __fdiv_rn(448.f, am) : 0.f;         // correctly rounded (once per row): bit-equal with a host restatement
+    if (lane == 0) *scale_out = am > 0.f ? __fdiv_rn(am, 448.f) : 1.f;
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+        const int gi = lane + 64 * g;
+        if (gi < ng) {
+            float t[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) t[e] = v[g][e] * inv;
+            *reinterpret_cast<uint2*>(q + gi * 8) = f32x8_to_fp8(t);
+        }
+    }
+}
+
+constexpr int QMAXG = 8;   // 8-element groups per lane of the standalone quantiser: H <= 64 * 8 * 8 = 4096
+template <typename T>
+__global__ void __launch_bounds__(256) quant_rows_fp8_kernel(const T* __restrict__ x, int ldx, unsigned char* __restrict__ q, int ldq,
+                                                             float* __restrict__ scale, int M, int H) {
+    const int lane = threadIdx.x & 63;
+    const int ng = H / 8;
+    for (int row = blockIdx.x * 4 + (threadIdx.x >> 6); row < M; row += gridDim.x * 4) {
+        float v[QMAXG][8];
+#pragma unroll
+        for (int g = 0; g < QMAXG; ++g) {
+            const int gi = lane + 64 * g;
+            if (gi < ng) load_vec<T, 8>(x + (size_t)row * ldx + gi * 8, v[g]);
+        }
+        row_quant_store<QMAXG>(v, ng, lane, q + (size_t)row * ldq, scale + row);
+    }
+}
+
 // ------------------------------------------------------------------ LN forward
+// y (optional when y8 is given) in T; y8 / ys (optional): the same row as e4m3 with its per-row scale (the next GEMM's fp8 A operand,
+// quantised from the fp32 result: one rounding instead of bf16 then e4m3).
 template <typename T>
 __global__ void __launch_bounds__(256) ln_fwd_kernel(const T* __restrict__ vin, int ldv, const float* __restrict__ add, int add_rows,
                                                      const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
                                                      T* __restrict__ y, int ldy, float* __restrict__ stats, int M, int H,
-                                                     uint64_t seed, uint32_t site, uint32_t thr16, float scale) {
+                                                     uint64_t seed, uint32_t site, uint32_t thr16, float scale,
+                                                     unsigned char* __restrict__ y8, int ld8, float* __restrict__ ys) {
     const int lane = threadIdx.x & 63;
     const int ng = H / 8;
     float ga[MAXG][8], be[MAXG][8];
@@ -167,7 +227,8 @@ __global__ void __launch_bounds__(256) ln_fwd_kernel(const T* __restrict__ vin, 
 #pragma unroll
             for (int e = 0; e < 8; ++e) v[g][e] = (v[g][e] - mean) * rstd * ga[g][e] + be[g][e];
         if (thr16) row_dropout(v, ng, lane, row, H, seed, site, thr16, scale);
-        row_store<T>(y + (size_t)row * ldy, ng, lane, v);
+        if (y) row_store<T>(y + (size_t)row * ldy, ng, lane, v);
+        if (y8) row_quant_store<MAXG>(v, ng, lane, y8 + (size_t)row * ld8, ys + row);
     }
 }
 
@@ -358,13 +419,14 @@ extern "C" int a4r_embed_bwd(void* stream, const int64_t* ids, int ld_ids, const
     return a4r_launch_status();
 }
 
-extern "C" int a4r_ln_fwd(void* stream, const void* v, int ldv, const float* add, int add_rows,
-                          const float* gamma, const float* beta, float eps,
-                          void* y, int ldy, float* stats, int M, int H, int dtype,
-                          float drop_p, uint32_t drop_site, uint64_t drop_seed) {
-    if (!v || !gamma || !beta || !y || bad_dtype(dtype) || M <= 0 || H <= 0 || H % 8 || H > 1024) return A4R_EINVAL;
+static int ln_fwd_launch(void* stream, const void* v, int ldv, const float* add, int add_rows, const float* gamma, const float* beta, float eps,
+                         void* y, int ldy, float* stats, int M, int H, int dtype, float drop_p, uint32_t drop_site, uint64_t drop_seed,
+                         void* y8, int ld8, float* ys) {
+    if (!v || !gamma || !beta || (!y && !y8) || bad_dtype(dtype) || M <= 0 || H <= 0 || H % 8 || H > 1024) return A4R_EINVAL;
     const int esz = dtype == A4R_F32 ? 4 : 2;
-    if ((ldv * esz) % 16 || (ldy * esz) % 16 || ldv < H || ldy < H || misaligned(v) || misaligned(y)) return A4R_EINVAL;
+    if ((ldv * esz) % 16 || ldv < H || misaligned(v)) return A4R_EINVAL;
+    if (y && ((ldy * esz) % 16 || ldy < H || misaligned(y))) return A4R_EINVAL;
+    if (y8 && (!ys || ld8 % 8 || ld8 < H || (reinterpret_cast<uintptr_t>(y8) & 7u))) return A4R_EINVAL;
     if (add && (add_rows <= 0 || misaligned(add))) return A4R_EINVAL;
     if (drop_p < 0.f || drop_p >= 1.f) return A4R_EINVAL;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
@@ -372,10 +434,37 @@ extern "C" int a4r_ln_fwd(void* stream, const void* v, int ldv, const float* add
     const float sc = a4r_keep_scale(drop_p);
     if (dtype == A4R_BF16)
         hipLaunchKernelGGL(ln_fwd_kernel<bf16_t>, dim3(row_grid(M)), dim3(256), 0, s, (const bf16_t*)v, ldv, add, add_rows, gamma, beta, eps,
-                           (bf16_t*)y, ldy, stats, M, H, drop_seed, drop_site, thr, sc);
+                           (bf16_t*)y, ldy, stats, M, H, drop_seed, drop_site, thr, sc, (unsigned char*)y8, ld8, ys);
     else
         hipLaunchKernelGGL(ln_fwd_kernel<float>, dim3(row_grid(M)), dim3(256), 0, s, (const float*)v, ldv, add, add_rows, gamma, beta, eps,
-                           (float*)y, ldy, stats, M, H, drop_seed, drop_site, thr, sc);
+                           (float*)y, ldy, stats, M, H, drop_seed, drop_site, thr, sc, (unsigned char*)y8, ld8, ys);
+    return a4r_launch_status();
+}
+
+extern "C" int a4r_ln_fwd(void* stream, const void* v, int ldv, const float* add, int add_rows,
+                          const float* gamma, const float* beta, float eps,
+                          void* y, int ldy, float* stats, int M, int H, int dtype,
+                          float drop_p, uint32_t drop_site, uint64_t drop_seed) {
+    if (!y) return A4R_EINVAL;
+    return ln_fwd_launch(stream, v, ldv, add, add_rows, gamma, beta, eps, y, ldy, stats, M, H, dtype, drop_p, drop_site, drop_seed, nullptr, 0, nullptr);
+}
+
+extern "C" int a4r_ln_fwd_fp8(void* stream, const void* v, int ldv, const float* add, int add_rows,
+                              const float* gamma, const float* beta, float eps,
+                              void* y, int ldy, void* y8, int ld8, float* yscale, float* stats, int M, int H, int dtype) {
+    if (!y8) return A4R_EINVAL;
+    return ln_fwd_launch(stream, v, ldv, add, add_rows, gamma, beta, eps, y, ldy, stats, M, H, dtype, 0.f, 0, 0, y8, ld8, yscale);
+}
+
+extern "C" int a4r_quant_rows_fp8(void* stream, const void* x, int ldx, void* q, int ldq, float* scale, int M, int H, int dtype) {
+    if (!x || !q || !scale || bad_dtype(dtype) || M <= 0 || H <= 0 || H % 8 || H > 4096) return A4R_EINVAL;
+    const int esz = dtype == A4R_F32 ? 4 : 2;
+    if ((ldx * esz) % 16 || ldx < H || misaligned(x) || ldq % 8 || ldq < H || (reinterpret_cast<uintptr_t>(q) & 7u)) return A4R_EINVAL;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    if (dtype == A4R_BF16)
+        hipLaunchKernelGGL(quant_rows_fp8_kernel<bf16_t>, dim3(row_grid(M)), dim3(256), 0, s, (const bf16_t*)x, ldx, (unsigned char*)q, ldq, scale, M, H);
+    else
+        hipLaunchKernelGGL(quant_rows_fp8_kernel<float>, dim3(row_grid(M)), dim3(256), 0, s, (const float*)x, ldx, (unsigned char*)q, ldq, scale, M, H);
     return a4r_launch_status();
 }
 

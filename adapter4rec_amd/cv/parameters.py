@@ -54,7 +54,8 @@ def parse_args(argv=None):
     p.add_argument('--num_dnn', type=int, default=0)
     p.add_argument('--hypercomplex_division', type=int, default=4)
     p.add_argument('--phm_init_range', type=float, default=0.0001)
-    p.add_argument('--compute_dtype', type=str, default=None, choices=[None, 'bf16', 'fp32'])
+    p.add_argument('--compute_dtype', type=str, default=None, choices=[None, 'bf16', 'fp32', 'fp8'],
+                   help="fp8: bf16 storage + OCP e4m3 operands for the frozen backbone's qkv / FFN-up forward GEMMs (BASELINE config 5)")
     p.add_argument('--eval_compute_dtype', type=str, default=None, choices=[None, 'bf16', 'fp32'],
                    help="dtype of eval's item sweep; None = --compute_dtype (the reference evaluates under the same AMP setting it trains with)")
     p.add_argument('--lora_r', type=int, default=12)              # run_adapter.py:386-387 hard-codes 12

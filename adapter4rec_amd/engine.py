@@ -178,9 +178,12 @@ class TransRecEngine:
         p0 = next(model.parameters())
         self._require_device(p0)
         self.dev = p0.device
-        if dtype not in ('bf16', 'fp32'):
-            raise ValueError("compute_dtype must be 'bf16' or 'fp32'")
-        self.T = torch.bfloat16 if dtype == 'bf16' else torch.float32
+        if dtype not in ('bf16', 'fp32', 'fp8'):
+            raise ValueError("compute_dtype must be 'bf16', 'fp32' or 'fp8'")
+        # fp8: bf16 storage everywhere + OCP e4m3 operands (per-token / per-output-channel scales) for the frozen backbone's forward
+        # GEMMs whose input is a LayerNorm output (qkv, FFN-up); everything else, and all of backward, is the bf16 path
+        self.fp8 = dtype == 'fp8'
+        self.T = torch.float32 if dtype == 'fp32' else torch.bfloat16
         self.S = getattr(args, 'num_words_title', 0)
         self.E = args.embedding_dim
         self.Lseq = args.max_seq_len + 1
@@ -194,6 +197,8 @@ class TransRecEngine:
         self._build_sasrec()
         self._check_coverage()
         self._finalize_packs()
+        if self.fp8:
+            self._build_fp8()
         self.cap_items = 0
         self.cap_users = 0
         self._bufs, self._saved_bert, self._saved_sas = {}, None, None
@@ -218,6 +223,19 @@ class TransRecEngine:
         finally:
             for p, f in flags:
                 p.requires_grad_(f)
+
+    def _build_fp8(self):
+        """e4m3 copies (+ per-output-channel scales) of the FROZEN qkv and FFN-up operands of every item-tower block."""
+        if not hasattr(self.bert_blocks[0], 'lnA'):
+            raise NotImplementedError("compute_dtype 'fp8' is wired for the image tower (pre-LN ViT / ViT-MAE: both fp8 GEMM inputs are "
+                                      'LayerNorm outputs); the text tower runs bf16')
+        for b in self.bert_blocks:
+            b.wqkv8 = b.wi8 = None
+            frozen_qkv = not b.lora and all(d is not None and not d.trainable for d in b.qkv)
+            if frozen_qkv and b.wqkv.shape[0] % 256 == 0 and b.wqkv.shape[1] % 128 == 0:
+                b.wqkv8, b.wqkv8s = L.quantize_weight_fp8(b.wqkv)
+            if not b.d_i.trainable and b.wi.shape[0] % 256 == 0 and b.wi.shape[1] % 128 == 0:
+                b.wi8, b.wi8s = L.quantize_weight_fp8(b.wi)
 
     def _require_device(self, p0):
         if not p0.is_cuda:

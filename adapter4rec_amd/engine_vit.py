@@ -180,9 +180,14 @@ class ViTRecEngine(TransRecEngine):
         """cls_rows = Ip: after attention only token 0 of every image (all the head reads, encoders.py:22,32) is carried on:
         x_out is then [Ip, H].  Results-neutral: the other rows of the last layer's output are never consumed."""
         T, H = blk.T, blk.H
-        n1 = bufs['n1'] if 'n1' in bufs else self._buf('n1', M, H, T)
-        L.ln_fwd(x, blk.lnA.gamma, blk.lnA.beta, blk.lnA.eps, n1, bufs['sta'], M=M)
-        L.gemm_nt(n1, blk.wqkv, bufs['qkv'], bias=blk.bqkv, M=M)
+        if self.fp8 and blk.wqkv8 is not None:      # LN_before emits the row as e4m3 + scale: the qkv GEMM runs on fp8 operands
+            n1q, n1s = self._buf('n1q', M, H, torch.uint8), self._buf('n1s', M, 1, torch.float32)
+            L.ln_fwd(x, blk.lnA.gamma, blk.lnA.beta, blk.lnA.eps, bufs.get('n1'), bufs['sta'], M=M, y8=n1q, ys=n1s)
+            L.gemm_nt(n1q, blk.wqkv8, bufs['qkv'], bias=blk.bqkv, M=M, scale_a=n1s, scale_b=blk.wqkv8s)
+        else:
+            n1 = bufs['n1'] if 'n1' in bufs else self._buf('n1', M, H, T)
+            L.ln_fwd(x, blk.lnA.gamma, blk.lnA.beta, blk.lnA.eps, n1, bufs['sta'], M=M)
+            L.gemm_nt(n1, blk.wqkv, bufs['qkv'], bias=blk.bqkv, M=M)
         ctx = bufs['ctx_o'] if 'ctx_o' in bufs else self._buf('ctx', M, H, T)
         L.attn_long_fwd(bufs['qkv'], ctx, bufs['lse'], n_items, blk.S, blk.nh, blk.dh, 0, H, 2 * H, blk.scale)
         if cls_rows is not None:
@@ -193,10 +198,15 @@ class ViTRecEngine(TransRecEngine):
         if 'ctx_s' in bufs:
             bufs['ctx_s'][:M].copy_(ctx[:M])
         self._vit_sub_forward(blk.ad1, ctx, blk.wo, blk.bo, x, bufs, '1', M, bufs['x1'])
-        n2 = bufs['n2_s'] if 'n2_s' in bufs else self._buf('n2', M, H, T)
-        L.ln_fwd(bufs['x1'], blk.lnB.gamma, blk.lnB.beta, blk.lnB.eps, n2, bufs['stb'], M=M)
         u = bufs['u_s'] if 'u_s' in bufs else self._buf('u', M, blk.F, T)
-        L.gemm_nt(n2, blk.wi, u, bias=blk.bi, C2=bufs['upre'], act=L.ACT_GELU, c2_deriv=True, M=M)
+        if self.fp8 and blk.wi8 is not None and M % 256 == 0:
+            n2q, n2s = self._buf('n2q', M, H, torch.uint8), self._buf('n2s', M, 1, torch.float32)
+            L.ln_fwd(bufs['x1'], blk.lnB.gamma, blk.lnB.beta, blk.lnB.eps, bufs.get('n2_s'), bufs['stb'], M=M, y8=n2q, ys=n2s)
+            L.gemm_nt(n2q, blk.wi8, u, bias=blk.bi, C2=bufs['upre'], act=L.ACT_GELU, c2_deriv=True, M=M, scale_a=n2s, scale_b=blk.wi8s)
+        else:
+            n2 = bufs['n2_s'] if 'n2_s' in bufs else self._buf('n2', M, H, T)
+            L.ln_fwd(bufs['x1'], blk.lnB.gamma, blk.lnB.beta, blk.lnB.eps, n2, bufs['stb'], M=M)
+            L.gemm_nt(n2, blk.wi, u, bias=blk.bi, C2=bufs['upre'], act=L.ACT_GELU, c2_deriv=True, M=M)
         self._vit_sub_forward(blk.ad2, u, blk.wo2, blk.bo2, bufs['x1'], bufs, '2', M, x_out)
 
     def _vit_sub_backward(self, blk, ad, dy, bufs, k, M, x_in=None):

@@ -56,7 +56,7 @@ WORKLOADS = {
                              'synthetic (seed 123456, 65536 items, 30-token titles, vocab 50265, pad id 1; random-init RoBERTa-base)'),
     'vit_lora': ('configs[2]', 8, 'HM-shape SASRec+ViT-B/16+LoRA r=8 (q, v) train step from uint8 224x224 images resident in HBM',
                  'synthetic (seed 123456, uint8 images U{0..255} [336, 224, 224, 3] per step; random-init ViT-B/16)'),
-    'mae_compacter': ('configs[4], bf16 instead of fp8', 8, 'Amazon-shape SASRec+ViT-MAE-base (75 % masked, 50 tokens)+Compacter train step from uint8 images',
+    'mae_compacter': ('configs[4]', 8, 'Amazon-shape SASRec+ViT-MAE-base (75 % masked, 50 tokens)+Compacter train step from uint8 images',
                       'synthetic (seed 123456, uint8 images, on-device masking noise; random-init ViT-MAE-base)'),
 }
 
@@ -305,7 +305,8 @@ def main():
     ap.add_argument('--batch', type=int, default=0, help="users per GPU per step (default: the reference's 32 for text, 8 for images)")
     ap.add_argument('--workload', default='bert_houlsby', choices=list(WORKLOADS),
                     help="bert_houlsby = the configuration BASELINE.json's metric is quoted on; the others are its remaining configs")
-    ap.add_argument('--dtype', default='bf16', choices=['bf16', 'fp32'])
+    ap.add_argument('--dtype', default='bf16', choices=['bf16', 'fp32', 'fp8'],
+                    help='fp8 (image workloads): bf16 storage + OCP e4m3 operands for the frozen encoder\'s qkv / FFN-up forward GEMMs')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-roofline', action='store_true')
     ap.add_argument('--gemm-variant', type=int, default=-1, help='A/B knob of a4r_gemm_variant (include/a4r.h); default: the library default')
@@ -430,19 +431,24 @@ def main():
             agg = probe.summary()
             shapes = probe.by_shape()
         E.WGRAD_STREAM = side
-        tname = 'torch.bfloat16' if a.dtype == 'bf16' else 'torch.float32'
+        tname = 'torch.float32' if a.dtype == 'fp32' else 'torch.bfloat16'
         key = max((k for k in agg if k[0] == tname and k[1] == tname), key=lambda k: agg[k][1])     # most GPU time
+        fp8_f = sum(v[0] for k, v in agg.items() if k[0] == 'torch.uint8')
+        fp8_t = sum(v[1] for k, v in agg.items() if k[0] == 'torch.uint8')
         f, t, n = agg[key]
         ach = f / t / 1e12
         total_f = sum(v[0] for v in agg.values())
         total_t = sum(v[1] for v in agg.values())
-        peak = MFMA_BF16_PEAK_TFLOPS if a.dtype == 'bf16' else 157.3
+        peak = 157.3 if a.dtype == 'fp32' else MFMA_BF16_PEAK_TFLOPS      # (the non-scaled e4m3 MFMA issues at the bf16 rate: same peak)
         roof = dict(bound='mfma', achieved=round(ach, 2), peak=peak, unit='TFLOP/s', frac=round(ach / peak, 4), traffic=None,
                     kernel=(f'gemm_nt_256_kernel<{a.dtype},{a.dtype},act={key[2][1]},dact={key[2][2]}>' if key[2][0] == 256 else (f'{key[2][0]}_kernel<{a.dtype},{a.dtype}>' if isinstance(key[2][0], str) else f'gemm_nt_kernel<{a.dtype},{a.dtype},{key[2][0]}>')), launches_per_step=n // 2,
                     avg_launch_us=round(t / n * 1e6, 2), flop_per_launch=f / n,
                     all_gemm_tflops=round(total_f / total_t / 1e12, 2), gemm_time_share_of_step=round(total_t / 2 / (dt / a.steps), 3),
                     step_tflops_per_gpu=round(a.batch * a.steps / dt * GFLOP_PER_USER[wl] / 1e3, 1),
                     step_frac_of_peak=round(a.batch * a.steps / dt * GFLOP_PER_USER[wl] / 1e3 / peak, 4))
+        if fp8_t > 0:
+            roof['fp8_gemm_tflops'] = round(fp8_f / fp8_t / 1e12, 2)
+            roof['fp8_share_of_gemm_flops'] = round(fp8_f / total_f, 3)
         # fabric/HBM bytes per launch of that kernel: not measurable from inside the process -- taken from the committed
         # rocprofv3 PMC passes over this same command (profiles/r01_g_pmc_hbm_traffic.json says how), B=32 bf16 only.
         pmc = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles', 'r01_g_pmc_hbm_traffic.json')
@@ -468,7 +474,7 @@ def main():
             'unit': 'user-sequences/sec', 'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup,
             'ms_per_step': round(dt / a.steps * 1e3, 3), 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
             'dtype': a.dtype, 'data': WORKLOADS[wl][3],
-            'config': {'workload': WORKLOADS[wl][2], 'baseline_config': WORKLOADS[wl][0],
+            'config': {'workload': WORKLOADS[wl][2], 'baseline_config': WORKLOADS[wl][0] + (' in bf16 (run with --dtype fp8 for its fp8 encoder)' if wl == 'mae_compacter' and a.dtype != 'fp8' else ''),
                        'users_per_gpu': a.batch, 'global_batch': world * a.batch, 'seq_len': 23,
                        'tokens_per_item': eng.S, 'items_per_user': 42, 'parallelism': f'dp{world}',
                        'path': 'public: optimizer.zero_grad(); FlatDDP(model)(items, mask); loss.backward(); FusedAdam.step()'},

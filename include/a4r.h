@@ -25,6 +25,7 @@ extern "C" {
 
 #define A4R_BF16 0
 #define A4R_F32 1
+#define A4R_FP8 2    /* a4r_gemm_nt in_dtype only: OCP e4m3fn, one byte per element, with per-row scales (a4r_gemm_t.scale_a / scale_b) */
 #define A4R_ACT_NONE 0
 #define A4R_ACT_RELU 1
 #define A4R_ACT_GELU 2       /* exact erf form (HF "gelu", nn.GELU) */
@@ -54,6 +55,10 @@ typedef struct {
     float drop_p; uint32_t drop_site; uint64_t drop_seed;
     int64_t drop_row0;    /* row index of A's first row inside the logical matrix the dropout mask is defined on (0 unless the
                            * caller splits one GEMM into several launches: the mask index is (drop_row0 + row) * N + col) */
+    /* in_dtype == A4R_FP8 (OCP e4m3fn operands, one byte per element; M % 256 == 0, N % 256 == 0, K % 128 == 0; out bf16):
+     * A [M, K] carries one scale per ROW (token), B [N, K] one per ROW (output channel): the accumulator is multiplied by
+     * scale_a[m] * scale_b[n] (fp32) before alpha and the bias.  Null for the other dtypes. */
+    const float* scale_a; const float* scale_b;
 } a4r_gemm_t;
 int a4r_gemm_nt(void* stream, const a4r_gemm_t* g);
 /* tuning knob for A/B measurements and tests: 0 = 128x128 tile, register-staged K pipeline; 1 = 128x128 tile, direct-to-LDS
@@ -169,6 +174,15 @@ int a4r_ln_fwd(void* stream, const void* v, int ldv, const float* add, int add_r
                const float* gamma, const float* beta, float eps,
                void* y, int ldy, float* stats, int M, int H, int dtype,
                float drop_p, uint32_t drop_site, uint64_t drop_seed);
+/* fp8 (OCP e4m3fn) operands of the frozen-backbone forward GEMMs (north_star "fp8 MFMA encoder"; the reference's reduced-precision
+ * path is fp16 AMP, Downstream/CV/run_adapter.py:565-593).  One fp32 scale per ROW: q[row] = e4m3(x[row] * 448 / amax(row)),
+ * scale[row] = amax(row) / 448.  a4r_ln_fwd_fp8 = a4r_ln_fwd that ALSO (y optional) emits the normalised row in that form straight
+ * from its fp32 registers -- the A operand of the qkv / FFN-up GEMM costs no extra pass; a4r_quant_rows_fp8 is the standalone pass
+ * (H % 8 == 0, H <= 4096) for operands no fused producer exists for. */
+int a4r_ln_fwd_fp8(void* stream, const void* v, int ldv, const float* add, int add_rows,
+                   const float* gamma, const float* beta, float eps,
+                   void* y, int ldy, void* y8, int ld8, float* yscale, float* stats, int M, int H, int dtype);
+int a4r_quant_rows_fp8(void* stream, const void* x, int ldx, void* q, int ldq, float* scale, int M, int H, int dtype);
 /* dv = LN backward of dy (through the same dropout mask when drop_p > 0); dgamma/dbeta (+=, fp32,
  * optional: --finetune_layernorm, run.py:496-501); dbias (+= column sums of dv, optional: the bias
  * gradient of the Linear whose output feeds v).  dres (optional) is added to dv before it is stored

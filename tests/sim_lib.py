@@ -11,7 +11,8 @@ import torch
 
 from adapter4rec_amd import _lib as REAL
 
-BF16, F32 = REAL.BF16, REAL.F32
+BF16, F32, FP8 = REAL.BF16, REAL.F32, REAL.FP8
+quantize_weight_fp8 = REAL.quantize_weight_fp8
 ACT_NONE, ACT_RELU, ACT_GELU, ACT_GELU_TANH, ACT_LEAKY = 0, 1, 2, 3, 4
 DACT_MUL = 15
 EVAL_MAX_HISTORY = REAL.EVAL_MAX_HISTORY
@@ -46,12 +47,21 @@ def _dact(pre, a):
     return p.grad
 
 
+def _deq(t, scale):
+    """e4m3 bit patterns (uint8) + per-row scale -> fp32."""
+    return t.view(torch.float8_e4m3fn).float() * scale.reshape(-1)[:t.shape[0], None]
+
+
 def gemm_nt(A, B, Cout, bias=None, C2=None, R1=None, R2=None, Pre=None, act=0, dact=0, alpha=1.0,
-            drop_p=0.0, drop_site=0, drop_seed=0, M=None, drop_first=False, c2_deriv=False):
+            drop_p=0.0, drop_site=0, drop_seed=0, M=None, drop_first=False, c2_deriv=False, scale_a=None, scale_b=None):
     assert drop_p == 0.0
     M = A.shape[0] if M is None else M
     assert M % 128 == 0 and B.shape[0] % 64 == 0 and B.shape[1] % 64 == 0, (M, B.shape)
-    v = alpha * (A[:M].float() @ B.float().t())
+    if A.dtype == torch.uint8:           # fp8 operands (include/a4r.h: A4R_FP8)
+        assert B.dtype == torch.uint8 and M % 256 == 0 and B.shape[0] % 256 == 0 and B.shape[1] % 128 == 0 and dact == 0
+        v = alpha * (_deq(A[:M], scale_a) @ _deq(B, scale_b).t())
+    else:
+        v = alpha * (A[:M].float() @ B.float().t())
     if bias is not None:
         v = v + bias
     if C2 is not None:
@@ -226,7 +236,19 @@ def embed_ln(ids, word, pos, type0, gamma, beta, eps, out, n_items, S, roberta=F
     out[:n_items * S] = torch.nn.functional.layer_norm(x, (x.shape[-1],), gamma, beta, eps).view(n_items * S, -1).to(out.dtype)
 
 
-def ln_fwd(v, gamma, beta, eps, y, stats, M=None, add=None, drop_p=0.0, drop_site=0, drop_seed=0):
+def _quant_rows(x, q, scale):
+    amax = x.abs().amax(1)
+    inv = torch.where(amax > 0, 448.0 / amax, torch.zeros_like(amax))
+    q[:x.shape[0]] = (x * inv[:, None]).to(torch.float8_e4m3fn).view(torch.uint8)
+    scale.view(-1)[:x.shape[0]] = torch.where(amax > 0, amax / 448.0, torch.ones_like(amax))
+
+
+def quant_rows_fp8(x, q, scale, M=None):
+    M = x.shape[0] if M is None else M
+    _quant_rows(x[:M].float(), q, scale)
+
+
+def ln_fwd(v, gamma, beta, eps, y, stats, M=None, add=None, drop_p=0.0, drop_site=0, drop_seed=0, y8=None, ys=None):
     assert drop_p == 0.0
     M = v.shape[0] if M is None else M
     x = v[:M].float()
@@ -235,9 +257,14 @@ def ln_fwd(v, gamma, beta, eps, y, stats, M=None, add=None, drop_p=0.0, drop_sit
     mu = x.mean(-1, keepdim=True)
     var = ((x - mu) ** 2).mean(-1, keepdim=True)
     rstd = torch.rsqrt(var + eps)
-    stats[:M, 0] = mu[:, 0]
-    stats[:M, 1] = rstd[:, 0]
-    y[:M] = ((x - mu) * rstd * gamma + beta).to(y.dtype)
+    if stats is not None:
+        stats[:M, 0] = mu[:, 0]
+        stats[:M, 1] = rstd[:, 0]
+    out = (x - mu) * rstd * gamma + beta
+    if y is not None:
+        y[:M] = out.to(y.dtype)
+    if y8 is not None:
+        _quant_rows(out, y8, ys)
 
 
 def ln_bwd(dy, v, stats, gamma, dv, M=None, add=None, dgamma=None, dbeta=None, dbias=None, dres=None,

@@ -160,7 +160,7 @@ def _mae_compacter_case(dev, dtype='fp32'):
     from adapter4rec_amd.inject import freeze_all
     from oracle import ref_cpu as R
     sd, cfg, fx, _, (images, mask), noise = load_cv_variant('cv_mae_houlsby')
-    if dtype == 'bf16':
+    if dtype in ('bf16', 'fp8'):
         sd = condition(sd)
     args = make_args(adapter_type='compacter', CV_model_load='vit-mae-base', compute_dtype=dtype)
     model = Model(args, 60, True, ViTMAEModel(GEOM))
@@ -186,22 +186,33 @@ def _mae_compacter_case(dev, dtype='fp32'):
     root = root.to(dev)
     loss = root.model(images.to(dev), mask.to(dev), dev, noise=noise.to(dev))
     loss.backward()
-    tol_l, tol_g = (1e-4, 1e-4) if dtype == 'fp32' else (3e-2, 0.12)
+    # fp8 (configs[4]: "fp8 MFMA encoder"): e4m3 operands carry ~2^-4 relative rounding per element, ~3 % per GEMM output after the
+    # contraction; the bound is the measured one with headroom (2 layers here)
+    tol_l, tol_g = {'fp32': (1e-4, 1e-4), 'bf16': (3e-2, 0.12), 'fp8': (8e-2, 0.35)}[dtype]
     assert abs(loss.item() - float(out['loss'].detach())) < tol_l * max(1.0, float(out['loss'].detach()))
     params = dict(root.named_parameters())
+    worst = 0.0
     for n in names:
         ref = grads[strip(n)].numpy()
+        worst = max(worst, float(np.abs(params[n].grad.cpu().numpy() - ref).max() / (np.abs(ref).max() + 1e-30)))
         np.testing.assert_allclose(params[n].grad.cpu().numpy(), ref, atol=1e-6 + tol_g * np.abs(ref).max(), rtol=0, err_msg=n)
+    print(f'mae+compacter {dtype}: loss {loss.item():.5f} vs {float(out["loss"].detach()):.5f}, worst gradient error / tensor max {worst:.4f}')
+    if dtype == 'fp8':                       # (H = 128 here: only the FFN-up operand [256, 128] has a 256-tile shape; see _fp8_case for qkv)
+        assert all(b.wi8 is not None for b in root.model._engine().bert_blocks)
 
 
 def test_cv_host_logic_mae_compacter(simulated):
     _mae_compacter_case('cpu')
 
 
+def test_cv_host_logic_mae_compacter_fp8(simulated):
+    _mae_compacter_case('cpu', 'fp8')
+
+
 @pytest.mark.gpu
-@pytest.mark.parametrize('dtype', ['fp32', 'bf16'])
+@pytest.mark.parametrize('dtype', ['fp32', 'bf16', 'fp8'])
 def test_cv_mae_compacter_gpu(dtype):
-    """configs[4]'s model (ViT-MAE + Compacter) through the C ABI."""
+    """configs[4]'s model (ViT-MAE + Compacter) through the C ABI; fp8 = its e4m3 encoder GEMMs (qkv, FFN-up)."""
     _mae_compacter_case('cuda:0', dtype)
 
 
@@ -332,6 +343,66 @@ def build_cv_other_geometry(device='cpu'):
     mask = torch.ones(3, 6)
     mask[1, :4] = 0
     return model.to(device), dict(tower='image', vit_heads=2, max_seq_len=6), images.to(device), mask.to(device)
+
+
+def _fp8_case(dev):
+    """fp8 encoder at a geometry where BOTH e4m3 GEMMs run (H = 256: qkv [768, 256], FFN-up [512, 256]); 64 x 64 images, patch 8
+    -> 65 tokens, Houlsby adapters, 4 users.  fp8 vs bf16 vs the fp32 oracle on the same weights."""
+    from adapter4rec_amd.cv import Model, ViTForImageClassification
+    from adapter4rec_amd.cv.inject import inject_adapters
+    from adapter4rec_amd.inject import freeze_all
+    from oracle import ref_cpu as R
+    torch.manual_seed(91)
+    geom = dict(GEOM, hidden_size=256, num_attention_heads=4, intermediate_size=512, image_size=64)
+    args = make_args(CV_resize=64, max_seq_len=6)
+    model = Model(args, 30, True, ViTForImageClassification(geom))
+    with torch.no_grad():
+        for n_, p in model.named_parameters():
+            if p.dim() == 1:
+                p.add_(0.1 * torch.randn_like(p))
+            if n_.endswith('classifier.weight'):
+                p.mul_(0.15)
+    freeze_all(model)
+    model = inject_adapters(model, args)
+    with torch.no_grad():
+        for n_, p in model.named_parameters():
+            if p.requires_grad:
+                p.add_(0.05 * torch.randn_like(p))
+    model.eval()
+    images = torch.randn(4 * 7 * 2, 3, 64, 64)
+    mask = torch.ones(4, 6)
+    mask[1, :4] = 0
+    sd = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
+    cfg = dict(R.DEFAULT_CFG, tower='image', vit_heads=4, max_seq_len=6)
+    names = [n for n, p in model.named_parameters() if p.requires_grad]
+    out, grads = R.loss_and_grads(sd, names, images, mask, cfg)
+    res = {}
+    for dtype in ('bf16', 'fp8'):
+        model.compute_dtype = dtype
+        model.invalidate_native()
+        for p in model.parameters():
+            p.grad = None
+        model.to(dev)
+        loss = model(images.to(dev), mask.to(dev), dev)
+        loss.backward()
+        eng = model._engine()
+        if dtype == 'fp8':
+            assert eng.fp8 and all(b.wqkv8 is not None and b.wi8 is not None for b in eng.bert_blocks)
+        worst = max(float((p.grad.cpu() - grads[n]).abs().max() / grads[n].abs().max().clamp_min(1e-30)) for n, p in model.named_parameters() if p.requires_grad)
+        res[dtype] = (abs(loss.item() - float(out['loss'].detach())), worst)
+        model.cpu()
+    print(f"fp8 encoder vs fp32 oracle: loss err bf16 {res['bf16'][0]:.2e} fp8 {res['fp8'][0]:.2e}; worst grad err / tensor max bf16 {res['bf16'][1]:.3f} fp8 {res['fp8'][1]:.3f}")
+    assert res['bf16'][0] < 3e-2 and res['bf16'][1] < 0.12
+    assert res['fp8'][0] < 8e-2 and res['fp8'][1] < 0.35
+
+
+def test_cv_host_logic_fp8_encoder(simulated):
+    _fp8_case('cpu')
+
+
+@pytest.mark.gpu
+def test_cv_fp8_encoder_gpu():
+    _fp8_case('cuda:0')
 
 
 def _check_other_geometry(dev):

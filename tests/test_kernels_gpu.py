@@ -719,6 +719,96 @@ def test_adapter_ln_rejects():
         L.adapter_ln_fwd(a, o, third, Wd, bd, Wu, bu, gamma, beta, 1e-12, 1, mk(64), mk(64), mk(128), mk(128), torch.zeros(64, 2, device=dev()))
 
 
+# ------------------------------------------------------------------ fp8 (OCP e4m3fn) operands
+def _q8_ref(x):
+    """host fp32 (IEEE divide: torch's device kernels turn tensor / scalar into a multiplication by the reciprocal)"""
+    d = x.device
+    x = x.detach().float().cpu()
+    amax = x.abs().amax(1)
+    inv = torch.where(amax > 0, torch.tensor(448.0) / amax, torch.zeros_like(amax))
+    return (x * inv[:, None]).to(torch.float8_e4m3fn).to(d), torch.where(amax > 0, amax / torch.tensor(448.0), torch.ones_like(amax)).to(d)
+
+
+@pytest.mark.parametrize('dt', ['bf16', 'f32'])
+@pytest.mark.parametrize('H', [128, 768, 1024, 3072])
+def test_quant_rows_fp8(dt, H):
+    """a4r_quant_rows_fp8 vs torch's float8_e4m3fn cast of the same scaled row: bit-exact (same RNE rounding, correctly rounded fp32
+    scaling), incl. an all-zero row."""
+    from adapter4rec_amd import _lib as L
+    M, t = 517, DT[dt]
+    x = rnd(M, H, dtype=t, scale=2.0, seed=H + 1)
+    x[3] = 0
+    x[5, 7] = 300.0
+    q = torch.zeros(M, H, dtype=torch.uint8, device=dev())
+    sc = torch.zeros(M, device=dev())
+    L.quant_rows_fp8(x, q, sc)
+    qr, sr = _q8_ref(x.float())
+    assert torch.equal(sc, sr)
+    assert torch.equal(q, qr.view(torch.uint8)), int((q != qr.view(torch.uint8)).sum())
+    deq = q.view(torch.float8_e4m3fn).float() * sc[:, None]
+    assert float(((deq - x.float()).abs() / x.float().abs().clamp_min(1e-3 * float(x.float().abs().max()))).max()) < 2 ** -3
+    assert torch.equal(q[3], torch.zeros_like(q[3])) and float(sc[3]) == 1.0
+
+
+def test_ln_fwd_fp8_output():
+    from adapter4rec_amd import _lib as L
+    M, H, t = 640, 768, torch.bfloat16
+    v = rnd(M, H, dtype=t, scale=1.5, seed=7)
+    gamma, beta = rnd(H, seed=8) * 0.1 + 1, rnd(H, seed=9) * 0.1
+    y, y2 = torch.zeros(M, H, dtype=t, device=dev()), torch.zeros(M, H, dtype=t, device=dev())
+    st, st2 = torch.zeros(M, 2, device=dev()), torch.zeros(M, 2, device=dev())
+    y8 = torch.zeros(M, H, dtype=torch.uint8, device=dev())
+    ys = torch.zeros(M, device=dev())
+    L.ln_fwd(v, gamma, beta, 1e-12, y, st)
+    L.ln_fwd(v, gamma, beta, 1e-12, y2, st2, y8=y8, ys=ys)
+    assert torch.equal(y, y2) and torch.equal(st, st2)              # the bf16 output is unchanged by the extra output
+    ref = torch.nn.functional.layer_norm(v.float(), (H,), gamma, beta, 1e-12)
+    deq = y8.view(torch.float8_e4m3fn).float() * ys[:, None]
+    close(ys, ref.abs().amax(1) / 448, torch.float32, 'row scale', atol32=1e-5, rtol32=1e-4)
+    assert float((deq - ref).abs().max()) <= 2 ** -4 * float(ref.abs().max()) + 1e-6
+    L.ln_fwd(v, gamma, beta, 1e-12, None, None, y8=y8, ys=ys)       # y and stats optional
+
+
+@pytest.mark.parametrize('M,N,K,act', [(256, 256, 128, 0), (512, 768, 768, 0), (256 * 9, 2304, 768, 0), (256 * 5, 3072, 768, 2), (256 * 3, 768, 3072, 0)])
+def test_gemm_fp8(M, N, K, act):
+    """a4r_gemm_nt with e4m3 operands + per-row scales vs the fp32 product of the DEQUANTISED operands (what the kernel computes up to
+    accumulation order), bias / GELU + derivative epilogue included; and within fp8 rounding of the unquantised product."""
+    from adapter4rec_amd import _lib as L
+    t = torch.bfloat16
+    A, B = rnd(M, K, scale=1.0, seed=M + 3), rnd(N, K, scale=0.05, seed=N + 5)
+    A[:, 0] *= 8                                                # rows with very different scales
+    Aq, As = _q8_ref(A)
+    Bq, Bs = L.quantize_weight_fp8(B)
+    bias = rnd(N, seed=11) * 0.1
+    C = torch.zeros(M, N, dtype=t, device=dev())
+    C2 = torch.zeros_like(C) if act else None
+    L.gemm_nt(Aq.view(torch.uint8), Bq, C, bias=bias, C2=C2, act=act, c2_deriv=bool(act), scale_a=As, scale_b=Bs)
+    ref = (Aq.float() * As[:, None]) @ (Bq.view(torch.float8_e4m3fn).float() * Bs[:, None]).t() + bias
+    if act:
+        pre = ref.clone().requires_grad_(True)
+        act_ref(pre, act).sum().backward()
+        close(C2, pre.grad, t, 'fp8 gemm gelu derivative')
+        ref = act_ref(ref, act)
+    close(C, ref, t, 'fp8 gemm vs dequantised product')
+    full = A @ B.t() + bias
+    if act:
+        full = act_ref(full, act)
+    err = float((C.float() - full).abs().max() / full.abs().max())
+    assert err < 6e-2, err                                       # e4m3: 2^-4 per element, averaged down by the contraction
+
+
+def test_gemm_fp8_rejects():
+    from adapter4rec_amd import _lib as L
+    A = torch.zeros(256, 128, dtype=torch.uint8, device=dev())
+    B = torch.zeros(256, 128, dtype=torch.uint8, device=dev())
+    C = torch.zeros(256, 256, dtype=torch.bfloat16, device=dev())
+    one = torch.ones(256, device=dev())
+    with pytest.raises(RuntimeError):
+        L.gemm_nt(A, B, C)                                       # no scales
+    with pytest.raises(RuntimeError):
+        L.gemm_nt(A[:128], B, C[:128], scale_a=one, scale_b=one)     # M % 256
+
+
 def test_gemm_tail_panels_split_launch():
     """777 tiles on 256 CUs: the last 3 row panels are launched on the 128-tile kernel (a4r_gemm.hip); results and the dropout
     mask (drop_row0) must equal the single-kernel launch."""
