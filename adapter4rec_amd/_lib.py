@@ -22,7 +22,8 @@ EXPORTS = [
     'a4r_version', 'a4r_gemm_nt', 'a4r_gemm_tn', 'a4r_colsum', 'a4r_attn_fwd', 'a4r_attn_bwd', 'a4r_embed_ln',
     'a4r_ln_fwd', 'a4r_ln_bwd', 'a4r_gather_rows', 'a4r_scatter_rows', 'a4r_act_bwd_f32', 'a4r_score_bce_fwd',
     'a4r_score_bce_bwd', 'a4r_emb_grad_add_inputs', 'a4r_take_inputs', 'a4r_adam_step', 'a4r_pack_matrices',
-    'a4r_eval_rank', 'a4r_dropout_apply', 'a4r_gemm_variant', 'a4r_adapter_ln_fwd', 'a4r_adapter_ln_bwd', 'a4r_ln_fwd_fp8', 'a4r_quant_rows_fp8', 'a4r_attn_long_fwd', 'a4r_attn_long_bwd', 'a4r_patchify', 'a4r_vit_assemble', 'a4r_resample_u8', 'a4r_embed_bwd',
+    'a4r_eval_rank', 'a4r_dropout_apply', 'a4r_gemm_variant', 'a4r_adapter_ln_fwd', 'a4r_adapter_ln_bwd', 'a4r_ln_fwd_fp8', 'a4r_quant_rows_fp8', 'a4r_lora_merge', 'a4r_phm_build', 'a4r_phm_bwd', 'a4r_unpack_add', 'a4r_memset_zero',
+    'a4r_scatter_rows_fill', 'a4r_attn_long_fwd', 'a4r_attn_long_bwd', 'a4r_patchify', 'a4r_vit_assemble', 'a4r_resample_u8', 'a4r_embed_bwd',
 ]
 
 
@@ -48,6 +49,15 @@ class AttnArgs(C.Structure):
 class PackDesc(C.Structure):
     _fields_ = [('src_off', C.c_int64), ('dst', C.c_void_p), ('rows', C.c_int32), ('cols', C.c_int32),
                 ('rows_pad', C.c_int32), ('cols_pad', C.c_int32), ('transpose', C.c_int32), ('dst_ld', C.c_int32)]
+
+
+class PhmDesc(C.Structure):
+    _fields_ = [('rule_off', C.c_int64), ('wl_off', C.c_int64), ('wr_off', C.c_int64), ('out_off', C.c_int64), ('G', C.c_void_p),
+                ('ldg', C.c_int32), ('in_f', C.c_int32), ('out_f', C.c_int32), ('n', C.c_int32), ('pad_', C.c_int32)]
+
+
+class AddDesc(C.Structure):
+    _fields_ = [('src', C.c_void_p), ('dst_off', C.c_int64), ('rows', C.c_int32), ('cols', C.c_int32), ('ld', C.c_int32), ('alpha', C.c_float)]
 
 
 _lib = None
@@ -322,6 +332,48 @@ def scatter_rows(src, dst, n, row_step):
     require_gpu(src, dst)
     _check(lib().a4r_scatter_rows(_stream(), _p(src), C.c_int(_ld(src)), _p(dst), C.c_int(_ld(dst)), C.c_int(n), C.c_int(row_step),
                                   C.c_int(src.shape[1]), C.c_int(_dt(src))), 'a4r_scatter_rows')
+
+
+def scatter_rows_fill(src, dst, n, row_step, fill_rows):
+    """dst[r] = src[r / row_step] for r % row_step == 0 (r / row_step < n), 0 elsewhere, r < fill_rows."""
+    require_gpu(src, dst)
+    _check(lib().a4r_scatter_rows_fill(_stream(), _p(src), C.c_int(_ld(src)), _p(dst), C.c_int(_ld(dst)), C.c_int(n), C.c_int(row_step),
+                                       C.c_int(src.shape[1]), C.c_int(_dt(src)), C.c_int(fill_rows)), 'a4r_scatter_rows_fill')
+
+
+def zero(t):
+    """hipMemsetAsync of a contiguous tensor on the current stream."""
+    require_gpu(t)
+    assert t.is_contiguous()
+    _check(lib().a4r_memset_zero(_stream(), _p(t), C.c_int64(t.numel() * t.element_size())), 'a4r_memset_zero')
+
+
+def lora_merge(W, A, B, scaling, dst, dstT, r):
+    """dst [out, in] (a row block of the packed qkv operand) and dstT [in, out] (a column block of its transpose) <- W + scaling B A."""
+    require_gpu(W, dst, dstT)
+    out_f, in_f = W.shape
+    assert W.dtype == torch.float32 and W.is_contiguous() and (r == 0 or (A.is_contiguous() and B.is_contiguous()))
+    _check(lib().a4r_lora_merge(_stream(), _p(W), _p(A) if r else C.c_void_p(0), _p(B) if r else C.c_void_p(0), C.c_float(scaling),
+                                _p(dst), C.c_int(_ld(dst)), _p(dstT), C.c_int(_ld(dstT)), C.c_int(out_f), C.c_int(in_f), C.c_int(r),
+                                C.c_int(_dt(dst))), 'a4r_lora_merge')
+
+
+def desc_table(entries, device):
+    """ctypes descriptor array -> device byte tensor."""
+    arr = (type(entries[0]) * len(entries))(*entries)
+    return torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(device)
+
+
+def phm_build(params, desc_dev, n_desc, eff):
+    _check(lib().a4r_phm_build(_stream(), _p(params), _p(desc_dev), C.c_int(n_desc), _p(eff)), 'a4r_phm_build')
+
+
+def phm_bwd(params, desc_dev, n_desc, grads):
+    _check(lib().a4r_phm_bwd(_stream(), _p(params), _p(desc_dev), C.c_int(n_desc), _p(grads)), 'a4r_phm_bwd')
+
+
+def unpack_add(target, desc_dev, n_desc, max_elems):
+    _check(lib().a4r_unpack_add(_stream(), _p(target), _p(desc_dev), C.c_int(n_desc), C.c_int(max_elems)), 'a4r_unpack_add')
 
 
 def dropout_apply(x, y, drop_p, drop_site, drop_seed, M=None):

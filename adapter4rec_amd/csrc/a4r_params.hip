@@ -1,0 +1,153 @@
+// Parameter-side kernels of the training step (tiny, launch-latency-bound) that used to be torch eager ops between the HIP
+// kernels: the LoRA merge W + B A / r into the packed qkv operand, the Compacter / PHM effective matrices and their three
+// gradients, the scatter of zero-padded gradient scratch into the flat gradient buffer, and a zero fill.
+//   LoRA      : loralib==0.1.1 lora.Linear as injected at Downstream/Text/run.py:414-428, Downstream/CV/run_adapter.py:384-395
+//   Compacter : PHMLinear, Downstream/Text/model/layers.py:25-166 (matvec_product :10-22, kronecker_product_einsum_batched
+//               kronecker.py:23-34): E[out, in] = (sum_k kron(rule[k], W_left[k] W_right[k]))^T
+#include "a4r_common.h"
+#include "../../include/a4r.h"
+
+namespace {
+
+// ------------------------------------------------------------------ LoRA merge
+// dst[o, i] = W[o, i] + s * sum_r B[o, r] A[r, i]   and   dstT[i, o] = the same value (the dgrad operand), compute dtype
+template <typename T>
+__global__ void __launch_bounds__(256) lora_merge_kernel(const float* __restrict__ W, const float* __restrict__ A, const float* __restrict__ B,
+                                                         float s, T* __restrict__ dst, int ld, T* __restrict__ dstT, int ldT,
+                                                         int out_f, int in_f, int r) {
+    const int total = out_f * in_f;
+    for (int e = blockIdx.x * 256 + threadIdx.x; e < total; e += gridDim.x * 256) {
+        const int o = e / in_f, i = e % in_f;
+        float acc = 0.f;
+        for (int k = 0; k < r; ++k) acc += B[o * r + k] * A[k * in_f + i];
+        const float v = W[e] + s * acc;
+        Elem<T>::st(dst + (size_t)o * ld + i, v);
+        Elem<T>::st(dstT + (size_t)i * ldT + o, v);
+    }
+}
+
+// ------------------------------------------------------------------ PHM (Compacter)
+struct PhmDesc {      // mirrors a4r_phm_desc_t
+    int64_t rule_off, wl_off, wr_off;     // fp32 offsets into `params`: rule [n, n, n], W_left [n, in/n], W_right [n, out/n]
+    int64_t out_off;                      // build: offset of E [out, in] in `eff`;  backward: unused
+    const float* G; int32_t ldg;          // backward: dL/dE, row stride ldg (zero-padded scratch of the weight-gradient GEMM)
+    int32_t in_f, out_f, n, pad_;
+};
+
+// E[b * oq + q][a * ip + p] = sum_k rule[k][a][b] Wl[k][p] Wr[k][q]            one workgroup per PHMLinear
+__global__ void __launch_bounds__(256) phm_build_kernel(const float* __restrict__ params, const PhmDesc* __restrict__ desc, float* __restrict__ eff) {
+    const PhmDesc d = desc[blockIdx.x];
+    const int n = d.n, ip = d.in_f / n, oq = d.out_f / n;
+    const float* rule = params + d.rule_off;
+    const float* wl = params + d.wl_off;
+    const float* wr = params + d.wr_off;
+    float* E = eff + d.out_off;
+    const int total = d.in_f * d.out_f;
+    for (int e = threadIdx.x; e < total; e += 256) {
+        const int o = e / d.in_f, i = e % d.in_f;
+        const int b = o / oq, q = o % oq, a = i / ip, p = i % ip;
+        float acc = 0.f;
+        for (int k = 0; k < n; ++k) acc += rule[(k * n + a) * n + b] * wl[k * ip + p] * wr[k * oq + q];
+        E[e] = acc;
+    }
+}
+
+// d rule[k][a][b] += sum_{p,q} G[b oq + q][a ip + p] Wl[k][p] Wr[k][q]
+// d Wl[k][p]      += sum_{a,b,q} G[.][.] rule[k][a][b] Wr[k][q]        d Wr[k][q] += sum_{a,b,p} G[.][.] rule[k][a][b] Wl[k][p]
+// through T[a][b][p][k'] := sum_q G[b oq + q][a ip + p] Wr[k'][q]  (LDS-free: recomputed per output; the matrices are <= 768 x 64)
+__global__ void __launch_bounds__(256) phm_bwd_kernel(const float* __restrict__ params, const PhmDesc* __restrict__ desc, float* __restrict__ grads) {
+    const PhmDesc d = desc[blockIdx.x];
+    const int n = d.n, ip = d.in_f / n, oq = d.out_f / n;
+    const float* rule = params + d.rule_off;
+    const float* wl = params + d.wl_off;
+    const float* wr = params + d.wr_off;
+    const float* G = d.G;
+    const int n_rule = n * n * n, n_wl = n * ip, n_wr = n * oq;
+    for (int w = threadIdx.x; w < n_rule + n_wl + n_wr; w += 256) {
+        float acc = 0.f;
+        if (w < n_rule) {
+            const int k = w / (n * n), a = (w / n) % n, b = w % n;
+            for (int q = 0; q < oq; ++q) {
+                const float* g = G + (size_t)(b * oq + q) * d.ldg + a * ip;
+                float t = 0.f;
+                for (int p = 0; p < ip; ++p) t += g[p] * wl[k * ip + p];
+                acc += t * wr[k * oq + q];
+            }
+            atomicAdd(grads + d.rule_off + w, acc);
+        } else if (w < n_rule + n_wl) {
+            const int k = (w - n_rule) / ip, p = (w - n_rule) % ip;
+            for (int a = 0; a < n; ++a)
+                for (int b = 0; b < n; ++b) {
+                    float t = 0.f;
+                    for (int q = 0; q < oq; ++q) t += G[(size_t)(b * oq + q) * d.ldg + a * ip + p] * wr[k * oq + q];
+                    acc += t * rule[(k * n + a) * n + b];
+                }
+            atomicAdd(grads + d.wl_off + (w - n_rule), acc);
+        } else {
+            const int k = (w - n_rule - n_wl) / oq, q = (w - n_rule - n_wl) % oq;
+            for (int a = 0; a < n; ++a)
+                for (int b = 0; b < n; ++b) {
+                    const float* g = G + (size_t)(b * oq + q) * d.ldg + a * ip;
+                    float t = 0.f;
+                    for (int p = 0; p < ip; ++p) t += g[p] * wl[k * ip + p];
+                    acc += t * rule[(k * n + a) * n + b];
+                }
+            atomicAdd(grads + d.wr_off + (w - n_rule - n_wl), acc);
+        }
+    }
+}
+
+// ------------------------------------------------------------------ scratch corner -> flat gradient
+struct AddDesc {      // mirrors a4r_add_desc_t
+    const float* src; int64_t dst_off; int32_t rows, cols, ld; float alpha;
+};
+__global__ void __launch_bounds__(256) unpack_add_kernel(float* __restrict__ target, const AddDesc* __restrict__ desc) {
+    const AddDesc d = desc[blockIdx.y];
+    const int total = d.rows * d.cols;
+    for (int e = blockIdx.x * 256 + threadIdx.x; e < total; e += gridDim.x * 256) {
+        const int r = e / d.cols, c = e % d.cols;
+        target[d.dst_off + e] += d.alpha * d.src[(size_t)r * d.ld + c];
+    }
+}
+
+}  // namespace
+
+extern "C" int a4r_lora_merge(void* stream, const float* W, const float* A, const float* B, float scaling,
+                              void* dst, int ld, void* dstT, int ldT, int out_f, int in_f, int r, int dtype) {
+    if (!W || !dst || !dstT || out_f <= 0 || in_f <= 0 || r < 0 || (r > 0 && (!A || !B)) || ld < in_f || ldT < out_f) return A4R_EINVAL;
+    if (dtype != A4R_BF16 && dtype != A4R_F32) return A4R_EINVAL;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    int grid = (out_f * in_f + 255) / 256; if (grid > 1024) grid = 1024;
+    if (dtype == A4R_BF16)
+        hipLaunchKernelGGL(lora_merge_kernel<bf16_t>, dim3(grid), dim3(256), 0, s, W, A, B, scaling, (bf16_t*)dst, ld, (bf16_t*)dstT, ldT, out_f, in_f, r);
+    else
+        hipLaunchKernelGGL(lora_merge_kernel<float>, dim3(grid), dim3(256), 0, s, W, A, B, scaling, (float*)dst, ld, (float*)dstT, ldT, out_f, in_f, r);
+    return a4r_launch_status();
+}
+
+extern "C" int a4r_phm_build(void* stream, const float* params, const a4r_phm_desc_t* desc_dev, int n_desc, float* eff) {
+    if (!params || !desc_dev || n_desc <= 0 || !eff) return A4R_EINVAL;
+    hipLaunchKernelGGL(phm_build_kernel, dim3(n_desc), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), params,
+                       reinterpret_cast<const PhmDesc*>(desc_dev), eff);
+    return a4r_launch_status();
+}
+
+extern "C" int a4r_phm_bwd(void* stream, const float* params, const a4r_phm_desc_t* desc_dev, int n_desc, float* grads) {
+    if (!params || !desc_dev || n_desc <= 0 || !grads) return A4R_EINVAL;
+    hipLaunchKernelGGL(phm_bwd_kernel, dim3(n_desc), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), params,
+                       reinterpret_cast<const PhmDesc*>(desc_dev), grads);
+    return a4r_launch_status();
+}
+
+extern "C" int a4r_unpack_add(void* stream, float* target, const a4r_add_desc_t* desc_dev, int n_desc, int max_elems) {
+    if (!target || !desc_dev || n_desc <= 0 || max_elems <= 0) return A4R_EINVAL;
+    int gx = (max_elems + 255) / 256; if (gx > 64) gx = 64;
+    hipLaunchKernelGGL(unpack_add_kernel, dim3(gx, n_desc), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), target,
+                       reinterpret_cast<const AddDesc*>(desc_dev));
+    return a4r_launch_status();
+}
+
+extern "C" int a4r_memset_zero(void* stream, void* p, int64_t bytes) {
+    if (!p || bytes <= 0) return A4R_EINVAL;
+    return hipMemsetAsync(p, 0, (size_t)bytes, reinterpret_cast<hipStream_t>(stream)) == hipSuccess ? A4R_OK : A4R_ELAUNCH;
+}

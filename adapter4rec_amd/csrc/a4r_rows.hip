@@ -349,6 +349,22 @@ __global__ void __launch_bounds__(256) rows_copy_kernel(const T* __restrict__ in
     }
 }
 
+// out[r] = in[r / step] if r % step == 0 and r / step < n else 0, for r < fill_rows
+template <typename T>
+__global__ void __launch_bounds__(256) scatter_fill_kernel(const T* __restrict__ in, int ldi, T* __restrict__ out, int ldo,
+                                                           int n, int row_step, int H, int fill_rows) {
+    constexpr int PER = Elem<T>::PER16;
+    const int cpr = H / PER;
+    const size_t total = (size_t)fill_rows * cpr;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const size_t r = i / cpr;
+        const int c = (int)(i % cpr) * PER;
+        uint4 v = make_uint4(0u, 0u, 0u, 0u);
+        if (r % row_step == 0 && r / row_step < (size_t)n) v = *reinterpret_cast<const uint4*>(in + (r / row_step) * ldi + c);
+        *reinterpret_cast<uint4*>(out + r * ldo + c) = v;
+    }
+}
+
 template <typename T>
 __global__ void __launch_bounds__(256) dropout_apply_kernel(const T* __restrict__ x, int ldx, T* __restrict__ y, int ldy, int M, int N,
                                                             uint64_t seed, uint32_t site, uint32_t thr16, float scale) {
@@ -521,6 +537,18 @@ extern "C" int a4r_gather_rows(void* stream, const void* in, int ldi, void* out,
 }
 extern "C" int a4r_scatter_rows(void* stream, const void* in, int ldi, void* out, int ldo, int n, int row_step, int H, int dtype) {
     return rows_copy(stream, in, ldi, out, ldo, n, row_step, H, dtype, true);
+}
+
+extern "C" int a4r_scatter_rows_fill(void* stream, const void* in, int ldi, void* out, int ldo, int n, int row_step, int H, int dtype, int fill_rows) {
+    if (!in || !out || bad_dtype(dtype) || n <= 0 || row_step <= 0 || H <= 0 || fill_rows < (n - 1) * row_step + 1) return A4R_EINVAL;
+    const int esz = dtype == A4R_F32 ? 4 : 2, per = 16 / esz;
+    if (H % per || (ldi * esz) % 16 || (ldo * esz) % 16 || misaligned(in) || misaligned(out)) return A4R_EINVAL;
+    const size_t total = (size_t)fill_rows * (H / per);
+    int grid = (int)((total + 255) / 256); if (grid > 4096) grid = 4096;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    if (dtype == A4R_BF16) hipLaunchKernelGGL(scatter_fill_kernel<bf16_t>, dim3(grid), dim3(256), 0, s, (const bf16_t*)in, ldi, (bf16_t*)out, ldo, n, row_step, H, fill_rows);
+    else hipLaunchKernelGGL(scatter_fill_kernel<float>, dim3(grid), dim3(256), 0, s, (const float*)in, ldi, (float*)out, ldo, n, row_step, H, fill_rows);
+    return a4r_launch_status();
 }
 
 extern "C" int a4r_act_bwd_f32(void* stream, const float* dy, const float* pre, float* dx, int64_t n, int act) {

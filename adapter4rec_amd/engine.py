@@ -85,9 +85,14 @@ class _Adapter:
         eng.add_pack_bias(b_down, self.bd)
         # scratch for padded weight gradients (used when d < dp, or for virtual matrices)
         direct = self.virtual is None and self.d == self.dp
-        self.s_wd = None if direct else torch.zeros(self.dp, width, dtype=torch.float32, device=dev)
-        self.s_wu = None if direct else torch.zeros(width, self.dp, dtype=torch.float32, device=dev)
-        self.s_bd = None if self.d == self.dp else torch.zeros(self.dp, dtype=torch.float32, device=dev)
+        self.s_wd = None if direct else eng.scratch(self.dp, width)
+        self.s_wu = None if direct else eng.scratch(width, self.dp)
+        self.s_bd = None if self.d == self.dp else eng.scratch(1, self.dp)[0]
+        if self.virtual is None and not direct:          # the valid corners go into the flat gradient at the end of backward
+            eng.add_corner(self.s_wu, self.p_wu, width, self.d)
+            eng.add_corner(self.s_wd, self.p_wd, self.d, width)
+        if self.s_bd is not None:
+            eng.add_corner(self.s_bd.view(1, -1), b_down, 1, self.d)
 
 
 class _Lora:
@@ -109,8 +114,10 @@ class _Lora:
         eng.add_pack(mod.lora_A, self.A, False)
         eng.add_pack(mod.lora_B, self.BT, True)
         self.g_A, self.g_B = eng.grad_view(mod.lora_A), eng.grad_view(mod.lora_B)
-        self.s_A = torch.zeros(self.rp, width, dtype=torch.float32, device=dev)
-        self.s_B = torch.zeros(width, self.rp, dtype=torch.float32, device=dev)
+        self.s_A = eng.scratch(self.rp, width)
+        self.s_B = eng.scratch(width, self.rp)
+        eng.add_corner(self.s_B, mod.lora_B, width, self.r, alpha=self.scaling)      # dB = (dq^T t) s
+        eng.add_corner(self.s_A, mod.lora_A, self.r, width)
 
     def merged(self):
         m = self.mod
@@ -146,7 +153,9 @@ class _Dense:
             self.w[:out_f, :in_f].copy_(w2.to(dt))
             self.wT[:in_f, :out_f].copy_(w2.t().to(dt))
         self.g_w = eng.grad_view(weight)
-        self.s_w = torch.zeros(self.w.shape, dtype=torch.float32, device=eng.dev) if (padded and self.g_w is not None) else None
+        self.s_w = eng.scratch(*self.w.shape) if (padded and self.g_w is not None) else None
+        if self.s_w is not None:
+            eng.add_corner(self.s_w, weight, out_f, in_f)
         self.b = self.g_b = self.s_b = None
         if bias is not None:
             if b_dst is None and padded:
@@ -161,7 +170,8 @@ class _Dense:
                 self.b = bias.data if bias.requires_grad else eng._f32(bias)     # trainable: the fp32 master (a flat_p view) itself
             self.g_b = eng.grad_view(bias)
             if padded and self.g_b is not None:
-                self.s_b = torch.zeros(self.w.shape[0], dtype=torch.float32, device=eng.dev)
+                self.s_b = eng.scratch(1, self.w.shape[0])[0]
+                eng.add_corner(self.s_b.view(1, -1), bias, 1, out_f)
         self.trainable = self.g_w is not None or self.g_b is not None
 
 
@@ -190,6 +200,7 @@ class TransRecEngine:
         self.seed = int(getattr(args, 'dropout_seed', 0x5eed))
         self.step_count = 0
         self._packs_T, self._packs_b, self._virtual = [], [], []
+        self._arena, self._arena_used, self._corners, self._corner_tab = [], 0, [], None
         # one-launch adapter + residual + LayerNorm kernels (a4r_adapter_fused.hip); A4R_FUSE_ADAPTERS=0: the three-launch forms (A/B runs, tests)
         self.fuse_adapters = bool(int(_os.environ.get('A4R_FUSE_ADAPTERS', '1'))) and bool(getattr(args, 'fuse_adapters', True))
         self._collect_trainables()
@@ -278,6 +289,37 @@ class TransRecEngine:
         shape = tuple(p.shape)
         return lambda: self._grad_target[off:off + n].view(shape)
 
+    ARENA = 4 << 20          # fp32 elements per chunk of the gradient-scratch arena (16 MiB)
+
+    def scratch(self, rows, cols):
+        """Zero-padded fp32 scratch matrix for a weight-gradient GEMM whose true shape is not a tile multiple.  All of them live in a
+        few large chunks: ONE memset per chunk clears them at the start of backward, ONE a4r_unpack_add launch at its end adds the
+        valid corners into the flat gradient (they used to be a zero_() and an add_() per matrix per step)."""
+        n = pad_to(rows * cols, 4)
+        if not self._arena or self._arena_used + n > self._arena[-1].numel():
+            self._arena.append(torch.zeros(max(self.ARENA, n), dtype=torch.float32, device=self.dev))
+            self._arena_used = 0
+        t = self._arena[-1][self._arena_used:self._arena_used + rows * cols].view(rows, cols)
+        self._arena_used += n
+        return t
+
+    def add_corner(self, src, p, rows, cols, alpha=1.0):
+        if p.requires_grad:
+            self._corners.append((src, p, rows, cols, float(alpha)))
+
+    def _zero_scratch(self):
+        for c in self._arena:
+            L.zero(c)
+
+    def _flush_corners(self):
+        if not self._corners:
+            return
+        if self._corner_tab is None:
+            ents = [L.AddDesc(src.data_ptr(), self.offsets[id(p)][0], rows, cols, src.stride(0), alpha) for src, p, rows, cols, alpha in self._corners]
+            self._corner_tab = (L.desc_table(ents, self.dev), len(ents), max(r * c for _, _, r, c, _ in self._corners))
+        tab, n, mx = self._corner_tab
+        L.unpack_add(self._grad_target, tab, n, mx)
+
     def add_pack(self, p, dst, transpose):
         self._packs_T.append((p, dst, transpose))
 
@@ -353,30 +395,41 @@ class TransRecEngine:
                 idx = [i for i, (_, d, _) in enumerate(ents) if code(d) == c]
                 if idx:
                     self._tabs_virt.append(table([ents[i] for i in idx], [offs[i] for i in idx]) + (c,))
+        # a4r_phm_build / a4r_phm_bwd descriptors: two PHMLinear per virtual adapter (down: [d, width] at v_off, up: [width, d] after it)
+        self._phm_tab, self._phm_n = None, 0
+        if self._virtual:
+            leaves = [q for a in self._virtual for lin in a.virtual for q in (lin.phm_rule, lin.W_left, lin.W_right)]
+            if all(q.requires_grad for q in leaves):
+                off = lambda q: self.offsets[id(q)][0]
+                ents = []
+                for a in self._virtual:
+                    dn, up = a.virtual
+                    ents.append(L.PhmDesc(off(dn.phm_rule), off(dn.W_left), off(dn.W_right), a.v_off, a.s_wd.data_ptr(), a.s_wd.stride(0),
+                                          dn.in_features, dn.out_features, dn.phm_dim, 0))
+                    ents.append(L.PhmDesc(off(up.phm_rule), off(up.W_left), off(up.W_right), a.v_off + a.d * a.width, a.s_wu.data_ptr(),
+                                          a.s_wu.stride(0), up.in_features, up.out_features, up.phm_dim, 0))
+                self._phm_tab, self._phm_n = L.desc_table(ents, self.dev), len(ents)
+            elif any(q.requires_grad for q in leaves):
+                raise NotImplementedError('Compacter tensors must be trainable (or frozen) together')
 
     def pack_trainables(self):
         """Refresh the kernel-side copies of the trainable matrices (call after every optimiser step)."""
         for tab, n, mx, c in self._tabs:
             L.pack_matrices(self.flat_p, tab, n, mx, c)
-        for blk in self.bert_blocks + self.sas_blocks:        # LoRA: re-merge W + B A / r into the packed qkv operand
+        for blk in self.bert_blocks + self.sas_blocks:        # LoRA: re-merge W + B A / r into the packed qkv operand (a4r_lora_merge)
             for lo in blk.lora:
-                H, sl = blk.H, lo.slot
-                w = lo.merged()
-                blk.wqkv[sl * H:(sl + 1) * H].copy_(w)
-                blk.wqkvT[:, sl * H:(sl + 1) * H].copy_(w.t())
-                if lo.mod.bias is not None:
-                    blk.bqkv[sl * H:(sl + 1) * H].copy_(lo.mod.bias.detach())
-        self._virt_graph = None
+                H, sl, m = blk.H, lo.slot, lo.mod
+                L.lora_merge(m.weight.data, m.lora_A.data if lo.r else None, m.lora_B.data if lo.r else None, lo.scaling,
+                             blk.wqkv[sl * H:(sl + 1) * H], blk.wqkvT[:, sl * H:(sl + 1) * H], lo.r)
         if self._virtual:
-            effs = []
-            with torch.enable_grad():
-                for a in self._virtual:
-                    wd, wu = a.virtual[0].effective_weight(), a.virtual[1].effective_weight()
-                    effs += [wd, wu]
-                    n = a.d * a.width
-                    self._virt_flat[a.v_off:a.v_off + n].copy_(wd.detach().reshape(-1))
-                    self._virt_flat[a.v_off + n:a.v_off + 2 * n].copy_(wu.detach().reshape(-1))
-            self._virt_graph = effs
+            if self._phm_tab is not None:                     # Compacter: effective matrices from (phm_rule, W_left, W_right), one launch
+                L.phm_build(self.flat_p, self._phm_tab, self._phm_n, self._virt_flat)
+            else:                                             # frozen Compacter tensors (inference snapshot): not in the flat buffer
+                with torch.no_grad():
+                    for a in self._virtual:
+                        n = a.d * a.width
+                        self._virt_flat[a.v_off:a.v_off + n].copy_(a.virtual[0].effective_weight().reshape(-1))
+                        self._virt_flat[a.v_off + n:a.v_off + 2 * n].copy_(a.virtual[1].effective_weight().reshape(-1))
             for tab, n, mx, c in self._tabs_virt:
                 L.pack_matrices(self._virt_flat, tab, n, mx, c)
 
@@ -483,6 +536,7 @@ class TransRecEngine:
             b.wqkv = torch.zeros(3 * H, H, dtype=self.T, device=self.dev)
             b.wqkvT = torch.zeros(H, 3 * H, dtype=self.T, device=self.dev)
             b.bqkv = torch.zeros(3 * H, dtype=torch.float32, device=self.dev)
+            self._pack_lora_bias(b, H)
             b.qkv = tuple(None if type(lin).__name__ == 'LoRALinear' else          # LoRA slots are merged in pack_trainables
                           _Dense(self, lin.weight, lin.bias, self.T, b.wqkv[sl * H:(sl + 1) * H], b.wqkvT[:, sl * H:(sl + 1) * H],
                                  b.bqkv[sl * H:(sl + 1) * H])
@@ -577,6 +631,7 @@ class TransRecEngine:
         b.wqkv = torch.zeros(3 * H, H, dtype=dt, device=self.dev)
         b.wqkvT = torch.zeros(H, 3 * H, dtype=dt, device=self.dev)
         b.bqkv = torch.zeros(3 * H, dtype=torch.float32, device=self.dev) if b.lora else None       # lora.Linear carries a bias
+        self._pack_lora_bias(b, H)
         b.qkv = tuple(None if type(lin).__name__ == 'LoRALinear' else
                       _Dense(self, lin.weight, None, dt, b.wqkv[sl * H:(sl + 1) * H], b.wqkvT[:, sl * H:(sl + 1) * H])
                       for sl, lin in enumerate((mha.w_Q, mha.w_K, mha.w_V)))
@@ -593,6 +648,12 @@ class TransRecEngine:
         b.need_dx = True
         b.T = dt
         return b
+
+    def _pack_lora_bias(self, b, H):
+        """lora.Linear keeps a (trainable) bias: its fp32 master is copied into the fused qkv bias by the per-step pack launch."""
+        for lo in b.lora:
+            if lo.mod.bias is not None:
+                self.add_pack_bias(lo.mod.bias, b.bqkv[lo.slot * H:(lo.slot + 1) * H])
 
     def _make_kadapter(self, mod, width, S, dt, site):
         k = _KAdapter()
@@ -754,7 +815,7 @@ class TransRecEngine:
         ph = blk.p_hidden if train else 0.0
         L.gemm_nt(x, blk.wqkv, bufs['qkv'], bias=blk.bqkv, M=M)
         if 'xin' in bufs:
-            bufs['xin'].copy_(x)                     # LoRA backward needs the block input (t = x A^T, dA = dt^T x)
+            L.gather_rows(x, bufs['xin'], M, 1)      # LoRA backward needs the block input (t = x A^T, dA = dt^T x)
         ctx = self._buf('ctx', M, H, T)
         L.attn_fwd(bufs['qkv'], ctx, key_mask, n_items, blk.S, blk.nh, blk.dh, 0, H, 2 * H, blk.causal, blk.scale, blk.mask_neg,
                    drop_p=pa, drop_site=blk.site, drop_seed=seed)
@@ -764,7 +825,7 @@ class TransRecEngine:
             L.gather_rows(x, x_c, n_items, blk.S)
             ctx, x, M = ctx_c, x_c, cls_rows
         if 'ctx_s' in bufs:
-            bufs['ctx_s'][:M].copy_(ctx[:M])
+            L.gather_rows(ctx, bufs['ctx_s'], M, 1)
         x1 = self._buf('x1', M, H, T)
         x1 = bufs['x1s'] if 'x1s' in bufs else x1
         self._sub_forward(blk, '1', ctx, blk.wo, blk.bo, x, blk.ln1, blk.ad1, blk.pl1, blk.lnn1, bufs, M, ph, blk.site + 1, seed, x1)
@@ -848,13 +909,8 @@ class TransRecEngine:
         dt = self._buf('lora_dt', M, lo.rp, T)
         L.gemm_nt(x, lo.A, t, M=M)                               # t  = x A^T
         L.gemm_nt(dq, lo.BT, dt, alpha=lo.scaling, M=M)          # dt = (dq B) s
-        lo.s_A.zero_()
-        lo.s_B.zero_()
-        L.gemm_tn(dq, t, lo.s_B, M=M)                            # dB = dq^T t s
-        L.gemm_tn(dt, x, lo.s_A, M=M)                            # dA = dt^T x
-        if lo.g_B is not None:
-            lo.g_B().add_(lo.s_B[:, :lo.r], alpha=lo.scaling)
-            lo.g_A().add_(lo.s_A[:lo.r])
+        L.gemm_tn(dq, t, lo.s_B, M=M)                            # dB = dq^T t s   (scratch: cleared at the start of backward, its valid
+        L.gemm_tn(dt, x, lo.s_A, M=M)                            # dA = dt^T x      corner added to the flat gradient by _flush_corners)
 
     WGRAD_SIDE_OK = True            # the text tower's backward joins the side stream before dv / dzp are reused (_sub_backward)
 
@@ -886,29 +942,14 @@ class TransRecEngine:
             self._wdone = self._wev[1]
             self._wev.reverse()
             if ad.g_bd is not None and ad.s_bd is not None:
-                self._wgrad_join()
-                ad.s_bd.zero_()
                 L.colsum(dzp, ad.s_bd, M=M)
-                ad.g_bd().add_(ad.s_bd[:ad.d])
             return
-        if ad.s_wu is None:
-            L.gemm_tn(dv, z, ad.g_wu(), M=M)
-            L.gemm_tn(dzp, down_in, ad.g_wd(), M=M)
-        else:
-            ad.s_wu.zero_()
-            ad.s_wd.zero_()
-            L.gemm_tn(dv, z, ad.s_wu, M=M)
-            L.gemm_tn(dzp, down_in, ad.s_wd, M=M)
-            if ad.virtual is None:
-                ad.g_wu().add_(ad.s_wu[:, :ad.d])
-                ad.g_wd().add_(ad.s_wd[:ad.d])
+        # zero-padded (d < 64) or virtual (Compacter) matrices: into the scratch arena (cleared at the start of backward; the valid
+        # corners reach the flat gradient through _flush_corners / a4r_phm_bwd at its end)
+        L.gemm_tn(dv, z, ad.s_wu if ad.s_wu is not None else ad.g_wu(), M=M)
+        L.gemm_tn(dzp, down_in, ad.s_wd if ad.s_wd is not None else ad.g_wd(), M=M)
         if ad.g_bd is not None:
-            if ad.s_bd is None:
-                L.colsum(dzp, ad.g_bd(), M=M)
-            else:
-                ad.s_bd.zero_()
-                L.colsum(dzp, ad.s_bd, M=M)
-                ad.g_bd().add_(ad.s_bd[:ad.d])
+            L.colsum(dzp, ad.s_bd if ad.s_bd is not None else ad.g_bd(), M=M)
 
     def _block_backward(self, blk, dx_out, key_mask, n_items, M, bufs, train, seed, dx_in, cls_rows=None):
         T, H, F = blk.T, blk.H, blk.F
@@ -934,12 +975,10 @@ class TransRecEngine:
         if cls_rows is not None:                   # back to token rows: gradients live on the CLS rows only
             M = M_full
             full = self._buf('dctx', M, H, T)
-            full.zero_()
-            L.scatter_rows(dctx, full, n_items, blk.S)
+            L.scatter_rows_fill(dctx, full, n_items, blk.S, M)          # CLS rows written, every other row zeroed, one pass
             dctx = full
             rfull = self._buf('dres_full', M, H, T)
-            rfull.zero_()
-            L.scatter_rows(dres1, rfull, n_items, blk.S)
+            L.scatter_rows_fill(dres1, rfull, n_items, blk.S, M)
             dres1 = rfull
         dqkv = self._buf_tail0('dqkv', M, 3 * H, T, n_items * blk.S)       # attn_bwd writes the real token rows only
         L.attn_bwd(bufs['qkv'], dctx, dqkv, key_mask, n_items, blk.S, blk.nh, blk.dh, 0, H, 2 * H, blk.causal, blk.scale, blk.mask_neg,
@@ -956,19 +995,9 @@ class TransRecEngine:
         if d is None or not d.trainable:
             return
         if d.g_w is not None:
-            if d.s_w is None:
-                L.gemm_tn(dy, x, d.g_w().view(d.out_f, d.in_f), M=M)
-            else:                                   # zero-padded storage: accumulate into a scratch, add the valid corner
-                d.s_w.zero_()
-                L.gemm_tn(dy, x, d.s_w, M=M)
-                d.g_w().view(d.out_f, d.in_f).add_(d.s_w[:d.out_f, :d.in_f])
+            L.gemm_tn(dy, x, d.s_w if d.s_w is not None else d.g_w().view(d.out_f, d.in_f), M=M)       # (zero-padded storage: scratch + corner)
         if d.g_b is not None:
-            if d.s_b is None:
-                L.colsum(dy, d.g_b(), M=M)
-            else:
-                d.s_b.zero_()
-                L.colsum(dy, d.s_b, M=M)
-                d.g_b().add_(d.s_b[:d.out_f])
+            L.colsum(dy, d.s_b if d.s_b is not None else d.g_b(), M=M)
 
     # ------------------------------------------------------------------ K-Adapter chains
     def _kad_chain_forward(self, x_last, n_items, M, Ip, train, seed, cls, keep):
@@ -1154,7 +1183,7 @@ class TransRecEngine:
         pos = self._buf('pos', B, self.Lseq - 1, torch.float32)
         neg = self._buf('neg', B, self.Lseq - 1, torch.float32)
         ws = self._buf('lossws', 1, 4, torch.float32)
-        ws.zero_()
+        L.zero(ws)
         L.score_bce_fwd(emb, prec, lm, pos, neg, ws, B, self.Lseq, self.E, self.arch == 'cpc')
         self._ctx = dict(B=B, n_items=n_items, M=M, Mu=Mu, seed=seed, train=train, lm=lm, key_mask=key_mask, emb=emb, pre=pre,
                          prec=prec, xin=xin, pos=pos, neg=neg, ws=ws, saved_b=saved_b, saved_s=saved_s)
@@ -1194,6 +1223,7 @@ class TransRecEngine:
         if not into_flat_grad:
             target.zero_()
         self._grad_target = target
+        self._zero_scratch()
         if grad_out is not None:
             grad_out = grad_out.detach().to(torch.float32).reshape(1)
         B, n_items, M, Mu, seed = c['B'], c['n_items'], c['M'], c['Mu'], c['seed']
@@ -1236,6 +1266,7 @@ class TransRecEngine:
         L.emb_grad_add_inputs(d_in, d_emb, B, self.Lseq, E)
         self._items_backward(c, d_emb, Ip)
         self._wgrad_join()
+        self._flush_corners()
         if self._virtual:
             self._virtual_backward()
         if into_flat_grad or not as_list:
@@ -1266,8 +1297,7 @@ class TransRecEngine:
             if not (self.bert_trains or self.train_emb):
                 return                             # frozen backbone: nothing trainable lies upstream of its activations
         elif not self.cls_only:
-            dxb.zero_()
-            L.scatter_rows(dcls, dxb, n_items, self.S)
+            L.scatter_rows_fill(dcls, dxb, n_items, self.S, M)
         spare = self._buf('dx_b', M, self.H, self.T)
         last = len(self.bert_blocks) - 1
         for i in range(last, -1, -1):
@@ -1294,19 +1324,6 @@ class TransRecEngine:
                 L.colsum(dpre, self.g_type()[0], M=M)
 
     def _virtual_backward(self):
-        """Compacter: chain the gradients of the effective matrices into (phm_rule, W_left, W_right) with autograd."""
-        effs, gouts = self._virt_graph, []
-        for a in self._virtual:
-            gouts += [a.s_wd[:a.d].contiguous(), a.s_wu[:, :a.d].contiguous()]
-        leaves = []
-        for a in self._virtual:
-            for lin in a.virtual:
-                leaves += [lin.W_left, lin.W_right]
-        rule = self._virtual[0].virtual[0].phm_rule
-        leaves = [p for p in dict.fromkeys(leaves + [rule]) if p.requires_grad]
-        grads = torch.autograd.grad(effs, leaves, gouts, allow_unused=True)
-        for p, g in zip(leaves, grads):
-            if g is not None:
-                off, n = self.offsets[id(p)]
-                self._grad_target[off:off + n].add_(g.reshape(-1))
-        self._virt_graph = None
+        """Compacter: the gradients of the effective matrices (the zero-padded scratch of the weight-gradient GEMMs) chained into
+        (phm_rule, W_left, W_right) by one a4r_phm_bwd launch."""
+        L.phm_bwd(self.flat_p, self._phm_tab, self._phm_n, self._grad_target)

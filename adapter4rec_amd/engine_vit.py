@@ -84,6 +84,7 @@ class ViTRecEngine(TransRecEngine):
             b.wqkv = torch.zeros(3 * H, H, dtype=self.T, device=self.dev)
             b.wqkvT = torch.zeros(H, 3 * H, dtype=self.T, device=self.dev)
             b.bqkv = torch.zeros(3 * H, dtype=torch.float32, device=self.dev)
+            self._pack_lora_bias(b, H)
             b.qkv = tuple(None if type(lin).__name__ == 'LoRALinear' else
                           _Dense(self, lin.weight, lin.bias, self.T, b.wqkv[sl * H:(sl + 1) * H], b.wqkvT[:, sl * H:(sl + 1) * H],
                                  b.bqkv[sl * H:(sl + 1) * H])
@@ -196,7 +197,7 @@ class ViTRecEngine(TransRecEngine):
             L.gather_rows(x, x_c, n_items, blk.S)
             ctx, x, M = ctx_c, x_c, cls_rows
         if 'ctx_s' in bufs:
-            bufs['ctx_s'][:M].copy_(ctx[:M])
+            L.gather_rows(ctx, bufs['ctx_s'], M, 1)
         self._vit_sub_forward(blk.ad1, ctx, blk.wo, blk.bo, x, bufs, '1', M, bufs['x1'])
         u = bufs['u_s'] if 'u_s' in bufs else self._buf('u', M, blk.F, T)
         if self.fp8 and blk.wi8 is not None and M % 256 == 0:
@@ -261,12 +262,10 @@ class ViTRecEngine(TransRecEngine):
         if cls_rows is not None:             # back to token rows: the gradients live on the CLS rows only
             M = M_full
             full = self._buf('dctx', M, H, T)
-            full.zero_()
-            L.scatter_rows(dctx, full, n_items, blk.S)
+            L.scatter_rows_fill(dctx, full, n_items, blk.S, M)          # CLS rows written, every other row zeroed, one pass
             dctx = full
             rfull = self._buf('dres_full', M, H, T)
-            rfull.zero_()
-            L.scatter_rows(dx1, rfull, n_items, blk.S)
+            L.scatter_rows_fill(dx1, rfull, n_items, blk.S, M)
             dx1 = rfull
         dqkv = self._buf_tail0('dqkv', M, 3 * H, T, n_items * blk.S)       # attn_long_bwd writes the real token rows only
         ws = self._buf('attn_ws', bufs['lse'].shape[0], 1, torch.float32)
@@ -357,8 +356,7 @@ class ViTRecEngine(TransRecEngine):
                  dgamma=gg(self.vit_ln.g_gamma), dbeta=gg(self.vit_ln.g_beta))
         dxb = self._buf('dx_a', M, H, self.T)
         if not self.cls_only:
-            dxb.zero_()
-            L.scatter_rows(dcls, dxb, n_items, self.S)
+            L.scatter_rows_fill(dcls, dxb, n_items, self.S, M)
         spare = self._buf('dx_b', M, H, self.T)
         last = len(self.bert_blocks) - 1
         for i in range(last, -1, -1):

@@ -195,6 +195,9 @@ int a4r_ln_bwd(void* stream, const void* dy, int lddy, const void* v, int ldv, c
 /* out[i, :] = in[i * row_stride_rows, :] (CLS gather, model/encoders.py:55) and its scatter-transpose. */
 int a4r_gather_rows(void* stream, const void* in, int ldi, void* out, int ldo, int n, int row_step, int H, int dtype);
 int a4r_scatter_rows(void* stream, const void* in, int ldi, void* out, int ldo, int n, int row_step, int H, int dtype);
+/* the scatter that also ZEROES every other row of out[0 .. fill_rows): the gradient of a CLS gather is written in one pass
+ * (no separate fill of the [tokens, H] buffer) */
+int a4r_scatter_rows_fill(void* stream, const void* in, int ldi, void* out, int ldo, int n, int row_step, int H, int dtype, int fill_rows);
 
 /* y = x * keep_mask(seed, site, index) / (1 - p) elementwise on [M,N] (index = row * N + col): backward of a
  * dropout whose forward ran inside a GEMM epilogue, for the cases no GEMM sits behind it. */
@@ -234,6 +237,29 @@ typedef struct {
     int64_t src_off; void* dst; int32_t rows, cols, rows_pad, cols_pad, transpose, dst_ld;   /* dst_ld 0 = cols_pad */
 } a4r_pack_desc_t;
 int a4r_pack_matrices(void* stream, const float* flat, const a4r_pack_desc_t* desc_dev, int n_desc, int max_elems, int dtype);
+
+/* ---- parameter-side kernels (a4r_params.hip): what the reference leaves to eager torch ops on the parameter tensors ----
+ * a4r_lora_merge: dst[o, i] = dstT[i, o] = W[o, i] + scaling * sum_r B[o, r] A[r, i] (loralib lora.Linear, run.py:414-428): the
+ *   merged weight goes straight into the packed q / v rows of the fused qkv operand and its transpose (compute dtype), every step.
+ * a4r_phm_build / a4r_phm_bwd: Compacter (PHMLinear, model/layers.py:25-166): E[out, in] = (sum_k kron(rule[k], W_left[k] W_right[k]))^T
+ *   for n_desc PHMLinear instances in one launch, and the gradients of rule / W_left / W_right from dL/dE (+=, fp32 atomics; the
+ *   gradient buffer has the parameter buffer's layout).
+ * a4r_unpack_add: target[dst_off + r * cols + c] += alpha * src[r * ld + c]: the valid corners of zero-padded gradient scratch
+ *   matrices into the flat gradient buffer, one launch for all of them.
+ * a4r_memset_zero: hipMemsetAsync on the stream. */
+typedef struct {
+    int64_t rule_off, wl_off, wr_off;   /* fp32 element offsets in `params` (and in `grads`): rule [n,n,n], W_left [n, in/n], W_right [n, out/n] */
+    int64_t out_off;                    /* a4r_phm_build: offset of E [out, in] (row-major, ld = in) in `eff` */
+    const float* G; int32_t ldg;        /* a4r_phm_bwd: dL/dE [out, in], row stride ldg */
+    int32_t in_f, out_f, n, pad_;
+} a4r_phm_desc_t;
+typedef struct { const float* src; int64_t dst_off; int32_t rows, cols, ld; float alpha; } a4r_add_desc_t;
+int a4r_lora_merge(void* stream, const float* W, const float* A, const float* B, float scaling,
+                   void* dst, int ld, void* dstT, int ldT, int out_f, int in_f, int r, int dtype);
+int a4r_phm_build(void* stream, const float* params, const a4r_phm_desc_t* desc_dev, int n_desc, float* eff);
+int a4r_phm_bwd(void* stream, const float* params, const a4r_phm_desc_t* desc_dev, int n_desc, float* grads);
+int a4r_unpack_add(void* stream, float* target, const a4r_add_desc_t* desc_dev, int n_desc, int max_elems);
+int a4r_memset_zero(void* stream, void* p, int64_t bytes);
 
 /* Eval (data_utils/metrics.py:82-116): for user u with vector prec[u] (fp32 [U,E]) and item table
  * item_emb (fp32 [N1,E], row 0 = pad item): rank[u] = 1 + #{i in 1..N1-1, i not in hist(u),

@@ -17,7 +17,7 @@ ACT_NONE, ACT_RELU, ACT_GELU, ACT_GELU_TANH, ACT_LEAKY = 0, 1, 2, 3, 4
 DACT_MUL = 15
 EVAL_MAX_HISTORY = REAL.EVAL_MAX_HISTORY
 ACT_BY_NAME = REAL.ACT_BY_NAME
-PackDesc = REAL.PackDesc
+PackDesc, PhmDesc, AddDesc, desc_table = REAL.PackDesc, REAL.PhmDesc, REAL.AddDesc, REAL.desc_table
 
 
 def lib():
@@ -288,6 +288,64 @@ def ln_bwd(dy, v, stats, gamma, dv, M=None, add=None, dgamma=None, dbeta=None, d
     if dres is not None:
         g = g + dres[:M].float()
     dv[:M] = g.to(dv.dtype)
+
+
+def _f32_at(ptr, n):
+    """fp32 view of host memory at a raw address (the descriptor tables carry data_ptr()s of CPU tensors here)."""
+    import numpy as np
+    return torch.from_numpy(np.ctypeslib.as_array((ctypes.c_float * n).from_address(ptr)))
+
+
+def _parse(desc_dev, cls, n):
+    raw = bytes(desc_dev.numpy().tobytes())
+    return [cls.from_buffer_copy(raw[i * ctypes.sizeof(cls):(i + 1) * ctypes.sizeof(cls)]) for i in range(n)]
+
+
+def scatter_rows_fill(src, dst, n, row_step, fill_rows):
+    dst[:fill_rows] = 0
+    dst[0:n * row_step:row_step] = src[:n]
+
+
+def zero(t):
+    t.zero_()
+
+
+def lora_merge(W, A, B, scaling, dst, dstT, r):
+    w = W.float() + (scaling * (B.float() @ A.float()) if r else 0)
+    dst.copy_(w.to(dst.dtype))
+    dstT.copy_(w.t().to(dstT.dtype))
+
+
+def _phm_E(params, d):
+    n, ip, oq = d.n, d.in_f // d.n, d.out_f // d.n
+    rule = params[d.rule_off:d.rule_off + n ** 3].view(n, n, n)
+    wl = params[d.wl_off:d.wl_off + n * ip].view(n, ip)
+    wr = params[d.wr_off:d.wr_off + n * oq].view(n, oq)
+    return rule, wl, wr
+
+
+def phm_build(params, desc_dev, n_desc, eff):
+    for d in _parse(desc_dev, PhmDesc, n_desc):
+        rule, wl, wr = _phm_E(params, d)
+        E = torch.einsum('kab,kp,kq->bqap', rule, wl, wr).reshape(d.out_f, d.in_f)         # E[b oq + q][a ip + p]
+        eff[d.out_off:d.out_off + d.in_f * d.out_f] = E.reshape(-1)
+
+
+def phm_bwd(params, desc_dev, n_desc, grads):
+    for d in _parse(desc_dev, PhmDesc, n_desc):
+        n, ip, oq = d.n, d.in_f // d.n, d.out_f // d.n
+        rule, wl, wr = _phm_E(params, d)
+        G = _f32_at(d.G, (d.out_f - 1) * d.ldg + d.in_f)
+        G = torch.as_strided(G, (d.out_f, d.in_f), (d.ldg, 1)).reshape(n, oq, n, ip)      # [b, q, a, p]
+        grads[d.rule_off:d.rule_off + n ** 3] += torch.einsum('bqap,kp,kq->kab', G, wl, wr).reshape(-1)
+        grads[d.wl_off:d.wl_off + n * ip] += torch.einsum('bqap,kab,kq->kp', G, rule, wr).reshape(-1)
+        grads[d.wr_off:d.wr_off + n * oq] += torch.einsum('bqap,kab,kp->kq', G, rule, wl).reshape(-1)
+
+
+def unpack_add(target, desc_dev, n_desc, max_elems):
+    for d in _parse(desc_dev, AddDesc, n_desc):
+        src = torch.as_strided(_f32_at(d.src, (d.rows - 1) * d.ld + d.cols), (d.rows, d.cols), (d.ld, 1))
+        target[d.dst_off:d.dst_off + d.rows * d.cols] += d.alpha * src.reshape(-1)
 
 
 def dropout_apply(x, y, drop_p, drop_site, drop_seed, M=None):

@@ -809,6 +809,78 @@ def test_gemm_fp8_rejects():
         L.gemm_nt(A[:128], B, C[:128], scale_a=one, scale_b=one)     # M % 256
 
 
+# ------------------------------------------------------------------ parameter-side kernels (a4r_params.hip)
+@pytest.mark.parametrize('dt', ['bf16', 'f32'])
+@pytest.mark.parametrize('r', [0, 4, 8])
+def test_lora_merge(dt, r):
+    from adapter4rec_amd import _lib as L
+    t, H = DT[dt], 192
+    W, A, B = rnd(H, H, seed=1), rnd(max(r, 1), H, seed=2), rnd(H, max(r, 1), seed=3)
+    big, bigT = torch.zeros(3 * H, H, dtype=t, device=dev()), torch.zeros(H, 3 * H, dtype=t, device=dev())
+    L.lora_merge(W, A[:r] if r else None, B[:, :r].contiguous() if r else None, 1.0 / max(r, 1), big[H:2 * H], bigT[:, H:2 * H], r)
+    ref = W + (B[:, :r] @ A[:r]) / max(r, 1) if r else W
+    close(big[H:2 * H], ref, t, 'merged rows')
+    close(bigT[:, H:2 * H], ref.t(), t, 'merged transpose')
+    assert float(big[:H].abs().max()) == 0 and float(bigT[:, 2 * H:].abs().max()) == 0      # the neighbouring slots are untouched
+
+
+def test_phm_build_and_backward_vs_autograd():
+    """a4r_phm_build / a4r_phm_bwd vs the reference's construction (model/layers.py:10-22,150-160, kronecker.py:23-34) through
+    torch autograd: two PHMLinear (768 -> 64, 64 -> 768) sharing one rule, gradient matrices read from zero-padded scratch."""
+    from adapter4rec_amd import _lib as L
+    from adapter4rec_amd.model.modules import PHMLinear
+    n = 4
+    torch.manual_seed(5)
+    rule = torch.nn.Parameter(torch.randn(n, n, n) * 0.3)
+    mods = [PHMLinear(768, 48, n), PHMLinear(48, 768, n)]
+    for m in mods:
+        m.set_phm_rule(rule)
+    leaves = [rule] + [q for m in mods for q in (m.W_left, m.W_right)]
+    sizes = [q.numel() for q in leaves]
+    offs = [sum(sizes[:i]) for i in range(len(sizes))]
+    flat = torch.cat([q.detach().reshape(-1) for q in leaves]).to(dev())
+    eff = torch.zeros(2 * 768 * 48, device=dev())
+    G = [torch.randn(64, 768, device=dev()), torch.randn(768, 64, device=dev())]          # zero-padded scratch shapes (48 -> 64)
+    G[0][48:] = 0
+    G[1][:, 48:] = 0
+    ents = [L.PhmDesc(offs[0], offs[1], offs[2], 0, G[0].data_ptr(), G[0].stride(0), 768, 48, n, 0),
+            L.PhmDesc(offs[0], offs[3], offs[4], 768 * 48, G[1].data_ptr(), G[1].stride(0), 48, 768, n, 0)]
+    tab = L.desc_table(ents, dev())
+    L.phm_build(flat, tab, 2, eff)
+    E = [m.effective_weight() for m in mods]                     # [out, in]
+    close(eff[:768 * 48].view(48, 768), E[0].detach(), torch.float32, 'E down', atol32=1e-5)
+    close(eff[768 * 48:].view(768, 48), E[1].detach(), torch.float32, 'E up', atol32=1e-5)
+    grads = torch.zeros_like(flat)
+    L.phm_bwd(flat, tab, 2, grads)
+    ref = torch.autograd.grad(E, leaves, [G[0][:48].cpu(), G[1][:, :48].cpu().contiguous()])
+    for q, o, r in zip(leaves, offs, ref):
+        close(grads[o:o + q.numel()], r.reshape(-1), torch.float32, 'phm grad', atol32=2e-3 * max(1.0, float(r.abs().max())), rtol32=2e-3)
+
+
+def test_unpack_add_and_scatter_fill():
+    from adapter4rec_amd import _lib as L
+    a, b = rnd(64, 96, seed=1), rnd(1, 64, seed=2)
+    target = rnd(5000, seed=3)
+    before = target.clone()
+    ents = [L.AddDesc(a.data_ptr(), 100, 16, 80, a.stride(0), 0.5), L.AddDesc(b.data_ptr(), 3000, 1, 16, b.stride(0), 1.0)]
+    L.unpack_add(target, L.desc_table(ents, dev()), 2, 16 * 80)
+    exp = before.clone()
+    exp[100:100 + 16 * 80] += 0.5 * a[:16, :80].reshape(-1)
+    exp[3000:3016] += b[0, :16]
+    close(target, exp, torch.float32, 'unpack_add', atol32=1e-6)
+    for t in (torch.bfloat16, torch.float32):
+        src = rnd(40, 128, dtype=t, seed=4)
+        dst = rnd(40 * 7 + 56, 128, dtype=t, seed=5)
+        tail = dst[280:].clone()
+        L.scatter_rows_fill(src, dst, 40, 7, 280)
+        ref = torch.zeros(280, 128, dtype=t, device=dev())
+        ref[0:280:7] = src
+        assert torch.equal(dst[:280], ref) and torch.equal(dst[280:], tail)
+    z = rnd(1000, seed=6)
+    L.zero(z[100:200])
+    assert float(z[100:200].abs().max()) == 0 and float(z[:100].abs().min()) > 0
+
+
 def test_gemm_tail_panels_split_launch():
     """777 tiles on 256 CUs: the last 3 row panels are launched on the 128-tile kernel (a4r_gemm.hip); results and the dropout
     mask (drop_row0) must equal the single-kernel launch."""
