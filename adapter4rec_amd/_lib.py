@@ -271,13 +271,13 @@ def embed_bwd(ids, dpre, dword, dpos, n_items, S, roberta=False, pad_id=0):
 
 
 def embed_ln(ids, word, pos, type0, gamma, beta, eps, out, n_items, S, roberta=False, pad_id=0,
-             drop_p=0.0, drop_site=0, drop_seed=0, pre_out=None, stats_out=None):
+             drop_p=0.0, drop_site=0, drop_seed=0, pre_out=None, stats_out=None, key_mask_out=None):
     require_gpu(ids, word, out)
     assert ids.dtype == torch.int64 and ids.stride(1) == 1
     _check(lib().a4r_embed_ln(_stream(), _p(ids), C.c_int(ids.stride(0)), _p(word), _p(pos), _p(type0), _p(gamma), _p(beta),
                               C.c_float(eps), _p(out), C.c_int(_ld(out)), C.c_int(n_items), C.c_int(S), C.c_int(word.shape[1]),
                               C.c_int(int(roberta)), C.c_int(pad_id), C.c_int(_dt(out)),
-                              C.c_float(drop_p), C.c_uint32(drop_site), C.c_uint64(drop_seed), _p(pre_out), _p(stats_out)), 'a4r_embed_ln')
+                              C.c_float(drop_p), C.c_uint32(drop_site), C.c_uint64(drop_seed), _p(pre_out), _p(stats_out), _p(key_mask_out)), 'a4r_embed_ln')
 
 
 def quantize_weight_fp8(w):

@@ -72,12 +72,13 @@ __global__ void __launch_bounds__(256) embed_ln_kernel(const int64_t* __restrict
                                                        const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
                                                        T* __restrict__ out, int ldo, int n_rows, int S, int H, int roberta, int pad_id,
                                                        uint64_t seed, uint32_t site, uint32_t thr16, float scale,
-                                                       T* __restrict__ pre_out, float* __restrict__ stats_out) {
+                                                       T* __restrict__ pre_out, float* __restrict__ stats_out, float* __restrict__ kmask_out) {
     const int lane = threadIdx.x & 63;
     const int ng = H / 8;
     for (int row = blockIdx.x * 4 + (threadIdx.x >> 6); row < n_rows; row += gridDim.x * 4) {
         const int item = row / S, s = row % S;
         const int64_t* idr = ids + (size_t)item * ld_ids;
+        if (kmask_out && lane == 0) kmask_out[row] = (float)idr[S + s];       // the attention key mask: columns S .. 2S-1 of the ids || mask row
         // a NEGATIVE id -(r + 1) reads word row r but counts as a pad token for the position ids: a soft prompt replaces the word
         // vector of a title's first tokens, RoBERTa's positions still follow the ORIGINAL ids (pads inside a short title's prompt)
         const int64_t idraw = idr[s];
@@ -401,10 +402,10 @@ inline int row_grid(int rows) { int g = (rows + 3) / 4; return g > 2048 ? 2048 :
 extern "C" int a4r_embed_ln(void* stream, const int64_t* ids, int ld_ids, const float* word, const float* pos,
                             const float* type0, const float* gamma, const float* beta, float eps,
                             void* out, int ldo, int n_items, int S, int H, int roberta, int pad_id, int dtype,
-                            float drop_p, uint32_t drop_site, uint64_t drop_seed, void* pre_out, float* stats_out) {
+                            float drop_p, uint32_t drop_site, uint64_t drop_seed, void* pre_out, float* stats_out, float* key_mask_out) {
     if (!ids || !word || !pos || !type0 || !gamma || !beta || !out) return A4R_EINVAL;
     if (pre_out && misaligned(pre_out)) return A4R_EINVAL;
-    if (bad_dtype(dtype) || n_items <= 0 || S <= 0 || H <= 0 || H % 8 || H > 1024 || ld_ids < S) return A4R_EINVAL;
+    if (bad_dtype(dtype) || n_items <= 0 || S <= 0 || H <= 0 || H % 8 || H > 1024 || ld_ids < S || (key_mask_out && ld_ids < 2 * S)) return A4R_EINVAL;
     const int esz = dtype == A4R_F32 ? 4 : 2;
     if ((ldo * esz) % 16 || ldo < H || misaligned(out) || misaligned(word) || misaligned(pos) || misaligned(type0)) return A4R_EINVAL;
     if (drop_p < 0.f || drop_p >= 1.f) return A4R_EINVAL;
@@ -414,10 +415,10 @@ extern "C" int a4r_embed_ln(void* stream, const int64_t* ids, int ld_ids, const 
     const float sc = a4r_keep_scale(drop_p);
     if (dtype == A4R_BF16)
         hipLaunchKernelGGL(embed_ln_kernel<bf16_t>, dim3(row_grid(rows)), dim3(256), 0, s, ids, ld_ids, word, pos, type0, gamma, beta, eps,
-                           (bf16_t*)out, ldo, rows, S, H, roberta, pad_id, drop_seed, drop_site, thr, sc, (bf16_t*)pre_out, stats_out);
+                           (bf16_t*)out, ldo, rows, S, H, roberta, pad_id, drop_seed, drop_site, thr, sc, (bf16_t*)pre_out, stats_out, key_mask_out);
     else
         hipLaunchKernelGGL(embed_ln_kernel<float>, dim3(row_grid(rows)), dim3(256), 0, s, ids, ld_ids, word, pos, type0, gamma, beta, eps,
-                           (float*)out, ldo, rows, S, H, roberta, pad_id, drop_seed, drop_site, thr, sc, (float*)pre_out, stats_out);
+                           (float*)out, ldo, rows, S, H, roberta, pad_id, drop_seed, drop_site, thr, sc, (float*)pre_out, stats_out, key_mask_out);
     return a4r_launch_status();
 }
 

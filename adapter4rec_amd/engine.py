@@ -1048,8 +1048,7 @@ class TransRecEngine:
         """news [n, 2S] int64 (ids || mask) -> (emb fp32 [Ipad, E], pre fp32 [Ipad, E]) ; keeps x_final for backward."""
         S, H = self.S, self.H
         M = pad_to(n_items * S, 256)
-        key_mask = self._buf('kmask', n_items, S, torch.float32)
-        key_mask.copy_(news[:, S:2 * S])
+        key_mask = self._buf('kmask', n_items, S, torch.float32)          # filled by a4r_embed_ln from the mask half of the rows
         x = self._buf('xa', M, H, self.T)
         keep = self.train_emb and saved is not None
         word = self.emb_word
@@ -1066,7 +1065,7 @@ class TransRecEngine:
                    x, n_items, S, roberta=self.roberta, pad_id=self.pad_id,
                    drop_p=self.p_hidden if train else 0.0, drop_site=999, drop_seed=seed,
                    pre_out=self._buf('emb_pre', M, H, self.T) if keep else None,
-                   stats_out=self._buf('emb_st', M, 2, torch.float32) if keep else None)
+                   stats_out=self._buf('emb_st', M, 2, torch.float32) if keep else None, key_mask_out=key_mask)
         self._news = news
         other = self._buf('xb', M, H, self.T)
         Ip = pad_to(n_items, 128)
@@ -1128,6 +1127,9 @@ class TransRecEngine:
             x = y
         return x, Mu
 
+    def _pre_forward(self, n_items):
+        """torch-side preparation of a step that must sit BEFORE its first kernel (image tower: the ViT-MAE masking order)."""
+
     # ------------------------------------------------------------------ public: inference entry points
     @torch.no_grad()
     def encode_items(self, news):
@@ -1163,6 +1165,7 @@ class TransRecEngine:
         assert B * 2 * self.Lseq == n_items and log_mask.shape == (B, self.Lseq - 1)
         news = sample_items.contiguous()
         lm = log_mask.float().contiguous()
+        self._pre_forward(n_items)
         self.pack_trainables()
         self.step_count += 1
         seed = (self.seed * 1000003 + self.step_count) & 0xFFFFFFFFFFFF

@@ -292,6 +292,12 @@ class ViTRecEngine(TransRecEngine):
         L.require_gpu(noise)
         return torch.argsort(noise.float(), dim=1)[:, :self.n_keep].to(torch.int32).contiguous()
 
+    _keep = None
+
+    def _pre_forward(self, n_items):
+        # the ViT-MAE masking order (torch rand + argsort) is drawn before the step's first HIP kernel, not between pack and patchify
+        self._keep = self._keep_indices(n_items, self.next_noise)
+
     def _encode(self, images, n_items, train, seed, saved):
         S, H = self.S, self.H
         M = pad_to(n_items * S, 256)
@@ -303,8 +309,8 @@ class ViTRecEngine(TransRecEngine):
                 raise ValueError(f'images must be [n, {self.C}, {self.R}, {self.R}], got {tuple(images.shape)} (no in-engine resize)')
             images = images.float()
         images = images.contiguous()
-        keep = self._keep_indices(n_items, self.next_noise)
-        self.next_noise = None
+        keep = self._keep if self._keep is not None else self._keep_indices(n_items, self.next_noise)
+        self._keep, self.next_noise = None, None
         Mp = pad_to(n_items * self.n_keep, 256)
         cols = self.C * self.P * self.P
         pat = self._buf('patches', Mp, cols, self.T)

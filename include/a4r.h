@@ -160,8 +160,9 @@ int a4r_resample_u8(void* stream, const void* src, void* dst, const int32_t* bou
 int a4r_embed_ln(void* stream, const int64_t* ids, int ld_ids, const float* word, const float* pos,
                  const float* type0, const float* gamma, const float* beta, float eps,
                  void* out, int ldo, int n_items, int S, int H, int roberta, int pad_id, int dtype,
-                 float drop_p, uint32_t drop_site, uint64_t drop_seed, void* pre_out, float* stats_out);
-/* pre_out (optional, same dtype / ld as out): the embedding sum before the LayerNorm; stats_out (optional, fp32 [rows, 2]):
+                 float drop_p, uint32_t drop_site, uint64_t drop_seed, void* pre_out, float* stats_out, float* key_mask_out);
+/* key_mask_out (optional, fp32 [n_items, S]): the attention key mask = columns S .. 2S-1 of the ids || mask rows (Bert_Encoder splits
+ * them at encoders.py:48-57), converted in the same pass.  pre_out (optional, same dtype / ld as out): the embedding sum before the LayerNorm; stats_out (optional, fp32 [rows, 2]):
  * mean, rstd -- what a4r_ln_bwd needs when the embedding LayerNorm or tables are trained (--finetune_layernorm, --fine_tune_to all).
  * a4r_embed_bwd: the nn.Embedding backward: dword[id] += dpre[row], dpos[pos_id] += dpre[row] (either table may be NULL). */
 int a4r_embed_bwd(void* stream, const int64_t* ids, int ld_ids, const void* dpre, int ldd, float* dword, float* dpos,

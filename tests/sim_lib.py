@@ -223,8 +223,10 @@ def embed_bwd(ids, dpre, dword, dpos, n_items, S, roberta=False, pad_id=0):
 
 
 def embed_ln(ids, word, pos, type0, gamma, beta, eps, out, n_items, S, roberta=False, pad_id=0,
-             drop_p=0.0, drop_site=0, drop_seed=0, pre_out=None, stats_out=None):
+             drop_p=0.0, drop_site=0, drop_seed=0, pre_out=None, stats_out=None, key_mask_out=None):
     assert drop_p == 0.0
+    if key_mask_out is not None:
+        key_mask_out[:n_items] = ids[:n_items, S:2 * S].float()
     idv, pid = _pos_ids(ids, n_items, S, roberta, pad_id)
     x = word[idv] + pos[pid] + type0
     if pre_out is not None:
