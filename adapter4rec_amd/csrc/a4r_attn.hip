@@ -12,6 +12,15 @@ namespace {
 
 template <typename T> A4R_DEV uint4 ldg16(const T* p) { return *reinterpret_cast<const uint4*>(p); }
 
+// Every LDS region of these kernels is PRIVATE to one wave (smem + wave * WAVE_LDS): a wave's LDS operations execute in issue order,
+// so a read sees the same wave's earlier writes once they have been issued -- what is needed between the write and the read phases is
+// an ordering point for the compiler and the wave's own counter, not a workgroup barrier.  (With __syncthreads() the four (item, head)
+// pairs of a workgroup ran in lock step: every wave waited for the slowest pair's loads at every phase.)
+A4R_DEV void wave_lds_fence() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+}
+
 template <typename T, int STRIDE> A4R_DEV void lds_put16(char* tile, int row, int ch, const uint4& v) {
     char* d = tile + row * STRIDE + ch * 16;
     if constexpr (STRIDE % 16 == 0) {
@@ -138,7 +147,7 @@ __global__ void __launch_bounds__(WAVES * 64) attn_fwd_kernel(const T* __restric
                 Elem<T>::st(reinterpret_cast<T*>(Ps + q * C::PSTRIDE) + key, pv);
             }
         }
-    __syncthreads();
+    wave_lds_fence();
 
     f32x4_t o[2][C::DT];
 #pragma unroll
@@ -158,7 +167,7 @@ __global__ void __launch_bounds__(WAVES * 64) attn_fwd_kernel(const T* __restric
             for (int mt = 0; mt < 2; ++mt) Mma<T>::mma(pa[mt], vb, o[mt][dt]);
         }
     }
-    __syncthreads();
+    wave_lds_fence();
     // stage O over the V tile, then 16-byte row stores
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt)
@@ -167,7 +176,7 @@ __global__ void __launch_bounds__(WAVES * 64) attn_fwd_kernel(const T* __restric
 #pragma unroll
             for (int rr = 0; rr < 4; ++rr)
                 Elem<T>::st(reinterpret_cast<T*>(Vs + (mt * 16 + kg * 4 + rr) * C::OSTRIDE) + dt * 16 + r16, o[mt][dt][rr]);
-    __syncthreads();
+    wave_lds_fence();
     if (active) {
 #pragma unroll
         for (int i = 0; i < C::NLD; ++i) {
@@ -214,7 +223,7 @@ A4R_DEV void store_block(char* stage, const f32x4_t (&acc)[2][AttnCfg<T, DH>::DT
 #pragma unroll
             for (int rr = 0; rr < 4; ++rr)
                 Elem<T>::st(reinterpret_cast<T*>(stage + (t * 16 + kg * 4 + rr) * C::OSTRIDE) + dt * 16 + r16, acc[t][dt][rr]);
-    __syncthreads();
+    wave_lds_fence();
     if (active) {
 #pragma unroll
         for (int i = 0; i < C::NLD; ++i) {
@@ -329,17 +338,17 @@ __global__ void __launch_bounds__(WAVES * 64) attn_bwd_kernel(const T* __restric
                 Elem<T>::st(reinterpret_cast<T*>(dST + key * C::PSTRIDE) + q, ds);
             }
         }
-    __syncthreads();
+    wave_lds_fence();
 
     f32x4_t acc[2][C::DT];
     img_times_tile<T, DH>(PT, dOs, lane, acc);          // dV[key][d] = sum_q P'[q][key] dO[q][d]
-    __syncthreads();
+    wave_lds_fence();
     store_block<T, DH>(dOs, acc, gbase + v_off, ld, S, lane, active);
     img_times_tile<T, DH>(dST, Qs, lane, acc);          // dK[key][d] = sum_q dS[q][key] Q[q][d]
-    __syncthreads();
+    wave_lds_fence();
     store_block<T, DH>(Qs, acc, gbase + k_off, ld, S, lane, active);
     img_times_tile<T, DH>(dS, Ks, lane, acc);           // dQ[q][d] = sum_key dS[q][key] K[key][d]
-    __syncthreads();
+    wave_lds_fence();
     store_block<T, DH>(Ks, acc, gbase + q_off, ld, S, lane, active);
 }
 
