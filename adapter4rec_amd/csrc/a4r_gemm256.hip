@@ -303,6 +303,16 @@ __global__ void __launch_bounds__(512, 2) gemm_nt_256_kernel(const a4r_gemm_t p,
         load_pre_n<TO, 8>(pre_ld[0][0], grow0, gcolp, epi);
         load_pre_n<TO, 8>(pre_ld[0][1], grow0, gcolp + 32, epi);
     }
+    // the residual operand R1 (dgrad GEMMs: the gradient of the residual branch) likewise one row ahead (bf16 outputs: 4 registers
+    // per group; the ping-pong K loop left the registers for it)
+    constexpr bool R1PF = sizeof(TO) == 2 && DACT == A4R_ACT_NONE;
+    uint4 r1_ld[2][2][1];
+    if constexpr (R1PF) {
+        if (epi.R1) {
+            load_res_n<TO, 8>(r1_ld[0][0], epi.R1, epi.ldr1, grow0, gcolp);
+            load_res_n<TO, 8>(r1_ld[0][1], epi.R1, epi.ldr1, grow0, gcolp + 32);
+        }
+    }
 #define A4R_EPI_PAIR(mi_, pr_)                                                                                              \
     {                                                                                                                       \
         float v_[8];                                                                                                        \
@@ -315,13 +325,19 @@ __global__ void __launch_bounds__(512, 2) gemm_nt_256_kernel(const a4r_gemm_t p,
         if constexpr (SCALED) {                                                                                             \
             _Pragma("unroll") for (int e_ = 0; e_ < 8; ++e_) v_[e_] *= sa8[mi_] * sb8[pr_][e_];                             \
         }                                                                                                                   \
-        epilogue_n<TO, 8, ACT, DACT>(v_, bias8[pr_], grow0 + (mi_) * 16, gcolp + (pr_) * 32, epi,                           \
-                                     DACT != A4R_ACT_NONE ? pre_ld[(mi_) & 1][pr_] : nullptr);                              \
+        epilogue_n<TO, 8, ACT, DACT, R1PF>(v_, bias8[pr_], grow0 + (mi_) * 16, gcolp + (pr_) * 32, epi,                     \
+                                           DACT != A4R_ACT_NONE ? pre_ld[(mi_) & 1][pr_] : nullptr, R1PF ? r1_ld[(mi_) & 1][pr_] : nullptr); \
     }
 #define A4R_EPI_ROW(mi_)                                                                                                    \
     if constexpr (DACT != A4R_ACT_NONE && (mi_) < 7) {                                                                      \
         load_pre_n<TO, 8>(pre_ld[((mi_) + 1) & 1][0], grow0 + ((mi_) + 1) * 16, gcolp, epi);                                \
         load_pre_n<TO, 8>(pre_ld[((mi_) + 1) & 1][1], grow0 + ((mi_) + 1) * 16, gcolp + 32, epi);                           \
+    }                                                                                                                       \
+    if constexpr (R1PF && (mi_) < 7) {                                                                                      \
+        if (epi.R1) {                                                                                                       \
+            load_res_n<TO, 8>(r1_ld[((mi_) + 1) & 1][0], epi.R1, epi.ldr1, grow0 + ((mi_) + 1) * 16, gcolp);                \
+            load_res_n<TO, 8>(r1_ld[((mi_) + 1) & 1][1], epi.R1, epi.ldr1, grow0 + ((mi_) + 1) * 16, gcolp + 32);           \
+        }                                                                                                                   \
     }                                                                                                                       \
     A4R_EPI_PAIR(mi_, 0) A4R_EPI_PAIR(mi_, 1)
     A4R_EPI_ROW(0) A4R_EPI_ROW(1) A4R_EPI_ROW(2) A4R_EPI_ROW(3) A4R_EPI_ROW(4) A4R_EPI_ROW(5) A4R_EPI_ROW(6) A4R_EPI_ROW(7)

@@ -63,7 +63,9 @@ template <typename TO, int NC> A4R_DEV void load_pre_n(uint4* q, uint32_t grow, 
         q[s] = *reinterpret_cast<const uint4*>(e.Pre + (size_t)grow * (uint32_t)e.ldpre + gcol + s * (16 / (int)sizeof(TO)));
 }
 
-template <typename TO, int NC, int ACT = -1, int DACT = -1>
+// R1PF: the caller ALWAYS passes r1_ld and has filled it whenever e.R1 is set (a run-time null test on a register array would send
+// the array to scratch)
+template <typename TO, int NC, int ACT = -1, int DACT = -1, bool R1PF = false>
 A4R_DEV void epilogue_n(float (&v)[NC], const float* bias, uint32_t grow, int gcol, const GemmEpi<TO>& e, const uint4* pre_ld = nullptr,
                         const uint4* r1_ld = nullptr, const uint4* r2_ld = nullptr) {
     const int act = ACT >= 0 ? ACT : e.act;
@@ -112,7 +114,7 @@ A4R_DEV void epilogue_n(float (&v)[NC], const float* bias, uint32_t grow, int gc
         epi_dropout<NC>(v, ((uint64_t)grow + e.row0) * (uint64_t)e.N + (uint64_t)gcol, e.drop_seed, e.drop_site, e.thr16, e.keep_scale);
     if (e.R1) {
         float t[NC];
-        if (r1_ld) {
+        if (R1PF || r1_ld) {
 #pragma unroll
             for (int s = 0; s < NC / Elem<TO>::PER16; ++s) Elem<TO>::unpack(r1_ld[s], t + s * Elem<TO>::PER16);
         } else {

@@ -266,7 +266,7 @@ def self_launch(a, argv):
     `python -m torch.distributed.run` on 127.0.0.1 as a CHILD process and exits with its code."""
     import socket
     import subprocess
-    if not os.environ.get('A4R_BENCH_CONTROL_ONLY') and torch.cuda.device_count() < a.gpus:
+    if not os.environ.get('A4R_BENCH_CONTROL_ONLY') and not os.environ.get('A4R_BENCH_OVERSUBSCRIBE') and torch.cuda.device_count() < a.gpus:
         raise SystemExit(f'bench.py --gpus {a.gpus}: only {torch.cuda.device_count()} GPU(s) visible')
     with socket.socket() as sk:
         sk.bind(('127.0.0.1', 0))
@@ -328,12 +328,17 @@ def main():
         return control_only(a, world, rank)
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs an MI355X (no CPU fallback)')
-    if world > torch.cuda.device_count():
+    oversub = bool(os.environ.get('A4R_BENCH_OVERSUBSCRIBE'))     # testing only: several ranks on one GPU (gloo; RCCL refuses duplicate GPUs)
+    if world > torch.cuda.device_count() and not oversub:
         raise SystemExit(f'{world} ranks but {torch.cuda.device_count()} GPU(s): one process per GPU')
+    local = local % torch.cuda.device_count()
     torch.cuda.set_device(local)
     device = torch.device('cuda', local)
     if world > 1:
-        dist.init_process_group(backend, init_method='env://', device_id=device)
+        if backend == 'nccl':
+            dist.init_process_group(backend, init_method='env://', device_id=device)
+        else:
+            dist.init_process_group(backend, init_method='env://')
     rccl_ranks = 1
     if world > 1:                                              # an actual collective over the group: the rank count RCCL sees
         t = torch.ones(1, device=device)
