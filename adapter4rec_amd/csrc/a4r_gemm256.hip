@@ -389,9 +389,9 @@ static int band_for(const a4r_gemm_t& g, int ntm, int ntn, int grid, int isz) {
     if (g_band > 1000) return g_band - 1000 < ntn ? g_band - 1000 : ntn;
     // automatic: band only when the whole B operand does not sit in an XCD's L2 next to the streaming A panels
     const double b_tile = 256.0 * g.K * isz;
-    if (b_tile * ntn <= 2.5e6) return 0;
+    if (b_tile * ntn <= 4.0e6) return 0;                    // (N = 2304, K = 768: 3.5 MB still shares an L2 with the A stream: PMC 250 MB read un-banded vs 339 banded)
     int gn = (int)(2.5e6 / b_tile);
-    if (gn < 1) return 0;                                   // one B tile alone is too large: panel-major (A read once) is the better map
+    if (gn < 2) return 0;                                   // a band of one tile re-reads A once per N-tile: panel-major (A read once) is the better map
     return gn < ntn ? gn : ntn;
 }
 
