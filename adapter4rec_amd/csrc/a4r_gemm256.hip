@@ -313,6 +313,13 @@ __global__ void __launch_bounds__(512, 2) gemm_nt_256_kernel(const a4r_gemm_t p,
             load_res_n<TO, 8>(r1_ld[0][1], epi.R1, epi.ldr1, grow0, gcolp + 32);
         }
     }
+#if (A4R_ABL & 32)      /* timing-only experiment: every store instruction covers whole 128-byte lines (8 rows x 128 B); WRONG data placement */
+#define A4R_EPI_CALL(mi_, pr_)                                                                                              \
+        epilogue_n<TO, 8, ACT, DACT, R1PF>(v_, bias8[pr_], grow0 - fr + (fr & 7) + 8 * (pr_) + (mi_) * 16, gcolp + (fr >> 3) * 32, epi,
+#else
+#define A4R_EPI_CALL(mi_, pr_)                                                                                              \
+        epilogue_n<TO, 8, ACT, DACT, R1PF>(v_, bias8[pr_], grow0 + (mi_) * 16, gcolp + (pr_) * 32, epi,
+#endif
 #define A4R_EPI_PAIR(mi_, pr_)                                                                                              \
     {                                                                                                                       \
         float v_[8];                                                                                                        \
@@ -325,7 +332,7 @@ __global__ void __launch_bounds__(512, 2) gemm_nt_256_kernel(const a4r_gemm_t p,
         if constexpr (SCALED) {                                                                                             \
             _Pragma("unroll") for (int e_ = 0; e_ < 8; ++e_) v_[e_] *= sa8[mi_] * sb8[pr_][e_];                             \
         }                                                                                                                   \
-        epilogue_n<TO, 8, ACT, DACT, R1PF>(v_, bias8[pr_], grow0 + (mi_) * 16, gcolp + (pr_) * 32, epi,                     \
+        A4R_EPI_CALL(mi_, pr_)                                                                                              \
                                            DACT != A4R_ACT_NONE ? pre_ld[(mi_) & 1][pr_] : nullptr, R1PF ? r1_ld[(mi_) & 1][pr_] : nullptr); \
     }
 #define A4R_EPI_ROW(mi_)                                                                                                    \
@@ -344,7 +351,9 @@ __global__ void __launch_bounds__(512, 2) gemm_nt_256_kernel(const a4r_gemm_t p,
 #undef A4R_EPI_ROW
 #undef A4R_EPI_PAIR
     if (!more) break;
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // stores of this tile + prologue loads of the next (vmcnt counts both)
+    // the next tile's 6 prologue units were issued BEFORE this tile's stores: all of them have landed once at most the 16 youngest
+    // operations (>= 16 stores per wave follow the DMAs) are still outstanding.  The stores themselves drain behind the next K loop.
+    asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
   }
 #undef A4R_PROLOGUE
 #undef A4R_ISSUE
