@@ -204,6 +204,10 @@ class TransRecEngine:
         # one-launch adapter + residual + LayerNorm kernels (a4r_adapter_fused.hip); A4R_FUSE_ADAPTERS=0: the three-launch forms (A/B runs, tests)
         self.fuse_adapters = bool(int(_os.environ.get('A4R_FUSE_ADAPTERS', '1'))) and bool(getattr(args, 'fuse_adapters', True))
         self._collect_trainables()
+        for p in self.trainable_params:            # resumed run (FusedAdam.load_state_dict): the counter-based dropout stream continues
+            if getattr(p, '_a4r_resume_step', None) is not None:
+                self.step_count = int(p._a4r_resume_step)
+                p._a4r_resume_step = None
         self._build_item_tower()
         self._build_sasrec()
         self._check_coverage()

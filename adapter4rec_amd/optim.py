@@ -85,22 +85,61 @@ class FusedAdam(torch.optim.Optimizer):
         L.adam_step(eng.flat_p, eng.flat_g, self._m, self._v, self._seg_end, self._seg_group, self._lr_dev, self._step,
                     beta1=g0['betas'][0], beta2=g0['betas'][1], eps=g0['eps'], grad_scale=grad_scale)
 
+    # -- checkpoint interchange with the reference (Downstream/Text/run.py:481-492, data_utils/utils.py:109-115): torch.optim.Adam's own
+    #    layout -- state[param] = {step, exp_avg, exp_avg_sq} -- written and read; the per-parameter tensors are views of the flat moments
+    def _state_views(self):
+        for g in self.param_groups:
+            for p in g['params']:
+                _, off, n = p._a4r_flat
+                self.state[p] = dict(step=torch.tensor(float(self._step)), exp_avg=self._m[off:off + n].view(p.shape),
+                                     exp_avg_sq=self._v[off:off + n].view(p.shape))
+
     def state_dict(self):
+        if self._bound is not None:
+            self._state_views()
         sd = super().state_dict()
         if self._bound is not None:
-            sd['a4r_flat'] = dict(step=self._step, m=self._m.clone(), v=self._v.clone())
+            sd['a4r'] = dict(engine_step_count=int(self._bound.step_count))      # the counter-based dropout stream resumes where it stopped
         return sd
 
     def load_state_dict(self, sd):
-        flat = sd.pop('a4r_flat', None) if isinstance(sd, dict) else None
-        super().load_state_dict(sd)
-        if flat is not None:
-            self._pending = flat
+        sd = dict(sd)                                          # the caller's dict is not modified
+        extra, legacy = sd.pop('a4r', None), sd.pop('a4r_flat', None)
+        super().load_state_dict(sd)                            # a reference checkpoint's exp_avg / exp_avg_sq / step land in self.state
+        self._pending = dict(extra=extra, legacy=legacy, late=self._bound is not None)
+        if extra:                                               # the engine may not exist yet (built at the first forward): leave the
+            for g in self.param_groups:                         # dropout counter on the parameters, TransRecEngine picks it up
+                for p in g['params']:
+                    if getattr(p, '_a4r_flat', None) is not None:
+                        p._a4r_flat[0].step_count = int(extra.get('engine_step_count', 0))
+                    else:
+                        p._a4r_resume_step = int(extra.get('engine_step_count', 0))
+        if self._bound is not None:
+            self._apply_pending()
 
     def _apply_pending(self):
-        flat = getattr(self, '_pending', None)
-        if flat is not None and self._bound is not None:
-            self._step = flat['step']
-            self._m.copy_(flat['m'])
-            self._v.copy_(flat['v'])
-            self._pending = None
+        pend = getattr(self, '_pending', None)
+        if pend is None or self._bound is None:
+            return
+        self._pending = None
+        if 'm' in pend:                                        # moments carried over an engine rebuild (step())
+            self._step = pend['step']
+            self._m.copy_(pend['m'])
+            self._v.copy_(pend['v'])
+            return
+        if pend.get('legacy') is not None:                     # round-1 checkpoints of this package
+            self._step = pend['legacy']['step']
+            self._m.copy_(pend['legacy']['m'])
+            self._v.copy_(pend['legacy']['v'])
+        else:
+            for g in self.param_groups:
+                for p in g['params']:
+                    st = self.state.get(p)
+                    if st and 'exp_avg' in st:
+                        _, off, n = p._a4r_flat
+                        self._m[off:off + n].copy_(st['exp_avg'].reshape(-1))
+                        self._v[off:off + n].copy_(st['exp_avg_sq'].reshape(-1))
+                        self._step = int(float(st['step']))
+            self._state_views()
+        if pend.get('extra') and pend.get('late'):             # engine existed when the state was loaded; a lazily built
+            self._bound.step_count = int(pend['extra'].get('engine_step_count', self._bound.step_count))   # one read p._a4r_resume_step

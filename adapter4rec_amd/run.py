@@ -78,6 +78,8 @@ def build_model(args, item_num, use_modal, bert_model, local_rank, Log_file, mod
         model.load_state_dict(ckpt2['model_state_dict'])
         start_epoch = int(re.split(r'[._-]', args.load_ckpt_name)[1])
         torch.set_rng_state(ckpt2['rng_state'])
+        if 'cuda_rng_state' in ckpt2 and torch.cuda.is_available():
+            torch.cuda.set_rng_state(ckpt2['cuda_rng_state'])
     if 'None' not in args.adding_adapter_to and 'None' not in args.finetune_layernorm:      # run.py:496-501
         for name, p in model.named_parameters():
             if 'adapter' not in name and ('LayerNorm' in name or 'layer_norm' in name):

@@ -2,6 +2,7 @@
 tests/sim_lib.py -- a torch restatement of the C-ABI kernels' documented semantics -- and checked against the
 reference's golden vectors.  This does not test the HIP kernels (tests/test_kernels_gpu.py, test_engine_gpu.py do);
 it keeps the Python orchestration honest in the GPU-less build container."""
+import copy
 import numpy as np
 import pytest
 import torch
@@ -226,3 +227,43 @@ def test_host_logic_eval_item_sweep_in_fp32_snapshot(simulated):
     assert inner._engine() is eng and all(p.requires_grad for p in eng.trainable_params)
     bf = inner.bert_encoder(items)
     assert 0 < (bf - ref2).abs().max() < 5e-2                        # the bf16 engine itself still answers, in bf16
+
+
+def test_host_logic_optimizer_checkpoint_interchange(simulated):
+    """Resume fidelity: FusedAdam writes and reads torch.optim.Adam's own state layout (state[param] = step / exp_avg /
+    exp_avg_sq, what a reference checkpoint holds, run.py:481-492), continues bit-for-bit after a save / load, restores the
+    engine's dropout counter, and does not modify the dict it is given."""
+    from adapter4rec_amd.inject import optimizer_groups
+    from adapter4rec_amd.optim import FusedAdam
+
+    def run(n, opt, root, items, mask):
+        for _ in range(n):
+            opt.zero_grad()
+            root(items, mask, 'cpu').backward()
+            opt.step()
+
+    root, args, fx, items, mask = build_cpu('houlsby')
+    opt = FusedAdam(optimizer_groups(root, args))
+    run(2, opt, root, items, mask)
+    sd_opt = copy.deepcopy(opt.state_dict())            # what torch.save would hold (state_dict itself returns live views, like Adam's)
+    sd_model = {k: v.clone() for k, v in root.state_dict().items()}
+    # the layout torch.optim.Adam itself would have written
+    names = [n for n, p in root.named_parameters() if p.requires_grad]
+    st = sd_opt['state']
+    assert len(st) == len(names) and all(set(v) >= {'step', 'exp_avg', 'exp_avg_sq'} for v in st.values())
+    assert float(next(iter(st.values()))['step']) == 2.0 and sd_opt['a4r']['engine_step_count'] == 2
+    adam = torch.optim.Adam(optimizer_groups(root, args))
+    adam.load_state_dict({k: v for k, v in sd_opt.items() if k != 'a4r'})                 # a plain Adam accepts it
+    run(1, opt, root, items, mask)
+    after3 = {k: v.clone() for k, v in root.state_dict().items()}
+    # resume in a fresh model + optimizer from the saved pair
+    root2, args2, _, _, _ = build_cpu('houlsby')
+    root2.load_state_dict(sd_model)
+    opt2 = FusedAdam(optimizer_groups(root2, args2))
+    keys_before = set(sd_opt)
+    opt2.load_state_dict(sd_opt)
+    assert set(sd_opt) == keys_before                                                      # caller's dict untouched
+    run(1, opt2, root2, items, mask)
+    assert getattr(root2, 'model', root2)._engine().step_count == 3
+    for k, v in after3.items():
+        torch.testing.assert_close(root2.state_dict()[k], v, rtol=0, atol=0)
