@@ -215,19 +215,20 @@ def attn_bwd(qkv, dout, dqkv, key_mask, n_items, S, n_heads, dh, q_off, k_off, v
     _check(lib().a4r_attn_bwd(_stream(), C.byref(a)), 'a4r_attn_bwd')
 
 
-def attn_long_fwd(qkv, out, lse, n_items, S, n_heads, dh, q_off, k_off, v_off, scale):
+def attn_long_fwd(qkv, out, lse, n_items, S, n_heads, dh, q_off, k_off, v_off, scale, drop_p=0.0, drop_site=0, drop_seed=0):
     require_gpu(qkv, out, lse)
     assert lse.dtype == torch.float32 and lse.numel() >= n_items * n_heads * S
-    a = _attn_args(qkv, q_off, k_off, v_off, None, n_items, S, n_heads, dh, False, scale, 0.0, 0.0, 0, 0)
+    a = _attn_args(qkv, q_off, k_off, v_off, None, n_items, S, n_heads, dh, False, scale, 0.0, drop_p, drop_site, drop_seed)
     a.out, a.ldo = _p(out), _ld(out)
     _check(lib().a4r_attn_long_fwd(_stream(), C.byref(a), _p(lse)), 'a4r_attn_long_fwd')
 
 
-def attn_long_bwd(qkv, out, dout, dqkv, lse, delta_ws, n_items, S, n_heads, dh, q_off, k_off, v_off, scale):
+def attn_long_bwd(qkv, out, dout, dqkv, lse, delta_ws, n_items, S, n_heads, dh, q_off, k_off, v_off, scale,
+                  drop_p=0.0, drop_site=0, drop_seed=0):
     """out: the ctx attn_long_fwd wrote (backward takes delta = dO . O from it)."""
     require_gpu(qkv, out, dout, dqkv, lse, delta_ws)
     assert _ld(dqkv) == _ld(qkv) and delta_ws.dtype == torch.float32 and delta_ws.numel() >= n_items * n_heads * S
-    a = _attn_args(qkv, q_off, k_off, v_off, None, n_items, S, n_heads, dh, False, scale, 0.0, 0.0, 0, 0)
+    a = _attn_args(qkv, q_off, k_off, v_off, None, n_items, S, n_heads, dh, False, scale, 0.0, drop_p, drop_site, drop_seed)
     assert _ld(out) == _ld(dout)
     a.out, a.dout, a.ldo, a.dqkv = _p(out), _p(dout), _ld(dout), _p(dqkv)
     _check(lib().a4r_attn_long_bwd(_stream(), C.byref(a), _p(lse), _p(delta_ws)), 'a4r_attn_long_bwd')

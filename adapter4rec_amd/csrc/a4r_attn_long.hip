@@ -1,5 +1,7 @@
-// a4r_attn_long_fwd / a4r_attn_long_bwd: un-masked multi-head attention for 32 < S <= 256 tokens per item, head width 64
-// -- the ViT / MAE item tower (S = 197 / 50; HF ViTSelfAttention as called from Downstream/CV/model/encoders.py:21-32).
+// a4r_attn_long_fwd / a4r_attn_long_bwd: un-masked multi-head attention for 32 < S <= 256 tokens per item, head width 64 or 32
+// -- the ViT / MAE item tower (S = 197 / 50, dh 64; HF ViTSelfAttention as called from Downstream/CV/model/encoders.py:21-32)
+// and the two TransformerBlocks inside each KAdapterBlock of VITKAdaptedCVModel (Downstream/CV/model/model.py:374-404,
+// modules.py:24-36,148-187: width 384, 12 heads of 32, all-ones mask, dropout on the probabilities).
 // The S <= 32 kernels of a4r_attn.hip keep a whole score matrix in one wave; here one workgroup (8 waves) owns one
 // (item, head) pair, stages the key-side matrices of that pair in LDS and never writes anything S x S to HBM.
 //
@@ -31,28 +33,30 @@ template <typename T> A4R_DEV uint4 ldg16(const T* p) { return *reinterpret_cast
 // staging and Q / dO load latency behind; with 4-wave workgroups the chip sat at 0.4 waves per SIMD (PMC).
 template <int NKT> struct WG { static constexpr int NWAVE = NKT <= 4 ? 4 : 8, NTHR = NWAVE * 64; };   // short sequences have <= 4 query blocks
 
-template <typename T> struct Geo {
+template <typename T, int DH> struct Geo {
     static constexpr int PER = Elem<T>::PER16;              // elements per 16-byte chunk
     static constexpr int KSTEP = Mma<T>::KSTEP;             // contraction length of one chunk step (32 / 16)
-    static constexpr int KS = 64 / KSTEP;                   // chunk steps over the head width (2 / 4)
-    static constexpr int CPR = 64 / PER;                    // chunks per row of a [*, 64] matrix (8 / 16)
-    static constexpr int ROWB = 64 * (int)sizeof(T);        // row bytes (128 / 256)
+    static constexpr int KS = DH / KSTEP;                   // chunk steps over the head width (dh 64: 2 / 4, dh 32: 1 / 2)
+    static constexpr int CPR = DH / PER;                    // chunks per row of a [*, DH] matrix (16 / 8 / 4)
+    static constexpr int ROWB = DH * (int)sizeof(T);        // row bytes (256 / 128 / 64)
     static constexpr int TPS = KSTEP / 16;                  // score tiles per chunk step (2 / 1)
-    static A4R_DEV int swz(int row) { return CPR == 8 ? ((row >> 1) & 7) : (row & 15); }
+    static constexpr int ND = DH / 16;                      // 16-column tiles of the head width
+    // 16 rows x one 16-byte chunk column per quarter wave: rows that share a 256-byte bank window get distinct chunk slots
+    static A4R_DEV int swz(int row) { return CPR == 16 ? (row & 15) : CPR == 8 ? ((row >> 1) & 7) : ((row >> 2) & 3); }
 };
 
-// [S][64] (global, row stride ld) -> LDS row-major [SP][64], 16-byte chunks XOR-swizzled; rows >= S are zero
-template <typename T> A4R_DEV void stage_rows(char* lds, const T* src, int ld, int S, int SP, int tid, int NTHR) {
-    using G = Geo<T>;
+// [S][DH] (global, row stride ld) -> LDS row-major [SP][DH], 16-byte chunks XOR-swizzled; rows >= S are zero
+template <typename T, int DH> A4R_DEV void stage_rows(char* lds, const T* src, int ld, int S, int SP, int tid, int NTHR) {
+    using G = Geo<T, DH>;
     for (int id = tid; id < SP * G::CPR; id += NTHR) {
         const int r = id / G::CPR, c = id % G::CPR;
         const uint4 v = r < S ? ldg16(src + (size_t)r * ld + c * G::PER) : make_uint4(0, 0, 0, 0);
         *reinterpret_cast<uint4*>(lds + r * G::ROWB + ((c ^ G::swz(r)) << 4)) = v;
     }
 }
-// [S][64] -> LDS transposed [64][SPT] (SPT = SP + 8 elements); columns >= S are zero
-template <typename T> A4R_DEV void stage_cols(T* lds, const T* src, int ld, int S, int SP, int SPT, int tid, int NTHR) {
-    using G = Geo<T>;
+// [S][DH] -> LDS transposed [DH][SPT] (SPT = SP + 8 elements); columns >= S are zero
+template <typename T, int DH> A4R_DEV void stage_cols(T* lds, const T* src, int ld, int S, int SP, int SPT, int tid, int NTHR) {
+    using G = Geo<T, DH>;
     for (int id = tid; id < SP * G::CPR; id += NTHR) {
         const int c = id / SP, r = id % SP;                  // consecutive lanes -> consecutive rows: LDS stores spread over banks
         const uint4 v = r < S ? ldg16(src + (size_t)r * ld + c * G::PER) : make_uint4(0, 0, 0, 0);
@@ -62,13 +66,13 @@ template <typename T> A4R_DEV void stage_cols(T* lds, const T* src, int ld, int 
     }
 }
 // operand chunk from a row-major image: row `row`, chunk step ks
-template <typename T> A4R_DEV uint4 frag_rows(const char* lds, int row, int ks, int kg) {
-    using G = Geo<T>;
+template <typename T, int DH> A4R_DEV uint4 frag_rows(const char* lds, int row, int ks, int kg) {
+    using G = Geo<T, DH>;
     return *reinterpret_cast<const uint4*>(lds + row * G::ROWB + (((ks * 4 + kg) ^ G::swz(row)) << 4));
 }
 // operand chunk from a transposed image: head column d, chunk step st over the (permuted) key/query index
-template <typename T> A4R_DEV uint4 frag_cols(const T* lds, int SPT, int d, int st, int kg) {
-    using G = Geo<T>;
+template <typename T, int DH> A4R_DEV uint4 frag_cols(const T* lds, int SPT, int d, int st, int kg) {
+    using G = Geo<T, DH>;
     const T* p = lds + d * SPT + G::KSTEP * st + 4 * kg;
     if constexpr (sizeof(T) == 2) {
         const uint2 lo = *reinterpret_cast<const uint2*>(p), hi = *reinterpret_cast<const uint2*>(p + 16);
@@ -82,22 +86,26 @@ template <typename T> A4R_DEV uint4 frag_cols(const T* lds, int SPT, int d, int 
 // contraction index asks for.  Lane 4q + p of a group supplies the address of block row q, columns 4p .. 4p+3.  EXEC must be
 // all ones (every call site sits in wave-uniform control flow).
 typedef short v4s_t __attribute__((ext_vector_type(4)));
-A4R_DEV uint4 frag_tr(const char* lds, int d0, int st, int lane) {
+template <int DH> A4R_DEV uint4 frag_tr(const char* lds, int d0, int st, int lane) {
+    using G = Geo<bf16_t, DH>;
     const int kg = lane >> 4, q = (lane >> 2) & 3, p = lane & 3;
     const int chunk = (d0 >> 3) + (p >> 1);
     const int r0 = 32 * st + 4 * kg + q, r1 = r0 + 16;
-    const char* a0 = lds + r0 * 128 + ((chunk ^ ((r0 >> 1) & 7)) << 4) + 8 * (p & 1);
-    const char* a1 = lds + r1 * 128 + ((chunk ^ ((r1 >> 1) & 7)) << 4) + 8 * (p & 1);
+    const char* a0 = lds + r0 * G::ROWB + ((chunk ^ G::swz(r0)) << 4) + 8 * (p & 1);
+    const char* a1 = lds + r1 * G::ROWB + ((chunk ^ G::swz(r1)) << 4) + 8 * (p & 1);
     const v4s_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) v4s_t*)(a0));
     const v4s_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) v4s_t*)(a1));
     const uint2 l2 = __builtin_bit_cast(uint2, lo), h2 = __builtin_bit_cast(uint2, hi);
     return make_uint4(l2.x, l2.y, h2.x, h2.y);
 }
 // one accessor for both element types: bf16 reads the row-major image transposed, fp32 a transposed copy
-template <typename T> A4R_DEV uint4 frag_T(const void* img, int SPT, int d0, int st, int lane) {
-    if constexpr (sizeof(T) == 2) return frag_tr(reinterpret_cast<const char*>(img), d0, st, lane);
-    else return frag_cols<T>(reinterpret_cast<const T*>(img), SPT, d0 + (lane & 15), st, lane >> 4);
+template <typename T, int DH> A4R_DEV uint4 frag_T(const void* img, int SPT, int d0, int st, int lane) {
+    if constexpr (sizeof(T) == 2) return frag_tr<DH>(reinterpret_cast<const char*>(img), d0, st, lane);
+    else return frag_cols<T, DH>(reinterpret_cast<const T*>(img), SPT, d0 + (lane & 15), st, lane >> 4);
 }
+// dropout of the probabilities (SelfAttention.dropout, modules.py:35): element (pair = item * heads + head, query, key); the four
+// consecutive keys of a transposed score tile share one hash
+A4R_DEV uint64_t drop_idx(int pair, int q, int key) { return (((uint64_t)pair * 256 + q) << 8) + key; }
 
 // probabilities / score gradients of chunk step st as an operand chunk (see the k-slot permutation in the header)
 template <typename T, int NKT> A4R_DEV uint4 pack_step(const f32x4_t (&t)[NKT], int st) {
@@ -126,14 +134,14 @@ A4R_DEV float red4(float v, bool mx) {       // over the 4 lanes l, l^16, l^32, 
 }
 
 // transposed score tiles of one 16-query block: s[kt][r] = scale * q[query c] . k[key 16 kt + 4 kg + r]  (keys >= S: -inf)
-template <typename T, int NKT>
-A4R_DEV void scores_t(const char* Kr, const uint4 (&qf)[Geo<T>::KS], f32x4_t (&s)[NKT], int S, float scale, int fr, int kg) {
-    using G = Geo<T>;
+template <typename T, int DH, int NKT>
+A4R_DEV void scores_t(const char* Kr, const uint4 (&qf)[Geo<T, DH>::KS], f32x4_t (&s)[NKT], int S, float scale, int fr, int kg) {
+    using G = Geo<T, DH>;
 #pragma unroll
     for (int kt = 0; kt < NKT; ++kt) {
         f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int ks = 0; ks < G::KS; ++ks) Mma<T>::mma(frag_rows<T>(Kr, kt * 16 + fr, ks, kg), qf[ks], acc);
+        for (int ks = 0; ks < G::KS; ++ks) Mma<T>::mma(frag_rows<T, DH>(Kr, kt * 16 + fr, ks, kg), qf[ks], acc);
 #pragma unroll
         for (int r = 0; r < 4; ++r) acc[r] = (kt * 16 + kg * 4 + r < S) ? acc[r] * scale : -INFINITY;
         s[kt] = acc;
@@ -141,24 +149,26 @@ A4R_DEV void scores_t(const char* Kr, const uint4 (&qf)[Geo<T>::KS], f32x4_t (&s
     }
 }
 
+struct Drop { uint64_t seed; uint32_t site, thr16; float keep_scale; };
+
 // ------------------------------------------------------------------------------------------------ forward
-template <typename T, int NKT>
+template <typename T, int DH, int NKT>
 __global__ void __launch_bounds__(WG<NKT>::NTHR, 4) attn_long_fwd_kernel(const T* __restrict__ qkv, int ld, int q_off, int k_off, int v_off,
                                                             T* __restrict__ ctx, int ldo, float* __restrict__ lse,
-                                                            int S, int nh, float scale) {
-    using G = Geo<T>;
+                                                            int S, int nh, float scale, Drop dr) {
+    using G = Geo<T, DH>;
     constexpr int NTHR = WG<NKT>::NTHR, NWAVE = WG<NKT>::NWAVE;
     constexpr int SP = NKT * 16, SPT = SP + 8, NST = SP / G::KSTEP;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr bool TR = sizeof(T) == 2;
-    char* Kr = smem;                                                  // [SP][64] row-major
-    char* Vimg = smem + SP * G::ROWB;                                 // bf16: [SP][64] row-major (read transposed); fp32: [64][SPT]
+    char* Kr = smem;                                                  // [SP][DH] row-major
+    char* Vimg = smem + SP * G::ROWB;                                 // bf16: [SP][DH] row-major (read transposed); fp32: [DH][SPT]
     const int item = blockIdx.x / nh, h = blockIdx.x % nh;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, fr = lane & 15, kg = lane >> 4;
-    const T* base = qkv + (size_t)item * S * ld + h * 64;
-    stage_rows<T>(Kr, base + k_off, ld, S, SP, tid, NTHR);
-    if constexpr (TR) stage_rows<T>(Vimg, base + v_off, ld, S, SP, tid, NTHR);
-    else stage_cols<T>(reinterpret_cast<T*>(Vimg), base + v_off, ld, S, SP, SPT, tid, NTHR);
+    const T* base = qkv + (size_t)item * S * ld + h * DH;
+    stage_rows<T, DH>(Kr, base + k_off, ld, S, SP, tid, NTHR);
+    if constexpr (TR) stage_rows<T, DH>(Vimg, base + v_off, ld, S, SP, tid, NTHR);
+    else stage_cols<T, DH>(reinterpret_cast<T*>(Vimg), base + v_off, ld, S, SP, SPT, tid, NTHR);
     __syncthreads();
     const int nqb = (S + 15) >> 4;
     for (int qb = wave; qb < nqb; qb += NWAVE) {
@@ -169,7 +179,7 @@ __global__ void __launch_bounds__(WG<NKT>::NTHR, 4) attn_long_fwd_kernel(const T
         for (int ks = 0; ks < G::KS; ++ks)
             qf[ks] = valid ? ldg16(base + q_off + (size_t)rq * ld + (ks * 4 + kg) * G::PER) : make_uint4(0, 0, 0, 0);
         f32x4_t s[NKT];
-        scores_t<T, NKT>(Kr, qf, s, S, scale, fr, kg);
+        scores_t<T, DH, NKT>(Kr, qf, s, S, scale, fr, kg);
         float m = -INFINITY;
 #pragma unroll
         for (int kt = 0; kt < NKT; ++kt)
@@ -187,31 +197,39 @@ __global__ void __launch_bounds__(WG<NKT>::NTHR, 4) attn_long_fwd_kernel(const T
         for (int kt = 0; kt < NKT; ++kt)
 #pragma unroll
             for (int r = 0; r < 4; ++r) s[kt][r] *= inv;
-        if (valid && kg == 0) lse[((size_t)item * nh + h) * S + rq] = m + __logf(l);
-        f32x4_t o[4];
+        if (dr.thr16) {                                       // P' = dropout(P): the 4 keys of a lane's tile column share one hash
 #pragma unroll
-        for (int dt = 0; dt < 4; ++dt) o[dt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+            for (int kt = 0; kt < NKT; ++kt) {
+                const uint64_t hsh = a4r_hash64(dr.seed, dr.site, drop_idx(blockIdx.x, rq, kt * 16 + kg * 4) >> 2);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) s[kt][r] = (((uint32_t)(hsh >> (16 * r)) & 0xffffu) >= dr.thr16) ? s[kt][r] * dr.keep_scale : 0.f;
+            }
+        }
+        if (valid && kg == 0) lse[((size_t)item * nh + h) * S + rq] = m + __logf(l);
+        f32x4_t o[G::ND];
+#pragma unroll
+        for (int dt = 0; dt < G::ND; ++dt) o[dt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int st = 0; st < NST; ++st) {                   // probabilities are packed step by step (keeping all NST chunks spilled)
             const uint4 pf = pack_step<T, NKT>(s, st);
 #pragma unroll
-            for (int dt = 0; dt < 4; ++dt) Mma<T>::mma(frag_T<T>(Vimg, SPT, dt * 16, st, lane), pf, o[dt]);
+            for (int dt = 0; dt < G::ND; ++dt) Mma<T>::mma(frag_T<T, DH>(Vimg, SPT, dt * 16, st, lane), pf, o[dt]);
             __builtin_amdgcn_sched_barrier(0);
         }
         if (valid) {
 #pragma unroll
-            for (int dt = 0; dt < 4; ++dt) store4<T>(ctx + ((size_t)item * S + rq) * ldo + h * 64 + dt * 16 + kg * 4, o[dt]);
+            for (int dt = 0; dt < G::ND; ++dt) store4<T>(ctx + ((size_t)item * S + rq) * ldo + h * DH + dt * 16 + kg * 4, o[dt]);
         }
     }
 }
 
 // ------------------------------------------------------------------------------------------------ backward: dq + delta
-template <typename T, int NKT>
+template <typename T, int DH, int NKT>
 __global__ void __launch_bounds__(WG<NKT>::NTHR, 4) attn_long_dq_kernel(const T* __restrict__ qkv, int ld, int q_off, int k_off, int v_off,
                                                            const T* __restrict__ dctx, int ldo, const T* __restrict__ octx,
                                                            const float* __restrict__ lse, float* __restrict__ delta,
-                                                           T* __restrict__ dqkv, int S, int nh, float scale) {
-    using G = Geo<T>;
+                                                           T* __restrict__ dqkv, int S, int nh, float scale, Drop dr) {
+    using G = Geo<T, DH>;
     constexpr int NTHR = WG<NKT>::NTHR, NWAVE = WG<NKT>::NWAVE;
     constexpr int SP = NKT * 16, SPT = SP + 8, NST = SP / G::KSTEP;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -221,10 +239,10 @@ __global__ void __launch_bounds__(WG<NKT>::NTHR, 4) attn_long_dq_kernel(const T*
     char* Kimg = TR ? Kr : smem + 2 * SP * G::ROWB;                   // bf16: K's row-major image doubles as the transposed operand
     const int item = blockIdx.x / nh, h = blockIdx.x % nh;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, fr = lane & 15, kg = lane >> 4;
-    const T* base = qkv + (size_t)item * S * ld + h * 64;
-    stage_rows<T>(Kr, base + k_off, ld, S, SP, tid, NTHR);
-    stage_rows<T>(Vr, base + v_off, ld, S, SP, tid, NTHR);
-    if constexpr (!TR) stage_cols<T>(reinterpret_cast<T*>(Kimg), base + k_off, ld, S, SP, SPT, tid, NTHR);
+    const T* base = qkv + (size_t)item * S * ld + h * DH;
+    stage_rows<T, DH>(Kr, base + k_off, ld, S, SP, tid, NTHR);
+    stage_rows<T, DH>(Vr, base + v_off, ld, S, SP, tid, NTHR);
+    if constexpr (!TR) stage_cols<T, DH>(reinterpret_cast<T*>(Kimg), base + k_off, ld, S, SP, SPT, tid, NTHR);
     __syncthreads();
     const int nqb = (S + 15) >> 4;
     for (int qb = wave; qb < nqb; qb += NWAVE) {
@@ -235,15 +253,15 @@ __global__ void __launch_bounds__(WG<NKT>::NTHR, 4) attn_long_dq_kernel(const T*
 #pragma unroll
         for (int ks = 0; ks < G::KS; ++ks) {
             qf[ks] = valid ? ldg16(base + q_off + (size_t)rq * ld + (ks * 4 + kg) * G::PER) : make_uint4(0, 0, 0, 0);
-            dof[ks] = valid ? ldg16(dctx + grow * ldo + h * 64 + (ks * 4 + kg) * G::PER) : make_uint4(0, 0, 0, 0);
+            dof[ks] = valid ? ldg16(dctx + grow * ldo + h * DH + (ks * 4 + kg) * G::PER) : make_uint4(0, 0, 0, 0);
         }
         const float lq = valid ? lse[((size_t)item * nh + h) * S + rq] : 0.f;
-        // delta = sum_k P dP = dO . O (the forward output): one dot product per query instead of a pass over all key tiles,
-        // so P, dP and dS are produced and consumed one chunk step (32 / 16 keys) at a time and never held for the whole row
+        // delta = sum_k P' dP' = dO . O (the forward output, dropout included): one dot product per query instead of a pass over all
+        // key tiles, so P, dP and dS are produced and consumed one chunk step (32 / 16 keys) at a time and never held for the whole row
         float dsum = 0.f;
 #pragma unroll
         for (int ks = 0; ks < G::KS; ++ks) {
-            const uint4 of = valid ? ldg16(octx + grow * ldo + h * 64 + (ks * 4 + kg) * G::PER) : make_uint4(0, 0, 0, 0);
+            const uint4 of = valid ? ldg16(octx + grow * ldo + h * DH + (ks * 4 + kg) * G::PER) : make_uint4(0, 0, 0, 0);
             float a8[G::PER], b8[G::PER];
             Elem<T>::unpack(of, a8);
             Elem<T>::unpack(dof[ks], b8);
@@ -252,9 +270,9 @@ __global__ void __launch_bounds__(WG<NKT>::NTHR, 4) attn_long_dq_kernel(const T*
         }
         dsum = red4(dsum, false);
         if (valid && kg == 0) delta[((size_t)item * nh + h) * S + rq] = dsum;
-        f32x4_t o[4];
+        f32x4_t o[G::ND];
 #pragma unroll
-        for (int dt = 0; dt < 4; ++dt) o[dt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+        for (int dt = 0; dt < G::ND; ++dt) o[dt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int st = 0; st < NST; ++st) {
             f32x4_t ds[G::TPS];
@@ -264,34 +282,38 @@ __global__ void __launch_bounds__(WG<NKT>::NTHR, 4) attn_long_dq_kernel(const T*
                 f32x4_t sc = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                 for (int ks = 0; ks < G::KS; ++ks) {
-                    Mma<T>::mma(frag_rows<T>(Kr, kt * 16 + fr, ks, kg), qf[ks], sc);
-                    Mma<T>::mma(frag_rows<T>(Vr, kt * 16 + fr, ks, kg), dof[ks], dp);
+                    Mma<T>::mma(frag_rows<T, DH>(Kr, kt * 16 + fr, ks, kg), qf[ks], sc);
+                    Mma<T>::mma(frag_rows<T, DH>(Vr, kt * 16 + fr, ks, kg), dof[ks], dp);
                 }
+                uint64_t hsh = 0;
+                if (dr.thr16) hsh = a4r_hash64(dr.seed, dr.site, drop_idx(blockIdx.x, rq, kt * 16 + kg * 4) >> 2);
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const float pv = (kt * 16 + kg * 4 + r < S) ? __expf(sc[r] * scale - lq) : 0.f;
-                    ds[t][r] = pv * (dp[r] - dsum) * scale;
+                    float dpr = dp[r];
+                    if (dr.thr16) dpr = (((uint32_t)(hsh >> (16 * r)) & 0xffffu) >= dr.thr16) ? dpr * dr.keep_scale : 0.f;
+                    ds[t][r] = pv * (dpr - dsum) * scale;
                 }
             }
             const uint4 dsf = pack_step<T, G::TPS>(ds, 0);
 #pragma unroll
-            for (int dt = 0; dt < 4; ++dt) Mma<T>::mma(frag_T<T>(Kimg, SPT, dt * 16, st, lane), dsf, o[dt]);
+            for (int dt = 0; dt < G::ND; ++dt) Mma<T>::mma(frag_T<T, DH>(Kimg, SPT, dt * 16, st, lane), dsf, o[dt]);
             __builtin_amdgcn_sched_barrier(0);
         }
         if (valid) {
 #pragma unroll
-            for (int dt = 0; dt < 4; ++dt) store4<T>(dqkv + grow * ld + q_off + h * 64 + dt * 16 + kg * 4, o[dt]);
+            for (int dt = 0; dt < G::ND; ++dt) store4<T>(dqkv + grow * ld + q_off + h * DH + dt * 16 + kg * 4, o[dt]);
         }
     }
 }
 
 // ------------------------------------------------------------------------------------------------ backward: dk, dv
-template <typename T, int NKT>
+template <typename T, int DH, int NKT>
 __global__ void __launch_bounds__(WG<NKT>::NTHR, 4) attn_long_dkdv_kernel(const T* __restrict__ qkv, int ld, int q_off, int k_off, int v_off,
                                                              const T* __restrict__ dctx, int ldo, const float* __restrict__ lse,
                                                              const float* __restrict__ delta, T* __restrict__ dqkv,
-                                                             int S, int nh, float scale) {
-    using G = Geo<T>;
+                                                             int S, int nh, float scale, Drop dr) {
+    using G = Geo<T, DH>;
     constexpr int NTHR = WG<NKT>::NTHR, NWAVE = WG<NKT>::NWAVE;
     constexpr int SP = NKT * 16, SPT = SP + 8, NG = SP / G::KSTEP;          // NG query groups of KSTEP queries
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -299,18 +321,18 @@ __global__ void __launch_bounds__(WG<NKT>::NTHR, 4) attn_long_dkdv_kernel(const 
     char* Qr = smem;
     char* Or = smem + SP * G::ROWB;
     char* Qimg = TR ? Qr : smem + 2 * SP * G::ROWB;
-    char* Oimg = TR ? Or : Qimg + 64 * SPT * sizeof(T);
-    float* lse_s = reinterpret_cast<float*>(TR ? smem + 2 * SP * G::ROWB : Oimg + 64 * SPT * sizeof(T));
+    char* Oimg = TR ? Or : Qimg + DH * SPT * sizeof(T);
+    float* lse_s = reinterpret_cast<float*>(TR ? smem + 2 * SP * G::ROWB : Oimg + DH * SPT * sizeof(T));
     float* del_s = lse_s + SP;
     const int item = blockIdx.x / nh, h = blockIdx.x % nh;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, fr = lane & 15, kg = lane >> 4;
-    const T* base = qkv + (size_t)item * S * ld + h * 64;
-    const T* dob = dctx + (size_t)item * S * ldo + h * 64;
-    stage_rows<T>(Qr, base + q_off, ld, S, SP, tid, NTHR);
-    stage_rows<T>(Or, dob, ldo, S, SP, tid, NTHR);
+    const T* base = qkv + (size_t)item * S * ld + h * DH;
+    const T* dob = dctx + (size_t)item * S * ldo + h * DH;
+    stage_rows<T, DH>(Qr, base + q_off, ld, S, SP, tid, NTHR);
+    stage_rows<T, DH>(Or, dob, ldo, S, SP, tid, NTHR);
     if constexpr (!TR) {
-        stage_cols<T>(reinterpret_cast<T*>(Qimg), base + q_off, ld, S, SP, SPT, tid, NTHR);
-        stage_cols<T>(reinterpret_cast<T*>(Oimg), dob, ldo, S, SP, SPT, tid, NTHR);
+        stage_cols<T, DH>(reinterpret_cast<T*>(Qimg), base + q_off, ld, S, SP, SPT, tid, NTHR);
+        stage_cols<T, DH>(reinterpret_cast<T*>(Oimg), dob, ldo, S, SP, SPT, tid, NTHR);
     }
     for (int i = tid; i < SP; i += NTHR) {
         lse_s[i] = i < S ? lse[((size_t)item * nh + h) * S + i] : 0.f;
@@ -327,9 +349,9 @@ __global__ void __launch_bounds__(WG<NKT>::NTHR, 4) attn_long_dkdv_kernel(const 
             kf[ks] = kvalid ? ldg16(base + k_off + (size_t)rk * ld + (ks * 4 + kg) * G::PER) : make_uint4(0, 0, 0, 0);
             vf[ks] = kvalid ? ldg16(base + v_off + (size_t)rk * ld + (ks * 4 + kg) * G::PER) : make_uint4(0, 0, 0, 0);
         }
-        f32x4_t dk[4], dv[4];
+        f32x4_t dk[G::ND], dv[G::ND];
 #pragma unroll
-        for (int dt = 0; dt < 4; ++dt) { dk[dt] = f32x4_t{0.f, 0.f, 0.f, 0.f}; dv[dt] = f32x4_t{0.f, 0.f, 0.f, 0.f}; }
+        for (int dt = 0; dt < G::ND; ++dt) { dk[dt] = f32x4_t{0.f, 0.f, 0.f, 0.f}; dv[dt] = f32x4_t{0.f, 0.f, 0.f, 0.f}; }
 #pragma unroll 1
         for (int g = 0; g < NG; ++g) {
             f32x4_t p[G::TPS], ds[G::TPS];
@@ -339,28 +361,30 @@ __global__ void __launch_bounds__(WG<NKT>::NTHR, 4) attn_long_dkdv_kernel(const 
                 f32x4_t sc = {0.f, 0.f, 0.f, 0.f}, dpt = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                 for (int ks = 0; ks < G::KS; ++ks) {
-                    Mma<T>::mma(frag_rows<T>(Qr, q0 + fr, ks, kg), kf[ks], sc);
-                    Mma<T>::mma(frag_rows<T>(Or, q0 + fr, ks, kg), vf[ks], dpt);
+                    Mma<T>::mma(frag_rows<T, DH>(Qr, q0 + fr, ks, kg), kf[ks], sc);
+                    Mma<T>::mma(frag_rows<T, DH>(Or, q0 + fr, ks, kg), vf[ks], dpt);
                 }
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int q = q0 + kg * 4 + r;
-                    const float pv = (kvalid && q < S) ? __expf(sc[r] * scale - lse_s[q]) : 0.f;
-                    p[t][r] = pv;
-                    ds[t][r] = pv * (dpt[r] - del_s[q]) * scale;
+                    float pv = (kvalid && q < S) ? __expf(sc[r] * scale - lse_s[q]) : 0.f;
+                    float keepf = 1.f;                        // here the tile's 4 rows are 4 QUERIES at one key: one hash each
+                    if (dr.thr16) keepf = dropout_keep(dr.seed, dr.site, drop_idx(blockIdx.x, q, rk), dr.thr16) ? dr.keep_scale : 0.f;
+                    p[t][r] = pv * keepf;
+                    ds[t][r] = pv * (dpt[r] * keepf - del_s[q]) * scale;
                 }
             }
             const uint4 pf = pack_step<T, G::TPS>(p, 0), dsf = pack_step<T, G::TPS>(ds, 0);
 #pragma unroll
-            for (int dt = 0; dt < 4; ++dt) {
-                Mma<T>::mma(frag_T<T>(Oimg, SPT, dt * 16, g, lane), pf, dv[dt]);
-                Mma<T>::mma(frag_T<T>(Qimg, SPT, dt * 16, g, lane), dsf, dk[dt]);
+            for (int dt = 0; dt < G::ND; ++dt) {
+                Mma<T>::mma(frag_T<T, DH>(Oimg, SPT, dt * 16, g, lane), pf, dv[dt]);
+                Mma<T>::mma(frag_T<T, DH>(Qimg, SPT, dt * 16, g, lane), dsf, dk[dt]);
             }
         }
         if (kvalid) {
-            T* row = dqkv + ((size_t)item * S + rk) * ld + h * 64 + kg * 4;
+            T* row = dqkv + ((size_t)item * S + rk) * ld + h * DH + kg * 4;
 #pragma unroll
-            for (int dt = 0; dt < 4; ++dt) {
+            for (int dt = 0; dt < G::ND; ++dt) {
                 store4<T>(row + k_off + dt * 16, dk[dt]);
                 store4<T>(row + v_off + dt * 16, dv[dt]);
             }
@@ -368,12 +392,12 @@ __global__ void __launch_bounds__(WG<NKT>::NTHR, 4) attn_long_dkdv_kernel(const 
     }
 }
 
-template <typename T> int nkt_for(int S) { return S <= 32 ? 2 : S <= 64 ? 4 : S <= 128 ? 8 : S <= 224 ? 14 : 16; }
+int nkt_for(int S) { return S <= 32 ? 2 : S <= 64 ? 4 : S <= 128 ? 8 : S <= 224 ? 14 : 16; }
 
-template <typename T, int NKT> constexpr size_t img_t() { return sizeof(T) == 2 ? 0 : 64 * (NKT * 16 + 8) * sizeof(T); }   // transposed copy (fp32 only)
-template <typename T, int NKT> size_t lds_fwd() { return (size_t)NKT * 16 * Geo<T>::ROWB + (sizeof(T) == 2 ? (size_t)NKT * 16 * Geo<T>::ROWB : img_t<T, NKT>()); }
-template <typename T, int NKT> size_t lds_dq() { return 2 * (size_t)NKT * 16 * Geo<T>::ROWB + img_t<T, NKT>(); }
-template <typename T, int NKT> size_t lds_dkdv() { return 2 * (size_t)NKT * 16 * Geo<T>::ROWB + 2 * img_t<T, NKT>() + 2 * NKT * 16 * sizeof(float); }
+template <typename T, int DH, int NKT> constexpr size_t img_t() { return sizeof(T) == 2 ? 0 : DH * (NKT * 16 + 8) * sizeof(T); }   // transposed copy (fp32 only)
+template <typename T, int DH, int NKT> size_t lds_fwd() { return (size_t)NKT * 16 * Geo<T, DH>::ROWB + (sizeof(T) == 2 ? (size_t)NKT * 16 * Geo<T, DH>::ROWB : img_t<T, DH, NKT>()); }
+template <typename T, int DH, int NKT> size_t lds_dq() { return 2 * (size_t)NKT * 16 * Geo<T, DH>::ROWB + img_t<T, DH, NKT>(); }
+template <typename T, int DH, int NKT> size_t lds_dkdv() { return 2 * (size_t)NKT * 16 * Geo<T, DH>::ROWB + 2 * img_t<T, DH, NKT>() + 2 * NKT * 16 * sizeof(float); }
 constexpr size_t LDS_MAX = 160 * 1024;
 
 template <typename K> int set_lds(K kernel, size_t bytes) {
@@ -383,28 +407,32 @@ template <typename K> int set_lds(K kernel, size_t bytes) {
     return A4R_OK;
 }
 
-template <typename T, int NKT> int run_fwd(hipStream_t s, const a4r_attn_t* a, float* lse) {
-    const size_t lds = lds_fwd<T, NKT>();
-    if (int rc = set_lds(attn_long_fwd_kernel<T, NKT>, lds)) return rc;
-    hipLaunchKernelGGL((attn_long_fwd_kernel<T, NKT>), dim3(a->n_items * a->n_heads), dim3(WG<NKT>::NTHR), lds, s, (const T*)a->qkv, a->ld, a->q_off,
-                       a->k_off, a->v_off, (T*)a->out, a->ldo, lse, a->S, a->n_heads, a->scale);
+Drop drop_of(const a4r_attn_t* a) { return Drop{a->drop_seed, a->drop_site, a4r_thr16(a->drop_p), a4r_keep_scale(a->drop_p)}; }
+
+template <typename T, int DH, int NKT> int run_fwd(hipStream_t s, const a4r_attn_t* a, float* lse) {
+    const size_t lds = lds_fwd<T, DH, NKT>();
+    if (int rc = set_lds(attn_long_fwd_kernel<T, DH, NKT>, lds)) return rc;
+    hipLaunchKernelGGL((attn_long_fwd_kernel<T, DH, NKT>), dim3(a->n_items * a->n_heads), dim3(WG<NKT>::NTHR), lds, s, (const T*)a->qkv, a->ld, a->q_off,
+                       a->k_off, a->v_off, (T*)a->out, a->ldo, lse, a->S, a->n_heads, a->scale, drop_of(a));
     return a4r_launch_status();
 }
-template <typename T, int NKT> int run_bwd(hipStream_t s, const a4r_attn_t* a, const float* lse, float* delta) {
-    const size_t l1 = lds_dq<T, NKT>(), l2 = lds_dkdv<T, NKT>();
-    if (int rc = set_lds(attn_long_dq_kernel<T, NKT>, l1)) return rc;
-    if (int rc = set_lds(attn_long_dkdv_kernel<T, NKT>, l2)) return rc;
+template <typename T, int DH, int NKT> int run_bwd(hipStream_t s, const a4r_attn_t* a, const float* lse, float* delta) {
+    const size_t l1 = lds_dq<T, DH, NKT>(), l2 = lds_dkdv<T, DH, NKT>();
+    if (int rc = set_lds(attn_long_dq_kernel<T, DH, NKT>, l1)) return rc;
+    if (int rc = set_lds(attn_long_dkdv_kernel<T, DH, NKT>, l2)) return rc;
     const dim3 grid(a->n_items * a->n_heads), block(WG<NKT>::NTHR);
-    hipLaunchKernelGGL((attn_long_dq_kernel<T, NKT>), grid, block, l1, s, (const T*)a->qkv, a->ld, a->q_off, a->k_off, a->v_off,
-                       (const T*)a->dout, a->ldo, (const T*)a->out, lse, delta, (T*)a->dqkv, a->S, a->n_heads, a->scale);
-    hipLaunchKernelGGL((attn_long_dkdv_kernel<T, NKT>), grid, block, l2, s, (const T*)a->qkv, a->ld, a->q_off, a->k_off, a->v_off,
-                       (const T*)a->dout, a->ldo, lse, (const float*)delta, (T*)a->dqkv, a->S, a->n_heads, a->scale);
+    hipLaunchKernelGGL((attn_long_dq_kernel<T, DH, NKT>), grid, block, l1, s, (const T*)a->qkv, a->ld, a->q_off, a->k_off, a->v_off,
+                       (const T*)a->dout, a->ldo, (const T*)a->out, lse, delta, (T*)a->dqkv, a->S, a->n_heads, a->scale, drop_of(a));
+    hipLaunchKernelGGL((attn_long_dkdv_kernel<T, DH, NKT>), grid, block, l2, s, (const T*)a->qkv, a->ld, a->q_off, a->k_off, a->v_off,
+                       (const T*)a->dout, a->ldo, lse, (const float*)delta, (T*)a->dqkv, a->S, a->n_heads, a->scale, drop_of(a));
     return a4r_launch_status();
 }
 
 int check(const a4r_attn_t* a, bool bwd) {
-    if (!a || !a->qkv || a->n_items <= 0 || a->S <= 0 || a->S > 256 || a->dh != 64 || a->n_heads <= 0) return A4R_EINVAL;
-    if (a->key_mask || a->causal || a->drop_p != 0.f) return A4R_EINVAL;           // the ViT / MAE tower uses none of them
+    if (!a || !a->qkv || a->n_items <= 0 || a->S <= 0 || a->S > 256 || (a->dh != 64 && a->dh != 32) || a->n_heads <= 0) return A4R_EINVAL;
+    if (a->key_mask || a->causal) return A4R_EINVAL;                               // neither the ViT / MAE tower nor its K-Adapter blocks mask
+    if (a->drop_p < 0.f || a->drop_p >= 1.f) return A4R_EINVAL;
+    if ((int64_t)a->n_items * a->n_heads >= (1ll << 40)) return A4R_EINVAL;        // dropout counter: 40 + 8 + 8 bits
     if (a->dtype != A4R_BF16 && a->dtype != A4R_F32) return A4R_EINVAL;
     const int es = a->dtype == A4R_BF16 ? 2 : 4;
     if ((a->ld * es) % 16 || (a->ldo * es) % 16 || (a->q_off * es) % 16 || (a->k_off * es) % 16 || (a->v_off * es) % 16) return A4R_EINVAL;
@@ -415,14 +443,16 @@ int check(const a4r_attn_t* a, bool bwd) {
     return A4R_OK;
 }
 
-#define A4R_NKT_SWITCH(T_, CALL_)                       \
-    switch (nkt_for<T_>(a->S)) {                        \
-        case 2: return CALL_(T_, 2);                    \
-        case 4: return CALL_(T_, 4);                    \
-        case 8: return CALL_(T_, 8);                    \
-        case 14: return CALL_(T_, 14);                  \
-        default: return CALL_(T_, 16);                  \
+#define A4R_NKT_SWITCH(T_, D_, CALL_)                   \
+    switch (nkt_for(a->S)) {                            \
+        case 2: return CALL_(T_, D_, 2);                \
+        case 4: return CALL_(T_, D_, 4);                \
+        case 8: return CALL_(T_, D_, 8);                \
+        case 14: return CALL_(T_, D_, 14);              \
+        default: return CALL_(T_, D_, 16);              \
     }
+#define A4R_DH_SWITCH(T_, CALL_)                                            \
+    if (a->dh == 64) { A4R_NKT_SWITCH(T_, 64, CALL_) } else { A4R_NKT_SWITCH(T_, 32, CALL_) }
 
 }  // namespace
 
@@ -430,9 +460,9 @@ extern "C" int a4r_attn_long_fwd(void* stream, const a4r_attn_t* a, float* lse) 
     if (int rc = check(a, false)) return rc;
     if (!lse) return A4R_EINVAL;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-#define A4R_F(T_, N_) run_fwd<T_, N_>(s, a, lse)
-    if (a->dtype == A4R_BF16) { A4R_NKT_SWITCH(bf16_t, A4R_F) }
-    A4R_NKT_SWITCH(float, A4R_F)
+#define A4R_F(T_, D_, N_) run_fwd<T_, D_, N_>(s, a, lse)
+    if (a->dtype == A4R_BF16) { A4R_DH_SWITCH(bf16_t, A4R_F) }
+    A4R_DH_SWITCH(float, A4R_F)
 #undef A4R_F
 }
 
@@ -440,8 +470,8 @@ extern "C" int a4r_attn_long_bwd(void* stream, const a4r_attn_t* a, const float*
     if (int rc = check(a, true)) return rc;
     if (!lse || !delta_ws) return A4R_EINVAL;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-#define A4R_B(T_, N_) run_bwd<T_, N_>(s, a, lse, delta_ws)
-    if (a->dtype == A4R_BF16) { A4R_NKT_SWITCH(bf16_t, A4R_B) }
-    A4R_NKT_SWITCH(float, A4R_B)
+#define A4R_B(T_, D_, N_) run_bwd<T_, D_, N_>(s, a, lse, delta_ws)
+    if (a->dtype == A4R_BF16) { A4R_DH_SWITCH(bf16_t, A4R_B) }
+    A4R_DH_SWITCH(float, A4R_B)
 #undef A4R_B
 }

@@ -4,8 +4,9 @@ from ..model.lora import LoRALinear
 from ..model.model import (CompacterModel, SASRecAdaptedSelfOutput, SASRecCompacterAdaptedSelfOutput,
                            SASRecPfeifferVer2AdaptedSelfOutput)
 from ..model.model import SASRecParallelAdaptedSelfOutput
+from ..model.model import SASRecKAdaptedTransformerBlocks
 from .model import (VITAdaptedOutput, VITAdaptedParallelOutput, VITAdaptedSelfOutput, VITCompacterAdaptedOutput,
-                    VITCompacterAdaptedSelfOutput)
+                    VITCompacterAdaptedSelfOutput, VITKAdaptedCVModel)
 
 
 def vit_layers(model):
@@ -24,6 +25,13 @@ def inject_adapters(model, args):
             lyr.attention.output = VITAdaptedSelfOutput(lyr.attention.output, args)
         for i, blk in enumerate(blocks):
             blocks[i] = SASRecPfeifferVer2AdaptedSelfOutput(blk, args)
+    elif 'kadapter' in t:                            # :378-383 (the reference addresses image_net.vit only: ViT-MAE has no .vit)
+        net = model.cv_encoder.image_net
+        if not hasattr(net, 'vit'):
+            raise NotImplementedError('K-Adapter on ViT-MAE (the reference wires it for ViTForImageClassification only)')
+        net.vit.encoder = VITKAdaptedCVModel(net.vit.encoder, args)
+        te = model.user_encoder.transformer_encoder
+        te.transformer_blocks = SASRecKAdaptedTransformerBlocks(te.transformer_blocks, args)
     elif 'lora' in t:                                # :384-395 (reference hard-codes r = 12 / 4 / 0; BASELINE config 3 asks r = 8)
         r_vit = int(getattr(args, 'lora_r', 12))
         r_q = int(getattr(args, 'lora_r_sasrec', 4))
@@ -63,7 +71,7 @@ def inject_adapters(model, args):
         for i, blk in enumerate(blocks):
             blocks[i] = SASRecParallelAdaptedSelfOutput(blk, args)
     else:
-        raise NotImplementedError(f'--adapter_type {t} on the image tower: K-Adapter and soft prompt are not wired natively')
+        raise NotImplementedError(f'--adapter_type {t} on the image tower')
     getattr(model, 'model', model).invalidate_native()
     return model
 

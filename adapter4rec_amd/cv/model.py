@@ -16,7 +16,8 @@ from ..model.bert import _Container
 from ..model.encoders import User_Encoder
 from ..model.model import (_NativeLoss, CompacterModel, SASRecAdaptedSelfOutput, SASRecCompacterAdaptedSelfOutput,   # noqa: F401
                            SASRecParallelAdaptedSelfOutput, SASRecPfeifferVer2AdaptedSelfOutput)
-from ..model.modules import AdapterBlock, HyperComplexAdapterBlock
+from ..model.model import SASRecKAdaptedTransformerBlocks  # noqa: F401
+from ..model.modules import AdapterBlock, HyperComplexAdapterBlock, KAdapterBlock
 
 
 class Vit_Encoder(nn.Module):                    # encoders.py:25-32
@@ -121,6 +122,25 @@ class SoftPrompt(_Container):                    # model.py:512-535: n_tokens le
         self.patch_embeddings = wte.patch_embeddings
         self.n_tokens = n_tokens
         self.Prompt_Tokens = nn.Parameter(torch.zeros(1, n_tokens, embed_dim))
+
+
+class VITKAdaptedCVModel(_Container):            # model.py:374-404 (K-Adapter on the image tower)
+    """Sits where ``image_net.vit.encoder`` was (run_adapter.py:378-380): KAdapterBlock j reads hidden_states[i + 1] for the j-th i of
+    --k_adapter_bert_list plus the previous adapter's output; ``com_dense`` fuses [last hidden state ; last adapter output] back to
+    the ViT width before ``vit.layernorm``.  Keys: ``...vit.encoder.vit_encoder.layer.*``, ``...bert_adapter_list.*``, ``...com_dense.*``."""
+
+    def __init__(self, vit_encoder, args):
+        super().__init__()
+        dim = vit_encoder.layer[0].layernorm_before.normalized_shape[0]       # the reference hard-codes 768 (ViT-B)
+        self.vit_encoder = vit_encoder
+        self.k_adapter_num_list = [int(i) + 1 for i in str(args.k_adapter_bert_list).split(',')]
+        self.bert_adapter_list = nn.ModuleList([KAdapterBlock(args, args.num_adapter_heads_bert, dim, args.k_adapter_bert_hidden_dim,
+                                                              args.adapter_dropout_rate) for _ in self.k_adapter_num_list])
+        self.com_dense = nn.Linear(dim * 2, dim)
+
+    @property
+    def layer(self):
+        return self.vit_encoder.layer
 
 
 # ---------------------------------------------------------------- ViT-side wrappers (pre-LN: no LayerNorm inside)

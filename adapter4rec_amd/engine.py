@@ -617,9 +617,11 @@ class TransRecEngine:
         Fv = ff.w_1.out_features
         F = pad_to(Fv, 64)
         dh = Hv // nh
-        if dh not in (32, 64) and not (0 < dh <= 16) or S > 32:
+        long = S > 32                 # K-Adapter blocks over the ViT token rows (S = 197 / 50): a4r_attn_long_*, no mask, dh 64 / 32
+        if dh not in (32, 64) and not (0 < dh <= 16 and not long) or S > 256 or (long and (causal or H != Hv)):
             raise NotImplementedError(f'transformer block geometry width={Hv} heads={nh} S={S}')
         b = _Block()
+        b.long = long
         b.lora = []
         for slot, lin in enumerate((mha.w_Q, mha.w_K, mha.w_V)):
             if type(lin).__name__ == 'LoRALinear':
@@ -733,6 +735,10 @@ class TransRecEngine:
         T, H, F = blk.T, blk.H, blk.F
         d = {}
         d['qkv'] = self._buf(pre + '.qkv', M, 3 * H, T)
+        if getattr(blk, 'long', False):              # a4r_attn_long_*: row log-sum-exp, and the forward output for delta = dO . O
+            d['lse'] = self._buf(pre + '.lse', (M // blk.S + 1) * blk.nh * blk.S, 1, torch.float32)
+            if not shared:
+                d['ctx_o'] = self._buf(pre + '.ctx_o', M, H, T)
         if Mc is not None:
             pre, M = pre + '.cls', Mc
         if (blk.lora or blk.pl1 == 'parallel' or blk.train_dense) and not shared:
@@ -820,9 +826,15 @@ class TransRecEngine:
         L.gemm_nt(x, blk.wqkv, bufs['qkv'], bias=blk.bqkv, M=M)
         if 'xin' in bufs:
             L.gather_rows(x, bufs['xin'], M, 1)      # LoRA backward needs the block input (t = x A^T, dA = dt^T x)
-        ctx = self._buf('ctx', M, H, T)
-        L.attn_fwd(bufs['qkv'], ctx, key_mask, n_items, blk.S, blk.nh, blk.dh, 0, H, 2 * H, blk.causal, blk.scale, blk.mask_neg,
-                   drop_p=pa, drop_site=blk.site, drop_seed=seed)
+        if getattr(blk, 'long', False):
+            assert key_mask is None
+            ctx = bufs['ctx_o'] if 'ctx_o' in bufs else self._buf('ctx', M, H, T)
+            L.attn_long_fwd(bufs['qkv'], ctx, bufs['lse'], n_items, blk.S, blk.nh, blk.dh, 0, H, 2 * H, blk.scale,
+                            drop_p=pa, drop_site=blk.site, drop_seed=seed)
+        else:
+            ctx = self._buf('ctx', M, H, T)
+            L.attn_fwd(bufs['qkv'], ctx, key_mask, n_items, blk.S, blk.nh, blk.dh, 0, H, 2 * H, blk.causal, blk.scale, blk.mask_neg,
+                       drop_p=pa, drop_site=blk.site, drop_seed=seed)
         if cls_rows is not None:
             ctx_c, x_c = self._buf('ctx_c', cls_rows, H, T), self._buf('x_c', cls_rows, H, T)
             L.gather_rows(ctx, ctx_c, n_items, blk.S)
@@ -985,8 +997,13 @@ class TransRecEngine:
             L.scatter_rows_fill(dres1, rfull, n_items, blk.S, M)
             dres1 = rfull
         dqkv = self._buf_tail0('dqkv', M, 3 * H, T, n_items * blk.S)       # attn_bwd writes the real token rows only
-        L.attn_bwd(bufs['qkv'], dctx, dqkv, key_mask, n_items, blk.S, blk.nh, blk.dh, 0, H, 2 * H, blk.causal, blk.scale, blk.mask_neg,
-                   drop_p=pa, drop_site=blk.site, drop_seed=seed)
+        if getattr(blk, 'long', False):
+            ws = self._buf('attn_ws', bufs['lse'].shape[0], 1, torch.float32)
+            L.attn_long_bwd(bufs['qkv'], bufs['ctx_o'], dctx, dqkv, bufs['lse'], ws, n_items, blk.S, blk.nh, blk.dh, 0, H, 2 * H, blk.scale,
+                            drop_p=pa, drop_site=blk.site, drop_seed=seed)
+        else:
+            L.attn_bwd(bufs['qkv'], dctx, dqkv, key_mask, n_items, blk.S, blk.nh, blk.dh, 0, H, 2 * H, blk.causal, blk.scale, blk.mask_neg,
+                       drop_p=pa, drop_site=blk.site, drop_seed=seed)
         for lo in blk.lora:
             self._lora_backward(blk, lo, dqkv, bufs['xin'], M)
         for sl, d in enumerate(blk.qkv):

@@ -70,7 +70,10 @@ class ViTRecEngine(TransRecEngine):
             raise NotImplementedError('training the ViT-MAE embedding side (--fine_tune_to all) is not wired natively')
         self.next_noise = None
         self.bert_blocks = []
-        for i, layer in enumerate(core.encoder.layer):
+        kmod, enc_mod = None, core.encoder
+        if type(enc_mod).__name__ == 'VITKAdaptedCVModel':       # model.py:374-404: the wrapper sits where vit.encoder was
+            kmod, enc_mod = enc_mod, enc_mod.vit_encoder
+        for i, layer in enumerate(enc_mod.layer):
             b = _Block()
             att = layer.attention.attention
             b.lora = []
@@ -114,6 +117,18 @@ class ViTRecEngine(TransRecEngine):
         else:
             self.fc_wT32.copy_(fc.weight.detach().t().float())
         self.cls_only = bool(getattr(self.args, 'cls_only_last', True))      # last layer: only the CLS rows go past attention
+        self.bert_trains = any(p.requires_grad for p in enc_mod.parameters())
+        self.bert_kads, self.bert_klist, self.d_com = [], [], None
+        if kmod is not None:
+            nb = len(self.bert_blocks)
+            self.bert_klist = [int(k) for k in kmod.k_adapter_num_list]
+            if any(k < 1 or k > nb for k in self.bert_klist):
+                raise ValueError(f'--k_adapter_bert_list {self.bert_klist} outside 1..{nb}')
+            if self.fp8:
+                raise NotImplementedError('K-Adapter on the fp8 image tower')
+            self.bert_kads = [self._make_kadapter(a, H, self.S, self.T, 6000 + 64 * j) for j, a in enumerate(kmod.bert_adapter_list)]
+            self.d_com = _Dense(self, kmod.com_dense.weight, kmod.com_dense.bias, self.T)
+            self.cls_only = False                      # the adapters attend over all tokens of the last layer's output
 
     def _vit_so(self, mod):
         """(dense Linear, adapter or None) of a plain or wrapped ViTSelfOutput / ViTOutput."""
@@ -335,7 +350,11 @@ class ViTRecEngine(TransRecEngine):
                 bufs = self._block_bufs('vit.shared', blk, M, True, Mc=Ip if cmode else None)
                 self._vit_block_forward(blk, x, n_items, M, bufs, cls if cmode else other, cls_rows=Ip if cmode else None)
                 x, other = (cls, other) if cmode else (other, x)
-        if not self.cls_only:
+            if (i + 1) in self.bert_klist and i + 1 < nb:
+                L.gather_rows(x, self._buf(f'khs{i + 1}', M, H, self.T), M, 1)      # hidden_states[i + 1], read by a K-Adapter below
+        if self.bert_kads:       # model.py:389-404: adapters chained over the listed hidden states, com_dense([last ; adapter]) -> layernorm
+            self._kad_chain_forward(x, n_items, M, Ip, train, seed, cls, saved is not None)
+        elif not self.cls_only:
             L.gather_rows(x, cls, n_items, S)
         cln = self._buf('cls_n', Ip, H, self.T)
         self._cls_st = self._buf('cls_st', Ip, 2, torch.float32)
@@ -361,12 +380,19 @@ class ViTRecEngine(TransRecEngine):
         L.ln_bwd(dcln, self._buf('cls', Ip, H, self.T), self._cls_st, self.vit_ln.gamma, dcls, M=Ip,
                  dgamma=gg(self.vit_ln.g_gamma), dbeta=gg(self.vit_ln.g_beta))
         dxb = self._buf('dx_a', M, H, self.T)
-        if not self.cls_only:
+        d_hs = {}
+        if self.bert_kads:
+            d_hs = self._kad_chain_backward(dcls, n_items, M, Ip, c['train'], c['seed'], dxb)
+            if not (self.bert_trains or self.train_emb):
+                return                             # frozen backbone: nothing trainable lies upstream of its activations
+        elif not self.cls_only:
             L.scatter_rows_fill(dcls, dxb, n_items, self.S, M)
         spare = self._buf('dx_b', M, H, self.T)
         last = len(self.bert_blocks) - 1
         for i in range(last, -1, -1):
             blk = self.bert_blocks[i]
+            if (i + 1) in d_hs:
+                dxb.add_(d_hs[i + 1])              # hidden_states[i + 1] also fed a K-Adapter
             if self.cls_only and i == last:
                 self._vit_block_backward(blk, dcls, n_items, M, c['saved_b'][i], spare if blk.need_dx else None, cls_rows=Ip)
             else:

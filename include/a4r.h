@@ -120,12 +120,15 @@ typedef struct {
 int a4r_attn_fwd(void* stream, const a4r_attn_t* a);
 int a4r_attn_bwd(void* stream, const a4r_attn_t* a);
 
-/* The same attention for 32 < S <= 256 tokens per item and dh == 64, without mask / causal / dropout (key_mask NULL,
- * causal 0, drop_p 0, else A4R_EINVAL): the ViT / ViT-MAE item tower (HF ViTSelfAttention under
- * Downstream/CV/model/encoders.py:21-32; S = 197 / 50).  One workgroup per (item, head); nothing S x S reaches HBM.
+/* The same attention for 32 < S <= 256 tokens per item and dh == 64 or 32, without mask / causal (key_mask NULL, causal 0,
+ * else A4R_EINVAL): the ViT / ViT-MAE item tower (HF ViTSelfAttention under Downstream/CV/model/encoders.py:21-32;
+ * S = 197 / 50, dh 64, drop_p 0) and the TransformerBlocks inside VITKAdaptedCVModel's KAdapterBlocks
+ * (Downstream/CV/model/model.py:374-404, modules.py:24-36,148-187; width 384 = 12 heads of 32, all-ones mask, dropout
+ * drop_p on the probabilities with the counter (item * heads + head, query, key)).  One workgroup per (item, head);
+ * nothing S x S reaches HBM.
  * fwd also writes lse [n_items, n_heads, S] fp32 (row max + log row sum of the scaled scores), which bwd reads;
  * bwd reads a->out = the ctx fwd wrote (ldo), a->dout = d ctx, and needs delta_ws [n_items, n_heads, S] fp32 scratch
- * (dO . O per query, produced by its dq launch, consumed by its dk/dv launch).  fp32 instantiation: backward needs S <= 128 (LDS). */
+ * (dO . O per query, produced by its dq launch, consumed by its dk/dv launch).  fp32, dh 64: backward needs S <= 128 (LDS). */
 int a4r_attn_long_fwd(void* stream, const a4r_attn_t* a, float* lse);
 int a4r_attn_long_bwd(void* stream, const a4r_attn_t* a, const float* lse, float* delta_ws);
 

@@ -400,13 +400,20 @@ def vit_layer(sd, lp, x, cfg):
 
 def vit_encode(sd, images, cfg, noise=None, return_all=False):
     p = _vit_prefix(sd)
+    kad = p + 'encoder.com_dense.weight' in sd      # Downstream/CV/model/model.py:374-404 VITKAdaptedCVModel sits where vit.encoder was
+    ep = p + ('encoder.vit_encoder.' if kad else 'encoder.')
     x = vit_embed(sd, images, cfg, noise)
-    hs = [x]
+    hs = [x]                                        # 4.20.1 ViTEncoder: hidden_states[0] = embedding output, [i + 1] = output of layer i
     i = 0
-    while f'{p}encoder.layer.{i}.layernorm_before.weight' in sd:
-        x = vit_layer(sd, f'{p}encoder.layer.{i}.', x, cfg)
+    while f'{ep}layer.{i}.layernorm_before.weight' in sd:
+        x = vit_layer(sd, f'{ep}layer.{i}.', x, cfg)
         hs.append(x)
         i += 1
+    if kad:                                         # :393-401: adapters chained over the listed hidden states, then com_dense([last ; adapter])
+        last = 0
+        for j, k in enumerate(int(t) + 1 for t in str(cfg['k_adapter_bert_list']).split(',')):
+            last = kadapter_block(sd, p + f'encoder.bert_adapter_list.{j}.', hs[k] + last, cfg['num_adapter_heads_bert'], cfg)
+        x = linear(torch.cat([x, last], -1), sd[p + 'encoder.com_dense.weight'], sd[p + 'encoder.com_dense.bias'])
     x = layer_norm(x, sd[p + 'layernorm.weight'], sd[p + 'layernorm.bias'], cfg.get('vit_ln_eps', 1e-12))
     return (x, hs) if return_all else x
 

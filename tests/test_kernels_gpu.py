@@ -314,16 +314,20 @@ def test_attention_fwd_bwd(dt, name, S, nh, dh, causal, neg):
           atol16=4e-2 * float(qr.grad.abs().max()))
 
 
-LONG_CASES = [('f32', 33, 2), ('f32', 50, 12), ('f32', 64, 3), ('f32', 100, 2), ('f32', 128, 2),
-              ('bf16', 33, 2), ('bf16', 50, 12), ('bf16', 65, 3), ('bf16', 128, 2), ('bf16', 197, 12), ('bf16', 224, 2), ('bf16', 256, 2)]
+LONG_CASES = [('f32', 33, 2, 64), ('f32', 50, 12, 64), ('f32', 64, 3, 64), ('f32', 100, 2, 64), ('f32', 128, 2, 64),
+              ('bf16', 33, 2, 64), ('bf16', 50, 12, 64), ('bf16', 65, 3, 64), ('bf16', 128, 2, 64), ('bf16', 197, 12, 64),
+              ('bf16', 224, 2, 64), ('bf16', 256, 2, 64),
+              # head width 32: the K-Adapter blocks of VITKAdaptedCVModel (width 384, 12 heads; S = 197 / 50)
+              ('f32', 33, 2, 32), ('f32', 50, 12, 32), ('f32', 100, 3, 32), ('f32', 197, 12, 32), ('f32', 256, 2, 32),
+              ('bf16', 40, 2, 32), ('bf16', 50, 12, 32), ('bf16', 128, 3, 32), ('bf16', 197, 12, 32), ('bf16', 256, 2, 32)]
 
 
-@pytest.mark.parametrize('dt,S,nh', LONG_CASES)
-def test_attention_long_fwd_bwd(dt, S, nh):
-    """a4r_attn_long_*: the un-masked ViT / MAE attention (S up to 256, dh 64) against fp32 torch softmax(QK^T/8)V."""
+@pytest.mark.parametrize('dt,S,nh,dh', LONG_CASES)
+def test_attention_long_fwd_bwd(dt, S, nh, dh):
+    """a4r_attn_long_*: the un-masked ViT / MAE attention (S up to 256, dh 64 / 32) against fp32 torch softmax(QK^T/sqrt(dh))V."""
     from adapter4rec_amd import _lib as L
     t = DT[dt]
-    n_items, dh = 5, 64
+    n_items = 5
     Hd = nh * dh
     Mp = ((n_items * S + 255) // 256) * 256
     qkv = rnd(Mp, 3 * Hd, dtype=t, seed=31 + S)
@@ -359,6 +363,54 @@ def test_attention_long_rejects():
         L.attn_long_bwd(qkv, out, out, torch.zeros_like(qkv), lse, torch.zeros_like(lse), 2, 200, 1, 64, 0, 64, 128, 0.125)
     with pytest.raises(RuntimeError):
         L.attn_long_fwd(qkv, out, lse, 1, 300, 1, 64, 0, 64, 128, 0.125)       # S > 256
+    with pytest.raises(RuntimeError):
+        L.attn_long_fwd(qkv, out, lse, 1, 100, 1, 48, 0, 64, 128, 0.125)       # head width other than 64 / 32
+    with pytest.raises(RuntimeError):
+        L.attn_long_fwd(qkv, out, lse, 1, 100, 1, 64, 0, 64, 128, 0.125, drop_p=1.0)
+
+
+@pytest.mark.parametrize('dt,S,nh,dh', [('f32', 64, 2, 64), ('f32', 100, 3, 32), ('bf16', 197, 12, 32), ('bf16', 197, 2, 64), ('bf16', 50, 12, 32)])
+def test_attention_long_dropout(dt, S, nh, dh):
+    """Dropout on the probabilities (SelfAttention.dropout, CV modules.py:35) in the long kernels.  The mask is read back from the
+    forward kernel itself (Q = K = 0 makes P uniform, V = a shifted identity exposes P' column block by column block; the mask is
+    a function of (seed, site, item, head, query, key) only), then forward and all three gradients are held to torch autograd
+    with that mask: forward, dq and dk/dv launches must regenerate exactly the same keep pattern."""
+    from adapter4rec_amd import _lib as L
+    t = DT[dt]
+    n_items, p, site, seed = 3, 0.3, 11, 1234
+    Hd = nh * dh
+    Mp = ((n_items * S + 255) // 256) * 256
+    offs = (0, Hd, 2 * Hd)
+    scale = 1.0 / math.sqrt(dh)
+    lse = torch.zeros(n_items * nh * S, device=dev())
+    keep = torch.zeros(n_items, nh, S, S, device=dev())
+    for blk in range((S + dh - 1) // dh):
+        probe = torch.zeros(Mp, 3 * Hd, dtype=t, device=dev())
+        v = probe[:n_items * S, 2 * Hd:].view(n_items, S, nh, dh)
+        for j in range(min(dh, S - blk * dh)):
+            v[:, blk * dh + j, :, j] = 1.0
+        o = torch.zeros(Mp, Hd, dtype=t, device=dev())
+        L.attn_long_fwd(probe, o, lse, n_items, S, nh, dh, *offs, scale, drop_p=p, drop_site=site, drop_seed=seed)
+        blkv = o[:n_items * S].float().view(n_items, S, nh, dh).permute(0, 2, 1, 3)[..., :min(dh, S - blk * dh)]
+        keep[..., blk * dh:blk * dh + blkv.shape[-1]] = (blkv > 0).float()
+    frac = keep.mean().item()
+    assert abs(frac - (1 - p)) < 0.01, frac
+    ks = 1.0 / (1.0 - round(p * 65536) / 65536.0)
+    qkv = rnd(Mp, 3 * Hd, dtype=t, seed=41 + S)
+    out = torch.zeros(Mp, Hd, dtype=t, device=dev())
+    L.attn_long_fwd(qkv, out, lse, n_items, S, nh, dh, *offs, scale, drop_p=p, drop_site=site, drop_seed=seed)
+    qr = qkv.float().clone().requires_grad_(True)
+    q, k, v = [qr[:n_items * S, o_:o_ + Hd].view(n_items, S, nh, dh).transpose(1, 2) for o_ in offs]
+    pr = torch.softmax(q @ k.transpose(-1, -2) * scale, -1) * keep * ks
+    ref = (pr @ v).transpose(1, 2).reshape(n_items * S, Hd)
+    close(out[:n_items * S], ref.detach(), t, f'attn_long dropout fwd S={S} {dt}', atol32=1e-4, rtol32=1e-4)
+    dout = rnd(Mp, Hd, dtype=t, seed=42)
+    dout[n_items * S:] = 0
+    dqkv = torch.zeros_like(qkv)
+    L.attn_long_bwd(qkv, out, dout, dqkv, lse, torch.zeros_like(lse), n_items, S, nh, dh, *offs, scale, drop_p=p, drop_site=site, drop_seed=seed)
+    ref.backward(dout[:n_items * S].float())
+    close(dqkv[:n_items * S], qr.grad[:n_items * S], t, f'attn_long dropout bwd S={S} {dt}', atol32=2e-4, rtol32=2e-4,
+          atol16=4e-2 * float(qr.grad.abs().max()))
 
 
 @pytest.mark.parametrize('dt', ['f32', 'bf16'])

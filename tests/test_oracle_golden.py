@@ -110,7 +110,7 @@ def test_cv_forward_and_grads(name):
             np.testing.assert_allclose(grads[strip(k)].numpy(), ref, atol=1e-5 + 1e-4 * np.abs(ref).max(), rtol=0, err_msg=k)
 
 
-@pytest.mark.parametrize('name', ['cv_vit_houlsby', 'cv_vit_compacter', 'cv_mae_houlsby'])
+@pytest.mark.parametrize('name', ['cv_vit_houlsby', 'cv_vit_compacter', 'cv_mae_houlsby', 'cv_vit_kadapter'])
 def test_cv_adam_three_steps(name):
     sd, cfg, fx, trainable, batch, _ = load_cv_variant(name)
     # lr groups are decided on the module names incl. the CompacterModel 'model.' prefix (none of the tests here depends on it)
@@ -118,7 +118,9 @@ def test_cv_adam_three_steps(name):
     np.testing.assert_allclose(losses3, fx['adam_losses'], atol=TOL * 20, rtol=0)
     for k in fx['trainable']:
         k = str(k)
-        np.testing.assert_allclose(p3[strip(k)].numpy(), fx['adam3/' + k], rtol=2e-4, atol=2e-7, err_msg=k)
+        # atol: Adam's update is lr * m / (sqrt(v) + 1e-8); where |g| is at fp32-rounding level the ratio is rounding noise, so an element
+        # may move by a small fraction of lr (5e-4 here) differently; 1e-6 = 0.2 % of one step
+        np.testing.assert_allclose(p3[strip(k)].numpy(), fx['adam3/' + k], rtol=2e-4, atol=1e-6, err_msg=k)
 
 
 def test_cv_backbone_matches_installed_hf():

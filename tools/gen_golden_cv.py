@@ -25,6 +25,8 @@ OUT = os.path.join(os.path.dirname(os.path.abspath(__file__)), '..', 'tests', 'g
 
 import model as refm  # noqa: E402
 from model import Model, ModelCPC  # noqa: E402
+from model.model import VITKAdaptedCVModel, SASRecKAdaptedTransformerBlocks  # noqa: E402
+from model.modules import KAdapterBlock  # noqa: E402
 from model.model import (SoftPrompt, VITAdaptedParallelOutput, SASRecParallelAdaptedSelfOutput, VITAdaptedSelfOutput, VITAdaptedOutput, VITCompacterAdaptedSelfOutput, VITCompacterAdaptedOutput,  # noqa: E402
                          SASRecAdaptedSelfOutput, SASRecPfeifferV2AdaptedSelfOutput, SASRecCompacterAdaptedSelfOutput)
 from model.modules import AdapterBlock, HyperComplexAdapterBlock  # noqa: E402
@@ -107,10 +109,14 @@ class Encoder(nn.Module):
         super().__init__()
         self.layer = nn.ModuleList([Layer() for _ in range(LAYERS)])
 
-    def forward(self, x):
+    def forward(self, x, head_mask=None, output_attentions=False, output_hidden_states=False, return_dict=True):
+        """4.20.1 ViTEncoder.forward's signature; with output_hidden_states the tuple form (last, all hidden states = the embedding
+        output followed by every layer's output, attentions [not produced here]) that VITKAdaptedCVModel indexes (model.py:388-391)."""
+        hs = (x,)
         for l_ in self.layer:
             x = l_(x)
-        return x
+            hs = hs + (x,)
+        return (x, hs, ()) if output_hidden_states else x
 
 
 class PatchEmbeddings(nn.Module):
@@ -149,8 +155,9 @@ class ViTModel(nn.Module):
         super().__init__()
         self.embeddings, self.encoder, self.layernorm = Embeddings(mae), Encoder(), nn.LayerNorm(HID, eps=1e-12)
 
-    def forward(self, px, **kw):
-        return (self.layernorm(self.encoder(self.embeddings(px))),)
+    def forward(self, px, **kw):        # 4.20.1 ViTModel.forward: keyword call into the encoder, sequence output = element 0
+        enc = self.encoder(self.embeddings(px), head_mask=None, output_attentions=None, output_hidden_states=None, return_dict=None)
+        return (self.layernorm(enc if torch.is_tensor(enc) else enc[0]),)
 
 
 class ViTForImageClassification(nn.Module):
@@ -216,6 +223,18 @@ def layers_of(m):
     return net.vit.encoder.layer if hasattr(net, 'vit') else net.encoder.layer
 
 
+def inject_kadapter(m, args):          # Downstream/CV/run_adapter.py:378-383 at the tiny width
+    net = m.cv_encoder.image_net
+    w = VITKAdaptedCVModel(net.vit.encoder, args)                 # hard-codes 768: the adapter list / com_dense are re-created at HID
+    w.bert_adapter_list = nn.ModuleList([KAdapterBlock(args, args.num_adapter_heads_bert, HID, args.k_adapter_bert_hidden_dim,
+                                                       args.adapter_dropout_rate) for _ in w.k_adapter_num_list])
+    w.com_dense = nn.Linear(HID * 2, HID)
+    net.vit.encoder = w
+    te = m.user_encoder.transformer_encoder
+    te.transformer_blocks = SASRecKAdaptedTransformerBlocks(te.transformer_blocks, args)
+    return m
+
+
 def inject(m, args):                   # Downstream/CV/run_adapter.py:369-447 at the tiny width (see module docstring)
     t = args.adapter_type
     blocks = m.user_encoder.transformer_encoder.transformer_blocks
@@ -231,6 +250,8 @@ def inject(m, args):                   # Downstream/CV/run_adapter.py:369-447 at
             if 'cv_encoder.image_net.classifier' in n_:
                 p.requires_grad = True
         return m
+    if 'kadapter' in t:
+        return inject_kadapter(m, args)
     if 'pfeiffer_ver2' in t:
         for lyr in layers_of(m):
             lyr.attention.output = wrap(VITAdaptedSelfOutput, lyr.attention.output, AdapterBlock)
@@ -274,7 +295,8 @@ def optimizer_for(m):                  # run_adapter.py:491-517
 def base_name(k):
     if k.startswith('model.'):
         k = k[len('model.'):]
-    return k.replace('.self_output.', '.').replace('.transformer_block.', '.')
+    return k.replace('.self_output.', '.').replace('.transformer_block.', '.').replace('.encoder.vit_encoder.', '.encoder.') \
+        .replace('.transformer_blocks.transformer_blocks.', '.transformer_blocks.')
 
 
 def run_variant(name, base_model, images, masks, noise, args, layernorm=False):
@@ -379,12 +401,17 @@ def main():
     base_mae.eval()
     d1, d2 = check_against_installed_hf(vit, mae_net, images[:6], noise[:6])
 
-    if not (len(sys.argv) > 1 and sys.argv[1] in ('--parallel-only', '--prompt-only')):
+    if not (len(sys.argv) > 1 and sys.argv[1] in ('--parallel-only', '--prompt-only', '--kadapter-only')):
       np.savez_compressed(os.path.join(OUT, 'cv_base.npz'), images=images.numpy(), log_mask=masks.numpy(), noise=noise.numpy(),
                         hf_check=np.array([d1, d2]), **{'sd/' + k: v.numpy() for k, v in base.state_dict().items()})
       np.savez_compressed(os.path.join(OUT, 'cv_base_mae.npz'), **{'sd/' + k: v.numpy() for k, v in base_mae.state_dict().items()})
     if len(sys.argv) > 1 and sys.argv[1] == '--parallel-only':      # added later: leaves the other fixtures untouched
         run_variant('cv_vit_parallel', base, images, masks, noise, make_args(is_serial='None'))
+        return
+    if len(sys.argv) > 1 and sys.argv[1] == '--kadapter-only':     # added in round 2
+        run_variant('cv_vit_kadapter', base, images, masks, noise,
+                    make_args(adapter_type='kadapter', k_adapter_bert_list='0,1', k_adapter_bert_hidden_dim=64, num_adapter_heads_bert=2,
+                              num_adapter_heads_sasrec=2))
         return
     if len(sys.argv) > 1 and sys.argv[1] == '--prompt-only':
         run_variant('cv_vit_prompt', base, images, masks, noise, make_args(adapter_type='prompt', n_tokens=5))
