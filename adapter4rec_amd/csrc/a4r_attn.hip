@@ -5,6 +5,7 @@
 // HBM.  Operands whose contraction index runs along tile rows (V in P.V; dO, Q, K in the backward
 // products) are staged once in LDS and gathered down columns; P / dS are re-laid out through LDS.
 // The kernel is HBM-bound (reads qkv once, writes ctx once); all softmax arithmetic is fp32.
+#include <cstdlib>
 #include "a4r_common.h"
 #include "../../include/a4r.h"
 
@@ -352,6 +353,249 @@ __global__ void __launch_bounds__(WAVES * 64) attn_bwd_kernel(const T* __restric
     store_block<T, DH>(Ks, acc, gbase + q_off, ld, S, lane, active);
 }
 
+// ------------------------------------------------------------------------------------------------ backward, bf16 (round 2)
+// The same mathematics arranged around what timing ablations showed (tools/attn_short_bench.py, A4R_ATTN_BWD_ABL: 1 = no stores,
+// 2 = no loads).  With neither loads nor stores the generic kernel above still took ~90 of its ~150 us at the text tower's shape: it
+// is INSTRUCTION-bound (a 16-lane shuffle reduction per query row, one dropout hash per element, precise expf, ~300 two-byte LDS
+// operations per lane for the P / dS / dS^T images, column gathers, output staging), not HBM-bound.  Here (40 us of work, 100 us total):
+//   * the scores are produced TRANSPOSED (S^T = K Q^T: rows = keys, the lane's column = a query), so a query's 32 keys are 8
+//     registers x the 4 lanes l, l^16, l^32, l^48: softmax and delta are register sums + two xor-shuffles, 4 consecutive keys share
+//     one dropout hash (the lots dropout_keep draws from), exp is v_exp_f32;
+//   * a 16 x 16 accumulator tile IS an MFMA operand chunk once the contraction index is permuted -- k-slot (kg, j) <-> row
+//     (j >> 2) * 16 + 4 kg + (j & 3) of the tile pair (tile 0 | tile 1) -- the same permutation ds_read_b64_tr_b16 applies to a
+//     row-major LDS image read down its columns (a4r_attn_long.hip).  dQ^T = K^T dS^T therefore takes dS^T straight from the
+//     accumulator registers and two transposed reads of the K image (the image = plain 16-byte stores of the very registers the
+//     score MFMAs consumed);
+//   * dV^T = dO^T P' and dK^T = Q^T dS contract over the queries with the KEY on the lane: P'^T and dS^T change hands once through
+//     the then-free K image (8 two-byte stores, 4 eight-byte loads per lane);
+//   * the three transposed products go back through the images so that rows leave as whole 16-byte chunks, 8 lanes = one 128-byte
+//     line: stored straight from the accumulators (8 bytes per lane, 32-byte pieces of 16 rows per instruction) the same bytes took
+//     32 us longer.
+// 12 KiB of LDS per wave (was 18.75), 140 VGPRs: three workgroups per CU.  Mask, causal and dropout semantics are the generic kernel's.
+typedef short bt_v4s_t __attribute__((ext_vector_type(4)));
+template <int DH> struct BtGeo {
+    static constexpr int ROWB = DH * 2, CPR = DH / 8, KSD = DH / 32, ND = DH / 16, IMG = 32 * ROWB;
+    static constexpr int WAVE_LDS = 2 * IMG + (IMG > 4096 ? IMG : 4096);      // Q, dO, K images; the K slot later holds P'^T | dS^T (2 x 2 KiB)
+    static A4R_DEV int swz(int row) { return CPR == 8 ? ((row >> 1) & 7) : ((row >> 2) & 3); }
+};
+template <int DH> A4R_DEV uint4 bt_frag_tr(const char* img, int d0, int lane) {
+    using G = BtGeo<DH>;
+    const int kg = lane >> 4, q = (lane >> 2) & 3, pp = lane & 3;
+    const int chunk = (d0 >> 3) + (pp >> 1);
+    const int r0 = 4 * kg + q, r1 = r0 + 16;
+    const char* a0 = img + r0 * G::ROWB + ((chunk ^ G::swz(r0)) << 4) + 8 * (pp & 1);
+    const char* a1 = img + r1 * G::ROWB + ((chunk ^ G::swz(r1)) << 4) + 8 * (pp & 1);
+    const bt_v4s_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) bt_v4s_t*)(a0));
+    const bt_v4s_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) bt_v4s_t*)(a1));
+    const uint2 l2 = __builtin_bit_cast(uint2, lo), h2 = __builtin_bit_cast(uint2, hi);
+    return make_uint4(l2.x, l2.y, h2.x, h2.y);
+}
+A4R_DEV uint4 bt_pack(const f32x4_t& a, const f32x4_t& b) {       // tile 0 rows | tile 1 rows of one lane column -> operand chunk
+    return make_uint4(f32_to_bf16_bits(a[0]) | (f32_to_bf16_bits(a[1]) << 16), f32_to_bf16_bits(a[2]) | (f32_to_bf16_bits(a[3]) << 16),
+                      f32_to_bf16_bits(b[0]) | (f32_to_bf16_bits(b[1]) << 16), f32_to_bf16_bits(b[2]) | (f32_to_bf16_bits(b[3]) << 16));
+}
+A4R_DEV void bt_store4(bf16_t* p, const f32x4_t& v) {
+    *reinterpret_cast<uint2*>(p) = make_uint2(f32_to_bf16_bits(v[0]) | (f32_to_bf16_bits(v[1]) << 16),
+                                              f32_to_bf16_bits(v[2]) | (f32_to_bf16_bits(v[3]) << 16));
+}
+A4R_DEV float bt_red4(float v, bool mx) {       // over the 4 lanes l, l^16, l^32, l^48 that share a column
+    const float a = __shfl_xor(v, 16, 64);
+    v = mx ? fmaxf(v, a) : v + a;
+    const float b = __shfl_xor(v, 32, 64);
+    return mx ? fmaxf(v, b) : v + b;
+}
+
+template <int DH, int WAVES>
+__global__ void __launch_bounds__(WAVES * 64, 3) attn_bwd_tr_kernel(const bf16_t* __restrict__ qkv, int ld, int q_off, int k_off, int v_off,
+                                                                 const bf16_t* __restrict__ dout, int ldo, bf16_t* __restrict__ dqkv,
+                                                                 const float* __restrict__ key_mask, int n_items, int S, int n_heads,
+                                                                 int causal, float scale, float mask_neg,
+                                                                 uint64_t seed, uint32_t site, uint32_t thr16, float keep_scale, int abl) {
+    using T = bf16_t;
+    using G = BtGeo<DH>;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int r16 = lane & 15, kg = lane >> 4;
+    char* Qi = smem + wave * G::WAVE_LDS;
+    char* Oi = Qi + G::IMG;
+    char* Ki = Oi + G::IMG;
+    const int total = n_items * n_heads;
+    const int gw = blockIdx.x * WAVES + wave;
+    if (gw >= total) return;                      // whole waves leave (no workgroup barrier below; EXEC stays all ones for the transposed reads)
+    const int item = gw / n_heads, head = gw % n_heads;
+    const T* base = qkv + (size_t)item * S * ld + head * DH;
+    const T* dbase = dout + (size_t)item * S * ldo + head * DH;
+    T* gbase = dqkv + (size_t)item * S * ld + head * DH;
+
+    float kmT[2][4];                              // key mask of the keys down the lane's rows
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int kt = nt * 16 + kg * 4 + r;
+            kmT[nt][r] = (kt < S) ? (key_mask ? key_mask[(size_t)item * S + kt] : 1.f) : 0.f;
+        }
+    // every global read of the pair is requested before anything is consumed, every byte once (rows >= S: Q, K, V clamp to row S - 1,
+    // finite values whose scores are masked / whose dS rows vanish because dO is zero there)
+    uint4 fq[G::KSD][2], fk[G::KSD][2], fd[G::KSD][2], fv[G::KSD][2];
+#pragma unroll
+    for (int ks = 0; ks < G::KSD; ++ks)
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const int row = t * 16 + r16, rc = min(row, S - 1);
+            if (abl & 2) { fq[ks][t] = make_uint4(lane, ks, t, 1); fk[ks][t] = fq[ks][t]; fv[ks][t] = fq[ks][t]; fd[ks][t] = fq[ks][t]; continue; }
+            fq[ks][t] = ldg16(base + (size_t)rc * ld + q_off + (ks * 4 + kg) * 8);
+            fk[ks][t] = ldg16(base + (size_t)rc * ld + k_off + (ks * 4 + kg) * 8);
+            fv[ks][t] = ldg16(base + (size_t)rc * ld + v_off + (ks * 4 + kg) * 8);
+            fd[ks][t] = make_uint4(0u, 0u, 0u, 0u);
+            if (row < S) fd[ks][t] = ldg16(dbase + (size_t)row * ldo + (ks * 4 + kg) * 8);
+        }
+#pragma unroll
+    for (int ks = 0; ks < G::KSD; ++ks)
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const int row = t * 16 + r16, off = row * G::ROWB + (((ks * 4 + kg) ^ G::swz(row)) << 4);
+            *reinterpret_cast<uint4*>(Qi + off) = fq[ks][t];
+            *reinterpret_cast<uint4*>(Ki + off) = fk[ks][t];
+            *reinterpret_cast<uint4*>(Oi + off) = fd[ks][t];
+        }
+    f32x4_t scT[2][2], dpT[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) { scT[a][b] = f32x4_t{0.f, 0.f, 0.f, 0.f}; dpT[a][b] = scT[a][b]; }
+#pragma unroll
+    for (int ks = 0; ks < G::KSD; ++ks)
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt) {
+                Mma<T>::mma(fk[ks][nt], fq[ks][mt], scT[nt][mt]);      // S^T  : rows key (4 kg + r of tile nt), column q = r16 of tile mt
+                Mma<T>::mma(fv[ks][nt], fd[ks][mt], dpT[nt][mt]);      // dP'^T = V dO^T
+            }
+    wave_lds_fence();                                     // the images are complete (this wave's own stores)
+    // ---- softmax / dropout / dS with the QUERY on the lane: its 32 keys are 8 registers x the lanes l, l^16, l^32, l^48
+    uint2 pw[2][2], dw[2][2];                             // P'^T and dS^T tiles as packed bf16 (4 consecutive keys of the lane's query)
+    f32x4_t aq[2][G::ND], av[2][G::ND], ak[2][G::ND];     // the three products, transposed: rows = 4 head columns, the lane's column = a token
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) {
+        const int q = mt * 16 + r16;
+        float x[2][4];
+        float m = -INFINITY;
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int key = nt * 16 + kg * 4 + r;
+                const float v = scT[nt][mt][r] * scale;
+                const bool allowed = (kmT[nt][r] != 0.f) && (!causal || key <= q);
+                x[nt][r] = key < S ? (allowed ? v : v + mask_neg) : -INFINITY;
+                m = fmaxf(m, x[nt][r]);
+            }
+        m = bt_red4(m, true);
+        float l = 0.f;
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { x[nt][r] = __expf(x[nt][r] - m); l += x[nt][r]; }
+        const float inv = 1.f / bt_red4(l, false);
+        float dsum = 0.f;
+        f32x4_t pk[2];
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) {
+            uint64_t hsh = 0;
+            if (thr16) hsh = a4r_hash64(seed, site, (((uint64_t)gw * 32 + q) * 32 + nt * 16 + kg * 4) >> 2);      // = dropout_keep's lots
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                x[nt][r] *= inv;                                                      // P
+                float keepf = 1.f;
+                if (thr16) keepf = (((uint32_t)(hsh >> (16 * r)) & 0xffffu) >= thr16) ? keep_scale : 0.f;
+                dpT[nt][mt][r] *= keepf;                                              // d loss / d P
+                pk[nt][r] = x[nt][r] * keepf;                                         // P'
+                dsum += dpT[nt][mt][r] * x[nt][r];
+            }
+        }
+        dsum = bt_red4(dsum, false);
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) dpT[nt][mt][r] = x[nt][r] * (dpT[nt][mt][r] - dsum) * scale;       // dS^T
+            pw[nt][mt] = make_uint2(f32_to_bf16_bits(pk[nt][0]) | (f32_to_bf16_bits(pk[nt][1]) << 16),
+                                    f32_to_bf16_bits(pk[nt][2]) | (f32_to_bf16_bits(pk[nt][3]) << 16));
+            dw[nt][mt] = make_uint2(f32_to_bf16_bits(dpT[nt][mt][0]) | (f32_to_bf16_bits(dpT[nt][mt][1]) << 16),
+                                    f32_to_bf16_bits(dpT[nt][mt][2]) | (f32_to_bf16_bits(dpT[nt][mt][3]) << 16));
+        }
+        const uint4 dsB = make_uint4(dw[0][mt].x, dw[0][mt].y, dw[1][mt].x, dw[1][mt].y);
+#pragma unroll
+        for (int dt = 0; dt < G::ND; ++dt) {
+            aq[mt][dt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+            Mma<T>::mma(bt_frag_tr<DH>(Ki, dt * 16, lane), dsB, aq[mt][dt]);       // dQ^T[d][q] = sum_key K[key][d] dS[q][key]
+        }
+    }
+    // ---- the other two products contract over the QUERIES with the key on the lane: the 16 x 16 tiles change hands through the
+    // (now free) K image, written [key][query] two bytes at a time and read back as the operand chunk itself (2 x 8 bytes)
+    wave_lds_fence();
+    unsigned short* Pt = reinterpret_cast<unsigned short*>(Ki);           // [32 keys][32 queries] bf16
+    unsigned short* Dt = Pt + 32 * 32;
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) {
+            const int q = mt * 16 + r16, k0 = nt * 16 + kg * 4;
+            Pt[(k0 + 0) * 32 + q] = (unsigned short)(pw[nt][mt].x & 0xffffu);
+            Pt[(k0 + 1) * 32 + q] = (unsigned short)(pw[nt][mt].x >> 16);
+            Pt[(k0 + 2) * 32 + q] = (unsigned short)(pw[nt][mt].y & 0xffffu);
+            Pt[(k0 + 3) * 32 + q] = (unsigned short)(pw[nt][mt].y >> 16);
+            Dt[(k0 + 0) * 32 + q] = (unsigned short)(dw[nt][mt].x & 0xffffu);
+            Dt[(k0 + 1) * 32 + q] = (unsigned short)(dw[nt][mt].x >> 16);
+            Dt[(k0 + 2) * 32 + q] = (unsigned short)(dw[nt][mt].y & 0xffffu);
+            Dt[(k0 + 3) * 32 + q] = (unsigned short)(dw[nt][mt].y >> 16);
+        }
+    wave_lds_fence();
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+        const int key = nt * 16 + r16;
+        const uint2 p0 = *reinterpret_cast<const uint2*>(Pt + key * 32 + kg * 4), p1 = *reinterpret_cast<const uint2*>(Pt + key * 32 + 16 + kg * 4);
+        const uint2 d0 = *reinterpret_cast<const uint2*>(Dt + key * 32 + kg * 4), d1 = *reinterpret_cast<const uint2*>(Dt + key * 32 + 16 + kg * 4);
+        const uint4 pB = make_uint4(p0.x, p0.y, p1.x, p1.y), dsB = make_uint4(d0.x, d0.y, d1.x, d1.y);
+#pragma unroll
+        for (int dt = 0; dt < G::ND; ++dt) {
+            av[nt][dt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+            ak[nt][dt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+            Mma<T>::mma(bt_frag_tr<DH>(Oi, dt * 16, lane), pB, av[nt][dt]);        // dV^T[d][key] = sum_q dO[q][d] P'[q][key]
+            Mma<T>::mma(bt_frag_tr<DH>(Qi, dt * 16, lane), dsB, ak[nt][dt]);       // dK^T[d][key] = sum_q Q[q][d] dS[q][key]
+        }
+    }
+    // ---- out: the three [32][DH] blocks go through the (now free) images so that a row leaves as whole 16-byte chunks, 8 lanes = one
+    // 128-byte line.  (Stored straight from the accumulators -- 8 bytes per lane, 32-byte pieces of 16 rows per instruction -- the same
+    // bytes took 32 us longer: A4R_ATTN_BWD_ABL=9 in tools/attn_short_bench.py.)
+    wave_lds_fence();
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        const int tok = t * 16 + r16;
+#pragma unroll
+        for (int dt = 0; dt < G::ND; ++dt) {
+            const int off = tok * G::ROWB + (((dt * 2 + (kg >> 1)) ^ G::swz(tok)) << 4) + 8 * (kg & 1);
+            bt_store4(reinterpret_cast<T*>(Qi + off), aq[t][dt]);
+            bt_store4(reinterpret_cast<T*>(Oi + off), av[t][dt]);
+            bt_store4(reinterpret_cast<T*>(Ki + off), ak[t][dt]);
+        }
+    }
+    wave_lds_fence();
+    if (!(abl & 1)) {
+#pragma unroll
+        for (int i = 0; i < 32 * G::CPR / 64; ++i) {
+            const int id = lane + 64 * i, row = id / G::CPR, ch = id % G::CPR;
+            if (row < S) {
+                const int off = row * G::ROWB + ((ch ^ G::swz(row)) << 4);
+                *reinterpret_cast<uint4*>(gbase + (size_t)row * ld + q_off + ch * 8) = *reinterpret_cast<const uint4*>(Qi + off);
+                *reinterpret_cast<uint4*>(gbase + (size_t)row * ld + v_off + ch * 8) = *reinterpret_cast<const uint4*>(Oi + off);
+                *reinterpret_cast<uint4*>(gbase + (size_t)row * ld + k_off + ch * 8) = *reinterpret_cast<const uint4*>(Ki + off);
+            }
+        }
+    }
+}
+
 struct Launch {
     hipStream_t s; const a4r_attn_t* a; uint32_t thr; float ks;
 };
@@ -371,7 +615,8 @@ template <typename T, int DH, int WAVES>
 int launch_bwd(const Launch& L) {
     using C = AttnCfg<T, DH>;
     const a4r_attn_t& a = *L.a;
-    constexpr int LDS = WAVES * (3 * 32 * C::GSTRIDE + 3 * 32 * C::PSTRIDE);
+    static const int pad = getenv("A4R_ATTN_BWD_LDS_PAD") ? atoi(getenv("A4R_ATTN_BWD_LDS_PAD")) : 0;      // occupancy experiment (tools/)
+    const int LDS = WAVES * (3 * 32 * C::GSTRIDE + 3 * 32 * C::PSTRIDE) + pad;
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_kernel<T, DH, WAVES>),
@@ -384,6 +629,24 @@ int launch_bwd(const Launch& L) {
                        a.n_items, a.S, a.n_heads, a.causal, a.scale, a.mask_neg, a.drop_seed, a.drop_site, L.thr, L.ks);
     return a4r_launch_status();
 }
+
+const int g_attn_bwd_abl = getenv("A4R_ATTN_BWD_ABL") ? atoi(getenv("A4R_ATTN_BWD_ABL")) : 0;      // timing ablations (wrong results): 1 no stores, 2 no loads
+template <int DH, int WAVES>
+int launch_bwd_tr(const Launch& L) {
+    const a4r_attn_t& a = *L.a;
+    constexpr int LDS = WAVES * BtGeo<DH>::WAVE_LDS;
+    static bool attr_set = false;
+    if (!attr_set && LDS > 48 * 1024) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_tr_kernel<DH, WAVES>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+        attr_set = true;
+    }
+    const int total = a.n_items * a.n_heads;
+    hipLaunchKernelGGL((attn_bwd_tr_kernel<DH, WAVES>), dim3((total + WAVES - 1) / WAVES), dim3(WAVES * 64), LDS, L.s,
+                       (const bf16_t*)a.qkv, a.ld, a.q_off, a.k_off, a.v_off, (const bf16_t*)a.dout, a.ldo, (bf16_t*)a.dqkv, a.key_mask,
+                       a.n_items, a.S, a.n_heads, a.causal, a.scale, a.mask_neg, a.drop_seed, a.drop_site, L.thr, L.ks, g_attn_bwd_abl);
+    return a4r_launch_status();
+}
+const bool g_attn_bwd_tr = !(getenv("A4R_ATTN_BWD_TR") && atoi(getenv("A4R_ATTN_BWD_TR")) == 0);      // 0: the generic kernel for bf16 too (A/B, tests)
 
 int check(const a4r_attn_t* a, bool bwd) {
     if (!a || !a->qkv) return A4R_EINVAL;
@@ -417,6 +680,11 @@ extern "C" int a4r_attn_bwd(void* stream, const a4r_attn_t* a) {
     if (int e = check(a, true)) return e;
     if (a->dh <= 16) return a4r_attn_small(reinterpret_cast<hipStream_t>(stream), a, true);
     Launch L{reinterpret_cast<hipStream_t>(stream), a, a4r_thr16(a->drop_p), a4r_keep_scale(a->drop_p)};
+    if (a->dtype == A4R_BF16 && g_attn_bwd_tr) {
+        // 4 waves per workgroup: 1 .. 4 measured the same (100 - 106 us at the text tower's shape), 6 and 12 (= all heads of an item in
+        // one workgroup) 127 / 134 us -- a workgroup's LDS is only released when its slowest wave is done
+        return a->dh == 64 ? launch_bwd_tr<64, 4>(L) : launch_bwd_tr<32, 4>(L);
+    }
     if (a->dtype == A4R_BF16) return a->dh == 64 ? launch_bwd<bf16_t, 64, 4>(L) : launch_bwd<bf16_t, 32, 4>(L);
     return a->dh == 64 ? launch_bwd<float, 64, 2>(L) : launch_bwd<float, 32, 4>(L);
 }

@@ -942,6 +942,8 @@ class TransRecEngine:
         dgrad chain reads these results); joined before dv / dzp are reused and at the end of the backward pass."""
         if ad.virtual is None and ad.g_wu is None:
             return                       # frozen adapter: nothing to accumulate
+        if _os.environ.get('A4R_DEBUG_SKIP_WGRAD'):      # measurement aid only (tools/): the step without its weight-gradient kernels
+            return
         if WGRAD_STREAM and self.WGRAD_SIDE_OK and ad.s_wu is None and ad.virtual is None and torch.device(self.dev).type == 'cuda':
             if self._wstream is None:
                 self._wstream = torch.cuda.Stream(device=self.dev)
