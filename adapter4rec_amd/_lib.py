@@ -15,6 +15,8 @@ LIB_PATH = os.environ.get('A4R_LIB_PATH') or os.path.join(_HERE, 'liba4r_hip.so'
 BF16, F32, FP8 = 0, 1, 2
 ACT_NONE, ACT_RELU, ACT_GELU, ACT_GELU_TANH, ACT_LEAKY = 0, 1, 2, 3, 4
 DACT_MUL = 15
+DACT_MUL_Q8 = 14          # Pre = the uint8 derivative tensor a c2_deriv='q8' launch wrote (include/a4r.h: c2_mode 2)
+Q8_OFF, Q8_STEP = 0.1289, 0.0049326
 EVAL_MAX_HISTORY = 64          # A4R_EVAL_MAX_HISTORY (include/a4r.h)
 ACT_BY_NAME = {'none': 0, 'relu': 1, 'RELU': 1, 'gelu': 2, 'GELU': 2, 'gelu_new': 3, 'leaky_relu': 4}
 
@@ -132,15 +134,16 @@ def gemm_nt(A, B, Cout, bias=None, C2=None, R1=None, R2=None, Pre=None, act=0, d
     N, K = B.shape
     din, dout = _dt(A), _dt(Cout)
     assert A.shape[1] == K and Cout.shape[1] == N and _dt(B) == din
-    for t in (C2, R1, R2, Pre):
-        assert t is None or _dt(t) == dout
+    q8c, q8p = c2_deriv == 'q8', dact == DACT_MUL_Q8
+    for t, q8 in ((C2, q8c), (R1, False), (R2, False), (Pre, q8p)):
+        assert t is None or (t.dtype == torch.uint8 if q8 else _dt(t) == dout)
     assert bias is None or bias.dtype == torch.float32
     # positional construction (field order of a4r_gemm_t): one C call instead of ~30 attribute stores -- this wrapper runs
     # ~220 times per training step
     g = GemmArgs(A.data_ptr(), B.data_ptr(), Cout.data_ptr(), _pi(bias), _pi(C2), _pi(R1), _pi(R2), _pi(Pre),
                  A.shape[0] if M is None else M, N, K, _ld(A), _ld(B), _ld(Cout),
                  _ld(C2) if C2 is not None else 0, _ld(R1) if R1 is not None else 0, _ld(R2) if R2 is not None else 0,
-                 _ld(Pre) if Pre is not None else 0, din, dout, act, dact, int(drop_first), int(c2_deriv), alpha, drop_p, drop_site,
+                 _ld(Pre) if Pre is not None else 0, din, dout, act, dact, int(drop_first), 2 if q8c else int(bool(c2_deriv)), alpha, drop_p, drop_site,
                  drop_seed, 0, _pi(scale_a), _pi(scale_b))
     _check(lib().a4r_gemm_nt(_stream(), C.byref(g)), 'a4r_gemm_nt')
 

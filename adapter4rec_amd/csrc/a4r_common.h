@@ -21,7 +21,7 @@ typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
 typedef __attribute__((ext_vector_type(4))) float f32x4_t;
 
 enum { A4R_BF16 = 0, A4R_F32 = 1, A4R_FP8 = 2 };      // A4R_FP8: OCP e4m3fn operands of a4r_gemm_nt (one byte per element)
-enum { A4R_ACT_NONE = 0, A4R_ACT_RELU = 1, A4R_ACT_GELU = 2, A4R_ACT_GELU_TANH = 3, A4R_ACT_LEAKY = 4, A4R_DACT_MUL_ = 15 };
+enum { A4R_ACT_NONE = 0, A4R_ACT_RELU = 1, A4R_ACT_GELU = 2, A4R_ACT_GELU_TANH = 3, A4R_ACT_LEAKY = 4, A4R_DACT_MULQ8_ = 14, A4R_DACT_MUL_ = 15 };
 
 // ---------------------------------------------------------------- error codes (C ABI)
 #define A4R_OK 0

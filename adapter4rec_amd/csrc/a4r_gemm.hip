@@ -258,7 +258,8 @@ extern "C" int a4r_gemm_nt(void* stream, const a4r_gemm_t* gp) {
     if (g.in_dtype == A4R_FP8) {          // e4m3 operands: the 256-tile kernel only, scales required
         if (g.M % 256 || g.N % 256 || g.K % 128 || g.out_dtype != A4R_BF16 || !g.scale_a || !g.scale_b) return A4R_EINVAL;
         if (g.lda < g.K || g.ldb < g.K || g.ldc < g.N || g.lda % 16 || g.ldb % 16 || (g.ldc * osz) % 16) return A4R_EINVAL;
-        if (!aligned16(g.A) || !aligned16(g.B) || !aligned16(g.C) || (g.C2 && (!aligned16(g.C2) || (g.ldc2 * osz) % 16 || g.ldc2 < g.N))) return A4R_EINVAL;
+        if (g.c2_mode < 0 || g.c2_mode > 2 || (g.C2 && g.c2_mode == 2 && g.act != A4R_ACT_GELU)) return A4R_EINVAL;
+        if (!aligned16(g.A) || !aligned16(g.B) || !aligned16(g.C) || (g.C2 && (!aligned16(g.C2) || (g.ldc2 * (g.c2_mode == 2 ? 1 : osz)) % 16 || g.ldc2 < g.N))) return A4R_EINVAL;
         if ((g.R1 && (!aligned16(g.R1) || (g.ldr1 * osz) % 16)) || (g.R2 && (!aligned16(g.R2) || (g.ldr2 * osz) % 16))) return A4R_EINVAL;
         if (g.drop_p < 0.f || g.drop_p >= 1.f) return A4R_EINVAL;
         const int rc = a4r_gemm_nt_256(reinterpret_cast<hipStream_t>(stream), g);
@@ -267,10 +268,14 @@ extern "C" int a4r_gemm_nt(void* stream, const a4r_gemm_t* gp) {
     if (g.lda < g.K || g.ldb < g.K || g.ldc < g.N) return A4R_EINVAL;
     if ((g.lda * isz) % 16 || (g.ldb * isz) % 16 || (g.ldc * osz) % 16) return A4R_EINVAL;
     if (!aligned16(g.A) || !aligned16(g.B) || !aligned16(g.C)) return A4R_EINVAL;
-    if (g.C2 && (!aligned16(g.C2) || (g.ldc2 * osz) % 16 || g.ldc2 < g.N)) return A4R_EINVAL;
+    // 8-bit stored derivative (c2_mode 2 / A4R_DACT_MUL_Q8): one byte per element, bf16 GEMMs only, GELU only
+    const bool c2q8 = g.C2 && g.c2_mode == 2, preq8 = g.dact == A4R_DACT_MULQ8_;
+    if ((c2q8 && (g.out_dtype != A4R_BF16 || g.act != A4R_ACT_GELU)) || (preq8 && g.out_dtype != A4R_BF16) || g.c2_mode < 0 || g.c2_mode > 2) return A4R_EINVAL;
+    const int c2sz = c2q8 ? 1 : osz, presz = preq8 ? 1 : osz;
+    if (g.C2 && (!aligned16(g.C2) || (g.ldc2 * c2sz) % 16 || g.ldc2 < g.N)) return A4R_EINVAL;
     if (g.R1 && (!aligned16(g.R1) || (g.ldr1 * osz) % 16 || g.ldr1 < g.N)) return A4R_EINVAL;
     if (g.R2 && (!aligned16(g.R2) || (g.ldr2 * osz) % 16 || g.ldr2 < g.N)) return A4R_EINVAL;
-    if (g.dact != A4R_ACT_NONE && (!g.Pre || !aligned16(g.Pre) || (g.ldpre * osz) % 16 || g.ldpre < g.N)) return A4R_EINVAL;
+    if (g.dact != A4R_ACT_NONE && (!g.Pre || !aligned16(g.Pre) || (g.ldpre * presz) % 16 || g.ldpre < g.N)) return A4R_EINVAL;
     if (g.drop_p < 0.f || g.drop_p >= 1.f) return A4R_EINVAL;
     if (g.dact == A4R_DACT_MUL_ && !g.Pre) return A4R_EINVAL;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
@@ -297,10 +302,10 @@ extern "C" int a4r_gemm_nt(void* stream, const a4r_gemm_t* gp) {
             auto adv = [&](const void* p, int ld, int sz) { return p ? (const void*)((const char*)p + head_rows * ld * sz) : nullptr; };
             g2.A = adv(g.A, g.lda, isz);
             g2.C = const_cast<void*>(adv(g.C, g.ldc, osz));
-            g2.C2 = const_cast<void*>(adv(g.C2, g.ldc2, osz));
+            g2.C2 = const_cast<void*>(adv(g.C2, g.ldc2, c2sz));
             g2.R1 = adv(g.R1, g.ldr1, osz);
             g2.R2 = adv(g.R2, g.ldr2, osz);
-            g2.Pre = adv(g.Pre, g.ldpre, osz);
+            g2.Pre = adv(g.Pre, g.ldpre, presz);
             const int rc = run_256(s, g1);
             if (rc == 0) {
                 if (g.in_dtype == A4R_BF16 && g.out_dtype == A4R_BF16) return launch_bn<bf16_t, bf16_t>(s, g2);

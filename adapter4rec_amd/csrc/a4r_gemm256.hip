@@ -299,7 +299,7 @@ __global__ void __launch_bounds__(512, 2) gemm_nt_256_kernel(const a4r_gemm_t p,
     // be hoisted above the previous group's store by the compiler (C may alias Pre for all it knows).
     constexpr int PS = DACT != A4R_ACT_NONE ? 8 * (int)sizeof(TO) / 16 : 1;
     uint4 pre_ld[2][2][PS];
-    if constexpr (DACT != A4R_ACT_NONE) {
+    if constexpr (DACT != A4R_ACT_NONE && !(A4R_ABL & 256)) {
         load_pre_n<TO, 8>(pre_ld[0][0], grow0, gcolp, epi);
         load_pre_n<TO, 8>(pre_ld[0][1], grow0, gcolp + 32, epi);
     }
@@ -336,7 +336,7 @@ __global__ void __launch_bounds__(512, 2) gemm_nt_256_kernel(const a4r_gemm_t p,
                                            DACT != A4R_ACT_NONE ? pre_ld[(mi_) & 1][pr_] : nullptr, R1PF ? r1_ld[(mi_) & 1][pr_] : nullptr); \
     }
 #define A4R_EPI_ROW(mi_)                                                                                                    \
-    if constexpr (DACT != A4R_ACT_NONE && (mi_) < 7) {                                                                      \
+    if constexpr (DACT != A4R_ACT_NONE && (mi_) < 7 && !(A4R_ABL & 256)) {                                                  \
         load_pre_n<TO, 8>(pre_ld[((mi_) + 1) & 1][0], grow0 + ((mi_) + 1) * 16, gcolp, epi);                                \
         load_pre_n<TO, 8>(pre_ld[((mi_) + 1) & 1][1], grow0 + ((mi_) + 1) * 16, gcolp + 32, epi);                           \
     }                                                                                                                       \
@@ -421,6 +421,9 @@ int dispatch_same(hipStream_t s, const a4r_gemm_t& g) {   // in == out dtype: th
     if (g.act == A4R_ACT_GELU && g.dact == A4R_ACT_NONE) return launch256<T, T, A4R_ACT_GELU, A4R_ACT_NONE>(s, g);
     if (g.act == A4R_ACT_RELU && g.dact == A4R_ACT_NONE) return launch256<T, T, A4R_ACT_RELU, A4R_ACT_NONE>(s, g);
     if (g.act == A4R_ACT_NONE && g.dact == A4R_DACT_MUL_) return launch256<T, T, A4R_ACT_NONE, A4R_DACT_MUL_>(s, g);
+    if constexpr (sizeof(T) == 2) {
+        if (g.act == A4R_ACT_NONE && g.dact == A4R_DACT_MULQ8_) return launch256<T, T, A4R_ACT_NONE, A4R_DACT_MULQ8_>(s, g);
+    }
     if (g.act == A4R_ACT_NONE && g.dact == A4R_ACT_GELU) return launch256<T, T, A4R_ACT_NONE, A4R_ACT_GELU>(s, g);
     if (g.act == A4R_ACT_NONE && g.dact == A4R_ACT_RELU) return launch256<T, T, A4R_ACT_NONE, A4R_ACT_RELU>(s, g);
     return 1;

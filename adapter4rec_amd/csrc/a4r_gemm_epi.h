@@ -28,6 +28,30 @@ A4R_DEV GemmEpi<TO> make_epi(const a4r_gemm_t& p, uint32_t thr16, float keep_sca
     return e;
 }
 
+// A stored GELU derivative as 8-bit fixed point (c2_mode 2 / A4R_DACT_MUL_Q8, include/a4r.h): gelu'(x) lies in [-0.1289, 1.1289];
+// 255 steps of 0.0049326 over that range, |error| <= 0.0025 -- the size of bf16's rounding error for a derivative near 1 (2^-9 ..
+// 2^-8) -- at half the bytes of the FFN-up GEMM's second output.
+#define A4R_Q8_OFF 0.1289f
+#define A4R_Q8_STEP 0.0049326f
+template <int NC> A4R_DEV void store_q8(uint8_t* p, const float* d) {
+    uint32_t w[NC / 4];
+#pragma unroll
+    for (int g = 0; g < NC / 4; ++g) {
+        w[g] = 0;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const float q = fminf(fmaxf(rintf((d[4 * g + i] + A4R_Q8_OFF) * (1.f / A4R_Q8_STEP)), 0.f), 255.f);
+            w[g] |= (uint32_t)q << (8 * i);
+        }
+    }
+    if constexpr (NC == 8) *reinterpret_cast<uint2*>(p) = make_uint2(w[0], w[1]);
+    else *reinterpret_cast<uint32_t*>(p) = w[0];
+}
+template <int NC> A4R_DEV void unpack_q8(const uint32_t* w, float* o) {
+#pragma unroll
+    for (int i = 0; i < NC; ++i) o[i] = (float)((w[i >> 2] >> (8 * (i & 3))) & 0xffu) * A4R_Q8_STEP - A4R_Q8_OFF;
+}
+
 // NC consecutive elements <-> fp32 registers (16 B per bf16x8 / fp32x4, 8 B per bf16x4)
 template <typename T, int NC> A4R_DEV void load_n(const T* p, float* o) {
     if constexpr (NC == 8) load_vec<T, 8>(p, o);
@@ -58,11 +82,20 @@ A4R_DEV void epi_dropout(float (&v)[NC], uint64_t e0, uint64_t seed, uint32_t si
 
 // pre_ld != nullptr: the NC elements of Pre were requested earlier by the caller (16-byte pieces; see load_pre_n)
 template <typename TO, int NC> A4R_DEV void load_pre_n(uint4* q, uint32_t grow, int gcol, const GemmEpi<TO>& e) {
+    if (e.dact == A4R_DACT_MULQ8_) {                         // one byte per element
+        const uint8_t* p8 = reinterpret_cast<const uint8_t*>(e.Pre) + (size_t)grow * (uint32_t)e.ldpre + gcol;
+        if constexpr (NC == 8) { const uint2 w = *reinterpret_cast<const uint2*>(p8); q[0].x = w.x; q[0].y = w.y; }
+        else q[0].x = *reinterpret_cast<const uint32_t*>(p8);
+        return;
+    }
 #pragma unroll
     for (int s = 0; s < NC * (int)sizeof(TO) / 16; ++s)
         q[s] = *reinterpret_cast<const uint4*>(e.Pre + (size_t)grow * (uint32_t)e.ldpre + gcol + s * (16 / (int)sizeof(TO)));
 }
 
+#ifndef A4R_ABL
+#define A4R_ABL 0      /* timing-only diagnostic builds (tools/gemm_abl.sh, tools/epi_abl.sh); epilogue bits: 64 no GELU arithmetic, 128 no C2 store, 256 no Pre operand, 512 no C store */
+#endif
 // R1PF: the caller ALWAYS passes r1_ld and has filled it whenever e.R1 is set (a run-time null test on a register array would send
 // the array to scratch)
 template <typename TO, int NC, int ACT = -1, int DACT = -1, bool R1PF = false>
@@ -75,8 +108,12 @@ A4R_DEV void epilogue_n(float (&v)[NC], const float* bias, uint32_t grow, int gc
     if (act == A4R_ACT_GELU && e.C2 && e.c2_mode) {          // value and derivative from one exp + one rcp
         float d[NC];
 #pragma unroll
-        for (int i = 0; i < NC; ++i) gelu_erf_both(v[i], v[i], d[i]);
-        store_n<TO, NC>(e.C2 + (size_t)grow * (uint32_t)e.ldc2 + gcol, d);
+        for (int i = 0; i < NC; ++i) {
+            if (A4R_ABL & 64) d[i] = v[i];
+            else gelu_erf_both(v[i], v[i], d[i]);
+        }
+        if (e.c2_mode == 2) store_q8<NC>(reinterpret_cast<uint8_t*>(e.C2) + (size_t)grow * (uint32_t)e.ldc2 + gcol, d);
+        else if (!(A4R_ABL & 128)) store_n<TO, NC>(e.C2 + (size_t)grow * (uint32_t)e.ldc2 + gcol, d);
     } else {
         if (e.C2) {
             if (e.c2_mode) {
@@ -93,15 +130,20 @@ A4R_DEV void epilogue_n(float (&v)[NC], const float* bias, uint32_t grow, int gc
             for (int i = 0; i < NC; ++i) v[i] = act_fwd(v[i], act);
         }
     }
-    if (dact != A4R_ACT_NONE) {
+    if (dact != A4R_ACT_NONE && !(A4R_ABL & 256)) {
         float pre[NC];
-        if (pre_ld) {
+        if (dact == A4R_DACT_MULQ8_) {
+            uint4 w;
+            if (pre_ld) w = pre_ld[0];
+            else load_pre_n<TO, NC>(&w, grow, gcol, e);
+            unpack_q8<NC>(&w.x, pre);
+        } else if (pre_ld) {
 #pragma unroll
             for (int s = 0; s < NC / Elem<TO>::PER16; ++s) Elem<TO>::unpack(pre_ld[s], pre + s * Elem<TO>::PER16);
         } else {
             load_n<TO, NC>(e.Pre + (size_t)grow * (uint32_t)e.ldpre + gcol, pre);
         }
-        if (dact == A4R_DACT_MUL_) {
+        if (dact == A4R_DACT_MUL_ || dact == A4R_DACT_MULQ8_) {
 #pragma unroll
             for (int i = 0; i < NC; ++i) v[i] *= pre[i];
         } else {
@@ -136,7 +178,7 @@ A4R_DEV void epilogue_n(float (&v)[NC], const float* bias, uint32_t grow, int gc
     }
     if (e.thr16 && !e.drop_first)
         epi_dropout<NC>(v, ((uint64_t)grow + e.row0) * (uint64_t)e.N + (uint64_t)gcol, e.drop_seed, e.drop_site, e.thr16, e.keep_scale);
-    store_n<TO, NC>(e.C + (size_t)grow * (uint32_t)e.ldc + gcol, v);
+    if (!(A4R_ABL & 512) || v[0] == 12345.678f) store_n<TO, NC>(e.C + (size_t)grow * (uint32_t)e.ldc + gcol, v);
 }
 // the NC elements of a residual operand as 16-byte pieces, for a caller that requests them ahead of use (r1_ld / r2_ld above)
 template <typename TO, int NC> A4R_DEV void load_res_n(uint4* q, const TO* R, int ldr, size_t grow, int gcol) {
@@ -159,7 +201,10 @@ template <typename TO, int DACT = -1>
 A4R_DEV void epi_issue(EpiLoads<TO>& L, size_t grow, int gcol, const GemmEpi<TO>& e) {
     constexpr int S = EpiLoads<TO>::S, PER = 16 / (int)sizeof(TO);
     const int dact = DACT >= 0 ? DACT : e.dact;
-    if (dact != A4R_ACT_NONE) {
+    if (dact == A4R_DACT_MULQ8_) {
+        const uint2 w = *reinterpret_cast<const uint2*>(reinterpret_cast<const uint8_t*>(e.Pre) + grow * e.ldpre + gcol);
+        L.pre[0].x = w.x; L.pre[0].y = w.y;
+    } else if (dact != A4R_ACT_NONE) {
 #pragma unroll
         for (int s = 0; s < S; ++s) L.pre[s] = *reinterpret_cast<const uint4*>(e.Pre + grow * e.ldpre + gcol + s * PER);
     }
@@ -190,7 +235,8 @@ A4R_DEV void epi_finish(float (&v)[8], const float* bias, const EpiLoads<TO>& L,
         float d[NC];
 #pragma unroll
         for (int i = 0; i < NC; ++i) gelu_erf_both(v[i], v[i], d[i]);
-        store_n<TO, NC>(e.C2 + grow * e.ldc2 + gcol, d);
+        if (e.c2_mode == 2) store_q8<NC>(reinterpret_cast<uint8_t*>(e.C2) + grow * e.ldc2 + gcol, d);
+        else store_n<TO, NC>(e.C2 + grow * e.ldc2 + gcol, d);
     } else {
         if (e.C2) {
             if (e.c2_mode) {
@@ -209,8 +255,9 @@ A4R_DEV void epi_finish(float (&v)[8], const float* bias, const EpiLoads<TO>& L,
     }
     if (dact != A4R_ACT_NONE) {
         float pre[NC];
-        epi_unpack8<TO>(L.pre, pre);
-        if (dact == A4R_DACT_MUL_) {
+        if (dact == A4R_DACT_MULQ8_) unpack_q8<NC>(&L.pre[0].x, pre);
+        else epi_unpack8<TO>(L.pre, pre);
+        if (dact == A4R_DACT_MUL_ || dact == A4R_DACT_MULQ8_) {
 #pragma unroll
             for (int i = 0; i < NC; ++i) v[i] *= pre[i];
         } else {

@@ -193,6 +193,8 @@ class TransRecEngine:
         # fp8: bf16 storage everywhere + OCP e4m3 operands (per-token / per-output-channel scales) for the frozen backbone's forward
         # GEMMs whose input is a LayerNorm output (qkv, FFN-up); everything else, and all of backward, is the bf16 path
         self.fp8 = dtype == 'fp8'
+        # bf16 storage: the saved GELU derivative of the encoder FFNs is kept as 8-bit fixed point (include/a4r.h c2_mode 2)
+        self.q8_deriv = dtype != 'fp32' and _os.environ.get('A4R_Q8_DERIV', '1') != '0'
         self.T = torch.float32 if dtype == 'fp32' else torch.bfloat16
         self.S = getattr(args, 'num_words_title', 0)
         self.E = args.embedding_dim
@@ -728,6 +730,10 @@ class TransRecEngine:
         self._dirty[key] = real
         return t
 
+    def _q8(self, blk):
+        """This block's saved FFN activation derivative is the uint8 form (GELU FFN, bf16 storage)."""
+        return self.q8_deriv and blk.T == torch.bfloat16 and getattr(blk, 'ffn_act', L.ACT_GELU) == L.ACT_GELU and blk.F % 16 == 0
+
     def _block_bufs(self, tag, blk, M, shared, Mc=None):
         """Activation buffers of one block: `shared` => transient set reused by every block (inference).
         Mc: row count of everything AFTER attention when only the CLS rows are carried on (last encoder layer)."""
@@ -751,7 +757,7 @@ class TransRecEngine:
         d['h1'] = self._buf(pre + '.h1', M, H, T)
         d['v1'] = self._buf(pre + '.v1', M, H, T)
         d['st1'] = self._buf(pre + '.st1', M, 2, torch.float32)
-        d['upre'] = self._buf(pre + '.upre', M, F, T)
+        d['upre'] = self._buf(pre + '.upre', M, F, torch.uint8 if self._q8(blk) else T)
         d['h2'] = self._buf(pre + '.h2', M, H, T)
         d['v2'] = self._buf(pre + '.v2', M, H, T)
         d['st2'] = self._buf(pre + '.st2', M, 2, torch.float32)
@@ -846,7 +852,7 @@ class TransRecEngine:
         x1 = bufs['x1s'] if 'x1s' in bufs else x1
         self._sub_forward(blk, '1', ctx, blk.wo, blk.bo, x, blk.ln1, blk.ad1, blk.pl1, blk.lnn1, bufs, M, ph, blk.site + 1, seed, x1)
         u = bufs['u_s'] if 'u_s' in bufs else self._buf('u', M, blk.F, T)
-        L.gemm_nt(x1, blk.wi, u, bias=blk.bi, C2=bufs['upre'], act=blk.ffn_act, c2_deriv=True, M=M)     # 'upre' holds act'(pre)
+        L.gemm_nt(x1, blk.wi, u, bias=blk.bi, C2=bufs['upre'], act=blk.ffn_act, c2_deriv='q8' if self._q8(blk) else True, M=M)     # 'upre' holds act'(pre)
         self._sub_forward(blk, '2', u, blk.wo2, blk.bo2, x1, blk.ln2, blk.ad2, blk.pl2, blk.lnn2, bufs, M, ph, blk.site + 2, seed, x_out)
 
     # ------------------------------------------------------------------ one block, backward
@@ -979,7 +985,7 @@ class TransRecEngine:
         dh2, dres2 = self._sub_backward(blk, '2', dx_out, blk.ln2, blk.ad2, blk.pl2, blk.lnn2, bufs, M, ph, blk.site + 2, seed)
         self._dense_wgrad(blk.d_o2, dh2, bufs.get('u_s'), M)
         du = self._buf('du', M, F, T)
-        L.gemm_nt(dh2, blk.wo2T, du, Pre=bufs['upre'], dact=L.DACT_MUL, M=M)
+        L.gemm_nt(dh2, blk.wo2T, du, Pre=bufs['upre'], dact=L.DACT_MUL_Q8 if self._q8(blk) else L.DACT_MUL, M=M)
         self._dense_wgrad(blk.d_i, du, bufs.get('x1s'), M)
         dx1 = self._buf('dx1', M, H, T)
         L.gemm_nt(du, blk.wiT, dx1, R1=dres2, M=M)

@@ -166,7 +166,7 @@ class ViTRecEngine(TransRecEngine):
             d['n2_s'] = self._buf(pre + '.n2_s', M, H, T)
             d['u_s'] = self._buf(pre + '.u_s', M, F, T)
         d['stb'] = self._buf(pre + '.stb', M, 2, torch.float32)
-        d['upre'] = self._buf(pre + '.upre', M, F, T)
+        d['upre'] = self._buf(pre + '.upre', M, F, torch.uint8 if self._q8(blk) else T)
         for k, ad in (('1', blk.ad1), ('2', blk.ad2)):
             if ad is not None:
                 d['h' + k] = self._buf(pre + '.h' + k, M, H, T)
@@ -218,11 +218,11 @@ class ViTRecEngine(TransRecEngine):
         if self.fp8 and blk.wi8 is not None and M % 256 == 0:
             n2q, n2s = self._buf('n2q', M, H, torch.uint8), self._buf('n2s', M, 1, torch.float32)
             L.ln_fwd(bufs['x1'], blk.lnB.gamma, blk.lnB.beta, blk.lnB.eps, bufs.get('n2_s'), bufs['stb'], M=M, y8=n2q, ys=n2s)
-            L.gemm_nt(n2q, blk.wi8, u, bias=blk.bi, C2=bufs['upre'], act=L.ACT_GELU, c2_deriv=True, M=M, scale_a=n2s, scale_b=blk.wi8s)
+            L.gemm_nt(n2q, blk.wi8, u, bias=blk.bi, C2=bufs['upre'], act=L.ACT_GELU, c2_deriv='q8' if self._q8(blk) else True, M=M, scale_a=n2s, scale_b=blk.wi8s)
         else:
             n2 = bufs['n2_s'] if 'n2_s' in bufs else self._buf('n2', M, H, T)
             L.ln_fwd(bufs['x1'], blk.lnB.gamma, blk.lnB.beta, blk.lnB.eps, n2, bufs['stb'], M=M)
-            L.gemm_nt(n2, blk.wi, u, bias=blk.bi, C2=bufs['upre'], act=L.ACT_GELU, c2_deriv=True, M=M)
+            L.gemm_nt(n2, blk.wi, u, bias=blk.bi, C2=bufs['upre'], act=L.ACT_GELU, c2_deriv='q8' if self._q8(blk) else True, M=M)
         self._vit_sub_forward(blk.ad2, u, blk.wo2, blk.bo2, bufs['x1'], bufs, '2', M, x_out)
 
     def _vit_sub_backward(self, blk, ad, dy, bufs, k, M, x_in=None):
@@ -259,7 +259,7 @@ class ViTRecEngine(TransRecEngine):
         d_o, dres2 = self._vit_sub_backward(blk, blk.ad2, dx_out, bufs, '2', M, x_in=bufs['x1'])
         self._dense_wgrad(blk.d_o2, d_o, bufs.get('u_s'), M)
         du = self._buf('du', M, F, T)
-        L.gemm_nt(d_o, blk.wo2T, du, Pre=bufs['upre'], dact=L.DACT_MUL, M=M)
+        L.gemm_nt(d_o, blk.wo2T, du, Pre=bufs['upre'], dact=L.DACT_MUL_Q8 if self._q8(blk) else L.DACT_MUL, M=M)
         self._dense_wgrad(blk.d_i, du, bufs.get('n2_s'), M)
         dn2 = self._buf('dn', M, H, T)
         L.gemm_nt(du, blk.wiT, dn2, M=M)

@@ -32,6 +32,7 @@ extern "C" {
 #define A4R_ACT_GELU_TANH 3  /* HF "gelu_new" (compacter, model/modules.py:220) */
 #define A4R_ACT_LEAKY 4
 #define A4R_DACT_MUL 15       /* dact only: multiply by Pre itself (Pre holds a stored derivative, see c2_mode) */
+#define A4R_DACT_MUL_Q8 14    /* dact only, out_dtype bf16: the same, Pre is the uint8 tensor c2_mode 2 wrote (ldpre in bytes) */
 
 int a4r_version(void);
 
@@ -50,7 +51,10 @@ typedef struct {
     int32_t in_dtype, out_dtype;
     int32_t act, dact;
     int32_t drop_first;   /* 0: dropout after the residual adds (backward form); 1: before them (forward form) */
-    int32_t c2_mode;      /* what C2 receives: 0 = the pre-activation, 1 = act'(pre-activation) (so that backward is one multiply) */
+    int32_t c2_mode;      /* what C2 receives: 0 = the pre-activation, 1 = act'(pre-activation) (so that backward is one multiply),
+                           * 2 (act GELU, out_dtype bf16) = gelu'(pre-activation) as 8-bit fixed point, one byte per element, ldc2 in
+                           * bytes: q = round((d + 0.1289) / 0.0049326), d in [-0.1289, 1.1289] (the range of gelu'), |error| <= 0.0025
+                           * -- bf16's own rounding error for a derivative near 1 -- at half the bytes */
     float alpha;
     float drop_p; uint32_t drop_site; uint64_t drop_seed;
     int64_t drop_row0;    /* row index of A's first row inside the logical matrix the dropout mask is defined on (0 unless the

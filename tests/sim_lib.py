@@ -15,6 +15,8 @@ BF16, F32, FP8 = REAL.BF16, REAL.F32, REAL.FP8
 quantize_weight_fp8 = REAL.quantize_weight_fp8
 ACT_NONE, ACT_RELU, ACT_GELU, ACT_GELU_TANH, ACT_LEAKY = 0, 1, 2, 3, 4
 DACT_MUL = 15
+DACT_MUL_Q8 = 14
+Q8_OFF, Q8_STEP = REAL.Q8_OFF, REAL.Q8_STEP
 EVAL_MAX_HISTORY = REAL.EVAL_MAX_HISTORY
 ACT_BY_NAME = REAL.ACT_BY_NAME
 PackDesc, PhmDesc, AddDesc, desc_table = REAL.PackDesc, REAL.PhmDesc, REAL.AddDesc, REAL.desc_table
@@ -64,10 +66,16 @@ def gemm_nt(A, B, Cout, bias=None, C2=None, R1=None, R2=None, Pre=None, act=0, d
         v = alpha * (A[:M].float() @ B.float().t())
     if bias is not None:
         v = v + bias
-    if C2 is not None:
+    if C2 is not None and c2_deriv == 'q8':      # include/a4r.h c2_mode 2: gelu' as 8-bit fixed point
+        assert act == ACT_GELU and C2.dtype == torch.uint8 and Cout.dtype == torch.bfloat16
+        C2[:M] = torch.clamp(torch.round((_dact(v, act) + Q8_OFF) * (1.0 / Q8_STEP)), 0, 255).to(torch.uint8)
+    elif C2 is not None:
         C2[:M] = (_dact(v, act) if c2_deriv else v).to(C2.dtype)
     v = _act(v, act)
-    if dact == 15:
+    if dact == 14:
+        assert Pre.dtype == torch.uint8
+        v = v * (Pre[:M].float() * Q8_STEP - Q8_OFF)
+    elif dact == 15:
         v = v * Pre[:M].float()
     elif dact:
         v = v * _dact(Pre[:M].float(), dact)

@@ -117,6 +117,37 @@ def test_gemm_epilogue_full(dt, gemm_variant):
         close(Cc, ref, t, f'gemm epilogue act={act} dact={dact}')
 
 
+@pytest.mark.parametrize('M,N,K', [(256, 256, 192), (512, 3072, 768), (128, 192, 128), (384, 768, 256)])
+def test_gemm_q8_derivative(M, N, K, gemm_variant):
+    """c2_mode 2 / A4R_DACT_MUL_Q8 (include/a4r.h): the saved GELU derivative as 8-bit fixed point.  The stored byte is the nearest
+    level of gelu'(pre) (pre = the fp32 accumulator the kernel saw: a level off where bf16-rounded operands' fp32 sums differ in the
+    last bits), the decoded value is within half a step, and the dgrad form multiplies by exactly the decoded value."""
+    from adapter4rec_amd import _lib as L
+    t = torch.bfloat16
+    A, B = rnd(M, K, dtype=t, seed=3), rnd(N, K, dtype=t, scale=0.1, seed=4)
+    bias = rnd(N, seed=5)
+    Cc = torch.zeros(M, N, dtype=t, device=dev())
+    C2 = torch.zeros(M, N, dtype=torch.uint8, device=dev())
+    L.gemm_nt(A, B, Cc, bias=bias, C2=C2, act=L.ACT_GELU, c2_deriv='q8')
+    pre = (A.float() @ B.float().t()) + bias
+    q = pre.clone().requires_grad_(True)
+    torch.nn.functional.gelu(q).sum().backward()
+    close(Cc, torch.nn.functional.gelu(pre), t, 'gemm gelu (q8 second output)')
+    dec = C2.float() * L.Q8_STEP - L.Q8_OFF
+    err = (dec - q.grad).abs().max().item()
+    assert err <= 0.5 * L.Q8_STEP + 2e-4, err
+    lvl = torch.clamp(torch.round((q.grad + L.Q8_OFF) / L.Q8_STEP), 0, 255)
+    assert (C2.float() - lvl).abs().max().item() <= 1 and (C2.float() != lvl).float().mean().item() < 0.01
+    G = rnd(M, K, dtype=t, seed=9)                      # dgrad form: dX = (G W) * stored derivative, W [N, K]^T -> use B as [N_out, K]
+    D = torch.zeros(M, N, dtype=t, device=dev())
+    L.gemm_nt(G, B, D, Pre=C2, dact=L.DACT_MUL_Q8)
+    close(D, (G.float() @ B.float().t()) * dec, t, 'gemm * q8 derivative')
+    with pytest.raises(RuntimeError):                   # fp32 outputs have no 8-bit form
+        L.gemm_nt(A.float(), B.float(), torch.zeros(M, N, device=dev()), C2=C2, act=L.ACT_GELU, c2_deriv='q8')
+    with pytest.raises(RuntimeError):                   # GELU only
+        L.gemm_nt(A, B, Cc, C2=C2, act=L.ACT_RELU, c2_deriv='q8')
+
+
 @pytest.mark.parametrize('to', ['bf16', 'f32'])
 def test_gemm_skinny64_epilogue(to):
     """N = 64 with bf16 operands goes to skinny64_kernel (a4r_gemm_skinny.hip): every epilogue form the adapter down-projections use

@@ -33,7 +33,7 @@ g = torch.Generator(device=dev).manual_seed(3)
 R = lambda *s, sc=1.0: (torch.randn(*s, device=dev, generator=g) * sc).to(t)
 rows = []
 CASES = (('qkv', 2304, 768, 'plain'), ('attn-out', 768, 768, 'drop'), ('ffn-up', 3072, 768, 'gelu'), ('ffn-down', 768, 3072, 'drop'),
-                         ('d ffn-down', 3072, 768, 'dmul'), ('d ffn-up', 768, 3072, 'res'), ('d attn-out', 768, 768, 'plain'), ('d qkv', 768, 2304, 'res'))
+                         ('ffn-up q8', 3072, 768, 'gelu8'), ('d ffn-down', 3072, 768, 'dmul'), ('d ffn-dn q8', 3072, 768, 'dmul8'), ('d ffn-up', 768, 3072, 'res'), ('d attn-out', 768, 768, 'plain'), ('d qkv', 768, 2304, 'res'))
 if PLAIN:
     CASES = (('k768', 768, 768, 'plain'), ('k3072', 768, 3072, 'plain'), ('n3072', 3072, 768, 'plain'))
 for name, N, K, form in CASES:
@@ -47,12 +47,19 @@ for name, N, K, form in CASES:
         f = lambda: L.gemm_nt(A, B, C, bias=bias, drop_p=0.1, drop_site=3, drop_seed=11)
     elif form == 'gelu':
         f = lambda: L.gemm_nt(A, B, C, bias=bias, C2=C2, act=L.ACT_GELU, c2_deriv=True)
+    elif form == 'gelu8':
+        C8 = torch.empty(M, N, device=dev, dtype=torch.uint8)
+        f = lambda: L.gemm_nt(A, B, C, bias=bias, C2=C8, act=L.ACT_GELU, c2_deriv='q8')
+    elif form == 'dmul8':
+        P8 = torch.randint(0, 256, (M, N), device=dev, dtype=torch.uint8)
+        f = lambda: L.gemm_nt(A, B, C, Pre=P8, dact=L.DACT_MUL_Q8)
     elif form == 'dmul':
         f = lambda: L.gemm_nt(A, B, C, Pre=Pre, dact=L.DACT_MUL)
     else:
         f = lambda: L.gemm_nt(A, B, C, R1=R1)
     ta = t_us(f)
+    tp = t_us(lambda: L.gemm_nt(A, B, C, bias=bias)) if form != 'plain' else ta      # the same product with the plain epilogue
     bb = bias.to(t)
     tv = t_us(lambda: torch.nn.functional.linear(A, B, bb)) if not PLAIN else float('nan')
     fl = 2.0 * M * N * K
-    print(f'{name:11s} M={M} N={N:4d} K={K:4d} {form:5s}: a4r {ta:7.1f} us {fl / ta / 1e6:7.1f} TF/s | vendor plain {tv:7.1f} us {fl / tv / 1e6:7.1f} TF/s')
+    print(f'{name:11s} M={M} N={N:4d} K={K:4d} {form:5s}: a4r {ta:7.1f} us {fl / ta / 1e6:7.1f} TF/s (plain {tp:7.1f} us) | vendor plain {tv:7.1f} us {fl / tv / 1e6:7.1f} TF/s')
