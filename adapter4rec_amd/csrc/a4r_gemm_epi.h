@@ -5,6 +5,9 @@
 #pragma once
 #include "a4r_common.h"
 #include "../../include/a4r.h"
+#ifndef A4R_ABL
+#define A4R_ABL 0      /* timing-only diagnostic builds (tools/gemm_abl.sh, tools/epi_abl.sh); epilogue bits: 64 no GELU arithmetic, 128 no C2 store, 256 no Pre operand, 512 no C store, 1024 non-temporal C / C2 stores */
+#endif
 
 template <typename TO>
 struct GemmEpi {
@@ -63,6 +66,15 @@ template <typename T, int NC> A4R_DEV void load_n(const T* p, float* o) {
     }
 }
 template <typename T, int NC> A4R_DEV void store_n(T* p, const float* o) {
+    // A4R_ABL & 1024: non-temporal output stores.  Kernel by kernel the hint was neutral or worse except on the '* 8-bit derivative'
+    // dgrad (240 against 262 - 274 us); end to end the step was 0.23 ms SLOWER with it there: the next GEMM reads that output.
+    if constexpr (NC == 8 && sizeof(T) == 2 && (A4R_ABL & 1024) != 0) {
+        const uint4 w = Elem<T>::pack(o);
+        typedef unsigned int v4u __attribute__((ext_vector_type(4)));
+        v4u x = {w.x, w.y, w.z, w.w};
+        __builtin_nontemporal_store(x, reinterpret_cast<v4u*>(p));
+        return;
+    }
     if constexpr (NC == 8) store_vec<T, 8>(p, o);
     else if constexpr (sizeof(T) == 4) store_vec<T, 4>(p, o);
     else
@@ -93,9 +105,6 @@ template <typename TO, int NC> A4R_DEV void load_pre_n(uint4* q, uint32_t grow, 
         q[s] = *reinterpret_cast<const uint4*>(e.Pre + (size_t)grow * (uint32_t)e.ldpre + gcol + s * (16 / (int)sizeof(TO)));
 }
 
-#ifndef A4R_ABL
-#define A4R_ABL 0      /* timing-only diagnostic builds (tools/gemm_abl.sh, tools/epi_abl.sh); epilogue bits: 64 no GELU arithmetic, 128 no C2 store, 256 no Pre operand, 512 no C store */
-#endif
 // R1PF: the caller ALWAYS passes r1_ld and has filled it whenever e.R1 is set (a run-time null test on a register array would send
 // the array to scratch)
 template <typename TO, int NC, int ACT = -1, int DACT = -1, bool R1PF = false>
