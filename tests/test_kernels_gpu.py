@@ -290,11 +290,11 @@ def test_gemm_tn_glds_bf16(M, P, Q):
 def test_colsum(dt):
     from adapter4rec_amd import _lib as L
     t = DT[dt]
-    for M, N in [(1280, 768), (640, 64), (100, 16)]:
+    for M, N in [(1280, 768), (640, 64), (100, 16), (66304, 768), (40448, 64), (7, 8)]:
         X = rnd(M, N, dtype=t, seed=17)
         out = torch.zeros(N, device=dev())
         L.colsum(X, out)
-        close(out, X.float().sum(0), torch.float32, 'colsum', atol32=2e-3, rtol32=1e-3)
+        close(out, X.float().sum(0), torch.float32, 'colsum', atol32=2e-3 * max(1.0, (M / 1280) ** 0.5), rtol32=1e-3)
 
 
 # ------------------------------------------------------------------ attention
