@@ -45,6 +45,13 @@ template <typename T, int DH> struct Geo {
     static A4R_DEV int swz(int row) { return CPR == 16 ? (row & 15) : CPR == 8 ? ((row >> 1) & 7) : ((row >> 2) & 3); }
 };
 
+// LDS layout of a workgroup: the staged matrices (lds_main_*), then one output staging block per wave (bf16 only)
+template <typename T, int DH> struct STG { static constexpr int BYTES = sizeof(T) == 2 ? 16 * DH * 2 : 0; };
+template <typename T, int DH, int NKT> constexpr size_t img_t() { return sizeof(T) == 2 ? 0 : DH * (NKT * 16 + 8) * sizeof(T); }   // transposed copy (fp32 only)
+template <typename T, int DH, int NKT> constexpr size_t lds_main_fwd() { return (size_t)NKT * 16 * Geo<T, DH>::ROWB + (sizeof(T) == 2 ? (size_t)NKT * 16 * Geo<T, DH>::ROWB : img_t<T, DH, NKT>()); }
+template <typename T, int DH, int NKT> constexpr size_t lds_main_dq() { return 2 * (size_t)NKT * 16 * Geo<T, DH>::ROWB + img_t<T, DH, NKT>(); }
+template <typename T, int DH, int NKT> constexpr size_t lds_main_dkdv() { return 2 * (size_t)NKT * 16 * Geo<T, DH>::ROWB + 2 * img_t<T, DH, NKT>() + 2 * NKT * 16 * sizeof(float); }
+
 // [S][DH] (global, row stride ld) -> LDS row-major [SP][DH], 16-byte chunks XOR-swizzled; rows >= S are zero
 template <typename T, int DH> A4R_DEV void stage_rows(char* lds, const T* src, int ld, int S, int SP, int tid, int NTHR) {
     using G = Geo<T, DH>;
@@ -133,6 +140,36 @@ A4R_DEV float red4(float v, bool mx) {       // over the 4 lanes l, l^16, l^32, 
     return mx ? fmaxf(v, b) : v + b;
 }
 
+// A wave's [16 tokens][DH] result block, held transposed in accumulators (lane (c, kg): token c, head columns dt * 16 + 4 kg .. + 3),
+// leaves through a wave-private LDS block so that every global store is a whole 16-byte chunk and 8 lanes cover a 128-byte line
+// (bf16; stored straight from the accumulators -- 8 bytes per lane, 32-byte pieces of 16 rows per instruction -- the short-sequence
+// backward moved the same bytes 32 us slower, a4r_attn.hip).  fp32 accumulators are 16 bytes per lane already.
+template <typename T, int DH>
+A4R_DEV void store_block16(char* stg, const f32x4_t (&o)[Geo<T, DH>::ND], T* g0, size_t ldg, int rows_valid, int lane) {
+    using G = Geo<T, DH>;
+    const int fr = lane & 15, kg = lane >> 4;
+    if constexpr (sizeof(T) == 4) {
+        if (fr < rows_valid) {
+#pragma unroll
+            for (int dt = 0; dt < G::ND; ++dt) store4<T>(g0 + (size_t)fr * ldg + dt * 16 + kg * 4, o[dt]);
+        }
+    } else {
+        constexpr int ROWB = DH * 2, CPR = DH / 8;
+#pragma unroll
+        for (int dt = 0; dt < G::ND; ++dt)
+            store4<T>(reinterpret_cast<T*>(stg + fr * ROWB + (((dt * 2 + (kg >> 1)) ^ G::swz(fr)) << 4) + 8 * (kg & 1)), o[dt]);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int i = 0; i < 16 * CPR / 64; ++i) {
+            const int id = lane + 64 * i, row = id / CPR, ch = id % CPR;
+            if (row < rows_valid)
+                *reinterpret_cast<uint4*>(g0 + (size_t)row * ldg + ch * 8) = *reinterpret_cast<const uint4*>(stg + row * ROWB + ((ch ^ G::swz(row)) << 4));
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
 // transposed score tiles of one 16-query block: s[kt][r] = scale * q[query c] . k[key 16 kt + 4 kg + r]  (keys >= S: -inf)
 template <typename T, int DH, int NKT>
 A4R_DEV void scores_t(const char* Kr, const uint4 (&qf)[Geo<T, DH>::KS], f32x4_t (&s)[NKT], int S, float scale, int fr, int kg) {
@@ -165,6 +202,7 @@ __global__ void __launch_bounds__(WG<NKT>::NTHR, 4) attn_long_fwd_kernel(const T
     char* Vimg = smem + SP * G::ROWB;                                 // bf16: [SP][DH] row-major (read transposed); fp32: [DH][SPT]
     const int item = blockIdx.x / nh, h = blockIdx.x % nh;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, fr = lane & 15, kg = lane >> 4;
+    char* stg = smem + lds_main_fwd<T, DH, NKT>() + wave * STG<T, DH>::BYTES;      // this wave's output staging block (bf16)
     const T* base = qkv + (size_t)item * S * ld + h * DH;
     stage_rows<T, DH>(Kr, base + k_off, ld, S, SP, tid, NTHR);
     if constexpr (TR) stage_rows<T, DH>(Vimg, base + v_off, ld, S, SP, tid, NTHR);
@@ -216,10 +254,7 @@ __global__ void __launch_bounds__(WG<NKT>::NTHR, 4) attn_long_fwd_kernel(const T
             for (int dt = 0; dt < G::ND; ++dt) Mma<T>::mma(frag_T<T, DH>(Vimg, SPT, dt * 16, st, lane), pf, o[dt]);
             __builtin_amdgcn_sched_barrier(0);
         }
-        if (valid) {
-#pragma unroll
-            for (int dt = 0; dt < G::ND; ++dt) store4<T>(ctx + ((size_t)item * S + rq) * ldo + h * DH + dt * 16 + kg * 4, o[dt]);
-        }
+        store_block16<T, DH>(stg, o, ctx + ((size_t)item * S + qb * 16) * ldo + h * DH, ldo, S - qb * 16, lane);
     }
 }
 
@@ -239,6 +274,7 @@ __global__ void __launch_bounds__(WG<NKT>::NTHR, 4) attn_long_dq_kernel(const T*
     char* Kimg = TR ? Kr : smem + 2 * SP * G::ROWB;                   // bf16: K's row-major image doubles as the transposed operand
     const int item = blockIdx.x / nh, h = blockIdx.x % nh;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, fr = lane & 15, kg = lane >> 4;
+    char* stg = smem + lds_main_dq<T, DH, NKT>() + wave * STG<T, DH>::BYTES;
     const T* base = qkv + (size_t)item * S * ld + h * DH;
     stage_rows<T, DH>(Kr, base + k_off, ld, S, SP, tid, NTHR);
     stage_rows<T, DH>(Vr, base + v_off, ld, S, SP, tid, NTHR);
@@ -300,10 +336,7 @@ __global__ void __launch_bounds__(WG<NKT>::NTHR, 4) attn_long_dq_kernel(const T*
             for (int dt = 0; dt < G::ND; ++dt) Mma<T>::mma(frag_T<T, DH>(Kimg, SPT, dt * 16, st, lane), dsf, o[dt]);
             __builtin_amdgcn_sched_barrier(0);
         }
-        if (valid) {
-#pragma unroll
-            for (int dt = 0; dt < G::ND; ++dt) store4<T>(dqkv + grow * ld + q_off + h * DH + dt * 16 + kg * 4, o[dt]);
-        }
+        store_block16<T, DH>(stg, o, dqkv + ((size_t)item * S + qb * 16) * ld + q_off + h * DH, ld, S - qb * 16, lane);
     }
 }
 
@@ -326,6 +359,7 @@ __global__ void __launch_bounds__(WG<NKT>::NTHR, 4) attn_long_dkdv_kernel(const 
     float* del_s = lse_s + SP;
     const int item = blockIdx.x / nh, h = blockIdx.x % nh;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, fr = lane & 15, kg = lane >> 4;
+    char* stg = smem + lds_main_dkdv<T, DH, NKT>() + wave * STG<T, DH>::BYTES;
     const T* base = qkv + (size_t)item * S * ld + h * DH;
     const T* dob = dctx + (size_t)item * S * ldo + h * DH;
     stage_rows<T, DH>(Qr, base + q_off, ld, S, SP, tid, NTHR);
@@ -381,23 +415,17 @@ __global__ void __launch_bounds__(WG<NKT>::NTHR, 4) attn_long_dkdv_kernel(const 
                 Mma<T>::mma(frag_T<T, DH>(Qimg, SPT, dt * 16, g, lane), dsf, dk[dt]);
             }
         }
-        if (kvalid) {
-            T* row = dqkv + ((size_t)item * S + rk) * ld + h * DH + kg * 4;
-#pragma unroll
-            for (int dt = 0; dt < G::ND; ++dt) {
-                store4<T>(row + k_off + dt * 16, dk[dt]);
-                store4<T>(row + v_off + dt * 16, dv[dt]);
-            }
-        }
+        T* blk = dqkv + ((size_t)item * S + kt * 16) * ld + h * DH;
+        store_block16<T, DH>(stg, dk, blk + k_off, ld, S - kt * 16, lane);
+        store_block16<T, DH>(stg, dv, blk + v_off, ld, S - kt * 16, lane);
     }
 }
 
 int nkt_for(int S) { return S <= 32 ? 2 : S <= 64 ? 4 : S <= 128 ? 8 : S <= 224 ? 14 : 16; }
 
-template <typename T, int DH, int NKT> constexpr size_t img_t() { return sizeof(T) == 2 ? 0 : DH * (NKT * 16 + 8) * sizeof(T); }   // transposed copy (fp32 only)
-template <typename T, int DH, int NKT> size_t lds_fwd() { return (size_t)NKT * 16 * Geo<T, DH>::ROWB + (sizeof(T) == 2 ? (size_t)NKT * 16 * Geo<T, DH>::ROWB : img_t<T, DH, NKT>()); }
-template <typename T, int DH, int NKT> size_t lds_dq() { return 2 * (size_t)NKT * 16 * Geo<T, DH>::ROWB + img_t<T, DH, NKT>(); }
-template <typename T, int DH, int NKT> size_t lds_dkdv() { return 2 * (size_t)NKT * 16 * Geo<T, DH>::ROWB + 2 * img_t<T, DH, NKT>() + 2 * NKT * 16 * sizeof(float); }
+template <typename T, int DH, int NKT> size_t lds_fwd() { return lds_main_fwd<T, DH, NKT>() + WG<NKT>::NWAVE * STG<T, DH>::BYTES; }
+template <typename T, int DH, int NKT> size_t lds_dq() { return lds_main_dq<T, DH, NKT>() + WG<NKT>::NWAVE * STG<T, DH>::BYTES; }
+template <typename T, int DH, int NKT> size_t lds_dkdv() { return lds_main_dkdv<T, DH, NKT>() + WG<NKT>::NWAVE * STG<T, DH>::BYTES; }
 constexpr size_t LDS_MAX = 160 * 1024;
 
 template <typename K> int set_lds(K kernel, size_t bytes) {
