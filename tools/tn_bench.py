@@ -1,0 +1,26 @@
+#!/usr/bin/env python
+"""a4r_gemm_tn on the adapter weight-gradient shapes of the step: dW_up [768, 64] = dv^T z, dW_down [64, 768] = dzp^T h; us, TB/s."""
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from adapter4rec_amd import _lib as L
+
+dev = torch.device('cuda:0')
+M = int(sys.argv[1]) if len(sys.argv) > 1 else 40448
+for P, Q in ((768, 64), (64, 768)):
+    X = torch.randn(M, P, device=dev).bfloat16()
+    Y = torch.randn(M, Q, device=dev).bfloat16()
+    out = torch.zeros(P, Q, device=dev)
+    for _ in range(5):
+        L.gemm_tn(X, Y, out)
+    torch.cuda.synchronize()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(30):
+        L.gemm_tn(X, Y, out)
+    b.record()
+    torch.cuda.synchronize()
+    us = a.elapsed_time(b) / 30 * 1e3
+    print(f'gemm_tn M={M} [{P} x {Q}]: {us:6.1f} us  {M * (P + Q) * 2 / us / 1e6:5.2f} TB/s')
