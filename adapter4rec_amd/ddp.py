@@ -19,6 +19,7 @@ class FlatDDP(nn.Module):
         self.process_group = process_group
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
         self._avg = dist.is_initialized() and dist.get_backend(process_group) == 'nccl'
+        self._pending = []
         if self.world > 1 and broadcast:                       # DDP constructor semantics: rank 0's state everywhere
             with torch.no_grad():
                 for t in list(module.parameters()) + list(module.buffers()):
@@ -39,6 +40,24 @@ class FlatDDP(nn.Module):
             dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.process_group)
             flat.mul_(1.0 / self.world)
         return flat
+
+    # ---- chunked exchange, overlapped with backward (the reference's DDP buckets, run.py:503,599)
+    def launch_(self, flat, lo, hi):
+        """Start the mean over ranks of flat[lo:hi] (gradients that are final) without blocking the launching stream: the
+        collective runs on the process group's own stream behind everything already enqueued; wait_all() joins it.  Every rank
+        launches the same ranges in the same order (the engine derives them from the parameter list)."""
+        if hi <= lo:
+            return
+        view = flat[lo:hi]
+        op = dist.ReduceOp.AVG if self._avg else dist.ReduceOp.SUM
+        self._pending.append((dist.all_reduce(view, op=op, group=self.process_group, async_op=True), view))
+
+    def wait_all(self):
+        for work, view in self._pending:
+            work.wait()
+            if not self._avg:
+                view.mul_(1.0 / self.world)
+        self._pending = []
 
     def forward(self, *args, **kwargs):
         return self.module(*args, **kwargs)

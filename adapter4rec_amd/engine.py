@@ -1226,6 +1226,50 @@ class TransRecEngine:
         c = self._ctx
         return c['pos'].clone(), c['neg'].clone()
 
+    OVERLAP_ALLREDUCE = bool(int(_os.environ.get('A4R_OVERLAP_ALLREDUCE', '1')))
+
+    def _grad_chunks(self):
+        """Flat-buffer ranges in the order backward FINISHES them: the user encoder (+ anything outside the item encoder's layers
+        that its backward completes), then the item encoder's layers last to first, then the rest (item head, embeddings, LayerNorms
+        outside the layers).  None when some gradient only reaches the flat buffer at the very end (zero-padded scratch corners,
+        Compacter's PHM chain): the exchange is then the single all-reduce."""
+        if getattr(self, '_chunks', 0) != 0:
+            return self._chunks
+        self._chunks = None
+        if self._corners or self._virtual or not self.OVERLAP_ALLREDUCE:
+            return None
+        import re
+        user, layers, rest = [], {}, []
+        for n, p in zip(self.trainable_names, self.trainable_params):
+            o, k = self.offsets[id(p)]
+            m = re.search(r'encoder\.layer\.(\d+)\.', n)
+            if 'user_encoder' in n:
+                user.append((o, o + k))
+            elif m and ('bert_encoder' in n or 'cv_encoder' in n):
+                layers.setdefault(int(m.group(1)), []).append((o, o + k))
+            else:
+                rest.append((o, o + k))
+        span = lambda r: (min(a for a, _ in r), max(b for _, b in r)) if r else None
+        out = dict(user=span(user), layers={i: span(r) for i, r in layers.items()}, rest=span(rest))
+        spans = sorted([s_ for s_ in [out['user'], out['rest']] + list(out['layers'].values()) if s_])
+        if any(a[1] > b[0] for a, b in zip(spans, spans[1:])):          # interleaved groups: no contiguous ranges to exchange separately
+            return None
+        self._chunks = out
+        return out
+
+    def _exchange(self, what):
+        """Start the all-reduce of one finished chunk (no-op outside an overlapped data-parallel backward)."""
+        ex = getattr(self, '_exch', None)
+        if ex is None:
+            return
+        ddp, ch, done = ex
+        rng = ch['layers'].get(what) if isinstance(what, int) else ch[what]
+        if rng is None or what in done:
+            return
+        done.add(what)
+        self._wgrad_join()                                     # the chunk's side-stream weight gradients have landed
+        ddp.launch_(self.flat_g, rng[0], rng[1])
+
     def backward_bound(self, grad_out):
         """Backward of the public path (loss.backward(), run.py:599) once FusedAdam owns the flat buffers: every p.grad IS a view
         of flat_g, so the kernels accumulate straight into it (no per-parameter gradient list, no AccumulateGrad adds) and the
@@ -1234,6 +1278,17 @@ class TransRecEngine:
         ddp = getattr(self.model, '_a4r_ddp', None)
         if self._flat_clean:
             self._flat_clean = False
+            ch = self._grad_chunks() if ddp is not None else None
+            if ch is not None:            # chunks are exchanged as backward finishes them, overlapped with the layers still to come
+                self._exch = (ddp, ch, set())
+                try:
+                    self.train_backward(grad_out, into_flat_grad=True)
+                    for what in ['user'] + sorted(ch['layers'], reverse=True) + ['rest']:
+                        self._exchange(what)                      # whatever the hooks did not reach (e.g. layers a frozen-input backward skips)
+                finally:
+                    self._exch = None
+                ddp.wait_all()
+                return
             self.train_backward(grad_out, into_flat_grad=True)
             if ddp is not None:                                   # DDP semantics: gradients averaged over ranks (run.py:503,599)
                 ddp.average_(self.flat_g)
@@ -1296,6 +1351,7 @@ class TransRecEngine:
         if self.g_pos_emb is not None:             # nn.Embedding(position) backward: the same rows are read by every user
             self.g_pos_emb()[:Tn].add_(d_in[:B * Tn].view(B, Tn, E).sum(0))
         L.emb_grad_add_inputs(d_in, d_emb, B, self.Lseq, E)
+        self._exchange('user')
         self._items_backward(c, d_emb, Ip)
         self._wgrad_join()
         self._flush_corners()
@@ -1334,6 +1390,8 @@ class TransRecEngine:
         last = len(self.bert_blocks) - 1
         for i in range(last, -1, -1):
             blk = self.bert_blocks[i]
+            if i < last:
+                self._exchange(i + 1)              # layer i + 1 is finished: its gradients go out while the layers below run
             if (i + 1) in d_hs:
                 dxb.add_(d_hs[i + 1])              # hidden_states[i + 1] also fed a K-Adapter
             if self.cls_only and i == last:

@@ -391,6 +391,8 @@ class ViTRecEngine(TransRecEngine):
         last = len(self.bert_blocks) - 1
         for i in range(last, -1, -1):
             blk = self.bert_blocks[i]
+            if i < last:
+                self._exchange(i + 1)              # layer i + 1 is finished: its gradients go out while the layers below run
             if (i + 1) in d_hs:
                 dxb.add_(d_hs[i + 1])              # hidden_states[i + 1] also fed a K-Adapter
             if self.cls_only and i == last:

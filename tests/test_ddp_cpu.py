@@ -120,3 +120,70 @@ def test_two_rank_gradient_average(tmp_path):
     finally:
         E.L, E.TransRecEngine._require_device = real_L, real_req
         MT.L = real_L
+
+
+def _overlap_worker(rank, world, port, out_dir):
+    sys.path.insert(0, HERE)
+    sys.path.insert(0, os.path.dirname(HERE))
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    import sim_lib
+    import adapter4rec_amd.engine as E
+    import adapter4rec_amd.optim as O
+    E.L = sim_lib
+    O.L = sim_lib
+    E.TransRecEngine._require_device = lambda self, p0: None
+    from test_engine_shapes import make
+    from adapter4rec_amd.ddp import FlatDDP
+    from adapter4rec_amd.inject import optimizer_groups
+    from adapter4rec_amd.optim import FusedAdam
+    model, args, _, ids, mask = make('four_users_wide_adapters', 'cpu')
+    args.fine_tune_lr, args.lr, args.adapter_bert_lr, args.adapter_sasrec_lr = 5e-5, 1e-4, 1.5e-4, 1.5e-4
+    B = mask.shape[0]
+    half = B // 2
+    per = ids.shape[0] // B
+    my_ids, my_mask = ids[rank * half * per:(rank + 1) * half * per], mask[rank * half:(rank + 1) * half]
+    model = FlatDDP(model)
+    opt = FusedAdam(optimizer_groups(model, args))
+    opt.zero_grad()
+    model(my_ids, my_mask, 'cpu').backward()                # (the first step binds FusedAdam to the engine's flat buffers)
+    opt.step()
+    out = {}
+    for mode in (True, False):
+        E.TransRecEngine.OVERLAP_ALLREDUCE = mode
+        inner = getattr(model.module, 'model', model.module)
+        if inner._native[0] is not None:
+            inner._engine()._chunks = 0                     # (re-derive the chunk plan under the other setting)
+        launches = []
+        real = FlatDDP.launch_
+        FlatDDP.launch_ = lambda self, flat, lo, hi: (launches.append((lo, hi)), real(self, flat, lo, hi))[1]
+        try:
+            opt.zero_grad()
+            model(my_ids, my_mask, 'cpu').backward()
+        finally:
+            FlatDDP.launch_ = real
+        eng = inner._engine()
+        out[mode] = dict(flat=eng.flat_g.clone(), launches=launches, plan=eng._grad_chunks())
+    torch.save(out, os.path.join(out_dir, f'o{rank}.pt'))
+    dist.destroy_process_group()
+
+
+def test_two_rank_chunked_overlapped_exchange(tmp_path):
+    """SURVEY 8(e) / the reference's bucketed DDP (run.py:503,599): with nothing zero-padded the flat gradient buffer goes out in
+    chunks as backward finishes them -- user encoder first, then the item encoder's layers last to first, then the rest -- each an
+    asynchronous all-reduce; the result is bit-identical to the single all-reduce, on both ranks, and every element is exchanged
+    exactly once."""
+    port = 29500 + ((os.getpid() + 7) % 500)
+    mp.spawn(_overlap_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    r0, r1 = torch.load(tmp_path / 'o0.pt', weights_only=False), torch.load(tmp_path / 'o1.pt', weights_only=False)
+    assert r0[True]['plan'] is not None and r0[False]['plan'] is None
+    la = r0[True]['launches']
+    assert len(la) >= 1 + 3 and la == r1[True]['launches'] and not r0[False]['launches']        # user + 3 layers (+ rest), same order on both ranks
+    spans = sorted(la)
+    assert all(a[1] <= b[0] for a, b in zip(spans, spans[1:]))                                     # disjoint
+    plan = r0[True]['plan']
+    assert la[0] == plan['user'] and la[1] == plan['layers'][2] and la[2] == plan['layers'][1]    # the order backward finishes them in
+    for mode in (True, False):
+        torch.testing.assert_close(r0[mode]['flat'], r1[mode]['flat'], rtol=0, atol=0)
+    torch.testing.assert_close(r0[True]['flat'], r0[False]['flat'], rtol=0, atol=0)
+    assert r0[True]['flat'].abs().sum() > 0

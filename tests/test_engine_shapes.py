@@ -14,6 +14,8 @@ CASES = {
     'one_user': dict(S=30, T=20, B=1, heads=2, layers=2),
     'long_history_32': dict(S=32, T=31, B=2, heads=4, layers=1),
     'five_users_cpc': dict(S=16, T=8, B=5, heads=2, layers=2, arch='cpc', adapter_type='pfeiffer', adapter_activation='relu'),
+    # every adapter 64 wide (nothing zero-padded): the geometry whose gradient exchange is chunked and overlapped (tests/test_ddp_cpu.py)
+    'four_users_wide_adapters': dict(S=16, T=8, B=4, heads=2, layers=3, adapter_down_size=64),
 }
 
 
@@ -25,7 +27,7 @@ def make(case, device, dtype='fp32'):
     args = argparse.Namespace(
         max_seq_len=T, l2_weight=0, embedding_dim=64, num_attention_heads=2, drop_rate=0.1, transformer_block=2,
         num_words_title=S, num_words_abstract=50, num_words_body=50, news_attributes=['title'], word_embedding_dim=128,
-        bert_model_load='bert_tiny', bert_adapter_down_size=64, adapter_down_size=16, adapter_dropout_rate=0.1,
+        bert_model_load='bert_tiny', bert_adapter_down_size=64, adapter_down_size=c.get('adapter_down_size', 16), adapter_dropout_rate=0.1,
         adapter_activation=c.get('adapter_activation', 'RELU'), hypercomplex_division=4, phm_init_range=1e-4,
         adapter_type=c.get('adapter_type', 'houslby'), is_serial='True', adding_adapter_to='all', arch=c.get('arch', 'sasrec'),
         compute_dtype=dtype)
