@@ -1231,26 +1231,33 @@ class TransRecEngine:
     def _grad_chunks(self):
         """Flat-buffer ranges in the order backward FINISHES them: the user encoder (+ anything outside the item encoder's layers
         that its backward completes), then the item encoder's layers last to first, then the rest (item head, embeddings, LayerNorms
-        outside the layers).  None when some gradient only reaches the flat buffer at the very end (zero-padded scratch corners,
-        Compacter's PHM chain): the exchange is then the single all-reduce."""
+        outside the layers).  A chunk holding a gradient that only reaches the flat buffer at the very end (a zero-padded scratch
+        corner: the reference's 16-wide SASRec adapters) is marked late and goes out after the flush.  None (= the single all-reduce)
+        for Compacter, whose PHM chain fills every adapter gradient at the end."""
         if getattr(self, '_chunks', 0) != 0:
             return self._chunks
         self._chunks = None
-        if self._corners or self._virtual or not self.OVERLAP_ALLREDUCE:
+        if self._virtual or not self.OVERLAP_ALLREDUCE:
             return None
+        late_ids = {id(p) for _, p, _, _, _ in self._corners}
         import re
-        user, layers, rest = [], {}, []
+        user, layers, rest, late = [], {}, [], set()
         for n, p in zip(self.trainable_names, self.trainable_params):
             o, k = self.offsets[id(p)]
             m = re.search(r'encoder\.layer\.(\d+)\.', n)
             if 'user_encoder' in n:
                 user.append((o, o + k))
+                key = 'user'
             elif m and ('bert_encoder' in n or 'cv_encoder' in n):
                 layers.setdefault(int(m.group(1)), []).append((o, o + k))
+                key = int(m.group(1))
             else:
                 rest.append((o, o + k))
+                key = 'rest'
+            if id(p) in late_ids:
+                late.add(key)
         span = lambda r: (min(a for a, _ in r), max(b for _, b in r)) if r else None
-        out = dict(user=span(user), layers={i: span(r) for i, r in layers.items()}, rest=span(rest))
+        out = dict(user=span(user), layers={i: span(r) for i, r in layers.items()}, rest=span(rest), late=late)
         spans = sorted([s_ for s_ in [out['user'], out['rest']] + list(out['layers'].values()) if s_])
         if any(a[1] > b[0] for a, b in zip(spans, spans[1:])):          # interleaved groups: no contiguous ranges to exchange separately
             return None
@@ -1262,9 +1269,9 @@ class TransRecEngine:
         ex = getattr(self, '_exch', None)
         if ex is None:
             return
-        ddp, ch, done = ex
+        ddp, ch, done, final = ex
         rng = ch['layers'].get(what) if isinstance(what, int) else ch[what]
-        if rng is None or what in done:
+        if rng is None or what in done or (what in ch['late'] and not final):
             return
         done.add(what)
         self._wgrad_join()                                     # the chunk's side-stream weight gradients have landed
@@ -1280,9 +1287,10 @@ class TransRecEngine:
             self._flat_clean = False
             ch = self._grad_chunks() if ddp is not None else None
             if ch is not None:            # chunks are exchanged as backward finishes them, overlapped with the layers still to come
-                self._exch = (ddp, ch, set())
+                self._exch = (ddp, ch, set(), False)
                 try:
                     self.train_backward(grad_out, into_flat_grad=True)
+                    self._exch = self._exch[:3] + (True,)         # the scratch corners are flushed: late chunks may go
                     for what in ['user'] + sorted(ch['layers'], reverse=True) + ['rest']:
                         self._exchange(what)                      # whatever the hooks did not reach (e.g. layers a frozen-input backward skips)
                 finally:

@@ -137,7 +137,7 @@ def _overlap_worker(rank, world, port, out_dir):
     from adapter4rec_amd.ddp import FlatDDP
     from adapter4rec_amd.inject import optimizer_groups
     from adapter4rec_amd.optim import FusedAdam
-    model, args, _, ids, mask = make('four_users_wide_adapters', 'cpu')
+    model, args, _, ids, mask = make(os.environ.get('A4R_TEST_OVERLAP_CASE', 'four_users_wide_adapters'), 'cpu')
     args.fine_tune_lr, args.lr, args.adapter_bert_lr, args.adapter_sasrec_lr = 5e-5, 1e-4, 1.5e-4, 1.5e-4
     B = mask.shape[0]
     half = B // 2
@@ -166,6 +166,21 @@ def _overlap_worker(rank, world, port, out_dir):
         out[mode] = dict(flat=eng.flat_g.clone(), launches=launches, plan=eng._grad_chunks())
     torch.save(out, os.path.join(out_dir, f'o{rank}.pt'))
     dist.destroy_process_group()
+
+
+def test_two_rank_chunked_exchange_padded_user_adapters(tmp_path, monkeypatch):
+    """The reference's default geometry has 16-wide SASRec adapters (zero-padded to 64 here: their gradients reach the flat buffer
+    with the end-of-backward corner flush): the user encoder's chunk then goes out LAST, the item encoder's layers still go out as
+    backward finishes them, and the result is the single all-reduce's."""
+    monkeypatch.setenv('A4R_TEST_OVERLAP_CASE', 'five_users_padded')
+    port = 29500 + ((os.getpid() + 13) % 500)
+    mp.spawn(_overlap_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    r0, r1 = torch.load(tmp_path / 'o0.pt', weights_only=False), torch.load(tmp_path / 'o1.pt', weights_only=False)
+    plan, la = r0[True]['plan'], r0[True]['launches']
+    assert plan is not None and 'user' in plan['late'] and la == r1[True]['launches']
+    assert la[0] == plan['layers'][1] and la[-1] == plan['user'] or la[-2] == plan['user']
+    torch.testing.assert_close(r0[True]['flat'], r0[False]['flat'], rtol=0, atol=0)
+    torch.testing.assert_close(r0[True]['flat'], r1[True]['flat'], rtol=0, atol=0)
 
 
 def test_two_rank_chunked_overlapped_exchange(tmp_path):
