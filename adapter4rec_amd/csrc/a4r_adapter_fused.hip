@@ -72,9 +72,9 @@ A4R_DEV void reduce_partials(const float (*zpart)[16][ZLD], int row, int zd, flo
 }
 template <int EPT>
 A4R_DEV void store_bf16_n(bf16_t* dst, const float (&v)[EPT]) {
-    if constexpr (EPT == 2) *reinterpret_cast<uint32_t*>(dst) = f32_to_bf16_bits(v[0]) | (f32_to_bf16_bits(v[1]) << 16);
-    else *reinterpret_cast<uint2*>(dst) = make_uint2(f32_to_bf16_bits(v[0]) | (f32_to_bf16_bits(v[1]) << 16),
-                                                      f32_to_bf16_bits(v[2]) | (f32_to_bf16_bits(v[3]) << 16));
+    if constexpr (EPT == 2) *reinterpret_cast<uint32_t*>(dst) = pack2_bf16(v[0], v[1]);
+    else *reinterpret_cast<uint2*>(dst) = make_uint2(pack2_bf16(v[0], v[1]),
+                                                      pack2_bf16(v[2], v[3]));
 }
 // byte offset of bottleneck column zd of row r in the swizzled bf16 [16][64] operand image (16-byte chunk c at c ^ ((r >> 1) & 7))
 A4R_DEV int zbf_off(int r, int zd) { return r * 128 + ((((zd >> 3) ^ ((r >> 1) & 7))) << 4) + (zd & 7) * 2; }

@@ -391,12 +391,12 @@ template <int DH> A4R_DEV uint4 bt_frag_tr(const char* img, int d0, int lane) {
     return make_uint4(l2.x, l2.y, h2.x, h2.y);
 }
 A4R_DEV uint4 bt_pack(const f32x4_t& a, const f32x4_t& b) {       // tile 0 rows | tile 1 rows of one lane column -> operand chunk
-    return make_uint4(f32_to_bf16_bits(a[0]) | (f32_to_bf16_bits(a[1]) << 16), f32_to_bf16_bits(a[2]) | (f32_to_bf16_bits(a[3]) << 16),
-                      f32_to_bf16_bits(b[0]) | (f32_to_bf16_bits(b[1]) << 16), f32_to_bf16_bits(b[2]) | (f32_to_bf16_bits(b[3]) << 16));
+    return make_uint4(pack2_bf16(a[0], a[1]), pack2_bf16(a[2], a[3]),
+                      pack2_bf16(b[0], b[1]), pack2_bf16(b[2], b[3]));
 }
 A4R_DEV void bt_store4(bf16_t* p, const f32x4_t& v) {
-    *reinterpret_cast<uint2*>(p) = make_uint2(f32_to_bf16_bits(v[0]) | (f32_to_bf16_bits(v[1]) << 16),
-                                              f32_to_bf16_bits(v[2]) | (f32_to_bf16_bits(v[3]) << 16));
+    *reinterpret_cast<uint2*>(p) = make_uint2(pack2_bf16(v[0], v[1]),
+                                              pack2_bf16(v[2], v[3]));
 }
 A4R_DEV float bt_red4(float v, bool mx) {       // over the 4 lanes l, l^16, l^32, l^48 that share a column
     const float a = __shfl_xor(v, 16, 64);
@@ -520,10 +520,10 @@ __global__ void __launch_bounds__(WAVES * 64, 3) attn_bwd_tr_kernel(const bf16_t
         for (int nt = 0; nt < 2; ++nt) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) dpT[nt][mt][r] = x[nt][r] * (dpT[nt][mt][r] - dsum) * scale;       // dS^T
-            pw[nt][mt] = make_uint2(f32_to_bf16_bits(pk[nt][0]) | (f32_to_bf16_bits(pk[nt][1]) << 16),
-                                    f32_to_bf16_bits(pk[nt][2]) | (f32_to_bf16_bits(pk[nt][3]) << 16));
-            dw[nt][mt] = make_uint2(f32_to_bf16_bits(dpT[nt][mt][0]) | (f32_to_bf16_bits(dpT[nt][mt][1]) << 16),
-                                    f32_to_bf16_bits(dpT[nt][mt][2]) | (f32_to_bf16_bits(dpT[nt][mt][3]) << 16));
+            pw[nt][mt] = make_uint2(pack2_bf16(pk[nt][0], pk[nt][1]),
+                                    pack2_bf16(pk[nt][2], pk[nt][3]));
+            dw[nt][mt] = make_uint2(pack2_bf16(dpT[nt][mt][0], dpT[nt][mt][1]),
+                                    pack2_bf16(dpT[nt][mt][2], dpT[nt][mt][3]));
         }
         const uint4 dsB = make_uint4(dw[0][mt].x, dw[0][mt].y, dw[1][mt].x, dw[1][mt].y);
 #pragma unroll

@@ -22,6 +22,7 @@
 //   dkdv (per 16-key tile, a wave owns its key tiles): S = Q K^T, dP = dO V^T (tiles with the KEY on the lane),
 //        dV^T += dO^T P, dK^T += Q^T dS  over all query groups; lse and delta come from LDS.
 // HBM-bound in principle (fwd: reads 3 M H, writes M H); measured numbers are in DESIGN.md.
+#include <cstdlib>
 #include "a4r_common.h"
 #include "../../include/a4r.h"
 
@@ -118,8 +119,8 @@ A4R_DEV uint64_t drop_idx(int pair, int q, int key) { return (((uint64_t)pair * 
 template <typename T, int NKT> A4R_DEV uint4 pack_step(const f32x4_t (&t)[NKT], int st) {
     if constexpr (sizeof(T) == 2) {
         const f32x4_t a = t[2 * st], b = t[2 * st + 1];
-        return make_uint4(f32_to_bf16_bits(a[0]) | (f32_to_bf16_bits(a[1]) << 16), f32_to_bf16_bits(a[2]) | (f32_to_bf16_bits(a[3]) << 16),
-                          f32_to_bf16_bits(b[0]) | (f32_to_bf16_bits(b[1]) << 16), f32_to_bf16_bits(b[2]) | (f32_to_bf16_bits(b[3]) << 16));
+        return make_uint4(pack2_bf16(a[0], a[1]), pack2_bf16(a[2], a[3]),
+                          pack2_bf16(b[0], b[1]), pack2_bf16(b[2], b[3]));
     } else {
         const f32x4_t a = t[st];
         return make_uint4(__float_as_uint(a[0]), __float_as_uint(a[1]), __float_as_uint(a[2]), __float_as_uint(a[3]));
@@ -128,8 +129,8 @@ template <typename T, int NKT> A4R_DEV uint4 pack_step(const f32x4_t (&t)[NKT], 
 // 4 consecutive head columns of one row, fp32 registers -> global
 template <typename T> A4R_DEV void store4(T* p, const f32x4_t& v) {
     if constexpr (sizeof(T) == 2)
-        *reinterpret_cast<uint2*>(p) = make_uint2(f32_to_bf16_bits(v[0]) | (f32_to_bf16_bits(v[1]) << 16),
-                                                  f32_to_bf16_bits(v[2]) | (f32_to_bf16_bits(v[3]) << 16));
+        *reinterpret_cast<uint2*>(p) = make_uint2(pack2_bf16(v[0], v[1]),
+                                                  pack2_bf16(v[2], v[3]));
     else
         *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
 }
@@ -170,23 +171,26 @@ A4R_DEV void store_block16(char* stg, const f32x4_t (&o)[Geo<T, DH>::ND], T* g0,
     }
 }
 
-// transposed score tiles of one 16-query block: s[kt][r] = scale * q[query c] . k[key 16 kt + 4 kg + r]  (keys >= S: -inf)
+// transposed RAW score tiles of one 16-query block: s[kt][r] = q[query c] . k[key 16 kt + 4 kg + r]  (keys >= S: -inf; the softmax
+// scale is folded into the exponent by the caller).  Only tiles that reach past S carry the per-element select.
 template <typename T, int DH, int NKT>
-A4R_DEV void scores_t(const char* Kr, const uint4 (&qf)[Geo<T, DH>::KS], f32x4_t (&s)[NKT], int S, float scale, int fr, int kg) {
+A4R_DEV void scores_t(const char* Kr, const uint4 (&qf)[Geo<T, DH>::KS], f32x4_t (&s)[NKT], int S, int fr, int kg) {
     using G = Geo<T, DH>;
 #pragma unroll
     for (int kt = 0; kt < NKT; ++kt) {
         f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int ks = 0; ks < G::KS; ++ks) Mma<T>::mma(frag_rows<T, DH>(Kr, kt * 16 + fr, ks, kg), qf[ks], acc);
+        if (kt * 16 + 16 > S) {                      // wave-uniform: the last one or two tiles
 #pragma unroll
-        for (int r = 0; r < 4; ++r) acc[r] = (kt * 16 + kg * 4 + r < S) ? acc[r] * scale : -INFINITY;
+            for (int r = 0; r < 4; ++r) acc[r] = (kt * 16 + kg * 4 + r < S) ? acc[r] : -INFINITY;
+        }
         s[kt] = acc;
         if ((kt & 1) == 1) __builtin_amdgcn_sched_barrier(0);      // keeps the scheduler from hoisting all 2 NKT fragment reads (spills)
     }
 }
 
-struct Drop { uint64_t seed; uint32_t site, thr16; float keep_scale; };
+struct Drop { uint64_t seed; uint32_t site, thr16; float keep_scale; int abl; };     // abl: timing ablations (A4R_ATTN_LONG_ABL; wrong results): 1 no stores, 2 no per-block global loads, 4 no staging loads, 8 no softmax arithmetic
 
 // ------------------------------------------------------------------------------------------------ forward
 template <typename T, int DH, int NKT>
@@ -204,9 +208,11 @@ __global__ void __launch_bounds__(WG<NKT>::NTHR, 4) attn_long_fwd_kernel(const T
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, fr = lane & 15, kg = lane >> 4;
     char* stg = smem + lds_main_fwd<T, DH, NKT>() + wave * STG<T, DH>::BYTES;      // this wave's output staging block (bf16)
     const T* base = qkv + (size_t)item * S * ld + h * DH;
-    stage_rows<T, DH>(Kr, base + k_off, ld, S, SP, tid, NTHR);
-    if constexpr (TR) stage_rows<T, DH>(Vimg, base + v_off, ld, S, SP, tid, NTHR);
-    else stage_cols<T, DH>(reinterpret_cast<T*>(Vimg), base + v_off, ld, S, SP, SPT, tid, NTHR);
+    if (!(dr.abl & 4)) {
+        stage_rows<T, DH>(Kr, base + k_off, ld, S, SP, tid, NTHR);
+        if constexpr (TR) stage_rows<T, DH>(Vimg, base + v_off, ld, S, SP, tid, NTHR);
+        else stage_cols<T, DH>(reinterpret_cast<T*>(Vimg), base + v_off, ld, S, SP, SPT, tid, NTHR);
+    }
     __syncthreads();
     const int nqb = (S + 15) >> 4;
     for (int qb = wave; qb < nqb; qb += NWAVE) {
@@ -215,35 +221,35 @@ __global__ void __launch_bounds__(WG<NKT>::NTHR, 4) attn_long_fwd_kernel(const T
         uint4 qf[G::KS];
 #pragma unroll
         for (int ks = 0; ks < G::KS; ++ks)
-            qf[ks] = valid ? ldg16(base + q_off + (size_t)rq * ld + (ks * 4 + kg) * G::PER) : make_uint4(0, 0, 0, 0);
+            qf[ks] = (valid && !(dr.abl & 2)) ? ldg16(base + q_off + (size_t)rq * ld + (ks * 4 + kg) * G::PER) : make_uint4(0, 0, 0, 0);
         f32x4_t s[NKT];
-        scores_t<T, DH, NKT>(Kr, qf, s, S, scale, fr, kg);
+        scores_t<T, DH, NKT>(Kr, qf, s, S, fr, kg);
         float m = -INFINITY;
 #pragma unroll
         for (int kt = 0; kt < NKT; ++kt)
 #pragma unroll
             for (int r = 0; r < 4; ++r) m = fmaxf(m, s[kt][r]);
-        m = red4(m, true);
+        m = red4(m, true);                                   // max of the RAW scores (scale > 0)
+        // p = exp(scale (s - m)) = exp2(s c - m c), c = scale log2(e): one fma + v_exp_f32 per element; the 1 / row-sum factor is
+        // applied to the 16 output values of the lane instead of its 4 NKT probabilities
+        const float c2 = scale * 1.44269504088896f, mc = m * c2;
         float l = 0.f;
 #pragma unroll
         for (int kt = 0; kt < NKT; ++kt)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) { s[kt][r] = __expf(s[kt][r] - m); l += s[kt][r]; }
+            for (int r = 0; r < 4; ++r) { if (!(dr.abl & 8)) s[kt][r] = __builtin_amdgcn_exp2f(fmaf(s[kt][r], c2, -mc)); l += s[kt][r]; }
         l = red4(l, false);
-        const float inv = 1.f / l;
-#pragma unroll
-        for (int kt = 0; kt < NKT; ++kt)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) s[kt][r] *= inv;
+        float inv = 1.f / l;
         if (dr.thr16) {                                       // P' = dropout(P): the 4 keys of a lane's tile column share one hash
+            inv *= dr.keep_scale;
 #pragma unroll
             for (int kt = 0; kt < NKT; ++kt) {
                 const uint64_t hsh = a4r_hash64(dr.seed, dr.site, drop_idx(blockIdx.x, rq, kt * 16 + kg * 4) >> 2);
 #pragma unroll
-                for (int r = 0; r < 4; ++r) s[kt][r] = (((uint32_t)(hsh >> (16 * r)) & 0xffffu) >= dr.thr16) ? s[kt][r] * dr.keep_scale : 0.f;
+                for (int r = 0; r < 4; ++r) s[kt][r] = (((uint32_t)(hsh >> (16 * r)) & 0xffffu) >= dr.thr16) ? s[kt][r] : 0.f;
             }
         }
-        if (valid && kg == 0) lse[((size_t)item * nh + h) * S + rq] = m + __logf(l);
+        if (valid && kg == 0) lse[((size_t)item * nh + h) * S + rq] = m * scale + __logf(l);
         f32x4_t o[G::ND];
 #pragma unroll
         for (int dt = 0; dt < G::ND; ++dt) o[dt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
@@ -254,7 +260,11 @@ __global__ void __launch_bounds__(WG<NKT>::NTHR, 4) attn_long_fwd_kernel(const T
             for (int dt = 0; dt < G::ND; ++dt) Mma<T>::mma(frag_T<T, DH>(Vimg, SPT, dt * 16, st, lane), pf, o[dt]);
             __builtin_amdgcn_sched_barrier(0);
         }
-        store_block16<T, DH>(stg, o, ctx + ((size_t)item * S + qb * 16) * ldo + h * DH, ldo, S - qb * 16, lane);
+#pragma unroll
+        for (int dt = 0; dt < G::ND; ++dt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) o[dt][r] *= inv;
+        if (!(dr.abl & 1)) store_block16<T, DH>(stg, o, ctx + ((size_t)item * S + qb * 16) * ldo + h * DH, ldo, S - qb * 16, lane);
     }
 }
 
@@ -291,7 +301,8 @@ __global__ void __launch_bounds__(WG<NKT>::NTHR, 4) attn_long_dq_kernel(const T*
             qf[ks] = valid ? ldg16(base + q_off + (size_t)rq * ld + (ks * 4 + kg) * G::PER) : make_uint4(0, 0, 0, 0);
             dof[ks] = valid ? ldg16(dctx + grow * ldo + h * DH + (ks * 4 + kg) * G::PER) : make_uint4(0, 0, 0, 0);
         }
-        const float lq = valid ? lse[((size_t)item * nh + h) * S + rq] : 0.f;
+        const float c2 = scale * 1.44269504088896f;
+        const float lq2 = (valid ? lse[((size_t)item * nh + h) * S + rq] : 0.f) * 1.44269504088896f;
         // delta = sum_k P' dP' = dO . O (the forward output, dropout included): one dot product per query instead of a pass over all
         // key tiles, so P, dP and dS are produced and consumed one chunk step (32 / 16 keys) at a time and never held for the whole row
         float dsum = 0.f;
@@ -323,12 +334,14 @@ __global__ void __launch_bounds__(WG<NKT>::NTHR, 4) attn_long_dq_kernel(const T*
                 }
                 uint64_t hsh = 0;
                 if (dr.thr16) hsh = a4r_hash64(dr.seed, dr.site, drop_idx(blockIdx.x, rq, kt * 16 + kg * 4) >> 2);
+                const bool partial = kt * 16 + 16 > S;                    // wave-uniform
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const float pv = (kt * 16 + kg * 4 + r < S) ? __expf(sc[r] * scale - lq) : 0.f;
+                    float pv = __builtin_amdgcn_exp2f(fmaf(sc[r], c2, -lq2));          // P = exp(scale s - lse)
+                    if (partial) pv = (kt * 16 + kg * 4 + r < S) ? pv : 0.f;
                     float dpr = dp[r];
                     if (dr.thr16) dpr = (((uint32_t)(hsh >> (16 * r)) & 0xffffu) >= dr.thr16) ? dpr * dr.keep_scale : 0.f;
-                    ds[t][r] = pv * (dpr - dsum) * scale;
+                    ds[t][r] = pv * (dpr - dsum);                                      // (x scale: applied to the 16 outputs of the lane)
                 }
             }
             const uint4 dsf = pack_step<T, G::TPS>(ds, 0);
@@ -336,6 +349,10 @@ __global__ void __launch_bounds__(WG<NKT>::NTHR, 4) attn_long_dq_kernel(const T*
             for (int dt = 0; dt < G::ND; ++dt) Mma<T>::mma(frag_T<T, DH>(Kimg, SPT, dt * 16, st, lane), dsf, o[dt]);
             __builtin_amdgcn_sched_barrier(0);
         }
+#pragma unroll
+        for (int dt = 0; dt < G::ND; ++dt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) o[dt][r] *= scale;
         store_block16<T, DH>(stg, o, dqkv + ((size_t)item * S + qb * 16) * ld + q_off + h * DH, ld, S - qb * 16, lane);
     }
 }
@@ -369,11 +386,12 @@ __global__ void __launch_bounds__(WG<NKT>::NTHR, 4) attn_long_dkdv_kernel(const 
         stage_cols<T, DH>(reinterpret_cast<T*>(Oimg), dob, ldo, S, SP, SPT, tid, NTHR);
     }
     for (int i = tid; i < SP; i += NTHR) {
-        lse_s[i] = i < S ? lse[((size_t)item * nh + h) * S + i] : 0.f;
+        lse_s[i] = i < S ? lse[((size_t)item * nh + h) * S + i] * 1.44269504088896f : 0.f;
         del_s[i] = i < S ? delta[((size_t)item * nh + h) * S + i] : 0.f;
     }
     __syncthreads();
     const int nkt = (S + 15) >> 4;
+    const float c2 = scale * 1.44269504088896f;
     for (int kt = wave; kt < nkt; kt += NWAVE) {
         const int rk = kt * 16 + fr;                          // this lane's key (column of every tile below)
         const bool kvalid = rk < S;
@@ -398,14 +416,17 @@ __global__ void __launch_bounds__(WG<NKT>::NTHR, 4) attn_long_dkdv_kernel(const 
                     Mma<T>::mma(frag_rows<T, DH>(Qr, q0 + fr, ks, kg), kf[ks], sc);
                     Mma<T>::mma(frag_rows<T, DH>(Or, q0 + fr, ks, kg), vf[ks], dpt);
                 }
+                const bool partial = q0 + 16 > S;                          // wave-uniform: query rows past S (lse_s = 0 there)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int q = q0 + kg * 4 + r;
-                    float pv = (kvalid && q < S) ? __expf(sc[r] * scale - lse_s[q]) : 0.f;
+                    float pv = __builtin_amdgcn_exp2f(fmaf(sc[r], c2, -lse_s[q]));     // lse_s holds lse log2(e)
+                    if (partial) pv = q < S ? pv : 0.f;
+                    if (!kvalid) pv = 0.f;
                     float keepf = 1.f;                        // here the tile's 4 rows are 4 QUERIES at one key: one hash each
                     if (dr.thr16) keepf = dropout_keep(dr.seed, dr.site, drop_idx(blockIdx.x, q, rk), dr.thr16) ? dr.keep_scale : 0.f;
                     p[t][r] = pv * keepf;
-                    ds[t][r] = pv * (dpt[r] * keepf - del_s[q]) * scale;
+                    ds[t][r] = pv * (dpt[r] * keepf - del_s[q]);                       // (x scale: applied to dK at the end)
                 }
             }
             const uint4 pf = pack_step<T, G::TPS>(p, 0), dsf = pack_step<T, G::TPS>(ds, 0);
@@ -415,6 +436,10 @@ __global__ void __launch_bounds__(WG<NKT>::NTHR, 4) attn_long_dkdv_kernel(const 
                 Mma<T>::mma(frag_T<T, DH>(Qimg, SPT, dt * 16, g, lane), dsf, dk[dt]);
             }
         }
+#pragma unroll
+        for (int dt = 0; dt < G::ND; ++dt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) dk[dt][r] *= scale;
         T* blk = dqkv + ((size_t)item * S + kt * 16) * ld + h * DH;
         store_block16<T, DH>(stg, dk, blk + k_off, ld, S - kt * 16, lane);
         store_block16<T, DH>(stg, dv, blk + v_off, ld, S - kt * 16, lane);
@@ -435,7 +460,10 @@ template <typename K> int set_lds(K kernel, size_t bytes) {
     return A4R_OK;
 }
 
-Drop drop_of(const a4r_attn_t* a) { return Drop{a->drop_seed, a->drop_site, a4r_thr16(a->drop_p), a4r_keep_scale(a->drop_p)}; }
+Drop drop_of(const a4r_attn_t* a) {
+    static const int abl = getenv("A4R_ATTN_LONG_ABL") ? atoi(getenv("A4R_ATTN_LONG_ABL")) : 0;
+    return Drop{a->drop_seed, a->drop_site, a4r_thr16(a->drop_p), a4r_keep_scale(a->drop_p), abl};
+}
 
 template <typename T, int DH, int NKT> int run_fwd(hipStream_t s, const a4r_attn_t* a, float* lse) {
     const size_t lds = lds_fwd<T, DH, NKT>();

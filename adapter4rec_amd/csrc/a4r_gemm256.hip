@@ -298,10 +298,10 @@ __global__ void __launch_bounds__(512, 2) gemm_nt_256_kernel(const a4r_gemm_t p,
     // row mi is finished and stored -- a load waited for where it is issued costs an L2 / HBM round trip per group, and it cannot
     // be hoisted above the previous group's store by the compiler (C may alias Pre for all it knows).
     constexpr int PS = DACT != A4R_ACT_NONE ? 8 * (int)sizeof(TO) / 16 : 1;
-    uint4 pre_ld[2][2][PS];
+    uint4 pre_ld_00[PS], pre_ld_01[PS], pre_ld_10[PS], pre_ld_11[PS];      // [row parity][pair]: four separate objects (one [2][2][PS] array went to scratch)
     if constexpr (DACT != A4R_ACT_NONE && !(A4R_ABL & 256)) {
-        load_pre_n<TO, 8>(pre_ld[0][0], grow0, gcolp, epi);
-        load_pre_n<TO, 8>(pre_ld[0][1], grow0, gcolp + 32, epi);
+        load_pre_n<TO, 8, DACT == A4R_DACT_MULQ8_>(pre_ld_00, grow0, gcolp, epi);
+        load_pre_n<TO, 8, DACT == A4R_DACT_MULQ8_>(pre_ld_01, grow0, gcolp + 32, epi);
     }
     // the residual operand R1 (dgrad GEMMs: the gradient of the residual branch) likewise one row ahead (bf16 outputs: 4 registers
     // per group; the ping-pong K loop left the registers for it)
@@ -320,7 +320,7 @@ __global__ void __launch_bounds__(512, 2) gemm_nt_256_kernel(const a4r_gemm_t p,
 #define A4R_EPI_CALL(mi_, pr_)                                                                                              \
         epilogue_n<TO, 8, ACT, DACT, R1PF>(v_, bias8[pr_], grow0 + (mi_) * 16, gcolp + (pr_) * 32, epi,
 #endif
-#define A4R_EPI_PAIR(mi_, pr_)                                                                                              \
+#define A4R_EPI_PAIR(mi_, pr_, par_)                                                                                        \
     {                                                                                                                       \
         float v_[8];                                                                                                        \
         _Pragma("unroll") for (int r_ = 0; r_ < 4; ++r_) {                                                                  \
@@ -333,12 +333,12 @@ __global__ void __launch_bounds__(512, 2) gemm_nt_256_kernel(const a4r_gemm_t p,
             _Pragma("unroll") for (int e_ = 0; e_ < 8; ++e_) v_[e_] *= sa8[mi_] * sb8[pr_][e_];                             \
         }                                                                                                                   \
         A4R_EPI_CALL(mi_, pr_)                                                                                              \
-                                           DACT != A4R_ACT_NONE ? pre_ld[(mi_) & 1][pr_] : nullptr, R1PF ? r1_ld[(mi_) & 1][pr_] : nullptr); \
+                                           DACT != A4R_ACT_NONE ? pre_ld_##par_##pr_ : nullptr, R1PF ? r1_ld[(mi_) & 1][pr_] : nullptr); \
     }
-#define A4R_EPI_ROW(mi_)                                                                                                    \
+#define A4R_EPI_ROW(mi_, par_, npar_)                                                                                       \
     if constexpr (DACT != A4R_ACT_NONE && (mi_) < 7 && !(A4R_ABL & 256)) {                                                  \
-        load_pre_n<TO, 8>(pre_ld[((mi_) + 1) & 1][0], grow0 + ((mi_) + 1) * 16, gcolp, epi);                                \
-        load_pre_n<TO, 8>(pre_ld[((mi_) + 1) & 1][1], grow0 + ((mi_) + 1) * 16, gcolp + 32, epi);                           \
+        load_pre_n<TO, 8, DACT == A4R_DACT_MULQ8_>(pre_ld_##npar_##0, grow0 + ((mi_) + 1) * 16, gcolp, epi);                \
+        load_pre_n<TO, 8, DACT == A4R_DACT_MULQ8_>(pre_ld_##npar_##1, grow0 + ((mi_) + 1) * 16, gcolp + 32, epi);           \
     }                                                                                                                       \
     if constexpr (R1PF && (mi_) < 7) {                                                                                      \
         if (epi.R1) {                                                                                                       \
@@ -346,8 +346,8 @@ __global__ void __launch_bounds__(512, 2) gemm_nt_256_kernel(const a4r_gemm_t p,
             load_res_n<TO, 8>(r1_ld[((mi_) + 1) & 1][1], epi.R1, epi.ldr1, grow0 + ((mi_) + 1) * 16, gcolp + 32);           \
         }                                                                                                                   \
     }                                                                                                                       \
-    A4R_EPI_PAIR(mi_, 0) A4R_EPI_PAIR(mi_, 1)
-    A4R_EPI_ROW(0) A4R_EPI_ROW(1) A4R_EPI_ROW(2) A4R_EPI_ROW(3) A4R_EPI_ROW(4) A4R_EPI_ROW(5) A4R_EPI_ROW(6) A4R_EPI_ROW(7)
+    A4R_EPI_PAIR(mi_, 0, par_) A4R_EPI_PAIR(mi_, 1, par_)
+    A4R_EPI_ROW(0, 0, 1) A4R_EPI_ROW(1, 1, 0) A4R_EPI_ROW(2, 0, 1) A4R_EPI_ROW(3, 1, 0) A4R_EPI_ROW(4, 0, 1) A4R_EPI_ROW(5, 1, 0) A4R_EPI_ROW(6, 0, 1) A4R_EPI_ROW(7, 1, 0)
 #undef A4R_EPI_ROW
 #undef A4R_EPI_PAIR
     if (!more) break;

@@ -78,8 +78,8 @@ template <typename T, int NC> A4R_DEV void store_n(T* p, const float* o) {
     if constexpr (NC == 8) store_vec<T, 8>(p, o);
     else if constexpr (sizeof(T) == 4) store_vec<T, 4>(p, o);
     else
-        *reinterpret_cast<uint2*>(p) = make_uint2(f32_to_bf16_bits(o[0]) | (f32_to_bf16_bits(o[1]) << 16),
-                                                  f32_to_bf16_bits(o[2]) | (f32_to_bf16_bits(o[3]) << 16));
+        *reinterpret_cast<uint2*>(p) = make_uint2(pack2_bf16(o[0], o[1]),
+                                                  pack2_bf16(o[2], o[3]));
 }
 
 template <int NC>
@@ -93,11 +93,13 @@ A4R_DEV void epi_dropout(float (&v)[NC], uint64_t e0, uint64_t seed, uint32_t si
 }
 
 // pre_ld != nullptr: the NC elements of Pre were requested earlier by the caller (16-byte pieces; see load_pre_n)
-template <typename TO, int NC> A4R_DEV void load_pre_n(uint4* q, uint32_t grow, int gcol, const GemmEpi<TO>& e) {
-    if (e.dact == A4R_DACT_MULQ8_) {                         // one byte per element
+// Q8: the Pre operand is the one-byte-per-element derivative tensor (compile-time: a run-time test here made the callers' register
+// arrays addressable and sent them to scratch)
+template <typename TO, int NC, bool Q8 = false> A4R_DEV void load_pre_n(uint4* q, uint32_t grow, int gcol, const GemmEpi<TO>& e) {
+    if constexpr (Q8) {
         const uint8_t* p8 = reinterpret_cast<const uint8_t*>(e.Pre) + (size_t)grow * (uint32_t)e.ldpre + gcol;
-        if constexpr (NC == 8) { const uint2 w = *reinterpret_cast<const uint2*>(p8); q[0].x = w.x; q[0].y = w.y; }
-        else q[0].x = *reinterpret_cast<const uint32_t*>(p8);
+        if constexpr (NC == 8) { const uint2 w = *reinterpret_cast<const uint2*>(p8); q[0] = make_uint4(w.x, w.y, 0u, 0u); }
+        else q[0] = make_uint4(*reinterpret_cast<const uint32_t*>(p8), 0u, 0u, 0u);
         return;
     }
 #pragma unroll
@@ -141,16 +143,25 @@ A4R_DEV void epilogue_n(float (&v)[NC], const float* bias, uint32_t grow, int gc
     }
     if (dact != A4R_ACT_NONE && !(A4R_ABL & 256)) {
         float pre[NC];
-        if (dact == A4R_DACT_MULQ8_) {
-            uint4 w;
-            if (pre_ld) w = pre_ld[0];
-            else load_pre_n<TO, NC>(&w, grow, gcol, e);
-            unpack_q8<NC>(&w.x, pre);
-        } else if (pre_ld) {
+        // (compile-time split: with the 8-bit form behind a run-time test the callers' prefetch arrays went to scratch)
+        constexpr bool Q8_CT = DACT == A4R_DACT_MULQ8_, Q8_RT = DACT < 0;
+        bool q8 = Q8_CT;
+        if constexpr (Q8_RT) q8 = dact == A4R_DACT_MULQ8_;
+        if constexpr (Q8_CT || Q8_RT) {
+            if (q8) {
+                uint4 w;
+                if (pre_ld) w = pre_ld[0];
+                else load_pre_n<TO, NC, true>(&w, grow, gcol, e);
+                unpack_q8<NC>(&w.x, pre);
+            }
+        }
+        if (!q8) {
+            if (pre_ld) {
 #pragma unroll
-            for (int s = 0; s < NC / Elem<TO>::PER16; ++s) Elem<TO>::unpack(pre_ld[s], pre + s * Elem<TO>::PER16);
-        } else {
-            load_n<TO, NC>(e.Pre + (size_t)grow * (uint32_t)e.ldpre + gcol, pre);
+                for (int s = 0; s < NC / Elem<TO>::PER16; ++s) Elem<TO>::unpack(pre_ld[s], pre + s * Elem<TO>::PER16);
+            } else {
+                load_n<TO, NC>(e.Pre + (size_t)grow * (uint32_t)e.ldpre + gcol, pre);
+            }
         }
         if (dact == A4R_DACT_MUL_ || dact == A4R_DACT_MULQ8_) {
 #pragma unroll
