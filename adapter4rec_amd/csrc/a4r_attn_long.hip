@@ -119,8 +119,10 @@ A4R_DEV uint64_t drop_idx(int pair, int q, int key) { return (((uint64_t)pair * 
 template <typename T, int NKT> A4R_DEV uint4 pack_step(const f32x4_t (&t)[NKT], int st) {
     if constexpr (sizeof(T) == 2) {
         const f32x4_t a = t[2 * st], b = t[2 * st + 1];
-        return make_uint4(pack2_bf16(a[0], a[1]), pack2_bf16(a[2], a[3]),
-                          pack2_bf16(b[0], b[1]), pack2_bf16(b[2], b[3]));
+        // (scalar conversions here on purpose: with the vector form the 14-tile forward kernel needs 31 more registers than its
+        // 128-register budget -- the scheduler hoists the conversions of all steps -- and spills: 158 -> 254 us)
+        return make_uint4(f32_to_bf16_bits(a[0]) | (f32_to_bf16_bits(a[1]) << 16), f32_to_bf16_bits(a[2]) | (f32_to_bf16_bits(a[3]) << 16),
+                          f32_to_bf16_bits(b[0]) | (f32_to_bf16_bits(b[1]) << 16), f32_to_bf16_bits(b[2]) | (f32_to_bf16_bits(b[3]) << 16));
     } else {
         const f32x4_t a = t[st];
         return make_uint4(__float_as_uint(a[0]), __float_as_uint(a[1]), __float_as_uint(a[2]), __float_as_uint(a[3]));
@@ -129,8 +131,8 @@ template <typename T, int NKT> A4R_DEV uint4 pack_step(const f32x4_t (&t)[NKT], 
 // 4 consecutive head columns of one row, fp32 registers -> global
 template <typename T> A4R_DEV void store4(T* p, const f32x4_t& v) {
     if constexpr (sizeof(T) == 2)
-        *reinterpret_cast<uint2*>(p) = make_uint2(pack2_bf16(v[0], v[1]),
-                                                  pack2_bf16(v[2], v[3]));
+        *reinterpret_cast<uint2*>(p) = make_uint2(f32_to_bf16_bits(v[0]) | (f32_to_bf16_bits(v[1]) << 16),
+                                                  f32_to_bf16_bits(v[2]) | (f32_to_bf16_bits(v[3]) << 16));
     else
         *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
 }

@@ -67,11 +67,10 @@ __global__ void __launch_bounds__(256) skinny64_kernel(const a4r_gemm_t p, uint3
 #pragma unroll
         for (int e = 0; e < 8; ++e) b8[pr][e] = epi.bias ? epi.bias[gcolp + pr * 32 + e] : 0.f;
     constexpr int PS = 8 * (int)sizeof(TO) / 16;
-    uint4 pre_ld[2][PS];
-    const bool has_pre = epi.dact != A4R_ACT_NONE;
-    if (has_pre) {
-        load_pre_n<TO, 8>(pre_ld[0], grow, gcolp, epi);
-        load_pre_n<TO, 8>(pre_ld[1], grow, gcolp + 32, epi);
+    uint4 pre_ld0[PS] = {}, pre_ld1[PS] = {};      // two objects, always handed to the epilogue (a run-time null / index made one array addressable: scratch)
+    if (epi.dact != A4R_ACT_NONE) {
+        load_pre_n<TO, 8>(pre_ld0, grow, gcolp, epi);
+        load_pre_n<TO, 8>(pre_ld1, grow, gcolp + 32, epi);
     }
     int a_off[2], b_off[2];
 #pragma unroll
@@ -114,7 +113,7 @@ __global__ void __launch_bounds__(256) skinny64_kernel(const a4r_gemm_t p, uint3
             v[r] = __uint_as_float(sw[0]);
             v[4 + r] = __uint_as_float(sw[1]);
         }
-        epilogue_n<TO, 8>(v, b8[pr], grow, gcolp + pr * 32, epi, has_pre ? pre_ld[pr] : nullptr);
+        epilogue_n<TO, 8>(v, b8[pr], grow, gcolp + pr * 32, epi, pr == 0 ? pre_ld0 : pre_ld1);
     }
 }
 
