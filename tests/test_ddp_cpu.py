@@ -172,7 +172,7 @@ def test_two_rank_chunked_exchange_padded_user_adapters(tmp_path, monkeypatch):
     """The reference's default geometry has 16-wide SASRec adapters (zero-padded to 64 here: their gradients reach the flat buffer
     with the end-of-backward corner flush): the user encoder's chunk then goes out LAST, the item encoder's layers still go out as
     backward finishes them, and the result is the single all-reduce's."""
-    monkeypatch.setenv('A4R_TEST_OVERLAP_CASE', 'five_users_padded')
+    monkeypatch.setenv('A4R_TEST_OVERLAP_CASE', 'four_users_padded')
     port = 29500 + ((os.getpid() + 13) % 500)
     mp.spawn(_overlap_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
     r0, r1 = torch.load(tmp_path / 'o0.pt', weights_only=False), torch.load(tmp_path / 'o1.pt', weights_only=False)

@@ -16,7 +16,7 @@ CASES = {
     'five_users_cpc': dict(S=16, T=8, B=5, heads=2, layers=2, arch='cpc', adapter_type='pfeiffer', adapter_activation='relu'),
     # every adapter 64 wide (nothing zero-padded): the geometry whose gradient exchange is chunked and overlapped (tests/test_ddp_cpu.py)
     'four_users_wide_adapters': dict(S=16, T=8, B=4, heads=2, layers=3, adapter_down_size=64),
-    'five_users_padded': dict(S=16, T=8, B=4, heads=2, layers=2),
+    'four_users_padded': dict(S=16, T=8, B=4, heads=2, layers=2),
 }
 
 
