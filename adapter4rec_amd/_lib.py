@@ -167,14 +167,14 @@ def adapter_ln_fwd(A, R1, R2, Wd, bd, Wu, bu, gamma, beta, eps, act, zp, z, v, y
 
 
 def adapter_ln_bwd(dy, v, stats, gamma, dres, zp, act, WuT, WdT, inner_res, dv, dzp, dh, dgamma=None, dbeta=None, dbias=None, M=None,
-                   drop_p=0.0, drop_site=0, drop_seed=0):
+                   drop_p=0.0, drop_site=0, drop_seed=0, dbd=None):
     require_gpu(dy, v, dv, dh)
     M = dy.shape[0] if M is None else M
     _check(lib().a4r_adapter_ln_bwd(_stream(), _p(dy), C.c_int(_ld(dy)), _p(v), C.c_int(_ld(v)), _p(stats), _p(gamma),
                                     _p(dres), C.c_int(_ld(dres) if dres is not None else 0), _p(zp), C.c_int(act), _p(WuT), _p(WdT),
                                     C.c_int(int(inner_res)), _p(dv), C.c_int(_ld(dv)), _p(dzp), _p(dh), C.c_int(_ld(dh)),
                                     _p(dgamma), _p(dbeta), _p(dbias), C.c_int(M), C.c_int(dy.shape[1]), C.c_int(WuT.shape[0]), C.c_int(_dt(dy)),
-                                    C.c_float(drop_p), C.c_uint32(drop_site), C.c_uint64(drop_seed)), 'a4r_adapter_ln_bwd')
+                                    C.c_float(drop_p), C.c_uint32(drop_site), C.c_uint64(drop_seed), _p(dbd)), 'a4r_adapter_ln_bwd')
 
 
 def gemm_tn(X, Y, Cacc, M=None):

@@ -232,7 +232,7 @@ struct AdBwdArgs {
     const bf16_t* zp; int act;
     const bf16_t* WuT; const bf16_t* WdT; int inner_res;
     bf16_t* dv; bf16_t* dzp; bf16_t* dh; int lddv, lddh;
-    float* dgamma; float* dbeta; float* dbias;
+    float* dgamma; float* dbeta; float* dbias; float* dbd;
     int M;
     uint64_t seed; uint32_t site, thr16; float keep_scale;
 };
@@ -273,6 +273,9 @@ __global__ void __launch_bounds__(NW * 64) adapter_ln_bwd_kernel(const AdBwdArgs
                     *reinterpret_cast<const uint4*>(p.WdT + (size_t)(c0 + s * 32 + (fr >> 2) * 8 + h * 4 + (fr & 3)) * 64 + ks * 32 + kg * 8);
 
     const int e0 = tid * EPT, rrow = e0 >> 6, rzd = e0 & 63;
+    float sd[EPT];                          // column sums of dzp over this workgroup's tiles (the down-projection's bias gradient)
+#pragma unroll
+    for (int i = 0; i < EPT; ++i) sd[i] = 0.f;
     float sg[KS][8], sb[KS][8], sv[KS][8];
 #pragma unroll
     for (int s = 0; s < KS; ++s)
@@ -379,7 +382,7 @@ __global__ void __launch_bounds__(NW * 64) adapter_ln_bwd_kernel(const AdBwdArgs
                 pre[2] = bf16_bits_to_f32(u.y & 0xffffu); pre[3] = bf16_bits_to_f32(u.y >> 16);
             }
 #pragma unroll
-            for (int i = 0; i < EPT; ++i) s_[i] *= act_bwd(pre[i], p.act);
+            for (int i = 0; i < EPT; ++i) { s_[i] *= act_bwd(pre[i], p.act); sd[i] += s_[i]; }
             store_bf16_n<EPT>(p.dzp + gi, s_);
             store_bf16_n<EPT>(reinterpret_cast<bf16_t*>(zbf + zbf_off(rrow, rzd)), s_);
         }
@@ -415,6 +418,19 @@ __global__ void __launch_bounds__(NW * 64) adapter_ln_bwd_kernel(const AdBwdArgs
 #pragma unroll
         for (int s = 0; s < KS; ++s) { d_cur[s] = d_nxt[s]; v_cur[s] = v_nxt[s]; }
         st_cur = st_nxt;
+    }
+    // ---- db_down = column sums of dzp: thread t holds columns (t EPT) & 63 of row (t EPT) >> 6 -> through LDS, one atomic per column
+    if (p.dbd) {
+        A4R_LDS_BARRIER();
+#pragma unroll
+        for (int i = 0; i < EPT; ++i) zpart[0][rrow][rzd + i] = sd[i];
+        A4R_LDS_BARRIER();
+        if (tid < 64) {
+            float t = 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) t += zpart[0][r][tid];
+            atomicAdd(p.dbd + tid, t);
+        }
     }
     // ---- column sums: over the 16 rows a lane group holds (lane & 15), then one atomic per column per workgroup
     if constexpr (WGB || WDB) {
@@ -494,7 +510,7 @@ extern "C" int a4r_adapter_ln_fwd(void* stream, const void* A, int lda, const vo
 extern "C" int a4r_adapter_ln_bwd(void* stream, const void* dy, int lddy, const void* v, int ldv, const float* stats, const float* gamma,
                                   const void* dres, int lddres, const void* zp, int act, const void* WuT, const void* WdT, int inner_res,
                                   void* dv, int lddv, void* dzp, void* dh, int lddh, float* dgamma, float* dbeta, float* dbias,
-                                  int M, int H, int d, int dtype, float drop_p, uint32_t drop_site, uint64_t drop_seed) {
+                                  int M, int H, int d, int dtype, float drop_p, uint32_t drop_site, uint64_t drop_seed, float* dbd) {
     if (!dy || !v || !stats || !gamma || !zp || !WuT || !WdT || !dv || !dzp || !dh) return A4R_EINVAL;
     if (dtype != A4R_BF16 || d != 64 || M <= 0 || M % 16) return A4R_EINVAL;
     if (lddy % 8 || ldv % 8 || (dres && lddres % 8) || lddv % 8 || lddh % 8) return A4R_EINVAL;
@@ -507,7 +523,7 @@ extern "C" int a4r_adapter_ln_bwd(void* stream, const void* dy, int lddy, const 
     a.zp = reinterpret_cast<const bf16_t*>(zp); a.act = act;
     a.WuT = reinterpret_cast<const bf16_t*>(WuT); a.WdT = reinterpret_cast<const bf16_t*>(WdT); a.inner_res = inner_res;
     a.dv = reinterpret_cast<bf16_t*>(dv); a.dzp = reinterpret_cast<bf16_t*>(dzp); a.dh = reinterpret_cast<bf16_t*>(dh);
-    a.lddv = lddv; a.lddh = lddh; a.dgamma = dgamma; a.dbeta = dbeta; a.dbias = dbias; a.M = M;
+    a.lddv = lddv; a.lddh = lddh; a.dgamma = dgamma; a.dbeta = dbeta; a.dbias = dbias; a.dbd = dbd; a.M = M;
     a.seed = drop_seed; a.site = drop_site; a.thr16 = a4r_thr16(drop_p); a.keep_scale = a4r_keep_scale(drop_p);
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     const int ntiles = M / 16, ncu = a4r_cu_count();

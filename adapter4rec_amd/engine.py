@@ -31,6 +31,7 @@ def pad_to(n, m):
 
 
 import os as _os
+FUSE_BD = bool(int(_os.environ.get('A4R_FUSE_BD', '1')))               # db_down from the fused adapter backward kernel (0: a4r_colsum launches, A/B)
 WGRAD_STREAM = bool(int(_os.environ.get('A4R_WGRAD_STREAM', '1')))     # adapter weight gradients on a side stream (see _adapter_wgrads); 0 = single stream
 
 class _LN:
@@ -878,14 +879,16 @@ class TransRecEngine:
         if pl == 'pfeiffer':
             va, t, sta = bufs['va' + which], bufs['t' + which], bufs['sta' + which]
             dt = self._buf('dt', M, H, T)
+            fused_bd = False
             if self._fuse_bwd(blk, ad, dy):
                 L.adapter_ln_bwd(dy, v, st, lnn.gamma, None, zp, ad.act, ad.wuT, ad.wdT, False, dv, dzp, dt,
-                                 dgamma=gg(lnn.g_gamma), dbeta=gg(lnn.g_beta), dbias=gg(ad.g_bu), M=M)
+                                 dgamma=gg(lnn.g_gamma), dbeta=gg(lnn.g_beta), dbias=gg(ad.g_bu), M=M, dbd=self._bd_target(ad))
+                fused_bd = self._bd_target(ad) is not None
             else:
                 L.ln_bwd(dy, v, st, lnn.gamma, dv, M=M, dgamma=gg(lnn.g_gamma), dbeta=gg(lnn.g_beta), dbias=gg(ad.g_bu))
                 L.gemm_nt(dv, ad.wuT, dzp, Pre=zp, dact=ad.act, M=M)
                 L.gemm_nt(dzp, ad.wdT, dt, M=M)
-            self._adapter_wgrads(ad, dv, z, dzp, t, M)
+            self._adapter_wgrads(ad, dv, z, dzp, t, M, bd_done=fused_bd)
             dva = self._buf('dva', M, H, T)
             L.ln_bwd(dt, va, sta, ln.gamma, dva, M=M, dgamma=gg(ln.g_gamma), dbeta=gg(ln.g_beta), dres=dv)
             if p_drop > 0:
@@ -897,8 +900,8 @@ class TransRecEngine:
             # ONE launch: LayerNorm backward, dzp = (dv Wu) * act'(zp), dh = mask * (dzp Wd [+ dv]) (a4r_adapter_fused.hip)
             L.adapter_ln_bwd(dy, v, st, ln.gamma, None, zp, ad.act, ad.wuT, ad.wdT, ad.kind != 'compacter', dv, dzp, dh,
                              dgamma=gg(ln.g_gamma), dbeta=gg(ln.g_beta), dbias=gg(ad.g_bu), M=M,
-                             drop_p=p_drop, drop_site=site, drop_seed=seed)
-            self._adapter_wgrads(ad, dv, z, dzp, h, M)
+                             drop_p=p_drop, drop_site=site, drop_seed=seed, dbd=self._bd_target(ad))
+            self._adapter_wgrads(ad, dv, z, dzp, h, M, bd_done=self._bd_target(ad) is not None)
             return dh, dv
         L.ln_bwd(dy, v, st, ln.gamma, dv, M=M, dgamma=gg(ln.g_gamma), dbeta=gg(ln.g_beta), dbias=gg(ad.g_bu))
         L.gemm_nt(dv, ad.wuT, dzp, Pre=zp, dact=ad.act, M=M)
@@ -942,8 +945,15 @@ class TransRecEngine:
             torch.cuda.current_stream().wait_event(self._wdone)
             self._wdone = None
 
-    def _adapter_wgrads(self, ad, dv, z, dzp, down_in, M):
-        """dW_up = dv^T z, dW_down = dzp^T down_in, db_down = colsum(dzp)  (db_up comes from ln_bwd's dbias).
+    def _bd_target(self, ad):
+        """Where the down-projection's bias gradient accumulates (64 floats: the flat gradient or its zero-padded scratch), or None."""
+        if ad.g_bd is None or not FUSE_BD:
+            return None
+        return ad.s_bd if ad.s_bd is not None else ad.g_bd()
+
+    def _adapter_wgrads(self, ad, dv, z, dzp, down_in, M, bd_done=False):
+        """dW_up = dv^T z, dW_down = dzp^T down_in, db_down = colsum(dzp)  (db_up comes from ln_bwd's dbias; bd_done: the fused
+        backward kernel has already accumulated db_down).
         A4R_WGRAD_STREAM=1: on a side stream, to run in the tail rounds of the dgrad GEMMs that follow (nothing on the
         dgrad chain reads these results); joined before dv / dzp are reused and at the end of the backward pass."""
         if ad.virtual is None and ad.g_wu is None:
@@ -960,19 +970,19 @@ class TransRecEngine:
                 self._wstream.wait_event(ev)
                 L.gemm_tn(dv, z, ad.g_wu(), M=M)
                 L.gemm_tn(dzp, down_in, ad.g_wd(), M=M)
-                if ad.g_bd is not None and ad.s_bd is None:
+                if ad.g_bd is not None and ad.s_bd is None and not bd_done:
                     L.colsum(dzp, ad.g_bd(), M=M)
                 self._wev[1].record()
             self._wdone = self._wev[1]
             self._wev.reverse()
-            if ad.g_bd is not None and ad.s_bd is not None:
+            if ad.g_bd is not None and ad.s_bd is not None and not bd_done:
                 L.colsum(dzp, ad.s_bd, M=M)
             return
         # zero-padded (d < 64) or virtual (Compacter) matrices: into the scratch arena (cleared at the start of backward; the valid
         # corners reach the flat gradient through _flush_corners / a4r_phm_bwd at its end)
         L.gemm_tn(dv, z, ad.s_wu if ad.s_wu is not None else ad.g_wu(), M=M)
         L.gemm_tn(dzp, down_in, ad.s_wd if ad.s_wd is not None else ad.g_wd(), M=M)
-        if ad.g_bd is not None:
+        if ad.g_bd is not None and not bd_done:
             L.colsum(dzp, ad.s_bd if ad.s_bd is not None else ad.g_bd(), M=M)
 
     def _block_backward(self, blk, dx_out, key_mask, n_items, M, bufs, train, seed, dx_in, cls_rows=None):

@@ -91,7 +91,8 @@ int a4r_colsum(void* stream, const void* X, int ldx, float* out, int M, int N, i
  *             null (Compacter: A = dense output, R1 = input; Pfeiffer: A = LN(h + input), R1 = h + input): two tensors streamed.
  *             Wd [64, H], Wu [H, 64] row-major bf16; outputs zp, z [M, 64], v, y [M, H], stats [M, 2] (mean, rstd).
  *   backward: dv = LayerNorm'(dy; v, stats, gamma) [+ dres]; dzp = (dv Wu) * act'(zp); dh = dropout_mask * (dzp Wd [+ dv if
- *             inner_res]); column sums dgamma += sum dy xhat, dbeta += sum dy, dbias += sum dv (each optional, fp32 atomics).
+ *             inner_res]); column sums dgamma += sum dy xhat, dbeta += sum dy, dbias += sum dv, dbd [64] += sum dzp (the
+ *             down-projection's bias gradient, from the fp32 values before their bf16 store) -- each optional, fp32 atomics.
  *             WuT [64, H] = Wu^T, WdT [H, 64] = Wd^T; the dropout mask is the dense output's (index row * H + col).
  * Returns A4R_EINVAL for anything else: the caller then uses the three-launch form (a4r_gemm_nt x 2 + a4r_ln_fwd / a4r_ln_bwd).
  * HBM bytes per launch: (4 H + 128) * 2 * M against ~7 H * 2 * M for the three launches. */
@@ -102,7 +103,7 @@ int a4r_adapter_ln_fwd(void* stream, const void* A, int lda, const void* R1, int
 int a4r_adapter_ln_bwd(void* stream, const void* dy, int lddy, const void* v, int ldv, const float* stats, const float* gamma,
                        const void* dres, int lddres, const void* zp, int act, const void* WuT, const void* WdT, int inner_res,
                        void* dv, int lddv, void* dzp, void* dh, int lddh, float* dgamma, float* dbeta, float* dbias,
-                       int M, int H, int d, int dtype, float drop_p, uint32_t drop_site, uint64_t drop_seed);
+                       int M, int H, int d, int dtype, float drop_p, uint32_t drop_site, uint64_t drop_seed, float* dbd);
 
 /* Short-sequence self-attention, one wave per (item, head), S <= 32, dh in {32, 64}.
  * BERT layer: HF BertSelfAttention (called from model/encoders.py:53); SASRec: SelfAttention

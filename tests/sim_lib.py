@@ -111,7 +111,7 @@ def adapter_ln_fwd(A, R1, R2, Wd, bd, Wu, bu, gamma, beta, eps, act, zp, z, v, y
 
 
 def adapter_ln_bwd(dy, v, stats, gamma, dres, zp, act, WuT, WdT, inner_res, dv, dzp, dh, dgamma=None, dbeta=None, dbias=None, M=None,
-                   drop_p=0.0, drop_site=0, drop_seed=0):
+                   drop_p=0.0, drop_site=0, drop_seed=0, dbd=None):
     """a4r_adapter_ln_bwd = ln_bwd | (dv Wu) * act'(zp) | dzp Wd (+ dv), with the kernel's bf16 storage points."""
     assert drop_p == 0.0
     M = dy.shape[0] if M is None else M
@@ -119,6 +119,8 @@ def adapter_ln_bwd(dy, v, stats, gamma, dres, zp, act, WuT, WdT, inner_res, dv, 
     dq = dv[:M].float()
     dz = (dq @ WuT.float().t()) * _dact(zp[:M].float(), act)
     dzp[:M] = dz.to(dzp.dtype)
+    if dbd is not None:
+        dbd += dz.sum(0)                 # (the kernel sums the fp32 values, before their bf16 store)
     o = dzp[:M].float() @ WdT.float().t()
     if inner_res:
         o = o + dq

@@ -752,9 +752,13 @@ def test_adapter_ln_bwd(H, act, inner, sums, drop):
     vec = lambda: torch.zeros(H, device=dev())
     dv, dzp, dh = mk(H), mk(dp), mk(H)
     dg, db, dbi = (vec() if 'g' in sums else None), (vec() if 'g' in sums else None), (vec() if 'b' in sums else None)
+    dbd = torch.zeros(dp, device=dev()) if 'b' in sums else None
     L.adapter_ln_bwd(dy, v, stats, gamma, None, zp, act, WuT, WdT, inner, dv, dzp, dh, dgamma=dg, dbeta=db, dbias=dbi, M=M,
-                     drop_p=drop, drop_site=9, drop_seed=4242)
+                     drop_p=drop, drop_site=9, drop_seed=4242, dbd=dbd)
     assert float(dv[M:].abs().max()) == 0 and float(dh[M:].abs().max()) == 0        # rows >= M untouched
+    if dbd is not None:                      # the down-projection's bias gradient = column sums of dzp
+        ref_bd = dzp[:M].float().sum(0)
+        close(dbd, ref_bd, torch.float32, 'dbd vs colsum(dzp)', atol32=2e-2 * max(1.0, float(ref_bd.abs().max())), rtol32=1e-2)
     # the three launches
     dv2, dzp2, dh2 = mk(H), mk(dp), mk(H)
     dg2, db2, dbi2 = (vec() if 'g' in sums else None), (vec() if 'g' in sums else None), (vec() if 'b' in sums else None)
