@@ -52,6 +52,7 @@ struct AdFwdArgs {
     const bf16_t* Wd; const bf16_t* Wu; const float* bd; const float* bu; const float* gamma; const float* beta;
     float eps; int act;
     bf16_t* zp; bf16_t* z; bf16_t* v; bf16_t* y; int ldv, ldy; float* stats; int M;
+    unsigned char* y8; int ld8; float* ys;      // optional: the LayerNorm output as OCP e4m3 + per-row scale (the next GEMM's fp8 A operand)
 };
 
 // sum of the NW partial [16][64] tiles for EPT consecutive bottleneck columns of one row (thread t: element t * EPT)
@@ -85,6 +86,7 @@ __global__ void __launch_bounds__(NW * 64) adapter_ln_fwd_kernel(const AdFwdArgs
     __shared__ __attribute__((aligned(16))) float zpart[NW][16][ZLD];
     __shared__ __attribute__((aligned(16))) char zbf[16 * 128];
     __shared__ float red[NW][16][2];
+    __shared__ float red8[NW][16];
     __shared__ __attribute__((aligned(16))) float par[3][H];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -210,16 +212,38 @@ __global__ void __launch_bounds__(NW * 64) adapter_ln_fwd_kernel(const AdFwdArgs
         for (int w = 0; w < NW; ++w) { const float d = red[w][fr][0] - mean; m2 += red[w][fr][1] + (float)CW * d * d; }
         const float rstd = rsqrtf(m2 * (1.f / H) + p.eps);
         if (wave == 0 && kg == 0) { p.stats[2 * row] = mean; p.stats[2 * row + 1] = rstd; }
+        float yv[KS][8];
+        float am = 0.f;
 #pragma unroll
         for (int s = 0; s < KS; ++s) {
-            float g8[8], b8[8], y8[8];
+            float g8[8], b8[8];
             *reinterpret_cast<float4*>(g8) = *reinterpret_cast<const float4*>(&par[1][cl + s * 32]);
             *reinterpret_cast<float4*>(g8 + 4) = *reinterpret_cast<const float4*>(&par[1][cl + s * 32 + 4]);
             *reinterpret_cast<float4*>(b8) = *reinterpret_cast<const float4*>(&par[2][cl + s * 32]);
             *reinterpret_cast<float4*>(b8 + 4) = *reinterpret_cast<const float4*>(&par[2][cl + s * 32 + 4]);
 #pragma unroll
-            for (int j = 0; j < 8; ++j) y8[j] = (vv[s][j] - mean) * rstd * g8[j] + b8[j];
-            *reinterpret_cast<uint4*>(p.y + row * p.ldy + cl + s * 32) = Elem<bf16_t>::pack(y8);
+            for (int j = 0; j < 8; ++j) { yv[s][j] = (vv[s][j] - mean) * rstd * g8[j] + b8[j]; am = fmaxf(am, fabsf(yv[s][j])); }
+            if (p.y) *reinterpret_cast<uint4*>(p.y + row * p.ldy + cl + s * 32) = Elem<bf16_t>::pack(yv[s]);
+        }
+        if (p.y8) {      // e4m3 row = y * 448 / max|y| from the fp32 values (one rounding; the same arithmetic as a4r_ln_fwd_fp8), scale = max|y| / 448
+            am = fmaxf(am, __shfl_xor(am, 16, 64));
+            am = fmaxf(am, __shfl_xor(am, 32, 64));
+            if (kg == 0) red8[wave][fr] = am;
+            A4R_LDS_BARRIER();
+            am = 0.f;
+#pragma unroll
+            for (int w = 0; w < NW; ++w) am = fmaxf(am, red8[w][fr]);
+            const float inv = am > 0.f ? __fdiv_rn(448.f, am) : 0.f;
+            if (wave == 0 && kg == 0) p.ys[row] = am > 0.f ? __fdiv_rn(am, 448.f) : 1.f;
+#pragma unroll
+            for (int s = 0; s < KS; ++s) {
+                int lo = 0, hi = 0;
+                lo = __builtin_amdgcn_cvt_pk_fp8_f32(yv[s][0] * inv, yv[s][1] * inv, lo, false);
+                lo = __builtin_amdgcn_cvt_pk_fp8_f32(yv[s][2] * inv, yv[s][3] * inv, lo, true);
+                hi = __builtin_amdgcn_cvt_pk_fp8_f32(yv[s][4] * inv, yv[s][5] * inv, hi, false);
+                hi = __builtin_amdgcn_cvt_pk_fp8_f32(yv[s][6] * inv, yv[s][7] * inv, hi, true);
+                *reinterpret_cast<uint2*>(p.y8 + row * p.ld8 + cl + s * 32) = make_uint2((unsigned)lo, (unsigned)hi);
+            }
         }
 #pragma unroll
         for (int s = 0; s < KS; ++s) { a_cur[s] = a_nxt[s]; o_cur[s] = o_nxt[s]; }
@@ -233,7 +257,7 @@ struct AdBwdArgs {
     const bf16_t* WuT; const bf16_t* WdT; int inner_res;
     bf16_t* dv; bf16_t* dzp; bf16_t* dh; int lddv, lddh;
     float* dgamma; float* dbeta; float* dbias; float* dbd;
-    int M;
+    int M, bias_total;
     uint64_t seed; uint32_t site, thr16; float keep_scale;
 };
 
@@ -346,13 +370,19 @@ __global__ void __launch_bounds__(NW * 64) adapter_ln_bwd_kernel(const AdBwdArgs
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 d8[j] = rstd * (g[s][j] - c1 - xh[s][j] * c2);
-                if constexpr (WDB) sv[s][j] += d8[j];
+                if constexpr (WDB) { if (!p.bias_total) sv[s][j] += d8[j]; }
             }
             if (p.dres) {
                 float r8[8];
                 Elem<bf16_t>::unpack(*reinterpret_cast<const uint4*>(p.dres + row * p.lddres + cl + s * 32), r8);
 #pragma unroll
                 for (int j = 0; j < 8; ++j) d8[j] += r8[j];
+            }
+            if constexpr (WDB) {             // pre-LN towers (ViT): the bias sits in the residual stream, its gradient is the TOTAL dv
+                if (p.bias_total) {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) sv[s][j] += d8[j];
+                }
             }
             dvp[s] = Elem<bf16_t>::pack(d8);
             *reinterpret_cast<uint4*>(p.dv + row * p.lddv + cl + s * 32) = dvp[s];
@@ -476,10 +506,12 @@ int a4r_cu_count();       // a4r_gemm256.hip
 extern "C" int a4r_adapter_ln_fwd(void* stream, const void* A, int lda, const void* R1, int ldr1, const void* R2, int ldr2,
                                   const void* Wd, const float* bd, const void* Wu, const float* bu,
                                   const float* gamma, const float* beta, float eps, int act,
-                                  void* zp, void* z, void* v, int ldv, void* y, int ldy, float* stats, int M, int H, int d, int dtype) {
-    if (!A || !R1 || !Wd || !bd || !Wu || !bu || !gamma || !beta || !zp || !z || !v || !y || !stats) return A4R_EINVAL;
+                                  void* zp, void* z, void* v, int ldv, void* y, int ldy, float* stats, int M, int H, int d, int dtype,
+                                  void* y8, int ld8, float* ys) {
+    if (!A || !R1 || !Wd || !bd || !Wu || !bu || !gamma || !beta || !zp || !z || !v || (!y && !y8) || !stats) return A4R_EINVAL;
+    if (y8 && (!ys || ld8 % 8 || ld8 < H || (reinterpret_cast<uintptr_t>(y8) & 7u))) return A4R_EINVAL;
     if (dtype != A4R_BF16 || d != 64 || M <= 0 || M % 16) return A4R_EINVAL;
-    if (lda % 8 || ldr1 % 8 || (R2 && ldr2 % 8) || ldv % 8 || ldy % 8) return A4R_EINVAL;
+    if (lda % 8 || ldr1 % 8 || (R2 && ldr2 % 8) || ldv % 8 || (y && ldy % 8)) return A4R_EINVAL;
     if (misaligned16(A) || misaligned16(R1) || misaligned16(R2) || misaligned16(Wd) || misaligned16(Wu) || misaligned16(v) || misaligned16(y) ||
         misaligned16(zp) || misaligned16(z) || (reinterpret_cast<uintptr_t>(stats) & 7u))
         return A4R_EINVAL;
@@ -494,6 +526,7 @@ extern "C" int a4r_adapter_ln_fwd(void* stream, const void* A, int lda, const vo
     a.gamma = gamma; a.beta = beta; a.eps = eps; a.act = act;
     a.zp = reinterpret_cast<bf16_t*>(zp); a.z = reinterpret_cast<bf16_t*>(z); a.v = reinterpret_cast<bf16_t*>(v); a.y = reinterpret_cast<bf16_t*>(y);
     a.ldv = ldv; a.ldy = ldy; a.stats = stats; a.M = M;
+    a.y8 = reinterpret_cast<unsigned char*>(y8); a.ld8 = ld8; a.ys = ys;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     const int ntiles = M / 16, ncu = a4r_cu_count();
     const int grid = ntiles < ncu ? ntiles : ncu;
@@ -510,7 +543,7 @@ extern "C" int a4r_adapter_ln_fwd(void* stream, const void* A, int lda, const vo
 extern "C" int a4r_adapter_ln_bwd(void* stream, const void* dy, int lddy, const void* v, int ldv, const float* stats, const float* gamma,
                                   const void* dres, int lddres, const void* zp, int act, const void* WuT, const void* WdT, int inner_res,
                                   void* dv, int lddv, void* dzp, void* dh, int lddh, float* dgamma, float* dbeta, float* dbias,
-                                  int M, int H, int d, int dtype, float drop_p, uint32_t drop_site, uint64_t drop_seed, float* dbd) {
+                                  int M, int H, int d, int dtype, float drop_p, uint32_t drop_site, uint64_t drop_seed, float* dbd, int flags) {
     if (!dy || !v || !stats || !gamma || !zp || !WuT || !WdT || !dv || !dzp || !dh) return A4R_EINVAL;
     if (dtype != A4R_BF16 || d != 64 || M <= 0 || M % 16) return A4R_EINVAL;
     if (lddy % 8 || ldv % 8 || (dres && lddres % 8) || lddv % 8 || lddh % 8) return A4R_EINVAL;
@@ -523,7 +556,7 @@ extern "C" int a4r_adapter_ln_bwd(void* stream, const void* dy, int lddy, const 
     a.zp = reinterpret_cast<const bf16_t*>(zp); a.act = act;
     a.WuT = reinterpret_cast<const bf16_t*>(WuT); a.WdT = reinterpret_cast<const bf16_t*>(WdT); a.inner_res = inner_res;
     a.dv = reinterpret_cast<bf16_t*>(dv); a.dzp = reinterpret_cast<bf16_t*>(dzp); a.dh = reinterpret_cast<bf16_t*>(dh);
-    a.lddv = lddv; a.lddh = lddh; a.dgamma = dgamma; a.dbeta = dbeta; a.dbias = dbias; a.dbd = dbd; a.M = M;
+    a.lddv = lddv; a.lddh = lddh; a.dgamma = dgamma; a.dbeta = dbeta; a.dbias = dbias; a.dbd = dbd; a.M = M; a.bias_total = flags & 1;
     a.seed = drop_seed; a.site = drop_site; a.thr16 = a4r_thr16(drop_p); a.keep_scale = a4r_keep_scale(drop_p);
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     const int ntiles = M / 16, ncu = a4r_cu_count();

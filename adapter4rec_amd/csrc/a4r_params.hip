@@ -63,36 +63,36 @@ __global__ void __launch_bounds__(256) phm_bwd_kernel(const float* __restrict__ 
     const float* wr = params + d.wr_off;
     const float* G = d.G;
     const int n_rule = n * n * n, n_wl = n * ip, n_wr = n * oq;
-    for (int w = threadIdx.x; w < n_rule + n_wl + n_wr; w += 256) {
+    // ONE WAVE per output, its lanes over the reduction index (gridDim.y workgroups share a PHMLinear's outputs).  One lane per
+    // output left the 64 + 64 long reductions (3072 strided terms each) to 128 lanes of the whole chip: 425 us per step on the
+    // ViT-MAE + Compacter workload.
+    const int lane = threadIdx.x & 63, wave = blockIdx.y * 4 + (threadIdx.x >> 6), nwave = gridDim.y * 4;
+    for (int w = wave; w < n_rule + n_wl + n_wr; w += nwave) {
         float acc = 0.f;
-        if (w < n_rule) {
+        if (w < n_rule) {                                   // sum over (q, p)
             const int k = w / (n * n), a = (w / n) % n, b = w % n;
-            for (int q = 0; q < oq; ++q) {
-                const float* g = G + (size_t)(b * oq + q) * d.ldg + a * ip;
-                float t = 0.f;
-                for (int p = 0; p < ip; ++p) t += g[p] * wl[k * ip + p];
-                acc += t * wr[k * oq + q];
+            for (int t = lane; t < oq * ip; t += 64) {
+                const int q = t / ip, p = t % ip;
+                acc += G[(size_t)(b * oq + q) * d.ldg + a * ip + p] * wl[k * ip + p] * wr[k * oq + q];
             }
-            atomicAdd(grads + d.rule_off + w, acc);
-        } else if (w < n_rule + n_wl) {
+            acc = wave_sum(acc);
+            if (lane == 0) atomicAdd(grads + d.rule_off + w, acc);
+        } else if (w < n_rule + n_wl) {                     // sum over (a, b, q)
             const int k = (w - n_rule) / ip, p = (w - n_rule) % ip;
-            for (int a = 0; a < n; ++a)
-                for (int b = 0; b < n; ++b) {
-                    float t = 0.f;
-                    for (int q = 0; q < oq; ++q) t += G[(size_t)(b * oq + q) * d.ldg + a * ip + p] * wr[k * oq + q];
-                    acc += t * rule[(k * n + a) * n + b];
-                }
-            atomicAdd(grads + d.wl_off + (w - n_rule), acc);
-        } else {
+            for (int t = lane; t < n * n * oq; t += 64) {
+                const int a = t / (n * oq), b = (t / oq) % n, q = t % oq;
+                acc += G[(size_t)(b * oq + q) * d.ldg + a * ip + p] * wr[k * oq + q] * rule[(k * n + a) * n + b];
+            }
+            acc = wave_sum(acc);
+            if (lane == 0) atomicAdd(grads + d.wl_off + (w - n_rule), acc);
+        } else {                                            // sum over (a, b, p)
             const int k = (w - n_rule - n_wl) / oq, q = (w - n_rule - n_wl) % oq;
-            for (int a = 0; a < n; ++a)
-                for (int b = 0; b < n; ++b) {
-                    const float* g = G + (size_t)(b * oq + q) * d.ldg + a * ip;
-                    float t = 0.f;
-                    for (int p = 0; p < ip; ++p) t += g[p] * wl[k * ip + p];
-                    acc += t * rule[(k * n + a) * n + b];
-                }
-            atomicAdd(grads + d.wr_off + (w - n_rule - n_wl), acc);
+            for (int t = lane; t < n * n * ip; t += 64) {
+                const int a = t / (n * ip), b = (t / ip) % n, p = t % ip;
+                acc += G[(size_t)(b * oq + q) * d.ldg + a * ip + p] * wl[k * ip + p] * rule[(k * n + a) * n + b];
+            }
+            acc = wave_sum(acc);
+            if (lane == 0) atomicAdd(grads + d.wr_off + (w - n_rule - n_wl), acc);
         }
     }
 }
@@ -134,7 +134,7 @@ extern "C" int a4r_phm_build(void* stream, const float* params, const a4r_phm_de
 
 extern "C" int a4r_phm_bwd(void* stream, const float* params, const a4r_phm_desc_t* desc_dev, int n_desc, float* grads) {
     if (!params || !desc_dev || n_desc <= 0 || !grads) return A4R_EINVAL;
-    hipLaunchKernelGGL(phm_bwd_kernel, dim3(n_desc), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), params,
+    hipLaunchKernelGGL(phm_bwd_kernel, dim3(n_desc, 16), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), params,
                        reinterpret_cast<const PhmDesc*>(desc_dev), grads);
     return a4r_launch_status();
 }

@@ -192,11 +192,29 @@ class ViTRecEngine(TransRecEngine):
         else:
             L.gemm_nt(z, ad.wu, out, bias=ad.bu, R1=h, R2=resid, M=M)
 
-    def _vit_block_forward(self, blk, x, n_items, M, bufs, x_out, cls_rows=None):
+    def _vit_fuse(self, blk, ad, t, bwd=False):
+        """The one-launch adapter + residual + LayerNorm kernels (a4r_adapter_fused.hip) serve the pre-LN tower too: v = the residual
+        stream after the sub-layer, y = the NEXT LayerNorm's output (LN_after for the attention sub-layer, the next layer's LN_before
+        for the FFN sub-layer).  Serial placement, bf16, bottleneck 64."""
+        if ad is None or getattr(ad, 'parallel', False):
+            return False
+        return (self._fuse_bwd if bwd else self._fuse)(blk, ad, t)
+
+    def _vit_block_forward(self, blk, x, n_items, M, bufs, x_out, cls_rows=None, n1_done=False, nxt=None):
         """cls_rows = Ip: after attention only token 0 of every image (all the head reads, encoders.py:22,32) is carried on:
-        x_out is then [Ip, H].  Results-neutral: the other rows of the last layer's output are never consumed."""
+        x_out is then [Ip, H].  Results-neutral: the other rows of the last layer's output are never consumed.
+        n1_done: the previous layer's fused FFN-adapter kernel already wrote this layer's LN_before output and statistics.
+        nxt = (next block, its buffers): this layer's FFN adapter is fused with the next layer's LN_before.  -> True when it was."""
         T, H = blk.T, blk.H
-        if self.fp8 and blk.wqkv8 is not None:      # LN_before emits the row as e4m3 + scale: the qkv GEMM runs on fp8 operands
+        fp8_qkv = self.fp8 and blk.wqkv8 is not None
+        if n1_done:
+            n1 = bufs['n1'] if 'n1' in bufs else self._buf('n1', M, H, T)
+            if fp8_qkv:                                 # (the fused kernel of the layer below wrote the e4m3 row and its scale)
+                n1q, n1s = self._buf('n1q', M, H, torch.uint8), self._buf('n1s', M, 1, torch.float32)
+                L.gemm_nt(n1q, blk.wqkv8, bufs['qkv'], bias=blk.bqkv, M=M, scale_a=n1s, scale_b=blk.wqkv8s)
+            else:
+                L.gemm_nt(n1, blk.wqkv, bufs['qkv'], bias=blk.bqkv, M=M)
+        elif fp8_qkv:      # LN_before emits the row as e4m3 + scale: the qkv GEMM runs on fp8 operands
             n1q, n1s = self._buf('n1q', M, H, torch.uint8), self._buf('n1s', M, 1, torch.float32)
             L.ln_fwd(x, blk.lnA.gamma, blk.lnA.beta, blk.lnA.eps, bufs.get('n1'), bufs['sta'], M=M, y8=n1q, ys=n1s)
             L.gemm_nt(n1q, blk.wqkv8, bufs['qkv'], bias=blk.bqkv, M=M, scale_a=n1s, scale_b=blk.wqkv8s)
@@ -213,17 +231,50 @@ class ViTRecEngine(TransRecEngine):
             ctx, x, M = ctx_c, x_c, cls_rows
         if 'ctx_s' in bufs:
             L.gather_rows(ctx, bufs['ctx_s'], M, 1)
-        self._vit_sub_forward(blk.ad1, ctx, blk.wo, blk.bo, x, bufs, '1', M, bufs['x1'])
-        u = bufs['u_s'] if 'u_s' in bufs else self._buf('u', M, blk.F, T)
-        if self.fp8 and blk.wi8 is not None and M % 256 == 0:
-            n2q, n2s = self._buf('n2q', M, H, torch.uint8), self._buf('n2s', M, 1, torch.float32)
-            L.ln_fwd(bufs['x1'], blk.lnB.gamma, blk.lnB.beta, blk.lnB.eps, bufs.get('n2_s'), bufs['stb'], M=M, y8=n2q, ys=n2s)
-            L.gemm_nt(n2q, blk.wi8, u, bias=blk.bi, C2=bufs['upre'], act=L.ACT_GELU, c2_deriv='q8' if self._q8(blk) else True, M=M, scale_a=n2s, scale_b=blk.wi8s)
+        fp8_fc1 = self.fp8 and blk.wi8 is not None and M % 256 == 0
+        n2 = bufs['n2_s'] if 'n2_s' in bufs else self._buf('n2', M, H, T)
+        if self._vit_fuse(blk, blk.ad1, ctx):       # dense | adapter + residual + LN_after in one launch
+            ad = blk.ad1
+            h = bufs['h1']
+            L.gemm_nt(ctx, blk.wo, h, bias=blk.bo, M=M)
+            comp = ad.kind == 'compacter'
+            n2q = n2s = None
+            if fp8_fc1:                                 # LN_after leaves the kernel as e4m3 + scale (bf16 copy only if something trains on it)
+                n2q, n2s = self._buf('n2q', M, H, torch.uint8), self._buf('n2s', M, 1, torch.float32)
+            L.adapter_ln_fwd(h, x if comp else h, None if comp else x, ad.wd, ad.bd, ad.wu, ad.bu, blk.lnB.gamma, blk.lnB.beta, blk.lnB.eps,
+                             ad.act, bufs['zp1'], bufs['z1'], bufs['x1'], n2 if (not fp8_fc1 or 'n2_s' in bufs) else None, bufs['stb'], M=M,
+                             y8=n2q, ys=n2s)
+            n2_done = True
         else:
-            n2 = bufs['n2_s'] if 'n2_s' in bufs else self._buf('n2', M, H, T)
-            L.ln_fwd(bufs['x1'], blk.lnB.gamma, blk.lnB.beta, blk.lnB.eps, n2, bufs['stb'], M=M)
-            L.gemm_nt(n2, blk.wi, u, bias=blk.bi, C2=bufs['upre'], act=L.ACT_GELU, c2_deriv='q8' if self._q8(blk) else True, M=M)
+            self._vit_sub_forward(blk.ad1, ctx, blk.wo, blk.bo, x, bufs, '1', M, bufs['x1'])
+            n2_done = False
+        u = bufs['u_s'] if 'u_s' in bufs else self._buf('u', M, blk.F, T)
+        c2d = 'q8' if self._q8(blk) else True
+        if fp8_fc1:
+            n2q, n2s = self._buf('n2q', M, H, torch.uint8), self._buf('n2s', M, 1, torch.float32)
+            if not n2_done:
+                L.ln_fwd(bufs['x1'], blk.lnB.gamma, blk.lnB.beta, blk.lnB.eps, bufs.get('n2_s'), bufs['stb'], M=M, y8=n2q, ys=n2s)
+            L.gemm_nt(n2q, blk.wi8, u, bias=blk.bi, C2=bufs['upre'], act=L.ACT_GELU, c2_deriv=c2d, M=M, scale_a=n2s, scale_b=blk.wi8s)
+        else:
+            if not n2_done:
+                L.ln_fwd(bufs['x1'], blk.lnB.gamma, blk.lnB.beta, blk.lnB.eps, n2, bufs['stb'], M=M)
+            L.gemm_nt(n2, blk.wi, u, bias=blk.bi, C2=bufs['upre'], act=L.ACT_GELU, c2_deriv=c2d, M=M)
+        if nxt is not None and cls_rows is None and self._vit_fuse(blk, blk.ad2, bufs['x1']):
+            nb_, nbufs = nxt                            # dense | adapter + residual + the NEXT layer's LN_before
+            ad = blk.ad2
+            h = bufs['h2']
+            L.gemm_nt(u, blk.wo2, h, bias=blk.bo2, M=M)
+            comp = ad.kind == 'compacter'
+            n1n = nbufs['n1'] if 'n1' in nbufs else self._buf('n1', M, H, T)
+            n1q = n1s = None
+            if self.fp8 and nb_.wqkv8 is not None:
+                n1q, n1s = self._buf('n1q', M, H, torch.uint8), self._buf('n1s', M, 1, torch.float32)
+            L.adapter_ln_fwd(h, bufs['x1'] if comp else h, None if comp else bufs['x1'], ad.wd, ad.bd, ad.wu, ad.bu,
+                             nb_.lnA.gamma, nb_.lnA.beta, nb_.lnA.eps, ad.act, bufs['zp2'], bufs['z2'], x_out,
+                             n1n if (n1q is None or 'n1' in nbufs) else None, nbufs['sta'], M=M, y8=n1q, ys=n1s)
+            return True
         self._vit_sub_forward(blk.ad2, u, blk.wo2, blk.bo2, bufs['x1'], bufs, '2', M, x_out)
+        return False
 
     def _vit_sub_backward(self, blk, ad, dy, bufs, k, M, x_in=None):
         """dy: gradient of the sub-layer output before the residual add -> (gradient of the dense output, gradient that goes to
@@ -250,13 +301,19 @@ class ViTRecEngine(TransRecEngine):
             L.colsum(dy, ad.g_bu(), M=M)
         return dh, dy
 
-    def _vit_block_backward(self, blk, dx_out, n_items, M, bufs, dx_in, cls_rows=None):
+    def _vit_block_backward(self, blk, dx_out, n_items, M, bufs, dx_in, cls_rows=None, pre2=None, prev=None):
+        """pre2 = (d_o, dres2): the FFN adapter's backward was already done by the NEXT layer (fused with its LN_before backward).
+        prev = (previous block, its buffers): this layer's LN_before backward runs fused with the previous layer's FFN adapter
+        backward -> returns that layer's pre2 (else None)."""
         T, H, F = blk.T, blk.H, blk.F
         gg = lambda f: f() if f is not None else None
         M_full = M
         if cls_rows is not None:
             M = cls_rows
-        d_o, dres2 = self._vit_sub_backward(blk, blk.ad2, dx_out, bufs, '2', M, x_in=bufs['x1'])
+        if pre2 is not None:
+            d_o, dres2 = pre2
+        else:
+            d_o, dres2 = self._vit_sub_backward(blk, blk.ad2, dx_out, bufs, '2', M, x_in=bufs['x1'])
         self._dense_wgrad(blk.d_o2, d_o, bufs.get('u_s'), M)
         du = self._buf('du', M, F, T)
         L.gemm_nt(d_o, blk.wo2T, du, Pre=bufs['upre'], dact=L.DACT_MUL_Q8 if self._q8(blk) else L.DACT_MUL, M=M)
@@ -264,14 +321,24 @@ class ViTRecEngine(TransRecEngine):
         dn2 = self._buf('dn', M, H, T)
         L.gemm_nt(du, blk.wiT, dn2, M=M)
         dx1 = self._buf('dx1', M, H, T)
-        L.ln_bwd(dn2, bufs['x1'], bufs['stb'], blk.lnB.gamma, dx1, M=M, dgamma=gg(blk.lnB.g_gamma), dbeta=gg(blk.lnB.g_beta), dres=dres2)
-        da, dres1 = self._vit_sub_backward(blk, blk.ad1, dx1, bufs, '1', M)
-        assert dres1 is dx1              # the parallel form exists at layer.output only (run_adapter.py:448-453)
+        if self._vit_fuse(blk, blk.ad1, dn2, bwd=True):
+            # ONE launch: LN_after backward (+ the residual-branch gradient), dzp = (dx1 Wu) * act'(zp), da = dzp Wd [+ dx1]
+            ad = blk.ad1
+            dzp = self._buf('dzp', M, ad.dp, T)
+            da = self._buf('dh1', M, H, T)
+            bd = self._bd_target(ad)
+            L.adapter_ln_bwd(dn2, bufs['x1'], bufs['stb'], blk.lnB.gamma, dres2, bufs['zp1'], ad.act, ad.wuT, ad.wdT, ad.kind != 'compacter',
+                             dx1, dzp, da, dgamma=gg(blk.lnB.g_gamma), dbeta=gg(blk.lnB.g_beta), dbias=gg(ad.g_bu), M=M, dbd=bd, bias_total=True)
+            self._adapter_wgrads(ad, dx1, bufs['z1'], dzp, bufs['h1'], M, bd_done=bd is not None)
+        else:
+            L.ln_bwd(dn2, bufs['x1'], bufs['stb'], blk.lnB.gamma, dx1, M=M, dgamma=gg(blk.lnB.g_gamma), dbeta=gg(blk.lnB.g_beta), dres=dres2)
+            da, dres1 = self._vit_sub_backward(blk, blk.ad1, dx1, bufs, '1', M)
+            assert dres1 is dx1              # the parallel form exists at layer.output only (run_adapter.py:448-453)
         self._dense_wgrad(blk.d_o, da, bufs.get('ctx_s'), M)
         ln_a = blk.lnA.g_gamma is not None           # --finetune_layernorm: layer 0 still owes its LN_before gradients
         qkv_train = any(d is not None and d.trainable for d in blk.qkv)
         if dx_in is None and not blk.lora and not ln_a and not qkv_train:
-            return
+            return None
         dctx = self._buf('dctx_c' if cls_rows is not None else 'dctx', M, H, T)
         L.gemm_nt(da, blk.woT, dctx, M=M)
         if cls_rows is not None:             # back to token rows: the gradients live on the CLS rows only
@@ -294,7 +361,20 @@ class ViTRecEngine(TransRecEngine):
                 dx_in = self._buf('dx_unused', M, H, T)
             dn1 = self._buf('dn', M, H, T)
             L.gemm_nt(dqkv, blk.wqkvT, dn1, M=M)
+            if prev is not None and self._vit_fuse(prev[0], prev[0].ad2, dn1, bwd=True):
+                # this layer's LN_before backward fused with the PREVIOUS layer's FFN-adapter backward (forward fused them too)
+                pb, pbufs = prev
+                ad = pb.ad2
+                dzp = self._buf('dzp2', M, ad.dp, T)
+                d_o_prev = self._buf('dh2', M, H, T)
+                bd = self._bd_target(ad)
+                L.adapter_ln_bwd(dn1, bufs['x0'], bufs['sta'], blk.lnA.gamma, dx1, pbufs['zp2'], ad.act, ad.wuT, ad.wdT, ad.kind != 'compacter',
+                                 dx_in, dzp, d_o_prev, dgamma=gg(blk.lnA.g_gamma), dbeta=gg(blk.lnA.g_beta), dbias=gg(ad.g_bu), M=M, dbd=bd,
+                                 bias_total=True)
+                self._adapter_wgrads(ad, dx_in, pbufs['z2'], dzp, pbufs['h2'], M, bd_done=bd is not None)
+                return d_o_prev, dx_in
             L.ln_bwd(dn1, bufs['x0'], bufs['sta'], blk.lnA.gamma, dx_in, M=M, dgamma=gg(blk.lnA.g_gamma), dbeta=gg(blk.lnA.g_beta), dres=dx1)
+        return None
 
     # ------------------------------------------------------------------ item tower
     def _keep_indices(self, n_items, noise):
@@ -340,15 +420,21 @@ class ViTRecEngine(TransRecEngine):
         nb = len(self.bert_blocks)
         Ip = pad_to(n_items, 128)
         cls = self._buf('cls', Ip, H, self.T)
+        n1_done = False
+        self._fused_next = {}                      # layer -> its FFN adapter ran fused with the next layer's LN_before (backward mirrors it)
         for i, blk in enumerate(self.bert_blocks):
             cmode = self.cls_only and i + 1 == nb
             if saved is not None:                 # training: layer i writes straight into layer i+1's saved input
                 out = saved[i + 1]['x0'] if i + 1 < nb else (cls if cmode else self._buf('x_last', M, H, self.T))
-                self._vit_block_forward(blk, x, n_items, M, saved[i], out, cls_rows=Ip if cmode else None)
+                nxt = (self.bert_blocks[i + 1], saved[i + 1]) if i + 1 < nb else None
+                n1_done = self._vit_block_forward(blk, x, n_items, M, saved[i], out, cls_rows=Ip if cmode else None, n1_done=n1_done, nxt=nxt)
+                self._fused_next[i] = n1_done
                 x = out
             else:                                 # inference: one transient buffer set, two ping-pong activations
                 bufs = self._block_bufs('vit.shared', blk, M, True, Mc=Ip if cmode else None)
-                self._vit_block_forward(blk, x, n_items, M, bufs, cls if cmode else other, cls_rows=Ip if cmode else None)
+                nxt = (self.bert_blocks[i + 1], bufs) if i + 1 < nb else None
+                n1_done = self._vit_block_forward(blk, x, n_items, M, bufs, cls if cmode else other, cls_rows=Ip if cmode else None,
+                                                  n1_done=n1_done, nxt=nxt)
                 x, other = (cls, other) if cmode else (other, x)
             if (i + 1) in self.bert_klist and i + 1 < nb:
                 L.gather_rows(x, self._buf(f'khs{i + 1}', M, H, self.T), M, 1)      # hidden_states[i + 1], read by a K-Adapter below
@@ -389,16 +475,18 @@ class ViTRecEngine(TransRecEngine):
             L.scatter_rows_fill(dcls, dxb, n_items, self.S, M)
         spare = self._buf('dx_b', M, H, self.T)
         last = len(self.bert_blocks) - 1
+        pre2 = None
         for i in range(last, -1, -1):
             blk = self.bert_blocks[i]
             if i < last:
                 self._exchange(i + 1)              # layer i + 1 is finished: its gradients go out while the layers below run
             if (i + 1) in d_hs:
                 dxb.add_(d_hs[i + 1])              # hidden_states[i + 1] also fed a K-Adapter
+            prev = (self.bert_blocks[i - 1], c['saved_b'][i - 1]) if i > 0 and self._fused_next.get(i - 1) else None
             if self.cls_only and i == last:
-                self._vit_block_backward(blk, dcls, n_items, M, c['saved_b'][i], spare if blk.need_dx else None, cls_rows=Ip)
+                pre2 = self._vit_block_backward(blk, dcls, n_items, M, c['saved_b'][i], spare if blk.need_dx else None, cls_rows=Ip, prev=prev)
             else:
-                self._vit_block_backward(blk, dxb, n_items, M, c['saved_b'][i], spare if blk.need_dx else None)
+                pre2 = self._vit_block_backward(blk, dxb, n_items, M, c['saved_b'][i], spare if blk.need_dx else None, pre2=pre2, prev=prev)
             dxb, spare = spare, dxb
         if self.train_emb:                       # ViTEmbeddings backward: token 0 -> cls + pos[0]; token 1 + j -> patch projection + pos[1 + j]
             S, NP = self.S, self.NP

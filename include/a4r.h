@@ -93,17 +93,22 @@ int a4r_colsum(void* stream, const void* X, int ldx, float* out, int M, int N, i
  *   backward: dv = LayerNorm'(dy; v, stats, gamma) [+ dres]; dzp = (dv Wu) * act'(zp); dh = dropout_mask * (dzp Wd [+ dv if
  *             inner_res]); column sums dgamma += sum dy xhat, dbeta += sum dy, dbias += sum dv, dbd [64] += sum dzp (the
  *             down-projection's bias gradient, from the fp32 values before their bf16 store) -- each optional, fp32 atomics.
+ *             flags bit 0: dbias sums dv AFTER dres is added (pre-LN towers -- HF ViTLayer under Downstream/CV/model/model.py:182-212:
+ *             v is the residual stream itself, dres the gradient that reaches it from the layers above; post-LN BERT: dres is not
+ *             part of the adapter's output gradient).
  *             WuT [64, H] = Wu^T, WdT [H, 64] = Wd^T; the dropout mask is the dense output's (index row * H + col).
  * Returns A4R_EINVAL for anything else: the caller then uses the three-launch form (a4r_gemm_nt x 2 + a4r_ln_fwd / a4r_ln_bwd).
  * HBM bytes per launch: (4 H + 128) * 2 * M against ~7 H * 2 * M for the three launches. */
 int a4r_adapter_ln_fwd(void* stream, const void* A, int lda, const void* R1, int ldr1, const void* R2, int ldr2,
                        const void* Wd, const float* bd, const void* Wu, const float* bu,
                        const float* gamma, const float* beta, float eps, int act,
-                       void* zp, void* z, void* v, int ldv, void* y, int ldy, float* stats, int M, int H, int d, int dtype);
+                       void* zp, void* z, void* v, int ldv, void* y, int ldy, float* stats, int M, int H, int d, int dtype,
+                       void* y8, int ld8, float* ys);   /* y8 / ys (optional; y may then be NULL): y as OCP e4m3 + per-row scale, the
+                                                           arithmetic of a4r_ln_fwd_fp8 (the fp8 A operand of the GEMM that follows) */
 int a4r_adapter_ln_bwd(void* stream, const void* dy, int lddy, const void* v, int ldv, const float* stats, const float* gamma,
                        const void* dres, int lddres, const void* zp, int act, const void* WuT, const void* WdT, int inner_res,
                        void* dv, int lddv, void* dzp, void* dh, int lddh, float* dgamma, float* dbeta, float* dbias,
-                       int M, int H, int d, int dtype, float drop_p, uint32_t drop_site, uint64_t drop_seed, float* dbd);
+                       int M, int H, int d, int dtype, float drop_p, uint32_t drop_site, uint64_t drop_seed, float* dbd, int flags);
 
 /* Short-sequence self-attention, one wave per (item, head), S <= 32, dh in {32, 64}.
  * BERT layer: HF BertSelfAttention (called from model/encoders.py:53); SASRec: SelfAttention

@@ -90,7 +90,7 @@ def adapter_ln_ok(A, d):
     return REAL.adapter_ln_ok(A, d)
 
 
-def adapter_ln_fwd(A, R1, R2, Wd, bd, Wu, bu, gamma, beta, eps, act, zp, z, v, y, stats, M=None):
+def adapter_ln_fwd(A, R1, R2, Wd, bd, Wu, bu, gamma, beta, eps, act, zp, z, v, y, stats, M=None, y8=None, ys=None):
     """a4r_adapter_ln_fwd: zp = A Wd^T + bd; z = act(zp); v = z Wu^T + bu + R1 + R2; y = LN(v) (bf16 storage points as the kernel's)."""
     M = A.shape[0] if M is None else M
     assert A.dtype == torch.bfloat16 and Wd.shape[0] == 64 and M % 16 == 0
@@ -107,16 +107,22 @@ def adapter_ln_fwd(A, R1, R2, Wd, bd, Wu, bu, gamma, beta, eps, act, zp, z, v, y
     rstd = torch.rsqrt(((vq - mu) ** 2).mean(-1, keepdim=True) + eps)
     stats[:M, 0] = mu[:, 0]
     stats[:M, 1] = rstd[:, 0]
-    y[:M] = ((vq - mu) * rstd * gamma + beta).to(y.dtype)
+    out = (vq - mu) * rstd * gamma + beta
+    if y is not None:
+        y[:M] = out.to(y.dtype)
+    if y8 is not None:
+        _quant_rows(out, y8, ys)
 
 
 def adapter_ln_bwd(dy, v, stats, gamma, dres, zp, act, WuT, WdT, inner_res, dv, dzp, dh, dgamma=None, dbeta=None, dbias=None, M=None,
-                   drop_p=0.0, drop_site=0, drop_seed=0, dbd=None):
+                   drop_p=0.0, drop_site=0, drop_seed=0, dbd=None, bias_total=False):
     """a4r_adapter_ln_bwd = ln_bwd | (dv Wu) * act'(zp) | dzp Wd (+ dv), with the kernel's bf16 storage points."""
     assert drop_p == 0.0
     M = dy.shape[0] if M is None else M
-    ln_bwd(dy, v, stats, gamma, dv, M=M, dgamma=dgamma, dbeta=dbeta, dbias=dbias, dres=dres)
+    ln_bwd(dy, v, stats, gamma, dv, M=M, dgamma=dgamma, dbeta=dbeta, dbias=None if bias_total else dbias, dres=dres)
     dq = dv[:M].float()
+    if bias_total and dbias is not None:
+        dbias += dq.sum(0)
     dz = (dq @ WuT.float().t()) * _dact(zp[:M].float(), act)
     dzp[:M] = dz.to(dzp.dtype)
     if dbd is not None:

@@ -731,6 +731,18 @@ def test_adapter_ln_fwd(H, mode):
     close(zp, zp2[:M], t, 'zp vs 3 launches', rtol16=1e-2, atol16=1e-2)
     close(v, v2[:M], t, 'v vs 3 launches', rtol16=1e-2, atol16=2e-2)
     close(y, y2[:M], t, 'y vs 3 launches', rtol16=1e-2, atol16=3e-2)
+    # e4m3 form of y (+ per-row scale) from the same launch, with and without the bf16 copy: the a4r_ln_fwd_fp8 arithmetic
+    for keep_y in (True, False):
+        y8, ys = torch.zeros(M, H, dtype=torch.uint8, device=dev()), torch.zeros(M, device=dev())
+        yb = mk(H) if keep_y else None
+        L.adapter_ln_fwd(a, R1, R2, Wd, bd, Wu, bu, gamma, beta, 1e-12, act, mk(dp), mk(dp), mk(H), yb, torch.zeros(M, 2, device=dev()), y8=y8, ys=ys)
+        if keep_y:
+            assert torch.equal(yb, y)
+        amax = y_r.abs().amax(1)
+        close(ys, amax / 448.0, torch.float32, 'fp8 row scale', atol32=1e-4, rtol32=2e-2)
+        deq = y8.view(torch.float8_e4m3fn).float() * ys[:, None]
+        assert float((deq - y_r).abs().max() / amax.max()) < 0.07                      # e4m3: 3 mantissa bits
+        assert int(y8.view(torch.float8_e4m3fn).float().abs().max()) == 448            # every row uses the full range
 
 
 @pytest.mark.parametrize('H', [128, 256, 512, 768])
