@@ -211,6 +211,23 @@ def test_cv_host_logic_mae_compacter_fp8(simulated):
     _mae_compacter_case('cpu', 'fp8')
 
 
+def test_cv_host_logic_mae_compacter_bf16_fused(simulated):
+    """bf16 storage: the image tower runs on the fused adapter + residual + next-LayerNorm launches (engine_vit._vit_fuse), forward and
+    backward, across the layer boundary."""
+    import adapter4rec_amd.engine_vit as EV
+    calls = []
+    real_f, real_b = sim_lib.adapter_ln_fwd, sim_lib.adapter_ln_bwd
+    sim_lib.adapter_ln_fwd = lambda *a, **k: (calls.append('f'), real_f(*a, **k))[1]
+    sim_lib.adapter_ln_bwd = lambda *a, **k: (calls.append('b'), real_b(*a, **k))[1]
+    try:
+        _mae_compacter_case('cpu', 'bf16')
+    finally:
+        sim_lib.adapter_ln_fwd, sim_lib.adapter_ln_bwd = real_f, real_b
+    # 2 layers x 2 adapters: the attention adapters fuse with LN_after (2), layer 0's FFN adapter with layer 1's LN_before (1); the last
+    # layer's FFN adapter (CLS rows, final LayerNorm) keeps the three-launch form
+    assert calls.count('f') == 3 and calls.count('b') == 3, calls
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize('dtype', ['fp32', 'bf16', 'fp8'])
 def test_cv_mae_compacter_gpu(dtype):
