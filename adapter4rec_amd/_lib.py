@@ -21,7 +21,7 @@ EVAL_MAX_HISTORY = 64          # A4R_EVAL_MAX_HISTORY (include/a4r.h)
 ACT_BY_NAME = {'none': 0, 'relu': 1, 'RELU': 1, 'gelu': 2, 'GELU': 2, 'gelu_new': 3, 'leaky_relu': 4}
 
 EXPORTS = [
-    'a4r_version', 'a4r_gemm_nt', 'a4r_gemm_tn', 'a4r_colsum', 'a4r_attn_fwd', 'a4r_attn_bwd', 'a4r_embed_ln',
+    'a4r_version', 'a4r_gemm_nt', 'a4r_gemm_tn', 'a4r_gemm_tn2', 'a4r_colsum', 'a4r_attn_fwd', 'a4r_attn_bwd', 'a4r_embed_ln',
     'a4r_ln_fwd', 'a4r_ln_bwd', 'a4r_gather_rows', 'a4r_scatter_rows', 'a4r_act_bwd_f32', 'a4r_score_bce_fwd',
     'a4r_score_bce_bwd', 'a4r_emb_grad_add_inputs', 'a4r_take_inputs', 'a4r_adam_step', 'a4r_pack_matrices',
     'a4r_eval_rank', 'a4r_dropout_apply', 'a4r_gemm_variant', 'a4r_adapter_ln_fwd', 'a4r_adapter_ln_bwd', 'a4r_ln_fwd_fp8', 'a4r_quant_rows_fp8', 'a4r_lora_merge', 'a4r_phm_build', 'a4r_phm_bwd', 'a4r_unpack_add', 'a4r_memset_zero',
@@ -185,6 +185,16 @@ def gemm_tn(X, Y, Cacc, M=None):
     M = X.shape[0] if M is None else M
     _check(lib().a4r_gemm_tn(_stream(), _p(X), C.c_int(_ld(X)), _p(Y), C.c_int(_ld(Y)), _p(Cacc), C.c_int(_ld(Cacc)),
                              C.c_int(M), C.c_int(X.shape[1]), C.c_int(Y.shape[1]), C.c_int(_dt(X))), 'a4r_gemm_tn')
+
+
+def gemm_tn2(X1, Y1, C1, X2, Y2, C2, M=None):
+    """C1 += X1^T Y1 and C2 += X2^T Y2 over the same M rows, one launch (bf16; equal tile counts)."""
+    require_gpu(X1, Y1, C1, X2, Y2, C2)
+    assert C1.dtype == torch.float32 and C2.dtype == torch.float32
+    M = X1.shape[0] if M is None else M
+    _check(lib().a4r_gemm_tn2(_stream(), _p(X1), C.c_int(_ld(X1)), _p(Y1), C.c_int(_ld(Y1)), _p(C1), C.c_int(_ld(C1)), C.c_int(X1.shape[1]), C.c_int(Y1.shape[1]),
+                              _p(X2), C.c_int(_ld(X2)), _p(Y2), C.c_int(_ld(Y2)), _p(C2), C.c_int(_ld(C2)), C.c_int(X2.shape[1]), C.c_int(Y2.shape[1]),
+                              C.c_int(M), C.c_int(_dt(X1))), 'a4r_gemm_tn2')
 
 
 def colsum(X, out, M=None):

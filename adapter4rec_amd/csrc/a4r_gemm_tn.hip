@@ -116,8 +116,14 @@ A4R_DEV void tn_glds16(const void* base, uint32_t voff, uint32_t lds_dst) {
     asm volatile("s_mov_b32 m0, %2\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(base), "s"(lds_dst) : "memory");
 }
 
-__global__ void __launch_bounds__(256) gemm_tn_glds_kernel(const bf16_t* __restrict__ X, int ldx, const bf16_t* __restrict__ Y, int ldy,
-                                                           float* __restrict__ C, int ldc, int M, int ntq, int rows_per_split) {
+struct TnProb { const bf16_t* X; const bf16_t* Y; float* C; int ldx, ldy, ldc, ntq; };
+__global__ void __launch_bounds__(256) gemm_tn_glds_kernel(const TnProb pa, const TnProb pb, int M, int rows_per_split) {
+    // blockIdx.z picks one of two products of one launch (the two weight gradients of an adapter: different operands, same token range)
+    const TnProb& pr = blockIdx.z == 0 ? pa : pb;
+    const bf16_t* __restrict__ X = pr.X;
+    const bf16_t* __restrict__ Y = pr.Y;
+    float* __restrict__ C = pr.C;
+    const int ldx = pr.ldx, ldy = pr.ldy, ldc = pr.ldc, ntq = pr.ntq;
     constexpr int NST = 3, STAGE = 16384;
     __shared__ __attribute__((aligned(16))) char lds[NST * STAGE];        // [stage][X 64 tokens | Y 64 tokens][128 B]
     const int tid = threadIdx.x, lane = tid & 63;
@@ -246,15 +252,37 @@ extern "C" int a4r_gemm_tn(void* stream, const void* X, int ldx, const void* Y, 
     const int rows_per_split = ((stages + splits - 1) / splits) * 64;
     splits = (M + rows_per_split - 1) / rows_per_split;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-    if (glds)
-        hipLaunchKernelGGL(gemm_tn_glds_kernel, dim3(tiles, splits), dim3(256), 0, s, (const bf16_t*)X, ldx, (const bf16_t*)Y, ldy,
-                           C, ldc, M, ntq, rows_per_split);
+    if (glds) {
+        const TnProb pa{(const bf16_t*)X, (const bf16_t*)Y, C, ldx, ldy, ldc, ntq};
+        hipLaunchKernelGGL(gemm_tn_glds_kernel, dim3(tiles, splits, 1), dim3(256), 0, s, pa, pa, M, rows_per_split);
+    }
     else if (dtype == A4R_BF16)
         hipLaunchKernelGGL(gemm_tn_kernel<bf16_t>, dim3(tiles, splits), dim3(256), 0, s, (const bf16_t*)X, ldx, (const bf16_t*)Y, ldy,
                            C, ldc, M, ntq, rows_per_split);
     else
         hipLaunchKernelGGL(gemm_tn_kernel<float>, dim3(tiles, splits), dim3(256), 0, s, (const float*)X, ldx, (const float*)Y, ldy,
                            C, ldc, M, ntq, rows_per_split);
+    return a4r_launch_status();
+}
+
+// Two products over the same token range in one launch (an adapter's dW_up = dv^T z and dW_down = dzp^T h): the ramp-up, tail and
+// atomic flush of one overlap the streaming of the other.  Same tile count required (P1 Q1 == P2 Q2), bf16 only.
+extern "C" int a4r_gemm_tn2(void* stream, const void* X1, int ldx1, const void* Y1, int ldy1, float* C1, int ldc1, int P1, int Q1,
+                            const void* X2, int ldx2, const void* Y2, int ldy2, float* C2, int ldc2, int P2, int Q2, int M, int dtype) {
+    if (!X1 || !Y1 || !C1 || !X2 || !Y2 || !C2 || M <= 0 || M % 64 || dtype != A4R_BF16) return A4R_EINVAL;
+    if (P1 <= 0 || Q1 <= 0 || P2 <= 0 || Q2 <= 0 || P1 % 64 || Q1 % 64 || P2 % 64 || Q2 % 64 || (P1 / 64) * (Q1 / 64) != (P2 / 64) * (Q2 / 64)) return A4R_EINVAL;
+    if ((ldx1 * 2) % 16 || (ldy1 * 2) % 16 || (ldx2 * 2) % 16 || (ldy2 * 2) % 16 || ldx1 < P1 || ldy1 < Q1 || ldc1 < Q1 || ldx2 < P2 || ldy2 < Q2 || ldc2 < Q2)
+        return A4R_EINVAL;
+    if ((reinterpret_cast<uintptr_t>(X1) | reinterpret_cast<uintptr_t>(Y1) | reinterpret_cast<uintptr_t>(X2) | reinterpret_cast<uintptr_t>(Y2)) & 15u) return A4R_EINVAL;
+    const int tiles = (P1 / 64) * (Q1 / 64);
+    int splits = (384 + tiles - 1) / tiles;                 // two products: half the splits of the single-product launch each
+    const int stages = M / 64;
+    if (splits > stages) splits = stages;
+    const int rows_per_split = ((stages + splits - 1) / splits) * 64;
+    splits = (M + rows_per_split - 1) / rows_per_split;
+    const TnProb pa{(const bf16_t*)X1, (const bf16_t*)Y1, C1, ldx1, ldy1, ldc1, Q1 / 64};
+    const TnProb pb{(const bf16_t*)X2, (const bf16_t*)Y2, C2, ldx2, ldy2, ldc2, Q2 / 64};
+    hipLaunchKernelGGL(gemm_tn_glds_kernel, dim3(tiles, splits, 2), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), pa, pb, M, rows_per_split);
     return a4r_launch_status();
 }
 

@@ -78,6 +78,10 @@ int a4r_gemm_variant(int v);
  * C must be zeroed (or hold the running sum) before the call; accumulation uses fp32 atomics. */
 int a4r_gemm_tn(void* stream, const void* X, int ldx, const void* Y, int ldy, float* C, int ldc,
                 int M, int P, int Q, int dtype);
+/* Two such products over the same M rows in ONE launch (an adapter's dW_up = dv^T z and dW_down = dzp^T h; bf16;
+ * (P1 / 64) (Q1 / 64) == (P2 / 64) (Q2 / 64)). */
+int a4r_gemm_tn2(void* stream, const void* X1, int ldx1, const void* Y1, int ldy1, float* C1, int ldc1, int P1, int Q1,
+                 const void* X2, int ldx2, const void* Y2, int ldy2, float* C2, int ldc2, int P2, int Q2, int M, int dtype);
 
 /* colsum[N] (fp32, +=) = sum over rows of X[M,N]: bias gradients. N % 8 == 0. */
 int a4r_colsum(void* stream, const void* X, int ldx, float* out, int M, int N, int dtype);

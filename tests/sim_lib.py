@@ -139,6 +139,11 @@ def gemm_tn(X, Y, Cacc, M=None):
     Cacc += X[:M].float().t() @ Y[:M].float()
 
 
+def gemm_tn2(X1, Y1, C1, X2, Y2, C2, M=None):
+    gemm_tn(X1, Y1, C1, M=M)
+    gemm_tn(X2, Y2, C2, M=M)
+
+
 def colsum(X, out, M=None):
     M = X.shape[0] if M is None else M
     out += X[:M].float().sum(0)

@@ -286,6 +286,21 @@ def test_gemm_tn_glds_bf16(M, P, Q):
     assert torch.equal(outs[0], outs[1])
 
 
+def test_gemm_tn2_two_products_one_launch():
+    """a4r_gemm_tn2 = two a4r_gemm_tn products over the same rows (an adapter's dW_up [H, 64] and dW_down [64, H])."""
+    from adapter4rec_amd import _lib as L
+    t = torch.bfloat16
+    for M, H in ((1280, 768), (4096, 128), (192, 256)):
+        X1, Y1 = rnd(M, H, dtype=t, seed=51), rnd(M, 64, dtype=t, seed=52)
+        X2, Y2 = rnd(M, 64, dtype=t, seed=53), rnd(M, H, dtype=t, seed=54)
+        C1, C2 = torch.zeros(H, 64, device=dev()), torch.zeros(64, H, device=dev())
+        L.gemm_tn2(X1, Y1, C1, X2, Y2, C2)
+        close(C1, X1.float().t() @ Y1.float(), torch.float32, 'tn2 first', atol32=2e-3 * (M / 1280) ** 0.5 * 8, rtol32=2e-3)
+        close(C2, X2.float().t() @ Y2.float(), torch.float32, 'tn2 second', atol32=2e-3 * (M / 1280) ** 0.5 * 8, rtol32=2e-3)
+    with pytest.raises(RuntimeError):                                          # unequal tile counts
+        L.gemm_tn2(X1, Y1, C1, X2, rnd(192, 128, dtype=t, seed=55), torch.zeros(64, 128, device=dev()))
+
+
 @pytest.mark.parametrize('dt', ['f32', 'bf16'])
 def test_colsum(dt):
     from adapter4rec_amd import _lib as L

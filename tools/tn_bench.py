@@ -24,3 +24,18 @@ for P, Q in ((768, 64), (64, 768)):
     torch.cuda.synchronize()
     us = a.elapsed_time(b) / 30 * 1e3
     print(f'gemm_tn M={M} [{P} x {Q}]: {us:6.1f} us  {M * (P + Q) * 2 / us / 1e6:5.2f} TB/s')
+
+X1, Y1 = torch.randn(M, 768, device=dev).bfloat16(), torch.randn(M, 64, device=dev).bfloat16()
+X2, Y2 = torch.randn(M, 64, device=dev).bfloat16(), torch.randn(M, 768, device=dev).bfloat16()
+C1, C2 = torch.zeros(768, 64, device=dev), torch.zeros(64, 768, device=dev)
+for _ in range(5):
+    L.gemm_tn2(X1, Y1, C1, X2, Y2, C2)
+torch.cuda.synchronize()
+a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+a.record()
+for _ in range(30):
+    L.gemm_tn2(X1, Y1, C1, X2, Y2, C2)
+b.record()
+torch.cuda.synchronize()
+us = a.elapsed_time(b) / 30 * 1e3
+print(f'gemm_tn2 M={M} both products in one launch: {us:6.1f} us  {M * (768 + 64) * 2 * 2 / us / 1e6:5.2f} TB/s')
