@@ -264,7 +264,7 @@ def test_cv_fp32_vs_reference_fixtures(name):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize('name', ['cv_vit_houlsby', 'cv_mae_houlsby', 'cv_vit_compacter'])
+@pytest.mark.parametrize('name', ['cv_vit_houlsby', 'cv_mae_houlsby', 'cv_vit_compacter', 'cv_vit_pfeiffer_ver2', 'cv_vit_houlsby_gelu_ln', 'cv_vit_cpc'])
 def test_cv_bf16_vs_oracle(name):
     """bf16 storage / fp32 accumulate vs the fp32 oracle on conditioned weights: loss 3e-2, gradients <= 12 % of tensor max."""
     from oracle import ref_cpu as R
