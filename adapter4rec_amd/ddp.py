@@ -30,7 +30,9 @@ class FlatDDP(nn.Module):
         inner = getattr(module, 'model', module)               # CompacterModel keeps the TransRec model in .model
         # plain attribute, NOT a registered sub-module: nn.Module.__setattr__ would make module <-> wrapper a cycle and
         # .train() / .eval() / .named_parameters() recurse forever on world > 1
-        object.__setattr__(inner, '_a4r_ddp', self if self.world > 1 else None)
+        # (A4R_DDP_FORCE=1: run the exchange with a single rank too -- exercises the RCCL calls on a one-GPU box)
+        force = bool(int(__import__('os').environ.get('A4R_DDP_FORCE', '0'))) and dist.is_initialized()
+        object.__setattr__(inner, '_a4r_ddp', self if (self.world > 1 or force) else None)
 
     def average_(self, flat):
         """In-place mean over ranks of one flat gradient buffer (a single RCCL all-reduce)."""
