@@ -28,6 +28,7 @@
 //   * the next tile's rows are requested before the current tile is processed (static vmcnt schedule: the last tile
 //     re-requests itself instead of branching).
 // Three workgroup barriers per tile.  The kernels are HBM-bound: 24 MFMAs per wave per 96 KB of traffic.
+#include <cstdlib>
 #include "a4r_common.h"
 #include "../../include/a4r.h"
 
@@ -257,7 +258,7 @@ struct AdBwdArgs {
     const bf16_t* WuT; const bf16_t* WdT; int inner_res;
     bf16_t* dv; bf16_t* dzp; bf16_t* dh; int lddv, lddh;
     float* dgamma; float* dbeta; float* dbias; float* dbd;
-    int M, bias_total;
+    int M, bias_total, abl;      // abl: timing ablations (A4R_ADAPTER_BWD_ABL; wrong results): 1 no stores, 2 no tile loads
     uint64_t seed; uint32_t site, thr16; float keep_scale;
 };
 
@@ -325,10 +326,11 @@ __global__ void __launch_bounds__(NW * 64) adapter_ln_bwd_kernel(const AdBwdArgs
             const size_t row = (size_t)tn * 16 + fr;
 #pragma unroll
             for (int s = 0; s < KS; ++s) {
+                if (p.abl & 2) { d_nxt[s] = make_uint4(0x3c003c00u, 0x3c003c00u, 0x3c003c00u, 0x3c003c00u); v_nxt[s] = d_nxt[s]; continue; }
                 d_nxt[s] = *reinterpret_cast<const uint4*>(p.dy + row * p.lddy + cl + s * 32);
                 v_nxt[s] = *reinterpret_cast<const uint4*>(p.v + row * p.ldv + cl + s * 32);
             }
-            st_nxt = *reinterpret_cast<const float2*>(p.stats + 2 * row);
+            st_nxt = (p.abl & 2) ? make_float2(0.f, 1.f) : *reinterpret_cast<const float2*>(p.stats + 2 * row);
         }
         const size_t row = (size_t)tile * 16 + fr;
         const float mean = st_cur.x, rstd = st_cur.y;
@@ -385,7 +387,7 @@ __global__ void __launch_bounds__(NW * 64) adapter_ln_bwd_kernel(const AdBwdArgs
                 }
             }
             dvp[s] = Elem<bf16_t>::pack(d8);
-            *reinterpret_cast<uint4*>(p.dv + row * p.lddv + cl + s * 32) = dvp[s];
+            if (!(p.abl & 1)) *reinterpret_cast<uint4*>(p.dv + row * p.lddv + cl + s * 32) = dvp[s];
         }
         // ---- dz partial over this wave's columns, summed through LDS; dzp = dz * act'(zp)
         f32x4_t zacc[4];
@@ -443,7 +445,8 @@ __global__ void __launch_bounds__(NW * 64) adapter_ln_bwd_kernel(const AdBwdArgs
                     o8[e + 4] = (((uint32_t)(h1 >> (16 * e)) & 0xffffu) >= p.thr16) ? o8[e + 4] * p.keep_scale : 0.f;
                 }
             }
-            *reinterpret_cast<uint4*>(p.dh + row * p.lddh + cl + s * 32) = Elem<bf16_t>::pack(o8);
+            if (!(p.abl & 1)) *reinterpret_cast<uint4*>(p.dh + row * p.lddh + cl + s * 32) = Elem<bf16_t>::pack(o8);
+            else if (o8[0] == 12345.f) p.dbias[0] = o8[1];
         }
 #pragma unroll
         for (int s = 0; s < KS; ++s) { d_cur[s] = d_nxt[s]; v_cur[s] = v_nxt[s]; }
@@ -557,6 +560,8 @@ extern "C" int a4r_adapter_ln_bwd(void* stream, const void* dy, int lddy, const 
     a.WuT = reinterpret_cast<const bf16_t*>(WuT); a.WdT = reinterpret_cast<const bf16_t*>(WdT); a.inner_res = inner_res;
     a.dv = reinterpret_cast<bf16_t*>(dv); a.dzp = reinterpret_cast<bf16_t*>(dzp); a.dh = reinterpret_cast<bf16_t*>(dh);
     a.lddv = lddv; a.lddh = lddh; a.dgamma = dgamma; a.dbeta = dbeta; a.dbias = dbias; a.dbd = dbd; a.M = M; a.bias_total = flags & 1;
+    static const int abl = getenv("A4R_ADAPTER_BWD_ABL") ? atoi(getenv("A4R_ADAPTER_BWD_ABL")) : 0;
+    a.abl = abl;
     a.seed = drop_seed; a.site = drop_site; a.thr16 = a4r_thr16(drop_p); a.keep_scale = a4r_keep_scale(drop_p);
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     const int ntiles = M / 16, ncu = a4r_cu_count();
