@@ -44,8 +44,19 @@ extern "C" int a4r_debug_stamps(unsigned long long* host_out) {
         g_a4r_stamps[(blockIdx.x * 4 + tile_no_) * 4 + 2 * (k_)] = __builtin_amdgcn_s_memtime();                             \
         g_a4r_stamps[(blockIdx.x * 4 + tile_no_) * 4 + 2 * (k_) + 1] = __builtin_amdgcn_s_memrealtime();                     \
     }
+// timeline (tools/gemm_timeline.py): s_memrealtime at kernel entry [0], per tile t < 3 at K-loop start / K-loop end / last store issued
+// [1 + 3t ..], and after the last tile's stores have drained [10]
+__device__ unsigned long long g_a4r_timeline[256 * 12];
+extern "C" int a4r_debug_timeline(unsigned long long* host_out) {
+    return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_a4r_timeline), sizeof(g_a4r_timeline)) == hipSuccess ? 0 : -2;
+}
+#define A4R_TL(slot_)                                                                                                        \
+    if (tid == 0 && (slot_) < 12 && blockIdx.x < 256) g_a4r_timeline[blockIdx.x * 12 + (slot_)] = __builtin_amdgcn_s_memrealtime();
+#define A4R_TLT(k_) if (tile_no_ < 3) { A4R_TL((k_) + 3 * tile_no_) }
 #else
 #define A4R_LOOP_STAMP(k_)
+#define A4R_TL(slot_)
+#define A4R_TLT(k_)
 #endif
 #define A4R_ST(k_)
 #define A4R_ST_NEXT
@@ -69,8 +80,9 @@ A4R_DEV void glds16(const void* base, uint32_t voff, uint32_t lds_dst) {
         : "memory");
 }
 
-template <typename TI, typename TO, int ACT, int DACT>
-__global__ void __launch_bounds__(512, 2) gemm_nt_256_kernel(const a4r_gemm_t p, int ntm, int ntn, int gn, uint32_t thr16, float keep_scale) {
+template <typename TI, typename TO, int ACT, int DACT, int EF>
+__global__ void __launch_bounds__(512, 2) gemm_nt_256_kernel(const a4r_gemm_t p, int ntm, int ntn, int gn_flags, uint32_t thr16, float keep_scale) {
+    const int gn = gn_flags & 0xffff;                     // band width of the tile map; bit 16: A4R_GEMM_NO_STREAM=1 (A/B switch)
     constexpr int ROWB = 128;
     constexpr int KT = ROWB / (int)sizeof(TI);
     __shared__ __attribute__((aligned(16))) char lds[8 * UNIT_BYTES];      // [buffer 2][unit 4][128 rows][128 B]
@@ -109,6 +121,7 @@ __global__ void __launch_bounds__(512, 2) gemm_nt_256_kernel(const a4r_gemm_t p,
         }
     };
     int t_loc = blockIdx.x >> 3;
+    A4R_TL(0)
     if (t_loc >= len_x) return;
     int tm, tn;
     tile_of(t_loc, tm, tn);
@@ -136,9 +149,12 @@ __global__ void __launch_bounds__(512, 2) gemm_nt_256_kernel(const a4r_gemm_t p,
     }
     const uint32_t dma_dst = lds0 + (uint32_t)(2 * wave) * 1024u;       // + buffer*4*UNIT + kind*UNIT + i*1024
 
+    // K-tiles past the end of this output tile's K range are the first K-tiles of the workgroup's NEXT output tile (has_next: nk is
+    // even, so ring-buffer parity carries over): the unit stream never stops between tiles, the next K loop starts on data that is
+    // already in LDS and the epilogue's own loads (bias, Pre, R1) do not queue behind a 96 KiB prologue burst.
 #define A4R_ISSUE(kind_, tile_, base_, off_)                                                                         \
-    if ((tile_) < nk) {                                                                                              \
-        const char* src_ = (base_) + (size_t)(tile_) * ROWB;                                                         \
+    if ((tile_) < nk || has_next) {                                                                                  \
+        const char* src_ = (tile_) < nk ? (base_) + (size_t)(tile_) * ROWB : (base_##_nx) + (size_t)((tile_) - nk) * ROWB; \
         const uint32_t dst_ = dma_dst + (uint32_t)((((tile_) & 1) * 4 + (kind_)) * UNIT_BYTES);                       \
         glds16(src_, off_[0], dst_);                                                                                 \
         glds16(src_, off_[1], dst_ + 1024u);                                                                         \
@@ -190,7 +206,7 @@ __global__ void __launch_bounds__(512, 2) gemm_nt_256_kernel(const a4r_gemm_t p,
     // K-tile u from ring buffer buf_ (compile-time).  n1 = a K-tile u+1 exists, n2 = u+2 exists (A4R_ISSUE skips what does not).
 #define A4R_KTILE(u_, buf_)                                                                                                         \
     {                                                                                                                               \
-        const bool n1 = (u_) + 1 < nk, n2 = (u_) + 2 < nk;                                                                          \
+        const bool n1 = (u_) + 1 < nk || has_next, n2 = (u_) + 2 < nk || has_next;                                                                        \
         A4R_PHASE(A4R_RD_B(b0, buf_, U_BLO) A4R_RD_A(af, buf_, U_ALO), A4R_ISSUE(U_BHI, (u_) + 1, Bbase, offB_hi), n1, "2", af, b0, 0, 0) \
         A4R_PHASE(A4R_RD_B(b1, buf_, U_BHI), A4R_ISSUE(U_AHI, (u_) + 1, Abase, offA_hi), n1, "0", af, b1, 0, 2)                     \
         A4R_PHASE(A4R_RD_A(af, buf_, U_AHI), A4R_ISSUE(U_ALO, (u_) + 2, Abase, offA_lo), n2, "4", af, b1, 4, 2)                     \
@@ -225,9 +241,13 @@ __global__ void __launch_bounds__(512, 2) gemm_nt_256_kernel(const a4r_gemm_t p,
     A4R_ISSUE(U_AHI, 0, Abase, offA_hi)         \
     A4R_ISSUE(U_ALO, 1, Abase, offA_lo)         \
     A4R_ISSUE(U_BLO, 1, Bbase, offB_lo)
+    bool has_next = false;
+    const char* Abase_nx = Abase;
+    const char* Bbase_nx = Bbase;
     A4R_PROLOGUE()
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     const GemmEpi<TO> epi = make_epi<TO>(p, thr16, keep_scale);
+    const bool stream = !(nk & 1) && !(gn_flags >> 16);
 
 #ifdef A4R_STAMP
   int tile_no_ = 0;
@@ -240,8 +260,20 @@ __global__ void __launch_bounds__(512, 2) gemm_nt_256_kernel(const a4r_gemm_t p,
 #pragma unroll
         for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
+    // the tile after this one (its first six units are issued by the last two K-tiles of this one's loop)
+    const int tm_done = tm, tn_done = tn;
+    t_loc += gridDim.x >> 3;
+    const bool more = t_loc < len_x;
+    if (more) {
+        tile_of(t_loc, tm, tn);
+        Abase_nx = reinterpret_cast<const char*>(Ap + (size_t)tm * 256 * lda);
+        Bbase_nx = reinterpret_cast<const char*>(Bp + (size_t)tn * 256 * ldb);
+    }
+    has_next = more && stream;
+
     uint4 af[4][2], b0[2][2], b1[2][2];
     A4R_LOOP_STAMP(0)
+    A4R_TLT(1)
     if (wave >= 4 && !(A4R_ABL & 8)) __builtin_amdgcn_s_barrier();          // waves 4-7 run one barrier behind waves 0-3 from here on
     for (int u = 0; u < nk; u += 2) {
         A4R_KTILE(u, 0)
@@ -250,9 +282,7 @@ __global__ void __launch_bounds__(512, 2) gemm_nt_256_kernel(const a4r_gemm_t p,
     if (wave < 4 && !(A4R_ABL & 8)) __builtin_amdgcn_s_barrier();           // re-align: all LDS reads of this tile are complete, the ring is free
     asm volatile("" ::: "memory");
     A4R_LOOP_STAMP(1)
-#ifdef A4R_STAMP
-    ++tile_no_;
-#endif
+    A4R_TLT(2)
 
     // ---- epilogue straight from the accumulators.  The MFMA operands are swapped (B fragment first), so the tile is
     // produced transposed: a lane's 4 registers of tile (mi, ni) are 4 CONSECUTIVE COLUMNS of one output row,
@@ -262,13 +292,10 @@ __global__ void __launch_bounds__(512, 2) gemm_nt_256_kernel(const a4r_gemm_t p,
     // tile with one workgroup per CU).
     // every LDS read of this tile completed before the last barrier: the ring is free, so the NEXT tile's first units
     // are put in flight now and land while this tile's accumulators are being written out.
-    const int tm_done = tm, tn_done = tn;
-    t_loc += gridDim.x >> 3;
-    const bool more = t_loc < len_x;
-    if (more) {
-        tile_of(t_loc, tm, tn);
-        Abase = reinterpret_cast<const char*>(Ap + (size_t)tm * 256 * lda);
-        Bbase = reinterpret_cast<const char*>(Bp + (size_t)tn * 256 * ldb);
+    has_next = false;
+    Abase = Abase_nx;
+    Bbase = Bbase_nx;
+    if (more && !stream) {                                // odd K-tile count: the next tile's first units are put in flight here
         A4R_PROLOGUE()
     }
     // Pair the lanes of 16-lane rows (l <-> l ^ 16) with v_permlane16_swap: lane (fr, kg) gives away the half it holds of
@@ -278,11 +305,37 @@ __global__ void __launch_bounds__(512, 2) gemm_nt_256_kernel(const a4r_gemm_t p,
     // whose issue rate (not bandwidth) bounded the epilogue.
     const size_t grow0 = (size_t)tm_done * 256 + wm * 128 + fr;
     const int gcolp = tn_done * 256 + wn * 64 + (kg & 1) * 16 + (kg >> 1) * 8;      // + pair * 32
-    float bias8[2][8];
+    // C addresses and dropout element indices: a UNIFORM per-tile / per-group part (scalar registers) + a per-lane part that is the same
+    // for every tile (c_lane, e0_lane: formed once per kernel) -- no 64-bit multiply per group
+    // (per-lane parts: bytes, 32-bit -- the host side checks M * ldc * sizeof(TO) < 4 GiB.  Re-formed per tile from a laundered lane id:
+    // as loop invariants they and the 24 sums derived from them would be kept in registers across the K loop)
+    int lane_e = lane;
+    asm volatile("" : "+v"(lane_e));
+    const int fr_e = lane_e & 15, kg_e = lane_e >> 4;
+    const uint32_t c_lane = (uint32_t)(((wm * 128 + fr_e) * epi.ldc + wn * 64 + (kg_e & 1) * 16 + (kg_e >> 1) * 8) * (int)sizeof(TO));
+    const uint32_t c_rowstep = (uint32_t)(16 * epi.ldc * (int)sizeof(TO));
+    const uint64_t e0_lane = (uint64_t)(wm * 128 + fr_e) * (uint64_t)epi.N + (uint64_t)(wn * 64 + (kg_e & 1) * 16 + (kg_e >> 1) * 8);
+    char* const c_tile = reinterpret_cast<char*>(epi.C) + ((size_t)tm_done * 256 * (uint32_t)epi.ldc + (size_t)tn_done * 256) * sizeof(TO);
+    const uint64_t e0_tile = ((uint64_t)tm_done * 256 + epi.row0) * (uint64_t)epi.N + (uint64_t)tn_done * 256;
+    float bias8[2][8];                                    // (gcolp % 8 == 0: 16-byte loads are aligned iff the bias pointer is)
 #pragma unroll
     for (int pr = 0; pr < 2; ++pr)
 #pragma unroll
-        for (int e = 0; e < 8; ++e) bias8[pr][e] = epi.bias ? epi.bias[gcolp + pr * 32 + e] : 0.f;
+        for (int e = 0; e < 8; ++e) bias8[pr][e] = 0.f;
+    if (epi.bias && (reinterpret_cast<uintptr_t>(epi.bias) & 15u)) {
+#pragma unroll
+        for (int pr = 0; pr < 2; ++pr)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) bias8[pr][e] = epi.bias[gcolp + pr * 32 + e];
+    } else if (epi.bias) {
+#pragma unroll
+        for (int pr = 0; pr < 2; ++pr)
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const float4 b4 = *reinterpret_cast<const float4*>(epi.bias + gcolp + pr * 32 + h * 4);
+                bias8[pr][h * 4 + 0] = b4.x; bias8[pr][h * 4 + 1] = b4.y; bias8[pr][h * 4 + 2] = b4.z; bias8[pr][h * 4 + 3] = b4.w;
+            }
+    }
     // fp8 operands: per-row scale of A (token) x per-row scale of B (output channel), applied to the raw accumulator
     constexpr bool SCALED = sizeof(TI) == 1;
     float sb8[2][8], sa8[8];
@@ -305,7 +358,7 @@ __global__ void __launch_bounds__(512, 2) gemm_nt_256_kernel(const a4r_gemm_t p,
     }
     // the residual operand R1 (dgrad GEMMs: the gradient of the residual branch) likewise one row ahead (bf16 outputs: 4 registers
     // per group; the ping-pong K loop left the registers for it)
-    constexpr bool R1PF = sizeof(TO) == 2 && DACT == A4R_ACT_NONE;
+    constexpr bool R1PF = sizeof(TO) == 2 && DACT == A4R_ACT_NONE && (EF < 0 || (EF & 2));
     uint4 r1_ld[2][2][1];
     if constexpr (R1PF) {
         if (epi.R1) {
@@ -313,12 +366,15 @@ __global__ void __launch_bounds__(512, 2) gemm_nt_256_kernel(const a4r_gemm_t p,
             load_res_n<TO, 8>(r1_ld[0][1], epi.R1, epi.ldr1, grow0, gcolp + 32);
         }
     }
+#define A4R_EPI_CDST(mi_, pr_) (reinterpret_cast<TO*>(c_tile + (c_lane + (uint32_t)(mi_) * c_rowstep)) + (pr_) * 32)
 #if (A4R_ABL & 32)      /* timing-only experiment: every store instruction covers whole 128-byte lines (8 rows x 128 B); WRONG data placement */
 #define A4R_EPI_CALL(mi_, pr_)                                                                                              \
-        epilogue_n<TO, 8, ACT, DACT, R1PF>(v_, bias8[pr_], grow0 - fr + (fr & 7) + 8 * (pr_) + (mi_) * 16, gcolp + (fr >> 3) * 32, epi,
+        epilogue_n<TO, 8, ACT, DACT, R1PF, false, EF>(v_, bias8[pr_], grow0 - fr + (fr & 7) + 8 * (pr_) + (mi_) * 16, gcolp + (fr >> 3) * 32, epi,
+#undef A4R_EPI_CDST
+#define A4R_EPI_CDST(mi_, pr_) nullptr
 #else
 #define A4R_EPI_CALL(mi_, pr_)                                                                                              \
-        epilogue_n<TO, 8, ACT, DACT, R1PF>(v_, bias8[pr_], grow0 + (mi_) * 16, gcolp + (pr_) * 32, epi,
+        epilogue_n<TO, 8, ACT, DACT, R1PF, true, EF>(v_, bias8[pr_], grow0 + (mi_) * 16, gcolp + (pr_) * 32, epi,
 #endif
 #define A4R_EPI_PAIR(mi_, pr_, par_)                                                                                        \
     {                                                                                                                       \
@@ -332,8 +388,10 @@ __global__ void __launch_bounds__(512, 2) gemm_nt_256_kernel(const a4r_gemm_t p,
         if constexpr (SCALED) {                                                                                             \
             _Pragma("unroll") for (int e_ = 0; e_ < 8; ++e_) v_[e_] *= sa8[mi_] * sb8[pr_][e_];                             \
         }                                                                                                                   \
+        const uint64_t e0_ = e0_lane + (e0_tile + (uint64_t)((mi_) * 16) * (uint64_t)epi.N + (pr_) * 32);                      \
         A4R_EPI_CALL(mi_, pr_)                                                                                              \
-                                           DACT != A4R_ACT_NONE ? pre_ld_##par_##pr_ : nullptr, R1PF ? r1_ld[(mi_) & 1][pr_] : nullptr); \
+                                           DACT != A4R_ACT_NONE ? pre_ld_##par_##pr_ : nullptr, R1PF ? r1_ld[(mi_) & 1][pr_] : nullptr, nullptr, \
+                                           A4R_EPI_CDST(mi_, pr_), e0_);                                                    \
     }
 #define A4R_EPI_ROW(mi_, par_, npar_)                                                                                       \
     if constexpr (DACT != A4R_ACT_NONE && (mi_) < 7 && !(A4R_ABL & 256)) {                                                  \
@@ -350,6 +408,15 @@ __global__ void __launch_bounds__(512, 2) gemm_nt_256_kernel(const a4r_gemm_t p,
     A4R_EPI_ROW(0, 0, 1) A4R_EPI_ROW(1, 1, 0) A4R_EPI_ROW(2, 0, 1) A4R_EPI_ROW(3, 1, 0) A4R_EPI_ROW(4, 0, 1) A4R_EPI_ROW(5, 1, 0) A4R_EPI_ROW(6, 0, 1) A4R_EPI_ROW(7, 1, 0)
 #undef A4R_EPI_ROW
 #undef A4R_EPI_PAIR
+#undef A4R_EPI_CDST
+    A4R_TLT(3)
+#ifdef A4R_STAMP
+    ++tile_no_;
+    if (!more) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        A4R_TL(10)
+    }
+#endif
     if (!more) break;
     // the next tile's 6 prologue units were issued BEFORE this tile's stores: all of them have landed once at most the 16 youngest
     // operations (>= 16 stores per wave follow the DMAs) are still outstanding.  The stores themselves drain behind the next K loop.
@@ -404,19 +471,39 @@ static int band_for(const a4r_gemm_t& g, int ntm, int ntn, int grid, int isz) {
     return gn < ntn ? gn : ntn;
 }
 
-template <typename TI, typename TO, int ACT, int DACT>
+template <typename TI, typename TO, int ACT, int DACT, int EF = -1>
 int launch256(hipStream_t s, const a4r_gemm_t& g) {
     const int ntm = g.M / 256, ntn = g.N / 256;
     const int n_cu = a4r_cu_count();
     int grid = ntm * ntn < n_cu ? ((ntm * ntn + 7) & ~7) : n_cu;       // a multiple of 8 (workgroups past an XCD's tile count exit at once)
-    const int gn = band_for(g, ntm, ntn, grid, (int)sizeof(TI));
-    hipLaunchKernelGGL((gemm_nt_256_kernel<TI, TO, ACT, DACT>), dim3(grid), dim3(512), 0, s, g, ntm, ntn, gn,
+    static const int no_stream = getenv("A4R_GEMM_NO_STREAM") ? atoi(getenv("A4R_GEMM_NO_STREAM")) != 0 : 0;
+    const int gn = band_for(g, ntm, ntn, grid, (int)sizeof(TI)) | (no_stream << 16);
+    hipLaunchKernelGGL((gemm_nt_256_kernel<TI, TO, ACT, DACT, EF>), dim3(grid), dim3(512), 0, s, g, ntm, ntn, gn,
                        a4r_thr16(g.drop_p), a4r_keep_scale(g.drop_p));
     return a4r_launch_status();
 }
 
+// which optional epilogue pieces a launch carries (the EF template argument of epilogue_n)
+static int epi_mask(const a4r_gemm_t& g) {
+    return (g.drop_p > 0.f ? 1 : 0) | (g.R1 ? 2 : 0) | (g.R2 ? 4 : 0) | (g.C2 ? 8 : 0);
+}
+
 template <typename T>
 int dispatch_same(hipStream_t s, const a4r_gemm_t& g) {   // in == out dtype: the activation forms the training step uses
+    // bf16 (the training step): the epilogue forms the step launches by the dozen get instantiations WITHOUT the run-time tests of the
+    // pieces they do not carry (A4R_GEMM_GENERIC_EPI=1: the all-purpose instantiation always)
+    static const int generic = getenv("A4R_GEMM_GENERIC_EPI") ? atoi(getenv("A4R_GEMM_GENERIC_EPI")) != 0 : 0;
+    if constexpr (sizeof(T) == 2) {
+        const int m = generic ? -1 : epi_mask(g);
+        if (g.act == A4R_ACT_NONE && g.dact == A4R_ACT_NONE) {
+            if (m == 0) return launch256<T, T, A4R_ACT_NONE, A4R_ACT_NONE, 0>(s, g);
+            if (m == 1) return launch256<T, T, A4R_ACT_NONE, A4R_ACT_NONE, 1>(s, g);
+            if (m == 2) return launch256<T, T, A4R_ACT_NONE, A4R_ACT_NONE, 2>(s, g);
+        }
+        if (g.act == A4R_ACT_GELU && g.dact == A4R_ACT_NONE && m == 8) return launch256<T, T, A4R_ACT_GELU, A4R_ACT_NONE, 8>(s, g);
+        if (g.act == A4R_ACT_NONE && g.dact == A4R_DACT_MULQ8_ && m == 0) return launch256<T, T, A4R_ACT_NONE, A4R_DACT_MULQ8_, 0>(s, g);
+        if (g.act == A4R_ACT_NONE && g.dact == A4R_DACT_MUL_ && m == 0) return launch256<T, T, A4R_ACT_NONE, A4R_DACT_MUL_, 0>(s, g);
+    }
     if (g.act == A4R_ACT_NONE && g.dact == A4R_ACT_NONE) return launch256<T, T, A4R_ACT_NONE, A4R_ACT_NONE>(s, g);
     if (g.act == A4R_ACT_GELU && g.dact == A4R_ACT_NONE) return launch256<T, T, A4R_ACT_GELU, A4R_ACT_NONE>(s, g);
     if (g.act == A4R_ACT_RELU && g.dact == A4R_ACT_NONE) return launch256<T, T, A4R_ACT_RELU, A4R_ACT_NONE>(s, g);
@@ -434,6 +521,7 @@ int dispatch_same(hipStream_t s, const a4r_gemm_t& g) {   // in == out dtype: th
 // called by a4r_gemm_nt (a4r_gemm.hip) after argument validation; returns 1 when the combination is not instantiated
 int a4r_gemm_nt_256(hipStream_t s, const a4r_gemm_t& g) {
     if (g.bias && (reinterpret_cast<uintptr_t>(g.bias) & 3u)) return 1;
+    if ((uint64_t)g.M * (uint64_t)g.ldc * (g.out_dtype == A4R_F32 ? 4u : 2u) >= (1ull << 32)) return 1;      // 32-bit per-lane output offsets
     if (g.in_dtype == A4R_FP8) {                      // e4m3 operands (frozen-backbone forward GEMMs): plain and GELU (+ derivative) epilogues
         if (g.out_dtype != A4R_BF16 || !g.scale_a || !g.scale_b || g.dact != A4R_ACT_NONE) return 1;
         if (g.act == A4R_ACT_NONE) return launch256<fp8_t, bf16_t, A4R_ACT_NONE, A4R_ACT_NONE>(s, g);

@@ -109,14 +109,20 @@ template <typename TO, int NC, bool Q8 = false> A4R_DEV void load_pre_n(uint4* q
 
 // R1PF: the caller ALWAYS passes r1_ld and has filled it whenever e.R1 is set (a run-time null test on a register array would send
 // the array to scratch)
-template <typename TO, int NC, int ACT = -1, int DACT = -1, bool R1PF = false>
+// EF >= 0: the caller states at compile time which optional pieces CAN be present (bit 1 dropout, 2 R1, 4 R2, 8 C2); the tests of the
+// others (a uniform branch each, 16 groups per tile) and their code are not emitted.  EF < 0: every piece behind its run-time test.
+template <typename TO, int NC, int ACT = -1, int DACT = -1, bool R1PF = false, bool FAST = false, int EF = -1>
 A4R_DEV void epilogue_n(float (&v)[NC], const float* bias, uint32_t grow, int gcol, const GemmEpi<TO>& e, const uint4* pre_ld = nullptr,
-                        const uint4* r1_ld = nullptr, const uint4* r2_ld = nullptr) {
+                        const uint4* r1_ld = nullptr, const uint4* r2_ld = nullptr, TO* cdst = nullptr, uint64_t e0v = 0) {
+    // FAST (cdst, e0v): the caller formed the address of C[grow][gcol] / the dropout element index itself (the 256-tile kernel: a uniform
+    // tile base + a per-lane 32-bit offset instead of a 64-bit multiply per group)
     const int act = ACT >= 0 ? ACT : e.act;
     const int dact = DACT >= 0 ? DACT : e.dact;
+    const uint32_t thr16 = (EF < 0 || (EF & 1)) ? e.thr16 : 0u;
+    const bool has_r1 = (EF < 0 || (EF & 2)) && e.R1, has_r2 = (EF < 0 || (EF & 4)) && e.R2, has_c2 = (EF < 0 || (EF & 8)) && e.C2;
 #pragma unroll
     for (int i = 0; i < NC; ++i) v[i] = v[i] * e.alpha + bias[i];
-    if (act == A4R_ACT_GELU && e.C2 && e.c2_mode) {          // value and derivative from one exp + one rcp
+    if (act == A4R_ACT_GELU && has_c2 && e.c2_mode) {          // value and derivative from one exp + one rcp
         float d[NC];
 #pragma unroll
         for (int i = 0; i < NC; ++i) {
@@ -126,7 +132,7 @@ A4R_DEV void epilogue_n(float (&v)[NC], const float* bias, uint32_t grow, int gc
         if (e.c2_mode == 2) store_q8<NC>(reinterpret_cast<uint8_t*>(e.C2) + (size_t)grow * (uint32_t)e.ldc2 + gcol, d);
         else if (!(A4R_ABL & 128)) store_n<TO, NC>(e.C2 + (size_t)grow * (uint32_t)e.ldc2 + gcol, d);
     } else {
-        if (e.C2) {
+        if (has_c2) {
             if (e.c2_mode) {
                 float d[NC];
 #pragma unroll
@@ -172,9 +178,9 @@ A4R_DEV void epilogue_n(float (&v)[NC], const float* bias, uint32_t grow, int gc
         }
     }
     // (the element index of the dropout mask is only formed when a mask is drawn: it is 64-bit arithmetic per group)
-    if (e.thr16 && e.drop_first)
-        epi_dropout<NC>(v, ((uint64_t)grow + e.row0) * (uint64_t)e.N + (uint64_t)gcol, e.drop_seed, e.drop_site, e.thr16, e.keep_scale);
-    if (e.R1) {
+    if (thr16 && e.drop_first)
+        epi_dropout<NC>(v, FAST ? e0v : ((uint64_t)grow + e.row0) * (uint64_t)e.N + (uint64_t)gcol, e.drop_seed, e.drop_site, thr16, e.keep_scale);
+    if (has_r1) {
         float t[NC];
         if (R1PF || r1_ld) {
 #pragma unroll
@@ -185,7 +191,7 @@ A4R_DEV void epilogue_n(float (&v)[NC], const float* bias, uint32_t grow, int gc
 #pragma unroll
         for (int i = 0; i < NC; ++i) v[i] += t[i];
     }
-    if (e.R2) {
+    if (has_r2) {
         float t[NC];
         if (r2_ld) {
 #pragma unroll
@@ -196,9 +202,9 @@ A4R_DEV void epilogue_n(float (&v)[NC], const float* bias, uint32_t grow, int gc
 #pragma unroll
         for (int i = 0; i < NC; ++i) v[i] += t[i];
     }
-    if (e.thr16 && !e.drop_first)
-        epi_dropout<NC>(v, ((uint64_t)grow + e.row0) * (uint64_t)e.N + (uint64_t)gcol, e.drop_seed, e.drop_site, e.thr16, e.keep_scale);
-    if (!(A4R_ABL & 512) || v[0] == 12345.678f) store_n<TO, NC>(e.C + (size_t)grow * (uint32_t)e.ldc + gcol, v);
+    if (thr16 && !e.drop_first)
+        epi_dropout<NC>(v, FAST ? e0v : ((uint64_t)grow + e.row0) * (uint64_t)e.N + (uint64_t)gcol, e.drop_seed, e.drop_site, thr16, e.keep_scale);
+    if (!(A4R_ABL & 512) || v[0] == 12345.678f) store_n<TO, NC>(FAST ? cdst : e.C + (size_t)grow * (uint32_t)e.ldc + gcol, v);
 }
 // the NC elements of a residual operand as 16-byte pieces, for a caller that requests them ahead of use (r1_ld / r2_ld above)
 template <typename TO, int NC> A4R_DEV void load_res_n(uint4* q, const TO* R, int ldr, size_t grow, int gcol) {

@@ -51,3 +51,26 @@ for i, e in enumerate(evs):
     if not ours(e.name):
         where = 'before first' if i < idx[0] else ('after last' if i > idx[-1] else 'BETWEEN')
         print(f'  [{i:4d}] {where:12s} {e.name[:110]}')
+
+# idle time between consecutive device activities of the busiest stream (kernel-boundary cost: drain + release + dispatch)
+by_stream = {}
+for e in evs:
+    by_stream.setdefault(getattr(e, 'device_index', 0) * 1000 + (getattr(e, 'device_resource_id', None) or 0), []).append(e)
+# torch.profiler does not expose the stream of an event portably: fall back to one list and merge overlapping intervals
+iv = sorted((e.time_range.start, e.time_range.end) for e in evs)
+span = iv[-1][1] - iv[0][0]
+busy, cur_s, cur_e, gaps = 0.0, iv[0][0], iv[0][1], []
+for s, t in iv[1:]:
+    if s > cur_e:
+        busy += cur_e - cur_s
+        gaps.append(s - cur_e)
+        cur_s, cur_e = s, t
+    else:
+        cur_e = max(cur_e, t)
+busy += cur_e - cur_s
+import numpy as np
+gaps = np.array(gaps)
+print(f'span first start .. last end {span / 1e3:.2f} ms; device busy (union of all streams) {busy / 1e3:.2f} ms; idle {gaps.sum() / 1e3:.2f} ms in {len(gaps)} gaps '
+      f'(median {np.median(gaps):.1f} us, p90 {np.percentile(gaps, 90):.1f} us, max {gaps.max():.1f} us)')
+big = sorted(((g, i) for i, g in enumerate(gaps)), reverse=True)[:8]
+print('largest gaps (us):', ', '.join(f'{g:.1f}' for g, _ in big))
