@@ -178,8 +178,12 @@ __global__ void __launch_bounds__(512, 2) gemm_nt_256_kernel(const a4r_gemm_t p,
 #ifndef A4R_ABL
 #define A4R_ABL 0          /* timing-only diagnostic builds (tools/gemm_abl.sh): 1 no DMA, 2 no MFMA, 4 no fragment reads, 8 no barriers, 16 no setprio */
 #endif
-#define A4R_PHASE(reads_, issue_, full_, tail_, ax_, bx_, m0_, n0_)                                    \
+#define A4R_PHASE(reads_, issue_, full_, tail_, ax_, bx_, m0_, n0_, z_)                                \
     A4R_ST(0)                                                                                         \
+    if (z_) {                      /* first K-tile of an output tile: this phase's quarter of the accumulators starts from zero */ \
+        _Pragma("unroll") for (int mi = 0; mi < 4; ++mi)                                              \
+            _Pragma("unroll") for (int ni = 0; ni < 2; ++ni) acc[(m0_) + mi][(n0_) + ni] = f32x4_t{0.f, 0.f, 0.f, 0.f}; \
+    }                                                                                                 \
     if (!(A4R_ABL & 4)) { reads_ }                                                                    \
     if (!(A4R_ABL & 1)) { issue_ }                                                                    \
     __builtin_amdgcn_sched_barrier(0);                                                                \
@@ -207,10 +211,11 @@ __global__ void __launch_bounds__(512, 2) gemm_nt_256_kernel(const a4r_gemm_t p,
 #define A4R_KTILE(u_, buf_)                                                                                                         \
     {                                                                                                                               \
         const bool n1 = (u_) + 1 < nk || has_next, n2 = (u_) + 2 < nk || has_next;                                                                        \
-        A4R_PHASE(A4R_RD_B(b0, buf_, U_BLO) A4R_RD_A(af, buf_, U_ALO), A4R_ISSUE(U_BHI, (u_) + 1, Bbase, offB_hi), n1, "2", af, b0, 0, 0) \
-        A4R_PHASE(A4R_RD_B(b1, buf_, U_BHI), A4R_ISSUE(U_AHI, (u_) + 1, Abase, offA_hi), n1, "0", af, b1, 0, 2)                     \
-        A4R_PHASE(A4R_RD_A(af, buf_, U_AHI), A4R_ISSUE(U_ALO, (u_) + 2, Abase, offA_lo), n2, "4", af, b1, 4, 2)                     \
-        A4R_PHASE(, A4R_ISSUE(U_BLO, (u_) + 2, Bbase, offB_lo), n2, "4", af, b0, 4, 0)                                              \
+        const bool z0 = (buf_) == 0 && (u_) == 0;                                                                                   \
+        A4R_PHASE(A4R_RD_B(b0, buf_, U_BLO) A4R_RD_A(af, buf_, U_ALO), A4R_ISSUE(U_BHI, (u_) + 1, Bbase, offB_hi), n1, "2", af, b0, 0, 0, z0) \
+        A4R_PHASE(A4R_RD_B(b1, buf_, U_BHI), A4R_ISSUE(U_AHI, (u_) + 1, Abase, offA_hi), n1, "0", af, b1, 0, 2, z0)                 \
+        A4R_PHASE(A4R_RD_A(af, buf_, U_AHI), A4R_ISSUE(U_ALO, (u_) + 2, Abase, offA_lo), n2, "4", af, b1, 4, 2, z0)                 \
+        A4R_PHASE(, A4R_ISSUE(U_BLO, (u_) + 2, Bbase, offB_lo), n2, "4", af, b0, 4, 0, z0)                                          \
     }
 
     f32x4_t acc[8][4];
@@ -242,12 +247,26 @@ __global__ void __launch_bounds__(512, 2) gemm_nt_256_kernel(const a4r_gemm_t p,
     A4R_ISSUE(U_ALO, 1, Abase, offA_lo)         \
     A4R_ISSUE(U_BLO, 1, Bbase, offB_lo)
     bool has_next = false;
+    const int tile_stride = (int)(gridDim.x >> 3);        // read once (behind the asm memory clobbers it was re-loaded from the dispatch packet per tile)
     const char* Abase_nx = Abase;
     const char* Bbase_nx = Bbase;
     A4R_PROLOGUE()
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     const GemmEpi<TO> epi = make_epi<TO>(p, thr16, keep_scale);
     const bool stream = !(nk & 1) && !(gn_flags >> 16);
+    // the tile after the current one: found before the current tile's K loop needs it, outside the barrier-to-barrier path (the scalar
+    // divisions of tile_of() sat between the top-of-tile barrier and the first phase)
+    int tm_nx = tm, tn_nx = tn;
+    bool more;
+#define A4R_NEXT_TILE()                                                                      \
+    t_loc += tile_stride;                                                                    \
+    more = t_loc < len_x;                                                                    \
+    if (more) {                                                                              \
+        tile_of(t_loc, tm_nx, tn_nx);                                                        \
+        Abase_nx = reinterpret_cast<const char*>(Ap + (size_t)tm_nx * 256 * lda);            \
+        Bbase_nx = reinterpret_cast<const char*>(Bp + (size_t)tn_nx * 256 * ldb);            \
+    }
+    A4R_NEXT_TILE()
 
 #ifdef A4R_STAMP
   int tile_no_ = 0;
@@ -255,21 +274,10 @@ __global__ void __launch_bounds__(512, 2) gemm_nt_256_kernel(const a4r_gemm_t p,
   for (;;) {                                              // ---- tiles of this workgroup
     __builtin_amdgcn_s_barrier();                         // every wave's prologue units have landed (vmcnt(0) above / below)
     asm volatile("" ::: "memory");
-#pragma unroll
-    for (int mi = 0; mi < 8; ++mi)
-#pragma unroll
-        for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-
-    // the tile after this one (its first six units are issued by the last two K-tiles of this one's loop)
+    // (the accumulators are zeroed quarter by quarter inside the LOAD segments of the first K-tile's four phases, next to the partner
+    // wave's MFMA segment: 128 v_mov per wave in front of the loop were 0.5 us per tile during which neither wave of a SIMD issued MFMAs)
     const int tm_done = tm, tn_done = tn;
-    t_loc += gridDim.x >> 3;
-    const bool more = t_loc < len_x;
-    if (more) {
-        tile_of(t_loc, tm, tn);
-        Abase_nx = reinterpret_cast<const char*>(Ap + (size_t)tm * 256 * lda);
-        Bbase_nx = reinterpret_cast<const char*>(Bp + (size_t)tn * 256 * ldb);
-    }
-    has_next = more && stream;
+    has_next = more && stream;                            // its first six units are issued by the last two K-tiles of this tile's loop
 
     uint4 af[4][2], b0[2][2], b1[2][2];
     A4R_LOOP_STAMP(0)
@@ -295,6 +303,8 @@ __global__ void __launch_bounds__(512, 2) gemm_nt_256_kernel(const a4r_gemm_t p,
     has_next = false;
     Abase = Abase_nx;
     Bbase = Bbase_nx;
+    tm = tm_nx;
+    tn = tn_nx;
     if (more && !stream) {                                // odd K-tile count: the next tile's first units are put in flight here
         A4R_PROLOGUE()
     }
@@ -418,10 +428,12 @@ __global__ void __launch_bounds__(512, 2) gemm_nt_256_kernel(const a4r_gemm_t p,
     }
 #endif
     if (!more) break;
+    A4R_NEXT_TILE()
     // the next tile's 6 prologue units were issued BEFORE this tile's stores: all of them have landed once at most the 16 youngest
     // operations (>= 16 stores per wave follow the DMAs) are still outstanding.  The stores themselves drain behind the next K loop.
     asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
   }
+#undef A4R_NEXT_TILE
 #undef A4R_PROLOGUE
 #undef A4R_ISSUE
 #undef A4R_RD_A
@@ -524,8 +536,9 @@ int a4r_gemm_nt_256(hipStream_t s, const a4r_gemm_t& g) {
     if ((uint64_t)g.M * (uint64_t)g.ldc * (g.out_dtype == A4R_F32 ? 4u : 2u) >= (1ull << 32)) return 1;      // 32-bit per-lane output offsets
     if (g.in_dtype == A4R_FP8) {                      // e4m3 operands (frozen-backbone forward GEMMs): plain and GELU (+ derivative) epilogues
         if (g.out_dtype != A4R_BF16 || !g.scale_a || !g.scale_b || g.dact != A4R_ACT_NONE) return 1;
-        if (g.act == A4R_ACT_NONE) return launch256<fp8_t, bf16_t, A4R_ACT_NONE, A4R_ACT_NONE>(s, g);
-        if (g.act == A4R_ACT_GELU) return launch256<fp8_t, bf16_t, A4R_ACT_GELU, A4R_ACT_NONE>(s, g);
+        const int m = epi_mask(g);
+        if (g.act == A4R_ACT_NONE) return m == 0 ? launch256<fp8_t, bf16_t, A4R_ACT_NONE, A4R_ACT_NONE, 0>(s, g) : launch256<fp8_t, bf16_t, A4R_ACT_NONE, A4R_ACT_NONE>(s, g);
+        if (g.act == A4R_ACT_GELU) return m == 8 ? launch256<fp8_t, bf16_t, A4R_ACT_GELU, A4R_ACT_NONE, 8>(s, g) : launch256<fp8_t, bf16_t, A4R_ACT_GELU, A4R_ACT_NONE>(s, g);
         return 1;
     }
     if (g.in_dtype == A4R_BF16 && g.out_dtype == A4R_BF16) return dispatch_same<bf16_t>(s, g);
