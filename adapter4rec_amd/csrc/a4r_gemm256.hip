@@ -123,6 +123,16 @@ __global__ void __launch_bounds__(512, 2) gemm_nt_256_kernel(const a4r_gemm_t p,
     int t_loc = blockIdx.x >> 3;
     A4R_TL(0)
     if (t_loc >= len_x) return;
+    {   // Staggered start (gn_flags >> 17 = delay in 10-ns ticks, A4R_GEMM_STAGGER = percent of a tile period, default 30, 0 = off):
+        // workgroups that own one tile fewer than the busiest of their XCD have a tile period of slack; started late, their epilogue
+        // store bursts fall into the other workgroups' K loops instead of on top of their bursts (tools/gemm_timeline.py: the K loop of
+        // the N = 2304 launch 18.6 -> 16.3 us per tile).  Same-box step: -1.5 % on the slower boxes of the pool, neutral on the fastest.
+        const int delay = gn_flags >> 17, stride0 = (int)(gridDim.x >> 3);
+        if (delay > 0 && (len_x - 1 - t_loc) / stride0 < (len_x - 1) / stride0) {
+            const uint64_t t_end = __builtin_amdgcn_s_memrealtime() + (uint64_t)delay;
+            while (__builtin_amdgcn_s_memrealtime() < t_end) __builtin_amdgcn_s_sleep(8);
+        }
+    }
     int tm, tn;
     tile_of(t_loc, tm, tn);
 
@@ -253,7 +263,7 @@ __global__ void __launch_bounds__(512, 2) gemm_nt_256_kernel(const a4r_gemm_t p,
     A4R_PROLOGUE()
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     const GemmEpi<TO> epi = make_epi<TO>(p, thr16, keep_scale);
-    const bool stream = !(nk & 1) && !(gn_flags >> 16);
+    const bool stream = !(nk & 1) && !((gn_flags >> 16) & 1);
     // the tile after the current one: found before the current tile's K loop needs it, outside the barrier-to-barrier path (the scalar
     // divisions of tile_of() sat between the top-of-tile barrier and the first phase)
     int tm_nx = tm, tn_nx = tn;
@@ -489,7 +499,13 @@ int launch256(hipStream_t s, const a4r_gemm_t& g) {
     const int n_cu = a4r_cu_count();
     int grid = ntm * ntn < n_cu ? ((ntm * ntn + 7) & ~7) : n_cu;       // a multiple of 8 (workgroups past an XCD's tile count exit at once)
     static const int no_stream = getenv("A4R_GEMM_NO_STREAM") ? atoi(getenv("A4R_GEMM_NO_STREAM")) != 0 : 0;
-    const int gn = band_for(g, ntm, ntn, grid, (int)sizeof(TI)) | (no_stream << 16);
+    static const int stagger_pct = getenv("A4R_GEMM_STAGGER") ? atoi(getenv("A4R_GEMM_STAGGER")) : 30;
+    int delay = 0;
+    if (stagger_pct > 0 && ntm * ntn > 2 * grid) {         // (tile period in 10-ns ticks ~ 145 per K-tile of 128 B + 400)
+        delay = (int)((g.K * (int)sizeof(TI) / 128 * 145 + 400) * stagger_pct / 100);
+        if (delay > 16383) delay = 16383;
+    }
+    const int gn = band_for(g, ntm, ntn, grid, (int)sizeof(TI)) | (no_stream << 16) | (delay << 17);
     hipLaunchKernelGGL((gemm_nt_256_kernel<TI, TO, ACT, DACT, EF>), dim3(grid), dim3(512), 0, s, g, ntm, ntn, gn,
                        a4r_thr16(g.drop_p), a4r_keep_scale(g.drop_p));
     return a4r_launch_status();
