@@ -147,8 +147,8 @@ A4R_DEV float erf_as(float z, float e_neg_z2) {
     const float az = fabsf(z);
     const float t = __builtin_amdgcn_rcpf(1.f + 0.3275911f * az);   // v_rcp_f32 (1 ulp)
     const float poly = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
-    const float r = 1.f - poly * e_neg_z2;
-    return z < 0.f ? -r : r;
+    const float r = 1.f - poly * e_neg_z2;                          // >= 0
+    return __builtin_copysignf(r, z);                               // (one v_bfi_b32; the compare + select form cost a v_cmp, a hazard nop and a v_cndmask)
 }
 A4R_DEV float gelu_erf_fwd(float x) {
     const float z = x * 0.70710678118654752440f;

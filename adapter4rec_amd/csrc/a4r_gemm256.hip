@@ -31,6 +31,12 @@
 #include <stdlib.h>
 #include "a4r_gemm_epi.h"
 
+#ifndef A4R_PF_Q8
+#define A4R_PF_Q8 8        /* rows of 16 the 8-bit Pre operand is requested ahead of its use (1, 2, 4 or 8 = the whole tile up front) */
+#endif
+#ifndef A4R_PF_R1
+#define A4R_PF_R1 8        /* likewise the residual operand R1 */
+#endif
 #ifdef A4R_STAMP
 // diagnostic build only (-DA4R_STAMP, tools/gemm_stamps.py): (s_memtime, s_memrealtime) of wave 0 of every workgroup at the start and the
 // end of the K loop of its first four output tiles -> shader cycles per K loop and the clock the chip holds (cycles / (realtime ticks / 100 MHz)).
@@ -138,6 +144,7 @@ __global__ void __launch_bounds__(512, 2) gemm_nt_256_kernel(const a4r_gemm_t p,
 
     const int lda = p.lda, ldb = p.ldb;
     const int nk = p.K / KT;
+    __builtin_assume(nk >= 1);                            // (host-checked; without it the accumulators count as live across the K loop and the epilogue copies every one before its in-place lane swap)
     const TI* Ap = reinterpret_cast<const TI*>(p.A);
     const TI* Bp = reinterpret_cast<const TI*>(p.B);
     const char* Abase = reinterpret_cast<const char*>(Ap + (size_t)tm * 256 * lda);
@@ -367,25 +374,38 @@ __global__ void __launch_bounds__(512, 2) gemm_nt_256_kernel(const a4r_gemm_t p,
 #pragma unroll
         for (int mi = 0; mi < 8; ++mi) sa8[mi] = p.scale_a[grow0 + mi * 16];
     }
-    // DACT instantiations (dgrad through an activation: C = acc * act'(Pre)): the Pre operand of row mi + 1 is requested before
-    // row mi is finished and stored -- a load waited for where it is issued costs an L2 / HBM round trip per group, and it cannot
-    // be hoisted above the previous group's store by the compiler (C may alias Pre for all it knows).
+    // Operands the epilogue READS -- Pre (dgrad through an activation: C = acc * act'(Pre)) and R1 (dgrad GEMMs: the gradient of the
+    // residual branch) -- are requested PRE_D / R1_D rows of 16 ahead of the row that consumes them: a load waited for where it is
+    // issued costs an L2 / HBM round trip per group (it cannot be hoisted above the previous group's store by the compiler: C may alias
+    // it for all it knows), and one row ahead still left ~0.8 us of latency exposed per row (tools/gemm_timeline.py: 6.7 - 9.3 us per
+    // tile against 2.0 us for the plain epilogue).  One object per (row, pair): indexed arrays of register arrays went to scratch.
     constexpr int PS = DACT != A4R_ACT_NONE ? 8 * (int)sizeof(TO) / 16 : 1;
-    uint4 pre_ld_00[PS], pre_ld_01[PS], pre_ld_10[PS], pre_ld_11[PS];      // [row parity][pair]: four separate objects (one [2][2][PS] array went to scratch)
-    if constexpr (DACT != A4R_ACT_NONE && !(A4R_ABL & 256)) {
-        load_pre_n<TO, 8, DACT == A4R_DACT_MULQ8_>(pre_ld_00, grow0, gcolp, epi);
-        load_pre_n<TO, 8, DACT == A4R_DACT_MULQ8_>(pre_ld_01, grow0, gcolp + 32, epi);
+    constexpr bool R1PF = sizeof(TO) == 2 && DACT == A4R_ACT_NONE && EF >= 0 && (EF & 2) != 0;      // (EF & 2: the launch HAS an R1 -- no run-time test around register arrays)
+    constexpr int PRE_D = DACT == A4R_DACT_MULQ8_ ? A4R_PF_Q8 : 1, R1_D = A4R_PF_R1;
+#define A4R_SLOTS(name_, n_) uint4 name_##0_0[n_], name_##0_1[n_], name_##1_0[n_], name_##1_1[n_], name_##2_0[n_], name_##2_1[n_], name_##3_0[n_],  \
+        name_##3_1[n_], name_##4_0[n_], name_##4_1[n_], name_##5_0[n_], name_##5_1[n_], name_##6_0[n_], name_##6_1[n_], name_##7_0[n_], name_##7_1[n_], \
+        name_##8_0[n_], name_##8_1[n_];
+    A4R_SLOTS(pre_s, PS)
+    A4R_SLOTS(r1_s, 1)
+#undef A4R_SLOTS
+#define A4R_LD_PRE(r_)                                                                                                      \
+    if constexpr (DACT != A4R_ACT_NONE && (r_) < 8 && !(A4R_ABL & 256)) {                                                   \
+        load_pre_n<TO, 8, DACT == A4R_DACT_MULQ8_>(pre_s##r_##_0, grow0 + (r_) * 16, gcolp, epi);                           \
+        load_pre_n<TO, 8, DACT == A4R_DACT_MULQ8_>(pre_s##r_##_1, grow0 + (r_) * 16, gcolp + 32, epi);                      \
     }
-    // the residual operand R1 (dgrad GEMMs: the gradient of the residual branch) likewise one row ahead (bf16 outputs: 4 registers
-    // per group; the ping-pong K loop left the registers for it)
-    constexpr bool R1PF = sizeof(TO) == 2 && DACT == A4R_ACT_NONE && (EF < 0 || (EF & 2));
-    uint4 r1_ld[2][2][1];
-    if constexpr (R1PF) {
-        if (epi.R1) {
-            load_res_n<TO, 8>(r1_ld[0][0], epi.R1, epi.ldr1, grow0, gcolp);
-            load_res_n<TO, 8>(r1_ld[0][1], epi.R1, epi.ldr1, grow0, gcolp + 32);
-        }
+#define A4R_LD_R1(r_)                                                                                                       \
+    if constexpr (R1PF && (r_) < 8) {                                                                                       \
+        load_res_n<TO, 8>(r1_s##r_##_0, epi.R1, epi.ldr1, grow0 + (r_) * 16, gcolp);                                        \
+        load_res_n<TO, 8>(r1_s##r_##_1, epi.R1, epi.ldr1, grow0 + (r_) * 16, gcolp + 32);                                   \
     }
+    // rows 0 .. D - 1 before the first row is processed; row mi + D while row mi is
+#define A4R_LD_FIRST(LD_, D_)                                                                                               \
+    LD_(0) if constexpr ((D_) > 1) { LD_(1) } if constexpr ((D_) > 2) { LD_(2) LD_(3) } if constexpr ((D_) > 4) { LD_(4) LD_(5) LD_(6) LD_(7) }
+    A4R_LD_FIRST(A4R_LD_PRE, PRE_D)
+    A4R_LD_FIRST(A4R_LD_R1, R1_D)
+#undef A4R_LD_FIRST
+#define A4R_LD_AHEAD(LD_, D_, n1_, n2_, n4_)                                                                                \
+    if constexpr ((D_) == 1) { LD_(n1_) } else if constexpr ((D_) == 2) { LD_(n2_) } else if constexpr ((D_) == 4) { LD_(n4_) }
 #define A4R_EPI_CDST(mi_, pr_) (reinterpret_cast<TO*>(c_tile + (c_lane + (uint32_t)(mi_) * c_rowstep)) + (pr_) * 32)
 #if (A4R_ABL & 32)      /* timing-only experiment: every store instruction covers whole 128-byte lines (8 rows x 128 B); WRONG data placement */
 #define A4R_EPI_CALL(mi_, pr_)                                                                                              \
@@ -396,7 +416,7 @@ __global__ void __launch_bounds__(512, 2) gemm_nt_256_kernel(const a4r_gemm_t p,
 #define A4R_EPI_CALL(mi_, pr_)                                                                                              \
         epilogue_n<TO, 8, ACT, DACT, R1PF, true, EF>(v_, bias8[pr_], grow0 + (mi_) * 16, gcolp + (pr_) * 32, epi,
 #endif
-#define A4R_EPI_PAIR(mi_, pr_, par_)                                                                                        \
+#define A4R_EPI_PAIR(mi_, pr_)                                                                                        \
     {                                                                                                                       \
         float v_[8];                                                                                                        \
         _Pragma("unroll") for (int r_ = 0; r_ < 4; ++r_) {                                                                  \
@@ -410,25 +430,21 @@ __global__ void __launch_bounds__(512, 2) gemm_nt_256_kernel(const a4r_gemm_t p,
         }                                                                                                                   \
         const uint64_t e0_ = e0_lane + (e0_tile + (uint64_t)((mi_) * 16) * (uint64_t)epi.N + (pr_) * 32);                      \
         A4R_EPI_CALL(mi_, pr_)                                                                                              \
-                                           DACT != A4R_ACT_NONE ? pre_ld_##par_##pr_ : nullptr, R1PF ? r1_ld[(mi_) & 1][pr_] : nullptr, nullptr, \
+                                           DACT != A4R_ACT_NONE ? pre_s##mi_##_##pr_ : nullptr, R1PF ? r1_s##mi_##_##pr_ : nullptr, nullptr, \
                                            A4R_EPI_CDST(mi_, pr_), e0_);                                                    \
     }
-#define A4R_EPI_ROW(mi_, par_, npar_)                                                                                       \
-    if constexpr (DACT != A4R_ACT_NONE && (mi_) < 7 && !(A4R_ABL & 256)) {                                                  \
-        load_pre_n<TO, 8, DACT == A4R_DACT_MULQ8_>(pre_ld_##npar_##0, grow0 + ((mi_) + 1) * 16, gcolp, epi);                \
-        load_pre_n<TO, 8, DACT == A4R_DACT_MULQ8_>(pre_ld_##npar_##1, grow0 + ((mi_) + 1) * 16, gcolp + 32, epi);           \
-    }                                                                                                                       \
-    if constexpr (R1PF && (mi_) < 7) {                                                                                      \
-        if (epi.R1) {                                                                                                       \
-            load_res_n<TO, 8>(r1_ld[((mi_) + 1) & 1][0], epi.R1, epi.ldr1, grow0 + ((mi_) + 1) * 16, gcolp);                \
-            load_res_n<TO, 8>(r1_ld[((mi_) + 1) & 1][1], epi.R1, epi.ldr1, grow0 + ((mi_) + 1) * 16, gcolp + 32);           \
-        }                                                                                                                   \
-    }                                                                                                                       \
-    A4R_EPI_PAIR(mi_, 0, par_) A4R_EPI_PAIR(mi_, 1, par_)
-    A4R_EPI_ROW(0, 0, 1) A4R_EPI_ROW(1, 1, 0) A4R_EPI_ROW(2, 0, 1) A4R_EPI_ROW(3, 1, 0) A4R_EPI_ROW(4, 0, 1) A4R_EPI_ROW(5, 1, 0) A4R_EPI_ROW(6, 0, 1) A4R_EPI_ROW(7, 1, 0)
+#define A4R_EPI_ROW(mi_, n1_, n2_, n4_)                                                                                     \
+    A4R_LD_AHEAD(A4R_LD_PRE, PRE_D, n1_, n2_, n4_)                                                                          \
+    A4R_LD_AHEAD(A4R_LD_R1, R1_D, n1_, n2_, n4_)                                                                            \
+    A4R_EPI_PAIR(mi_, 0) A4R_EPI_PAIR(mi_, 1)
+    A4R_EPI_ROW(0, 1, 2, 4) A4R_EPI_ROW(1, 2, 3, 5) A4R_EPI_ROW(2, 3, 4, 6) A4R_EPI_ROW(3, 4, 5, 7) A4R_EPI_ROW(4, 5, 6, 8) A4R_EPI_ROW(5, 6, 7, 8)
+    A4R_EPI_ROW(6, 7, 8, 8) A4R_EPI_ROW(7, 8, 8, 8)
 #undef A4R_EPI_ROW
 #undef A4R_EPI_PAIR
 #undef A4R_EPI_CDST
+#undef A4R_LD_AHEAD
+#undef A4R_LD_PRE
+#undef A4R_LD_R1
     A4R_TLT(3)
 #ifdef A4R_STAMP
     ++tile_no_;

@@ -42,10 +42,8 @@ template <int NC> A4R_DEV void store_q8(uint8_t* p, const float* d) {
     for (int g = 0; g < NC / 4; ++g) {
         w[g] = 0;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const float q = fminf(fmaxf(rintf((d[4 * g + i] + A4R_Q8_OFF) * (1.f / A4R_Q8_STEP)), 0.f), 255.f);
-            w[g] |= (uint32_t)q << (8 * i);
-        }
+        for (int i = 0; i < 4; ++i)      // v_cvt_pk_u8_f32: saturating float -> byte i of the word (of an integer-valued float: no rounding question)
+            w[g] = __builtin_amdgcn_cvt_pk_u8_f32(rintf((d[4 * g + i] + A4R_Q8_OFF) * (1.f / A4R_Q8_STEP)), (uint32_t)i, w[g]);
     }
     if constexpr (NC == 8) *reinterpret_cast<uint2*>(p) = make_uint2(w[0], w[1]);
     else *reinterpret_cast<uint32_t*>(p) = w[0];
@@ -119,7 +117,7 @@ A4R_DEV void epilogue_n(float (&v)[NC], const float* bias, uint32_t grow, int gc
     const int act = ACT >= 0 ? ACT : e.act;
     const int dact = DACT >= 0 ? DACT : e.dact;
     const uint32_t thr16 = (EF < 0 || (EF & 1)) ? e.thr16 : 0u;
-    const bool has_r1 = (EF < 0 || (EF & 2)) && e.R1, has_r2 = (EF < 0 || (EF & 4)) && e.R2, has_c2 = (EF < 0 || (EF & 8)) && e.C2;
+    const bool has_r1 = R1PF || ((EF < 0 || (EF & 2)) && e.R1), has_r2 = (EF < 0 || (EF & 4)) && e.R2, has_c2 = (EF < 0 || (EF & 8)) && e.C2;
 #pragma unroll
     for (int i = 0; i < NC; ++i) v[i] = v[i] * e.alpha + bias[i];
     if (act == A4R_ACT_GELU && has_c2 && e.c2_mode) {          // value and derivative from one exp + one rcp

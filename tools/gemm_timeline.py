@@ -15,17 +15,34 @@ from adapter4rec_amd import _lib as L
 dev = torch.device('cuda:0')
 M = int(os.environ.get('M', 40448))
 L.gemm_variant(4)
-for N, K in ((768, 3072), (768, 768), (3072, 768), (2304, 768)):
+FORMS = os.environ.get('FORMS', 'plain').split(',')          # plain, bias, drop, res, gelu8, dmul8 (the step's epilogue forms)
+for N, K, form in [(n, k, f) for f in FORMS for n, k in (((768, 3072), (768, 768), (3072, 768), (2304, 768)) if f == 'plain' else ((3072, 768),) if f in ('gelu8', 'dmul8') else ((768, 768), (768, 3072)))]:
     A = torch.randn(M, K, device=dev).bfloat16()
     B = (torch.randn(N, K, device=dev) * 0.05).bfloat16()
     Cc = torch.empty(M, N, device=dev, dtype=torch.bfloat16)
+    bias = torch.zeros(N, device=dev)
+    if form == 'plain':
+        run = lambda: L.gemm_nt(A, B, Cc)
+    elif form == 'bias':
+        run = lambda: L.gemm_nt(A, B, Cc, bias=bias)
+    elif form == 'drop':
+        run = lambda: L.gemm_nt(A, B, Cc, bias=bias, drop_p=0.1, drop_site=3, drop_seed=11)
+    elif form == 'res':
+        R1 = torch.randn(M, N, device=dev).bfloat16()
+        run = lambda: L.gemm_nt(A, B, Cc, R1=R1)
+    elif form == 'gelu8':
+        C8 = torch.empty(M, N, device=dev, dtype=torch.uint8)
+        run = lambda: L.gemm_nt(A, B, Cc, bias=bias, C2=C8, act=L.ACT_GELU, c2_deriv='q8')
+    elif form == 'dmul8':
+        P8 = torch.randint(0, 256, (M, N), device=dev, dtype=torch.uint8)
+        run = lambda: L.gemm_nt(A, B, Cc, Pre=P8, dact=L.DACT_MUL_Q8)
     for _ in range(100):
-        L.gemm_nt(A, B, Cc)
+        run()
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     for _ in range(20):
-        L.gemm_nt(A, B, Cc)
+        run()
     e1.record()
     torch.cuda.synchronize()
     us = e0.elapsed_time(e1) / 20 * 1e3
@@ -39,7 +56,7 @@ for N, K in ((768, 3072), (768, 768), (3072, 768), (2304, 768)):
     def q(col, sel=slice(None)):
         v = rel[sel, col]
         return f'{np.median(v):6.1f} [{v.min():6.1f} {v.max():6.1f}]'
-    print(f'N={N} K={K}: launch {us:6.1f} us ({ntile} tiles = {ntile / 256:.2f} rounds)   us after the first entry: median [min max] over 256 workgroups')
+    print(f'{form} N={N} K={K}: launch {us:6.1f} us ({ntile} tiles = {ntile / 256:.2f} rounds)   us after the first entry: median [min max] over 256 workgroups')
     print(f'   entry {q(0)}')
     for t in range(min(3, (ntile + 255) // 256)):
         has = rel[:, 1 + 3 * t] > 0 if t else slice(None)
