@@ -33,7 +33,8 @@ def pad_to(n, m):
 import os as _os
 TN2 = bool(int(_os.environ.get('A4R_TN2', '1')))                       # an adapter's two weight gradients in one launch (0: two a4r_gemm_tn, A/B)
 FUSE_BD = bool(int(_os.environ.get('A4R_FUSE_BD', '1')))               # db_down from the fused adapter backward kernel (0: a4r_colsum launches, A/B)
-WGRAD_STREAM = bool(int(_os.environ.get('A4R_WGRAD_STREAM', '1')))     # adapter weight gradients on a side stream (see _adapter_wgrads); 0 = single stream
+WGRAD_STREAM = bool(int(_os.environ.get('A4R_WGRAD_STREAM', '0')))     # 1 = adapter weight gradients on a side stream (see _adapter_wgrads): +1.3 % in round 1, neutral since the GEMM's
+                                                                        # late-starting workgroups use the same idle CUs (same-box 19.07 vs 18.98 ms): off by default
 
 class _LN:
     """LayerNorm parameters (fp32) + optional gradient sinks."""

@@ -161,7 +161,16 @@ class GemmProbe:
             elif bf16_in and N == 64 and M % 64 == 0:
                 tile = ('skinny64',)
             elif M % 256 == 0 and N % 256 == 0 and (K * A.element_size()) % 128 == 0:
-                tile = (256,) + ad
+                # + the epilogue instantiation (a4r_gemm256.hip dispatch_same: pieces a launch carries, bit 1 dropout, 2 R1, 4 R2, 8 C2;
+                # -1 = the all-purpose instantiation) -- each is its own row in a rocprofv3 summary
+                names = ('bias', 'C2', 'R1', 'R2', 'Pre', 'act', 'dact', 'alpha', 'drop_p')
+                kw = dict(zip(names, a)); kw.update(k)
+                m = (1 if kw.get('drop_p', 0.0) > 0 else 0) | (2 if kw.get('R1') is not None else 0) | (4 if kw.get('R2') is not None else 0) | (8 if kw.get('C2') is not None else 0)
+                inst = {(0, 0): (0, 1, 2), (self.L.ACT_GELU, 0): (8,), (0, self.L.DACT_MUL_Q8): (0,), (0, self.L.DACT_MUL): (0,)}
+                if A.dtype == torch.uint8:                   # e4m3 operands
+                    inst = {(0, 0): (0,), (self.L.ACT_GELU, 0): (8,)}
+                ef = m if (A.dtype in (torch.bfloat16, torch.uint8) and Cout.dtype == torch.bfloat16 and m in inst.get(ad, ())) else -1
+                tile = (256,) + ad + (ef,)
             else:
                 tile = (128 if N % 128 == 0 else 64,)
             self.rec.append((str(A.dtype), str(Cout.dtype), tile, M, N, K, e0, e1))
@@ -446,24 +455,29 @@ def main():
         total_t = sum(v[1] for v in agg.values())
         peak = 157.3 if a.dtype == 'fp32' else MFMA_BF16_PEAK_TFLOPS      # (the non-scaled e4m3 MFMA issues at the bf16 rate: same peak)
         roof = dict(bound='mfma', achieved=round(ach, 2), peak=peak, unit='TFLOP/s', frac=round(ach / peak, 4), traffic=None,
-                    kernel=(f'gemm_nt_256_kernel<{a.dtype},{a.dtype},act={key[2][1]},dact={key[2][2]}>' if key[2][0] == 256 else (f'{key[2][0]}_kernel<{a.dtype},{a.dtype}>' if isinstance(key[2][0], str) else f'gemm_nt_kernel<{a.dtype},{a.dtype},{key[2][0]}>')), launches_per_step=n // 2,
+                    kernel=(f'gemm_nt_256_kernel<{a.dtype},{a.dtype},act={key[2][1]},dact={key[2][2]},epilogue_pieces={key[2][3]}>' if key[2][0] == 256 else (f'{key[2][0]}_kernel<{a.dtype},{a.dtype}>' if isinstance(key[2][0], str) else f'gemm_nt_kernel<{a.dtype},{a.dtype},{key[2][0]}>')), launches_per_step=n // 2,
                     avg_launch_us=round(t / n * 1e6, 2), flop_per_launch=f / n,
-                    all_gemm_tflops=round(total_f / total_t / 1e12, 2), gemm_time_share_of_step=round(total_t / 2 / (dt / a.steps), 3),
+                    all_gemm_tflops=round(total_f / total_t / 1e12, 2),
+                    # every instantiation of the 256-tile kernel with the activation template arguments of the dominant one (round 1 - 2's
+                    # `<0,0>` row: the epilogue instantiations were one kernel then)
+                    same_act_family_tflops=round(sum(v[0] for k, v in agg.items() if k[2][:3] == key[2][:3] and k[0] == key[0]) /
+                                                 sum(v[1] for k, v in agg.items() if k[2][:3] == key[2][:3] and k[0] == key[0]) / 1e12, 2),
+                    same_act_family_launches_per_step=sum(v[2] for k, v in agg.items() if k[2][:3] == key[2][:3] and k[0] == key[0]) // 2, gemm_time_share_of_step=round(total_t / 2 / (dt / a.steps), 3),
                     step_tflops_per_gpu=round(a.batch * a.steps / dt * GFLOP_PER_USER[wl] / 1e3, 1),
                     step_frac_of_peak=round(a.batch * a.steps / dt * GFLOP_PER_USER[wl] / 1e3 / peak, 4))
         if fp8_t > 0:
             roof['fp8_gemm_tflops'] = round(fp8_f / fp8_t / 1e12, 2)
             roof['fp8_share_of_gemm_flops'] = round(fp8_f / total_f, 3)
         # fabric/HBM bytes per launch of that kernel: not measurable from inside the process -- taken from the committed
-        # rocprofv3 PMC passes over this same command (profiles/r02_i_pmc_hbm_traffic.json says how); only when the run IS that
+        # rocprofv3 PMC passes over this same command (profiles/r02_j_pmc_hbm_traffic.json says how); only when the run IS that
         # command's configuration (bert_houlsby, B=32, bf16), null otherwise.
-        pmc = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles', 'r02_i_pmc_hbm_traffic.json')
+        pmc = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles', 'r02_j_pmc_hbm_traffic.json')
         if key[2][0] == 256 and a.dtype == 'bf16' and a.batch == 32 and wl == 'bert_houlsby' and os.path.exists(pmc):
-            mangled = f'gemm_nt_256_kernelIDF16bDF16bLi{key[2][1]}ELi{key[2][2]}E'
+            mangled = f'gemm_nt_256_kernelIDF16bDF16bLi{key[2][1]}ELi{key[2][2]}ELi{key[2][3]}E'.replace('Li-1E', 'Lin1E')
             for kname, rec in json.load(open(pmc))['kernels'].items():
                 if mangled in kname:
                     roof['traffic'] = rec['traffic_bytes_per_launch']
-                    roof['traffic_source'] = ('NOT measured in this run: profiles/r02_i_pmc_hbm_traffic.json, separate rocprofv3 --pmc FETCH_SIZE / '
+                    roof['traffic_source'] = ('NOT measured in this run: profiles/r02_j_pmc_hbm_traffic.json, separate rocprofv3 --pmc FETCH_SIZE / '
                                               'WRITE_SIZE passes over this same command (2 x FETCH correction of the gfx950 guide)')
         if os.environ.get('A4R_BENCH_SHAPES'):
             print(json.dumps(shapes, indent=1), file=sys.stderr)

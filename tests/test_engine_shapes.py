@@ -138,3 +138,12 @@ def test_large_then_small_batch_host_logic(simulated, case):
 @pytest.mark.parametrize('case', ['short_titles', 'five_users_cpc', 'long_history_32'])
 def test_large_then_small_batch_gpu(case):
     large_then_small(case, 'cuda:0')
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('case', ['one_user', 'four_users_wide_adapters'])
+def test_wgrad_side_stream_gpu(monkeypatch, case):
+    """A4R_WGRAD_STREAM=1 (adapter weight gradients on a side stream; off by default since the end of round 2) against the oracle."""
+    import adapter4rec_amd.engine as E
+    monkeypatch.setattr(E, 'WGRAD_STREAM', True)
+    check(case, 'cuda:0')
