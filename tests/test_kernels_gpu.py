@@ -1017,3 +1017,42 @@ def test_gemm_tail_panels_split_launch():
     close(c_a, c_b, torch.bfloat16, 'split vs single launch', rtol16=2e-2, atol16=2e-2)
     close(c2_a[-768:], c2_b[-768:], torch.bfloat16, 'tail C2', rtol16=2e-2, atol16=2e-2)
     assert float((c_a[-768:] != R1[-768:]).float().mean()) > 0.5     # the tail was really written
+
+
+@pytest.mark.parametrize('K', [192, 256, 768])
+def test_gemm256_many_tiles_per_workgroup(K):
+    """540 output tiles on 256 persistent workgroups: every workgroup walks 2 - 3 tiles, so the unit stream continues ACROSS tiles
+    (K / 64 even) or a prologue is issued per tile (K / 64 odd: K = 192), workgroups with a tile of slack start late, and each epilogue
+    instantiation of the training step (plain, dropout, residual, GELU + 8-bit derivative, * 8-bit derivative) runs on tiles that are
+    not a workgroup's first.  Checked against the 128-tile kernel (same epilogue code, one tile per workgroup) and fp32 torch."""
+    from adapter4rec_amd import _lib as L
+    t = torch.bfloat16
+    M, N = 180 * 256, 768
+    A, B = rnd(M, K, dtype=t, seed=81), rnd(N, K, dtype=t, scale=0.05, seed=82)
+    bias, R1 = rnd(N, seed=83), rnd(M, N, dtype=t, seed=84)
+    P8 = torch.randint(0, 256, (M, N), device=dev(), dtype=torch.uint8, generator=torch.Generator(device=dev()).manual_seed(85))
+    res = []
+    for v in (4, 1):
+        old = L.gemm_variant(v)
+        plain, drop, resid, gel, dm = (torch.zeros(M, N, dtype=t, device=dev()) for _ in range(5))
+        C8 = torch.zeros(M, N, dtype=torch.uint8, device=dev())
+        L.gemm_nt(A, B, plain, bias=bias)
+        L.gemm_nt(A, B, drop, bias=bias, drop_p=0.1, drop_site=3, drop_seed=11)
+        L.gemm_nt(A, B, resid, R1=R1)
+        L.gemm_nt(A, B, gel, bias=bias, C2=C8, act=L.ACT_GELU, c2_deriv='q8')
+        L.gemm_nt(A, B, dm, Pre=P8, dact=L.DACT_MUL_Q8)
+        L.gemm_variant(old)
+        res.append((plain, drop, resid, gel, C8, dm))
+    names = ('plain', 'dropout', 'residual', 'gelu', 'gelu derivative q8', '* derivative q8')
+    for nm, a, b in zip(names, res[0], res[1]):
+        if a.dtype == torch.uint8:
+            assert int((a.int() - b.int()).abs().max()) <= 1, nm
+        else:
+            close(a, b, t, nm + ': 256-tile vs 128-tile kernel', rtol16=2e-2, atol16=2e-2)
+    assert torch.equal(res[0][1] == 0, res[1][1] == 0), 'dropout pattern'
+    rows = torch.arange(0, M, 997, device=dev())                  # sampled rows of every panel region, incl. the last tiles
+    pre = A[rows].float() @ B.float().t()
+    close(res[0][0][rows], pre + bias, t, 'plain vs torch')
+    close(res[0][2][rows], pre + R1[rows].float(), t, 'residual vs torch')
+    close(res[0][3][rows], torch.nn.functional.gelu(pre + bias), t, 'gelu vs torch')
+    close(res[0][5][rows], pre * (P8[rows].float() * L.Q8_STEP - L.Q8_OFF), t, '* derivative vs torch')
