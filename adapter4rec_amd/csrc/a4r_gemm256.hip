@@ -28,6 +28,15 @@
 //        phase 1 B_hi (phase 0), phase 2 A_hi (phase 1).
 //   WAR  a slot is re-filled no earlier than two phases after its last read: phase 0 issues B_hi(t+1) (slot last read in phase 1
 //        of t-1), phase 1 A_hi(t+1) (phase 2 of t-1), phase 2 A_lo(t+2) (phase 0 of t), phase 3 B_lo(t+2) (phase 0 of t).
+//
+// Between output tiles (a workgroup is persistent and walks 2 - 8 tiles per launch; tools/gemm_timeline.py stamps this part):
+//   * the unit stream does NOT stop at the end of a tile's K range: with an even K-tile count the issue slots of the last two
+//     K-tiles fetch K-tiles 0 and 1 (first six units) of the workgroup's NEXT output tile into the same ring positions (same issue
+//     pattern as the steady state, so the RAW / WAR arguments above hold unchanged); odd counts issue a six-unit prologue instead;
+//   * the accumulators are zeroed inside the LOAD segments of the first K-tile (the compiler peels it into MFMAs with C = 0);
+//   * the epilogue (straight from the accumulators, no LDS) is instantiated per set of optional pieces (EF: dropout, R1, R2, C2), reads
+//     its Pre / R1 operands of the whole tile up front, and is followed by a counted vmcnt(16): the stores drain behind the next K loop;
+//   * workgroups that own one tile fewer than the busiest of their XCD start a fraction of a tile period late (A4R_GEMM_STAGGER).
 #include <stdlib.h>
 #include "a4r_gemm_epi.h"
 
