@@ -105,9 +105,10 @@ __global__ void __launch_bounds__(256) gemm_nt_kernel(const a4r_gemm_t p, int nt
 
     if constexpr (GLDS) {
         stage_glds<TI, BN>(lds0, A, lda, B, ldb, 0, wave, lane);
-        __syncthreads();
+        if (nk > 1) stage_glds<TI, BN>(lds1, A, lda, B, ldb, KT, wave, lane);       // the first TWO stages are requested together: the small
+        __syncthreads();                                                             // fp32 launches (2 K stages) pay one load latency, not two
         for (int kt = 0; kt < nk; kt += 2) {
-            if (kt + 1 < nk) stage_glds<TI, BN>(lds1, A, lda, B, ldb, (kt + 1) * KT, wave, lane);
+            if (kt > 0 && kt + 1 < nk) stage_glds<TI, BN>(lds1, A, lda, B, ldb, (kt + 1) * KT, wave, lane);
             compute_stage<TI, BN>(lds0, wm, wn, lane, acc);
             __syncthreads();
             if (kt + 1 < nk) {
