@@ -29,8 +29,23 @@
 //     re-requests itself instead of branching).
 // Three workgroup barriers per tile.  The kernels are HBM-bound: 24 MFMAs per wave per 96 KB of traffic.
 #include <cstdlib>
+#include <type_traits>
 #include "a4r_common.h"
 #include "../../include/a4r.h"
+
+#ifdef A4R_STAMP
+// diagnostic build only (tools/adapter_timeline.py): s_memrealtime of waves 0 and 7 of every workgroup around the three barriers of its
+// THIRD backward tile: [wg][wave 0 / 7][top, before / after barrier 1, before / after barrier 2, before / after barrier 3, end]
+__device__ unsigned long long g_a4r_ad_stamps[256 * 2 * 8];
+extern "C" int a4r_debug_adapter_stamps(unsigned long long* host_out) {
+    return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_a4r_ad_stamps), sizeof(g_a4r_ad_stamps)) == hipSuccess ? 0 : -2;
+}
+#define A4R_AD_ST(k_)                                                                                                  \
+    if (lane == 0 && (wave == 0 || wave == NW - 1) && tile == (int)blockIdx.x + 2 * (int)gridDim.x && blockIdx.x < 256)  \
+        g_a4r_ad_stamps[(blockIdx.x * 2 + (wave ? 1 : 0)) * 8 + (k_)] = __builtin_amdgcn_s_memrealtime();
+#else
+#define A4R_AD_ST(k_)
+#endif
 
 namespace {
 
@@ -258,13 +273,21 @@ struct AdBwdArgs {
     const bf16_t* WuT; const bf16_t* WdT; int inner_res;
     bf16_t* dv; bf16_t* dzp; bf16_t* dh; int lddv, lddh;
     float* dgamma; float* dbeta; float* dbias; float* dbd;
-    int M, bias_total, abl;      // abl: timing ablations (A4R_ADAPTER_BWD_ABL; wrong results): 1 no stores, 2 no tile loads
+    int M, bias_total;
     uint64_t seed; uint32_t site, thr16; float keep_scale;
 };
 
 // WGB: accumulate dgamma / dbeta (trainable LayerNorm: Pfeiffer's LN_new, --finetune_layernorm); WDB: dbias = column sums of dv
 // BEFORE dres is added (the up-projection bias sits inside the LayerNorm input).
-template <int CW, int NW, bool WGB, bool WDB>
+// DRES: a gradient arrives along the residual stream as well (pre-LN towers) and is read row by row like dy and v.
+// Every global load and store of the tile loop is UNCONDITIONAL (template flags, the timing-only A4R_AD_ABL macro): with run-time tests
+// around them (`if (p.dres)`, an ablation knob read from the arguments) the number of operations behind a load differs by path and hipcc falls
+// back to s_waitcnt vmcnt(0) -- at the top of every tile and in front of the act' operand -- which drains the tile's own stores and the
+// requests for the next tiles every time (adapter_ln_bwd 67 -> 74 us in the step when the knob went in).
+#ifndef A4R_AD_ABL
+#define A4R_AD_ABL 0          /* timing-only diagnostic builds (-DA4R_AD_ABL=n): 1 no tile stores, 2 no tile loads */
+#endif
+template <int CW, int NW, bool WGB, bool WDB, bool DRES>
 __global__ void __launch_bounds__(NW * 64) adapter_ln_bwd_kernel(const AdBwdArgs p) {
     constexpr int KS = CW / 32, H = CW * NW, NT = NW * 64, EPT = 1024 / NT;
     __shared__ __attribute__((aligned(16))) float zpart[NW][16][ZLD];
@@ -308,40 +331,44 @@ __global__ void __launch_bounds__(NW * 64) adapter_ln_bwd_kernel(const AdBwdArgs
         for (int j = 0; j < 8; ++j) { sg[s][j] = 0.f; sb[s][j] = 0.f; sv[s][j] = 0.f; }
 
     const int ntiles = p.M / 16;
-    uint4 d_cur[KS], v_cur[KS], d_nxt[KS], v_nxt[KS];
-    float2 st_cur, st_nxt;
-    {
-        const size_t row = (size_t)blockIdx.x * 16 + fr;
+    // rows are requested TWO tiles ahead where the registers allow it (DEEP): with ~12 MB in flight chip-wide a request takes longer than the
+    // ~5 us of arithmetic of one tile.  The thread's EPT pre-activations (operand of act') and the DRES rows travel with them.
+    constexpr bool DEEP = CW < 96 || (!WGB && !DRES);
+    typedef typename std::conditional<EPT == 2, uint32_t, uint2>::type zp_t;
+    struct Rows { uint4 d[KS], v[KS], r[DRES ? KS : 1]; float2 st; zp_t zp; };
+    auto request = [&](Rows& R, int t) {
+        const size_t row = (size_t)t * 16 + fr;
 #pragma unroll
         for (int s = 0; s < KS; ++s) {
-            d_cur[s] = *reinterpret_cast<const uint4*>(p.dy + row * p.lddy + cl + s * 32);
-            v_cur[s] = *reinterpret_cast<const uint4*>(p.v + row * p.ldv + cl + s * 32);
+            if (A4R_AD_ABL & 2) { R.d[s] = make_uint4(0x3c003c00u, 0x3c003c00u, 0x3c003c00u, 0x3c003c00u); R.v[s] = R.d[s]; if constexpr (DRES) R.r[s] = R.d[s]; continue; }
+            R.d[s] = *reinterpret_cast<const uint4*>(p.dy + row * p.lddy + cl + s * 32);
+            R.v[s] = *reinterpret_cast<const uint4*>(p.v + row * p.ldv + cl + s * 32);
+            if constexpr (DRES) R.r[s] = *reinterpret_cast<const uint4*>(p.dres + row * p.lddres + cl + s * 32);
         }
-        st_cur = *reinterpret_cast<const float2*>(p.stats + 2 * row);
-    }
+        R.st = (A4R_AD_ABL & 2) ? make_float2(0.f, 1.f) : *reinterpret_cast<const float2*>(p.stats + 2 * row);
+        R.zp = *reinterpret_cast<const zp_t*>(p.zp + ((size_t)t * 16 + rrow) * 64 + rzd);
+    };
+    const int G = (int)gridDim.x;
+    Rows cur, nxt, nn;
+    request(cur, (int)blockIdx.x);
+    if constexpr (DEEP) request(nxt, (int)blockIdx.x + G < ntiles ? (int)blockIdx.x + G : (int)blockIdx.x);
     A4R_LDS_BARRIER();
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         {
-            const int tn = tile + (int)gridDim.x < ntiles ? tile + (int)gridDim.x : tile;
-            const size_t row = (size_t)tn * 16 + fr;
-#pragma unroll
-            for (int s = 0; s < KS; ++s) {
-                if (p.abl & 2) { d_nxt[s] = make_uint4(0x3c003c00u, 0x3c003c00u, 0x3c003c00u, 0x3c003c00u); v_nxt[s] = d_nxt[s]; continue; }
-                d_nxt[s] = *reinterpret_cast<const uint4*>(p.dy + row * p.lddy + cl + s * 32);
-                v_nxt[s] = *reinterpret_cast<const uint4*>(p.v + row * p.ldv + cl + s * 32);
-            }
-            st_nxt = (p.abl & 2) ? make_float2(0.f, 1.f) : *reinterpret_cast<const float2*>(p.stats + 2 * row);
+            const int ahead = (DEEP ? 2 : 1) * G;
+            request(nn, tile + ahead < ntiles ? tile + ahead : tile);       // (past the end: re-request this tile, the schedule stays static)
         }
+        A4R_AD_ST(0)
         const size_t row = (size_t)tile * 16 + fr;
-        const float mean = st_cur.x, rstd = st_cur.y;
+        const float mean = cur.st.x, rstd = cur.st.y;
         // ---- LayerNorm backward, part 1: xhat, g = dy * gamma, the two row means
         float xh[KS][8], g[KS][8];
         float c1 = 0.f, c2 = 0.f;
 #pragma unroll
         for (int s = 0; s < KS; ++s) {
             float d8[8], ga8[8];
-            Elem<bf16_t>::unpack(d_cur[s], d8);
-            Elem<bf16_t>::unpack(v_cur[s], xh[s]);
+            Elem<bf16_t>::unpack(cur.d[s], d8);
+            Elem<bf16_t>::unpack(cur.v[s], xh[s]);
             *reinterpret_cast<float4*>(ga8) = *reinterpret_cast<const float4*>(&par[cl + s * 32]);
             *reinterpret_cast<float4*>(ga8 + 4) = *reinterpret_cast<const float4*>(&par[cl + s * 32 + 4]);
 #pragma unroll
@@ -358,7 +385,9 @@ __global__ void __launch_bounds__(NW * 64) adapter_ln_bwd_kernel(const AdBwdArgs
         c1 = kg_sum(c1);
         c2 = kg_sum(c2);
         if (kg == 0) { red[wave][fr][0] = c1; red[wave][fr][1] = c2; }
+        A4R_AD_ST(1)
         A4R_LDS_BARRIER();
+        A4R_AD_ST(2)
         c1 = 0.f; c2 = 0.f;
 #pragma unroll
         for (int w = 0; w < NW; ++w) { c1 += red[w][fr][0]; c2 += red[w][fr][1]; }
@@ -374,9 +403,9 @@ __global__ void __launch_bounds__(NW * 64) adapter_ln_bwd_kernel(const AdBwdArgs
                 d8[j] = rstd * (g[s][j] - c1 - xh[s][j] * c2);
                 if constexpr (WDB) { if (!p.bias_total) sv[s][j] += d8[j]; }
             }
-            if (p.dres) {
+            if constexpr (DRES) {
                 float r8[8];
-                Elem<bf16_t>::unpack(*reinterpret_cast<const uint4*>(p.dres + row * p.lddres + cl + s * 32), r8);
+                Elem<bf16_t>::unpack(cur.r[s], r8);
 #pragma unroll
                 for (int j = 0; j < 8; ++j) d8[j] += r8[j];
             }
@@ -387,7 +416,7 @@ __global__ void __launch_bounds__(NW * 64) adapter_ln_bwd_kernel(const AdBwdArgs
                 }
             }
             dvp[s] = Elem<bf16_t>::pack(d8);
-            if (!(p.abl & 1)) *reinterpret_cast<uint4*>(p.dv + row * p.lddv + cl + s * 32) = dvp[s];
+            if (!(A4R_AD_ABL & 1)) *reinterpret_cast<uint4*>(p.dv + row * p.lddv + cl + s * 32) = dvp[s];
         }
         // ---- dz partial over this wave's columns, summed through LDS; dzp = dz * act'(zp)
         f32x4_t zacc[4];
@@ -399,17 +428,19 @@ __global__ void __launch_bounds__(NW * 64) adapter_ln_bwd_kernel(const AdBwdArgs
             for (int nt = 0; nt < 4; ++nt) Mma<bf16_t>::mma(wu[s][nt], dvp[s], zacc[nt]);
 #pragma unroll
         for (int nt = 0; nt < 4; ++nt) *reinterpret_cast<f32x4_t*>(&zpart[wave][fr][nt * 16 + kg * 4]) = zacc[nt];
+        A4R_AD_ST(3)
         A4R_LDS_BARRIER();
+        A4R_AD_ST(4)
         {
             float s_[EPT];
             reduce_partials<NW, EPT>(zpart, rrow, rzd, s_);
             const size_t gi = ((size_t)tile * 16 + rrow) * 64 + rzd;
             float pre[EPT];
             if constexpr (EPT == 2) {
-                const uint32_t u = *reinterpret_cast<const uint32_t*>(p.zp + gi);
+                const uint32_t u = cur.zp;
                 pre[0] = bf16_bits_to_f32(u & 0xffffu); pre[1] = bf16_bits_to_f32(u >> 16);
             } else {
-                const uint2 u = *reinterpret_cast<const uint2*>(p.zp + gi);
+                const uint2 u = cur.zp;
                 pre[0] = bf16_bits_to_f32(u.x & 0xffffu); pre[1] = bf16_bits_to_f32(u.x >> 16);
                 pre[2] = bf16_bits_to_f32(u.y & 0xffffu); pre[3] = bf16_bits_to_f32(u.y >> 16);
             }
@@ -418,7 +449,9 @@ __global__ void __launch_bounds__(NW * 64) adapter_ln_bwd_kernel(const AdBwdArgs
             store_bf16_n<EPT>(p.dzp + gi, s_);
             store_bf16_n<EPT>(reinterpret_cast<bf16_t*>(zbf + zbf_off(rrow, rzd)), s_);
         }
+        A4R_AD_ST(5)
         A4R_LDS_BARRIER();
+        A4R_AD_ST(6)
         // ---- dh = dzp . Wd (+ dv: the adapter's inner residual), through the dense output's dropout mask
         uint4 zf[2];
 #pragma unroll
@@ -445,12 +478,12 @@ __global__ void __launch_bounds__(NW * 64) adapter_ln_bwd_kernel(const AdBwdArgs
                     o8[e + 4] = (((uint32_t)(h1 >> (16 * e)) & 0xffffu) >= p.thr16) ? o8[e + 4] * p.keep_scale : 0.f;
                 }
             }
-            if (!(p.abl & 1)) *reinterpret_cast<uint4*>(p.dh + row * p.lddh + cl + s * 32) = Elem<bf16_t>::pack(o8);
+            if (!(A4R_AD_ABL & 1)) *reinterpret_cast<uint4*>(p.dh + row * p.lddh + cl + s * 32) = Elem<bf16_t>::pack(o8);
             else if (o8[0] == 12345.f) p.dbias[0] = o8[1];
         }
-#pragma unroll
-        for (int s = 0; s < KS; ++s) { d_cur[s] = d_nxt[s]; v_cur[s] = v_nxt[s]; }
-        st_cur = st_nxt;
+        A4R_AD_ST(7)
+        if constexpr (DEEP) { cur = nxt; nxt = nn; }
+        else cur = nn;
     }
     // ---- db_down = column sums of dzp: thread t holds columns (t EPT) & 63 of row (t EPT) >> 6 -> through LDS, one atomic per column
     if (p.dbd) {
@@ -492,14 +525,18 @@ int launch_fwd(hipStream_t s, const AdFwdArgs& a, int grid) {
     hipLaunchKernelGGL((adapter_ln_fwd_kernel<CW, NW>), dim3(grid), dim3(NW * 64), 0, s, a);
     return a4r_launch_status();
 }
+template <int CW, int NW, bool DRES>
+int launch_bwd_d(hipStream_t s, const AdBwdArgs& a, int grid) {
+    const bool wgb = a.dgamma || a.dbeta, wdb = a.dbias != nullptr;
+    if (wgb && wdb) hipLaunchKernelGGL((adapter_ln_bwd_kernel<CW, NW, true, true, DRES>), dim3(grid), dim3(NW * 64), 0, s, a);
+    else if (wgb) hipLaunchKernelGGL((adapter_ln_bwd_kernel<CW, NW, true, false, DRES>), dim3(grid), dim3(NW * 64), 0, s, a);
+    else if (wdb) hipLaunchKernelGGL((adapter_ln_bwd_kernel<CW, NW, false, true, DRES>), dim3(grid), dim3(NW * 64), 0, s, a);
+    else hipLaunchKernelGGL((adapter_ln_bwd_kernel<CW, NW, false, false, DRES>), dim3(grid), dim3(NW * 64), 0, s, a);
+    return a4r_launch_status();
+}
 template <int CW, int NW>
 int launch_bwd(hipStream_t s, const AdBwdArgs& a, int grid) {
-    const bool wgb = a.dgamma || a.dbeta, wdb = a.dbias != nullptr;
-    if (wgb && wdb) hipLaunchKernelGGL((adapter_ln_bwd_kernel<CW, NW, true, true>), dim3(grid), dim3(NW * 64), 0, s, a);
-    else if (wgb) hipLaunchKernelGGL((adapter_ln_bwd_kernel<CW, NW, true, false>), dim3(grid), dim3(NW * 64), 0, s, a);
-    else if (wdb) hipLaunchKernelGGL((adapter_ln_bwd_kernel<CW, NW, false, true>), dim3(grid), dim3(NW * 64), 0, s, a);
-    else hipLaunchKernelGGL((adapter_ln_bwd_kernel<CW, NW, false, false>), dim3(grid), dim3(NW * 64), 0, s, a);
-    return a4r_launch_status();
+    return a.dres ? launch_bwd_d<CW, NW, true>(s, a, grid) : launch_bwd_d<CW, NW, false>(s, a, grid);
 }
 
 }  // namespace
@@ -560,8 +597,6 @@ extern "C" int a4r_adapter_ln_bwd(void* stream, const void* dy, int lddy, const 
     a.WuT = reinterpret_cast<const bf16_t*>(WuT); a.WdT = reinterpret_cast<const bf16_t*>(WdT); a.inner_res = inner_res;
     a.dv = reinterpret_cast<bf16_t*>(dv); a.dzp = reinterpret_cast<bf16_t*>(dzp); a.dh = reinterpret_cast<bf16_t*>(dh);
     a.lddv = lddv; a.lddh = lddh; a.dgamma = dgamma; a.dbeta = dbeta; a.dbias = dbias; a.dbd = dbd; a.M = M; a.bias_total = flags & 1;
-    static const int abl = getenv("A4R_ADAPTER_BWD_ABL") ? atoi(getenv("A4R_ADAPTER_BWD_ABL")) : 0;
-    a.abl = abl;
     a.seed = drop_seed; a.site = drop_site; a.thr16 = a4r_thr16(drop_p); a.keep_scale = a4r_keep_scale(drop_p);
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     const int ntiles = M / 16, ncu = a4r_cu_count();
