@@ -25,23 +25,39 @@ namespace {
 
 constexpr int ROWB = 128;   // bytes of K per tile row per stage
 
+// one 1-KiB LDS-DMA: LDS[lds_dst + lane*16 .. +16) <- global[base + voff .. +16).  Inline asm, as in a4r_gemm256.hip: the compiler neither
+// counts these loads nor knows that they write LDS, so it inserts no s_waitcnt of its own -- the K loop's counted waits are the only ones
+// (with the builtin form it drained the whole ring once per turn: it cannot order a ring of in-flight DMAs against the reads).
+A4R_DEV void glds16_nt(const void* base, uint32_t voff, uint32_t lds_dst) {
+    uint32_t keep;
+    asm volatile(
+        "s_mov_b32 %0, m0\n\t"
+        "s_mov_b32 m0, %3\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dwordx4 %1, %2\n\t"
+        "s_mov_b32 m0, %0"
+        : "=&s"(keep)
+        : "v"(voff), "s"(base), "s"(lds_dst)
+        : "memory");
+}
+
 template <typename TI, int BN>
 A4R_DEV void stage_glds(char* stage, const TI* __restrict__ A, int lda, const TI* __restrict__ B, int ldb, int k0, int wave, int lane) {
     constexpr int PER = Elem<TI>::PER16;
     constexpr int NLB = BN / 32;
     const int glr = lane >> 3, glc = lane & 7;
-    char* Bs = stage + 128 * ROWB;
+    const uint32_t s0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)stage;
+    const TI* Ak = A + k0;                                  // uniform bases; per-lane byte offsets are 32-bit (128 tile rows x ld)
+    const TI* Bk = B + k0;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int q = 4 * wave + i, r = 8 * q + glr, c = glc ^ ((r >> 1) & 7);
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(A + (size_t)r * lda + k0 + c * PER),
-                                         (__attribute__((address_space(3))) void*)(stage + q * 1024), 16, 0, 0);
+        glds16_nt(Ak, (uint32_t)((r * lda + c * PER) * (int)sizeof(TI)), s0 + (uint32_t)(q * 1024));
     }
 #pragma unroll
     for (int i = 0; i < NLB; ++i) {
         const int q = NLB * wave + i, r = 8 * q + glr, c = glc ^ ((r >> 1) & 7);
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(B + (size_t)r * ldb + k0 + c * PER),
-                                         (__attribute__((address_space(3))) void*)(Bs + q * 1024), 16, 0, 0);
+        glds16_nt(Bk, (uint32_t)((r * ldb + c * PER) * (int)sizeof(TI)), s0 + (uint32_t)(128 * ROWB + q * 1024));
     }
 }
 
@@ -82,7 +98,13 @@ __global__ void __launch_bounds__(256) gemm_nt_kernel(const a4r_gemm_t p, int nt
     constexpr int SBYTES = (STAGE > 64 * BN * 4) ? STAGE : 64 * BN * 4;   // a stage also holds 64 fp32 epilogue rows
     __shared__ __attribute__((aligned(16))) char lds0[SBYTES];
     __shared__ __attribute__((aligned(16))) char lds1[SBYTES];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // GLDS: a FOUR-deep ring (distinct objects again: the compiler must see that a DMA into one does not alias the reads of another).  Three
+    // stages are in flight while one is multiplied: with two, every 128-byte K stage paid a full DMA round trip (~2 us: the tail-panel
+    // launches of the image tower, 12 - 48 stages each, were 8.5 % of its step; the SASRec tower's K = 256 launches 17 - 25 us)
+    __shared__ __attribute__((aligned(16))) char lds2[GLDS ? STAGE : 16];
+    __shared__ __attribute__((aligned(16))) char lds3[GLDS ? STAGE : 16];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // uniform: the LDS-DMA destination goes through M0
     const int wm = wave >> 1, wn = wave & 1;
 
     // bijective XCD-aware remap of the 1-D grid
@@ -104,19 +126,37 @@ __global__ void __launch_bounds__(256) gemm_nt_kernel(const a4r_gemm_t p, int nt
     const int nk = Kdim / KT;
 
     if constexpr (GLDS) {
-        stage_glds<TI, BN>(lds0, A, lda, B, ldb, 0, wave, lane);
-        if (nk > 1) stage_glds<TI, BN>(lds1, A, lda, B, ldb, KT, wave, lane);       // the first TWO stages are requested together: the small
-        __syncthreads();                                                             // fp32 launches (2 K stages) pay one load latency, not two
-        for (int kt = 0; kt < nk; kt += 2) {
-            if (kt > 0 && kt + 1 < nk) stage_glds<TI, BN>(lds1, A, lda, B, ldb, (kt + 1) * KT, wave, lane);
-            compute_stage<TI, BN>(lds0, wm, wn, lane, acc);
-            __syncthreads();
-            if (kt + 1 < nk) {
-                if (kt + 2 < nk) stage_glds<TI, BN>(lds0, A, lda, B, ldb, (kt + 2) * KT, wave, lane);
-                compute_stage<TI, BN>(lds1, wm, wn, lane, acc);
-                __syncthreads();
-            }
+        // step i (stage i lives in object i % 4): wait for THIS wave's DMAs of stage i -- a counted vmcnt: the up to two younger stages stay
+        // in flight --, barrier (every wave's part of stage i has landed; every wave is done reading stage i - 1), request stage i + 3 into
+        // the object stage i - 1 was read from, multiply stage i.
+        constexpr int DPS = 4 + NLB;                                    // DMA instructions per stage per wave
+#define A4R_WAIT_STAGE(i_)                                                                          \
+        {                                                                                           \
+            const int after_ = nk - 1 - (i_);                          /* stages requested after stage i_ */ \
+            if (after_ >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * DPS) : "memory");         \
+            else if (after_ == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(DPS) : "memory");        \
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                   \
+            __builtin_amdgcn_s_barrier();                                                           \
+            asm volatile("" ::: "memory");                                                          \
         }
+#define A4R_STEP(i_, cur_, refill_)                                                                 \
+        if ((i_) < nk) {                                                                            \
+            A4R_WAIT_STAGE(i_)                                                                      \
+            if ((i_) + 3 < nk) stage_glds<TI, BN>(refill_, A, lda, B, ldb, ((i_) + 3) * KT, wave, lane); \
+            compute_stage<TI, BN>(cur_, wm, wn, lane, acc);                                         \
+        }
+        stage_glds<TI, BN>(lds0, A, lda, B, ldb, 0, wave, lane);
+        if (nk > 1) stage_glds<TI, BN>(lds1, A, lda, B, ldb, KT, wave, lane);
+        if (nk > 2) stage_glds<TI, BN>(lds2, A, lda, B, ldb, 2 * KT, wave, lane);
+        for (int kt = 0; kt < nk; kt += 4) {
+            A4R_STEP(kt, lds0, lds3)
+            A4R_STEP(kt + 1, lds1, lds0)
+            A4R_STEP(kt + 2, lds2, lds1)
+            A4R_STEP(kt + 3, lds3, lds2)
+        }
+#undef A4R_STEP
+#undef A4R_WAIT_STAGE
+        __syncthreads();                                                // all reads done: lds0 / lds1 become the epilogue's staging rows
     } else {
         // register staging of one K stage (explicit scalars: arrays captured by reference went to scratch)
         uint4 ra0, ra1, ra2, ra3, rb0, rb1, rb2, rb3;
