@@ -108,28 +108,32 @@ __global__ void __launch_bounds__(WAVES * 64) attn_fwd_kernel(const T* __restric
     const T* base = qkv + (size_t)item * S * ld + head * DH;
 
     // (the key mask too: it used to be the third serial round trip of the wave)
+    // Loads are UNCONDITIONAL (clamped rows / keys, the out-of-range ones zeroed where they are consumed): with `if (row < S)` around
+    // them hipcc waited with vmcnt(0) after every conditional group -- three serialized round trips instead of one.
     float km[2];
 #pragma unroll
     for (int nt = 0; nt < 2; ++nt) {
         const int key = nt * 16 + r16;
-        km[nt] = (key < S) ? (key_mask ? key_mask[(size_t)item * S + key] : 1.f) : 0.f;
+        km[nt] = key_mask ? key_mask[(size_t)item * S + min(key, S - 1)] : 1.f;
     }
     // V is requested before the scores are computed (its loads used to be issued only after Q K^T had waited for Q and K)
     uint4 sv[C::NLD];
 #pragma unroll
     for (int i = 0; i < C::NLD; ++i) {
         const int id = lane + 64 * i, row = id / C::CPR, ch = id % C::CPR;
-        sv[i] = make_uint4(0u, 0u, 0u, 0u);
-        if (row < S) sv[i] = ldg16(base + (size_t)row * ld + v_off + ch * C::PER);
+        sv[i] = ldg16(base + (size_t)min(row, S - 1) * ld + v_off + ch * C::PER);
     }
     f32x4_t sc[2][2];
     qk_scores<T, DH>(base, ld, q_off, k_off, S, lane, sc);
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt)
+        if (nt * 16 + r16 >= S) km[nt] = 0.f;
 
     // stage V (rows >= S are zero so that 0 * V stays 0)
 #pragma unroll
     for (int i = 0; i < C::NLD; ++i) {
         const int id = lane + 64 * i, row = id / C::CPR, ch = id % C::CPR;
-        lds_put16<T, C::GSTRIDE>(Vs, row, ch, sv[i]);
+        lds_put16<T, C::GSTRIDE>(Vs, row, ch, row < S ? sv[i] : make_uint4(0u, 0u, 0u, 0u));
     }
 
 #pragma unroll
@@ -267,7 +271,7 @@ __global__ void __launch_bounds__(WAVES * 64) attn_bwd_kernel(const T* __restric
 #pragma unroll
     for (int nt = 0; nt < 2; ++nt) {
         const int key = nt * 16 + r16;
-        km[nt] = (key < S) ? (key_mask ? key_mask[(size_t)item * S + key] : 1.f) : 0.f;
+        km[nt] = key_mask ? key_mask[(size_t)item * S + min(key, S - 1)] : 1.f;      // (unconditional load, clamped; keys >= S zeroed below)
     }
     // Every global read of the pair is requested BEFORE anything is consumed, and every byte ONCE: the row-major operand fragments
     // of Q K^T and dO V^T (lane (r16, kg) holds the 16-byte chunk ks * 4 + kg of rows r16 and 16 + r16) are exactly the chunks the
@@ -283,9 +287,11 @@ __global__ void __launch_bounds__(WAVES * 64) attn_bwd_kernel(const T* __restric
             fq[ks][t] = ldg16(base + (size_t)rc * ld + q_off + (ks * 4 + kg) * C::PER);
             fk[ks][t] = ldg16(base + (size_t)rc * ld + k_off + (ks * 4 + kg) * C::PER);
             fv[ks][t] = ldg16(base + (size_t)rc * ld + v_off + (ks * 4 + kg) * C::PER);
-            fd[ks][t] = make_uint4(0u, 0u, 0u, 0u);
-            if (row < S) fd[ks][t] = ldg16(dbase + (size_t)row * ldo + (ks * 4 + kg) * C::PER);
+            fd[ks][t] = ldg16(dbase + (size_t)rc * ldo + (ks * 4 + kg) * C::PER);      // (unconditional: rows >= S are zeroed when staged)
         }
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt)
+        if (nt * 16 + r16 >= S) km[nt] = 0.f;
 #pragma unroll
     for (int ks = 0; ks < C::KSD; ++ks)
 #pragma unroll
@@ -295,6 +301,7 @@ __global__ void __launch_bounds__(WAVES * 64) attn_bwd_kernel(const T* __restric
             const uint4 z = make_uint4(0u, 0u, 0u, 0u);
             lds_put16<T, C::GSTRIDE>(Qs, row, ch, in ? fq[ks][t] : z);
             lds_put16<T, C::GSTRIDE>(Ks, row, ch, in ? fk[ks][t] : z);
+            if (!in) fd[ks][t] = z;
             lds_put16<T, C::GSTRIDE>(dOs, row, ch, fd[ks][t]);
         }
 
@@ -354,6 +361,9 @@ __global__ void __launch_bounds__(WAVES * 64) attn_bwd_kernel(const T* __restric
 }
 
 // ------------------------------------------------------------------------------------------------ backward, bf16 (round 2)
+#ifndef A4R_ATTN_BWD_ABL_CT
+#define A4R_ATTN_BWD_ABL_CT 0      /* timing-only builds (-DA4R_ATTN_BWD_ABL_CT=n; wrong results): 1 no stores, 2 no loads -- compile time: see the load loop */
+#endif
 // The same mathematics arranged around what timing ablations showed (tools/attn_short_bench.py, A4R_ATTN_BWD_ABL: 1 = no stores,
 // 2 = no loads).  With neither loads nor stores the generic kernel above still took ~90 of its ~150 us at the text tower's shape: it
 // is INSTRUCTION-bound (a 16-lane shuffle reduction per query row, one dropout hash per element, precise expf, ~300 two-byte LDS
@@ -410,7 +420,7 @@ __global__ void __launch_bounds__(WAVES * 64, 3) attn_bwd_tr_kernel(const bf16_t
                                                                  const bf16_t* __restrict__ dout, int ldo, bf16_t* __restrict__ dqkv,
                                                                  const float* __restrict__ key_mask, int n_items, int S, int n_heads,
                                                                  int causal, float scale, float mask_neg,
-                                                                 uint64_t seed, uint32_t site, uint32_t thr16, float keep_scale, int abl) {
+                                                                 uint64_t seed, uint32_t site, uint32_t thr16, float keep_scale) {
     using T = bf16_t;
     using G = BtGeo<DH>;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -433,7 +443,7 @@ __global__ void __launch_bounds__(WAVES * 64, 3) attn_bwd_tr_kernel(const bf16_t
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int kt = nt * 16 + kg * 4 + r;
-            kmT[nt][r] = (kt < S) ? (key_mask ? key_mask[(size_t)item * S + kt] : 1.f) : 0.f;
+            kmT[nt][r] = (kt < S) ? (key_mask ? key_mask[(size_t)item * S + kt] : 1.f) : 0.f;      // (as a clamped unconditional load hipcc turned each value into a predicate at once: eight serialized waits)
         }
     // every global read of the pair is requested before anything is consumed, every byte once (rows >= S: Q, K, V clamp to row S - 1,
     // finite values whose scores are masked / whose dS rows vanish because dO is zero there)
@@ -443,18 +453,20 @@ __global__ void __launch_bounds__(WAVES * 64, 3) attn_bwd_tr_kernel(const bf16_t
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
             const int row = t * 16 + r16, rc = min(row, S - 1);
-            if (abl & 2) { fq[ks][t] = make_uint4(lane, ks, t, 1); fk[ks][t] = fq[ks][t]; fv[ks][t] = fq[ks][t]; fd[ks][t] = fq[ks][t]; continue; }
+            // (all sixteen loads UNCONDITIONAL and back to back: behind a run-time ablation test, or with dO under `if (row < S)`, hipcc
+            // put an s_waitcnt vmcnt(0) after every group of four -- four serialized round trips at the start of every workgroup)
+            if (A4R_ATTN_BWD_ABL_CT & 2) { fq[ks][t] = make_uint4(lane, ks, t, 1); fk[ks][t] = fq[ks][t]; fv[ks][t] = fq[ks][t]; fd[ks][t] = fq[ks][t]; continue; }
             fq[ks][t] = ldg16(base + (size_t)rc * ld + q_off + (ks * 4 + kg) * 8);
             fk[ks][t] = ldg16(base + (size_t)rc * ld + k_off + (ks * 4 + kg) * 8);
             fv[ks][t] = ldg16(base + (size_t)rc * ld + v_off + (ks * 4 + kg) * 8);
-            fd[ks][t] = make_uint4(0u, 0u, 0u, 0u);
-            if (row < S) fd[ks][t] = ldg16(dbase + (size_t)row * ldo + (ks * 4 + kg) * 8);
+            fd[ks][t] = ldg16(dbase + (size_t)rc * ldo + (ks * 4 + kg) * 8);      // rows >= S: zeroed below, where it is consumed
         }
 #pragma unroll
     for (int ks = 0; ks < G::KSD; ++ks)
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
             const int row = t * 16 + r16, off = row * G::ROWB + (((ks * 4 + kg) ^ G::swz(row)) << 4);
+            if (row >= S) fd[ks][t] = make_uint4(0u, 0u, 0u, 0u);
             *reinterpret_cast<uint4*>(Qi + off) = fq[ks][t];
             *reinterpret_cast<uint4*>(Ki + off) = fk[ks][t];
             *reinterpret_cast<uint4*>(Oi + off) = fd[ks][t];
@@ -582,7 +594,7 @@ __global__ void __launch_bounds__(WAVES * 64, 3) attn_bwd_tr_kernel(const bf16_t
         }
     }
     wave_lds_fence();
-    if (!(abl & 1)) {
+    if (!(A4R_ATTN_BWD_ABL_CT & 1)) {
 #pragma unroll
         for (int i = 0; i < 32 * G::CPR / 64; ++i) {
             const int id = lane + 64 * i, row = id / G::CPR, ch = id % G::CPR;
@@ -630,7 +642,6 @@ int launch_bwd(const Launch& L) {
     return a4r_launch_status();
 }
 
-const int g_attn_bwd_abl = getenv("A4R_ATTN_BWD_ABL") ? atoi(getenv("A4R_ATTN_BWD_ABL")) : 0;      // timing ablations (wrong results): 1 no stores, 2 no loads
 template <int DH, int WAVES>
 int launch_bwd_tr(const Launch& L) {
     const a4r_attn_t& a = *L.a;
@@ -643,7 +654,7 @@ int launch_bwd_tr(const Launch& L) {
     const int total = a.n_items * a.n_heads;
     hipLaunchKernelGGL((attn_bwd_tr_kernel<DH, WAVES>), dim3((total + WAVES - 1) / WAVES), dim3(WAVES * 64), LDS, L.s,
                        (const bf16_t*)a.qkv, a.ld, a.q_off, a.k_off, a.v_off, (const bf16_t*)a.dout, a.ldo, (bf16_t*)a.dqkv, a.key_mask,
-                       a.n_items, a.S, a.n_heads, a.causal, a.scale, a.mask_neg, a.drop_seed, a.drop_site, L.thr, L.ks, g_attn_bwd_abl);
+                       a.n_items, a.S, a.n_heads, a.causal, a.scale, a.mask_neg, a.drop_seed, a.drop_site, L.thr, L.ks);
     return a4r_launch_status();
 }
 const bool g_attn_bwd_tr = !(getenv("A4R_ATTN_BWD_TR") && atoi(getenv("A4R_ATTN_BWD_TR")) == 0);      // 0: the generic kernel for bf16 too (A/B, tests)
