@@ -469,15 +469,15 @@ def main():
             roof['fp8_gemm_tflops'] = round(fp8_f / fp8_t / 1e12, 2)
             roof['fp8_share_of_gemm_flops'] = round(fp8_f / total_f, 3)
         # fabric/HBM bytes per launch of that kernel: not measurable from inside the process -- taken from the committed
-        # rocprofv3 PMC passes over this same command (profiles/r02_j_pmc_hbm_traffic.json says how); only when the run IS that
+        # rocprofv3 PMC passes over this same command (profiles/r02_l_pmc_hbm_traffic.json says how); only when the run IS that
         # command's configuration (bert_houlsby, B=32, bf16), null otherwise.
-        pmc = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles', 'r02_j_pmc_hbm_traffic.json')
+        pmc = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles', 'r02_l_pmc_hbm_traffic.json')
         if key[2][0] == 256 and a.dtype == 'bf16' and a.batch == 32 and wl == 'bert_houlsby' and os.path.exists(pmc):
             mangled = f'gemm_nt_256_kernelIDF16bDF16bLi{key[2][1]}ELi{key[2][2]}ELi{key[2][3]}E'.replace('Li-1E', 'Lin1E')
             for kname, rec in json.load(open(pmc))['kernels'].items():
                 if mangled in kname:
                     roof['traffic'] = rec['traffic_bytes_per_launch']
-                    roof['traffic_source'] = ('NOT measured in this run: profiles/r02_j_pmc_hbm_traffic.json, separate rocprofv3 --pmc FETCH_SIZE / '
+                    roof['traffic_source'] = ('NOT measured in this run: profiles/r02_l_pmc_hbm_traffic.json, separate rocprofv3 --pmc FETCH_SIZE / '
                                               'WRITE_SIZE passes over this same command (2 x FETCH correction of the gfx950 guide)')
         if os.environ.get('A4R_BENCH_SHAPES'):
             print(json.dumps(shapes, indent=1), file=sys.stderr)
