@@ -390,7 +390,7 @@ __global__ void __launch_bounds__(512, 2) gemm_nt_256_kernel(const a4r_gemm_t p,
     // tile against 2.0 us for the plain epilogue).  One object per (row, pair): indexed arrays of register arrays went to scratch.
     constexpr int PS = DACT != A4R_ACT_NONE ? 8 * (int)sizeof(TO) / 16 : 1;
     constexpr bool R1PF = sizeof(TO) == 2 && DACT == A4R_ACT_NONE && EF >= 0 && (EF & 2) != 0;      // (EF & 2: the launch HAS an R1 -- no run-time test around register arrays)
-    constexpr int PRE_D = DACT == A4R_DACT_MULQ8_ ? A4R_PF_Q8 : 1, R1_D = A4R_PF_R1;
+    constexpr int PRE_D = DACT == A4R_DACT_MULQ8_ ? A4R_PF_Q8 : 1, R1_D = (EF & 1) ? 2 : A4R_PF_R1;      // (with the dropout arithmetic the whole-tile request spills)
 #define A4R_SLOTS(name_, n_) uint4 name_##0_0[n_], name_##0_1[n_], name_##1_0[n_], name_##1_1[n_], name_##2_0[n_], name_##2_1[n_], name_##3_0[n_],  \
         name_##3_1[n_], name_##4_0[n_], name_##4_1[n_], name_##5_0[n_], name_##5_1[n_], name_##6_0[n_], name_##6_1[n_], name_##7_0[n_], name_##7_1[n_], \
         name_##8_0[n_], name_##8_1[n_];
@@ -552,6 +552,7 @@ int dispatch_same(hipStream_t s, const a4r_gemm_t& g) {   // in == out dtype: th
             if (m == 0) return launch256<T, T, A4R_ACT_NONE, A4R_ACT_NONE, 0>(s, g);
             if (m == 1) return launch256<T, T, A4R_ACT_NONE, A4R_ACT_NONE, 1>(s, g);
             if (m == 2) return launch256<T, T, A4R_ACT_NONE, A4R_ACT_NONE, 2>(s, g);
+            if (m == 3) return launch256<T, T, A4R_ACT_NONE, A4R_ACT_NONE, 3>(s, g);      // dense + dropout + residual: an un-adapted BertSelfOutput / BertOutput (Pfeiffer, LoRA)
         }
         if (g.act == A4R_ACT_GELU && g.dact == A4R_ACT_NONE && m == 8) return launch256<T, T, A4R_ACT_GELU, A4R_ACT_NONE, 8>(s, g);
         if (g.act == A4R_ACT_NONE && g.dact == A4R_DACT_MULQ8_ && m == 0) return launch256<T, T, A4R_ACT_NONE, A4R_DACT_MULQ8_, 0>(s, g);

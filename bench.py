@@ -166,7 +166,7 @@ class GemmProbe:
                 names = ('bias', 'C2', 'R1', 'R2', 'Pre', 'act', 'dact', 'alpha', 'drop_p')
                 kw = dict(zip(names, a)); kw.update(k)
                 m = (1 if kw.get('drop_p', 0.0) > 0 else 0) | (2 if kw.get('R1') is not None else 0) | (4 if kw.get('R2') is not None else 0) | (8 if kw.get('C2') is not None else 0)
-                inst = {(0, 0): (0, 1, 2), (self.L.ACT_GELU, 0): (8,), (0, self.L.DACT_MUL_Q8): (0,), (0, self.L.DACT_MUL): (0,)}
+                inst = {(0, 0): (0, 1, 2, 3), (self.L.ACT_GELU, 0): (8,), (0, self.L.DACT_MUL_Q8): (0,), (0, self.L.DACT_MUL): (0,)}
                 if A.dtype == torch.uint8:                   # e4m3 operands
                     inst = {(0, 0): (0,), (self.L.ACT_GELU, 0): (8,)}
                 ef = m if (A.dtype in (torch.bfloat16, torch.uint8) and Cout.dtype == torch.bfloat16 and m in inst.get(ad, ())) else -1

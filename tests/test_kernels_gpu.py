@@ -1034,22 +1034,24 @@ def test_gemm256_many_tiles_per_workgroup(K):
     res = []
     for v in (4, 1):
         old = L.gemm_variant(v)
-        plain, drop, resid, gel, dm = (torch.zeros(M, N, dtype=t, device=dev()) for _ in range(5))
+        plain, drop, resid, gel, dm, dropres = (torch.zeros(M, N, dtype=t, device=dev()) for _ in range(6))
         C8 = torch.zeros(M, N, dtype=torch.uint8, device=dev())
         L.gemm_nt(A, B, plain, bias=bias)
         L.gemm_nt(A, B, drop, bias=bias, drop_p=0.1, drop_site=3, drop_seed=11)
         L.gemm_nt(A, B, resid, R1=R1)
+        L.gemm_nt(A, B, dropres, bias=bias, R1=R1, drop_p=0.1, drop_site=5, drop_seed=13, drop_first=True)
         L.gemm_nt(A, B, gel, bias=bias, C2=C8, act=L.ACT_GELU, c2_deriv='q8')
         L.gemm_nt(A, B, dm, Pre=P8, dact=L.DACT_MUL_Q8)
         L.gemm_variant(old)
-        res.append((plain, drop, resid, gel, C8, dm))
-    names = ('plain', 'dropout', 'residual', 'gelu', 'gelu derivative q8', '* derivative q8')
+        res.append((plain, drop, resid, gel, C8, dm, dropres))
+    names = ('plain', 'dropout', 'residual', 'gelu', 'gelu derivative q8', '* derivative q8', 'dropout + residual')
     for nm, a, b in zip(names, res[0], res[1]):
         if a.dtype == torch.uint8:
             assert int((a.int() - b.int()).abs().max()) <= 1, nm
         else:
             close(a, b, t, nm + ': 256-tile vs 128-tile kernel', rtol16=2e-2, atol16=2e-2)
     assert torch.equal(res[0][1] == 0, res[1][1] == 0), 'dropout pattern'
+    assert torch.equal(res[0][6] == R1, res[1][6] == R1), 'dropout pattern (dropout + residual form)'
     rows = torch.arange(0, M, 997, device=dev())                  # sampled rows of every panel region, incl. the last tiles
     pre = A[rows].float() @ B.float().t()
     close(res[0][0][rows], pre + bias, t, 'plain vs torch')
