@@ -324,8 +324,9 @@ __global__ void __launch_bounds__(512, 2) gemm_nt_256_kernel(const a4r_gemm_t p,
     // i.e. 8 B (bf16) / 16 B (fp32) per lane and 32 B / 64 B runs per row -- no LDS round trip, no barriers, and the 32
     // independent (mi, ni) groups give the memory system all the parallelism it needs (the LDS-staged form cost ~25 us per
     // tile with one workgroup per CU).
-    // every LDS read of this tile completed before the last barrier: the ring is free, so the NEXT tile's first units
-    // are put in flight now and land while this tile's accumulators are being written out.
+    // Every LDS read of this tile completed before the last barrier.  The NEXT tile's first six units are already on their way (issued
+    // by this tile's last two K-tiles) -- or, with an odd K-tile count, are put in flight here -- and land while the accumulators are
+    // being written out.
     has_next = false;
     Abase = Abase_nx;
     Bbase = Bbase_nx;
@@ -342,7 +343,7 @@ __global__ void __launch_bounds__(512, 2) gemm_nt_256_kernel(const a4r_gemm_t p,
     const size_t grow0 = (size_t)tm_done * 256 + wm * 128 + fr;
     const int gcolp = tn_done * 256 + wn * 64 + (kg & 1) * 16 + (kg >> 1) * 8;      // + pair * 32
     // C addresses and dropout element indices: a UNIFORM per-tile / per-group part (scalar registers) + a per-lane part that is the same
-    // for every tile (c_lane, e0_lane: formed once per kernel) -- no 64-bit multiply per group
+    // for every tile (c_lane, e0_lane) -- no 64-bit multiply per group
     // (per-lane parts: bytes, 32-bit -- the host side checks M * ldc * sizeof(TO) < 4 GiB.  Re-formed per tile from a laundered lane id:
     // as loop invariants they and the 24 sums derived from them would be kept in registers across the K loop)
     int lane_e = lane;
