@@ -329,13 +329,14 @@ def ln_fwd(v, gamma, beta, eps, y, stats, M=None, add=None, drop_p=0.0, drop_sit
 
 
 def ln_bwd(dy, v, stats, gamma, dv, M=None, add=None, dgamma=None, dbeta=None, dbias=None, dres=None,
-           drop_p=0.0, drop_site=0, drop_seed=0):
+           drop_p=0.0, drop_site=0, drop_seed=0, dv2=None, drop2_p=0.0, drop2_site=0, drop2_seed=0):
     require_gpu(dy, v, dv)
     M = v.shape[0] if M is None else M
     _check(lib().a4r_ln_bwd(_stream(), _p(dy), C.c_int(_ld(dy)), _p(v), C.c_int(_ld(v)), _p(add),
                             C.c_int(add.shape[0] if add is not None else 0), _p(stats), _p(gamma), _p(dres), C.c_int(_ld(dres) if dres is not None else 0), _p(dv), C.c_int(_ld(dv)),
                             _p(dgamma), _p(dbeta), _p(dbias), C.c_int(M), C.c_int(v.shape[1]), C.c_int(_dt(v)),
-                            C.c_float(drop_p), C.c_uint32(drop_site), C.c_uint64(drop_seed)), 'a4r_ln_bwd')
+                            C.c_float(drop_p), C.c_uint32(drop_site), C.c_uint64(drop_seed),
+                            _p(dv2), C.c_int(_ld(dv2) if dv2 is not None else 0), C.c_float(drop2_p), C.c_uint32(drop2_site), C.c_uint64(drop2_seed)), 'a4r_ln_bwd')
 
 
 def gather_rows(src, dst, n, row_step):

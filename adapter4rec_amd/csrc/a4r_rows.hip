@@ -243,7 +243,8 @@ __global__ void __launch_bounds__(256) ln_bwd_kernel(const T* __restrict__ dy, i
                                                      const float* __restrict__ gamma, const T* __restrict__ dres, int lddres,
                                                      T* __restrict__ dv, int lddv,
                                                      float* __restrict__ dgamma, float* __restrict__ dbeta, float* __restrict__ dbias,
-                                                     int M, int H, uint64_t seed, uint32_t site, uint32_t thr16, float scale) {
+                                                     int M, int H, uint64_t seed, uint32_t site, uint32_t thr16, float scale,
+                                                     T* __restrict__ dv2, int lddv2, uint64_t seed2, uint32_t site2, uint32_t thr2, float scale2) {
     __shared__ float red[(WGB ? 2 : 0) + (WDB ? 1 : 0) + 1][4][1024];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int ng = H / 8;
@@ -308,6 +309,10 @@ __global__ void __launch_bounds__(256) ln_bwd_kernel(const T* __restrict__ dy, i
                 for (int e = 0; e < 8; ++e) d[g][e] += rr[g][e];
         }
         row_store<T>(dv + (size_t)row * lddv, ng, lane, d);
+        if (dv2) {       // second output: dv through ANOTHER dropout mask (the gradient of a dense output that was dropped out before the residual add)
+            if (thr2) row_dropout(d, ng, lane, row, H, seed2, site2, thr2, scale2);
+            row_store<T>(dv2 + (size_t)row * lddv2, ng, lane, d);
+        }
     }
     if constexpr (!WGB && !WDB) return;
     constexpr int SV = WGB ? 2 : 0;
@@ -488,7 +493,9 @@ extern "C" int a4r_quant_rows_fp8(void* stream, const void* x, int ldx, void* q,
 extern "C" int a4r_ln_bwd(void* stream, const void* dy, int lddy, const void* v, int ldv, const float* add, int add_rows,
                           const float* stats, const float* gamma, const void* dres, int lddres, void* dv, int lddv,
                           float* dgamma, float* dbeta, float* dbias, int M, int H, int dtype,
-                          float drop_p, uint32_t drop_site, uint64_t drop_seed) {
+                          float drop_p, uint32_t drop_site, uint64_t drop_seed,
+                          void* dv2, int lddv2, float drop2_p, uint32_t drop2_site, uint64_t drop2_seed) {
+    if (dv2 && (misaligned(dv2) || (lddv2 * (dtype == A4R_F32 ? 4 : 2)) % 16 || lddv2 < H || drop2_p < 0.f || drop2_p >= 1.f)) return A4R_EINVAL;
     if (dres && (misaligned(dres) || (lddres * (dtype == A4R_F32 ? 4 : 2)) % 16 || lddres < H)) return A4R_EINVAL;
     if (!dy || !v || !stats || !gamma || !dv || bad_dtype(dtype) || M <= 0 || H <= 0 || H % 8 || H > 1024) return A4R_EINVAL;
     const int esz = dtype == A4R_F32 ? 4 : 2;
@@ -505,7 +512,7 @@ extern "C" int a4r_ln_bwd(void* stream, const void* dy, int lddy, const void* v,
 #define A4R_LNB(T_, G_, B_)                                                                                                   \
     hipLaunchKernelGGL((ln_bwd_kernel<T_, G_, B_>), dim3(grid), dim3(256), 0, s, (const T_*)dy, lddy, (const T_*)v, ldv, add,    \
                        add_rows, stats, gamma, (const T_*)dres, lddres, (T_*)dv, lddv, dgamma, dbeta, dbias, M, H, drop_seed,  \
-                       drop_site, thr, sc)
+                       drop_site, thr, sc, (T_*)dv2, lddv2, drop2_seed, drop2_site, a4r_thr16(drop2_p), a4r_keep_scale(drop2_p))
     if (dtype == A4R_BF16) {
         if (wgb && wdb) A4R_LNB(bf16_t, true, true); else if (wgb) A4R_LNB(bf16_t, true, false);
         else if (wdb) A4R_LNB(bf16_t, false, true); else A4R_LNB(bf16_t, false, false);

@@ -868,6 +868,11 @@ class TransRecEngine:
         self._wgrad_join()                               # dzp / dv are about to be overwritten
         if ad is None:
             dv = self._buf('dv' + which, M, H, T)
+            if p_drop > 0 and getattr(blk, 'Hv', H) == H:          # one launch writes dv and mask * dv (a4r_ln_bwd's second output; mask index = row * H + col)
+                dh = self._buf('dh' + which, M, H, T)
+                L.ln_bwd(dy, v, st, ln.gamma, dv, M=M, dgamma=gg(ln.g_gamma), dbeta=gg(ln.g_beta),
+                         dv2=dh, drop2_p=p_drop, drop2_site=site, drop2_seed=seed)
+                return dh, dv
             L.ln_bwd(self._vc(blk, dy), self._vc(blk, v), st, ln.gamma, self._vc(blk, dv), M=M, dgamma=gg(ln.g_gamma), dbeta=gg(ln.g_beta))
             if p_drop > 0:
                 dh = self._buf('dh' + which, M, H, T)
@@ -892,10 +897,11 @@ class TransRecEngine:
                 L.gemm_nt(dzp, ad.wdT, dt, M=M)
             self._adapter_wgrads(ad, dv, z, dzp, t, M, bd_done=fused_bd)
             dva = self._buf('dva', M, H, T)
-            L.ln_bwd(dt, va, sta, ln.gamma, dva, M=M, dgamma=gg(ln.g_gamma), dbeta=gg(ln.g_beta), dres=dv)
             if p_drop > 0:
-                L.dropout_apply(dva, dh, p_drop, site, seed, M=M)
+                L.ln_bwd(dt, va, sta, ln.gamma, dva, M=M, dgamma=gg(ln.g_gamma), dbeta=gg(ln.g_beta), dres=dv,
+                         dv2=dh, drop2_p=p_drop, drop2_site=site, drop2_seed=seed)
                 return dh, dva
+            L.ln_bwd(dt, va, sta, ln.gamma, dva, M=M, dgamma=gg(ln.g_gamma), dbeta=gg(ln.g_beta), dres=dv)
             return dva, dva
         h = bufs['h' + which]
         if pl != 'parallel' and self._fuse_bwd(blk, ad, dy):

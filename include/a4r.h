@@ -208,7 +208,11 @@ int a4r_quant_rows_fp8(void* stream, const void* x, int ldx, void* q, int ldq, f
 int a4r_ln_bwd(void* stream, const void* dy, int lddy, const void* v, int ldv, const float* add, int add_rows,
                const float* stats, const float* gamma, const void* dres, int lddres, void* dv, int lddv,
                float* dgamma, float* dbeta, float* dbias, int M, int H, int dtype,
-               float drop_p, uint32_t drop_site, uint64_t drop_seed);
+               float drop_p, uint32_t drop_site, uint64_t drop_seed,
+               void* dv2, int lddv2, float drop2_p, uint32_t drop2_site, uint64_t drop2_seed);
+/* dv2 (optional, same dtype): dv through the dropout mask (drop2_*) -- BertSelfOutput / BertOutput apply dropout to the dense output BEFORE the
+ * residual add (HF modeling_bert.py BertSelfOutput.forward, wrapped by model/model.py:292-297): the residual branch gets dv, the dense layer's dgrad
+ * GEMM gets mask * dv; written by the same launch instead of a separate a4r_dropout_apply pass over dv. */
 
 /* out[i, :] = in[i * row_stride_rows, :] (CLS gather, model/encoders.py:55) and its scatter-transpose. */
 int a4r_gather_rows(void* stream, const void* in, int ldi, void* out, int ldo, int n, int row_step, int H, int dtype);

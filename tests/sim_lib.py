@@ -293,8 +293,8 @@ def ln_fwd(v, gamma, beta, eps, y, stats, M=None, add=None, drop_p=0.0, drop_sit
 
 
 def ln_bwd(dy, v, stats, gamma, dv, M=None, add=None, dgamma=None, dbeta=None, dbias=None, dres=None,
-           drop_p=0.0, drop_site=0, drop_seed=0):
-    assert drop_p == 0.0
+           drop_p=0.0, drop_site=0, drop_seed=0, dv2=None, drop2_p=0.0, drop2_site=0, drop2_seed=0):
+    assert drop_p == 0.0 and drop2_p == 0.0
     M = v.shape[0] if M is None else M
     x = v[:M].float()
     if add is not None:
@@ -313,6 +313,8 @@ def ln_bwd(dy, v, stats, gamma, dv, M=None, add=None, dgamma=None, dbeta=None, d
     if dres is not None:
         g = g + dres[:M].float()
     dv[:M] = g.to(dv.dtype)
+    if dv2 is not None:
+        dv2[:M] = g.to(dv2.dtype)
 
 
 def _f32_at(ptr, n):

@@ -561,6 +561,32 @@ def test_ln_dropout_adjoint():
 
 
 @pytest.mark.parametrize('dt', ['f32', 'bf16'])
+def test_ln_bwd_second_output_through_dropout(dt):
+    """a4r_ln_bwd's optional second output = a4r_dropout_apply of its first (same mask index row * H + col; bit for bit in fp32), with and without
+    the residual-branch operand; the first output and the column sums are unchanged by it."""
+    from adapter4rec_amd import _lib as L
+    t = DT[dt]
+    M, H = 300, 256
+    v, dy, dres = rnd(M, H, dtype=t, seed=61), rnd(M, H, dtype=t, seed=62), rnd(M, H, dtype=t, seed=63)
+    gamma, stats = 1 + 0.1 * rnd(H, seed=64), torch.zeros(M, 2, device=dev())
+    y = torch.zeros(M, H, dtype=t, device=dev())
+    L.ln_fwd(v, gamma, torch.zeros(H, device=dev()), 1e-6, y, stats)
+    for res in (None, dres):
+        dv_a, dv_b, dh_a, dh_b = (torch.zeros(M, H, dtype=t, device=dev()) for _ in range(4))
+        dba, dbb = torch.zeros(H, device=dev()), torch.zeros(H, device=dev())
+        L.ln_bwd(dy, v, stats, gamma, dv_a, dres=res, dbias=dba)
+        L.dropout_apply(dv_a, dh_a, 0.2, 7, 99)
+        L.ln_bwd(dy, v, stats, gamma, dv_b, dres=res, dbias=dbb, dv2=dh_b, drop2_p=0.2, drop2_site=7, drop2_seed=99)
+        assert torch.equal(dv_a, dv_b) and torch.equal(dh_a == 0, dh_b == 0)
+        if dt == 'f32':
+            assert torch.equal(dh_a, dh_b)
+        else:                        # the fused launch scales the fp32 value and rounds ONCE; the two-launch form rounds dv first
+            torch.testing.assert_close(dh_a.float(), dh_b.float(), rtol=2 ** -7, atol=1e-3)
+        torch.testing.assert_close(dba, dbb, rtol=1e-5, atol=1e-5)
+        assert abs((dh_b == 0).float().mean().item() - 0.2) < 0.02
+
+
+@pytest.mark.parametrize('dt', ['f32', 'bf16'])
 def test_gather_scatter_rows(dt):
     from adapter4rec_amd import _lib as L
     t = DT[dt]
