@@ -12,6 +12,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('A4R_LIB_PATH') or os.path.join(_HERE, 'liba4r_hip.so')    # A4R_LIB_PATH: A/B builds (tools/), same C ABI
 
+ABI_VERSION = 300          # = A4R_ABI_VERSION of include/a4r.h (tests/test_abi_cpu.py compares the two)
 BF16, F32, FP8 = 0, 1, 2
 ACT_NONE, ACT_RELU, ACT_GELU, ACT_GELU_TANH, ACT_LEAKY = 0, 1, 2, 3, 4
 DACT_MUL = 15
@@ -76,6 +77,10 @@ def lib():
         _lib = C.CDLL(LIB_PATH)
         for name in EXPORTS:
             getattr(_lib, name).restype = C.c_int
+        got = _lib.a4r_version()
+        if got != ABI_VERSION:        # an older A/B build has every export but other argument lists: calling it would pass shifted pointers
+            _lib = None
+            raise RuntimeError(f'{LIB_PATH} has ABI version {got}, this binding is for {ABI_VERSION}: rebuild it (make -C adapter4rec_amd/csrc)')
     return _lib
 
 

@@ -191,4 +191,4 @@ extern "C" int a4r_pack_matrices(void* stream, const float* flat, const a4r_pack
     return a4r_launch_status();
 }
 
-extern "C" int a4r_version(void) { return 100; }
+extern "C" int a4r_version(void) { return A4R_ABI_VERSION; }

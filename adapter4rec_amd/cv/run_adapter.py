@@ -17,7 +17,7 @@ import torch.distributed as dist
 from torch.utils.data import DataLoader
 
 from ..data_utils.utils import get_checkpoint, para_and_log, report_time_eval, report_time_train, save_model, setuplogger
-from ..ddp import FlatDDP
+from ..ddp import FlatDDP, any_rank
 from ..inject import freeze_all
 from ..optim import FusedAdam
 from . import Model, ModelCPC, ViTForImageClassification, ViTMAEModel
@@ -133,13 +133,13 @@ def train(args, use_modal, local_rank, Log_file, Log_screen, model_dir, start_ti
             bz_loss.backward()
             optimizer.step()
             if batch_index % steps_for_log == 0:
-                if torch.isnan(loss):
+                if any_rank(torch.isnan(loss)):                          # every rank breaks together: the evaluation below uses collectives
                     need_break = True
                     break
                 Log_file.info('cnt: {}, Ed: {}, batch loss: {:.5f}, sum loss: {:.5f}'.format(
                     batch_index, batch_index * args.batch_size, loss.item() / batch_index, loss.item()))
             batch_index += 1
-        if not need_break and bool(torch.isnan(loss)):                 # a NaN after the last log step: never evaluate / save NaN weights
+        if not need_break and any_rank(torch.isnan(loss)):                 # a NaN after the last log step: never evaluate / save NaN weights
             need_break = True
         if not need_break:
             hit10 = run_eval_once(model, db, item_id_to_keys, hist_valid, users_valid, 256, item_num, 'valid', local_rank, args, Log_file)

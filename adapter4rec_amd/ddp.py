@@ -11,6 +11,16 @@ import torch.distributed as dist
 from torch import nn
 
 
+def any_rank(flag, group=None):
+    """Logical OR of a host or 0-d device flag over the ranks of `group` (one MAX all-reduce); the flag itself without a process group."""
+    if not (dist.is_initialized() and dist.get_world_size(group) > 1):
+        return bool(flag)
+    dev = 'cuda' if dist.get_backend(group) == 'nccl' else 'cpu'
+    t = torch.as_tensor(flag).to(dev).reshape(1).to(torch.int32)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
+    return bool(t.item())
+
+
 class FlatDDP(nn.Module):
     def __init__(self, module, device_ids=None, output_device=None, find_unused_parameters=False, process_group=None,
                  broadcast=True):
@@ -55,11 +65,18 @@ class FlatDDP(nn.Module):
         self._pending.append((dist.all_reduce(view, op=op, group=self.process_group, async_op=True), view))
 
     def wait_all(self):
-        for work, view in self._pending:
+        """Join every chunk launched since the last call.  Always runs (engine.backward_bound calls it from a `finally`): a backward
+        that raised after some launches must not leave works in flight whose 1/world scaling (gloo) would be applied to a later step."""
+        pending, self._pending = self._pending, []
+        for work, view in pending:
             work.wait()
             if not self._avg:
                 view.mul_(1.0 / self.world)
-        self._pending = []
+
+    def any_rank(self, flag):
+        """True on EVERY rank when `flag` is true on any of them (the end-of-epoch NaN test of run.py:601-603 decides whether the ranks
+        enter the evaluation's collectives: a rank-local decision would leave the others waiting in an all-gather)."""
+        return any_rank(flag, self.process_group)
 
     def forward(self, *args, **kwargs):
         return self.module(*args, **kwargs)

@@ -735,6 +735,8 @@ class TransRecEngine:
 
     def _q8(self, blk):
         """This block's saved FFN activation derivative is the uint8 form (GELU FFN, bf16 storage)."""
+        if blk.d_i is not None and (blk.d_i.trainable or blk.d_o2.trainable):
+            return False             # --fine_tune_to all: dW_i / dx1 of a TRAINABLE FFN use the derivative at storage precision, not the 8-bit form
         return self.q8_deriv and blk.T == torch.bfloat16 and getattr(blk, 'ffn_act', L.ACT_GELU) == L.ACT_GELU and blk.F % 16 == 0
 
     def _block_bufs(self, tag, blk, M, shared, Mc=None):
@@ -1320,7 +1322,7 @@ class TransRecEngine:
                         self._exchange(what)                      # whatever the hooks did not reach (e.g. layers a frozen-input backward skips)
                 finally:
                     self._exch = None
-                ddp.wait_all()
+                    ddp.wait_all()                                # also after an exception: nothing stays in flight into the next step
                 return
             self.train_backward(grad_out, into_flat_grad=True)
             if ddp is not None:                                   # DDP semantics: gradients averaged over ranks (run.py:503,599)

@@ -72,7 +72,9 @@ class FusedAdam(torch.optim.Optimizer):
         elif next(p for g in self.param_groups for p in g['params'])._a4r_flat[0] is not self._bound:
             # the model rebuilt its engine (.to(device) / load_state_dict): move the moments over to the new flat buffers
             self._pending = dict(step=self._step, m=self._m, v=self._v)
+            old = self._bound
             self._bind()
+            self._bound.step_count = max(self._bound.step_count, old.step_count)     # the counter-based dropout stream continues, it does not restart
         else:
             self._attach_grads()
         eng = self._bound

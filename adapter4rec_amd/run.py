@@ -19,7 +19,7 @@ from torch.utils.data import DataLoader
 from .data_utils import (BuildTrainDataset, eval_model, get_doc_input_bert, get_item_embeddings, read_behaviors,
                          read_news_bert)
 from .data_utils.utils import (get_checkpoint, para_and_log, report_time_eval, report_time_train, save_model, setuplogger)
-from .ddp import FlatDDP
+from .ddp import FlatDDP, any_rank
 from .inject import freeze_all, inject_adapters, optimizer_groups
 from .model import BertBackbone, Model, ModelCPC
 from .optim import FusedAdam
@@ -141,13 +141,13 @@ def train(args, use_modal, local_rank, Log_file, Log_screen, model_dir, start_ti
             bz_loss.backward()
             optimizer.step()
             if batch_index % steps_for_log == 0:                      # the only host sync: NaN check + log line
-                if torch.isnan(loss):
+                if any_rank(torch.isnan(loss)):                          # every rank breaks together: the evaluation below uses collectives
                     need_break = True
                     break
                 Log_file.info('cnt: {}, Ed: {}, batch loss: {:.5f}, sum loss: {:.5f}'.format(
                     batch_index, batch_index * args.batch_size, loss.item() / batch_index, loss.item()))
             batch_index += 1
-        if not need_break and bool(torch.isnan(loss)):                 # a NaN after the last log step of the epoch: the reference checks
+        if not need_break and any_rank(torch.isnan(loss)):                 # a NaN after the last log step of the epoch: the reference checks
             need_break = True                                          # every batch (run.py:601-603); never evaluate / save NaN weights
         if not need_break:
             hit10 = run_eval_once(model, item_content, hist_valid, users_valid, 512, item_num, use_modal, 'valid', local_rank, args, Log_file)

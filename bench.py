@@ -275,8 +275,7 @@ def self_launch(a, argv):
     `python -m torch.distributed.run` on 127.0.0.1 as a CHILD process and exits with its code."""
     import socket
     import subprocess
-    if not os.environ.get('A4R_BENCH_CONTROL_ONLY') and not os.environ.get('A4R_BENCH_OVERSUBSCRIBE') and torch.cuda.device_count() < a.gpus:
-        raise SystemExit(f'bench.py --gpus {a.gpus}: only {torch.cuda.device_count()} GPU(s) visible')
+    # (no device query here: the launcher holds no GPU state at all; every rank checks `world > torch.cuda.device_count()` itself in main())
     with socket.socket() as sk:
         sk.bind(('127.0.0.1', 0))
         port = sk.getsockname()[1]

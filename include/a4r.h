@@ -34,6 +34,9 @@ extern "C" {
 #define A4R_DACT_MUL 15       /* dact only: multiply by Pre itself (Pre holds a stored derivative, see c2_mode) */
 #define A4R_DACT_MUL_Q8 14    /* dact only, out_dtype bf16: the same, Pre is the uint8 tensor c2_mode 2 wrote (ldpre in bytes) */
 
+/* ABI version: bumped whenever a signature or struct below changes.  The Python binding (adapter4rec_amd/_lib.py) refuses a
+ * library whose a4r_version() differs, so an A/B build made before a signature change cannot be called with shifted arguments. */
+#define A4R_ABI_VERSION 300
 int a4r_version(void);
 
 /* C[M,N] = epilogue(alpha * A[M,K] . B[N,K]^T): every nn.Linear on the path (HF BertSelfAttention

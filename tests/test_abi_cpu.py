@@ -27,7 +27,10 @@ def test_library_exports_every_declared_symbol():
     for name in declared():
         assert hasattr(lib, name), name
     assert sorted(_lib.EXPORTS) == declared()
-    assert lib.a4r_version() >= 100
+    hdr = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'include', 'a4r.h')).read()
+    import re as _re
+    want = int(_re.search(r'#define A4R_ABI_VERSION (\d+)', hdr).group(1))
+    assert lib.a4r_version() == want == _lib.ABI_VERSION
 
 
 def test_binding_struct_sizes_match_header():
