@@ -103,6 +103,16 @@ def test_two_rank_gradient_average(tmp_path):
             acc = g if acc is None else {k: acc[k] + g[k] for k in g}
         for k in acc:
             np.testing.assert_allclose(r0['grads'][k].numpy(), (acc[k] / 2).numpy(), rtol=1e-5, atol=1e-7, err_msg=k)
+        # the IMPORTED reference under torch DDP (Downstream/Text/run.py:503,597-600) on two gloo ranks, same weights, same
+        # 2 + 2 split of the users (tools/gen_golden_r3.py ddp2): the averaged gradients every rank of the reference ends up with
+        ref = np.load(os.path.join(HERE, 'golden', 'ddp2_houlsby.npz'))
+        assert int(ref['users_per_rank']) == half
+        np.testing.assert_allclose([r0['loss'], r1['loss']], ref['rank_losses'], atol=1e-4, rtol=0)
+        keys = [k for k in ref.files if k.startswith('grad/')]
+        assert len(keys) == len(acc)
+        for k in keys:
+            want = ref[k]
+            np.testing.assert_allclose(r0['grads']['module.' + k[5:]].numpy(), want, atol=1e-6 + 1e-4 * np.abs(want).max(), rtol=0, err_msg=k)
         # the sharded + gathered item table == a single-process sweep with the (identical, post-step) adapter weights
         root, args, fx, items, mask = build_cpu('houlsby')
         sd = root.state_dict()

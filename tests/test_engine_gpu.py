@@ -306,3 +306,38 @@ def test_finetune_all_fp32_vs_oracle_and_fixture(ln_only):
             l_.backward()
             opt.step()
         assert model(items, mask, 'cuda:0').item() < l0          # three Adam steps on one batch must lower its loss
+
+
+@pytest.mark.parametrize('name', ['houlsby', 'houlsby_gelu', 'pfeiffer', 'roberta_cpc_pfeiffer'])
+def test_step_bf16_vs_reference_autocast(name):
+    """the bf16 path is bounded by the reference's OWN reduced-precision path.  <name>_autocast.npz
+    (tools/gen_golden_r3.py) holds the imported reference's step under torch.autocast(bfloat16) (`with autocast(): bz_loss = model(...)`,
+    Pretraining/Text/run.py:319-324) on the weights and batch of <name>.npz.  Both distances are measured from the SAME fp32 reference
+    numbers: the HIP bf16 step may be at most 2x as far from them as the reference's autocast step is (plus a small floor for
+    quantities the autocast run happens to hit exactly)."""
+    import os
+    from golden_util import GOLDEN
+    root, args, sd, cfg, fx, items, mask = build(name, 'bf16')
+    ac = np.load(os.path.join(GOLDEN, name + '_autocast.npz'))
+    loss = root(items, mask, 0)
+    loss.backward()
+    inner = getattr(root, 'model', root)
+    embs = inner.bert_encoder(items).cpu().numpy()
+    params = dict(root.named_parameters())
+    d_hip = dict(loss=abs(loss.item() - float(fx['loss'])), emb=np.abs(embs - fx['input_embs_all']).max())
+    d_ac = dict(loss=abs(float(ac['loss']) - float(fx['loss'])), emb=np.abs(ac['input_embs_all'] - fx['input_embs_all']).max())
+    g_hip, g_ac = [], []
+    for k in fx['trainable']:
+        k = str(k)
+        ref = fx['grad/' + k]
+        s = np.abs(ref).max() + 1e-30
+        g_hip.append(np.abs(params[k].grad.cpu().numpy() - ref).max() / s)
+        g_ac.append(np.abs(ac['grad/' + k] - ref).max() / s)
+    d_hip['grad'], d_ac['grad'] = max(g_hip), max(g_ac)
+    # per tensor the ratio is noisy (a bias gradient is a signed sum of a few hundred terms); the median over tensors is the stable figure
+    med = float(np.median(np.array(g_hip) / (np.array(g_ac) + 1e-12)))
+    print(f'{name}: HIP bf16 vs fp32 reference {d_hip}; reference autocast(bf16) vs fp32 reference {d_ac}; median per-tensor gradient error ratio {med:.2f}')
+    assert d_hip['emb'] <= 2.0 * d_ac['emb'] + 1e-3, (d_hip, d_ac)
+    assert d_hip['grad'] <= 2.0 * d_ac['grad'] + 5e-3, (d_hip, d_ac)
+    assert d_hip['loss'] <= 2.0 * d_ac['loss'] + 1e-2, (d_hip, d_ac)
+    assert med <= 2.0, med

@@ -127,3 +127,56 @@ def test_cv_backbone_matches_installed_hf():
     """The generator first checked its 4.20.1-shaped backbone against the installed HuggingFace ViT / ViT-MAE."""
     d = np.load(GOLDEN + '/cv_base.npz')['hf_check']
     assert d.max() < 2e-5
+
+
+# ------------------------------------------------------------------ round 3: the oracle pinned at the BENCHMARKED geometry
+BASE_GEOM = {
+    'bert_houlsby_gelu': (dict(encoder='bert', act='GELU'), dict(adapter_activation='GELU')),
+    'roberta_pfeiffer_cpc': (dict(encoder='roberta', act='relu', adapter_type='pfeiffer', arch='cpc'),
+                             dict(adapter_activation='relu', adapter_type='pfeiffer', arch='cpc', encoder='roberta', bert_ln_eps=1e-5, pad_token_id=1)),
+}
+
+
+@pytest.mark.parametrize('name', list(BASE_GEOM))
+def test_oracle_at_base_geometry_vs_imported_reference(name):
+    """BERT-base (vocab 30 522) and RoBERTa-base (vocab 50 265, position ids offset by the pad id) geometry, 12 layers, 84 items: the
+    restatement vs what the IMPORTED reference computed on the same seeded weights (tools/gen_golden_r3.py base): loss, scores,
+    embeddings, prec_vec and the gradients the fixture keeps."""
+    import os
+    from base_cases import build_text_case, checksum
+    kw, ocfg = BASE_GEOM[name]
+    model, items, mask = build_text_case(**kw)
+    fx = np.load(os.path.join(GOLDEN, f'base_geom_{name}.npz'))
+    want = float(fx['weights_checksum'])
+    assert abs(checksum(model) - want) <= 1e-6 * max(1.0, abs(want))
+    sd = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    kept = [k[5:] for k in fx.files if k.startswith('grad/')]
+    out, grads = R.loss_and_grads(sd, kept, items, mask, dict(R.DEFAULT_CFG, **ocfg))
+    assert abs(float(out['loss'].detach()) - float(fx['loss'])) < TOL
+    np.testing.assert_allclose(out['input_embs_all'].detach().numpy(), fx['input_embs_all'], atol=TOL, rtol=0)
+    np.testing.assert_allclose(out['prec_vec'].detach().numpy(), fx['prec_vec'], atol=TOL, rtol=0)
+    pos, neg = out['pos_score'].detach().numpy(), out['neg_score'].detach().numpy()
+    if ocfg.get('arch') == 'cpc':
+        np.testing.assert_allclose(pos, fx['pos_score'][:, -1], atol=TOL, rtol=0)
+        np.testing.assert_allclose(neg, fx['neg_score'][:, -1], atol=TOL, rtol=0)
+    else:
+        v = mask.bool().numpy()
+        np.testing.assert_allclose(pos[v], fx['pos_score'][v], atol=TOL, rtol=0)
+        np.testing.assert_allclose(neg[v], fx['neg_score'][v], atol=TOL, rtol=0)
+    for k in kept:
+        ref = fx['grad/' + k]
+        np.testing.assert_allclose(grads[k].numpy(), ref, atol=1e-6 + 1e-4 * np.abs(ref).max(), rtol=0, err_msg=k)
+
+
+@pytest.mark.parametrize('name', ['houlsby', 'houlsby_gelu', 'pfeiffer', 'roberta_cpc_pfeiffer'])
+def test_autocast_fixture_is_a_reduced_precision_run_of_the_same_step(name):
+    """<name>_autocast.npz = the imported reference under torch.autocast(bfloat16) on the weights / batch of <name>.npz: close to the
+    fp32 fixture (a bf16-sized distance, not a different computation) and not identical to it."""
+    import os
+    fx, ac = np.load(os.path.join(GOLDEN, name + '.npz')), np.load(os.path.join(GOLDEN, name + '_autocast.npz'))
+    d_emb = np.abs(ac['input_embs_all'] - fx['input_embs_all']).max()
+    assert 1e-5 < d_emb < 5e-2 and abs(float(ac['loss']) - float(fx['loss'])) < 5e-2
+    rel = ac['grad_rel_err_vs_fp32']
+    assert 1e-4 < rel.max() < 0.2
+    keys = [k for k in ac.files if k.startswith('grad/')]
+    assert len(keys) == len(rel) == len([k for k in fx.files if k.startswith('grad/')])
