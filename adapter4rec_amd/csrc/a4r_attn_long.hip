@@ -12,8 +12,8 @@
 // probabilities feed the next product as an MFMA operand WITHOUT any re-layout by permuting the contraction index:
 //     k-slot (kg, j) of chunk step st  <->  key  KSTEP*st + (j >> 2)*16 + 4*kg + (j & 3)
 // (two score tiles per step for bf16, one for fp32).  The other operand of such a product needs, per lane, 4 + 4
-// consecutive KEYS at one head column -- i.e. a transposed copy of V (or K, Q, dO), which is written once per workgroup
-// when the matrix is staged ([64][S_pad + 8] elements: 8-byte reads, conflict-free per half wave).
+// consecutive KEYS at one head column -- i.e. V (or K, Q, dO) read TRANSPOSED from its row-major LDS image: ds_read_b64_tr_b16 for
+// bf16, four 4-byte gathers for fp32 (frag_T; no second, transposed image of anything).
 //
 // forward  (per 16-query block): S^T = K Q^T | softmax | O^T = V^T P^T         + lse = max + log(sum) per query (fp32)
 // backward, two launches (FlashAttention-2 split, no atomics):
@@ -48,8 +48,8 @@ template <typename T, int DH> struct Geo {
 
 // LDS layout of a workgroup: the staged matrices (lds_main_*), then one output staging block per wave (bf16 only)
 template <typename T, int DH> struct STG { static constexpr int BYTES = sizeof(T) == 2 ? 16 * DH * 2 : 0; };
-template <typename T, int DH, int NKT> constexpr size_t img_t() { return sizeof(T) == 2 ? 0 : DH * (NKT * 16 + 8) * sizeof(T); }   // transposed copy (fp32 only)
-template <typename T, int DH, int NKT> constexpr size_t lds_main_fwd() { return (size_t)NKT * 16 * Geo<T, DH>::ROWB + (sizeof(T) == 2 ? (size_t)NKT * 16 * Geo<T, DH>::ROWB : img_t<T, DH, NKT>()); }
+template <typename T, int DH, int NKT> constexpr size_t img_t() { return 0; }   // (round 3: no transposed copy for fp32 either -- with it the fp32 backward needed 174 / 235 KB of LDS at S = 197 and could not run ViT-B/16)
+template <typename T, int DH, int NKT> constexpr size_t lds_main_fwd() { return 2 * (size_t)NKT * 16 * Geo<T, DH>::ROWB; }
 template <typename T, int DH, int NKT> constexpr size_t lds_main_dq() { return 2 * (size_t)NKT * 16 * Geo<T, DH>::ROWB + img_t<T, DH, NKT>(); }
 template <typename T, int DH, int NKT> constexpr size_t lds_main_dkdv() { return 2 * (size_t)NKT * 16 * Geo<T, DH>::ROWB + 2 * img_t<T, DH, NKT>() + 2 * NKT * 16 * sizeof(float); }
 
@@ -62,34 +62,12 @@ template <typename T, int DH> A4R_DEV void stage_rows(char* lds, const T* src, i
         *reinterpret_cast<uint4*>(lds + r * G::ROWB + ((c ^ G::swz(r)) << 4)) = v;
     }
 }
-// [S][DH] -> LDS transposed [DH][SPT] (SPT = SP + 8 elements); columns >= S are zero
-template <typename T, int DH> A4R_DEV void stage_cols(T* lds, const T* src, int ld, int S, int SP, int SPT, int tid, int NTHR) {
-    using G = Geo<T, DH>;
-    for (int id = tid; id < SP * G::CPR; id += NTHR) {
-        const int c = id / SP, r = id % SP;                  // consecutive lanes -> consecutive rows: LDS stores spread over banks
-        const uint4 v = r < S ? ldg16(src + (size_t)r * ld + c * G::PER) : make_uint4(0, 0, 0, 0);
-        const T* e = reinterpret_cast<const T*>(&v);
-#pragma unroll
-        for (int j = 0; j < G::PER; ++j) lds[(c * G::PER + j) * SPT + r] = e[j];
-    }
-}
 // operand chunk from a row-major image: row `row`, chunk step ks
 template <typename T, int DH> A4R_DEV uint4 frag_rows(const char* lds, int row, int ks, int kg) {
     using G = Geo<T, DH>;
     return *reinterpret_cast<const uint4*>(lds + row * G::ROWB + (((ks * 4 + kg) ^ G::swz(row)) << 4));
 }
-// operand chunk from a transposed image: head column d, chunk step st over the (permuted) key/query index
-template <typename T, int DH> A4R_DEV uint4 frag_cols(const T* lds, int SPT, int d, int st, int kg) {
-    using G = Geo<T, DH>;
-    const T* p = lds + d * SPT + G::KSTEP * st + 4 * kg;
-    if constexpr (sizeof(T) == 2) {
-        const uint2 lo = *reinterpret_cast<const uint2*>(p), hi = *reinterpret_cast<const uint2*>(p + 16);
-        return make_uint4(lo.x, lo.y, hi.x, hi.y);
-    } else {
-        return *reinterpret_cast<const uint4*>(p);
-    }
-}
-// The same operand chunk for bf16 WITHOUT a transposed copy: ds_read_b64_tr_b16 gathers, per 16-lane group, a 4-row x 16-column
+// The transposed operand chunk (4 + 4 consecutive keys at one head column) for bf16 WITHOUT a transposed copy: ds_read_b64_tr_b16 gathers, per 16-lane group, a 4-row x 16-column
 // block of a ROW-major image and hands lane i the block's column i (4 consecutive rows) -- exactly the 4 + 4 keys the permuted
 // contraction index asks for.  Lane 4q + p of a group supplies the address of block row q, columns 4p .. 4p+3.  EXEC must be
 // all ones (every call site sits in wave-uniform control flow).
@@ -107,9 +85,23 @@ template <int DH> A4R_DEV uint4 frag_tr(const char* lds, int d0, int st, int lan
     return make_uint4(l2.x, l2.y, h2.x, h2.y);
 }
 // one accessor for both element types: bf16 reads the row-major image transposed, fp32 a transposed copy
+// fp32 (the parity instantiation): the same 4 consecutive rows at one head column, gathered with four 4-byte reads from the ROW-major
+// swizzled image (no transposed copy: two [64][S + 8] fp32 images next to the row-major ones did not fit the LDS at S = 197)
+template <int DH> A4R_DEV uint4 frag_gather_f32(const char* lds, int d, int st, int kg) {
+    using G = Geo<float, DH>;
+    uint4 r;
+    uint32_t* o = &r.x;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int row = G::KSTEP * st + 4 * kg + j;
+        o[j] = *reinterpret_cast<const uint32_t*>(lds + row * G::ROWB + (((d >> 2) ^ G::swz(row)) << 4) + (d & 3) * 4);
+    }
+    return r;
+}
+// one accessor for both element types: both read the row-major image transposed
 template <typename T, int DH> A4R_DEV uint4 frag_T(const void* img, int SPT, int d0, int st, int lane) {
     if constexpr (sizeof(T) == 2) return frag_tr<DH>(reinterpret_cast<const char*>(img), d0, st, lane);
-    else return frag_cols<T, DH>(reinterpret_cast<const T*>(img), SPT, d0 + (lane & 15), st, lane >> 4);
+    else return frag_gather_f32<DH>(reinterpret_cast<const char*>(img), d0 + (lane & 15), st, lane >> 4);
 }
 // dropout of the probabilities (SelfAttention.dropout, modules.py:35): element (pair = item * heads + head, query, key); the four
 // consecutive keys of a transposed score tile share one hash
@@ -203,17 +195,15 @@ __global__ void __launch_bounds__(WG<NKT>::NTHR, 4) attn_long_fwd_kernel(const T
     constexpr int NTHR = WG<NKT>::NTHR, NWAVE = WG<NKT>::NWAVE;
     constexpr int SP = NKT * 16, SPT = SP + 8, NST = SP / G::KSTEP;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    constexpr bool TR = sizeof(T) == 2;
     char* Kr = smem;                                                  // [SP][DH] row-major
-    char* Vimg = smem + SP * G::ROWB;                                 // bf16: [SP][DH] row-major (read transposed); fp32: [DH][SPT]
+    char* Vimg = smem + SP * G::ROWB;                                 // [SP][DH] row-major (read transposed: ds_read_b64_tr_b16 / 4-byte gathers)
     const int item = blockIdx.x / nh, h = blockIdx.x % nh;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, fr = lane & 15, kg = lane >> 4;
     char* stg = smem + lds_main_fwd<T, DH, NKT>() + wave * STG<T, DH>::BYTES;      // this wave's output staging block (bf16)
     const T* base = qkv + (size_t)item * S * ld + h * DH;
     if (!(dr.abl & 4)) {
         stage_rows<T, DH>(Kr, base + k_off, ld, S, SP, tid, NTHR);
-        if constexpr (TR) stage_rows<T, DH>(Vimg, base + v_off, ld, S, SP, tid, NTHR);
-        else stage_cols<T, DH>(reinterpret_cast<T*>(Vimg), base + v_off, ld, S, SP, SPT, tid, NTHR);
+        stage_rows<T, DH>(Vimg, base + v_off, ld, S, SP, tid, NTHR);
     }
     __syncthreads();
     const int nqb = (S + 15) >> 4;
@@ -280,17 +270,15 @@ __global__ void __launch_bounds__(WG<NKT>::NTHR, 4) attn_long_dq_kernel(const T*
     constexpr int NTHR = WG<NKT>::NTHR, NWAVE = WG<NKT>::NWAVE;
     constexpr int SP = NKT * 16, SPT = SP + 8, NST = SP / G::KSTEP;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    constexpr bool TR = sizeof(T) == 2;
     char* Kr = smem;
     char* Vr = smem + SP * G::ROWB;
-    char* Kimg = TR ? Kr : smem + 2 * SP * G::ROWB;                   // bf16: K's row-major image doubles as the transposed operand
+    char* Kimg = Kr;                                                  // K's row-major image doubles as the transposed operand
     const int item = blockIdx.x / nh, h = blockIdx.x % nh;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, fr = lane & 15, kg = lane >> 4;
     char* stg = smem + lds_main_dq<T, DH, NKT>() + wave * STG<T, DH>::BYTES;
     const T* base = qkv + (size_t)item * S * ld + h * DH;
     stage_rows<T, DH>(Kr, base + k_off, ld, S, SP, tid, NTHR);
     stage_rows<T, DH>(Vr, base + v_off, ld, S, SP, tid, NTHR);
-    if constexpr (!TR) stage_cols<T, DH>(reinterpret_cast<T*>(Kimg), base + k_off, ld, S, SP, SPT, tid, NTHR);
     __syncthreads();
     const int nqb = (S + 15) >> 4;
     for (int qb = wave; qb < nqb; qb += NWAVE) {
@@ -369,12 +357,11 @@ __global__ void __launch_bounds__(WG<NKT>::NTHR, 4) attn_long_dkdv_kernel(const 
     constexpr int NTHR = WG<NKT>::NTHR, NWAVE = WG<NKT>::NWAVE;
     constexpr int SP = NKT * 16, SPT = SP + 8, NG = SP / G::KSTEP;          // NG query groups of KSTEP queries
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    constexpr bool TR = sizeof(T) == 2;
     char* Qr = smem;
     char* Or = smem + SP * G::ROWB;
-    char* Qimg = TR ? Qr : smem + 2 * SP * G::ROWB;
-    char* Oimg = TR ? Or : Qimg + DH * SPT * sizeof(T);
-    float* lse_s = reinterpret_cast<float*>(TR ? smem + 2 * SP * G::ROWB : Oimg + DH * SPT * sizeof(T));
+    char* Qimg = Qr;
+    char* Oimg = Or;
+    float* lse_s = reinterpret_cast<float*>(smem + 2 * SP * G::ROWB);
     float* del_s = lse_s + SP;
     const int item = blockIdx.x / nh, h = blockIdx.x % nh;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, fr = lane & 15, kg = lane >> 4;
@@ -383,10 +370,6 @@ __global__ void __launch_bounds__(WG<NKT>::NTHR, 4) attn_long_dkdv_kernel(const 
     const T* dob = dctx + (size_t)item * S * ldo + h * DH;
     stage_rows<T, DH>(Qr, base + q_off, ld, S, SP, tid, NTHR);
     stage_rows<T, DH>(Or, dob, ldo, S, SP, tid, NTHR);
-    if constexpr (!TR) {
-        stage_cols<T, DH>(reinterpret_cast<T*>(Qimg), base + q_off, ld, S, SP, SPT, tid, NTHR);
-        stage_cols<T, DH>(reinterpret_cast<T*>(Oimg), dob, ldo, S, SP, SPT, tid, NTHR);
-    }
     for (int i = tid; i < SP; i += NTHR) {
         lse_s[i] = i < S ? lse[((size_t)item * nh + h) * S + i] * 1.44269504088896f : 0.f;
         del_s[i] = i < S ? delta[((size_t)item * nh + h) * S + i] : 0.f;

@@ -95,6 +95,14 @@ A4R_DEV void glds16(const void* base, uint32_t voff, uint32_t lds_dst) {
         : "memory");
 }
 
+typedef int i32x8_t __attribute__((ext_vector_type(8)));
+A4R_DEV f32x4_t mma_mx8(const uint4& a0, const uint4& a1, const uint4& b0, const uint4& b1, f32x4_t c) {
+    const i32x8_t a = {(int)a0.x, (int)a0.y, (int)a0.z, (int)a0.w, (int)a1.x, (int)a1.y, (int)a1.z, (int)a1.w};
+    const i32x8_t b = {(int)b0.x, (int)b0.y, (int)b0.z, (int)b0.w, (int)b1.x, (int)b1.y, (int)b1.z, (int)b1.w};
+    // cbsz = blgp = 0: both operands OCP e4m3; scales: E8M0 127 = 2^0 in every byte
+    return __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(a, b, c, 0, 0, 0, 0x7F7F7F7F, 0, 0x7F7F7F7F);
+}
+
 template <typename TI, typename TO, int ACT, int DACT, int EF>
 __global__ void __launch_bounds__(512, 2) gemm_nt_256_kernel(const a4r_gemm_t p, int ntm, int ntn, int gn_flags, uint32_t thr16, float keep_scale) {
     const int gn = gn_flags & 0xffff;                     // band width of the tile map; bit 16: A4R_GEMM_NO_STREAM=1 (A/B switch)
@@ -194,13 +202,30 @@ __global__ void __launch_bounds__(512, 2) gemm_nt_256_kernel(const a4r_gemm_t p,
     _Pragma("unroll") for (int ni = 0; ni < 2; ++ni)                                                  \
         _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                              \
             dst_[ni][ks] = *reinterpret_cast<const uint4*>(lds + ((buf_) * 4 + (unit_)) * UNIT_BYTES + b_off[ni][ks]);
+    // e4m3 operands: ONE block-scaled v_mfma_scale_f32_16x16x128_f8f6f4 per output tile and K-tile (the 2 x 16 bytes a lane holds of a
+    // 128-byte K-tile row are its 32-element K block; both operands use the same byte -> contraction-slot map, so the products pair the
+    // right elements).  The E8M0 block scales are all 2^0: the per-token / per-channel fp32 scales stay in the epilogue, the instruction
+    // is used for its issue rate -- 32 cycles for K = 128 against 4 x 16 for the non-scaled K = 32 form, i.e. twice the bf16 rate
+    // (A4R_FP8_MX=0 at compile time: the non-scaled form, A/B builds).
+#ifndef A4R_FP8_MX
+#define A4R_FP8_MX 1
+#endif
 #define A4R_MFMA16(ax_, bx_, m0_, n0_)                                                                \
+    if constexpr (sizeof(TI) == 1 && A4R_FP8_MX) {                                                    \
+        _Pragma("unroll") for (int mi = 0; mi < 4; ++mi)                                              \
+            _Pragma("unroll") for (int ni = 0; ni < 2; ++ni)                                          \
+                acc[(m0_) + mi][(n0_) + ni] = mma_mx8(bx_[ni][0], bx_[ni][1], ax_[mi][0], ax_[mi][1], acc[(m0_) + mi][(n0_) + ni]); \
+    } else {                                                                                          \
     _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                                  \
         _Pragma("unroll") for (int mi = 0; mi < 4; ++mi)                                              \
             _Pragma("unroll") for (int ni = 0; ni < 2; ++ni)                                          \
-                Mma<TI>::mma(bx_[ni][ks], ax_[mi][ks], acc[(m0_) + mi][(n0_) + ni]);
+                Mma<TI>::mma(bx_[ni][ks], ax_[mi][ks], acc[(m0_) + mi][(n0_) + ni]);                  \
+    }
     // full_: the units this phase's counted wait leaves in flight were all issued -> vmcnt(8) (four units may stay in flight);
     // else the shorter count tail_ of the end of the K range.  ONE copy of every phase (duplicated phase bodies spill).
+#ifndef A4R_Z0_NOWAIT
+#define A4R_Z0_NOWAIT 1    /* 0: the counted vmcnt(8) also in the first K-tile of an output tile (A/B builds) */
+#endif
 #ifndef A4R_ABL
 #define A4R_ABL 0          /* timing-only diagnostic builds (tools/gemm_abl.sh): 1 no DMA, 2 no MFMA, 4 no fragment reads, 8 no barriers, 16 no setprio */
 #endif
@@ -214,7 +239,9 @@ __global__ void __launch_bounds__(512, 2) gemm_nt_256_kernel(const a4r_gemm_t p,
     if (!(A4R_ABL & 1)) { issue_ }                                                                    \
     __builtin_amdgcn_sched_barrier(0);                                                                \
     A4R_ST(1)                                                                                         \
-    if (full_) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");                                       \
+    if (z_ && A4R_Z0_NOWAIT) { /* first K-tile of an output tile: every unit read before K-tile 1's phase 1 was issued BEFORE the previous */ \
+    } /* tile's stores and has landed (counted wait + barrier at the top of the tile): no wait, the stores keep draining for these 4 phases */ \
+    else if (full_) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");                                  \
     else asm volatile("s_waitcnt vmcnt(" tail_ ")" ::: "memory");                                     \
     A4R_ST(2)                                                                                         \
     if (!(A4R_ABL & 8)) __builtin_amdgcn_s_barrier();                                                 \
@@ -245,6 +272,9 @@ __global__ void __launch_bounds__(512, 2) gemm_nt_256_kernel(const a4r_gemm_t p,
     }
 
     f32x4_t acc[8][4];
+    // store instructions a wave issues per output tile: 8 rows x 2 pairs of 16-byte (bf16) / 2 x 16-byte (fp32) stores, + the second output
+    // (a LOWER bound: the generic EF < 0 instantiation may or may not carry a second output)
+    constexpr int EPI_STORES = 16 * ((int)sizeof(TO) / 2) + ((EF >= 0 && (EF & 8)) ? 16 : 0);
 
     // fragment addressing (unit-local): A rows wm*64 + mi4*16 + (lane&15), B rows wn*32 + ni2*16 + (lane&15)
     const int fr = lane & 15, kg = lane >> 4;
@@ -467,7 +497,9 @@ __global__ void __launch_bounds__(512, 2) gemm_nt_256_kernel(const a4r_gemm_t p,
     A4R_NEXT_TILE()
     // the next tile's 6 prologue units were issued BEFORE this tile's stores: all of them have landed once at most the 16 youngest
     // operations (>= 16 stores per wave follow the DMAs) are still outstanding.  The stores themselves drain behind the next K loop.
-    asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+    // (vmcnt counts stores and is in order: a smaller count than the epilogue's store count would wait for stores here)
+    if constexpr (EPI_STORES >= 32) asm volatile("s_waitcnt vmcnt(32)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
   }
 #undef A4R_NEXT_TILE
 #undef A4R_PROLOGUE

