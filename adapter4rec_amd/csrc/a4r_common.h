@@ -118,6 +118,16 @@ template <> struct Mma<fp8_t> {
     }
 };
 
+// 8 fp32 -> 8 OCP e4m3 bytes (v_cvt_pk_fp8_f32: round to nearest even; the caller keeps |v| <= 448)
+A4R_DEV uint2 f32x8_to_fp8(const float (&v)[8]) {
+    int lo = 0, hi = 0;
+    lo = __builtin_amdgcn_cvt_pk_fp8_f32(v[0], v[1], lo, false);
+    lo = __builtin_amdgcn_cvt_pk_fp8_f32(v[2], v[3], lo, true);
+    hi = __builtin_amdgcn_cvt_pk_fp8_f32(v[4], v[5], hi, false);
+    hi = __builtin_amdgcn_cvt_pk_fp8_f32(v[6], v[7], hi, true);
+    return make_uint2((unsigned)lo, (unsigned)hi);
+}
+
 // Gather one operand chunk DOWN a column of a row-major LDS tile (the "transposed" operand form:
 // the contraction index runs along tile rows).  Lane (i = l & 15, kg = l >> 4) collects
 // tile[k0 + kg*PER16 + j][col0 + i], j = 0..PER16-1.  stride_b = tile row stride in bytes.

@@ -302,6 +302,8 @@ extern "C" int a4r_gemm_nt(void* stream, const a4r_gemm_t* gp) {
         if (g.c2_mode < 0 || g.c2_mode > 2 || (g.C2 && g.c2_mode == 2 && g.act != A4R_ACT_GELU)) return A4R_EINVAL;
         if (!aligned16(g.A) || !aligned16(g.B) || !aligned16(g.C) || (g.C2 && (!aligned16(g.C2) || (g.ldc2 * (g.c2_mode == 2 ? 1 : osz)) % 16 || g.ldc2 < g.N))) return A4R_EINVAL;
         if ((g.R1 && (!aligned16(g.R1) || (g.ldr1 * osz) % 16)) || (g.R2 && (!aligned16(g.R2) || (g.ldr2 * osz) % 16))) return A4R_EINVAL;
+        if (g.dact != A4R_ACT_NONE && (g.dact != A4R_DACT_MULQ8_ || !g.Pre || !aligned16(g.Pre) || g.ldpre % 16 || g.ldpre < g.N)) return A4R_EINVAL;   // (the 8-bit derivative form only)
+        if (g.c_fp8 && (g.ldc % 16 || g.R1 || g.R2)) return A4R_EINVAL;                                     // e4m3 C: ldc counts bytes
         if (g.drop_p < 0.f || g.drop_p >= 1.f) return A4R_EINVAL;
         const int rc = a4r_gemm_nt_256(reinterpret_cast<hipStream_t>(stream), g);
         return rc == 1 ? A4R_EINVAL : rc;

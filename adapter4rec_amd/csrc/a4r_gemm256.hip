@@ -379,10 +379,12 @@ __global__ void __launch_bounds__(512, 2) gemm_nt_256_kernel(const a4r_gemm_t p,
     int lane_e = lane;
     asm volatile("" : "+v"(lane_e));
     const int fr_e = lane_e & 15, kg_e = lane_e >> 4;
-    const uint32_t c_lane = (uint32_t)(((wm * 128 + fr_e) * epi.ldc + wn * 64 + (kg_e & 1) * 16 + (kg_e >> 1) * 8) * (int)sizeof(TO));
-    const uint32_t c_rowstep = (uint32_t)(16 * epi.ldc * (int)sizeof(TO));
+    constexpr bool C8 = EF >= 0 && (EF & 16) != 0;         // C leaves as e4m3 bytes (a4r_gemm_t.c_fp8): one byte per element, ldc in bytes
+    constexpr int CSZ = C8 ? 1 : (int)sizeof(TO);
+    const uint32_t c_lane = (uint32_t)(((wm * 128 + fr_e) * epi.ldc + wn * 64 + (kg_e & 1) * 16 + (kg_e >> 1) * 8) * CSZ);
+    const uint32_t c_rowstep = (uint32_t)(16 * epi.ldc * CSZ);
     const uint64_t e0_lane = (uint64_t)(wm * 128 + fr_e) * (uint64_t)epi.N + (uint64_t)(wn * 64 + (kg_e & 1) * 16 + (kg_e >> 1) * 8);
-    char* const c_tile = reinterpret_cast<char*>(epi.C) + ((size_t)tm_done * 256 * (uint32_t)epi.ldc + (size_t)tn_done * 256) * sizeof(TO);
+    char* const c_tile = reinterpret_cast<char*>(epi.C) + ((size_t)tm_done * 256 * (uint32_t)epi.ldc + (size_t)tn_done * 256) * CSZ;
     const uint64_t e0_tile = ((uint64_t)tm_done * 256 + epi.row0) * (uint64_t)epi.N + (uint64_t)tn_done * 256;
     float bias8[2][8];                                    // (gcolp % 8 == 0: 16-byte loads are aligned iff the bias pointer is)
 #pragma unroll
@@ -413,6 +415,18 @@ __global__ void __launch_bounds__(512, 2) gemm_nt_256_kernel(const a4r_gemm_t p,
             for (int e = 0; e < 8; ++e) sb8[pr][e] = p.scale_b[gcolp + pr * 32 + e];
 #pragma unroll
         for (int mi = 0; mi < 8; ++mi) sa8[mi] = p.scale_a[grow0 + mi * 16];
+    }
+    // e4m3 output: the multiplier that takes a finished value to its stored form (per row of 16: c_fp8 2 scales a row by its A row's scale)
+    float cmul8[8];
+#pragma unroll
+    for (int mi = 0; mi < 8; ++mi) cmul8[mi] = 1.f;
+    if constexpr (C8) {
+#pragma unroll
+        for (int mi = 0; mi < 8; ++mi) {
+            const float so = p.c_fp8 == 2 ? sa8[mi] * p.c_scale : p.c_scale;
+            cmul8[mi] = __frcp_rn(so);
+            if (p.c_fp8 == 2 && tn_done == 0 && wn == 0 && kg == 0) p.c_scale_out[grow0 + mi * 16] = so;      // (one writer per row)
+        }
     }
     // Operands the epilogue READS -- Pre (dgrad through an activation: C = acc * act'(Pre)) and R1 (dgrad GEMMs: the gradient of the
     // residual branch) -- are requested PRE_D / R1_D rows of 16 ahead of the row that consumes them: a load waited for where it is
@@ -446,7 +460,7 @@ __global__ void __launch_bounds__(512, 2) gemm_nt_256_kernel(const a4r_gemm_t p,
 #undef A4R_LD_FIRST
 #define A4R_LD_AHEAD(LD_, D_, n1_, n2_, n4_)                                                                                \
     if constexpr ((D_) == 1) { LD_(n1_) } else if constexpr ((D_) == 2) { LD_(n2_) } else if constexpr ((D_) == 4) { LD_(n4_) }
-#define A4R_EPI_CDST(mi_, pr_) (reinterpret_cast<TO*>(c_tile + (c_lane + (uint32_t)(mi_) * c_rowstep)) + (pr_) * 32)
+#define A4R_EPI_CDST(mi_, pr_) reinterpret_cast<TO*>(c_tile + (c_lane + (uint32_t)(mi_) * c_rowstep) + (pr_) * 32 * CSZ)
 #if (A4R_ABL & 32)      /* timing-only experiment: every store instruction covers whole 128-byte lines (8 rows x 128 B); WRONG data placement */
 #define A4R_EPI_CALL(mi_, pr_)                                                                                              \
         epilogue_n<TO, 8, ACT, DACT, R1PF, false, EF>(v_, bias8[pr_], grow0 - fr + (fr & 7) + 8 * (pr_) + (mi_) * 16, gcolp + (fr >> 3) * 32, epi,
@@ -471,7 +485,7 @@ __global__ void __launch_bounds__(512, 2) gemm_nt_256_kernel(const a4r_gemm_t p,
         const uint64_t e0_ = e0_lane + (e0_tile + (uint64_t)((mi_) * 16) * (uint64_t)epi.N + (pr_) * 32);                      \
         A4R_EPI_CALL(mi_, pr_)                                                                                              \
                                            DACT != A4R_ACT_NONE ? pre_s##mi_##_##pr_ : nullptr, R1PF ? r1_s##mi_##_##pr_ : nullptr, nullptr, \
-                                           A4R_EPI_CDST(mi_, pr_), e0_);                                                    \
+                                           A4R_EPI_CDST(mi_, pr_), e0_, cmul8[mi_]);                                        \
     }
 #define A4R_EPI_ROW(mi_, n1_, n2_, n4_)                                                                                     \
     A4R_LD_AHEAD(A4R_LD_PRE, PRE_D, n1_, n2_, n4_)                                                                          \
@@ -609,9 +623,18 @@ int dispatch_same(hipStream_t s, const a4r_gemm_t& g) {   // in == out dtype: th
 int a4r_gemm_nt_256(hipStream_t s, const a4r_gemm_t& g) {
     if (g.bias && (reinterpret_cast<uintptr_t>(g.bias) & 3u)) return 1;
     if ((uint64_t)g.M * (uint64_t)g.ldc * (g.out_dtype == A4R_F32 ? 4u : 2u) >= (1ull << 32)) return 1;      // 32-bit per-lane output offsets
-    if (g.in_dtype == A4R_FP8) {                      // e4m3 operands (frozen-backbone forward GEMMs): plain and GELU (+ derivative) epilogues
-        if (g.out_dtype != A4R_BF16 || !g.scale_a || !g.scale_b || g.dact != A4R_ACT_NONE) return 1;
+    if (g.in_dtype == A4R_FP8) {                      // e4m3 operands (frozen-backbone GEMMs): plain and GELU (+ derivative) epilogues, and the
+        if (g.out_dtype != A4R_BF16 || !g.scale_a || !g.scale_b) return 1;          // two forms whose OUTPUT is the next fp8 GEMM's A operand
         const int m = epi_mask(g);
+        if (g.c_fp8) {
+            if ((g.c_fp8 != 1 && g.c_fp8 != 2) || !(g.c_scale > 0.f) || (g.c_fp8 == 2 && !g.c_scale_out)) return 1;
+            if (g.act == A4R_ACT_GELU && g.dact == A4R_ACT_NONE && m == 8 && g.c2_mode == 2)              // FFN-up: u as e4m3 + gelu' as 8 bits
+                return launch256<fp8_t, bf16_t, A4R_ACT_GELU, A4R_ACT_NONE, 24>(s, g);
+            if (g.act == A4R_ACT_NONE && g.dact == A4R_DACT_MULQ8_ && m == 0)                             // d FFN-down: du = (dy W) * gelu' as e4m3
+                return launch256<fp8_t, bf16_t, A4R_ACT_NONE, A4R_DACT_MULQ8_, 16>(s, g);
+            return 1;
+        }
+        if (g.dact != A4R_ACT_NONE) return 1;
         if (g.act == A4R_ACT_NONE) return m == 0 ? launch256<fp8_t, bf16_t, A4R_ACT_NONE, A4R_ACT_NONE, 0>(s, g) : launch256<fp8_t, bf16_t, A4R_ACT_NONE, A4R_ACT_NONE>(s, g);
         if (g.act == A4R_ACT_GELU) return m == 8 ? launch256<fp8_t, bf16_t, A4R_ACT_GELU, A4R_ACT_NONE, 8>(s, g) : launch256<fp8_t, bf16_t, A4R_ACT_GELU, A4R_ACT_NONE>(s, g);
         return 1;

@@ -111,7 +111,7 @@ template <typename TO, int NC, bool Q8 = false> A4R_DEV void load_pre_n(uint4* q
 // others (a uniform branch each, 16 groups per tile) and their code are not emitted.  EF < 0: every piece behind its run-time test.
 template <typename TO, int NC, int ACT = -1, int DACT = -1, bool R1PF = false, bool FAST = false, int EF = -1>
 A4R_DEV void epilogue_n(float (&v)[NC], const float* bias, uint32_t grow, int gcol, const GemmEpi<TO>& e, const uint4* pre_ld = nullptr,
-                        const uint4* r1_ld = nullptr, const uint4* r2_ld = nullptr, TO* cdst = nullptr, uint64_t e0v = 0) {
+                        const uint4* r1_ld = nullptr, const uint4* r2_ld = nullptr, TO* cdst = nullptr, uint64_t e0v = 0, float cmul = 1.f) {
     // FAST (cdst, e0v): the caller formed the address of C[grow][gcol] / the dropout element index itself (the 256-tile kernel: a uniform
     // tile base + a per-lane 32-bit offset instead of a 64-bit multiply per group)
     const int act = ACT >= 0 ? ACT : e.act;
@@ -202,6 +202,14 @@ A4R_DEV void epilogue_n(float (&v)[NC], const float* bias, uint32_t grow, int gc
     }
     if (thr16 && !e.drop_first)
         epi_dropout<NC>(v, FAST ? e0v : ((uint64_t)grow + e.row0) * (uint64_t)e.N + (uint64_t)gcol, e.drop_seed, e.drop_site, thr16, e.keep_scale);
+    if constexpr (EF >= 0 && (EF & 16) != 0) {               // C as OCP e4m3 bytes (a4r_gemm_t.c_fp8): v * cmul, saturated at +-448, 8 bytes per lane
+        static_assert(NC == 8 && FAST, "e4m3 output: the 256-tile kernel's form");
+        float t[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) t[i] = __builtin_amdgcn_fmed3f(v[i] * cmul, -448.f, 448.f);
+        *reinterpret_cast<uint2*>(cdst) = f32x8_to_fp8(t);
+        return;
+    }
     if (!(A4R_ABL & 512) || v[0] == 12345.678f) store_n<TO, NC>(FAST ? cdst : e.C + (size_t)grow * (uint32_t)e.ldc + gcol, v);
 }
 // the NC elements of a residual operand as 16-byte pieces, for a caller that requests them ahead of use (r1_ld / r2_ld above)

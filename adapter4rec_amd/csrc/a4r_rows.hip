@@ -141,14 +141,6 @@ __global__ void __launch_bounds__(256) embed_bwd_kernel(const int64_t* __restric
 // ------------------------------------------------------------------ fp8 (OCP e4m3fn) row quantisation
 // x8[row] = e4m3(x[row] * 448 / amax(row)), scale[row] = amax(row) / 448: one scale per row (token), the A operand form of the
 // fp8 a4r_gemm_nt.  v_cvt_pk_fp8_f32 rounds to nearest even; |x * 448 / amax| <= 448 = the e4m3 maximum, so nothing overflows.
-A4R_DEV uint2 f32x8_to_fp8(const float (&v)[8]) {
-    int lo = 0, hi = 0;
-    lo = __builtin_amdgcn_cvt_pk_fp8_f32(v[0], v[1], lo, false);
-    lo = __builtin_amdgcn_cvt_pk_fp8_f32(v[2], v[3], lo, true);
-    hi = __builtin_amdgcn_cvt_pk_fp8_f32(v[4], v[5], hi, false);
-    hi = __builtin_amdgcn_cvt_pk_fp8_f32(v[6], v[7], hi, true);
-    return make_uint2((unsigned)lo, (unsigned)hi);
-}
 A4R_DEV float wave_max(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));

@@ -244,18 +244,44 @@ class TransRecEngine:
             for p, f in flags:
                 p.requires_grad_(f)
 
+    FP8_U_SCALE = 0.25          # static scale of the FFN's GELU output as e4m3 (|u| <= 112 representable, subnormal step 5e-4)
+    FP8_DU_MARGIN = 16.0        # c_scale of the d FFN-down output = margin x max column norm of W2 (see _build_fp8)
+
     def _build_fp8(self):
-        """e4m3 copies (+ per-output-channel scales) of the FROZEN qkv and FFN-up operands of every item-tower block."""
+        """e4m3 copies (+ per-output-channel scales) of the FROZEN operands of every item-tower block: forward qkv, attention-output,
+        FFN-up, FFN-down, and the two FFN dgrad operands (W2^T for du = (d_o W2) * gelu', W1^T for dn2 = du W1).
+        The dgrad chain keeps ONE scale per token row: d_o is quantised per row (absmax / 448); du inherits that row scale times
+        c_du = FP8_DU_MARGIN x max_c |W2[:, c]|_2 -- |du[m, c]| <= |d_o[m]|_2 |W2[:, c]|_2 1.13 <= 31 x absmax(d_o[m]) |W2[:, c]|_2 at the very
+        worst (all elements equal and aligned), ~1.2 x typically: with the margin at 16 a typical element is stored near 8 (of 448) and e4m3,
+        being floating point, loses no precision to the head-room."""
         if not hasattr(self.bert_blocks[0], 'lnA'):
             raise NotImplementedError("compute_dtype 'fp8' is wired for the image tower (pre-LN ViT / ViT-MAE: both fp8 GEMM inputs are "
                                       'LayerNorm outputs); the text tower runs bf16')
+        ok = lambda w: w.shape[0] % 256 == 0 and w.shape[1] % 128 == 0
+        more = _os.environ.get('A4R_FP8_MORE', '1') != '0'              # 0: round 2's coverage (forward qkv + FFN-up only; A/B runs)
         for b in self.bert_blocks:
-            b.wqkv8 = b.wi8 = None
+            b.wqkv8 = b.wi8 = b.wo8 = b.wo28 = b.wo2T8 = b.wiT8 = None
             frozen_qkv = not b.lora and all(d is not None and not d.trainable for d in b.qkv)
-            if frozen_qkv and b.wqkv.shape[0] % 256 == 0 and b.wqkv.shape[1] % 128 == 0:
+            if frozen_qkv and ok(b.wqkv):
                 b.wqkv8, b.wqkv8s = L.quantize_weight_fp8(b.wqkv)
-            if not b.d_i.trainable and b.wi.shape[0] % 256 == 0 and b.wi.shape[1] % 128 == 0:
+            if not b.d_i.trainable and ok(b.wi):
                 b.wi8, b.wi8s = L.quantize_weight_fp8(b.wi)
+            if more and not b.d_o.trainable and ok(b.wo):
+                b.wo8, b.wo8s = L.quantize_weight_fp8(b.wo)
+            if more and b.wi8 is not None and not b.d_o2.trainable and ok(b.wo2) and ok(b.wo2T) and ok(b.wiT) and self._q8(b):
+                b.wo28, b.wo28s = L.quantize_weight_fp8(b.wo2)          # forward FFN-down  [H, F]
+                b.wo2T8, b.wo2T8s = L.quantize_weight_fp8(b.wo2T)       # d FFN-down        [F, H]: rows = columns of du
+                b.wiT8, b.wiT8s = L.quantize_weight_fp8(b.wiT)          # d FFN-up          [H, F]
+                b.c_du = float(self.FP8_DU_MARGIN * b.wo2T.float().norm(dim=1).max())
+
+    def _const_rows(self, name, rows, value):
+        """[rows, 1] fp32 buffer filled with `value` (the constant scale_a of an fp8 GEMM whose A operand carries a static scale)."""
+        key = ('const.' + name, 1, torch.float32)
+        t = self._bufs.get(key)
+        if t is None or t.shape[0] < rows:
+            t = torch.full((rows, 1), float(value), dtype=torch.float32, device=self.dev)
+            self._bufs[key] = t
+        return t[:rows]
 
     def _require_device(self, p0):
         if not p0.is_cuda:

@@ -175,17 +175,19 @@ class ViTRecEngine(TransRecEngine):
         return d
 
     # ------------------------------------------------------------------ one pre-LN layer
-    def _vit_sub_forward(self, ad, dense_in, w, bias, resid, bufs, k, M, out):
+    def _vit_sub_forward(self, ad, dense_in, w, bias, resid, bufs, k, M, out, scales=None):
+        """scales = (scale_a, scale_b): dense_in / w are e4m3 operands (the fp8 encoder's FFN-down)."""
+        sk = dict(scale_a=scales[0], scale_b=scales[1]) if scales is not None else {}
         if ad is None:
-            L.gemm_nt(dense_in, w, out, bias=bias, R1=resid, M=M)
+            L.gemm_nt(dense_in, w, out, bias=bias, R1=resid, M=M, **sk)
             return
         h, zp, z = bufs['h' + k], bufs['zp' + k], bufs['z' + k]
         if getattr(ad, 'parallel', False):    # model.py:165-179: dense(u) + x + [fc_up(act(fc_down(x))) + x], the adapter reads the sub-layer INPUT x
             L.gemm_nt(resid, ad.wd, z, bias=ad.bd, C2=zp, act=ad.act, M=M)
             L.gemm_nt(z, ad.wu, h, bias=ad.bu, R1=resid, R2=resid, M=M)
-            L.gemm_nt(dense_in, w, out, bias=bias, R1=h, M=M)
+            L.gemm_nt(dense_in, w, out, bias=bias, R1=h, M=M, **sk)
             return
-        L.gemm_nt(dense_in, w, h, bias=bias, M=M)
+        L.gemm_nt(dense_in, w, h, bias=bias, M=M, **sk)
         L.gemm_nt(h, ad.wd, z, bias=ad.bd, C2=zp, act=ad.act, M=M)
         if ad.kind == 'compacter':            # no inner residual (Downstream/CV/model/modules.py HyperComplexAdapterBlock.forward)
             L.gemm_nt(z, ad.wu, out, bias=ad.bu, R1=resid, M=M)
@@ -233,10 +235,16 @@ class ViTRecEngine(TransRecEngine):
             L.gather_rows(ctx, bufs['ctx_s'], M, 1)
         fp8_fc1 = self.fp8 and blk.wi8 is not None and M % 256 == 0
         n2 = bufs['n2_s'] if 'n2_s' in bufs else self._buf('n2', M, H, T)
+        fp8_o = self.fp8 and blk.wo8 is not None and M % 256 == 0 and 'ctx_s' not in bufs
         if self._vit_fuse(blk, blk.ad1, ctx):       # dense | adapter + residual + LN_after in one launch
             ad = blk.ad1
             h = bufs['h1']
-            L.gemm_nt(ctx, blk.wo, h, bias=blk.bo, M=M)
+            if fp8_o:                                   # the attention output as e4m3 + per-token scale (one pass), then the fp8 GEMM
+                c8, cs = self._buf('ctx8', M, H, torch.uint8), self._buf('ctx8s', M, 1, torch.float32)
+                L.quant_rows_fp8(ctx, c8, cs, M=M)
+                L.gemm_nt(c8, blk.wo8, h, bias=blk.bo, M=M, scale_a=cs, scale_b=blk.wo8s)
+            else:
+                L.gemm_nt(ctx, blk.wo, h, bias=blk.bo, M=M)
             comp = ad.kind == 'compacter'
             n2q = n2s = None
             if fp8_fc1:                                 # LN_after leaves the kernel as e4m3 + scale (bf16 copy only if something trains on it)
@@ -250,11 +258,18 @@ class ViTRecEngine(TransRecEngine):
             n2_done = False
         u = bufs['u_s'] if 'u_s' in bufs else self._buf('u', M, blk.F, T)
         c2d = 'q8' if self._q8(blk) else True
+        fp8_ffn = fp8_fc1 and blk.wo28 is not None and 'u_s' not in bufs       # FFN-up writes u as e4m3, FFN-down (and both dgrads) run on e4m3
+        w2, w2s = (blk.wo28, (self._const_rows('su', M, self.FP8_U_SCALE), blk.wo28s)) if fp8_ffn else (blk.wo2, None)
         if fp8_fc1:
             n2q, n2s = self._buf('n2q', M, H, torch.uint8), self._buf('n2s', M, 1, torch.float32)
             if not n2_done:
                 L.ln_fwd(bufs['x1'], blk.lnB.gamma, blk.lnB.beta, blk.lnB.eps, bufs.get('n2_s'), bufs['stb'], M=M, y8=n2q, ys=n2s)
-            L.gemm_nt(n2q, blk.wi8, u, bias=blk.bi, C2=bufs['upre'], act=L.ACT_GELU, c2_deriv=c2d, M=M, scale_a=n2s, scale_b=blk.wi8s)
+            if fp8_ffn:
+                u = self._buf('u8', M, blk.F, torch.uint8)
+                L.gemm_nt(n2q, blk.wi8, u, bias=blk.bi, C2=bufs['upre'], act=L.ACT_GELU, c2_deriv='q8', M=M, scale_a=n2s, scale_b=blk.wi8s,
+                          c_fp8=1, c_scale=self.FP8_U_SCALE)
+            else:
+                L.gemm_nt(n2q, blk.wi8, u, bias=blk.bi, C2=bufs['upre'], act=L.ACT_GELU, c2_deriv=c2d, M=M, scale_a=n2s, scale_b=blk.wi8s)
         else:
             if not n2_done:
                 L.ln_fwd(bufs['x1'], blk.lnB.gamma, blk.lnB.beta, blk.lnB.eps, n2, bufs['stb'], M=M)
@@ -263,7 +278,10 @@ class ViTRecEngine(TransRecEngine):
             nb_, nbufs = nxt                            # dense | adapter + residual + the NEXT layer's LN_before
             ad = blk.ad2
             h = bufs['h2']
-            L.gemm_nt(u, blk.wo2, h, bias=blk.bo2, M=M)
+            if w2s is not None:
+                L.gemm_nt(u, w2, h, bias=blk.bo2, M=M, scale_a=w2s[0], scale_b=w2s[1])
+            else:
+                L.gemm_nt(u, w2, h, bias=blk.bo2, M=M)
             comp = ad.kind == 'compacter'
             n1n = nbufs['n1'] if 'n1' in nbufs else self._buf('n1', M, H, T)
             n1q = n1s = None
@@ -273,7 +291,7 @@ class ViTRecEngine(TransRecEngine):
                              nb_.lnA.gamma, nb_.lnA.beta, nb_.lnA.eps, ad.act, bufs['zp2'], bufs['z2'], x_out,
                              n1n if (n1q is None or 'n1' in nbufs) else None, nbufs['sta'], M=M, y8=n1q, ys=n1s)
             return True
-        self._vit_sub_forward(blk.ad2, u, blk.wo2, blk.bo2, bufs['x1'], bufs, '2', M, x_out)
+        self._vit_sub_forward(blk.ad2, u, w2, blk.bo2, bufs['x1'], bufs, '2', M, x_out, scales=w2s)
         return False
 
     def _vit_sub_backward(self, blk, ad, dy, bufs, k, M, x_in=None):
@@ -315,11 +333,21 @@ class ViTRecEngine(TransRecEngine):
         else:
             d_o, dres2 = self._vit_sub_backward(blk, blk.ad2, dx_out, bufs, '2', M, x_in=bufs['x1'])
         self._dense_wgrad(blk.d_o2, d_o, bufs.get('u_s'), M)
-        du = self._buf('du', M, F, T)
-        L.gemm_nt(d_o, blk.wo2T, du, Pre=bufs['upre'], dact=L.DACT_MUL_Q8 if self._q8(blk) else L.DACT_MUL, M=M)
-        self._dense_wgrad(blk.d_i, du, bufs.get('n2_s'), M)
         dn2 = self._buf('dn', M, H, T)
-        L.gemm_nt(du, blk.wiT, dn2, M=M)
+        if self.fp8 and blk.wo2T8 is not None and M % 256 == 0 and bufs['upre'].dtype == torch.uint8 and 'u_s' not in bufs:
+            # frozen FFN, both dgrads on e4m3 operands with ONE scale per token row carried through the chain (_build_fp8):
+            #   d_o -> e4m3 + row scale | du = (d_o W2) * gelu' leaves its GEMM as e4m3 with scale[m] * c_du | dn2 = du W1 (bf16 out)
+            do8, dos = self._buf('do8', M, H, torch.uint8), self._buf('do8s', M, 1, torch.float32)
+            L.quant_rows_fp8(d_o, do8, dos, M=M)
+            du8, dus = self._buf('du8', M, F, torch.uint8), self._buf('du8s', M, 1, torch.float32)
+            L.gemm_nt(do8, blk.wo2T8, du8, Pre=bufs['upre'], dact=L.DACT_MUL_Q8, M=M, scale_a=dos, scale_b=blk.wo2T8s,
+                      c_fp8=2, c_scale=blk.c_du, c_scale_out=dus)
+            L.gemm_nt(du8, blk.wiT8, dn2, M=M, scale_a=dus, scale_b=blk.wiT8s)
+        else:
+            du = self._buf('du', M, F, T)
+            L.gemm_nt(d_o, blk.wo2T, du, Pre=bufs['upre'], dact=L.DACT_MUL_Q8 if self._q8(blk) else L.DACT_MUL, M=M)
+            self._dense_wgrad(blk.d_i, du, bufs.get('n2_s'), M)
+            L.gemm_nt(du, blk.wiT, dn2, M=M)
         dx1 = self._buf('dx1', M, H, T)
         if self._vit_fuse(blk, blk.ad1, dn2, bwd=True):
             # ONE launch: LN_after backward (+ the residual-branch gradient), dzp = (dx1 Wu) * act'(zp), da = dzp Wd [+ dx1]

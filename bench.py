@@ -168,13 +168,14 @@ class GemmProbe:
                 kw = dict(zip(names, a)); kw.update(k)
                 m = (1 if kw.get('drop_p', 0.0) > 0 else 0) | (2 if kw.get('R1') is not None else 0) | (4 if kw.get('R2') is not None else 0) | (8 if kw.get('C2') is not None else 0)
                 inst = {(0, 0): (0, 1, 2, 3), (self.L.ACT_GELU, 0): (8,), (0, self.L.DACT_MUL_Q8): (0,), (0, self.L.DACT_MUL): (0,)}
-                if A.dtype == torch.uint8:                   # e4m3 operands
-                    inst = {(0, 0): (0,), (self.L.ACT_GELU, 0): (8,)}
-                ef = m if (A.dtype in (torch.bfloat16, torch.uint8) and Cout.dtype == torch.bfloat16 and m in inst.get(ad, ())) else -1
+                if A.dtype == torch.uint8:                   # e4m3 operands (+ 16: the output leaves as e4m3 too, a4r_gemm_t.c_fp8)
+                    inst = {(0, 0): (0,), (self.L.ACT_GELU, 0): (8, 24), (0, self.L.DACT_MUL_Q8): (16,)}
+                    m |= 16 if kw.get('c_fp8') else 0
+                ef = m if (A.dtype in (torch.bfloat16, torch.uint8) and Cout.dtype in (torch.bfloat16, torch.uint8) and m in inst.get(ad, ())) else -1
                 tile = (256,) + ad + (ef,)
             else:
                 tile = (128 if N % 128 == 0 else 64,)
-            self.rec.append((str(A.dtype), str(Cout.dtype), tile, M, N, K, e0, e1))
+            self.rec.append((str(A.dtype), 'torch.bfloat16' if Cout.dtype == torch.uint8 else str(Cout.dtype), tile, M, N, K, e0, e1))      # (an e4m3 C belongs to the bf16-storage step)
         self.L.gemm_nt = wrapped
         return self
 

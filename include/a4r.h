@@ -36,7 +36,7 @@ extern "C" {
 
 /* ABI version: bumped whenever a signature or struct below changes.  The Python binding (adapter4rec_amd/_lib.py) refuses a
  * library whose a4r_version() differs, so an A/B build made before a signature change cannot be called with shifted arguments. */
-#define A4R_ABI_VERSION 300
+#define A4R_ABI_VERSION 301
 int a4r_version(void);
 
 /* C[M,N] = epilogue(alpha * A[M,K] . B[N,K]^T): every nn.Linear on the path (HF BertSelfAttention
@@ -66,6 +66,13 @@ typedef struct {
      * A [M, K] carries one scale per ROW (token), B [N, K] one per ROW (output channel): the accumulator is multiplied by
      * scale_a[m] * scale_b[n] (fp32) before alpha and the bias.  Null for the other dtypes. */
     const float* scale_a; const float* scale_b;
+    /* C stored as OCP e4m3 bytes (in_dtype A4R_FP8 only; C then has ONE byte per element and ldc counts bytes; out_dtype stays
+     * A4R_BF16 = the type of R1 / R2 / Pre / C2) -- the next fp8 GEMM's A operand straight from this epilogue:
+     *   c_fp8 = 1: C = e4m3(sat(v / c_scale)), one static scale for the whole tensor (the FFN's GELU output: O(1) values, the consumer
+     *              passes a constant scale_a = c_scale);
+     *   c_fp8 = 2: C = e4m3(sat(v / (scale_a[m] * c_scale))) and c_scale_out[m] = scale_a[m] * c_scale: a row of the result inherits the
+     *              scale of the row of A it came from times a per-layer constant (dgrad chains: du = (dy W) * gelu', |du[m]| <~ |dy[m]| |W|). */
+    int32_t c_fp8; float c_scale; float* c_scale_out;
 } a4r_gemm_t;
 int a4r_gemm_nt(void* stream, const a4r_gemm_t* g);
 /* tuning knob for A/B measurements and tests: 0 = 128x128 tile, register-staged K pipeline; 1 = 128x128 tile, direct-to-LDS

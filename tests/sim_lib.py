@@ -55,19 +55,20 @@ def _deq(t, scale):
 
 
 def gemm_nt(A, B, Cout, bias=None, C2=None, R1=None, R2=None, Pre=None, act=0, dact=0, alpha=1.0,
-            drop_p=0.0, drop_site=0, drop_seed=0, M=None, drop_first=False, c2_deriv=False, scale_a=None, scale_b=None):
+            drop_p=0.0, drop_site=0, drop_seed=0, M=None, drop_first=False, c2_deriv=False, scale_a=None, scale_b=None,
+            c_fp8=0, c_scale=1.0, c_scale_out=None):
     assert drop_p == 0.0
     M = A.shape[0] if M is None else M
     assert M % 128 == 0 and B.shape[0] % 64 == 0 and B.shape[1] % 64 == 0, (M, B.shape)
     if A.dtype == torch.uint8:           # fp8 operands (include/a4r.h: A4R_FP8)
-        assert B.dtype == torch.uint8 and M % 256 == 0 and B.shape[0] % 256 == 0 and B.shape[1] % 128 == 0 and dact == 0
+        assert B.dtype == torch.uint8 and M % 256 == 0 and B.shape[0] % 256 == 0 and B.shape[1] % 128 == 0 and (dact == 0 or (dact == 14 and c_fp8 == 2))
         v = alpha * (_deq(A[:M], scale_a) @ _deq(B, scale_b).t())
     else:
         v = alpha * (A[:M].float() @ B.float().t())
     if bias is not None:
         v = v + bias
     if C2 is not None and c2_deriv == 'q8':      # include/a4r.h c2_mode 2: gelu' as 8-bit fixed point
-        assert act == ACT_GELU and C2.dtype == torch.uint8 and Cout.dtype == torch.bfloat16
+        assert act == ACT_GELU and C2.dtype == torch.uint8 and (Cout.dtype == torch.bfloat16 or c_fp8)
         C2[:M] = torch.clamp(torch.round((_dact(v, act) + Q8_OFF) * (1.0 / Q8_STEP)), 0, 255).to(torch.uint8)
     elif C2 is not None:
         C2[:M] = (_dact(v, act) if c2_deriv else v).to(C2.dtype)
@@ -83,6 +84,13 @@ def gemm_nt(A, B, Cout, bias=None, C2=None, R1=None, R2=None, Pre=None, act=0, d
         v = v + R1[:M].float()
     if R2 is not None:
         v = v + R2[:M].float()
+    if c_fp8:                            # e4m3 output (include/a4r.h a4r_gemm_t.c_fp8): static scale, or the A row's scale x c_scale
+        assert A.dtype == torch.uint8 and Cout.dtype == torch.uint8 and R1 is None and R2 is None
+        so = torch.full((M,), float(c_scale)) if c_fp8 == 1 else scale_a.reshape(-1)[:M].float() * float(c_scale)
+        if c_fp8 == 2:
+            c_scale_out.view(-1)[:M] = so
+        Cout[:M] = torch.clamp(v / so[:, None], -448.0, 448.0).to(torch.float8_e4m3fn).view(torch.uint8)
+        return
     Cout[:M] = v.to(Cout.dtype)
 
 
