@@ -12,7 +12,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('A4R_LIB_PATH') or os.path.join(_HERE, 'liba4r_hip.so')    # A4R_LIB_PATH: A/B builds (tools/), same C ABI
 
-ABI_VERSION = 301          # = A4R_ABI_VERSION of include/a4r.h (tests/test_abi_cpu.py compares the two)
+ABI_VERSION = 302          # = A4R_ABI_VERSION of include/a4r.h (tests/test_abi_cpu.py compares the two)
 BF16, F32, FP8 = 0, 1, 2
 ACT_NONE, ACT_RELU, ACT_GELU, ACT_GELU_TANH, ACT_LEAKY = 0, 1, 2, 3, 4
 DACT_MUL = 15
@@ -26,7 +26,7 @@ EXPORTS = [
     'a4r_ln_fwd', 'a4r_ln_bwd', 'a4r_gather_rows', 'a4r_scatter_rows', 'a4r_act_bwd_f32', 'a4r_score_bce_fwd',
     'a4r_score_bce_bwd', 'a4r_emb_grad_add_inputs', 'a4r_take_inputs', 'a4r_adam_step', 'a4r_pack_matrices',
     'a4r_eval_rank', 'a4r_dropout_apply', 'a4r_gemm_variant', 'a4r_adapter_ln_fwd', 'a4r_adapter_ln_bwd', 'a4r_ln_fwd_fp8', 'a4r_quant_rows_fp8', 'a4r_lora_merge', 'a4r_phm_build', 'a4r_phm_bwd', 'a4r_unpack_add', 'a4r_memset_zero',
-    'a4r_scatter_rows_fill', 'a4r_attn_long_fwd', 'a4r_attn_long_bwd', 'a4r_patchify', 'a4r_vit_assemble', 'a4r_resample_u8', 'a4r_embed_bwd',
+    'a4r_sasrec_block_fwd', 'a4r_sasrec_block_bwd', 'a4r_scatter_rows_fill', 'a4r_attn_long_fwd', 'a4r_attn_long_bwd', 'a4r_patchify', 'a4r_vit_assemble', 'a4r_resample_u8', 'a4r_embed_bwd',
 ]
 
 
@@ -58,6 +58,15 @@ class PackDesc(C.Structure):
 class PhmDesc(C.Structure):
     _fields_ = [('rule_off', C.c_int64), ('wl_off', C.c_int64), ('wr_off', C.c_int64), ('out_off', C.c_int64), ('G', C.c_void_p),
                 ('ldg', C.c_int32), ('in_f', C.c_int32), ('out_f', C.c_int32), ('n', C.c_int32), ('pad_', C.c_int32)]
+
+
+class SasrecBlock(C.Structure):
+    """a4r_sasrec_block_t (include/a4r.h)."""
+    _PTRS = ('wqkv', 'wfc', 'w1', 'b1', 'w2', 'b2', 'ln1_g', 'ln1_b', 'ln2_g', 'ln2_b', 'wd1', 'bd1', 'wu1', 'bu1', 'wd2', 'bd2', 'wu2', 'bu2',
+             'g_wd1', 'g_bd1', 'g_wu1', 'g_bu1', 'g_wd2', 'g_bd2', 'g_wu2', 'g_bu2')
+    _fields_ = [(n, C.c_void_p) for n in _PTRS] + \
+               [(n, C.c_int32) for n in ('E', 'n_heads', 'F', 'd', 'ldwu', 'ldg_d', 'ldg_u', 'act', 'inner_res')] + \
+               [(n, C.c_float) for n in ('eps', 'mask_neg', 'drop_attn', 'drop_hidden')] + [('drop_site', C.c_uint32), ('drop_seed', C.c_uint64)]
 
 
 class AddDesc(C.Structure):
@@ -189,6 +198,22 @@ def adapter_ln_bwd(dy, v, stats, gamma, dres, zp, act, WuT, WdT, inner_res, dv, 
                                     C.c_int(int(inner_res)), _p(dv), C.c_int(_ld(dv)), _p(dzp), _p(dh), C.c_int(_ld(dh)),
                                     _p(dgamma), _p(dbeta), _p(dbias), C.c_int(M), C.c_int(dy.shape[1]), C.c_int(WuT.shape[0]), C.c_int(_dt(dy)),
                                     C.c_float(drop_p), C.c_uint32(drop_site), C.c_uint64(drop_seed), _p(dbd), C.c_int(int(bias_total))), 'a4r_adapter_ln_bwd')
+
+
+def sasrec_block(desc, x, log_mask, out, n_users, T, train, dy=None):
+    """a4r_sasrec_block_fwd (dy None: out = y) / a4r_sasrec_block_bwd (out = dx; the adapter gradients are added into desc.g_*).
+    desc: dict of the a4r_sasrec_block_t fields (tensors for the pointer fields, None = null)."""
+    require_gpu(x, log_mask, out, dy)
+    assert x.dtype == torch.float32 and out.dtype == torch.float32 and log_mask.dtype == torch.float32 and x.shape[1] == 64 and x.is_contiguous() and out.is_contiguous()
+    b = SasrecBlock()
+    for k, v in desc.items():
+        setattr(b, k, (v.data_ptr() if v is not None else None) if k in SasrecBlock._PTRS else v)
+    if dy is None:
+        _check(lib().a4r_sasrec_block_fwd(_stream(), C.byref(b), _p(x), _p(log_mask), _p(out), C.c_int(n_users), C.c_int(T), C.c_int(int(train))), 'a4r_sasrec_block_fwd')
+    else:
+        assert dy.dtype == torch.float32 and dy.is_contiguous()
+        _check(lib().a4r_sasrec_block_bwd(_stream(), C.byref(b), _p(x), _p(log_mask), _p(dy), _p(out), C.c_int(n_users), C.c_int(T), C.c_int(int(train))),
+               'a4r_sasrec_block_bwd')
 
 
 def gemm_tn(X, Y, Cacc, M=None):

@@ -150,7 +150,9 @@ __global__ void __launch_bounds__(512, 2) gemm_nt_256_kernel(const a4r_gemm_t p,
         // workgroups that own one tile fewer than the busiest of their XCD have a tile period of slack; started late, their epilogue
         // store bursts fall into the other workgroups' K loops instead of on top of their bursts (tools/gemm_timeline.py: the K loop of
         // the N = 2304 launch 18.6 -> 16.3 us per tile).  Same-box step: -1.5 % on the slower boxes of the pool, neutral on the fastest.
-        const int delay = gn_flags >> 17, stride0 = (int)(gridDim.x >> 3);
+        const int delay = (gn_flags >> 17) & 0x3fff, stride0 = (int)(gridDim.x >> 3);
+        // (round 3 measured the delay on EVERY second workgroup, slack or not: 244 vs 244 us on the GELU launch, 245 - 255 vs 232 - 253 on the
+        // '* derivative' dgrad -- the store bursts of workgroups in phase are not what the epilogue costs)
         if (delay > 0 && (len_x - 1 - t_loc) / stride0 < (len_x - 1) / stride0) {
             const uint64_t t_end = __builtin_amdgcn_s_memrealtime() + (uint64_t)delay;
             while (__builtin_amdgcn_s_memrealtime() < t_end) __builtin_amdgcn_s_sleep(8);

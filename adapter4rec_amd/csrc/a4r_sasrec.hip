@@ -136,7 +136,9 @@ A4R_DEV void block_forward(float* lds, const Lay& L, const BlockW& w, const floa
     float* H2 = lds + L.h2; float* ZP2 = lds + L.zp2; float* Z2 = lds + L.z2; float* V2 = lds + L.v2; float* ST = lds + L.st;
     const int dpe = L.sz - 4;
     // 1. qkv = x Wqkv^T  (12 column tiles, 3 per wave)
-    for (int ct = wave; ct < 3 * E / 16; ct += 4) {
+#pragma unroll
+    for (int t3 = 0; t3 < 3; ++t3) {                 // (a compile-time trip count: the 12 B-operand loads of the stage are requested together)
+        const int ct = wave + 4 * t3;
         f32x4_t acc[2]; zero2(acc);
         mm_nt<E>(X, SX, w.wqkv, E, ct * 16, lane, acc);
         tile_each(acc, ct * 16, lane, [&](int r, int c, float v) { QKV[r * SQ + c] = v; });
@@ -245,7 +247,9 @@ A4R_DEV void block_forward(float* lds, const Lay& L, const BlockW& w, const floa
     ln_rows(V1, X1, ST, w.ln1g, w.ln1b, w.eps, T, wave, lane);
     __syncthreads();
     // 5. u = relu(x1 W1^T + b1)   (16 column tiles, 4 per wave)
-    for (int ct = wave; ct < F / 16; ct += 4) {
+#pragma unroll
+    for (int t4 = 0; t4 < 4; ++t4) {
+        const int ct = wave + 4 * t4;
         f32x4_t acc[2]; zero2(acc);
         mm_nt<E>(X1, SX, w.w1, E, ct * 16, lane, acc);
         tile_each(acc, ct * 16, lane, [&](int r, int c, float v) { v += w.b1[c]; U[r * SU + c] = v > 0.f ? v : 0.f; });
@@ -441,7 +445,9 @@ __global__ void __launch_bounds__(256) sasrec_block_bwd_kernel(const float* __re
         __syncthreads();
     }
     // dU = (dO2 W2) * relu'(u), in place over U: B[n = F column][k = E] = W2[k][n] (global [E, F])
-    for (int ct = wave; ct < F / 16; ct += 4) {
+#pragma unroll
+    for (int t4 = 0; t4 < 4; ++t4) {
+        const int ct = wave + 4 * t4;
         f32x4_t acc[2]; zero2(acc);
         mm_nn<E>(V2, SX, w.w2, F, ct * 16, lane, acc);
         tile_each(acc, ct * 16, lane, [&](int r, int c, float v) { U[r * SU + c] = U[r * SU + c] > 0.f ? v : 0.f; });
@@ -471,7 +477,8 @@ __global__ void __launch_bounds__(256) sasrec_block_bwd_kernel(const float* __re
         tile_each(acc, wave * 16, lane, [&](int r, int c, float v) { CTX[r * SX + c] = v; });
     }
     __syncthreads();
-    // attention backward.  dP_h = dCTX_h V_h^T (rows of dCTX x rows of V); dS = P (dPd - sum_k dPd Pd) scale with Pd = dropout(P)
+    // attention backward.  dPd_h = dCTX_h V_h^T (rows of dCTX x rows of V) is the gradient of the DROPPED probabilities; dP = dPd * mask
+    // (mask = 0 or 1 / (1 - p)); dS = P (dP - sum_k dP_k P_k) scale
     float* DP = U;                                                 // [NH][RP][SPR]
     float* DQKV = lds + L.h;                                       // [RP][SQ] over H .. X1
     {
@@ -498,7 +505,7 @@ __global__ void __launch_bounds__(256) sasrec_block_bwd_kernel(const float* __re
                 float mk = 1.f;
                 if (TRAIN && w.thr_attn) mk = keep_elem(w.seed, w.site, (((uint64_t)(user * NH + hd) * 32 + q) << 5) + key, w.thr_attn) ? w.ks_attn : 0.f;
                 dpd[ct] = s[ct][r] * mk;
-                dot += dpd[ct] * mk * pp[ct];                      // sum_k dPd[k] Pd[k]... see note below
+                dot += dpd[ct] * pp[ct];                           // (dpd is already the gradient w.r.t. the PRE-dropout probability)
             }
             dot = group16_sum(dot);
 #pragma unroll
@@ -554,10 +561,78 @@ __global__ void __launch_bounds__(256) sasrec_block_bwd_kernel(const float* __re
 }  // namespace
 
 // ------------------------------------------------------------------------------------------------ C ABI
-static int lds_floats(int dpe, bool bwd) { return Lay(dpe).total; }
+namespace {
+constexpr size_t LDS_LIMIT = 160 * 1024;
 
-extern "C" int a4r_sasrec_block_fwd(void* stream, const a4r_sasrec_block_t* b, const float* x, const float* log_mask, float* y, int n_users, int T, int train) {
-    if (!b || !x || !log_mask || !y || n_users <= 0 || T <= 0 || T > 32) return A4R_EINVAL;
-    if (b->E != 64 || b->n_heads != 2 || b->F != 256 || b->d <= 0 || b->d > 64) return A4R_EINVAL;
-    return -3;
+int fill(const a4r_sasrec_block_t* b, int T, int train, BlockW& w, int& dpe) {
+    if (!b || T <= 0 || T > RP) return A4R_EINVAL;
+    if (b->E != E || b->n_heads != NH || b->F != F || b->d <= 0 || b->d > 64 || b->ldwu < b->d || b->ldwu % 4) return A4R_EINVAL;
+    const void* need[] = {b->wqkv, b->wfc, b->w1, b->b1, b->w2, b->b2, b->ln1_g, b->ln1_b, b->ln2_g, b->ln2_b,
+                          b->wd1, b->bd1, b->wu1, b->bu1, b->wd2, b->bd2, b->wu2, b->bu2};
+    for (const void* q : need)
+        if (!q || (reinterpret_cast<uintptr_t>(q) & 15u)) return A4R_EINVAL;           // 16-byte operand chunks / float4 rows
+    if (b->drop_attn < 0.f || b->drop_attn >= 1.f || b->drop_hidden < 0.f || b->drop_hidden >= 1.f) return A4R_EINVAL;
+    dpe = (b->d + 15) & ~15;
+    if (dpe > b->ldwu) return A4R_EINVAL;                                               // (the zero padding of Wd / bd / Wu must cover the 16-column tiles)
+    if ((size_t)Lay(dpe).total * sizeof(float) > LDS_LIMIT) return A4R_EINVAL;          // d > 32: the multi-launch path
+    w.wqkv = b->wqkv; w.wfc = b->wfc; w.w1 = b->w1; w.b1 = b->b1; w.w2 = b->w2; w.b2 = b->b2;
+    w.ln1g = b->ln1_g; w.ln1b = b->ln1_b; w.ln2g = b->ln2_g; w.ln2b = b->ln2_b;
+    w.wd1 = b->wd1; w.bd1 = b->bd1; w.wu1 = b->wu1; w.bu1 = b->bu1; w.wd2 = b->wd2; w.bd2 = b->bd2; w.wu2 = b->wu2; w.bu2 = b->bu2;
+    w.ldwu = b->ldwu; w.d = b->d; w.act = b->act; w.inner_res = b->inner_res;
+    w.eps = b->eps; w.scale = 1.f / sqrtf((float)DH); w.mask_neg = b->mask_neg;
+    w.p_attn = train ? b->drop_attn : 0.f; w.p_hidden = train ? b->drop_hidden : 0.f;
+    w.thr_attn = a4r_thr16(w.p_attn); w.thr_hidden = a4r_thr16(w.p_hidden);
+    w.ks_attn = a4r_keep_scale(w.p_attn); w.ks_hidden = a4r_keep_scale(w.p_hidden);
+    w.site = b->drop_site; w.seed = b->drop_seed;
+    return A4R_OK;
+}
+
+template <typename K> int set_lds(K kernel, size_t bytes) {
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) == hipSuccess ? A4R_OK : A4R_ELAUNCH;
+}
+}  // namespace
+
+extern "C" int a4r_sasrec_block_fwd(void* stream, const a4r_sasrec_block_t* b, const float* x, const float* log_mask, float* y,
+                                    int n_users, int T, int train) {
+    BlockW w;
+    int dpe = 0;
+    if (!x || !log_mask || !y || n_users <= 0) return A4R_EINVAL;
+    if ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y)) & 15u) return A4R_EINVAL;
+    if (int rc = fill(b, T, train, w, dpe)) return rc;
+    const size_t lds = (size_t)Lay(dpe).total * sizeof(float);
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    const bool tr = w.thr_attn || w.thr_hidden;
+    if (tr) {
+        if (int rc = set_lds(sasrec_block_fwd_kernel<true>, lds)) return rc;
+        hipLaunchKernelGGL(sasrec_block_fwd_kernel<true>, dim3(n_users), dim3(256), lds, s, x, log_mask, y, w, T, dpe);
+    } else {
+        if (int rc = set_lds(sasrec_block_fwd_kernel<false>, lds)) return rc;
+        hipLaunchKernelGGL(sasrec_block_fwd_kernel<false>, dim3(n_users), dim3(256), lds, s, x, log_mask, y, w, T, dpe);
+    }
+    return a4r_launch_status();
+}
+
+extern "C" int a4r_sasrec_block_bwd(void* stream, const a4r_sasrec_block_t* b, const float* x, const float* log_mask, const float* dy, float* dx,
+                                    int n_users, int T, int train) {
+    BlockW w;
+    BlockG g;
+    int dpe = 0;
+    if (!x || !log_mask || !dy || !dx || n_users <= 0) return A4R_EINVAL;
+    if ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(dy) | reinterpret_cast<uintptr_t>(dx)) & 15u) return A4R_EINVAL;
+    if (int rc = fill(b, T, train, w, dpe)) return rc;
+    g.wd1 = b->g_wd1; g.bd1 = b->g_bd1; g.wu1 = b->g_wu1; g.bu1 = b->g_bu1; g.wd2 = b->g_wd2; g.bd2 = b->g_bd2; g.wu2 = b->g_wu2; g.bu2 = b->g_bu2;
+    g.ldgd = b->ldg_d; g.ldgu = b->ldg_u;
+    if ((g.wd1 || g.wd2) && g.ldgd < E) return A4R_EINVAL;
+    if ((g.wu1 || g.wu2) && g.ldgu < b->d) return A4R_EINVAL;
+    const size_t lds = (size_t)Lay(dpe).total * sizeof(float);
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    const bool tr = w.thr_attn || w.thr_hidden;
+    if (tr) {
+        if (int rc = set_lds(sasrec_block_bwd_kernel<true>, lds)) return rc;
+        hipLaunchKernelGGL(sasrec_block_bwd_kernel<true>, dim3(n_users), dim3(256), lds, s, x, log_mask, dy, dx, w, g, T, dpe);
+    } else {
+        if (int rc = set_lds(sasrec_block_bwd_kernel<false>, lds)) return rc;
+        hipLaunchKernelGGL(sasrec_block_bwd_kernel<false>, dim3(n_users), dim3(256), lds, s, x, log_mask, dy, dx, w, g, T, dpe);
+    }
+    return a4r_launch_status();
 }

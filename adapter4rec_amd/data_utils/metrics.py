@@ -36,9 +36,12 @@ def get_item_embeddings(model, item_content, test_batch_size, args, use_modal, l
     content = torch.as_tensor(np.asarray(item_content)).long()
     lo, hi, chunk, world = _my_shard(content.shape[0])
     out = []
+    # the reference's test_batch_size (512 at run.py:650) is sized for ITS activation memory; the native encoder takes 4 096 titles per
+    # call (fp32 sweep of 65 537 titles: 3.44 s at 512, 2.63 s = 84 % of the exact-fp32 MFMA peak at 4 096; profiles/r03_a_eval_bench.json)
+    step = max(int(test_batch_size), 4096)
     with torch.no_grad():
-        for i in range(lo, hi, test_batch_size):
-            out.append(enc(content[i:min(i + test_batch_size, hi)].to(dev)))
+        for i in range(lo, hi, step):
+            out.append(enc(content[i:min(i + step, hi)].to(dev)))
     return _gather_shards(torch.cat(out, 0) if out else torch.zeros(0, enc_dim(model, args), device=dev), content.shape[0], chunk, world)
 
 

@@ -639,6 +639,41 @@ class TransRecEngine:
             self.sas_kads = [self._make_kadapter(m, E, self.Lseq - 1, f32, 5000 + 64 * j) for j, m in enumerate(tbs.adapter_list)]
             self.d_com2 = _Dense(self, tbs.com_dense2.weight, tbs.com_dense2.bias, f32)
 
+    SAS_FUSED = bool(int(_os.environ.get('A4R_SAS_FUSED', '1')))       # 0: the multi-launch user tower (A/B runs)
+
+    def _sas_fused_ok(self):
+        """The one-launch-per-block kernels (a4r_sasrec.hip) serve the user tower when every block is the reference's default shape:
+        64 wide, 2 heads x 32, d_inner 256, frozen dense weights and LayerNorms, a serial Houlsby or Compacter adapter after both
+        sub-layers with bottleneck <= 32, no LoRA / Pfeiffer / parallel / K-Adapter.  Anything else keeps the multi-launch path."""
+        if not self.SAS_FUSED or self.sas_kads or not self.sas_blocks or self.Lseq - 1 > 32:
+            return False
+        for b in self.sas_blocks:
+            if (b.H, getattr(b, 'Hv', b.H), b.nh, b.F, b.T) != (64, 64, 2, 256, torch.float32) or not b.causal or b.lora or b.train_dense:
+                return False
+            if b.ad1 is None or b.ad2 is None or b.pl1 != 'serial' or b.pl2 != 'serial' or b.lnn1 is not None or b.lnn2 is not None:
+                return False
+            if any(a.d > 32 or a.dp != 64 or a.act != b.ad1.act or a.kind != b.ad1.kind or a.d != b.ad1.d for a in (b.ad1, b.ad2)):
+                return False
+            if any(f is not None for ln in (b.ln1, b.ln2) for f in (ln.g_gamma, ln.g_beta)):
+                return False
+        return True
+
+    def _sas_desc(self, b, seed, with_grads):
+        """a4r_sasrec_block_t fields of one block (the gradient sinks are resolved against the CURRENT gradient target)."""
+        gg = lambda f: f() if f is not None else None
+        d = dict(wqkv=b.wqkv, wfc=b.wo, w1=b.wi, b1=b.bi, w2=b.wo2, b2=b.bo2, ln1_g=b.ln1.gamma, ln1_b=b.ln1.beta, ln2_g=b.ln2.gamma, ln2_b=b.ln2.beta,
+                 E=64, n_heads=2, F=256, d=b.ad1.d, ldwu=b.ad1.dp, ldg_d=64, ldg_u=64, act=b.ad1.act, inner_res=int(b.ad1.kind != 'compacter'),
+                 eps=float(b.ln1.eps), mask_neg=float(b.mask_neg), drop_attn=float(b.p_attn), drop_hidden=float(b.p_hidden),
+                 drop_site=int(b.site), drop_seed=int(seed))
+        for k, ad in (('1', b.ad1), ('2', b.ad2)):
+            d.update({'wd' + k: ad.wd, 'bd' + k: ad.bd, 'wu' + k: ad.wu, 'bu' + k: ad.bu})
+            trains = with_grads and (ad.virtual is not None or ad.g_wu is not None)
+            # (d < 64: the zero-padded scratch matrices whose valid corners _flush_corners / a4r_phm_bwd pick up, as the multi-launch path)
+            d.update({'g_wd' + k: ad.s_wd if trains else None, 'g_wu' + k: ad.s_wu if trains else None,
+                      'g_bd' + k: (ad.s_bd if ad.s_bd is not None else gg(ad.g_bd)) if (with_grads and ad.g_bd is not None) else None,
+                      'g_bu' + k: gg(ad.g_bu) if with_grads else None})
+        return d
+
     def _make_block(self, tb, Hv, nh, S, dt, causal, mask_neg, p_drop, site):
         """A plain post-LN TransformerBlock (modules.py:16-87: bias-free w_Q / w_K / w_V / fc, ReLU FFN with biases, LayerNorm eps
         1e-6) as an engine _Block.  Widths that are not multiples of 64 (K-Adapter blocks: 16) are stored zero-padded to 64; the
@@ -1180,6 +1215,12 @@ class TransRecEngine:
         st0 = self._buf('sst0', Mu, 2, torch.float32)
         L.ln_fwd(xin, self.sas_ln0.gamma, self.sas_ln0.beta, self.sas_ln0.eps, x, st0, M=Mu, add=self.pos_emb[:Tn],
                  drop_p=self.p_sas if train else 0.0, drop_site=4000, drop_seed=seed)
+        if self._sas_fused_ok():                       # one launch per block; backward recomputes from the block inputs kept here
+            xs = [x] + [self._buf(f'sas.fused{j}', Mu, E, torch.float32) for j in range(len(self.sas_blocks))]
+            for j, blk in enumerate(self.sas_blocks):
+                L.sasrec_block(self._sas_desc(blk, seed, False), xs[j], log_mask, xs[j + 1], B, Tn, train)
+            self._sas_xs = xs
+            return xs[-1], Mu
         other = self._buf('sx_b', Mu, E, torch.float32)
         keep = saved is not None
         if self.sas_kads and keep and (getattr(self, '_kad_saved_s', None) is None or self._kad_saved_Mu != Mu):
@@ -1394,8 +1435,12 @@ class TransRecEngine:
             dlast = self._buf('sk_dlast', Mu, E, torch.float32)
             dlast.copy_(dcat[:, E:])
         pp = [self._buf('sdx_a', Mu, E, torch.float32), self._buf('sdx_b', Mu, E, torch.float32)]
+        fused = self._sas_fused_ok()
         for k, j in enumerate(range(len(self.sas_blocks) - 1, -1, -1)):
-            self._block_backward(self.sas_blocks[j], dx, c['lm'], B, Mu, c['saved_s'][j], train, seed, pp[k % 2])
+            if fused:
+                L.sasrec_block(self._sas_desc(self.sas_blocks[j], seed, True), self._sas_xs[j], c['lm'], pp[k % 2], B, Tn, train, dy=dx)
+            else:
+                self._block_backward(self.sas_blocks[j], dx, c['lm'], B, Mu, c['saved_s'][j], train, seed, pp[k % 2])
             dx = pp[k % 2]
             if self.sas_kads:
                 kad = self.sas_kads[j]

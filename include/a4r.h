@@ -36,7 +36,7 @@ extern "C" {
 
 /* ABI version: bumped whenever a signature or struct below changes.  The Python binding (adapter4rec_amd/_lib.py) refuses a
  * library whose a4r_version() differs, so an A/B build made before a signature change cannot be called with shifted arguments. */
-#define A4R_ABI_VERSION 301
+#define A4R_ABI_VERSION 302
 int a4r_version(void);
 
 /* C[M,N] = epilogue(alpha * A[M,K] . B[N,K]^T): every nn.Linear on the path (HF BertSelfAttention
@@ -88,6 +88,28 @@ int a4r_gemm_variant(int v);
  * C must be zeroed (or hold the running sum) before the call; accumulation uses fp32 atomics. */
 int a4r_gemm_tn(void* stream, const void* X, int ldx, const void* Y, int ldy, float* C, int ldc,
                 int M, int P, int Q, int dtype);
+/* One SASRec transformer block of the user encoder per launch and direction (fp32; E = 64, 2 heads x 32, d_inner 256, T <= 32 rows per
+ * user, adapter bottleneck d <= 32): TransformerBlock with the two bottleneck adapters of SASRecAdaptedSelfOutput (model/model.py:341-376;
+ * inner_res 1) or SASRecCompacterAdaptedSelfOutput (:666-720; inner_res 0, the PHM matrices materialised):
+ *   h = dropout(MHA(x) fc^T); x1 = LN1(x + A1(h)); y = LN2(x1 + A2(dropout(relu(x1 W1^T + b1) W2^T + b2)));  A(h) = act(h Wd^T + bd) Wu^T + bu [+ h]
+ * attention: causal + log_mask (additive mask_neg on masked keys, model/encoders.py:24-28), probability dropout drop_attn; the two hidden
+ * dropouts drop_hidden; masks = counter hash of (drop_seed, drop_site + {0, 1, 2}, element) -- applied only when train != 0.
+ * One workgroup per user holds every activation of its rows in LDS; bwd recomputes the forward from x (nothing else is saved), writes dx
+ * and ADDS the adapter gradients into g_* (fp32 atomics; null = not wanted; g_wd* [d, ldg_d >= 64], g_wu* [64, ldg_u >= d]).
+ * Dense weights and LayerNorms are treated as frozen.  Wd* [>= 16-multiple of d rows, 64] and bd*, Wu* [64, ldwu] are zero-padded past d. */
+typedef struct {
+    const float *wqkv, *wfc, *w1, *b1, *w2, *b2;              /* [192, 64] (q | k | v rows), [64, 64], [256, 64], [256], [64, 256], [64] */
+    const float *ln1_g, *ln1_b, *ln2_g, *ln2_b;               /* [64] each */
+    const float *wd1, *bd1, *wu1, *bu1, *wd2, *bd2, *wu2, *bu2;
+    float *g_wd1, *g_bd1, *g_wu1, *g_bu1, *g_wd2, *g_bd2, *g_wu2, *g_bu2;
+    int32_t E, n_heads, F, d, ldwu, ldg_d, ldg_u, act, inner_res;
+    float eps, mask_neg, drop_attn, drop_hidden;
+    uint32_t drop_site; uint64_t drop_seed;
+} a4r_sasrec_block_t;
+int a4r_sasrec_block_fwd(void* stream, const a4r_sasrec_block_t* b, const float* x, const float* log_mask, float* y, int n_users, int T, int train);
+int a4r_sasrec_block_bwd(void* stream, const a4r_sasrec_block_t* b, const float* x, const float* log_mask, const float* dy, float* dx,
+                         int n_users, int T, int train);
+
 /* Two such products over the same M rows in ONE launch (an adapter's dW_up = dv^T z and dW_down = dzp^T h; bf16;
  * (P1 / 64) (Q1 / 64) == (P2 / 64) (Q2 / 64)). */
 int a4r_gemm_tn2(void* stream, const void* X1, int ldx1, const void* Y1, int ldy1, float* C1, int ldc1, int P1, int Q1,

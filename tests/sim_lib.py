@@ -483,3 +483,60 @@ def eval_rank(prec, item_emb, target, hist_ptr, hist_idx, rank):
         h = hist_idx[int(hist_ptr[u]):int(hist_ptr[u + 1])].long()
         s[h] = -float('inf')
         rank[u] = int((s[1:] > ts).sum()) + 1
+
+
+# ------------------------------------------------------------------ a4r_sasrec_block_fwd / _bwd (one launch per SASRec block)
+def _sasrec_block_fn(d, x, log_mask, T):
+    """The block's forward as differentiable torch ops (dropout off: the CPU suite has none).  x [B * T, 64]."""
+    B = x.shape[0] // T
+    E, nh, dh = 64, 2, 32
+    xx = x.view(B, T, E)
+    qkv = xx @ d['wqkv'].t()
+    q, k, v = (t.view(B, T, nh, dh).transpose(1, 2) for t in qkv.split(E, dim=-1))
+    s = (q @ k.transpose(-1, -2)) / math.sqrt(dh)
+    allowed = (log_mask[:, None, None, :] != 0) & torch.tril(torch.ones(T, T, dtype=torch.bool))[None, None]
+    s = torch.where(allowed, s, s + d['mask_neg'])
+    ctx = (torch.softmax(s, -1) @ v).transpose(1, 2).reshape(B, T, E)
+    h = ctx @ d['wfc'].t()
+
+    def adapter(hh, k_):
+        dd = d['d']
+        zp = hh @ d['wd' + k_][:dd].t() + d['bd' + k_][:dd]
+        return _act(zp, d['act']) @ d['wu' + k_][:, :dd].t() + d['bu' + k_] + (hh if d['inner_res'] else 0)
+
+    def ln(vv, g, b):
+        mu = vv.mean(-1, keepdim=True)
+        return (vv - mu) * torch.rsqrt(((vv - mu) ** 2).mean(-1, keepdim=True) + d['eps']) * g + b
+    x1 = ln(xx + adapter(h, '1'), d['ln1_g'], d['ln1_b'])
+    h2 = torch.relu(x1 @ d['w1'].t() + d['b1']) @ d['w2'].t() + d['b2']
+    return ln(x1 + adapter(h2, '2'), d['ln2_g'], d['ln2_b']).reshape(B * T, E)
+
+
+def sasrec_block(desc, x, log_mask, out, n_users, T, train, dy=None):
+    assert not (train and (desc['drop_attn'] or desc['drop_hidden'])), 'sim_lib has no dropout'
+    n = n_users * T
+    if dy is None:
+        with torch.no_grad():
+            out[:n] = _sasrec_block_fn(desc, x[:n], log_mask[:n_users], T)
+        return
+    names = ('wd1', 'bd1', 'wu1', 'bu1', 'wd2', 'bd2', 'wu2', 'bu2')
+    with torch.enable_grad():                       # (called from inside an autograd Function's backward: grad mode is off there)
+        leaf = {k: desc[k].detach().clone().requires_grad_(True) for k in names}
+        xin = x[:n].detach().clone().requires_grad_(True)
+        y = _sasrec_block_fn(dict(desc, **leaf), xin, log_mask[:n_users], T)
+        grads = torch.autograd.grad(y, [xin] + [leaf[k] for k in names], dy[:n], allow_unused=True)
+    out[:n] = grads[0]
+    dd = desc['d']
+    for k, g in zip(names, grads[1:]):
+        g = g.detach() if g is not None else None
+        tgt = desc['g_' + k]
+        if tgt is None or g is None:
+            continue
+        if k.startswith('wd'):
+            tgt[:dd, :64] += g[:dd]
+        elif k.startswith('wu'):
+            tgt[:64, :dd] += g[:, :dd]
+        elif k.startswith('bd'):
+            tgt[:dd] += g[:dd]
+        else:
+            tgt += g

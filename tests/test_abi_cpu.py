@@ -38,12 +38,13 @@ def test_binding_struct_sizes_match_header():
     import subprocess
     import tempfile
     from adapter4rec_amd import _lib
-    src = '#include <stdio.h>\n#include "a4r.h"\nint main(){printf("%zu %zu %zu\\n", sizeof(a4r_gemm_t), sizeof(a4r_attn_t), sizeof(a4r_pack_desc_t));return 0;}\n'
+    src = '#include <stdio.h>\n#include <stddef.h>\n#include "a4r.h"\nint main(){printf("%zu %zu %zu %zu %zu %zu\\n", sizeof(a4r_gemm_t), sizeof(a4r_attn_t), sizeof(a4r_pack_desc_t), sizeof(a4r_sasrec_block_t), offsetof(a4r_sasrec_block_t, drop_seed), offsetof(a4r_gemm_t, c_scale_out));return 0;}\n'
     with tempfile.TemporaryDirectory() as d:
         open(os.path.join(d, 'p.c'), 'w').write(src)
         subprocess.check_call(['gcc', '-I', os.path.join(ROOT, 'include'), os.path.join(d, 'p.c'), '-o', os.path.join(d, 'p')])
         out = subprocess.check_output([os.path.join(d, 'p')]).decode().split()
-    assert [int(x) for x in out] == [ctypes.sizeof(_lib.GemmArgs), ctypes.sizeof(_lib.AttnArgs), ctypes.sizeof(_lib.PackDesc)]
+    assert [int(x) for x in out] == [ctypes.sizeof(_lib.GemmArgs), ctypes.sizeof(_lib.AttnArgs), ctypes.sizeof(_lib.PackDesc),
+                                     ctypes.sizeof(_lib.SasrecBlock), _lib.SasrecBlock.drop_seed.offset, _lib.GemmArgs.c_scale_out.offset]
 
 
 def test_no_cpu_fallback():

@@ -1084,3 +1084,148 @@ def test_gemm256_many_tiles_per_workgroup(K):
     close(res[0][2][rows], pre + R1[rows].float(), t, 'residual vs torch')
     close(res[0][3][rows], torch.nn.functional.gelu(pre + bias), t, 'gelu vs torch')
     close(res[0][5][rows], pre * (P8[rows].float() * L.Q8_STEP - L.Q8_OFF), t, '* derivative vs torch')
+
+
+# ------------------------------------------------------------------ round 3: e4m3 GEMM outputs, the fused SASRec block
+@pytest.mark.parametrize('M,N,K', [(512, 3072, 768), (256 * 5, 1024, 256)])
+def test_gemm_fp8_output_static_scale(M, N, K):
+    """c_fp8 = 1 (the fp8 encoder's FFN-up): C = e4m3(gelu(.) / c_scale) next to the 8-bit derivative output; the stored bytes are the
+    correctly rounded e4m3 of the fp32 epilogue value of the dequantised product."""
+    from adapter4rec_amd import _lib as L
+    A, B = rnd(M, K, seed=M + 1), rnd(N, K, scale=0.05, seed=N + 2)
+    Aq, As = _q8_ref(A)
+    Bq, Bs = L.quantize_weight_fp8(B)
+    bias = rnd(N, seed=13) * 0.1
+    C8 = torch.zeros(M, N, dtype=torch.uint8, device=dev())
+    D8 = torch.zeros(M, N, dtype=torch.uint8, device=dev())
+    L.gemm_nt(Aq.view(torch.uint8), Bq, C8, bias=bias, C2=D8, act=L.ACT_GELU, c2_deriv='q8', scale_a=As, scale_b=Bs, c_fp8=1, c_scale=0.25)
+    pre = (Aq.float() * As[:, None]) @ (Bq.view(torch.float8_e4m3fn).float() * Bs[:, None]).t() + bias
+    ref = torch.nn.functional.gelu(pre)
+    got = C8.view(torch.float8_e4m3fn).float() * 0.25
+    # one e4m3 rounding (2^-4 relative, half a subnormal step 2^-10 * 0.25 absolute) on top of fp32 accumulation-order noise
+    err = (got - ref).abs()
+    assert bool((err <= 2 ** -4 * ref.abs() + 2 ** -10 * 0.25 + 1e-4).all()), float(err.max())
+    want = (ref / 0.25).clamp(-448, 448).to(torch.float8_e4m3fn).view(torch.uint8)
+    assert float((C8 != want).float().mean()) < 2e-3            # identical bytes except where accumulation order moves a value across a rounding boundary
+    dref = (pre.clone().requires_grad_(True))
+    torch.nn.functional.gelu(dref).sum().backward()
+    assert float(((D8.float() * L.Q8_STEP - L.Q8_OFF) - dref.grad).abs().max()) < 4e-3
+
+
+def test_gemm_fp8_output_row_scale_chain():
+    """c_fp8 = 2 (the fp8 encoder's FFN dgrads): du = (dy W2) * gelu' leaves as e4m3 with scale_a[m] * c_scale per row, that scale is written
+    out, and the next GEMM consumes both: the chain reproduces the fp32 chain to e4m3 rounding."""
+    from adapter4rec_amd import _lib as L
+    M, H, F = 768, 256, 1024
+    dy = rnd(M, H, seed=5) * torch.logspace(-6, -2, M, device=dev())[:, None]          # gradient rows of very different magnitude
+    W2, W1 = rnd(H, F, scale=0.03, seed=6), rnd(F, H, scale=0.03, seed=7)              # forward weights [out, in]
+    g = torch.rand(M, F, device=dev())                                                  # saved gelu' in [0, 1]
+    P8 = torch.clamp(torch.round((g + L.Q8_OFF) / L.Q8_STEP), 0, 255).to(torch.uint8)
+    gq = P8.float() * L.Q8_STEP - L.Q8_OFF
+    dq, ds = torch.zeros(M, H, dtype=torch.uint8, device=dev()), torch.zeros(M, 1, device=dev())
+    L.quant_rows_fp8(dy.to(torch.bfloat16), dq, ds)
+    W2T8, W2T8s = L.quantize_weight_fp8(W2.t().contiguous())                            # [F, H]
+    W1T8, W1T8s = L.quantize_weight_fp8(W1.t().contiguous())                            # [H, F]
+    c_du = 16.0 * float(W2.t().norm(dim=1).max())
+    du8, dus = torch.zeros(M, F, dtype=torch.uint8, device=dev()), torch.zeros(M, 1, device=dev())
+    L.gemm_nt(dq, W2T8, du8, Pre=P8, dact=L.DACT_MUL_Q8, scale_a=ds, scale_b=W2T8s, c_fp8=2, c_scale=c_du, c_scale_out=dus)
+    torch.testing.assert_close(dus, ds * c_du, rtol=1e-6, atol=0)
+    dyd = dq.view(torch.float8_e4m3fn).float() * ds
+    du_ref = (dyd @ (W2T8.view(torch.float8_e4m3fn).float() * W2T8s[:, None]).t()) * gq
+    du_got = du8.view(torch.float8_e4m3fn).float() * dus
+    rel = (du_got - du_ref).abs() / du_ref.abs().amax(1, keepdim=True)
+    assert float(rel.max()) < 2 ** -4 and float((du8.view(torch.float8_e4m3fn).float().abs() >= 448).float().mean()) == 0.0      # no saturation
+    dx = torch.zeros(M, H, dtype=torch.bfloat16, device=dev())
+    L.gemm_nt(du8, W1T8, dx, scale_a=dus, scale_b=W1T8s)
+    full = ((dy.to(torch.bfloat16).float() @ W2) * g) @ W1                              # the unquantised chain
+    err = (dx.float() - full).abs().amax(1) / full.abs().amax(1)
+    # per ROW (the row scales carry 4 decades of magnitude): five e4m3 / 8-bit roundings along the chain and a contraction of only 256 / 1 024
+    # terms -- measured worst row 0.09, mean 0.05 of the row's maximum
+    assert float(err.max()) < 0.15 and float(err.mean()) < 0.08, (float(err.max()), float(err.mean()))
+
+
+def _sasrec_case(d, act, inner, seed, B=6, T=20):
+    g = torch.Generator().manual_seed(seed)
+    r = lambda *s, sc=1.0: (torch.randn(*s, generator=g) * sc).to(dev())
+    desc = dict(wqkv=r(192, 64, sc=0.15), wfc=r(64, 64, sc=0.15), w1=r(256, 64, sc=0.15), b1=r(256, sc=0.1), w2=r(64, 256, sc=0.08), b2=r(64, sc=0.1),
+                ln1_g=1 + r(64, sc=0.1), ln1_b=r(64, sc=0.1), ln2_g=1 + r(64, sc=0.1), ln2_b=r(64, sc=0.1),
+                E=64, n_heads=2, F=256, d=d, ldwu=64, ldg_d=64, ldg_u=64, act=act, inner_res=int(inner), eps=1e-6, mask_neg=-1e9,
+                drop_attn=0.0, drop_hidden=0.0, drop_site=4096, drop_seed=1234567)
+    for k in ('1', '2'):
+        wd, wu, bd = torch.zeros(64, 64, device=dev()), torch.zeros(64, 64, device=dev()), torch.zeros(64, device=dev())
+        wd[:d], wu[:, :d], bd[:d] = r(d, 64, sc=0.2), r(64, d, sc=0.2), r(d, sc=0.1)
+        desc.update({'wd' + k: wd, 'bd' + k: bd, 'wu' + k: wu, 'bu' + k: r(64, sc=0.1)})
+        desc.update({'g_wd' + k: torch.zeros(64, 64, device=dev()), 'g_wu' + k: torch.zeros(64, 64, device=dev()),
+                     'g_bd' + k: torch.zeros(64, device=dev()), 'g_bu' + k: torch.zeros(64, device=dev())})
+    x = r(B * T, 64)
+    mask = torch.ones(B, T, device=dev())
+    for u, pad in enumerate((0, 11, 19, 5, 0, 17)[:B]):
+        mask[u, :pad] = 0                                          # left-padded histories (a fully padded query row attends uniformly)
+    return desc, x, mask, r(B * T, 64)
+
+
+@pytest.mark.parametrize('d,act,inner', [(16, 1, True), (16, 3, False), (24, 2, True), (32, 1, True)])
+def test_sasrec_block_vs_torch(d, act, inner):
+    """a4r_sasrec_block_fwd / _bwd (one launch per block) vs the same block in torch autograd (tests/sim_lib.py restates
+    modules.py:45-87 + model.py:341-376): output, input gradient and the eight adapter gradients, fp32."""
+    import sim_lib
+    from adapter4rec_amd import _lib as L
+    B, T = 6, 20
+    desc, x, mask, dy = _sasrec_case(d, act, inner, seed=40 + d + act)
+    y = torch.zeros_like(x)
+    L.sasrec_block(desc, x, mask, y, B, T, False)
+    cpu = lambda t: t.detach().cpu() if torch.is_tensor(t) else t
+    dc = {k: cpu(v) for k, v in desc.items()}
+    for k in list(dc):
+        if k.startswith('g_'):
+            dc[k] = torch.zeros_like(dc[k])
+    y_ref = torch.zeros(B * T, 64)
+    sim_lib.sasrec_block(dc, cpu(x), cpu(mask), y_ref, B, T, False)
+    close(y, y_ref, torch.float32, 'sasrec block forward', atol32=5e-5, rtol32=5e-5)
+    dx, dx_ref = torch.zeros_like(x), torch.zeros(B * T, 64)
+    L.sasrec_block(desc, x, mask, dx, B, T, False, dy=dy)
+    sim_lib.sasrec_block(dc, cpu(x), cpu(mask), dx_ref, B, T, False, dy=cpu(dy))
+    close(dx, dx_ref, torch.float32, 'sasrec block dx', atol32=1e-4, rtol32=1e-4)
+    for k in ('wd1', 'bd1', 'wu1', 'bu1', 'wd2', 'bd2', 'wu2', 'bu2'):
+        ref = dc['g_' + k]
+        close(desc['g_' + k], ref, torch.float32, 'sasrec block g_' + k, atol32=1e-4 * float(ref.abs().max()) + 1e-6, rtol32=1e-4)
+        if k.startswith('wd'):
+            assert float(desc['g_' + k][d:].abs().max()) == 0.0           # nothing lands in the zero padding
+        if k.startswith('wu'):
+            assert float(desc['g_' + k][:, d:].abs().max()) == 0.0
+
+
+def test_sasrec_block_dropout_is_consistent():
+    """train = 1: the masks are a pure function of (seed, site, element) -- two forwards agree bit for bit, another seed differs, and the
+    backward differentiates the forward WITH its masks (directional derivative of the kernel's own forward)."""
+    from adapter4rec_amd import _lib as L
+    B, T = 6, 20
+    desc, x, mask, dy = _sasrec_case(16, 1, True, seed=77)
+    desc.update(drop_attn=0.1, drop_hidden=0.1)
+    y0, y1, y2 = (torch.zeros_like(x) for _ in range(3))
+    L.sasrec_block(desc, x, mask, y0, B, T, True)
+    L.sasrec_block(desc, x, mask, y1, B, T, True)
+    assert torch.equal(y0, y1)
+    L.sasrec_block(dict(desc, drop_seed=99), x, mask, y2, B, T, True)
+    assert float((y0 - y2).abs().max()) > 1e-3
+    ye = torch.zeros_like(x)
+    L.sasrec_block(desc, x, mask, ye, B, T, False)
+    assert float((y0 - ye).abs().max()) > 1e-3                             # train mode really drops
+    v = torch.randn_like(x)
+    eps = 2e-3
+
+    def fd_check(dd, train, what):
+        dx = torch.zeros_like(x)
+        L.sasrec_block(dd, x, mask, dx, B, T, train, dy=dy)
+        yp, ym = torch.zeros_like(x), torch.zeros_like(x)
+        L.sasrec_block(dd, x + eps * v, mask, yp, B, T, train)
+        L.sasrec_block(dd, x - eps * v, mask, ym, B, T, train)
+        num = float((((yp - ym).double() / (2 * eps)) * dy.double()).sum())
+        ana = float((dx.double() * v.double()).sum())
+        print(f'{what}: directional derivative numeric {num:.4f} analytic {ana:.4f}')
+        return num, ana
+    n0, a0 = fd_check(desc, False, 'no dropout')                           # calibrates the method (fp32 central difference through LN / softmax / ReLU kinks)
+    tol = max(3.0 * abs(n0 - a0), 2e-2 * max(1.0, abs(a0)))
+    for dd, what in ((dict(desc, drop_hidden=0.0), 'attention dropout only'), (dict(desc, drop_attn=0.0), 'hidden dropout only'), (desc, 'both')):
+        num, ana = fd_check(dd, True, what)
+        assert abs(num - ana) < tol, (what, num, ana, tol)
