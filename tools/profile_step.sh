@@ -14,6 +14,11 @@ if [ "$PMC" = "pmc" ]; then
   rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $OUT/${TAG}_pmc_w -o w --output-format csv -- python3 $ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-roofline --workload $WL > /dev/null 2>&1
   python3 $ROOT/tools/pmc_summary.py $OUT/${TAG}_pmc_f $OUT/${TAG}_pmc_w > $OUT/${TAG}_pmc_hbm_traffic.json
   rm -rf $OUT/${TAG}_pmc_f $OUT/${TAG}_pmc_w
+  # matrix-pipe utilisation (north_star: "rocprof reporting ... MFMA utilisation"): one counter per pass, program directly after --
+  rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES --kernel-trace -d $OUT/${TAG}_pmc_m -o m --output-format csv -- python3 $ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-roofline --workload $WL > /dev/null 2>&1
+  rocprofv3 --pmc GRBM_GUI_ACTIVE --kernel-trace -d $OUT/${TAG}_pmc_g -o g --output-format csv -- python3 $ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-roofline --workload $WL > /dev/null 2>&1
+  python3 $ROOT/tools/pmc_mfma.py $OUT/${TAG}_pmc_m $OUT/${TAG}_pmc_g > $OUT/${TAG}_pmc_mfma_util.json
+  rm -rf $OUT/${TAG}_pmc_m $OUT/${TAG}_pmc_g
 fi
 rm -rf $OUT/${TAG}_prof
 cat $OUT/${TAG}_bench.json
