@@ -12,7 +12,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('A4R_LIB_PATH') or os.path.join(_HERE, 'liba4r_hip.so')    # A4R_LIB_PATH: A/B builds (tools/), same C ABI
 
-ABI_VERSION = 302          # = A4R_ABI_VERSION of include/a4r.h (tests/test_abi_cpu.py compares the two)
+ABI_VERSION = 303          # = A4R_ABI_VERSION of include/a4r.h (tests/test_abi_cpu.py compares the two)
 BF16, F32, FP8 = 0, 1, 2
 ACT_NONE, ACT_RELU, ACT_GELU, ACT_GELU_TANH, ACT_LEAKY = 0, 1, 2, 3, 4
 DACT_MUL = 15
@@ -39,7 +39,7 @@ class GemmArgs(C.Structure):
                 ('in_dtype', C.c_int32), ('out_dtype', C.c_int32), ('act', C.c_int32), ('dact', C.c_int32),
                 ('drop_first', C.c_int32), ('c2_mode', C.c_int32), ('alpha', C.c_float), ('drop_p', C.c_float), ('drop_site', C.c_uint32), ('drop_seed', C.c_uint64),
                 ('drop_row0', C.c_int64), ('scale_a', C.c_void_p), ('scale_b', C.c_void_p),
-                ('c_fp8', C.c_int32), ('c_scale', C.c_float), ('c_scale_out', C.c_void_p)]
+                ('c_fp8', C.c_int32), ('c_scale', C.c_float), ('c_scale_out', C.c_void_p), ('q8_tiled', C.c_int32)]
 
 
 class AttnArgs(C.Structure):
@@ -144,8 +144,9 @@ def require_gpu(*tensors):
 # ------------------------------------------------------------------ wrappers
 def gemm_nt(A, B, Cout, bias=None, C2=None, R1=None, R2=None, Pre=None, act=0, dact=0, alpha=1.0,
             drop_p=0.0, drop_site=0, drop_seed=0, M=None, drop_first=False, c2_deriv=False, scale_a=None, scale_b=None,
-            c_fp8=0, c_scale=1.0, c_scale_out=None):
-    """c_fp8 (fp8 operands only): Cout is a uint8 tensor that receives the result as e4m3 bytes (include/a4r.h: 1 = static scale c_scale,
+            c_fp8=0, c_scale=1.0, c_scale_out=None, q8_tiled=False):
+    """q8_tiled: the 8-bit derivative tensor (C2 with c2_deriv='q8' / Pre with DACT_MUL_Q8) in the 256-tile kernel's own order (include/a4r.h).
+    c_fp8 (fp8 operands only): Cout is a uint8 tensor that receives the result as e4m3 bytes (include/a4r.h: 1 = static scale c_scale,
     2 = row m scaled by scale_a[m] * c_scale, that product written to c_scale_out[m])."""
     if not (A.is_cuda and B.is_cuda and Cout.is_cuda):
         require_gpu(A, B, Cout)
@@ -165,7 +166,7 @@ def gemm_nt(A, B, Cout, bias=None, C2=None, R1=None, R2=None, Pre=None, act=0, d
                  A.shape[0] if M is None else M, N, K, _ld(A), _ld(B), _ld(Cout),
                  _ld(C2) if C2 is not None else 0, _ld(R1) if R1 is not None else 0, _ld(R2) if R2 is not None else 0,
                  _ld(Pre) if Pre is not None else 0, din, dout, act, dact, int(drop_first), 2 if q8c else int(bool(c2_deriv)), alpha, drop_p, drop_site,
-                 drop_seed, 0, _pi(scale_a), _pi(scale_b), int(c_fp8), float(c_scale), _pi(c_scale_out))
+                 drop_seed, 0, _pi(scale_a), _pi(scale_b), int(c_fp8), float(c_scale), _pi(c_scale_out), int(bool(q8_tiled)))
     _check(lib().a4r_gemm_nt(_stream(), C.byref(g)), 'a4r_gemm_nt')
 
 

@@ -304,6 +304,7 @@ extern "C" int a4r_gemm_nt(void* stream, const a4r_gemm_t* gp) {
         if ((g.R1 && (!aligned16(g.R1) || (g.ldr1 * osz) % 16)) || (g.R2 && (!aligned16(g.R2) || (g.ldr2 * osz) % 16))) return A4R_EINVAL;
         if (g.dact != A4R_ACT_NONE && (g.dact != A4R_DACT_MULQ8_ || !g.Pre || !aligned16(g.Pre) || g.ldpre % 16 || g.ldpre < g.N)) return A4R_EINVAL;   // (the 8-bit derivative form only)
         if (g.c_fp8 && (g.ldc % 16 || g.R1 || g.R2)) return A4R_EINVAL;                                     // e4m3 C: ldc counts bytes
+        if (g.q8_tiled && ((g.C2 && g.c2_mode == 2 && g.ldc2 != g.N) || (g.dact == A4R_DACT_MULQ8_ && g.ldpre != g.N))) return A4R_EINVAL;
         if (g.drop_p < 0.f || g.drop_p >= 1.f) return A4R_EINVAL;
         const int rc = a4r_gemm_nt_256(reinterpret_cast<hipStream_t>(stream), g);
         return rc == 1 ? A4R_EINVAL : rc;
@@ -321,6 +322,7 @@ extern "C" int a4r_gemm_nt(void* stream, const a4r_gemm_t* gp) {
     if (g.dact != A4R_ACT_NONE && (!g.Pre || !aligned16(g.Pre) || (g.ldpre * presz) % 16 || g.ldpre < g.N)) return A4R_EINVAL;
     if (g.drop_p < 0.f || g.drop_p >= 1.f) return A4R_EINVAL;
     if (g.dact == A4R_DACT_MUL_ && !g.Pre) return A4R_EINVAL;
+    if (g.q8_tiled && ((c2q8 && g.ldc2 != g.N) || (preq8 && g.ldpre != g.N))) return A4R_EINVAL;      // tile-native 8-bit derivative: a dense [M, N] byte tensor
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     if (g_variant == 2 && g.K == 64 && g.N >= 256) {
         const int rc = a4r_gemm_nt_skinnyk(s, g);
@@ -341,6 +343,7 @@ extern "C" int a4r_gemm_nt(void* stream, const a4r_gemm_t* gp) {
             a4r_gemm_t g1 = g, g2 = g;
             g1.M = (int)head_rows;
             g2.M = g.M - (int)head_rows;
+            g2.q8_tiled = 0;                      // the tail rows' 8-bit derivative stays row-major (whole row panels: same byte offset either way)
             g2.drop_row0 = g.drop_row0 + head_rows;
             auto adv = [&](const void* p, int ld, int sz) { return p ? (const void*)((const char*)p + head_rows * ld * sz) : nullptr; };
             g2.A = adv(g.A, g.lda, isz);

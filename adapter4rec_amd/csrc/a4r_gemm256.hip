@@ -388,6 +388,11 @@ __global__ void __launch_bounds__(512, 2) gemm_nt_256_kernel(const a4r_gemm_t p,
     const uint64_t e0_lane = (uint64_t)(wm * 128 + fr_e) * (uint64_t)epi.N + (uint64_t)(wn * 64 + (kg_e & 1) * 16 + (kg_e >> 1) * 8);
     char* const c_tile = reinterpret_cast<char*>(epi.C) + ((size_t)tm_done * 256 * (uint32_t)epi.ldc + (size_t)tn_done * 256) * CSZ;
     const uint64_t e0_tile = ((uint64_t)tm_done * 256 + epi.row0) * (uint64_t)epi.N + (uint64_t)tn_done * 256;
+    // 8-bit derivative in tile-native order (a4r_gemm_t.q8_tiled): this lane's 8 bytes of group g sit at tile base + wave * 8192 + g * 512 + lane * 8
+    const bool q8t = p.q8_tiled != 0;
+    const size_t q8_off = ((size_t)(tm_done * ntn + tn_done) * 8 + wave) * 8192 + (size_t)lane_e * 8;
+    const uint8_t* const q8_pre = reinterpret_cast<const uint8_t*>(epi.Pre) + q8_off;
+    uint8_t* const q8_c2 = reinterpret_cast<uint8_t*>(epi.C2) + q8_off;
     float bias8[2][8];                                    // (gcolp % 8 == 0: 16-byte loads are aligned iff the bias pointer is)
 #pragma unroll
     for (int pr = 0; pr < 2; ++pr)
@@ -446,8 +451,15 @@ __global__ void __launch_bounds__(512, 2) gemm_nt_256_kernel(const a4r_gemm_t p,
 #undef A4R_SLOTS
 #define A4R_LD_PRE(r_)                                                                                                      \
     if constexpr (DACT != A4R_ACT_NONE && (r_) < 8 && !(A4R_ABL & 256)) {                                                   \
+        if (DACT == A4R_DACT_MULQ8_ && q8t) {          /* tile-native order: 512 contiguous bytes per wave instruction */   \
+            const uint2 w0_ = *reinterpret_cast<const uint2*>(q8_pre + (2 * (r_)) * 512);                                   \
+            const uint2 w1_ = *reinterpret_cast<const uint2*>(q8_pre + (2 * (r_) + 1) * 512);                               \
+            pre_s##r_##_0[0] = make_uint4(w0_.x, w0_.y, 0u, 0u);                                                            \
+            pre_s##r_##_1[0] = make_uint4(w1_.x, w1_.y, 0u, 0u);                                                            \
+        } else {                                                                                                            \
         load_pre_n<TO, 8, DACT == A4R_DACT_MULQ8_>(pre_s##r_##_0, grow0 + (r_) * 16, gcolp, epi);                           \
         load_pre_n<TO, 8, DACT == A4R_DACT_MULQ8_>(pre_s##r_##_1, grow0 + (r_) * 16, gcolp + 32, epi);                      \
+        }                                                                                                                   \
     }
 #define A4R_LD_R1(r_)                                                                                                       \
     if constexpr (R1PF && (r_) < 8) {                                                                                       \
@@ -487,7 +499,7 @@ __global__ void __launch_bounds__(512, 2) gemm_nt_256_kernel(const a4r_gemm_t p,
         const uint64_t e0_ = e0_lane + (e0_tile + (uint64_t)((mi_) * 16) * (uint64_t)epi.N + (pr_) * 32);                      \
         A4R_EPI_CALL(mi_, pr_)                                                                                              \
                                            DACT != A4R_ACT_NONE ? pre_s##mi_##_##pr_ : nullptr, R1PF ? r1_s##mi_##_##pr_ : nullptr, nullptr, \
-                                           A4R_EPI_CDST(mi_, pr_), e0_, cmul8[mi_]);                                        \
+                                           A4R_EPI_CDST(mi_, pr_), e0_, cmul8[mi_], q8t ? q8_c2 + (2 * (mi_) + (pr_)) * 512 : nullptr); \
     }
 #define A4R_EPI_ROW(mi_, n1_, n2_, n4_)                                                                                     \
     A4R_LD_AHEAD(A4R_LD_PRE, PRE_D, n1_, n2_, n4_)                                                                          \

@@ -111,7 +111,8 @@ template <typename TO, int NC, bool Q8 = false> A4R_DEV void load_pre_n(uint4* q
 // others (a uniform branch each, 16 groups per tile) and their code are not emitted.  EF < 0: every piece behind its run-time test.
 template <typename TO, int NC, int ACT = -1, int DACT = -1, bool R1PF = false, bool FAST = false, int EF = -1>
 A4R_DEV void epilogue_n(float (&v)[NC], const float* bias, uint32_t grow, int gcol, const GemmEpi<TO>& e, const uint4* pre_ld = nullptr,
-                        const uint4* r1_ld = nullptr, const uint4* r2_ld = nullptr, TO* cdst = nullptr, uint64_t e0v = 0, float cmul = 1.f) {
+                        const uint4* r1_ld = nullptr, const uint4* r2_ld = nullptr, TO* cdst = nullptr, uint64_t e0v = 0, float cmul = 1.f,
+                        uint8_t* q8dst = nullptr) {      // q8dst: where this group's 8-bit derivative goes when not row-major (a4r_gemm_t.q8_tiled)
     // FAST (cdst, e0v): the caller formed the address of C[grow][gcol] / the dropout element index itself (the 256-tile kernel: a uniform
     // tile base + a per-lane 32-bit offset instead of a 64-bit multiply per group)
     const int act = ACT >= 0 ? ACT : e.act;
@@ -127,7 +128,7 @@ A4R_DEV void epilogue_n(float (&v)[NC], const float* bias, uint32_t grow, int gc
             if (A4R_ABL & 64) d[i] = v[i];
             else gelu_erf_both(v[i], v[i], d[i]);
         }
-        if (e.c2_mode == 2) store_q8<NC>(reinterpret_cast<uint8_t*>(e.C2) + (size_t)grow * (uint32_t)e.ldc2 + gcol, d);
+        if (e.c2_mode == 2) store_q8<NC>(q8dst ? q8dst : reinterpret_cast<uint8_t*>(e.C2) + (size_t)grow * (uint32_t)e.ldc2 + gcol, d);
         else if (!(A4R_ABL & 128)) store_n<TO, NC>(e.C2 + (size_t)grow * (uint32_t)e.ldc2 + gcol, d);
     } else {
         if (has_c2) {

@@ -800,6 +800,13 @@ class TransRecEngine:
             return False             # --fine_tune_to all: dW_i / dx1 of a TRAINABLE FFN use the derivative at storage precision, not the 8-bit form
         return self.q8_deriv and blk.T == torch.bfloat16 and getattr(blk, 'ffn_act', L.ACT_GELU) == L.ACT_GELU and blk.F % 16 == 0
 
+    Q8_TILED = _os.environ.get('A4R_Q8_TILED', '1') != '0'
+
+    def _q8t(self, blk, M):
+        """The 8-bit derivative tensor in the 256-tile kernel's own order (a4r_gemm_t.q8_tiled): only its writer (FFN-up) and its reader
+        (the `* derivative` dgrad) ever touch it, and both see the same [M, F]."""
+        return self.Q8_TILED and self._q8(blk) and M % 256 == 0 and blk.F % 256 == 0
+
     def _block_bufs(self, tag, blk, M, shared, Mc=None):
         """Activation buffers of one block: `shared` => transient set reused by every block (inference).
         Mc: row count of everything AFTER attention when only the CLS rows are carried on (last encoder layer)."""
@@ -918,7 +925,8 @@ class TransRecEngine:
         x1 = bufs['x1s'] if 'x1s' in bufs else x1
         self._sub_forward(blk, '1', ctx, blk.wo, blk.bo, x, blk.ln1, blk.ad1, blk.pl1, blk.lnn1, bufs, M, ph, blk.site + 1, seed, x1)
         u = bufs['u_s'] if 'u_s' in bufs else self._buf('u', M, blk.F, T)
-        L.gemm_nt(x1, blk.wi, u, bias=blk.bi, C2=bufs['upre'], act=blk.ffn_act, c2_deriv='q8' if self._q8(blk) else True, M=M)     # 'upre' holds act'(pre)
+        L.gemm_nt(x1, blk.wi, u, bias=blk.bi, C2=bufs['upre'], act=blk.ffn_act, c2_deriv='q8' if self._q8(blk) else True, M=M,      # 'upre' holds act'(pre)
+                  q8_tiled=self._q8t(blk, M))
         self._sub_forward(blk, '2', u, blk.wo2, blk.bo2, x1, blk.ln2, blk.ad2, blk.pl2, blk.lnn2, bufs, M, ph, blk.site + 2, seed, x_out)
 
     # ------------------------------------------------------------------ one block, backward
@@ -1073,7 +1081,7 @@ class TransRecEngine:
         dh2, dres2 = self._sub_backward(blk, '2', dx_out, blk.ln2, blk.ad2, blk.pl2, blk.lnn2, bufs, M, ph, blk.site + 2, seed)
         self._dense_wgrad(blk.d_o2, dh2, bufs.get('u_s'), M)
         du = self._buf('du', M, F, T)
-        L.gemm_nt(dh2, blk.wo2T, du, Pre=bufs['upre'], dact=L.DACT_MUL_Q8 if self._q8(blk) else L.DACT_MUL, M=M)
+        L.gemm_nt(dh2, blk.wo2T, du, Pre=bufs['upre'], dact=L.DACT_MUL_Q8 if self._q8(blk) else L.DACT_MUL, M=M, q8_tiled=self._q8t(blk, M))
         self._dense_wgrad(blk.d_i, du, bufs.get('x1s'), M)
         dx1 = self._buf('dx1', M, H, T)
         L.gemm_nt(du, blk.wiT, dx1, R1=dres2, M=M)

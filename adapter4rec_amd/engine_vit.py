@@ -267,13 +267,13 @@ class ViTRecEngine(TransRecEngine):
             if fp8_ffn:
                 u = self._buf('u8', M, blk.F, torch.uint8)
                 L.gemm_nt(n2q, blk.wi8, u, bias=blk.bi, C2=bufs['upre'], act=L.ACT_GELU, c2_deriv='q8', M=M, scale_a=n2s, scale_b=blk.wi8s,
-                          c_fp8=1, c_scale=self.FP8_U_SCALE)
+                          c_fp8=1, c_scale=self.FP8_U_SCALE, q8_tiled=self._q8t(blk, M))
             else:
-                L.gemm_nt(n2q, blk.wi8, u, bias=blk.bi, C2=bufs['upre'], act=L.ACT_GELU, c2_deriv=c2d, M=M, scale_a=n2s, scale_b=blk.wi8s)
+                L.gemm_nt(n2q, blk.wi8, u, bias=blk.bi, C2=bufs['upre'], act=L.ACT_GELU, c2_deriv=c2d, M=M, scale_a=n2s, scale_b=blk.wi8s, q8_tiled=self._q8t(blk, M))
         else:
             if not n2_done:
                 L.ln_fwd(bufs['x1'], blk.lnB.gamma, blk.lnB.beta, blk.lnB.eps, n2, bufs['stb'], M=M)
-            L.gemm_nt(n2, blk.wi, u, bias=blk.bi, C2=bufs['upre'], act=L.ACT_GELU, c2_deriv=c2d, M=M)
+            L.gemm_nt(n2, blk.wi, u, bias=blk.bi, C2=bufs['upre'], act=L.ACT_GELU, c2_deriv=c2d, M=M, q8_tiled=self._q8t(blk, M))
         if nxt is not None and cls_rows is None and self._vit_fuse(blk, blk.ad2, bufs['x1']):
             nb_, nbufs = nxt                            # dense | adapter + residual + the NEXT layer's LN_before
             ad = blk.ad2
@@ -341,11 +341,11 @@ class ViTRecEngine(TransRecEngine):
             L.quant_rows_fp8(d_o, do8, dos, M=M)
             du8, dus = self._buf('du8', M, F, torch.uint8), self._buf('du8s', M, 1, torch.float32)
             L.gemm_nt(do8, blk.wo2T8, du8, Pre=bufs['upre'], dact=L.DACT_MUL_Q8, M=M, scale_a=dos, scale_b=blk.wo2T8s,
-                      c_fp8=2, c_scale=blk.c_du, c_scale_out=dus)
+                      c_fp8=2, c_scale=blk.c_du, c_scale_out=dus, q8_tiled=self._q8t(blk, M))
             L.gemm_nt(du8, blk.wiT8, dn2, M=M, scale_a=dus, scale_b=blk.wiT8s)
         else:
             du = self._buf('du', M, F, T)
-            L.gemm_nt(d_o, blk.wo2T, du, Pre=bufs['upre'], dact=L.DACT_MUL_Q8 if self._q8(blk) else L.DACT_MUL, M=M)
+            L.gemm_nt(d_o, blk.wo2T, du, Pre=bufs['upre'], dact=L.DACT_MUL_Q8 if self._q8(blk) else L.DACT_MUL, M=M, q8_tiled=self._q8t(blk, M))
             self._dense_wgrad(blk.d_i, du, bufs.get('n2_s'), M)
             L.gemm_nt(du, blk.wiT, dn2, M=M)
         dx1 = self._buf('dx1', M, H, T)

@@ -36,7 +36,7 @@ extern "C" {
 
 /* ABI version: bumped whenever a signature or struct below changes.  The Python binding (adapter4rec_amd/_lib.py) refuses a
  * library whose a4r_version() differs, so an A/B build made before a signature change cannot be called with shifted arguments. */
-#define A4R_ABI_VERSION 302
+#define A4R_ABI_VERSION 303
 int a4r_version(void);
 
 /* C[M,N] = epilogue(alpha * A[M,K] . B[N,K]^T): every nn.Linear on the path (HF BertSelfAttention
@@ -73,6 +73,14 @@ typedef struct {
      *   c_fp8 = 2: C = e4m3(sat(v / (scale_a[m] * c_scale))) and c_scale_out[m] = scale_a[m] * c_scale: a row of the result inherits the
      *              scale of the row of A it came from times a per-layer constant (dgrad chains: du = (dy W) * gelu', |du[m]| <~ |dy[m]| |W|). */
     int32_t c_fp8; float c_scale; float* c_scale_out;
+    /* q8_tiled != 0: the 8-bit derivative tensor (C2 under c2_mode 2, Pre under A4R_DACT_MUL_Q8) is stored in the TILE-NATIVE order of the
+     * 256 x 256 kernel instead of row-major: byte offset of (tile tm, tn; wave w; group g = 2 * row16 + pair; lane l) =
+     *   ((tm * (N / 256) + tn) * 8 + w) * 8192 + g * 512 + l * 8,
+     * so that a wave's store / load instruction moves 512 contiguous bytes (row-major: 16 segments of 32).  The tensor is only ever
+     * written by the FFN-up launch and read by the `* derivative` dgrad launch of the same [M, N]; both must set the flag.  Rows that a
+     * launch hands to the 128-tile kernel (tail row panels, small shapes) stay row-major -- a function of (M, N) only, so the two launches
+     * agree.  ldc2 / ldpre must equal N. */
+    int32_t q8_tiled;
 } a4r_gemm_t;
 int a4r_gemm_nt(void* stream, const a4r_gemm_t* g);
 /* tuning knob for A/B measurements and tests: 0 = 128x128 tile, register-staged K pipeline; 1 = 128x128 tile, direct-to-LDS

@@ -56,8 +56,8 @@ def _deq(t, scale):
 
 def gemm_nt(A, B, Cout, bias=None, C2=None, R1=None, R2=None, Pre=None, act=0, dact=0, alpha=1.0,
             drop_p=0.0, drop_site=0, drop_seed=0, M=None, drop_first=False, c2_deriv=False, scale_a=None, scale_b=None,
-            c_fp8=0, c_scale=1.0, c_scale_out=None):
-    assert drop_p == 0.0
+            c_fp8=0, c_scale=1.0, c_scale_out=None, q8_tiled=False):
+    assert drop_p == 0.0          # (q8_tiled: a storage order private to the two launches that share the tensor -- nothing to simulate)
     M = A.shape[0] if M is None else M
     assert M % 128 == 0 and B.shape[0] % 64 == 0 and B.shape[1] % 64 == 0, (M, B.shape)
     if A.dtype == torch.uint8:           # fp8 operands (include/a4r.h: A4R_FP8)

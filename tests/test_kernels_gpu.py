@@ -1230,3 +1230,30 @@ def test_sasrec_block_dropout_is_consistent():
     for dd, what in ((dict(desc, drop_hidden=0.0), 'attention dropout only'), (dict(desc, drop_attn=0.0), 'hidden dropout only'), (desc, 'both')):
         num, ana = fd_check(dd, True, what)
         assert abs(num - ana) < tol, (what, num, ana, tol)
+
+
+@pytest.mark.parametrize('M,N,K', [(256 * 5, 1024, 256), (256 * 66, 1024, 128)])      # the second: 264 tiles = one round + a tail row panel pair on the 128-tile kernel
+def test_gemm_q8_tiled_layout_roundtrip(M, N, K):
+    """a4r_gemm_t.q8_tiled: the 8-bit GELU derivative written by the FFN-up launch in the 256-tile kernel's own order and read back by the
+    `* derivative` dgrad launch gives bit-identical results to the row-major pipeline; the stored bytes are a permutation of the row-major ones."""
+    from adapter4rec_amd import _lib as L
+    t = torch.bfloat16
+    A, B = rnd(M, K, dtype=t, seed=1), rnd(N, K, dtype=t, scale=0.1, seed=2)
+    dY, W = rnd(M, K, dtype=t, seed=3), rnd(N, K, dtype=t, scale=0.1, seed=4)
+    bias = rnd(N, seed=5) * 0.1
+    outs = {}
+    for tiled in (False, True):
+        C = torch.zeros(M, N, dtype=t, device=dev())
+        D = torch.zeros(M, N, dtype=torch.uint8, device=dev())
+        L.gemm_nt(A, B, C, bias=bias, C2=D, act=L.ACT_GELU, c2_deriv='q8', q8_tiled=tiled)
+        G = torch.zeros(M, N, dtype=t, device=dev())
+        L.gemm_nt(dY, W, G, Pre=D, dact=L.DACT_MUL_Q8, q8_tiled=tiled)
+        outs[tiled] = (C, D, G)
+    assert torch.equal(outs[False][0], outs[True][0]) and torch.equal(outs[False][2], outs[True][2])
+    d0, d1 = outs[False][1], outs[True][1]
+    assert not torch.equal(d0, d1) and torch.equal(torch.sort(d0.flatten())[0], torch.sort(d1.flatten())[0])
+    # a tile's 65 536 bytes hold exactly that tile's values
+    tm, tn = 1, 2
+    tile_rm = d0[tm * 256:(tm + 1) * 256, tn * 256:(tn + 1) * 256].flatten()
+    tile_t = d1.flatten()[(tm * (N // 256) + tn) * 65536:(tm * (N // 256) + tn + 1) * 65536]
+    assert torch.equal(torch.sort(tile_rm)[0], torch.sort(tile_t)[0])
