@@ -1232,7 +1232,9 @@ def test_sasrec_block_dropout_is_consistent():
         assert abs(num - ana) < tol, (what, num, ana, tol)
 
 
-@pytest.mark.parametrize('M,N,K', [(256 * 5, 1024, 256), (256 * 66, 1024, 128)])      # the second: 264 tiles = one round + a tail row panel pair on the 128-tile kernel
+# 160 tiles: the 256-tile kernel alone (fewer than 128 tiles go to the 128-tile kernel, row-major either way); 264 tiles: one round + a tail
+# row-panel pair on the 128-tile kernel, whose rows stay row-major
+@pytest.mark.parametrize('M,N,K', [(256 * 40, 1024, 256), (256 * 66, 1024, 128)])
 def test_gemm_q8_tiled_layout_roundtrip(M, N, K):
     """a4r_gemm_t.q8_tiled: the 8-bit GELU derivative written by the FFN-up launch in the 256-tile kernel's own order and read back by the
     `* derivative` dgrad launch gives bit-identical results to the row-major pipeline; the stored bytes are a permutation of the row-major ones."""
