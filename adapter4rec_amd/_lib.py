@@ -12,7 +12,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('A4R_LIB_PATH') or os.path.join(_HERE, 'liba4r_hip.so')    # A4R_LIB_PATH: A/B builds (tools/), same C ABI
 
-ABI_VERSION = 303          # = A4R_ABI_VERSION of include/a4r.h (tests/test_abi_cpu.py compares the two)
+ABI_VERSION = 304          # = A4R_ABI_VERSION of include/a4r.h (tests/test_abi_cpu.py compares the two)
 BF16, F32, FP8 = 0, 1, 2
 ACT_NONE, ACT_RELU, ACT_GELU, ACT_GELU_TANH, ACT_LEAKY = 0, 1, 2, 3, 4
 DACT_MUL = 15
@@ -66,7 +66,8 @@ class SasrecBlock(C.Structure):
              'g_wd1', 'g_bd1', 'g_wu1', 'g_bu1', 'g_wd2', 'g_bd2', 'g_wu2', 'g_bu2')
     _fields_ = [(n, C.c_void_p) for n in _PTRS] + \
                [(n, C.c_int32) for n in ('E', 'n_heads', 'F', 'd', 'ldwu', 'ldg_d', 'ldg_u', 'act', 'inner_res')] + \
-               [(n, C.c_float) for n in ('eps', 'mask_neg', 'drop_attn', 'drop_hidden')] + [('drop_site', C.c_uint32), ('drop_seed', C.c_uint64)]
+               [(n, C.c_float) for n in ('eps', 'mask_neg', 'drop_attn', 'drop_hidden')] + [('drop_site', C.c_uint32), ('drop_seed', C.c_uint64)] + \
+               [('mode', C.c_int32)] + [(n, C.c_void_p) for n in ('ln3_g', 'ln3_b', 'g_ln3_g', 'g_ln3_b')]
 
 
 class AddDesc(C.Structure):
@@ -208,7 +209,7 @@ def sasrec_block(desc, x, log_mask, out, n_users, T, train, dy=None):
     assert x.dtype == torch.float32 and out.dtype == torch.float32 and log_mask.dtype == torch.float32 and x.shape[1] == 64 and x.is_contiguous() and out.is_contiguous()
     b = SasrecBlock()
     for k, v in desc.items():
-        setattr(b, k, (v.data_ptr() if v is not None else None) if k in SasrecBlock._PTRS else v)
+        setattr(b, k, (v.data_ptr() if v is not None else None) if (k in SasrecBlock._PTRS or k in ('ln3_g', 'ln3_b', 'g_ln3_g', 'g_ln3_b')) else v)
     if dy is None:
         _check(lib().a4r_sasrec_block_fwd(_stream(), C.byref(b), _p(x), _p(log_mask), _p(out), C.c_int(n_users), C.c_int(T), C.c_int(int(train))), 'a4r_sasrec_block_fwd')
     else:

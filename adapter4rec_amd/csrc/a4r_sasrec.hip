@@ -33,16 +33,17 @@ struct Lay {                      // LDS layout in floats (dpe = adapter width r
         auto take = [&](int n) { const int r = o; o += n; return r; };
         x = take(RP * SX); qkv = take(RP * SQ); p = take(NH * RP * SPR); ctx = take(RP * SX); h = take(RP * SX);
         zp1 = take(RP * sz); z1 = take(RP * sz); v1 = take(RP * SX); x1 = take(RP * SX); u = take(RP * SU); h2 = take(RP * SX);
-        zp2 = take(RP * sz); z2 = take(RP * sz); v2 = take(RP * SX); st = take(4 * RP); g1 = take(RP * SX);
+        zp2 = take(RP * sz); z2 = take(RP * sz); v2 = take(RP * SX); st = take(6 * RP); g1 = take(RP * SX);
         total = o;
     }
 };
 
 struct BlockW {                   // device pointers of one block (fp32)
     const float *wqkv, *wfc, *w1, *b1, *w2, *b2;                    // [3E, E], [E, E], [F, E], [F], [E, F], [E]
-    const float *ln1g, *ln1b, *ln2g, *ln2b;
+    const float *ln1g, *ln1b, *ln2g, *ln2b, *ln3g, *ln3b;          // ln3: the Pfeiffer form's new LayerNorm (mode 1)
     const float *wd1, *bd1, *wu1, *bu1, *wd2, *bd2, *wu2, *bu2;     // adapters: Wd [dp, E] (ld E), bd [dp], Wu [E, dp] (ld ldwu), bu [E]
-    int ldwu, d, act, inner_res;                                    // d = true bottleneck width, rows d.. of Wd / columns d.. of Wu are zero padding
+    int ldwu, d, act, inner_res, mode;                              // d = true bottleneck width, rows d.. of Wd / columns d.. of Wu are zero padding
+                                                                    // mode 0: an adapter after both sub-layers (Houlsby / Compacter); 1: Pfeiffer (adapter after LN2, + LN3)
     float eps, scale, mask_neg;
     float p_attn, p_hidden;
     uint32_t thr_attn, thr_hidden, site;
@@ -51,7 +52,7 @@ struct BlockW {                   // device pointers of one block (fp32)
 };
 
 struct BlockG {                   // gradient sinks (fp32, +=), any may be null
-    float *wd1, *bd1, *wu1, *bu1, *wd2, *bd2, *wu2, *bu2;
+    float *wd1, *bd1, *wu1, *bu1, *wd2, *bd2, *wu2, *bu2, *ln3g, *ln3b;
     int ldgd, ldgu;               // leading dimensions of the Wd / Wu gradient matrices ([d, E] -> E or the padded scratch's; [E, d] -> d or dp)
 };
 
@@ -218,7 +219,10 @@ A4R_DEV void block_forward(float* lds, const Lay& L, const BlockW& w, const floa
         });
     }
     __syncthreads();
-    // 4. adapter 1 + residual -> v1, LN1 -> x1
+    // 4. [adapter 1] + residual -> v1, LN1 -> x1
+    if (w.mode == 1) {                                   // Pfeiffer: the attention sub-layer carries no adapter (model.py:458-471)
+        for (int id = tid; id < RP * E; id += 256) { const int r = id >> 6, c = id & 63; V1[r * SX + c] = H[r * SX + c] + X[r * SX + c]; }
+    } else {
     for (int ct = wave; ct < dpe / 16; ct += 4) {
         f32x4_t acc[2]; zero2(acc);
         mm_nt<E>(H, SX, w.wd1, E, ct * 16, lane, acc);
@@ -243,6 +247,7 @@ A4R_DEV void block_forward(float* lds, const Lay& L, const BlockW& w, const floa
             V1[r * SX + c] = v + w.bu1[c] + (w.inner_res ? H[r * SX + c] : 0.f) + X[r * SX + c];
         });
     }
+    }
     __syncthreads();
     ln_rows(V1, X1, ST, w.ln1g, w.ln1b, w.eps, T, wave, lane);
     __syncthreads();
@@ -266,10 +271,20 @@ A4R_DEV void block_forward(float* lds, const Lay& L, const BlockW& w, const floa
         });
     }
     __syncthreads();
-    // 7. adapter 2 + residual -> v2, LN2 -> y
+    // 7. mode 0: adapter 2 on h2, + x1 -> v2, LN2 -> y
+    //    mode 1 (Pfeiffer, model.py:321-329 / :458-471): va = h2 + x1; t = LN2(va); v3 = adapter(t) + va; y = LN3(v3)
+    //    (buffers: va -> V2, t -> H (dead since v1), v3 -> H2 (dead once va exists); statistics of LN2 at ST + 2 RP, of LN3 at ST + 4 RP)
+    const float* AIN = H2;                               // the adapter's input rows
+    if (w.mode == 1) {
+        for (int id = tid; id < RP * E; id += 256) { const int r = id >> 6, c = id & 63; V2[r * SX + c] = H2[r * SX + c] + X1[r * SX + c]; }
+        __syncthreads();
+        ln_rows(V2, H, ST + 2 * RP, w.ln2g, w.ln2b, w.eps, T, wave, lane);
+        __syncthreads();
+        AIN = H;
+    }
     for (int ct = wave; ct < dpe / 16; ct += 4) {
         f32x4_t acc[2]; zero2(acc);
-        mm_nt<E>(H2, SX, w.wd2, E, ct * 16, lane, acc);
+        mm_nt<E>(AIN, SX, w.wd2, E, ct * 16, lane, acc);
         tile_each(acc, ct * 16, lane, [&](int r, int c, float v) {
             v += w.bd2[c];
             ZP2[r * L.sz + c] = v;
@@ -287,12 +302,17 @@ A4R_DEV void block_forward(float* lds, const Lay& L, const BlockW& w, const floa
             Mma<float>::mma(a0, b, acc[0]);
             Mma<float>::mma(a1, b, acc[1]);
         }
-        tile_each(acc, wave * 16, lane, [&](int r, int c, float v) {
-            V2[r * SX + c] = v + w.bu2[c] + (w.inner_res ? H2[r * SX + c] : 0.f) + X1[r * SX + c];
-        });
+        if (w.mode == 1) {
+            tile_each(acc, wave * 16, lane, [&](int r, int c, float v) { H2[r * SX + c] = v + w.bu2[c] + V2[r * SX + c]; });
+        } else {
+            tile_each(acc, wave * 16, lane, [&](int r, int c, float v) {
+                V2[r * SX + c] = v + w.bu2[c] + (w.inner_res ? H2[r * SX + c] : 0.f) + X1[r * SX + c];
+            });
+        }
     }
     __syncthreads();
-    ln_rows(V2, yout, ST + 2 * RP, w.ln2g, w.ln2b, w.eps, T, wave, lane);
+    if (w.mode == 1) ln_rows(H2, yout, ST + 4 * RP, w.ln3g, w.ln3b, w.eps, T, wave, lane);
+    else ln_rows(V2, yout, ST + 2 * RP, w.ln2g, w.ln2b, w.eps, T, wave, lane);
     __syncthreads();
 }
 
@@ -338,6 +358,27 @@ A4R_DEV void ln_bwd_rows(float* dy, const float* v, const float* st, const float
             dy[r * SX + lane] = 0.f;
         }
     }
+}
+
+// the same, also accumulating dgamma += sum_r dy xhat, dbeta += sum_r dy (a trainable LayerNorm: the Pfeiffer form's LN3)
+A4R_DEV void ln_bwd_rows_params(float* dy, const float* v, const float* st, const float* g, float* dg, float* db, int T, int wave, int lane) {
+    float ag = 0.f, ab = 0.f;
+    for (int r = wave; r < RP; r += 4) {
+        if (r < T) {
+            const float mean = st[2 * r], rstd = st[2 * r + 1];
+            const float xh = (v[r * SX + lane] - mean) * rstd;
+            const float d0 = dy[r * SX + lane];
+            ag += d0 * xh;
+            ab += d0;
+            const float dxh = d0 * g[lane];
+            const float m1 = wave_sum(dxh) * (1.f / E), m2 = wave_sum(dxh * xh) * (1.f / E);
+            dy[r * SX + lane] = rstd * (dxh - m1 - xh * m2);
+        } else {
+            dy[r * SX + lane] = 0.f;
+        }
+    }
+    if (dg) atomicAdd(dg + lane, ag);
+    if (db) atomicAdd(db + lane, ab);
 }
 
 // adapter backward on LDS images: dv [RP, E] (gradient at the adapter's output = LN input gradient), h = the adapter's input.
@@ -417,6 +458,8 @@ A4R_DEV void adapter_backward(const float* DV, const float* Hin, const float* ZP
 //   H2  (dead after adapter 2's weight gradients) <- dX1 = dU W1 + dV2, LN1 backward in place = dV1 (kept to the end: residual of dX)
 //   V1  (dead after LN1 backward) <- adapter 1's input gradient, through h's dropout mask = dO1
 //   [H, ZP1, Z1, V1, X1] (contiguous, all dead once dCTX is formed) <- dQKV [RP][SQ]
+// Pfeiffer (mode 1): v3 sits in H2, t in H, va in V2; dT -> X1, LN2 backward in place there, + dV3 = dVA (kept in X1 as the residual
+// gradient), dO2 -> V2; from dU on the two modes share the code.
 template <bool TRAIN>
 __global__ void __launch_bounds__(256) sasrec_block_bwd_kernel(const float* __restrict__ x, const float* __restrict__ log_mask, const float* __restrict__ dy,
                                                                 float* __restrict__ dx, BlockW w, BlockG g, int T, int dpe) {
@@ -432,8 +475,28 @@ __global__ void __launch_bounds__(256) sasrec_block_bwd_kernel(const float* __re
     float* ZP1 = lds + L.zp1; float* Z1 = lds + L.z1; float* V1 = lds + L.v1; float* U = lds + L.u;
     float* H2 = lds + L.h2; float* ZP2 = lds + L.zp2; float* Z2 = lds + L.z2; float* V2 = lds + L.v2; float* ST = lds + L.st; float* G1 = lds + L.g1;
     float* DZ = CTX;                                               // [RP][sz] inside an [RP][SX] image (sz <= SX)
+    float* X1b = lds + L.x1;
     load_rows(G1, dy + (size_t)user * T * E, T, tid);
     __syncthreads();
+    const float* RES2;                                             // the gradient that reaches x1 along the residual of the FFN sub-layer
+    if (w.mode == 1) {
+        // Pfeiffer: y = LN3(v3), v3 = adapter(t) + va, t = LN2(va), va = h2 + x1   (v3 in H2, t in H, va in V2)
+        ln_bwd_rows_params(G1, H2, ST + 4 * RP, w.ln3g, g.ln3g, g.ln3b, T, wave, lane);      // dV3
+        __syncthreads();
+        adapter_backward(G1, H, ZP2, Z2, DZ, X1b, L, w.wd2, w.wu2, w.ldwu, w.d, w.act, 0, g.wd2, g.bd2, g.wu2, g.bu2, g.ldgd, g.ldgu, T, tid);    // dT -> X1b
+        ln_bwd_rows(X1b, V2, ST + 2 * RP, w.ln2g, T, wave, lane);
+        __syncthreads();
+        for (int id = tid; id < RP * E; id += 256) {               // dVA = LN2 backward + dV3; dO2 = dVA through h2's dropout mask -> V2
+            const int r = id >> 6, c = id & 63;
+            const float dva = X1b[r * SX + c] + G1[r * SX + c];
+            X1b[r * SX + c] = dva;
+            float o = dva;
+            if (TRAIN && w.thr_hidden) o = keep_elem(w.seed, w.site + 2, ((uint64_t)user * 32 + r) * E + c, w.thr_hidden) ? dva * w.ks_hidden : 0.f;
+            V2[r * SX + c] = o;
+        }
+        __syncthreads();
+        RES2 = X1b;
+    } else {
     ln_bwd_rows(G1, V2, ST + 2 * RP, w.ln2g, T, wave, lane);       // dV2
     __syncthreads();
     adapter_backward(G1, H2, ZP2, Z2, DZ, V2, L, w.wd2, w.wu2, w.ldwu, w.d, w.act, w.inner_res, g.wd2, g.bd2, g.wu2, g.bu2, g.ldgd, g.ldgu, T, tid);
@@ -444,6 +507,8 @@ __global__ void __launch_bounds__(256) sasrec_block_bwd_kernel(const float* __re
         }
         __syncthreads();
     }
+        RES2 = G1;
+    }
     // dU = (dO2 W2) * relu'(u), in place over U: B[n = F column][k = E] = W2[k][n] (global [E, F])
 #pragma unroll
     for (int t4 = 0; t4 < 4; ++t4) {
@@ -453,16 +518,21 @@ __global__ void __launch_bounds__(256) sasrec_block_bwd_kernel(const float* __re
         tile_each(acc, ct * 16, lane, [&](int r, int c, float v) { U[r * SU + c] = U[r * SU + c] > 0.f ? v : 0.f; });
     }
     __syncthreads();
-    // dX1 = dU W1 + dV2 -> H2: B[n = E column][k = F] = W1[k][n] (global [F, E])
+    // dX1 = dU W1 + (the residual branch's gradient: dV2 / dVA) -> H2: B[n = E column][k = F] = W1[k][n] (global [F, E])
     {
         f32x4_t acc[2]; zero2(acc);
         mm_nn<F>(U, SU, w.w1, E, wave * 16, lane, acc);
-        tile_each(acc, wave * 16, lane, [&](int r, int c, float v) { H2[r * SX + c] = v + G1[r * SX + c]; });
+        tile_each(acc, wave * 16, lane, [&](int r, int c, float v) { H2[r * SX + c] = v + RES2[r * SX + c]; });
     }
     __syncthreads();
     ln_bwd_rows(H2, V1, ST, w.ln1g, T, wave, lane);                // dV1
     __syncthreads();
-    adapter_backward(H2, H, ZP1, Z1, DZ, V1, L, w.wd1, w.wu1, w.ldwu, w.d, w.act, w.inner_res, g.wd1, g.bd1, g.wu1, g.bu1, g.ldgd, g.ldgu, T, tid);
+    if (w.mode == 1) {                                             // no adapter on the attention sub-layer: dH = dV1
+        for (int id = tid; id < RP * E; id += 256) { const int r = id >> 6, c = id & 63; V1[r * SX + c] = H2[r * SX + c]; }
+        __syncthreads();
+    } else {
+        adapter_backward(H2, H, ZP1, Z1, DZ, V1, L, w.wd1, w.wu1, w.ldwu, w.d, w.act, w.inner_res, g.wd1, g.bd1, g.wu1, g.bu1, g.ldgd, g.ldgu, T, tid);
+    }
     if (TRAIN && w.thr_hidden) {                                   // through the dropout of h -> dO1
         for (int id = tid; id < RP * E; id += 256) {
             const int r = id >> 6, c = id & 63;
@@ -567,6 +637,8 @@ constexpr size_t LDS_LIMIT = 160 * 1024;
 int fill(const a4r_sasrec_block_t* b, int T, int train, BlockW& w, int& dpe) {
     if (!b || T <= 0 || T > RP) return A4R_EINVAL;
     if (b->E != E || b->n_heads != NH || b->F != F || b->d <= 0 || b->d > 64 || b->ldwu < b->d || b->ldwu % 4) return A4R_EINVAL;
+    if (b->mode != 0 && b->mode != 1) return A4R_EINVAL;
+    if (b->mode == 1 && (!b->ln3_g || !b->ln3_b || ((reinterpret_cast<uintptr_t>(b->ln3_g) | reinterpret_cast<uintptr_t>(b->ln3_b)) & 3u))) return A4R_EINVAL;
     const void* need[] = {b->wqkv, b->wfc, b->w1, b->b1, b->w2, b->b2, b->ln1_g, b->ln1_b, b->ln2_g, b->ln2_b,
                           b->wd1, b->bd1, b->wu1, b->bu1, b->wd2, b->bd2, b->wu2, b->bu2};
     for (const void* q : need)
@@ -576,7 +648,8 @@ int fill(const a4r_sasrec_block_t* b, int T, int train, BlockW& w, int& dpe) {
     if (dpe > b->ldwu) return A4R_EINVAL;                                               // (the zero padding of Wd / bd / Wu must cover the 16-column tiles)
     if ((size_t)Lay(dpe).total * sizeof(float) > LDS_LIMIT) return A4R_EINVAL;          // d > 32: the multi-launch path
     w.wqkv = b->wqkv; w.wfc = b->wfc; w.w1 = b->w1; w.b1 = b->b1; w.w2 = b->w2; w.b2 = b->b2;
-    w.ln1g = b->ln1_g; w.ln1b = b->ln1_b; w.ln2g = b->ln2_g; w.ln2b = b->ln2_b;
+    w.ln1g = b->ln1_g; w.ln1b = b->ln1_b; w.ln2g = b->ln2_g; w.ln2b = b->ln2_b; w.ln3g = b->ln3_g; w.ln3b = b->ln3_b;
+    w.mode = b->mode;
     w.wd1 = b->wd1; w.bd1 = b->bd1; w.wu1 = b->wu1; w.bu1 = b->bu1; w.wd2 = b->wd2; w.bd2 = b->bd2; w.wu2 = b->wu2; w.bu2 = b->bu2;
     w.ldwu = b->ldwu; w.d = b->d; w.act = b->act; w.inner_res = b->inner_res;
     w.eps = b->eps; w.scale = 1.f / sqrtf((float)DH); w.mask_neg = b->mask_neg;
@@ -621,6 +694,7 @@ extern "C" int a4r_sasrec_block_bwd(void* stream, const a4r_sasrec_block_t* b, c
     if ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(dy) | reinterpret_cast<uintptr_t>(dx)) & 15u) return A4R_EINVAL;
     if (int rc = fill(b, T, train, w, dpe)) return rc;
     g.wd1 = b->g_wd1; g.bd1 = b->g_bd1; g.wu1 = b->g_wu1; g.bu1 = b->g_bu1; g.wd2 = b->g_wd2; g.bd2 = b->g_bd2; g.wu2 = b->g_wu2; g.bu2 = b->g_bu2;
+    g.ln3g = b->g_ln3_g; g.ln3b = b->g_ln3_b;
     g.ldgd = b->ldg_d; g.ldgu = b->ldg_u;
     if ((g.wd1 || g.wd2) && g.ldgd < E) return A4R_EINVAL;
     if ((g.wu1 || g.wu2) && g.ldgu < b->d) return A4R_EINVAL;

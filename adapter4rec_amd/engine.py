@@ -650,9 +650,12 @@ class TransRecEngine:
         for b in self.sas_blocks:
             if (b.H, getattr(b, 'Hv', b.H), b.nh, b.F, b.T) != (64, 64, 2, 256, torch.float32) or not b.causal or b.lora or b.train_dense:
                 return False
-            if b.ad1 is None or b.ad2 is None or b.pl1 != 'serial' or b.pl2 != 'serial' or b.lnn1 is not None or b.lnn2 is not None:
+            pfe = b.ad1 is None and b.ad2 is not None and b.pl2 == 'pfeiffer' and b.lnn2 is not None       # SASRecPfeifferAdaptedSelfOutput
+            ser = b.ad1 is not None and b.ad2 is not None and b.pl1 == 'serial' and b.pl2 == 'serial' and b.lnn1 is None and b.lnn2 is None
+            if not (pfe or ser):
                 return False
-            if any(a.d > 32 or a.dp != 64 or a.act != b.ad1.act or a.kind != b.ad1.kind or a.d != b.ad1.d for a in (b.ad1, b.ad2)):
+            ads = (b.ad2,) if pfe else (b.ad1, b.ad2)
+            if any(a.d > 32 or a.dp != 64 or a.act != b.ad2.act or a.kind != b.ad2.kind or a.d != b.ad2.d or a.virtual is not None and pfe for a in ads):
                 return False
             if any(f is not None for ln in (b.ln1, b.ln2) for f in (ln.g_gamma, ln.g_beta)):
                 return False
@@ -661,17 +664,23 @@ class TransRecEngine:
     def _sas_desc(self, b, seed, with_grads):
         """a4r_sasrec_block_t fields of one block (the gradient sinks are resolved against the CURRENT gradient target)."""
         gg = lambda f: f() if f is not None else None
+        a0 = b.ad1 if b.ad1 is not None else b.ad2
         d = dict(wqkv=b.wqkv, wfc=b.wo, w1=b.wi, b1=b.bi, w2=b.wo2, b2=b.bo2, ln1_g=b.ln1.gamma, ln1_b=b.ln1.beta, ln2_g=b.ln2.gamma, ln2_b=b.ln2.beta,
-                 E=64, n_heads=2, F=256, d=b.ad1.d, ldwu=b.ad1.dp, ldg_d=64, ldg_u=64, act=b.ad1.act, inner_res=int(b.ad1.kind != 'compacter'),
+                 E=64, n_heads=2, F=256, d=a0.d, ldwu=a0.dp, ldg_d=64, ldg_u=64, act=a0.act, inner_res=int(a0.kind == 'houlsby'), mode=0,
                  eps=float(b.ln1.eps), mask_neg=float(b.mask_neg), drop_attn=float(b.p_attn), drop_hidden=float(b.p_hidden),
                  drop_site=int(b.site), drop_seed=int(seed))
-        for k, ad in (('1', b.ad1), ('2', b.ad2)):
+        pfe = b.ad1 is None
+        if pfe:                                     # mode 1: adapter 1's operand slots are unused (non-null for the argument check)
+            d.update(mode=1, ln3_g=b.lnn2.gamma, ln3_b=b.lnn2.beta, g_ln3_g=gg(b.lnn2.g_gamma) if with_grads else None,
+                     g_ln3_b=gg(b.lnn2.g_beta) if with_grads else None, inner_res=0, d=b.ad2.d, ldwu=b.ad2.dp, act=b.ad2.act)
+        for k, ad in (('1', b.ad2 if pfe else b.ad1), ('2', b.ad2)):
             d.update({'wd' + k: ad.wd, 'bd' + k: ad.bd, 'wu' + k: ad.wu, 'bu' + k: ad.bu})
-            trains = with_grads and (ad.virtual is not None or ad.g_wu is not None)
+            trains = with_grads and (ad.virtual is not None or ad.g_wu is not None) and not (pfe and k == '1')
             # (d < 64: the zero-padded scratch matrices whose valid corners _flush_corners / a4r_phm_bwd pick up, as the multi-launch path)
+            wg = with_grads and not (pfe and k == '1')
             d.update({'g_wd' + k: ad.s_wd if trains else None, 'g_wu' + k: ad.s_wu if trains else None,
-                      'g_bd' + k: (ad.s_bd if ad.s_bd is not None else gg(ad.g_bd)) if (with_grads and ad.g_bd is not None) else None,
-                      'g_bu' + k: gg(ad.g_bu) if with_grads else None})
+                      'g_bd' + k: (ad.s_bd if ad.s_bd is not None else gg(ad.g_bd)) if (wg and ad.g_bd is not None) else None,
+                      'g_bu' + k: gg(ad.g_bu) if wg else None})
         return d
 
     def _make_block(self, tb, Hv, nh, S, dt, causal, mask_neg, p_drop, site):

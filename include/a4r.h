@@ -36,7 +36,7 @@ extern "C" {
 
 /* ABI version: bumped whenever a signature or struct below changes.  The Python binding (adapter4rec_amd/_lib.py) refuses a
  * library whose a4r_version() differs, so an A/B build made before a signature change cannot be called with shifted arguments. */
-#define A4R_ABI_VERSION 303
+#define A4R_ABI_VERSION 304
 int a4r_version(void);
 
 /* C[M,N] = epilogue(alpha * A[M,K] . B[N,K]^T): every nn.Linear on the path (HF BertSelfAttention
@@ -113,6 +113,9 @@ typedef struct {
     int32_t E, n_heads, F, d, ldwu, ldg_d, ldg_u, act, inner_res;
     float eps, mask_neg, drop_attn, drop_hidden;
     uint32_t drop_site; uint64_t drop_seed;
+    /* mode 1 = SASRecPfeifferAdaptedSelfOutput (model/model.py:458-471): no adapter on the attention sub-layer (wd1 .. bu1 unused but non-null),
+     * va = h2 + x1; t = LN2(va); y = LN3(adapter2(t) + va) with the NEW LayerNorm ln3 (trainable: g_ln3_g / g_ln3_b, fp32 atomics). */
+    int32_t mode; const float *ln3_g, *ln3_b; float *g_ln3_g, *g_ln3_b;
 } a4r_sasrec_block_t;
 int a4r_sasrec_block_fwd(void* stream, const a4r_sasrec_block_t* b, const float* x, const float* log_mask, float* y, int n_users, int T, int train);
 int a4r_sasrec_block_bwd(void* stream, const a4r_sasrec_block_t* b, const float* x, const float* log_mask, const float* dy, float* dx,

@@ -507,6 +507,11 @@ def _sasrec_block_fn(d, x, log_mask, T):
     def ln(vv, g, b):
         mu = vv.mean(-1, keepdim=True)
         return (vv - mu) * torch.rsqrt(((vv - mu) ** 2).mean(-1, keepdim=True) + d['eps']) * g + b
+    if d.get('mode', 0) == 1:                      # SASRecPfeifferAdaptedSelfOutput (model.py:458-471)
+        x1 = ln(xx + h, d['ln1_g'], d['ln1_b'])
+        va = torch.relu(x1 @ d['w1'].t() + d['b1']) @ d['w2'].t() + d['b2'] + x1
+        t = ln(va, d['ln2_g'], d['ln2_b'])
+        return ln(adapter(t, '2') + va, d['ln3_g'], d['ln3_b']).reshape(B * T, E)
     x1 = ln(xx + adapter(h, '1'), d['ln1_g'], d['ln1_b'])
     h2 = torch.relu(x1 @ d['w1'].t() + d['b1']) @ d['w2'].t() + d['b2']
     return ln(x1 + adapter(h2, '2'), d['ln2_g'], d['ln2_b']).reshape(B * T, E)
@@ -519,7 +524,7 @@ def sasrec_block(desc, x, log_mask, out, n_users, T, train, dy=None):
         with torch.no_grad():
             out[:n] = _sasrec_block_fn(desc, x[:n], log_mask[:n_users], T)
         return
-    names = ('wd1', 'bd1', 'wu1', 'bu1', 'wd2', 'bd2', 'wu2', 'bu2')
+    names = ('wd1', 'bd1', 'wu1', 'bu1', 'wd2', 'bd2', 'wu2', 'bu2') + (('ln3_g', 'ln3_b') if desc.get('mode', 0) == 1 else ())
     with torch.enable_grad():                       # (called from inside an autograd Function's backward: grad mode is off there)
         leaf = {k: desc[k].detach().clone().requires_grad_(True) for k in names}
         xin = x[:n].detach().clone().requires_grad_(True)
@@ -529,7 +534,7 @@ def sasrec_block(desc, x, log_mask, out, n_users, T, train, dy=None):
     dd = desc['d']
     for k, g in zip(names, grads[1:]):
         g = g.detach() if g is not None else None
-        tgt = desc['g_' + k]
+        tgt = desc.get('g_' + k)
         if tgt is None or g is None:
             continue
         if k.startswith('wd'):

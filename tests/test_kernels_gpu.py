@@ -1145,7 +1145,7 @@ def test_gemm_fp8_output_row_scale_chain():
     assert float(err.max()) < 0.15 and float(err.mean()) < 0.08, (float(err.max()), float(err.mean()))
 
 
-def _sasrec_case(d, act, inner, seed, B=6, T=20):
+def _sasrec_case(d, act, inner, seed, B=6, T=20, mode=0):
     g = torch.Generator().manual_seed(seed)
     r = lambda *s, sc=1.0: (torch.randn(*s, generator=g) * sc).to(dev())
     desc = dict(wqkv=r(192, 64, sc=0.15), wfc=r(64, 64, sc=0.15), w1=r(256, 64, sc=0.15), b1=r(256, sc=0.1), w2=r(64, 256, sc=0.08), b2=r(64, sc=0.1),
@@ -1158,6 +1158,8 @@ def _sasrec_case(d, act, inner, seed, B=6, T=20):
         desc.update({'wd' + k: wd, 'bd' + k: bd, 'wu' + k: wu, 'bu' + k: r(64, sc=0.1)})
         desc.update({'g_wd' + k: torch.zeros(64, 64, device=dev()), 'g_wu' + k: torch.zeros(64, 64, device=dev()),
                      'g_bd' + k: torch.zeros(64, device=dev()), 'g_bu' + k: torch.zeros(64, device=dev())})
+    if mode == 1:                                                # Pfeiffer form: a third, trainable LayerNorm
+        desc.update(mode=1, ln3_g=1 + r(64, sc=0.1), ln3_b=r(64, sc=0.1), g_ln3_g=torch.zeros(64, device=dev()), g_ln3_b=torch.zeros(64, device=dev()))
     x = r(B * T, 64)
     mask = torch.ones(B, T, device=dev())
     for u, pad in enumerate((0, 11, 19, 5, 0, 17)[:B]):
@@ -1165,14 +1167,14 @@ def _sasrec_case(d, act, inner, seed, B=6, T=20):
     return desc, x, mask, r(B * T, 64)
 
 
-@pytest.mark.parametrize('d,act,inner', [(16, 1, True), (16, 3, False), (24, 2, True), (32, 1, True)])
-def test_sasrec_block_vs_torch(d, act, inner):
+@pytest.mark.parametrize('d,act,inner,mode', [(16, 1, True, 0), (16, 3, False, 0), (24, 2, True, 0), (32, 1, True, 0), (16, 1, False, 1), (16, 4, False, 1)])
+def test_sasrec_block_vs_torch(d, act, inner, mode):
     """a4r_sasrec_block_fwd / _bwd (one launch per block) vs the same block in torch autograd (tests/sim_lib.py restates
     modules.py:45-87 + model.py:341-376): output, input gradient and the eight adapter gradients, fp32."""
     import sim_lib
     from adapter4rec_amd import _lib as L
     B, T = 6, 20
-    desc, x, mask, dy = _sasrec_case(d, act, inner, seed=40 + d + act)
+    desc, x, mask, dy = _sasrec_case(d, act, inner, seed=40 + d + act, mode=mode)
     y = torch.zeros_like(x)
     L.sasrec_block(desc, x, mask, y, B, T, False)
     cpu = lambda t: t.detach().cpu() if torch.is_tensor(t) else t
@@ -1187,7 +1189,7 @@ def test_sasrec_block_vs_torch(d, act, inner):
     L.sasrec_block(desc, x, mask, dx, B, T, False, dy=dy)
     sim_lib.sasrec_block(dc, cpu(x), cpu(mask), dx_ref, B, T, False, dy=cpu(dy))
     close(dx, dx_ref, torch.float32, 'sasrec block dx', atol32=1e-4, rtol32=1e-4)
-    for k in ('wd1', 'bd1', 'wu1', 'bu1', 'wd2', 'bd2', 'wu2', 'bu2'):
+    for k in (('wd2', 'bd2', 'wu2', 'bu2', 'ln3_g', 'ln3_b') if mode == 1 else ('wd1', 'bd1', 'wu1', 'bu1', 'wd2', 'bd2', 'wu2', 'bu2')):
         ref = dc['g_' + k]
         close(desc['g_' + k], ref, torch.float32, 'sasrec block g_' + k, atol32=1e-4 * float(ref.abs().max()) + 1e-6, rtol32=1e-4)
         if k.startswith('wd'):
@@ -1196,12 +1198,13 @@ def test_sasrec_block_vs_torch(d, act, inner):
             assert float(desc['g_' + k][:, d:].abs().max()) == 0.0
 
 
-def test_sasrec_block_dropout_is_consistent():
+@pytest.mark.parametrize('mode', [0, 1])
+def test_sasrec_block_dropout_is_consistent(mode):
     """train = 1: the masks are a pure function of (seed, site, element) -- two forwards agree bit for bit, another seed differs, and the
     backward differentiates the forward WITH its masks (directional derivative of the kernel's own forward)."""
     from adapter4rec_amd import _lib as L
     B, T = 6, 20
-    desc, x, mask, dy = _sasrec_case(16, 1, True, seed=77)
+    desc, x, mask, dy = _sasrec_case(16, 1, mode == 0, seed=77, mode=mode)
     desc.update(drop_attn=0.1, drop_hidden=0.1)
     y0, y1, y2 = (torch.zeros_like(x) for _ in range(3))
     L.sasrec_block(desc, x, mask, y0, B, T, True)
