@@ -103,24 +103,53 @@ class _Lora:
     every step (so forward and dgrad cost nothing extra); the low-rank gradients come from four skinny products in backward:
     t = x A^T, dt = (dq B) s, dB = dq^T t s, dA = dt^T x."""
 
-    def __init__(self, mod, width, eng, dt, slot):
+    SHARE = _os.environ.get('A4R_LORA_SHARE', '1') != '0'
+
+    def __init__(self, mod, width, eng, dt, slot, share=None):
+        """share = (dict, off): this LoRA is one of a block's two small-rank ones (r <= 16: the image tower's q, v at r = 8).  They then use
+        ONE [64, width] A operand (rank rows at off .. off + r), ONE t = x A^T and ONE dA = dt^T x launch; only the products that read
+        this projection's own gradient (dt = dq B, dB = dq^T t, the bias sum) stay per LoRA.  The rank was padded to 64 columns anyway."""
         self.mod, self.slot, self.width = mod, slot, width
         self.r, self.rp, self.scaling = mod.r, pad_to(mod.r, 64), float(mod.scaling)
         dev = eng.dev
         self.g_bias = eng.grad_view(mod.bias) if mod.bias is not None else None
         self.g_W = None
+        self.share = None
         if self.r == 0:                  # loralib: r = 0 leaves a plain Linear whose weight stays trainable (CV run_adapter.py:394)
             self.g_W = eng.grad_view(mod.weight)
             return
-        self.A = torch.zeros(self.rp, width, dtype=dt, device=dev)        # lora_A [r, in]        (NT operand of t = x A^T)
+        self.g_A, self.g_B = eng.grad_view(mod.lora_A), eng.grad_view(mod.lora_B)
         self.BT = torch.zeros(self.rp, width, dtype=dt, device=dev)       # lora_B^T [r, out]     (NT operand of dt = dq B)
+        self.s_B = eng.scratch(width, self.rp)
+        if share is not None:
+            sh, off = share
+            self.share, self.off = sh, off
+            if 'A' not in sh:
+                sh['A'] = torch.zeros(self.rp, width, dtype=dt, device=dev)
+                sh['s_A'] = eng.scratch(self.rp, width)
+            self.A, self.s_A = sh['A'], sh['s_A']
+            eng.add_pack(mod.lora_A, sh['A'][off:off + 16], False)                   # rows off .. off + r (zero-padded to 16)
+            eng.add_pack(mod.lora_B, self.BT[off:off + 16], True)                    # B^T at the same rank rows: dt lands in columns off .. off + r
+            eng.add_corner(self.s_B[:, off:off + 16], mod.lora_B, width, self.r, alpha=self.scaling)
+            eng.add_corner(sh['s_A'][off:off + 16], mod.lora_A, self.r, width)
+            return
+        self.A = torch.zeros(self.rp, width, dtype=dt, device=dev)        # lora_A [r, in]        (NT operand of t = x A^T)
         eng.add_pack(mod.lora_A, self.A, False)
         eng.add_pack(mod.lora_B, self.BT, True)
-        self.g_A, self.g_B = eng.grad_view(mod.lora_A), eng.grad_view(mod.lora_B)
         self.s_A = eng.scratch(self.rp, width)
-        self.s_B = eng.scratch(width, self.rp)
         eng.add_corner(self.s_B, mod.lora_B, width, self.r, alpha=self.scaling)      # dB = (dq^T t) s
         eng.add_corner(self.s_A, mod.lora_A, self.r, width)
+
+    @classmethod
+    def for_block(cls, lins, width, eng, dt):
+        """The _Lora objects of a block's (query, key, value) projections; two small-rank ones share their A-side launches."""
+        idx = [i for i, lin in enumerate(lins) if type(lin).__name__ == 'LoRALinear']
+        small = [i for i in idx if 0 < lins[i].r <= 16]
+        share = {} if (cls.SHARE and len(small) == 2 and len(idx) == 2) else None
+        out = []
+        for i in idx:
+            out.append(cls(lins[i], width, eng, dt, i, share=(share, 16 * small.index(i)) if share is not None else None))
+        return out
 
     def merged(self):
         m = self.mod
@@ -558,12 +587,10 @@ class TransRecEngine:
         for i, layer in enumerate(bert.encoder.layer):
             b = _Block()
             att = layer.attention.self
-            b.lora = []
-            for slot, lin in enumerate((att.query, att.key, att.value)):
-                if type(lin).__name__ == 'LoRALinear':
-                    b.lora.append(_Lora(lin, H, self, self.T, slot))
-                elif type(lin).__name__ != 'Linear':
+            for lin in (att.query, att.key, att.value):
+                if type(lin).__name__ not in ('LoRALinear', 'Linear'):
                     raise NotImplementedError(f'projection module {type(lin).__name__}')
+            b.lora = _Lora.for_block((att.query, att.key, att.value), H, self, self.T)
             b.H, b.F, b.nh, b.dh, b.S = H, self.F, nh, H // nh, self.S
             b.causal, b.mask_neg, b.scale = False, FMIN, 1.0 / math.sqrt(H // nh)
             b.ffn_act = L.ACT_GELU
@@ -697,12 +724,10 @@ class TransRecEngine:
             raise NotImplementedError(f'transformer block geometry width={Hv} heads={nh} S={S}')
         b = _Block()
         b.long = long
-        b.lora = []
-        for slot, lin in enumerate((mha.w_Q, mha.w_K, mha.w_V)):
-            if type(lin).__name__ == 'LoRALinear':
-                b.lora.append(_Lora(lin, Hv, self, dt, slot))
-            elif type(lin).__name__ != 'Linear':
+        for lin in (mha.w_Q, mha.w_K, mha.w_V):
+            if type(lin).__name__ not in ('LoRALinear', 'Linear'):
                 raise NotImplementedError(f'projection module {type(lin).__name__}')
+        b.lora = _Lora.for_block((mha.w_Q, mha.w_K, mha.w_V), Hv, self, dt)
         if b.lora and H != Hv:
             raise NotImplementedError('LoRA on a zero-padded block')
         b.H, b.Hv, b.F, b.nh, b.dh, b.S = H, Hv, F, nh, dh, S
@@ -1009,6 +1034,33 @@ class TransRecEngine:
         self._adapter_wgrads(ad, dv, z, dzp, h, M)
         return dh, dv
 
+    def _lora_backward_all(self, blk, dqkv, x, M):
+        """Low-rank gradients of every LoRA of a block.  Two small-rank LoRAs (the image tower's q, v) share the launches that read x:
+        t = x [A_q ; A_v]^T once, dt = (dq B_q + dv B_v) s accumulated into one [M, 64] buffer, dA = dt^T x once, the two dB = d.^T t
+        products in one a4r_gemm_tn2 launch -- 7 launches and 2 passes over x instead of 10 and 4."""
+        sh = blk.lora[0].share if blk.lora else None
+        if sh is None or any(lo.share is not sh for lo in blk.lora):
+            for lo in blk.lora:
+                self._lora_backward(blk, lo, dqkv, x, M)
+            return
+        H, T = blk.H, blk.T
+        a, b = blk.lora
+        dqa, dqb = dqkv[:, a.slot * H:(a.slot + 1) * H], dqkv[:, b.slot * H:(b.slot + 1) * H]
+        for lo, dq in ((a, dqa), (b, dqb)):
+            if lo.g_bias is not None:
+                L.colsum(dq, lo.g_bias(), M=M)
+        t = self._buf('lora_t', M, 64, T)
+        dt = self._buf('lora_dt', M, 64, T)
+        L.gemm_nt(x, sh['A'], t, M=M)                                  # t[:, off .. off + r] per LoRA
+        L.gemm_nt(dqa, a.BT, dt, alpha=a.scaling, M=M)                 # dt = (dq B_q) s        (columns 0 .. r)
+        L.gemm_nt(dqb, b.BT, dt, alpha=b.scaling, R1=dt, M=M)          #    + (dv B_v) s        (columns 16 .. 16 + r)
+        if TN2 and T == torch.bfloat16 and M % 64 == 0:
+            L.gemm_tn2(dqa, t, a.s_B, dqb, t, b.s_B, M=M)              # dB_. = d.^T t (the corner of its own rank columns is flushed)
+        else:
+            L.gemm_tn(dqa, t, a.s_B, M=M)
+            L.gemm_tn(dqb, t, b.s_B, M=M)
+        L.gemm_tn(dt, x, sh['s_A'], M=M)                               # dA rows off .. off + r per LoRA
+
     def _lora_backward(self, blk, lo, dqkv, x, M):
         H, T = blk.H, blk.T
         dq = dqkv[:, lo.slot * H:(lo.slot + 1) * H]
@@ -1117,8 +1169,7 @@ class TransRecEngine:
         else:
             L.attn_bwd(bufs['qkv'], dctx, dqkv, key_mask, n_items, blk.S, blk.nh, blk.dh, 0, H, 2 * H, blk.causal, blk.scale, blk.mask_neg,
                        drop_p=pa, drop_site=blk.site, drop_seed=seed)
-        for lo in blk.lora:
-            self._lora_backward(blk, lo, dqkv, bufs['xin'], M)
+        self._lora_backward_all(blk, dqkv, bufs['xin'], M)
         for sl, d in enumerate(blk.qkv):
             self._dense_wgrad(d, dqkv[:, sl * H:(sl + 1) * H], bufs.get('xin'), M)
         if dx_in is not None:

@@ -76,12 +76,10 @@ class ViTRecEngine(TransRecEngine):
         for i, layer in enumerate(enc_mod.layer):
             b = _Block()
             att = layer.attention.attention
-            b.lora = []
-            for slot, lin in enumerate((att.query, att.key, att.value)):
-                if type(lin).__name__ == 'LoRALinear':
-                    b.lora.append(_Lora(lin, H, self, self.T, slot))
-                elif type(lin).__name__ != 'Linear':
+            for lin in (att.query, att.key, att.value):
+                if type(lin).__name__ not in ('LoRALinear', 'Linear'):
                     raise NotImplementedError(f'projection module {type(lin).__name__}')
+            b.lora = _Lora.for_block((att.query, att.key, att.value), H, self, self.T)
             b.H, b.F, b.nh, b.dh, b.S = H, self.F, nh, 64, self.S
             b.scale = 1.0 / math.sqrt(64)
             b.wqkv = torch.zeros(3 * H, H, dtype=self.T, device=self.dev)
@@ -380,8 +378,7 @@ class ViTRecEngine(TransRecEngine):
         dqkv = self._buf_tail0('dqkv', M, 3 * H, T, n_items * blk.S)       # attn_long_bwd writes the real token rows only
         ws = self._buf('attn_ws', bufs['lse'].shape[0], 1, torch.float32)
         L.attn_long_bwd(bufs['qkv'], bufs['ctx_o'], dctx, dqkv, bufs['lse'], ws, n_items, blk.S, blk.nh, blk.dh, 0, H, 2 * H, blk.scale)
-        for lo in blk.lora:
-            self._lora_backward(blk, lo, dqkv, bufs['n1'], M)
+        self._lora_backward_all(blk, dqkv, bufs['n1'], M)
         for sl, d in enumerate(blk.qkv):
             self._dense_wgrad(d, dqkv[:, sl * H:(sl + 1) * H], bufs.get('n1'), M)
         if dx_in is not None or ln_a:
