@@ -1169,7 +1169,8 @@ class TransRecEngine:
         else:
             L.attn_bwd(bufs['qkv'], dctx, dqkv, key_mask, n_items, blk.S, blk.nh, blk.dh, 0, H, 2 * H, blk.causal, blk.scale, blk.mask_neg,
                        drop_p=pa, drop_site=blk.site, drop_seed=seed)
-        self._lora_backward_all(blk, dqkv, bufs['xin'], M)
+        if blk.lora:
+            self._lora_backward_all(blk, dqkv, bufs['xin'], M)
         for sl, d in enumerate(blk.qkv):
             self._dense_wgrad(d, dqkv[:, sl * H:(sl + 1) * H], bufs.get('xin'), M)
         if dx_in is not None:

@@ -378,7 +378,8 @@ class ViTRecEngine(TransRecEngine):
         dqkv = self._buf_tail0('dqkv', M, 3 * H, T, n_items * blk.S)       # attn_long_bwd writes the real token rows only
         ws = self._buf('attn_ws', bufs['lse'].shape[0], 1, torch.float32)
         L.attn_long_bwd(bufs['qkv'], bufs['ctx_o'], dctx, dqkv, bufs['lse'], ws, n_items, blk.S, blk.nh, blk.dh, 0, H, 2 * H, blk.scale)
-        self._lora_backward_all(blk, dqkv, bufs['n1'], M)
+        if blk.lora:
+            self._lora_backward_all(blk, dqkv, bufs['n1'], M)
         for sl, d in enumerate(blk.qkv):
             self._dense_wgrad(d, dqkv[:, sl * H:(sl + 1) * H], bufs.get('n1'), M)
         if dx_in is not None or ln_a:
