@@ -12,7 +12,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('A4R_LIB_PATH') or os.path.join(_HERE, 'liba4r_hip.so')    # A4R_LIB_PATH: A/B builds (tools/), same C ABI
 
-ABI_VERSION = 304          # = A4R_ABI_VERSION of include/a4r.h (tests/test_abi_cpu.py compares the two)
+ABI_VERSION = 305          # = A4R_ABI_VERSION of include/a4r.h (tests/test_abi_cpu.py compares the two)
 BF16, F32, FP8 = 0, 1, 2
 ACT_NONE, ACT_RELU, ACT_GELU, ACT_GELU_TANH, ACT_LEAKY = 0, 1, 2, 3, 4
 DACT_MUL = 15
@@ -186,20 +186,21 @@ def adapter_ln_fwd(A, R1, R2, Wd, bd, Wu, bu, gamma, beta, eps, act, zp, z, v, y
     assert y is not None or y8 is not None
     _check(lib().a4r_adapter_ln_fwd(_stream(), _p(A), C.c_int(_ld(A)), _p(R1), C.c_int(_ld(R1)), _p(R2), C.c_int(_ld(R2) if R2 is not None else 0),
                                     _p(Wd), _p(bd), _p(Wu), _p(bu), _p(gamma), _p(beta), C.c_float(eps), C.c_int(act),
-                                    _p(zp), _p(z), _p(v), C.c_int(_ld(v)), _p(y), C.c_int(_ld(y) if y is not None else 0), _p(stats),
+                                    _p(zp), _p(z), _p(v), C.c_int(_ld(v) if v is not None else 0), _p(y), C.c_int(_ld(y) if y is not None else 0), _p(stats),
                                     C.c_int(M), C.c_int(A.shape[1]), C.c_int(Wd.shape[0]), C.c_int(_dt(A)),
                                     _p(y8), C.c_int(_ld(y8) if y8 is not None else 0), _p(ys)), 'a4r_adapter_ln_fwd')
 
 
 def adapter_ln_bwd(dy, v, stats, gamma, dres, zp, act, WuT, WdT, inner_res, dv, dzp, dh, dgamma=None, dbeta=None, dbias=None, M=None,
-                   drop_p=0.0, drop_site=0, drop_seed=0, dbd=None, bias_total=False):
+                   drop_p=0.0, drop_site=0, drop_seed=0, dbd=None, bias_total=False, beta_y=None):
+    """beta_y: the forward kept y = LN(v) instead of v (called with v=None); `v` is that y and xhat is rebuilt as (y - beta_y) / gamma."""
     require_gpu(dy, v, dv, dh)
     M = dy.shape[0] if M is None else M
     _check(lib().a4r_adapter_ln_bwd(_stream(), _p(dy), C.c_int(_ld(dy)), _p(v), C.c_int(_ld(v)), _p(stats), _p(gamma),
                                     _p(dres), C.c_int(_ld(dres) if dres is not None else 0), _p(zp), C.c_int(act), _p(WuT), _p(WdT),
                                     C.c_int(int(inner_res)), _p(dv), C.c_int(_ld(dv)), _p(dzp), _p(dh), C.c_int(_ld(dh)),
                                     _p(dgamma), _p(dbeta), _p(dbias), C.c_int(M), C.c_int(dy.shape[1]), C.c_int(WuT.shape[0]), C.c_int(_dt(dy)),
-                                    C.c_float(drop_p), C.c_uint32(drop_site), C.c_uint64(drop_seed), _p(dbd), C.c_int(int(bias_total))), 'a4r_adapter_ln_bwd')
+                                    C.c_float(drop_p), C.c_uint32(drop_site), C.c_uint64(drop_seed), _p(dbd), C.c_int(int(bias_total)), _p(beta_y)), 'a4r_adapter_ln_bwd')
 
 
 def sasrec_block(desc, x, log_mask, out, n_users, T, train, dy=None):

@@ -204,7 +204,7 @@ __global__ void __launch_bounds__(NW * 64) adapter_ln_fwd_kernel(const AdFwdArgs
                 vv[s][j] = x;
             }
             const uint4 pk = Elem<bf16_t>::pack(vv[s]);
-            *reinterpret_cast<uint4*>(p.v + row * p.ldv + cl + s * 32) = pk;
+            if (p.v) *reinterpret_cast<uint4*>(p.v + row * p.ldv + cl + s * 32) = pk;      // (null: backward rebuilds xhat from y, see FY below)
             Elem<bf16_t>::unpack(pk, vv[s]);
 #pragma unroll
             for (int j = 0; j < 8; ++j) s1 += vv[s][j];
@@ -268,7 +268,7 @@ __global__ void __launch_bounds__(NW * 64) adapter_ln_fwd_kernel(const AdFwdArgs
 
 struct AdBwdArgs {
     const bf16_t* dy; const bf16_t* v; const bf16_t* dres; int lddy, ldv, lddres;
-    const float* stats; const float* gamma;
+    const float* stats; const float* gamma; const float* beta;      // beta != null (FY): `v` holds y = LN(v), xhat = (y - beta) / gamma
     const bf16_t* zp; int act;
     const bf16_t* WuT; const bf16_t* WdT; int inner_res;
     bf16_t* dv; bf16_t* dzp; bf16_t* dh; int lddv, lddh;
@@ -287,7 +287,9 @@ struct AdBwdArgs {
 #ifndef A4R_AD_ABL
 #define A4R_AD_ABL 0          /* timing-only diagnostic builds (-DA4R_AD_ABL=n): 1 no tile stores, 2 no tile loads */
 #endif
-template <int CW, int NW, bool WGB, bool WDB, bool DRES>
+// FY: the forward did not keep v (the LayerNorm's input sum) but only y = LN(v), which the next GEMM reads anyway: xhat = (y - beta) / gamma
+// per column (1 / gamma and -beta / gamma sit in LDS next to gamma), rstd from the saved statistics -- 62 MB less written per forward launch.
+template <int CW, int NW, bool WGB, bool WDB, bool DRES, bool FY = false>
 __global__ void __launch_bounds__(NW * 64) adapter_ln_bwd_kernel(const AdBwdArgs p) {
     constexpr int KS = CW / 32, H = CW * NW, NT = NW * 64, EPT = 1024 / NT;
     __shared__ __attribute__((aligned(16))) float zpart[NW][16][ZLD];
@@ -300,6 +302,10 @@ __global__ void __launch_bounds__(NW * 64) adapter_ln_bwd_kernel(const AdBwdArgs
     const int c0 = wave * CW;
     const int cl = c0 + kg * 8;
     for (int c = tid; c < H; c += NT) par[c] = p.gamma[c];
+    __shared__ __attribute__((aligned(16))) float par_fy[FY ? 2 : 1][FY ? H : 4];      // 1 / gamma, -beta / gamma
+    if constexpr (FY) {
+        for (int c = tid; c < H; c += NT) { const float ig = 1.f / p.gamma[c]; par_fy[0][c] = ig; par_fy[1][c] = -p.beta[c] * ig; }
+    }
 
     // dz = dv . Wu (contraction over H: WuT [64, H]) keeps its fragments in registers; dh = dzp . Wd (contraction over 64:
     // WdT [H, 64]) keeps them in LDS in fragment order (a wave's private 2 KS x 2 KiB, read back as conflict-free
@@ -371,9 +377,16 @@ __global__ void __launch_bounds__(NW * 64) adapter_ln_bwd_kernel(const AdBwdArgs
             Elem<bf16_t>::unpack(cur.v[s], xh[s]);
             *reinterpret_cast<float4*>(ga8) = *reinterpret_cast<const float4*>(&par[cl + s * 32]);
             *reinterpret_cast<float4*>(ga8 + 4) = *reinterpret_cast<const float4*>(&par[cl + s * 32 + 4]);
+            float ig8[8], ib8[8];
+            if constexpr (FY) {
+                *reinterpret_cast<float4*>(ig8) = *reinterpret_cast<const float4*>(&par_fy[0][cl + s * 32]);
+                *reinterpret_cast<float4*>(ig8 + 4) = *reinterpret_cast<const float4*>(&par_fy[0][cl + s * 32 + 4]);
+                *reinterpret_cast<float4*>(ib8) = *reinterpret_cast<const float4*>(&par_fy[1][cl + s * 32]);
+                *reinterpret_cast<float4*>(ib8 + 4) = *reinterpret_cast<const float4*>(&par_fy[1][cl + s * 32 + 4]);
+            }
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
-                const float x = (xh[s][j] - mean) * rstd;
+                const float x = FY ? fmaf(xh[s][j], ig8[j], ib8[j]) : (xh[s][j] - mean) * rstd;
                 if constexpr (WGB) { sg[s][j] += d8[j] * x; sb[s][j] += d8[j]; }
                 const float gg = d8[j] * ga8[j];
                 xh[s][j] = x;
@@ -528,6 +541,13 @@ int launch_fwd(hipStream_t s, const AdFwdArgs& a, int grid) {
 template <int CW, int NW, bool DRES>
 int launch_bwd_d(hipStream_t s, const AdBwdArgs& a, int grid) {
     const bool wgb = a.dgamma || a.dbeta, wdb = a.dbias != nullptr;
+    if (a.beta) {                                  // xhat from y: instantiated for the frozen-LayerNorm post-LN form the text tower runs
+        if constexpr (!DRES) {
+            if (!wgb && wdb) { hipLaunchKernelGGL((adapter_ln_bwd_kernel<CW, NW, false, true, false, true>), dim3(grid), dim3(NW * 64), 0, s, a); return a4r_launch_status(); }
+            if (!wgb && !wdb) { hipLaunchKernelGGL((adapter_ln_bwd_kernel<CW, NW, false, false, false, true>), dim3(grid), dim3(NW * 64), 0, s, a); return a4r_launch_status(); }
+        }
+        return A4R_EINVAL;
+    }
     if (wgb && wdb) hipLaunchKernelGGL((adapter_ln_bwd_kernel<CW, NW, true, true, DRES>), dim3(grid), dim3(NW * 64), 0, s, a);
     else if (wgb) hipLaunchKernelGGL((adapter_ln_bwd_kernel<CW, NW, true, false, DRES>), dim3(grid), dim3(NW * 64), 0, s, a);
     else if (wdb) hipLaunchKernelGGL((adapter_ln_bwd_kernel<CW, NW, false, true, DRES>), dim3(grid), dim3(NW * 64), 0, s, a);
@@ -548,10 +568,10 @@ extern "C" int a4r_adapter_ln_fwd(void* stream, const void* A, int lda, const vo
                                   const float* gamma, const float* beta, float eps, int act,
                                   void* zp, void* z, void* v, int ldv, void* y, int ldy, float* stats, int M, int H, int d, int dtype,
                                   void* y8, int ld8, float* ys) {
-    if (!A || !R1 || !Wd || !bd || !Wu || !bu || !gamma || !beta || !zp || !z || !v || (!y && !y8) || !stats) return A4R_EINVAL;
+    if (!A || !R1 || !Wd || !bd || !Wu || !bu || !gamma || !beta || !zp || !z || (!v && !y) || (!y && !y8) || !stats) return A4R_EINVAL;      // v may be null when y is kept
     if (y8 && (!ys || ld8 % 8 || ld8 < H || (reinterpret_cast<uintptr_t>(y8) & 7u))) return A4R_EINVAL;
     if (dtype != A4R_BF16 || d != 64 || M <= 0 || M % 16) return A4R_EINVAL;
-    if (lda % 8 || ldr1 % 8 || (R2 && ldr2 % 8) || ldv % 8 || (y && ldy % 8)) return A4R_EINVAL;
+    if (lda % 8 || ldr1 % 8 || (R2 && ldr2 % 8) || (v && ldv % 8) || (y && ldy % 8)) return A4R_EINVAL;
     if (misaligned16(A) || misaligned16(R1) || misaligned16(R2) || misaligned16(Wd) || misaligned16(Wu) || misaligned16(v) || misaligned16(y) ||
         misaligned16(zp) || misaligned16(z) || (reinterpret_cast<uintptr_t>(stats) & 7u))
         return A4R_EINVAL;
@@ -583,7 +603,8 @@ extern "C" int a4r_adapter_ln_fwd(void* stream, const void* A, int lda, const vo
 extern "C" int a4r_adapter_ln_bwd(void* stream, const void* dy, int lddy, const void* v, int ldv, const float* stats, const float* gamma,
                                   const void* dres, int lddres, const void* zp, int act, const void* WuT, const void* WdT, int inner_res,
                                   void* dv, int lddv, void* dzp, void* dh, int lddh, float* dgamma, float* dbeta, float* dbias,
-                                  int M, int H, int d, int dtype, float drop_p, uint32_t drop_site, uint64_t drop_seed, float* dbd, int flags) {
+                                  int M, int H, int d, int dtype, float drop_p, uint32_t drop_site, uint64_t drop_seed, float* dbd, int flags,
+                                  const float* beta_y) {
     if (!dy || !v || !stats || !gamma || !zp || !WuT || !WdT || !dv || !dzp || !dh) return A4R_EINVAL;
     if (dtype != A4R_BF16 || d != 64 || M <= 0 || M % 16) return A4R_EINVAL;
     if (lddy % 8 || ldv % 8 || (dres && lddres % 8) || lddv % 8 || lddh % 8) return A4R_EINVAL;
@@ -592,7 +613,7 @@ extern "C" int a4r_adapter_ln_bwd(void* stream, const void* dy, int lddy, const 
         return A4R_EINVAL;
     AdBwdArgs a{};
     a.dy = reinterpret_cast<const bf16_t*>(dy); a.v = reinterpret_cast<const bf16_t*>(v); a.dres = reinterpret_cast<const bf16_t*>(dres);
-    a.lddy = lddy; a.ldv = ldv; a.lddres = lddres; a.stats = stats; a.gamma = gamma;
+    a.lddy = lddy; a.ldv = ldv; a.lddres = lddres; a.stats = stats; a.gamma = gamma; a.beta = beta_y;
     a.zp = reinterpret_cast<const bf16_t*>(zp); a.act = act;
     a.WuT = reinterpret_cast<const bf16_t*>(WuT); a.WdT = reinterpret_cast<const bf16_t*>(WdT); a.inner_res = inner_res;
     a.dv = reinterpret_cast<bf16_t*>(dv); a.dzp = reinterpret_cast<bf16_t*>(dzp); a.dh = reinterpret_cast<bf16_t*>(dh);

@@ -835,6 +835,23 @@ class TransRecEngine:
         return self.q8_deriv and blk.T == torch.bfloat16 and getattr(blk, 'ffn_act', L.ACT_GELU) == L.ACT_GELU and blk.F % 16 == 0
 
     Q8_TILED = _os.environ.get('A4R_Q8_TILED', '1') != '0'
+    VSKIP = _os.environ.get('A4R_VSKIP', '1') != '0'
+
+    def _vskip(self, blk, which):
+        """Sub-layer `which` of a post-LN block keeps y = LN(v) per layer (the tensor the next GEMM reads anyway) instead of v, and the fused
+        adapter backward rebuilds xhat = (y - beta) / gamma: 62 MB less written per fused forward launch at B = 32.  Needs the one-launch
+        kernels (bf16, serial Houlsby / Compacter placement), a frozen LayerNorm and |gamma| bounded away from 0."""
+        ad, pl, ln = (blk.ad1, blk.pl1, blk.ln1) if which == '1' else (blk.ad2, blk.pl2, blk.ln2)
+        if not self.VSKIP or ad is None or pl != 'serial' or hasattr(blk, 'lnA') or blk.T != torch.bfloat16:
+            return False
+        if not (self.fuse_adapters and getattr(blk, 'Hv', blk.H) == blk.H and blk.H in (128, 256, 512, 768) and ad.dp == 64):
+            return False
+        if ln.g_gamma is not None or ln.g_beta is not None:
+            return False
+        key = '_vskip_ok' + which
+        if not hasattr(blk, key):
+            setattr(blk, key, bool(float(ln.gamma.detach().abs().min()) > 1e-3))
+        return getattr(blk, key)
 
     def _q8t(self, blk, M):
         """The 8-bit derivative tensor in the 256-tile kernel's own order (a4r_gemm_t.q8_tiled): only its writer (FFN-up) and its reader
@@ -861,12 +878,13 @@ class TransRecEngine:
         if blk.train_dense and not shared:           # inputs of attention.output.dense and output.dense (weight gradients)
             d['ctx_s'] = self._buf(pre + '.ctx_s', M, H, T)
             d['u_s'] = self._buf(pre + '.u_s', M, F, T)
+        keep_y = not shared and Mc is None        # (training buffers of a full-row layer: the CLS-only last layer keeps v)
         d['h1'] = self._buf(pre + '.h1', M, H, T)
-        d['v1'] = self._buf(pre + '.v1', M, H, T)
+        d['y1' if keep_y and self._vskip(blk, '1') else 'v1'] = self._buf(pre + '.v1', M, H, T)
         d['st1'] = self._buf(pre + '.st1', M, 2, torch.float32)
         d['upre'] = self._buf(pre + '.upre', M, F, torch.uint8 if self._q8(blk) else T)
         d['h2'] = self._buf(pre + '.h2', M, H, T)
-        d['v2'] = self._buf(pre + '.v2', M, H, T)
+        d['y2' if keep_y and self._vskip(blk, '2') else 'v2'] = self._buf(pre + '.v2', M, H, T)
         d['st2'] = self._buf(pre + '.st2', M, 2, torch.float32)
         for k, ad, pl in (('1', blk.ad1, blk.pl1), ('2', blk.ad2, blk.pl2)):
             if ad is not None:
@@ -887,7 +905,8 @@ class TransRecEngine:
     # ------------------------------------------------------------------ one block, forward
     def _sub_forward(self, blk, which, dense_in, w, bias, resid, ln, ad, pl, lnn, bufs, M, p_drop, site, seed, out):
         """dense -> dropout -> [adapter] -> LN(residual + .)  for the attention-output (which='1') or FFN-output ('2') half."""
-        h, v, st = bufs['h' + which], bufs['v' + which], bufs['st' + which]
+        h, v, st = bufs['h' + which], bufs.get('v' + which), bufs['st' + which]        # v None: this sub-layer keeps y (`out` IS bufs['y' + which])
+        assert v is not None or out.data_ptr() == bufs['y' + which].data_ptr()
         if ad is None:
             L.gemm_nt(dense_in, w, v, bias=bias, R1=resid, drop_p=p_drop, drop_site=site, drop_seed=seed, drop_first=True, M=M)
             L.ln_fwd(self._vc(blk, v), ln.gamma, ln.beta, ln.eps, self._vc(blk, out), st, M=M)
@@ -957,6 +976,10 @@ class TransRecEngine:
             L.gather_rows(ctx, bufs['ctx_s'], M, 1)
         x1 = self._buf('x1', M, H, T)
         x1 = bufs['x1s'] if 'x1s' in bufs else x1
+        if 'y1' in bufs:                           # kept per layer: backward rebuilds xhat from it (_vskip)
+            if 'x1s' in bufs:
+                raise RuntimeError('y1 and x1s are the same tensor: one of them should not have been allocated')
+            x1 = bufs['y1']
         self._sub_forward(blk, '1', ctx, blk.wo, blk.bo, x, blk.ln1, blk.ad1, blk.pl1, blk.lnn1, bufs, M, ph, blk.site + 1, seed, x1)
         u = bufs['u_s'] if 'u_s' in bufs else self._buf('u', M, blk.F, T)
         L.gemm_nt(x1, blk.wi, u, bias=blk.bi, C2=bufs['upre'], act=blk.ffn_act, c2_deriv='q8' if self._q8(blk) else True, M=M,      # 'upre' holds act'(pre)
@@ -968,7 +991,10 @@ class TransRecEngine:
         """Backward of _sub_forward.  Returns (d_dense_out, d_resid): gradient wrt the dense output (already through
         its dropout mask) and wrt the residual input.  Writes adapter / LN parameter gradients."""
         T, H = blk.T, blk.H
-        v, st = bufs['v' + which], bufs['st' + which]
+        v, st = bufs.get('v' + which), bufs['st' + which]
+        beta_y = None
+        if v is None:                                    # the forward kept y = LN(v) instead (see _vskip)
+            v, beta_y = bufs['y' + which], ln.beta
         gg = lambda f: f() if f is not None else None
         self._wgrad_join()                               # dzp / dv are about to be overwritten
         if ad is None:
@@ -1013,9 +1039,10 @@ class TransRecEngine:
             # ONE launch: LayerNorm backward, dzp = (dv Wu) * act'(zp), dh = mask * (dzp Wd [+ dv]) (a4r_adapter_fused.hip)
             L.adapter_ln_bwd(dy, v, st, ln.gamma, None, zp, ad.act, ad.wuT, ad.wdT, ad.kind != 'compacter', dv, dzp, dh,
                              dgamma=gg(ln.g_gamma), dbeta=gg(ln.g_beta), dbias=gg(ad.g_bu), M=M,
-                             drop_p=p_drop, drop_site=site, drop_seed=seed, dbd=self._bd_target(ad))
+                             drop_p=p_drop, drop_site=site, drop_seed=seed, dbd=self._bd_target(ad), beta_y=beta_y)
             self._adapter_wgrads(ad, dv, z, dzp, h, M, bd_done=self._bd_target(ad) is not None)
             return dh, dv
+        assert beta_y is None, 'a sub-layer that keeps y instead of v runs the fused backward only'
         L.ln_bwd(dy, v, st, ln.gamma, dv, M=M, dgamma=gg(ln.g_gamma), dbeta=gg(ln.g_beta), dbias=gg(ad.g_bu))
         L.gemm_nt(dv, ad.wuT, dzp, Pre=zp, dact=ad.act, M=M)
         if pl == 'parallel':
@@ -1254,6 +1281,7 @@ class TransRecEngine:
                    stats_out=self._buf('emb_st', M, 2, torch.float32) if keep else None, key_mask_out=key_mask)
         self._news = news
         other = self._buf('xb', M, H, self.T)
+        xa_buf = x
         Ip = pad_to(n_items, 128)
         cls = self._buf('cls', Ip, H, self.T)
         last = len(self.bert_blocks) - 1
@@ -1262,9 +1290,14 @@ class TransRecEngine:
             bufs = saved[i] if saved is not None else self._block_bufs('bert.shared', blk, M, True, Mc=Ip if cmode else None)
             if cmode:
                 self._block_forward(blk, x, key_mask, n_items, M, bufs, train, seed, cls, cls_rows=Ip)
+            elif 'y2' in bufs:                     # the layer's output is kept per layer (backward reads it, _vskip): no ping-pong
+                self._block_forward(blk, x, key_mask, n_items, M, bufs, train, seed, bufs['y2'])
+                x = bufs['y2']
             else:
-                self._block_forward(blk, x, key_mask, n_items, M, bufs, train, seed, other)
-                x, other = other, x
+                out = other if x.data_ptr() != other.data_ptr() else xa_buf       # a transient buffer that is not the current input (x may be a kept y2)
+                self._block_forward(blk, x, key_mask, n_items, M, bufs, train, seed, out)
+                x = out
+            if not cmode:
                 if (i + 1) in self.bert_klist and i != last:
                     self._buf(f'khs{i + 1}', M, H, self.T).copy_(x)      # hidden_states[i + 1], read by a K-Adapter below
         if self.bert_kads:

@@ -36,7 +36,7 @@ extern "C" {
 
 /* ABI version: bumped whenever a signature or struct below changes.  The Python binding (adapter4rec_amd/_lib.py) refuses a
  * library whose a4r_version() differs, so an A/B build made before a signature change cannot be called with shifted arguments. */
-#define A4R_ABI_VERSION 304
+#define A4R_ABI_VERSION 305
 int a4r_version(void);
 
 /* C[M,N] = epilogue(alpha * A[M,K] . B[N,K]^T): every nn.Linear on the path (HF BertSelfAttention
@@ -155,7 +155,9 @@ int a4r_adapter_ln_fwd(void* stream, const void* A, int lda, const void* R1, int
 int a4r_adapter_ln_bwd(void* stream, const void* dy, int lddy, const void* v, int ldv, const float* stats, const float* gamma,
                        const void* dres, int lddres, const void* zp, int act, const void* WuT, const void* WdT, int inner_res,
                        void* dv, int lddv, void* dzp, void* dh, int lddh, float* dgamma, float* dbeta, float* dbias,
-                       int M, int H, int d, int dtype, float drop_p, uint32_t drop_site, uint64_t drop_seed, float* dbd, int flags);
+                       int M, int H, int d, int dtype, float drop_p, uint32_t drop_site, uint64_t drop_seed, float* dbd, int flags,
+                       const float* beta_y);      /* beta_y != NULL: the forward was called with v = NULL and `v` here is its y = LN(v): xhat = (y - beta_y) / gamma
+                                                   * (post-LN form with frozen LayerNorm, no dres; min |gamma| is the caller's responsibility) */
 
 /* Short-sequence self-attention, one wave per (item, head), S <= 32, dh in {32, 64}.
  * BERT layer: HF BertSelfAttention (called from model/encoders.py:53); SASRec: SelfAttention

@@ -109,8 +109,9 @@ def adapter_ln_fwd(A, R1, R2, Wd, bd, Wu, bu, gamma, beta, eps, act, zp, z, v, y
     zz = _act(p, act).to(z.dtype)
     z[:M] = zz
     vv = zz.float() @ Wu.float().t() + bu + R1[:M].float() + (R2[:M].float() if R2 is not None else 0)
-    v[:M] = vv.to(v.dtype)
-    vq = v[:M].float()
+    vq = vv.to(A.dtype).float()               # (the kernel's statistics are those of the bf16-rounded sum, stored or not)
+    if v is not None:
+        v[:M] = vv.to(v.dtype)
     mu = vq.mean(-1, keepdim=True)
     rstd = torch.rsqrt(((vq - mu) ** 2).mean(-1, keepdim=True) + eps)
     stats[:M, 0] = mu[:, 0]
@@ -123,11 +124,22 @@ def adapter_ln_fwd(A, R1, R2, Wd, bd, Wu, bu, gamma, beta, eps, act, zp, z, v, y
 
 
 def adapter_ln_bwd(dy, v, stats, gamma, dres, zp, act, WuT, WdT, inner_res, dv, dzp, dh, dgamma=None, dbeta=None, dbias=None, M=None,
-                   drop_p=0.0, drop_site=0, drop_seed=0, dbd=None, bias_total=False):
-    """a4r_adapter_ln_bwd = ln_bwd | (dv Wu) * act'(zp) | dzp Wd (+ dv), with the kernel's bf16 storage points."""
+                   drop_p=0.0, drop_site=0, drop_seed=0, dbd=None, bias_total=False, beta_y=None):
+    """a4r_adapter_ln_bwd = ln_bwd | (dv Wu) * act'(zp) | dzp Wd (+ dv), with the kernel's bf16 storage points.
+    beta_y: `v` is y = LN(v) (the forward did not keep v): xhat = (y - beta_y) / gamma."""
     assert drop_p == 0.0
     M = dy.shape[0] if M is None else M
-    ln_bwd(dy, v, stats, gamma, dv, M=M, dgamma=dgamma, dbeta=dbeta, dbias=None if bias_total else dbias, dres=dres)
+    if beta_y is not None:
+        assert dres is None and dgamma is None and dbeta is None
+        xh = (v[:M].float() - beta_y) / gamma
+        rstd = stats[:M, 1:2]
+        dx = dy[:M].float() * gamma
+        g = rstd * (dx - dx.mean(-1, keepdim=True) - xh * (dx * xh).mean(-1, keepdim=True))
+        if dbias is not None:
+            dbias += g.sum(0)
+        dv[:M] = g.to(dv.dtype)
+    else:
+        ln_bwd(dy, v, stats, gamma, dv, M=M, dgamma=dgamma, dbeta=dbeta, dbias=None if bias_total else dbias, dres=dres)
     dq = dv[:M].float()
     if bias_total and dbias is not None:
         dbias += dq.sum(0)

@@ -1262,3 +1262,50 @@ def test_gemm_q8_tiled_layout_roundtrip(M, N, K):
     tile_rm = d0[tm * 256:(tm + 1) * 256, tn * 256:(tn + 1) * 256].flatten()
     tile_t = d1.flatten()[(tm * (N // 256) + tn) * 65536:(tm * (N // 256) + tn + 1) * 65536]
     assert torch.equal(torch.sort(tile_rm)[0], torch.sort(tile_t)[0])
+
+
+@pytest.mark.parametrize('H', [256, 768])
+@pytest.mark.parametrize('act,inner,sums,drop', [(1, True, 'b', 0.1), (3, False, '', 0.0)])
+def test_adapter_ln_bwd_from_y(H, act, inner, sums, drop):
+    """beta_y: the forward kept only y = LN(v) (a4r_adapter_ln_fwd with v = NULL) and the backward rebuilds xhat = (y - beta) / gamma.
+    Against the v-based launch on the same sub-layer: xhat differs by y's bf16 rounding only."""
+    from adapter4rec_amd import _lib as L
+    M, Mp, dp, t = 16 * 301, 16 * 304, 64, torch.bfloat16
+    A, R, Wd, Wu, bd, bu, gamma, beta = _adapter_case(H, Mp, seed=220)
+    mk = lambda c: torch.zeros(Mp, c, dtype=t, device=dev())
+    zp, z, v, y, y_only = mk(dp), mk(dp), mk(H), mk(H), mk(H)
+    st, st2 = torch.zeros(Mp, 2, device=dev()), torch.zeros(Mp, 2, device=dev())
+    r1, r2 = (A, R) if inner else (R, None)
+    L.adapter_ln_fwd(A, r1, r2, Wd, bd, Wu, bu, gamma, beta, 1e-12, act, zp, z, v, y, st, M=M)
+    zp2, z2 = mk(dp), mk(dp)
+    L.adapter_ln_fwd(A, r1, r2, Wd, bd, Wu, bu, gamma, beta, 1e-12, act, zp2, z2, None, y_only, st2, M=M)        # v not stored
+    assert torch.equal(y, y_only) and torch.equal(st, st2) and torch.equal(zp, zp2)
+    dy = rnd(Mp, H, dtype=t, seed=231)
+    WuT, WdT = Wu.t().contiguous(), Wd.t().contiguous()
+    outs = []
+    for src, by in ((v, None), (y, beta)):
+        dv, dzp, dh = mk(H), mk(dp), mk(H)
+        dbi = torch.zeros(H, device=dev()) if 'b' in sums else None
+        dbd = torch.zeros(dp, device=dev()) if 'b' in sums else None
+        L.adapter_ln_bwd(dy, src, st, gamma, None, zp, act, WuT, WdT, inner, dv, dzp, dh, dbias=dbi, M=M, drop_p=drop, drop_site=9, drop_seed=4242,
+                         dbd=dbd, beta_y=by)
+        outs.append((dv, dzp, dh, dbi, dbd))
+    (dv0, dz0, dh0, b0, d0), (dv1, dz1, dh1, b1, d1) = outs
+    # torch fp32 from the UNROUNDED LayerNorm input is the common reference: both launches sit within bf16 rounding of it
+    vf = v.float()[:M]
+    mean, rstd = st[:M, 0:1], st[:M, 1:2]
+    xh = (vf - mean) * rstd
+    gq = dy[:M].float() * gamma
+    dv_r = rstd * (gq - gq.mean(-1, keepdim=True) - xh * (gq * xh).mean(-1, keepdim=True))
+    e0, e1 = float((dv0[:M].float() - dv_r).abs().max()), float((dv1[:M].float() - dv_r).abs().max())
+    scale = float(dv_r.abs().max())
+    print(f'H={H}: dv error vs fp32 torch: from v {e0 / scale:.2e}, from y {e1 / scale:.2e} (of max |dv| {scale:.3f})')
+    assert e1 < 3.0 * e0 + 2e-2 * scale
+    close(dv1[:M], dv0[:M], t, 'dv from y vs from v', rtol16=3e-2, atol16=2e-2 * scale)
+    close(dz1[:M], dz0[:M], t, 'dzp from y vs from v', rtol16=5e-2, atol16=3e-2 * float(dz0.float().abs().max()))
+    if drop:
+        assert torch.equal(dh0[:M] == 0, dh1[:M] == 0)
+    close(dh1[:M], dh0[:M], t, 'dh from y vs from v', rtol16=5e-2, atol16=3e-2 * float(dh0.float().abs().max()))
+    if b0 is not None:
+        close(b1, b0, torch.float32, 'dbias', atol32=3e-2 * max(1.0, float(b0.abs().max())), rtol32=3e-2)
+        close(d1, d0, torch.float32, 'dbd', atol32=3e-2 * max(1.0, float(d0.abs().max())), rtol32=3e-2)
