@@ -12,7 +12,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('A4R_LIB_PATH') or os.path.join(_HERE, 'liba4r_hip.so')    # A4R_LIB_PATH: A/B builds (tools/), same C ABI
 
-ABI_VERSION = 305          # = A4R_ABI_VERSION of include/a4r.h (tests/test_abi_cpu.py compares the two)
+ABI_VERSION = 306          # = A4R_ABI_VERSION of include/a4r.h (tests/test_abi_cpu.py compares the two)
 BF16, F32, FP8 = 0, 1, 2
 ACT_NONE, ACT_RELU, ACT_GELU, ACT_GELU_TANH, ACT_LEAKY = 0, 1, 2, 3, 4
 DACT_MUL = 15
@@ -25,7 +25,7 @@ EXPORTS = [
     'a4r_version', 'a4r_gemm_nt', 'a4r_gemm_tn', 'a4r_gemm_tn2', 'a4r_colsum', 'a4r_attn_fwd', 'a4r_attn_bwd', 'a4r_embed_ln',
     'a4r_ln_fwd', 'a4r_ln_bwd', 'a4r_gather_rows', 'a4r_scatter_rows', 'a4r_act_bwd_f32', 'a4r_score_bce_fwd',
     'a4r_score_bce_bwd', 'a4r_emb_grad_add_inputs', 'a4r_take_inputs', 'a4r_adam_step', 'a4r_pack_matrices',
-    'a4r_eval_rank', 'a4r_dropout_apply', 'a4r_gemm_variant', 'a4r_adapter_ln_fwd', 'a4r_adapter_ln_bwd', 'a4r_ln_fwd_fp8', 'a4r_quant_rows_fp8', 'a4r_lora_merge', 'a4r_phm_build', 'a4r_phm_bwd', 'a4r_unpack_add', 'a4r_memset_zero',
+    'a4r_eval_rank', 'a4r_dropout_apply', 'a4r_gemm_variant', 'a4r_adapter_ln_fwd', 'a4r_adapter_ln_bwd', 'a4r_ln_fwd_fp8', 'a4r_quant_rows_fp8', 'a4r_lora_merge', 'a4r_lora_merge_batch', 'a4r_phm_build', 'a4r_phm_bwd', 'a4r_unpack_add', 'a4r_memset_zero',
     'a4r_sasrec_block_fwd', 'a4r_sasrec_block_bwd', 'a4r_scatter_rows_fill', 'a4r_attn_long_fwd', 'a4r_attn_long_bwd', 'a4r_patchify', 'a4r_vit_assemble', 'a4r_resample_u8', 'a4r_embed_bwd',
 ]
 
@@ -413,6 +413,26 @@ def lora_merge(W, A, B, scaling, dst, dstT, r):
     _check(lib().a4r_lora_merge(_stream(), _p(W), _p(A) if r else C.c_void_p(0), _p(B) if r else C.c_void_p(0), C.c_float(scaling),
                                 _p(dst), C.c_int(_ld(dst)), _p(dstT), C.c_int(_ld(dstT)), C.c_int(out_f), C.c_int(in_f), C.c_int(r),
                                 C.c_int(_dt(dst))), 'a4r_lora_merge')
+
+
+class LoraDesc(C.Structure):
+    _fields_ = [('W', C.c_void_p), ('A', C.c_void_p), ('B', C.c_void_p), ('dst', C.c_void_p), ('dstT', C.c_void_p),
+                ('scaling', C.c_float), ('ld', C.c_int32), ('ldT', C.c_int32), ('out_f', C.c_int32), ('in_f', C.c_int32), ('r', C.c_int32)]
+
+
+def lora_table(entries, device):
+    """entries: (W, A, B, scaling, dst, dstT, r) per projection (the arguments of lora_merge) -> (device table, n, max elements, dtype code)."""
+    descs = []
+    for W, A, B, s, dst, dstT, r in entries:
+        assert W.dtype == torch.float32 and W.is_contiguous() and (r == 0 or (A.is_contiguous() and B.is_contiguous())) and _dt(dst) == _dt(entries[0][4])
+        descs.append(LoraDesc(W.data_ptr(), A.data_ptr() if r else 0, B.data_ptr() if r else 0, dst.data_ptr(), dstT.data_ptr(), float(s),
+                              _ld(dst), _ld(dstT), W.shape[0], W.shape[1], int(r)))
+    return desc_table(descs, device), len(descs), max(W.numel() for W, *_ in entries), _dt(entries[0][4])
+
+
+def lora_merge_batch(tab):
+    t, n, mx, code = tab
+    _check(lib().a4r_lora_merge_batch(_stream(), _p(t), C.c_int(n), C.c_int(mx), C.c_int(code)), 'a4r_lora_merge_batch')
 
 
 def desc_table(entries, device):

@@ -104,6 +104,7 @@ class _Lora:
     t = x A^T, dt = (dq B) s, dB = dq^T t s, dA = dt^T x."""
 
     SHARE = _os.environ.get('A4R_LORA_SHARE', '1') != '0'
+    ONES_COL = 32            # (shared form: rank columns 0 - 7 and 16 - 23 are in use)
 
     def __init__(self, mod, width, eng, dt, slot, share=None):
         """share = (dict, off): this LoRA is one of a block's two small-rank ones (r <= 16: the image tower's q, v at r = 8).  They then use
@@ -132,6 +133,13 @@ class _Lora:
             eng.add_pack(mod.lora_B, self.BT[off:off + 16], True)                    # B^T at the same rank rows: dt lands in columns off .. off + r
             eng.add_corner(self.s_B[:, off:off + 16], mod.lora_B, width, self.r, alpha=self.scaling)
             eng.add_corner(sh['s_A'][off:off + 16], mod.lora_A, self.r, width)
+            # the bias gradient (column sums of this projection's gradient) rides in the dB product: column ONES_COL of t is a column of
+            # ones (a bias of the t = x A^T launch: row ONES_COL of A is zero), so (dq^T t)[:, ONES_COL] = sum over rows of dq
+            if 'ones' not in sh:
+                sh['ones'] = torch.zeros(self.rp, dtype=torch.float32, device=dev)
+                sh['ones'][self.ONES_COL] = 1.0
+            if self.g_bias is not None:
+                eng.add_corner(self.s_B[:, self.ONES_COL:self.ONES_COL + 1], mod.bias, width, 1)
             return
         self.A = torch.zeros(self.rp, width, dtype=dt, device=dev)        # lora_A [r, in]        (NT operand of t = x A^T)
         eng.add_pack(mod.lora_A, self.A, False)
@@ -480,11 +488,18 @@ class TransRecEngine:
         """Refresh the kernel-side copies of the trainable matrices (call after every optimiser step)."""
         for tab, n, mx, c in self._tabs:
             L.pack_matrices(self.flat_p, tab, n, mx, c)
-        for blk in self.bert_blocks + self.sas_blocks:        # LoRA: re-merge W + B A / r into the packed qkv operand (a4r_lora_merge)
-            for lo in blk.lora:
-                H, sl, m = blk.H, lo.slot, lo.mod
-                L.lora_merge(m.weight.data, m.lora_A.data if lo.r else None, m.lora_B.data if lo.r else None, lo.scaling,
-                             blk.wqkv[sl * H:(sl + 1) * H], blk.wqkvT[:, sl * H:(sl + 1) * H], lo.r)
+        # LoRA: re-merge W + B A / r into the packed qkv operands -- every LoRA-carrying projection of a dtype in one launch (a4r_lora_merge_batch)
+        if getattr(self, '_lora_tabs', None) is None:
+            groups = {}
+            for blk in self.bert_blocks + self.sas_blocks:
+                for lo in blk.lora:
+                    H, sl, m = blk.H, lo.slot, lo.mod
+                    groups.setdefault(blk.wqkv.dtype, []).append(
+                        (m.weight.data, m.lora_A.data if lo.r else None, m.lora_B.data if lo.r else None, lo.scaling,
+                         blk.wqkv[sl * H:(sl + 1) * H], blk.wqkvT[:, sl * H:(sl + 1) * H], lo.r))
+            self._lora_tabs = [L.lora_table(ents, self.dev) for ents in groups.values()]
+        for tab in self._lora_tabs:
+            L.lora_merge_batch(tab)
         if self._virtual:
             if self._phm_tab is not None:                     # Compacter: effective matrices from (phm_rule, W_left, W_right), one launch
                 L.phm_build(self.flat_p, self._phm_tab, self._phm_n, self._virt_flat)
@@ -1064,7 +1079,8 @@ class TransRecEngine:
     def _lora_backward_all(self, blk, dqkv, x, M):
         """Low-rank gradients of every LoRA of a block.  Two small-rank LoRAs (the image tower's q, v) share the launches that read x:
         t = x [A_q ; A_v]^T once, dt = (dq B_q + dv B_v) s accumulated into one [M, 64] buffer, dA = dt^T x once, the two dB = d.^T t
-        products in one a4r_gemm_tn2 launch -- 7 launches and 2 passes over x instead of 10 and 4."""
+        products in one a4r_gemm_tn2 launch, and the two bias gradients come out of that launch too (a column of ones in t) -- 5 launches and
+        2 passes over x instead of 10 and 4."""
         sh = blk.lora[0].share if blk.lora else None
         if sh is None or any(lo.share is not sh for lo in blk.lora):
             for lo in blk.lora:
@@ -1073,12 +1089,9 @@ class TransRecEngine:
         H, T = blk.H, blk.T
         a, b = blk.lora
         dqa, dqb = dqkv[:, a.slot * H:(a.slot + 1) * H], dqkv[:, b.slot * H:(b.slot + 1) * H]
-        for lo, dq in ((a, dqa), (b, dqb)):
-            if lo.g_bias is not None:
-                L.colsum(dq, lo.g_bias(), M=M)
         t = self._buf('lora_t', M, 64, T)
         dt = self._buf('lora_dt', M, 64, T)
-        L.gemm_nt(x, sh['A'], t, M=M)                                  # t[:, off .. off + r] per LoRA
+        L.gemm_nt(x, sh['A'], t, bias=sh['ones'], M=M)                 # t[:, off .. off + r] per LoRA; t[:, ONES_COL] = 1 (bias gradients, see _Lora)
         L.gemm_nt(dqa, a.BT, dt, alpha=a.scaling, M=M)                 # dt = (dq B_q) s        (columns 0 .. r)
         L.gemm_nt(dqb, b.BT, dt, alpha=b.scaling, R1=dt, M=M)          #    + (dv B_v) s        (columns 16 .. 16 + r)
         if TN2 and T == torch.bfloat16 and M % 64 == 0:

@@ -36,7 +36,7 @@ extern "C" {
 
 /* ABI version: bumped whenever a signature or struct below changes.  The Python binding (adapter4rec_amd/_lib.py) refuses a
  * library whose a4r_version() differs, so an A/B build made before a signature change cannot be called with shifted arguments. */
-#define A4R_ABI_VERSION 305
+#define A4R_ABI_VERSION 306
 int a4r_version(void);
 
 /* C[M,N] = epilogue(alpha * A[M,K] . B[N,K]^T): every nn.Linear on the path (HF BertSelfAttention
@@ -323,6 +323,13 @@ typedef struct {
 typedef struct { const float* src; int64_t dst_off; int32_t rows, cols, ld; float alpha; } a4r_add_desc_t;
 int a4r_lora_merge(void* stream, const float* W, const float* A, const float* B, float scaling,
                    void* dst, int ld, void* dstT, int ldT, int out_f, int in_f, int r, int dtype);
+/* The same for n_desc projections in ONE launch (every LoRA of the model; device table of descriptors, all destinations of one dtype);
+ * max_elems = the largest out_f * in_f. */
+typedef struct {
+    const float* W; const float* A; const float* B; void* dst; void* dstT;
+    float scaling; int32_t ld, ldT, out_f, in_f, r;
+} a4r_lora_desc_t;
+int a4r_lora_merge_batch(void* stream, const a4r_lora_desc_t* desc_dev, int n_desc, int max_elems, int dtype);
 int a4r_phm_build(void* stream, const float* params, const a4r_phm_desc_t* desc_dev, int n_desc, float* eff);
 int a4r_phm_bwd(void* stream, const float* params, const a4r_phm_desc_t* desc_dev, int n_desc, float* grads);
 int a4r_unpack_add(void* stream, float* target, const a4r_add_desc_t* desc_dev, int n_desc, int max_elems);

@@ -363,6 +363,15 @@ def lora_merge(W, A, B, scaling, dst, dstT, r):
     dstT.copy_(w.t().to(dstT.dtype))
 
 
+def lora_table(entries, device):
+    return list(entries)
+
+
+def lora_merge_batch(tab):
+    for W, A, B, s, dst, dstT, r in tab:
+        lora_merge(W, A, B, s, dst, dstT, r)
+
+
 def _phm_E(params, d):
     n, ip, oq = d.n, d.in_f // d.n, d.out_f // d.n
     rule = params[d.rule_off:d.rule_off + n ** 3].view(n, n, n)
