@@ -55,7 +55,7 @@ struct PhmDesc {      // mirrors a4r_phm_desc_t
     int32_t in_f, out_f, n, pad_;
 };
 
-// E[b * oq + q][a * ip + p] = sum_k rule[k][a][b] Wl[k][p] Wr[k][q]            one workgroup per PHMLinear
+// E[b * oq + q][a * ip + p] = sum_k rule[k][a][b] Wl[k][p] Wr[k][q]            gridDim.y workgroups per PHMLinear
 __global__ void __launch_bounds__(256) phm_build_kernel(const float* __restrict__ params, const PhmDesc* __restrict__ desc, float* __restrict__ eff) {
     const PhmDesc d = desc[blockIdx.x];
     const int n = d.n, ip = d.in_f / n, oq = d.out_f / n;
@@ -64,7 +64,7 @@ __global__ void __launch_bounds__(256) phm_build_kernel(const float* __restrict_
     const float* wr = params + d.wr_off;
     float* E = eff + d.out_off;
     const int total = d.in_f * d.out_f;
-    for (int e = threadIdx.x; e < total; e += 256) {
+    for (int e = blockIdx.y * 256 + threadIdx.x; e < total; e += 256 * gridDim.y) {      // (gridDim.y workgroups share a PHMLinear: one alone took 103 us for 52 of them)
         const int o = e / d.in_f, i = e % d.in_f;
         const int b = o / oq, q = o % oq, a = i / ip, p = i % ip;
         float acc = 0.f;
@@ -158,14 +158,14 @@ extern "C" int a4r_lora_merge_batch(void* stream, const a4r_lora_desc_t* desc_de
 
 extern "C" int a4r_phm_build(void* stream, const float* params, const a4r_phm_desc_t* desc_dev, int n_desc, float* eff) {
     if (!params || !desc_dev || n_desc <= 0 || !eff) return A4R_EINVAL;
-    hipLaunchKernelGGL(phm_build_kernel, dim3(n_desc), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), params,
+    hipLaunchKernelGGL(phm_build_kernel, dim3(n_desc, 8), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), params,
                        reinterpret_cast<const PhmDesc*>(desc_dev), eff);
     return a4r_launch_status();
 }
 
 extern "C" int a4r_phm_bwd(void* stream, const float* params, const a4r_phm_desc_t* desc_dev, int n_desc, float* grads) {
     if (!params || !desc_dev || n_desc <= 0 || !grads) return A4R_EINVAL;
-    hipLaunchKernelGGL(phm_bwd_kernel, dim3(n_desc, 16), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), params,
+    hipLaunchKernelGGL(phm_bwd_kernel, dim3(n_desc, 56), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), params,      // 896 outputs of a [64, 768] PHMLinear = 4 per wave
                        reinterpret_cast<const PhmDesc*>(desc_dev), grads);
     return a4r_launch_status();
 }
