@@ -276,6 +276,7 @@ int a4r_gemm_nt_skinny64(hipStream_t s, const a4r_gemm_t& g); // a4r_gemm_skinny
 int a4r_gemm_nt_skinnyk(hipStream_t s, const a4r_gemm_t& g);  // a4r_gemm_skinny.hip (K == 64, bf16: the adapter up-projections)
 static int run_256(hipStream_t s, const a4r_gemm_t& g);
 int a4r_cu_count();                                          // a4r_gemm256.hip: CU count rounded down to a multiple of 8
+extern "C" int a4r_gemm_tail_plan(int M, int N, int* p_full, int* kp);   // a4r_gemm256.hip: 1 = the launch cuts its last partial round into short tiles
 
 static int run_256(hipStream_t s, const a4r_gemm_t& g) { return a4r_gemm_nt_256(s, g); }
 
@@ -338,7 +339,11 @@ extern "C" int a4r_gemm_nt(void* stream, const a4r_gemm_t* gp) {
         // (measured 505 vs 454, 735 vs 624, 774 vs 637 TF/s at M = 10240; the large tile wins from 198 tiles on)
         if (tiles * 2 <= ncu && g_variant == 2) goto small_tiles;
         // (measured on the ViT step: 194 vs 190 user-seq/s with the split applied at every K against long K only)
-        if (tiles > ncu && rem > 0 && rem * 4 <= ncu && rem % ntn == 0 && g_variant < 4) {
+        int pf_ = 0, kp_ = 0;
+        if (a4r_gemm_tail_plan(g.M, g.N, &pf_, &kp_)) {       // the partial round runs as short tiles inside the same launch
+            const int rc = run_256(s, g);
+            if (rc != 1) return rc;
+        } else if (tiles > ncu && rem > 0 && rem * 4 <= ncu && rem % ntn == 0 && g_variant < 4) {
             const int64_t head_rows = (int64_t)(ntm - rem / ntn) * 256;
             a4r_gemm_t g1 = g, g2 = g;
             g1.M = (int)head_rows;

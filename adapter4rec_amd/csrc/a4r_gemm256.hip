@@ -103,12 +103,27 @@ A4R_DEV f32x4_t mma_mx8(const uint4& a0, const uint4& a1, const uint4& b0, const
     return __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(a, b, c, 0, 0, 0, 0x7F7F7F7F, 0, 0x7F7F7F7F);
 }
 
-template <typename TI, typename TO, int ACT, int DACT, int EF>
-__global__ void __launch_bounds__(512, 2) gemm_nt_256_kernel(const a4r_gemm_t p, int ntm, int ntn, int gn_flags, uint32_t thr16, float keep_scale) {
+// DMA source offsets (bytes from a short tile's first row) of unit row ul of the A_lo / A_hi units: half (ul >> 6) owns rows half * 16 kp + local,
+// local = ul & 63 (+ 64 in A_hi); unit rows whose local row is past 16 kp are fetched from the tile's first row (valid memory, never used).
+A4R_DEV void tail_a_offsets(int ul, int c, int kp, int lda_bytes, uint32_t& lo, uint32_t& hi) {
+    const int half = ul >> 6, loc = ul & 63, act = 16 * kp;
+    lo = (uint32_t)((loc < act ? half * act + loc : 0) * lda_bytes + c * 16);
+    hi = (uint32_t)((loc + 64 < act ? half * act + loc + 64 : 0) * lda_bytes + c * 16);
+}
+
+// The tiles of one workgroup.  TAIL = false: the full 256 x 256 tiles of the persistent tile map (ntm row panels).  TAIL = true: ONE short tile of
+// 32 * t_kp rows (t_kp = 1..7 MFMA row tiles per wave instead of 8) at row t_row0, column panel t_tn -- the rows past the last full ROUND of
+// 256-row tiles are cut into short tiles, one per CU, so that every CU finishes together instead of 0 < f < 1 of the CUs running a whole
+// extra tile (launch256 below).  A short tile uses the same LDS images, unit stream and phases; wave half wm owns rows
+// t_row0 + wm * 16 t_kp + [0, 16 t_kp): unit rows past 16 t_kp of a half are DMA'd from the tile's first row (never used), the MFMA
+// segments run the first t_kp row tiles only and the epilogue leaves after row t_kp - 1.  The non-TAIL instantiation puts the first six
+// units of the workgroup's short tile in flight at the start of its last epilogue (t_ready).
+template <typename TI, typename TO, int ACT, int DACT, int EF, bool TAIL>
+A4R_DEV void gemm256_tiles(const a4r_gemm_t& p, char* lds, int ntm, int ntn, int gn_flags, uint32_t thr16, float keep_scale,
+                           const int t_row0, const int t_tn, const int t_kp, bool& t_ready) {
     const int gn = gn_flags & 0xffff;                     // band width of the tile map; bit 16: A4R_GEMM_NO_STREAM=1 (A/B switch)
     constexpr int ROWB = 128;
     constexpr int KT = ROWB / (int)sizeof(TI);
-    __shared__ __attribute__((aligned(16))) char lds[8 * UNIT_BYTES];      // [buffer 2][unit 4][128 rows][128 B]
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 2, wn = wave & 3;
@@ -145,8 +160,8 @@ __global__ void __launch_bounds__(512, 2) gemm_nt_256_kernel(const a4r_gemm_t p,
     };
     int t_loc = blockIdx.x >> 3;
     A4R_TL(0)
-    if (t_loc >= len_x) return;
-    {   // Staggered start (gn_flags >> 17 = delay in 10-ns ticks, A4R_GEMM_STAGGER = percent of a tile period, default 30, 0 = off):
+    if (!TAIL && t_loc >= len_x) return;
+    if constexpr (!TAIL) {   // Staggered start (gn_flags >> 17 = delay in 10-ns ticks, A4R_GEMM_STAGGER = percent of a tile period, default 30, 0 = off):
         // workgroups that own one tile fewer than the busiest of their XCD have a tile period of slack; started late, their epilogue
         // store bursts fall into the other workgroups' K loops instead of on top of their bursts (tools/gemm_timeline.py: the K loop of
         // the N = 2304 launch 18.6 -> 16.3 us per tile).  Same-box step: -1.5 % on the slower boxes of the pool, neutral on the fastest.
@@ -158,15 +173,18 @@ __global__ void __launch_bounds__(512, 2) gemm_nt_256_kernel(const a4r_gemm_t p,
             while (__builtin_amdgcn_s_memrealtime() < t_end) __builtin_amdgcn_s_sleep(8);
         }
     }
-    int tm, tn;
-    tile_of(t_loc, tm, tn);
+    int tm = 0, tn = t_tn;
+    if constexpr (!TAIL) tile_of(t_loc, tm, tn);
+    // short tile: rows per wave half, active MFMA row tiles in the A_lo / A_hi phases
+    const int hrow = TAIL ? 16 * t_kp : 128;
+    const int kp_lo = t_kp < 4 ? t_kp : 4, kp_hi = t_kp - 4;
 
     const int lda = p.lda, ldb = p.ldb;
     const int nk = p.K / KT;
     __builtin_assume(nk >= 1);                            // (host-checked; without it the accumulators count as live across the K loop and the epilogue copies every one before its in-place lane swap)
     const TI* Ap = reinterpret_cast<const TI*>(p.A);
     const TI* Bp = reinterpret_cast<const TI*>(p.B);
-    const char* Abase = reinterpret_cast<const char*>(Ap + (size_t)tm * 256 * lda);
+    const char* Abase = reinterpret_cast<const char*>(Ap + (size_t)(TAIL ? t_row0 : tm * 256) * lda);
     const char* Bbase = reinterpret_cast<const char*>(Bp + (size_t)tn * 256 * ldb);
     const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)lds;
 
@@ -180,6 +198,7 @@ __global__ void __launch_bounds__(512, 2) gemm_nt_256_kernel(const a4r_gemm_t p,
         const int rb = ul + (ul >> 5) * 32;                              // B_lo tile row; B_hi = + 32
         offA_lo[i] = (uint32_t)(ra * lda * (int)sizeof(TI) + c * 16);
         offA_hi[i] = (uint32_t)((ra + 64) * lda * (int)sizeof(TI) + c * 16);
+        if constexpr (TAIL) tail_a_offsets(ul, c, t_kp, lda * (int)sizeof(TI), offA_lo[i], offA_hi[i]);
         offB_lo[i] = (uint32_t)(rb * ldb * (int)sizeof(TI) + c * 16);
         offB_hi[i] = (uint32_t)((rb + 32) * ldb * (int)sizeof(TI) + c * 16);
     }
@@ -212,8 +231,20 @@ __global__ void __launch_bounds__(512, 2) gemm_nt_256_kernel(const a4r_gemm_t p,
 #ifndef A4R_FP8_MX
 #define A4R_FP8_MX 1
 #endif
-#define A4R_MFMA16(ax_, bx_, m0_, n0_)                                                                \
-    if constexpr (sizeof(TI) == 1 && A4R_FP8_MX) {                                                    \
+#define A4R_MFMA16(ax_, bx_, m0_, n0_, lim_)                                                          \
+    if constexpr (TAIL) {              /* short tile: the first lim_ row tiles of this phase's half */  \
+        _Pragma("unroll") for (int mi = 0; mi < 4; ++mi) {                                            \
+            if (mi >= (lim_)) break;                                                                  \
+            if constexpr (sizeof(TI) == 1 && A4R_FP8_MX) {                                            \
+                _Pragma("unroll") for (int ni = 0; ni < 2; ++ni)                                      \
+                    acc[(m0_) + mi][(n0_) + ni] = mma_mx8(bx_[ni][0], bx_[ni][1], ax_[mi][0], ax_[mi][1], acc[(m0_) + mi][(n0_) + ni]); \
+            } else {                                                                                  \
+                _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                      \
+                    _Pragma("unroll") for (int ni = 0; ni < 2; ++ni)                                  \
+                        Mma<TI>::mma(bx_[ni][ks], ax_[mi][ks], acc[(m0_) + mi][(n0_) + ni]);          \
+            }                                                                                         \
+        }                                                                                             \
+    } else if constexpr (sizeof(TI) == 1 && A4R_FP8_MX) {                                             \
         _Pragma("unroll") for (int mi = 0; mi < 4; ++mi)                                              \
             _Pragma("unroll") for (int ni = 0; ni < 2; ++ni)                                          \
                 acc[(m0_) + mi][(n0_) + ni] = mma_mx8(bx_[ni][0], bx_[ni][1], ax_[mi][0], ax_[mi][1], acc[(m0_) + mi][(n0_) + ni]); \
@@ -231,7 +262,7 @@ __global__ void __launch_bounds__(512, 2) gemm_nt_256_kernel(const a4r_gemm_t p,
 #ifndef A4R_ABL
 #define A4R_ABL 0          /* timing-only diagnostic builds (tools/gemm_abl.sh): 1 no DMA, 2 no MFMA, 4 no fragment reads, 8 no barriers, 16 no setprio */
 #endif
-#define A4R_PHASE(reads_, issue_, full_, tail_, ax_, bx_, m0_, n0_, z_)                                \
+#define A4R_PHASE(reads_, issue_, full_, tail_, ax_, bx_, m0_, n0_, z_, lim_)                          \
     A4R_ST(0)                                                                                         \
     if (z_) {                      /* first K-tile of an output tile: this phase's quarter of the accumulators starts from zero */ \
         _Pragma("unroll") for (int mi = 0; mi < 4; ++mi)                                              \
@@ -254,7 +285,7 @@ __global__ void __launch_bounds__(512, 2) gemm_nt_256_kernel(const a4r_gemm_t p,
     __builtin_amdgcn_sched_barrier(0);                                                                \
     A4R_ST(4)                                                                                         \
     if (!(A4R_ABL & 16)) __builtin_amdgcn_s_setprio(1);                                               \
-    if (!(A4R_ABL & 2)) { A4R_MFMA16(ax_, bx_, m0_, n0_) }                                            \
+    if (!(A4R_ABL & 2)) { A4R_MFMA16(ax_, bx_, m0_, n0_, lim_) }                                      \
     if (!(A4R_ABL & 16)) __builtin_amdgcn_s_setprio(0);                                               \
     __builtin_amdgcn_sched_barrier(0);                                                                \
     A4R_ST(5)                                                                                         \
@@ -267,16 +298,13 @@ __global__ void __launch_bounds__(512, 2) gemm_nt_256_kernel(const a4r_gemm_t p,
     {                                                                                                                               \
         const bool n1 = (u_) + 1 < nk || has_next, n2 = (u_) + 2 < nk || has_next;                                                                        \
         const bool z0 = (buf_) == 0 && (u_) == 0;                                                                                   \
-        A4R_PHASE(A4R_RD_B(b0, buf_, U_BLO) A4R_RD_A(af, buf_, U_ALO), A4R_ISSUE(U_BHI, (u_) + 1, Bbase, offB_hi), n1, "2", af, b0, 0, 0, z0) \
-        A4R_PHASE(A4R_RD_B(b1, buf_, U_BHI), A4R_ISSUE(U_AHI, (u_) + 1, Abase, offA_hi), n1, "0", af, b1, 0, 2, z0)                 \
-        A4R_PHASE(A4R_RD_A(af, buf_, U_AHI), A4R_ISSUE(U_ALO, (u_) + 2, Abase, offA_lo), n2, "4", af, b1, 4, 2, z0)                 \
-        A4R_PHASE(, A4R_ISSUE(U_BLO, (u_) + 2, Bbase, offB_lo), n2, "4", af, b0, 4, 0, z0)                                          \
+        A4R_PHASE(A4R_RD_B(b0, buf_, U_BLO) A4R_RD_A(af, buf_, U_ALO), A4R_ISSUE(U_BHI, (u_) + 1, Bbase, offB_hi), n1, "2", af, b0, 0, 0, z0, kp_lo) \
+        A4R_PHASE(A4R_RD_B(b1, buf_, U_BHI), A4R_ISSUE(U_AHI, (u_) + 1, Abase, offA_hi), n1, "0", af, b1, 0, 2, z0, kp_lo)          \
+        A4R_PHASE(A4R_RD_A(af, buf_, U_AHI), A4R_ISSUE(U_ALO, (u_) + 2, Abase, offA_lo), n2, "4", af, b1, 4, 2, z0, kp_hi)          \
+        A4R_PHASE(, A4R_ISSUE(U_BLO, (u_) + 2, Bbase, offB_lo), n2, "4", af, b0, 4, 0, z0, kp_hi)                                   \
     }
 
     f32x4_t acc[8][4];
-    // store instructions a wave issues per output tile: 8 rows x 2 pairs of 16-byte (bf16) / 2 x 16-byte (fp32) stores, + the second output
-    // (a LOWER bound: the generic EF < 0 instantiation may or may not carry a second output)
-    constexpr int EPI_STORES = 16 * ((int)sizeof(TO) / 2) + ((EF >= 0 && (EF & 8)) ? 16 : 0);
 
     // fragment addressing (unit-local): A rows wm*64 + mi4*16 + (lane&15), B rows wn*32 + ni2*16 + (lane&15)
     const int fr = lane & 15, kg = lane >> 4;
@@ -297,19 +325,28 @@ __global__ void __launch_bounds__(512, 2) gemm_nt_256_kernel(const a4r_gemm_t p,
         }
 
     // ---- prologue of a tile: the first 6 units in stream order (K-tile 0 and A_lo, B_lo of K-tile 1)
-#define A4R_PROLOGUE()                          \
-    A4R_ISSUE(U_ALO, 0, Abase, offA_lo)         \
-    A4R_ISSUE(U_BLO, 0, Bbase, offB_lo)         \
-    A4R_ISSUE(U_BHI, 0, Bbase, offB_hi)         \
-    A4R_ISSUE(U_AHI, 0, Abase, offA_hi)         \
-    A4R_ISSUE(U_ALO, 1, Abase, offA_lo)         \
-    A4R_ISSUE(U_BLO, 1, Bbase, offB_lo)
+#define A4R_PROLOGUE_AT(Ab_, alo_, ahi_, Bb_)    \
+    A4R_ISSUE(U_ALO, 0, Ab_, alo_)              \
+    A4R_ISSUE(U_BLO, 0, Bb_, offB_lo)           \
+    A4R_ISSUE(U_BHI, 0, Bb_, offB_hi)           \
+    A4R_ISSUE(U_AHI, 0, Ab_, ahi_)              \
+    A4R_ISSUE(U_ALO, 1, Ab_, alo_)              \
+    A4R_ISSUE(U_BLO, 1, Bb_, offB_lo)
+#define A4R_PROLOGUE() A4R_PROLOGUE_AT(Abase, offA_lo, offA_hi, Bbase)
     bool has_next = false;
     const int tile_stride = (int)(gridDim.x >> 3);        // read once (behind the asm memory clobbers it was re-loaded from the dispatch packet per tile)
     const char* Abase_nx = Abase;
     const char* Bbase_nx = Bbase;
-    A4R_PROLOGUE()
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    // store instructions a wave issues per output tile: 8 rows x 2 pairs of 16-byte (bf16) / 2 x 16-byte (fp32) stores, + the second output
+    // (a LOWER bound: the generic EF < 0 instantiation may or may not carry a second output)
+    constexpr int EPI_STORES = 16 * ((int)sizeof(TO) / 2) + ((EF >= 0 && (EF & 8)) ? 16 : 0);
+    if (TAIL && t_ready) {     // the six units were issued at the start of the last full tile's epilogue, BEFORE its >= EPI_STORES stores
+        if constexpr (EPI_STORES >= 32) asm volatile("s_waitcnt vmcnt(32)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+    } else {
+        A4R_PROLOGUE()
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
     const GemmEpi<TO> epi = make_epi<TO>(p, thr16, keep_scale);
     const bool stream = !(nk & 1) && !((gn_flags >> 16) & 1);
     // the tile after the current one: found before the current tile's K loop needs it, outside the barrier-to-barrier path (the scalar
@@ -318,7 +355,7 @@ __global__ void __launch_bounds__(512, 2) gemm_nt_256_kernel(const a4r_gemm_t p,
     bool more;
 #define A4R_NEXT_TILE()                                                                      \
     t_loc += tile_stride;                                                                    \
-    more = t_loc < len_x;                                                                    \
+    more = !TAIL && t_loc < len_x;                                                           \
     if (more) {                                                                              \
         tile_of(t_loc, tm_nx, tn_nx);                                                        \
         Abase_nx = reinterpret_cast<const char*>(Ap + (size_t)tm_nx * 256 * lda);            \
@@ -367,12 +404,27 @@ __global__ void __launch_bounds__(512, 2) gemm_nt_256_kernel(const a4r_gemm_t p,
     if (more && !stream) {                                // odd K-tile count: the next tile's first units are put in flight here
         A4R_PROLOGUE()
     }
+    if (!TAIL && !more && t_kp > 0) {                     // last full tile: the first units of this workgroup's short tile
+        const char* const At = reinterpret_cast<const char*>(Ap + (size_t)t_row0 * lda);
+        const char* const Bt = reinterpret_cast<const char*>(Bp + (size_t)t_tn * 256 * ldb);
+        const char* const At_nx = At;
+        const char* const Bt_nx = Bt;
+        uint32_t ta_lo[2], ta_hi[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int ul = 8 * (2 * wave + i) + (lane >> 3);
+            tail_a_offsets(ul, (lane & 7) ^ ((ul >> 1) & 7), t_kp, lda * (int)sizeof(TI), ta_lo[i], ta_hi[i]);
+        }
+        A4R_PROLOGUE_AT(At, ta_lo, ta_hi, Bt)
+        t_ready = true;
+    }
     // Pair the lanes of 16-lane rows (l <-> l ^ 16) with v_permlane16_swap: lane (fr, kg) gives away the half it holds of
     // the neighbouring tile and receives the missing half of its own, so that it ends up with 8 CONSECUTIVE columns
     //   kg even: tile 2*pair,     columns (kg >> 1) * 8 .. + 7        kg odd: tile 2*pair + 1, same columns
     // = one 16-byte (bf16) store per lane and 64-byte runs per row: half the store instructions of the 8-byte form,
     // whose issue rate (not bandwidth) bounded the epilogue.
-    const size_t grow0 = (size_t)tm_done * 256 + wm * 128 + fr;
+    const int row0_done = TAIL ? t_row0 : tm_done * 256;
+    const size_t grow0 = (size_t)row0_done + wm * hrow + fr;
     const int gcolp = tn_done * 256 + wn * 64 + (kg & 1) * 16 + (kg >> 1) * 8;      // + pair * 32
     // C addresses and dropout element indices: a UNIFORM per-tile / per-group part (scalar registers) + a per-lane part that is the same
     // for every tile (c_lane, e0_lane) -- no 64-bit multiply per group
@@ -383,14 +435,18 @@ __global__ void __launch_bounds__(512, 2) gemm_nt_256_kernel(const a4r_gemm_t p,
     const int fr_e = lane_e & 15, kg_e = lane_e >> 4;
     constexpr bool C8 = EF >= 0 && (EF & 16) != 0;         // C leaves as e4m3 bytes (a4r_gemm_t.c_fp8): one byte per element, ldc in bytes
     constexpr int CSZ = C8 ? 1 : (int)sizeof(TO);
-    const uint32_t c_lane = (uint32_t)(((wm * 128 + fr_e) * epi.ldc + wn * 64 + (kg_e & 1) * 16 + (kg_e >> 1) * 8) * CSZ);
+    const uint32_t c_lane = (uint32_t)(((wm * hrow + fr_e) * epi.ldc + wn * 64 + (kg_e & 1) * 16 + (kg_e >> 1) * 8) * CSZ);
     const uint32_t c_rowstep = (uint32_t)(16 * epi.ldc * CSZ);
-    const uint64_t e0_lane = (uint64_t)(wm * 128 + fr_e) * (uint64_t)epi.N + (uint64_t)(wn * 64 + (kg_e & 1) * 16 + (kg_e >> 1) * 8);
-    char* const c_tile = reinterpret_cast<char*>(epi.C) + ((size_t)tm_done * 256 * (uint32_t)epi.ldc + (size_t)tn_done * 256) * CSZ;
-    const uint64_t e0_tile = ((uint64_t)tm_done * 256 + epi.row0) * (uint64_t)epi.N + (uint64_t)tn_done * 256;
+    const uint64_t e0_lane = (uint64_t)(wm * hrow + fr_e) * (uint64_t)epi.N + (uint64_t)(wn * 64 + (kg_e & 1) * 16 + (kg_e >> 1) * 8);
+    char* const c_tile = reinterpret_cast<char*>(epi.C) + ((size_t)row0_done * (uint32_t)epi.ldc + (size_t)tn_done * 256) * CSZ;
+    const uint64_t e0_tile = ((uint64_t)row0_done + epi.row0) * (uint64_t)epi.N + (uint64_t)tn_done * 256;
     // 8-bit derivative in tile-native order (a4r_gemm_t.q8_tiled): this lane's 8 bytes of group g sit at tile base + wave * 8192 + g * 512 + lane * 8
     const bool q8t = p.q8_tiled != 0;
-    const size_t q8_off = ((size_t)(tm_done * ntn + tn_done) * 8 + wave) * 8192 + (size_t)lane_e * 8;
+    // (short tile: the row panel [t_row0, + 32 t_kp) x N starts at byte t_row0 * N; its tiles, then the waves' t_kp KiB blocks, follow each other)
+    const size_t q8_off = TAIL ? (size_t)t_row0 * (size_t)epi.N + ((size_t)tn_done * 8 + wave) * (size_t)(t_kp * 1024) + (size_t)lane_e * 8
+                               : ((size_t)(tm_done * ntn + tn_done) * 8 + wave) * 8192 + (size_t)lane_e * 8;
+    // short tile: operand rows past the last active one are requested from the last active row (valid memory, never consumed)
+#define A4R_RC(r_) (TAIL ? ((r_) < t_kp ? (r_) : t_kp - 1) : (r_))
     const uint8_t* const q8_pre = reinterpret_cast<const uint8_t*>(epi.Pre) + q8_off;
     uint8_t* const q8_c2 = reinterpret_cast<uint8_t*>(epi.C2) + q8_off;
     float bias8[2][8];                                    // (gcolp % 8 == 0: 16-byte loads are aligned iff the bias pointer is)
@@ -421,7 +477,7 @@ __global__ void __launch_bounds__(512, 2) gemm_nt_256_kernel(const a4r_gemm_t p,
 #pragma unroll
             for (int e = 0; e < 8; ++e) sb8[pr][e] = p.scale_b[gcolp + pr * 32 + e];
 #pragma unroll
-        for (int mi = 0; mi < 8; ++mi) sa8[mi] = p.scale_a[grow0 + mi * 16];
+        for (int mi = 0; mi < 8; ++mi) sa8[mi] = p.scale_a[grow0 + A4R_RC(mi) * 16];
     }
     // e4m3 output: the multiplier that takes a finished value to its stored form (per row of 16: c_fp8 2 scales a row by its A row's scale)
     float cmul8[8];
@@ -432,7 +488,7 @@ __global__ void __launch_bounds__(512, 2) gemm_nt_256_kernel(const a4r_gemm_t p,
         for (int mi = 0; mi < 8; ++mi) {
             const float so = p.c_fp8 == 2 ? sa8[mi] * p.c_scale : p.c_scale;
             cmul8[mi] = __frcp_rn(so);
-            if (p.c_fp8 == 2 && tn_done == 0 && wn == 0 && kg == 0) p.c_scale_out[grow0 + mi * 16] = so;      // (one writer per row)
+            if (p.c_fp8 == 2 && tn_done == 0 && wn == 0 && kg == 0 && (!TAIL || mi < t_kp)) p.c_scale_out[grow0 + mi * 16] = so;      // (one writer per row)
         }
     }
     // Operands the epilogue READS -- Pre (dgrad through an activation: C = acc * act'(Pre)) and R1 (dgrad GEMMs: the gradient of the
@@ -452,19 +508,19 @@ __global__ void __launch_bounds__(512, 2) gemm_nt_256_kernel(const a4r_gemm_t p,
 #define A4R_LD_PRE(r_)                                                                                                      \
     if constexpr (DACT != A4R_ACT_NONE && (r_) < 8 && !(A4R_ABL & 256)) {                                                   \
         if (DACT == A4R_DACT_MULQ8_ && q8t) {          /* tile-native order: 512 contiguous bytes per wave instruction */   \
-            const uint2 w0_ = *reinterpret_cast<const uint2*>(q8_pre + (2 * (r_)) * 512);                                   \
-            const uint2 w1_ = *reinterpret_cast<const uint2*>(q8_pre + (2 * (r_) + 1) * 512);                               \
+            const uint2 w0_ = *reinterpret_cast<const uint2*>(q8_pre + (2 * A4R_RC(r_)) * 512);                             \
+            const uint2 w1_ = *reinterpret_cast<const uint2*>(q8_pre + (2 * A4R_RC(r_) + 1) * 512);                         \
             pre_s##r_##_0[0] = make_uint4(w0_.x, w0_.y, 0u, 0u);                                                            \
             pre_s##r_##_1[0] = make_uint4(w1_.x, w1_.y, 0u, 0u);                                                            \
         } else {                                                                                                            \
-        load_pre_n<TO, 8, DACT == A4R_DACT_MULQ8_>(pre_s##r_##_0, grow0 + (r_) * 16, gcolp, epi);                           \
-        load_pre_n<TO, 8, DACT == A4R_DACT_MULQ8_>(pre_s##r_##_1, grow0 + (r_) * 16, gcolp + 32, epi);                      \
+        load_pre_n<TO, 8, DACT == A4R_DACT_MULQ8_>(pre_s##r_##_0, grow0 + A4R_RC(r_) * 16, gcolp, epi);                     \
+        load_pre_n<TO, 8, DACT == A4R_DACT_MULQ8_>(pre_s##r_##_1, grow0 + A4R_RC(r_) * 16, gcolp + 32, epi);                \
         }                                                                                                                   \
     }
 #define A4R_LD_R1(r_)                                                                                                       \
     if constexpr (R1PF && (r_) < 8) {                                                                                       \
-        load_res_n<TO, 8>(r1_s##r_##_0, epi.R1, epi.ldr1, grow0 + (r_) * 16, gcolp);                                        \
-        load_res_n<TO, 8>(r1_s##r_##_1, epi.R1, epi.ldr1, grow0 + (r_) * 16, gcolp + 32);                                   \
+        load_res_n<TO, 8>(r1_s##r_##_0, epi.R1, epi.ldr1, grow0 + A4R_RC(r_) * 16, gcolp);                                  \
+        load_res_n<TO, 8>(r1_s##r_##_1, epi.R1, epi.ldr1, grow0 + A4R_RC(r_) * 16, gcolp + 32);                             \
     }
     // rows 0 .. D - 1 before the first row is processed; row mi + D while row mi is
 #define A4R_LD_FIRST(LD_, D_)                                                                                               \
@@ -505,8 +561,14 @@ __global__ void __launch_bounds__(512, 2) gemm_nt_256_kernel(const a4r_gemm_t p,
     A4R_LD_AHEAD(A4R_LD_PRE, PRE_D, n1_, n2_, n4_)                                                                          \
     A4R_LD_AHEAD(A4R_LD_R1, R1_D, n1_, n2_, n4_)                                                                            \
     A4R_EPI_PAIR(mi_, 0) A4R_EPI_PAIR(mi_, 1)
-    A4R_EPI_ROW(0, 1, 2, 4) A4R_EPI_ROW(1, 2, 3, 5) A4R_EPI_ROW(2, 3, 4, 6) A4R_EPI_ROW(3, 4, 5, 7) A4R_EPI_ROW(4, 5, 6, 8) A4R_EPI_ROW(5, 6, 7, 8)
-    A4R_EPI_ROW(6, 7, 8, 8) A4R_EPI_ROW(7, 8, 8, 8)
+    // (short tile: leave after the last active row -- straight-line code with exits, so hipcc's counted waits stay exact)
+#define A4R_EPI_END(n_) if (TAIL && t_kp <= (n_)) break;
+    do {
+        A4R_EPI_ROW(0, 1, 2, 4) A4R_EPI_END(1) A4R_EPI_ROW(1, 2, 3, 5) A4R_EPI_END(2) A4R_EPI_ROW(2, 3, 4, 6) A4R_EPI_END(3) A4R_EPI_ROW(3, 4, 5, 7) A4R_EPI_END(4)
+        A4R_EPI_ROW(4, 5, 6, 8) A4R_EPI_END(5) A4R_EPI_ROW(5, 6, 7, 8) A4R_EPI_END(6) A4R_EPI_ROW(6, 7, 8, 8) A4R_EPI_END(7) A4R_EPI_ROW(7, 8, 8, 8)
+    } while (0);
+#undef A4R_EPI_END
+#undef A4R_RC
 #undef A4R_EPI_ROW
 #undef A4R_EPI_PAIR
 #undef A4R_EPI_CDST
@@ -539,6 +601,28 @@ __global__ void __launch_bounds__(512, 2) gemm_nt_256_kernel(const a4r_gemm_t p,
 #undef A4R_KTILE
 }
 
+// ntm = row panels of FULL tiles; the tail_rows rows behind them (0 = none) are cut into short tiles of 32 * tail_kp rows, tile j (row-panel
+// major) on workgroup (j / wg_per_xcd, j % wg_per_xcd) = (XCD, index): the short tiles of one row panel share an XCD's L2.
+template <typename TI, typename TO, int ACT, int DACT, int EF>
+__global__ void __launch_bounds__(512, 2) gemm_nt_256_kernel(const a4r_gemm_t p, int ntm, int ntn, int gn_flags, uint32_t thr16, float keep_scale,
+                                                             int tail_kp, int tail_rows) {
+    __shared__ __attribute__((aligned(16))) char lds[8 * UNIT_BYTES];      // [buffer 2][unit 4][128 rows][128 B]
+    int t_row0 = 0, t_tn = 0, t_kp = 0;
+    if (tail_kp > 0) {
+        const int h = 32 * tail_kp;
+        const int jt = (int)(blockIdx.x & 7) * (int)(gridDim.x >> 3) + (int)(blockIdx.x >> 3);
+        if (jt < (tail_rows + h - 1) / h * ntn) {
+            const int jp = jt / ntn, left = tail_rows - jp * h;
+            t_tn = jt - jp * ntn;
+            t_row0 = ntm * 256 + jp * h;
+            t_kp = left < h ? left / 32 : tail_kp;           // (the last row panel may be shorter)
+        }
+    }
+    bool t_ready = false;
+    if (ntm > 0) gemm256_tiles<TI, TO, ACT, DACT, EF, false>(p, lds, ntm, ntn, gn_flags, thr16, keep_scale, t_row0, t_tn, t_kp, t_ready);
+    if (t_kp > 0) gemm256_tiles<TI, TO, ACT, DACT, EF, true>(p, lds, ntm, ntn, gn_flags, thr16, keep_scale, t_row0, t_tn, t_kp, t_ready);
+}
+
 }  // namespace
 
 int a4r_cu_count() {
@@ -552,6 +636,37 @@ int a4r_cu_count() {
         if (n_cu < 8) n_cu = 8;
     }
     return n_cu;
+}
+
+// Short-tile tail of a launch.  tiles = R full rounds of the persistent grid + a partial one: the first p_full = floor(R * grid / ntn) row
+// panels keep 256-row tiles (<= R per workgroup), the rows behind them are cut into tiles of 32 * kp rows with the smallest kp that needs at
+// most one tile per workgroup -- R + f(kp) tile periods instead of R + 1.  Measured (tools/gemm_tail_probe.py, one tile per CU, all CUs):
+// f = 0.61 - 0.70 at kp = 1, 0.81 at kp = 4, 0.96 - 0.98 at kp = 7 -- a K-tile's DMA issue, fragment reads and barriers do not shrink with
+// the MFMA count -- so the split is used for kp <= 3 only (A4R_GEMM_TAIL = the largest kp, default 3, 0 = never; at kp = 4 - 7 the BERT step
+// lost 2 %: the gain is below what the banded tile map, which a tail excludes, is worth on the N = 3072 launches).  A function of (M, N)
+// and the CU count only: the launch that writes a tile-native 8-bit derivative and the one that reads it agree on the split.
+static int g_tail_max = -1;
+extern "C" int a4r_gemm_tail_max(int k) {
+    if (g_tail_max < 0) g_tail_max = getenv("A4R_GEMM_TAIL") ? atoi(getenv("A4R_GEMM_TAIL")) : 3;
+    const int old = g_tail_max;
+    if (k >= 0) g_tail_max = k < 7 ? k : 7;
+    return old;
+}
+extern "C" int a4r_gemm_tail_plan(int M, int N, int* p_full, int* kp) {
+    if (!p_full || !kp || M <= 0 || N < 256) { if (p_full) *p_full = M > 0 ? M / 256 : 0; if (kp) *kp = 0; return 0; }
+    const int on = a4r_gemm_tail_max(-1);
+    const int ntm = M / 256, ntn = N / 256, grid = a4r_cu_count(), nt = ntm * ntn;
+    *p_full = ntm;
+    *kp = 0;
+    if (!on || ntn > grid || nt % grid == 0) return 0;
+    const int pf = (nt / grid) * grid / ntn, rows = (ntm - pf) * 256;
+    for (int k = 1; k <= (on < 7 ? on : 7); ++k)
+        if ((rows + 32 * k - 1) / (32 * k) * ntn <= grid) {
+            *p_full = pf;
+            *kp = k;
+            return 1;
+        }
+    return 0;
 }
 
 namespace {
@@ -581,9 +696,18 @@ static int band_for(const a4r_gemm_t& g, int ntm, int ntn, int grid, int isz) {
 
 template <typename TI, typename TO, int ACT, int DACT, int EF = -1>
 int launch256(hipStream_t s, const a4r_gemm_t& g) {
-    const int ntm = g.M / 256, ntn = g.N / 256;
+    int ntm = g.M / 256;
+    const int ntn = g.N / 256;
     const int n_cu = a4r_cu_count();
     int grid = ntm * ntn < n_cu ? ((ntm * ntn + 7) & ~7) : n_cu;       // a multiple of 8 (workgroups past an XCD's tile count exit at once)
+    int p_full = ntm, tail_kp = 0;
+    a4r_gemm_tail_plan(g.M, g.N, &p_full, &tail_kp);
+    const int tail_rows = (ntm - p_full) * 256;
+    if (tail_kp > 0) {
+        const int n_tail = (tail_rows + 32 * tail_kp - 1) / (32 * tail_kp) * ntn;
+        if (p_full == 0) grid = (n_tail + 7) & ~7;
+        ntm = p_full;
+    }
     static const int no_stream = getenv("A4R_GEMM_NO_STREAM") ? atoi(getenv("A4R_GEMM_NO_STREAM")) != 0 : 0;
     static const int stagger_pct = getenv("A4R_GEMM_STAGGER") ? atoi(getenv("A4R_GEMM_STAGGER")) : 30;
     int delay = 0;
@@ -591,9 +715,10 @@ int launch256(hipStream_t s, const a4r_gemm_t& g) {
         delay = (int)((g.K * (int)sizeof(TI) / 128 * 145 + 400) * stagger_pct / 100);
         if (delay > 16383) delay = 16383;
     }
-    const int gn = band_for(g, ntm, ntn, grid, (int)sizeof(TI)) | (no_stream << 16) | (delay << 17);
+    // (with a short-tile tail the panel-major map: whole panels per XCD would leave the XCDs uneven numbers of full tiles)
+    const int gn = (tail_kp > 0 ? 0 : band_for(g, ntm, ntn, grid, (int)sizeof(TI))) | (no_stream << 16) | (delay << 17);
     hipLaunchKernelGGL((gemm_nt_256_kernel<TI, TO, ACT, DACT, EF>), dim3(grid), dim3(512), 0, s, g, ntm, ntn, gn,
-                       a4r_thr16(g.drop_p), a4r_keep_scale(g.drop_p));
+                       a4r_thr16(g.drop_p), a4r_keep_scale(g.drop_p), tail_kp, tail_rows);
     return a4r_launch_status();
 }
 

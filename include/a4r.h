@@ -36,7 +36,7 @@ extern "C" {
 
 /* ABI version: bumped whenever a signature or struct below changes.  The Python binding (adapter4rec_amd/_lib.py) refuses a
  * library whose a4r_version() differs, so an A/B build made before a signature change cannot be called with shifted arguments. */
-#define A4R_ABI_VERSION 306
+#define A4R_ABI_VERSION 307
 int a4r_version(void);
 
 /* C[M,N] = epilogue(alpha * A[M,K] . B[N,K]^T): every nn.Linear on the path (HF BertSelfAttention
@@ -78,15 +78,26 @@ typedef struct {
      *   ((tm * (N / 256) + tn) * 8 + w) * 8192 + g * 512 + l * 8,
      * so that a wave's store / load instruction moves 512 contiguous bytes (row-major: 16 segments of 32).  The tensor is only ever
      * written by the FFN-up launch and read by the `* derivative` dgrad launch of the same [M, N]; both must set the flag.  Rows that a
-     * launch hands to the 128-tile kernel (tail row panels, small shapes) stay row-major -- a function of (M, N) only, so the two launches
-     * agree.  ldc2 / ldpre must equal N. */
+     * launch hands to the 128-tile kernel (small shapes) stay row-major -- a function of (M, N) only, so the two launches agree.
+     * Rows the launch covers with SHORT tiles (a4r_gemm_tail_plan below: row panels of h = 32 * kp rows from row p_full * 256 on): the panel
+     * at row r0 starts at byte r0 * N and holds, per N-tile tn and wave w, kp KiB in the same (group, lane) order:
+     *   r0 * N + (tn * 8 + w) * kp * 1024 + g * 512 + l * 8,   g < 2 * kp.          ldc2 / ldpre must equal N. */
     int32_t q8_tiled;
 } a4r_gemm_t;
 int a4r_gemm_nt(void* stream, const a4r_gemm_t* g);
+/* How the 256 x 256-tile kernel covers an [M, N] output whose tile count is not a multiple of the CU count: the first *p_full row
+ * panels of 256 rows are whole rounds of full tiles, the rows behind them are cut into SHORT tiles of 32 * *kp rows, at most one per CU,
+ * inside the same launch -- used when kp <= A4R_GEMM_TAIL (environment, default 3, up to 7, 0 = never: a short tile costs 0.6 - 0.7 of a
+ * full one at kp = 1 and 0.97 at kp = 7).  Returns 1 when a short-tile tail is used (else *p_full = M / 256, *kp = 0).  Results do not
+ * depend on the split (same K order per element). */
+int a4r_gemm_tail_plan(int M, int N, int* p_full, int* kp);
+/* the largest kp a4r_gemm_tail_plan accepts (0 - 7; k < 0 only queries; initial value: A4R_GEMM_TAIL or 3); returns the previous one.  For
+ * tests and A/B runs -- change it between, never inside, a write / read pair of a tile-native 8-bit derivative. */
+int a4r_gemm_tail_max(int k);
 /* tuning knob for A/B measurements and tests: 0 = 128x128 tile, register-staged K pipeline; 1 = 128x128 tile, direct-to-LDS
  * (global_load_lds) pipeline; 2 (default) = 256x256 tile with a 2-deep LDS-DMA ring kept in flight across barriers
  * wherever M % 256 == 0, N % 256 == 0 (variant 1 elsewhere), chosen automatically: fewer 256-tiles than half the CUs -> the
- * 128-tile kernel; a last round of only a few whole row panels -> those panels on the 128-tile kernel; 4 = the 256 tile
+ * 128-tile kernel; a partial last round -> short tiles in the same launch (a4r_gemm_tail_plan); 4 = the 256 tile
  * forced (tests).  Results of 2 / 4 agree bit for bit, the others to fp32 summation order; returns the previous setting
  * (-1 for the retired variants 3 and 5, any other v only queries). */
 int a4r_gemm_variant(int v);

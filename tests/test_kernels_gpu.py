@@ -1087,6 +1087,98 @@ def test_gemm256_many_tiles_per_workgroup(K):
     close(res[0][5][rows], pre * (P8[rows].float() * L.Q8_STEP - L.Q8_OFF), t, '* derivative vs torch')
 
 
+# (M / 256, N, K): short-tile heights kp = 1 .. 7 behind one round of full tiles at N = 768, and launches that are ALL short tiles (fewer tiles than CUs)
+@pytest.mark.parametrize('ntm,N,K', [(86, 768, 256), (96, 768, 192), (107, 768, 128), (117, 768, 256), (128, 768, 128), (139, 768, 256), (149, 768, 128),
+                                     (25, 1024, 256), (9, 1024, 384), (70, 3072, 128)])
+def test_gemm256_short_tile_tail(ntm, N, K):
+    """a4r_gemm_tail_plan: the rows behind the last whole round of 256-row tiles run as short tiles (32 kp rows) in the same launch.  Every
+    epilogue form of the training step on full AND short tiles against the 128-tile kernel (same epilogue code, other tiling) and fp32 torch;
+    dropout masks identical; the tile-native 8-bit derivative written and read through short tiles equals the row-major pipeline bit for bit."""
+    from adapter4rec_amd import _lib as L
+    t = torch.bfloat16
+    M = ntm * 256
+    old_max = L.gemm_tail_max(7)              # (the default uses short tiles up to kp = 3 only)
+    try:
+        _short_tile_tail_case(L, t, M, N, K, ntm)
+    finally:
+        L.gemm_tail_max(old_max)
+
+
+def _short_tile_tail_case(L, t, M, N, K, ntm):
+    pf, kp = L.gemm_tail_plan(M, N)
+    assert kp >= 1 and pf < ntm, (pf, kp)
+    A, B = rnd(M, K, dtype=t, seed=81), rnd(N, K, dtype=t, scale=0.05, seed=82)
+    bias, R1 = rnd(N, seed=83), rnd(M, N, dtype=t, seed=84)
+    P8 = torch.randint(0, 256, (M, N), device=dev(), dtype=torch.uint8, generator=torch.Generator(device=dev()).manual_seed(85))
+    res = []
+    for v in (4, 1):
+        old = L.gemm_variant(v)
+        plain, drop, resid, gel, dm, dropres = (torch.full((M, N), 7.0, dtype=t, device=dev()) for _ in range(6))
+        C8 = torch.zeros(M, N, dtype=torch.uint8, device=dev())
+        L.gemm_nt(A, B, plain, bias=bias)
+        L.gemm_nt(A, B, drop, bias=bias, drop_p=0.1, drop_site=3, drop_seed=11)
+        L.gemm_nt(A, B, resid, R1=R1)
+        L.gemm_nt(A, B, dropres, bias=bias, R1=R1, drop_p=0.1, drop_site=5, drop_seed=13, drop_first=True)
+        L.gemm_nt(A, B, gel, bias=bias, C2=C8, act=L.ACT_GELU, c2_deriv='q8')
+        L.gemm_nt(A, B, dm, Pre=P8, dact=L.DACT_MUL_Q8)
+        L.gemm_variant(old)
+        res.append((plain, drop, resid, gel, C8, dm, dropres))
+    names = ('plain', 'dropout', 'residual', 'gelu', 'gelu derivative q8', '* derivative q8', 'dropout + residual')
+    for nm, a, b in zip(names, res[0], res[1]):
+        if a.dtype == torch.uint8:
+            assert int((a.int() - b.int()).abs().max()) <= 1, nm
+        else:
+            close(a, b, t, nm + ': 256-tile (short tail) vs 128-tile kernel', rtol16=2e-2, atol16=2e-2)
+    assert torch.equal(res[0][1] == 0, res[1][1] == 0), 'dropout pattern'
+    assert torch.equal(res[0][6] == R1, res[1][6] == R1), 'dropout pattern (dropout + residual form)'
+    rows = torch.cat([torch.arange(0, M, 509, device=dev()), torch.arange(pf * 256, M, 37, device=dev())])     # the tail densely
+    pre = A[rows].float() @ B.float().t()
+    close(res[0][0][rows], pre + bias, t, 'plain vs torch')
+    close(res[0][2][rows], pre + R1[rows].float(), t, 'residual vs torch')
+    close(res[0][3][rows], torch.nn.functional.gelu(pre + bias), t, 'gelu vs torch')
+    close(res[0][5][rows], pre * (P8[rows].float() * L.Q8_STEP - L.Q8_OFF), t, '* derivative vs torch')
+    # tile-native derivative through the short tiles
+    old = L.gemm_variant(4)
+    outs = {}
+    for tiled in (False, True):
+        Cg = torch.zeros(M, N, dtype=t, device=dev())
+        D = torch.zeros(M, N, dtype=torch.uint8, device=dev())
+        L.gemm_nt(A, B, Cg, bias=bias, C2=D, act=L.ACT_GELU, c2_deriv='q8', q8_tiled=tiled)
+        G = torch.zeros(M, N, dtype=t, device=dev())
+        L.gemm_nt(A, B, G, Pre=D, dact=L.DACT_MUL_Q8, q8_tiled=tiled)
+        outs[tiled] = (Cg, D, G)
+    L.gemm_variant(old)
+    assert torch.equal(outs[False][0], outs[True][0]) and torch.equal(outs[False][2], outs[True][2])
+    assert torch.equal(outs[False][0], res[0][3])
+    assert torch.equal(torch.sort(outs[False][1].flatten())[0], torch.sort(outs[True][1].flatten())[0])
+    # fp32 instantiation (the evaluation sweep), plain form
+    Af, Bf = A.float(), B.float()
+    Cf = torch.zeros(M, N, device=dev())
+    old = L.gemm_variant(4)
+    L.gemm_nt(Af, Bf, Cf, bias=bias)
+    L.gemm_variant(old)
+    close(Cf[rows], pre + bias, torch.float32, 'fp32 plain vs torch')
+
+
+def test_gemm_tail_plan_properties():
+    """The split is a function of (M, N) only, keeps at most one short tile per CU and never more full tiles per CU than whole rounds."""
+    from adapter4rec_amd import _lib as L
+    ncu = 256
+    assert (L.gemm_tail_max(-1) != 3 or L.gemm_tail_plan(40448, 768) == (158, 0)) and L.gemm_tail_plan(66304, 768) == (256, 1)
+    old_max = L.gemm_tail_max(7)
+    plans = {(M, N): L.gemm_tail_plan(M, N) for M, N in [(40448, 768), (40448, 2304), (40448, 3072), (66304, 768), (16896, 3072), (256, 256), (256 * 57, 1024), (160 * 256, 768)]}
+    L.gemm_tail_max(old_max)
+    assert plans[(40448, 768)] == (85, 7) and plans[(40448, 3072)] == (149, 4)
+    for (M, N), (pf, kp) in plans.items():
+        ntm, ntn = M // 256, N // 256
+        assert 0 <= pf <= ntm and 0 <= kp <= 7
+        if kp:
+            rows = (ntm - pf) * 256
+            assert -(-rows // (32 * kp)) * ntn <= ncu and pf * ntn <= (ntm * ntn // ncu) * ncu
+        else:
+            assert pf == ntm
+
+
 # ------------------------------------------------------------------ round 3: e4m3 GEMM outputs, the fused SASRec block
 @pytest.mark.parametrize('M,N,K', [(512, 3072, 768), (256 * 5, 1024, 256)])
 def test_gemm_fp8_output_static_scale(M, N, K):
@@ -1257,11 +1349,21 @@ def test_gemm_q8_tiled_layout_roundtrip(M, N, K):
     assert torch.equal(outs[False][0], outs[True][0]) and torch.equal(outs[False][2], outs[True][2])
     d0, d1 = outs[False][1], outs[True][1]
     assert not torch.equal(d0, d1) and torch.equal(torch.sort(d0.flatten())[0], torch.sort(d1.flatten())[0])
-    # a tile's 65 536 bytes hold exactly that tile's values
-    tm, tn = 1, 2
-    tile_rm = d0[tm * 256:(tm + 1) * 256, tn * 256:(tn + 1) * 256].flatten()
-    tile_t = d1.flatten()[(tm * (N // 256) + tn) * 65536:(tm * (N // 256) + tn + 1) * 65536]
-    assert torch.equal(torch.sort(tile_rm)[0], torch.sort(tile_t)[0])
+    # a tile's bytes hold exactly that tile's values: a full tile (65 536 bytes at tile index * 65 536), and a short tile of the tail
+    # (a4r_gemm_tail_plan: row panel at row r0 starts at byte r0 * N; its N-tiles of 32 kp x 256 bytes follow each other)
+    pf, kp = L.gemm_tail_plan(M, N)
+    tn = 2
+    if pf > 1:
+        tm = 1
+        tile_rm = d0[tm * 256:(tm + 1) * 256, tn * 256:(tn + 1) * 256].flatten()
+        tile_t = d1.flatten()[(tm * (N // 256) + tn) * 65536:(tm * (N // 256) + tn + 1) * 65536]
+        assert torch.equal(torch.sort(tile_rm)[0], torch.sort(tile_t)[0])
+    if kp:
+        h = 32 * kp
+        r0 = pf * 256 + h                                   # the second short row panel
+        tile_rm = d0[r0:r0 + h, tn * 256:(tn + 1) * 256].flatten()
+        tile_t = d1.flatten()[r0 * N + tn * h * 256:r0 * N + (tn + 1) * h * 256]
+        assert torch.equal(torch.sort(tile_rm)[0], torch.sort(tile_t)[0])
 
 
 @pytest.mark.parametrize('H', [256, 768])
