@@ -73,8 +73,32 @@ extern "C" int a4r_debug_timeline(unsigned long long* host_out) {
 #define A4R_TL(slot_)
 #define A4R_TLT(k_)
 #endif
+#ifdef A4R_PHASE_STAMP
+// diagnostic build only (-DA4R_PHASE_STAMP, tools/gemm_phase_stamps.py): s_memtime at seven points of every phase of K-tiles 4 and 5 of the first
+// full tile, waves 0 and 4 (one per ping-pong half) of workgroups 0..63: [wg][half][phase 0..7][point 0..6 (+1 pad)].  Points: 0 phase start,
+// 1 reads + DMA issued, 2 counted vmcnt passed, 3 barrier passed, 4 fragments arrived (lgkmcnt 0), 5 last MFMA issued, 6 trailing barrier passed.
+// The stamps are SMEM returns collected by ONE extra lgkmcnt(0) at the end of the phase; nothing in the kernel reads them.
+__device__ unsigned long long g_a4r_phase_stamps[64 * 2 * 8 * 8];
+extern "C" int a4r_debug_phase_stamps(unsigned long long* host_out) {
+    return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_a4r_phase_stamps), sizeof(g_a4r_phase_stamps)) == hipSuccess ? 0 : -2;
+}
+#define A4R_ST_BEGIN(u_) const bool st_on_ = !TAIL && st_tile_ == 0 && (u_) >= 4 && (u_) < 6 && (wave & 3) == 0 && blockIdx.x < 64; \
+    int st_idx_ = ((u_) - 4) * 4; unsigned long long st_t0 = 0, st_t1 = 0, st_t2 = 0, st_t3 = 0, st_t4 = 0, st_t5 = 0, st_t6 = 0;
+#define A4R_ST(k_) if (st_on_) asm volatile("s_memtime %0" : "=s"(st_t##k_));
+#define A4R_ST_NEXT                                                                                                              \
+    if (st_on_) {                                                                                                                \
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                                       \
+        unsigned long long* d_ = g_a4r_phase_stamps + (size_t)(((blockIdx.x * 2 + (wave >> 2)) * 8 + st_idx_) * 8);              \
+        d_[0] = st_t0; d_[1] = st_t1; d_[2] = st_t2; d_[3] = st_t3; d_[4] = st_t4; d_[5] = st_t5; d_[6] = st_t6;                  \
+    }                                                                                                                            \
+    ++st_idx_;
+#define A4R_ST_TILE_DONE ++st_tile_;
+#else
+#define A4R_ST_BEGIN(u_)
 #define A4R_ST(k_)
 #define A4R_ST_NEXT
+#define A4R_ST_TILE_DONE
+#endif
 
 namespace {
 
@@ -218,11 +242,11 @@ A4R_DEV void gemm256_tiles(const a4r_gemm_t& p, char* lds, int ntm, int ntn, int
 #define A4R_RD_A(dst_, buf_, unit_)                                                                   \
     _Pragma("unroll") for (int mi = 0; mi < 4; ++mi)                                                  \
         _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                              \
-            dst_[mi][ks] = *reinterpret_cast<const uint4*>(lds + ((buf_) * 4 + (unit_)) * UNIT_BYTES + a_off[mi][ks]);
+            dst_[mi][ks] = *reinterpret_cast<const uint4*>((lds + a_base[buf_][ks]) + ((unit_) * UNIT_BYTES + mi * 2048));
 #define A4R_RD_B(dst_, buf_, unit_)                                                                   \
     _Pragma("unroll") for (int ni = 0; ni < 2; ++ni)                                                  \
         _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                              \
-            dst_[ni][ks] = *reinterpret_cast<const uint4*>(lds + ((buf_) * 4 + (unit_)) * UNIT_BYTES + b_off[ni][ks]);
+            dst_[ni][ks] = *reinterpret_cast<const uint4*>((lds + b_base[buf_][ks]) + ((unit_) * UNIT_BYTES + ni * 2048));
     // e4m3 operands: ONE block-scaled v_mfma_scale_f32_16x16x128_f8f6f4 per output tile and K-tile (the 2 x 16 bytes a lane holds of a
     // 128-byte K-tile row are its 32-element K block; both operands use the same byte -> contraction-slot map, so the products pair the
     // right elements).  The E8M0 block scales are all 2^0: the per-token / per-channel fp32 scales stay in the epilogue, the instruction
@@ -262,7 +286,7 @@ A4R_DEV void gemm256_tiles(const a4r_gemm_t& p, char* lds, int ntm, int ntn, int
 #ifndef A4R_ABL
 #define A4R_ABL 0          /* timing-only diagnostic builds (tools/gemm_abl.sh): 1 no DMA, 2 no MFMA, 4 no fragment reads, 8 no barriers, 16 no setprio */
 #endif
-#define A4R_PHASE(reads_, issue_, full_, tail_, ax_, bx_, m0_, n0_, z_, lim_)                          \
+#define A4R_PHASE(reads_, issue_, full_, cnt_, tail_, ax_, bx_, m0_, n0_, z_, lim_)                    \
     A4R_ST(0)                                                                                         \
     if (z_) {                      /* first K-tile of an output tile: this phase's quarter of the accumulators starts from zero */ \
         _Pragma("unroll") for (int mi = 0; mi < 4; ++mi)                                              \
@@ -274,7 +298,7 @@ A4R_DEV void gemm256_tiles(const a4r_gemm_t& p, char* lds, int ntm, int ntn, int
     A4R_ST(1)                                                                                         \
     if (z_ && A4R_Z0_NOWAIT) { /* first K-tile of an output tile: every unit read before K-tile 1's phase 1 was issued BEFORE the previous */ \
     } /* tile's stores and has landed (counted wait + barrier at the top of the tile): no wait, the stores keep draining for these 4 phases */ \
-    else if (full_) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");                                  \
+    else if (full_) asm volatile("s_waitcnt vmcnt(" cnt_ ")" ::: "memory");                           \
     else asm volatile("s_waitcnt vmcnt(" tail_ ")" ::: "memory");                                     \
     A4R_ST(2)                                                                                         \
     if (!(A4R_ABL & 8)) __builtin_amdgcn_s_barrier();                                                 \
@@ -294,35 +318,61 @@ A4R_DEV void gemm256_tiles(const a4r_gemm_t& p, char* lds, int ntm, int ntn, int
     A4R_ST(6)                                                                                         \
     A4R_ST_NEXT
     // K-tile u from ring buffer buf_ (compile-time).  n1 = a K-tile u+1 exists, n2 = u+2 exists (A4R_ISSUE skips what does not).
+#ifndef A4R_DMA_SCHED
+#define A4R_DMA_SCHED 1
+#endif
+#if A4R_DMA_SCHED == 0
 #define A4R_KTILE(u_, buf_)                                                                                                         \
     {                                                                                                                               \
         const bool n1 = (u_) + 1 < nk || has_next, n2 = (u_) + 2 < nk || has_next;                                                                        \
         const bool z0 = (buf_) == 0 && (u_) == 0;                                                                                   \
-        A4R_PHASE(A4R_RD_B(b0, buf_, U_BLO) A4R_RD_A(af, buf_, U_ALO), A4R_ISSUE(U_BHI, (u_) + 1, Bbase, offB_hi), n1, "2", af, b0, 0, 0, z0, kp_lo) \
-        A4R_PHASE(A4R_RD_B(b1, buf_, U_BHI), A4R_ISSUE(U_AHI, (u_) + 1, Abase, offA_hi), n1, "0", af, b1, 0, 2, z0, kp_lo)          \
-        A4R_PHASE(A4R_RD_A(af, buf_, U_AHI), A4R_ISSUE(U_ALO, (u_) + 2, Abase, offA_lo), n2, "4", af, b1, 4, 2, z0, kp_hi)          \
-        A4R_PHASE(, A4R_ISSUE(U_BLO, (u_) + 2, Bbase, offB_lo), n2, "4", af, b0, 4, 0, z0, kp_hi)                                   \
+        A4R_ST_BEGIN(u_)                                                                                                            \
+        asm volatile("" : "+v"(a_base[buf_][0]), "+v"(a_base[buf_][1]), "+v"(b_base[buf_][0]), "+v"(b_base[buf_][1]));              \
+        A4R_PHASE(A4R_RD_B(b0, buf_, U_BLO) A4R_RD_A(af, buf_, U_ALO), A4R_ISSUE(U_BHI, (u_) + 1, Bbase, offB_hi), n1, "8", "2", af, b0, 0, 0, z0, kp_lo) \
+        A4R_PHASE(A4R_RD_B(b1, buf_, U_BHI), A4R_ISSUE(U_AHI, (u_) + 1, Abase, offA_hi), n1, "8", "0", af, b1, 0, 2, z0, kp_lo)     \
+        A4R_PHASE(A4R_RD_A(af, buf_, U_AHI), A4R_ISSUE(U_ALO, (u_) + 2, Abase, offA_lo), n2, "8", "4", af, b1, 4, 2, z0, kp_hi)     \
+        A4R_PHASE(, A4R_ISSUE(U_BLO, (u_) + 2, Bbase, offB_lo), n2, "8", "4", af, b0, 4, 0, z0, kp_hi)                              \
     }
+#else
+    // A4R_DMA_SCHED 1 (A/B builds): the DMA issues sit in the two phases with the fewest fragment reads (4 and 0 instead of 12 / 4 / 8 / 0):
+    // phase 1 issues B_hi, A_hi of K-tile u + 1, phase 3 A_lo, B_lo of u + 2 -- the same unit stream.  Counted waits (queue after the phase's
+    // issues, oldest first): phase 0 [B_hi A_hi (u+1) | A_lo B_lo (u+2)] must retire B_hi -> vmcnt(6); phase 1 [A_hi(u+1) A_lo B_lo (u+2) B_hi A_hi (u+2)]
+    // must retire A_hi -> vmcnt(8); phase 2 reads nothing new in phase 3 -> no wait; phase 3 [B_hi A_hi (u+1) A_lo B_lo (u+2)] must retire
+    // A_lo, B_lo (u+1) -> vmcnt(8).  WAR: every slot is re-filled >= 2 phases after its last read (B_hi: phase 1 of u-1, A_hi: 2 of u-1, A_lo / B_lo: 0 of u).
+#define A4R_KTILE(u_, buf_)                                                                                                         \
+    {                                                                                                                               \
+        const bool n1 = (u_) + 1 < nk || has_next, n2 = (u_) + 2 < nk || has_next;                                                                        \
+        const bool z0 = (buf_) == 0 && (u_) == 0;                                                                                   \
+        A4R_ST_BEGIN(u_)                                                                                                            \
+        asm volatile("" : "+v"(a_base[buf_][0]), "+v"(a_base[buf_][1]), "+v"(b_base[buf_][0]), "+v"(b_base[buf_][1]));              \
+        A4R_PHASE(A4R_RD_B(b0, buf_, U_BLO) A4R_RD_A(af, buf_, U_ALO), , n1, "6", "2", af, b0, 0, 0, z0, kp_lo)                     \
+        A4R_PHASE(A4R_RD_B(b1, buf_, U_BHI), A4R_ISSUE(U_BHI, (u_) + 1, Bbase, offB_hi) A4R_ISSUE(U_AHI, (u_) + 1, Abase, offA_hi), n1, "8", "0", af, b1, 0, 2, z0, kp_lo) \
+        A4R_PHASE(A4R_RD_A(af, buf_, U_AHI), , true, "63", "63", af, b1, 4, 2, z0, kp_hi)                                           \
+        A4R_PHASE(, A4R_ISSUE(U_ALO, (u_) + 2, Abase, offA_lo) A4R_ISSUE(U_BLO, (u_) + 2, Bbase, offB_lo), n2, "8", "0", af, b0, 4, 0, z0, kp_hi) \
+    }
+#endif
 
     f32x4_t acc[8][4];
+#ifdef A4R_PHASE_STAMP
+    int st_tile_ = 0;
+#endif
 
-    // fragment addressing (unit-local): A rows wm*64 + mi4*16 + (lane&15), B rows wn*32 + ni2*16 + (lane&15)
+    // fragment addressing (unit-local): A rows wm*64 + mi*16 + (lane&15), B rows wn*32 + ni*16 + (lane&15).  The swizzle term (row >> 1) & 7 only
+    // depends on lane & 15 (the wave's and the tile's row offsets are multiples of 16), so a fragment's address is ONE per-lane base per K-half
+    // + a compile-time constant (ring buffer, unit, mi / ni * 2048): the constants ride in the ds_read offset field instead of a v_add per read
+    // in every LOAD segment (12 address registers and ~10 vector instructions per phase, issued next to the partner wave's MFMAs).
     const int fr = lane & 15, kg = lane >> 4;
-    int a_off[4][2], b_off[2][2];
+    // (one base per ring buffer: the offset field holds 16 bits.  The bases are laundered once per K-tile: as loop invariants, hipcc hoists
+    // every base + constant into a register of its own)
+    uint32_t a_base[2][2], b_base[2][2];
 #pragma unroll
-    for (int mi = 0; mi < 4; ++mi)
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            const int row = wm * 64 + mi * 16 + fr, ch = ks * 4 + kg;
-            a_off[mi][ks] = row * ROWB + ((ch ^ ((row >> 1) & 7)) << 4);
-        }
-#pragma unroll
-    for (int ni = 0; ni < 2; ++ni)
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            const int row = wn * 32 + ni * 16 + fr, ch = ks * 4 + kg;
-            b_off[ni][ks] = row * ROWB + ((ch ^ ((row >> 1) & 7)) << 4);
-        }
+    for (int ks = 0; ks < 2; ++ks) {
+        const int sw = (((ks * 4 + kg) ^ ((fr >> 1) & 7)) << 4);
+        a_base[0][ks] = (uint32_t)((wm * 64 + fr) * ROWB + sw);
+        b_base[0][ks] = (uint32_t)((wn * 32 + fr) * ROWB + sw);
+        a_base[1][ks] = a_base[0][ks] + 4u * UNIT_BYTES;
+        b_base[1][ks] = b_base[0][ks] + 4u * UNIT_BYTES;
+    }
 
     // ---- prologue of a tile: the first 6 units in stream order (K-tile 0 and A_lo, B_lo of K-tile 1)
 #define A4R_PROLOGUE_AT(Ab_, alo_, ahi_, Bb_)    \
@@ -383,6 +433,7 @@ A4R_DEV void gemm256_tiles(const a4r_gemm_t& p, char* lds, int ntm, int ntn, int
         if (u + 1 < nk) A4R_KTILE(u + 1, 1)
     }
     if (wave < 4 && !(A4R_ABL & 8)) __builtin_amdgcn_s_barrier();           // re-align: all LDS reads of this tile are complete, the ring is free
+    A4R_ST_TILE_DONE
     asm volatile("" ::: "memory");
     A4R_LOOP_STAMP(1)
     A4R_TLT(2)
