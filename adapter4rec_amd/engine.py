@@ -298,9 +298,16 @@ class TransRecEngine:
         more = _os.environ.get('A4R_FP8_MORE', '1') != '0'              # 0: round 2's coverage (forward qkv + FFN-up only; A/B runs)
         for b in self.bert_blocks:
             b.wqkv8 = b.wi8 = b.wo8 = b.wo28 = b.wo2T8 = b.wiT8 = None
+            b.wqkv8_dyn = False
             frozen_qkv = not b.lora and all(d is not None and not d.trainable for d in b.qkv)
             if frozen_qkv and ok(b.wqkv):
                 b.wqkv8, b.wqkv8s = L.quantize_weight_fp8(b.wqkv)
+            elif more and b.lora and all(d is None or not d.trainable for d in b.qkv) and ok(b.wqkv):       # (None: a LoRA-carrying slot)
+                # LoRA on q / v (configs[2]): the FORWARD operand is the merged W + B A / r, re-quantised after every merge (pack_trainables:
+                # one row pass over [3H, H] per layer); the LoRA gradients and dx keep using the bf16 operands
+                b.wqkv8 = torch.zeros(b.wqkv.shape, dtype=torch.uint8, device=b.wqkv.device)
+                b.wqkv8s = torch.zeros(b.wqkv.shape[0], dtype=torch.float32, device=b.wqkv.device)
+                b.wqkv8_dyn = True
             if not b.d_i.trainable and ok(b.wi):
                 b.wi8, b.wi8s = L.quantize_weight_fp8(b.wi)
             if more and not b.d_o.trainable and ok(b.wo):
@@ -500,6 +507,10 @@ class TransRecEngine:
             self._lora_tabs = [L.lora_table(ents, self.dev) for ents in groups.values()]
         for tab in self._lora_tabs:
             L.lora_merge_batch(tab)
+        if self.fp8:
+            for blk in self.bert_blocks:
+                if getattr(blk, 'wqkv8_dyn', False):
+                    L.quant_rows_fp8(blk.wqkv, blk.wqkv8, blk.wqkv8s.view(-1, 1))
         if self._virtual:
             if self._phm_tab is not None:                     # Compacter: effective matrices from (phm_rule, W_left, W_right), one launch
                 L.phm_build(self.flat_p, self._phm_tab, self._phm_n, self._virt_flat)

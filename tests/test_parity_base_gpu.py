@@ -177,7 +177,7 @@ def test_vit_base_geometry_step_vs_oracle(kind):
     out, grads = R.loss_and_grads(osd, [strip(n) for n in names], R.normalize_u8(u8), mask, ocfg)
     ref_loss, ref_emb = float(out['loss'].detach()), out['input_embs_all'].detach()
     res = {}
-    for dtype in ('fp32', 'bf16') + (('fp8',) if mae else ()):
+    for dtype in ('fp32', 'bf16', 'fp8'):             # fp8: the e4m3 encoder (configs[4]; on ViT + LoRA the merged qkv operand is re-quantised per step)
         inner.compute_dtype = dtype
         inner.invalidate_native()
         for p in root.parameters():
@@ -187,6 +187,9 @@ def test_vit_base_geometry_step_vs_oracle(kind):
         nz = noise.to(DEV) if noise is not None else None
         loss = inner(u8.to(DEV), mask.to(DEV), DEV, noise=nz) if mae else root(u8.to(DEV), mask.to(DEV), DEV)
         loss.backward()
+        if dtype == 'fp8' and not mae:                   # every layer's qkv ran on the re-quantised merged (W + B A / r) operand
+            eng = inner._native[0]
+            assert eng is not None and eng.fp8 and all(b.wqkv8 is not None and b.wqkv8_dyn for b in eng.bert_blocks)
         with torch.no_grad():
             emb = (inner.cv_encoder(u8.to(DEV), noise=nz) if mae else inner.cv_encoder(u8.to(DEV))).cpu()
         g = {strip(n): p.grad.detach().cpu().clone() for n, p in root.named_parameters() if p.requires_grad}
@@ -199,9 +202,8 @@ def test_vit_base_geometry_step_vs_oracle(kind):
     assert f['grad'] < (2e-3 if mae else 1e-4), f
     b = res['bf16']                                      # measured on MI355X, ~2x headroom
     assert b['loss'] < 3e-2 and b['emb'] < 4e-2 and b['grad'] < 0.25, b
-    if mae:
-        q = res['fp8']
-        assert q['loss'] < 8e-2 and q['emb'] < 0.1 and q['grad'] < 0.5, q
+    q = res['fp8']
+    assert q['loss'] < (8e-2 if mae else 0.2) and q['emb'] < (0.1 if mae else 0.15) and q['grad'] < 0.5, q       # (197 tokens per item, no adapters: measured 0.136 / 0.074 / 0.235)
 
 
 def build_eval_case(n_items=2000, n_users=600, seed=5):
