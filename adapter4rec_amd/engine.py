@@ -291,9 +291,8 @@ class TransRecEngine:
         c_du = FP8_DU_MARGIN x max_c |W2[:, c]|_2 -- |du[m, c]| <= |d_o[m]|_2 |W2[:, c]|_2 1.13 <= 31 x absmax(d_o[m]) |W2[:, c]|_2 at the very
         worst (all elements equal and aligned), ~1.2 x typically: with the margin at 16 a typical element is stored near 8 (of 448) and e4m3,
         being floating point, loses no precision to the head-room."""
-        if not hasattr(self.bert_blocks[0], 'lnA'):
-            raise NotImplementedError("compute_dtype 'fp8' is wired for the image tower (pre-LN ViT / ViT-MAE: both fp8 GEMM inputs are "
-                                      'LayerNorm outputs); the text tower runs bf16')
+        # (pre-LN image tower: engine_vit.py -- both fp8 GEMM inputs are LayerNorm outputs; post-LN text tower: _block_forward below -- the
+        # block input and the attention-output sub-layer's LayerNorm output leave the fused adapter kernel as e4m3 + row scale)
         ok = lambda w: w.shape[0] % 256 == 0 and w.shape[1] % 128 == 0
         more = _os.environ.get('A4R_FP8_MORE', '1') != '0'              # 0: round 2's coverage (forward qkv + FFN-up only; A/B runs)
         for b in self.bert_blocks:
@@ -929,18 +928,27 @@ class TransRecEngine:
         return t if hv == t.shape[1] else t[:, :hv]
 
     # ------------------------------------------------------------------ one block, forward
-    def _sub_forward(self, blk, which, dense_in, w, bias, resid, ln, ad, pl, lnn, bufs, M, p_drop, site, seed, out):
-        """dense -> dropout -> [adapter] -> LN(residual + .)  for the attention-output (which='1') or FFN-output ('2') half."""
+    def _sub_forward(self, blk, which, dense_in, w, bias, resid, ln, ad, pl, lnn, bufs, M, p_drop, site, seed, out, scales=None, out8=None):
+        """dense -> dropout -> [adapter] -> LN(residual + .)  for the attention-output (which='1') or FFN-output ('2') half.
+        scales = (scale_a, scale_b): dense_in / w are e4m3 operands (fp8 encoder).  out8 = (q, scale): `out` is ALSO wanted as e4m3 rows +
+        per-row scales (the next fp8 GEMM's A operand): written by the fused adapter kernel, by one more row pass everywhere else."""
         h, v, st = bufs['h' + which], bufs.get('v' + which), bufs['st' + which]        # v None: this sub-layer keeps y (`out` IS bufs['y' + which])
         assert v is not None or out.data_ptr() == bufs['y' + which].data_ptr()
+        sk = dict(scale_a=scales[0], scale_b=scales[1]) if scales is not None else {}
+        y8, ys = out8 if out8 is not None else (None, None)
+        if not (ad is not None and pl not in ('pfeiffer', 'parallel') and self._fuse(blk, ad, h)):
+            if out8 is not None:                   # (not the one-launch kernel: quantise `out` afterwards)
+                self._sub_forward(blk, which, dense_in, w, bias, resid, ln, ad, pl, lnn, bufs, M, p_drop, site, seed, out, scales=scales)
+                L.quant_rows_fp8(out, y8, ys, M=M)
+                return
         if ad is None:
-            L.gemm_nt(dense_in, w, v, bias=bias, R1=resid, drop_p=p_drop, drop_site=site, drop_seed=seed, drop_first=True, M=M)
+            L.gemm_nt(dense_in, w, v, bias=bias, R1=resid, drop_p=p_drop, drop_site=site, drop_seed=seed, drop_first=True, M=M, **sk)
             L.ln_fwd(self._vc(blk, v), ln.gamma, ln.beta, ln.eps, self._vc(blk, out), st, M=M)
             return
         zp, z = bufs['zp' + which], bufs['z' + which]
         if pl == 'pfeiffer':          # model.py:321-329 / :458-471
             va, t, sta = bufs['va' + which], bufs['t' + which], bufs['sta' + which]
-            L.gemm_nt(dense_in, w, va, bias=bias, R1=resid, drop_p=p_drop, drop_site=site, drop_seed=seed, drop_first=True, M=M)   # h + input
+            L.gemm_nt(dense_in, w, va, bias=bias, R1=resid, drop_p=p_drop, drop_site=site, drop_seed=seed, drop_first=True, M=M, **sk)   # h + input
             L.ln_fwd(va, ln.gamma, ln.beta, ln.eps, t, sta, M=M)
             if self._fuse(blk, ad, t):
                 L.adapter_ln_fwd(t, va, None, ad.wd, ad.bd, ad.wu, ad.bu, lnn.gamma, lnn.beta, lnn.eps, ad.act, zp, z, v, out, st, M=M)
@@ -950,16 +958,16 @@ class TransRecEngine:
             L.ln_fwd(v, lnn.gamma, lnn.beta, lnn.eps, out, st, M=M)
             return
         if pl == 'parallel':          # model.py:265-270 / :474-520: LN(adapter(input) + dense_out + input), adapter has its inner residual
-            L.gemm_nt(dense_in, w, h, bias=bias, R1=resid, drop_p=p_drop, drop_site=site, drop_seed=seed, drop_first=True, M=M)   # h + input
+            L.gemm_nt(dense_in, w, h, bias=bias, R1=resid, drop_p=p_drop, drop_site=site, drop_seed=seed, drop_first=True, M=M, **sk)   # h + input
             L.gemm_nt(resid, ad.wd, z, bias=ad.bd, C2=zp, act=ad.act, M=M)
             L.gemm_nt(z, ad.wu, v, bias=ad.bu, R1=h, R2=resid, M=M)          # up + (h + input) + input
             L.ln_fwd(v, ln.gamma, ln.beta, ln.eps, out, st, M=M)
             return
-        L.gemm_nt(dense_in, w, h, bias=bias, drop_p=p_drop, drop_site=site, drop_seed=seed, M=M)
+        L.gemm_nt(dense_in, w, h, bias=bias, drop_p=p_drop, drop_site=site, drop_seed=seed, M=M, **sk)
         comp = ad.kind == 'compacter'  # no inner residual (modules.py:248-252); Houlsby: fc_up(act(fc_down(h))) + h, then + input (model.py:292-297)
         if self._fuse(blk, ad, h):     # ONE launch: down-projection, activation, up-projection, residual(s), LayerNorm (a4r_adapter_fused.hip)
             L.adapter_ln_fwd(h, resid if comp else h, None if comp else resid, ad.wd, ad.bd, ad.wu, ad.bu, ln.gamma, ln.beta, ln.eps, ad.act,
-                             zp, z, v, out, st, M=M)
+                             zp, z, v, out, st, M=M, y8=y8, ys=ys)
             return
         L.gemm_nt(h, ad.wd, z, bias=ad.bd, C2=zp, act=ad.act, M=M)
         if comp:
@@ -975,13 +983,22 @@ class TransRecEngine:
         """The one-launch adapter kernels apply (bf16, bottleneck 64, a width they are instantiated for, no zero-padded block)."""
         return self.fuse_adapters and getattr(blk, 'Hv', blk.H) == blk.H and L.adapter_ln_ok(t, ad.dp)
 
-    def _block_forward(self, blk, x, key_mask, n_items, M, bufs, train, seed, x_out, cls_rows=None):
+    def _block_forward(self, blk, x, key_mask, n_items, M, bufs, train, seed, x_out, cls_rows=None, x8=None, want8=False):
         """cls_rows = Ip: after attention only row 0 of every item (the CLS token, all the item head reads,
-        model/encoders.py:55) is carried through attention-output, FFN and adapters: x_out is then [Ip, H]."""
+        model/encoders.py:55) is carried through attention-output, FFN and adapters: x_out is then [Ip, H].
+        fp8 encoder (post-LN text tower): x8 = (e4m3 rows, row scales) of x when the layer below produced them; want8: return the same
+        for x_out (None otherwise).  Frozen qkv / attention-output / FFN-up / FFN-down run on e4m3 operands, everything else as in bf16."""
         T, H = blk.T, blk.H
         pa = blk.p_attn if train else 0.0
         ph = blk.p_hidden if train else 0.0
-        L.gemm_nt(x, blk.wqkv, bufs['qkv'], bias=blk.bqkv, M=M)
+        f8 = self.fp8 and T == torch.bfloat16 and M % 256 == 0 and getattr(blk, 'wqkv8', None) is not None
+        if f8:
+            if x8 is None:
+                x8 = (self._buf('x8', M, H, torch.uint8), self._buf('x8s', M, 1, torch.float32))
+                L.quant_rows_fp8(x, x8[0], x8[1], M=M)
+            L.gemm_nt(x8[0], blk.wqkv8, bufs['qkv'], bias=blk.bqkv, M=M, scale_a=x8[1], scale_b=blk.wqkv8s)
+        else:
+            L.gemm_nt(x, blk.wqkv, bufs['qkv'], bias=blk.bqkv, M=M)
         if 'xin' in bufs:
             L.gather_rows(x, bufs['xin'], M, 1)      # LoRA backward needs the block input (t = x A^T, dA = dt^T x)
         if getattr(blk, 'long', False):
@@ -1006,11 +1023,35 @@ class TransRecEngine:
             if 'x1s' in bufs:
                 raise RuntimeError('y1 and x1s are the same tensor: one of them should not have been allocated')
             x1 = bufs['y1']
-        self._sub_forward(blk, '1', ctx, blk.wo, blk.bo, x, blk.ln1, blk.ad1, blk.pl1, blk.lnn1, bufs, M, ph, blk.site + 1, seed, x1)
+        f8 = self.fp8 and T == torch.bfloat16 and M % 256 == 0             # (M: the CLS rows in the last layer)
+        f8_o = f8 and getattr(blk, 'wo8', None) is not None and 'ctx_s' not in bufs
+        f8_up = f8 and getattr(blk, 'wi8', None) is not None and blk.ffn_act == L.ACT_GELU
+        f8_ffn = f8_up and getattr(blk, 'wo28', None) is not None and 'u_s' not in bufs and self._q8(blk)
+        x1_8 = (self._buf('x1_8', M, H, torch.uint8), self._buf('x1_8s', M, 1, torch.float32)) if f8_up else None
+        if f8_o:                                   # the attention output as e4m3 + per-token scale (one row pass), then the fp8 GEMM
+            c8, cs = self._buf('ctx8', M, H, torch.uint8), self._buf('ctx8s', M, 1, torch.float32)
+            L.quant_rows_fp8(ctx, c8, cs, M=M)
+            self._sub_forward(blk, '1', c8, blk.wo8, blk.bo, x, blk.ln1, blk.ad1, blk.pl1, blk.lnn1, bufs, M, ph, blk.site + 1, seed, x1,
+                              scales=(cs, blk.wo8s), out8=x1_8)
+        else:
+            self._sub_forward(blk, '1', ctx, blk.wo, blk.bo, x, blk.ln1, blk.ad1, blk.pl1, blk.lnn1, bufs, M, ph, blk.site + 1, seed, x1, out8=x1_8)
+        out8 = (self._buf('x8', M, H, torch.uint8), self._buf('x8s', M, 1, torch.float32)) if (want8 and f8) else None
+        if f8_ffn:         # FFN-up writes u as e4m3 with a static scale (+ the 8-bit derivative), FFN-down reads it
+            u = self._buf('u8', M, blk.F, torch.uint8)
+            L.gemm_nt(x1_8[0], blk.wi8, u, bias=blk.bi, C2=bufs['upre'], act=L.ACT_GELU, c2_deriv='q8', M=M, scale_a=x1_8[1], scale_b=blk.wi8s,
+                      c_fp8=1, c_scale=self.FP8_U_SCALE, q8_tiled=self._q8t(blk, M))
+            self._sub_forward(blk, '2', u, blk.wo28, blk.bo2, x1, blk.ln2, blk.ad2, blk.pl2, blk.lnn2, bufs, M, ph, blk.site + 2, seed, x_out,
+                              scales=(self._const_rows('su', M, self.FP8_U_SCALE), blk.wo28s), out8=out8)
+            return out8
         u = bufs['u_s'] if 'u_s' in bufs else self._buf('u', M, blk.F, T)
-        L.gemm_nt(x1, blk.wi, u, bias=blk.bi, C2=bufs['upre'], act=blk.ffn_act, c2_deriv='q8' if self._q8(blk) else True, M=M,      # 'upre' holds act'(pre)
-                  q8_tiled=self._q8t(blk, M))
-        self._sub_forward(blk, '2', u, blk.wo2, blk.bo2, x1, blk.ln2, blk.ad2, blk.pl2, blk.lnn2, bufs, M, ph, blk.site + 2, seed, x_out)
+        if f8_up:
+            L.gemm_nt(x1_8[0], blk.wi8, u, bias=blk.bi, C2=bufs['upre'], act=L.ACT_GELU, c2_deriv='q8' if self._q8(blk) else True, M=M,
+                      scale_a=x1_8[1], scale_b=blk.wi8s, q8_tiled=self._q8t(blk, M))
+        else:
+            L.gemm_nt(x1, blk.wi, u, bias=blk.bi, C2=bufs['upre'], act=blk.ffn_act, c2_deriv='q8' if self._q8(blk) else True, M=M,      # 'upre' holds act'(pre)
+                      q8_tiled=self._q8t(blk, M))
+        self._sub_forward(blk, '2', u, blk.wo2, blk.bo2, x1, blk.ln2, blk.ad2, blk.pl2, blk.lnn2, bufs, M, ph, blk.site + 2, seed, x_out, out8=out8)
+        return out8
 
     # ------------------------------------------------------------------ one block, backward
     def _sub_backward(self, blk, which, dy, ln, ad, pl, lnn, bufs, M, p_drop, site, seed):
@@ -1192,11 +1233,22 @@ class TransRecEngine:
             M = cls_rows
         dh2, dres2 = self._sub_backward(blk, '2', dx_out, blk.ln2, blk.ad2, blk.pl2, blk.lnn2, bufs, M, ph, blk.site + 2, seed)
         self._dense_wgrad(blk.d_o2, dh2, bufs.get('u_s'), M)
-        du = self._buf('du', M, F, T)
-        L.gemm_nt(dh2, blk.wo2T, du, Pre=bufs['upre'], dact=L.DACT_MUL_Q8 if self._q8(blk) else L.DACT_MUL, M=M, q8_tiled=self._q8t(blk, M))
-        self._dense_wgrad(blk.d_i, du, bufs.get('x1s'), M)
         dx1 = self._buf('dx1', M, H, T)
-        L.gemm_nt(du, blk.wiT, dx1, R1=dres2, M=M)
+        if (self.fp8 and getattr(blk, 'wo2T8', None) is not None and T == torch.bfloat16 and M % 256 == 0 and bufs['upre'].dtype == torch.uint8
+                and 'u_s' not in bufs):
+            # frozen FFN, both dgrads on e4m3 operands with ONE scale per token row carried through the chain (_build_fp8):
+            #   dh2 -> e4m3 + row scale | du = (dh2 W2) * gelu' leaves its GEMM as e4m3 with scale[m] * c_du | dx1 = du W1 + dres2 (bf16 out)
+            do8, dos = self._buf('do8', M, H, torch.uint8), self._buf('do8s', M, 1, torch.float32)
+            L.quant_rows_fp8(dh2, do8, dos, M=M)
+            du8, dus = self._buf('du8', M, F, torch.uint8), self._buf('du8s', M, 1, torch.float32)
+            L.gemm_nt(do8, blk.wo2T8, du8, Pre=bufs['upre'], dact=L.DACT_MUL_Q8, M=M, scale_a=dos, scale_b=blk.wo2T8s,
+                      c_fp8=2, c_scale=blk.c_du, c_scale_out=dus, q8_tiled=self._q8t(blk, M))
+            L.gemm_nt(du8, blk.wiT8, dx1, R1=dres2, M=M, scale_a=dus, scale_b=blk.wiT8s)
+        else:
+            du = self._buf('du', M, F, T)
+            L.gemm_nt(dh2, blk.wo2T, du, Pre=bufs['upre'], dact=L.DACT_MUL_Q8 if self._q8(blk) else L.DACT_MUL, M=M, q8_tiled=self._q8t(blk, M))
+            self._dense_wgrad(blk.d_i, du, bufs.get('x1s'), M)
+            L.gemm_nt(du, blk.wiT, dx1, R1=dres2, M=M)
         dh1, dres1 = self._sub_backward(blk, '1', dx1, blk.ln1, blk.ad1, blk.pl1, blk.lnn1, bufs, M, ph, blk.site + 1, seed)
         self._dense_wgrad(blk.d_o, dh1, bufs.get('ctx_s'), M)
         qkv_train = any(d is not None and d.trainable for d in blk.qkv)
@@ -1309,17 +1361,19 @@ class TransRecEngine:
         Ip = pad_to(n_items, 128)
         cls = self._buf('cls', Ip, H, self.T)
         last = len(self.bert_blocks) - 1
+        x8 = None                                  # fp8 encoder: (e4m3 rows, row scales) of x, handed from layer to layer
         for i, blk in enumerate(self.bert_blocks):
             cmode = self.cls_only and i == last
             bufs = saved[i] if saved is not None else self._block_bufs('bert.shared', blk, M, True, Mc=Ip if cmode else None)
+            w8 = self.fp8 and i != last
             if cmode:
-                self._block_forward(blk, x, key_mask, n_items, M, bufs, train, seed, cls, cls_rows=Ip)
+                self._block_forward(blk, x, key_mask, n_items, M, bufs, train, seed, cls, cls_rows=Ip, x8=x8)
             elif 'y2' in bufs:                     # the layer's output is kept per layer (backward reads it, _vskip): no ping-pong
-                self._block_forward(blk, x, key_mask, n_items, M, bufs, train, seed, bufs['y2'])
+                x8 = self._block_forward(blk, x, key_mask, n_items, M, bufs, train, seed, bufs['y2'], x8=x8, want8=w8)
                 x = bufs['y2']
             else:
                 out = other if x.data_ptr() != other.data_ptr() else xa_buf       # a transient buffer that is not the current input (x may be a kept y2)
-                self._block_forward(blk, x, key_mask, n_items, M, bufs, train, seed, out)
+                x8 = self._block_forward(blk, x, key_mask, n_items, M, bufs, train, seed, out, x8=x8, want8=w8)
                 x = out
             if not cmode:
                 if (i + 1) in self.bert_klist and i != last:

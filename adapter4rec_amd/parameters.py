@@ -1,5 +1,5 @@
 """Command-line flags of the reference, same spellings and defaults (Downstream/Text/parameters.py:4-86, incl. the
-misspelt default --adapter_type houslby), plus: --compute_dtype {bf16,fp32}, and --local-rank / LOCAL_RANK accepted
+misspelt default --adapter_type houslby), plus: --compute_dtype {bf16,fp32,fp8}, and --local-rank / LOCAL_RANK accepted
 next to --local_rank (torch >= 2.0 launchers pass the hyphenated form)."""
 import argparse
 import os
@@ -71,7 +71,7 @@ def build_parser():
     p.add_argument('--hypercomplex_division', type=int, default=4)
     p.add_argument('--phm_init_range', type=float, default=0.0001)
     # ============= native path ==================
-    p.add_argument('--compute_dtype', type=str, default='bf16', choices=['bf16', 'fp32'],
+    p.add_argument('--compute_dtype', type=str, default='bf16', choices=['bf16', 'fp32', 'fp8'],
                    help='item-encoder storage type on the MI355X path (fp32 = reference precision of Downstream/Text)')
     p.add_argument('--eval_compute_dtype', type=str, default='fp32', choices=['bf16', 'fp32'],
                    help="dtype of eval's item sweep (get_item_embeddings).  Default fp32 = the reference's eval precision: HR@10 / nDCG@10 "

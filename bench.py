@@ -323,7 +323,8 @@ def main():
     ap.add_argument('--workload', default='bert_houlsby', choices=list(WORKLOADS),
                     help="bert_houlsby = the configuration BASELINE.json's metric is quoted on; the others are its remaining configs")
     ap.add_argument('--dtype', default='bf16', choices=['bf16', 'fp32', 'fp8'],
-                    help='fp8 (image workloads): bf16 storage + OCP e4m3 operands for the frozen encoder\'s qkv / FFN-up forward GEMMs')
+                    help='fp8: bf16 storage + OCP e4m3 operands (block-scaled MFMA rate) for the frozen encoder\'s qkv / attention-output / FFN forward GEMMs and the FFN dgrads, '
+                         'text and image towers (BASELINE.json quotes the headline in bf16: the default)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-roofline', action='store_true')
     ap.add_argument('--gemm-variant', type=int, default=-1, help='A/B knob of a4r_gemm_variant (include/a4r.h); default: the library default')

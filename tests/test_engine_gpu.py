@@ -345,3 +345,76 @@ def test_step_bf16_vs_reference_autocast(name):
     assert d_hip['loss'] <= 2.0 * d_ac['loss'] + 1e-2, (d_hip, d_ac)
     assert med <= 2.0 and p90 <= 3.0, (med, p90)
     assert d_hip['grad'] <= 3.0 * d_ac['grad'] + 5e-3 and d_hip['grad'] < 0.12, (d_hip, d_ac)
+
+
+def _text_fp8_case(dev, adapter_type='houslby', act='GELU'):
+    """fp8 encoder on the post-LN text tower at a geometry where every e4m3 GEMM engages (H = 256: qkv [768, 256], attention-output
+    [256, 256], FFN [512, 256] / [256, 512]; 2 layers, 4 heads of 64): fp8 vs bf16 vs the fp32 oracle on the same conditioned weights.
+    Reference op: HF BertLayer inside Downstream/Text/model/encoders.py:39-56 (the reference has no reduced-precision text path)."""
+    from adapter4rec_amd.inject import freeze_all, inject_adapters
+    from adapter4rec_amd.model import BertBackbone, Model
+    from oracle import ref_cpu as R
+    geom = dict(GEOM, hidden_size=256, num_attention_heads=4, intermediate_size=512)
+    args = make_args(compute_dtype='fp32', word_embedding_dim=256, bert_model_load='bert_mini', adapter_type=adapter_type, adapter_activation=act)      # ('mini': width 256, model.py:23)
+    torch.manual_seed(7)
+    model = Model(args, 60, True, BertBackbone(geom))
+    freeze_all(model)
+    model = inject_adapters(model, args)
+    with torch.no_grad():
+        for n, p in model.named_parameters():
+            if p.requires_grad:
+                p.add_(0.02 * torch.randn_like(p))
+            if n.endswith('title.fc.weight') or n.endswith('title.fc.bias'):
+                p.mul_(0.25)                                  # O(1) scores (see condition())
+    model.eval()
+    g = torch.Generator().manual_seed(2)
+    B, Lh, S = 3, 21, 30
+    ids = torch.zeros(B, Lh, 2, 2 * S, dtype=torch.int64)
+    mask = torch.zeros(B, Lh - 1)
+    for u in range(B):
+        n = Lh if u == 0 else 6 + 5 * u
+        for slot in range(Lh - n, Lh):
+            for side in range(2):
+                if side == 1 and slot == Lh - 1:
+                    continue
+                ln = int(torch.randint(5, S + 1, (1,), generator=g))
+                ids[u, slot, side, :ln] = torch.randint(1, 120, (ln,), generator=g)
+                ids[u, slot, side, S:S + ln] = 1
+        mask[u, Lh - n:] = 1
+    items = ids.view(-1, 2 * S)
+    sd = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    names = [n for n, p in model.named_parameters() if p.requires_grad]
+    cfg = dict(R.DEFAULT_CFG, adapter_type=adapter_type, adapter_activation=act, bert_heads=4)
+    out, grads = R.loss_and_grads(sd, names, items, mask, cfg)
+    ref_loss = float(out['loss'].detach())
+    res = {}
+    for dtype in ('bf16', 'fp8'):
+        model.compute_dtype = dtype
+        model.invalidate_native()
+        for p in model.parameters():
+            p.grad = None
+        model.to(dev)
+        loss = model(items.to(dev), mask.to(dev), dev)
+        loss.backward()
+        if dtype == 'fp8':
+            eng = model._engine()
+            assert eng.fp8 and all(b.wqkv8 is not None and b.wo8 is not None and b.wi8 is not None and b.wo28 is not None and b.wo2T8 is not None
+                                   for b in eng.bert_blocks)
+        with torch.no_grad():
+            emb = model.bert_encoder(items.to(dev)).cpu()
+        worst = 0.0
+        for n, p in model.named_parameters():
+            if p.requires_grad:
+                r = grads[n]
+                worst = max(worst, float((p.grad.cpu() - r).abs().max() / r.abs().max().clamp_min(1e-30)))
+        res[dtype] = (abs(float(loss.detach()) - ref_loss), float((emb - out['input_embs_all'].detach()).abs().max()), worst)
+        model.cpu()
+    print(f'text fp8 encoder vs fp32 oracle ({adapter_type}): loss / emb / worst-gradient error bf16 {res["bf16"]}, fp8 {res["fp8"]} (loss {ref_loss:.4f})')
+    assert res['bf16'][0] < 3e-2 and res['bf16'][1] < 3e-2 and res['bf16'][2] < 0.15, res
+    assert res['fp8'][0] < 8e-2 and res['fp8'][1] < 0.1 and res['fp8'][2] < 0.4, res
+    return res
+
+
+@pytest.mark.parametrize('adapter_type', ['houslby', 'pfeiffer'])
+def test_text_fp8_encoder_gpu(adapter_type):
+    _text_fp8_case('cuda:0', adapter_type)

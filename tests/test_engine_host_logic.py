@@ -267,3 +267,9 @@ def test_host_logic_optimizer_checkpoint_interchange(simulated):
     assert getattr(root2, 'model', root2)._engine().step_count == 3
     for k, v in after3.items():
         torch.testing.assert_close(root2.state_dict()[k], v, rtol=0, atol=0)
+
+
+@pytest.mark.parametrize('adapter_type', ['houslby', 'pfeiffer'])
+def test_host_logic_text_fp8_encoder(simulated, adapter_type):
+    """The fp8 wiring of the post-LN text tower (e4m3 rows handed from layer to layer, FFN dgrad chain) through the CPU restatement."""
+    TG._text_fp8_case('cpu', adapter_type)
