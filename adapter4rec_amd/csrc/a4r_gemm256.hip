@@ -7,15 +7,16 @@
 //     A_lo = tile rows {0-63, 128-191}   (the upper 64 rows of both M-halves of waves)      A_hi = rows {64-127, 192-255}
 //     B_lo = B rows 64w + [0,32)                                                             B_hi = 64w + [32,64)
 // held in a 2-deep ring (2 x 64 KiB of LDS) filled by LDS-DMA (global_load_lds_dwordx4 through inline asm: hipcc neither counts
-// it nor drains it) that stays IN FLIGHT ACROSS BARRIERS: every phase issues ONE unit (2 DMA per wave) and waits with a COUNTED
-// vmcnt(8) -- all but the newest four units have landed -- so a unit has ~5 phases (>1 K-tile) to arrive.  Stream order
-// A_lo(t), B_lo(t), B_hi(t), A_hi(t), A_lo(t+1), ...; the XOR swizzle c ^ ((r >> 1) & 7) is applied on the DMA SOURCE address and
+// it nor drains it) that stays IN FLIGHT ACROSS BARRIERS behind COUNTED vmcnt waits -- all but the newest three or four units have landed --
+// so a unit has 3 - 4 phases (~1 K-tile) to arrive.  Stream order A_lo(t), B_lo(t), B_hi(t), A_hi(t), A_lo(t+1), ...; since round 3 the
+// issues sit in the two phases with the fewest fragment reads (phase 1: B_hi, A_hi of t+1; phase 3: A_lo, B_lo of t+2; A4R_DMA_SCHED below --
+// 0 = one unit per phase, the round-2 schedule the hazard notes of this header were first written for).  The XOR swizzle c ^ ((r >> 1) & 7) is applied on the DMA SOURCE address and
 // on the fragment read (the LDS image itself is lane-linear), which makes the ds_read_b128 of the fragments conflict-free.
 //
 // Schedule: a PING-PONG between the two waves of every SIMD.  A K-tile is four phases, one output quadrant of the wave each:
 //     (A_lo,B_lo) (A_lo,B_hi) (A_hi,B_hi) (A_hi,B_lo)
 // and a phase is, for every wave, the same straight code
-//     LOAD segment : ds_read this phase's new fragments (12 / 4 / 8 / 0 reads) | issue one unit's DMA | s_waitcnt vmcnt(8)
+//     LOAD segment : ds_read this phase's new fragments (12 / 4 / 8 / 0 reads) | issue 0 / 2 / 0 / 2 units' DMA | counted s_waitcnt vmcnt
 //     s_barrier | s_waitcnt lgkmcnt(0) | s_setprio 1 | 16 MFMA | s_setprio 0 | s_barrier
 // Waves 4-7 execute ONE extra s_barrier before the loop (waves 0-3 one after it), so the two halves run exactly one barrier
 // apart: while waves 0-3 are in their MFMA segment, waves 4-7 are in their LOAD segment and vice versa.  Each SIMD's matrix
@@ -26,8 +27,9 @@
 //   RAW  a unit read in phase p is retired by every wave's counted wait in LOAD_(p-1): both halves execute that wait before a
 //        barrier the reader passes before LOAD_p.  Phase 0 reads A_lo, B_lo (retired in phase 3 of the previous K-tile),
 //        phase 1 B_hi (phase 0), phase 2 A_hi (phase 1).
-//   WAR  a slot is re-filled no earlier than two phases after its last read: phase 0 issues B_hi(t+1) (slot last read in phase 1
-//        of t-1), phase 1 A_hi(t+1) (phase 2 of t-1), phase 2 A_lo(t+2) (phase 0 of t), phase 3 B_lo(t+2) (phase 0 of t).
+//   WAR  a slot is re-filled no earlier than two phases after its last read: phase 1 issues B_hi(t+1) (slot last read in phase 1
+//        of t-1) and A_hi(t+1) (phase 2 of t-1), phase 3 A_lo(t+2) and B_lo(t+2) (both last read in phase 0 of t).
+//   RAW  under A4R_DMA_SCHED 1: see the counted waits next to A4R_KTILE.
 //
 // Between output tiles (a workgroup is persistent and walks 2 - 8 tiles per launch; tools/gemm_timeline.py stamps this part):
 //   * the unit stream does NOT stop at the end of a tile's K range: with an even K-tile count the issue slots of the last two
