@@ -424,6 +424,17 @@ A4R_DEV void gemm256_tiles(const a4r_gemm_t& p, char* lds, int ntm, int ntn, int
     // (the accumulators are zeroed quarter by quarter inside the LOAD segments of the first K-tile's four phases, next to the partner
     // wave's MFMA segment: 128 v_mov per wave in front of the loop were 0.5 us per tile during which neither wave of a SIMD issued MFMAs)
     const int tm_done = tm, tn_done = tn;
+    // EF bit 32 (the `* 8-bit derivative` dgrad with a tile-native derivative tensor): the tile's whole Pre operand -- 16 x 8 bytes per lane --
+    // is requested HERE, in front of the K loop, and waits in 32 registers: its HBM time (124 MB per launch at B = 32) falls into the K loop,
+    // which leaves HBM idle, instead of into the epilogue, where the matrix pipe idles.  In order with the unit stream: the counted wait of
+    // K-tile 1 retires these loads too (they are ~1.4 us old by then).
+    constexpr bool PRE_TOP = !TAIL && EF >= 0 && (EF & 32) != 0 && DACT == A4R_DACT_MULQ8_ && sizeof(TO) == 2;
+    uint2 pt_[16];
+    if constexpr (PRE_TOP) {
+        const uint8_t* const src_ = reinterpret_cast<const uint8_t*>(p.Pre) + ((size_t)(tm * ntn + tn) * 8 + wave) * 8192 + (size_t)lane * 8;
+#pragma unroll
+        for (int g_ = 0; g_ < 16; ++g_) pt_[g_] = *reinterpret_cast<const uint2*>(src_ + g_ * 512);
+    }
     has_next = more && stream;                            // its first six units are issued by the last two K-tiles of this tile's loop
 
     uint4 af[4][2], b0[2][2], b1[2][2];
@@ -578,7 +589,13 @@ A4R_DEV void gemm256_tiles(const a4r_gemm_t& p, char* lds, int ntm, int ntn, int
     // rows 0 .. D - 1 before the first row is processed; row mi + D while row mi is
 #define A4R_LD_FIRST(LD_, D_)                                                                                               \
     LD_(0) if constexpr ((D_) > 1) { LD_(1) } if constexpr ((D_) > 2) { LD_(2) LD_(3) } if constexpr ((D_) > 4) { LD_(4) LD_(5) LD_(6) LD_(7) }
-    A4R_LD_FIRST(A4R_LD_PRE, PRE_D)
+    if constexpr (PRE_TOP) {
+#define A4R_PT(r_) pre_s##r_##_0[0] = make_uint4(pt_[2 * (r_)].x, pt_[2 * (r_)].y, 0u, 0u); pre_s##r_##_1[0] = make_uint4(pt_[2 * (r_) + 1].x, pt_[2 * (r_) + 1].y, 0u, 0u);
+        A4R_PT(0) A4R_PT(1) A4R_PT(2) A4R_PT(3) A4R_PT(4) A4R_PT(5) A4R_PT(6) A4R_PT(7)
+#undef A4R_PT
+    } else {
+        A4R_LD_FIRST(A4R_LD_PRE, PRE_D)
+    }
     A4R_LD_FIRST(A4R_LD_R1, R1_D)
 #undef A4R_LD_FIRST
 #define A4R_LD_AHEAD(LD_, D_, n1_, n2_, n4_)                                                                                \
@@ -794,7 +811,8 @@ int dispatch_same(hipStream_t s, const a4r_gemm_t& g) {   // in == out dtype: th
             if (m == 3) return launch256<T, T, A4R_ACT_NONE, A4R_ACT_NONE, 3>(s, g);      // dense + dropout + residual: an un-adapted BertSelfOutput / BertOutput (Pfeiffer, LoRA)
         }
         if (g.act == A4R_ACT_GELU && g.dact == A4R_ACT_NONE && m == 8) return launch256<T, T, A4R_ACT_GELU, A4R_ACT_NONE, 8>(s, g);
-        if (g.act == A4R_ACT_NONE && g.dact == A4R_DACT_MULQ8_ && m == 0) return launch256<T, T, A4R_ACT_NONE, A4R_DACT_MULQ8_, 0>(s, g);
+        if (g.act == A4R_ACT_NONE && g.dact == A4R_DACT_MULQ8_ && m == 0)            // (32: tile-native derivative, requested in front of the K loop)
+            return g.q8_tiled ? launch256<T, T, A4R_ACT_NONE, A4R_DACT_MULQ8_, 32>(s, g) : launch256<T, T, A4R_ACT_NONE, A4R_DACT_MULQ8_, 0>(s, g);
         if (g.act == A4R_ACT_NONE && g.dact == A4R_DACT_MUL_ && m == 0) return launch256<T, T, A4R_ACT_NONE, A4R_DACT_MUL_, 0>(s, g);
     }
     if (g.act == A4R_ACT_NONE && g.dact == A4R_ACT_NONE) return launch256<T, T, A4R_ACT_NONE, A4R_ACT_NONE>(s, g);

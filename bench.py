@@ -167,7 +167,9 @@ class GemmProbe:
                 names = ('bias', 'C2', 'R1', 'R2', 'Pre', 'act', 'dact', 'alpha', 'drop_p')
                 kw = dict(zip(names, a)); kw.update(k)
                 m = (1 if kw.get('drop_p', 0.0) > 0 else 0) | (2 if kw.get('R1') is not None else 0) | (4 if kw.get('R2') is not None else 0) | (8 if kw.get('C2') is not None else 0)
-                inst = {(0, 0): (0, 1, 2, 3), (self.L.ACT_GELU, 0): (8,), (0, self.L.DACT_MUL_Q8): (0,), (0, self.L.DACT_MUL): (0,)}
+                inst = {(0, 0): (0, 1, 2, 3), (self.L.ACT_GELU, 0): (8,), (0, self.L.DACT_MUL_Q8): (0, 32), (0, self.L.DACT_MUL): (0,)}
+                if A.dtype == torch.bfloat16 and ad == (0, self.L.DACT_MUL_Q8) and kw.get('q8_tiled'):
+                    m |= 32                                  # (tile-native derivative: the instantiation that requests it in front of the K loop)
                 if A.dtype == torch.uint8:                   # e4m3 operands (+ 16: the output leaves as e4m3 too, a4r_gemm_t.c_fp8)
                     inst = {(0, 0): (0,), (self.L.ACT_GELU, 0): (8, 24), (0, self.L.DACT_MUL_Q8): (16,)}
                     m |= 16 if kw.get('c_fp8') else 0
