@@ -32,6 +32,8 @@ template <typename T> A4R_DEV uint4 ldg16(const T* p) { return *reinterpret_cast
 
 // 8 waves per (item, head) workgroup: two workgroups (114 KB of LDS at S = 197) give a CU 4 waves per SIMD to hide the
 // staging and Q / dO load latency behind; with 4-wave workgroups the chip sat at 0.4 waves per SIMD (PMC).
+// (round 3: 7 waves for S = 197 -- its 13 query blocks / key tiles in two even rounds instead of 8 + 5 -- ran the ViT step 2 % SLOWER: 14 instead of
+// 16 waves per CU hide less of the staging latency than the idle second round costs)
 template <int NKT> struct WG { static constexpr int NWAVE = NKT <= 4 ? 4 : 8, NTHR = NWAVE * 64; };   // short sequences have <= 4 query blocks
 
 template <typename T, int DH> struct Geo {
