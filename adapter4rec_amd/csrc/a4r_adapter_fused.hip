@@ -285,7 +285,7 @@ struct AdBwdArgs {
 // back to s_waitcnt vmcnt(0) -- at the top of every tile and in front of the act' operand -- which drains the tile's own stores and the
 // requests for the next tiles every time (adapter_ln_bwd 67 -> 74 us in the step when the knob went in).
 #ifndef A4R_AD_ABL
-#define A4R_AD_ABL 0          /* timing-only diagnostic builds (-DA4R_AD_ABL=n): 1 no tile stores, 2 no tile loads */
+#define A4R_AD_ABL 0          /* timing-only diagnostic builds (-DA4R_AD_ABL=n): 1 no tile stores, 2 no tile loads, 4 no column-sum flush (atomics) at the end of the backward */
 #endif
 // FY: the forward did not keep v (the LayerNorm's input sum) but only y = LN(v), which the next GEMM reads anyway: xhat = (y - beta) / gamma
 // per column (1 / gamma and -beta / gamma sit in LDS next to gamma), rstd from the saved statistics -- 62 MB less written per forward launch.
@@ -499,6 +499,7 @@ __global__ void __launch_bounds__(NW * 64) adapter_ln_bwd_kernel(const AdBwdArgs
         else cur = nn;
     }
     // ---- db_down = column sums of dzp: thread t holds columns (t EPT) & 63 of row (t EPT) >> 6 -> through LDS, one atomic per column
+    if (A4R_AD_ABL & 4) return;                 // (timing only: no column-sum flush)
     if (p.dbd) {
         A4R_LDS_BARRIER();
 #pragma unroll

@@ -282,6 +282,9 @@ A4R_DEV void gemm256_tiles(const a4r_gemm_t& p, char* lds, int ntm, int ntn, int
     }
     // full_: the units this phase's counted wait leaves in flight were all issued -> vmcnt(8) (four units may stay in flight);
     // else the shorter count tail_ of the end of the K range.  ONE copy of every phase (duplicated phase bodies spill).
+#ifndef A4R_LGKM_ALL
+#define A4R_LGKM_ALL 1     /* 0 (A/B builds): no lgkmcnt(0) in front of the MFMA segment -- hipcc's own counted waits let the first MFMAs start on the first fragments */
+#endif
 #ifndef A4R_Z0_NOWAIT
 #define A4R_Z0_NOWAIT 1    /* 0: the counted vmcnt(8) also in the first K-tile of an output tile (A/B builds) */
 #endif
@@ -307,7 +310,7 @@ A4R_DEV void gemm256_tiles(const a4r_gemm_t& p, char* lds, int ntm, int ntn, int
     asm volatile("" ::: "memory");                                                                    \
     __builtin_amdgcn_sched_barrier(0);                                                                \
     A4R_ST(3)                                                                                         \
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                \
+    if (A4R_LGKM_ALL) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                              \
     __builtin_amdgcn_sched_barrier(0);                                                                \
     A4R_ST(4)                                                                                         \
     if (!(A4R_ABL & 16)) __builtin_amdgcn_s_setprio(1);                                               \
