@@ -12,7 +12,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('A4R_LIB_PATH') or os.path.join(_HERE, 'liba4r_hip.so')    # A4R_LIB_PATH: A/B builds (tools/), same C ABI
 
-ABI_VERSION = 307          # = A4R_ABI_VERSION of include/a4r.h (tests/test_abi_cpu.py compares the two)
+ABI_VERSION = 308          # = A4R_ABI_VERSION of include/a4r.h (tests/test_abi_cpu.py compares the two)
 BF16, F32, FP8 = 0, 1, 2
 ACT_NONE, ACT_RELU, ACT_GELU, ACT_GELU_TANH, ACT_LEAKY = 0, 1, 2, 3, 4
 DACT_MUL = 15
@@ -238,14 +238,15 @@ def gemm_tn(X, Y, Cacc, M=None):
                              C.c_int(M), C.c_int(X.shape[1]), C.c_int(Y.shape[1]), C.c_int(_dt(X))), 'a4r_gemm_tn')
 
 
-def gemm_tn2(X1, Y1, C1, X2, Y2, C2, M=None):
-    """C1 += X1^T Y1 and C2 += X2^T Y2 over the same M rows, one launch (bf16; equal tile counts)."""
-    require_gpu(X1, Y1, C1, X2, Y2, C2)
+def gemm_tn2(X1, Y1, C1, X2, Y2, C2, M=None, xsum1=None, xsum2=None):
+    """C1 += X1^T Y1 and C2 += X2^T Y2 over the same M rows, one launch (bf16; equal tile counts); xsum_k[p] += column sums of X_k."""
+    require_gpu(X1, Y1, C1, X2, Y2, C2, xsum1, xsum2)
     assert C1.dtype == torch.float32 and C2.dtype == torch.float32
+    assert (xsum1 is None or (xsum1.dtype == torch.float32 and xsum1.numel() >= X1.shape[1])) and (xsum2 is None or (xsum2.dtype == torch.float32 and xsum2.numel() >= X2.shape[1]))
     M = X1.shape[0] if M is None else M
     _check(lib().a4r_gemm_tn2(_stream(), _p(X1), C.c_int(_ld(X1)), _p(Y1), C.c_int(_ld(Y1)), _p(C1), C.c_int(_ld(C1)), C.c_int(X1.shape[1]), C.c_int(Y1.shape[1]),
                               _p(X2), C.c_int(_ld(X2)), _p(Y2), C.c_int(_ld(Y2)), _p(C2), C.c_int(_ld(C2)), C.c_int(X2.shape[1]), C.c_int(Y2.shape[1]),
-                              C.c_int(M), C.c_int(_dt(X1))), 'a4r_gemm_tn2')
+                              C.c_int(M), C.c_int(_dt(X1)), _p(xsum1), _p(xsum2)), 'a4r_gemm_tn2')
 
 
 def colsum(X, out, M=None):

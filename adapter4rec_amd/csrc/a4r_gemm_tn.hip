@@ -116,7 +116,11 @@ A4R_DEV void tn_glds16(const void* base, uint32_t voff, uint32_t lds_dst) {
     asm volatile("s_mov_b32 m0, %2\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(base), "s"(lds_dst) : "memory");
 }
 
-struct TnProb { const bf16_t* X; const bf16_t* Y; float* C; int ldx, ldy, ldc, ntq; };
+// xsum (optional): xsum[p] += sum over the rows of X[:, p] -- the bias gradient that belongs to a weight gradient (db_up = colsum(dv) next to
+// dW_up = dv^T z, db_down = colsum(dzp) next to dW_down = dzp^T h) as two more MFMAs per stage against an all-ones operand in the workgroups
+// of the first Q-tile: 64 atomics per workgroup on ~32-way contended addresses instead of the 832 the fused adapter backward issued from
+// each of its 256 workgroups onto the same 832 addresses (6 - 9 us at the end of that launch).
+struct TnProb { const bf16_t* X; const bf16_t* Y; float* C; int ldx, ldy, ldc, ntq; float* xsum; };
 __global__ void __launch_bounds__(256) gemm_tn_glds_kernel(const TnProb pa, const TnProb pb, int M, int rows_per_split) {
     // blockIdx.z picks one of two products of one launch (the two weight gradients of an adapter: different operands, same token range)
     const TnProb& pr = blockIdx.z == 0 ? pa : pb;
@@ -160,6 +164,9 @@ __global__ void __launch_bounds__(256) gemm_tn_glds_kernel(const TnProb pa, cons
     issue(0);
     issue(1);
     f32x4_t acc00 = {0.f, 0.f, 0.f, 0.f}, acc01 = acc00, acc10 = acc00, acc11 = acc00;
+    const bool xs = pr.xsum != nullptr && (tile % ntq) == 0 && wq == 0;          // (wave-uniform)
+    f32x4_t xs0 = acc00, xs1 = acc00;
+    const uint4 ones = make_uint4(0x3F803F80u, 0x3F803F80u, 0x3F803F80u, 0x3F803F80u);
     for (int t = 0; t < ns; ++t) {
         if (t + 1 < ns) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -176,9 +183,20 @@ __global__ void __launch_bounds__(256) gemm_tn_glds_kernel(const TnProb pa, cons
             Mma<bf16_t>::mma(a0, b1, acc01);
             Mma<bf16_t>::mma(a1, b0, acc10);
             Mma<bf16_t>::mma(a1, b1, acc11);
+            if (xs) {
+                Mma<bf16_t>::mma(a0, ones, xs0);
+                Mma<bf16_t>::mma(a1, ones, xs1);
+            }
         }
     }
     const int prow = p0 + wp * 32 + (lane >> 4) * 4, qcol = q0 + wq * 32 + (lane & 15);
+    if (xs && (lane & 15) == 0) {            // every column of the ones product holds the row sum: one lane per row writes it
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) {
+            atomicAdd(pr.xsum + prow + rr, xs0[rr]);
+            atomicAdd(pr.xsum + prow + 16 + rr, xs1[rr]);
+        }
+    }
 #pragma unroll
     for (int rr = 0; rr < 4; ++rr) {
         atomicAdd(C + (size_t)(prow + rr) * ldc + qcol, acc00[rr]);
@@ -253,7 +271,7 @@ extern "C" int a4r_gemm_tn(void* stream, const void* X, int ldx, const void* Y, 
     splits = (M + rows_per_split - 1) / rows_per_split;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     if (glds) {
-        const TnProb pa{(const bf16_t*)X, (const bf16_t*)Y, C, ldx, ldy, ldc, ntq};
+        const TnProb pa{(const bf16_t*)X, (const bf16_t*)Y, C, ldx, ldy, ldc, ntq, nullptr};
         hipLaunchKernelGGL(gemm_tn_glds_kernel, dim3(tiles, splits, 1), dim3(256), 0, s, pa, pa, M, rows_per_split);
     }
     else if (dtype == A4R_BF16)
@@ -268,7 +286,8 @@ extern "C" int a4r_gemm_tn(void* stream, const void* X, int ldx, const void* Y, 
 // Two products over the same token range in one launch (an adapter's dW_up = dv^T z and dW_down = dzp^T h): the ramp-up, tail and
 // atomic flush of one overlap the streaming of the other.  Same tile count required (P1 Q1 == P2 Q2), bf16 only.
 extern "C" int a4r_gemm_tn2(void* stream, const void* X1, int ldx1, const void* Y1, int ldy1, float* C1, int ldc1, int P1, int Q1,
-                            const void* X2, int ldx2, const void* Y2, int ldy2, float* C2, int ldc2, int P2, int Q2, int M, int dtype) {
+                            const void* X2, int ldx2, const void* Y2, int ldy2, float* C2, int ldc2, int P2, int Q2, int M, int dtype,
+                            float* xsum1, float* xsum2) {
     if (!X1 || !Y1 || !C1 || !X2 || !Y2 || !C2 || M <= 0 || M % 64 || dtype != A4R_BF16) return A4R_EINVAL;
     if (P1 <= 0 || Q1 <= 0 || P2 <= 0 || Q2 <= 0 || P1 % 64 || Q1 % 64 || P2 % 64 || Q2 % 64 || (P1 / 64) * (Q1 / 64) != (P2 / 64) * (Q2 / 64)) return A4R_EINVAL;
     if ((ldx1 * 2) % 16 || (ldy1 * 2) % 16 || (ldx2 * 2) % 16 || (ldy2 * 2) % 16 || ldx1 < P1 || ldy1 < Q1 || ldc1 < Q1 || ldx2 < P2 || ldy2 < Q2 || ldc2 < Q2)
@@ -280,8 +299,8 @@ extern "C" int a4r_gemm_tn2(void* stream, const void* X1, int ldx1, const void* 
     if (splits > stages) splits = stages;
     const int rows_per_split = ((stages + splits - 1) / splits) * 64;
     splits = (M + rows_per_split - 1) / rows_per_split;
-    const TnProb pa{(const bf16_t*)X1, (const bf16_t*)Y1, C1, ldx1, ldy1, ldc1, Q1 / 64};
-    const TnProb pb{(const bf16_t*)X2, (const bf16_t*)Y2, C2, ldx2, ldy2, ldc2, Q2 / 64};
+    const TnProb pa{(const bf16_t*)X1, (const bf16_t*)Y1, C1, ldx1, ldy1, ldc1, Q1 / 64, xsum1};
+    const TnProb pb{(const bf16_t*)X2, (const bf16_t*)Y2, C2, ldx2, ldy2, ldc2, Q2 / 64, xsum2};
     hipLaunchKernelGGL(gemm_tn_glds_kernel, dim3(tiles, splits, 2), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), pa, pb, M, rows_per_split);
     return a4r_launch_status();
 }

@@ -32,6 +32,7 @@ def pad_to(n, m):
 
 import os as _os
 TN2 = bool(int(_os.environ.get('A4R_TN2', '1')))                       # an adapter's two weight gradients in one launch (0: two a4r_gemm_tn, A/B)
+TN2_BIAS = bool(int(_os.environ.get('A4R_TN2_BIAS', '1')))             # an adapter's two bias gradients from its weight-gradient launch (0: from the fused backward's end-of-launch flush, A/B)
 FUSE_BD = bool(int(_os.environ.get('A4R_FUSE_BD', '1')))               # db_down from the fused adapter backward kernel (0: a4r_colsum launches, A/B)
 WGRAD_STREAM = bool(int(_os.environ.get('A4R_WGRAD_STREAM', '0')))     # 1 = adapter weight gradients on a side stream (see _adapter_wgrads): +1.3 % in round 1, neutral since the GEMM's
                                                                         # late-starting workgroups use the same idle CUs (same-box 19.07 vs 18.98 ms): off by default
@@ -1104,10 +1105,11 @@ class TransRecEngine:
         h = bufs['h' + which]
         if pl != 'parallel' and self._fuse_bwd(blk, ad, dy):
             # ONE launch: LayerNorm backward, dzp = (dv Wu) * act'(zp), dh = mask * (dzp Wd [+ dv]) (a4r_adapter_fused.hip)
+            b2 = self._tn2_bias_ok(ad, dv, M) and self._bd_target(ad) is not None and dv.shape[1] * z.shape[1] == dzp.shape[1] * h.shape[1]
             L.adapter_ln_bwd(dy, v, st, ln.gamma, None, zp, ad.act, ad.wuT, ad.wdT, ad.kind != 'compacter', dv, dzp, dh,
-                             dgamma=gg(ln.g_gamma), dbeta=gg(ln.g_beta), dbias=gg(ad.g_bu), M=M,
-                             drop_p=p_drop, drop_site=site, drop_seed=seed, dbd=self._bd_target(ad), beta_y=beta_y)
-            self._adapter_wgrads(ad, dv, z, dzp, h, M, bd_done=self._bd_target(ad) is not None)
+                             dgamma=gg(ln.g_gamma), dbeta=gg(ln.g_beta), dbias=None if b2 else gg(ad.g_bu), M=M,
+                             drop_p=p_drop, drop_site=site, drop_seed=seed, dbd=None if b2 else self._bd_target(ad), beta_y=beta_y)
+            self._adapter_wgrads(ad, dv, z, dzp, h, M, bd_done=self._bd_target(ad) is not None, bias_in_tn2=b2)
             return dh, dv
         assert beta_y is None, 'a sub-layer that keeps y instead of v runs the fused backward only'
         L.ln_bwd(dy, v, st, ln.gamma, dv, M=M, dgamma=gg(ln.g_gamma), dbeta=gg(ln.g_beta), dbias=gg(ad.g_bu))
@@ -1183,9 +1185,17 @@ class TransRecEngine:
             return None
         return ad.s_bd if ad.s_bd is not None else ad.g_bd()
 
-    def _adapter_wgrads(self, ad, dv, z, dzp, down_in, M, bd_done=False):
+    def _tn2_bias_ok(self, ad, dv, M):
+        """The adapter's two bias gradients can ride in its weight-gradient launch (a4r_gemm_tn2's xsum outputs: db_up = colsum(dv),
+        db_down = colsum(dzp), from the bf16 tensors that launch reads anyway) instead of in the fused backward kernel's end-of-launch
+        flush -- 832 atomics from each of its 256 workgroups onto the same addresses, 6 - 9 us per launch (A4R_TN2_BIAS=0: the flush)."""
+        return (TN2_BIAS and TN2 and not (WGRAD_STREAM and self.WGRAD_SIDE_OK) and dv.dtype == torch.bfloat16 and M % 64 == 0
+                and ad.virtual is None and ad.g_wu is not None and ad.s_wu is None and ad.s_bd is None and ad.g_bu is not None and ad.g_bd is not None
+                and ad.dp == 64 and not _os.environ.get('A4R_DEBUG_SKIP_WGRAD'))
+
+    def _adapter_wgrads(self, ad, dv, z, dzp, down_in, M, bd_done=False, bias_in_tn2=False):
         """dW_up = dv^T z, dW_down = dzp^T down_in, db_down = colsum(dzp)  (db_up comes from ln_bwd's dbias; bd_done: the fused
-        backward kernel has already accumulated db_down).
+        backward kernel has already accumulated db_down; bias_in_tn2: neither was accumulated, both ride in this launch).
         A4R_WGRAD_STREAM=1: on a side stream, to run in the tail rounds of the dgrad GEMMs that follow (nothing on the
         dgrad chain reads these results); joined before dv / dzp are reused and at the end of the backward pass."""
         if ad.virtual is None and ad.g_wu is None:
@@ -1216,6 +1226,10 @@ class TransRecEngine:
         # zero-padded (d < 64) or virtual (Compacter) matrices: into the scratch arena (cleared at the start of backward; the valid
         # corners reach the flat gradient through _flush_corners / a4r_phm_bwd at its end)
         t_wu, t_wd = (ad.s_wu if ad.s_wu is not None else ad.g_wu()), (ad.s_wd if ad.s_wd is not None else ad.g_wd())
+        if bias_in_tn2:
+            assert dv.shape[1] * z.shape[1] == dzp.shape[1] * down_in.shape[1]
+            L.gemm_tn2(dv, z, t_wu, dzp, down_in, t_wd, M=M, xsum1=ad.g_bu(), xsum2=ad.g_bd())
+            return
         if TN2 and dv.dtype == torch.bfloat16 and dv.shape[1] * z.shape[1] == dzp.shape[1] * down_in.shape[1] and M % 64 == 0:
             L.gemm_tn2(dv, z, t_wu, dzp, down_in, t_wd, M=M)
         else:

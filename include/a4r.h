@@ -36,7 +36,7 @@ extern "C" {
 
 /* ABI version: bumped whenever a signature or struct below changes.  The Python binding (adapter4rec_amd/_lib.py) refuses a
  * library whose a4r_version() differs, so an A/B build made before a signature change cannot be called with shifted arguments. */
-#define A4R_ABI_VERSION 307
+#define A4R_ABI_VERSION 308
 int a4r_version(void);
 
 /* C[M,N] = epilogue(alpha * A[M,K] . B[N,K]^T): every nn.Linear on the path (HF BertSelfAttention
@@ -133,9 +133,11 @@ int a4r_sasrec_block_bwd(void* stream, const a4r_sasrec_block_t* b, const float*
                          int n_users, int T, int train);
 
 /* Two such products over the same M rows in ONE launch (an adapter's dW_up = dv^T z and dW_down = dzp^T h; bf16;
- * (P1 / 64) (Q1 / 64) == (P2 / 64) (Q2 / 64)). */
+ * (P1 / 64) (Q1 / 64) == (P2 / 64) (Q2 / 64)).  xsum1 / xsum2 (either may be null): xsum_k[p] (fp32, +=) = sum over the rows of
+ * X_k[:, p] -- the bias gradients that go with the two weight gradients (db_up = colsum(dv), db_down = colsum(dzp)), from the same pass. */
 int a4r_gemm_tn2(void* stream, const void* X1, int ldx1, const void* Y1, int ldy1, float* C1, int ldc1, int P1, int Q1,
-                 const void* X2, int ldx2, const void* Y2, int ldy2, float* C2, int ldc2, int P2, int Q2, int M, int dtype);
+                 const void* X2, int ldx2, const void* Y2, int ldy2, float* C2, int ldc2, int P2, int Q2, int M, int dtype,
+                 float* xsum1, float* xsum2);
 
 /* colsum[N] (fp32, +=) = sum over rows of X[M,N]: bias gradients. N % 8 == 0. */
 int a4r_colsum(void* stream, const void* X, int ldx, float* out, int M, int N, int dtype);

@@ -159,9 +159,14 @@ def gemm_tn(X, Y, Cacc, M=None):
     Cacc += X[:M].float().t() @ Y[:M].float()
 
 
-def gemm_tn2(X1, Y1, C1, X2, Y2, C2, M=None):
+def gemm_tn2(X1, Y1, C1, X2, Y2, C2, M=None, xsum1=None, xsum2=None):
     gemm_tn(X1, Y1, C1, M=M)
     gemm_tn(X2, Y2, C2, M=M)
+    m = X1.shape[0] if M is None else M
+    if xsum1 is not None:
+        xsum1.view(-1)[:X1.shape[1]] += X1[:m].float().sum(0)
+    if xsum2 is not None:
+        xsum2.view(-1)[:X2.shape[1]] += X2[:m].float().sum(0)
 
 
 def colsum(X, out, M=None):

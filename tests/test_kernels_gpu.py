@@ -297,6 +297,16 @@ def test_gemm_tn2_two_products_one_launch():
         L.gemm_tn2(X1, Y1, C1, X2, Y2, C2)
         close(C1, X1.float().t() @ Y1.float(), torch.float32, 'tn2 first', atol32=2e-3 * (M / 1280) ** 0.5 * 8, rtol32=2e-3)
         close(C2, X2.float().t() @ Y2.float(), torch.float32, 'tn2 second', atol32=2e-3 * (M / 1280) ** 0.5 * 8, rtol32=2e-3)
+        # + the column sums of both X operands from the same pass (the bias gradients that go with the two weight gradients), accumulating
+        C1b, C2b = torch.zeros_like(C1), torch.zeros_like(C2)
+        s1, s2 = torch.full((H,), 0.5, device=dev()), torch.full((64,), -1.0, device=dev())
+        L.gemm_tn2(X1, Y1, C1b, X2, Y2, C2b, xsum1=s1, xsum2=s2)
+        assert torch.equal(C1b, C1) or float((C1b - C1).abs().max()) < 1e-3           # (atomic order differs between launches)
+        close(s1, 0.5 + X1.float().sum(0), torch.float32, 'tn2 xsum1', atol32=2e-3 * (M / 1280) ** 0.5 * 8, rtol32=2e-3)
+        close(s2, -1.0 + X2.float().sum(0), torch.float32, 'tn2 xsum2', atol32=2e-3 * (M / 1280) ** 0.5 * 8, rtol32=2e-3)
+        s3 = torch.zeros(H, device=dev())
+        L.gemm_tn2(X1, Y1, C1b, X2, Y2, C2b, xsum1=s3)                                    # one of the two only
+        close(s3, X1.float().sum(0), torch.float32, 'tn2 xsum1 alone', atol32=2e-3 * (M / 1280) ** 0.5 * 8, rtol32=2e-3)
     with pytest.raises(RuntimeError):                                          # unequal tile counts
         L.gemm_tn2(X1, Y1, C1, X2, rnd(192, 128, dtype=t, seed=55), torch.zeros(64, 128, device=dev()))
 
