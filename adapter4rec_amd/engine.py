@@ -1086,15 +1086,17 @@ class TransRecEngine:
             va, t, sta = bufs['va' + which], bufs['t' + which], bufs['sta' + which]
             dt = self._buf('dt', M, H, T)
             fused_bd = False
+            b2 = False
             if self._fuse_bwd(blk, ad, dy):
+                b2 = self._tn2_bias_ok(ad, dv, M)
                 L.adapter_ln_bwd(dy, v, st, lnn.gamma, None, zp, ad.act, ad.wuT, ad.wdT, False, dv, dzp, dt,
-                                 dgamma=gg(lnn.g_gamma), dbeta=gg(lnn.g_beta), dbias=gg(ad.g_bu), M=M, dbd=self._bd_target(ad))
+                                 dgamma=gg(lnn.g_gamma), dbeta=gg(lnn.g_beta), dbias=None if b2 else gg(ad.g_bu), M=M, dbd=None if b2 else self._bd_target(ad))
                 fused_bd = self._bd_target(ad) is not None
             else:
                 L.ln_bwd(dy, v, st, lnn.gamma, dv, M=M, dgamma=gg(lnn.g_gamma), dbeta=gg(lnn.g_beta), dbias=gg(ad.g_bu))
                 L.gemm_nt(dv, ad.wuT, dzp, Pre=zp, dact=ad.act, M=M)
                 L.gemm_nt(dzp, ad.wdT, dt, M=M)
-            self._adapter_wgrads(ad, dv, z, dzp, t, M, bd_done=fused_bd)
+            self._adapter_wgrads(ad, dv, z, dzp, t, M, bd_done=fused_bd, bias_in_tn2=b2)
             dva = self._buf('dva', M, H, T)
             if p_drop > 0:
                 L.ln_bwd(dt, va, sta, ln.gamma, dva, M=M, dgamma=gg(ln.g_gamma), dbeta=gg(ln.g_beta), dres=dv,
@@ -1105,7 +1107,7 @@ class TransRecEngine:
         h = bufs['h' + which]
         if pl != 'parallel' and self._fuse_bwd(blk, ad, dy):
             # ONE launch: LayerNorm backward, dzp = (dv Wu) * act'(zp), dh = mask * (dzp Wd [+ dv]) (a4r_adapter_fused.hip)
-            b2 = self._tn2_bias_ok(ad, dv, M) and self._bd_target(ad) is not None and dv.shape[1] * z.shape[1] == dzp.shape[1] * h.shape[1]
+            b2 = self._tn2_bias_ok(ad, dv, M)
             L.adapter_ln_bwd(dy, v, st, ln.gamma, None, zp, ad.act, ad.wuT, ad.wdT, ad.kind != 'compacter', dv, dzp, dh,
                              dgamma=gg(ln.g_gamma), dbeta=gg(ln.g_beta), dbias=None if b2 else gg(ad.g_bu), M=M,
                              drop_p=p_drop, drop_site=site, drop_seed=seed, dbd=None if b2 else self._bd_target(ad), beta_y=beta_y)
@@ -1190,8 +1192,8 @@ class TransRecEngine:
         db_down = colsum(dzp), from the bf16 tensors that launch reads anyway) instead of in the fused backward kernel's end-of-launch
         flush -- 832 atomics from each of its 256 workgroups onto the same addresses, 6 - 9 us per launch (A4R_TN2_BIAS=0: the flush)."""
         return (TN2_BIAS and TN2 and not (WGRAD_STREAM and self.WGRAD_SIDE_OK) and dv.dtype == torch.bfloat16 and M % 64 == 0
-                and ad.virtual is None and ad.g_wu is not None and ad.s_wu is None and ad.s_bd is None and ad.g_bu is not None and ad.g_bd is not None
-                and ad.dp == 64 and not _os.environ.get('A4R_DEBUG_SKIP_WGRAD'))
+                and (ad.virtual is not None or ad.g_wu is not None) and ad.s_bd is None and ad.g_bu is not None and ad.g_bd is not None
+                and self._bd_target(ad) is not None and ad.dp == 64 and dv.shape[1] % 64 == 0 and not _os.environ.get('A4R_DEBUG_SKIP_WGRAD'))
 
     def _adapter_wgrads(self, ad, dv, z, dzp, down_in, M, bd_done=False, bias_in_tn2=False):
         """dW_up = dv^T z, dW_down = dzp^T down_in, db_down = colsum(dzp)  (db_up comes from ln_bwd's dbias; bd_done: the fused

@@ -353,9 +353,11 @@ class ViTRecEngine(TransRecEngine):
             dzp = self._buf('dzp', M, ad.dp, T)
             da = self._buf('dh1', M, H, T)
             bd = self._bd_target(ad)
+            b2 = self._tn2_bias_ok(ad, dx1, M)          # (bias_total: db_up = colsum of the TOTAL dx1 this launch writes = the weight-gradient launch's X operand)
             L.adapter_ln_bwd(dn2, bufs['x1'], bufs['stb'], blk.lnB.gamma, dres2, bufs['zp1'], ad.act, ad.wuT, ad.wdT, ad.kind != 'compacter',
-                             dx1, dzp, da, dgamma=gg(blk.lnB.g_gamma), dbeta=gg(blk.lnB.g_beta), dbias=gg(ad.g_bu), M=M, dbd=bd, bias_total=True)
-            self._adapter_wgrads(ad, dx1, bufs['z1'], dzp, bufs['h1'], M, bd_done=bd is not None)
+                             dx1, dzp, da, dgamma=gg(blk.lnB.g_gamma), dbeta=gg(blk.lnB.g_beta), dbias=None if b2 else gg(ad.g_bu), M=M,
+                             dbd=None if b2 else bd, bias_total=True)
+            self._adapter_wgrads(ad, dx1, bufs['z1'], dzp, bufs['h1'], M, bd_done=bd is not None, bias_in_tn2=b2)
         else:
             L.ln_bwd(dn2, bufs['x1'], bufs['stb'], blk.lnB.gamma, dx1, M=M, dgamma=gg(blk.lnB.g_gamma), dbeta=gg(blk.lnB.g_beta), dres=dres2)
             da, dres1 = self._vit_sub_backward(blk, blk.ad1, dx1, bufs, '1', M)
@@ -394,10 +396,11 @@ class ViTRecEngine(TransRecEngine):
                 dzp = self._buf('dzp2', M, ad.dp, T)
                 d_o_prev = self._buf('dh2', M, H, T)
                 bd = self._bd_target(ad)
+                b2 = self._tn2_bias_ok(ad, dx_in, M)
                 L.adapter_ln_bwd(dn1, bufs['x0'], bufs['sta'], blk.lnA.gamma, dx1, pbufs['zp2'], ad.act, ad.wuT, ad.wdT, ad.kind != 'compacter',
-                                 dx_in, dzp, d_o_prev, dgamma=gg(blk.lnA.g_gamma), dbeta=gg(blk.lnA.g_beta), dbias=gg(ad.g_bu), M=M, dbd=bd,
-                                 bias_total=True)
-                self._adapter_wgrads(ad, dx_in, pbufs['z2'], dzp, pbufs['h2'], M, bd_done=bd is not None)
+                                 dx_in, dzp, d_o_prev, dgamma=gg(blk.lnA.g_gamma), dbeta=gg(blk.lnA.g_beta), dbias=None if b2 else gg(ad.g_bu), M=M,
+                                 dbd=None if b2 else bd, bias_total=True)
+                self._adapter_wgrads(ad, dx_in, pbufs['z2'], dzp, pbufs['h2'], M, bd_done=bd is not None, bias_in_tn2=b2)
                 return d_o_prev, dx_in
             L.ln_bwd(dn1, bufs['x0'], bufs['sta'], blk.lnA.gamma, dx_in, M=M, dgamma=gg(blk.lnA.g_gamma), dbeta=gg(blk.lnA.g_beta), dres=dx1)
         return None
