@@ -4,6 +4,7 @@
 // the grid; each workgroup keeps a 64x64 fp32 partial in registers for its whole token range and
 // flushes it once with fp32 atomics (4 waves x 2x2 tiles of 16x16).
 // a4r_colsum: out[N] += sum_m X[m, :]  (bias gradients).
+#include <cstdlib>
 #include "a4r_common.h"
 #include "../../include/a4r.h"
 
@@ -294,7 +295,8 @@ extern "C" int a4r_gemm_tn2(void* stream, const void* X1, int ldx1, const void* 
         return A4R_EINVAL;
     if ((reinterpret_cast<uintptr_t>(X1) | reinterpret_cast<uintptr_t>(Y1) | reinterpret_cast<uintptr_t>(X2) | reinterpret_cast<uintptr_t>(Y2)) & 15u) return A4R_EINVAL;
     const int tiles = (P1 / 64) * (Q1 / 64);
-    int splits = (384 + tiles - 1) / tiles;                 // two products: half the splits of the single-product launch each
+    static const int wgs_per_product = getenv("A4R_TN2_WGS") ? atoi(getenv("A4R_TN2_WGS")) : 384;       // (A/B runs)
+    int splits = (wgs_per_product + tiles - 1) / tiles;     // two products: half the splits of the single-product launch each
     const int stages = M / 64;
     if (splits > stages) splits = stages;
     const int rows_per_split = ((stages + splits - 1) / splits) * 64;

@@ -39,3 +39,15 @@ b.record()
 torch.cuda.synchronize()
 us = a.elapsed_time(b) / 30 * 1e3
 print(f'gemm_tn2 M={M} both products in one launch: {us:6.1f} us  {M * (768 + 64) * 2 * 2 / us / 1e6:5.2f} TB/s')
+# + the bias sums from the same pass (what the step launches since the end of round 3)
+s1, s2 = torch.zeros(768, device=dev), torch.zeros(64, device=dev)
+for _ in range(5):
+    L.gemm_tn2(X1, Y1, C1, X2, Y2, C2, xsum1=s1, xsum2=s2)
+torch.cuda.synchronize()
+a.record()
+for _ in range(30):
+    L.gemm_tn2(X1, Y1, C1, X2, Y2, C2, xsum1=s1, xsum2=s2)
+b.record()
+torch.cuda.synchronize()
+us = a.elapsed_time(b) / 30 * 1e3
+print(f'gemm_tn2 + column sums M={M}: {us:6.1f} us  {M * (768 + 64) * 2 * 2 / us / 1e6:5.2f} TB/s   (A4R_TN2_WGS={os.environ.get("A4R_TN2_WGS", "384")})')
