@@ -273,3 +273,27 @@ def test_host_logic_optimizer_checkpoint_interchange(simulated):
 def test_host_logic_text_fp8_encoder(simulated, adapter_type):
     """The fp8 wiring of the post-LN text tower (e4m3 rows handed from layer to layer, FFN dgrad chain) through the CPU restatement."""
     TG._text_fp8_case('cpu', adapter_type)
+
+
+@pytest.mark.parametrize('name', ['kadapter', 'prompt', 'houlsby_parallel', 'compacter', 'pfeiffer_ver2', 'houlsby_cpc', 'roberta_prompt'])
+def test_host_logic_text_fp8_every_placement(simulated, name):
+    """--compute_dtype fp8 on every adapter placement of the text tower (tiny geometry: only the FFN-up operand has a 256-tile shape, the other
+    GEMMs of the same blocks stay bf16): the wiring runs, the loss stays next to the bf16 run's and every gradient is finite and close."""
+    root, args, fx, items, mask = build_cpu(name)
+    inner = getattr(root, 'model', root)
+    res = {}
+    for dt in ('bf16', 'fp8'):
+        inner.compute_dtype = dt
+        inner.invalidate_native()
+        for p in root.parameters():
+            p.grad = None
+        loss = root(items, mask, 'cpu')
+        loss.backward()
+        res[dt] = (loss.item(), {n: p.grad.clone() for n, p in root.named_parameters() if p.requires_grad})
+    eng = inner._engine()
+    assert eng.fp8 and all(getattr(b, 'wi8', None) is not None for b in eng.bert_blocks)
+    assert abs(res['fp8'][0] - res['bf16'][0]) < 0.05 * max(1.0, abs(res['bf16'][0]))
+    for n, g in res['bf16'][1].items():
+        g8 = res['fp8'][1][n]
+        assert torch.isfinite(g8).all(), n
+        assert float((g8 - g).abs().max()) <= 0.5 * float(g.abs().max()) + 1e-6, n
