@@ -176,6 +176,58 @@ A4R_DEV void gelu_erf_both(float x, float& g, float& dg) {     // one exp, one r
     g = x * cdf;
     dg = cdf + x * 0.3989422804014327f * e;
 }
+// The same for N values (N even), sweep by sweep over N / 2 packed pairs.  Element by element hipcc runs each pair's dependent chain of packed-fp32
+// instructions to its end before it starts the next pair's, and a packed result consumed by the very next instruction costs a wait state
+// (~790 s_nop per 256 x 256 tile epilogue and wave); the empty asm after each sweep ties the pairs together so that a result is consumed N / 2
+// instructions later.
+typedef float a4r_f2_t __attribute__((ext_vector_type(2)));
+template <int N>
+A4R_DEV void gelu_erf_both_n(float (&x)[N], float (&dg)[N]) {
+    static_assert(N % 2 == 0 && N <= 8, "pairs");
+    constexpr int P = N / 2;
+    a4r_f2_t xv[P], z[P], e[P], t[P], pl[P], xc[P];
+#define A4R_TIE(a_) if constexpr (P == 4) asm volatile("" : "+v"(a_[0]), "+v"(a_[1]), "+v"(a_[2]), "+v"(a_[3])); else if constexpr (P == 2) asm volatile("" : "+v"(a_[0]), "+v"(a_[1]));
+#pragma unroll
+    for (int j = 0; j < P; ++j) { xv[j] = a4r_f2_t{x[2 * j], x[2 * j + 1]}; z[j] = xv[j] * 0.70710678118654752440f; xc[j] = xv[j] * 0.3989422804014327f; }
+#pragma unroll
+    for (int j = 0; j < P; ++j) {
+        const a4r_f2_t q = -z[j] * z[j];
+        e[j] = a4r_f2_t{__expf(q.x), __expf(q.y)};
+        t[j] = a4r_f2_t{__builtin_amdgcn_rcpf(1.f + 0.3275911f * fabsf(z[j].x)), __builtin_amdgcn_rcpf(1.f + 0.3275911f * fabsf(z[j].y))};
+    }
+    A4R_TIE(t)
+#pragma unroll
+    for (int j = 0; j < P; ++j) pl[j] = t[j] * 1.061405429f + (-1.453152027f);
+    A4R_TIE(pl)
+#pragma unroll
+    for (int j = 0; j < P; ++j) pl[j] = t[j] * pl[j] + 1.421413741f;
+    A4R_TIE(pl)
+#pragma unroll
+    for (int j = 0; j < P; ++j) pl[j] = t[j] * pl[j] + (-0.284496736f);
+    A4R_TIE(pl)
+#pragma unroll
+    for (int j = 0; j < P; ++j) pl[j] = t[j] * pl[j] + 0.254829592f;
+    A4R_TIE(pl)
+#pragma unroll
+    for (int j = 0; j < P; ++j) pl[j] = t[j] * pl[j];
+    A4R_TIE(pl)
+#pragma unroll
+    for (int j = 0; j < P; ++j) pl[j] = 1.f - pl[j] * e[j];
+    A4R_TIE(pl)
+#pragma unroll
+    for (int j = 0; j < P; ++j) pl[j] = a4r_f2_t{__builtin_copysignf(pl[j].x, z[j].x), __builtin_copysignf(pl[j].y, z[j].y)} * 0.5f + 0.5f;      // cdf
+    A4R_TIE(pl)
+#pragma unroll
+    for (int j = 0; j < P; ++j) e[j] = xc[j] * e[j] + pl[j];      // derivative
+    A4R_TIE(e)
+#pragma unroll
+    for (int j = 0; j < P; ++j) {
+        const a4r_f2_t g = xv[j] * pl[j];
+        x[2 * j] = g.x; x[2 * j + 1] = g.y;
+        dg[2 * j] = e[j].x; dg[2 * j + 1] = e[j].y;
+    }
+#undef A4R_TIE
+}
 A4R_DEV float act_fwd(float x, int act) {
     switch (act) {
         case A4R_ACT_RELU: return x > 0.f ? x : 0.f;

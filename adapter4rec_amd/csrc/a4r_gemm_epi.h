@@ -123,10 +123,11 @@ A4R_DEV void epilogue_n(float (&v)[NC], const float* bias, uint32_t grow, int gc
     for (int i = 0; i < NC; ++i) v[i] = v[i] * e.alpha + bias[i];
     if (act == A4R_ACT_GELU && has_c2 && e.c2_mode) {          // value and derivative from one exp + one rcp
         float d[NC];
+        if (A4R_ABL & 64) {
 #pragma unroll
-        for (int i = 0; i < NC; ++i) {
-            if (A4R_ABL & 64) d[i] = v[i];
-            else gelu_erf_both(v[i], v[i], d[i]);
+            for (int i = 0; i < NC; ++i) d[i] = v[i];
+        } else {
+            gelu_erf_both_n<NC>(v, d);
         }
         if (e.c2_mode == 2) store_q8<NC>(q8dst ? q8dst : reinterpret_cast<uint8_t*>(e.C2) + (size_t)grow * (uint32_t)e.ldc2 + gcol, d);
         else if (!(A4R_ABL & 128)) store_n<TO, NC>(e.C2 + (size_t)grow * (uint32_t)e.ldc2 + gcol, d);
