@@ -12,7 +12,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('A4R_LIB_PATH') or os.path.join(_HERE, 'liba4r_hip.so')    # A4R_LIB_PATH: A/B builds (tools/), same C ABI
 
-ABI_VERSION = 308          # = A4R_ABI_VERSION of include/a4r.h (tests/test_abi_cpu.py compares the two)
+ABI_VERSION = 401          # = A4R_ABI_VERSION of include/a4r.h (tests/test_abi_cpu.py compares the two)
 BF16, F32, FP8 = 0, 1, 2
 ACT_NONE, ACT_RELU, ACT_GELU, ACT_GELU_TANH, ACT_LEAKY = 0, 1, 2, 3, 4
 DACT_MUL = 15
@@ -25,7 +25,7 @@ EXPORTS = [
     'a4r_version', 'a4r_gemm_nt', 'a4r_gemm_tn', 'a4r_gemm_tn2', 'a4r_colsum', 'a4r_attn_fwd', 'a4r_attn_bwd', 'a4r_embed_ln',
     'a4r_ln_fwd', 'a4r_ln_bwd', 'a4r_gather_rows', 'a4r_scatter_rows', 'a4r_act_bwd_f32', 'a4r_score_bce_fwd',
     'a4r_score_bce_bwd', 'a4r_emb_grad_add_inputs', 'a4r_take_inputs', 'a4r_adam_step', 'a4r_pack_matrices',
-    'a4r_eval_rank', 'a4r_dropout_apply', 'a4r_gemm_variant', 'a4r_gemm_tail_plan', 'a4r_gemm_tail_max', 'a4r_adapter_ln_fwd', 'a4r_adapter_ln_bwd', 'a4r_ln_fwd_fp8', 'a4r_quant_rows_fp8', 'a4r_lora_merge', 'a4r_lora_merge_batch', 'a4r_phm_build', 'a4r_phm_bwd', 'a4r_unpack_add', 'a4r_memset_zero',
+    'a4r_eval_rank', 'a4r_dropout_apply', 'a4r_gemm_variant', 'a4r_gemm_tail_plan', 'a4r_gemm_tail_max', 'a4r_gemm_rows_256', 'a4r_adapter_ln_fwd', 'a4r_adapter_ln_bwd', 'a4r_ln_fwd_fp8', 'a4r_quant_rows_fp8', 'a4r_lora_merge', 'a4r_lora_merge_batch', 'a4r_phm_build', 'a4r_phm_bwd', 'a4r_unpack_add', 'a4r_memset_zero',
     'a4r_sasrec_block_fwd', 'a4r_sasrec_block_bwd', 'a4r_scatter_rows_fill', 'a4r_attn_long_fwd', 'a4r_attn_long_bwd', 'a4r_patchify', 'a4r_vit_assemble', 'a4r_resample_u8', 'a4r_embed_bwd',
 ]
 
@@ -184,6 +184,11 @@ def gemm_tail_plan(M, N):
     pf, kp = C.c_int(0), C.c_int(0)
     lib().a4r_gemm_tail_plan(C.c_int(M), C.c_int(N), C.byref(pf), C.byref(kp))
     return pf.value, kp.value
+
+
+def gemm_rows_256(M, N):
+    """Leading rows of an [M, N] gemm_nt output that the 256-tile kernel computes (= the tile-native part of a q8_tiled tensor)."""
+    return lib().a4r_gemm_rows_256(C.c_int(M), C.c_int(N))
 
 
 def adapter_ln_ok(A, d):

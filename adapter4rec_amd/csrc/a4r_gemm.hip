@@ -282,6 +282,45 @@ static int run_256(hipStream_t s, const a4r_gemm_t& g) { return a4r_gemm_nt_256(
 
 extern int g_tn_variant;                                     // a4r_gemm_tn.hip: 0 = register-staged weight-gradient kernel for bf16 too
 
+// Leading rows (a multiple of 256) of an [M, N] output that the 256 x 256-tile kernel computes; the rows behind them go to the 128-tile
+// kernel.  A function of (M, N), the CU count and a4r_gemm_variant only -- NOT of the operand type: a tile-native 8-bit derivative
+// (a4r_gemm_t.q8_tiled) is tile-native on exactly these rows and row-major behind them, for every launch that writes or reads it.
+//   * fewer 256-tiles than half the CUs (8 users: 120 tiles at N = 768): the 128-tile kernel fills the chip better (measured 505 vs
+//     454, 735 vs 624, 774 vs 637 TF/s at M = 10240; the large tile wins from 198 tiles on) -> 0;
+//   * a partial last round that a4r_gemm_tail_plan cuts into short tiles runs inside the same launch -> M;
+//   * a last round of only a few whole row panels (ViT-B/16 at 8 users: 777 tiles = 3 rounds + 9 tiles) goes to the 128-tile kernel
+//     as a second launch instead of costing a full round (N = 768, K = 3072: 4 -> 3 rounds + ~1/4) -> the rows in front of it.
+extern "C" int a4r_gemm_rows_256(int M, int N) {
+    if (g_variant < 2 || M <= 0 || N <= 0 || M % 256 || N % 256) return 0;
+    const int ntm = M / 256, ntn = N / 256, tiles = ntm * ntn, ncu = a4r_cu_count();
+    const int rem = tiles % ncu;
+    if (tiles * 2 <= ncu && g_variant == 2) return 0;
+    int pf_ = 0, kp_ = 0;
+    if (a4r_gemm_tail_plan(M, N, &pf_, &kp_)) return M;
+    if (tiles > ncu && rem > 0 && rem * 4 <= ncu && rem % ntn == 0 && g_variant < 4) return (ntm - rem / ntn) * 256;
+    return M;
+}
+
+// g -> g1 (rows [0, head_rows), keeps q8_tiled) + g2 (the rows behind them, 8-bit derivative row-major: whole row panels, so the byte
+// offset of row head_rows is the same in both orders)
+static void split_rows(const a4r_gemm_t& g, int64_t head_rows, int isz, int osz, int c2sz, int presz, a4r_gemm_t& g1, a4r_gemm_t& g2) {
+    g1 = g;
+    g2 = g;
+    g1.M = (int)head_rows;
+    g2.M = g.M - (int)head_rows;
+    g2.q8_tiled = 0;
+    g2.drop_row0 = g.drop_row0 + head_rows;
+    auto adv = [&](const void* p, int64_t ld, int sz) { return p ? (const void*)((const char*)p + head_rows * ld * sz) : nullptr; };
+    g2.A = adv(g.A, g.lda, isz);
+    g2.C = const_cast<void*>(adv(g.C, g.ldc, g.c_fp8 ? 1 : osz));
+    g2.C2 = const_cast<void*>(adv(g.C2, g.ldc2, c2sz));
+    g2.R1 = adv(g.R1, g.ldr1, osz);
+    g2.R2 = adv(g.R2, g.ldr2, osz);
+    g2.Pre = adv(g.Pre, g.ldpre, presz);
+    if (g.scale_a) g2.scale_a = g.scale_a + head_rows;
+    if (g.c_scale_out) g2.c_scale_out = g.c_scale_out + head_rows;
+}
+
 extern "C" int a4r_gemm_variant(int v) {
     const int old = g_variant;
     if (v == 3 || v == 5) return -1;         // the four-wave forms were measured slower and are no longer part of the library (tools/rejected_kernels/)
@@ -307,7 +346,25 @@ extern "C" int a4r_gemm_nt(void* stream, const a4r_gemm_t* gp) {
         if (g.c_fp8 && (g.ldc % 16 || g.R1 || g.R2)) return A4R_EINVAL;                                     // e4m3 C: ldc counts bytes
         if (g.q8_tiled && ((g.C2 && g.c2_mode == 2 && g.ldc2 != g.N) || (g.dact == A4R_DACT_MULQ8_ && g.ldpre != g.N))) return A4R_EINVAL;
         if (g.drop_p < 0.f || g.drop_p >= 1.f) return A4R_EINVAL;
-        const int rc = a4r_gemm_nt_256(reinterpret_cast<hipStream_t>(stream), g);
+        hipStream_t s8 = reinterpret_cast<hipStream_t>(stream);
+        const bool q8op = (g.C2 && g.c2_mode == 2) || g.dact == A4R_DACT_MULQ8_;
+        if (g.q8_tiled && q8op) {
+            // The tile-native 8-bit derivative covers the rows a bf16 launch over the same [M, N] would give the 256-tile kernel
+            // (a4r_gemm_rows_256); the rows behind them are row-major.  e4m3 operands always run on the 256-tile kernel, so the launch
+            // is cut at the same row: its writer or reader on the other side may be a bf16 launch (fp8 FFN-up + bf16 dgrad).
+            const int head_rows = a4r_gemm_rows_256(g.M, g.N);
+            if (head_rows < g.M) {
+                a4r_gemm_t g1, g2;
+                split_rows(g, head_rows, 1, osz, g.c2_mode == 2 ? 1 : osz, 1, g1, g2);
+                if (head_rows > 0) {
+                    const int rc = a4r_gemm_nt_256(s8, g1);
+                    if (rc != 0) return rc == 1 ? A4R_EINVAL : rc;
+                }
+                const int rc = a4r_gemm_nt_256(s8, g2);
+                return rc == 1 ? A4R_EINVAL : rc;
+            }
+        }
+        const int rc = a4r_gemm_nt_256(s8, g);
         return rc == 1 ? A4R_EINVAL : rc;
     }
     if (g.lda < g.K || g.ldb < g.K || g.ldc < g.N) return A4R_EINVAL;
@@ -330,33 +387,13 @@ extern "C" int a4r_gemm_nt(void* stream, const a4r_gemm_t* gp) {
         if (rc != 1) return rc;
     }
     if (g_variant >= 2 && g.M % 256 == 0 && g.N % 256 == 0 && (g.K * isz) % 128 == 0) {
-        // Tile quantisation: the persistent 256-tile grid runs ceil(tiles / CUs) rounds.  When the last round would hold only a
-        // few whole row panels (ViT-B/16 at 8 users: 777 tiles = 3 rounds + 9 tiles), those panels go to the 128-tile kernel as
-        // a second launch instead of costing a full round (N = 768, K = 3072: 4 -> 3 rounds + ~1/4).
-        const int ntm = g.M / 256, ntn = g.N / 256, tiles = ntm * ntn, ncu = a4r_cu_count();
-        const int rem = tiles % ncu;
-        // fewer 256-tiles than half the CUs (8 users: 120 tiles at N = 768): the 128-tile kernel fills the chip better
-        // (measured 505 vs 454, 735 vs 624, 774 vs 637 TF/s at M = 10240; the large tile wins from 198 tiles on)
-        if (tiles * 2 <= ncu && g_variant == 2) goto small_tiles;
-        // (measured on the ViT step: 194 vs 190 user-seq/s with the split applied at every K against long K only)
-        int pf_ = 0, kp_ = 0;
-        if (a4r_gemm_tail_plan(g.M, g.N, &pf_, &kp_)) {       // the partial round runs as short tiles inside the same launch
-            const int rc = run_256(s, g);
-            if (rc != 1) return rc;
-        } else if (tiles > ncu && rem > 0 && rem * 4 <= ncu && rem % ntn == 0 && g_variant < 4) {
-            const int64_t head_rows = (int64_t)(ntm - rem / ntn) * 256;
-            a4r_gemm_t g1 = g, g2 = g;
-            g1.M = (int)head_rows;
-            g2.M = g.M - (int)head_rows;
-            g2.q8_tiled = 0;                      // the tail rows' 8-bit derivative stays row-major (whole row panels: same byte offset either way)
-            g2.drop_row0 = g.drop_row0 + head_rows;
-            auto adv = [&](const void* p, int ld, int sz) { return p ? (const void*)((const char*)p + head_rows * ld * sz) : nullptr; };
-            g2.A = adv(g.A, g.lda, isz);
-            g2.C = const_cast<void*>(adv(g.C, g.ldc, osz));
-            g2.C2 = const_cast<void*>(adv(g.C2, g.ldc2, c2sz));
-            g2.R1 = adv(g.R1, g.ldr1, osz);
-            g2.R2 = adv(g.R2, g.ldr2, osz);
-            g2.Pre = adv(g.Pre, g.ldpre, presz);
+        // How many leading rows the 256-tile kernel takes is a4r_gemm_rows_256(M, N) -- shared with the fp8 branch above, so that the
+        // writer and the reader of a tile-native 8-bit derivative agree on its layout whatever their operand types.
+        const int head_rows = a4r_gemm_rows_256(g.M, g.N);
+        if (head_rows == 0) goto small_tiles;
+        if (head_rows < g.M) {
+            a4r_gemm_t g1, g2;
+            split_rows(g, head_rows, isz, osz, c2sz, presz, g1, g2);
             const int rc = run_256(s, g1);
             if (rc == 0) {
                 if (g.in_dtype == A4R_BF16 && g.out_dtype == A4R_BF16) return launch_bn<bf16_t, bf16_t>(s, g2);
@@ -366,7 +403,7 @@ extern "C" int a4r_gemm_nt(void* stream, const a4r_gemm_t* gp) {
             }
             if (rc != 1) return rc;
         } else {
-            const int rc = run_256(s, g);
+            const int rc = run_256(s, g);        // (a partial last round may run as short tiles inside the same launch: a4r_gemm_tail_plan)
             if (rc != 1) return rc;              // 1 = this (dtype, act, dact) combination has no large-tile instantiation
         }
     }

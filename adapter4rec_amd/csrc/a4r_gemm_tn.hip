@@ -295,7 +295,8 @@ extern "C" int a4r_gemm_tn2(void* stream, const void* X1, int ldx1, const void* 
         return A4R_EINVAL;
     if ((reinterpret_cast<uintptr_t>(X1) | reinterpret_cast<uintptr_t>(Y1) | reinterpret_cast<uintptr_t>(X2) | reinterpret_cast<uintptr_t>(Y2)) & 15u) return A4R_EINVAL;
     const int tiles = (P1 / 64) * (Q1 / 64);
-    static const int wgs_per_product = getenv("A4R_TN2_WGS") ? atoi(getenv("A4R_TN2_WGS")) : 384;       // (A/B runs)
+    static const int wgs_env = getenv("A4R_TN2_WGS") ? atoi(getenv("A4R_TN2_WGS")) : 384;                 // (A/B runs)
+    const int wgs_per_product = wgs_env > 0 ? wgs_env : 384;                                                // (0 / not a number / negative: the default)
     int splits = (wgs_per_product + tiles - 1) / tiles;     // two products: half the splits of the single-product launch each
     const int stages = M / 64;
     if (splits > stages) splits = stages;

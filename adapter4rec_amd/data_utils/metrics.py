@@ -6,6 +6,7 @@ the history, drops the pad column and reports mean Hit@10 / nDCG@10 -- but the p
 label matrix and the argsort are replaced by one launch of a4r_eval_rank (rank of the target, history excluded, no
 [users, items] matrix in HBM)."""
 import math
+import os
 
 import numpy as np
 import torch
@@ -38,7 +39,8 @@ def get_item_embeddings(model, item_content, test_batch_size, args, use_modal, l
     out = []
     # the reference's test_batch_size (512 at run.py:650) is sized for ITS activation memory; the native encoder takes 4 096 titles per
     # call (fp32 sweep of 65 537 titles: 3.44 s at 512, 2.63 s = 84 % of the exact-fp32 MFMA peak at 4 096; profiles/r03_a_eval_bench.json)
-    step = max(int(test_batch_size), 4096)
+    # A4R_EVAL_SWEEP_BATCH overrides it either way (e.g. a smaller sweep to fit memory next to a large training state).
+    step = int(os.environ.get('A4R_EVAL_SWEEP_BATCH', 0)) or max(int(test_batch_size), 4096)
     with torch.no_grad():
         for i in range(lo, hi, step):
             out.append(enc(content[i:min(i + step, hi)].to(dev)))

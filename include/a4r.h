@@ -36,7 +36,7 @@ extern "C" {
 
 /* ABI version: bumped whenever a signature or struct below changes.  The Python binding (adapter4rec_amd/_lib.py) refuses a
  * library whose a4r_version() differs, so an A/B build made before a signature change cannot be called with shifted arguments. */
-#define A4R_ABI_VERSION 308
+#define A4R_ABI_VERSION 401
 int a4r_version(void);
 
 /* C[M,N] = epilogue(alpha * A[M,K] . B[N,K]^T): every nn.Linear on the path (HF BertSelfAttention
@@ -94,6 +94,11 @@ int a4r_gemm_tail_plan(int M, int N, int* p_full, int* kp);
 /* the largest kp a4r_gemm_tail_plan accepts (0 - 7; k < 0 only queries; initial value: A4R_GEMM_TAIL or 3); returns the previous one.  For
  * tests and A/B runs -- change it between, never inside, a write / read pair of a tile-native 8-bit derivative. */
 int a4r_gemm_tail_max(int k);
+/* Leading rows (a multiple of 256; 0 .. M) of an [M, N] a4r_gemm_nt output that the 256 x 256-tile kernel computes; the rows behind them go
+ * to the 128-tile kernel.  A function of (M, N), the CU count and a4r_gemm_variant only, never of the operand type: a tile-native 8-bit
+ * derivative (q8_tiled) is tile-native on exactly these rows and row-major behind them for EVERY launch that writes or reads it -- e4m3
+ * launches, which always run on the 256-tile kernel, are cut at the same row. */
+int a4r_gemm_rows_256(int M, int N);
 /* tuning knob for A/B measurements and tests: 0 = 128x128 tile, register-staged K pipeline; 1 = 128x128 tile, direct-to-LDS
  * (global_load_lds) pipeline; 2 (default) = 256x256 tile with a 2-deep LDS-DMA ring kept in flight across barriers
  * wherever M % 256 == 0, N % 256 == 0 (variant 1 elsewhere), chosen automatically: fewer 256-tiles than half the CUs -> the

@@ -16,7 +16,13 @@ Parity pin: ``tests/golden/*.npz`` were produced by ``tools/gen_golden.py`` by
 importing the reference (``Downstream/Text/model``, ``data_utils``) in the build
 container; ``tests/test_oracle_golden.py`` checks this file against them.
 LoRA (third-party ``loralib==0.1.1``, absent from the reference tree and the image)
-is restated from its published semantics and is *parity unpinned*.
+is restated from its published semantics (W x + b + (alpha / r) B A x, alpha = 1) and
+pinned ALGEBRAICALLY through the reference's own numbers: with W = W_base - B A / r the
+layer is the reference's plain Linear at W_base, so ``lora_linear`` must reproduce the
+imported reference's forward and dA = B^T dW / r, dB = dW A^T / r must follow from the
+reference's own dL/dW (``tests/golden/lora_pin_{text,image}.npz``, written by
+``tools/gen_golden_r4.py``; ``test_lora_pinned_through_merged_weights``).  What stays
+unpinned is only loralib's initialisation and its alpha default, which no run captures.
 """
 import math
 import random
@@ -107,7 +113,7 @@ def compacter_block(sd, p, h, cfg):
 
 
 def lora_linear(sd, p, x, r):
-    """loralib==0.1.1 lora.Linear (third party; parity unpinned): W x + b + (x A^T B^T) * (alpha/r), alpha=1."""
+    """loralib==0.1.1 lora.Linear (third party; pinned through merged weights, see the module docstring): W x + b + (x A^T B^T) * (alpha/r), alpha=1."""
     y = linear(x, sd[p + 'weight'], sd.get(p + 'bias'))
     if p + 'lora_A' in sd and r > 0:
         y = y + (x @ sd[p + 'lora_A'].t() @ sd[p + 'lora_B'].t()) * (1.0 / r)

@@ -91,3 +91,45 @@ def load_cv_variant(name):
     trainable = [strip(str(k)) for k in fx['trainable']]
     batch = (torch.from_numpy(common['images']), torch.from_numpy(common['log_mask']))
     return sd, cfg, fx, trainable, batch, cfg['noise']
+
+
+# ---------------------------------------------------------------- LoRA pinned through merged weights (tools/gen_golden_r4.py)
+def lora_pin_case(tower, r_enc=8, r_sas=4, seed=11):
+    """loralib is absent, but W x + b + (B A / r) x is the reference's own plain Linear at the merged weight W + B A / r.  With
+    W := W_base - B A / r the LoRA layer IS the pinned base layer: its forward must equal the imported reference's numbers in
+    lora_pin_<tower>.npz and its gradients follow from the reference's dL/dW by the chain rule
+        dA = B^T dW / r,   dB = dW A^T / r,   dbias = the reference's dbias.
+    -> (sd with lora_A / lora_B / shifted weight, oracle cfg, batch, pin fixture, {name: expected gradient}).
+    Image tower: SASRec w_V is a plain trainable Linear (Downstream/CV/run_adapter.py:394, r = 0): its expected gradient is dW itself."""
+    pin = np.load(os.path.join(GOLDEN, 'lora_pin_%s.npz' % tower))
+    if tower == 'text':
+        sd, cfg, _, _, batch, _ = load_variant('finetune_all')
+        cfg = dict(cfg, adapter_type='lora', lora_r_bert=r_enc, lora_r_sasrec=r_sas)
+    else:
+        sd, cfg, _, _, batch, _ = load_cv_variant('cv_vit_frozen')
+        cfg = dict(cfg, adapter_type='lora', lora_r_vit=r_enc, lora_r_sasrec=r_sas)
+    sd = dict(sd)
+    g = torch.Generator().manual_seed(seed)
+    expect = {}
+    for k in pin.files:
+        if not k.startswith('grad/'):
+            continue
+        n = k[5:]
+        dW = torch.from_numpy(pin[k])
+        if n.endswith('.bias'):
+            expect[n] = dW
+            continue
+        p = n[:-len('weight')]
+        sas = 'multi_head_attention' in p
+        if tower == 'image' and p.endswith('w_V.'):
+            expect[n] = dW
+            continue
+        r = r_sas if sas else r_enc
+        W = sd[n]
+        A = torch.randn(r, W.shape[1], generator=g) * 0.3
+        B = torch.randn(W.shape[0], r, generator=g) * 0.3
+        sd[p + 'lora_A'], sd[p + 'lora_B'] = A, B
+        sd[n] = W - (B @ A) / r
+        expect[p + 'lora_A'] = (B.t() @ dW) / r
+        expect[p + 'lora_B'] = (dW @ A.t()) / r
+    return sd, cfg, batch, pin, expect

@@ -145,6 +145,12 @@ def test_cv_host_logic_uint8_and_lora(simulated):
     _lora_case('cpu')
 
 
+def test_cv_host_logic_lora_pinned(simulated):
+    """ViT + LoRA against the imported reference's own numbers through merged weights (golden_util.lora_pin_case)."""
+    from test_engine_host_logic import lora_pin_step
+    lora_pin_step('cpu', 'image')
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize('dtype', ['fp32', 'bf16'])
 def test_cv_vit_lora_gpu(dtype):

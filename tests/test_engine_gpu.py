@@ -258,6 +258,15 @@ def test_eval_pipeline_vs_reference_fixture():
         assert abs(nd.mean() - float(fx[tag + '_means'][1])) < 1e-3
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize('tower', ['text', 'image'])
+def test_lora_step_vs_reference_merged(tower):
+    """a7 through the C ABI, pinned by the reference's own numbers: LoRA layers whose merged weight is the base weight reproduce the imported
+    reference's loss (1e-4) and their dA / dB follow the reference's dL/dW (tests/golden/lora_pin_*.npz, tools/gen_golden_r4.py)."""
+    from test_engine_host_logic import lora_pin_step
+    lora_pin_step('cuda:0', tower)
+
+
 @pytest.mark.parametrize('dtype', ['fp32', 'bf16'])
 def test_lora_vs_oracle(dtype):
     """a7: LoRA on q/v (BERT) and w_Q/w_V (SASRec).  loralib is third party and absent => parity unpinned by the reference;

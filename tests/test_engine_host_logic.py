@@ -123,6 +123,48 @@ def build_lora_cpu(dtype='fp32'):
     return model, args, osd, ocfg, items, mask
 
 
+def lora_pin_step(dev, tower='text'):
+    """The LoRA model on lora_pin_case's weights (W = W_base - B A / r): loss / embeddings vs the IMPORTED reference's numbers, dA / dB /
+    dbias vs the chain rule through the reference's own dL/dW (golden_util.lora_pin_case) -- a7 pinned without loralib."""
+    import adapter4rec_amd.inject as I
+    from golden_util import lora_pin_case
+    sd, cfg, (items, mask), pin, expect = lora_pin_case(tower)
+    if tower == 'text':
+        from adapter4rec_amd.model import BertBackbone, Model
+        args = TG.make_args(compute_dtype='fp32', adapter_type='lora', bert_adapter_down_size=8, adapter_down_size=4)
+        model = Model(args, 200, True, BertBackbone(dict(TG.GEOM)))
+        inj = I.inject_adapters
+    else:
+        import test_engine_cv as TC
+        from adapter4rec_amd.cv import Model, ViTForImageClassification
+        from adapter4rec_amd.cv.inject import inject_adapters as inj
+        args = TC.make_args(adapter_type='lora', lora_r=8, lora_r_sasrec=4, compute_dtype='fp32')
+        model = Model(args, 60, True, ViTForImageClassification(TC.GEOM))
+    I.freeze_all(model)
+    model = inj(model, args)
+    # (the reference's SASRec w_Q / w_V are bias-free Linears; the lora.Linear that replaces them has a bias: zero = the base layer)
+    missing = model.load_state_dict(sd, strict=False)
+    assert not missing.unexpected_keys and all(k.endswith(('w_Q.bias', 'w_V.bias')) for k in missing.missing_keys), missing
+    with torch.no_grad():
+        for n, p in model.named_parameters():
+            if n in missing.missing_keys:
+                p.zero_()
+    model.eval().to(dev)
+    names = [n for n, p in model.named_parameters() if p.requires_grad]
+    assert set(expect) <= set(names), sorted(set(expect) - set(names))
+    loss = model(items.to(dev), mask.to(dev), dev)
+    loss.backward()
+    assert abs(loss.item() - float(pin['loss'])) < 1e-4
+    params = dict(model.named_parameters())
+    for n, ref in expect.items():
+        ref = ref.numpy()
+        np.testing.assert_allclose(params[n].grad.cpu().numpy(), ref, atol=1e-6 + 1e-4 * np.abs(ref).max(), rtol=0, err_msg=n)
+
+
+def test_host_logic_lora_pinned(simulated):
+    lora_pin_step('cpu', 'text')
+
+
 def test_host_logic_lora(simulated):
     from oracle import ref_cpu as R
     model, args, osd, ocfg, items, mask = build_lora_cpu()

@@ -1376,6 +1376,57 @@ def test_gemm_q8_tiled_layout_roundtrip(M, N, K):
         assert torch.equal(torch.sort(tile_rm)[0], torch.sort(tile_t)[0])
 
 
+# an e4m3 FFN-up launch (always the 256-tile kernel) writes the tile-native derivative that a bf16 dgrad launch reads -- at a shape
+# the bf16 launch gives to the 128-tile kernel (16 tiles) and at one whose last row panels it hands over (264 tiles, short tiles switched off)
+@pytest.mark.parametrize('M,N,K,tail', [(1024, 1024, 256, None), (256 * 66, 1024, 128, 0), (256 * 66, 1024, 128, None)])
+def test_gemm_q8_tiled_fp8_writer_bf16_reader(M, N, K, tail):
+    """The layout of a q8_tiled tensor is a function of (M, N) only (a4r_gemm_rows_256): an e4m3 writer and a bf16 reader (and the reverse
+    pair) of the same [M, N] agree on it, so the tiled pipeline equals the row-major one bit for bit."""
+    from adapter4rec_amd import _lib as L
+    t = torch.bfloat16
+    old = L.gemm_tail_max(tail) if tail is not None else None
+    try:
+        rows = L.gemm_rows_256(M, N)
+        assert rows % 256 == 0 and 0 <= rows <= M
+        if (M, tail) == (1024, None):
+            assert rows == 0
+        if tail == 0:
+            assert 0 < rows < M
+        A, B = rnd(M, K, dtype=t, seed=1), rnd(N, K, dtype=t, scale=0.1, seed=2)
+        dY, W = rnd(M, K, dtype=t, seed=3), rnd(N, K, dtype=t, scale=0.1, seed=4)
+        bias = rnd(N, seed=5) * 0.1
+        A8, As = torch.zeros(M, K, dtype=torch.uint8, device=dev()), torch.zeros(M, 1, device=dev())
+        L.quant_rows_fp8(A, A8, As)
+        B8, Bs = L.quantize_weight_fp8(B)
+        dY8, dYs = torch.zeros(M, K, dtype=torch.uint8, device=dev()), torch.zeros(M, 1, device=dev())
+        L.quant_rows_fp8(dY, dY8, dYs)
+        W8, Ws = L.quantize_weight_fp8(W)
+        outs = {}
+        for tiled in (False, True):
+            C = torch.zeros(M, N, dtype=t, device=dev())
+            D = torch.zeros(M, N, dtype=torch.uint8, device=dev())
+            L.gemm_nt(A8, B8, C, bias=bias, C2=D, act=L.ACT_GELU, c2_deriv='q8', scale_a=As, scale_b=Bs, q8_tiled=tiled)       # e4m3 writer
+            G = torch.zeros(M, N, dtype=t, device=dev())
+            L.gemm_nt(dY, W, G, Pre=D, dact=L.DACT_MUL_Q8, q8_tiled=tiled)                                                    # bf16 reader
+            D2 = torch.zeros(M, N, dtype=torch.uint8, device=dev())
+            C2_ = torch.zeros(M, N, dtype=t, device=dev())
+            L.gemm_nt(A, B, C2_, bias=bias, C2=D2, act=L.ACT_GELU, c2_deriv='q8', q8_tiled=tiled)                              # bf16 writer
+            G8 = torch.zeros(M, N, dtype=torch.uint8, device=dev())
+            G8s = torch.zeros(M, 1, device=dev())
+            L.gemm_nt(dY8, W8, G8, Pre=D2, dact=L.DACT_MUL_Q8, scale_a=dYs, scale_b=Ws, c_fp8=2, c_scale=2.0, c_scale_out=G8s,
+                      q8_tiled=tiled)                                                                                          # e4m3 reader
+            outs[tiled] = (C, G, G8, G8s, D)
+        for i in range(4):
+            assert torch.equal(outs[False][i], outs[True][i]), i
+        d0, d1 = outs[False][4], outs[True][4]
+        assert torch.equal(d0[rows:], d1[rows:])                   # row-major behind the 256-tile rows
+        if rows:
+            assert not torch.equal(d0[:rows], d1[:rows]) and torch.equal(torch.sort(d0[:rows].flatten())[0], torch.sort(d1[:rows].flatten())[0])
+    finally:
+        if old is not None:
+            L.gemm_tail_max(old)
+
+
 @pytest.mark.parametrize('H', [256, 768])
 @pytest.mark.parametrize('act,inner,sums,drop', [(1, True, 'b', 0.1), (3, False, '', 0.0)])
 def test_adapter_ln_bwd_from_y(H, act, inner, sums, drop):

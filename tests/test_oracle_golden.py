@@ -26,6 +26,26 @@ def test_forward_and_grads(name):
         np.testing.assert_allclose(got, ref, atol=1e-5 + 1e-4 * np.abs(ref).max(), rtol=0, err_msg=k)
 
 
+@pytest.mark.parametrize('tower', ['text', 'image'])
+def test_lora_pinned_through_merged_weights(tower):
+    """a7: loralib==0.1.1 is absent, so LoRA is pinned ALGEBRAICALLY through the reference's own numbers (tools/gen_golden_r4.py): with
+    W = W_base - B A / r (B != 0) the oracle's lora_linear must reproduce the imported reference's forward on the base weights, and its
+    dA / dB must equal the chain rule through the reference's own dL/dW of the replaced query / value / w_Q / w_V Linears."""
+    from golden_util import lora_pin_case
+    sd, cfg, (items, mask), pin, expect = lora_pin_case(tower)
+    assert sum('lora_A' in k for k in expect) >= 6
+    with torch.no_grad():
+        out = R.model_forward(sd, items, mask, cfg)
+    np.testing.assert_allclose(out['input_embs_all'].numpy(), pin['input_embs_all'], atol=1e-5, rtol=0)
+    np.testing.assert_allclose(out['prec_vec'].numpy(), pin['prec_vec'], atol=1e-5, rtol=0)
+    assert abs(float(out['loss']) - float(pin['loss'])) < 1e-5
+    names = list(expect)
+    _, grads = R.loss_and_grads(sd, names, items, mask, cfg)
+    for n in names:
+        ref = expect[n].numpy()
+        np.testing.assert_allclose(grads[n].numpy(), ref, atol=1e-6 + 1e-4 * np.abs(ref).max(), rtol=0, err_msg=n)
+
+
 def test_hidden_states_per_layer():
     sd, cfg, fx, _, (items, _), _ = load_variant('houlsby')
     with torch.no_grad():
