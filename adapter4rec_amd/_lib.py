@@ -26,7 +26,7 @@ EXPORTS = [
     'a4r_ln_fwd', 'a4r_ln_bwd', 'a4r_gather_rows', 'a4r_scatter_rows', 'a4r_act_bwd_f32', 'a4r_score_bce_fwd',
     'a4r_score_bce_bwd', 'a4r_emb_grad_add_inputs', 'a4r_take_inputs', 'a4r_adam_step', 'a4r_pack_matrices',
     'a4r_eval_rank', 'a4r_dropout_apply', 'a4r_gemm_variant', 'a4r_gemm_tail_plan', 'a4r_gemm_tail_max', 'a4r_gemm_rows_256', 'a4r_adapter_ln_fwd', 'a4r_adapter_ln_bwd', 'a4r_ln_fwd_fp8', 'a4r_quant_rows_fp8', 'a4r_lora_merge', 'a4r_lora_merge_batch', 'a4r_phm_build', 'a4r_phm_bwd', 'a4r_unpack_add', 'a4r_memset_zero',
-    'a4r_sasrec_block_fwd', 'a4r_sasrec_block_bwd', 'a4r_scatter_rows_fill', 'a4r_attn_long_fwd', 'a4r_attn_long_bwd', 'a4r_patchify', 'a4r_vit_assemble', 'a4r_resample_u8', 'a4r_embed_bwd',
+    'a4r_sasrec_block_fwd', 'a4r_sasrec_block_bwd', 'a4r_scatter_rows_fill', 'a4r_attn_long_fwd', 'a4r_attn_long_bwd', 'a4r_patchify', 'a4r_vit_assemble', 'a4r_resample_u8', 'a4r_embed_bwd', 'a4r_mae_keep_indices',
 ]
 
 
@@ -196,15 +196,19 @@ def adapter_ln_ok(A, d):
     return A.dtype == torch.bfloat16 and d == 64 and A.shape[1] in (128, 256, 512, 768, 1024)
 
 
-def adapter_ln_fwd(A, R1, R2, Wd, bd, Wu, bu, gamma, beta, eps, act, zp, z, v, y, stats, M=None, y8=None, ys=None):
-    require_gpu(A, R1, R2, v, y)
+def adapter_ln_fwd(A, R1, R2, Wd, bd, Wu, bu, gamma, beta, eps, act, zp, z, v, y, stats, M=None, y8=None, ys=None, res32=None, y32=None):
+    """res32 / y32 (fp32 [M, H], optional): the residual operand that is not A read in fp32, and y before its bf16 rounding (include/a4r.h)."""
+    require_gpu(A, R1, R2, v, y, res32, y32)
     M = A.shape[0] if M is None else M
     assert y is not None or y8 is not None
+    assert all(t is None or (t.dtype == torch.float32 and t.shape[0] >= M) for t in (res32, y32))
     _check(lib().a4r_adapter_ln_fwd(_stream(), _p(A), C.c_int(_ld(A)), _p(R1), C.c_int(_ld(R1)), _p(R2), C.c_int(_ld(R2) if R2 is not None else 0),
                                     _p(Wd), _p(bd), _p(Wu), _p(bu), _p(gamma), _p(beta), C.c_float(eps), C.c_int(act),
                                     _p(zp), _p(z), _p(v), C.c_int(_ld(v) if v is not None else 0), _p(y), C.c_int(_ld(y) if y is not None else 0), _p(stats),
                                     C.c_int(M), C.c_int(A.shape[1]), C.c_int(Wd.shape[0]), C.c_int(_dt(A)),
-                                    _p(y8), C.c_int(_ld(y8) if y8 is not None else 0), _p(ys)), 'a4r_adapter_ln_fwd')
+                                    _p(y8), C.c_int(_ld(y8) if y8 is not None else 0), _p(ys),
+                                    _p(res32), C.c_int(_ld(res32) if res32 is not None else 0), _p(y32), C.c_int(_ld(y32) if y32 is not None else 0)),
+           'a4r_adapter_ln_fwd')
 
 
 def adapter_ln_bwd(dy, v, stats, gamma, dres, zp, act, WuT, WdT, inner_res, dv, dzp, dh, dgamma=None, dbeta=None, dbias=None, M=None,
@@ -319,6 +323,15 @@ def patchify(img, out, patch, keep_idx=None):
     assert keep_idx is None or (keep_idx.dtype == torch.int32 and keep_idx.is_contiguous() and keep_idx.shape[0] == n)
     _check(lib().a4r_patchify(_stream(), _p(img), C.c_int(kind), _p(out), C.c_int(_ld(out)), _p(keep_idx), C.c_int(n_keep),
                               C.c_int(n), C.c_int(Cc), C.c_int(Hi), C.c_int(Wi), C.c_int(patch), C.c_int(_dt(out))), 'a4r_patchify')
+
+
+def mae_keep_indices(keep, n_patches, noise=None, seed=0, site=0):
+    """keep int32 [n_items, n_keep] <- argsort(noise, 1)[:, :n_keep] (stable); noise None: counter-hash uniform noise drawn on the device."""
+    require_gpu(keep, noise)
+    assert keep.dtype == torch.int32 and keep.is_contiguous()
+    assert noise is None or (noise.dtype == torch.float32 and noise.is_contiguous() and tuple(noise.shape) == (keep.shape[0], n_patches))
+    _check(lib().a4r_mae_keep_indices(_stream(), _p(noise), _p(keep), C.c_int(keep.shape[0]), C.c_int(n_patches), C.c_int(keep.shape[1]),
+                                      C.c_uint64(int(seed) & (2 ** 64 - 1)), C.c_uint32(site)), 'a4r_mae_keep_indices')
 
 
 def resample_u8(src, dst, bounds, kk, n_outer, in_len, out_len, inner):

@@ -69,6 +69,9 @@ struct AdFwdArgs {
     float eps; int act;
     bf16_t* zp; bf16_t* z; bf16_t* v; bf16_t* y; int ldv, ldy; float* stats; int M;
     unsigned char* y8; int ld8; float* ys;      // optional: the LayerNorm output as OCP e4m3 + per-row scale (the next GEMM's fp8 A operand)
+    // --residual_dtype fp32 (round 4): the residual stream between sub-layers in fp32, as under the reference's autocast (its LayerNorm
+    // outputs fp32 and the residual add promotes to it): O32 replaces O as the residual operand, y32 is y before its bf16 rounding
+    const float* O32; int ldo32; float* y32; int ldy32;
 };
 
 // sum of the NW partial [16][64] tiles for EPT consecutive bottleneck columns of one row (thread t: element t * EPT)
@@ -96,9 +99,10 @@ A4R_DEV void store_bf16_n(bf16_t* dst, const float (&v)[EPT]) {
 // byte offset of bottleneck column zd of row r in the swizzled bf16 [16][64] operand image (16-byte chunk c at c ^ ((r >> 1) & 7))
 A4R_DEV int zbf_off(int r, int zd) { return r * 128 + ((((zd >> 3) ^ ((r >> 1) & 7))) << 4) + (zd & 7) * 2; }
 
-template <int CW, int NW>
+// R32: the residual operand is the fp32 tensor O32 (two 16-byte pieces per 8 columns instead of one)
+template <int CW, int NW, bool R32 = false>
 __global__ void __launch_bounds__(NW * 64) adapter_ln_fwd_kernel(const AdFwdArgs p) {
-    constexpr int KS = CW / 32, H = CW * NW, NT = NW * 64, EPT = 1024 / NT;
+    constexpr int KS = CW / 32, H = CW * NW, NT = NW * 64, EPT = 1024 / NT, OP = R32 ? 2 : 1;
     __shared__ __attribute__((aligned(16))) float zpart[NW][16][ZLD];
     __shared__ __attribute__((aligned(16))) char zbf[16 * 128];
     __shared__ float red[NW][16][2];
@@ -132,14 +136,21 @@ __global__ void __launch_bounds__(NW * 64) adapter_ln_fwd_kernel(const AdFwdArgs
     for (int i = 0; i < EPT; ++i) bd_r[i] = p.bd[rzd + i];
 
     const int ntiles = p.M / 16;
-    uint4 a_cur[KS], o_cur[KS], a_nxt[KS], o_nxt[KS];
+    uint4 a_cur[KS], o_cur[KS * OP], a_nxt[KS], o_nxt[KS * OP];
+#define A4R_AD_LOAD_O(dst_, row_)                                                                                       \
+    if constexpr (R32) {                                                                                               \
+        _Pragma("unroll") for (int s = 0; s < KS; ++s) {                                                               \
+            dst_[2 * s] = *reinterpret_cast<const uint4*>(p.O32 + (row_) * p.ldo32 + cl + s * 32);                      \
+            dst_[2 * s + 1] = *reinterpret_cast<const uint4*>(p.O32 + (row_) * p.ldo32 + cl + s * 32 + 4);              \
+        }                                                                                                              \
+    } else {                                                                                                           \
+        _Pragma("unroll") for (int s = 0; s < KS; ++s) dst_[s] = *reinterpret_cast<const uint4*>(p.O + (row_) * p.ldo + cl + s * 32); \
+    }
     {
         const size_t row = (size_t)blockIdx.x * 16 + fr;
 #pragma unroll
-        for (int s = 0; s < KS; ++s) {
-            a_cur[s] = *reinterpret_cast<const uint4*>(p.A + row * p.lda + cl + s * 32);
-            o_cur[s] = *reinterpret_cast<const uint4*>(p.O + row * p.ldo + cl + s * 32);
-        }
+        for (int s = 0; s < KS; ++s) a_cur[s] = *reinterpret_cast<const uint4*>(p.A + row * p.lda + cl + s * 32);
+        A4R_AD_LOAD_O(o_cur, row)
     }
     A4R_LDS_BARRIER();                                       // par[] visible
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
@@ -147,10 +158,8 @@ __global__ void __launch_bounds__(NW * 64) adapter_ln_fwd_kernel(const AdFwdArgs
             const int tn = tile + (int)gridDim.x < ntiles ? tile + (int)gridDim.x : tile;
             const size_t row = (size_t)tn * 16 + fr;
 #pragma unroll
-            for (int s = 0; s < KS; ++s) {
-                a_nxt[s] = *reinterpret_cast<const uint4*>(p.A + row * p.lda + cl + s * 32);
-                o_nxt[s] = *reinterpret_cast<const uint4*>(p.O + row * p.ldo + cl + s * 32);
-            }
+            for (int s = 0; s < KS; ++s) a_nxt[s] = *reinterpret_cast<const uint4*>(p.A + row * p.lda + cl + s * 32);
+            A4R_AD_LOAD_O(o_nxt, row)
         }
         const size_t row = (size_t)tile * 16 + fr;
         // ---- down-projection: partial over this wave's CW columns
@@ -187,14 +196,22 @@ __global__ void __launch_bounds__(NW * 64) adapter_ln_fwd_kernel(const AdFwdArgs
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) Mma<bf16_t>::mma(wu[t][ks], zf[ks], acc[t]);
         }
-        // ---- v = up + bias + residual(s), rounded to its bf16 storage (LayerNorm runs on what backward will re-read)
+        // ---- v = up + bias + residual(s) in fp32.  The LayerNorm runs on the UNROUNDED sum (round 4): rounding v to its bf16 storage first
+        // (rounds 1 - 3: "what backward will re-read") was one rounding of an O(1) tensor per sub-layer that the reference's autocast path
+        // does not have -- its LayerNorm reads the fp32 sum -- and cost 1.2 - 2.2x its distance from fp32 on scores / embeddings at BERT-base
+        // (tests/test_parity_base_gpu.py).  Backward: xhat = (v_bf16 - mean) rstd or (y - beta) / gamma, either way within bf16 rounding.
         float vv[KS][8];
         float s1 = 0.f;
 #pragma unroll
         for (int s = 0; s < KS; ++s) {
             float af[8], of[8], bu8[8];
             Elem<bf16_t>::unpack(a_cur[s], af);
-            Elem<bf16_t>::unpack(o_cur[s], of);
+            if constexpr (R32) {
+                *reinterpret_cast<uint4*>(of) = o_cur[2 * s];
+                *reinterpret_cast<uint4*>(of + 4) = o_cur[2 * s + 1];
+            } else {
+                Elem<bf16_t>::unpack(o_cur[s], of);
+            }
             *reinterpret_cast<float4*>(bu8) = *reinterpret_cast<const float4*>(&par[0][cl + s * 32]);
             *reinterpret_cast<float4*>(bu8 + 4) = *reinterpret_cast<const float4*>(&par[0][cl + s * 32 + 4]);
 #pragma unroll
@@ -203,9 +220,7 @@ __global__ void __launch_bounds__(NW * 64) adapter_ln_fwd_kernel(const AdFwdArgs
                 if (p.a_in_resid) x += af[j];
                 vv[s][j] = x;
             }
-            const uint4 pk = Elem<bf16_t>::pack(vv[s]);
-            if (p.v) *reinterpret_cast<uint4*>(p.v + row * p.ldv + cl + s * 32) = pk;      // (null: backward rebuilds xhat from y, see FY below)
-            Elem<bf16_t>::unpack(pk, vv[s]);
+            if (p.v) *reinterpret_cast<uint4*>(p.v + row * p.ldv + cl + s * 32) = Elem<bf16_t>::pack(vv[s]);      // (null: backward rebuilds xhat from y, see FY below)
 #pragma unroll
             for (int j = 0; j < 8; ++j) s1 += vv[s][j];
         }
@@ -240,6 +255,10 @@ __global__ void __launch_bounds__(NW * 64) adapter_ln_fwd_kernel(const AdFwdArgs
 #pragma unroll
             for (int j = 0; j < 8; ++j) { yv[s][j] = (vv[s][j] - mean) * rstd * g8[j] + b8[j]; am = fmaxf(am, fabsf(yv[s][j])); }
             if (p.y) *reinterpret_cast<uint4*>(p.y + row * p.ldy + cl + s * 32) = Elem<bf16_t>::pack(yv[s]);
+            if (p.y32) {
+                *reinterpret_cast<float4*>(p.y32 + row * p.ldy32 + cl + s * 32) = make_float4(yv[s][0], yv[s][1], yv[s][2], yv[s][3]);
+                *reinterpret_cast<float4*>(p.y32 + row * p.ldy32 + cl + s * 32 + 4) = make_float4(yv[s][4], yv[s][5], yv[s][6], yv[s][7]);
+            }
         }
         if (p.y8) {      // e4m3 row = y * 448 / max|y| from the fp32 values (one rounding; the same arithmetic as a4r_ln_fwd_fp8), scale = max|y| / 448
             am = fmaxf(am, __shfl_xor(am, 16, 64));
@@ -262,8 +281,11 @@ __global__ void __launch_bounds__(NW * 64) adapter_ln_fwd_kernel(const AdFwdArgs
             }
         }
 #pragma unroll
-        for (int s = 0; s < KS; ++s) { a_cur[s] = a_nxt[s]; o_cur[s] = o_nxt[s]; }
+        for (int s = 0; s < KS; ++s) a_cur[s] = a_nxt[s];
+#pragma unroll
+        for (int s = 0; s < KS * OP; ++s) o_cur[s] = o_nxt[s];
     }
+#undef A4R_AD_LOAD_O
 }
 
 struct AdBwdArgs {
@@ -536,7 +558,8 @@ inline bool misaligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p)
 
 template <int CW, int NW>
 int launch_fwd(hipStream_t s, const AdFwdArgs& a, int grid) {
-    hipLaunchKernelGGL((adapter_ln_fwd_kernel<CW, NW>), dim3(grid), dim3(NW * 64), 0, s, a);
+    if (a.O32) hipLaunchKernelGGL((adapter_ln_fwd_kernel<CW, NW, true>), dim3(grid), dim3(NW * 64), 0, s, a);
+    else hipLaunchKernelGGL((adapter_ln_fwd_kernel<CW, NW, false>), dim3(grid), dim3(NW * 64), 0, s, a);
     return a4r_launch_status();
 }
 template <int CW, int NW, bool DRES>
@@ -568,8 +591,9 @@ extern "C" int a4r_adapter_ln_fwd(void* stream, const void* A, int lda, const vo
                                   const void* Wd, const float* bd, const void* Wu, const float* bu,
                                   const float* gamma, const float* beta, float eps, int act,
                                   void* zp, void* z, void* v, int ldv, void* y, int ldy, float* stats, int M, int H, int d, int dtype,
-                                  void* y8, int ld8, float* ys) {
+                                  void* y8, int ld8, float* ys, const float* res32, int ldres32, float* y32, int ldy32) {
     if (!A || !R1 || !Wd || !bd || !Wu || !bu || !gamma || !beta || !zp || !z || (!v && !y) || (!y && !y8) || !stats) return A4R_EINVAL;      // v may be null when y is kept
+    if ((res32 && (ldres32 % 4 || ldres32 < H || misaligned16(res32))) || (y32 && (ldy32 % 4 || ldy32 < H || misaligned16(y32)))) return A4R_EINVAL;
     if (y8 && (!ys || ld8 % 8 || ld8 < H || (reinterpret_cast<uintptr_t>(y8) & 7u))) return A4R_EINVAL;
     if (dtype != A4R_BF16 || d != 64 || M <= 0 || M % 16) return A4R_EINVAL;
     if (lda % 8 || ldr1 % 8 || (R2 && ldr2 % 8) || (v && ldv % 8) || (y && ldy % 8)) return A4R_EINVAL;
@@ -588,6 +612,7 @@ extern "C" int a4r_adapter_ln_fwd(void* stream, const void* A, int lda, const vo
     a.zp = reinterpret_cast<bf16_t*>(zp); a.z = reinterpret_cast<bf16_t*>(z); a.v = reinterpret_cast<bf16_t*>(v); a.y = reinterpret_cast<bf16_t*>(y);
     a.ldv = ldv; a.ldy = ldy; a.stats = stats; a.M = M;
     a.y8 = reinterpret_cast<unsigned char*>(y8); a.ld8 = ld8; a.ys = ys;
+    a.O32 = res32; a.ldo32 = ldres32; a.y32 = y32; a.ldy32 = ldy32;      // (res32: the fp32 twin of the residual operand that is not A)
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     const int ntiles = M / 16, ncu = a4r_cu_count();
     const int grid = ntiles < ncu ? ntiles : ncu;

@@ -181,12 +181,31 @@ A4R_DEV void gelu_erf_both(float x, float& g, float& dg) {     // one exp, one r
 // (~790 s_nop per 256 x 256 tile epilogue and wave); the empty asm after each sweep ties the pairs together so that a result is consumed N / 2
 // instructions later.
 typedef float a4r_f2_t __attribute__((ext_vector_type(2)));
+#ifndef A4R_GELU_V2
+#define A4R_GELU_V2 1      /* 0 (A/B builds): round 3's form -- z = x / sqrt 2 formed, exp through a multiply by log2(e) */
+#endif
 template <int N>
 A4R_DEV void gelu_erf_both_n(float (&x)[N], float (&dg)[N]) {
     static_assert(N % 2 == 0 && N <= 8, "pairs");
     constexpr int P = N / 2;
     a4r_f2_t xv[P], z[P], e[P], t[P], pl[P], xc[P];
 #define A4R_TIE(a_) if constexpr (P == 4) asm volatile("" : "+v"(a_[0]), "+v"(a_[1]), "+v"(a_[2]), "+v"(a_[3])); else if constexpr (P == 2) asm volatile("" : "+v"(a_[0]), "+v"(a_[1]));
+#if A4R_GELU_V2
+    // The constants of the chain folded into each other (round 4: the epilogue is vector-issue bound, every instruction counts):
+    //   exp(-x^2 / 2) = exp2(-(c x)^2), c = sqrt(log2(e) / 2): v_exp_f32 IS exp2 -- no multiply by log2(e) per element;
+    //   t = 1 / (1 + p |z|), z = x / sqrt 2  ->  1 / (1 + (p / sqrt 2) |x|): one fma on |x|, z itself is never formed;
+    //   sign(erf(z)) = sign(x).
+#pragma unroll
+    for (int j = 0; j < P; ++j) { xv[j] = a4r_f2_t{x[2 * j], x[2 * j + 1]}; z[j] = xv[j] * 0.84932180028801904272f; xc[j] = xv[j] * 0.3989422804014327f; }
+#pragma unroll
+    for (int j = 0; j < P; ++j) {
+        const a4r_f2_t q = -z[j] * z[j];
+        e[j] = a4r_f2_t{__builtin_amdgcn_exp2f(q.x), __builtin_amdgcn_exp2f(q.y)};
+        t[j] = a4r_f2_t{__builtin_amdgcn_rcpf(__builtin_fmaf(fabsf(xv[j].x), 0.23164190423296285f, 1.f)),
+                        __builtin_amdgcn_rcpf(__builtin_fmaf(fabsf(xv[j].y), 0.23164190423296285f, 1.f))};
+        z[j] = xv[j];                   // (only the sign is read below)
+    }
+#else
 #pragma unroll
     for (int j = 0; j < P; ++j) { xv[j] = a4r_f2_t{x[2 * j], x[2 * j + 1]}; z[j] = xv[j] * 0.70710678118654752440f; xc[j] = xv[j] * 0.3989422804014327f; }
 #pragma unroll
@@ -195,6 +214,7 @@ A4R_DEV void gelu_erf_both_n(float (&x)[N], float (&dg)[N]) {
         e[j] = a4r_f2_t{__expf(q.x), __expf(q.y)};
         t[j] = a4r_f2_t{__builtin_amdgcn_rcpf(1.f + 0.3275911f * fabsf(z[j].x)), __builtin_amdgcn_rcpf(1.f + 0.3275911f * fabsf(z[j].y))};
     }
+#endif
     A4R_TIE(t)
 #pragma unroll
     for (int j = 0; j < P; ++j) pl[j] = t[j] * 1.061405429f + (-1.453152027f);

@@ -42,6 +42,9 @@
 #include <stdlib.h>
 #include "a4r_gemm_epi.h"
 
+#ifndef A4R_C2Q8_CT
+#define A4R_C2Q8_CT 1      /* 0 (A/B builds): the GELU + 8-bit-derivative launch tests c2_mode / the C2 pointer per group at run time (round 3) */
+#endif
 #ifndef A4R_PF_Q8
 #define A4R_PF_Q8 8        /* rows of 16 the 8-bit Pre operand is requested ahead of its use (1, 2, 4 or 8 = the whole tile up front) */
 #endif
@@ -813,7 +816,8 @@ int dispatch_same(hipStream_t s, const a4r_gemm_t& g) {   // in == out dtype: th
             if (m == 2) return launch256<T, T, A4R_ACT_NONE, A4R_ACT_NONE, 2>(s, g);
             if (m == 3) return launch256<T, T, A4R_ACT_NONE, A4R_ACT_NONE, 3>(s, g);      // dense + dropout + residual: an un-adapted BertSelfOutput / BertOutput (Pfeiffer, LoRA)
         }
-        if (g.act == A4R_ACT_GELU && g.dact == A4R_ACT_NONE && m == 8) return launch256<T, T, A4R_ACT_GELU, A4R_ACT_NONE, 8>(s, g);
+        if (g.act == A4R_ACT_GELU && g.dact == A4R_ACT_NONE && m == 8)               // (64: the second output is the 8-bit derivative, known at compile time)
+            return (g.c2_mode == 2 && A4R_C2Q8_CT) ? launch256<T, T, A4R_ACT_GELU, A4R_ACT_NONE, 8 | 64 * A4R_C2Q8_CT>(s, g) : launch256<T, T, A4R_ACT_GELU, A4R_ACT_NONE, 8>(s, g);
         if (g.act == A4R_ACT_NONE && g.dact == A4R_DACT_MULQ8_ && m == 0)            // (32: tile-native derivative, requested in front of the K loop)
             return g.q8_tiled ? launch256<T, T, A4R_ACT_NONE, A4R_DACT_MULQ8_, 32>(s, g) : launch256<T, T, A4R_ACT_NONE, A4R_DACT_MULQ8_, 0>(s, g);
         if (g.act == A4R_ACT_NONE && g.dact == A4R_DACT_MUL_ && m == 0) return launch256<T, T, A4R_ACT_NONE, A4R_DACT_MUL_, 0>(s, g);
@@ -842,7 +846,7 @@ int a4r_gemm_nt_256(hipStream_t s, const a4r_gemm_t& g) {
         if (g.c_fp8) {
             if ((g.c_fp8 != 1 && g.c_fp8 != 2) || !(g.c_scale > 0.f) || (g.c_fp8 == 2 && !g.c_scale_out)) return 1;
             if (g.act == A4R_ACT_GELU && g.dact == A4R_ACT_NONE && m == 8 && g.c2_mode == 2)              // FFN-up: u as e4m3 + gelu' as 8 bits
-                return launch256<fp8_t, bf16_t, A4R_ACT_GELU, A4R_ACT_NONE, 24>(s, g);
+                return launch256<fp8_t, bf16_t, A4R_ACT_GELU, A4R_ACT_NONE, 24 | 64 * A4R_C2Q8_CT>(s, g);
             if (g.act == A4R_ACT_NONE && g.dact == A4R_DACT_MULQ8_ && m == 0)                             // d FFN-down: du = (dy W) * gelu' as e4m3
                 return launch256<fp8_t, bf16_t, A4R_ACT_NONE, A4R_DACT_MULQ8_, 16>(s, g);
             return 1;

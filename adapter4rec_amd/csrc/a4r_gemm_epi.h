@@ -36,8 +36,26 @@ A4R_DEV GemmEpi<TO> make_epi(const a4r_gemm_t& p, uint32_t thr16, float keep_sca
 // 2^-8) -- at half the bytes of the FFN-up GEMM's second output.
 #define A4R_Q8_OFF 0.1289f
 #define A4R_Q8_STEP 0.0049326f
+#ifndef A4R_Q8_V2
+#define A4R_Q8_V2 1        /* 0 (A/B builds): round 3's form (add, multiply, v_rndne, convert per element) */
+#endif
 template <int NC> A4R_DEV void store_q8(uint8_t* p, const float* d) {
     uint32_t w[NC / 4];
+#if A4R_Q8_V2
+    // v_cvt_pk_u8_f32 itself rounds to nearest even and saturates at 0 / 255 (probed on gfx950, build/probe_cvt.hip: 0.5 -> 0, 1.5 -> 2,
+    // 2.5 -> 2, 254.5 -> 254, 300 -> 255, -0.6 -> 0): no v_rndne in front of it, and the add / multiply run as packed pairs -- 2 + 1
+    // instructions per element down to 1/2 + 1/2 + 1, the stored byte unchanged.
+    typedef float f2_ __attribute__((ext_vector_type(2)));
+    f2_ t[NC / 2];
+#pragma unroll
+    for (int j = 0; j < NC / 2; ++j) t[j] = (f2_{d[2 * j], d[2 * j + 1]} + A4R_Q8_OFF) * (1.f / A4R_Q8_STEP);
+#pragma unroll
+    for (int g = 0; g < NC / 4; ++g) {
+        w[g] = 0;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) w[g] = __builtin_amdgcn_cvt_pk_u8_f32(i & 1 ? t[2 * g + (i >> 1)].y : t[2 * g + (i >> 1)].x, (uint32_t)i, w[g]);
+    }
+#else
 #pragma unroll
     for (int g = 0; g < NC / 4; ++g) {
         w[g] = 0;
@@ -45,6 +63,7 @@ template <int NC> A4R_DEV void store_q8(uint8_t* p, const float* d) {
         for (int i = 0; i < 4; ++i)      // v_cvt_pk_u8_f32: saturating float -> byte i of the word (of an integer-valued float: no rounding question)
             w[g] = __builtin_amdgcn_cvt_pk_u8_f32(rintf((d[4 * g + i] + A4R_Q8_OFF) * (1.f / A4R_Q8_STEP)), (uint32_t)i, w[g]);
     }
+#endif
     if constexpr (NC == 8) *reinterpret_cast<uint2*>(p) = make_uint2(w[0], w[1]);
     else *reinterpret_cast<uint32_t*>(p) = w[0];
 }
@@ -118,10 +137,14 @@ A4R_DEV void epilogue_n(float (&v)[NC], const float* bias, uint32_t grow, int gc
     const int act = ACT >= 0 ? ACT : e.act;
     const int dact = DACT >= 0 ? DACT : e.dact;
     const uint32_t thr16 = (EF < 0 || (EF & 1)) ? e.thr16 : 0u;
-    const bool has_r1 = R1PF || ((EF < 0 || (EF & 2)) && e.R1), has_r2 = (EF < 0 || (EF & 4)) && e.R2, has_c2 = (EF < 0 || (EF & 8)) && e.C2;
+    // EF bit 64 (with 8): the second output IS the 8-bit GELU derivative (c2_mode 2) -- stated by the dispatcher, so neither the pointer nor
+    // the mode is tested per group (16 uniform branches per tile that also kept hipcc from scheduling across the groups)
+    constexpr bool C2Q8 = EF >= 0 && (EF & 64) != 0;
+    const bool has_r1 = R1PF || ((EF < 0 || (EF & 2)) && e.R1), has_r2 = (EF < 0 || (EF & 4)) && e.R2, has_c2 = C2Q8 || ((EF < 0 || (EF & 8)) && e.C2);
+    const int c2_mode = C2Q8 ? 2 : e.c2_mode;
 #pragma unroll
     for (int i = 0; i < NC; ++i) v[i] = v[i] * e.alpha + bias[i];
-    if (act == A4R_ACT_GELU && has_c2 && e.c2_mode) {          // value and derivative from one exp + one rcp
+    if (act == A4R_ACT_GELU && has_c2 && c2_mode) {          // value and derivative from one exp + one rcp
         float d[NC];
         if (A4R_ABL & 64) {
 #pragma unroll
@@ -129,11 +152,11 @@ A4R_DEV void epilogue_n(float (&v)[NC], const float* bias, uint32_t grow, int gc
         } else {
             gelu_erf_both_n<NC>(v, d);
         }
-        if (e.c2_mode == 2) store_q8<NC>(q8dst ? q8dst : reinterpret_cast<uint8_t*>(e.C2) + (size_t)grow * (uint32_t)e.ldc2 + gcol, d);
+        if (c2_mode == 2) { if (!(A4R_ABL & 128)) store_q8<NC>(q8dst ? q8dst : reinterpret_cast<uint8_t*>(e.C2) + (size_t)grow * (uint32_t)e.ldc2 + gcol, d); }
         else if (!(A4R_ABL & 128)) store_n<TO, NC>(e.C2 + (size_t)grow * (uint32_t)e.ldc2 + gcol, d);
     } else {
         if (has_c2) {
-            if (e.c2_mode) {
+            if (c2_mode) {
                 float d[NC];
 #pragma unroll
                 for (int i = 0; i < NC; ++i) d[i] = act_bwd(v[i], act);

@@ -114,6 +114,43 @@ extern "C" int a4r_vit_assemble(void* stream, const void* patches, int ldp, cons
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
+// a4r_mae_keep_indices: ViT-MAE random masking (HF ViTMAEEmbeddings.random_masking, reached from Downstream/CV/model/encoders.py:8-22):
+// ids_keep = argsort(noise, dim = 1)[:, :n_keep].  One workgroup per item; the row of noise sits in LDS and every patch COUNTS the
+// patches that sort in front of it (smaller noise, or equal noise and smaller index = the stable order), which IS its position in the
+// argsort -- n_patches^2 / 256 compares per thread (196 patches: 150), no sort network, no scratch.  noise NULL: the noise is drawn here,
+// uniform in [0, 1) from the counter hash (seed, site, item * n_patches + patch) -- the training path; an explicit noise tensor (parity
+// runs, explicit-noise fixtures) is ranked as given and reproduces a stable argsort bit for bit.
+namespace {
+constexpr int MAE_MAX_PATCHES = 4096;
+__global__ void __launch_bounds__(256) mae_keep_kernel(const float* __restrict__ noise, int32_t* __restrict__ keep, int n_patches, int n_keep,
+                                                       uint64_t seed, uint32_t site) {
+    __shared__ float v[MAE_MAX_PATCHES];
+    const int item = blockIdx.x;
+    for (int i = threadIdx.x; i < n_patches; i += 256) {
+        if (noise) v[i] = noise[(long)item * n_patches + i];
+        else v[i] = (float)(uint32_t)(a4r_hash64(seed, site, (uint64_t)item * (uint64_t)n_patches + (uint64_t)i) >> 40) * (1.f / 16777216.f);   // 24 bits: exact in fp32
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < n_patches; i += 256) {
+        const float x = v[i];
+        int rank = 0;
+        for (int j = 0; j < n_patches; ++j) {
+            const float y = v[j];                                      // (same address for the whole wave: an LDS broadcast)
+            rank += (y < x || (y == x && j < i)) ? 1 : 0;
+        }
+        if (rank < n_keep) keep[(long)item * n_keep + rank] = i;
+    }
+}
+}  // namespace
+
+extern "C" int a4r_mae_keep_indices(void* stream, const float* noise, int32_t* keep, int n_items, int n_patches, int n_keep,
+                                    uint64_t seed, uint32_t site) {
+    if (!keep || n_items <= 0 || n_patches <= 0 || n_patches > MAE_MAX_PATCHES || n_keep <= 0 || n_keep > n_patches) return A4R_EINVAL;
+    hipLaunchKernelGGL(mae_keep_kernel, dim3(n_items), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), noise, keep, n_patches, n_keep, seed, site);
+    return a4r_launch_status();
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
 // a4r_resample_u8: one pass of Pillow's fixed-point separable resampler (third party: Pillow src/libImaging/Resample.c,
 // ImagingResampleHorizontal_8bpc / Vertical_8bpc), which is what torchvision's Resize((R, R)) runs on the PIL image at
 // Downstream/CV/data_utils/dataset.py:77-81.  The coefficient tables come from the host (adapter4rec_amd/cv/image_io.py:

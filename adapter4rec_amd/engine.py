@@ -237,6 +237,9 @@ class TransRecEngine:
         # bf16 storage: the saved GELU derivative of the encoder FFNs is kept as 8-bit fixed point (include/a4r.h c2_mode 2)
         self.q8_deriv = dtype != 'fp32' and _os.environ.get('A4R_Q8_DERIV', '1') != '0'
         self.T = torch.float32 if dtype == 'fp32' else torch.bfloat16
+        # --residual_dtype fp32 (bf16 storage): fp32 twins of the residual stream, keyed by the bf16 tensor they shadow (see _sub_forward)
+        self.res32 = dtype != 'fp32' and getattr(args, 'residual_dtype', 'bf16') == 'fp32'
+        self._twin = {}
         self.S = getattr(args, 'num_words_title', 0)
         self.E = args.embedding_dim
         self.Lseq = args.max_seq_len + 1
@@ -937,6 +940,7 @@ class TransRecEngine:
         scales = (scale_a, scale_b): dense_in / w are e4m3 operands (fp8 encoder).  out8 = (q, scale): `out` is ALSO wanted as e4m3 rows +
         per-row scales (the next fp8 GEMM's A operand): written by the fused adapter kernel, by one more row pass everywhere else."""
         h, v, st = bufs['h' + which], bufs.get('v' + which), bufs['st' + which]        # v None: this sub-layer keeps y (`out` IS bufs['y' + which])
+        self._twin.pop(out.data_ptr(), None)           # (whatever fp32 twin an earlier sub-layer left for this buffer is stale from here on)
         assert v is not None or out.data_ptr() == bufs['y' + which].data_ptr()
         sk = dict(scale_a=scales[0], scale_b=scales[1]) if scales is not None else {}
         y8, ys = out8 if out8 is not None else (None, None)
@@ -970,8 +974,17 @@ class TransRecEngine:
         L.gemm_nt(dense_in, w, h, bias=bias, drop_p=p_drop, drop_site=site, drop_seed=seed, M=M, **sk)
         comp = ad.kind == 'compacter'  # no inner residual (modules.py:248-252); Houlsby: fc_up(act(fc_down(h))) + h, then + input (model.py:292-297)
         if self._fuse(blk, ad, h):     # ONE launch: down-projection, activation, up-projection, residual(s), LayerNorm (a4r_adapter_fused.hip)
+            r32 = y32 = None
+            if self.res32 and blk.T == torch.bfloat16:
+                # the residual stream in fp32 (reference under autocast: LayerNorm outputs fp32, BertSelfOutput's add promotes to it): this
+                # sub-layer reads the fp32 twin of its residual input when the sub-layer below left one, and leaves the twin of its output
+                # in one of two transient buffers (attention half / FFN half: a half's twin is dead once the next half of its kind has run)
+                r32 = self._twin_of(resid, M)
+                y32 = self._buf('res32.' + which, M, blk.H, torch.float32)
             L.adapter_ln_fwd(h, resid if comp else h, None if comp else resid, ad.wd, ad.bd, ad.wu, ad.bu, ln.gamma, ln.beta, ln.eps, ad.act,
-                             zp, z, v, out, st, M=M, y8=y8, ys=ys)
+                             zp, z, v, out, st, M=M, y8=y8, ys=ys, **(dict(res32=r32, y32=y32) if y32 is not None else {}))
+            if y32 is not None:
+                self._twin[out.data_ptr()] = y32
             return
         L.gemm_nt(h, ad.wd, z, bias=ad.bd, C2=zp, act=ad.act, M=M)
         if comp:
@@ -979,6 +992,12 @@ class TransRecEngine:
         else:
             L.gemm_nt(z, ad.wu, v, bias=ad.bu, R1=h, R2=resid, M=M)
         L.ln_fwd(v, ln.gamma, ln.beta, ln.eps, out, st, M=M)
+
+    def _twin_of(self, t, M):
+        """The fp32 twin of residual-stream tensor t ([>= M, H]) when the producing sub-layer left one in this forward (else None: the bf16
+        tensor itself is the residual, e.g. the embedding output or a sub-layer that ran on the multi-launch path)."""
+        w = self._twin.get(t.data_ptr())
+        return w if (w is not None and w.shape[0] >= M and w.shape[1] == t.shape[1]) else None
 
     def _fuse_bwd(self, blk, ad, t):
         return self._fuse(blk, ad, t) and blk.H != 1024          # (the backward kernel's LDS image of Wd does not fit at H = 1024)
@@ -1018,6 +1037,11 @@ class TransRecEngine:
             ctx_c, x_c = self._buf('ctx_c', cls_rows, H, T), self._buf('x_c', cls_rows, H, T)
             L.gather_rows(ctx, ctx_c, n_items, blk.S)
             L.gather_rows(x, x_c, n_items, blk.S)
+            x32 = self._twin_of(x, M) if self.res32 else None
+            if x32 is not None:                        # the CLS rows of the fp32 residual stream too
+                x_c32 = self._buf('x_c32', cls_rows, H, torch.float32)
+                L.gather_rows(x32, x_c32, n_items, blk.S)
+                self._twin[x_c.data_ptr()] = x_c32
             ctx, x, M = ctx_c, x_c, cls_rows
         if 'ctx_s' in bufs:
             L.gather_rows(ctx, bufs['ctx_s'], M, 1)
@@ -1356,6 +1380,7 @@ class TransRecEngine:
         """news [n, 2S] int64 (ids || mask) -> (emb fp32 [Ipad, E], pre fp32 [Ipad, E]) ; keeps x_final for backward."""
         S, H = self.S, self.H
         M = pad_to(n_items * S, 256)
+        self._twin.clear()
         key_mask = self._buf('kmask', n_items, S, torch.float32)          # filled by a4r_embed_ln from the mask half of the rows
         x = self._buf('xa', M, H, self.T)
         keep = self.train_emb and saved is not None

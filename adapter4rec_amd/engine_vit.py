@@ -411,10 +411,13 @@ class ViTRecEngine(TransRecEngine):
         argsort order.  noise None: drawn on the device (training); explicit noise: parity runs."""
         if not self.mae:
             return None
-        if noise is None:
-            noise = torch.rand(n_items, self.NP, device=self.dev)
-        L.require_gpu(noise)
-        return torch.argsort(noise.float(), dim=1)[:, :self.n_keep].to(torch.int32).contiguous()
+        keep = self._buf('mae_keep', n_items, self.n_keep, torch.int32)
+        if noise is None:              # counter-hash noise per (seed, item, patch): a4r_mae_keep_indices draws and ranks it in one launch
+            self._mae_draw = getattr(self, '_mae_draw', 0) + 1
+            L.mae_keep_indices(keep, self.NP, None, seed=(self.seed * 1000003 + self._mae_draw) & 0xFFFFFFFFFFFF, site=4900)
+        else:
+            L.mae_keep_indices(keep, self.NP, noise.to(self.dev, torch.float32).contiguous())
+        return keep
 
     _keep = None
 
@@ -425,6 +428,7 @@ class ViTRecEngine(TransRecEngine):
     def _encode(self, images, n_items, train, seed, saved):
         S, H = self.S, self.H
         M = pad_to(n_items * S, 256)
+        self._twin.clear()
         if images.dtype == torch.uint8:
             if images.shape[1:] != (self.R, self.R, self.C):
                 raise ValueError(f'uint8 images must be [n, {self.R}, {self.R}, {self.C}] (HWC), got {tuple(images.shape)}')

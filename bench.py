@@ -167,11 +167,13 @@ class GemmProbe:
                 names = ('bias', 'C2', 'R1', 'R2', 'Pre', 'act', 'dact', 'alpha', 'drop_p')
                 kw = dict(zip(names, a)); kw.update(k)
                 m = (1 if kw.get('drop_p', 0.0) > 0 else 0) | (2 if kw.get('R1') is not None else 0) | (4 if kw.get('R2') is not None else 0) | (8 if kw.get('C2') is not None else 0)
-                inst = {(0, 0): (0, 1, 2, 3), (self.L.ACT_GELU, 0): (8,), (0, self.L.DACT_MUL_Q8): (0, 32), (0, self.L.DACT_MUL): (0,)}
+                inst = {(0, 0): (0, 1, 2, 3), (self.L.ACT_GELU, 0): (8, 72), (0, self.L.DACT_MUL_Q8): (0, 32), (0, self.L.DACT_MUL): (0,)}
+                if ad == (self.L.ACT_GELU, 0) and kw.get('c2_deriv') == 'q8':
+                    m |= 64                                  # (the second output is the 8-bit derivative: known at compile time since round 4)
                 if A.dtype == torch.bfloat16 and ad == (0, self.L.DACT_MUL_Q8) and kw.get('q8_tiled'):
                     m |= 32                                  # (tile-native derivative: the instantiation that requests it in front of the K loop)
                 if A.dtype == torch.uint8:                   # e4m3 operands (+ 16: the output leaves as e4m3 too, a4r_gemm_t.c_fp8)
-                    inst = {(0, 0): (0,), (self.L.ACT_GELU, 0): (8, 24), (0, self.L.DACT_MUL_Q8): (16,)}
+                    inst = {(0, 0): (0,), (self.L.ACT_GELU, 0): (8, 72, 88), (0, self.L.DACT_MUL_Q8): (16,)}
                     m |= 16 if kw.get('c_fp8') else 0
                 ef = m if (A.dtype in (torch.bfloat16, torch.uint8) and Cout.dtype in (torch.bfloat16, torch.uint8) and m in inst.get(ad, ())) else -1
                 tile = (256,) + ad + (ef,)
@@ -422,7 +424,13 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    rank_ms = [round(dt / a.steps * 1e3, 3)]
     if world > 1:
+        # every rank's own clock over the same K steps (they end at a barrier, so the spread is what each rank measured between ITS
+        # synchronisation points): the first SCALE record shows by itself whether one rank / link lags; `value` uses the MAX
+        each = [torch.zeros(1, device=device, dtype=torch.float64) for _ in range(world)]
+        dist.all_gather(each, torch.tensor([dt], device=device, dtype=torch.float64))
+        rank_ms = [round(float(x.item()) / a.steps * 1e3, 3) for x in each]
         t = torch.tensor([dt], device=device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
@@ -538,6 +546,8 @@ def main():
                        'tokens_per_item': eng.S, 'items_per_user': 42, 'parallelism': f'dp{world}',
                        'path': 'public: optimizer.zero_grad(); FlatDDP(model)(items, mask); loss.backward(); FusedAdam.step()'},
             'rccl_ranks': rccl_ranks, 'allreduce_bytes_per_step': int(eng.flat_g.numel() * 4) if world > 1 else 0, 'allreduce_us': ar_us,
+            'ms_per_step_ranks': rank_ms, 'ms_per_step_spread': round(max(rank_ms) - min(rank_ms), 3),
+            'allreduce_overlapped': bool(world > 1 and eng.OVERLAP_ALLREDUCE and eng._grad_chunks() is not None),
             'loss': round(loss_val, 5), 'roofline': roof, 'cpu_baseline': cpu,
         }
         print(json.dumps(out))

@@ -168,8 +168,14 @@ int a4r_adapter_ln_fwd(void* stream, const void* A, int lda, const void* R1, int
                        const void* Wd, const float* bd, const void* Wu, const float* bu,
                        const float* gamma, const float* beta, float eps, int act,
                        void* zp, void* z, void* v, int ldv, void* y, int ldy, float* stats, int M, int H, int d, int dtype,
-                       void* y8, int ld8, float* ys);   /* y8 / ys (optional; y may then be NULL): y as OCP e4m3 + per-row scale, the
+                       void* y8, int ld8, float* ys,    /* y8 / ys (optional; y may then be NULL): y as OCP e4m3 + per-row scale, the
                                                            arithmetic of a4r_ln_fwd_fp8 (the fp8 A operand of the GEMM that follows) */
+                       const float* res32, int ldres32, float* y32, int ldy32);
+/* The LayerNorm of the forward runs on the fp32 sum v (its bf16 copy `v`, when asked for, is for the backward only).
+ * res32 / y32 (both optional; --residual_dtype fp32): the residual stream between sub-layers kept in fp32, as under the reference's
+ * autocast (LayerNorm outputs fp32 there and `hidden_states + input_tensor` promotes to it, HF BertSelfOutput / BertOutput under
+ * Downstream/Text/model/model.py:292-297): res32 [M, H] fp32 replaces the residual operand that is NOT A (R2 in the Houlsby form, R1
+ * in the Compacter form; that bf16 pointer is then only used to tell the forms apart), y32 [M, H] receives y before its bf16 rounding. */
 int a4r_adapter_ln_bwd(void* stream, const void* dy, int lddy, const void* v, int ldv, const float* stats, const float* gamma,
                        const void* dres, int lddres, const void* zp, int act, const void* WuT, const void* WdT, int inner_res,
                        void* dv, int lddv, void* dzp, void* dh, int lddh, float* dgamma, float* dbeta, float* dbias,
@@ -223,6 +229,13 @@ int a4r_patchify(void* stream, const void* img, int src_kind, void* out, int ldo
                  int n_items, int C, int Himg, int Wimg, int patch, int dtype);
 int a4r_vit_assemble(void* stream, const void* patches, int ldp, const float* cls, const float* pos, const int32_t* keep_idx,
                      void* out, int ldo, int n_items, int n_keep, int H, int dtype, int tokens_out);
+
+/* ViT-MAE random masking (HF ViTMAEEmbeddings.random_masking under Downstream/CV/model/encoders.py:8-22): keep[item][0 .. n_keep) =
+ * argsort(noise[item][0 .. n_patches))[: n_keep] in the STABLE order (ties by index).  noise fp32 [n_items, n_patches], or NULL: uniform
+ * [0, 1) noise drawn on the device from the counter hash (seed, site, item * n_patches + patch), 24 bits per draw.  NaNs in an explicit
+ * noise tensor are not supported (they sort nowhere).  n_patches <= 4096. */
+int a4r_mae_keep_indices(void* stream, const float* noise, int32_t* keep, int n_items, int n_patches, int n_keep, uint64_t seed,
+                         uint32_t site);
 
 /* One pass of Pillow's 8-bit separable resampler (third party; what torchvision's Resize((R, R)) executes on the PIL image
  * at Downstream/CV/data_utils/dataset.py:77-81): src uint8 [n_outer, in_len, inner] -> dst uint8 [n_outer, out_len, inner],

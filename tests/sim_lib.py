@@ -98,9 +98,15 @@ def adapter_ln_ok(A, d):
     return REAL.adapter_ln_ok(A, d)
 
 
-def adapter_ln_fwd(A, R1, R2, Wd, bd, Wu, bu, gamma, beta, eps, act, zp, z, v, y, stats, M=None, y8=None, ys=None):
-    """a4r_adapter_ln_fwd: zp = A Wd^T + bd; z = act(zp); v = z Wu^T + bu + R1 + R2; y = LN(v) (bf16 storage points as the kernel's)."""
+def adapter_ln_fwd(A, R1, R2, Wd, bd, Wu, bu, gamma, beta, eps, act, zp, z, v, y, stats, M=None, y8=None, ys=None, res32=None, y32=None):
+    """a4r_adapter_ln_fwd: zp = A Wd^T + bd; z = act(zp); v = z Wu^T + bu + R1 + R2; y = LN(v) (bf16 storage points as the kernel's).
+    res32: the fp32 twin of the residual operand that is not A; y32: y before its bf16 rounding."""
     M = A.shape[0] if M is None else M
+    if res32 is not None:                    # replaces the residual that is not A
+        if R2 is None or R1 is A or R1.data_ptr() == A.data_ptr():
+            R1, R2 = (R1, res32) if R2 is not None else (res32, None)
+        else:
+            R1 = res32
     assert A.dtype == torch.bfloat16 and Wd.shape[0] == 64 and M % 16 == 0
     assert (R1 is A and R2 is not None) or (R2 is A) or (R2 is None and R1 is not A) or \
         (R1.data_ptr() == A.data_ptr() and R2 is not None) or (R2 is not None and R2.data_ptr() == A.data_ptr())
@@ -109,7 +115,7 @@ def adapter_ln_fwd(A, R1, R2, Wd, bd, Wu, bu, gamma, beta, eps, act, zp, z, v, y
     zz = _act(p, act).to(z.dtype)
     z[:M] = zz
     vv = zz.float() @ Wu.float().t() + bu + R1[:M].float() + (R2[:M].float() if R2 is not None else 0)
-    vq = vv.to(A.dtype).float()               # (the kernel's statistics are those of the bf16-rounded sum, stored or not)
+    vq = vv                                   # (round 4: the LayerNorm runs on the fp32 sum; the bf16 copy v is for the backward)
     if v is not None:
         v[:M] = vv.to(v.dtype)
     mu = vq.mean(-1, keepdim=True)
@@ -119,6 +125,8 @@ def adapter_ln_fwd(A, R1, R2, Wd, bd, Wu, bu, gamma, beta, eps, act, zp, z, v, y
     out = (vq - mu) * rstd * gamma + beta
     if y is not None:
         y[:M] = out.to(y.dtype)
+    if y32 is not None:
+        y32[:M] = out
     if y8 is not None:
         _quant_rows(out, y8, ys)
 
@@ -229,6 +237,12 @@ def patchify(img, out, patch, keep_idx=None):
         cols = torch.gather(cols, 1, keep_idx.long()[:, :, None].expand(-1, -1, cols.shape[2]))
     rows = cols.reshape(-1, cols.shape[2])
     out[:rows.shape[0], :rows.shape[1]] = rows.to(out.dtype)
+
+
+def mae_keep_indices(keep, n_patches, noise=None, seed=0, site=0):
+    if noise is None:
+        noise = torch.rand(keep.shape[0], n_patches, generator=torch.Generator().manual_seed(int(seed) & 0x7FFFFFFF))
+    keep[:] = torch.argsort(noise.float(), dim=1, stable=True)[:, :keep.shape[1]].to(torch.int32)
 
 
 def resample_u8(src, dst, bounds, kk, n_outer, in_len, out_len, inner):

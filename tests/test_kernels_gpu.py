@@ -759,7 +759,7 @@ def test_adapter_ln_fwd(H, mode):
     zp_r = a.float() @ Wd.float().t() + bd
     z_r = act_ref(zp_r, act)
     v_r = z_r.to(t).float() @ Wu.float().t() + bu + R1.float() + (R2.float() if R2 is not None else 0)
-    vq = v_r.to(t).float()                                    # LayerNorm runs on the stored (bf16) v
+    vq = v_r                                                  # LayerNorm runs on the fp32 sum (round 4; rounds 1 - 3: on the bf16-rounded v)
     y_r = torch.nn.functional.layer_norm(vq, (H,), gamma, beta, 1e-12)
     close(zp, zp_r, t, 'zp')
     close(z, z_r, t, 'z')
@@ -1472,3 +1472,40 @@ def test_adapter_ln_bwd_from_y(H, act, inner, sums, drop):
     if b0 is not None:
         close(b1, b0, torch.float32, 'dbias', atol32=3e-2 * max(1.0, float(b0.abs().max())), rtol32=3e-2)
         close(d1, d0, torch.float32, 'dbd', atol32=3e-2 * max(1.0, float(d0.abs().max())), rtol32=3e-2)
+
+
+@pytest.mark.parametrize('n_items,NP,n_keep', [(84, 196, 49), (7, 16, 4), (3, 1000, 1000)])
+def test_mae_keep_indices(n_items, NP, n_keep):
+    """a4r_mae_keep_indices (HF ViTMAEEmbeddings.random_masking under Downstream/CV/model/encoders.py:8-22): explicit noise -> bit-equal to
+    a stable argsort, ties included; noise drawn on the device -> distinct in-range indices per item, reproducible per seed, uniform."""
+    from adapter4rec_amd import _lib as L
+    g = torch.Generator().manual_seed(3)
+    noise = torch.rand(n_items, NP, generator=g)
+    noise[0, : NP // 2] = noise[0, NP // 2: 2 * (NP // 2)]            # ties: the stable order decides
+    noise[-1] = 0.25
+    keep = torch.full((n_items, n_keep), -1, dtype=torch.int32, device=dev())
+    L.mae_keep_indices(keep, NP, noise.to(dev()))
+    ref = torch.argsort(noise, dim=1, stable=True)[:, :n_keep].to(torch.int32)
+    assert torch.equal(keep.cpu(), ref)
+    k1 = torch.full((n_items, n_keep), -1, dtype=torch.int32, device=dev())
+    k2, k3 = k1.clone(), k1.clone()
+    L.mae_keep_indices(k1, NP, None, seed=77, site=4900)
+    L.mae_keep_indices(k2, NP, None, seed=77, site=4900)
+    L.mae_keep_indices(k3, NP, None, seed=78, site=4900)
+    assert torch.equal(k1, k2) and (n_keep == NP or not torch.equal(k1, k3))
+    srt = torch.sort(k1.long(), dim=1)[0]
+    assert int(srt.min()) >= 0 and int(srt.max()) < NP and bool((srt[:, 1:] > srt[:, :-1]).all())
+
+
+def test_mae_keep_indices_uniform():
+    from adapter4rec_amd import _lib as L
+    n_items, NP, n_keep = 4096, 196, 49
+    k = torch.zeros(n_items, n_keep, dtype=torch.int32, device=dev())
+    L.mae_keep_indices(k, NP, None, seed=5, site=4900)
+    cnt = torch.bincount(k.flatten().long().cpu(), minlength=NP).double()
+    p = n_keep / NP
+    z = (cnt - n_items * p) / (n_items * p * (1 - p)) ** 0.5
+    assert float(z.abs().max()) < 5.0, float(z.abs().max())
+    first = torch.bincount(k[:, 0].long().cpu(), minlength=NP).double()        # the smallest-noise patch is uniform over the patches
+    z0 = (first - n_items / NP) / (n_items / NP) ** 0.5
+    assert float(z0.abs().max()) < 5.0, float(z0.abs().max())

@@ -22,8 +22,9 @@ def build_base(seed=3, users=2, n_items=4096, act='RELU'):
     return build_text_case('bert', act, seed=seed, users=users, n_items=n_items)
 
 
-def hip_step(model, dtype, items, mask):
+def hip_step(model, dtype, items, mask, residual='bf16'):
     model.compute_dtype = dtype
+    model.args.residual_dtype = residual
     model.invalidate_native()
     for p in model.parameters():
         p.grad = None
@@ -102,8 +103,8 @@ def test_base_geometry_step_fp32_and_bf16_vs_oracle_and_reference(name):
     assert abs(ref['loss'] - rfx['loss']) < 1e-4 and float((ref['emb'] - rfx['emb']).abs().max()) < 1e-4
     assert float((ref['pos'] - rfx['pos']).abs().max()) < 1e-4 and float((ref['neg'] - rfx['neg']).abs().max()) < 1e-4
 
-    def step(dtype):
-        o = hip_step(model, dtype, items, mask)
+    def step(dtype, residual='bf16'):
+        o = hip_step(model, dtype, items, mask, residual)
         o['pos'], o['neg'] = sel(o['pos']), sel(o['neg'])
         return o
 
@@ -150,9 +151,26 @@ def test_base_geometry_step_fp32_and_bf16_vs_oracle_and_reference(name):
     print(f'{name} HIP bf16 vs the reference under autocast(bfloat16), both measured from the fp32 reference:')
     for k, v in rep.items():
         print('   ', k, {a: (round(b, 5) if isinstance(b, float) else b) for a, b in v.items()})
-    for k in ('pos', 'neg', 'emb'):                     # "as accurate as the reference's AMP": within 2x of ITS distance from fp32
-        assert rep[k]['hip_rms'] <= 2.0 * rep[k]['ref_autocast_rms'] + 1e-3, (k, rep[k])
+    # "as accurate as the reference's AMP": HIP bf16's distance from fp32 against the reference-under-autocast's own, per quantity.
+    # Serial Houlsby (one-launch adapter kernels; since round 4 their LayerNorm reads the fp32 sum instead of its bf16 rounding): measured
+    # rms ratios 1.19 / 1.33 / 1.25 (pos / neg / emb; rounds 1 - 3: 2.2 / 1.5 / 1.6) -> bound = measured + 20 %.  Pfeiffer (no adapter in the
+    # attention half: dense + residual leave the GEMM as bf16 and a4r_ln_fwd reads that) keeps the 2x bound.
+    houlsby = kw.get('adapter_type', 'houslby') == 'houslby'
+    lim = 1.6 if houlsby else 2.0
+    for k in ('pos', 'neg', 'emb'):
+        assert rep[k]['hip_rms'] <= lim * rep[k]['ref_autocast_rms'] + 1e-3, (k, rep[k])
         assert rep[k]['hip_max'] <= 3.0 * rep[k]['ref_autocast_max'] + 1e-3, (k, rep[k])
+    if houlsby:
+        # --residual_dtype fp32: the residual stream between sub-layers in fp32, as under the reference's autocast (its LayerNorm outputs
+        # fp32).  Measured 0.77 / 0.63 / 0.78 of the reference-under-autocast's distance from fp32: at least as accurate as the reference's AMP.
+        r32 = step('bf16', 'fp32')
+        hip32 = dict(pos=r32['pos'] - rfx['pos'], neg=r32['neg'] - rfx['neg'], emb=r32['emb'] - rfx['emb'])
+        rep32 = {k: dict(hip_rms=rms(hip32[k]), ref_autocast_rms=rms(acd[k]), ratio=rms(hip32[k]) / max(rms(acd[k]), 1e-30)) for k in hip32}
+        print(f'{name} HIP bf16 + --residual_dtype fp32 vs the reference under autocast(bfloat16):', {k: round(v['ratio'], 3) for k, v in rep32.items()})
+        for k in ('pos', 'neg', 'emb'):
+            assert rep32[k]['hip_rms'] <= 1.0 * rep32[k]['ref_autocast_rms'] + 1e-3, (k, rep32[k])
+        g32, w32 = grad_err(r32['grads'], ref['grads'])
+        assert g32 < 0.2 and abs(r32['loss'] - ref['loss']) < 3e-2, (g32, w32, r32['loss'])
     assert rep['grad']['median_ratio'] <= 2.0 and rep['grad']['hip_worst'] <= 2.0 * rep['grad']['ref_autocast_worst'] + 0.02, rep['grad']
     # fp8 encoder on the text tower (north_star: "fp8 MFMA encoder"): frozen qkv / attention-output / FFN GEMMs + the FFN dgrads on e4m3
     # operands (per-token x per-channel scales), everything else as in bf16.  Measured bounds with ~2x headroom.
