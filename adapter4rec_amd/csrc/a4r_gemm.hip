@@ -323,7 +323,7 @@ static void split_rows(const a4r_gemm_t& g, int64_t head_rows, int isz, int osz,
 
 extern "C" int a4r_gemm_variant(int v) {
     const int old = g_variant;
-    if (v == 3 || v == 5) return -1;         // the four-wave forms were measured slower and are no longer part of the library (tools/rejected_kernels/)
+    if (v == 3 || v == 5) return -1;         // the four-wave forms were measured slower and are no longer part of the library
     if (v >= 0 && v <= 4) g_tn_variant = v != 0;
     if (v >= 0 && v <= 4) g_variant = v;     // 0/1: 128-tile kernels, 2: automatic (default), 4: eight-wave 256 tile forced
     return old;

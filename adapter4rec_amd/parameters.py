@@ -73,6 +73,11 @@ def build_parser():
     # ============= native path ==================
     p.add_argument('--compute_dtype', type=str, default='bf16', choices=['bf16', 'fp32', 'fp8'],
                    help='item-encoder storage type on the MI355X path (fp32 = reference precision of Downstream/Text)')
+    p.add_argument('--device_sampler', type=int, default=0,
+                   help='1: training batches are drawn ON THE GPU (data_utils.DeviceTrainSampler: user sequences and item contents resident in HBM, '
+                        "negatives by vectorised rejection) instead of BuildTrainDataset + DataLoader workers -- the same distribution as "
+                        'Downstream/Text/data_utils/dataset.py:24-49, not the same random stream; the host then only enqueues.  0 (default): the '
+                        "reference's DataLoader path (bit-pinned); it keeps up with the GPU from ~4 workers on (profiles/r04_*_run_throughput.json)")
     p.add_argument('--residual_dtype', type=str, default='bf16', choices=['bf16', 'fp32'],
                    help="bf16 storage only: fp32 keeps the item encoder's residual stream between sub-layers in fp32, as the reference's "
                         'autocast(bfloat16) does (its LayerNorm outputs fp32): scores / embeddings then sit at 0.7 - 0.9x the distance of the '

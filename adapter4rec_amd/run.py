@@ -18,6 +18,7 @@ from torch.utils.data import DataLoader
 
 from .data_utils import (BuildTrainDataset, eval_model, get_doc_input_bert, get_item_embeddings, read_behaviors,
                          read_news_bert)
+from .data_utils.dataset import DeviceTrainSampler
 from .data_utils.utils import (get_checkpoint, para_and_log, report_time_eval, report_time_train, save_model, setuplogger)
 from .ddp import FlatDDP, any_rank
 from .inject import freeze_all, inject_adapters, optimizer_groups
@@ -117,6 +118,16 @@ def train(args, use_modal, local_rank, Log_file, Log_screen, model_dir, start_ti
     train_dl = DataLoader(train_dataset, batch_size=args.batch_size, num_workers=args.num_workers,
                           worker_init_fn=worker_init, pin_memory=True, sampler=sampler)
     model, start_epoch, ckpt2 = build_model(args, item_num, use_modal, bert_model, local_rank, Log_file, model_dir)
+    dev_sampler = None
+    if getattr(args, 'device_sampler', 0):             # batches drawn on the GPU; the DistributedSampler still shards and shuffles the users
+        dev_sampler = DeviceTrainSampler(users_train, item_content, item_num, args.max_seq_len, next(model.parameters()).device,
+                                         seed=123456 + dist.get_rank())
+
+        def device_batches():
+            ids = list(iter(sampler))
+            for i in range(0, len(ids), args.batch_size):
+                items, mask = dev_sampler.sample(ids[i:i + args.batch_size])
+                yield items.view(-1, args.max_seq_len + 1, 2, items.size(-1)), mask
     model = FlatDDP(model, device_ids=[local_rank], output_device=local_rank)
     optimizer = FusedAdam(optimizer_groups(model, args))
     if ckpt2 is not None:
@@ -131,8 +142,10 @@ def train(args, use_modal, local_rank, Log_file, Log_screen, model_dir, start_ti
         Log_file.info('epoch {} start'.format(now_epoch))
         loss, batch_index, need_break = 0.0, 1, False
         train_dl.sampler.set_epoch(now_epoch)
+        if dev_sampler is not None:
+            dev_sampler.set_epoch(now_epoch)
         model.train()
-        for sample_items, log_mask in train_dl:
+        for sample_items, log_mask in (train_dl if dev_sampler is None else device_batches()):
             sample_items, log_mask = sample_items.to(local_rank, non_blocking=True), log_mask.to(local_rank, non_blocking=True)
             sample_items = sample_items.view(-1, sample_items.size(-1))
             optimizer.zero_grad()

@@ -253,7 +253,7 @@ def cpu_baseline(device, sample_users=8):
         t0 = time.perf_counter()
         out, grads = one_step()
         times.append(time.perf_counter() - t0)
-    dt = sum(times) / len(times)
+    dt = sum(times) / len(times)            # `value` is the MEAN; the fastest step is reported next to it (host cores are shared: the spread is large)
     ref_loss = float(out['loss'].detach())
     diff = {}
     for dtype in ('fp32', 'bf16'):
@@ -274,7 +274,8 @@ def cpu_baseline(device, sample_users=8):
                            grad_max_err_rel_to_tensor_max=gerr, worst_grad=worst)
         del m
     torch.cuda.empty_cache()
-    return dict(value=sample_users / dt, unit='user-sequences/sec', cores=torch.get_num_threads(), kind='port',
+    return dict(value=sample_users / dt, value_best_step=sample_users / min(times), step_seconds=[round(t, 2) for t in times],
+                unit='user-sequences/sec', cores=torch.get_num_threads(), kind='port',
                 sample=f'1 warm-up + 3 timed train steps (fwd+bwd+Adam) of oracle/ref_cpu.py, B={sample_users} users ({sample_users * 42} items x 30 tokens), '
                        f'BERT-base+Houlsby fp32, dropout off (BASELINE.json configs[0]): ' + ' / '.join(f'{t:.1f}' for t in times) + ' s',
                 loss=ref_loss, diff=diff,
@@ -330,6 +331,10 @@ def main():
                     help='fp8: bf16 storage + OCP e4m3 operands (block-scaled MFMA rate) for the frozen encoder\'s qkv / attention-output / FFN forward GEMMs and the FFN dgrads, '
                          'text and image towers (BASELINE.json quotes the headline in bf16: the default)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--host-images', action='store_true',
+                    help='image workloads: ALSO time the step with its uint8 batch coming from PINNED HOST memory every step (H2D on a copy stream, '
+                         'overlapped with the previous step: the LMDB -> GPU pipeline of SURVEY 8(d)); reported next to `value`, which stays the '
+                         'HBM-resident figure')
     ap.add_argument('--no-roofline', action='store_true')
     ap.add_argument('--gemm-variant', type=int, default=-1, help='A/B knob of a4r_gemm_variant (include/a4r.h); default: the library default')
     a = ap.parse_args()
@@ -454,6 +459,73 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         ar_us = round(float(t.item()), 1)
 
+    host_leg = None
+    if image and a.host_images:
+        # The input pipeline of Downstream/CV/data_utils/dataset.py:85-113 ends in a host tensor per batch; here that tensor is the raw uint8
+        # HWC batch (resize / normalise / patchify run on the GPU).  Two pinned host batches, two device buffers, one copy stream: the copy of
+        # batch i + 1 is enqueued as soon as step i has been enqueued and waits (event) for step i - 1, the last reader of its buffer.
+        K = a.steps
+        pinned = [b[0].cpu().pin_memory() for b in batches]
+        dev_buf = [torch.empty_like(batches[0][0]) for _ in range(2)]
+        copy_s = torch.cuda.Stream(device=device)
+        ready = [torch.cuda.Event() for _ in range(2)]           # H2D of buffer j finished
+        freed = [torch.cuda.Event() for _ in range(2)]           # the step that read buffer j has been enqueued in full
+        main_s = torch.cuda.current_stream(device)
+        mask_dev = batches[0][1]
+
+        def put(i):
+            j = i % 2
+            with torch.cuda.stream(copy_s):
+                copy_s.wait_event(freed[j])
+                dev_buf[j].copy_(pinned[i % len(pinned)], non_blocking=True)
+                ready[j].record(copy_s)
+
+        def host_step(i):
+            j = i % 2
+            main_s.wait_event(ready[j])
+            opt.zero_grad()
+            loss = ddp(dev_buf[j], mask_dev, local)
+            loss.backward()
+            opt.step()
+            freed[j].record(main_s)
+            put(i + 2)
+            return loss
+        for j in range(2):
+            freed[j].record(main_s)
+        put(0)
+        put(1)
+        for i in range(max(3, a.warmup // 2)):
+            host_step(i)
+        i0 = max(3, a.warmup // 2)
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        t0h = time.perf_counter()
+        for i in range(K):
+            host_step(i0 + i)
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        dth = time.perf_counter() - t0h
+        if world > 1:
+            t = torch.tensor([dth], device=device, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dth = float(t.item())
+        # the copy on its own (no compute beside it): what the PCIe leg costs when nothing hides it
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize()
+        e0.record()
+        for i in range(10):
+            dev_buf[0].copy_(pinned[0], non_blocking=True)
+        e1.record()
+        torch.cuda.synchronize()
+        h2d_ms = e0.elapsed_time(e1) / 10
+        nbytes = pinned[0].numel()
+        host_leg = {'value_with_h2d': round(world * a.batch * K / dth, 2), 'ms_per_step_with_h2d': round(dth / K * 1e3, 3),
+                    'h2d_bytes_per_step': int(nbytes), 'h2d_ms_alone': round(h2d_ms, 3), 'h2d_GBps_alone': round(nbytes / h2d_ms / 1e6, 1),
+                    'overlap': 'copy stream, double-buffered pinned host -> device, batch i + 1 copied during step i',
+                    'with_over_without': round((world * a.batch * K / dth) / (world * a.batch * a.steps / dt), 4)}
+
     roof = None
     if rank == 0 and not a.no_roofline:
         import adapter4rec_amd.engine as E
@@ -502,8 +574,14 @@ def main():
                     instantiations=table, dominant_instantiation=inst_name(key),
                     dominant_instantiation_tflops=round(rows[key][0] / rows[key][1] / 1e12, 2),
                     all_gemm_tflops=round(total_f / total_t / 1e12, 2), gemm_time_share_of_step=round(total_t / 2 / (dt / a.steps), 3),
-                    step_tflops_per_gpu=round(a.batch * a.steps / dt * GFLOP_PER_USER[wl] / 1e3, 1),
-                    step_frac_of_peak=round(a.batch * a.steps / dt * GFLOP_PER_USER[wl] / 1e3 / peak, 4))
+                    # EXECUTED flops: 2MNK of every a4r_gemm_nt launch of one step (the probe above), i.e. without the work the path skips
+                    # (the last layer's attention-output / FFN half runs on the CLS rows only, layer 0 has no d qkv) -- SURVEY 8(d)
+                    executed_gemm_tflop_per_step=round(total_f / 2 / 1e12, 3),
+                    step_tflops_per_gpu=round(total_f / 2 / (dt / a.steps) / 1e12, 1),
+                    step_frac_of_peak=round(total_f / 2 / (dt / a.steps) / 1e12 / peak, 4),
+                    # SURVEY's formula (42 items x 12 FULL layers, forward + 2 x backward): what a path that skips nothing would execute
+                    algorithmic_step_tflops_per_gpu=round(a.batch * a.steps / dt * GFLOP_PER_USER[wl] / 1e3, 1),
+                    algorithmic_step_frac_of_peak=round(a.batch * a.steps / dt * GFLOP_PER_USER[wl] / 1e3 / peak, 4))
         if fp8_t > 0:
             roof['fp8_gemm_tflops'] = round(fp8_f / fp8_t / 1e12, 2)
             roof['fp8_share_of_gemm_flops'] = round(fp8_f / total_f, 3)
@@ -550,6 +628,8 @@ def main():
             'allreduce_overlapped': bool(world > 1 and eng.OVERLAP_ALLREDUCE and eng._grad_chunks() is not None),
             'loss': round(loss_val, 5), 'roofline': roof, 'cpu_baseline': cpu,
         }
+        if host_leg is not None:
+            out['host_images'] = host_leg
         print(json.dumps(out))
     if world > 1:
         dist.barrier()                 # rank 0 ran its instrumented pass alone: leave the group together

@@ -23,7 +23,7 @@ def text_args(dtype, act='RELU', adapter_type='houslby', arch='sasrec'):
         adding_adapter_to='all', arch=arch, compute_dtype=dtype)
 
 
-def build_text_case(encoder='bert', act='RELU', adapter_type='houslby', arch='sasrec', seed=3, users=2, n_items=4096):
+def build_text_case(encoder='bert', act='RELU', adapter_type='houslby', arch='sasrec', seed=3, users=2, n_items=4096, full_histories=False):
     """BERT-base / RoBERTa-base geometry (12 x 768, 12 heads, F = 3072, S = 30), `users` users = 42 item slots each: one full
     history and short ones (left-padded with the PAD item), full and partially padded titles."""
     from adapter4rec_amd.inject import freeze_all, inject_adapters
@@ -45,7 +45,7 @@ def build_text_case(encoder='bert', act='RELU', adapter_type='houslby', arch='sa
     ids = torch.zeros(users, L, 2, 60, dtype=torch.int64)
     mask = torch.zeros(users, L - 1)
     for u in range(users):
-        n = L if u == 0 else 9                        # one full history, one short (left-padded with the PAD item)
+        n = L if (u == 0 or full_histories) else 9    # one full history, one short (left-padded with the PAD item); full_histories: every user full
         for slot in range(L - n, L):
             for side in range(2):
                 if side == 1 and slot == L - 1:

@@ -13,7 +13,14 @@ def pytest_configure(config):
 
 
 def pytest_collection_modifyitems(config, items):
-    """GPU tests are skipped (not failed) when no device is visible and -m gpu was not asked for."""
+    """GPU tests are skipped (not failed) when no device is visible and -m gpu was not asked for.
+    The two entry-point tests (run.py / run_adapter.py end to end: DataLoader worker processes are FORKED from the test process) go first:
+    forked from a process that has already run the kernel suites (thousands of device allocations mapped) the same test took 43 - 161 s
+    instead of 5 (measured, profiles/LOG.md round 4) -- the cost of fork() under a large ROCm address space, not of anything it tests."""
+    first = [it for it in items if it.fspath.basename in ('test_text_run.py', 'test_cv_run.py') and 'gpu' in it.keywords]
+    if first:
+        rest = [it for it in items if it not in first]
+        items[:] = first + rest
     import torch
     if torch.cuda.is_available():
         return

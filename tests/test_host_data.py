@@ -148,3 +148,31 @@ def test_device_train_sampler_matches_dataset_distribution():
         c = counts[u, allowed]
         exp = c.sum() / len(allowed)
         assert counts[u].sum() == c.sum() and (np.abs(c - exp) < 6 * np.sqrt(exp) + 1).all()        # uniform over the allowed items
+
+
+def test_device_train_sampler_large_catalogue_is_sync_free_and_clean():
+    """item_num >= 4096: the unconditional four-round rejection (no host wait per batch) -- negatives in range, never one of the user's
+    own items, zero on pad slots and on the last slot; set_epoch() makes the stream a function of (seed, epoch)."""
+    from adapter4rec_amd.data_utils import DeviceTrainSampler
+    rng = np.random.default_rng(1)
+    item_num, L = 5000, 21
+    content = np.arange((item_num + 1) * 4, dtype=np.int64).reshape(item_num + 1, 4)
+    content[0] = 0
+    u2seq = {u: [int(x) for x in rng.choice(np.arange(1, item_num + 1), int(rng.integers(3, 22)), replace=False)] for u in range(64)}
+    sm = DeviceTrainSampler(u2seq, content, item_num, 20, 'cpu', seed=3)
+    sm.set_epoch(2)
+    a_items, a_mask = sm.sample(list(range(64)))
+    sm.set_epoch(2)
+    b_items, _ = sm.sample(list(range(64)))
+    sm.set_epoch(3)
+    c_items, _ = sm.sample(list(range(64)))
+    assert torch.equal(a_items, b_items) and not torch.equal(a_items, c_items)
+    ids = (a_items.view(64, L, 2, 4)[..., 0] // 4)                  # content row i starts at 4 i: recover the item ids
+    for u in range(64):
+        n = len(u2seq[u])
+        pos, neg = ids[u, :, 0], ids[u, :, 1]
+        assert pos[L - n:].tolist() == u2seq[u] and (pos[:L - n] == 0).all()
+        real = neg[L - n:L - 1]
+        assert (neg[:L - n] == 0).all() and neg[-1] == 0 and (real >= 1).all() and (real <= item_num).all()
+        assert not set(real.tolist()) & set(u2seq[u])
+        assert a_mask[u].tolist() == [0.0] * (L - n) + [1.0] * (n - 1)

@@ -158,7 +158,8 @@ def test_base_geometry_step_fp32_and_bf16_vs_oracle_and_reference(name):
     houlsby = kw.get('adapter_type', 'houslby') == 'houslby'
     lim = 1.6 if houlsby else 2.0
     for k in ('pos', 'neg', 'emb'):
-        assert rep[k]['hip_rms'] <= lim * rep[k]['ref_autocast_rms'] + 1e-3, (k, rep[k])
+        if hip[k].numel() >= 16:                        # (CPC scores one position per user: 2 numbers here -- no statistic; the embeddings carry the bound)
+            assert rep[k]['hip_rms'] <= lim * rep[k]['ref_autocast_rms'] + 1e-3, (k, rep[k])
         assert rep[k]['hip_max'] <= 3.0 * rep[k]['ref_autocast_max'] + 1e-3, (k, rep[k])
     if houlsby:
         # --residual_dtype fp32: the residual stream between sub-layers in fp32, as under the reference's autocast (its LayerNorm outputs
@@ -181,6 +182,43 @@ def test_base_geometry_step_fp32_and_bf16_vs_oracle_and_reference(name):
     assert d8['loss'] < 0.15 and d8['emb'] < 0.3 and d8['pos'] < 1.0 and d8['neg'] < 1.0, d8
     assert d8['grad'] < (0.8 if cpc else 0.5), d8
     assert rep['loss']['hip'] <= 2.0 * rep['loss']['ref_autocast'] + 1e-2, rep['loss']      # (a scalar: signed errors can cancel in either run)
+
+
+def test_bench_size_step_fp32_vs_oracle():
+    """no oracle comparison at the exact size bench.py times.  BERT-base + Houlsby (GELU adapters: smooth), B = 32 users with full
+    histories = 1 344 items x 30 tokens = 40 320 token rows (158 row tiles of the 256-tile GEMM: the persistent grid's multi-round tile map,
+    the banded map of the N = 3072 launches, staggered start, the CLS-row last layer), fp32 instantiation of the same kernels vs the CPU oracle.
+    The oracle runs the 32 users as 4 chunks of 8 (the loss -- BCE over valid positions, one sampled negative each, model/model.py:58-68 --
+    has no term that couples users, so loss and gradients are the valid-position-weighted means of the chunks'): ~6 s and ~10 GB of autograd
+    state per chunk instead of 40 GB for the whole batch."""
+    from base_cases import build_text_case
+    from oracle import ref_cpu as R
+    B, CH = 32, 8
+    model, items, mask = build_text_case(encoder='bert', act='GELU', users=B, full_histories=True)
+    sd = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    names = [n for n, p in model.named_parameters() if p.requires_grad]
+    cfg = dict(R.DEFAULT_CFG, adapter_activation='GELU')
+    per = items.shape[0] // B
+    n_valid = float((mask != 0).sum())
+    loss_ref, g_ref, pos_ref, neg_ref, emb_ref = 0.0, None, [], [], []
+    for c in range(B // CH):
+        it, mk = items[c * CH * per:(c + 1) * CH * per], mask[c * CH:(c + 1) * CH]
+        w = float((mk != 0).sum()) / n_valid
+        out, grads = R.loss_and_grads(sd, names, it, mk, cfg)
+        loss_ref += w * float(out['loss'].detach())
+        g_ref = {k: w * v for k, v in grads.items()} if g_ref is None else {k: g_ref[k] + w * grads[k] for k in grads}
+        pos_ref.append(out['pos_score'].detach())
+        neg_ref.append(out['neg_score'].detach())
+        emb_ref.append(out['input_embs_all'].detach())
+    valid = mask.bool()
+    pos_ref, neg_ref, emb_ref = torch.cat(pos_ref)[valid], torch.cat(neg_ref)[valid], torch.cat(emb_ref)
+    o = hip_step(model, 'fp32', items, mask)
+    d = dict(loss=abs(o['loss'] - loss_ref), pos=float((o['pos'][valid] - pos_ref).abs().max()), neg=float((o['neg'][valid] - neg_ref).abs().max()),
+             emb=float((o['emb'] - emb_ref).abs().max()))
+    g, where = grad_err(o['grads'], g_ref)
+    print(f'bench-size (B = {B}, {items.shape[0]} items) fp32 HIP vs chunked oracle: {d}, worst gradient {g:.2e} ({where}); loss {loss_ref:.5f}')
+    assert d['loss'] < 1e-4 and d['pos'] < 1e-4 and d['neg'] < 1e-4 and d['emb'] < 1e-4, d
+    assert g < 1e-4, (g, where)
 
 
 @pytest.mark.parametrize('kind', ['vit_lora', 'mae_compacter'])
@@ -325,7 +363,7 @@ def test_eval_hr_ndcg_fp32_and_bf16_vs_oracle_2000_items():
 
 def test_training_trajectory_bf16_vs_fp32_oracle_hr_ndcg():
     """the bf16 path was bounded per step only -- is a model TRAINED in bf16 as good as one trained by the fp32 reference
-    arithmetic?  40 Adam steps (B = 32 users per step, a new batch every step, dropout off, adapter lr 3e-4 in both towers, the
+    arithmetic?  24 Adam steps (B = 32 users per step, a new batch every step, dropout off, adapter lr 3e-4 in both towers, the
     reference's Adam: run.py:505-529) from the conditioned weights of build_eval_case, (a) by the CPU oracle in fp32 and (b) by the HIP
     path in bf16 (FusedAdam, public path).  Then BOTH resulting weight sets are evaluated by the oracle in fp32 on 2 000 items x 2 000
     users (metrics.py:82-116): HR@10 / nDCG@10 within 1e-3 (= 2 users), loss curves within the stated bound."""
@@ -334,7 +372,7 @@ def test_training_trajectory_bf16_vs_fp32_oracle_hr_ndcg():
     from adapter4rec_amd.inject import optimizer_groups
     from adapter4rec_amd.optim import FusedAdam
     from oracle import ref_cpu as R
-    n_items, n_users, steps, B = 2000, 2000, 40, 32
+    n_items, n_users, steps, B = 2000, 2000, 24, 32          # (24 steps since round 4: the CPU oracle's 40 took 160 - 200 s of the GPU suite)
     model, args, content, eval_seq, hist = build_eval_case(n_items=n_items, n_users=n_users)
     lrs = dict(fine_tune_lr=1e-4, lr=1e-4, adapter_bert_lr=3e-4, adapter_sasrec_lr=3e-4)     # (CPU dry run: loss 23.7 -> 13.7, HR@10 0.4225 -> 0.365, parameters move by 1.3e-2)
     for k, v in lrs.items():

@@ -108,6 +108,32 @@ def test_text_run_host_logic_simulated(tmp_path, monkeypatch):
     """The same flow on CPU: run.py's host logic (readers, DataLoader, FlatDDP, FusedAdam, eval, save_model, resume) with the kernel
     library replaced by tests/sim_lib.py (a torch restatement of the C ABI; it has no dropout, so the rates are 0 here), gloo instead
     of RCCL and device index 0 mapped to the CPU."""
+    _simulate(monkeypatch)
+    _two_epochs_resume_and_oracle_hr(tmp_path, monkeypatch, ['hidden_dropout_prob', 'attention_probs_dropout_prob'])
+
+
+def test_text_run_device_sampler_simulated(tmp_path, monkeypatch):
+    """--device_sampler 1: run.py draws its batches with DeviceTrainSampler instead of BuildTrainDataset + DataLoader -- same epoch
+    structure (40 users = 16 + 16 + 8, sharded and shuffled by the DistributedSampler), finite falling loss, evaluation and checkpoint."""
+    _simulate(monkeypatch)
+    data = write_toy(str(tmp_path))
+    cp = os.path.join(str(tmp_path), 'pretrained_models', 'bert', 'bert_tiny', 'config.json')
+    c = json.load(open(cp))
+    c.update(hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0)
+    json.dump(c, open(cp, 'w'))
+    monkeypatch.chdir(os.path.join(str(tmp_path), 'work'))
+    a = dict(loss=[], batch=[], eval=[])
+    _run(['--root_data_dir', data, '--dataset', 'toy', '--behaviors', 'behaviors.tsv', '--news', 'news.tsv', '--mode', 'train',
+          '--bert_model_load', 'bert_tiny', '--freeze_paras_before', '0', '--adapter_type', 'houslby', '--adding_adapter_to', 'all',
+          '--fine_tune_to', 'None', '--pretrained_model_name', 'None', '--embedding_dim', '64', '--batch_size', '16', '--num_workers', '0',
+          '--logging_num', '3', '--testing_num', '1', '--max_seq_len', '20', '--min_seq_len', '5', '--lr', '1e-3', '--adapter_bert_lr', '1e-3',
+          '--adapter_sasrec_lr', '1e-3', '--label_screen', 'dev', '--epoch', '3', '--device_sampler', '1'], monkeypatch, a)
+    assert a['batch'] == [16, 16, 8] * 3, a['batch']
+    assert all(np.isfinite(a['loss'])) and np.mean(a['loss'][-3:]) < np.mean(a['loss'][:3]), a['loss']
+    assert len(a['eval']) >= 3
+
+
+def _simulate(monkeypatch):
     import torch.distributed as dist
     import sim_lib
     import adapter4rec_amd.data_utils.metrics as MT
@@ -128,7 +154,6 @@ def test_text_run_host_logic_simulated(tmp_path, monkeypatch):
     monkeypatch.setattr(torch.Tensor, 'to', lambda self, *a, **k: real_tto(self, *on_cpu(a), **{q: v for q, v in k.items() if q != 'non_blocking'}))
     real_parse = run.parse_args
     monkeypatch.setattr(run, 'parse_args', lambda argv=None: real_parse(list(argv) + ['--drop_rate', '0', '--adapter_dropout_rate', '0']))
-    _two_epochs_resume_and_oracle_hr(tmp_path, monkeypatch, ['hidden_dropout_prob', 'attention_probs_dropout_prob'])
 
 
 def _two_epochs_resume_and_oracle_hr(tmp_path, monkeypatch, zero_cfg):
