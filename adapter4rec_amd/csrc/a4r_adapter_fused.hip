@@ -136,12 +136,9 @@ __global__ void __launch_bounds__(NW * 64) adapter_ln_fwd_kernel(const AdFwdArgs
     for (int i = 0; i < EPT; ++i) bd_r[i] = p.bd[rzd + i];
 
     const int ntiles = p.M / 16;
-#ifndef A4R_AD_PF2
-#define A4R_AD_PF2 1       /* rows requested TWO tiles ahead (round 4; 0 = one tile ahead, A/B builds): ~96 KB instead of ~48 KB in flight per CU */
-#endif
-    constexpr bool PF2 = A4R_AD_PF2 != 0 && !R32 && CW <= 96;  // (the fp32-residual form and H = 1024 have no registers left for a third set: they would spill)
+    // (rows are requested ONE tile ahead.  Two tiles ahead -- a third register set, ~96 KB in flight per CU -- measured slower in round 4:
+    // 54.1 - 55.3 us against 51.4 us per launch at M = 40 448, 246 VGPRs; profiles/r04_e_adapter_ab.txt)
     uint4 a_cur[KS], o_cur[KS * OP], a_nxt[KS], o_nxt[KS * OP];
-    uint4 a_n2[PF2 ? KS : 1], o_n2[PF2 ? KS * OP : 1];
 #define A4R_AD_LOAD_O(dst_, row_)                                                                                       \
     if constexpr (R32) {                                                                                               \
         _Pragma("unroll") for (int s = 0; s < KS; ++s) {                                                               \
@@ -156,23 +153,10 @@ __global__ void __launch_bounds__(NW * 64) adapter_ln_fwd_kernel(const AdFwdArgs
 #pragma unroll
         for (int s = 0; s < KS; ++s) a_cur[s] = *reinterpret_cast<const uint4*>(p.A + row * p.lda + cl + s * 32);
         A4R_AD_LOAD_O(o_cur, row)
-        if constexpr (PF2) {
-            const int t1 = (int)blockIdx.x + (int)gridDim.x < ntiles ? (int)blockIdx.x + (int)gridDim.x : (int)blockIdx.x;
-            const size_t row1 = (size_t)t1 * 16 + fr;
-#pragma unroll
-            for (int s = 0; s < KS; ++s) a_nxt[s] = *reinterpret_cast<const uint4*>(p.A + row1 * p.lda + cl + s * 32);
-            A4R_AD_LOAD_O(o_nxt, row1)
-        }
     }
     A4R_LDS_BARRIER();                                       // par[] visible
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-        if constexpr (PF2) {   // request the rows of the tile after next (tiles past the end re-request an own tile: the vmcnt schedule stays static)
-            const int tn = tile + 2 * (int)gridDim.x < ntiles ? tile + 2 * (int)gridDim.x : tile;
-            const size_t row = (size_t)tn * 16 + fr;
-#pragma unroll
-            for (int s = 0; s < KS; ++s) a_n2[s] = *reinterpret_cast<const uint4*>(p.A + row * p.lda + cl + s * 32);
-            A4R_AD_LOAD_O(o_n2, row)
-        } else {               // request the next tile's rows now (the last tile re-requests itself: the vmcnt schedule stays static)
+        {   // request the next tile's rows now (the last tile re-requests itself: the vmcnt schedule stays static)
             const int tn = tile + (int)gridDim.x < ntiles ? tile + (int)gridDim.x : tile;
             const size_t row = (size_t)tn * 16 + fr;
 #pragma unroll
@@ -302,12 +286,6 @@ __global__ void __launch_bounds__(NW * 64) adapter_ln_fwd_kernel(const AdFwdArgs
         for (int s = 0; s < KS; ++s) a_cur[s] = a_nxt[s];
 #pragma unroll
         for (int s = 0; s < KS * OP; ++s) o_cur[s] = o_nxt[s];
-        if constexpr (PF2) {
-#pragma unroll
-            for (int s = 0; s < KS; ++s) a_nxt[s] = a_n2[s];
-#pragma unroll
-            for (int s = 0; s < KS * OP; ++s) o_nxt[s] = o_n2[s];
-        }
     }
 #undef A4R_AD_LOAD_O
 }

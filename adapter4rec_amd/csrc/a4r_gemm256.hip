@@ -359,6 +359,54 @@ A4R_DEV void gemm256_tiles(const a4r_gemm_t& p, char* lds, int ntm, int ntn, int
         A4R_PHASE(, A4R_ISSUE(U_ALO, (u_) + 2, Abase, offA_lo) A4R_ISSUE(U_BLO, (u_) + 2, Bbase, offB_lo), n2, "8", "0", af, b0, 4, 0, z0, kp_hi) \
     }
 #endif
+#ifndef A4R_PHASES
+#define A4R_PHASES 4
+#endif
+#if A4R_PHASES == 2
+    // TWO phases per K-tile (round 4 experiment, -DA4R_PHASES=2): the quadrant pairs (A_lo,B_lo)+(A_lo,B_hi) and (A_hi,B_hi)+(A_hi,B_lo) run as ONE
+    // MFMA segment of 32 each -- half the barriers per K-tile and 512-cycle matrix segments for the partner wave's LOAD segment (16 / 8 fragment
+    // reads + 4 DMA pieces + the counted wait) to hide behind, instead of 256.  Same unit stream and prologue as A4R_DMA_SCHED 1:
+    //   LOAD_A(u): read A_lo, B_lo, B_hi (u) | issue B_hi, A_hi (u+1) | wait: A_hi(u) landed     -> vmcnt(8)  [A_lo B_lo (u+1) + the 4 just issued stay]
+    //   LOAD_B(u): read A_hi (u)             | issue A_lo, B_lo (u+2) | wait: B_hi(u+1) landed   -> vmcnt(6)  [A_hi(u+1) + the 4 just issued stay]
+    // RAW: a wait sits in front of a barrier that every reader of the unit passes before its LOAD segment.  WAR: B_hi / A_lo / B_lo slots are
+    // re-filled >= 2 intervals after their last read; A_hi(u+1)'s slot was last read in LOAD_B(u-1), by the other half ONE interval earlier --
+    // so the fragment reads are retired (lgkmcnt(0)) BEFORE the barrier that ends a LOAD segment, not behind it.
+#define A4R_PHASE2(reads_, issue_, waitstmt_, ax_, bxa_, na_, bxb_, nb_, m0_, z_, lim_)                 \
+    if (z_) {                                                                                           \
+        _Pragma("unroll") for (int mi = 0; mi < 4; ++mi)                                              \
+            _Pragma("unroll") for (int ni = 0; ni < 4; ++ni) acc[(m0_) + mi][ni] = f32x4_t{0.f, 0.f, 0.f, 0.f}; \
+    }                                                                                                 \
+    { reads_ }                                                                                        \
+    { issue_ }                                                                                        \
+    __builtin_amdgcn_sched_barrier(0);                                                                \
+    waitstmt_                                                                                         \
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                \
+    __builtin_amdgcn_s_barrier();                                                                     \
+    asm volatile("" ::: "memory");                                                                    \
+    __builtin_amdgcn_sched_barrier(0);                                                                \
+    __builtin_amdgcn_s_setprio(1);                                                                    \
+    A4R_MFMA16(ax_, bxa_, m0_, na_, lim_)                                                             \
+    A4R_MFMA16(ax_, bxb_, m0_, nb_, lim_)                                                             \
+    __builtin_amdgcn_s_setprio(0);                                                                    \
+    __builtin_amdgcn_sched_barrier(0);                                                                \
+    __builtin_amdgcn_s_barrier();                                                                     \
+    asm volatile("" ::: "memory");
+#undef A4R_KTILE
+#define A4R_KTILE(u_, buf_)                                                                                                         \
+    {                                                                                                                               \
+        const bool n1 = (u_) + 1 < nk || has_next, n2 = (u_) + 2 < nk || has_next;                                                  \
+        const bool z0 = (buf_) == 0 && (u_) == 0;                                                                                   \
+        asm volatile("" : "+v"(a_base[buf_][0]), "+v"(a_base[buf_][1]), "+v"(b_base[buf_][0]), "+v"(b_base[buf_][1]));              \
+        A4R_PHASE2(A4R_RD_B(b0, buf_, U_BLO) A4R_RD_B(b1, buf_, U_BHI) A4R_RD_A(af, buf_, U_ALO),                                   \
+                   A4R_ISSUE(U_BHI, (u_) + 1, Bbase, offB_hi) A4R_ISSUE(U_AHI, (u_) + 1, Abase, offA_hi),                           \
+                   if (z0) { } else if (n1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");, \
+                   af, b0, 0, b1, 2, 0, z0, kp_lo)                                                                                  \
+        A4R_PHASE2(A4R_RD_A(af, buf_, U_AHI),                                                                                       \
+                   A4R_ISSUE(U_ALO, (u_) + 2, Abase, offA_lo) A4R_ISSUE(U_BLO, (u_) + 2, Bbase, offB_lo),                           \
+                   if (n2) asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); else if (n1) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");, \
+                   af, b1, 2, b0, 0, 4, z0, kp_hi)                                                                                  \
+    }
+#endif
 
     f32x4_t acc[8][4];
 #ifdef A4R_PHASE_STAMP
