@@ -330,7 +330,7 @@ A4R_DEV void gemm256_tiles(const a4r_gemm_t& p, char* lds, int ntm, int ntn, int
 #define A4R_DMA_SCHED 1
 #endif
 #if A4R_DMA_SCHED == 0
-#define A4R_KTILE(u_, buf_)                                                                                                         \
+#define A4R_KTILE4(u_, buf_)                                                                                                         \
     {                                                                                                                               \
         const bool n1 = (u_) + 1 < nk || has_next, n2 = (u_) + 2 < nk || has_next;                                                                        \
         const bool z0 = (buf_) == 0 && (u_) == 0;                                                                                   \
@@ -347,7 +347,7 @@ A4R_DEV void gemm256_tiles(const a4r_gemm_t& p, char* lds, int ntm, int ntn, int
     // issues, oldest first): phase 0 [B_hi A_hi (u+1) | A_lo B_lo (u+2)] must retire B_hi -> vmcnt(6); phase 1 [A_hi(u+1) A_lo B_lo (u+2) B_hi A_hi (u+2)]
     // must retire A_hi -> vmcnt(8); phase 2 reads nothing new in phase 3 -> no wait; phase 3 [B_hi A_hi (u+1) A_lo B_lo (u+2)] must retire
     // A_lo, B_lo (u+1) -> vmcnt(8).  WAR: every slot is re-filled >= 2 phases after its last read (B_hi: phase 1 of u-1, A_hi: 2 of u-1, A_lo / B_lo: 0 of u).
-#define A4R_KTILE(u_, buf_)                                                                                                         \
+#define A4R_KTILE4(u_, buf_)                                                                                                         \
     {                                                                                                                               \
         const bool n1 = (u_) + 1 < nk || has_next, n2 = (u_) + 2 < nk || has_next;                                                                        \
         const bool z0 = (buf_) == 0 && (u_) == 0;                                                                                   \
@@ -360,12 +360,16 @@ A4R_DEV void gemm256_tiles(const a4r_gemm_t& p, char* lds, int ntm, int ntn, int
     }
 #endif
 #ifndef A4R_PHASES
-#define A4R_PHASES 4
+#define A4R_PHASES 2       /* phases per K-tile for bf16 / fp32 operands: 2 (round 4) or 4 (rounds 2 - 3; A/B builds) */
 #endif
-#if A4R_PHASES == 2
-    // TWO phases per K-tile (round 4 experiment, -DA4R_PHASES=2): the quadrant pairs (A_lo,B_lo)+(A_lo,B_hi) and (A_hi,B_hi)+(A_hi,B_lo) run as ONE
+#ifndef A4R_PHASES_FP8
+#define A4R_PHASES_FP8 4   /* likewise for e4m3 operands */
+#endif
+    // TWO phases per K-tile (round 4): the quadrant pairs (A_lo,B_lo)+(A_lo,B_hi) and (A_hi,B_hi)+(A_hi,B_lo) run as ONE
     // MFMA segment of 32 each -- half the barriers per K-tile and 512-cycle matrix segments for the partner wave's LOAD segment (16 / 8 fragment
-    // reads + 4 DMA pieces + the counted wait) to hide behind, instead of 256.  Same unit stream and prologue as A4R_DMA_SCHED 1:
+    // reads + 4 DMA pieces + the counted wait) to hide behind, instead of 256.  Same-box A/B against the four-phase schedule
+    // (profiles/r04_f_ab_forms_p2.txt): qkv -6 %, attention-output -3 %, the K = 2304 / 3072 dgrads -2 %, the epilogue-heavy FFN launches
+    // -1 %; step 17.51 -> 17.39 ms.  Same unit stream and prologue as A4R_DMA_SCHED 1:
     //   LOAD_A(u): read A_lo, B_lo, B_hi (u) | issue B_hi, A_hi (u+1) | wait: A_hi(u) landed     -> vmcnt(8)  [A_lo B_lo (u+1) + the 4 just issued stay]
     //   LOAD_B(u): read A_hi (u)             | issue A_lo, B_lo (u+2) | wait: B_hi(u+1) landed   -> vmcnt(6)  [A_hi(u+1) + the 4 just issued stay]
     // RAW: a wait sits in front of a barrier that every reader of the unit passes before its LOAD segment.  WAR: B_hi / A_lo / B_lo slots are
@@ -391,8 +395,7 @@ A4R_DEV void gemm256_tiles(const a4r_gemm_t& p, char* lds, int ntm, int ntn, int
     __builtin_amdgcn_sched_barrier(0);                                                                \
     __builtin_amdgcn_s_barrier();                                                                     \
     asm volatile("" ::: "memory");
-#undef A4R_KTILE
-#define A4R_KTILE(u_, buf_)                                                                                                         \
+#define A4R_KTILE2(u_, buf_)                                                                                                        \
     {                                                                                                                               \
         const bool n1 = (u_) + 1 < nk || has_next, n2 = (u_) + 2 < nk || has_next;                                                  \
         const bool z0 = (buf_) == 0 && (u_) == 0;                                                                                   \
@@ -406,7 +409,8 @@ A4R_DEV void gemm256_tiles(const a4r_gemm_t& p, char* lds, int ntm, int ntn, int
                    if (n2) asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); else if (n1) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");, \
                    af, b1, 2, b0, 0, 4, z0, kp_hi)                                                                                  \
     }
-#endif
+    constexpr bool PH2 = (sizeof(TI) == 1 ? A4R_PHASES_FP8 : A4R_PHASES) == 2;
+#define A4R_KTILE(u_, buf_) if constexpr (PH2) { A4R_KTILE2(u_, buf_) } else { A4R_KTILE4(u_, buf_) }
 
     f32x4_t acc[8][4];
 #ifdef A4R_PHASE_STAMP
@@ -722,7 +726,10 @@ A4R_DEV void gemm256_tiles(const a4r_gemm_t& p, char* lds, int ntm, int ntn, int
 #undef A4R_RD_B
 #undef A4R_MFMA16
 #undef A4R_PHASE
+#undef A4R_PHASE2
 #undef A4R_KTILE
+#undef A4R_KTILE2
+#undef A4R_KTILE4
 }
 
 // ntm = row panels of FULL tiles; the tail_rows rows behind them (0 = none) are cut into short tiles of 32 * tail_kp rows, tile j (row-panel
