@@ -363,7 +363,7 @@ A4R_DEV void gemm256_tiles(const a4r_gemm_t& p, char* lds, int ntm, int ntn, int
 #define A4R_PHASES 2       /* phases per K-tile for bf16 / fp32 operands: 2 (round 4) or 4 (rounds 2 - 3; A/B builds) */
 #endif
 #ifndef A4R_PHASES_FP8
-#define A4R_PHASES_FP8 4   /* likewise for e4m3 operands */
+#define A4R_PHASES_FP8 2   /* likewise for e4m3 operands (same-box: BERT-base fp8 2 006 -> 2 058 user-seq/s, MAE + Compacter fp8 926 -> 952; profiles/r04_g_fp8_ab.txt) */
 #endif
     // TWO phases per K-tile (round 4): the quadrant pairs (A_lo,B_lo)+(A_lo,B_hi) and (A_hi,B_hi)+(A_hi,B_lo) run as ONE
     // MFMA segment of 32 each -- half the barriers per K-tile and 512-cycle matrix segments for the partner wave's LOAD segment (16 / 8 fragment
