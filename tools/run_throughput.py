@@ -82,7 +82,7 @@ def one_run(data, root, workers, batch, extra):
     argv = ['--root_data_dir', data, '--dataset', 'synth', '--behaviors', 'behaviors.tsv', '--news', 'news.tsv', '--mode', 'train',
             '--bert_model_load', 'bert_base_uncased', '--freeze_paras_before', '0', '--adapter_type', 'houslby', '--adding_adapter_to', 'all',
             '--fine_tune_to', 'None', '--pretrained_model_name', 'None', '--embedding_dim', '64', '--batch_size', str(batch),
-            '--num_workers', str(workers), '--logging_num', '4', '--testing_num', '1', '--max_seq_len', '20', '--min_seq_len', '5',
+            '--num_workers', str(workers), '--logging_num', '1', '--testing_num', '1', '--max_seq_len', '20', '--min_seq_len', '5',
             '--epoch', '1', '--label_screen', 'tp', '--compute_dtype', 'bf16', '--eval_compute_dtype', 'bf16'] + extra
     cwd = os.getcwd()
     os.chdir(os.path.join(root, 'work'))
