@@ -362,6 +362,9 @@ A4R_DEV void gemm256_tiles(const a4r_gemm_t& p, char* lds, int ntm, int ntn, int
 #ifndef A4R_PHASES
 #define A4R_PHASES 2       /* phases per K-tile for bf16 / fp32 operands: 2 (round 4) or 4 (rounds 2 - 3; A/B builds) */
 #endif
+#ifndef A4R_PRIO
+#define A4R_PRIO 1         /* two-phase schedule: s_setprio 1 around the MFMA segment (1), around the LOAD segment (2), nowhere (0) -- A/B builds */
+#endif
 #ifndef A4R_PHASES_FP8
 #define A4R_PHASES_FP8 2   /* likewise for e4m3 operands (same-box: BERT-base fp8 2 006 -> 2 058 user-seq/s, MAE + Compacter fp8 926 -> 952; profiles/r04_g_fp8_ab.txt) */
 #endif
@@ -380,20 +383,21 @@ A4R_DEV void gemm256_tiles(const a4r_gemm_t& p, char* lds, int ntm, int ntn, int
         _Pragma("unroll") for (int mi = 0; mi < 4; ++mi)                                              \
             _Pragma("unroll") for (int ni = 0; ni < 4; ++ni) acc[(m0_) + mi][ni] = f32x4_t{0.f, 0.f, 0.f, 0.f}; \
     }                                                                                                 \
-    { reads_ }                                                                                        \
-    { issue_ }                                                                                        \
+    if (A4R_PRIO == 2) __builtin_amdgcn_s_setprio(1);                                                 \
+    if (!(A4R_ABL & 4)) { reads_ }                                                                    \
+    if (!(A4R_ABL & 1)) { issue_ }                                                                    \
     __builtin_amdgcn_sched_barrier(0);                                                                \
     waitstmt_                                                                                         \
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                \
-    __builtin_amdgcn_s_barrier();                                                                     \
+    if (A4R_PRIO == 2) __builtin_amdgcn_s_setprio(0);                                                 \
+    if (!(A4R_ABL & 8)) __builtin_amdgcn_s_barrier();                                                 \
     asm volatile("" ::: "memory");                                                                    \
     __builtin_amdgcn_sched_barrier(0);                                                                \
-    __builtin_amdgcn_s_setprio(1);                                                                    \
-    A4R_MFMA16(ax_, bxa_, m0_, na_, lim_)                                                             \
-    A4R_MFMA16(ax_, bxb_, m0_, nb_, lim_)                                                             \
-    __builtin_amdgcn_s_setprio(0);                                                                    \
+    if (A4R_PRIO == 1 && !(A4R_ABL & 16)) __builtin_amdgcn_s_setprio(1);                              \
+    if (!(A4R_ABL & 2)) { A4R_MFMA16(ax_, bxa_, m0_, na_, lim_) A4R_MFMA16(ax_, bxb_, m0_, nb_, lim_) } \
+    if (A4R_PRIO == 1 && !(A4R_ABL & 16)) __builtin_amdgcn_s_setprio(0);                              \
     __builtin_amdgcn_sched_barrier(0);                                                                \
-    __builtin_amdgcn_s_barrier();                                                                     \
+    if (!(A4R_ABL & 8)) __builtin_amdgcn_s_barrier();                                                 \
     asm volatile("" ::: "memory");
 #define A4R_KTILE2(u_, buf_)                                                                                                        \
     {                                                                                                                               \
