@@ -57,10 +57,7 @@ def parse_args(argv=None):
     p.add_argument('--compute_dtype', type=str, default=None, choices=[None, 'bf16', 'fp32', 'fp8'],
                    help="fp8: bf16 storage + OCP e4m3 operands for the frozen backbone's qkv / FFN-up forward GEMMs (BASELINE config 5)")
     p.add_argument('--residual_dtype', type=str, default='bf16', choices=['bf16', 'fp32'],
-                   help="bf16 storage only: fp32 keeps the item encoder's residual stream between sub-layers in fp32, as the reference's "
-                        'autocast(bfloat16) does (its LayerNorm outputs fp32): scores / embeddings then sit at 0.7 - 0.9x the distance of the '
-                        "reference's own autocast path from fp32 instead of 1.2 - 1.3x, for ~6 bytes more HBM traffic per token and sub-layer "
-                        '(serial Houlsby / Compacter adapters on the one-launch kernels; other placements keep the bf16 stream)')
+                   help='accepted for symmetry with the text entry point; fp32 raises on the image tower (pre-LN: the residual stream is the stored tensor v)')
     p.add_argument('--eval_compute_dtype', type=str, default=None, choices=[None, 'bf16', 'fp32'],
                    help="dtype of eval's item sweep; None = --compute_dtype (the reference evaluates under the same AMP setting it trains with)")
     p.add_argument('--lora_r', type=int, default=12)              # run_adapter.py:386-387 hard-codes 12

@@ -68,6 +68,9 @@ class ViTRecEngine(TransRecEngine):
         self.train_emb = self.d_patch.trainable or self.g_cls is not None or self.g_postab is not None or self.g_prompt is not None
         if self.train_emb and self.mae:
             raise NotImplementedError('training the ViT-MAE embedding side (--fine_tune_to all) is not wired natively')
+        if self.res32:
+            raise NotImplementedError('--residual_dtype fp32 is wired for the text tower (post-LN sub-layers on the one-launch adapter kernels); the pre-LN '
+                                      'image tower stores its residual stream v itself in the compute dtype')
         self.next_noise = None
         self.bert_blocks = []
         kmod, enc_mod = None, core.encoder
