@@ -821,10 +821,20 @@ static int band_for(const a4r_gemm_t& g, int ntm, int ntn, int grid, int isz) {
     const int rounds_bal = (ntm * ntn + grid - 1) / grid, rounds_band = (max_len + wg_x - 1) / wg_x;
     if (ntm < 8 || rounds_band > rounds_bal) return 0;
     if (g_band > 1000) return g_band - 1000 < ntn ? g_band - 1000 : ntn;
-    // automatic: band only when the whole B operand does not sit in an XCD's L2 next to the streaming A panels
+    // automatic, long outputs (>= 128 row panels = 16 per XCD: the text tower at 32 users, the image tower): whole row panels per XCD walked in
+    // bands of THREE N-tiles for every N (round 4, same-box sweeps of A4R_GEMM_BAND over all workloads, profiles/r04_m_band_sweep.txt: BERT-base
+    // 17.21 -> 17.00 ms, RoBERTa 17.55 -> 17.27, BERT fp8 15.32 -> 15.17, ViT + LoRA +-0; at 66 row panels -- ViT-MAE -- the same policy costs
+    // 1.4 %, so shorter outputs keep the rule below).  A 3-tile B band is 1.2 MB at K = 768: it stays in the XCD's L2 whatever the A stream does,
+    // and the A panels it re-reads (4 x at N = 3072) come from the Infinity Cache.
+    static const int long_band = getenv("A4R_GEMM_BAND_LONG") ? atoi(getenv("A4R_GEMM_BAND_LONG")) : 3;
+    if (long_band > 0 && ntm >= 128) return long_band < ntn ? long_band : ntn;
+    // shorter outputs: band only when the whole B operand does not sit in an XCD's L2 next to the streaming A panels
+    // (A4R_GEMM_BAND_FIT / A4R_GEMM_BAND_BYTES: the two thresholds, bytes -- A/B sweeps)
+    static const double fit = getenv("A4R_GEMM_BAND_FIT") ? atof(getenv("A4R_GEMM_BAND_FIT")) : 4.0e6;
+    static const double budget = getenv("A4R_GEMM_BAND_BYTES") ? atof(getenv("A4R_GEMM_BAND_BYTES")) : 2.5e6;
     const double b_tile = 256.0 * g.K * isz;
-    if (b_tile * ntn <= 4.0e6) return 0;                    // (N = 2304, K = 768: 3.5 MB still shares an L2 with the A stream: PMC 250 MB read un-banded vs 339 banded)
-    int gn = (int)(2.5e6 / b_tile);
+    if (b_tile * ntn <= fit) return 0;                      // (N = 2304, K = 768: 3.5 MB still shares an L2 with the A stream: PMC 250 MB read un-banded vs 339 banded)
+    int gn = (int)(budget / b_tile);
     if (gn < 2) return 0;                                   // a band of one tile re-reads A once per N-tile: panel-major (A read once) is the better map
     return gn < ntn ? gn : ntn;
 }
