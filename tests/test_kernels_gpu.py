@@ -1509,3 +1509,32 @@ def test_mae_keep_indices_uniform():
     first = torch.bincount(k[:, 0].long().cpu(), minlength=NP).double()        # the smallest-noise patch is uniform over the patches
     z0 = (first - n_items / NP) / (n_items / NP) ** 0.5
     assert float(z0.abs().max()) < 5.0, float(z0.abs().max())
+
+
+@pytest.mark.parametrize('M,N,K', [(40448, 768, 3072), (40448, 3072, 768), (16896, 2304, 768), (40448, 768, 192), (2560, 768, 2304)])
+def test_gemm256_ring_race_screen(M, N, K):
+    """The LDS-DMA ring of the 256-tile kernel (two phases per K-tile since round 4: fragment reads retired in front of the barrier that ends
+    a LOAD segment, A_hi re-filled one interval after its last read): the launch is deterministic, so a run that differs bitwise from the first
+    is a fragment read that overtook its DMA or a slot re-filled under a reader.  Twelve runs per shape, every other one beside 512 MB of
+    copy traffic on a second stream (moves the DMA landing times); even and odd K-tile counts, short-tile tails, a banded map.
+    tools/gemm_race_screen.py is the long form (more shapes, fp32, the epilogue forms of the step)."""
+    from adapter4rec_amd import _lib as L
+    t = torch.bfloat16
+    A, B = rnd(M, K, dtype=t, seed=1), rnd(N, K, dtype=t, scale=0.05, seed=2)
+    bias = rnd(N, seed=3) * 0.1
+    side = torch.cuda.Stream()
+    ja, jb = torch.empty(64 << 20, device=dev()), torch.empty(64 << 20, device=dev())
+    first = None
+    for it in range(12):
+        C = torch.empty(M, N, dtype=t, device=dev())
+        if it % 2:
+            with torch.cuda.stream(side):
+                jb.copy_(ja)
+        L.gemm_nt(A, B, C, bias=bias)
+        torch.cuda.synchronize()
+        if first is None:
+            first = C
+            ref = A.float() @ B.float().t() + bias
+            assert float((C.float() - ref).abs().max() / ref.abs().max()) < 2e-2
+        else:
+            assert torch.equal(C, first), f'run {it} differs from run 0'
