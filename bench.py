@@ -433,9 +433,10 @@ def main():
     if world > 1:
         # every rank's own clock over the same K steps (they end at a barrier, so the spread is what each rank measured between ITS
         # synchronisation points): the first SCALE record shows by itself whether one rank / link lags; `value` uses the MAX
-        each = [torch.zeros(1, device=device, dtype=torch.float64) for _ in range(world)]
-        dist.all_gather(each, torch.tensor([dt], device=device, dtype=torch.float64))
-        rank_ms = [round(float(x.item()) / a.steps * 1e3, 3) for x in each]
+        each = torch.zeros(world, device=device, dtype=torch.float64)      # (an all-reduce of one-hot rows: every backend has it for device tensors)
+        each[rank] = dt
+        dist.all_reduce(each)
+        rank_ms = [round(float(x) / a.steps * 1e3, 3) for x in each.tolist()]
         t = torch.tensor([dt], device=device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
