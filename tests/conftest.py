@@ -10,6 +10,11 @@ if ROOT not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line('markers', 'gpu: needs a real MI355X (run with -m gpu on the GPU box)')
+    # The CPU oracle's tensors are small (tiny-geometry fixtures: 128-wide, 2 layers): on the GPU box torch starts 128 OpenMP threads on 256
+    # host CPUs and a 3-second evaluation takes 36 (measured, round 4: the 24-step trajectory test 145 s -> the oracle's share 107 s of it).
+    import torch
+    if torch.get_num_threads() > 16:
+        torch.set_num_threads(16)
 
 
 def pytest_collection_modifyitems(config, items):

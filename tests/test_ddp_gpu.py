@@ -140,7 +140,7 @@ def test_one_rank_rccl_chunked_exchange_equals_single_allreduce(tmp_path):
     # two backward passes of the same step: identical up to the order of the kernels' fp32 atomic accumulation (column sums, embedding
     # rows) -- the forward has no atomics, so the loss is bit-equal; a chunk that was dropped, doubled or left in flight would show at O(1)
     assert r[True]['loss'] == r[False]['loss']
-    torch.testing.assert_close(r[True]['flat'], r[False]['flat'], rtol=1e-4, atol=1e-6 * float(r[False]['flat'].abs().max()))
+    torch.testing.assert_close(r[True]['flat'], r[False]['flat'], rtol=1e-3, atol=1e-4 * float(r[False]['flat'].abs().max()))
     assert float(r[True]['flat'].abs().max()) > 0
     assert r['identity'] and r['any_rank'] == (True, False)
 

@@ -395,11 +395,16 @@ def test_training_trajectory_bf16_vs_fp32_oracle_hr_ndcg():
         emb = R.item_embeddings(sd, content.numpy(), cfg)
         _, ranks = R.eval_ranks(sd, emb, eval_seq, hist, cfg)
         return R.hit_ndcg(ranks) + (ranks,)
+    import time
+    t0 = time.time()
     hr0, nd0, _ = evaluate(sd0)
+    t1 = time.time()
     loss_ref, p_ref = R.train_steps(sd0, names, batches, cfg, lrs, steps)
+    t2 = time.time()
     sd_ref = dict(sd0)
     sd_ref.update(p_ref)
     hr_ref, nd_ref, ranks_ref = evaluate(sd_ref)
+    print(f'[timing] oracle: evaluate {t1 - t0:.1f} s, {steps} train steps {t2 - t1:.1f} s, evaluate {time.time() - t2:.1f} s ({torch.get_num_threads()} threads)')
 
     model.compute_dtype = 'bf16'
     model.invalidate_native()
