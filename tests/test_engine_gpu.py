@@ -161,6 +161,39 @@ def test_step_bf16_bound(name):
     assert worst < 0.15, (worst, worst_k)          # (0.11 - 0.14 on the user tower's 16-wide adapters, by which roundings the item tower's forward has)
 
 
+def test_step_bf16_residual_fp32():
+    """--residual_dtype fp32 (the item encoder's residual stream between sub-layers in fp32, as under the reference's autocast) on the tiny
+    Houlsby fixture: the step stays inside the bf16 bounds of test_step_bf16_bound, the fp32 twins are really used (embeddings differ from the
+    bf16-residual run) and the embeddings are at least as close to the fp32 oracle as with the bf16 stream."""
+    from oracle import ref_cpu as R
+    root, args, sd, cfg, fx, items, mask = build('houlsby', 'bf16')
+    sd = condition(sd)
+    root.load_state_dict({str(k): sd[strip(str(k))] for k in fx['all_keys']}, strict=True)
+    trainable = [strip(str(k)) for k in fx['trainable']]
+    out, grads = R.loss_and_grads(sd, trainable, items.cpu(), mask.cpu(), cfg)
+    inner = getattr(root, 'model', root)
+    res = {}
+    for rd in ('bf16', 'fp32'):
+        inner.args.residual_dtype = rd
+        inner.invalidate_native()
+        for p in root.parameters():
+            p.grad = None
+        loss = root(items, mask, 0)
+        loss.backward()
+        assert inner._engine().res32 == (rd == 'fp32')
+        emb = inner.bert_encoder(items).cpu()
+        params = dict(root.named_parameters())
+        worst = max(float(np.abs(params[str(k)].grad.cpu().numpy() - grads[strip(str(k))].numpy()).max() / (np.abs(grads[strip(str(k))].numpy()).max() + 1e-12))
+                    for k in fx['trainable'])
+        res[rd] = dict(loss=abs(loss.item() - float(out['loss'].detach())), emb=emb, emb_err=float((emb - out['input_embs_all'].detach()).abs().max()),
+                       emb_rms=float((emb - out['input_embs_all'].detach()).double().pow(2).mean().sqrt()), grad=worst)
+    print({k: {a: (round(b, 5) if isinstance(b, float) else None) for a, b in v.items()} for k, v in res.items()})
+    r32, r16 = res['fp32'], res['bf16']
+    assert r32['loss'] < 2e-2 and r32['emb_err'] < 2e-2 and r32['grad'] < 0.15, r32
+    assert not torch.equal(r32['emb'], r16['emb'])
+    assert r32['emb_rms'] <= 1.05 * r16['emb_rms'], (r32['emb_rms'], r16['emb_rms'])
+
+
 @pytest.mark.parametrize('name', ['houlsby', 'roberta_cpc_pfeiffer'])
 def test_step_bf16_matches_bf16_restatement(name):
     """The same step through tests/sim_lib.py (a torch restatement of the kernels' semantics that rounds to bf16 at the

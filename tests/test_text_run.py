@@ -112,10 +112,7 @@ def test_text_run_host_logic_simulated(tmp_path, monkeypatch):
     _two_epochs_resume_and_oracle_hr(tmp_path, monkeypatch, ['hidden_dropout_prob', 'attention_probs_dropout_prob'])
 
 
-def test_text_run_device_sampler_simulated(tmp_path, monkeypatch):
-    """--device_sampler 1: run.py draws its batches with DeviceTrainSampler instead of BuildTrainDataset + DataLoader -- same epoch
-    structure (40 users = 16 + 16 + 8, sharded and shuffled by the DistributedSampler), finite falling loss, evaluation and checkpoint."""
-    _simulate(monkeypatch)
+def _device_sampler_run(tmp_path, monkeypatch):
     data = write_toy(str(tmp_path))
     cp = os.path.join(str(tmp_path), 'pretrained_models', 'bert', 'bert_tiny', 'config.json')
     c = json.load(open(cp))
@@ -127,10 +124,25 @@ def test_text_run_device_sampler_simulated(tmp_path, monkeypatch):
           '--bert_model_load', 'bert_tiny', '--freeze_paras_before', '0', '--adapter_type', 'houslby', '--adding_adapter_to', 'all',
           '--fine_tune_to', 'None', '--pretrained_model_name', 'None', '--embedding_dim', '64', '--batch_size', '16', '--num_workers', '0',
           '--logging_num', '3', '--testing_num', '1', '--max_seq_len', '20', '--min_seq_len', '5', '--lr', '1e-3', '--adapter_bert_lr', '1e-3',
-          '--adapter_sasrec_lr', '1e-3', '--label_screen', 'dev', '--epoch', '3', '--device_sampler', '1'], monkeypatch, a)
+          '--adapter_sasrec_lr', '1e-3', '--label_screen', 'dev', '--epoch', '3', '--device_sampler', '1', '--drop_rate', '0',
+          '--adapter_dropout_rate', '0'], monkeypatch, a)
     assert a['batch'] == [16, 16, 8] * 3, a['batch']
     assert all(np.isfinite(a['loss'])) and np.mean(a['loss'][-3:]) < np.mean(a['loss'][:3]), a['loss']
     assert len(a['eval']) >= 3
+
+
+@pytest.mark.gpu
+def test_text_run_device_sampler_gpu(tmp_path, monkeypatch):
+    """--device_sampler 1 through run.py on the GPU: batches drawn by DeviceTrainSampler on the device (no DataLoader), three epochs of
+    16 + 16 + 8 users, finite falling loss, evaluation and checkpoint as usual."""
+    _device_sampler_run(tmp_path, monkeypatch)
+
+
+def test_text_run_device_sampler_simulated(tmp_path, monkeypatch):
+    """--device_sampler 1: run.py draws its batches with DeviceTrainSampler instead of BuildTrainDataset + DataLoader -- same epoch
+    structure (40 users = 16 + 16 + 8, sharded and shuffled by the DistributedSampler), finite falling loss, evaluation and checkpoint."""
+    _simulate(monkeypatch)
+    _device_sampler_run(tmp_path, monkeypatch)
 
 
 def _simulate(monkeypatch):
