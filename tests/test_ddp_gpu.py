@@ -137,9 +137,9 @@ def test_one_rank_rccl_chunked_exchange_equals_single_allreduce(tmp_path):
     assert len(r[True]['launches']) >= 2 and len(r[False]['launches']) <= 1, (r[True]['launches'], r[False]['launches'])
     covered = sorted(r[True]['launches'])
     assert all(a[1] <= b[0] for a, b in zip(covered, covered[1:]))                     # disjoint: no element is averaged twice
-    # two backward passes of the same step: identical up to the order of the kernels' fp32 atomic accumulation (column sums, embedding
-    # rows) -- the forward has no atomics, so the loss is bit-equal; a chunk that was dropped, doubled or left in flight would show at O(1)
-    assert r[True]['loss'] == r[False]['loss']
+    # two passes of the same step: identical up to the order of the kernels' fp32 atomic accumulation (the loss sum itself, column sums,
+    # embedding rows); a chunk that was dropped, doubled or left in flight would show at O(1)
+    assert abs(r[True]['loss'] - r[False]['loss']) <= 1e-5 * abs(r[False]['loss'])
     torch.testing.assert_close(r[True]['flat'], r[False]['flat'], rtol=1e-3, atol=1e-4 * float(r[False]['flat'].abs().max()))
     assert float(r[True]['flat'].abs().max()) > 0
     assert r['identity'] and r['any_rank'] == (True, False)
