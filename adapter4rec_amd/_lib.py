@@ -12,7 +12,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('A4R_LIB_PATH') or os.path.join(_HERE, 'liba4r_hip.so')    # A4R_LIB_PATH: A/B builds (tools/), same C ABI
 
-ABI_VERSION = 401          # = A4R_ABI_VERSION of include/a4r.h (tests/test_abi_cpu.py compares the two)
+ABI_VERSION = 402          # = A4R_ABI_VERSION of include/a4r.h (tests/test_abi_cpu.py compares the two)
 BF16, F32, FP8 = 0, 1, 2
 ACT_NONE, ACT_RELU, ACT_GELU, ACT_GELU_TANH, ACT_LEAKY = 0, 1, 2, 3, 4
 DACT_MUL = 15
@@ -25,7 +25,7 @@ EXPORTS = [
     'a4r_version', 'a4r_gemm_nt', 'a4r_gemm_tn', 'a4r_gemm_tn2', 'a4r_colsum', 'a4r_attn_fwd', 'a4r_attn_bwd', 'a4r_embed_ln',
     'a4r_ln_fwd', 'a4r_ln_bwd', 'a4r_gather_rows', 'a4r_scatter_rows', 'a4r_act_bwd_f32', 'a4r_score_bce_fwd',
     'a4r_score_bce_bwd', 'a4r_emb_grad_add_inputs', 'a4r_take_inputs', 'a4r_adam_step', 'a4r_pack_matrices',
-    'a4r_eval_rank', 'a4r_dropout_apply', 'a4r_gemm_variant', 'a4r_gemm_tail_plan', 'a4r_gemm_tail_max', 'a4r_gemm_rows_256', 'a4r_adapter_ln_fwd', 'a4r_adapter_ln_bwd', 'a4r_ln_fwd_fp8', 'a4r_quant_rows_fp8', 'a4r_lora_merge', 'a4r_lora_merge_batch', 'a4r_phm_build', 'a4r_phm_bwd', 'a4r_unpack_add', 'a4r_memset_zero',
+    'a4r_eval_rank', 'a4r_dropout_apply', 'a4r_gemm_variant', 'a4r_gemm_tail_plan', 'a4r_gemm_tail_max', 'a4r_gemm_rows_256', 'a4r_adapter_ln_fwd', 'a4r_adapter_ln_bwd', 'a4r_ln_fwd_fp8', 'a4r_ln_fwd_sum', 'a4r_quant_rows_fp8', 'a4r_lora_merge', 'a4r_lora_merge_batch', 'a4r_phm_build', 'a4r_phm_bwd', 'a4r_unpack_add', 'a4r_memset_zero',
     'a4r_sasrec_block_fwd', 'a4r_sasrec_block_bwd', 'a4r_scatter_rows_fill', 'a4r_attn_long_fwd', 'a4r_attn_long_bwd', 'a4r_patchify', 'a4r_vit_assemble', 'a4r_resample_u8', 'a4r_embed_bwd', 'a4r_mae_keep_indices',
 ]
 
@@ -381,6 +381,19 @@ def quant_rows_fp8(x, q, scale, M=None):
     assert q.dtype == torch.uint8 and scale.dtype == torch.float32
     _check(lib().a4r_quant_rows_fp8(_stream(), _p(x), C.c_int(_ld(x)), _p(q), C.c_int(_ld(q)), _p(scale), C.c_int(M), C.c_int(x.shape[1]),
                                     C.c_int(_dt(x))), 'a4r_quant_rows_fp8')
+
+
+def ln_fwd_sum(h, res, gamma, beta, eps, y, stats, M=None, res32=None, sum_out=None, sum32=None, y32=None):
+    """y = LN(h + residual), sum in fp32, normalised unrounded; residual = res32 (fp32) when given, else res (h's dtype).  Optional outputs:
+    sum_out (h's dtype), sum32, y32 (fp32)."""
+    require_gpu(h, res, res32, y, sum_out, sum32, y32)
+    M = h.shape[0] if M is None else M
+    assert res32 is not None or res is not None
+    _check(lib().a4r_ln_fwd_sum(_stream(), _p(h), C.c_int(_ld(h)), _p(res32), C.c_int(_ld(res32) if res32 is not None else 0), _p(res),
+                                C.c_int(_ld(res) if res is not None else 0), _p(gamma), _p(beta), C.c_float(eps), _p(y), C.c_int(_ld(y)),
+                                _p(sum_out), C.c_int(_ld(sum_out) if sum_out is not None else 0), _p(sum32), C.c_int(_ld(sum32) if sum32 is not None else 0),
+                                _p(y32), C.c_int(_ld(y32) if y32 is not None else 0), _p(stats), C.c_int(M), C.c_int(h.shape[1]), C.c_int(_dt(h))),
+           'a4r_ln_fwd_sum')
 
 
 def ln_fwd(v, gamma, beta, eps, y, stats, M=None, add=None, drop_p=0.0, drop_site=0, drop_seed=0, y8=None, ys=None):

@@ -225,6 +225,45 @@ __global__ void __launch_bounds__(256) ln_fwd_kernel(const T* __restrict__ vin, 
     }
 }
 
+// ------------------------------------------------------------------ residual add + LN (round 4: --residual_dtype fp32 on un-adapted sub-layers)
+// s = h + res (fp32; res either the fp32 twin of the residual stream or its T tensor); y = LayerNorm(s) from the UNROUNDED sum.  Optional
+// outputs: sum (T: what a4r_ln_bwd re-reads as v), sum32 (fp32: the residual operand of a fused adapter launch that follows, Pfeiffer), y32
+// (y before its rounding: the next sub-layer's fp32 residual).  The reference under autocast runs exactly this arithmetic: the dense output is
+// bf16, `hidden_states + input_tensor` promotes to the fp32 LayerNorm output of the layer below, LayerNorm runs in fp32 (HF BertSelfOutput /
+// BertOutput reached from Downstream/Text/model/encoders.py:53).
+template <typename T>
+__global__ void __launch_bounds__(256) ln_fwd_sum_kernel(const T* __restrict__ h, int ldh, const float* __restrict__ res32, int ldr32, const T* __restrict__ res,
+                                                         int ldr, const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
+                                                         T* __restrict__ y, int ldy, T* __restrict__ sum, int lds_, float* __restrict__ sum32, int lds32,
+                                                         float* __restrict__ y32, int ldy32, float* __restrict__ stats, int M, int H) {
+    const int lane = threadIdx.x & 63;
+    const int ng = H / 8;
+    float ga[MAXG][8], be[MAXG][8];
+    row_load<float>(gamma, ng, lane, ga);
+    row_load<float>(beta, ng, lane, be);
+    for (int row = blockIdx.x * 4 + (threadIdx.x >> 6); row < M; row += gridDim.x * 4) {
+        float v[MAXG][8], a[MAXG][8];
+        row_load<T>(h + (size_t)row * ldh, ng, lane, v);
+        if (res32) row_load<float>(res32 + (size_t)row * ldr32, ng, lane, a);
+        else row_load<T>(res + (size_t)row * ldr, ng, lane, a);
+#pragma unroll
+        for (int g = 0; g < MAXG; ++g)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[g][e] += a[g][e];
+        if (sum) row_store<T>(sum + (size_t)row * lds_, ng, lane, v);
+        if (sum32) row_store<float>(sum32 + (size_t)row * lds32, ng, lane, v);
+        float mean, rstd;
+        row_stats(v, ng, lane, H, eps, mean, rstd);
+        if (lane == 0) { stats[2 * (size_t)row] = mean; stats[2 * (size_t)row + 1] = rstd; }
+#pragma unroll
+        for (int g = 0; g < MAXG; ++g)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[g][e] = (v[g][e] - mean) * rstd * ga[g][e] + be[g][e];
+        row_store<T>(y + (size_t)row * ldy, ng, lane, v);
+        if (y32) row_store<float>(y32 + (size_t)row * ldy32, ng, lane, v);
+    }
+}
+
 // ------------------------------------------------------------------ LN backward
 // dv = rstd * (dxhat - mean(dxhat) - xhat * mean(dxhat * xhat)), dxhat = dy * gamma (dy first goes back through
 // the forward's dropout mask).  Column sums (dgamma, dbeta, dbias = sum dv) are kept per lane over the rows a
@@ -461,6 +500,27 @@ extern "C" int a4r_ln_fwd(void* stream, const void* v, int ldv, const float* add
                           float drop_p, uint32_t drop_site, uint64_t drop_seed) {
     if (!y) return A4R_EINVAL;
     return ln_fwd_launch(stream, v, ldv, add, add_rows, gamma, beta, eps, y, ldy, stats, M, H, dtype, drop_p, drop_site, drop_seed, nullptr, 0, nullptr);
+}
+
+extern "C" int a4r_ln_fwd_sum(void* stream, const void* h, int ldh, const float* res32, int ldres32, const void* res, int ldres,
+                              const float* gamma, const float* beta, float eps, void* y, int ldy, void* sum, int ldsum, float* sum32, int ldsum32,
+                              float* y32, int ldy32, float* stats, int M, int H, int dtype) {
+    if (!h || (!res32 && !res) || !gamma || !beta || !y || !stats || bad_dtype(dtype) || M <= 0 || H <= 0 || H % 8 || H > 1024) return A4R_EINVAL;
+    const int esz = dtype == A4R_F32 ? 4 : 2;
+    if ((ldh * esz) % 16 || ldh < H || misaligned(h) || (ldy * esz) % 16 || ldy < H || misaligned(y)) return A4R_EINVAL;
+    if (res32 && (ldres32 % 4 || ldres32 < H || misaligned(res32))) return A4R_EINVAL;
+    if (!res32 && ((ldres * esz) % 16 || ldres < H || misaligned(res))) return A4R_EINVAL;
+    if (sum && ((ldsum * esz) % 16 || ldsum < H || misaligned(sum))) return A4R_EINVAL;
+    if (sum32 && (ldsum32 % 4 || ldsum32 < H || misaligned(sum32))) return A4R_EINVAL;
+    if (y32 && (ldy32 % 4 || ldy32 < H || misaligned(y32))) return A4R_EINVAL;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    if (dtype == A4R_BF16)
+        hipLaunchKernelGGL(ln_fwd_sum_kernel<bf16_t>, dim3(row_grid(M)), dim3(256), 0, s, (const bf16_t*)h, ldh, res32, ldres32, (const bf16_t*)res, ldres, gamma,
+                           beta, eps, (bf16_t*)y, ldy, (bf16_t*)sum, ldsum, sum32, ldsum32, y32, ldy32, stats, M, H);
+    else
+        hipLaunchKernelGGL(ln_fwd_sum_kernel<float>, dim3(row_grid(M)), dim3(256), 0, s, (const float*)h, ldh, res32, ldres32, (const float*)res, ldres, gamma,
+                           beta, eps, (float*)y, ldy, (float*)sum, ldsum, sum32, ldsum32, y32, ldy32, stats, M, H);
+    return a4r_launch_status();
 }
 
 extern "C" int a4r_ln_fwd_fp8(void* stream, const void* v, int ldv, const float* add, int add_rows,

@@ -949,13 +949,34 @@ class TransRecEngine:
                 self._sub_forward(blk, which, dense_in, w, bias, resid, ln, ad, pl, lnn, bufs, M, p_drop, site, seed, out, scales=scales)
                 L.quant_rows_fp8(out, y8, ys, M=M)
                 return
+        # --residual_dtype fp32 on the sub-layers WITHOUT a one-launch serial adapter (un-adapted: Pfeiffer's attention half, LoRA, frozen,
+        # soft prompt; Pfeiffer's FFN half): the dense output leaves the GEMM alone (bf16, as the reference's autocast Linear does), the
+        # residual -- the fp32 twin the sub-layer below left, or the bf16 tensor itself at the first layer -- is added in fp32 inside
+        # a4r_ln_fwd_sum, which normalises the unrounded sum and leaves the fp32 twin of its own output.
+        r32mode = self.res32 and blk.T == torch.bfloat16 and getattr(blk, 'Hv', blk.H) == blk.H and v is not None and v.shape[1] == blk.H
         if ad is None:
+            if r32mode:
+                hd = self._buf('res32.h', M, blk.H, blk.T)
+                L.gemm_nt(dense_in, w, hd, bias=bias, drop_p=p_drop, drop_site=site, drop_seed=seed, M=M, **sk)
+                y32 = self._buf('res32.' + which, M, blk.H, torch.float32)
+                L.ln_fwd_sum(hd, resid, ln.gamma, ln.beta, ln.eps, out, st, M=M, res32=self._twin_of(resid, M), sum_out=v, y32=y32)
+                self._twin[out.data_ptr()] = y32
+                return
             L.gemm_nt(dense_in, w, v, bias=bias, R1=resid, drop_p=p_drop, drop_site=site, drop_seed=seed, drop_first=True, M=M, **sk)
             L.ln_fwd(self._vc(blk, v), ln.gamma, ln.beta, ln.eps, self._vc(blk, out), st, M=M)
             return
         zp, z = bufs['zp' + which], bufs['z' + which]
         if pl == 'pfeiffer':          # model.py:321-329 / :458-471
             va, t, sta = bufs['va' + which], bufs['t' + which], bufs['sta' + which]
+            if r32mode and self._fuse(blk, ad, t):
+                hd = self._buf('res32.h', M, blk.H, blk.T)
+                va32 = self._buf('res32.va', M, blk.H, torch.float32)
+                L.gemm_nt(dense_in, w, hd, bias=bias, drop_p=p_drop, drop_site=site, drop_seed=seed, M=M, **sk)
+                L.ln_fwd_sum(hd, resid, ln.gamma, ln.beta, ln.eps, t, sta, M=M, res32=self._twin_of(resid, M), sum_out=va, sum32=va32)   # va = h + input
+                y32 = self._buf('res32.' + which, M, blk.H, torch.float32)
+                L.adapter_ln_fwd(t, va, None, ad.wd, ad.bd, ad.wu, ad.bu, lnn.gamma, lnn.beta, lnn.eps, ad.act, zp, z, v, out, st, M=M, res32=va32, y32=y32)
+                self._twin[out.data_ptr()] = y32
+                return
             L.gemm_nt(dense_in, w, va, bias=bias, R1=resid, drop_p=p_drop, drop_site=site, drop_seed=seed, drop_first=True, M=M, **sk)   # h + input
             L.ln_fwd(va, ln.gamma, ln.beta, ln.eps, t, sta, M=M)
             if self._fuse(blk, ad, t):

@@ -82,7 +82,8 @@ def build_parser():
                    help="bf16 storage only: fp32 keeps the item encoder's residual stream between sub-layers in fp32, as the reference's "
                         'autocast(bfloat16) does (its LayerNorm outputs fp32): scores / embeddings then sit at 0.7 - 0.9x the distance of the '
                         "reference's own autocast path from fp32 instead of 1.2 - 1.3x, for ~6 bytes more HBM traffic per token and sub-layer "
-                        '(serial Houlsby / Compacter adapters on the one-launch kernels; other placements keep the bf16 stream)')
+                        '(serial Houlsby / Compacter adapters on the one-launch kernels, un-adapted sub-layers and Pfeiffer through a4r_ln_fwd_sum; '
+                        'parallel Houlsby and K-Adapter blocks keep the bf16 stream; text tower only)')
     p.add_argument('--eval_compute_dtype', type=str, default='fp32', choices=['bf16', 'fp32'],
                    help="dtype of eval's item sweep (get_item_embeddings).  Default fp32 = the reference's eval precision: HR@10 / nDCG@10 "
                         'and per-user ranks then match the fp32 reference exactly on the trained weights (a bf16 sweep moves a few users across '

@@ -36,7 +36,7 @@ extern "C" {
 
 /* ABI version: bumped whenever a signature or struct below changes.  The Python binding (adapter4rec_amd/_lib.py) refuses a
  * library whose a4r_version() differs, so an A/B build made before a signature change cannot be called with shifted arguments. */
-#define A4R_ABI_VERSION 401
+#define A4R_ABI_VERSION 402
 int a4r_version(void);
 
 /* C[M,N] = epilogue(alpha * A[M,K] . B[N,K]^T): every nn.Linear on the path (HF BertSelfAttention
@@ -268,6 +268,12 @@ int a4r_ln_fwd(void* stream, const void* v, int ldv, const float* add, int add_r
                const float* gamma, const float* beta, float eps,
                void* y, int ldy, float* stats, int M, int H, int dtype,
                float drop_p, uint32_t drop_site, uint64_t drop_seed);
+/* y = LayerNorm(h + residual) with the sum taken in fp32 and normalised UNROUNDED (un-adapted sub-layers under --residual_dtype fp32: HF
+ * BertSelfOutput / BertOutput as the reference's autocast runs them).  The residual is res32 (fp32 [M, H]) when given, else res (h's dtype).
+ * Optional outputs: sum (h's dtype: the v that a4r_ln_bwd re-reads), sum32 (fp32), y32 (y before its rounding).  stats [M, 2] = (mean, rstd). */
+int a4r_ln_fwd_sum(void* stream, const void* h, int ldh, const float* res32, int ldres32, const void* res, int ldres,
+                   const float* gamma, const float* beta, float eps, void* y, int ldy, void* sum, int ldsum, float* sum32, int ldsum32,
+                   float* y32, int ldy32, float* stats, int M, int H, int dtype);
 /* fp8 (OCP e4m3fn) operands of the frozen-backbone forward GEMMs (north_star "fp8 MFMA encoder"; the reference's reduced-precision
  * path is fp16 AMP, Downstream/CV/run_adapter.py:565-593).  One fp32 scale per ROW: q[row] = e4m3(x[row] * 448 / amax(row)),
  * scale[row] = amax(row) / 448.  a4r_ln_fwd_fp8 = a4r_ln_fwd that ALSO (y optional) emits the normalised row in that form straight

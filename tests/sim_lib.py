@@ -312,6 +312,23 @@ def quant_rows_fp8(x, q, scale, M=None):
     _quant_rows(x[:M].float(), q, scale)
 
 
+def ln_fwd_sum(h, res, gamma, beta, eps, y, stats, M=None, res32=None, sum_out=None, sum32=None, y32=None):
+    M = h.shape[0] if M is None else M
+    x = h[:M].float() + (res32[:M] if res32 is not None else res[:M].float())
+    if sum_out is not None:
+        sum_out[:M] = x.to(sum_out.dtype)
+    if sum32 is not None:
+        sum32[:M] = x
+    mu = x.mean(-1, keepdim=True)
+    rstd = torch.rsqrt(((x - mu) ** 2).mean(-1, keepdim=True) + eps)
+    stats[:M, 0] = mu[:, 0]
+    stats[:M, 1] = rstd[:, 0]
+    out = (x - mu) * rstd * gamma + beta
+    y[:M] = out.to(y.dtype)
+    if y32 is not None:
+        y32[:M] = out
+
+
 def ln_fwd(v, gamma, beta, eps, y, stats, M=None, add=None, drop_p=0.0, drop_site=0, drop_seed=0, y8=None, ys=None):
     assert drop_p == 0.0
     M = v.shape[0] if M is None else M

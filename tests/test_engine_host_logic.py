@@ -101,6 +101,46 @@ def test_host_logic_bf16_mode(simulated, name):
         assert np.abs(params[k].grad.numpy() - ref).max() <= 0.15 * np.abs(ref).max() + 1e-9, k      # (bf16 noise: 0.11 - 0.14 by which roundings the forward has)
 
 
+@pytest.mark.parametrize('name', ['houlsby', 'pfeiffer', 'roberta_cpc_pfeiffer', 'prompt'])
+def test_host_logic_residual_fp32(simulated, name):
+    """--residual_dtype fp32 through every sub-layer form of the text tower (one-launch serial adapter, un-adapted sub-layer and Pfeiffer's FFN
+    half through a4r_ln_fwd_sum): the step stays inside the bf16 bounds against the fp32 oracle, the fp32 twins are consumed (embeddings
+    differ from the bf16-stream run) and are at least as close to the oracle."""
+    from golden_util import load_variant
+    from oracle import ref_cpu as R
+    root, args, fx, items, mask = build_cpu(name)
+    sd, cfg, *_ = load_variant(name)
+    sd = TG.condition(sd)
+    inner = getattr(root, 'model', root)
+    inner.compute_dtype = 'bf16'
+    root.load_state_dict({str(k): sd[strip(str(k))] for k in fx['all_keys']}, strict=True)
+    tr = [strip(str(k)) for k in fx['trainable']]
+    out, grads = R.loss_and_grads(sd, tr, items, mask, cfg)
+    res = {}
+    for rd in ('bf16', 'fp32'):
+        inner.args.residual_dtype = rd
+        inner.invalidate_native()
+        for p in root.parameters():
+            p.grad = None
+        loss = root(items, mask, 'cpu')
+        loss.backward()
+        with torch.no_grad():
+            emb = inner.bert_encoder(items)
+        params = dict(root.named_parameters())
+        rel = {str(k): float(np.abs(params[str(k)].grad.numpy() - grads[strip(str(k))].numpy()).max() / (np.abs(grads[strip(str(k))].numpy()).max() + 1e-12))
+               for k in fx['trainable']}
+        # RELU-gated down-projection gradients under CPC (one scored position per user) rest on a handful of token rows: a relu' that flips
+        # under bf16 rounding moves them by 0.07 - 0.25 of their max, either way, with any change of the roundings upstream -- bounded apart
+        gated = [v for k, v in rel.items() if 'fc_down' in k]
+        worst = max(v for k, v in rel.items() if 'fc_down' not in k or cfg['arch'] != 'cpc')
+        assert not gated or max(gated) < 0.3, max(gated)
+        res[rd] = (abs(loss.item() - float(out['loss'].detach())), emb, float((emb - out['input_embs_all'].detach()).double().pow(2).mean().sqrt()), worst)
+    print(name, {k: (round(v[0], 5), round(v[2], 6), round(v[3], 4)) for k, v in res.items()})
+    assert res['fp32'][0] < 2e-2 and res['fp32'][3] < 0.15, (res['fp32'][::3], res['bf16'][::3])
+    assert not torch.equal(res['fp32'][1], res['bf16'][1])
+    assert res['fp32'][2] <= 1.05 * res['bf16'][2], (res['fp32'][2], res['bf16'][2])
+
+
 def build_lora_cpu(dtype='fp32'):
     """LoRA has no reference fixture (loralib is absent): weights are seeded here and the oracle is the only checker."""
     import adapter4rec_amd.inject as I

@@ -1538,3 +1538,29 @@ def test_gemm256_ring_race_screen(M, N, K):
             assert float((C.float() - ref).abs().max() / ref.abs().max()) < 2e-2
         else:
             assert torch.equal(C, first), f'run {it} differs from run 0'
+
+
+@pytest.mark.parametrize('t', [torch.bfloat16, torch.float32])
+@pytest.mark.parametrize('twin', [True, False])
+def test_ln_fwd_sum(t, twin):
+    """a4r_ln_fwd_sum: y = LN(h + residual), sum in fp32, normalised unrounded; residual = the fp32 twin or the T tensor; outputs sum (T),
+    sum32, y32, stats -- against torch fp32."""
+    from adapter4rec_amd import _lib as L
+    M, H = 16 * 301, 768
+    h, r = rnd(M, H, dtype=t, seed=1), rnd(M, H, dtype=t, seed=2) * 3.0
+    r32 = rnd(M, H, seed=3) * 3.0
+    gamma, beta = 1.0 + 0.1 * rnd(H, seed=4), 0.1 * rnd(H, seed=5)
+    y, sm = torch.zeros(M, H, dtype=t, device=dev()), torch.zeros(M, H, dtype=t, device=dev())
+    s32, y32, st = torch.zeros(M, H, device=dev()), torch.zeros(M, H, device=dev()), torch.zeros(M, 2, device=dev())
+    L.ln_fwd_sum(h, r, gamma, beta, 1e-12, y, st, res32=r32 if twin else None, sum_out=sm, sum32=s32, y32=y32)
+    ref_s = h.float() + (r32 if twin else r.float())
+    ref_y = torch.nn.functional.layer_norm(ref_s, (H,), gamma, beta, 1e-12)
+    close(s32, ref_s, torch.float32, 'sum32', atol32=1e-6, rtol32=1e-6)
+    close(sm, ref_s, t, 'sum')
+    close(y32, ref_y, torch.float32, 'y32', atol32=2e-5, rtol32=2e-5)
+    close(y, ref_y, t, 'y')
+    close(st[:, 0], ref_s.mean(-1), torch.float32, 'mean', atol32=1e-5, rtol32=1e-5)
+    close(st[:, 1], torch.rsqrt(ref_s.var(-1, unbiased=False) + 1e-12), torch.float32, 'rstd', atol32=1e-5, rtol32=1e-4)
+    y2, st2 = torch.zeros(M, H, dtype=t, device=dev()), torch.zeros(M, 2, device=dev())
+    L.ln_fwd_sum(h, r, gamma, beta, 1e-12, y2, st2, res32=r32 if twin else None)          # the optional outputs do not change y
+    assert torch.equal(y, y2) and torch.equal(st, st2)

@@ -161,17 +161,19 @@ def test_base_geometry_step_fp32_and_bf16_vs_oracle_and_reference(name):
         if hip[k].numel() >= 16:                        # (CPC scores one position per user: 2 numbers here -- no statistic; the embeddings carry the bound)
             assert rep[k]['hip_rms'] <= lim * rep[k]['ref_autocast_rms'] + 1e-3, (k, rep[k])
         assert rep[k]['hip_max'] <= 3.0 * rep[k]['ref_autocast_max'] + 1e-3, (k, rep[k])
-    if houlsby:
+    if True:
         # --residual_dtype fp32: the residual stream between sub-layers in fp32, as under the reference's autocast (its LayerNorm outputs
-        # fp32).  Measured 0.77 / 0.63 / 0.78 of the reference-under-autocast's distance from fp32: at least as accurate as the reference's AMP.
+        # fp32).  Measured 0.77 / 0.63 / 0.78 of the reference-under-autocast's distance from fp32 (serial Houlsby) and 0.80 on the embeddings
+        # of RoBERTa + Pfeiffer (un-adapted attention half + Pfeiffer FFN half through a4r_ln_fwd_sum): at least as accurate as the reference's AMP.
         r32 = step('bf16', 'fp32')
         hip32 = dict(pos=r32['pos'] - rfx['pos'], neg=r32['neg'] - rfx['neg'], emb=r32['emb'] - rfx['emb'])
         rep32 = {k: dict(hip_rms=rms(hip32[k]), ref_autocast_rms=rms(acd[k]), ratio=rms(hip32[k]) / max(rms(acd[k]), 1e-30)) for k in hip32}
         print(f'{name} HIP bf16 + --residual_dtype fp32 vs the reference under autocast(bfloat16):', {k: round(v['ratio'], 3) for k, v in rep32.items()})
         for k in ('pos', 'neg', 'emb'):
-            assert rep32[k]['hip_rms'] <= 1.0 * rep32[k]['ref_autocast_rms'] + 1e-3, (k, rep32[k])
+            if hip32[k].numel() >= 16:
+                assert rep32[k]['hip_rms'] <= 1.0 * rep32[k]['ref_autocast_rms'] + 1e-3, (k, rep32[k])
         g32, w32 = grad_err(r32['grads'], ref['grads'])
-        assert g32 < 0.2 and abs(r32['loss'] - ref['loss']) < 3e-2, (g32, w32, r32['loss'])
+        assert g32 < (0.4 if cpc else 0.2) and abs(r32['loss'] - ref['loss']) < 3e-2, (g32, w32, r32['loss'])
     assert rep['grad']['median_ratio'] <= 2.0 and rep['grad']['hip_worst'] <= 2.0 * rep['grad']['ref_autocast_worst'] + 0.02, rep['grad']
     # fp8 encoder on the text tower (north_star: "fp8 MFMA encoder"): frozen qkv / attention-output / FFN GEMMs + the FFN dgrads on e4m3
     # operands (per-token x per-channel scales), everything else as in bf16.  Measured bounds with ~2x headroom.
