@@ -122,9 +122,21 @@ A4R_DEV void tn_glds16(const void* base, uint32_t voff, uint32_t lds_dst) {
 // of the first Q-tile: 64 atomics per workgroup on ~32-way contended addresses instead of the 832 the fused adapter backward issued from
 // each of its 256 workgroups onto the same 832 addresses (6 - 9 us at the end of that launch).
 struct TnProb { const bf16_t* X; const bf16_t* Y; float* C; int ldx, ldy, ldc, ntq; float* xsum; };
-__global__ void __launch_bounds__(256) gemm_tn_glds_kernel(const TnProb pa, const TnProb pb, int M, int rows_per_split) {
+__global__ void __launch_bounds__(256) gemm_tn_glds_kernel(const TnProb pa, const TnProb pb, int M, int rows_per_split, int xcd_groups) {
     // blockIdx.z picks one of two products of one launch (the two weight gradients of an adapter: different operands, same token range)
-    const TnProb& pr = blockIdx.z == 0 ? pa : pb;
+    // xcd_groups (round 4): the T = gridDim.x output tiles of one (token range, product) share the NARROW operand's slab ([rows, 64]: z for
+    // dW_up, dzp for dW_down) -- 12 tiles at H = 768 -- and cut every row of the wide operand into 128-byte pieces.  Dealt to the XCDs in launch
+    // order (x fastest) the 12 land on all 8 XCDs and the slab is fetched 8 times; remapped so that a group sits on ONE XCD (workgroups b
+    // and b + 8 share an XCD under round-robin placement: speed only) it is fetched once and re-read from that XCD's L2.
+    int bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
+    if (xcd_groups) {
+        const int T = gridDim.x, lin = blockIdx.x + T * (blockIdx.y + gridDim.y * blockIdx.z);
+        const int slot = lin >> 3, grp = (slot / T) * 8 + (lin & 7);
+        bx = slot % T;
+        by = grp % (int)gridDim.y;
+        bz = grp / (int)gridDim.y;
+    }
+    const TnProb& pr = bz == 0 ? pa : pb;
     const bf16_t* __restrict__ X = pr.X;
     const bf16_t* __restrict__ Y = pr.Y;
     float* __restrict__ C = pr.C;
@@ -134,7 +146,7 @@ __global__ void __launch_bounds__(256) gemm_tn_glds_kernel(const TnProb pa, cons
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wp = wave >> 1, wq = wave & 1;
-    const int tile = blockIdx.x, split = blockIdx.y;
+    const int tile = bx, split = by;
     const int p0 = (tile / ntq) * 64, q0 = (tile % ntq) * 64;
     const int m_begin = split * rows_per_split;
     const int m_end = min(M, m_begin + rows_per_split);
@@ -257,6 +269,12 @@ __global__ void __launch_bounds__(256) colsum_kernel(const T* __restrict__ X, in
 
 int g_tn_variant = 1;          // 0: register-staged kernel for bf16 too (tests / A-B via a4r_gemm_variant(0))
 
+// 1 when the launch's (token range, product) groups can be dealt whole to the 8 XCDs (A4R_TN_XCD=0: launch order, A/B runs)
+static int tn_xcd_groups(int groups) {
+    static const int on = getenv("A4R_TN_XCD") ? atoi(getenv("A4R_TN_XCD")) != 0 : 1;
+    return on && groups % 8 == 0;
+}
+
 extern "C" int a4r_gemm_tn(void* stream, const void* X, int ldx, const void* Y, int ldy, float* C, int ldc,
                            int M, int P, int Q, int dtype) {
     if (!X || !Y || !C || M <= 0 || P <= 0 || Q <= 0 || M % 64 || P % 64 || Q % 64) return A4R_EINVAL;
@@ -273,7 +291,7 @@ extern "C" int a4r_gemm_tn(void* stream, const void* X, int ldx, const void* Y, 
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     if (glds) {
         const TnProb pa{(const bf16_t*)X, (const bf16_t*)Y, C, ldx, ldy, ldc, ntq, nullptr};
-        hipLaunchKernelGGL(gemm_tn_glds_kernel, dim3(tiles, splits, 1), dim3(256), 0, s, pa, pa, M, rows_per_split);
+        hipLaunchKernelGGL(gemm_tn_glds_kernel, dim3(tiles, splits, 1), dim3(256), 0, s, pa, pa, M, rows_per_split, tn_xcd_groups(splits));
     }
     else if (dtype == A4R_BF16)
         hipLaunchKernelGGL(gemm_tn_kernel<bf16_t>, dim3(tiles, splits), dim3(256), 0, s, (const bf16_t*)X, ldx, (const bf16_t*)Y, ldy,
@@ -304,7 +322,8 @@ extern "C" int a4r_gemm_tn2(void* stream, const void* X1, int ldx1, const void* 
     splits = (M + rows_per_split - 1) / rows_per_split;
     const TnProb pa{(const bf16_t*)X1, (const bf16_t*)Y1, C1, ldx1, ldy1, ldc1, Q1 / 64, xsum1};
     const TnProb pb{(const bf16_t*)X2, (const bf16_t*)Y2, C2, ldx2, ldy2, ldc2, Q2 / 64, xsum2};
-    hipLaunchKernelGGL(gemm_tn_glds_kernel, dim3(tiles, splits, 2), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), pa, pb, M, rows_per_split);
+    hipLaunchKernelGGL(gemm_tn_glds_kernel, dim3(tiles, splits, 2), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), pa, pb, M, rows_per_split,
+                       tn_xcd_groups(2 * splits));
     return a4r_launch_status();
 }
 
