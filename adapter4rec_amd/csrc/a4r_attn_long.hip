@@ -29,6 +29,9 @@
 namespace {
 
 template <typename T> A4R_DEV uint4 ldg16(const T* p) { return *reinterpret_cast<const uint4*>(p); }
+// the lane index as a value the compiler cannot see through: the dropout counters are rebuilt from it INSIDE the (wave-uniform) dropout branch, so their
+// loop-invariant parts are not hoisted into registers held across the key loops of runs without dropout (round 4: those registers were the spills)
+A4R_DEV int opaque_lane(int lane) { asm volatile("" : "+v"(lane)); return lane; }
 
 // 8 waves per (item, head) workgroup: two workgroups (114 KB of LDS at S = 197) give a CU 4 waves per SIMD to hide the
 // staging and Q / dO load latency behind; with 4-wave workgroups the chip sat at 0.4 waves per SIMD (PMC).
@@ -55,15 +58,28 @@ template <typename T, int DH, int NKT> constexpr size_t lds_main_fwd() { return 
 template <typename T, int DH, int NKT> constexpr size_t lds_main_dq() { return 2 * (size_t)NKT * 16 * Geo<T, DH>::ROWB + img_t<T, DH, NKT>(); }
 template <typename T, int DH, int NKT> constexpr size_t lds_main_dkdv() { return 2 * (size_t)NKT * 16 * Geo<T, DH>::ROWB + 2 * img_t<T, DH, NKT>() + 2 * NKT * 16 * sizeof(float); }
 
-// [S][DH] (global, row stride ld) -> LDS row-major [SP][DH], 16-byte chunks XOR-swizzled; rows >= S are zero
-template <typename T, int DH> A4R_DEV void stage_rows(char* lds, const T* src, int ld, int S, int SP, int tid, int NTHR) {
+// [S][DH] (global, row stride ld) -> LDS row-major [SP][DH], 16-byte chunks XOR-swizzled; rows >= S are zero.  Two phases, so that a workgroup has
+// the rows of BOTH its staged matrices in flight before the first LDS write (round 4: the one-call form compiled to a rolled loop of
+// load -> s_waitcnt vmcnt(0) -> ds_write, 4 + 4 dependent HBM round trips before the workgroup's first product).
+template <typename T, int DH, int SP, int NTHR> struct Stager {
     using G = Geo<T, DH>;
-    for (int id = tid; id < SP * G::CPR; id += NTHR) {
-        const int r = id / G::CPR, c = id % G::CPR;
-        const uint4 v = r < S ? ldg16(src + (size_t)r * ld + c * G::PER) : make_uint4(0, 0, 0, 0);
-        *reinterpret_cast<uint4*>(lds + r * G::ROWB + ((c ^ G::swz(r)) << 4)) = v;
+    static constexpr int TOTAL = SP * G::CPR, NIT = (TOTAL + NTHR - 1) / NTHR;
+    uint4 v[NIT];
+    A4R_DEV void request(const T* src, int ld, int S, int tid) {
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int id = tid + it * NTHR, r = id / G::CPR, c = id % G::CPR;
+            v[it] = (id < TOTAL && r < S) ? ldg16(src + (size_t)r * ld + c * G::PER) : make_uint4(0, 0, 0, 0);
+        }
     }
-}
+    A4R_DEV void commit(char* lds, int tid) const {
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int id = tid + it * NTHR, r = id / G::CPR, c = id % G::CPR;
+            if (id < TOTAL) *reinterpret_cast<uint4*>(lds + r * G::ROWB + ((c ^ G::swz(r)) << 4)) = v[it];
+        }
+    }
+};
 // operand chunk from a row-major image: row `row`, chunk step ks
 template <typename T, int DH> A4R_DEV uint4 frag_rows(const char* lds, int row, int ks, int kg) {
     using G = Geo<T, DH>;
@@ -109,14 +125,14 @@ template <typename T, int DH> A4R_DEV uint4 frag_T(const void* img, int SPT, int
 // consecutive keys of a transposed score tile share one hash
 A4R_DEV uint64_t drop_idx(int pair, int q, int key) { return (((uint64_t)pair * 256 + q) << 8) + key; }
 
+
 // probabilities / score gradients of chunk step st as an operand chunk (see the k-slot permutation in the header)
+// (round 4: ONE v_cvt_pk_bf16_f32 per pair -- the scalar form cost 4 vector instructions per pair (two conversions, shift, or); the
+// hoisting that made the vector form spill in round 2 is held back by the callers' per-step scheduling barriers)
 template <typename T, int NKT> A4R_DEV uint4 pack_step(const f32x4_t (&t)[NKT], int st) {
     if constexpr (sizeof(T) == 2) {
         const f32x4_t a = t[2 * st], b = t[2 * st + 1];
-        // (scalar conversions here on purpose: with the vector form the 14-tile forward kernel needs 31 more registers than its
-        // 128-register budget -- the scheduler hoists the conversions of all steps -- and spills: 158 -> 254 us)
-        return make_uint4(f32_to_bf16_bits(a[0]) | (f32_to_bf16_bits(a[1]) << 16), f32_to_bf16_bits(a[2]) | (f32_to_bf16_bits(a[3]) << 16),
-                          f32_to_bf16_bits(b[0]) | (f32_to_bf16_bits(b[1]) << 16), f32_to_bf16_bits(b[2]) | (f32_to_bf16_bits(b[3]) << 16));
+        return make_uint4(pack2_bf16(a[0], a[1]), pack2_bf16(a[2], a[3]), pack2_bf16(b[0], b[1]), pack2_bf16(b[2], b[3]));
     } else {
         const f32x4_t a = t[st];
         return make_uint4(__float_as_uint(a[0]), __float_as_uint(a[1]), __float_as_uint(a[2]), __float_as_uint(a[3]));
@@ -142,8 +158,9 @@ A4R_DEV float red4(float v, bool mx) {       // over the 4 lanes l, l^16, l^32, 
 // (bf16; stored straight from the accumulators -- 8 bytes per lane, 32-byte pieces of 16 rows per instruction -- the short-sequence
 // backward moved the same bytes 32 us slower, a4r_attn.hip).  fp32 accumulators are 16 bytes per lane already.
 template <typename T, int DH>
-A4R_DEV void store_block16(char* stg, const f32x4_t (&o)[Geo<T, DH>::ND], T* g0, size_t ldg, int rows_valid, int lane) {
+A4R_DEV void store_block16(char* stg, const f32x4_t (&o)[Geo<T, DH>::ND], T* g0, size_t ldg, int rows_valid, int lane_) {
     using G = Geo<T, DH>;
+    const int lane = opaque_lane(lane_);                     // the addresses below are rebuilt here, not kept in registers across the caller's loops
     const int fr = lane & 15, kg = lane >> 4;
     if constexpr (sizeof(T) == 4) {
         if (fr < rows_valid) {
@@ -167,26 +184,64 @@ A4R_DEV void store_block16(char* stg, const f32x4_t (&o)[Geo<T, DH>::ND], T* g0,
     }
 }
 
-// transposed RAW score tiles of one 16-query block: s[kt][r] = q[query c] . k[key 16 kt + 4 kg + r]  (keys >= S: -inf; the softmax
-// scale is folded into the exponent by the caller).  Only tiles that reach past S carry the per-element select.
-template <typename T, int DH, int NKT>
-A4R_DEV void scores_t(const char* Kr, const uint4 (&qf)[Geo<T, DH>::KS], f32x4_t (&s)[NKT], int S, int fr, int kg) {
-    using G = Geo<T, DH>;
+// first key tile that can reach past S in the NKT instantiation (nkt_for: S > 16 * the previous instantiation's tiles)
+template <int NKT> constexpr int kt_partial_lo() { return NKT == 2 ? 0 : NKT == 4 ? 2 : NKT == 8 ? 4 : NKT == 14 ? 8 : 14; }
+
+// -inf on the keys >= S of the score tiles (transposed: lane (c, kg) holds keys 16 kt + 4 kg + r).  Only the tiles that CAN be partial in this
+// instantiation are looked at, each behind a real wave-uniform branch (round 4: the per-tile test inside the product loop had been if-converted into
+// two selects per element on every tile, their 56 lane masks spilled to a VGPR and read back with v_readlane -- 16 vector instructions per tile).
+template <int NKT> A4R_DEV void mask_keys(f32x4_t (&s)[NKT], int S, int kg, float fill) {
+    const int lim = S - kg * 4;
 #pragma unroll
-    for (int kt = 0; kt < NKT; ++kt) {
-        f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
+    for (int kt = kt_partial_lo<NKT>(); kt < NKT; ++kt) {
+        if (kt * 16 + 16 > S) {
+            asm volatile("" ::: "memory");                   // keeps the branch a branch
 #pragma unroll
-        for (int ks = 0; ks < G::KS; ++ks) Mma<T>::mma(frag_rows<T, DH>(Kr, kt * 16 + fr, ks, kg), qf[ks], acc);
-        if (kt * 16 + 16 > S) {                      // wave-uniform: the last one or two tiles
-#pragma unroll
-            for (int r = 0; r < 4; ++r) acc[r] = (kt * 16 + kg * 4 + r < S) ? acc[r] : -INFINITY;
+            for (int r = 0; r < 4; ++r) s[kt][r] = (kt * 16 + r < lim) ? s[kt][r] : fill;
         }
-        s[kt] = acc;
-        if ((kt & 1) == 1) __builtin_amdgcn_sched_barrier(0);      // keeps the scheduler from hoisting all 2 NKT fragment reads (spills)
     }
 }
 
-struct Drop { uint64_t seed; uint32_t site, thr16; float keep_scale; int abl; };     // abl: timing ablations (A4R_ATTN_LONG_ABL; wrong results): 1 no stores, 2 no per-block global loads, 4 no staging loads, 8 no softmax arithmetic
+// transposed RAW score tiles of one 16-query block: s[kt][r] = q[query c] . k[key 16 kt + 4 kg + r]  (keys >= S: -inf; the softmax
+// scale is folded into the exponent by the caller).  The key-side fragments of the next tile group are requested before the products of
+// the current one (one group = 2 tiles for bf16: two independent accumulator chains), a scheduling barrier per group keeps the order.
+template <typename T, int DH, int NKT>
+A4R_DEV void scores_t(const char* Kr, const uint4 (&qf)[Geo<T, DH>::KS], f32x4_t (&s)[NKT], int S, int fr, int kg) {
+    using G = Geo<T, DH>;
+    constexpr int TPG = sizeof(T) == 2 ? 2 : 1, NGRP = NKT / TPG;
+    static_assert(NKT % TPG == 0, "tile groups");
+    constexpr bool PF = sizeof(T) == 2;                      // (the fp32 parity instantiation has no registers for a second fragment set)
+    uint4 kf[PF ? 2 : 1][TPG][G::KS];
+    if constexpr (PF) {
+#pragma unroll
+        for (int t = 0; t < TPG; ++t)
+#pragma unroll
+            for (int ks = 0; ks < G::KS; ++ks) kf[0][t][ks] = frag_rows<T, DH>(Kr, t * 16 + fr, ks, kg);
+    }
+#pragma unroll
+    for (int g = 0; g < NGRP; ++g) {
+        const int gl = PF ? g + 1 : g;                       // the group whose fragments are requested in this region
+        if (gl < NGRP) {
+#pragma unroll
+            for (int t = 0; t < TPG; ++t)
+#pragma unroll
+                for (int ks = 0; ks < G::KS; ++ks) kf[PF ? (gl & 1) : 0][t][ks] = frag_rows<T, DH>(Kr, (gl * TPG + t) * 16 + fr, ks, kg);
+        }
+        f32x4_t acc[TPG];
+#pragma unroll
+        for (int t = 0; t < TPG; ++t) acc[t] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < G::KS; ++ks)
+#pragma unroll
+            for (int t = 0; t < TPG; ++t) Mma<T>::mma(kf[PF ? (g & 1) : 0][t][ks], qf[ks], acc[t]);
+#pragma unroll
+        for (int t = 0; t < TPG; ++t) s[g * TPG + t] = acc[t];
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    mask_keys<NKT>(s, S, kg, -INFINITY);
+}
+
+struct Drop { uint64_t seed; uint32_t site, thr16; float keep_scale; };
 
 // ------------------------------------------------------------------------------------------------ forward
 template <typename T, int DH, int NKT>
@@ -203,19 +258,32 @@ __global__ void __launch_bounds__(WG<NKT>::NTHR, 4) attn_long_fwd_kernel(const T
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, fr = lane & 15, kg = lane >> 4;
     char* stg = smem + lds_main_fwd<T, DH, NKT>() + wave * STG<T, DH>::BYTES;      // this wave's output staging block (bf16)
     const T* base = qkv + (size_t)item * S * ld + h * DH;
-    if (!(dr.abl & 4)) {
-        stage_rows<T, DH>(Kr, base + k_off, ld, S, SP, tid, NTHR);
-        stage_rows<T, DH>(Vimg, base + v_off, ld, S, SP, tid, NTHR);
+    const int nqb = (S + 15) >> 4;
+    // the query rows of a block are requested one block ahead: the first before the key side is staged (its latency hides behind the staging's),
+    // the next at the top of the current block's arithmetic
+    uint4 qn[G::KS];
+    auto request_q = [&](int qb) {
+        const int rq = qb * 16 + fr;
+#pragma unroll
+        for (int ks = 0; ks < G::KS; ++ks)
+            qn[ks] = rq < S ? ldg16(base + q_off + (size_t)rq * ld + (ks * 4 + kg) * G::PER) : make_uint4(0, 0, 0, 0);
+    };
+    if (wave < nqb) request_q(wave);
+    {
+        Stager<T, DH, SP, NTHR> sk, sv;
+        sk.request(base + k_off, ld, S, tid);
+        sv.request(base + v_off, ld, S, tid);
+        sk.commit(Kr, tid);
+        sv.commit(Vimg, tid);
     }
     __syncthreads();
-    const int nqb = (S + 15) >> 4;
     for (int qb = wave; qb < nqb; qb += NWAVE) {
         const int rq = qb * 16 + fr;
         const bool valid = rq < S;
         uint4 qf[G::KS];
 #pragma unroll
-        for (int ks = 0; ks < G::KS; ++ks)
-            qf[ks] = (valid && !(dr.abl & 2)) ? ldg16(base + q_off + (size_t)rq * ld + (ks * 4 + kg) * G::PER) : make_uint4(0, 0, 0, 0);
+        for (int ks = 0; ks < G::KS; ++ks) qf[ks] = qn[ks];
+        if (qb + NWAVE < nqb) request_q(qb + NWAVE);
         f32x4_t s[NKT];
         scores_t<T, DH, NKT>(Kr, qf, s, S, fr, kg);
         float m = -INFINITY;
@@ -224,41 +292,56 @@ __global__ void __launch_bounds__(WG<NKT>::NTHR, 4) attn_long_fwd_kernel(const T
 #pragma unroll
             for (int r = 0; r < 4; ++r) m = fmaxf(m, s[kt][r]);
         m = red4(m, true);                                   // max of the RAW scores (scale > 0)
-        // p = exp(scale (s - m)) = exp2(s c - m c), c = scale log2(e): one fma + v_exp_f32 per element; the 1 / row-sum factor is
+        // p = exp(scale (s - m)) = exp2(s c - m c), c = scale log2(e): one (packed) fma + v_exp_f32 per element; the 1 / row-sum factor is
         // applied to the 16 output values of the lane instead of its 4 NKT probabilities
         const float c2 = scale * 1.44269504088896f, mc = m * c2;
-        float l = 0.f;
+        const f32x4_t c2v = {c2, c2, c2, c2}, mcv = {-mc, -mc, -mc, -mc};
+        f32x4_t lv = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int kt = 0; kt < NKT; ++kt)
+        for (int kt = 0; kt < NKT; ++kt) {
+            f32x4_t t = __builtin_elementwise_fma(s[kt], c2v, mcv);
 #pragma unroll
-            for (int r = 0; r < 4; ++r) { if (!(dr.abl & 8)) s[kt][r] = __builtin_amdgcn_exp2f(fmaf(s[kt][r], c2, -mc)); l += s[kt][r]; }
-        l = red4(l, false);
-        float inv = 1.f / l;
+            for (int r = 0; r < 4; ++r) t[r] = __builtin_amdgcn_exp2f(t[r]);
+            s[kt] = t;
+            lv += t;
+        }
+        const float l = red4((lv[0] + lv[1]) + (lv[2] + lv[3]), false);           // >= 1: the row maximum contributes exp2(0)
+        float inv = sizeof(T) == 2 ? __builtin_amdgcn_rcpf(l) : 1.f / l;
         if (dr.thr16) {                                       // P' = dropout(P): the 4 keys of a lane's tile column share one hash
             inv *= dr.keep_scale;
+            const int ol = opaque_lane(lane), orq = qb * 16 + (ol & 15), okg = ol >> 4;
 #pragma unroll
             for (int kt = 0; kt < NKT; ++kt) {
-                const uint64_t hsh = a4r_hash64(dr.seed, dr.site, drop_idx(blockIdx.x, rq, kt * 16 + kg * 4) >> 2);
+                const uint64_t hsh = a4r_hash64(dr.seed, dr.site, drop_idx(blockIdx.x, orq, kt * 16 + okg * 4) >> 2);
 #pragma unroll
                 for (int r = 0; r < 4; ++r) s[kt][r] = (((uint32_t)(hsh >> (16 * r)) & 0xffffu) >= dr.thr16) ? s[kt][r] : 0.f;
             }
         }
-        if (valid && kg == 0) lse[((size_t)item * nh + h) * S + rq] = m * scale + __logf(l);
+        if (valid && kg == 0) lse[((size_t)item * nh + h) * S + rq] = m * scale + __builtin_amdgcn_logf(l) * 0.69314718055994531f;   // v_log_f32 = log2; l is a normal number
         f32x4_t o[G::ND];
 #pragma unroll
         for (int dt = 0; dt < G::ND; ++dt) o[dt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+        // O^T += V^T P^T in regions of HALF head-column tiles: the transposed V fragments of the next region are requested before the products of the
+        // current one; probabilities are packed step by step (keeping all NST chunks spilled)
+        constexpr int HALF = G::ND >= 4 ? 2 : G::ND, NR = G::ND / HALF, NREG = NST * NR;
+        uint4 vf[2][HALF], pf = make_uint4(0, 0, 0, 0);
 #pragma unroll
-        for (int st = 0; st < NST; ++st) {                   // probabilities are packed step by step (keeping all NST chunks spilled)
-            const uint4 pf = pack_step<T, NKT>(s, st);
+        for (int j = 0; j < HALF; ++j) vf[0][j] = frag_T<T, DH>(Vimg, SPT, j * 16, 0, lane);
 #pragma unroll
-            for (int dt = 0; dt < G::ND; ++dt) Mma<T>::mma(frag_T<T, DH>(Vimg, SPT, dt * 16, st, lane), pf, o[dt]);
+        for (int i = 0; i < NREG; ++i) {
+            const int st = i / NR, hr = i % NR;
+            if (hr == 0) pf = pack_step<T, NKT>(s, st);
+            if (i + 1 < NREG) {
+#pragma unroll
+                for (int j = 0; j < HALF; ++j) vf[(i + 1) & 1][j] = frag_T<T, DH>(Vimg, SPT, (((i + 1) % NR) * HALF + j) * 16, (i + 1) / NR, lane);
+            }
+#pragma unroll
+            for (int j = 0; j < HALF; ++j) Mma<T>::mma(vf[i & 1][j], pf, o[hr * HALF + j]);
             __builtin_amdgcn_sched_barrier(0);
         }
 #pragma unroll
-        for (int dt = 0; dt < G::ND; ++dt)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) o[dt][r] *= inv;
-        if (!(dr.abl & 1)) store_block16<T, DH>(stg, o, ctx + ((size_t)item * S + qb * 16) * ldo + h * DH, ldo, S - qb * 16, lane);
+        for (int dt = 0; dt < G::ND; ++dt) o[dt] *= f32x4_t{inv, inv, inv, inv};
+        store_block16<T, DH>(stg, o, ctx + ((size_t)item * S + qb * 16) * ldo + h * DH, ldo, S - qb * 16, lane);
     }
 }
 
@@ -279,72 +362,125 @@ __global__ void __launch_bounds__(WG<NKT>::NTHR, 4) attn_long_dq_kernel(const T*
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, fr = lane & 15, kg = lane >> 4;
     char* stg = smem + lds_main_dq<T, DH, NKT>() + wave * STG<T, DH>::BYTES;
     const T* base = qkv + (size_t)item * S * ld + h * DH;
-    stage_rows<T, DH>(Kr, base + k_off, ld, S, SP, tid, NTHR);
-    stage_rows<T, DH>(Vr, base + v_off, ld, S, SP, tid, NTHR);
-    __syncthreads();
     const int nqb = (S + 15) >> 4;
+    // the q / dO / O rows and the lse of a wave's FIRST block are requested before the key side is staged (their latency runs under the staging's);
+    // a second set for the next block does not fit the registers of the head-width-64 instantiations: with it they spilled inside the key loop, and a
+    // scratch reload's vmcnt(0) waits for every prefetch in flight
+    uint4 qn[G::KS], don[G::KS], on[G::KS];
+    float lqn = 0.f;
+    auto request_rows = [&](int qb) {
+        const int ol = opaque_lane(lane), rq = qb * 16 + (ol & 15), okg = ol >> 4;      // (addresses rebuilt per call, not held across the loops)
+        const bool valid = rq < S;
+        const size_t grow = (size_t)item * S + rq;
+#pragma unroll
+        for (int ks = 0; ks < G::KS; ++ks) {
+            qn[ks] = valid ? ldg16(base + q_off + (size_t)rq * ld + (ks * 4 + okg) * G::PER) : make_uint4(0, 0, 0, 0);
+            don[ks] = valid ? ldg16(dctx + grow * ldo + h * DH + (ks * 4 + okg) * G::PER) : make_uint4(0, 0, 0, 0);
+            on[ks] = valid ? ldg16(octx + grow * ldo + h * DH + (ks * 4 + okg) * G::PER) : make_uint4(0, 0, 0, 0);
+        }
+        lqn = valid ? lse[((size_t)item * nh + h) * S + rq] : 0.f;
+    };
+    if (wave < nqb) request_rows(wave);
+    {
+        Stager<T, DH, SP, NTHR> sk, sv;
+        sk.request(base + k_off, ld, S, tid);
+        sv.request(base + v_off, ld, S, tid);
+        sk.commit(Kr, tid);
+        sv.commit(Vr, tid);
+    }
+    __syncthreads();
+    const float c2 = scale * 1.44269504088896f;
+    const f32x4_t c2v = {c2, c2, c2, c2};
     for (int qb = wave; qb < nqb; qb += NWAVE) {
         const int rq = qb * 16 + fr;
         const bool valid = rq < S;
-        const size_t grow = (size_t)item * S + rq;
-        uint4 qf[G::KS], dof[G::KS];
+        if (qb != wave) request_rows(qb);
+        uint4 qf[G::KS], dof[G::KS], of[G::KS];
 #pragma unroll
-        for (int ks = 0; ks < G::KS; ++ks) {
-            qf[ks] = valid ? ldg16(base + q_off + (size_t)rq * ld + (ks * 4 + kg) * G::PER) : make_uint4(0, 0, 0, 0);
-            dof[ks] = valid ? ldg16(dctx + grow * ldo + h * DH + (ks * 4 + kg) * G::PER) : make_uint4(0, 0, 0, 0);
-        }
-        const float c2 = scale * 1.44269504088896f;
-        const float lq2 = (valid ? lse[((size_t)item * nh + h) * S + rq] : 0.f) * 1.44269504088896f;
+        for (int ks = 0; ks < G::KS; ++ks) { qf[ks] = qn[ks]; dof[ks] = don[ks]; of[ks] = on[ks]; }
+        const float lq2 = lqn * 1.44269504088896f;
         // delta = sum_k P' dP' = dO . O (the forward output, dropout included): one dot product per query instead of a pass over all
         // key tiles, so P, dP and dS are produced and consumed one chunk step (32 / 16 keys) at a time and never held for the whole row
         float dsum = 0.f;
 #pragma unroll
         for (int ks = 0; ks < G::KS; ++ks) {
-            const uint4 of = valid ? ldg16(octx + grow * ldo + h * DH + (ks * 4 + kg) * G::PER) : make_uint4(0, 0, 0, 0);
             float a8[G::PER], b8[G::PER];
-            Elem<T>::unpack(of, a8);
+            Elem<T>::unpack(of[ks], a8);
             Elem<T>::unpack(dof[ks], b8);
 #pragma unroll
             for (int e = 0; e < G::PER; ++e) dsum += a8[e] * b8[e];
         }
         dsum = red4(dsum, false);
         if (valid && kg == 0) delta[((size_t)item * nh + h) * S + rq] = dsum;
+        const f32x4_t lqv = {-lq2, -lq2, -lq2, -lq2}, dsv = {dsum, dsum, dsum, dsum};
+        const int lim = S - kg * 4;
         f32x4_t o[G::ND];
 #pragma unroll
         for (int dt = 0; dt < G::ND; ++dt) o[dt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+        // per key tile: S^T and dP^T (row fragments of K and V), then the element-wise stage; the next tile's fragments are requested between the
+        // two (and the transposed K fragments of the step's dQ product before its first tile), so the LDS latency runs under vector work
+        uint4 rk[G::KS], rv[G::KS];
+#pragma unroll
+        for (int ks = 0; ks < G::KS; ++ks) { rk[ks] = frag_rows<T, DH>(Kr, fr, ks, kg); rv[ks] = frag_rows<T, DH>(Vr, fr, ks, kg); }
 #pragma unroll
         for (int st = 0; st < NST; ++st) {
             f32x4_t ds[G::TPS];
+            constexpr int HALF = G::ND >= 4 ? 2 : G::ND;
+            uint4 tf[2][HALF];                                  // transposed K fragments, two slots of HALF head-column tiles
 #pragma unroll
             for (int t = 0; t < G::TPS; ++t) {
                 const int kt = st * G::TPS + t;
                 f32x4_t sc = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                 for (int ks = 0; ks < G::KS; ++ks) {
-                    Mma<T>::mma(frag_rows<T, DH>(Kr, kt * 16 + fr, ks, kg), qf[ks], sc);
-                    Mma<T>::mma(frag_rows<T, DH>(Vr, kt * 16 + fr, ks, kg), dof[ks], dp);
+                    Mma<T>::mma(rk[ks], qf[ks], sc);
+                    Mma<T>::mma(rv[ks], dof[ks], dp);
                 }
-                uint64_t hsh = 0;
-                if (dr.thr16) hsh = a4r_hash64(dr.seed, dr.site, drop_idx(blockIdx.x, rq, kt * 16 + kg * 4) >> 2);
-                const bool partial = kt * 16 + 16 > S;                    // wave-uniform
+                __builtin_amdgcn_sched_barrier(0);
+                if (kt + 1 < NKT) {
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    float pv = __builtin_amdgcn_exp2f(fmaf(sc[r], c2, -lq2));          // P = exp(scale s - lse)
-                    if (partial) pv = (kt * 16 + kg * 4 + r < S) ? pv : 0.f;
-                    float dpr = dp[r];
-                    if (dr.thr16) dpr = (((uint32_t)(hsh >> (16 * r)) & 0xffffu) >= dr.thr16) ? dpr * dr.keep_scale : 0.f;
-                    ds[t][r] = pv * (dpr - dsum);                                      // (x scale: applied to the 16 outputs of the lane)
+                    for (int ks = 0; ks < G::KS; ++ks) {
+                        rk[ks] = frag_rows<T, DH>(Kr, (kt + 1) * 16 + fr, ks, kg);
+                        rv[ks] = frag_rows<T, DH>(Vr, (kt + 1) * 16 + fr, ks, kg);
+                    }
                 }
+                if (t == G::TPS - 1) {
+#pragma unroll
+                    for (int j = 0; j < HALF; ++j) tf[0][j] = frag_T<T, DH>(Kimg, SPT, j * 16, st, lane);
+                }
+                f32x4_t pv = __builtin_elementwise_fma(sc, c2v, lqv);                   // P = exp(scale s - lse)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) pv[r] = __builtin_amdgcn_exp2f(pv[r]);
+                if (kt >= kt_partial_lo<NKT>() && kt * 16 + 16 > S) {                    // wave-uniform: the last one or two tiles
+                    asm volatile("" ::: "memory");
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) pv[r] = (kt * 16 + r < lim) ? pv[r] : 0.f;
+                }
+                if (dr.thr16) {
+                    const int ol = opaque_lane(lane);
+                    const uint64_t hsh = a4r_hash64(dr.seed, dr.site, drop_idx(blockIdx.x, qb * 16 + (ol & 15), kt * 16 + (ol >> 4) * 4) >> 2);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) dp[r] = (((uint32_t)(hsh >> (16 * r)) & 0xffffu) >= dr.thr16) ? dp[r] * dr.keep_scale : 0.f;
+                }
+                ds[t] = pv * (dp - dsv);                                               // (x scale: applied to the 16 outputs of the lane)
+                __builtin_amdgcn_sched_barrier(0);
             }
             const uint4 dsf = pack_step<T, G::TPS>(ds, 0);
+            if constexpr (G::ND > HALF) {
 #pragma unroll
-            for (int dt = 0; dt < G::ND; ++dt) Mma<T>::mma(frag_T<T, DH>(Kimg, SPT, dt * 16, st, lane), dsf, o[dt]);
+                for (int j = 0; j < HALF; ++j) tf[1][j] = frag_T<T, DH>(Kimg, SPT, (HALF + j) * 16, st, lane);
+            }
+#pragma unroll
+            for (int j = 0; j < HALF; ++j) Mma<T>::mma(tf[0][j], dsf, o[j]);
+            if constexpr (G::ND > HALF) {
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int j = 0; j < HALF; ++j) Mma<T>::mma(tf[1][j], dsf, o[HALF + j]);
+            }
             __builtin_amdgcn_sched_barrier(0);
         }
 #pragma unroll
-        for (int dt = 0; dt < G::ND; ++dt)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) o[dt][r] *= scale;
+        for (int dt = 0; dt < G::ND; ++dt) o[dt] *= f32x4_t{scale, scale, scale, scale};
         store_block16<T, DH>(stg, o, dqkv + ((size_t)item * S + qb * 16) * ld + q_off + h * DH, ld, S - qb * 16, lane);
     }
 }
@@ -366,67 +502,130 @@ __global__ void __launch_bounds__(WG<NKT>::NTHR, 4) attn_long_dkdv_kernel(const 
     float* lse_s = reinterpret_cast<float*>(smem + 2 * SP * G::ROWB);
     float* del_s = lse_s + SP;
     const int item = blockIdx.x / nh, h = blockIdx.x % nh;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, fr = lane & 15, kg = lane >> 4;
+    const int tid = threadIdx.x, lane0 = tid & 63, wave = tid >> 6;
     char* stg = smem + lds_main_dkdv<T, DH, NKT>() + wave * STG<T, DH>::BYTES;
     const T* base = qkv + (size_t)item * S * ld + h * DH;
     const T* dob = dctx + (size_t)item * S * ldo + h * DH;
-    stage_rows<T, DH>(Qr, base + q_off, ld, S, SP, tid, NTHR);
-    stage_rows<T, DH>(Or, dob, ldo, S, SP, tid, NTHR);
-    for (int i = tid; i < SP; i += NTHR) {
-        lse_s[i] = i < S ? lse[((size_t)item * nh + h) * S + i] * 1.44269504088896f : 0.f;
-        del_s[i] = i < S ? delta[((size_t)item * nh + h) * S + i] : 0.f;
-    }
-    __syncthreads();
     const int nkt = (S + 15) >> 4;
-    const float c2 = scale * 1.44269504088896f;
-    for (int kt = wave; kt < nkt; kt += NWAVE) {
-        const int rk = kt * 16 + fr;                          // this lane's key (column of every tile below)
-        const bool kvalid = rk < S;
-        uint4 kf[G::KS], vf[G::KS];
+    // the K / V rows of a wave's first key tile are requested before the query side is staged
+    uint4 kn[G::KS], vn[G::KS];
+    auto request_kv = [&](int kt) {
+        const int ol = opaque_lane(lane0), rk = kt * 16 + (ol & 15), okg = ol >> 4;      // (addresses rebuilt per call, not held across the loops)
 #pragma unroll
         for (int ks = 0; ks < G::KS; ++ks) {
-            kf[ks] = kvalid ? ldg16(base + k_off + (size_t)rk * ld + (ks * 4 + kg) * G::PER) : make_uint4(0, 0, 0, 0);
-            vf[ks] = kvalid ? ldg16(base + v_off + (size_t)rk * ld + (ks * 4 + kg) * G::PER) : make_uint4(0, 0, 0, 0);
+            kn[ks] = rk < S ? ldg16(base + k_off + (size_t)rk * ld + (ks * 4 + okg) * G::PER) : make_uint4(0, 0, 0, 0);
+            vn[ks] = rk < S ? ldg16(base + v_off + (size_t)rk * ld + (ks * 4 + okg) * G::PER) : make_uint4(0, 0, 0, 0);
         }
+    };
+    if (wave < nkt) request_kv(wave);
+    {
+        Stager<T, DH, SP, NTHR> sq, so;
+        sq.request(base + q_off, ld, S, tid);
+        so.request(dob, ldo, S, tid);
+        static_assert(SP <= NTHR, "one row statistic per thread");
+        const bool rv = tid < S;
+        const float lv = rv ? lse[((size_t)item * nh + h) * S + tid] * 1.44269504088896f : 0.f;
+        const float dv0 = rv ? delta[((size_t)item * nh + h) * S + tid] : 0.f;
+        sq.commit(Qr, tid);
+        so.commit(Or, tid);
+        if (tid < SP) { lse_s[tid] = lv; del_s[tid] = dv0; }
+    }
+    __syncthreads();
+    const float c2 = scale * 1.44269504088896f;
+    const f32x4_t c2v = {c2, c2, c2, c2};
+    for (int kt = wave; kt < nkt; kt += NWAVE) {
+        // (lane-derived addresses are rebuilt per key tile from an opaque copy of the lane index: held across this loop they were spilled and reloaded)
+        const int lane = opaque_lane(lane0), fr = lane & 15, kg = lane >> 4;
+        if (kt != wave) request_kv(kt);
+        uint4 kf[G::KS], vf[G::KS];
+#pragma unroll
+        for (int ks = 0; ks < G::KS; ++ks) { kf[ks] = kn[ks]; vf[ks] = vn[ks]; }
         f32x4_t dk[G::ND], dv[G::ND];
 #pragma unroll
         for (int dt = 0; dt < G::ND; ++dt) { dk[dt] = f32x4_t{0.f, 0.f, 0.f, 0.f}; dv[dt] = f32x4_t{0.f, 0.f, 0.f, 0.f}; }
+        // per 16-query tile: S and dP (row fragments of Q and dO; the next tile's are requested right after the products), then the element-wise
+        // stage.  Query rows >= S need no select: their Q / dO rows, lse and delta are zero in LDS, so P = 1 meets dO = 0 and dS = 0; key columns >= S
+        // (zero K / V rows) only reach output columns that are never stored.
+        uint4 rq_[G::KS], ro[G::KS];
+#pragma unroll
+        for (int ks = 0; ks < G::KS; ++ks) { rq_[ks] = frag_rows<T, DH>(Qr, fr, ks, kg); ro[ks] = frag_rows<T, DH>(Or, fr, ks, kg); }
 #pragma unroll 1
         for (int g = 0; g < NG; ++g) {
-            f32x4_t p[G::TPS], ds[G::TPS];
+            constexpr int HALF = G::ND >= 4 ? 2 : G::ND;
+            uint4 tf[2][HALF];                                  // transposed fragments, two slots of HALF head-column tiles
+            uint32_t pw[4], dw[4];                            // the step's P and dS operand chunks, packed tile by tile
 #pragma unroll
             for (int t = 0; t < G::TPS; ++t) {
                 const int q0 = g * G::KSTEP + t * 16;         // tile rows = queries q0 + 4 kg + r, column = key rk
                 f32x4_t sc = {0.f, 0.f, 0.f, 0.f}, dpt = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                 for (int ks = 0; ks < G::KS; ++ks) {
-                    Mma<T>::mma(frag_rows<T, DH>(Qr, q0 + fr, ks, kg), kf[ks], sc);
-                    Mma<T>::mma(frag_rows<T, DH>(Or, q0 + fr, ks, kg), vf[ks], dpt);
+                    Mma<T>::mma(rq_[ks], kf[ks], sc);
+                    Mma<T>::mma(ro[ks], vf[ks], dpt);
                 }
-                const bool partial = q0 + 16 > S;                          // wave-uniform: query rows past S (lse_s = 0 there)
+                __builtin_amdgcn_sched_barrier(0);
+                {
+                    const int qn0 = q0 + 16 < SP ? q0 + 16 : 0;       // (the last tile wraps to rows that are simply not used)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int q = q0 + kg * 4 + r;
-                    float pv = __builtin_amdgcn_exp2f(fmaf(sc[r], c2, -lse_s[q]));     // lse_s holds lse log2(e)
-                    if (partial) pv = q < S ? pv : 0.f;
-                    if (!kvalid) pv = 0.f;
-                    float keepf = 1.f;                        // here the tile's 4 rows are 4 QUERIES at one key: one hash each
-                    if (dr.thr16) keepf = dropout_keep(dr.seed, dr.site, drop_idx(blockIdx.x, q, rk), dr.thr16) ? dr.keep_scale : 0.f;
-                    p[t][r] = pv * keepf;
-                    ds[t][r] = pv * (dpt[r] * keepf - del_s[q]);                       // (x scale: applied to dK at the end)
+                    for (int ks = 0; ks < G::KS; ++ks) { rq_[ks] = frag_rows<T, DH>(Qr, qn0 + fr, ks, kg); ro[ks] = frag_rows<T, DH>(Or, qn0 + fr, ks, kg); }
                 }
-            }
-            const uint4 pf = pack_step<T, G::TPS>(p, 0), dsf = pack_step<T, G::TPS>(ds, 0);
+                const f32x4_t l4 = *reinterpret_cast<const f32x4_t*>(lse_s + q0 + kg * 4), d4 = *reinterpret_cast<const f32x4_t*>(del_s + q0 + kg * 4);
+                if (t == G::TPS - 1) {
 #pragma unroll
-            for (int dt = 0; dt < G::ND; ++dt) {
-                Mma<T>::mma(frag_T<T, DH>(Oimg, SPT, dt * 16, g, lane), pf, dv[dt]);
-                Mma<T>::mma(frag_T<T, DH>(Qimg, SPT, dt * 16, g, lane), dsf, dk[dt]);
+                    for (int j = 0; j < HALF; ++j) tf[0][j] = frag_T<T, DH>(Oimg, SPT, j * 16, g, lane);
+                }
+                f32x4_t pv = __builtin_elementwise_fma(sc, c2v, -l4), dsv;               // lse_s holds lse log2(e)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) pv[r] = __builtin_amdgcn_exp2f(pv[r]);
+                if (dr.thr16) {                               // here the tile's 4 rows are 4 QUERIES at one key: one hash each
+                    const int ol = opaque_lane(lane), ork = kt * 16 + (ol & 15), okg = ol >> 4;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float keepf = dropout_keep(dr.seed, dr.site, drop_idx(blockIdx.x, q0 + okg * 4 + r, ork), dr.thr16) ? dr.keep_scale : 0.f;
+                        dsv[r] = pv[r] * (dpt[r] * keepf - d4[r]);
+                        pv[r] *= keepf;
+                    }
+                } else {
+                    dsv = pv * (dpt - d4);                                              // (x scale: applied to dK at the end)
+                }
+                if constexpr (sizeof(T) == 2) {
+                    pw[2 * t] = pack2_bf16(pv[0], pv[1]); pw[2 * t + 1] = pack2_bf16(pv[2], pv[3]);
+                    dw[2 * t] = pack2_bf16(dsv[0], dsv[1]); dw[2 * t + 1] = pack2_bf16(dsv[2], dsv[3]);
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) { pw[r] = __float_as_uint(pv[r]); dw[r] = __float_as_uint(dsv[r]); }
+                }
+                __builtin_amdgcn_sched_barrier(0);
             }
+            const uint4 pf = make_uint4(pw[0], pw[1], pw[2], pw[3]), dsf = make_uint4(dw[0], dw[1], dw[2], dw[3]);
+            // dV^T += dO^T P, dK^T += Q^T dS, HALF head-column tiles at a time: a slot is refilled as soon as its products are issued
+            if constexpr (G::ND > HALF) {
+#pragma unroll
+                for (int j = 0; j < HALF; ++j) tf[1][j] = frag_T<T, DH>(Oimg, SPT, (HALF + j) * 16, g, lane);
+            }
+#pragma unroll
+            for (int j = 0; j < HALF; ++j) Mma<T>::mma(tf[0][j], pf, dv[j]);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int j = 0; j < HALF; ++j) tf[0][j] = frag_T<T, DH>(Qimg, SPT, j * 16, g, lane);
+            if constexpr (G::ND > HALF) {
+#pragma unroll
+                for (int j = 0; j < HALF; ++j) Mma<T>::mma(tf[1][j], pf, dv[HALF + j]);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int j = 0; j < HALF; ++j) tf[1][j] = frag_T<T, DH>(Qimg, SPT, (HALF + j) * 16, g, lane);
+            }
+#pragma unroll
+            for (int j = 0; j < HALF; ++j) Mma<T>::mma(tf[0][j], dsf, dk[j]);
+            if constexpr (G::ND > HALF) {
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int j = 0; j < HALF; ++j) Mma<T>::mma(tf[1][j], dsf, dk[HALF + j]);
+            }
+            __builtin_amdgcn_sched_barrier(0);
         }
 #pragma unroll
-        for (int dt = 0; dt < G::ND; ++dt)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) dk[dt][r] *= scale;
+        for (int dt = 0; dt < G::ND; ++dt) dk[dt] *= f32x4_t{scale, scale, scale, scale};
         T* blk = dqkv + ((size_t)item * S + kt * 16) * ld + h * DH;
         store_block16<T, DH>(stg, dk, blk + k_off, ld, S - kt * 16, lane);
         store_block16<T, DH>(stg, dv, blk + v_off, ld, S - kt * 16, lane);
@@ -448,8 +647,7 @@ template <typename K> int set_lds(K kernel, size_t bytes) {
 }
 
 Drop drop_of(const a4r_attn_t* a) {
-    static const int abl = getenv("A4R_ATTN_LONG_ABL") ? atoi(getenv("A4R_ATTN_LONG_ABL")) : 0;
-    return Drop{a->drop_seed, a->drop_site, a4r_thr16(a->drop_p), a4r_keep_scale(a->drop_p), abl};
+    return Drop{a->drop_seed, a->drop_site, a4r_thr16(a->drop_p), a4r_keep_scale(a->drop_p)};
 }
 
 template <typename T, int DH, int NKT> int run_fwd(hipStream_t s, const a4r_attn_t* a, float* lse) {
