@@ -404,15 +404,21 @@ __global__ void __launch_bounds__(WG<NKT>::NTHR, 4) attn_long_dq_kernel(const T*
         float dsum = 0.f;
 #pragma unroll
         for (int ks = 0; ks < G::KS; ++ks) {
-            float a8[G::PER], b8[G::PER];
-            Elem<T>::unpack(of[ks], a8);
-            Elem<T>::unpack(dof[ks], b8);
+            if constexpr (sizeof(T) == 2) {                   // v_dot2c_f32_bf16: two exact products and the fp32 sums per instruction
+                const uint32_t a4[4] = {of[ks].x, of[ks].y, of[ks].z, of[ks].w}, b4[4] = {dof[ks].x, dof[ks].y, dof[ks].z, dof[ks].w};
 #pragma unroll
-            for (int e = 0; e < G::PER; ++e) dsum += a8[e] * b8[e];
+                for (int e = 0; e < 4; ++e) dsum = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2_raw_t, a4[e]), __builtin_bit_cast(bf16x2_raw_t, b4[e]), dsum, false);
+            } else {
+                float a8[G::PER], b8[G::PER];
+                Elem<T>::unpack(of[ks], a8);
+                Elem<T>::unpack(dof[ks], b8);
+#pragma unroll
+                for (int e = 0; e < G::PER; ++e) dsum += a8[e] * b8[e];
+            }
         }
         dsum = red4(dsum, false);
         if (valid && kg == 0) delta[((size_t)item * nh + h) * S + rq] = dsum;
-        const f32x4_t lqv = {-lq2, -lq2, -lq2, -lq2}, dsv = {dsum, dsum, dsum, dsum};
+        const f32x4_t lqv = {-lq2, -lq2, -lq2, -lq2}, ndsv = {-dsum, -dsum, -dsum, -dsum};
         const int lim = S - kg * 4;
         f32x4_t o[G::ND];
 #pragma unroll
@@ -430,7 +436,7 @@ __global__ void __launch_bounds__(WG<NKT>::NTHR, 4) attn_long_dq_kernel(const T*
 #pragma unroll
             for (int t = 0; t < G::TPS; ++t) {
                 const int kt = st * G::TPS + t;
-                f32x4_t sc = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
+                f32x4_t sc = {0.f, 0.f, 0.f, 0.f}, dp = ndsv;      // dP - delta straight from the matrix pipe: the accumulator starts at -delta
 #pragma unroll
                 for (int ks = 0; ks < G::KS; ++ks) {
                     Mma<T>::mma(rk[ks], qf[ks], sc);
@@ -460,9 +466,9 @@ __global__ void __launch_bounds__(WG<NKT>::NTHR, 4) attn_long_dq_kernel(const T*
                     const int ol = opaque_lane(lane);
                     const uint64_t hsh = a4r_hash64(dr.seed, dr.site, drop_idx(blockIdx.x, qb * 16 + (ol & 15), kt * 16 + (ol >> 4) * 4) >> 2);
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) dp[r] = (((uint32_t)(hsh >> (16 * r)) & 0xffffu) >= dr.thr16) ? dp[r] * dr.keep_scale : 0.f;
+                    for (int r = 0; r < 4; ++r) dp[r] = ((((uint32_t)(hsh >> (16 * r)) & 0xffffu) >= dr.thr16) ? (dp[r] + dsum) * dr.keep_scale : 0.f) - dsum;
                 }
-                ds[t] = pv * (dp - dsv);                                               // (x scale: applied to the 16 outputs of the lane)
+                ds[t] = pv * dp;                                                       // (x scale: applied to the 16 outputs of the lane)
                 __builtin_amdgcn_sched_barrier(0);
             }
             const uint4 dsf = pack_step<T, G::TPS>(ds, 0);
@@ -524,8 +530,8 @@ __global__ void __launch_bounds__(WG<NKT>::NTHR, 4) attn_long_dkdv_kernel(const 
         so.request(dob, ldo, S, tid);
         static_assert(SP <= NTHR, "one row statistic per thread");
         const bool rv = tid < S;
-        const float lv = rv ? lse[((size_t)item * nh + h) * S + tid] * 1.44269504088896f : 0.f;
-        const float dv0 = rv ? delta[((size_t)item * nh + h) * S + tid] : 0.f;
+        const float lv = rv ? lse[((size_t)item * nh + h) * S + tid] * -1.44269504088896f : 0.f;
+        const float dv0 = rv ? -delta[((size_t)item * nh + h) * S + tid] : 0.f;
         sq.commit(Qr, tid);
         so.commit(Or, tid);
         if (tid < SP) { lse_s[tid] = lv; del_s[tid] = dv0; }
@@ -557,7 +563,9 @@ __global__ void __launch_bounds__(WG<NKT>::NTHR, 4) attn_long_dkdv_kernel(const 
 #pragma unroll
             for (int t = 0; t < G::TPS; ++t) {
                 const int q0 = g * G::KSTEP + t * 16;         // tile rows = queries q0 + 4 kg + r, column = key rk
-                f32x4_t sc = {0.f, 0.f, 0.f, 0.f}, dpt = {0.f, 0.f, 0.f, 0.f};
+                // (del_s holds -delta: dP - delta comes straight from the matrix pipe, the accumulator starts there; lse_s holds -lse log2(e))
+                const f32x4_t l4 = *reinterpret_cast<const f32x4_t*>(lse_s + q0 + kg * 4), d4 = *reinterpret_cast<const f32x4_t*>(del_s + q0 + kg * 4);
+                f32x4_t sc = {0.f, 0.f, 0.f, 0.f}, dpt = d4;
 #pragma unroll
                 for (int ks = 0; ks < G::KS; ++ks) {
                     Mma<T>::mma(rq_[ks], kf[ks], sc);
@@ -569,12 +577,11 @@ __global__ void __launch_bounds__(WG<NKT>::NTHR, 4) attn_long_dkdv_kernel(const 
 #pragma unroll
                     for (int ks = 0; ks < G::KS; ++ks) { rq_[ks] = frag_rows<T, DH>(Qr, qn0 + fr, ks, kg); ro[ks] = frag_rows<T, DH>(Or, qn0 + fr, ks, kg); }
                 }
-                const f32x4_t l4 = *reinterpret_cast<const f32x4_t*>(lse_s + q0 + kg * 4), d4 = *reinterpret_cast<const f32x4_t*>(del_s + q0 + kg * 4);
                 if (t == G::TPS - 1) {
 #pragma unroll
                     for (int j = 0; j < HALF; ++j) tf[0][j] = frag_T<T, DH>(Oimg, SPT, j * 16, g, lane);
                 }
-                f32x4_t pv = __builtin_elementwise_fma(sc, c2v, -l4), dsv;               // lse_s holds lse log2(e)
+                f32x4_t pv = __builtin_elementwise_fma(sc, c2v, l4), dsv;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) pv[r] = __builtin_amdgcn_exp2f(pv[r]);
                 if (dr.thr16) {                               // here the tile's 4 rows are 4 QUERIES at one key: one hash each
@@ -582,11 +589,11 @@ __global__ void __launch_bounds__(WG<NKT>::NTHR, 4) attn_long_dkdv_kernel(const 
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         const float keepf = dropout_keep(dr.seed, dr.site, drop_idx(blockIdx.x, q0 + okg * 4 + r, ork), dr.thr16) ? dr.keep_scale : 0.f;
-                        dsv[r] = pv[r] * (dpt[r] * keepf - d4[r]);
+                        dsv[r] = pv[r] * ((dpt[r] - d4[r]) * keepf + d4[r]);
                         pv[r] *= keepf;
                     }
                 } else {
-                    dsv = pv * (dpt - d4);                                              // (x scale: applied to dK at the end)
+                    dsv = pv * dpt;                                                     // (x scale: applied to dK at the end)
                 }
                 if constexpr (sizeof(T) == 2) {
                     pw[2 * t] = pack2_bf16(pv[0], pv[1]); pw[2 * t + 1] = pack2_bf16(pv[2], pv[3]);
