@@ -113,7 +113,16 @@ __global__ void __launch_bounds__(NW * 64) adapter_ln_fwd_kernel(const AdFwdArgs
     const int fr = lane & 15, kg = lane >> 4;
     const int c0 = wave * CW;
     const int cl = c0 + kg * 8;                              // + 32 s: first column of the lane's piece s
-    for (int c = tid; c < H; c += NT) { par[0][c] = p.bu[c]; par[1][c] = p.gamma[c]; par[2][c] = p.beta[c]; }
+    // the per-column parameters are REQUESTED here and written to LDS after the weight and first-tile requests below (round 4: as a plain copy loop this
+    // compiled to H / NT dependent rounds of load -> wait -> ds_write ahead of everything else the workgroup asks for)
+    constexpr int NPAR = (H + NT - 1) / NT;
+    float par_r[NPAR][3];
+#pragma unroll
+    for (int i = 0; i < NPAR; ++i) {
+        const int c = tid + i * NT;
+        const bool in = c < H;
+        par_r[i][0] = in ? p.bu[c] : 0.f; par_r[i][1] = in ? p.gamma[c] : 0.f; par_r[i][2] = in ? p.beta[c] : 0.f;
+    }
 
     // weight fragments (W side of the MFMA: a lane supplies weight row (lane & 15), 8 contraction elements at lane >> 4)
     uint4 wd[KS][4], wu[2 * KS][2];
@@ -153,6 +162,11 @@ __global__ void __launch_bounds__(NW * 64) adapter_ln_fwd_kernel(const AdFwdArgs
 #pragma unroll
         for (int s = 0; s < KS; ++s) a_cur[s] = *reinterpret_cast<const uint4*>(p.A + row * p.lda + cl + s * 32);
         A4R_AD_LOAD_O(o_cur, row)
+    }
+#pragma unroll
+    for (int i = 0; i < NPAR; ++i) {
+        const int c = tid + i * NT;
+        if (c < H) { par[0][c] = par_r[i][0]; par[1][c] = par_r[i][1]; par[2][c] = par_r[i][2]; }
     }
     A4R_LDS_BARRIER();                                       // par[] visible
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
@@ -325,10 +339,24 @@ __global__ void __launch_bounds__(NW * 64) adapter_ln_bwd_kernel(const AdBwdArgs
     const int fr = lane & 15, kg = lane >> 4;
     const int c0 = wave * CW;
     const int cl = c0 + kg * 8;
-    for (int c = tid; c < H; c += NT) par[c] = p.gamma[c];
     __shared__ __attribute__((aligned(16))) float par_fy[FY ? 2 : 1][FY ? H : 4];      // 1 / gamma, -beta / gamma
-    if constexpr (FY) {
-        for (int c = tid; c < H; c += NT) { const float ig = 1.f / p.gamma[c]; par_fy[0][c] = ig; par_fy[1][c] = -p.beta[c] * ig; }
+    {   // (all parameter requests first, then the LDS writes: as copy loops these were H / NT dependent rounds of load -> wait -> write)
+        constexpr int NPAR = (H + NT - 1) / NT;
+        float g_r[NPAR], b_r[NPAR];
+#pragma unroll
+        for (int i = 0; i < NPAR; ++i) {
+            const int c = tid + i * NT;
+            g_r[i] = c < H ? p.gamma[c] : 1.f;
+            b_r[i] = (FY && c < H) ? p.beta[c] : 0.f;
+        }
+#pragma unroll
+        for (int i = 0; i < NPAR; ++i) {
+            const int c = tid + i * NT;
+            if (c < H) {
+                par[c] = g_r[i];
+                if constexpr (FY) { const float ig = 1.f / g_r[i]; par_fy[0][c] = ig; par_fy[1][c] = -b_r[i] * ig; }
+            }
+        }
     }
 
     // dz = dv . Wu (contraction over H: WuT [64, H]) keeps its fragments in registers; dh = dzp . Wd (contraction over 64:

@@ -553,6 +553,39 @@ def test_ln_fwd_bwd(dt, H):
     close(dbias, vr.grad.sum(0), torch.float32, 'ln dbias', **tol)   # summed in fp32 before dv is rounded
 
 
+@pytest.mark.parametrize('dt', ['f32', 'bf16'])
+@pytest.mark.parametrize('M,H', [(1, 768), (4 * 2048 + 3, 768), (777, 384), (130, 1024), (4 * 2048 * 3 + 17, 64)])
+def test_ln_lean_forms_equal_general(dt, M, H):
+    """The lean LayerNorm kernels (no additive table / dropout / e4m3 output; backward without parameter gradients or a second output: what the image
+    tower's un-adapted sub-layers launch) against the general kernels on the same rows -- the general form is forced with an all-zero additive table --
+    and against torch fp32: every row count around the grid-stride loop's edges (one row, a partial last round, more than two rounds), group counts
+    that leave the second 8-element group of a lane empty (H = 384, 64), half full (768) and full (1024), with and without the residual-branch operand."""
+    from adapter4rec_amd import _lib as L
+    t = DT[dt]
+    v, dy, dres = rnd(M, H, dtype=t, seed=71, scale=2.0), rnd(M, H, dtype=t, seed=72), rnd(M, H, dtype=t, seed=73)
+    gamma, beta = rnd(H, seed=74) * 0.2 + 1, rnd(H, seed=75) * 0.1
+    zero_add = torch.zeros(1, H, device=dev())
+    y_l, y_g = torch.zeros(M, H, dtype=t, device=dev()), torch.zeros(M, H, dtype=t, device=dev())
+    st_l, st_g = torch.zeros(M, 2, device=dev()), torch.zeros(M, 2, device=dev())
+    L.ln_fwd(v, gamma, beta, 1e-6, y_l, st_l)
+    L.ln_fwd(v, gamma, beta, 1e-6, y_g, st_g, add=zero_add)
+    assert torch.equal(y_l, y_g) and torch.equal(st_l, st_g)
+    ref = torch.nn.functional.layer_norm(v.float(), (H,), gamma, beta, 1e-6)
+    close(y_l, ref, t, f'lean ln fwd M={M} H={H}', atol32=1e-4)
+    for res in (None, dres):
+        dv_l, dv_g = torch.zeros(M, H, dtype=t, device=dev()), torch.zeros(M, H, dtype=t, device=dev())
+        L.ln_bwd(dy, v, st_l, gamma, dv_l, dres=res)
+        L.ln_bwd(dy, v, st_l, gamma, dv_g, dres=res, add=zero_add)
+        if dt == 'f32':
+            torch.testing.assert_close(dv_l, dv_g, rtol=1e-5, atol=1e-5)        # same arithmetic, xhat rebuilt in the second pass
+        else:
+            torch.testing.assert_close(dv_l.float(), dv_g.float(), rtol=2 ** -7, atol=2 ** -7)
+        vr = v.float().clone().requires_grad_(True)
+        torch.nn.functional.layer_norm(vr, (H,), gamma, beta, 1e-6).backward(dy.float())
+        want = vr.grad + (res.float() if res is not None else 0)
+        close(dv_l, want, t, f'lean ln bwd M={M} H={H}', atol32=3e-4)
+
+
 def test_ln_dropout_adjoint():
     from adapter4rec_amd import _lib as L
     M, H = 128, 64
