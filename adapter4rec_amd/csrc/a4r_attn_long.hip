@@ -26,9 +26,35 @@
 #include "a4r_common.h"
 #include "../../include/a4r.h"
 
+#ifndef A4R_ATTN_W14
+#define A4R_ATTN_W14 8
+#endif
 namespace {
 
 template <typename T> A4R_DEV uint4 ldg16(const T* p) { return *reinterpret_cast<const uint4*>(p); }
+// The [S][DH] slice of one (item, head) as a raw buffer: 16-byte loads at a 32-bit byte offset (+ a scalar offset), and every access that starts past
+// the slice's last row returns ZERO in hardware -- the rows >= S of the staged images and of the last query / key block need no branch, no select and
+// no 64-bit address arithmetic (round 4: those were ~8 vector instructions and an exec-mask branch per 16-byte load).
+typedef unsigned int u32x4_raw_t __attribute__((ext_vector_type(4)));
+struct RowsView {
+    __amdgpu_buffer_rsrc_t r;
+    uint32_t ldb;                                            // row stride in bytes
+    template <typename T> static A4R_DEV RowsView make(const T* p, int ld, int S, int DH) {
+        const uint32_t ldb = (uint32_t)ld * (uint32_t)sizeof(T);
+        return RowsView{__builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(p), 0, (int)((uint32_t)(S - 1) * ldb + (uint32_t)DH * (uint32_t)sizeof(T)), 0x27000), ldb};
+    }
+    A4R_DEV uint4 load(uint32_t voff, uint32_t soff = 0) const {
+        return __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, (int)soff, 0));
+    }
+    A4R_DEV uint4 row_chunk(int row, int chunk) const { return load((uint32_t)row * ldb + (uint32_t)chunk * 16u); }
+    A4R_DEV void store(uint32_t voff, const uint4& v) const {                        // (a store that starts past the last row is dropped)
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_raw_t, v), r, (int)voff, 0, 0);
+    }
+    A4R_DEV void store8(uint32_t voff, const uint2& v) const {
+        typedef unsigned int u32x2_raw_t __attribute__((ext_vector_type(2)));
+        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2_raw_t, v), r, (int)voff, 0, 0);
+    }
+};
 // the lane index as a value the compiler cannot see through: the dropout counters are rebuilt from it INSIDE the (wave-uniform) dropout branch, so their
 // loop-invariant parts are not hoisted into registers held across the key loops of runs without dropout (round 4: those registers were the spills)
 A4R_DEV int opaque_lane(int lane) { asm volatile("" : "+v"(lane)); return lane; }
@@ -37,7 +63,7 @@ A4R_DEV int opaque_lane(int lane) { asm volatile("" : "+v"(lane)); return lane; 
 // staging and Q / dO load latency behind; with 4-wave workgroups the chip sat at 0.4 waves per SIMD (PMC).
 // (round 3: 7 waves for S = 197 -- its 13 query blocks / key tiles in two even rounds instead of 8 + 5 -- ran the ViT step 2 % SLOWER: 14 instead of
 // 16 waves per CU hide less of the staging latency than the idle second round costs)
-template <int NKT> struct WG { static constexpr int NWAVE = NKT <= 4 ? 4 : 8, NTHR = NWAVE * 64; };   // short sequences have <= 4 query blocks
+template <int NKT> struct WG { static constexpr int NWAVE = NKT <= 4 ? 4 : (NKT == 14 ? A4R_ATTN_W14 : 8), NTHR = NWAVE * 64; };   // short sequences have <= 4 query blocks
 
 template <typename T, int DH> struct Geo {
     static constexpr int PER = Elem<T>::PER16;              // elements per 16-byte chunk
@@ -65,12 +91,11 @@ template <typename T, int DH, int SP, int NTHR> struct Stager {
     using G = Geo<T, DH>;
     static constexpr int TOTAL = SP * G::CPR, NIT = (TOTAL + NTHR - 1) / NTHR;
     uint4 v[NIT];
-    A4R_DEV void request(const T* src, int ld, int S, int tid) {
+    A4R_DEV void request(const RowsView& src, int tid) {
+        static_assert(NTHR % G::CPR == 0, "a thread keeps its chunk column");
+        const uint32_t voff = (uint32_t)(tid / G::CPR) * src.ldb + (uint32_t)(tid % G::CPR) * 16u;
 #pragma unroll
-        for (int it = 0; it < NIT; ++it) {
-            const int id = tid + it * NTHR, r = id / G::CPR, c = id % G::CPR;
-            v[it] = (id < TOTAL && r < S) ? ldg16(src + (size_t)r * ld + c * G::PER) : make_uint4(0, 0, 0, 0);
-        }
+        for (int it = 0; it < NIT; ++it) v[it] = src.load(voff, (uint32_t)(it * (NTHR / G::CPR)) * src.ldb);      // (ids >= TOTAL are rows >= SP >= S: zero)
     }
     A4R_DEV void commit(char* lds, int tid) const {
 #pragma unroll
@@ -158,15 +183,15 @@ A4R_DEV float red4(float v, bool mx) {       // over the 4 lanes l, l^16, l^32, 
 // (bf16; stored straight from the accumulators -- 8 bytes per lane, 32-byte pieces of 16 rows per instruction -- the short-sequence
 // backward moved the same bytes 32 us slower, a4r_attn.hip).  fp32 accumulators are 16 bytes per lane already.
 template <typename T, int DH>
-A4R_DEV void store_block16(char* stg, const f32x4_t (&o)[Geo<T, DH>::ND], T* g0, size_t ldg, int rows_valid, int lane_) {
+A4R_DEV void store_block16(char* stg, const f32x4_t (&o)[Geo<T, DH>::ND], const RowsView& dst, int row0, int lane_) {
     using G = Geo<T, DH>;
     const int lane = opaque_lane(lane_);                     // the addresses below are rebuilt here, not kept in registers across the caller's loops
     const int fr = lane & 15, kg = lane >> 4;
     if constexpr (sizeof(T) == 4) {
-        if (fr < rows_valid) {
 #pragma unroll
-            for (int dt = 0; dt < G::ND; ++dt) store4<T>(g0 + (size_t)fr * ldg + dt * 16 + kg * 4, o[dt]);
-        }
+        for (int dt = 0; dt < G::ND; ++dt)
+            dst.store((uint32_t)(row0 + fr) * dst.ldb + (uint32_t)(dt * 16 + kg * 4) * 4u,
+                      make_uint4(__float_as_uint(o[dt][0]), __float_as_uint(o[dt][1]), __float_as_uint(o[dt][2]), __float_as_uint(o[dt][3])));
     } else {
         constexpr int ROWB = DH * 2, CPR = DH / 8;
 #pragma unroll
@@ -177,8 +202,7 @@ A4R_DEV void store_block16(char* stg, const f32x4_t (&o)[Geo<T, DH>::ND], T* g0,
 #pragma unroll
         for (int i = 0; i < 16 * CPR / 64; ++i) {
             const int id = lane + 64 * i, row = id / CPR, ch = id % CPR;
-            if (row < rows_valid)
-                *reinterpret_cast<uint4*>(g0 + (size_t)row * ldg + ch * 8) = *reinterpret_cast<const uint4*>(stg + row * ROWB + ((ch ^ G::swz(row)) << 4));
+            dst.store((uint32_t)(row0 + row) * dst.ldb + (uint32_t)ch * 16u, *reinterpret_cast<const uint4*>(stg + row * ROWB + ((ch ^ G::swz(row)) << 4)));
         }
         __builtin_amdgcn_wave_barrier();
     }
@@ -262,17 +286,16 @@ __global__ void __launch_bounds__(WG<NKT>::NTHR, 4) attn_long_fwd_kernel(const T
     // the query rows of a block are requested one block ahead: the first before the key side is staged (its latency hides behind the staging's),
     // the next at the top of the current block's arithmetic
     uint4 qn[G::KS];
+    const RowsView qview = RowsView::make(base + q_off, ld, S, DH), cview = RowsView::make(ctx + (size_t)item * S * ldo + h * DH, ldo, S, DH);
     auto request_q = [&](int qb) {
-        const int rq = qb * 16 + fr;
 #pragma unroll
-        for (int ks = 0; ks < G::KS; ++ks)
-            qn[ks] = rq < S ? ldg16(base + q_off + (size_t)rq * ld + (ks * 4 + kg) * G::PER) : make_uint4(0, 0, 0, 0);
+        for (int ks = 0; ks < G::KS; ++ks) qn[ks] = qview.row_chunk(qb * 16 + fr, ks * 4 + kg);
     };
     if (wave < nqb) request_q(wave);
     {
         Stager<T, DH, SP, NTHR> sk, sv;
-        sk.request(base + k_off, ld, S, tid);
-        sv.request(base + v_off, ld, S, tid);
+        sk.request(RowsView::make(base + k_off, ld, S, DH), tid);
+        sv.request(RowsView::make(base + v_off, ld, S, DH), tid);
         sk.commit(Kr, tid);
         sv.commit(Vimg, tid);
     }
@@ -341,7 +364,7 @@ __global__ void __launch_bounds__(WG<NKT>::NTHR, 4) attn_long_fwd_kernel(const T
         }
 #pragma unroll
         for (int dt = 0; dt < G::ND; ++dt) o[dt] *= f32x4_t{inv, inv, inv, inv};
-        store_block16<T, DH>(stg, o, ctx + ((size_t)item * S + qb * 16) * ldo + h * DH, ldo, S - qb * 16, lane);
+        store_block16<T, DH>(stg, o, cview, qb * 16, lane);
     }
 }
 
@@ -368,23 +391,24 @@ __global__ void __launch_bounds__(WG<NKT>::NTHR, 4) attn_long_dq_kernel(const T*
     // scratch reload's vmcnt(0) waits for every prefetch in flight
     uint4 qn[G::KS], don[G::KS], on[G::KS];
     float lqn = 0.f;
+    const RowsView qview = RowsView::make(base + q_off, ld, S, DH), doview = RowsView::make(dctx + (size_t)item * S * ldo + h * DH, ldo, S, DH),
+                   oview = RowsView::make(octx + (size_t)item * S * ldo + h * DH, ldo, S, DH),
+                   dqview = RowsView::make(dqkv + (size_t)item * S * ld + q_off + h * DH, ld, S, DH);
     auto request_rows = [&](int qb) {
-        const int ol = opaque_lane(lane), rq = qb * 16 + (ol & 15), okg = ol >> 4;      // (addresses rebuilt per call, not held across the loops)
-        const bool valid = rq < S;
-        const size_t grow = (size_t)item * S + rq;
+        const int ol = opaque_lane(lane), rq = qb * 16 + (ol & 15), okg = ol >> 4;      // (offsets rebuilt per call, not held across the loops)
 #pragma unroll
         for (int ks = 0; ks < G::KS; ++ks) {
-            qn[ks] = valid ? ldg16(base + q_off + (size_t)rq * ld + (ks * 4 + okg) * G::PER) : make_uint4(0, 0, 0, 0);
-            don[ks] = valid ? ldg16(dctx + grow * ldo + h * DH + (ks * 4 + okg) * G::PER) : make_uint4(0, 0, 0, 0);
-            on[ks] = valid ? ldg16(octx + grow * ldo + h * DH + (ks * 4 + okg) * G::PER) : make_uint4(0, 0, 0, 0);
+            qn[ks] = qview.row_chunk(rq, ks * 4 + okg);
+            don[ks] = doview.row_chunk(rq, ks * 4 + okg);
+            on[ks] = oview.row_chunk(rq, ks * 4 + okg);
         }
-        lqn = valid ? lse[((size_t)item * nh + h) * S + rq] : 0.f;
+        lqn = rq < S ? lse[((size_t)item * nh + h) * S + rq] : 0.f;
     };
     if (wave < nqb) request_rows(wave);
     {
         Stager<T, DH, SP, NTHR> sk, sv;
-        sk.request(base + k_off, ld, S, tid);
-        sv.request(base + v_off, ld, S, tid);
+        sk.request(RowsView::make(base + k_off, ld, S, DH), tid);
+        sv.request(RowsView::make(base + v_off, ld, S, DH), tid);
         sk.commit(Kr, tid);
         sv.commit(Vr, tid);
     }
@@ -487,7 +511,7 @@ __global__ void __launch_bounds__(WG<NKT>::NTHR, 4) attn_long_dq_kernel(const T*
         }
 #pragma unroll
         for (int dt = 0; dt < G::ND; ++dt) o[dt] *= f32x4_t{scale, scale, scale, scale};
-        store_block16<T, DH>(stg, o, dqkv + ((size_t)item * S + qb * 16) * ld + q_off + h * DH, ld, S - qb * 16, lane);
+        store_block16<T, DH>(stg, o, dqview, qb * 16, lane);
     }
 }
 
@@ -515,19 +539,22 @@ __global__ void __launch_bounds__(WG<NKT>::NTHR, 4) attn_long_dkdv_kernel(const 
     const int nkt = (S + 15) >> 4;
     // the K / V rows of a wave's first key tile are requested before the query side is staged
     uint4 kn[G::KS], vn[G::KS];
+    const RowsView kview = RowsView::make(base + k_off, ld, S, DH), vview = RowsView::make(base + v_off, ld, S, DH),
+                   dkview = RowsView::make(dqkv + (size_t)item * S * ld + k_off + h * DH, ld, S, DH),
+                   dvview = RowsView::make(dqkv + (size_t)item * S * ld + v_off + h * DH, ld, S, DH);
     auto request_kv = [&](int kt) {
-        const int ol = opaque_lane(lane0), rk = kt * 16 + (ol & 15), okg = ol >> 4;      // (addresses rebuilt per call, not held across the loops)
+        const int ol = opaque_lane(lane0), rk = kt * 16 + (ol & 15), okg = ol >> 4;      // (offsets rebuilt per call, not held across the loops)
 #pragma unroll
         for (int ks = 0; ks < G::KS; ++ks) {
-            kn[ks] = rk < S ? ldg16(base + k_off + (size_t)rk * ld + (ks * 4 + okg) * G::PER) : make_uint4(0, 0, 0, 0);
-            vn[ks] = rk < S ? ldg16(base + v_off + (size_t)rk * ld + (ks * 4 + okg) * G::PER) : make_uint4(0, 0, 0, 0);
+            kn[ks] = kview.row_chunk(rk, ks * 4 + okg);
+            vn[ks] = vview.row_chunk(rk, ks * 4 + okg);
         }
     };
     if (wave < nkt) request_kv(wave);
     {
         Stager<T, DH, SP, NTHR> sq, so;
-        sq.request(base + q_off, ld, S, tid);
-        so.request(dob, ldo, S, tid);
+        sq.request(RowsView::make(base + q_off, ld, S, DH), tid);
+        so.request(RowsView::make(dob, ldo, S, DH), tid);
         static_assert(SP <= NTHR, "one row statistic per thread");
         const bool rv = tid < S;
         const float lv = rv ? lse[((size_t)item * nh + h) * S + tid] * -1.44269504088896f : 0.f;
@@ -633,9 +660,8 @@ __global__ void __launch_bounds__(WG<NKT>::NTHR, 4) attn_long_dkdv_kernel(const 
         }
 #pragma unroll
         for (int dt = 0; dt < G::ND; ++dt) dk[dt] *= f32x4_t{scale, scale, scale, scale};
-        T* blk = dqkv + ((size_t)item * S + kt * 16) * ld + h * DH;
-        store_block16<T, DH>(stg, dk, blk + k_off, ld, S - kt * 16, lane);
-        store_block16<T, DH>(stg, dv, blk + v_off, ld, S - kt * 16, lane);
+        store_block16<T, DH>(stg, dk, dkview, kt * 16, lane);
+        store_block16<T, DH>(stg, dv, dvview, kt * 16, lane);
     }
 }
 
