@@ -12,7 +12,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('A4R_LIB_PATH') or os.path.join(_HERE, 'liba4r_hip.so')    # A4R_LIB_PATH: A/B builds (tools/), same C ABI
 
-ABI_VERSION = 402          # = A4R_ABI_VERSION of include/a4r.h (tests/test_abi_cpu.py compares the two)
+ABI_VERSION = 403          # = A4R_ABI_VERSION of include/a4r.h (tests/test_abi_cpu.py compares the two)
 BF16, F32, FP8 = 0, 1, 2
 ACT_NONE, ACT_RELU, ACT_GELU, ACT_GELU_TANH, ACT_LEAKY = 0, 1, 2, 3, 4
 DACT_MUL = 15
@@ -25,7 +25,7 @@ EXPORTS = [
     'a4r_version', 'a4r_gemm_nt', 'a4r_gemm_tn', 'a4r_gemm_tn2', 'a4r_colsum', 'a4r_attn_fwd', 'a4r_attn_bwd', 'a4r_embed_ln',
     'a4r_ln_fwd', 'a4r_ln_bwd', 'a4r_gather_rows', 'a4r_scatter_rows', 'a4r_act_bwd_f32', 'a4r_score_bce_fwd',
     'a4r_score_bce_bwd', 'a4r_emb_grad_add_inputs', 'a4r_take_inputs', 'a4r_adam_step', 'a4r_pack_matrices',
-    'a4r_eval_rank', 'a4r_dropout_apply', 'a4r_gemm_variant', 'a4r_gemm_tail_plan', 'a4r_gemm_tail_max', 'a4r_gemm_rows_256', 'a4r_adapter_ln_fwd', 'a4r_adapter_ln_bwd', 'a4r_ln_fwd_fp8', 'a4r_ln_fwd_sum', 'a4r_quant_rows_fp8', 'a4r_lora_merge', 'a4r_lora_merge_batch', 'a4r_phm_build', 'a4r_phm_bwd', 'a4r_unpack_add', 'a4r_memset_zero',
+    'a4r_eval_rank', 'a4r_dropout_apply', 'a4r_gemm_variant', 'a4r_gemm_tail_plan', 'a4r_gemm_tail_max', 'a4r_gemm_rows_256', 'a4r_adapter_ln_fwd', 'a4r_adapter_ln_bwd', 'a4r_ln_fwd_fp8', 'a4r_ln_fwd_sum', 'a4r_quant_rows_fp8', 'a4r_lora_merge', 'a4r_lora_merge_batch', 'a4r_lora_bwd_fused', 'a4r_lora_bwd_fused_ws_floats', 'a4r_phm_build', 'a4r_phm_bwd', 'a4r_unpack_add', 'a4r_memset_zero',
     'a4r_sasrec_block_fwd', 'a4r_sasrec_block_bwd', 'a4r_scatter_rows_fill', 'a4r_attn_long_fwd', 'a4r_attn_long_bwd', 'a4r_patchify', 'a4r_vit_assemble', 'a4r_resample_u8', 'a4r_embed_bwd', 'a4r_mae_keep_indices',
 ]
 
@@ -476,6 +476,34 @@ def lora_table(entries, device):
 def lora_merge_batch(tab):
     t, n, mx, code = tab
     _check(lib().a4r_lora_merge_batch(_stream(), _p(t), C.c_int(n), C.c_int(mx), C.c_int(code)), 'a4r_lora_merge_batch')
+
+
+def lora_bwd_fused_ok(x, M, H):
+    """the geometry a4r_lora_bwd_fused is built for (everything else keeps the separate products)"""
+    return x.dtype == torch.bfloat16 and H == 768 and M % 16 == 0
+
+
+_lora_ws = {}
+
+
+def lora_bwd_fused(x, dqa, dqb, Aa, Ab, BTa, BTb, scale_a, scale_b, dAa, dAb, dBa, dBb, dbias_a, dbias_b, M):
+    """One pass over x, dqa, dqb: dAa | dAb += dt^T x, dBa += dqa^T t_a, dBb += dqb^T t_b (unscaled), dbias_. += column sums (include/a4r.h).  The
+    weight operands are views of 8 rank rows, the outputs views into the fp32 scratch matrices the corners are flushed from."""
+    require_gpu(x, dqa, dqb, dAa, dBa)
+    H = x.shape[1]
+    assert _ld(dqa) == _ld(dqb) and _ld(Aa) == _ld(Ab) == _ld(BTa) == _ld(BTb) and _ld(dAa) == _ld(dAb) and _ld(dBa) == _ld(dBb)
+    ldbias = 0
+    for bvec in (dbias_a, dbias_b):
+        if bvec is not None:
+            assert bvec.dtype == torch.float32 and bvec.dim() == 1
+            ldbias = bvec.stride(0)
+    ws = _lora_ws.get(x.device)                      # the workgroups' column sums before their reduction: one buffer per device (stream-ordered reuse)
+    if ws is None:
+        ws = _lora_ws[x.device] = torch.empty(int(lib().a4r_lora_bwd_fused_ws_floats(C.c_int(H))), dtype=torch.float32, device=x.device)
+    _check(lib().a4r_lora_bwd_fused(_stream(), _p(x), C.c_int(_ld(x)), _p(dqa), _p(dqb), C.c_int(_ld(dqa)), _p(Aa), _p(Ab), _p(BTa), _p(BTb),
+                                    C.c_int(_ld(Aa)), C.c_float(scale_a), C.c_float(scale_b), _p(dAa), _p(dAb), C.c_int(_ld(dAa)), _p(dBa), _p(dBb),
+                                    C.c_int(_ld(dBa)), _p(dbias_a), _p(dbias_b), C.c_int(ldbias), C.c_int(M), C.c_int(H), C.c_int(_dt(x)),
+                                    _p(ws), C.c_int64(ws.numel())), 'a4r_lora_bwd_fused')
 
 
 def desc_table(entries, device):

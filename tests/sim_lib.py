@@ -408,6 +408,27 @@ def lora_merge_batch(tab):
         lora_merge(W, A, B, s, dst, dstT, r)
 
 
+def lora_bwd_fused_ok(x, M, H):
+    return x.dtype == torch.bfloat16 and H == 768 and M % 16 == 0
+
+
+def lora_bwd_fused(x, dqa, dqb, Aa, Ab, BTa, BTb, scale_a, scale_b, dAa, dAb, dBa, dBb, dbias_a, dbias_b, M):
+    """include/a4r.h: t and dt rounded to the element type between the two stages"""
+    xf, qa, qb = x[:M].float(), dqa[:M].float(), dqb[:M].float()
+    A = torch.cat([Aa[:8].float(), Ab[:8].float()], 0)                     # [16, H]
+    t = (xf @ A.t()).to(x.dtype).float()                                   # [M, 16]
+    dt = torch.cat([(qa @ BTa[:8].float().t()) * scale_a, (qb @ BTb[:8].float().t()) * scale_b], 1).to(x.dtype).float()
+    dA = dt.t() @ xf                                                       # [16, H]
+    dAa[:8] += dA[:8]
+    dAb[:8] += dA[8:]
+    dBa[:, :8] += qa.t() @ t[:, :8]
+    dBb[:, :8] += qb.t() @ t[:, 8:]
+    if dbias_a is not None:
+        dbias_a += qa.sum(0)
+    if dbias_b is not None:
+        dbias_b += qb.sum(0)
+
+
 def _phm_E(params, d):
     n, ip, oq = d.n, d.in_f // d.n, d.out_f // d.n
     rule = params[d.rule_off:d.rule_off + n ** 3].view(n, n, n)
