@@ -1,0 +1,24 @@
+# the round's final artifact set (gpurun_out/r04_q_*): copy what is cited to profiles/
+TAG=${1:-r04_q}
+bash tools/profile_step.sh $TAG pmc bert_houlsby bf16 > /dev/null 2>&1
+cp gpurun_out/${TAG}_pmc_hbm_traffic.json profiles/ 2>/dev/null      # bench.py reads the newest traffic file for its roofline.traffic
+python bench.py > gpurun_out/${TAG}_bench_full.json 2> gpurun_out/${TAG}_bench_full.err
+for wl in "bert_houlsby fp8" "roberta_pfeiffer_cpc bf16" "roberta_pfeiffer_cpc fp8" "vit_lora bf16" "vit_lora fp8" "mae_compacter bf16" "mae_compacter fp8"; do
+  set -- $wl
+  sfx=""; [ "$2" = "fp8" ] && sfx="_fp8"
+  python bench.py --steps 60 --warmup 15 --no-cpu-baseline --workload $1 --dtype $2 > gpurun_out/${TAG}_bench_$1$sfx.json 2>/dev/null
+done
+bash tools/profile_step.sh ${TAG}_vit nopmc vit_lora bf16 > /dev/null 2>&1
+bash tools/profile_step.sh ${TAG}_mae nopmc mae_compacter fp8 > /dev/null 2>&1
+python tools/attn_bench.py > gpurun_out/${TAG}_kernels.txt 2>&1
+python tools/ln_bench.py >> gpurun_out/${TAG}_kernels.txt 2>&1
+python tools/lora_bench.py >> gpurun_out/${TAG}_kernels.txt 2>&1
+python tools/adapter_bench.py 2>&1 | tail -4 >> gpurun_out/${TAG}_kernels.txt
+tail -c 1500 gpurun_out/${TAG}_bench_full.json
+for f in gpurun_out/${TAG}_bench_*.json; do python - $f <<'EOP'
+import json,sys
+try:
+    d=json.loads(open(sys.argv[1]).read().strip().splitlines()[-1]); print(sys.argv[1].split('/')[-1], d['ms_per_step'], d['value'])
+except Exception as e: print(sys.argv[1], 'ERR', e)
+EOP
+done
