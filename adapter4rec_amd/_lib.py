@@ -12,7 +12,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('A4R_LIB_PATH') or os.path.join(_HERE, 'liba4r_hip.so')    # A4R_LIB_PATH: A/B builds (tools/), same C ABI
 
-ABI_VERSION = 403          # = A4R_ABI_VERSION of include/a4r.h (tests/test_abi_cpu.py compares the two)
+ABI_VERSION = 404          # = A4R_ABI_VERSION of include/a4r.h (tests/test_abi_cpu.py compares the two)
 BF16, F32, FP8 = 0, 1, 2
 ACT_NONE, ACT_RELU, ACT_GELU, ACT_GELU_TANH, ACT_LEAKY = 0, 1, 2, 3, 4
 DACT_MUL = 15
@@ -486,9 +486,10 @@ def lora_bwd_fused_ok(x, M, H):
 _lora_ws = {}
 
 
-def lora_bwd_fused(x, dqa, dqb, Aa, Ab, BTa, BTb, scale_a, scale_b, dAa, dAb, dBa, dBb, dbias_a, dbias_b, M):
+def lora_bwd_fused(x, dqa, dqb, Aa, Ab, BTa, BTb, scale_a, scale_b, dAa, dAb, dBa, dBb, dbias_a, dbias_b, M, rank_rows=8):
     """One pass over x, dqa, dqb: dAa | dAb += dt^T x, dBa += dqa^T t_a, dBb += dqb^T t_b (unscaled), dbias_. += column sums (include/a4r.h).  The
-    weight operands are views of 8 rank rows, the outputs views into the fp32 scratch matrices the corners are flushed from."""
+    weight operands are views of rank_rows (8, or 16 for ranks 9 - 15) rank rows, the outputs views into the fp32 scratch matrices the corners are
+    flushed from."""
     require_gpu(x, dqa, dqb, dAa, dBa)
     H = x.shape[1]
     assert _ld(dqa) == _ld(dqb) and _ld(Aa) == _ld(Ab) == _ld(BTa) == _ld(BTb) and _ld(dAa) == _ld(dAb) and _ld(dBa) == _ld(dBb)
@@ -503,7 +504,7 @@ def lora_bwd_fused(x, dqa, dqb, Aa, Ab, BTa, BTb, scale_a, scale_b, dAa, dAb, dB
     _check(lib().a4r_lora_bwd_fused(_stream(), _p(x), C.c_int(_ld(x)), _p(dqa), _p(dqb), C.c_int(_ld(dqa)), _p(Aa), _p(Ab), _p(BTa), _p(BTb),
                                     C.c_int(_ld(Aa)), C.c_float(scale_a), C.c_float(scale_b), _p(dAa), _p(dAb), C.c_int(_ld(dAa)), _p(dBa), _p(dBb),
                                     C.c_int(_ld(dBa)), _p(dbias_a), _p(dbias_b), C.c_int(ldbias), C.c_int(M), C.c_int(H), C.c_int(_dt(x)),
-                                    _p(ws), C.c_int64(ws.numel())), 'a4r_lora_bwd_fused')
+                                    C.c_int(rank_rows), _p(ws), C.c_int64(ws.numel())), 'a4r_lora_bwd_fused')
 
 
 def desc_table(entries, device):

@@ -1195,13 +1195,14 @@ class TransRecEngine:
         H, T = blk.H, blk.T
         a, b = blk.lora
         dqa, dqb = dqkv[:, a.slot * H:(a.slot + 1) * H], dqkv[:, b.slot * H:(b.slot + 1) * H]
-        if self.LORA_FUSED and a.r <= 8 and b.r <= 8 and L.lora_bwd_fused_ok(x, M, H):
-            # round 4: all of the below in ONE pass over x, dq, dv (a4r_lora_bwd_fused: 306 MB instead of 612 MB per layer at the image tower's rows)
-            oc = _Lora.ONES_COL
-            L.lora_bwd_fused(x, dqa, dqb, sh['A'][a.off:a.off + 8], sh['A'][b.off:b.off + 8], a.BT[a.off:a.off + 8], b.BT[b.off:b.off + 8],
-                             a.scaling, b.scaling, sh['s_A'][a.off:a.off + 8], sh['s_A'][b.off:b.off + 8],
-                             a.s_B[:, a.off:a.off + 8], b.s_B[:, b.off:b.off + 8],
-                             a.s_B[:, oc] if a.g_bias is not None else None, b.s_B[:, oc] if b.g_bias is not None else None, M)
+        if self.LORA_FUSED and a.r <= 15 and b.r <= 15 and L.lora_bwd_fused_ok(x, M, H):
+            # round 4: all of the below in ONE pass over x, dq, dv (a4r_lora_bwd_fused: 306 MB instead of 612 MB per layer at the image tower's rows);
+            # ranks <= 8 share one rank tile, 9 - 15 (CV/run_adapter.py's hard-coded 12) get one each
+            oc, R = _Lora.ONES_COL, (8 if a.r <= 8 and b.r <= 8 else 16)
+            L.lora_bwd_fused(x, dqa, dqb, sh['A'][a.off:a.off + R], sh['A'][b.off:b.off + R], a.BT[a.off:a.off + R], b.BT[b.off:b.off + R],
+                             a.scaling, b.scaling, sh['s_A'][a.off:a.off + R], sh['s_A'][b.off:b.off + R],
+                             a.s_B[:, a.off:a.off + R], b.s_B[:, b.off:b.off + R],
+                             a.s_B[:, oc] if a.g_bias is not None else None, b.s_B[:, oc] if b.g_bias is not None else None, M, rank_rows=R)
             return
         t = self._buf('lora_t', M, 64, T)
         dt = self._buf('lora_dt', M, 64, T)

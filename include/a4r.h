@@ -36,7 +36,7 @@ extern "C" {
 
 /* ABI version: bumped whenever a signature or struct below changes.  The Python binding (adapter4rec_amd/_lib.py) refuses a
  * library whose a4r_version() differs, so an A/B build made before a signature change cannot be called with shifted arguments. */
-#define A4R_ABI_VERSION 403
+#define A4R_ABI_VERSION 404
 int a4r_version(void);
 
 /* C[M,N] = epilogue(alpha * A[M,K] . B[N,K]^T): every nn.Linear on the path (HF BertSelfAttention
@@ -372,13 +372,14 @@ int a4r_lora_merge_batch(void* stream, const a4r_lora_desc_t* desc_dev, int n_de
  * qkv gradient):  t = x [Aa ; Ab]^T,  dt = (dqa BTa^T) scale_a | (dqb BTb^T) scale_b,  dAa | dAb += dt^T x  ([8, H] each, row stride lda),
  * dBa += dqa^T t[:, 0:8], dBb += dqb^T t[:, 8:16]  ([H, 8] each, row stride ldb; WITHOUT the LoRA scaling: the caller applies it),
  * dbias_a / dbias_b (optional, element stride ldbias) += the column sums of dqa / dqb.  Aa, Ab, BTa (= B_a^T), BTb: 8 rank rows of H elements each
- * (row stride ldw; rows past a LoRA's rank must be zero).  t and dt are rounded to bf16 between the two stages, as the separate launches store them.
+ * (row stride ldw; rows past a LoRA's rank must be zero).  rank_rows = 16 is the same for ranks up to 15 (the image tower's default r = 12): 16 rank
+ * rows per operand, dAa | dAb [16, H], dBa | dBb [H, 15].  t and dt are rounded to bf16 between the two stages, as the separate launches store them.
  * Two launches: the pass over the rows, then the reduction of the workgroups' column sums from the workspace `ws` into the destinations.
  * bf16, H = 768, M % 16 == 0; everything else: A4R_EINVAL (the caller keeps the separate a4r_gemm_nt / a4r_gemm_tn launches for those). */
 int a4r_lora_bwd_fused(void* stream, const void* x, int ldx, const void* dqa, const void* dqb, int lddq,
                        const void* Aa, const void* Ab, const void* BTa, const void* BTb, int ldw, float scale_a, float scale_b,
                        float* dAa, float* dAb, int lda, float* dBa, float* dBb, int ldb, float* dbias_a, float* dbias_b, int ldbias,
-                       int M, int H, int dtype, float* ws, int64_t ws_floats);
+                       int M, int H, int dtype, int rank_rows, float* ws, int64_t ws_floats);
 /* fp32 elements of the workspace `ws` above (the workgroups' column sums before their reduction; contents need not be kept between calls) */
 int a4r_lora_bwd_fused_ws_floats(int H);
 int a4r_phm_build(void* stream, const float* params, const a4r_phm_desc_t* desc_dev, int n_desc, float* eff);

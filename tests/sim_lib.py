@@ -412,17 +412,19 @@ def lora_bwd_fused_ok(x, M, H):
     return x.dtype == torch.bfloat16 and H == 768 and M % 16 == 0
 
 
-def lora_bwd_fused(x, dqa, dqb, Aa, Ab, BTa, BTb, scale_a, scale_b, dAa, dAb, dBa, dBb, dbias_a, dbias_b, M):
+def lora_bwd_fused(x, dqa, dqb, Aa, Ab, BTa, BTb, scale_a, scale_b, dAa, dAb, dBa, dBb, dbias_a, dbias_b, M, rank_rows=8):
     """include/a4r.h: t and dt rounded to the element type between the two stages"""
+    R = rank_rows
+    nb = R - (R == 16)                                                     # dB columns written (rank 15 of the wide form is the row of ones)
     xf, qa, qb = x[:M].float(), dqa[:M].float(), dqb[:M].float()
-    A = torch.cat([Aa[:8].float(), Ab[:8].float()], 0)                     # [16, H]
-    t = (xf @ A.t()).to(x.dtype).float()                                   # [M, 16]
-    dt = torch.cat([(qa @ BTa[:8].float().t()) * scale_a, (qb @ BTb[:8].float().t()) * scale_b], 1).to(x.dtype).float()
-    dA = dt.t() @ xf                                                       # [16, H]
-    dAa[:8] += dA[:8]
-    dAb[:8] += dA[8:]
-    dBa[:, :8] += qa.t() @ t[:, :8]
-    dBb[:, :8] += qb.t() @ t[:, 8:]
+    A = torch.cat([Aa[:R].float(), Ab[:R].float()], 0)                     # [2 R, H]
+    t = (xf @ A.t()).to(x.dtype).float()                                   # [M, 2 R]
+    dt = torch.cat([(qa @ BTa[:R].float().t()) * scale_a, (qb @ BTb[:R].float().t()) * scale_b], 1).to(x.dtype).float()
+    dA = dt.t() @ xf                                                       # [2 R, H]
+    dAa[:R] += dA[:R]
+    dAb[:R] += dA[R:]
+    dBa[:, :nb] += qa.t() @ t[:, :nb]
+    dBb[:, :nb] += qb.t() @ t[:, R:R + nb]
     if dbias_a is not None:
         dbias_a += qa.sum(0)
     if dbias_b is not None:

@@ -586,12 +586,13 @@ def test_ln_lean_forms_equal_general(dt, M, H):
         close(dv_l, want, t, f'lean ln bwd M={M} H={H}', atol32=3e-4)
 
 
+@pytest.mark.parametrize('R,ra,rb', [(8, 8, 5), (16, 12, 12), (16, 15, 9)])
 @pytest.mark.parametrize('M,bias', [(16, True), (16 * 257, True), (16 * 1200 + 16, False)])
-def test_lora_bwd_fused(M, bias):
+def test_lora_bwd_fused(M, bias, R, ra, rb):
     """a4r_lora_bwd_fused against its CPU restatement (tests/sim_lib.py, pinned to the five products it replaces by tests/test_lora_fused_cpu.py): one
-    tile, one tile per workgroup + 1, many tiles per workgroup; strided operands and outputs as the engine hands them over (slices of the fused qkv
-    gradient, rank rows 0 - 7 / 16 - 23 of 64-row weight operands, corners of the fp32 scratch matrices, the bias sums in a column of one of them);
-    outputs are ACCUMULATED into."""
+    tile, one tile per workgroup + 1, many tiles per workgroup; both rank-tile forms (ranks <= 8 share a tile; 9 - 15, the image tower's hard-coded
+    12, get one each); strided operands and outputs as the engine hands them over (slices of the fused qkv gradient, rank rows 0 .. / 16 .. of 64-row
+    weight operands, corners of the fp32 scratch matrices, the bias sums in a column of one of them); outputs are ACCUMULATED into."""
     from adapter4rec_amd import _lib as L
     import sim_lib as S
     H, rp, oc, T = 768, 64, 32, torch.bfloat16
@@ -599,34 +600,33 @@ def test_lora_bwd_fused(M, bias):
     dqkv = rnd(M, 3 * H, dtype=T, seed=82, scale=0.1)
     dqa, dqb = dqkv[:, :H], dqkv[:, 2 * H:]
     A, BTa, BTb = (torch.zeros(rp, H, dtype=T, device=dev()) for _ in range(3))
-    A[0:8], A[16:21] = rnd(8, H, dtype=T, seed=83, scale=0.05), rnd(5, H, dtype=T, seed=84, scale=0.05)       # ranks 8 and 5
-    BTa[0:8], BTb[16:21] = rnd(8, H, dtype=T, seed=85, scale=0.05), rnd(5, H, dtype=T, seed=86, scale=0.05)
+    A[0:ra], A[16:16 + rb] = rnd(ra, H, dtype=T, seed=83, scale=0.05), rnd(rb, H, dtype=T, seed=84, scale=0.05)
+    BTa[0:ra], BTb[16:16 + rb] = rnd(ra, H, dtype=T, seed=85, scale=0.05), rnd(rb, H, dtype=T, seed=86, scale=0.05)
     outs = []
     for lib_ in (L, S):
         sA = torch.full((rp, H), 0.5, device=dev())
         sBa, sBb = torch.full((H, rp), 0.25, device=dev()), torch.full((H, rp), -0.25, device=dev())
-        args = (x, dqa, dqb, A[0:8], A[16:24], BTa[0:8], BTb[16:24], 0.125, 2.0, sA[0:8], sA[16:24], sBa[:, 0:8], sBb[:, 16:24],
-                sBa[:, oc] if bias else None, sBb[:, oc] if bias else None, M)
-        if lib_ is L:
-            assert L.lora_bwd_fused_ok(x, M, H)
-            lib_.lora_bwd_fused(*args)
+        if lib_ is S:
+            x_, dqa_, dqb_, A_, BTa_, BTb_, sA, sBa, sBb = (v.cpu() for v in (x, dqa, dqb, A, BTa, BTb, sA, sBa, sBb))
         else:
-            cpu = [a.cpu() if torch.is_tensor(a) else a for a in args]
-            sA, sBa, sBb = sA.cpu(), sBa.cpu(), sBb.cpu()
-            cpu[9:15] = [sA[0:8], sA[16:24], sBa[:, 0:8], sBb[:, 16:24], sBa[:, oc] if bias else None, sBb[:, oc] if bias else None]
-            lib_.lora_bwd_fused(*cpu)
+            x_, dqa_, dqb_, A_, BTa_, BTb_ = x, dqa, dqb, A, BTa, BTb
+            assert L.lora_bwd_fused_ok(x, M, H)
+        lib_.lora_bwd_fused(x_, dqa_, dqb_, A_[0:R], A_[16:16 + R], BTa_[0:R], BTb_[16:16 + R], 0.125, 2.0, sA[0:R], sA[16:16 + R], sBa[:, 0:R],
+                            sBb[:, 16:16 + R], sBa[:, oc] if bias else None, sBb[:, oc] if bias else None, M, rank_rows=R)
         outs.append((sA.cpu(), sBa.cpu(), sBb.cpu()))
     (gA, gBa, gBb), (wA, wBa, wBb) = outs
     for got, want, what in ((gA, wA, 'dA'), (gBa, wBa, 'dB_q'), (gBb, wBb, 'dB_v')):
         scale = float((want - want.flatten()[0]).abs().max()) + 1e-6
         err = float((got - want).abs().max())
         assert err <= 2e-2 * scale, (what, err, scale)            # t / dt are rounded to bf16 from sums in a different order: a last-place flip moves a product by 2^-8
-    # untouched: everything outside the corners and the ones column
-    assert torch.equal(gA[8:16], torch.full((8, H), 0.5)) and torch.equal(gA[24:], torch.full((rp - 24, H), 0.5))
-    assert torch.equal(gBa[:, 8:oc], torch.full((H, oc - 8), 0.25)) and torch.equal(gBb[:, :16], torch.full((H, 16), -0.25))
+    # untouched: everything outside the two rank slots and the ones column; rank rows past a LoRA's r see zero weights: zero gradient
+    assert torch.equal(gA[32:], torch.full((rp - 32, H), 0.5)) and torch.equal(gBa[:, 16:oc], torch.full((H, oc - 16), 0.25))
+    assert torch.equal(gBb[:, :16], torch.full((H, 16), -0.25)) and torch.equal(gBb[:, oc + 1:], torch.full((H, rp - oc - 1), -0.25))
+    if R == 8:
+        assert torch.equal(gA[8:16], torch.full((8, H), 0.5)) and torch.equal(gBa[:, 8:16], torch.full((H, 8), 0.25))
     if not bias:
         assert torch.equal(gBa[:, oc], torch.full((H,), 0.25))
-    assert torch.equal(gA[21:24], torch.full((3, H), 0.5) + 0) or float((gA[21:24] - 0.5).abs().max()) < 1e-6      # rank rows past r = 5: zero weights, zero gradient
+    assert float((gA[16 + rb:16 + R] - 0.5).abs().max()) < 1e-6 if rb < R else True
 
 
 def test_ln_dropout_adjoint():

@@ -7,9 +7,13 @@ import torch
 import sim_lib as S
 
 
-def test_fused_restatement_equals_the_five_products():
+import pytest
+
+
+@pytest.mark.parametrize('r,R', [(8, 8), (12, 16), (15, 16)])
+def test_fused_restatement_equals_the_five_products(r, R):
     g = torch.Generator().manual_seed(5)
-    M, H, r, rp, oc = 256, 768, 8, 64, 32
+    M, H, rp, oc = 256, 768, 64, 32
     T = torch.bfloat16
     x = torch.randn(M, H, generator=g).to(T)
     dqkv = (torch.randn(M, 3 * H, generator=g) * 0.1).to(T)
@@ -34,7 +38,8 @@ def test_fused_restatement_equals_the_five_products():
     # the one pass
     fBa, fBb, fA = torch.zeros(H, rp), torch.zeros(H, rp), torch.zeros(rp, H)
     assert S.lora_bwd_fused_ok(x, M, H)
-    S.lora_bwd_fused(x, dqa, dqb, A[0:8], A[16:24], BTa[0:8], BTb[16:24], sa, sb, fA[0:8], fA[16:24], fBa[:, 0:8], fBb[:, 16:24], fBa[:, oc], fBb[:, oc], M)
+    S.lora_bwd_fused(x, dqa, dqb, A[0:R], A[16:16 + R], BTa[0:R], BTb[16:16 + R], sa, sb, fA[0:R], fA[16:16 + R], fBa[:, 0:R], fBb[:, 16:16 + R],
+                     fBa[:, oc], fBb[:, oc], M, rank_rows=R)
     # what the corner flush reads: the rank corners and the ones column
     torch.testing.assert_close(fA[0:r], sA[0:r], rtol=2e-2, atol=2e-3)               # (dt holds the sum of two bf16-rounded products in the five-launch form)
     torch.testing.assert_close(fA[16:16 + r], sA[16:16 + r], rtol=2e-2, atol=2e-3)
