@@ -1,5 +1,5 @@
-# the round's final artifact set (gpurun_out/r04_q_*): copy what is cited to profiles/
-TAG=${1:-r04_q}
+# the round's final artifact set (gpurun_out/r04_r_*): copy what is cited to profiles/
+TAG=${1:-r04_r}
 bash tools/profile_step.sh $TAG pmc bert_houlsby bf16 > /dev/null 2>&1
 cp gpurun_out/${TAG}_pmc_hbm_traffic.json profiles/ 2>/dev/null      # bench.py reads the newest traffic file for its roofline.traffic
 python bench.py > gpurun_out/${TAG}_bench_full.json 2> gpurun_out/${TAG}_bench_full.err
