@@ -69,24 +69,24 @@ def checksum(model):
     return tot
 
 
-def cv_args(dtype, kind):
+def cv_args(dtype, kind, lora_r=8):
     mae = kind == 'mae_compacter'
     return argparse.Namespace(
         max_seq_len=20, l2_weight=0, embedding_dim=64, num_attention_heads=2, drop_rate=0.1, transformer_block=2,
         CV_model_load='vit-mae-base' if mae else 'vit-base-patch16-224', CV_resize=224,
         cv_adapter_down_size=64, adapter_down_size=16, adapter_dropout_rate=0.1, adapter_activation='RELU',
         hypercomplex_division=4, phm_init_range=1e-4, adapter_type='compacter' if mae else 'lora',
-        is_serial='True', adding_adapter_to='all', arch='sasrec', compute_dtype=dtype, lora_r=8, lora_r_sasrec=4)
+        is_serial='True', adding_adapter_to='all', arch='sasrec', compute_dtype=dtype, lora_r=lora_r, lora_r_sasrec=4)
 
 
-def build_vit_case(kind='vit_lora', seed=7, users=1):
+def build_vit_case(kind='vit_lora', seed=7, users=1, lora_r=8):
     """configs[2] / configs[4] at the benchmarked geometry: ViT-B/16 (768 x 12, 224 x 224 images -> 197 tokens) + LoRA r = 8, or
     ViT-MAE-base (75 % masked -> 50 tokens) + Compacter; `users` users = 42 image slots each (uint8 HWC pixels)."""
     from adapter4rec_amd.cv import Model, ViTForImageClassification, ViTMAEModel
     from adapter4rec_amd.cv.inject import inject_adapters
     from adapter4rec_amd.inject import freeze_all
     torch.manual_seed(seed)
-    args = cv_args('fp32', kind)
+    args = cv_args('fp32', kind, lora_r)
     if kind == 'mae_compacter':
         net = ViTMAEModel()
     else:

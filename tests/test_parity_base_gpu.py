@@ -223,6 +223,47 @@ def test_bench_size_step_fp32_vs_oracle():
     assert g < 1e-4, (g, where)
 
 
+@pytest.mark.parametrize('r', [8, 12])
+def test_vit_lora_fused_backward_equals_separate_products(r):
+    """ViT-B/16 + LoRA at the benchmarked geometry, bf16: the step with a4r_lora_bwd_fused (one pass over x, dq, dv; r = 8: the shared rank tile,
+    r = 12 = run_adapter.py's hard-coded rank: a rank tile per LoRA) against the same step with the five separate products (engine.LORA_FUSED off):
+    the same loss (the forward is untouched), every LoRA gradient of the image tower within bf16 noise of the other path, everything else equal up to the
+    order of the kernels' fp32 atomic sums."""
+    from base_cases import build_vit_case
+    import adapter4rec_amd.engine as E
+    root, u8, mask, _ = build_vit_case('vit_lora', lora_r=r)
+    inner = getattr(root, 'model', root)
+    inner.compute_dtype = 'bf16'
+    out = {}
+    for fused in (True, False):
+        E.TransRecEngine.LORA_FUSED = fused
+        try:
+            inner.invalidate_native()
+            for p in root.parameters():
+                p.grad = None
+            root.to(DEV)
+            root.eval()
+            loss = root(u8.to(DEV), mask.to(DEV), DEV)
+            loss.backward()
+            out[fused] = (float(loss.detach()), {n: p.grad.detach().cpu().clone() for n, p in root.named_parameters() if p.requires_grad})
+        finally:
+            E.TransRecEngine.LORA_FUSED = True
+            root.cpu()
+    (lf, gf), (ls, gs) = out[True], out[False]
+    assert abs(lf - ls) <= 1e-6 * abs(ls)                # (two runs of one step differ in the order of their fp32 atomic sums)
+    worst = 0.0
+    for n in gf:
+        a, b = gf[n], gs[n]
+        if 'lora_' in n and 'cv_encoder' in n:
+            e = float((a - b).abs().max()) / (float(b.abs().max()) + 1e-12)
+            worst = max(worst, e)
+            assert e < 2e-2, (n, e)
+        else:
+            assert float((a - b).abs().max()) <= 1e-3 * (float(b.abs().max()) + 1e-12), n
+    assert any('lora_A' in n and 'cv_encoder' in n for n in gf)
+    print(f'r = {r}: fused vs separate LoRA gradients, worst max|diff| / max|g| = {worst:.2e}')
+
+
 @pytest.mark.parametrize('kind', ['vit_lora', 'mae_compacter'])
 def test_vit_base_geometry_step_vs_oracle(kind):
     """The image tower at the geometry bench.py times (tiny-geometry parity only): ViT-B/16 (768 x 12 layers x 197 tokens)
