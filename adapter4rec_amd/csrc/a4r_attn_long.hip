@@ -666,6 +666,8 @@ __global__ void __launch_bounds__(WG<NKT>::NTHR, 4) attn_long_dkdv_kernel(const 
 }
 
 int nkt_for(int S) { return S <= 32 ? 2 : S <= 64 ? 4 : S <= 128 ? 8 : S <= 224 ? 14 : 16; }
+// kt_partial_lo<NKT>() (which key tiles can reach past S) restates this map: a launch whose S does not fit its instantiation's assumption is refused
+template <int NKT> bool s_fits(int S) { return S <= NKT * 16 && S > 16 * kt_partial_lo<NKT>(); }
 
 template <typename T, int DH, int NKT> size_t lds_fwd() { return lds_main_fwd<T, DH, NKT>() + WG<NKT>::NWAVE * STG<T, DH>::BYTES; }
 template <typename T, int DH, int NKT> size_t lds_dq() { return lds_main_dq<T, DH, NKT>() + WG<NKT>::NWAVE * STG<T, DH>::BYTES; }
@@ -684,6 +686,7 @@ Drop drop_of(const a4r_attn_t* a) {
 }
 
 template <typename T, int DH, int NKT> int run_fwd(hipStream_t s, const a4r_attn_t* a, float* lse) {
+    if (!s_fits<NKT>(a->S)) return A4R_EINVAL;
     const size_t lds = lds_fwd<T, DH, NKT>();
     if (int rc = set_lds(attn_long_fwd_kernel<T, DH, NKT>, lds)) return rc;
     hipLaunchKernelGGL((attn_long_fwd_kernel<T, DH, NKT>), dim3(a->n_items * a->n_heads), dim3(WG<NKT>::NTHR), lds, s, (const T*)a->qkv, a->ld, a->q_off,
@@ -691,6 +694,7 @@ template <typename T, int DH, int NKT> int run_fwd(hipStream_t s, const a4r_attn
     return a4r_launch_status();
 }
 template <typename T, int DH, int NKT> int run_bwd(hipStream_t s, const a4r_attn_t* a, const float* lse, float* delta) {
+    if (!s_fits<NKT>(a->S)) return A4R_EINVAL;
     const size_t l1 = lds_dq<T, DH, NKT>(), l2 = lds_dkdv<T, DH, NKT>();
     if (int rc = set_lds(attn_long_dq_kernel<T, DH, NKT>, l1)) return rc;
     if (int rc = set_lds(attn_long_dkdv_kernel<T, DH, NKT>, l2)) return rc;

@@ -566,12 +566,12 @@ inline bool misaligned(const void* p) { return (reinterpret_cast<uintptr_t>(p) &
 inline int row_grid(int rows) { int g = (rows + 3) / 4; return g > 2048 ? 2048 : (g < 1 ? 1 : g); }
 // grid of a lean LayerNorm launch: never more workgroups than are resident at once (occupancy x CUs) -- every wave then walks the same number of rows
 // (+- 1) with its next row always requested, instead of a second, thin round of workgroups starting when the first has finished
-template <typename K> int resident_grid(K kernel, int rows) {
-    static int cap = 0;                                      // (one value per instantiation)
+template <auto Kernel> int resident_grid(int rows) {         // (the kernel is a template VALUE: one cached capacity per kernel, not per signature)
+    static int cap = 0;
     if (!cap) {
         int per_cu = 0, dev = 0;
         hipDeviceProp_t pr;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, 256, 0) != hipSuccess || per_cu < 1) per_cu = 4;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, Kernel, 256, 0) != hipSuccess || per_cu < 1) per_cu = 4;
         cap = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess && pr.multiProcessorCount > 0 ? pr.multiProcessorCount : 256) * per_cu;
     }
     const int g = (rows + 3) / 4;
@@ -632,9 +632,9 @@ static int ln_fwd_launch(void* stream, const void* v, int ldv, const float* add,
     const float sc = a4r_keep_scale(drop_p);
     if (!add && !thr && !y8) {                                // the lean form (the image tower's un-adapted LayerNorms)
         if (dtype == A4R_BF16)
-            hipLaunchKernelGGL(ln_fwd_lean_kernel<bf16_t>, dim3(resident_grid(ln_fwd_lean_kernel<bf16_t>, M)), dim3(256), 0, s, (const bf16_t*)v, ldv, gamma, beta, eps, (bf16_t*)y, ldy, stats, M, H);
+            hipLaunchKernelGGL(ln_fwd_lean_kernel<bf16_t>, dim3(resident_grid<ln_fwd_lean_kernel<bf16_t>>(M)), dim3(256), 0, s, (const bf16_t*)v, ldv, gamma, beta, eps, (bf16_t*)y, ldy, stats, M, H);
         else
-            hipLaunchKernelGGL(ln_fwd_lean_kernel<float>, dim3(resident_grid(ln_fwd_lean_kernel<float>, M)), dim3(256), 0, s, (const float*)v, ldv, gamma, beta, eps, (float*)y, ldy, stats, M, H);
+            hipLaunchKernelGGL(ln_fwd_lean_kernel<float>, dim3(resident_grid<ln_fwd_lean_kernel<float>>(M)), dim3(256), 0, s, (const float*)v, ldv, gamma, beta, eps, (float*)y, ldy, stats, M, H);
         return a4r_launch_status();
     }
     if (dtype == A4R_BF16)
@@ -714,10 +714,10 @@ extern "C" int a4r_ln_bwd(void* stream, const void* dy, int lddy, const void* v,
     const bool wgb = dgamma || dbeta, wdb = dbias != nullptr;
     if (!wgb && !wdb && !add && !thr && !dv2) {               // the lean form (frozen LayerNorm parameters, no dropout: the image tower under LoRA)
         if (dtype == A4R_BF16)
-            hipLaunchKernelGGL(ln_bwd_lean_kernel<bf16_t>, dim3(resident_grid(ln_bwd_lean_kernel<bf16_t>, M)), dim3(256), 0, s, (const bf16_t*)dy, lddy, (const bf16_t*)v, ldv, stats, gamma,
+            hipLaunchKernelGGL(ln_bwd_lean_kernel<bf16_t>, dim3(resident_grid<ln_bwd_lean_kernel<bf16_t>>(M)), dim3(256), 0, s, (const bf16_t*)dy, lddy, (const bf16_t*)v, ldv, stats, gamma,
                                (const bf16_t*)dres, lddres, (bf16_t*)dv, lddv, M, H);
         else
-            hipLaunchKernelGGL(ln_bwd_lean_kernel<float>, dim3(resident_grid(ln_bwd_lean_kernel<float>, M)), dim3(256), 0, s, (const float*)dy, lddy, (const float*)v, ldv, stats, gamma,
+            hipLaunchKernelGGL(ln_bwd_lean_kernel<float>, dim3(resident_grid<ln_bwd_lean_kernel<float>>(M)), dim3(256), 0, s, (const float*)dy, lddy, (const float*)v, ldv, stats, gamma,
                                (const float*)dres, lddres, (float*)dv, lddv, M, H);
         return a4r_launch_status();
     }
