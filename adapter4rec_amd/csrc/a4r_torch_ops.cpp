@@ -14,6 +14,7 @@
 //   torch.ops.a4r.score_bce_fwd / _bwd     a4r_score_bce_*        Model.forward / ModelCPC.forward head     (model/model.py:58-68,127-133)
 //   torch.ops.a4r.fused_adam_step          a4r_adam_step          optim.Adam over the flat buffers, lr groups (run.py:505-529)
 //   torch.ops.a4r.topk_rank_eval           a4r_eval_rank          eval_model's per-user rank                (data_utils/metrics.py:82-116)
+//   torch.ops.a4r.lora_bwd                 a4r_lora_bwd_fused     loralib Linear (query, value): every low-rank gradient in one pass (run_adapter.py:384-395)
 //   torch.ops.a4r.abi_version              a4r_version
 #include <ATen/ATen.h>
 #include <c10/hip/HIPStream.h>
@@ -199,6 +200,40 @@ void topk_rank_eval(const Tensor& prec, const Tensor& item_emb, const Tensor& ta
            "a4r_eval_rank");
 }
 
+// The low-rank gradients of a block's two LoRAs (query: a, value: b) from one pass over x [M, H] and the two slices dqa, dqb [M, H] of the fused qkv
+// gradient.  Aa, Ab, BTa (= B_a^T), BTb: [R, H] views (R = 8: ranks <= 8, or 16: ranks <= 15; rows past the rank zero); dAa, dAb [R, H] and dBa, dBb
+// [H, >= R] fp32, ACCUMULATED into (dB without the LoRA scaling); dbias_a / dbias_b: optional strided fp32 vectors += column sums of dqa / dqb.
+void lora_bwd(const Tensor& x, const Tensor& dqa, const Tensor& dqb, const Tensor& Aa, const Tensor& Ab, const Tensor& BTa, const Tensor& BTb, double scale_a,
+              double scale_b, Tensor dAa, Tensor dAb, Tensor dBa, Tensor dBb, const optional<Tensor>& dbias_a, const optional<Tensor>& dbias_b, Tensor ws) {
+    chk_mat(x, "x", x); chk_mat(dqa, "dqa", x); chk_mat(dqb, "dqb", x);
+    const int64_t M = x.size(0), H = x.size(1), R = Aa.size(0);
+    TORCH_CHECK(dqa.sizes() == x.sizes() && dqb.sizes() == x.sizes() && dqa.stride(0) == dqb.stride(0), "a4r::lora_bwd: dqa / dqb must be [M, H] views with one row stride");
+    for (const Tensor* w : {&Aa, &Ab, &BTa, &BTb}) {
+        chk_mat(*w, "weight operand", x);
+        TORCH_CHECK(w->scalar_type() == x.scalar_type() && w->size(0) == R && w->size(1) == H && w->stride(0) == Aa.stride(0),
+                    "a4r::lora_bwd: Aa, Ab, BTa, BTb must be [R, H] views of x's dtype with one row stride");
+    }
+    TORCH_CHECK(R == 8 || R == 16, "a4r::lora_bwd: 8 (ranks <= 8) or 16 (ranks <= 15) rank rows, got ", R);
+    for (const Tensor* o : {(const Tensor*)&dAa, (const Tensor*)&dAb, (const Tensor*)&dBa, (const Tensor*)&dBb}) {
+        chk_mat(*o, "gradient", x);
+        TORCH_CHECK(o->scalar_type() == at::kFloat, "a4r::lora_bwd: gradients are fp32");
+    }
+    TORCH_CHECK(dAa.size(0) == R && dAb.size(0) == R && dAa.size(1) == H && dAb.size(1) == H && dAa.stride(0) == dAb.stride(0), "a4r::lora_bwd: dAa, dAb must be [R, H]");
+    TORCH_CHECK(dBa.size(0) == H && dBb.size(0) == H && dBa.stride(0) == dBb.stride(0), "a4r::lora_bwd: dBa, dBb must be [H, >= R]");
+    int ldbias = 0;
+    for (const optional<Tensor>* b : {&dbias_a, &dbias_b})
+        if (b->has_value() && (*b)->defined()) {
+            TORCH_CHECK((*b)->is_cuda() && (*b)->scalar_type() == at::kFloat && (*b)->dim() == 1 && (*b)->numel() == H, "a4r::lora_bwd: bias sums are fp32 [H] (strided) device vectors");
+            ldbias = (int)(*b)->stride(0);
+        }
+    chk_f32(ws, "ws", x, a4r_lora_bwd_fused_ws_floats((int)H));
+    status(a4r_lora_bwd_fused(cur_stream(x), x.data_ptr(), (int)x.stride(0), dqa.data_ptr(), dqb.data_ptr(), (int)dqa.stride(0), Aa.data_ptr(), Ab.data_ptr(),
+                              BTa.data_ptr(), BTb.data_ptr(), (int)Aa.stride(0), (float)scale_a, (float)scale_b, dAa.data_ptr<float>(), dAb.data_ptr<float>(),
+                              (int)dAa.stride(0), dBa.data_ptr<float>(), dBb.data_ptr<float>(), (int)dBa.stride(0), (float*)mptr(dbias_a), (float*)mptr(dbias_b), ldbias,
+                              (int)M, (int)H, dt_of(x), (int)R, ws.data_ptr<float>(), ws.numel()),
+           "a4r_lora_bwd_fused");
+}
+
 int64_t abi_version() { return a4r_version(); }
 
 }  // namespace
@@ -220,5 +255,7 @@ TORCH_LIBRARY(a4r, m) {
     m.def("fused_adam_step(Tensor(a!) p, Tensor g, Tensor(b!) m, Tensor(c!) v, Tensor seg_end, Tensor seg_group, Tensor group_lr, int step, float beta1=0.9, "
           "float beta2=0.999, float eps=1e-8, float grad_scale=1.0) -> ()", &fused_adam_step);
     m.def("topk_rank_eval(Tensor prec, Tensor item_emb, Tensor target, Tensor hist_ptr, Tensor hist_idx, Tensor(a!) rank) -> ()", &topk_rank_eval);
+    m.def("lora_bwd(Tensor x, Tensor dqa, Tensor dqb, Tensor Aa, Tensor Ab, Tensor BTa, Tensor BTb, float scale_a, float scale_b, Tensor(a!) dAa, Tensor(b!) dAb, "
+          "Tensor(c!) dBa, Tensor(d!) dBb, Tensor(e!)? dbias_a, Tensor(f!)? dbias_b, Tensor(g!) ws) -> ()", &lora_bwd);
     m.def("abi_version() -> int", &abi_version);
 }

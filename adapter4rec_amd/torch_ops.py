@@ -14,7 +14,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 OPS_LIB_PATH = os.path.join(_HERE, 'liba4r_torch_ops.so')
 OPS = ('gemm_nt', 'adapter_residual_ln_fwd', 'adapter_residual_ln_bwd', 'ln_fwd', 'score_bce_fwd', 'score_bce_bwd', 'fused_adam_step',
-       'topk_rank_eval', 'abi_version')
+       'topk_rank_eval', 'lora_bwd', 'abi_version')
 _loaded = False
 
 

@@ -108,3 +108,23 @@ def test_ops_equal_ctypes_binding():
         s[hist] = float('-inf')
         s[0] = float('-inf')
         assert int(rank[u]) == 1 + int((s > s[tu]).sum()), u
+    # ---- LoRA backward in one pass (ranks 8 + 5 in the shared-tile form) against the ctypes binding
+    Ml = 16 * 300
+    xl, dqkv = r(Ml, H).to(t), r(Ml, 3 * H, sc=0.1).to(t)
+    dqa, dqb = dqkv[:, :H], dqkv[:, 2 * H:]
+    Aop, BTa, BTb = (torch.zeros(64, H, dtype=t, device=dev) for _ in range(3))
+    Aop[0:8], Aop[16:21], BTa[0:8], BTb[16:21] = r(8, H, sc=0.05).to(t), r(5, H, sc=0.05).to(t), r(8, H, sc=0.05).to(t), r(5, H, sc=0.05).to(t)
+    res = []
+    for use_op in (False, True):
+        sA, sBa, sBb = torch.zeros(64, H, device=dev), torch.zeros(H, 64, device=dev), torch.zeros(H, 64, device=dev)
+        if use_op:
+            ws = torch.empty(int(L.lib().a4r_lora_bwd_fused_ws_floats(H)), device=dev)
+            ops.lora_bwd(xl, dqa, dqb, Aop[0:8], Aop[16:24], BTa[0:8], BTb[16:24], 0.125, 0.25, sA[0:8], sA[16:24], sBa[:, 0:8], sBb[:, 16:24], sBa[:, 32], sBb[:, 32], ws)
+        else:
+            L.lora_bwd_fused(xl, dqa, dqb, Aop[0:8], Aop[16:24], BTa[0:8], BTb[16:24], 0.125, 0.25, sA[0:8], sA[16:24], sBa[:, 0:8], sBb[:, 16:24], sBa[:, 32], sBb[:, 32], Ml)
+        res.append((sA, sBa, sBb))
+    for a_, b_ in zip(*res):                                  # the same two launches; the second one's atomics may land in another order
+        torch.testing.assert_close(a_, b_, rtol=1e-5, atol=1e-5 * float(b_.abs().max()))
+    assert float(res[1][0].abs().max()) > 0 and float(res[1][1][:, 32].abs().max()) > 0
+    with pytest.raises(RuntimeError, match='rank rows'):
+        ops.lora_bwd(xl, dqa, dqb, Aop[0:4], Aop[16:20], BTa[0:4], BTb[16:20], 1.0, 1.0, sA[0:4], sA[16:20], sBa[:, 0:8], sBb[:, 16:24], None, None, ws)
