@@ -582,7 +582,7 @@ __global__ void __launch_bounds__(WG<NKT>::NTHR, 4) attn_long_dkdv_kernel(const 
         uint4 rq_[G::KS], ro[G::KS];
 #pragma unroll
         for (int ks = 0; ks < G::KS; ++ks) { rq_[ks] = frag_rows<T, DH>(Qr, fr, ks, kg); ro[ks] = frag_rows<T, DH>(Or, fr, ks, kg); }
-#pragma unroll 1
+#pragma unroll                                          // (round 4: rolled, the loop rebuilt its LDS offsets every group: unrolled -3 % on the backward at S = 197)
         for (int g = 0; g < NG; ++g) {
             constexpr int HALF = G::ND >= 4 ? 2 : G::ND;
             uint4 tf[2][HALF];                                  // transposed fragments, two slots of HALF head-column tiles
