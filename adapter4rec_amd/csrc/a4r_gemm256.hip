@@ -860,8 +860,11 @@ int launch256(hipStream_t s, const a4r_gemm_t& g) {
         delay = (int)((g.K * (int)sizeof(TI) / 128 * 145 + 400) * stagger_pct / 100);
         if (delay > 16383) delay = 16383;
     }
-    // (with a short-tile tail the panel-major map: whole panels per XCD would leave the XCDs uneven numbers of full tiles)
-    const int gn = (tail_kp > 0 ? 0 : band_for(g, ntm, ntn, grid, (int)sizeof(TI))) | (no_stream << 16) | (delay << 17);
+    // (with a short-tile tail the panel-major map -- whole panels per XCD would leave the XCDs uneven numbers of full tiles --, EXCEPT when the full
+    // panels divide evenly over the 8 XCDs: the image tower's 259 panels = 256 full + a tail, 32 per XCD; round 4, A4R_GEMM_BAND_TAIL=0 = never)
+    static const int band_tail = getenv("A4R_GEMM_BAND_TAIL") ? atoi(getenv("A4R_GEMM_BAND_TAIL")) != 0 : 1;
+    const bool band_ok = tail_kp == 0 || (band_tail && sizeof(TI) == 2 && ntm > 0 && ntm % 8 == 0 && grid == n_cu);   // (ViT + LoRA same box: bf16 30.16 -> 30.05 ms; e4m3 +0.4 %: bf16 only)
+    const int gn = (band_ok ? band_for(g, ntm, ntn, grid, (int)sizeof(TI)) : 0) | (no_stream << 16) | (delay << 17);
     hipLaunchKernelGGL((gemm_nt_256_kernel<TI, TO, ACT, DACT, EF>), dim3(grid), dim3(512), 0, s, g, ntm, ntn, gn,
                        a4r_thr16(g.drop_p), a4r_keep_scale(g.drop_p), tail_kp, tail_rows);
     return a4r_launch_status();
