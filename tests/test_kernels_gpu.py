@@ -1051,6 +1051,27 @@ def test_lora_merge(dt, r):
     assert float(big[:H].abs().max()) == 0 and float(bigT[:, 2 * H:].abs().max()) == 0      # the neighbouring slots are untouched
 
 
+@pytest.mark.parametrize('dt', ['bf16', 'f32'])
+def test_lora_merge_batch_tiled_and_elementwise(dt):
+    """a4r_lora_merge_batch over a mixed table: 768 x 768 projections (r = 8, 12) and a 64 x 64 one take the 64 x 64-tile path (whole-row pieces, the
+    transposed copy through LDS), a 192 x 96 one the element-wise path; rows and transposed columns land in slots of packed operands, neighbours untouched."""
+    from adapter4rec_amd import _lib as L
+    t = DT[dt]
+    shapes = [(768, 768, 8), (768, 768, 12), (64, 64, 4), (192, 96, 8)]
+    ents, want = [], []
+    for n, (o, i, r) in enumerate(shapes):
+        W, A, B = rnd(o, i, seed=10 + n), rnd(r, i, seed=20 + n), rnd(o, r, seed=30 + n)
+        big, bigT = torch.zeros(3 * o, i + 8, dtype=t, device=dev()), torch.zeros(i, 3 * o + 8, dtype=t, device=dev())
+        ents.append((W, A, B, 2.0 / r, big[o:2 * o, :i], bigT[:, o:2 * o], r))
+        want.append((W + (B @ A) * (2.0 / r), big, bigT, o, i))
+    L.lora_merge_batch(L.lora_table(ents, dev()))
+    for ref, big, bigT, o, i in want:
+        close(big[o:2 * o, :i], ref, t, 'merged rows')
+        close(bigT[:, o:2 * o], ref.t(), t, 'merged transpose')
+        assert float(big[:o].abs().max()) == 0 and float(big[2 * o:].abs().max()) == 0 and float(big[:, i:].abs().max()) == 0
+        assert float(bigT[:, :o].abs().max()) == 0 and float(bigT[:, 2 * o:].abs().max()) == 0
+
+
 def test_phm_build_and_backward_vs_autograd():
     """a4r_phm_build / a4r_phm_bwd vs the reference's construction (model/layers.py:10-22,150-160, kronecker.py:23-34) through
     torch autograd: two PHMLinear (768 -> 64, 64 -> 768) sharing one rule, gradient matrices read from zero-padded scratch."""
