@@ -854,7 +854,7 @@ int launch256(hipStream_t s, const a4r_gemm_t& g) {
         ntm = p_full;
     }
     static const int no_stream = getenv("A4R_GEMM_NO_STREAM") ? atoi(getenv("A4R_GEMM_NO_STREAM")) != 0 : 0;
-    static const int stagger_pct = getenv("A4R_GEMM_STAGGER") ? atoi(getenv("A4R_GEMM_STAGGER")) : 30;
+    static const int stagger_pct = getenv("A4R_GEMM_STAGGER") ? atoi(getenv("A4R_GEMM_STAGGER")) : 50;     // (30 until the end of round 4; re-swept after the band policy: LOG.md part D)
     int delay = 0;
     if (stagger_pct > 0 && ntm * ntn > 2 * grid) {         // (tile period in 10-ns ticks ~ 145 per K-tile of 128 B + 400)
         delay = (int)((g.K * (int)sizeof(TI) / 128 * 145 + 400) * stagger_pct / 100);
