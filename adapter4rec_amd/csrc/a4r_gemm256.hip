@@ -190,7 +190,7 @@ A4R_DEV void gemm256_tiles(const a4r_gemm_t& p, char* lds, int ntm, int ntn, int
     int t_loc = blockIdx.x >> 3;
     A4R_TL(0)
     if (!TAIL && t_loc >= len_x) return;
-    if constexpr (!TAIL) {   // Staggered start (gn_flags >> 17 = delay in 10-ns ticks, A4R_GEMM_STAGGER = percent of a tile period, default 30, 0 = off):
+    if constexpr (!TAIL) {   // Staggered start (gn_flags >> 17 = delay in 10-ns ticks, A4R_GEMM_STAGGER = percent of a tile period, default 50, 0 = off):
         // workgroups that own one tile fewer than the busiest of their XCD have a tile period of slack; started late, their epilogue
         // store bursts fall into the other workgroups' K loops instead of on top of their bursts (tools/gemm_timeline.py: the K loop of
         // the N = 2304 launch 18.6 -> 16.3 us per tile).  Same-box step: -1.5 % on the slower boxes of the pool, neutral on the fastest.
