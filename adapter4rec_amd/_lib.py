@@ -12,7 +12,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('A4R_LIB_PATH') or os.path.join(_HERE, 'liba4r_hip.so')    # A4R_LIB_PATH: A/B builds (tools/), same C ABI
 
-ABI_VERSION = 404          # = A4R_ABI_VERSION of include/a4r.h (tests/test_abi_cpu.py compares the two)
+ABI_VERSION = 405          # = A4R_ABI_VERSION of include/a4r.h (tests/test_abi_cpu.py compares the two)
 BF16, F32, FP8 = 0, 1, 2
 ACT_NONE, ACT_RELU, ACT_GELU, ACT_GELU_TANH, ACT_LEAKY = 0, 1, 2, 3, 4
 DACT_MUL = 15
@@ -22,7 +22,7 @@ EVAL_MAX_HISTORY = 64          # A4R_EVAL_MAX_HISTORY (include/a4r.h)
 ACT_BY_NAME = {'none': 0, 'relu': 1, 'RELU': 1, 'gelu': 2, 'GELU': 2, 'gelu_new': 3, 'leaky_relu': 4}
 
 EXPORTS = [
-    'a4r_version', 'a4r_gemm_nt', 'a4r_gemm_tn', 'a4r_gemm_tn2', 'a4r_colsum', 'a4r_attn_fwd', 'a4r_attn_bwd', 'a4r_embed_ln',
+    'a4r_version', 'a4r_gemm_nt', 'a4r_gemm_tn', 'a4r_gemm_tn_bias', 'a4r_gemm_tn_multi', 'a4r_gemm_tn2', 'a4r_colsum', 'a4r_attn_fwd', 'a4r_attn_bwd', 'a4r_embed_ln',
     'a4r_ln_fwd', 'a4r_ln_bwd', 'a4r_gather_rows', 'a4r_scatter_rows', 'a4r_act_bwd_f32', 'a4r_score_bce_fwd',
     'a4r_score_bce_bwd', 'a4r_emb_grad_add_inputs', 'a4r_take_inputs', 'a4r_adam_step', 'a4r_pack_matrices',
     'a4r_eval_rank', 'a4r_dropout_apply', 'a4r_gemm_variant', 'a4r_gemm_tail_plan', 'a4r_gemm_tail_max', 'a4r_gemm_rows_256', 'a4r_adapter_ln_fwd', 'a4r_adapter_ln_bwd', 'a4r_ln_fwd_fp8', 'a4r_ln_fwd_sum', 'a4r_quant_rows_fp8', 'a4r_lora_merge', 'a4r_lora_merge_batch', 'a4r_lora_bwd_fused', 'a4r_lora_bwd_fused_ws_floats', 'a4r_phm_build', 'a4r_phm_bwd', 'a4r_unpack_add', 'a4r_memset_zero',
@@ -245,6 +245,34 @@ def gemm_tn(X, Y, Cacc, M=None):
     M = X.shape[0] if M is None else M
     _check(lib().a4r_gemm_tn(_stream(), _p(X), C.c_int(_ld(X)), _p(Y), C.c_int(_ld(Y)), _p(Cacc), C.c_int(_ld(Cacc)),
                              C.c_int(M), C.c_int(X.shape[1]), C.c_int(Y.shape[1]), C.c_int(_dt(X))), 'a4r_gemm_tn')
+
+
+def gemm_tn_bias(X, Y, Cacc, xsum, M=None):
+    """Cacc += X^T Y and xsum[:P] += column sums of X (a trainable Linear's dW and db from one pass over dy)."""
+    require_gpu(X, Y, Cacc, xsum)
+    assert Cacc.dtype == torch.float32 and xsum.dtype == torch.float32 and xsum.numel() >= X.shape[1] and _dt(X) == _dt(Y)
+    M = X.shape[0] if M is None else M
+    _check(lib().a4r_gemm_tn_bias(_stream(), _p(X), C.c_int(_ld(X)), _p(Y), C.c_int(_ld(Y)), _p(Cacc), C.c_int(_ld(Cacc)),
+                                  C.c_int(M), C.c_int(X.shape[1]), C.c_int(Y.shape[1]), C.c_int(_dt(X)), _p(xsum)), 'a4r_gemm_tn_bias')
+
+
+class TnProb(C.Structure):
+    _fields_ = [('X', C.c_void_p), ('Y', C.c_void_p), ('C', C.c_void_p), ('xsum', C.c_void_p),
+                ('ldx', C.c_int32), ('ldy', C.c_int32), ('ldc', C.c_int32), ('P', C.c_int32), ('Q', C.c_int32), ('pad_', C.c_int32)]
+
+
+def gemm_tn_multi(probs, M=None):
+    """probs: 1..4 tuples (X, Y, Cacc, xsum or None) over the same M rows: Cacc += X^T Y, xsum += column sums of X (include/a4r.h: a4r_gemm_tn_multi)."""
+    assert 1 <= len(probs) <= 4
+    arr = (TnProb * len(probs))()
+    dt = _dt(probs[0][0])
+    M = probs[0][0].shape[0] if M is None else M
+    for a, (X, Y, Cacc, xsum) in zip(arr, probs):
+        require_gpu(X, Y, Cacc, xsum)
+        assert Cacc.dtype == torch.float32 and _dt(X) == dt and _dt(Y) == dt and (xsum is None or (xsum.dtype == torch.float32 and xsum.numel() >= X.shape[1]))
+        a.X, a.Y, a.C, a.xsum = X.data_ptr(), Y.data_ptr(), Cacc.data_ptr(), (xsum.data_ptr() if xsum is not None else None)
+        a.ldx, a.ldy, a.ldc, a.P, a.Q = _ld(X), _ld(Y), _ld(Cacc), X.shape[1], Y.shape[1]
+    _check(lib().a4r_gemm_tn_multi(_stream(), arr, C.c_int(len(probs)), C.c_int(M), C.c_int(dt)), 'a4r_gemm_tn_multi')
 
 
 def gemm_tn2(X1, Y1, C1, X2, Y2, C2, M=None, xsum1=None, xsum2=None):

@@ -275,12 +275,17 @@ static int tn_xcd_groups(int groups) {
     return on && groups % 8 == 0;
 }
 
+// a4r_gemm_tn256.hip: the 256 x 256-tile kernel for large outputs (weight gradients of trainable backbone Linears)
+int a4r_tn256_takes(int M, int P, int Q, int dtype);
+int a4r_tn256_launch(void* stream, const void* X, int ldx, const void* Y, int ldy, float* C, int ldc, int M, int P, int Q, float* xsum);
+
 extern "C" int a4r_gemm_tn(void* stream, const void* X, int ldx, const void* Y, int ldy, float* C, int ldc,
                            int M, int P, int Q, int dtype) {
     if (!X || !Y || !C || M <= 0 || P <= 0 || Q <= 0 || M % 64 || P % 64 || Q % 64) return A4R_EINVAL;
     const int esz = dtype == A4R_F32 ? 4 : 2;
     if ((dtype != A4R_F32 && dtype != A4R_BF16) || (ldx * esz) % 16 || (ldy * esz) % 16 || ldx < P || ldy < Q || ldc < Q) return A4R_EINVAL;
     if ((reinterpret_cast<uintptr_t>(X) | reinterpret_cast<uintptr_t>(Y)) & 15u) return A4R_EINVAL;
+    if (g_tn_variant != 0 && a4r_tn256_takes(M, P, Q, dtype)) return a4r_tn256_launch(stream, X, ldx, Y, ldy, C, ldc, M, P, Q, nullptr);
     const int ntp = P / 64, ntq = Q / 64, tiles = ntp * ntq;
     const bool glds = dtype == A4R_BF16 && g_tn_variant != 0;
     int splits = ((glds ? 768 : 512) + tiles - 1) / tiles;  // one round of three (two) workgroups per CU
@@ -325,6 +330,54 @@ extern "C" int a4r_gemm_tn2(void* stream, const void* X1, int ldx1, const void* 
     hipLaunchKernelGGL(gemm_tn_glds_kernel, dim3(tiles, splits, 2), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), pa, pb, M, rows_per_split,
                        tn_xcd_groups(2 * splits));
     return a4r_launch_status();
+}
+
+extern "C" int a4r_colsum(void* stream, const void* X, int ldx, float* out, int M, int N, int dtype);
+
+// a4r_gemm_tn plus xsum[p] += column sums of X (a Linear's weight AND bias gradient from one pass over dy: dW = dy^T x, db = colsum(dy)).
+// Large bf16 outputs: both from the 256-tile launch; every other shape: a4r_gemm_tn followed by a4r_colsum.
+extern "C" int a4r_gemm_tn_bias(void* stream, const void* X, int ldx, const void* Y, int ldy, float* C, int ldc,
+                                int M, int P, int Q, int dtype, float* xsum) {
+    if (!xsum) return a4r_gemm_tn(stream, X, ldx, Y, ldy, C, ldc, M, P, Q, dtype);
+    if (!X || !Y || !C || M <= 0 || P <= 0 || Q <= 0 || M % 64 || P % 64 || Q % 64) return A4R_EINVAL;
+    const int esz = dtype == A4R_F32 ? 4 : 2;
+    if ((dtype != A4R_F32 && dtype != A4R_BF16) || (ldx * esz) % 16 || (ldy * esz) % 16 || ldx < P || ldy < Q || ldc < Q) return A4R_EINVAL;
+    if ((reinterpret_cast<uintptr_t>(X) | reinterpret_cast<uintptr_t>(Y)) & 15u) return A4R_EINVAL;
+    if (g_tn_variant != 0 && a4r_tn256_takes(M, P, Q, dtype)) return a4r_tn256_launch(stream, X, ldx, Y, ldy, C, ldc, M, P, Q, xsum);
+    const int rc = a4r_gemm_tn(stream, X, ldx, Y, ldy, C, ldc, M, P, Q, dtype);
+    return rc != A4R_OK ? rc : a4r_colsum(stream, X, ldx, xsum, M, P, dtype);
+}
+
+int a4r_tn256_launch_multi(void* stream, int n, const void* const* X, const int* ldx, const void* const* Y, const int* ldy, float* const* C, const int* ldc,
+                           const int* P, const int* Q, float* const* xsum, int M);
+
+// 1 <= n <= 4 weight (+ bias) gradients over the same M token rows: ONE launch of the 256-tile kernel when every product qualifies for it (the
+// workgroups' single atomic flush is shared: 36 tiles x 7 token splits for q, k, v and the attention output together instead of 9 x 28 four times),
+// otherwise a4r_gemm_tn_bias per product.
+extern "C" int a4r_gemm_tn_multi(void* stream, const a4r_tn_prob_t* pr, int n, int M, int dtype) {
+    if (!pr || n < 1 || n > 4) return A4R_EINVAL;
+    bool big = g_tn_variant != 0;
+    const int esz = dtype == A4R_F32 ? 4 : 2;
+    for (int i = 0; i < n; ++i) {
+        const a4r_tn_prob_t& q = pr[i];
+        if (!q.X || !q.Y || !q.C || M <= 0 || q.P <= 0 || q.Q <= 0 || M % 64 || q.P % 64 || q.Q % 64) return A4R_EINVAL;
+        if ((dtype != A4R_F32 && dtype != A4R_BF16) || (q.ldx * esz) % 16 || (q.ldy * esz) % 16 || q.ldx < q.P || q.ldy < q.Q || q.ldc < q.Q) return A4R_EINVAL;
+        if ((reinterpret_cast<uintptr_t>(q.X) | reinterpret_cast<uintptr_t>(q.Y)) & 15u) return A4R_EINVAL;
+        big = big && a4r_tn256_takes(M, q.P, q.Q, dtype);
+    }
+    if (big) {
+        const void* X[4]; const void* Y[4]; float* Cc[4]; float* xs[4]; int ldx[4], ldy[4], ldc[4], P[4], Q[4];
+        for (int i = 0; i < n; ++i) {
+            X[i] = pr[i].X; Y[i] = pr[i].Y; Cc[i] = pr[i].C; xs[i] = pr[i].xsum;
+            ldx[i] = pr[i].ldx; ldy[i] = pr[i].ldy; ldc[i] = pr[i].ldc; P[i] = pr[i].P; Q[i] = pr[i].Q;
+        }
+        return a4r_tn256_launch_multi(stream, n, X, ldx, Y, ldy, Cc, ldc, P, Q, xs, M);
+    }
+    for (int i = 0; i < n; ++i) {
+        const int rc = a4r_gemm_tn_bias(stream, pr[i].X, pr[i].ldx, pr[i].Y, pr[i].ldy, pr[i].C, pr[i].ldc, M, pr[i].P, pr[i].Q, dtype, pr[i].xsum);
+        if (rc != A4R_OK) return rc;
+    }
+    return A4R_OK;
 }
 
 extern "C" int a4r_colsum(void* stream, const void* X, int ldx, float* out, int M, int N, int dtype) {

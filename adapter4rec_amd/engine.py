@@ -1325,8 +1325,12 @@ class TransRecEngine:
             self._dense_wgrad(blk.d_i, du, bufs.get('x1s'), M)
             L.gemm_nt(du, blk.wiT, dx1, R1=dres2, M=M)
         dh1, dres1 = self._sub_backward(blk, '1', dx1, blk.ln1, blk.ad1, blk.pl1, blk.lnn1, bufs, M, ph, blk.site + 1, seed)
-        self._dense_wgrad(blk.d_o, dh1, bufs.get('ctx_s'), M)
         qkv_train = any(d is not None and d.trainable for d in blk.qkv)
+        pend = []                                                  # the attention output's weight gradient rides in the q / k / v launch below
+        if qkv_train and cls_rows is None:                         # (same token rows; dh1 and ctx_s are not written in between)
+            pend = [(blk.d_o, dh1, bufs.get('ctx_s'))]
+        else:
+            self._dense_wgrad(blk.d_o, dh1, bufs.get('ctx_s'), M)
         if dx_in is None and not blk.lora and not qkv_train:      # first encoder layer: nothing trainable sits below its attention
             return
         dctx = self._buf('dctx_c' if cls_rows is not None else 'dctx', M, H, T)
@@ -1349,14 +1353,27 @@ class TransRecEngine:
                        drop_p=pa, drop_site=blk.site, drop_seed=seed)
         if blk.lora:
             self._lora_backward_all(blk, dqkv, bufs['xin'], M)
-        for sl, d in enumerate(blk.qkv):
-            self._dense_wgrad(d, dqkv[:, sl * H:(sl + 1) * H], bufs.get('xin'), M)
+        self._dense_wgrads([(d, dqkv[:, sl * H:(sl + 1) * H], bufs.get('xin')) for sl, d in enumerate(blk.qkv)] + pend, M)
         if dx_in is not None:
             L.gemm_nt(dqkv, blk.wqkvT, dx_in, R1=dres1, M=M)
+
+    def _dense_wgrads(self, items, M):
+        """_dense_wgrad for up to four (Linear, dy, x) over the same M token rows: one a4r_gemm_tn_multi call (large bf16 products: ONE launch)."""
+        live = [(d, dy, x) for d, dy, x in items if d is not None and d.trainable]
+        if len(live) < 2 or len(live) > 4 or any(d.g_w is None for d, _, _ in live):
+            for d, dy, x in live:
+                self._dense_wgrad(d, dy, x, M)
+            return
+        L.gemm_tn_multi([(dy, x, d.s_w if d.s_w is not None else d.g_w().view(d.out_f, d.in_f),
+                          None if d.g_b is None else (d.s_b if d.s_b is not None else d.g_b())) for d, dy, x in live], M=M)
 
     def _dense_wgrad(self, d, dy, x, M):
         """dW += dy^T x, db += column sums of dy for a trainable backbone Linear (--fine_tune_to all)."""
         if d is None or not d.trainable:
+            return
+        if d.g_w is not None and d.g_b is not None:               # one pass over dy for both (large bf16 outputs: one launch, a4r_gemm_tn256.hip)
+            L.gemm_tn_bias(dy, x, d.s_w if d.s_w is not None else d.g_w().view(d.out_f, d.in_f),
+                           d.s_b if d.s_b is not None else d.g_b(), M=M)
             return
         if d.g_w is not None:
             L.gemm_tn(dy, x, d.s_w if d.s_w is not None else d.g_w().view(d.out_f, d.in_f), M=M)       # (zero-padded storage: scratch + corner)

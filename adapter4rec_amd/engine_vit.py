@@ -365,9 +365,13 @@ class ViTRecEngine(TransRecEngine):
             L.ln_bwd(dn2, bufs['x1'], bufs['stb'], blk.lnB.gamma, dx1, M=M, dgamma=gg(blk.lnB.g_gamma), dbeta=gg(blk.lnB.g_beta), dres=dres2)
             da, dres1 = self._vit_sub_backward(blk, blk.ad1, dx1, bufs, '1', M)
             assert dres1 is dx1              # the parallel form exists at layer.output only (run_adapter.py:448-453)
-        self._dense_wgrad(blk.d_o, da, bufs.get('ctx_s'), M)
         ln_a = blk.lnA.g_gamma is not None           # --finetune_layernorm: layer 0 still owes its LN_before gradients
         qkv_train = any(d is not None and d.trainable for d in blk.qkv)
+        pend = []                                    # the attention output's weight gradient rides in the q / k / v launch below (engine.py)
+        if qkv_train and cls_rows is None:
+            pend = [(blk.d_o, da, bufs.get('ctx_s'))]
+        else:
+            self._dense_wgrad(blk.d_o, da, bufs.get('ctx_s'), M)
         if dx_in is None and not blk.lora and not ln_a and not qkv_train:
             return None
         dctx = self._buf('dctx_c' if cls_rows is not None else 'dctx', M, H, T)
@@ -385,8 +389,7 @@ class ViTRecEngine(TransRecEngine):
         L.attn_long_bwd(bufs['qkv'], bufs['ctx_o'], dctx, dqkv, bufs['lse'], ws, n_items, blk.S, blk.nh, blk.dh, 0, H, 2 * H, blk.scale)
         if blk.lora:
             self._lora_backward_all(blk, dqkv, bufs['n1'], M)
-        for sl, d in enumerate(blk.qkv):
-            self._dense_wgrad(d, dqkv[:, sl * H:(sl + 1) * H], bufs.get('n1'), M)
+        self._dense_wgrads([(d, dqkv[:, sl * H:(sl + 1) * H], bufs.get('n1')) for sl, d in enumerate(blk.qkv)] + pend, M)
         if dx_in is not None or ln_a:
             if dx_in is None:
                 dx_in = self._buf('dx_unused', M, H, T)

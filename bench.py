@@ -35,7 +35,9 @@ sys.path.insert(0, ROOT)
 MFMA_BF16_PEAK_TFLOPS = 2500.0      # dense bf16, /opt/skills/guides/MI355X_MICROARCH.md
 MFMA_FP8_PEAK_TFLOPS = 5000.0       # dense fp8 (block-scaled MFMA), same guide; BASELINE.md section 4 prices configs[4] against it
 # algorithmic GFLOP per user-sequence (12 S 42 [2 x 14 155 776 + 3 (4SH + f_ad)], + patch embedding for images)
-GFLOP_PER_USER = {'bert_houlsby': 450.1, 'roberta_pfeiffer_cpc': 441.2, 'vit_lora': 3005.9 + 9.7, 'mae_compacter': 754.8 + 9.7}
+GFLOP_PER_USER = {'bert_houlsby': 450.1, 'roberta_pfeiffer_cpc': 441.2, 'vit_lora': 3005.9 + 9.7, 'mae_compacter': 754.8 + 9.7,
+                  # full fine-tuning: forward + dgrad + wgrad of every dense product, attention 3x: 12 S 42 [3 x 14 155 776 + 3 x 4SH]
+                  'bert_pretrain': 646.3}
 SEED = 123456
 
 
@@ -59,6 +61,10 @@ WORKLOADS = {
                  'synthetic (seed 123456, uint8 images U{0..255} [336, 224, 224, 3] per step; random-init ViT-B/16)'),
     'mae_compacter': ('configs[4]', 8, 'Amazon-shape SASRec+ViT-MAE-base (75 % masked, 50 tokens)+Compacter train step from uint8 images',
                       'synthetic (seed 123456, uint8 images, on-device masking noise; random-init ViT-MAE-base)'),
+    # not a BASELINE.json config: the reference's OTHER half (Pretraining/Text/script/sm_base_sasrec.py: nothing frozen, no adapters, B = 32),
+    # SURVEY 8(f) n3 -- every backbone weight gradient runs (a4r_gemm_tn), Adam over ~110 M parameters
+    'bert_pretrain': ('Pretraining/Text (SURVEY 8f n3)', 32, 'MIND-shape SASRec+BERT-base FULL fine-tuning train step (--fine_tune_to all, no adapters), dropout on',
+                      'synthetic (seed 123456, 65536 items, 30-token titles, full 23-item histories; random-init BERT-base)'),
 }
 
 
@@ -132,7 +138,11 @@ def build_model(args, device, roberta=False):
     from adapter4rec_amd.optim import FusedAdam
     torch.manual_seed(SEED)
     model = (ModelCPC if args.arch == 'cpc' else Model)(args, 65536, True, BertBackbone(ROBERTA_BASE if roberta else BERT_BASE))
-    freeze_all(model)
+    if 'None' in args.adding_adapter_to:                      # Pretraining/: nothing frozen but the pooler (run.py:317-319)
+        for n, p in model.named_parameters():
+            p.requires_grad = 'pooler' not in n
+    else:
+        freeze_all(model)
     model = inject_adapters(model, args)
     model.to(device)
     model.train()
@@ -388,6 +398,8 @@ def main():
         args = make_args(a.batch, a.dtype)
         if wl == 'roberta_pfeiffer_cpc':
             args.adapter_type, args.adapter_activation, args.arch, args.bert_model_load = 'pfeiffer', 'relu', 'cpc', 'roberta_base'
+        if wl == 'bert_pretrain':
+            args.adapter_type, args.adding_adapter_to = 'none', 'None'
         model, opt = build_model(args, device, roberta=(wl == 'roberta_pfeiffer_cpc'))
         g = torch.Generator().manual_seed(SEED + rank)            # users are sharded: every rank draws its own users
         gc = torch.Generator().manual_seed(SEED)
@@ -615,7 +627,8 @@ def main():
         users = world * a.batch * a.steps
         out = {
             'metric': {'bert_houlsby': 'user-sequences/sec, seq_len=23 BERT+SASRec+Adapter', 'roberta_pfeiffer_cpc': 'user-sequences/sec, seq_len=23 RoBERTa+CPC+Pfeiffer',
-                       'vit_lora': 'user-sequences/sec, seq_len=23 ViT+SASRec+LoRA', 'mae_compacter': 'user-sequences/sec, seq_len=23 MAE+SASRec+Compacter'}[wl],
+                       'vit_lora': 'user-sequences/sec, seq_len=23 ViT+SASRec+LoRA', 'mae_compacter': 'user-sequences/sec, seq_len=23 MAE+SASRec+Compacter',
+                       'bert_pretrain': 'user-sequences/sec, seq_len=23 BERT+SASRec full fine-tuning (Pretraining/Text)'}[wl],
             'value': round(users / dt, 2),
             'unit': 'user-sequences/sec', 'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup,
             'ms_per_step': round(dt / a.steps * 1e3, 3), 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,

@@ -36,7 +36,7 @@ extern "C" {
 
 /* ABI version: bumped whenever a signature or struct below changes.  The Python binding (adapter4rec_amd/_lib.py) refuses a
  * library whose a4r_version() differs, so an A/B build made before a signature change cannot be called with shifted arguments. */
-#define A4R_ABI_VERSION 404
+#define A4R_ABI_VERSION 405
 int a4r_version(void);
 
 /* C[M,N] = epilogue(alpha * A[M,K] . B[N,K]^T): every nn.Linear on the path (HF BertSelfAttention
@@ -112,6 +112,23 @@ int a4r_gemm_variant(int v);
  * C must be zeroed (or hold the running sum) before the call; accumulation uses fp32 atomics. */
 int a4r_gemm_tn(void* stream, const void* X, int ldx, const void* Y, int ldy, float* C, int ldc,
                 int M, int P, int Q, int dtype);
+/* a4r_gemm_tn plus xsum[p] += sum_m X[m, p] (p < P): weight AND bias gradient of a trainable nn.Linear from one pass over dy -- dW = dy^T x,
+ * db = colsum(dy) -- i.e. the autograd of every dense product of HF BertLayer / ViTLayer under `--fine_tune_to all` (Downstream/Text/run.py:366-371)
+ * and in Pretraining/ (Pretraining/Text/run.py:319-324: nothing frozen).  bf16 with P % 256 == 0, Q % 256 == 0, M >= 4096: one launch of the
+ * 256 x 256-tile kernel (csrc/a4r_gemm_tn256.hip), which a4r_gemm_tn uses for those shapes too; otherwise a4r_gemm_tn then a4r_colsum.
+ * xsum NULL = a4r_gemm_tn.  Same argument checks and error codes as a4r_gemm_tn. */
+int a4r_gemm_tn_bias(void* stream, const void* X, int ldx, const void* Y, int ldy, float* C, int ldc,
+                     int M, int P, int Q, int dtype, float* xsum);
+/* 1 <= n <= 4 such products over the SAME M token rows in one call: C_i[P_i, Q_i] += X_i^T Y_i, xsum_i (optional) += column sums of X_i -- e.g. the
+ * query / key / value weight gradients (X_i = the three column slices of the fused qkv gradient, Y_i = the block input) and the attention output's
+ * (HF BertSelfAttention / BertSelfOutput under full fine-tuning).  When every product is a large bf16 one (a4r_gemm_tn_bias above) they run as ONE
+ * launch whose workgroups share the token splits and the single atomic flush; otherwise one a4r_gemm_tn_bias per product.  n outside 1..4 or any
+ * product failing a4r_gemm_tn's checks: A4R_EINVAL, nothing launched. */
+typedef struct a4r_tn_prob_t {
+    const void* X; const void* Y; float* C; float* xsum;
+    int32_t ldx, ldy, ldc, P, Q, pad_;
+} a4r_tn_prob_t;
+int a4r_gemm_tn_multi(void* stream, const a4r_tn_prob_t* probs, int n, int M, int dtype);
 /* One SASRec transformer block of the user encoder per launch and direction (fp32; E = 64, 2 heads x 32, d_inner 256, T <= 32 rows per
  * user, adapter bottleneck d <= 32): TransformerBlock with the two bottleneck adapters of SASRecAdaptedSelfOutput (model/model.py:341-376;
  * inner_res 1) or SASRecCompacterAdaptedSelfOutput (:666-720; inner_res 0, the PHM matrices materialised):

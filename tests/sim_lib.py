@@ -167,6 +167,18 @@ def gemm_tn(X, Y, Cacc, M=None):
     Cacc += X[:M].float().t() @ Y[:M].float()
 
 
+def gemm_tn_bias(X, Y, Cacc, xsum, M=None):
+    gemm_tn(X, Y, Cacc, M=M)
+    colsum(X, xsum, M=M)
+
+
+def gemm_tn_multi(probs, M=None):
+    for X, Y, Cacc, xsum in probs:
+        gemm_tn(X, Y, Cacc, M=M)
+        if xsum is not None:
+            colsum(X, xsum, M=M)
+
+
 def gemm_tn2(X1, Y1, C1, X2, Y2, C2, M=None, xsum1=None, xsum2=None):
     gemm_tn(X1, Y1, C1, M=M)
     gemm_tn(X2, Y2, C2, M=M)

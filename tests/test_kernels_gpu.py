@@ -286,6 +286,69 @@ def test_gemm_tn_glds_bf16(M, P, Q):
     assert torch.equal(outs[0], outs[1])
 
 
+@pytest.mark.parametrize('M,P,Q', [(40448, 768, 768), (40448, 3072, 768), (40448, 768, 3072), (4096, 256, 256), (64 * 67, 512, 256), (66304, 768, 2304)])
+def test_gemm_tn_256_bf16(M, P, Q):
+    """256 x 256-tile weight-gradient kernel (a4r_gemm_tn256.hip: trainable backbone Linears, --fine_tune_to all / Pretraining): token splits with a
+    ragged last split, operands as views (ld > width: a slice of the fused qkv gradient), accumulation onto a non-zero C, and the column sums of
+    X from the same launch (a4r_gemm_tn_bias).  Small-integer operands make every token sum exact in fp32 whatever the atomic order, so the
+    result must equal torch AND the 64-tile kernel bit for bit."""
+    from adapter4rec_amd import _lib as L
+    g = torch.Generator().manual_seed(23)
+    Xb = torch.randint(-3, 4, (M, P + 256), generator=g).to(torch.bfloat16).to(dev())
+    Yb = torch.randint(-2, 3, (M, Q + 64), generator=g).to(torch.bfloat16).to(dev())
+    X, Y = Xb[:, 256:], Yb[:, :Q]
+    ref = 3.0 + X.float().t() @ Y.float()
+    Cc = torch.full((P, Q), 3.0, device=dev())
+    L.gemm_tn(X, Y, Cc)
+    assert torch.equal(Cc, ref), float((Cc - ref).abs().max())
+    old = L.gemm_variant(0)                                   # the register-staged 64-tile kernel
+    C0 = torch.full((P, Q), 3.0, device=dev())
+    L.gemm_tn(X, Y, C0)
+    L.gemm_variant(old)
+    assert torch.equal(C0, ref)
+    Cb, xs = torch.full((P + 64, Q + 64), 3.0, device=dev()), torch.full((P,), -2.0, device=dev())
+    L.gemm_tn_bias(X, Y, Cb[:P, :Q], xs)                      # C as a view too
+    assert torch.equal(Cb[:P, :Q], ref)
+    assert torch.equal(Cb[P:], torch.full_like(Cb[P:], 3.0)) and torch.equal(Cb[:, Q:], torch.full_like(Cb[:, Q:], 3.0))
+    assert torch.equal(xs, -2.0 + X.float().sum(0)), float((xs + 2.0 - X.float().sum(0)).abs().max())
+
+
+@pytest.mark.parametrize('M,H,n', [(40448, 768, 4), (4096, 256, 2), (64 * 67, 512, 3), (1280, 64, 4)])
+def test_gemm_tn_multi(M, H, n):
+    """a4r_gemm_tn_multi: the q / k / v weight + bias gradients (X = column slices of one fused [M, 3H] gradient, Y = the shared block input) and the
+    attention output's (its own operands) over the same token rows in ONE call -- one launch of the 256-tile kernel when H % 256 == 0, the
+    per-product path otherwise (H = 64).  Exact small-integer operands: equal to torch bit for bit; a product without xsum leaves nothing behind."""
+    from adapter4rec_amd import _lib as L
+    g = torch.Generator().manual_seed(29)
+    dqkv = torch.randint(-3, 4, (M, 3 * H), generator=g).to(torch.bfloat16).to(dev())
+    xin = torch.randint(-2, 3, (M, H), generator=g).to(torch.bfloat16).to(dev())
+    dh1 = torch.randint(-2, 3, (M, H), generator=g).to(torch.bfloat16).to(dev())
+    ctx = torch.randint(-3, 4, (M, H + 64), generator=g).to(torch.bfloat16).to(dev())[:, 64:]
+    ops = [(dqkv[:, i * H:(i + 1) * H], xin) for i in range(3)] + [(dh1, ctx)]
+    ops = ops[4 - n:]
+    Cs = [torch.full((H, H), float(i), device=dev()) for i in range(n)]
+    xs = [None if i == 1 else torch.full((H,), 0.5 * i, device=dev()) for i in range(n)]
+    L.gemm_tn_multi([(X, Y, Cc, x) for (X, Y), Cc, x in zip(ops, Cs, xs)])
+    for i, ((X, Y), Cc, x) in enumerate(zip(ops, Cs, xs)):
+        ref = float(i) + X.float().t() @ Y.float()
+        assert torch.equal(Cc, ref), (i, float((Cc - ref).abs().max()))
+        if x is not None:
+            assert torch.equal(x, 0.5 * i + X.float().sum(0)), i
+    with pytest.raises(RuntimeError):
+        L.gemm_tn_multi([(ops[0][0], ops[0][1], Cs[0], None)] * 5 if False else [(ops[0][0][:, :32], ops[0][1], Cs[0][:32], None)])      # P % 64 != 0
+
+
+def test_gemm_tn_bias_small_shapes_fall_back():
+    """a4r_gemm_tn_bias on shapes the 256-tile kernel does not take (adapter-sized outputs, fp32): a4r_gemm_tn + a4r_colsum."""
+    from adapter4rec_amd import _lib as L
+    for t, M, P, Q in ((torch.bfloat16, 1280, 768, 64), (torch.float32, 640, 64, 128), (torch.bfloat16, 2048, 256, 256)):
+        X, Y = rnd(M, P, dtype=t, seed=61), rnd(M, Q, dtype=t, seed=62)
+        Cc, xs = torch.zeros(P, Q, device=dev()), torch.zeros(P, device=dev())
+        L.gemm_tn_bias(X, Y, Cc, xs)
+        close(Cc, X.float().t() @ Y.float(), torch.float32, 'tn_bias C', atol32=2e-2, rtol32=2e-3)
+        close(xs, X.float().sum(0), torch.float32, 'tn_bias xsum', atol32=2e-2, rtol32=2e-3)
+
+
 def test_gemm_tn2_two_products_one_launch():
     """a4r_gemm_tn2 = two a4r_gemm_tn products over the same rows (an adapter's dW_up [H, 64] and dW_down [64, H])."""
     from adapter4rec_amd import _lib as L
