@@ -824,6 +824,56 @@ def test_adam_matches_torch():
     torch.testing.assert_close(p, torch.cat([q.detach() for q in params]), rtol=1e-5, atol=1e-7)
 
 
+def test_adam_quads_equal_scalar_kernel():
+    """Full fine-tuning steps ~110 M parameters through a4r_adam_step: buffers of >= 2^20 elements on 16-byte addresses take adam4_kernel (four
+    parameters per lane) + the scalar kernel on the n % 4 tail.  Same arithmetic per element: bit-identical to the scalar kernel (reached here
+    through a view that starts 4 bytes into the buffers), segments of odd lengths straddling the quads."""
+    from adapter4rec_amd import _lib as L
+    sizes, groups, lrs = [1000003, 5, 64, 2 ** 20 + 1, 18], [0, 2, 1, 3, 1], [5e-5, 1e-4, 1.5e-4, 2e-4]
+    n = sum(sizes)
+    seg_end = torch.tensor([sum(sizes[:i + 1]) for i in range(len(sizes))], dtype=torch.int32, device=dev())
+    seg_group = torch.tensor(groups, dtype=torch.int32, device=dev())
+    glr = torch.tensor(lrs, device=dev())
+    p0 = rnd(n, seed=74)
+    bufs = []
+    for off in (0, 1):                                    # off = 1: misaligned views -> the scalar kernel for everything
+        p, m, v = [torch.zeros(n + 4, device=dev())[off:off + n] for _ in range(3)]
+        p.copy_(p0)
+        for step in range(1, 4):
+            g = torch.zeros(n + 4, device=dev())[off:off + n]
+            g.copy_(rnd(n, seed=75 + step))
+            L.adam_step(p, g, m, v, seg_end, seg_group, glr, step)
+        bufs.append((p.clone(), m.clone(), v.clone()))
+    for a, b in zip(*bufs):
+        assert torch.equal(a, b)
+    assert not torch.equal(bufs[0][0], p0)
+
+
+def test_pack_matrices_large_tiled():
+    """Matrix lists that hold a large matrix (>= 256 x 256 elements: trainable backbone weights) go through the 64 x 64-tile kernel: plain and
+    transposed copies, zero padding, a destination that is a column block of a wider matrix (dst_ld), ragged edge tiles; a small matrix in the list."""
+    from adapter4rec_amd import _lib as L
+    shapes = [(768, 3072), (3072, 768), (300, 257), (16, 64)]
+    flat = rnd(sum(r * c for r, c in shapes), seed=76)
+    wide = torch.full((320, 3 * 320), 7.0, dtype=torch.bfloat16, device=dev())
+    dsts = [torch.zeros(768, 3072, dtype=torch.bfloat16, device=dev()), torch.zeros(768, 3072, dtype=torch.bfloat16, device=dev()), wide[:, 320:640],
+            torch.zeros(64, 64, dtype=torch.bfloat16, device=dev())]
+    descs = (L.PackDesc * 4)()
+    off = 0
+    for i, ((r, c), d, tr, pad) in enumerate(zip(shapes, dsts, (0, 1, 1, 0), ((768, 3072), (768, 3072), (320, 320), (64, 64)))):
+        descs[i] = L.PackDesc(off, d.data_ptr(), r, c, pad[0], pad[1], tr, 3 * 320 if i == 2 else 0)
+        off += r * c
+    raw = torch.frombuffer(bytearray(bytes(descs)), dtype=torch.uint8).to(dev())
+    L.pack_matrices(flat, raw, 4, 768 * 3072, L.BF16)
+    srcs = torch.split(flat, [r * c for r, c in shapes])
+    assert torch.equal(dsts[0], srcs[0].view(768, 3072).bfloat16())
+    assert torch.equal(dsts[1], srcs[1].view(3072, 768).t().bfloat16())
+    ref = torch.zeros(320, 320, dtype=torch.bfloat16, device=dev())
+    ref[:257, :300] = srcs[2].view(300, 257).t().bfloat16()
+    assert torch.equal(wide[:, 320:640], ref) and bool((wide[:, :320] == 7).all()) and bool((wide[:, 640:] == 7).all())
+    assert torch.equal(dsts[3][:16], srcs[3].view(16, 64).bfloat16()) and torch.count_nonzero(dsts[3][16:]) == 0
+
+
 def test_pack_matrices():
     import ctypes as C
     from adapter4rec_amd import _lib as L
