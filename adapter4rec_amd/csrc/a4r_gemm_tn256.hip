@@ -209,9 +209,10 @@ __global__ void __launch_bounds__(512, 1) gemm_tn_256_kernel(const Tn256 p) {
 }  // namespace
 
 // 1 = the shape takes the 256-tile kernel (a4r_gemm_tn / a4r_gemm_tn_bias dispatch on it; A4R_TN256=0: never, A/B runs)
+int g_tn256_on = 1;            // a4r_gemm_variant(6 / 7)
 int a4r_tn256_takes(int M, int P, int Q, int dtype) {
     static const int on = getenv("A4R_TN256") ? atoi(getenv("A4R_TN256")) != 0 : 1;
-    return on && dtype == A4R_BF16 && P % 256 == 0 && Q % 256 == 0 && M % 64 == 0 && M >= 4096;
+    return on && g_tn256_on && dtype == A4R_BF16 && P % 256 == 0 && Q % 256 == 0 && M % 64 == 0 && M >= 4096;
 }
 
 // n <= 4 products over the same M token rows; every product must pass a4r_tn256_takes

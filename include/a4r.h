@@ -104,7 +104,8 @@ int a4r_gemm_rows_256(int M, int N);
  * wherever M % 256 == 0, N % 256 == 0 (variant 1 elsewhere), chosen automatically: fewer 256-tiles than half the CUs -> the
  * 128-tile kernel; a partial last round -> short tiles in the same launch (a4r_gemm_tail_plan); 4 = the 256 tile
  * forced (tests).  Results of 2 / 4 agree bit for bit, the others to fp32 summation order; returns the previous setting
- * (-1 for the retired variants 3 and 5, any other v only queries). */
+ * (-1 for the retired variants 3 and 5, any other v only queries).  6 / 7 leave all of that alone and switch the 256 x 256-tile
+ * weight-gradient kernel of a4r_gemm_tn / _tn_bias / _tn_multi off / on (tests: the same step on the 64-tile kernels). */
 int a4r_gemm_variant(int v);
 
 /* C[P,Q] (fp32, +=) = X[M,P]^T . Y[M,Q]: weight gradients of the trainable adapter matrices

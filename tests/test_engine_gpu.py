@@ -353,6 +353,41 @@ def test_finetune_all_fp32_vs_oracle_and_fixture(ln_only):
         assert model(items, mask, 'cuda:0').item() < l0          # three Adam steps on one batch must lower its loss
 
 
+@pytest.mark.gpu
+def test_finetune_all_bf16_large_weight_gradient_kernel():
+    """--fine_tune_to all at a geometry where the backbone's weight gradients take the 256 x 256-tile kernel (H = 768, F = 3072, 5 376 token rows:
+    a4r_gemm_tn256.hip through a4r_gemm_tn_bias / a4r_gemm_tn_multi -- q, k, v and the attention output in one launch, bias sums in the launch):
+    every gradient of a 2-layer bf16 step against the same step on the 64-tile kernels + a4r_colsum (a4r_gemm_variant(6)).  Both sum the same
+    bf16 products in fp32; only the order differs."""
+    import bench
+    from adapter4rec_amd import _lib as L
+    from adapter4rec_amd.model import BERT_BASE, BertBackbone, Model
+    args = bench.make_args(4, 'bf16')
+    args.adapter_type, args.adding_adapter_to, args.drop_rate = 'none', 'None', 0.0
+    torch.manual_seed(5)
+    model = Model(args, 2000, True, BertBackbone(dict(BERT_BASE, num_hidden_layers=2, vocab_size=2000, hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0)))
+    for n, p in model.named_parameters():
+        p.requires_grad = 'pooler' not in n
+    model.to('cuda:0').eval()
+    g = torch.Generator().manual_seed(6)
+    content = bench.synth_content(2000, g)
+    content[1:, 1:29] = torch.randint(1000, 1999, (2000, 28), generator=g)
+    items, mask = [t.to('cuda:0') for t in bench.synth_batches(content, 2000, 4, 1, g)[0]]
+    grads = []
+    for variant in (7, 6):
+        L.gemm_variant(variant)
+        model.zero_grad()
+        loss = model(items, mask, 'cuda:0')
+        loss.backward()
+        L.gemm_variant(7)
+        grads.append({n: p.grad.float().clone() for n, p in model.named_parameters() if p.grad is not None})
+    assert len(grads[0]) > 30 and grads[0].keys() == grads[1].keys()
+    for n in grads[0]:
+        a, b = grads[0][n], grads[1][n]
+        assert float(b.abs().max()) > 0 or 'position_embeddings' in n or 'token_type' in n, n
+        assert float((a - b).abs().max()) <= 1e-6 + 2e-4 * float(b.abs().max()), (n, float((a - b).abs().max()), float(b.abs().max()))
+
+
 @pytest.mark.parametrize('name', ['houlsby', 'houlsby_gelu', 'pfeiffer', 'roberta_cpc_pfeiffer'])
 def test_step_bf16_vs_reference_autocast(name):
     """the bf16 path is bounded by the reference's OWN reduced-precision path.  <name>_autocast.npz
