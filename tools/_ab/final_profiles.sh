@@ -8,6 +8,8 @@ for wl in "bert_houlsby fp8" "roberta_pfeiffer_cpc bf16" "roberta_pfeiffer_cpc f
   sfx=""; [ "$2" = "fp8" ] && sfx="_fp8"
   python bench.py --steps 60 --warmup 15 --no-cpu-baseline --workload $1 --dtype $2 > gpurun_out/${TAG}_bench_$1$sfx.json 2>/dev/null
 done
+python bench.py --steps 60 --warmup 15 --no-cpu-baseline --workload bert_pretrain > gpurun_out/${TAG}_bench_bert_pretrain.json 2>/dev/null
+bash tools/profile_step.sh ${TAG}_pretrain nopmc bert_pretrain bf16 > /dev/null 2>&1
 bash tools/profile_step.sh ${TAG}_vit nopmc vit_lora bf16 > /dev/null 2>&1
 bash tools/profile_step.sh ${TAG}_mae nopmc mae_compacter fp8 > /dev/null 2>&1
 python tools/attn_bench.py > gpurun_out/${TAG}_kernels.txt 2>&1
