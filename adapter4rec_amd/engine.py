@@ -1051,7 +1051,8 @@ class TransRecEngine:
             L.attn_long_fwd(bufs['qkv'], ctx, bufs['lse'], n_items, blk.S, blk.nh, blk.dh, 0, H, 2 * H, blk.scale,
                             drop_p=pa, drop_site=blk.site, drop_seed=seed)
         else:
-            ctx = self._buf('ctx', M, H, T)
+            # (trainable attention output: its weight gradient needs ctx per layer -- the attention kernel writes the kept buffer directly)
+            ctx = bufs['ctx_s'] if ('ctx_s' in bufs and cls_rows is None) else self._buf('ctx', M, H, T)
             L.attn_fwd(bufs['qkv'], ctx, key_mask, n_items, blk.S, blk.nh, blk.dh, 0, H, 2 * H, blk.causal, blk.scale, blk.mask_neg,
                        drop_p=pa, drop_site=blk.site, drop_seed=seed)
         if cls_rows is not None:
@@ -1064,7 +1065,7 @@ class TransRecEngine:
                 L.gather_rows(x32, x_c32, n_items, blk.S)
                 self._twin[x_c.data_ptr()] = x_c32
             ctx, x, M = ctx_c, x_c, cls_rows
-        if 'ctx_s' in bufs:
+        if 'ctx_s' in bufs and ctx is not bufs['ctx_s']:
             L.gather_rows(ctx, bufs['ctx_s'], M, 1)
         x1 = self._buf('x1', M, H, T)
         x1 = bufs['x1s'] if 'x1s' in bufs else x1
