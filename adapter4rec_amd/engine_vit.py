@@ -66,8 +66,8 @@ class ViTRecEngine(TransRecEngine):
         self.pos_tab = tab(emb.position_embeddings).reshape(self.NP + 1, H)
         self.g_cls, self.g_postab = self.grad_view(emb.cls_token), self.grad_view(emb.position_embeddings)
         self.train_emb = self.d_patch.trainable or self.g_cls is not None or self.g_postab is not None or self.g_prompt is not None
-        if self.train_emb and self.mae:
-            raise NotImplementedError('training the ViT-MAE embedding side (--fine_tune_to all) is not wired natively')
+        if self.g_prompt is not None and self.mae and self.train_emb:
+            raise NotImplementedError('soft prompt on a ViT-MAE tower with a trainable embedding side is not wired')
         if self.res32:
             raise NotImplementedError('--residual_dtype fp32 is wired for the text tower (post-LN sub-layers on the one-launch adapter kernels); the pre-LN '
                                       'image tower stores its residual stream v itself in the compute dtype')
@@ -445,6 +445,7 @@ class ViTRecEngine(TransRecEngine):
         images = images.contiguous()
         keep = self._keep if self._keep is not None else self._keep_indices(n_items, self.next_noise)
         self._keep, self.next_noise = None, None
+        self._keep_used = keep                      # (ViT-MAE with a trainable embedding side: the backward scatters by the same indices)
         Mp = pad_to(n_items * self.n_keep, 256)
         cols = self.C * self.P * self.P
         pat = self._buf('patches', Mp, cols, self.T)
@@ -527,7 +528,26 @@ class ViTRecEngine(TransRecEngine):
             else:
                 pre2 = self._vit_block_backward(blk, dxb, n_items, M, c['saved_b'][i], spare if blk.need_dx else None, pre2=pre2, prev=prev)
             dxb, spare = spare, dxb
-        if self.train_emb:                       # ViTEmbeddings backward: token 0 -> cls + pos[0]; token 1 + j -> patch projection + pos[1 + j]
+        if self.train_emb and self.mae:
+            # ViTMAEEmbeddings backward (HF modeling_vit_mae.py, Pretraining/CV's shipped configuration: CV_model_load = 'mae', nothing frozen): token 0
+            # = cls + pos[0]; token 1 + j = projection(kept patch j) + pos[1 + keep[j]].  The patch matrix of the forward holds exactly the kept
+            # patches in token order, so dW = d(tokens 1..)^T patches with no scatter; position embeddings are a fixed sin-cos table in HF
+            # (requires_grad False) -- if a caller did make them trainable their rows are reached through the keep indices.
+            S, nk = self.S, self.n_keep
+            d3 = dxb[:n_items * S].view(n_items, S, H)
+            if self.g_cls is not None:
+                self.g_cls().view(H).add_(d3[:, 0].float().sum(0))
+            if self.g_postab is not None:
+                gp = self.g_postab().view(self.NP + 1, H)
+                gp[0].add_(d3[:, 0].float().sum(0))
+                gp.index_add_(0, (self._keep_used[:n_items].long() + 1).reshape(-1), d3[:, 1:1 + nk].float().reshape(n_items * nk, H))
+            if self.d_patch.trainable:
+                Mp = pad_to(n_items * nk, 256)
+                dpe = self._buf('d_patch_emb', Mp, H, self.T)
+                dpe[:n_items * nk].copy_(d3[:, 1:1 + nk].reshape(n_items * nk, H))
+                dpe[n_items * nk:].zero_()
+                self._dense_wgrad(self.d_patch, dpe, self._buf('patches', Mp, self.C * self.P * self.P, self.T), Mp)
+        elif self.train_emb:                     # ViTEmbeddings backward: token 0 -> cls + pos[0]; token 1 + j -> patch projection + pos[1 + j]
             S, NP = self.S, self.NP
             d3 = dxb[:n_items * S].view(n_items, S, H)
             if self.g_prompt is not None:
@@ -542,10 +562,7 @@ class ViTRecEngine(TransRecEngine):
                 dpe = self._buf('d_patch_emb', Mp, H, self.T)
                 dpe[:n_items * NP].copy_(d3[:, 1:].reshape(n_items * NP, H))
                 dpe[n_items * NP:].zero_()
-                if self.d_patch.g_w is not None:
-                    L.gemm_tn(dpe, self._buf('patches', Mp, self.C * self.P * self.P, self.T), self.d_patch.g_w().view(H, -1), M=Mp)
-                if self.d_patch.g_b is not None:
-                    L.colsum(dpe, self.d_patch.g_b(), M=Mp)
+                self._dense_wgrad(self.d_patch, dpe, self._buf('patches', Mp, self.C * self.P * self.P, self.T), Mp)
 
     # ------------------------------------------------------------------ public: inference
     @torch.no_grad()

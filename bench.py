@@ -37,7 +37,9 @@ MFMA_FP8_PEAK_TFLOPS = 5000.0       # dense fp8 (block-scaled MFMA), same guide;
 # algorithmic GFLOP per user-sequence (12 S 42 [2 x 14 155 776 + 3 (4SH + f_ad)], + patch embedding for images)
 GFLOP_PER_USER = {'bert_houlsby': 450.1, 'roberta_pfeiffer_cpc': 441.2, 'vit_lora': 3005.9 + 9.7, 'mae_compacter': 754.8 + 9.7,
                   # full fine-tuning: forward + dgrad + wgrad of every dense product, attention 3x: 12 S 42 [3 x 14 155 776 + 3 x 4SH]
-                  'bert_pretrain': 646.3}
+                  'bert_pretrain': 646.3,
+                  # 12 S 42 [3 x 14 155 776 + 3 x 4SH] at S = 50 + the patch projection forward and weight gradient
+                  'mae_pretrain': 1081.8 + 2 * 9.7 / 4}
 SEED = 123456
 
 
@@ -63,6 +65,8 @@ WORKLOADS = {
                       'synthetic (seed 123456, uint8 images, on-device masking noise; random-init ViT-MAE-base)'),
     # not a BASELINE.json config: the reference's OTHER half (Pretraining/Text/script/sm_base_sasrec.py: nothing frozen, no adapters, B = 32),
     # SURVEY 8(f) n3 -- every backbone weight gradient runs (a4r_gemm_tn), Adam over ~110 M parameters
+    'mae_pretrain': ('Pretraining/CV (SURVEY 8f n3)', 8, 'HM-shape SASRec+ViT-MAE-base (75 % masked, 50 tokens) FULL fine-tuning train step (Pretraining/CV/script/sm_vit_sasrec.py: nothing frozen) from uint8 images',
+                     'synthetic (seed 123456, uint8 images, on-device masking noise; random-init ViT-MAE-base)'),
     'bert_pretrain': ('Pretraining/Text (SURVEY 8f n3)', 32, 'MIND-shape SASRec+BERT-base FULL fine-tuning train step (--fine_tune_to all, no adapters), dropout on',
                       'synthetic (seed 123456, 65536 items, 30-token titles, full 23-item histories; random-init BERT-base)'),
 }
@@ -71,10 +75,10 @@ WORKLOADS = {
 def make_cv_args(batch, dtype, workload):
     a = argparse.Namespace(
         max_seq_len=20, l2_weight=0, embedding_dim=64, num_attention_heads=2, drop_rate=0.1, transformer_block=2,
-        CV_model_load='vit-mae-base' if workload == 'mae_compacter' else 'vit-base-patch16-224', CV_resize=224,
+        CV_model_load='vit-mae-base' if workload in ('mae_compacter', 'mae_pretrain') else 'vit-base-patch16-224', CV_resize=224,
         cv_adapter_down_size=64, adapter_down_size=16, adapter_dropout_rate=0.1, adapter_activation='RELU',
-        hypercomplex_division=4, phm_init_range=1e-4, adapter_type='compacter' if workload == 'mae_compacter' else 'lora',
-        is_serial='True', adding_adapter_to='all', arch='sasrec', compute_dtype=dtype, batch_size=batch, lora_r=8, lora_r_sasrec=4,
+        hypercomplex_division=4, phm_init_range=1e-4, adapter_type='compacter' if workload == 'mae_compacter' else ('none' if workload == 'mae_pretrain' else 'lora'),
+        is_serial='True', adding_adapter_to='None' if workload == 'mae_pretrain' else 'all', arch='sasrec', compute_dtype=dtype, batch_size=batch, lora_r=8, lora_r_sasrec=4,
         fine_tune_lr=1e-5, lr=1e-3, adapter_cv_lr=5e-4, adapter_sasrec_lr=1e-4)
     return a
 
@@ -91,7 +95,10 @@ def build_cv_model(args, device):
         net = ViTForImageClassification(num_labels=args.embedding_dim)      # classifier swapped for Linear(768, 64), run_adapter.py:291-296
         torch.nn.init.xavier_normal_(net.classifier.weight)
     model = Model(args, 8192, True, net)
-    freeze_all(model)
+    if 'None' in args.adding_adapter_to:                      # Pretraining/CV: nothing frozen (HF's fixed sin-cos position table stays as constructed)
+        pass
+    else:
+        freeze_all(model)
     model = inject_adapters(model, args)
     model.to(device)
     model.train()
@@ -389,7 +396,7 @@ def main():
         L.gemm_variant(a.gemm_variant)
     wl = a.workload
     a.batch = a.batch or WORKLOADS[wl][1]
-    image = wl in ('vit_lora', 'mae_compacter')
+    image = wl in ('vit_lora', 'mae_compacter', 'mae_pretrain')
     if image:
         args = make_cv_args(a.batch, a.dtype, wl)
         model, opt = build_cv_model(args, device)
@@ -628,7 +635,8 @@ def main():
         out = {
             'metric': {'bert_houlsby': 'user-sequences/sec, seq_len=23 BERT+SASRec+Adapter', 'roberta_pfeiffer_cpc': 'user-sequences/sec, seq_len=23 RoBERTa+CPC+Pfeiffer',
                        'vit_lora': 'user-sequences/sec, seq_len=23 ViT+SASRec+LoRA', 'mae_compacter': 'user-sequences/sec, seq_len=23 MAE+SASRec+Compacter',
-                       'bert_pretrain': 'user-sequences/sec, seq_len=23 BERT+SASRec full fine-tuning (Pretraining/Text)'}[wl],
+                       'bert_pretrain': 'user-sequences/sec, seq_len=23 BERT+SASRec full fine-tuning (Pretraining/Text)',
+                       'mae_pretrain': 'user-sequences/sec, seq_len=23 MAE+SASRec full fine-tuning (Pretraining/CV)'}[wl],
             'value': round(users / dt, 2),
             'unit': 'user-sequences/sec', 'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup,
             'ms_per_step': round(dt / a.steps * 1e3, 3), 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,

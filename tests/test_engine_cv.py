@@ -325,12 +325,32 @@ def build_cv_finetune_all(device='cpu', dtype='fp32'):
     return model.to(device), sd, dict(cfg, adapter_type='none'), images.to(device), mask.to(device)
 
 
-def _check_all_grads(model, sd, cfg, images, mask, dev):
+def build_cv_mae_finetune_all(device='cpu', dtype='fp32', train_pos=False):
+    """Pretraining/CV's shipped configuration (script/sm_vit_sasrec.py: CV_model_load = 'mae', nothing frozen): ViT-MAE with its embedding side
+    trainable -- patch projection and cls token; the position table is HF's fixed sin-cos one (requires_grad False) unless train_pos."""
+    from adapter4rec_amd.cv import Model, ViTMAEModel
+    sd, cfg, fx, _, (images, mask), noise = load_cv_variant('cv_mae_houlsby')
+    args = make_args(compute_dtype=dtype, adding_adapter_to='None', CV_model_load='vit-mae-base')
+    torch.manual_seed(31)
+    model = Model(args, 60, True, ViTMAEModel(GEOM))
+    model.cv_encoder.cv_proj = torch.nn.Linear(128, 64)
+    own = model.state_dict()
+    plain = {k: v for k, v in sd.items() if k in own}               # the backbone / user-encoder tensors of the fixture (its adapters are left out)
+    assert len(plain) > 20 and any('patch_embeddings.projection.weight' in k for k in plain)      # (wrapped sub-layers have other key names: those keep their seeded init)
+    model.load_state_dict(plain, strict=False)
+    sd2 = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    for n, p in model.named_parameters():
+        p.requires_grad = train_pos or 'position_embeddings' not in n
+    model.eval()
+    return model.to(device), sd2, dict(cfg, adapter_type='none', mae=True), images.to(device), mask.to(device), noise.to(device)
+
+
+def _check_all_grads(model, sd, cfg, images, mask, dev, noise=None, need_pos=True):
     from oracle import ref_cpu as R
     names = [n for n, p in model.named_parameters() if p.requires_grad]
-    assert any('patch_embeddings.projection.weight' in n for n in names) and any('position_embeddings' in n for n in names)
+    assert any('patch_embeddings.projection.weight' in n for n in names) and (not need_pos or any('position_embeddings' in n for n in names))
     out, grads = R.loss_and_grads(sd, names, images.cpu(), mask.cpu(), cfg)
-    loss = model(images, mask, dev)
+    loss = model(images, mask, dev) if noise is None else model(images, mask, dev, noise=noise)
     loss.backward()
     assert abs(loss.item() - float(out['loss'].detach())) < 1e-4 * max(1.0, float(out['loss'].detach()))
     params = dict(model.named_parameters())
@@ -341,6 +361,19 @@ def _check_all_grads(model, sd, cfg, images, mask, dev):
 
 def test_cv_host_logic_finetune_all(simulated):
     _check_all_grads(*build_cv_finetune_all(), 'cpu')
+
+
+@pytest.mark.parametrize('train_pos', [False, True])
+def test_cv_host_logic_mae_finetune_all(simulated, train_pos):
+    m, sd, cfg, images, mask, noise = build_cv_mae_finetune_all(train_pos=train_pos)
+    _check_all_grads(m, sd, cfg, images, mask, 'cpu', noise=noise, need_pos=train_pos)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('train_pos', [False, True])
+def test_cv_mae_finetune_all_fp32_vs_oracle(train_pos):
+    m, sd, cfg, images, mask, noise = build_cv_mae_finetune_all(device='cuda:0', train_pos=train_pos)
+    _check_all_grads(m, sd, cfg, images, mask, 'cuda:0', noise=noise, need_pos=train_pos)
 
 
 @pytest.mark.gpu

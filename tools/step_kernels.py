@@ -16,7 +16,7 @@ dtype = sys.argv[2] if len(sys.argv) > 2 else 'bf16'
 dev = torch.device('cuda:0')
 torch.cuda.set_device(0)
 B = bench.WORKLOADS[wl][1]
-if wl in ('vit_lora', 'mae_compacter'):
+if wl in ('vit_lora', 'mae_compacter', 'mae_pretrain'):
     model, opt = bench.build_cv_model(bench.make_cv_args(B, dtype, wl), dev)
     batches = bench.synth_image_batches(B, 2, dev, 1)
 else:
