@@ -2,6 +2,7 @@
 // small elementwise helpers.  One 64-lane wave owns one row of width H <= 1024 (H % 8 == 0): lane l
 // holds the 8-element groups l and l + 64, so every global access is 16 B (bf16) / 2 x 16 B (fp32)
 // per lane and the row statistics are two wave reductions.  All arithmetic is fp32.
+#include <cstdlib>
 #include "a4r_common.h"
 #include "../../include/a4r.h"
 
@@ -354,6 +355,114 @@ __global__ void __launch_bounds__(256) ln_bwd_lean_kernel(const T* __restrict__ 
             }
         }
         cv = nv; cd = nd;
+    }
+}
+
+// The same backward WITH the LayerNorm's parameter gradients (dgamma, dbeta) and the optional second output through another dropout mask --
+// trainable LayerNorms of un-adapted sub-layers: full fine-tuning (Pretraining/, --fine_tune_to all) and --finetune_layernorm.  ln_bwd_kernel below
+// ran these at 2.3 TB/s (82 us at 40 448 x 768: one row in flight per wave, up to 1024 workgroups each flushing 2 H column sums with atomics onto the
+// same addresses).  Here: the lean kernel's loads (gamma in LDS, the wave's next row requested under this row's arithmetic), EIGHT waves per
+// workgroup and one workgroup per CU, so that 256 workgroups flush instead of 1024 (0.4 M atomics instead of 1.6 M).
+template <typename T>
+__global__ void __launch_bounds__(512) ln_bwd_pg_kernel(const T* __restrict__ dy, int lddy, const T* __restrict__ vin, int ldv, const float* __restrict__ stats,
+                                                        const float* __restrict__ gamma, const T* __restrict__ dres, int lddres, T* __restrict__ dv, int lddv,
+                                                        float* __restrict__ dgamma, float* __restrict__ dbeta, int M, int H,
+                                                        T* __restrict__ dv2, int lddv2, uint64_t seed2, uint32_t site2, uint32_t thr2, float scale2) {
+    __shared__ __attribute__((aligned(16))) float gs[1024];
+    __shared__ float red[2][8][1024];
+    for (int c = threadIdx.x; c < 1024; c += 512) gs[c] = c < H ? gamma[c] : 0.f;
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, ng = H / 8;
+    const int row0 = blockIdx.x * 8 + wave, step = gridDim.x * 8;
+    const float invH = 1.f / (float)H;
+    float sg[MAXG][8], sb[MAXG][8];
+#pragma unroll
+    for (int g = 0; g < MAXG; ++g)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { sg[g][e] = 0.f; sb[g][e] = 0.f; }
+    RawRow<T> cv, cd;
+    float2 cst = make_float2(0.f, 0.f);
+    if (row0 < M) {
+        cv.request(vin + (size_t)row0 * ldv, ng, lane);
+        cd.request(dy + (size_t)row0 * lddy, ng, lane);
+        cst = *reinterpret_cast<const float2*>(stats + 2 * (size_t)row0);
+    }
+    for (int row = row0; row < M; row += step) {
+        const float mean = cst.x, rstd = cst.y;
+        RawRow<T> nv = cv, nd = cd, rr;
+        if (dres) rr.request(dres + (size_t)row * lddres, ng, lane);
+        if (row + step < M) {
+            nv.request(vin + (size_t)(row + step) * ldv, ng, lane);
+            nd.request(dy + (size_t)(row + step) * lddy, ng, lane);
+            cst = *reinterpret_cast<const float2*>(stats + 2 * (size_t)(row + step));
+        }
+        float c1 = 0.f, c2 = 0.f;
+#pragma unroll
+        for (int g = 0; g < MAXG; ++g) {
+            float ga[8], xh[8], dx[8];
+            cv.unpack(g, xh);
+            cd.unpack(g, dx);
+            lds_vec8(gs + (lane + 64 * g < ng ? lane + 64 * g : 0) * 8, ga);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float x = (xh[e] - mean) * rstd;        // (groups past the row: dy was requested as zero -> nothing accumulates)
+                sg[g][e] += dx[e] * x;
+                sb[g][e] += dx[e];
+                const float t = dx[e] * ga[e];
+                c1 += t;
+                c2 += t * x;
+            }
+        }
+        c1 = wave_sum(c1) * invH;
+        c2 = wave_sum(c2) * invH;
+        cv.forget();
+        cd.forget();
+#pragma unroll
+        for (int g = 0; g < MAXG; ++g) {
+            const int gi = lane + 64 * g;
+            if (gi < ng) {
+                float ga[8], xh[8], dx[8], r8[8];
+                cv.unpack(g, xh);
+                cd.unpack(g, dx);
+                lds_vec8(gs + gi * 8, ga);
+                if (dres) rr.unpack(g, r8);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    dx[e] = rstd * (dx[e] * ga[e] - c1 - (xh[e] - mean) * rstd * c2);
+                    if (dres) dx[e] += r8[e];
+                }
+                store_vec<T, 8>(dv + (size_t)row * lddv + gi * 8, dx);
+                if (dv2) {          // second output: dv through ANOTHER dropout mask (row_dropout's element -> lot map)
+                    if (thr2) {
+                        const uint64_t e0 = (uint64_t)row * (uint64_t)H + (uint64_t)gi * 8;
+                        const uint64_t h0 = a4r_hash64(seed2, site2, e0 >> 2), h1 = a4r_hash64(seed2, site2, (e0 >> 2) + 1);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            dx[e] = (((uint32_t)(h0 >> (16 * e)) & 0xffffu) >= thr2) ? dx[e] * scale2 : 0.f;
+                            dx[e + 4] = (((uint32_t)(h1 >> (16 * e)) & 0xffffu) >= thr2) ? dx[e + 4] * scale2 : 0.f;
+                        }
+                    }
+                    store_vec<T, 8>(dv2 + (size_t)row * lddv2 + gi * 8, dx);
+                }
+            }
+        }
+        cv = nv; cd = nd;
+    }
+#pragma unroll
+    for (int g = 0; g < MAXG; ++g) {
+        const int gi = lane + 64 * g;
+        if (gi < ng) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { red[0][wave][gi * 8 + e] = sg[g][e]; red[1][wave][gi * 8 + e] = sb[g][e]; }
+        }
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < H; c += 512) {
+        float a = 0.f, b = 0.f;
+#pragma unroll
+        for (int w = 0; w < 8; ++w) { a += red[0][w][c]; b += red[1][w][c]; }
+        if (dgamma) atomicAdd(dgamma + c, a);
+        if (dbeta) atomicAdd(dbeta + c, b);
     }
 }
 
@@ -719,6 +828,24 @@ extern "C" int a4r_ln_bwd(void* stream, const void* dy, int lddy, const void* v,
         else
             hipLaunchKernelGGL(ln_bwd_lean_kernel<float>, dim3(resident_grid<ln_bwd_lean_kernel<float>>(M)), dim3(256), 0, s, (const float*)dy, lddy, (const float*)v, ldv, stats, gamma,
                                (const float*)dres, lddres, (float*)dv, lddv, M, H);
+        return a4r_launch_status();
+    }
+    static const int pg_on = getenv("A4R_LN_PG") ? atoi(getenv("A4R_LN_PG")) != 0 : 1;          // (A/B runs: 0 = ln_bwd_kernel)
+    if (pg_on && wgb && !wdb && !add && !thr && M >= 2048) {     // trainable LayerNorm of an un-adapted sub-layer: parameter gradients on lean loads
+        int dev = 0, ncu = 256;
+        hipDeviceProp_t pr;
+        static int ncu_c = 0;
+        if (!ncu_c) ncu_c = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess && pr.multiProcessorCount > 0) ? pr.multiProcessorCount : 256;
+        ncu = ncu_c;
+        int g8 = (M + 7) / 8; if (g8 > ncu) g8 = ncu;
+        const uint32_t thr2 = a4r_thr16(drop2_p);
+        const float sc2 = a4r_keep_scale(drop2_p);
+        if (dtype == A4R_BF16)
+            hipLaunchKernelGGL(ln_bwd_pg_kernel<bf16_t>, dim3(g8), dim3(512), 0, s, (const bf16_t*)dy, lddy, (const bf16_t*)v, ldv, stats, gamma, (const bf16_t*)dres, lddres,
+                               (bf16_t*)dv, lddv, dgamma, dbeta, M, H, (bf16_t*)dv2, lddv2, drop2_seed, drop2_site, thr2, sc2);
+        else
+            hipLaunchKernelGGL(ln_bwd_pg_kernel<float>, dim3(g8), dim3(512), 0, s, (const float*)dy, lddy, (const float*)v, ldv, stats, gamma, (const float*)dres, lddres,
+                               (float*)dv, lddv, dgamma, dbeta, M, H, (float*)dv2, lddv2, drop2_seed, drop2_site, thr2, sc2);
         return a4r_launch_status();
     }
     if (grid > 1024) grid = 1024;    // 3-4 blocks per CU (VGPR-limited); bounds the column-sum atomics to 1024 x H per accumulator

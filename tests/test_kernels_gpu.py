@@ -737,6 +737,48 @@ def test_ln_bwd_second_output_through_dropout(dt):
 
 
 @pytest.mark.parametrize('dt', ['f32', 'bf16'])
+@pytest.mark.parametrize('M,H', [(2048, 768), (40448, 768), (2051, 384), (8 * 256 * 2 + 5, 1024), (16896, 768)])
+def test_ln_bwd_param_grads_lean_loads(dt, M, H):
+    """a4r_ln_bwd with dgamma / dbeta on >= 2048 rows (trainable LayerNorms of un-adapted sub-layers: full fine-tuning, --finetune_layernorm) runs
+    ln_bwd_pg_kernel (8-wave workgroups, one per CU, next row in flight): against the general kernel -- forced by an all-zero additive table -- and torch
+    fp32, with / without the residual-branch operand and the second output through a dropout mask (same mask as a4r_dropout_apply); gradients ACCUMULATE."""
+    from adapter4rec_amd import _lib as L
+    t = DT[dt]
+    v, dy, dres = rnd(M, H, dtype=t, seed=91, scale=2.0), rnd(M, H, dtype=t, seed=92), rnd(M, H, dtype=t, seed=93)
+    gamma, beta = rnd(H, seed=94) * 0.2 + 1, rnd(H, seed=95) * 0.1
+    zero_add = torch.zeros(1, H, device=dev())
+    y, st = torch.zeros(M, H, dtype=t, device=dev()), torch.zeros(M, 2, device=dev())
+    L.ln_fwd(v, gamma, beta, 1e-6, y, st)
+    vr = v.float().clone().requires_grad_(True)
+    gr, br = gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
+    torch.nn.functional.layer_norm(vr, (H,), gr, br, 1e-6).backward(dy.float())
+    for res, second in ((None, False), (dres, True)):
+        outs = []
+        for add in (None, zero_add):
+            dv, dh = torch.zeros(M, H, dtype=t, device=dev()), torch.zeros(M, H, dtype=t, device=dev())
+            dg, db = torch.full((H,), 0.5, device=dev()), torch.full((H,), -0.25, device=dev())
+            kw = dict(dv2=dh, drop2_p=0.1, drop2_site=5, drop2_seed=77) if second else {}
+            L.ln_bwd(dy, v, st, gamma, dv, dres=res, add=add, dgamma=dg, dbeta=db, **kw)
+            outs.append((dv, dh, dg, db))
+        (dv_n, dh_n, dg_n, db_n), (dv_g, dh_g, dg_g, db_g) = outs
+        tol = dict(rtol=1e-5, atol=1e-5) if dt == 'f32' else dict(rtol=2 ** -7, atol=2 ** -7)
+        torch.testing.assert_close(dv_n.float(), dv_g.float(), **tol)
+        scale_ = float(dg_g.abs().max()) + 1.0
+        torch.testing.assert_close(dg_n, dg_g, rtol=1e-4, atol=2e-5 * scale_ * (M / 2048) ** 0.5)
+        torch.testing.assert_close(db_n, db_g, rtol=1e-4, atol=2e-5 * scale_ * (M / 2048) ** 0.5)
+        close(dv_n, vr.grad + (res.float() if res is not None else 0), t, f'ln bwd pg M={M} H={H}', atol32=3e-4)
+        if dt == 'f32':
+            torch.testing.assert_close(dg_n, 0.5 + gr.grad, rtol=2e-4, atol=2e-4 * scale_)
+            torch.testing.assert_close(db_n, -0.25 + br.grad, rtol=2e-4, atol=2e-4 * scale_)
+        if second:
+            assert torch.equal(dh_n == 0, dh_g == 0) and abs((dh_n == 0).float().mean().item() - 0.1) < 0.02
+            torch.testing.assert_close(dh_n.float(), dh_g.float(), **tol)
+            ref2 = torch.zeros(M, H, dtype=t, device=dev())
+            L.dropout_apply(dv_n, ref2, 0.1, 5, 77)
+            assert torch.equal(ref2 == 0, dh_n == 0)
+
+
+@pytest.mark.parametrize('dt', ['f32', 'bf16'])
 def test_gather_scatter_rows(dt):
     from adapter4rec_amd import _lib as L
     t = DT[dt]
