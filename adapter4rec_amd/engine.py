@@ -1043,7 +1043,7 @@ class TransRecEngine:
             L.gemm_nt(x8[0], blk.wqkv8, bufs['qkv'], bias=blk.bqkv, M=M, scale_a=x8[1], scale_b=blk.wqkv8s)
         else:
             L.gemm_nt(x, blk.wqkv, bufs['qkv'], bias=blk.bqkv, M=M)
-        if 'xin' in bufs:
+        if 'xin' in bufs and x.data_ptr() != bufs['xin'].data_ptr():
             L.gather_rows(x, bufs['xin'], M, 1)      # LoRA backward needs the block input (t = x A^T, dA = dt^T x)
         if getattr(blk, 'long', False):
             assert key_mask is None
@@ -1433,6 +1433,12 @@ class TransRecEngine:
         self._twin.clear()
         key_mask = self._buf('kmask', n_items, S, torch.float32)          # filled by a4r_embed_ln from the mask half of the rows
         x = self._buf('xa', M, H, self.T)
+        # training with kept block inputs (LoRA, trainable q / k / v, the parallel placement): the producer writes a layer's input straight into
+        # that layer's kept buffer instead of the layer copying it (one [M, H] copy per layer)
+        direct_xin = lambda j: (saved is not None and j < len(self.bert_blocks) and 'xin' in saved[j] and 'y2' not in saved[j]
+                                and tuple(saved[j]['xin'].shape) == (M, H))
+        if direct_xin(0):
+            x = saved[0]['xin']
         keep = self.train_emb and saved is not None
         word = self.emb_word
         if self.prompt_n:                          # refresh the learned rows, point the first n ids of every title at them
@@ -1451,7 +1457,7 @@ class TransRecEngine:
                    stats_out=self._buf('emb_st', M, 2, torch.float32) if keep else None, key_mask_out=key_mask)
         self._news = news
         other = self._buf('xb', M, H, self.T)
-        xa_buf = x
+        xa_buf = self._buf('xa', M, H, self.T)     # (the transient buffer, also when the embedding went straight into layer 0's kept input)
         Ip = pad_to(n_items, 128)
         cls = self._buf('cls', Ip, H, self.T)
         last = len(self.bert_blocks) - 1
@@ -1467,6 +1473,8 @@ class TransRecEngine:
                 x = bufs['y2']
             else:
                 out = other if x.data_ptr() != other.data_ptr() else xa_buf       # a transient buffer that is not the current input (x may be a kept y2)
+                if direct_xin(i + 1) and not (self.fp8 and i != last):
+                    out = saved[i + 1]['xin']
                 x8 = self._block_forward(blk, x, key_mask, n_items, M, bufs, train, seed, out, x8=x8, want8=w8)
                 x = out
             if not cmode:
