@@ -131,6 +131,58 @@ def _device_sampler_run(tmp_path, monkeypatch):
     assert len(a['eval']) >= 3
 
 
+def _pretrain_then_downstream(tmp_path, monkeypatch):
+    """The reference's two-stage flow through the one entry point: (1) the Pretraining/ configuration -- no adapters, nothing frozen (`--fine_tune_to
+    all --adding_adapter_to None`, Pretraining/Text/script/sm_base_sasrec.py) -- trains every backbone weight and saves epoch checkpoints with PLAIN key
+    names; (2) the Downstream/ configuration loads that checkpoint by `--pretrained_model_dir / --pretrained_model_name` (run.py:376-382), freezes it,
+    injects Houlsby adapters and trains those only.  Asserted: stage 1's loss falls and its checkpoint holds un-adapted keys; stage 2 starts from
+    stage 1's weights (its first evaluation = stage 1's last one: fresh adapters with zero-initialised up-projections ... are NOT zero in the
+    reference either, so only 'finite and close'), leaves the backbone untouched and lowers its own loss."""
+    import glob
+    data = write_toy(str(tmp_path))
+    cp = os.path.join(str(tmp_path), 'pretrained_models', 'bert', 'bert_tiny', 'config.json')
+    c = json.load(open(cp))
+    c.update(hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0)
+    json.dump(c, open(cp, 'w'))
+    monkeypatch.chdir(os.path.join(str(tmp_path), 'work'))
+    common = ['--root_data_dir', data, '--dataset', 'toy', '--behaviors', 'behaviors.tsv', '--news', 'news.tsv', '--mode', 'train',
+              '--bert_model_load', 'bert_tiny', '--freeze_paras_before', '0', '--embedding_dim', '64', '--batch_size', '16', '--num_workers', '0',
+              '--logging_num', '3', '--testing_num', '1', '--max_seq_len', '20', '--min_seq_len', '5', '--drop_rate', '0', '--adapter_dropout_rate', '0']
+    a = dict(loss=[], batch=[], eval=[])
+    _run(common + ['--adapter_type', 'none', '--adding_adapter_to', 'None', '--fine_tune_to', 'all', '--pretrained_model_name', 'None',
+                   '--lr', '1e-3', '--fine_tune_lr', '2e-4', '--label_screen', 'pre', '--epoch', '3'], monkeypatch, a)
+    assert all(np.isfinite(a['loss'])) and np.mean(a['loss'][-3:]) < np.mean(a['loss'][:3]), a['loss']
+    ck = sorted(glob.glob(os.path.join(str(tmp_path), 'work', 'checkpoint_*', 'cpt_*', 'epoch-3.pt')))
+    assert len(ck) == 1, ck
+    sd1 = torch.load(ck[0], map_location='cpu')['model_state_dict']
+    assert not any('adapter' in k for k in sd1) and any(k.endswith('attention.output.dense.weight') for k in sd1)
+    b = dict(loss=[], batch=[], eval=[])
+    _run(common + ['--adapter_type', 'houslby', '--adding_adapter_to', 'all', '--fine_tune_to', 'None', '--pretrained_model_dir', os.path.dirname(ck[0]),
+                   '--pretrained_model_name', 'epoch-3', '--lr', '1e-3', '--adapter_bert_lr', '1e-3', '--adapter_sasrec_lr', '1e-3',
+                   '--label_screen', 'down', '--epoch', '2'], monkeypatch, b)
+    assert all(np.isfinite(b['loss'])) and np.mean(b['loss'][-3:]) < np.mean(b['loss'][:3]), b['loss']
+    ck2 = [f for f in sorted(glob.glob(os.path.join(str(tmp_path), 'work', 'checkpoint_*', 'cpt_*', 'epoch-2.pt')))
+           if os.path.dirname(f) != os.path.dirname(ck[0])]
+    assert len(ck2) == 1, ck2
+    sd2 = torch.load(ck2[0], map_location='cpu')['model_state_dict']
+    assert any('adapter' in k for k in sd2)
+    frozen = [k for k in sd1 if k.endswith('attention.self.query.weight') or k.endswith('intermediate.dense.weight') or 'word_embeddings' in k]
+    assert len(frozen) >= 5
+    for k in frozen:                                     # the pretrained backbone came through stage 2 bit for bit
+        assert torch.equal(sd1[k], sd2[k]), k
+    assert abs(b['loss'][0] - a['loss'][-1]) < 1.0       # stage 2 starts where stage 1 stopped (fresh adapters perturb it a little)
+
+
+@pytest.mark.gpu
+def test_text_run_pretrain_then_downstream_gpu(tmp_path, monkeypatch):
+    _pretrain_then_downstream(tmp_path, monkeypatch)
+
+
+def test_text_run_pretrain_then_downstream_simulated(tmp_path, monkeypatch):
+    _simulate(monkeypatch)
+    _pretrain_then_downstream(tmp_path, monkeypatch)
+
+
 @pytest.mark.gpu
 def test_text_run_device_sampler_gpu(tmp_path, monkeypatch):
     """--device_sampler 1 through run.py on the GPU: batches drawn by DeviceTrainSampler on the device (no DataLoader), three epochs of
