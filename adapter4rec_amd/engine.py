@@ -1561,15 +1561,84 @@ class TransRecEngine:
         return out[:B * Tn].view(B, Tn, E).clone()
 
     # ------------------------------------------------------------------ public: training step
+    # Item slots whose embeddings no line of the model ever reads (SURVEY 8a "results-neutral savings"): per user the batch carries L positives
+    # and L negatives in the order p0 n0 p1 n1 ... (dataset.py:24-49 -> view(-1, 2S), run.py:591).  Model.forward (model.py:48-70) scores
+    # neg[:, :-1]: the LAST negative (which the dataset fills with the pad item) is dropped -- slot 2L - 1.  ModelCPC.forward (:113-135) scores the
+    # last position only: of the negatives just n[L-2] is read.  Those items are not encoded (1 of 42 / 20 of 42 per user): the kept rows are
+    # gathered in front of the item tower, their embeddings scattered back into the full [B, L, 2] layout (the other rows stay zero: never read,
+    # their gradients are exactly zero) and the gradient rows gathered again for the tower's backward.  Every kept item sees the same arithmetic
+    # as before (rows are independent through the tower); with dropout ON the masks are indexed by the compact row, i.e. another, equally valid
+    # draw.  A4R_SKIP_UNUSED_ITEMS=0: encode all 2L slots (A/B runs).
+
+    def _kept_rows(self, B):
+        """Rows of the compact item batch: n_c; None when every slot is encoded.  CPC drops 20 of 42 items: always worth it (RoBERTa + Pfeiffer + CPC
+        16.97 -> 9.97 ms per step).  SASRec drops 1 of 42: the tower's large launches cost whole ROUNDS of 256-row tiles on the CUs, so 2.4 % fewer
+        rows pay only where they remove a round (ViT-B/16 at 8 users: 259 -> 253 row panels = 4 -> 3 rounds of the H-wide GEMMs, 29.2 -> 26.9 ms); at
+        the headline's 158 -> 154 panels (2 rounds either way) the step was 1.5 % SLOWER with the gather / scatter launches added: all slots stay."""
+        if _os.environ.get('A4R_SKIP_UNUSED_ITEMS', '1') == '0' or self.Lseq < 3:
+            return None
+        if self.arch == 'cpc':
+            return B * (self.Lseq + 1)
+        n_c = B * (2 * self.Lseq - 1)
+        if _os.environ.get('A4R_SKIP_UNUSED_ITEMS') == '2':           # (A/B runs: compact whatever the round count)
+            return n_c
+        ncu = 256
+        if torch.device(self.dev).type == 'cuda':
+            ncu = torch.cuda.get_device_properties(self.dev).multi_processor_count
+        ntn = max(1, self.H // 256)
+        rounds = lambda n: -(-(pad_to(n * self.S, 256) // 256 * ntn) // ncu)
+        return n_c if rounds(n_c) < rounds(B * 2 * self.Lseq) else None
+
+    def _slots_copy(self, full, comp, B, to_compact):
+        """Between the full slot layout `full` [>= B*2L, W] and the compact one `comp` [>= n_c, W] (fp32 views, W % 4 == 0): strided row copies only.
+        SASRec: the first 2L - 1 slots of every user (a [B, (2L-1) W] block of the [B, 2L W] view); CPC: all positives (every second row), then n[L-2]."""
+        Ls, W = self.Lseq, full.shape[1]
+        if self.arch == 'cpc':
+            f2 = full[2 * Ls - 3:]
+            if to_compact:
+                L.gather_rows(full, comp, B * Ls, 2)
+                L.gather_rows(f2, comp[B * Ls:], B, 2 * Ls)
+            else:
+                L.scatter_rows(comp, full, B * Ls, 2)
+                L.scatter_rows(comp[B * Ls:], f2, B, 2 * Ls)
+            return
+        k = (2 * Ls - 1) * W
+        fv = full[:B * 2 * Ls].view(B, 2 * Ls * W)[:, :k]
+        cv = comp[:B * (2 * Ls - 1)].view(B, k)
+        if to_compact:
+            L.gather_rows(fv, cv, B, 1)
+        else:
+            L.gather_rows(cv, fv, B, 1)
+
     def train_forward(self, sample_items, log_mask):
         """sample_items [B*L*2, 2S] int64, log_mask [B, L-1] -> loss (0-d fp32 device tensor)."""
         L.require_gpu(sample_items, log_mask)
         train = self.model.training
-        n_items = sample_items.shape[0]
-        B = n_items // (2 * self.Lseq)
-        assert B * 2 * self.Lseq == n_items and log_mask.shape == (B, self.Lseq - 1)
+        n_full = sample_items.shape[0]
+        B = n_full // (2 * self.Lseq)
+        assert B * 2 * self.Lseq == n_full and log_mask.shape == (B, self.Lseq - 1)
         news = sample_items.contiguous()
         lm = log_mask.float().contiguous()
+        n_items = n_full
+        n_c = self._kept_rows(B)
+        row_bytes = news[0].numel() * news.element_size() if n_full else 0
+        noise = getattr(self, 'next_noise', None)  # (ViT-MAE: explicit masking noise comes per item of the FULL layout)
+        if noise is not None and n_c is not None:
+            noise = noise.to(self.dev, torch.float32).contiguous()
+            if noise.dim() != 2 or noise.shape[0] != n_full or (noise.shape[1] * 4) % 16:
+                n_c = None
+        if n_c is not None and row_bytes % 16 == 0:
+            if noise is not None:
+                nzc = self._buf('noise_c', n_c, noise.shape[1], torch.float32)
+                self._slots_copy(noise, nzc, B, True)
+                self.next_noise = nzc
+            src = news.view(n_full, -1).view(torch.float32)
+            comp = self._buf('items_c', n_c, src.shape[1], torch.float32)
+            self._slots_copy(src, comp, B, True)
+            news = comp.view(news.dtype).view((n_c,) + tuple(news.shape[1:]))
+            n_items = n_c
+        else:
+            n_c = None
         self._pre_forward(n_items)
         self.pack_trainables()
         self.step_count += 1
@@ -1585,6 +1654,11 @@ class TransRecEngine:
             self._saved_M, self._saved_Mu = M, Mu
         saved_b, saved_s = self._saved_bert, self._saved_sas
         emb, pre, key_mask, M = self._encode(news, n_items, train, seed, saved_b)
+        if n_c is not None:                        # back to the [B, L, 2] slot layout the head indexes
+            emb_c = emb
+            emb = self._buf('emb_full', pad_to(n_full, 128), self.E, torch.float32)
+            L.zero(emb)
+            self._slots_copy(emb, emb_c, B, False)
         xin = self._buf('sxin', Mu, self.E, torch.float32)
         L.take_inputs(emb, xin, B, self.Lseq, self.E)
         prec, Mu = self._user_forward(xin, lm, B, train, seed, saved_s)
@@ -1593,7 +1667,7 @@ class TransRecEngine:
         ws = self._buf('lossws', 1, 4, torch.float32)
         L.zero(ws)
         L.score_bce_fwd(emb, prec, lm, pos, neg, ws, B, self.Lseq, self.E, self.arch == 'cpc')
-        self._ctx = dict(B=B, n_items=n_items, M=M, Mu=Mu, seed=seed, train=train, lm=lm, key_mask=key_mask, emb=emb, pre=pre,
+        self._ctx = dict(B=B, n_items=n_items, n_full=n_full, M=M, Mu=Mu, seed=seed, train=train, lm=lm, key_mask=key_mask, emb=emb, pre=pre,
                          prec=prec, xin=xin, pos=pos, neg=neg, ws=ws, saved_b=saved_b, saved_s=saved_s)
         return ws[0, 0].clone()
 
@@ -1698,11 +1772,12 @@ class TransRecEngine:
         if grad_out is not None:
             grad_out = grad_out.detach().to(torch.float32).reshape(1)
         B, n_items, M, Mu, seed = c['B'], c['n_items'], c['M'], c['Mu'], c['seed']
+        n_full = c.get('n_full', n_items)          # the head works on the full slot layout, the item tower on the kept rows (train_forward)
         E, Tn = self.E, self.Lseq - 1
         train = c['train']
-        Ip = pad_to(n_items, 128)
+        Ip = pad_to(n_full, 128)
         d_prec = self._buf_tail0('d_prec', Mu, E, torch.float32, B * Tn)     # score_bce_bwd writes the real rows only
-        d_emb = self._buf_tail0('d_emb', Ip, E, torch.float32, n_items)
+        d_emb = self._buf_tail0('d_emb', Ip, E, torch.float32, n_full)
         L.score_bce_bwd(c['emb'], c['prec'], c['lm'], c['pos'], c['neg'], c['ws'], 1.0, d_prec, d_emb, B, self.Lseq, E, self.arch == 'cpc',
                         scale_dev=grad_out)
         # SASRec blocks, last to first
@@ -1743,6 +1818,11 @@ class TransRecEngine:
             self.g_pos_emb()[:Tn].add_(d_in[:B * Tn].view(B, Tn, E).sum(0))
         L.emb_grad_add_inputs(d_in, d_emb, B, self.Lseq, E)
         self._exchange('user')
+        if n_full != n_items:
+            Ip = pad_to(n_items, 128)
+            d_emb_c = self._buf_tail0('d_emb_c', Ip, E, torch.float32, n_items)
+            self._slots_copy(d_emb, d_emb_c, B, True)
+            d_emb = d_emb_c
         self._items_backward(c, d_emb, Ip)
         self._wgrad_join()
         self._flush_corners()

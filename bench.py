@@ -643,7 +643,10 @@ def main():
             'dtype': a.dtype, 'data': WORKLOADS[wl][3],
             'config': {'workload': WORKLOADS[wl][2], 'baseline_config': WORKLOADS[wl][0] + (' in bf16 (run with --dtype fp8 for its fp8 encoder)' if wl == 'mae_compacter' and a.dtype != 'fp8' else ''),
                        'users_per_gpu': a.batch, 'global_batch': world * a.batch, 'seq_len': 23,
-                       'tokens_per_item': eng.S, 'items_per_user': 42, 'parallelism': f'dp{world}',
+                       'tokens_per_item': eng.S, 'items_per_user': 42,
+                       # item slots the model reads: Model.forward drops every user's last negative, ModelCPC.forward reads one negative only; the
+                       # engine does not encode unread slots where that removes work (engine.py: _kept_rows; A4R_SKIP_UNUSED_ITEMS=0: all 42)
+                       'items_encoded_per_user': (eng._kept_rows(a.batch) or 42 * a.batch) // a.batch, 'parallelism': f'dp{world}',
                        'path': 'public: optimizer.zero_grad(); FlatDDP(model)(items, mask); loss.backward(); FusedAdam.step()'},
             'rccl_ranks': rccl_ranks, 'allreduce_bytes_per_step': int(eng.flat_g.numel() * 4) if world > 1 else 0, 'allreduce_us': ar_us,
             'ms_per_step_ranks': rank_ms, 'ms_per_step_spread': round(max(rank_ms) - min(rank_ms), 3),

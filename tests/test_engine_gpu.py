@@ -60,6 +60,32 @@ def build(name, dtype='fp32'):
     return root, args, sd, cfg, fx, items.to('cuda:0'), mask.to('cuda:0')
 
 
+@pytest.mark.parametrize('name', ['houlsby', 'houlsby_cpc', 'pfeiffer'])
+def test_step_fp32_unused_item_slots_not_encoded(name, monkeypatch):
+    """A4R_SKIP_UNUSED_ITEMS=2 forces the compact item batch (engine.py: _kept_rows -- the last negative of every user under SASRec, all negatives
+    but one under CPC are never read by Model.forward / ModelCPC.forward and are not encoded): loss, scores and every trainable gradient still
+    equal the reference's numbers; with =0 (every slot encoded) likewise -- the two paths agree."""
+    res = {}
+    for mode in ('2', '0'):
+        monkeypatch.setenv('A4R_SKIP_UNUSED_ITEMS', mode)
+        root, args, sd, cfg, fx, items, mask = build(name, 'fp32')
+        inner = getattr(root, 'model', root)
+        eng = inner._engine()
+        assert (eng._kept_rows(mask.shape[0]) is not None) == (mode == '2')
+        loss = root(items, mask, 0)
+        loss.backward()
+        assert abs(loss.item() - float(fx['loss'])) < 1e-4, (mode, loss.item(), float(fx['loss']))
+        params = dict(root.named_parameters())
+        for k in fx['trainable']:
+            k = str(k)
+            ref = fx['grad/' + k]
+            np.testing.assert_allclose(params[k].grad.cpu().numpy(), ref, atol=1e-6 + 1e-4 * np.abs(ref).max(), rtol=0, err_msg=f'{mode} {k}')
+        res[mode] = (loss.item(), {str(k): params[str(k)].grad.clone() for k in fx['trainable']})
+    assert abs(res['2'][0] - res['0'][0]) < 1e-5
+    for k, g in res['2'][1].items():
+        assert float((g - res['0'][1][k]).abs().max()) <= 1e-6 + 2e-5 * float(g.abs().max()), k
+
+
 @pytest.mark.parametrize('name', list(ARGS))
 def test_step_fp32_vs_reference_golden(name):
     root, args, sd, cfg, fx, items, mask = build(name, 'fp32')

@@ -56,6 +56,24 @@ def test_host_logic_forward_backward(simulated, name):
         np.testing.assert_allclose(params[k].grad.numpy(), ref, atol=1e-6 + 1e-4 * np.abs(ref).max(), rtol=0, err_msg=k)
 
 
+@pytest.mark.parametrize('name', ['houlsby', 'houlsby_cpc', 'roberta_cpc_pfeiffer'])
+def test_host_logic_unused_item_slots_not_encoded(simulated, monkeypatch, name):
+    """The compact item batch forced on (A4R_SKIP_UNUSED_ITEMS=2; CPC compacts by itself): the item slots Model.forward / ModelCPC.forward never
+    read are not encoded, and loss and every gradient still equal the reference's fixture (same checks as test_host_logic)."""
+    monkeypatch.setenv('A4R_SKIP_UNUSED_ITEMS', '2')
+    root, args, fx, items, mask = build_cpu(name)
+    inner = getattr(root, 'model', root)
+    assert inner._engine()._kept_rows(mask.shape[0]) is not None
+    loss = root(items, mask, 'cpu')
+    loss.backward()
+    assert abs(loss.item() - float(fx['loss'])) < 1e-4
+    params = dict(root.named_parameters())
+    for k in fx['trainable']:
+        k = str(k)
+        ref = fx['grad/' + k]
+        np.testing.assert_allclose(params[k].grad.numpy(), ref, atol=1e-6 + 1e-4 * np.abs(ref).max(), rtol=0, err_msg=k)
+
+
 @pytest.mark.parametrize('name', ['houlsby', 'compacter'])
 def test_host_logic_fused_adam(simulated, name):
     from adapter4rec_amd.inject import optimizer_groups
