@@ -12,7 +12,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('A4R_LIB_PATH') or os.path.join(_HERE, 'liba4r_hip.so')    # A4R_LIB_PATH: A/B builds (tools/), same C ABI
 
-ABI_VERSION = 405          # = A4R_ABI_VERSION of include/a4r.h (tests/test_abi_cpu.py compares the two)
+ABI_VERSION = 406          # = A4R_ABI_VERSION of include/a4r.h (tests/test_abi_cpu.py compares the two)
 BF16, F32, FP8 = 0, 1, 2
 ACT_NONE, ACT_RELU, ACT_GELU, ACT_GELU_TANH, ACT_LEAKY = 0, 1, 2, 3, 4
 DACT_MUL = 15
@@ -23,7 +23,7 @@ ACT_BY_NAME = {'none': 0, 'relu': 1, 'RELU': 1, 'gelu': 2, 'GELU': 2, 'gelu_new'
 
 EXPORTS = [
     'a4r_version', 'a4r_gemm_nt', 'a4r_gemm_tn', 'a4r_gemm_tn_bias', 'a4r_gemm_tn_multi', 'a4r_gemm_tn2', 'a4r_colsum', 'a4r_attn_fwd', 'a4r_attn_bwd', 'a4r_embed_ln',
-    'a4r_ln_fwd', 'a4r_ln_bwd', 'a4r_gather_rows', 'a4r_scatter_rows', 'a4r_act_bwd_f32', 'a4r_score_bce_fwd',
+    'a4r_ln_fwd', 'a4r_ln_bwd', 'a4r_gather_rows', 'a4r_scatter_rows', 'a4r_rows_idx_copy', 'a4r_act_bwd_f32', 'a4r_score_bce_fwd',
     'a4r_score_bce_bwd', 'a4r_emb_grad_add_inputs', 'a4r_take_inputs', 'a4r_adam_step', 'a4r_pack_matrices',
     'a4r_eval_rank', 'a4r_dropout_apply', 'a4r_gemm_variant', 'a4r_gemm_tail_plan', 'a4r_gemm_tail_max', 'a4r_gemm_rows_256', 'a4r_adapter_ln_fwd', 'a4r_adapter_ln_bwd', 'a4r_ln_fwd_fp8', 'a4r_ln_fwd_sum', 'a4r_quant_rows_fp8', 'a4r_lora_merge', 'a4r_lora_merge_batch', 'a4r_lora_bwd_fused', 'a4r_lora_bwd_fused_ws_floats', 'a4r_phm_build', 'a4r_phm_bwd', 'a4r_unpack_add', 'a4r_memset_zero',
     'a4r_sasrec_block_fwd', 'a4r_sasrec_block_bwd', 'a4r_scatter_rows_fill', 'a4r_attn_long_fwd', 'a4r_attn_long_bwd', 'a4r_patchify', 'a4r_vit_assemble', 'a4r_resample_u8', 'a4r_embed_bwd', 'a4r_mae_keep_indices',
@@ -454,6 +454,15 @@ def gather_rows(src, dst, n, row_step):
     require_gpu(src, dst)
     _check(lib().a4r_gather_rows(_stream(), _p(src), C.c_int(_ld(src)), _p(dst), C.c_int(_ld(dst)), C.c_int(n), C.c_int(row_step),
                                  C.c_int(src.shape[1]), C.c_int(_dt(src))), 'a4r_gather_rows')
+
+
+def rows_idx_copy(src, dst, idx, n, scatter=False):
+    """dst[r] = src[idx[r]] (scatter: dst[idx[r]] = src[r]) for r < n; 2-D tensors of one dtype, row bytes a multiple of 16; idx int32 on the device."""
+    require_gpu(src, dst, idx)
+    assert src.dim() == 2 and dst.dim() == 2 and src.dtype == dst.dtype and src.shape[1] == dst.shape[1] and idx.dtype == torch.int32 and idx.numel() >= n
+    es = src.element_size()
+    _check(lib().a4r_rows_idx_copy(_stream(), _p(src), C.c_int64(src.stride(0) * es), _p(dst), C.c_int64(dst.stride(0) * es), _p(idx), C.c_int(n),
+                                   C.c_int64(src.shape[1] * es), C.c_int(int(scatter))), 'a4r_rows_idx_copy')
 
 
 def scatter_rows(src, dst, n, row_step):

@@ -613,6 +613,20 @@ __global__ void __launch_bounds__(256) ln_bwd_kernel(const T* __restrict__ dy, i
 }
 
 // ------------------------------------------------------------------ row gather / scatter, elementwise
+// out[r, :] = in[idx[r], :] (gather) or out[idx[r], :] = in[r, :] (scatter; idx without repeats), 16-byte pieces: the rows of the item slots a batch
+// really uses (ragged histories: the pad slots of short users are not encoded, engine.py train_forward)
+__global__ void __launch_bounds__(256) rows_idx_copy_kernel(const char* __restrict__ in, size_t ldi_b, char* __restrict__ out, size_t ldo_b,
+                                                            const int32_t* __restrict__ idx, int n, int pieces, int scatter) {
+    const size_t total = (size_t)n * pieces;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const size_t r = i / pieces;
+        const size_t c = (i - r * pieces) * 16;
+        const size_t other = (size_t)idx[r];
+        const size_t ri = scatter ? r : other, ro = scatter ? other : r;
+        *reinterpret_cast<uint4*>(out + ro * ldo_b + c) = *reinterpret_cast<const uint4*>(in + ri * ldi_b + c);
+    }
+}
+
 template <typename T, bool SCATTER>
 __global__ void __launch_bounds__(256) rows_copy_kernel(const T* __restrict__ in, int ldi, T* __restrict__ out, int ldo,
                                                         int n, int row_step, int H) {
@@ -878,6 +892,18 @@ static int rows_copy(void* stream, const void* in, int ldi, void* out, int ldo, 
         if (scatter) hipLaunchKernelGGL((rows_copy_kernel<float, true>), dim3(grid), dim3(256), 0, s, (const float*)in, ldi, (float*)out, ldo, n, row_step, H);
         else hipLaunchKernelGGL((rows_copy_kernel<float, false>), dim3(grid), dim3(256), 0, s, (const float*)in, ldi, (float*)out, ldo, n, row_step, H);
     }
+    return a4r_launch_status();
+}
+extern "C" int a4r_rows_idx_copy(void* stream, const void* in, int64_t ldi_bytes, void* out, int64_t ldo_bytes, const int32_t* idx, int n,
+                                 int64_t row_bytes, int scatter) {
+    if (!in || !out || !idx || n <= 0 || row_bytes <= 0 || row_bytes % 16 || ldi_bytes % 16 || ldo_bytes % 16 || ldi_bytes < row_bytes || ldo_bytes < row_bytes ||
+        misaligned(in) || misaligned(out) || row_bytes / 16 > 0x7fffffff)
+        return A4R_EINVAL;
+    const int pieces = (int)(row_bytes / 16);
+    const size_t total = (size_t)n * pieces;
+    int grid = (int)((total + 255) / 256); if (grid > 2048) grid = 2048;
+    hipLaunchKernelGGL(rows_idx_copy_kernel, dim3(grid), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), (const char*)in, (size_t)ldi_bytes, (char*)out,
+                       (size_t)ldo_bytes, idx, n, pieces, scatter ? 1 : 0);
     return a4r_launch_status();
 }
 extern "C" int a4r_gather_rows(void* stream, const void* in, int ldi, void* out, int ldo, int n, int row_step, int H, int dtype) {

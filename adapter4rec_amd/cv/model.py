@@ -102,6 +102,11 @@ class _CVBase(nn.Module):
     def forward(self, sample_items, log_mask, local_rank=None, noise=None):
         eng = self._engine()
         eng.next_noise = noise                   # ViT-MAE: explicit masking noise [n, n_patches] (parity runs); None = drawn on device
+        if not log_mask.is_cuda:                 # host log_mask: the batch's pad structure, read without a sync (model/model.py)
+            eng.host_log_mask = log_mask
+            log_mask = log_mask.to(eng.dev, non_blocking=True)
+        else:
+            eng.host_log_mask = None
         if torch.is_grad_enabled() and eng.n_trainable:
             return _NativeLoss.apply(eng, sample_items, log_mask, *eng.trainable_params)
         return eng.train_forward(sample_items, log_mask)

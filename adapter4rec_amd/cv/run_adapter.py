@@ -126,8 +126,7 @@ def train(args, use_modal, local_rank, Log_file, Log_screen, model_dir, start_ti
         train_dl.sampler.set_epoch(now_epoch)
         for sample_items, log_mask in train_dl:
             sample_items = sample_items.view(-1, R, R, 3)              # uint8 HWC (the reference: .view(-1, 3, R, R) of fp32)
-            log_mask = log_mask.to(local_rank, non_blocking=True)
-            optimizer.zero_grad()
+            optimizer.zero_grad()                                      # (log_mask stays on the host: Model.forward uploads it, the engine reads the pad slots from it)
             bz_loss = model(sample_items, log_mask, local_rank)
             loss += bz_loss.detach()
             bz_loss.backward()

@@ -1589,9 +1589,45 @@ class TransRecEngine:
         rounds = lambda n: -(-(pad_to(n * self.S, 256) // 256 * ntn) // ncu)
         return n_c if rounds(n_c) < rounds(B * 2 * self.Lseq) else None
 
-    def _slots_copy(self, full, comp, B, to_compact):
+    host_log_mask = None           # set by Model.forward when run.py hands log_mask over on the host
+
+    def _kept_index(self, hm, B):
+        """Ragged histories: BuildTrainDataset pads a short user's positives AND negatives with item 0 (dataset.py:24-49) and neither
+        forward reads those slots -- position p's input is masked out of every valid query's attention, pad positions are outside the loss.  From the
+        HOST copy of log_mask [B, L-1]: rows (int32, ascending) of the slots that ARE read -- positive p when it is an input (mask[p]) or a target
+        (mask[p-1]), negative p when mask[p] (CPC: the inputs, the last target, negative L-2).  None: every slot is read (the static rule decides)."""
+        import numpy as np
+        lm = (hm.detach().reshape(B, self.Lseq - 1).numpy() != 0)
+        Ls, T = self.Lseq, self.Lseq - 1
+        pos = np.zeros((B, Ls), bool)
+        neg = np.zeros((B, Ls), bool)
+        pos[:, :T] |= lm
+        if self.arch == 'cpc':
+            pos[:, Ls - 1] = True
+            neg[:, T - 1] = True
+        else:
+            pos[:, 1:] |= lm
+            neg[:, :T] = lm
+        if self.sas_kads:              # KAdapterBlock attends with an all-ones mask (modules.py:175-185): pad positions' inputs DO reach valid outputs
+            pos[:] = True
+        need = np.stack([pos, neg], 2).reshape(-1)
+        n_c = int(need.sum())
+        n_static = self._kept_rows(B)
+        if n_c == 0 or n_c >= (n_static if n_static is not None else B * 2 * Ls):
+            return None
+        idx = torch.from_numpy(np.nonzero(need)[0].astype(np.int32))
+        return idx.to(self.dev, non_blocking=True), n_c
+
+    def _slots_copy(self, full, comp, B, to_compact, idx=None):
         """Between the full slot layout `full` [>= B*2L, W] and the compact one `comp` [>= n_c, W] (fp32 views, W % 4 == 0): strided row copies only.
-        SASRec: the first 2L - 1 slots of every user (a [B, (2L-1) W] block of the [B, 2L W] view); CPC: all positives (every second row), then n[L-2]."""
+        SASRec: the first 2L - 1 slots of every user (a [B, (2L-1) W] block of the [B, 2L W] view); CPC: all positives (every second row), then n[L-2].
+        idx = (device int32 rows, n_c): the indexed form for ragged batches (a4r_rows_idx_copy)."""
+        if idx is not None:
+            if to_compact:
+                L.rows_idx_copy(full, comp, idx[0], idx[1])
+            else:
+                L.rows_idx_copy(comp, full, idx[0], idx[1], scatter=True)
+            return
         Ls, W = self.Lseq, full.shape[1]
         if self.arch == 'cpc':
             f2 = full[2 * Ls - 3:]
@@ -1621,6 +1657,12 @@ class TransRecEngine:
         lm = log_mask.float().contiguous()
         n_items = n_full
         n_c = self._kept_rows(B)
+        kidx = None
+        hm, self.host_log_mask = self.host_log_mask, None
+        if hm is not None and not hm.is_cuda and tuple(hm.shape) == (B, self.Lseq - 1) and _os.environ.get('A4R_SKIP_UNUSED_ITEMS', '1') != '0':
+            kidx = self._kept_index(hm, B)
+            if kidx is not None:
+                n_c = kidx[1]
         row_bytes = news[0].numel() * news.element_size() if n_full else 0
         noise = getattr(self, 'next_noise', None)  # (ViT-MAE: explicit masking noise comes per item of the FULL layout)
         if noise is not None and n_c is not None:
@@ -1630,15 +1672,15 @@ class TransRecEngine:
         if n_c is not None and row_bytes % 16 == 0:
             if noise is not None:
                 nzc = self._buf('noise_c', n_c, noise.shape[1], torch.float32)
-                self._slots_copy(noise, nzc, B, True)
+                self._slots_copy(noise, nzc, B, True, kidx)
                 self.next_noise = nzc
             src = news.view(n_full, -1).view(torch.float32)
             comp = self._buf('items_c', n_c, src.shape[1], torch.float32)
-            self._slots_copy(src, comp, B, True)
+            self._slots_copy(src, comp, B, True, kidx)
             news = comp.view(news.dtype).view((n_c,) + tuple(news.shape[1:]))
             n_items = n_c
         else:
-            n_c = None
+            n_c, kidx = None, None
         self._pre_forward(n_items)
         self.pack_trainables()
         self.step_count += 1
@@ -1658,7 +1700,7 @@ class TransRecEngine:
             emb_c = emb
             emb = self._buf('emb_full', pad_to(n_full, 128), self.E, torch.float32)
             L.zero(emb)
-            self._slots_copy(emb, emb_c, B, False)
+            self._slots_copy(emb, emb_c, B, False, kidx)
         xin = self._buf('sxin', Mu, self.E, torch.float32)
         L.take_inputs(emb, xin, B, self.Lseq, self.E)
         prec, Mu = self._user_forward(xin, lm, B, train, seed, saved_s)
@@ -1667,7 +1709,7 @@ class TransRecEngine:
         ws = self._buf('lossws', 1, 4, torch.float32)
         L.zero(ws)
         L.score_bce_fwd(emb, prec, lm, pos, neg, ws, B, self.Lseq, self.E, self.arch == 'cpc')
-        self._ctx = dict(B=B, n_items=n_items, n_full=n_full, M=M, Mu=Mu, seed=seed, train=train, lm=lm, key_mask=key_mask, emb=emb, pre=pre,
+        self._ctx = dict(B=B, n_items=n_items, n_full=n_full, kidx=kidx, M=M, Mu=Mu, seed=seed, train=train, lm=lm, key_mask=key_mask, emb=emb, pre=pre,
                          prec=prec, xin=xin, pos=pos, neg=neg, ws=ws, saved_b=saved_b, saved_s=saved_s)
         return ws[0, 0].clone()
 
@@ -1821,7 +1863,7 @@ class TransRecEngine:
         if n_full != n_items:
             Ip = pad_to(n_items, 128)
             d_emb_c = self._buf_tail0('d_emb_c', Ip, E, torch.float32, n_items)
-            self._slots_copy(d_emb, d_emb_c, B, True)
+            self._slots_copy(d_emb, d_emb_c, B, True, c.get('kidx'))
             d_emb = d_emb_c
         self._items_backward(c, d_emb, Ip)
         self._wgrad_join()

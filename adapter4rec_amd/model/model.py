@@ -94,6 +94,13 @@ class _TransRecBase(nn.Module):
 
     def forward(self, sample_items, log_mask, local_rank=None):
         eng = self._engine()
+        if not log_mask.is_cuda:
+            # log_mask still on the host (run.py hands over the DataLoader's tensor): the engine reads the batch's pad structure from it WITHOUT a
+            # device synchronisation -- the item slots of short histories that the loss never reads are not encoded (engine.py train_forward)
+            eng.host_log_mask = log_mask
+            log_mask = log_mask.to(sample_items.device, non_blocking=True)
+        else:
+            eng.host_log_mask = None
         if torch.is_grad_enabled() and eng.n_trainable:
             return _NativeLoss.apply(eng, sample_items, log_mask, *eng.trainable_params)
         return eng.train_forward(sample_items, log_mask)

@@ -127,13 +127,25 @@ def synth_content(n_items, g):
     return c
 
 
-def synth_batches(content, n_items, batch, n_batches, g):
-    """Full 23-item histories: train seq = 21 items, log_mask = ones(20); one uniformly sampled negative per position."""
+def synth_batches(content, n_items, batch, n_batches, g, ragged=False):
+    """Full 23-item histories: train seq = 21 items, log_mask = ones(20); one uniformly sampled negative per position.
+    ragged (--ragged-histories, reported separately): train lengths ~ U{2..21}, left-padded with item 0 in the positive AND the negative slot, log_mask =
+    [0] * pad + [1] * (len - 1) -- BuildTrainDataset.__getitem__, Downstream/Text/data_utils/dataset.py:24-49."""
     out = []
     for _ in range(n_batches):
         seqs = torch.stack([torch.randperm(n_items, generator=g)[:21] + 1 for _ in range(batch)])        # [B, 21]
         negs = torch.randint(1, n_items + 1, (batch, 21), generator=g)
         negs[:, -1] = 0
+        if ragged:
+            lens = torch.randint(2, 22, (batch,), generator=g)
+            lm = torch.zeros(batch, 20)
+            for b in range(batch):
+                pad = 21 - int(lens[b])
+                seqs[b, :pad], negs[b, :pad] = 0, 0
+                lm[b, pad:] = 1
+            ids = torch.stack([seqs, negs], 2).view(-1)
+            out.append((content[ids].contiguous(), lm))
+            continue
         ids = torch.stack([seqs, negs], 2).view(-1)                                                      # [B*21*2]
         out.append((content[ids].contiguous(), torch.ones(batch, 20)))
     return out
@@ -353,6 +365,10 @@ def main():
                          'overlapped with the previous step: the LMDB -> GPU pipeline of SURVEY 8(d)); reported next to `value`, which stays the '
                          'HBM-resident figure')
     ap.add_argument('--no-roofline', action='store_true')
+    ap.add_argument('--ragged-histories', action='store_true',
+                    help='text workloads, NOT the canonical benchmark: user histories of 2 .. 21 items (left-padded with item 0), log_mask handed over on the host; '
+                         'the engine does not encode the pad slots')
+    ap.add_argument('--ragged-device-mask', action='store_true', help='with --ragged-histories: log_mask on the device (every slot encoded: the A/B)')
     ap.add_argument('--gemm-variant', type=int, default=-1, help='A/B knob of a4r_gemm_variant (include/a4r.h); default: the library default')
     a = ap.parse_args()
 
@@ -414,7 +430,10 @@ def main():
         if wl == 'roberta_pfeiffer_cpc':                           # <s> ... </s>, pad id 1
             content[1:, 0], content[1:, 29] = 0, 2
             content[1:, 1:29] = torch.randint(3, 50265, (65536, 28), generator=gc)
-        batches = [(i.to(device), m.to(device)) for i, m in synth_batches(content, 65536, a.batch, 4, g)]
+        # --ragged-histories: log_mask stays on the HOST, as run.py hands it over (the engine reads the pad slots from it; --ragged-device-mask: on the device,
+        # i.e. every slot encoded -- the A/B of that path)
+        batches = [(i.to(device), m if (a.ragged_histories and not a.ragged_device_mask) else m.to(device))
+                   for i, m in synth_batches(content, 65536, a.batch, 4, g, ragged=a.ragged_histories)]
     from adapter4rec_amd.ddp import FlatDDP
     ddp = FlatDDP(model, device_ids=[local], output_device=local)     # broadcasts rank 0's state once (run.py:503); frozen weights never move again
     inner = getattr(model, 'model', model)
@@ -424,7 +443,7 @@ def main():
         items, mask = batches[i % len(batches)]
         if api:                                                # the engine API underneath (instrumented pass on rank 0: no collective)
             eng.flat_g.zero_()
-            loss = eng.train_forward(items, mask)
+            loss = eng.train_forward(items, mask.to(device))
             eng.train_backward(into_flat_grad=True)
             opt.step()
             return loss
@@ -640,7 +659,7 @@ def main():
             'value': round(users / dt, 2),
             'unit': 'user-sequences/sec', 'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup,
             'ms_per_step': round(dt / a.steps * 1e3, 3), 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
-            'dtype': a.dtype, 'data': WORKLOADS[wl][3],
+            'dtype': a.dtype, 'data': WORKLOADS[wl][3] + (' -- RAGGED histories of 2..21 items (not the canonical benchmark)' if getattr(a, 'ragged_histories', False) else ''),
             'config': {'workload': WORKLOADS[wl][2], 'baseline_config': WORKLOADS[wl][0] + (' in bf16 (run with --dtype fp8 for its fp8 encoder)' if wl == 'mae_compacter' and a.dtype != 'fp8' else ''),
                        'users_per_gpu': a.batch, 'global_batch': world * a.batch, 'seq_len': 23,
                        'tokens_per_item': eng.S, 'items_per_user': 42,

@@ -36,7 +36,7 @@ extern "C" {
 
 /* ABI version: bumped whenever a signature or struct below changes.  The Python binding (adapter4rec_amd/_lib.py) refuses a
  * library whose a4r_version() differs, so an A/B build made before a signature change cannot be called with shifted arguments. */
-#define A4R_ABI_VERSION 405
+#define A4R_ABI_VERSION 406
 int a4r_version(void);
 
 /* C[M,N] = epilogue(alpha * A[M,K] . B[N,K]^T): every nn.Linear on the path (HF BertSelfAttention
@@ -317,6 +317,12 @@ int a4r_ln_bwd(void* stream, const void* dy, int lddy, const void* v, int ldv, c
 /* out[i, :] = in[i * row_stride_rows, :] (CLS gather, model/encoders.py:55) and its scatter-transpose. */
 int a4r_gather_rows(void* stream, const void* in, int ldi, void* out, int ldo, int n, int row_step, int H, int dtype);
 int a4r_scatter_rows(void* stream, const void* in, int ldi, void* out, int ldo, int n, int row_step, int H, int dtype);
+/* Rows by index, any element type (sizes in BYTES, multiples of 16): scatter == 0: out[r] = in[idx[r]]; scatter != 0: out[idx[r]] = in[r] (idx without
+ * repeats), r < n.  The item rows of a training batch that the loss really reads -- BuildTrainDataset pads short histories with item 0 in the positive
+ * AND the negative slot (Downstream/Text/data_utils/dataset.py:24-49), and neither Model.forward nor ModelCPC.forward (model/model.py:48-70, 113-135) reads
+ * those slots -- are gathered in front of the item tower and their embeddings scattered back into the [B, L, 2] slot layout. */
+int a4r_rows_idx_copy(void* stream, const void* in, int64_t ldi_bytes, void* out, int64_t ldo_bytes, const int32_t* idx, int n,
+                      int64_t row_bytes, int scatter);
 /* the scatter that also ZEROES every other row of out[0 .. fill_rows): the gradient of a CLS gather is written in one pass
  * (no separate fill of the [tokens, H] buffer) */
 int a4r_scatter_rows_fill(void* stream, const void* in, int ldi, void* out, int ldo, int n, int row_step, int H, int dtype, int fill_rows);

@@ -483,6 +483,13 @@ def gather_rows(src, dst, n, row_step):
     dst[:n] = src[0:n * row_step:row_step]
 
 
+def rows_idx_copy(src, dst, idx, n, scatter=False):
+    if scatter:
+        dst[idx[:n].long()] = src[:n]
+    else:
+        dst[:n] = src[idx[:n].long()]
+
+
 def scatter_rows(src, dst, n, row_step):
     dst[0:n * row_step:row_step] = src[:n]
 

@@ -86,6 +86,26 @@ def test_step_fp32_unused_item_slots_not_encoded(name, monkeypatch):
         assert float((g - res['0'][1][k]).abs().max()) <= 1e-6 + 2e-5 * float(g.abs().max()), k
 
 
+@pytest.mark.parametrize('name', ['houlsby', 'houlsby_cpc', 'compacter', 'kadapter', 'roberta_cpc_pfeiffer'])
+def test_step_fp32_host_log_mask_pad_slots_not_encoded(name):
+    """log_mask handed over on the HOST (what run.py does with the DataLoader's tensor): the engine reads the batch's pad structure from it without a
+    device synchronisation and does not encode the item slots of short histories that the loss never reads (a4r_rows_idx_copy gathers the rest).  The
+    fixtures' batches hold two short users of four: loss and every trainable gradient still equal the REFERENCE's numbers (which encoded every slot)."""
+    root, args, sd, cfg, fx, items, mask = build(name, 'fp32')
+    inner = getattr(root, 'model', root)
+    eng = inner._engine()
+    loss = root(items, mask.cpu(), 0)
+    kidx = eng._ctx['kidx']
+    assert kidx is not None and kidx[1] < items.shape[0] and eng._ctx['n_items'] == kidx[1]
+    loss.backward()
+    assert abs(loss.item() - float(fx['loss'])) < 1e-4, (loss.item(), float(fx['loss']))
+    params = dict(root.named_parameters())
+    for k in fx['trainable']:
+        k = str(k)
+        ref = fx['grad/' + k]
+        np.testing.assert_allclose(params[k].grad.cpu().numpy(), ref, atol=1e-6 + 1e-4 * np.abs(ref).max(), rtol=0, err_msg=k)
+
+
 @pytest.mark.parametrize('name', list(ARGS))
 def test_step_fp32_vs_reference_golden(name):
     root, args, sd, cfg, fx, items, mask = build(name, 'fp32')

@@ -778,6 +778,26 @@ def test_ln_bwd_param_grads_lean_loads(dt, M, H):
             assert torch.equal(ref2 == 0, dh_n == 0)
 
 
+def test_rows_idx_copy():
+    """a4r_rows_idx_copy: rows by index, any element type (int64 id rows, fp32 embeddings, uint8 images), strided views on both sides, gather and its
+    scatter inverse; untouched destination rows keep their contents."""
+    from adapter4rec_amd import _lib as L
+    g = torch.Generator().manual_seed(9)
+    idx = torch.randperm(500, generator=g)[:123].sort().values.to(torch.int32).to(dev())
+    for src in (torch.randint(0, 30000, (500, 60), generator=g).to(dev()), rnd(500, 64, seed=3), torch.randint(0, 255, (500, 48), generator=g).to(torch.uint8).to(dev()),
+                rnd(500, 72, seed=4)[:, 4:68]):
+        comp = torch.zeros(130, src.shape[1] + 16, dtype=src.dtype, device=dev())[:, :src.shape[1]]
+        L.rows_idx_copy(src, comp, idx, 123)
+        assert torch.equal(comp[:123], src[idx.long()]) and torch.count_nonzero(comp[123:]) == 0
+        back = torch.full_like(src, 7)
+        L.rows_idx_copy(comp, back, idx, 123, scatter=True)
+        want = torch.full_like(src, 7)
+        want[idx.long()] = src[idx.long()]
+        assert torch.equal(back, want)
+    with pytest.raises(RuntimeError):
+        L.rows_idx_copy(rnd(8, 6), rnd(8, 6), idx, 4)                       # 24-byte rows
+
+
 @pytest.mark.parametrize('dt', ['f32', 'bf16'])
 def test_gather_scatter_rows(dt):
     from adapter4rec_amd import _lib as L
