@@ -1687,8 +1687,9 @@ class TransRecEngine:
         seed = (self.seed * 1000003 + self.step_count) & 0xFFFFFFFFFFFF
         M = pad_to(n_items * self.S, 256)
         Mu = pad_to(B * (self.Lseq - 1), 128)
-        if self._saved_bert is None or self._saved_M != M or self._saved_Mu != Mu:
-            Ipc = pad_to(n_items, 128)
+        Ipc = pad_to(n_items, 128)
+        if self._saved_bert is None or self._saved_M != M or self._saved_Mu != Mu or getattr(self, '_saved_Ip', Ipc) != Ipc:
+            self._saved_Ip = Ipc                   # (the item count changes from step to step when pad slots are left out)
             nb = len(self.bert_blocks)
             self._saved_bert = [self._block_bufs(f'bert.{i}', b, M, False, Mc=Ipc if (self.cls_only and i == nb - 1) else None)
                                 for i, b in enumerate(self.bert_blocks)]
