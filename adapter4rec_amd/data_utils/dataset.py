@@ -44,7 +44,7 @@ class DeviceTrainSampler:
     replace it -- distribution pinned, not bit-pinned"): all user sequences live on the GPU as one left-padded [U, L] table, a batch
     is a gather + one vectorised rejection loop.  Same distribution as dataset.py:24-49: one negative per real position, uniform over
     1..item_num minus the user's own sequence; negatives row = [0]*pad + negs + [0]; log_mask = [0]*pad + [1]*(len - 1).
-    ``sample(user_ids)`` -> (item_content[ids] [B*L*2, 2*words] int64, log_mask [B, L-1] fp32), both on the device."""
+    ``sample(user_ids)`` -> (item_content[ids] [B*L*2, 2*words] int64 on the device, log_mask [B, L-1] fp32 on the HOST)."""
 
     def __init__(self, u2seq, item_content, item_num, max_seq_len, device, seed=0):
         self.L, self.item_num, self.device = max_seq_len + 1, item_num, torch.device(device)
@@ -55,6 +55,7 @@ class DeviceTrainSampler:
             tab[r, self.L - len(seq):] = seq
         self.row_of = {u: r for r, u in enumerate(users)}
         self.seqs = torch.from_numpy(tab).to(self.device)
+        self.valid_host = tab != 0                 # (the pad structure of every user is known on the host: log_mask is handed over as a HOST tensor)
         self.content = torch.as_tensor(np.asarray(item_content)).long().to(self.device)
         self.seed = int(seed)
         self.gen = torch.Generator(device=self.device)
@@ -65,10 +66,14 @@ class DeviceTrainSampler:
         self.gen.manual_seed(self.seed * 1000003 + int(epoch))
 
     def sample(self, user_ids):
-        rows = torch.as_tensor([self.row_of[int(u)] for u in user_ids], device=self.device)
+        row_list = [self.row_of[int(u)] for u in user_ids]
+        rows = torch.as_tensor(row_list, device=self.device)
         seq = self.seqs[rows]                                              # [B, L], 0 = pad
         valid = seq != 0
-        log_mask = (valid[:, :-1] & valid[:, 1:]).float()                 # positions that have an input AND a target
+        vh = self.valid_host[row_list]
+        # positions that have an input AND a target; computed from the host table and returned ON THE HOST (as the DataLoader's log_mask is): Model.forward
+        # uploads it, and the engine finds the batch's pad slots in the host copy without a synchronisation (they are not encoded)
+        log_mask = torch.from_numpy((vh[:, :-1] & vh[:, 1:]).astype(np.float32))
         need = torch.cat([valid[:, 1:], torch.zeros_like(valid[:, :1])], 1) & valid        # every real slot except the last one
         neg = torch.randint(1, self.item_num + 1, seq.shape, device=self.device, generator=self.gen)
         # rejection: redraw the slots that hit the user's own items.  A slot clashes with probability <= L / item_num per draw: with a real
