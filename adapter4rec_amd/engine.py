@@ -241,6 +241,7 @@ class TransRecEngine:
         self.res32 = dtype != 'fp32' and getattr(args, 'residual_dtype', 'bf16') == 'fp32'
         self._twin = {}
         self.S = getattr(args, 'num_words_title', 0)
+        self.S0 = self.S                           # the title length of the data; self.S may be shorter for one training step (train_forward)
         self.E = args.embedding_dim
         self.Lseq = args.max_seq_len + 1
         self.seed = int(getattr(args, 'dropout_seed', 0x5eed))
@@ -1539,6 +1540,7 @@ class TransRecEngine:
     @torch.no_grad()
     def encode_items(self, news):
         L.require_gpu(news)
+        self._set_S(self.S0)
         n = news.shape[0]
         news = news.contiguous()
         if news.dtype != torch.int64:
@@ -1590,6 +1592,16 @@ class TransRecEngine:
         return n_c if rounds(n_c) < rounds(B * 2 * self.Lseq) else None
 
     host_log_mask = None           # set by Model.forward when run.py hands log_mask over on the host
+    host_max_tokens = None         # likewise: the longest title (tokens with attention mask 1) among the batch's items, read from the host copy
+
+    def _set_S(self, S):
+        """Tokens per item of the text tower for what runs next (pad tokens inside a title never reach the CLS output -- masked as keys,
+        their own rows are not read).  When every title of a training batch is shorter than the data's title length, the step runs on the first S
+        tokens only; inference and the next step start from the full length again."""
+        if S != self.S and type(self) is TransRecEngine:
+            self.S = S
+            for b in self.bert_blocks:
+                b.S = S
 
     def _kept_index(self, hm, B):
         """Ragged histories: BuildTrainDataset pads a short user's positives AND negatives with item 0 (dataset.py:24-49) and neither
@@ -1681,6 +1693,20 @@ class TransRecEngine:
             n_items = n_c
         else:
             n_c, kidx = None, None
+        # short titles: the step's token count (even: 16-byte row pieces).  Not with K-Adapter blocks on the text tower (KAdapterBlock attends with an
+        # all-ones mask: pad tokens reach the CLS row there) and not with a soft prompt.
+        hmt, self.host_max_tokens = self.host_max_tokens, None
+        S_step = self.S0
+        if (hmt is not None and type(self) is TransRecEngine and not self.bert_kads and not self.prompt_n and self.S0 % 2 == 0 and news.dim() == 2
+                and news.dtype == torch.int64 and news.shape[1] == 2 * self.S0 and _os.environ.get('A4R_SKIP_UNUSED_ITEMS', '1') != '0'):
+            S_step = min(self.S0, max(2, (int(hmt) + 1) // 2 * 2))
+        self._set_S(S_step)
+        if S_step < self.S0:                       # rows [ids(S0) | mask(S0)] -> [ids(S) | mask(S)]
+            src = news.view(torch.float32)
+            dst = self._buf('items_t', n_items, 4 * S_step, torch.float32)
+            L.gather_rows(src[:, :2 * S_step], dst[:, :2 * S_step], n_items, 1)
+            L.gather_rows(src[:, 2 * self.S0:2 * self.S0 + 2 * S_step], dst[:, 2 * S_step:], n_items, 1)
+            news = dst.view(torch.int64)
         self._pre_forward(n_items)
         self.pack_trainables()
         self.step_count += 1
@@ -1710,7 +1736,7 @@ class TransRecEngine:
         ws = self._buf('lossws', 1, 4, torch.float32)
         L.zero(ws)
         L.score_bce_fwd(emb, prec, lm, pos, neg, ws, B, self.Lseq, self.E, self.arch == 'cpc')
-        self._ctx = dict(B=B, n_items=n_items, n_full=n_full, kidx=kidx, M=M, Mu=Mu, seed=seed, train=train, lm=lm, key_mask=key_mask, emb=emb, pre=pre,
+        self._ctx = dict(B=B, n_items=n_items, n_full=n_full, kidx=kidx, S=self.S, M=M, Mu=Mu, seed=seed, train=train, lm=lm, key_mask=key_mask, emb=emb, pre=pre,
                          prec=prec, xin=xin, pos=pos, neg=neg, ws=ws, saved_b=saved_b, saved_s=saved_s)
         return ws[0, 0].clone()
 
@@ -1815,6 +1841,7 @@ class TransRecEngine:
         if grad_out is not None:
             grad_out = grad_out.detach().to(torch.float32).reshape(1)
         B, n_items, M, Mu, seed = c['B'], c['n_items'], c['M'], c['Mu'], c['seed']
+        self._set_S(c.get('S', self.S))            # (the token count the forward ran on)
         n_full = c.get('n_full', n_items)          # the head works on the full slot layout, the item tower on the kept rows (train_forward)
         E, Tn = self.E, self.Lseq - 1
         train = c['train']

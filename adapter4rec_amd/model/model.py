@@ -94,6 +94,13 @@ class _TransRecBase(nn.Module):
 
     def forward(self, sample_items, log_mask, local_rank=None):
         eng = self._engine()
+        eng.host_max_tokens = None
+        if not sample_items.is_cuda and sample_items.dim() == 2 and sample_items.dtype == torch.int64:
+            # the batch still on the host (run.py): the longest title among its items is read here -- a training step then runs on that many tokens
+            # per item instead of --num_words_title (pad tokens never reach the CLS output) -- and the rows are uploaded
+            # (numpy, not torch: a torch CPU reduction wakes the whole intra-op thread pool -- 128 threads on the GPU boxes -- and cost ~19 ms per step)
+            eng.host_max_tokens = int(sample_items.numpy()[:, sample_items.shape[1] // 2:].sum(1).max()) if sample_items.shape[0] else None
+            sample_items = sample_items.to(eng.dev, non_blocking=True)
         if not log_mask.is_cuda:
             # log_mask still on the host (run.py hands over the DataLoader's tensor): the engine reads the batch's pad structure from it WITHOUT a
             # device synchronisation -- the item slots of short histories that the loss never reads are not encoded (engine.py train_forward)

@@ -148,8 +148,9 @@ def train(args, use_modal, local_rank, Log_file, Log_screen, model_dir, start_ti
         for sample_items, log_mask in (train_dl if dev_sampler is None else device_batches()):
             # (log_mask stays on the host when it comes from the DataLoader: Model.forward uploads it and the engine reads the batch's pad slots from
             #  the host copy -- short histories' pad items are not encoded; the reference moves both, run.py:591-596)
-            sample_items = sample_items.to(local_rank, non_blocking=True)
-            sample_items = sample_items.view(-1, sample_items.size(-1))
+            sample_items = sample_items.view(-1, sample_items.size(-1))      # (a DataLoader batch stays on the host too: Model.forward reads its longest title, then uploads it)
+            if dev_sampler is not None:
+                sample_items = sample_items.to(local_rank, non_blocking=True)
             optimizer.zero_grad()
             bz_loss = model(sample_items, log_mask, local_rank)
             loss += bz_loss.detach()

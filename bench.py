@@ -369,6 +369,10 @@ def main():
                     help='text workloads, NOT the canonical benchmark: user histories of 2 .. 21 items (left-padded with item 0), log_mask handed over on the host; '
                          'the engine does not encode the pad slots')
     ap.add_argument('--ragged-device-mask', action='store_true', help='with --ragged-histories: log_mask on the device (every slot encoded: the A/B)')
+    ap.add_argument('--short-titles', action='store_true',
+                    help="text workloads, NOT the canonical benchmark: SURVEY 8(d)'s 'realistic' titles of n ~ U{6..20} tokens (30-token rows, the rest pad); the "
+                         'batch is handed over on the HOST every step (as run.py does) and the step runs on the longest title of the batch')
+    ap.add_argument('--short-titles-device', action='store_true', help='with --short-titles: batches resident on the device (30 tokens per item: the A/B)')
     ap.add_argument('--gemm-variant', type=int, default=-1, help='A/B knob of a4r_gemm_variant (include/a4r.h); default: the library default')
     a = ap.parse_args()
 
@@ -432,7 +436,19 @@ def main():
             content[1:, 1:29] = torch.randint(3, 50265, (65536, 28), generator=gc)
         # --ragged-histories: log_mask stays on the HOST, as run.py hands it over (the engine reads the pad slots from it; --ragged-device-mask: on the device,
         # i.e. every slot encoded -- the A/B of that path)
-        batches = [(i.to(device), m if (a.ragged_histories and not a.ragged_device_mask) else m.to(device))
+        if a.short_titles:                                         # titles of 6 .. 20 tokens: [CLS] t .. [SEP] pad ...
+            lens = torch.randint(6, 21, (content.shape[0],), generator=gc)
+            col = torch.arange(30)[None, :]
+            sep = 2 if wl == 'roberta_pfeiffer_cpc' else 102
+            padid = 1 if wl == 'roberta_pfeiffer_cpc' else 0
+            ids, am = content[:, :30].clone(), content[:, 30:].clone()
+            ids = torch.where(col == (lens[:, None] - 1), torch.full_like(ids, sep), ids)
+            ids = torch.where(col >= lens[:, None], torch.full_like(ids, padid), ids)
+            am = (col < lens[:, None]).long()
+            ids[0], am[0] = content[0, :30], content[0, 30:]
+            content = torch.cat([ids, am], 1)
+        batches = [((i.pin_memory() if (a.short_titles and not a.short_titles_device) else i.to(device)),
+                    m if ((a.ragged_histories and not a.ragged_device_mask) or (a.short_titles and not a.short_titles_device)) else m.to(device))
                    for i, m in synth_batches(content, 65536, a.batch, 4, g, ragged=a.ragged_histories)]
     from adapter4rec_amd.ddp import FlatDDP
     ddp = FlatDDP(model, device_ids=[local], output_device=local)     # broadcasts rank 0's state once (run.py:503); frozen weights never move again
@@ -443,7 +459,7 @@ def main():
         items, mask = batches[i % len(batches)]
         if api:                                                # the engine API underneath (instrumented pass on rank 0: no collective)
             eng.flat_g.zero_()
-            loss = eng.train_forward(items, mask.to(device))
+            loss = eng.train_forward(items.to(device), mask.to(device))
             eng.train_backward(into_flat_grad=True)
             opt.step()
             return loss
@@ -659,7 +675,7 @@ def main():
             'value': round(users / dt, 2),
             'unit': 'user-sequences/sec', 'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup,
             'ms_per_step': round(dt / a.steps * 1e3, 3), 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
-            'dtype': a.dtype, 'data': WORKLOADS[wl][3] + (' -- RAGGED histories of 2..21 items (not the canonical benchmark)' if getattr(a, 'ragged_histories', False) else ''),
+            'dtype': a.dtype, 'data': WORKLOADS[wl][3] + (' -- RAGGED histories of 2..21 items (not the canonical benchmark)' if getattr(a, 'ragged_histories', False) else '') + (' -- SHORT titles of 6..20 tokens (not the canonical benchmark)' if getattr(a, 'short_titles', False) else ''),
             'config': {'workload': WORKLOADS[wl][2], 'baseline_config': WORKLOADS[wl][0] + (' in bf16 (run with --dtype fp8 for its fp8 encoder)' if wl == 'mae_compacter' and a.dtype != 'fp8' else ''),
                        'users_per_gpu': a.batch, 'global_batch': world * a.batch, 'seq_len': 23,
                        'tokens_per_item': eng.S, 'items_per_user': 42,

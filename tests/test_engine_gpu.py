@@ -106,6 +106,27 @@ def test_step_fp32_host_log_mask_pad_slots_not_encoded(name):
         np.testing.assert_allclose(params[k].grad.cpu().numpy(), ref, atol=1e-6 + 1e-4 * np.abs(ref).max(), rtol=0, err_msg=k)
 
 
+@pytest.mark.parametrize('name', ['houlsby', 'roberta_cpc_pfeiffer'])
+def test_step_fp32_short_titles_run_on_fewer_tokens(name):
+    """A batch handed over on the host whose titles all end by token 16: the training step runs on 16 tokens per item instead of 30 (pad tokens never
+    reach the CLS output) -- loss and every gradient equal the oracle's on the same batch at the full title length; also together with the host
+    log_mask (pad slots of the fixture's two short users left out)."""
+    import test_engine_host_logic as TH
+    root, items, mask, names, out, grads = TH.short_title_case(name, device='cuda:0')
+    inner = getattr(root, 'model', root)
+    loss = root(items, mask, 0)                      # both still CPU tensors: Model.forward uploads them
+    c = inner._engine()._ctx
+    assert c['S'] == 16 and c['kidx'] is not None
+    loss.backward()
+    assert abs(loss.item() - float(out['loss'].detach())) < 1e-4
+    params = dict(root.named_parameters())
+    for n in names:
+        ref = grads[n].numpy()
+        np.testing.assert_allclose(params[n].grad.cpu().numpy(), ref, atol=1e-6 + 1e-4 * np.abs(ref).max(), rtol=0, err_msg=n)
+    emb = inner.bert_encoder(items.to('cuda:0'))
+    assert inner._engine().S == items.shape[1] // 2 and emb.shape[0] == items.shape[0]
+
+
 @pytest.mark.parametrize('name', list(ARGS))
 def test_step_fp32_vs_reference_golden(name):
     root, args, sd, cfg, fx, items, mask = build(name, 'fp32')
