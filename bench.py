@@ -106,14 +106,25 @@ def build_cv_model(args, device):
     return model, opt
 
 
-def synth_image_batches(batch, n_batches, device, seed):
-    """uint8 HWC images, 21 + 21 slots per user; the last negative slot is never filled (dataset.py:94-105)."""
+def synth_image_batches(batch, n_batches, device, seed, ragged=False, host_mask=True):
+    """uint8 HWC images, 21 + 21 slots per user; the last negative slot is never filled (dataset.py:94-105).
+    ragged (--ragged-histories): train lengths ~ U{2..21}, the pad slots of a short user stay ZERO images in the positive and the negative slot
+    (Build_Lmdb_Dataset.__getitem__, Downstream/CV/data_utils/dataset.py:85-113), log_mask = [0] * pad + [1] * (len - 1), on the host unless host_mask
+    is False (the A/B: every slot encoded)."""
     g = torch.Generator(device=device).manual_seed(seed)
+    gh = torch.Generator().manual_seed(seed)
     out = []
     for _ in range(n_batches):
         img = torch.randint(0, 256, (batch, 21, 2, 224, 224, 3), generator=g, device=device, dtype=torch.uint8)
         img[:, -1, 1] = 0
-        out.append((img.view(-1, 224, 224, 3), torch.ones(batch, 20, device=device)))
+        lm = torch.ones(batch, 20)
+        if ragged:
+            lens = torch.randint(2, 22, (batch,), generator=gh)
+            for b in range(batch):
+                pad = 21 - int(lens[b])
+                img[b, :pad] = 0
+                lm[b, :pad] = 0
+        out.append((img.view(-1, 224, 224, 3), lm if (ragged and host_mask) else lm.to(device)))
     return out
 
 
@@ -366,7 +377,7 @@ def main():
                          'HBM-resident figure')
     ap.add_argument('--no-roofline', action='store_true')
     ap.add_argument('--ragged-histories', action='store_true',
-                    help='text workloads, NOT the canonical benchmark: user histories of 2 .. 21 items (left-padded with item 0), log_mask handed over on the host; '
+                    help='NOT the canonical benchmark: user histories of 2 .. 21 items (left-padded with item 0 / zero images), log_mask handed over on the host; '
                          'the engine does not encode the pad slots')
     ap.add_argument('--ragged-device-mask', action='store_true', help='with --ragged-histories: log_mask on the device (every slot encoded: the A/B)')
     ap.add_argument('--short-titles', action='store_true',
@@ -420,7 +431,7 @@ def main():
     if image:
         args = make_cv_args(a.batch, a.dtype, wl)
         model, opt = build_cv_model(args, device)
-        batches = synth_image_batches(a.batch, 2, device, SEED + rank)
+        batches = synth_image_batches(a.batch, 4 if a.ragged_histories else 2, device, SEED + rank, ragged=a.ragged_histories, host_mask=not a.ragged_device_mask)
     else:
         args = make_args(a.batch, a.dtype)
         if wl == 'roberta_pfeiffer_cpc':
