@@ -15,6 +15,8 @@
 // M is split over the grid (tiles x splits ~ one workgroup per CU); a workgroup flushes its tile ONCE with fp32 atomics.  Workgroups are dealt to
 // the XCDs so that one XCD owns whole token ranges: the tiles that share an X slab (same P panel) or a Y slab (same Q panel) of a token range
 // read it from that XCD's L2.
+// A four-wave form (one wave per SIMD, 128 x 128 wave tiles, 256 AGPR accumulators, fragments double-buffered in registers: 2/3 of the LDS reads per
+// MFMA, half the waves per barrier) was built and measured 8 - 11 % slower (commit ec8ff10, profiles/r04_y_tn256_four_wave_ab.txt, LOG.md part D).
 // xsum (optional): xsum[p] += the column sums of X -- the bias gradient db = colsum(dy) next to dW = dy^T x -- as MFMAs against an all-ones
 // operand in the workgroups of the first Q panel, spread over the four Q-side waves (2 extra MFMAs per 32).
 #include <cstdlib>
@@ -206,122 +208,6 @@ __global__ void __launch_bounds__(512, 1) gemm_tn_256_kernel(const Tn256 p) {
             for (int g = 0; g < 4; ++g) atomicAdd(C + (size_t)(prow + f * 16 + rr) * ldc + qcol + g * 16, acc[f][g][rr]);
 }
 
-// EXPERIMENT (A4R_TN256_W4=1; end of round 4): the same tile, ring and flush with FOUR waves, one per SIMD, each owning 128 x 128 of the tile (8 x 8
-// MFMA tiles = 256 accumulator registers in the AGPR half of a one-wave-per-SIMD kernel's 512).  Per stage a wave reads 8 + 8 fragments for 64 MFMAs
-// (0.25 transposed 16-byte reads per MFMA instead of 0.375; the CU reads 64 KiB of LDS per stage instead of 96) and there are half as many waves at
-// the barrier.  No ping-pong partner: the fragments are double-buffered in registers -- stage t + 1's reads are issued in front of stage t's MFMAs
-// and land behind them.  No bias sums in this form.  Measured against the 8-wave kernel in profiles/LOG.md.
-__global__ void __launch_bounds__(256, 1) gemm_tn_256w4_kernel(const Tn256 p) {
-    __shared__ __attribute__((aligned(16))) char lds[TNB_NST * TNB_STAGE];
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wp = wave >> 1, wq = wave & 1;
-    const int tiles = p.tiles, total = tiles * p.splits;
-    const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3, q8 = total >> 3, r8 = total & 7;
-    const int v = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + j;
-    const int split = v / tiles, tile_l = v - split * tiles;
-    int k = 0;
-    for (int i = 1; i < p.nprob; ++i) k = tile_l >= p.pr[i].tile0 ? i : k;
-    const Tn256P& pk = p.pr[k];
-    const int tile = tile_l - pk.tile0;
-    const int tp = tile / pk.ntq, tq = tile - tp * pk.ntq;
-    const int m_begin = split * p.rows_per_split;
-    const int m_end = min(p.M, m_begin + p.rows_per_split);
-    const int ns = (m_end - m_begin) / TNB_TOK;
-    const int ldx = pk.ldx, ldy = pk.ldy;
-    const char* Xb = reinterpret_cast<const char*>(pk.X + (size_t)m_begin * ldx + tp * 256);
-    const char* Yb = reinterpret_cast<const char*>(pk.Y + (size_t)m_begin * ldy + tq * 256);
-    float* const C_k = pk.C;
-    const int ldc = pk.ldc;
-    const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)lds;
-
-    // DMA: wave w fills X image w and Y image w of every stage (four 1-KiB pieces each)
-    uint32_t voffX[4], voffY[4];
-#pragma unroll
-    for (int rb = 0; rb < 4; ++rb) {
-        const int r = 8 * rb + (lane >> 3);
-        const int c = (lane & 7) ^ ((r >> 1) & 7);
-        voffX[rb] = (uint32_t)(r * ldx * 2 + wave * 128 + c * 16);
-        voffY[rb] = (uint32_t)(r * ldy * 2 + wave * 128 + c * 16);
-    }
-    const uint32_t dst0 = lds0 + (uint32_t)(wave * TNB_IMG);
-    auto issue = [&](int t) {
-        if (t < ns) {
-            const uint32_t sb = (uint32_t)((t & (TNB_NST - 1)) * TNB_STAGE);
-            const char* x = Xb + (size_t)t * TNB_TOK * ldx * 2;
-            const char* y = Yb + (size_t)t * TNB_TOK * ldy * 2;
-#pragma unroll
-            for (int rb = 0; rb < 4; ++rb) tnb_glds16(x, voffX[rb], dst0 + sb + rb * 1024);
-#pragma unroll
-            for (int rb = 0; rb < 4; ++rb) tnb_glds16(y, voffY[rb], dst0 + sb + 4 * TNB_IMG + rb * 1024);
-        }
-    };
-    issue(0);
-    issue(1);
-    issue(2);
-    uint32_t fo0[4], fo1[4];
-    {
-        const int kg = lane >> 4, q = (lane >> 2) & 3, pp = lane & 3;
-        const int r0 = 4 * kg + q, r1 = r0 + 16;
-#pragma unroll
-        for (int d = 0; d < 4; ++d) {
-            const int chunk = 2 * d + (pp >> 1);
-            fo0[d] = (uint32_t)(r0 * 128 + ((chunk ^ ((r0 >> 1) & 7)) << 4) + 8 * (pp & 1));
-            fo1[d] = (uint32_t)(r1 * 128 + ((chunk ^ ((r1 >> 1) & 7)) << 4) + 8 * (pp & 1));
-        }
-    }
-    f32x4_t acc[8][8];
-#pragma unroll
-    for (int f = 0; f < 8; ++f)
-#pragma unroll
-        for (int g = 0; g < 8; ++g) acc[f][g] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-    const char* xa = lds + wp * 2 * TNB_IMG;
-    const char* yb = lds + (4 + wq * 2) * TNB_IMG;
-    uint4 a0[8], b0[8], a1[8], b1[8];
-#define TNW4_READ(a_, b_, sb_)                                                                                  \
-    _Pragma("unroll") for (int g = 0; g < 8; ++g) b_[g] = tnb_frag(yb + (sb_) + (g >> 2) * TNB_IMG, fo0[g & 3], fo1[g & 3]); \
-    _Pragma("unroll") for (int f = 0; f < 8; ++f) a_[f] = tnb_frag(xa + (sb_) + (f >> 2) * TNB_IMG, fo0[f & 3], fo1[f & 3]);
-#define TNW4_MMA(a_, b_)                                                                                        \
-    _Pragma("unroll") for (int f = 0; f < 8; ++f)                                                               \
-        _Pragma("unroll") for (int g = 0; g < 8; ++g) Mma<bf16_t>::mma(a_[f], b_[g], acc[f][g]);
-    // one stage: stage t's fragments are in (ac_, bc_) (requested one stage ago); wait for stage t + 1's DMA, barrier, refill the slot of stage
-    // t - 1, request stage t + 1's fragments into (an_, bn_), then the 64 MFMAs of stage t.  (lgkmcnt counts to 15 only: hipcc makes the first MFMAs
-    // wait until 14 of the 32 new requests are left.  With the requests between two halves of the MFMAs it spilled 7 registers -- the reloads wait on
-    // vmcnt(0) behind the DMA ring -- and copied accumulators inside the loop.)
-#define TNW4_STAGE(t_, ac_, bc_, an_, bn_)                                                                      \
-    if ((t_) + 3 < ns) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");          /* stage t + 1 landed: t + 2 (8 instructions) may stay in flight */ \
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                       \
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                            /* stage t's fragments (requested a stage ago) */ \
-    __builtin_amdgcn_s_barrier();                                                                               \
-    asm volatile("" ::: "memory");                                                                              \
-    issue((t_) + 3);                                                                                            \
-    if ((t_) + 1 < ns) { TNW4_READ(an_, bn_, (((t_) + 1) & (TNB_NST - 1)) * TNB_STAGE) }                        \
-    TNW4_MMA(ac_, bc_)
-    if (ns > 2) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
-    else if (ns > 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    TNW4_READ(a0, b0, 0)
-    int t = 0;
-    for (; t + 1 < ns; t += 2) {
-        TNW4_STAGE(t, a0, b0, a1, b1)
-        TNW4_STAGE(t + 1, a1, b1, a0, b0)
-    }
-    if (t < ns) { TNW4_STAGE(t, a0, b0, a1, b1) }
-#undef TNW4_STAGE
-#undef TNW4_MMA
-#undef TNW4_READ
-    if (p.flags & 1) return;
-    const int prow = tp * 256 + wp * 128 + (lane >> 4) * 4, qcol = tq * 256 + wq * 128 + (lane & 15);
-    float* __restrict__ C = C_k;
-#pragma unroll
-    for (int f = 0; f < 8; ++f)
-#pragma unroll
-        for (int rr = 0; rr < 4; ++rr)
-#pragma unroll
-            for (int g = 0; g < 8; ++g) atomicAdd(C + (size_t)(prow + f * 16 + rr) * ldc + qcol + g * 16, acc[f][g][rr]);
-}
-
 }  // namespace
 
 // 1 = the shape takes the 256-tile kernel (a4r_gemm_tn / a4r_gemm_tn_bias dispatch on it; A4R_TN256=0: never, A/B runs)
@@ -353,11 +239,7 @@ int a4r_tn256_launch_multi(void* stream, int n, const void* const* X, const int*
     if (splits > stages) splits = stages;
     p.rows_per_split = ((stages + splits - 1) / splits) * 64;
     p.splits = (M + p.rows_per_split - 1) / p.rows_per_split;
-    static const int w4 = getenv("A4R_TN256_W4") ? atoi(getenv("A4R_TN256_W4")) : 0;             // experiment: four waves, 128 x 128 wave tiles (no bias sums)
-    bool any_xs = false;
-    for (int i = 0; i < n; ++i) any_xs = any_xs || (xsum && xsum[i]);
-    if (w4 && !any_xs) hipLaunchKernelGGL(gemm_tn_256w4_kernel, dim3(tiles * p.splits), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), p);
-    else hipLaunchKernelGGL(gemm_tn_256_kernel, dim3(tiles * p.splits), dim3(512), 0, reinterpret_cast<hipStream_t>(stream), p);
+    hipLaunchKernelGGL(gemm_tn_256_kernel, dim3(tiles * p.splits), dim3(512), 0, reinterpret_cast<hipStream_t>(stream), p);
     return a4r_launch_status();
 }
 
