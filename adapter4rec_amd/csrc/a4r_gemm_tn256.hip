@@ -189,7 +189,9 @@ __global__ void __launch_bounds__(512, 1) gemm_tn_256_kernel(const Tn256 p) {
         asm volatile("" ::: "memory");
     }
     if (wp == 0) __builtin_amdgcn_s_barrier();
-    if (p.flags & 1) return;                                          // (timing-only diagnostic: A4R_TN256_DBG=1, no flush)
+#ifdef A4R_DEBUG_KNOBS                                                 // tools-only build (make DEBUG_KNOBS=1): never in the shipped library
+    if (p.flags & 1) return;                                          // (timing-only diagnostic: A4R_TN256_DBG=1, no flush -- results wrong)
+#endif
 
     const int prow = tp * 256 + wp * 128 + (lane >> 4) * 4, qcol = tq * 256 + wq * 64 + (lane & 15);
     if (xs && (lane & 15) == 0) {            // every column of the ones product holds the row sum: one lane per row writes it
@@ -229,8 +231,12 @@ int a4r_tn256_launch_multi(void* stream, int n, const void* const* X, const int*
         if (i < n) tiles += (P[s] / 256) * (Q[s] / 256);
     }
     p.nprob = n; p.tiles = tiles; p.M = M;
+#ifdef A4R_DEBUG_KNOBS
     static const int dbg = getenv("A4R_TN256_DBG") ? atoi(getenv("A4R_TN256_DBG")) : 0;          // bit 0: no flush (timing only, results wrong)
     p.flags = dbg;
+#else
+    p.flags = 0;
+#endif
     const int stages = M / 64;
     static const int wgs_env = getenv("A4R_TN256_WGS") ? atoi(getenv("A4R_TN256_WGS")) : 256;          // (A/B runs)
     const int wgs = wgs_env > 0 ? wgs_env : 256;

@@ -690,12 +690,15 @@ inline int row_grid(int rows) { int g = (rows + 3) / 4; return g > 2048 ? 2048 :
 // grid of a lean LayerNorm launch: never more workgroups than are resident at once (occupancy x CUs) -- every wave then walks the same number of rows
 // (+- 1) with its next row always requested, instead of a second, thin round of workgroups starting when the first has finished
 template <auto Kernel> int resident_grid(int rows) {         // (the kernel is a template VALUE: one cached capacity per kernel, not per signature)
-    static int cap = 0;
+    static int caps[16] = {0};                                // per device id (one process per GPU sees one entry; a process that drives several must not mix them)
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) dev = 0;
+    int& cap = caps[dev];
     if (!cap) {
-        int per_cu = 0, dev = 0;
+        int per_cu = 0;
         hipDeviceProp_t pr;
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, Kernel, 256, 0) != hipSuccess || per_cu < 1) per_cu = 4;
-        cap = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess && pr.multiProcessorCount > 0 ? pr.multiProcessorCount : 256) * per_cu;
+        cap = (hipGetDeviceProperties(&pr, dev) == hipSuccess && pr.multiProcessorCount > 0 ? pr.multiProcessorCount : 256) * per_cu;
     }
     const int g = (rows + 3) / 4;
     return g > cap ? cap : (g < 1 ? 1 : g);
@@ -848,9 +851,10 @@ extern "C" int a4r_ln_bwd(void* stream, const void* dy, int lddy, const void* v,
     if (pg_on && wgb && !wdb && !add && !thr && M >= 2048) {     // trainable LayerNorm of an un-adapted sub-layer: parameter gradients on lean loads
         int dev = 0, ncu = 256;
         hipDeviceProp_t pr;
-        static int ncu_c = 0;
-        if (!ncu_c) ncu_c = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess && pr.multiProcessorCount > 0) ? pr.multiProcessorCount : 256;
-        ncu = ncu_c;
+        static int ncu_c[16] = {0};                          // per device id
+        if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) dev = 0;
+        if (!ncu_c[dev]) ncu_c[dev] = (hipGetDeviceProperties(&pr, dev) == hipSuccess && pr.multiProcessorCount > 0) ? pr.multiProcessorCount : 256;
+        ncu = ncu_c[dev];
         int g8 = (M + 7) / 8; if (g8 > ncu) g8 = ncu;
         const uint32_t thr2 = a4r_thr16(drop2_p);
         const float sc2 = a4r_keep_scale(drop2_p);

@@ -1254,7 +1254,7 @@ class TransRecEngine:
         flush -- 832 atomics from each of its 256 workgroups onto the same addresses, 6 - 9 us per launch (A4R_TN2_BIAS=0: the flush)."""
         return (TN2_BIAS and TN2 and not (WGRAD_STREAM and self.WGRAD_SIDE_OK) and dv.dtype == torch.bfloat16 and M % 64 == 0
                 and (ad.virtual is not None or ad.g_wu is not None) and ad.s_bd is None and ad.g_bu is not None and ad.g_bd is not None
-                and self._bd_target(ad) is not None and ad.dp == 64 and dv.shape[1] % 64 == 0 and not _os.environ.get('A4R_DEBUG_SKIP_WGRAD'))
+                and self._bd_target(ad) is not None and ad.dp == 64 and dv.shape[1] % 64 == 0)
 
     def _adapter_wgrads(self, ad, dv, z, dzp, down_in, M, bd_done=False, bias_in_tn2=False):
         """dW_up = dv^T z, dW_down = dzp^T down_in, db_down = colsum(dzp)  (db_up comes from ln_bwd's dbias; bd_done: the fused
@@ -1263,8 +1263,6 @@ class TransRecEngine:
         dgrad chain reads these results); joined before dv / dzp are reused and at the end of the backward pass."""
         if ad.virtual is None and ad.g_wu is None:
             return                       # frozen adapter: nothing to accumulate
-        if _os.environ.get('A4R_DEBUG_SKIP_WGRAD'):      # measurement aid only (tools/): the step without its weight-gradient kernels
-            return
         if WGRAD_STREAM and self.WGRAD_SIDE_OK and ad.s_wu is None and ad.virtual is None and torch.device(self.dev).type == 'cuda':
             if self._wstream is None:
                 self._wstream = torch.cuda.Stream(device=self.dev)

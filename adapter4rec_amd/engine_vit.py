@@ -419,8 +419,17 @@ class ViTRecEngine(TransRecEngine):
             return None
         keep = self._buf('mae_keep', n_items, self.n_keep, torch.int32)
         if noise is None:              # counter-hash noise per (seed, item, patch): a4r_mae_keep_indices draws and ranks it in one launch
-            self._mae_draw = getattr(self, '_mae_draw', 0) + 1
-            L.mae_keep_indices(keep, self.NP, None, seed=(self.seed * 1000003 + self._mae_draw) & 0xFFFFFFFFFFFF, site=4900)
+            # stream = (dropout_seed, the engine's PERSISTED step counter, draws since that counter last moved, rank): a resumed run continues
+            # the stream instead of replaying the first run's masks, and the ranks of a data-parallel job mask differently (as
+            # DeviceTrainSampler.set_epoch does for the negatives)
+            step = self.step_count + 1
+            if getattr(self, '_mae_step', None) != step:
+                self._mae_step, self._mae_draw = step, 0
+            self._mae_draw += 1
+            import torch.distributed as dist
+            rank = dist.get_rank() if dist.is_available() and dist.is_initialized() else 0
+            mix = (self.seed * 1000003 + step) * 1000033 + self._mae_draw * 8191 + rank * 0x9E3779B97F4A7C15
+            L.mae_keep_indices(keep, self.NP, None, seed=mix & 0xFFFFFFFFFFFF, site=4900)
         else:
             L.mae_keep_indices(keep, self.NP, noise.to(self.dev, torch.float32).contiguous())
         return keep

@@ -4,8 +4,10 @@
     y = x W^T + b + (x A^T B^T) * (lora_alpha / r),   lora_alpha = 1
 
 ``weight`` is frozen, ``bias`` stays trainable (loralib only freezes ``weight``), ``lora_A`` [r, in] is
-kaiming-uniform(a = sqrt(5)), ``lora_B`` [out, r] zeros.  loralib is not in the image and not vendored: this restatement
-is *parity unpinned* (checked against oracle/ref_cpu.py::lora_linear only)."""
+kaiming-uniform(a = sqrt(5)), ``lora_B`` [out, r] zeros.  loralib is not in the image and not vendored.  Parity is pinned through the
+reference's own numbers: with ``W = W_base - B A / r`` the oracle and the HIP path must reproduce the imported
+reference's forward, and ``dA = B^T dW / r``, ``dB = dW A^T / r`` from its ``dW`` (tools/gen_golden_r4.py -> tests/golden/lora_pin_*.npz,
+tests/test_oracle_golden.py, tests/test_engine_gpu.py).  What stays unpinnable here: loralib's own init and its ``lora_alpha`` default."""
 import math
 
 import torch

@@ -9,6 +9,7 @@ signatures (Downstream/Text/model/model.py) -- the drop-in boundary of SURVEY.md
 Forward/backward run on the MI355X-native engine (adapter4rec_amd/engine.py); there is no eager
 PyTorch path behind these classes.
 """
+import numpy as np
 import torch
 from torch import nn
 from torch.nn.init import xavier_normal_
@@ -99,7 +100,11 @@ class _TransRecBase(nn.Module):
             # the batch still on the host (run.py): the longest title among its items is read here -- a training step then runs on that many tokens
             # per item instead of --num_words_title (pad tokens never reach the CLS output) -- and the rows are uploaded
             # (numpy, not torch: a torch CPU reduction wakes the whole intra-op thread pool -- 128 threads on the GPU boxes -- and cost ~19 ms per step)
-            eng.host_max_tokens = int(sample_items.numpy()[:, sample_items.shape[1] // 2:].sum(1).max()) if sample_items.shape[0] else None
+            # The bound is the LAST attended position (not the count of mask ones): a left-padded tokenizer, a mask with holes or a non-0/1 mask
+            # keeps every attended token, whatever its column.
+            if sample_items.shape[0]:
+                m = sample_items.numpy()[:, sample_items.shape[1] // 2:] != 0
+                eng.host_max_tokens = int((m * np.arange(1, m.shape[1] + 1, dtype=np.int64)).max())
             sample_items = sample_items.to(eng.dev, non_blocking=True)
         if not log_mask.is_cuda:
             # log_mask still on the host (run.py hands over the DataLoader's tensor): the engine reads the batch's pad structure from it WITHOUT a

@@ -244,6 +244,22 @@ class GemmProbe:
         return {k: dict(launches=v[2], avg_us=round(v[1] / v[2] * 1e6, 1), tflops=round(v[0] / v[1] / 1e12, 1)) for k, v in out.items()}
 
 
+RESULTS_CHANGING_KNOBS = ('A4R_DEBUG_SKIP_WGRAD', 'A4R_TN256_DBG')     # timing-only switches of tools builds: gradients wrong / missing by design
+
+
+def env_knobs():
+    return {k: v for k, v in sorted(os.environ.items()) if k.startswith('A4R_')}
+
+
+def lib_id():
+    """path (relative to the repo) and sha256[:16] of the kernel library this process loaded"""
+    import hashlib
+    from adapter4rec_amd import _lib
+    with open(_lib.LIB_PATH, 'rb') as f:
+        h = hashlib.sha256(f.read()).hexdigest()[:16]
+    return {'path': os.path.relpath(_lib.LIB_PATH, ROOT), 'sha16': h}
+
+
 def host_threads():
     """Threads the CPU baseline may really use: CPU affinity, capped by the cgroup quota and by 32
     (an over-subscribed pool -- 256 threads on a quota of a few cores -- ran 20x slower)."""
@@ -386,6 +402,12 @@ def main():
     ap.add_argument('--short-titles-device', action='store_true', help='with --short-titles: batches resident on the device (30 tokens per item: the A/B)')
     ap.add_argument('--gemm-variant', type=int, default=-1, help='A/B knob of a4r_gemm_variant (include/a4r.h); default: the library default')
     a = ap.parse_args()
+    # Every A4R_* variable of the environment goes into the JSON line (`env_knobs`): a record made with an A/B knob set says so itself.
+    # Knobs that make results WRONG on purpose only exist in tools-only builds (make DEBUG_KNOBS=1, tools/*.sh -D builds under tools/_ab/);
+    # bench.py refuses to run with one of them set, whatever library is loaded.
+    refused = [k for k in env_knobs() if k in RESULTS_CHANGING_KNOBS or k.startswith('A4R_DEBUG_')]
+    if refused:
+        raise SystemExit(f'bench.py: refusing to run with results-changing knob(s) set: {refused}')
 
     if a.gpus > 1 and 'WORLD_SIZE' not in os.environ:
         self_launch(a, sys.argv[1:])                           # never returns
@@ -698,6 +720,7 @@ def main():
             'ms_per_step_ranks': rank_ms, 'ms_per_step_spread': round(max(rank_ms) - min(rank_ms), 3),
             'allreduce_overlapped': bool(world > 1 and eng.OVERLAP_ALLREDUCE and eng._grad_chunks() is not None),
             'loss': round(loss_val, 5), 'roofline': roof, 'cpu_baseline': cpu,
+            'env_knobs': env_knobs(), 'lib': lib_id(),
         }
         if host_leg is not None:
             out['host_images'] = host_leg

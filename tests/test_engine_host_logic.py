@@ -106,6 +106,34 @@ def test_host_logic_short_titles_run_on_fewer_tokens(simulated, name):
     assert inner._engine().S == items.shape[1] // 2 and emb.shape[0] == items.shape[0]
 
 
+@pytest.mark.parametrize('name', ['houlsby', 'roberta_cpc_pfeiffer'])
+def test_host_logic_non_prefix_mask_keeps_every_attended_token(simulated, name):
+    """the per-step title length is bounded by the LAST attended column, not by the count of mask ones.  Masks with a hole and with one
+    token attended far behind the others (11 ones, the last in column 20): the step must keep 22 columns, and loss / gradients must equal the
+    oracle on the full 30-token rows."""
+    from oracle import ref_cpu as R
+    from golden_util import load_variant
+    root, args, fx, items, mask = build_cpu(name)
+    sd, cfg, *_ = load_variant(name)
+    items = items.clone()
+    S = items.shape[1] // 2
+    items[:, S:] = 0
+    items[:, S:S + 10] = 1
+    items[:, S + 3] = 0                  # a hole
+    items[1::3, S + 20] = 1              # one straggler per third item, far behind the prefix
+    names = [str(k) for k in fx['trainable']]
+    out, grads = R.loss_and_grads(sd, names, items, mask, cfg)
+    inner = getattr(root, 'model', root)
+    loss = root(items, mask, 'cpu')
+    assert inner._engine()._ctx['S'] == 22
+    loss.backward()
+    assert abs(loss.item() - float(out['loss'].detach())) < 1e-4
+    params = dict(root.named_parameters())
+    for n in names:
+        ref = grads[n].numpy()
+        np.testing.assert_allclose(params[n].grad.numpy(), ref, atol=1e-6 + 1e-4 * np.abs(ref).max(), rtol=0, err_msg=n)
+
+
 @pytest.mark.parametrize('name', ['houlsby', 'compacter'])
 def test_host_logic_fused_adam(simulated, name):
     from adapter4rec_amd.inject import optimizer_groups
