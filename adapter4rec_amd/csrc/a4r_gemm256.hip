@@ -544,169 +544,9 @@ A4R_DEV void gemm256_tiles(const a4r_gemm_t& p, char* lds, int ntm, int ntn, int
         A4R_PROLOGUE_AT(At, ta_lo, ta_hi, Bt)
         t_ready = true;
     }
-    // Pair the lanes of 16-lane rows (l <-> l ^ 16) with v_permlane16_swap: lane (fr, kg) gives away the half it holds of
-    // the neighbouring tile and receives the missing half of its own, so that it ends up with 8 CONSECUTIVE columns
-    //   kg even: tile 2*pair,     columns (kg >> 1) * 8 .. + 7        kg odd: tile 2*pair + 1, same columns
-    // = one 16-byte (bf16) store per lane and 64-byte runs per row: half the store instructions of the 8-byte form,
-    // whose issue rate (not bandwidth) bounded the epilogue.
-    const int row0_done = TAIL ? t_row0 : tm_done * 256;
-    const size_t grow0 = (size_t)row0_done + wm * hrow + fr;
-    const int gcolp = tn_done * 256 + wn * 64 + (kg & 1) * 16 + (kg >> 1) * 8;      // + pair * 32
-    // C addresses and dropout element indices: a UNIFORM per-tile / per-group part (scalar registers) + a per-lane part that is the same
-    // for every tile (c_lane, e0_lane) -- no 64-bit multiply per group
-    // (per-lane parts: bytes, 32-bit -- the host side checks M * ldc * sizeof(TO) < 4 GiB.  Re-formed per tile from a laundered lane id:
-    // as loop invariants they and the 24 sums derived from them would be kept in registers across the K loop)
-    int lane_e = lane;
-    asm volatile("" : "+v"(lane_e));
-    const int fr_e = lane_e & 15, kg_e = lane_e >> 4;
-    constexpr bool C8 = EF >= 0 && (EF & 16) != 0;         // C leaves as e4m3 bytes (a4r_gemm_t.c_fp8): one byte per element, ldc in bytes
-    constexpr int CSZ = C8 ? 1 : (int)sizeof(TO);
-    const uint32_t c_lane = (uint32_t)(((wm * hrow + fr_e) * epi.ldc + wn * 64 + (kg_e & 1) * 16 + (kg_e >> 1) * 8) * CSZ);
-    const uint32_t c_rowstep = (uint32_t)(16 * epi.ldc * CSZ);
-    const uint64_t e0_lane = (uint64_t)(wm * hrow + fr_e) * (uint64_t)epi.N + (uint64_t)(wn * 64 + (kg_e & 1) * 16 + (kg_e >> 1) * 8);
-    char* const c_tile = reinterpret_cast<char*>(epi.C) + ((size_t)row0_done * (uint32_t)epi.ldc + (size_t)tn_done * 256) * CSZ;
-    const uint64_t e0_tile = ((uint64_t)row0_done + epi.row0) * (uint64_t)epi.N + (uint64_t)tn_done * 256;
-    // 8-bit derivative in tile-native order (a4r_gemm_t.q8_tiled): this lane's 8 bytes of group g sit at tile base + wave * 8192 + g * 512 + lane * 8
-    const bool q8t = p.q8_tiled != 0;
-    // (short tile: the row panel [t_row0, + 32 t_kp) x N starts at byte t_row0 * N; its tiles, then the waves' t_kp KiB blocks, follow each other)
-    const size_t q8_off = TAIL ? (size_t)t_row0 * (size_t)epi.N + ((size_t)tn_done * 8 + wave) * (size_t)(t_kp * 1024) + (size_t)lane_e * 8
-                               : ((size_t)(tm_done * ntn + tn_done) * 8 + wave) * 8192 + (size_t)lane_e * 8;
-    // short tile: operand rows past the last active one are requested from the last active row (valid memory, never consumed)
-#define A4R_RC(r_) (TAIL ? ((r_) < t_kp ? (r_) : t_kp - 1) : (r_))
-    const uint8_t* const q8_pre = reinterpret_cast<const uint8_t*>(epi.Pre) + q8_off;
-    uint8_t* const q8_c2 = reinterpret_cast<uint8_t*>(epi.C2) + q8_off;
-    float bias8[2][8];                                    // (gcolp % 8 == 0: 16-byte loads are aligned iff the bias pointer is)
-#pragma unroll
-    for (int pr = 0; pr < 2; ++pr)
-#pragma unroll
-        for (int e = 0; e < 8; ++e) bias8[pr][e] = 0.f;
-    if (epi.bias && (reinterpret_cast<uintptr_t>(epi.bias) & 15u)) {
-#pragma unroll
-        for (int pr = 0; pr < 2; ++pr)
-#pragma unroll
-            for (int e = 0; e < 8; ++e) bias8[pr][e] = epi.bias[gcolp + pr * 32 + e];
-    } else if (epi.bias) {
-#pragma unroll
-        for (int pr = 0; pr < 2; ++pr)
-#pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                const float4 b4 = *reinterpret_cast<const float4*>(epi.bias + gcolp + pr * 32 + h * 4);
-                bias8[pr][h * 4 + 0] = b4.x; bias8[pr][h * 4 + 1] = b4.y; bias8[pr][h * 4 + 2] = b4.z; bias8[pr][h * 4 + 3] = b4.w;
-            }
-    }
-    // fp8 operands: per-row scale of A (token) x per-row scale of B (output channel), applied to the raw accumulator
-    constexpr bool SCALED = sizeof(TI) == 1;
-    float sb8[2][8], sa8[8];
-    if constexpr (SCALED) {
-#pragma unroll
-        for (int pr = 0; pr < 2; ++pr)
-#pragma unroll
-            for (int e = 0; e < 8; ++e) sb8[pr][e] = p.scale_b[gcolp + pr * 32 + e];
-#pragma unroll
-        for (int mi = 0; mi < 8; ++mi) sa8[mi] = p.scale_a[grow0 + A4R_RC(mi) * 16];
-    }
-    // e4m3 output: the multiplier that takes a finished value to its stored form (per row of 16: c_fp8 2 scales a row by its A row's scale)
-    float cmul8[8];
-#pragma unroll
-    for (int mi = 0; mi < 8; ++mi) cmul8[mi] = 1.f;
-    if constexpr (C8) {
-#pragma unroll
-        for (int mi = 0; mi < 8; ++mi) {
-            const float so = p.c_fp8 == 2 ? sa8[mi] * p.c_scale : p.c_scale;
-            cmul8[mi] = __frcp_rn(so);
-            if (p.c_fp8 == 2 && tn_done == 0 && wn == 0 && kg == 0 && (!TAIL || mi < t_kp)) p.c_scale_out[grow0 + mi * 16] = so;      // (one writer per row)
-        }
-    }
-    // Operands the epilogue READS -- Pre (dgrad through an activation: C = acc * act'(Pre)) and R1 (dgrad GEMMs: the gradient of the
-    // residual branch) -- are requested PRE_D / R1_D rows of 16 ahead of the row that consumes them: a load waited for where it is
-    // issued costs an L2 / HBM round trip per group (it cannot be hoisted above the previous group's store by the compiler: C may alias
-    // it for all it knows), and one row ahead still left ~0.8 us of latency exposed per row (tools/gemm_timeline.py: 6.7 - 9.3 us per
-    // tile against 2.0 us for the plain epilogue).  One object per (row, pair): indexed arrays of register arrays went to scratch.
-    constexpr int PS = DACT != A4R_ACT_NONE ? 8 * (int)sizeof(TO) / 16 : 1;
-    constexpr bool R1PF = sizeof(TO) == 2 && DACT == A4R_ACT_NONE && EF >= 0 && (EF & 2) != 0;      // (EF & 2: the launch HAS an R1 -- no run-time test around register arrays)
-    constexpr int PRE_D = DACT == A4R_DACT_MULQ8_ ? A4R_PF_Q8 : 1, R1_D = (EF & 1) ? 2 : A4R_PF_R1;      // (with the dropout arithmetic the whole-tile request spills)
-#define A4R_SLOTS(name_, n_) uint4 name_##0_0[n_], name_##0_1[n_], name_##1_0[n_], name_##1_1[n_], name_##2_0[n_], name_##2_1[n_], name_##3_0[n_],  \
-        name_##3_1[n_], name_##4_0[n_], name_##4_1[n_], name_##5_0[n_], name_##5_1[n_], name_##6_0[n_], name_##6_1[n_], name_##7_0[n_], name_##7_1[n_], \
-        name_##8_0[n_], name_##8_1[n_];
-    A4R_SLOTS(pre_s, PS)
-    A4R_SLOTS(r1_s, 1)
-#undef A4R_SLOTS
-#define A4R_LD_PRE(r_)                                                                                                      \
-    if constexpr (DACT != A4R_ACT_NONE && (r_) < 8 && !(A4R_ABL & 256)) {                                                   \
-        if (DACT == A4R_DACT_MULQ8_ && q8t) {          /* tile-native order: 512 contiguous bytes per wave instruction */   \
-            const uint2 w0_ = *reinterpret_cast<const uint2*>(q8_pre + (2 * A4R_RC(r_)) * 512);                             \
-            const uint2 w1_ = *reinterpret_cast<const uint2*>(q8_pre + (2 * A4R_RC(r_) + 1) * 512);                         \
-            pre_s##r_##_0[0] = make_uint4(w0_.x, w0_.y, 0u, 0u);                                                            \
-            pre_s##r_##_1[0] = make_uint4(w1_.x, w1_.y, 0u, 0u);                                                            \
-        } else {                                                                                                            \
-        load_pre_n<TO, 8, DACT == A4R_DACT_MULQ8_>(pre_s##r_##_0, grow0 + A4R_RC(r_) * 16, gcolp, epi);                     \
-        load_pre_n<TO, 8, DACT == A4R_DACT_MULQ8_>(pre_s##r_##_1, grow0 + A4R_RC(r_) * 16, gcolp + 32, epi);                \
-        }                                                                                                                   \
-    }
-#define A4R_LD_R1(r_)                                                                                                       \
-    if constexpr (R1PF && (r_) < 8) {                                                                                       \
-        load_res_n<TO, 8>(r1_s##r_##_0, epi.R1, epi.ldr1, grow0 + A4R_RC(r_) * 16, gcolp);                                  \
-        load_res_n<TO, 8>(r1_s##r_##_1, epi.R1, epi.ldr1, grow0 + A4R_RC(r_) * 16, gcolp + 32);                             \
-    }
-    // rows 0 .. D - 1 before the first row is processed; row mi + D while row mi is
-#define A4R_LD_FIRST(LD_, D_)                                                                                               \
-    LD_(0) if constexpr ((D_) > 1) { LD_(1) } if constexpr ((D_) > 2) { LD_(2) LD_(3) } if constexpr ((D_) > 4) { LD_(4) LD_(5) LD_(6) LD_(7) }
-    if constexpr (PRE_TOP) {
-#define A4R_PT(r_) pre_s##r_##_0[0] = make_uint4(pt_[2 * (r_)].x, pt_[2 * (r_)].y, 0u, 0u); pre_s##r_##_1[0] = make_uint4(pt_[2 * (r_) + 1].x, pt_[2 * (r_) + 1].y, 0u, 0u);
-        A4R_PT(0) A4R_PT(1) A4R_PT(2) A4R_PT(3) A4R_PT(4) A4R_PT(5) A4R_PT(6) A4R_PT(7)
-#undef A4R_PT
-    } else {
-        A4R_LD_FIRST(A4R_LD_PRE, PRE_D)
-    }
-    A4R_LD_FIRST(A4R_LD_R1, R1_D)
-#undef A4R_LD_FIRST
-#define A4R_LD_AHEAD(LD_, D_, n1_, n2_, n4_)                                                                                \
-    if constexpr ((D_) == 1) { LD_(n1_) } else if constexpr ((D_) == 2) { LD_(n2_) } else if constexpr ((D_) == 4) { LD_(n4_) }
-#define A4R_EPI_CDST(mi_, pr_) reinterpret_cast<TO*>(c_tile + (c_lane + (uint32_t)(mi_) * c_rowstep) + (pr_) * 32 * CSZ)
-#if (A4R_ABL & 32)      /* timing-only experiment: every store instruction covers whole 128-byte lines (8 rows x 128 B); WRONG data placement */
-#define A4R_EPI_CALL(mi_, pr_)                                                                                              \
-        epilogue_n<TO, 8, ACT, DACT, R1PF, false, EF>(v_, bias8[pr_], grow0 - fr + (fr & 7) + 8 * (pr_) + (mi_) * 16, gcolp + (fr >> 3) * 32, epi,
-#undef A4R_EPI_CDST
-#define A4R_EPI_CDST(mi_, pr_) nullptr
-#else
-#define A4R_EPI_CALL(mi_, pr_)                                                                                              \
-        epilogue_n<TO, 8, ACT, DACT, R1PF, true, EF>(v_, bias8[pr_], grow0 + (mi_) * 16, gcolp + (pr_) * 32, epi,
-#endif
-#define A4R_EPI_PAIR(mi_, pr_)                                                                                        \
-    {                                                                                                                       \
-        float v_[8];                                                                                                        \
-        _Pragma("unroll") for (int r_ = 0; r_ < 4; ++r_) {                                                                  \
-            const auto sw_ = __builtin_amdgcn_permlane16_swap(__float_as_uint(acc[mi_][2 * (pr_)][r_]),                     \
-                                                              __float_as_uint(acc[mi_][2 * (pr_) + 1][r_]), false, false);  \
-            v_[r_] = __uint_as_float(sw_[0]);                                                                               \
-            v_[4 + r_] = __uint_as_float(sw_[1]);                                                                           \
-        }                                                                                                                   \
-        if constexpr (SCALED) {                                                                                             \
-            _Pragma("unroll") for (int e_ = 0; e_ < 8; ++e_) v_[e_] *= sa8[mi_] * sb8[pr_][e_];                             \
-        }                                                                                                                   \
-        const uint64_t e0_ = e0_lane + (e0_tile + (uint64_t)((mi_) * 16) * (uint64_t)epi.N + (pr_) * 32);                      \
-        A4R_EPI_CALL(mi_, pr_)                                                                                              \
-                                           DACT != A4R_ACT_NONE ? pre_s##mi_##_##pr_ : nullptr, R1PF ? r1_s##mi_##_##pr_ : nullptr, nullptr, \
-                                           A4R_EPI_CDST(mi_, pr_), e0_, cmul8[mi_], q8t ? q8_c2 + (2 * (mi_) + (pr_)) * 512 : nullptr); \
-    }
-#define A4R_EPI_ROW(mi_, n1_, n2_, n4_)                                                                                     \
-    A4R_LD_AHEAD(A4R_LD_PRE, PRE_D, n1_, n2_, n4_)                                                                          \
-    A4R_LD_AHEAD(A4R_LD_R1, R1_D, n1_, n2_, n4_)                                                                            \
-    A4R_EPI_PAIR(mi_, 0) A4R_EPI_PAIR(mi_, 1)
-    // (short tile: leave after the last active row -- straight-line code with exits, so hipcc's counted waits stay exact)
-#define A4R_EPI_END(n_) if (TAIL && t_kp <= (n_)) break;
-    do {
-        A4R_EPI_ROW(0, 1, 2, 4) A4R_EPI_END(1) A4R_EPI_ROW(1, 2, 3, 5) A4R_EPI_END(2) A4R_EPI_ROW(2, 3, 4, 6) A4R_EPI_END(3) A4R_EPI_ROW(3, 4, 5, 7) A4R_EPI_END(4)
-        A4R_EPI_ROW(4, 5, 6, 8) A4R_EPI_END(5) A4R_EPI_ROW(5, 6, 7, 8) A4R_EPI_END(6) A4R_EPI_ROW(6, 7, 8, 8) A4R_EPI_END(7) A4R_EPI_ROW(7, 8, 8, 8)
-    } while (0);
-#undef A4R_EPI_END
-#undef A4R_RC
-#undef A4R_EPI_ROW
-#undef A4R_EPI_PAIR
-#undef A4R_EPI_CDST
-#undef A4R_LD_AHEAD
-#undef A4R_LD_PRE
-#undef A4R_LD_R1
+#define A4R_ACC_LOAD4(dst_, mi_, ni_) _Pragma("unroll") for (int r4_ = 0; r4_ < 4; ++r4_) dst_[r4_] = acc[mi_][ni_][r4_];
+#include "a4r_gemm256_epi.inc"
+#undef A4R_ACC_LOAD4
     A4R_TLT(3)
 #ifdef A4R_STAMP
     ++tile_no_;
@@ -804,6 +644,16 @@ extern "C" int a4r_gemm_tail_plan(int M, int N, int* p_full, int* kp) {
     return 0;
 }
 
+// a4r_gemm256w4.hip: the four-wave, hand-scheduled form of this kernel (bf16 operands, no short-tile tail, an even K-tile count >= 4)
+int a4r_gemm_nt_256w4(hipStream_t s, const a4r_gemm_t& g, int to_f32, int act, int dact, int ef, int ntm, int ntn, int gn, int grid);
+static int g_w4 = -1;
+int a4r_gemm_w4(int v) {            // v = 0 / 1 sets, anything else queries (a4r_gemm_variant 8 / 9; initial value: A4R_GEMM_W4 or 0)
+    if (g_w4 < 0) g_w4 = getenv("A4R_GEMM_W4") ? atoi(getenv("A4R_GEMM_W4")) != 0 : 0;
+    const int old = g_w4;
+    if (v == 0 || v == 1) g_w4 = v;
+    return old;
+}
+
 namespace {
 
 int g_band = -1;        // A4R_GEMM_BAND: -1 = automatic, 0 = panel-major map always, n > 0 = bands of n N-tiles wherever the banded map applies
@@ -865,6 +715,13 @@ int launch256(hipStream_t s, const a4r_gemm_t& g) {
     static const int band_tail = getenv("A4R_GEMM_BAND_TAIL") ? atoi(getenv("A4R_GEMM_BAND_TAIL")) != 0 : 1;
     const bool band_ok = tail_kp == 0 || (band_tail && sizeof(TI) == 2 && ntm > 0 && ntm % 8 == 0 && grid == n_cu);   // (ViT + LoRA same box: bf16 30.16 -> 30.05 ms; e4m3 +0.4 %: bf16 only)
     const int gn = (band_ok ? band_for(g, ntm, ntn, grid, (int)sizeof(TI)) : 0) | (no_stream << 16) | (delay << 17);
+    if constexpr (sizeof(TI) == 2) {                       // bf16 operands: the four-wave kernel (a4r_gemm256w4.hip) where it applies and is switched on
+        const int nk = g.K / 64;
+        if (a4r_gemm_w4(-1) && tail_kp == 0 && ntm > 0 && nk >= 4 && !(nk & 1)) {
+            const int r = a4r_gemm_nt_256w4(s, g, sizeof(TO) == 4, ACT, DACT, EF, ntm, ntn, gn, grid);
+            if (r != 1) return r;                          // (1: this epilogue form is not instantiated there)
+        }
+    }
     hipLaunchKernelGGL((gemm_nt_256_kernel<TI, TO, ACT, DACT, EF>), dim3(grid), dim3(512), 0, s, g, ntm, ntn, gn,
                        a4r_thr16(g.drop_p), a4r_keep_scale(g.drop_p), tail_kp, tail_rows);
     return a4r_launch_status();
