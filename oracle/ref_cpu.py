@@ -46,6 +46,16 @@ DEFAULT_CFG = dict(
 )
 
 
+# --------------------------------------------------------------------------- training-mode dropout (optional)
+def _drop(cfg, kind, site, x, p_key, **kw):
+    """cfg['drop'] = an oracle.dropout_masks.DropoutStream (tests only): multiply by the SAME keep mask the HIP kernels regenerate from
+    (seed, site, element) at this site of the reference (torch.nn.Dropout, train mode).  Absent: eval mode, no dropout (the fixtures' mode)."""
+    d = cfg.get('drop')
+    if d is None or site is None:
+        return x
+    return x * d.mask(kind, site, x, float(cfg.get(p_key, 0.0)), **kw)
+
+
 # --------------------------------------------------------------------------- math
 def layer_norm(x, w, b, eps):
     mu = x.mean(-1, keepdim=True)
@@ -140,10 +150,11 @@ def bert_embed(sd, ids, cfg):
         w = sd[e + 'word_embeddings.weight'][ids]
     x = w + sd[e + 'position_embeddings.weight'][position_ids(ids, cfg)] \
         + sd[e + 'token_type_embeddings.weight'][0]
-    return layer_norm(x, sd[e + 'LayerNorm.weight'], sd[e + 'LayerNorm.bias'], cfg['bert_ln_eps'])
+    x = layer_norm(x, sd[e + 'LayerNorm.weight'], sd[e + 'LayerNorm.bias'], cfg['bert_ln_eps'])
+    return _drop(cfg, 'rows', 999, x, 'p_hidden')          # HF BertEmbeddings.forward: LayerNorm -> dropout
 
 
-def bert_self_output(sd, p, hidden, inp, cfg):
+def bert_self_output(sd, p, hidden, inp, cfg, site=None, rows='rows'):
     """The (possibly wrapped) BertSelfOutput / BertOutput at prefix ``p``.
 
     plain HF:                dense -> dropout -> LN(h + inp)
@@ -154,10 +165,11 @@ def bert_self_output(sd, p, hidden, inp, cfg):
     """
     eps = cfg['bert_ln_eps']
     if p + 'self_output.dense.weight' not in sd:                       # un-adapted
-        h = linear(hidden, sd[p + 'dense.weight'], sd[p + 'dense.bias'])
+        h = _drop(cfg, rows, site, linear(hidden, sd[p + 'dense.weight'], sd[p + 'dense.bias']), 'p_hidden')
         return layer_norm(h + inp, sd[p + 'LayerNorm.weight'], sd[p + 'LayerNorm.bias'], eps)
     so = p + 'self_output.'
     h = linear(hidden, sd[so + 'dense.weight'], sd[so + 'dense.bias'])
+    h = _drop(cfg, rows, site, h, 'p_hidden')               # every wrapper: self_output.dropout right behind self_output.dense (model.py:266-268, 293-294, 322-323, 716-717)
     lw, lb = sd[so + 'LayerNorm.weight'], sd[so + 'LayerNorm.bias']
     if p + 'LN.weight' in sd:                                          # Pfeiffer
         r = h
@@ -171,7 +183,7 @@ def bert_self_output(sd, p, hidden, inp, cfg):
     return layer_norm(houlsby_block(sd, p + 'adapter.', h, cfg) + inp, lw, lb, eps)
 
 
-def bert_attention(sd, p, x, key_mask, cfg):
+def bert_attention(sd, p, x, key_mask, cfg, site=None):
     """HF BertSelfAttention (eager): softmax(QK^T/sqrt(dh) + (1-mask)*finfo.min) V."""
     n, s, hdim = x.shape
     nh = cfg['bert_heads']
@@ -182,7 +194,7 @@ def bert_attention(sd, p, x, key_mask, cfg):
     q, k, v = [t.view(n, s, nh, dh).transpose(1, 2) for t in (q, k, v)]
     sc = q @ k.transpose(-1, -2) / math.sqrt(dh)
     sc = sc + (1.0 - key_mask.float())[:, None, None, :] * torch.finfo(torch.float32).min
-    pr = torch.softmax(sc, -1)
+    pr = _drop(cfg, 'attn_item', site, torch.softmax(sc, -1), 'p_attn', head_dim=dh)      # HF BertSelfAttention: dropout(attention_probs)
     return (pr @ v).transpose(1, 2).reshape(n, s, hdim)
 
 
@@ -192,10 +204,14 @@ def bert_encode(sd, ids, key_mask, cfg, return_all=False):
     i = 0
     while BERT + f'encoder.layer.{i}.attention.self.query.weight' in sd:
         lp = BERT + f'encoder.layer.{i}.'
-        ctx = bert_attention(sd, lp + 'attention.self.', x, key_mask, cfg)
-        x1 = bert_self_output(sd, lp + 'attention.output.', ctx, x, cfg)
+        # (masks only: behind the LAST layer's attention the product keeps the CLS row of every item -- all the item head reads -- so its
+        # two dense dropouts there are drawn on [items, H] rows; 'rows_cls' puts that mask on token 0 and leaves the other tokens alone;
+        # cfg['drop_cls_only'] = engine.cls_only: False for the parallel form and the K-Adapter, which need every token row)
+        rows = 'rows' if (BERT + f'encoder.layer.{i + 1}.attention.self.query.weight' in sd or return_all or not cfg.get('drop_cls_only', True)) else 'rows_cls'
+        ctx = bert_attention(sd, lp + 'attention.self.', x, key_mask, cfg, site=16 * i)
+        x1 = bert_self_output(sd, lp + 'attention.output.', ctx, x, cfg, site=16 * i + 1, rows=rows)
         u = gelu_erf(linear(x1, sd[lp + 'intermediate.dense.weight'], sd[lp + 'intermediate.dense.bias']))
-        x = bert_self_output(sd, lp + 'output.', u, x1, cfg)
+        x = bert_self_output(sd, lp + 'output.', u, x1, cfg, site=16 * i + 2, rows=rows)
         outs.append(x)
         i += 1
     return outs if return_all else x
@@ -224,6 +240,8 @@ def text_encoder(sd, news, cfg, return_all=False):
 def kadapter_block(sd, p, x, n_heads, cfg):
     """model/modules.py:161-206 KAdapterBlock: down_project -> 2 plain post-LN TransformerBlocks under an all-zero additive mask (no
     key mask, NOT causal) -> up_project, + input."""
+    if cfg.get('drop') is not None:
+        raise NotImplementedError('training-mode masks are not restated for the K-Adapter blocks')
     h = linear(x, sd[p + 'down_project.weight'], sd[p + 'down_project.bias'])
     c = dict(cfg, sasrec_heads=n_heads, lora_r_sasrec=0, is_serial='True')
     for j in range(2):
@@ -237,7 +255,7 @@ def _sasrec_names(sd, bp):
     return tb + 'multi_head_attention.', tb + 'feed_forward.'
 
 
-def sasrec_block(sd, bp, x, add_mask, cfg):
+def sasrec_block(sd, bp, x, add_mask, cfg, site=None):
     """modules.py:45-87 (plain block) and the wrappers model/model.py:341-376 (Houlsby),
     :388-423 (pfeiffer_ver2), :435-471 (pfeiffer), :474-520 (parallel), :659-693 (compacter)."""
     mha, ff = _sasrec_names(sd, bp)
@@ -249,13 +267,16 @@ def sasrec_block(sd, bp, x, add_mask, cfg):
     v = lora_linear(sd, mha + 'w_V.', x, cfg['lora_r_sasrec'])
     q, k, v = [z.view(b, t, nh, dk).transpose(1, 2) for z in (q, k, v)]
     pr = torch.softmax(q @ k.transpose(-1, -2) / (dk ** 0.5) + add_mask, -1)
+    pr = _drop(cfg, 'attn_user', site, pr, 'p_sas')                                        # modules.py:40 SelfAttention.dropout
     h = linear((pr @ v).transpose(1, 2).reshape(b, t, d), sd[mha + 'fc.weight'])
+    h = _drop(cfg, 'rows_user', None if site is None else site + 1, h, 'p_sas')           # modules.py:70 dropout(fc(x)); every wrapper keeps it there
     ln1 = (sd[mha + 'layer_norm.weight'], sd[mha + 'layer_norm.bias'], 1e-6)
     ln2 = (sd[ff + 'layer_norm.weight'], sd[ff + 'layer_norm.bias'], 1e-6)
 
     def ffn(z):
-        return linear(torch.clamp(linear(z, sd[ff + 'w_1.weight'], sd[ff + 'w_1.bias']), min=0),
-                      sd[ff + 'w_2.weight'], sd[ff + 'w_2.bias'])
+        o = linear(torch.clamp(linear(z, sd[ff + 'w_1.weight'], sd[ff + 'w_1.bias']), min=0),
+                   sd[ff + 'w_2.weight'], sd[ff + 'w_2.bias'])
+        return _drop(cfg, 'rows_user', None if site is None else site + 2, o, 'p_sas')     # modules.py:27 dropout(w_2(relu(w_1 x)))
 
     if bp + 'LN.weight' in sd:                                         # pfeiffer
         x1 = layer_norm(x + h, *ln1)
@@ -287,6 +308,7 @@ def user_encoder(sd, input_embs, log_mask, cfg):
     add_mask = torch.where(allowed, torch.tensor(0.0), torch.tensor(-1e9))
     x = layer_norm(input_embs + sd[UE + 'position_embedding.weight'][:t],
                    sd[UE + 'layer_norm.weight'], sd[UE + 'layer_norm.bias'], 1e-6)
+    x = _drop(cfg, 'rows', 4000, x, 'p_sas')                # modules.py:104 dropout(layer_norm(input + position))
     i = 0
     if UE + 'transformer_blocks.com_dense2.weight' in sd:      # K-Adapter, model/model.py:562-583 SASRecKAdaptedTransformerBlocks
         last = 0
@@ -299,7 +321,7 @@ def user_encoder(sd, input_embs, log_mask, cfg):
         bp = UE + f'transformer_blocks.{i}.'
         if not any(k.startswith(bp) for k in sd):
             break
-        x = sasrec_block(sd, bp, x, add_mask, cfg)
+        x = sasrec_block(sd, bp, x, add_mask, cfg, site=4096 + 16 * i)
         i += 1
     return x
 

@@ -1,0 +1,185 @@
+"""World-size-8 rehearsal of the data-parallel path on CPU (gloo, eight processes, kernels simulated by tests/sim_lib.py): what the driver's 8-GPU
+scaling run executes over RCCL, at the target's rank count, on BASELINE.json configs[3]'s model family (RoBERTa + Pfeiffer + CPC: a trainable
+LayerNorm per adapter, CPC's item-slot compaction) and with ragged histories that give every rank a different kept-row count.
+
+  (a) three optimizer steps through FlatDDP + FusedAdam: the replicas end BIT-IDENTICAL, the averaged gradients of step 1 equal the mean of the
+      per-rank gradients of the CPU oracle;
+  (b) host-side log masks with a different number of encoded item slots on every rank (the chunked exchange is the same byte ranges everywhere);
+  (c) SequentialDistributedSampler + the sharded item sweep with user / item counts that 8 does not divide: HR@10 / nDCG@10 = one process's;
+  (d) a NaN on one rank stops all of them (FlatDDP.any_rank);
+  (e) bench.py --gpus 8: launcher, rendezvous and the single JSON line (control-only).
+Reference: Downstream/Text/run.py:503,584,599-603, data_utils/dataset.py:81-108, data_utils/metrics.py:35-48."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+WORLD = 8
+NAME = 'roberta_cpc_pfeiffer'
+
+
+def rank_batch(items, mask, rank):
+    """two users per rank out of the fixture's four, histories cut to a rank-dependent length (left-padded like BuildTrainDataset.__getitem__,
+    dataset.py:24-49): log_mask = [0] * pad + [1] * (len - 1)"""
+    B = mask.shape[0]
+    users = [rank % B, (rank + 1 + rank // B) % B]
+    it = items.view(B, 42, -1)[users].clone()
+    real = items[(items[:, items.shape[1] // 2:] != 0).any(1)]
+    empty = ~(it[..., it.shape[-1] // 2:] != 0).any(-1)       # the fixture's short users hold the pad item (no attended token) in their pad slots:
+    it[empty] = real[: int(empty.sum())]                        # every slot gets a real title here, the raggedness comes from lm below
+    lm = torch.ones(2, mask.shape[1])
+    for j in range(2):
+        keep = 3 + 2 * ((rank + 3 * j) % 8)             # 3 .. 17 valid positions
+        lm[j, :mask.shape[1] - keep] = 0
+    return it.reshape(2 * 42, -1), lm
+
+
+def _setup(rank, world, port):
+    sys.path.insert(0, HERE)
+    sys.path.insert(0, os.path.dirname(HERE))
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    torch.set_num_threads(1)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    import sim_lib
+    import adapter4rec_amd.engine as E
+    import adapter4rec_amd.optim as O
+    import adapter4rec_amd.data_utils.metrics as MT
+    E.L = sim_lib
+    O.L = sim_lib
+    MT.L = sim_lib
+    E.TransRecEngine._require_device = lambda self, p0: None
+
+
+def _train_worker(rank, world, port, out_dir):
+    _setup(rank, world, port)
+    from test_engine_host_logic import build_cpu
+    from adapter4rec_amd.ddp import FlatDDP
+    from adapter4rec_amd.inject import optimizer_groups
+    from adapter4rec_amd.optim import FusedAdam
+    root, args, fx, items, mask = build_cpu(NAME)
+    with torch.no_grad():                                # ranks start apart: the wrapper must broadcast rank 0's state
+        for p in root.parameters():
+            if p.requires_grad:
+                p.add_(0.003 * rank)
+    model = FlatDDP(root)
+    opt = FusedAdam(optimizer_groups(model, args))
+    my_items, my_mask = rank_batch(items, mask, rank)
+    inner = getattr(root, 'model', root)
+    out = dict(kept=[], losses=[])
+    for step in range(3):
+        opt.zero_grad()
+        loss = model(my_items, my_mask, 'cpu')          # log_mask on the HOST: the pad structure is read there, unread slots are not encoded
+        out['kept'].append(int(inner._engine()._ctx['n_items']))
+        loss.backward()
+        if step == 0:
+            out['grads'] = {n: p.grad.clone() for n, p in model.named_parameters() if p.requires_grad}
+        opt.step()
+        out['losses'].append(loss.item())
+    out['params'] = {n: p.detach().clone() for n, p in model.named_parameters() if p.requires_grad}
+    # (d) the end-of-epoch NaN decision of run.py:601-603: rank 5 alone sees a NaN -> every rank must say so; nobody -> nobody
+    out['nan_any'] = model.any_rank(rank == 5)
+    out['nan_none'] = model.any_rank(False)
+    torch.save(out, os.path.join(out_dir, f't{rank}.pt'))
+    dist.destroy_process_group()
+
+
+def test_world8_three_steps_ragged_masks(tmp_path):
+    port = 29500 + ((os.getpid() + 101) % 400)
+    mp.spawn(_train_worker, args=(WORLD, port, str(tmp_path)), nprocs=WORLD, join=True)
+    res = [torch.load(tmp_path / f't{r}.pt', weights_only=False) for r in range(WORLD)]
+    for r in range(1, WORLD):
+        for k in res[0]['params']:
+            assert torch.equal(res[0]['params'][k], res[r]['params'][k]), (r, k)           # replicas bit-identical after three steps
+            assert torch.equal(res[0]['grads'][k], res[r]['grads'][k]), (r, k)             # every rank holds the same averaged gradient
+    assert all(x['nan_any'] is True and x['nan_none'] is False for x in res)
+    kept = [x['kept'][0] for x in res]
+    assert len(set(kept)) >= 4, kept                                                        # really ragged: different item counts per rank
+    # the averaged gradient = the mean over ranks of the ORACLE's per-rank gradients (from rank 0's weights, which the wrapper broadcast)
+    sys.path.insert(0, HERE)
+    from golden_util import load_variant, strip
+    from oracle import ref_cpu as R
+    sd, cfg, fx, trainable, (items, mask), base = load_variant(NAME)
+    names = [strip(str(k)) for k in fx['trainable']]
+    acc, losses = None, []
+    for r in range(WORLD):
+        it, lm = rank_batch(items, mask, r)
+        o, g = R.loss_and_grads(sd, names, it, lm, cfg)
+        losses.append(float(o['loss'].detach()))
+        acc = g if acc is None else {k: acc[k] + g[k] for k in g}
+    np.testing.assert_allclose([x['losses'][0] for x in res], losses, atol=1e-4, rtol=0)
+    for k in names:
+        want = (acc[k] / WORLD).numpy()
+        got = res[0]['grads']['module.' + k].numpy()
+        np.testing.assert_allclose(got, want, atol=1e-6 + 1e-4 * np.abs(want).max(), rtol=0, err_msg=k)
+    assert all(np.isfinite(x['losses']).all() for x in res)
+
+
+def _eval_users(n_users, n_items):
+    rng = np.random.default_rng(4)
+    eval_seq, hist = {}, {}
+    for u in range(n_users):
+        seq = [int(x) for x in rng.choice(np.arange(1, n_items), size=int(rng.integers(3, 22)), replace=False)]
+        eval_seq[u], hist[u] = seq, torch.LongTensor(seq[:-1])
+    return eval_seq, hist
+
+
+def _eval_worker(rank, world, port, out_dir):
+    _setup(rank, world, port)
+    import logging
+    from test_engine_host_logic import build_cpu
+    from adapter4rec_amd.ddp import FlatDDP
+    from adapter4rec_amd.data_utils.metrics import eval_model, get_item_embeddings
+    root, args, fx, items, mask = build_cpu('houlsby')
+    model = FlatDDP(root)
+    g = torch.Generator().manual_seed(3)
+    content = items[torch.randint(0, items.shape[0], (101,), generator=g)]                 # 101 items: 8 does not divide them
+    table = get_item_embeddings(model, content.numpy(), 16, args, True, 'cpu')
+    eval_seq, hist = _eval_users(13, 101)                                                   # 13 users on 8 ranks x batch 4
+    hit = eval_model(model, hist, eval_seq, table, 4, args, 100, logging.getLogger('ddp8'), 'valid', 'cpu')
+    torch.save(dict(table=table, hit=hit, content=content), os.path.join(out_dir, f'e{rank}.pt'))
+    dist.destroy_process_group()
+
+
+def test_world8_sharded_item_sweep_and_eval(tmp_path):
+    port = 29500 + ((os.getpid() + 211) % 400)
+    mp.spawn(_eval_worker, args=(WORLD, port, str(tmp_path)), nprocs=WORLD, join=True)
+    res = [torch.load(tmp_path / f'e{r}.pt', weights_only=False) for r in range(WORLD)]
+    for r in range(1, WORLD):
+        assert torch.equal(res[0]['table'], res[r]['table'])
+        assert res[0]['hit'] == res[r]['hit']
+    assert res[0]['table'].shape == (101, 64)
+    sys.path.insert(0, HERE)
+    import logging
+    import sim_lib
+    import adapter4rec_amd.engine as E
+    import adapter4rec_amd.data_utils.metrics as MT
+    real_L, real_req = E.L, E.TransRecEngine._require_device
+    try:
+        E.L = sim_lib
+        MT.L = sim_lib
+        E.TransRecEngine._require_device = lambda self, p0: None
+        from test_engine_host_logic import build_cpu
+        from adapter4rec_amd.data_utils.metrics import eval_model, get_item_embeddings
+        root, args, fx, items, mask = build_cpu('houlsby')
+        full = get_item_embeddings(root, res[0]['content'].numpy(), 16, args, True, 'cpu')
+        np.testing.assert_allclose(res[0]['table'].numpy(), full.numpy(), rtol=0, atol=1e-6)
+        eval_seq, hist = _eval_users(13, 101)
+        hit1 = eval_model(root, hist, eval_seq, full, 4, args, 100, logging.getLogger('ddp8'), 'valid', 'cpu')
+        assert res[0]['hit'] == hit1
+    finally:
+        E.L, E.TransRecEngine._require_device = real_L, real_req
+        MT.L = real_L
+
+
+def test_world8_bench_launch_control_only():
+    from test_bench_launch import json_lines, run
+    r = run(['--gpus', '8', '--steps', '1', '--warmup', '0', '--workload', 'roberta_pfeiffer_cpc'])
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = json_lines(r.stdout)
+    assert len(lines) == 1, r.stdout
+    assert lines[0]['n_gpus'] == 8 and lines[0]['rccl_ranks'] == 8
