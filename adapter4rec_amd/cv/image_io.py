@@ -115,9 +115,12 @@ class Build_Lmdb_Dataset(torch.utils.data.Dataset):
     Sampling is the reference's: left-padded slots, one ``random.randint`` negative per position rejected while in the
     user's sequence, last negative slot and pad slots left empty (zeros)."""
 
-    def __init__(self, u2seq, item_num, max_seq_len, db, item_id_to_keys, resize, device='cuda'):
+    def __init__(self, u2seq, item_num, max_seq_len, db, item_id_to_keys, resize, device='cuda', host=False):
+        """host=True (DataLoader worker processes, --num_workers > 0): __getitem__ touches no device -- it returns the decoded records stacked by
+        source size + their slots; collate_host() merges a batch's groups and assemble_batch() uploads / resizes / scatters them in the training process"""
         self.u2seq, self.item_num, self.max_seq_len = u2seq, item_num, max_seq_len + 1
         self.db, self.item_id_to_keys, self.resize, self.device = db, item_id_to_keys, resize, torch.device(device)
+        self.host = bool(host)
 
     def __len__(self):
         return len(self.u2seq)
@@ -147,9 +150,41 @@ class Build_Lmdb_Dataset(torch.utils.data.Dataset):
                 neg = random.randint(1, self.item_num)
             ids.append(neg); slots.append((mask_len + i, 1))
         ids.append(seq[-1]); slots.append((mask_len + tokens_len, 0))
+        if self.host:
+            raw = [decode_record(self.db.get(self.item_id_to_keys[i])) for i in ids]
+            groups = {}
+            for j, a in enumerate(raw):
+                groups.setdefault(tuple(a.shape), []).append(j)
+            out = []
+            for shape, idx in groups.items():
+                out.append((torch.from_numpy(np.stack([raw[j] for j in idx])), torch.tensor([slots[j][0] for j in idx]), torch.tensor([slots[j][1] for j in idx])))
+            return out, torch.tensor(log_mask, dtype=torch.float32)
         imgs = self._load(ids)
         sample = torch.zeros(self.max_seq_len, 2, self.resize, self.resize, 3, dtype=torch.uint8, device=self.device)
         rows = torch.tensor([s[0] for s in slots], device=self.device)
         cols = torch.tensor([s[1] for s in slots], device=self.device)
         sample[rows, cols] = imgs
         return sample, torch.tensor(log_mask, dtype=torch.float32)
+
+
+def collate_host(batch):
+    """DataLoader collate_fn for Build_Lmdb_Dataset(host=True): the batch's records merged per source size
+    -> ([(uint8 [n, H, W, 3], sample index [n], slot row [n], slot column [n]) per size], log_mask [B, L - 1]); plain tensors, so pin_memory applies"""
+    by_shape = {}
+    for b, (groups, _) in enumerate(batch):
+        for t, rows, cols in groups:
+            g = by_shape.setdefault(tuple(t.shape[1:]), ([], [], [], []))
+            g[0].append(t); g[1].append(torch.full((t.shape[0],), b, dtype=torch.long)); g[2].append(rows); g[3].append(cols)
+    merged = [(torch.cat(g[0]), torch.cat(g[1]), torch.cat(g[2]), torch.cat(g[3])) for g in by_shape.values()]
+    return merged, torch.stack([m for _, m in batch])
+
+
+def assemble_batch(merged, B, L, R, device):
+    """the training process's half of the host path: one H2D copy + two resample launches per source size, scattered into uint8 [B, L, 2, R, R, 3]
+    (pad slots and every user's last negative stay zero, as Build_Lmdb_Dataset.__getitem__ leaves them)"""
+    out = torch.zeros(B, L, 2, R, R, 3, dtype=torch.uint8, device=device)
+    for t, bidx, rows, cols in merged:
+        x = t.to(device, non_blocking=True)
+        y = resize_to_square(x, R) if (x.shape[1] != R or x.shape[2] != R) else x
+        out[bidx.to(device, non_blocking=True), rows.to(device, non_blocking=True), cols.to(device, non_blocking=True)] = y
+    return out

@@ -22,7 +22,7 @@ from ..inject import freeze_all
 from ..optim import FusedAdam
 from . import Model, ModelCPC, ViTForImageClassification, ViTMAEModel
 from .data_utils import eval_model, get_itemLMDB_embeddings, open_image_db, read_behaviors, read_images
-from .image_io import Build_Lmdb_Dataset
+from .image_io import Build_Lmdb_Dataset, assemble_batch, collate_host
 from .inject import inject_adapters, optimizer_groups
 from .parameters import parse_args
 
@@ -32,7 +32,12 @@ def load_backbone(args, Log_file):
     (transformers >= 5 renamed the modules); a config-only directory gives a random-init backbone of that geometry."""
     mae = 'mae' in args.CV_model_load
     path = '../pretrained_models/' + (args.CV_model_load if mae else 'vit-base-patch16-224')
-    net = ViTMAEModel() if mae else ViTForImageClassification()
+    geom = None
+    if os.path.exists(os.path.join(path, 'config.json')):              # (HF from_pretrained reads the geometry from the directory's config.json)
+        import json
+        with open(os.path.join(path, 'config.json')) as f:
+            geom = {k: v for k, v in json.load(f).items() if not isinstance(v, (dict, list))}
+    net = ViTMAEModel(geom) if mae else ViTForImageClassification(geom)
     weights = [os.path.join(path, f) for f in ('model.safetensors', 'pytorch_model.bin') if os.path.exists(os.path.join(path, f))]
     if weights:
         Log_file.info(f'load {path} ...')
@@ -104,10 +109,17 @@ def train(args, use_modal, local_rank, Log_file, Log_screen, model_dir, start_ti
         os.path.join(args.root_data_dir, args.dataset, args.behaviors), before_keys, before_name2id, args.max_seq_len,
         args.min_seq_len, Log_file)
     db = open_image_db(os.path.join(args.root_data_dir, args.dataset, args.lmdb_data))
-    train_dataset = Build_Lmdb_Dataset(users_train, item_num, args.max_seq_len, db, item_id_to_keys, args.CV_resize, device=f'cuda:{local_rank}')
+    # --num_workers n > 0 (the reference's DataLoader pool, run_adapter.py:448-450; its 12 workers do PIL resizing on the CPU): the workers decode the
+    # records and stack them by source size (no device in a worker), the pinned batches are uploaded, resized and scattered on the GPU here
+    # (image_io.assemble_batch) while the previous step computes.  --num_workers 0: decode in this process.
+    host = args.num_workers > 0
+    train_dataset = Build_Lmdb_Dataset(users_train, item_num, args.max_seq_len, db, item_id_to_keys, args.CV_resize, device=f'cuda:{local_rank}', host=host)
     sampler = torch.utils.data.distributed.DistributedSampler(train_dataset)
-    # records are decoded in this process and resized on the GPU: no worker pool (the reference's 12 workers do PIL on the CPU)
-    train_dl = DataLoader(train_dataset, batch_size=args.batch_size, num_workers=0, sampler=sampler, collate_fn=_collate)
+    if host:
+        train_dl = DataLoader(train_dataset, batch_size=args.batch_size, num_workers=args.num_workers, sampler=sampler, collate_fn=collate_host,
+                              pin_memory=True, persistent_workers=True, prefetch_factor=2)
+    else:
+        train_dl = DataLoader(train_dataset, batch_size=args.batch_size, num_workers=0, sampler=sampler, collate_fn=_collate)
     model, start_epoch, ckpt2 = build_model(args, item_num, use_modal, cv_model, local_rank, Log_file, model_dir)
     model = FlatDDP(model, device_ids=[local_rank], output_device=local_rank)
     optimizer = FusedAdam(optimizer_groups(model, args))
@@ -124,7 +136,13 @@ def train(args, use_modal, local_rank, Log_file, Log_screen, model_dir, start_ti
         loss, batch_index, need_break = 0.0, 1, False
         model.train()
         train_dl.sampler.set_epoch(now_epoch)
+        # Build_Lmdb_Dataset draws its negatives from Python's `random` in THIS process (no worker pool, see above), and the checkpoint holds the torch
+        # RNG state only (utils.py:109-115): the epoch's stream is re-seeded from the torch generator, so a resumed run draws the negatives the
+        # uninterrupted run would have (the text entry point gets the same from its DataLoader workers' torch-derived seeds)
+        random.seed(int(torch.randint(0, 2 ** 31 - 1, (1,)).item()))
         for sample_items, log_mask in train_dl:
+            if host:
+                sample_items = assemble_batch(sample_items, log_mask.shape[0], args.max_seq_len + 1, R, torch.device('cuda', local_rank))
             sample_items = sample_items.view(-1, R, R, 3)              # uint8 HWC (the reference: .view(-1, 3, R, R) of fp32)
             optimizer.zero_grad()                                      # (log_mask stays on the host: Model.forward uploads it, the engine reads the pad slots from it)
             bz_loss = model(sample_items, log_mask, local_rank)

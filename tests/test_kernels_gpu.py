@@ -1344,7 +1344,7 @@ def test_gemm256_four_wave_bit_equal_to_eight_wave(N, K):
     try:
         for v in (8, 9):
             L.gemm_variant(v)
-            o = {k: torch.full((M, N), float('nan'), dtype=t, device=dev()) for k in ('plain', 'drop', 'res', 'dropres', 'gelu8t', 'dmul8t', 'gelu', 'gelu_c2', 'dmul', 'relu')}
+            o = {k: torch.full((M, N), float('nan'), dtype=t, device=dev()) for k in ('plain', 'drop', 'res', 'dropres', 'gelu8t', 'gelu', 'gelu_c2', 'dmul', 'relu')}
             C8 = torch.zeros(M, N, dtype=torch.uint8, device=dev())
             f32 = torch.zeros(M, N, dtype=torch.float32, device=dev())
             L.gemm_nt(A, B, o['plain'], bias=bias)
