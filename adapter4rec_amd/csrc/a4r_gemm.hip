@@ -287,8 +287,10 @@ extern int g_tn_variant;                                     // a4r_gemm_tn.hip:
 // Leading rows (a multiple of 256) of an [M, N] output that the 256 x 256-tile kernel computes; the rows behind them go to the 128-tile
 // kernel.  A function of (M, N), the CU count and a4r_gemm_variant only -- NOT of the operand type: a tile-native 8-bit derivative
 // (a4r_gemm_t.q8_tiled) is tile-native on exactly these rows and row-major behind them, for every launch that writes or reads it.
-//   * fewer 256-tiles than half the CUs (8 users: 120 tiles at N = 768): the 128-tile kernel fills the chip better (measured 505 vs
-//     454, 735 vs 624, 774 vs 637 TF/s at M = 10240; the large tile wins from 198 tiles on) -> 0;
+//   * no more 256-tiles than a QUARTER of the CUs (the CLS-only last layer: 18 tiles): the 128-tile kernel fills the chip better -> 0.
+//     (Rounds 1 - 4 drew the line at half the CUs, from round-2 measurements; re-measured on round-5 code, tools/gemm_small_m.py ->
+//     profiles/r05_e_gemm_small_m.txt: at 90 - 120 tiles the 256-tile kernel is 1.2 - 1.6 x faster at every K -- 8 users, N = 768: 20.8 vs
+//     25.9 us at K = 768, 57.1 vs 68.2 at K = 3072 --, at <= 60 tiles it wins at K = 768 and loses 15 - 20 % at K >= 2304.)
 //   * a partial last round that a4r_gemm_tail_plan cuts into short tiles runs inside the same launch -> M;
 //   * a last round of only a few whole row panels (ViT-B/16 at 8 users: 777 tiles = 3 rounds + 9 tiles) goes to the 128-tile kernel
 //     as a second launch instead of costing a full round (N = 768, K = 3072: 4 -> 3 rounds + ~1/4) -> the rows in front of it.
@@ -296,7 +298,7 @@ extern "C" int a4r_gemm_rows_256(int M, int N) {
     if (g_variant < 2 || M <= 0 || N <= 0 || M % 256 || N % 256) return 0;
     const int ntm = M / 256, ntn = N / 256, tiles = ntm * ntn, ncu = a4r_cu_count();
     const int rem = tiles % ncu;
-    if (tiles * 2 <= ncu && g_variant == 2) return 0;
+    if (tiles * 4 <= ncu && g_variant == 2) return 0;
     int pf_ = 0, kp_ = 0;
     if (a4r_gemm_tail_plan(M, N, &pf_, &kp_)) return M;
     if (tiles > ncu && rem > 0 && rem * 4 <= ncu && rem % ntn == 0 && g_variant < 4) return (ntm - rem / ntn) * 256;

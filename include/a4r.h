@@ -101,7 +101,7 @@ int a4r_gemm_tail_max(int k);
 int a4r_gemm_rows_256(int M, int N);
 /* tuning knob for A/B measurements and tests: 0 = 128x128 tile, register-staged K pipeline; 1 = 128x128 tile, direct-to-LDS
  * (global_load_lds) pipeline; 2 (default) = 256x256 tile with a 2-deep LDS-DMA ring kept in flight across barriers
- * wherever M % 256 == 0, N % 256 == 0 (variant 1 elsewhere), chosen automatically: fewer 256-tiles than half the CUs -> the
+ * wherever M % 256 == 0, N % 256 == 0 (variant 1 elsewhere), chosen automatically: no more 256-tiles than a quarter of the CUs -> the
  * 128-tile kernel; a partial last round -> short tiles in the same launch (a4r_gemm_tail_plan); 4 = the 256 tile
  * forced (tests).  Results of 2 / 4 agree bit for bit, the others to fp32 summation order; returns the previous setting
  * (-1 for the retired variants 3 and 5, any other v only queries).  6 / 7 leave all of that alone and switch the 256 x 256-tile
