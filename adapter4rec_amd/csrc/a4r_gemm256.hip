@@ -781,7 +781,13 @@ int a4r_gemm_nt_256(hipStream_t s, const a4r_gemm_t& g) {
             return 1;
         }
         if (g.dact != A4R_ACT_NONE) return 1;
-        if (g.act == A4R_ACT_NONE) return m == 0 ? launch256<fp8_t, bf16_t, A4R_ACT_NONE, A4R_ACT_NONE, 0>(s, g) : launch256<fp8_t, bf16_t, A4R_ACT_NONE, A4R_ACT_NONE>(s, g);
+        if (g.act == A4R_ACT_NONE) {                  // (round 5: the dropout / residual forms without their run-time tests too -- 33 launches of the fp8 step ran the all-purpose one)
+            if (m == 0) return launch256<fp8_t, bf16_t, A4R_ACT_NONE, A4R_ACT_NONE, 0>(s, g);
+            if (m == 1) return launch256<fp8_t, bf16_t, A4R_ACT_NONE, A4R_ACT_NONE, 1>(s, g);
+            if (m == 2) return launch256<fp8_t, bf16_t, A4R_ACT_NONE, A4R_ACT_NONE, 2>(s, g);
+            if (m == 3) return launch256<fp8_t, bf16_t, A4R_ACT_NONE, A4R_ACT_NONE, 3>(s, g);
+            return launch256<fp8_t, bf16_t, A4R_ACT_NONE, A4R_ACT_NONE>(s, g);
+        }
         if (g.act == A4R_ACT_GELU) return m == 8 ? launch256<fp8_t, bf16_t, A4R_ACT_GELU, A4R_ACT_NONE, 8>(s, g) : launch256<fp8_t, bf16_t, A4R_ACT_GELU, A4R_ACT_NONE>(s, g);
         return 1;
     }
