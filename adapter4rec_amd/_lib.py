@@ -12,7 +12,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('A4R_LIB_PATH') or os.path.join(_HERE, 'liba4r_hip.so')    # A4R_LIB_PATH: A/B builds (tools/), same C ABI
 
-ABI_VERSION = 406          # = A4R_ABI_VERSION of include/a4r.h (tests/test_abi_cpu.py compares the two)
+ABI_VERSION = 407          # = A4R_ABI_VERSION of include/a4r.h (tests/test_abi_cpu.py compares the two)
 BF16, F32, FP8 = 0, 1, 2
 ACT_NONE, ACT_RELU, ACT_GELU, ACT_GELU_TANH, ACT_LEAKY = 0, 1, 2, 3, 4
 DACT_MUL = 15
@@ -47,7 +47,7 @@ class AttnArgs(C.Structure):
                 ('out', C.c_void_p), ('ldo', C.c_int32), ('dout', C.c_void_p), ('dqkv', C.c_void_p), ('key_mask', C.c_void_p),
                 ('n_items', C.c_int32), ('S', C.c_int32), ('n_heads', C.c_int32), ('dh', C.c_int32), ('causal', C.c_int32),
                 ('dtype', C.c_int32), ('scale', C.c_float), ('mask_neg', C.c_float),
-                ('drop_p', C.c_float), ('drop_site', C.c_uint32), ('drop_seed', C.c_uint64)]
+                ('drop_p', C.c_float), ('drop_site', C.c_uint32), ('drop_seed', C.c_uint64), ('offsets', C.c_void_p)]
 
 
 class PackDesc(C.Structure):
@@ -292,8 +292,12 @@ def colsum(X, out, M=None):
     _check(lib().a4r_colsum(_stream(), _p(X), C.c_int(_ld(X)), _p(out), C.c_int(M), C.c_int(X.shape[1]), C.c_int(_dt(X))), 'a4r_colsum')
 
 
-def _attn_args(qkv, q_off, k_off, v_off, key_mask, n_items, S, n_heads, dh, causal, scale, mask_neg, drop_p, drop_site, drop_seed):
+def _attn_args(qkv, q_off, k_off, v_off, key_mask, n_items, S, n_heads, dh, causal, scale, mask_neg, drop_p, drop_site, drop_seed, offsets=None):
     a = AttnArgs()
+    if offsets is not None:
+        require_gpu(offsets)
+        assert offsets.dtype == torch.int32 and offsets.numel() >= n_items + 1
+    a.offsets = _p(offsets)
     a.qkv, a.ld, a.q_off, a.k_off, a.v_off = _p(qkv), _ld(qkv), q_off, k_off, v_off
     a.key_mask = _p(key_mask)
     a.n_items, a.S, a.n_heads, a.dh, a.causal, a.dtype = n_items, S, n_heads, dh, int(causal), _dt(qkv)
@@ -303,18 +307,19 @@ def _attn_args(qkv, q_off, k_off, v_off, key_mask, n_items, S, n_heads, dh, caus
 
 
 def attn_fwd(qkv, out, key_mask, n_items, S, n_heads, dh, q_off, k_off, v_off, causal, scale, mask_neg,
-             drop_p=0.0, drop_site=0, drop_seed=0):
+             drop_p=0.0, drop_site=0, drop_seed=0, offsets=None):
+    """offsets (int32 [n_items + 1] on the device): packed items, see a4r_attn_t.offsets"""
     require_gpu(qkv, out)
-    a = _attn_args(qkv, q_off, k_off, v_off, key_mask, n_items, S, n_heads, dh, causal, scale, mask_neg, drop_p, drop_site, drop_seed)
+    a = _attn_args(qkv, q_off, k_off, v_off, key_mask, n_items, S, n_heads, dh, causal, scale, mask_neg, drop_p, drop_site, drop_seed, offsets)
     a.out, a.ldo = _p(out), _ld(out)
     _check(lib().a4r_attn_fwd(_stream(), C.byref(a)), 'a4r_attn_fwd')
 
 
 def attn_bwd(qkv, dout, dqkv, key_mask, n_items, S, n_heads, dh, q_off, k_off, v_off, causal, scale, mask_neg,
-             drop_p=0.0, drop_site=0, drop_seed=0):
+             drop_p=0.0, drop_site=0, drop_seed=0, offsets=None):
     require_gpu(qkv, dout, dqkv)
     assert _ld(dqkv) == _ld(qkv)
-    a = _attn_args(qkv, q_off, k_off, v_off, key_mask, n_items, S, n_heads, dh, causal, scale, mask_neg, drop_p, drop_site, drop_seed)
+    a = _attn_args(qkv, q_off, k_off, v_off, key_mask, n_items, S, n_heads, dh, causal, scale, mask_neg, drop_p, drop_site, drop_seed, offsets)
     a.dout, a.ldo, a.dqkv = _p(dout), _ld(dout), _p(dqkv)
     _check(lib().a4r_attn_bwd(_stream(), C.byref(a)), 'a4r_attn_bwd')
 

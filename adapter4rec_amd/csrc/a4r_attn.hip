@@ -91,8 +91,9 @@ A4R_DEV void softmax_row(const float (&s)[2], int q, int r16, int S, const float
 template <typename T, int DH, int WAVES>
 __global__ void __launch_bounds__(WAVES * 64) attn_fwd_kernel(const T* __restrict__ qkv, int ld, int q_off, int k_off, int v_off,
                                                               T* __restrict__ out, int ldo, const float* __restrict__ key_mask,
-                                                              int n_items, int S, int n_heads, int causal, float scale, float mask_neg,
-                                                              uint64_t seed, uint32_t site, uint32_t thr16, float keep_scale) {
+                                                              int n_items, int S_in, int n_heads, int causal, float scale, float mask_neg,
+                                                              uint64_t seed, uint32_t site, uint32_t thr16, float keep_scale,
+                                                              const int* __restrict__ offsets) {
     using C = AttnCfg<T, DH>;
     constexpr int WAVE_LDS = 32 * C::PSTRIDE + 32 * C::GSTRIDE;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -105,7 +106,10 @@ __global__ void __launch_bounds__(WAVES * 64) attn_fwd_kernel(const T* __restric
     const bool active = gw < total;
     if (!active) gw = total - 1;
     const int item = gw / n_heads, head = gw % n_heads;
-    const T* base = qkv + (size_t)item * S * ld + head * DH;
+    // packed items (a4r_attn_t.offsets): item i owns rows [offsets[i], offsets[i + 1]) -- its own token count, no pad rows in the tensors
+    const int row0 = offsets ? __builtin_amdgcn_readfirstlane(offsets[item]) : item * S_in;
+    const int S = offsets ? __builtin_amdgcn_readfirstlane(offsets[item + 1]) - row0 : S_in;
+    const T* base = qkv + (size_t)row0 * ld + head * DH;
 
     // (the key mask too: it used to be the third serial round trip of the wave)
     // Loads are UNCONDITIONAL (clamped rows / keys, the out-of-range ones zeroed where they are consumed): with `if (row < S)` around
@@ -114,7 +118,7 @@ __global__ void __launch_bounds__(WAVES * 64) attn_fwd_kernel(const T* __restric
 #pragma unroll
     for (int nt = 0; nt < 2; ++nt) {
         const int key = nt * 16 + r16;
-        km[nt] = key_mask ? key_mask[(size_t)item * S + min(key, S - 1)] : 1.f;
+        km[nt] = key_mask ? key_mask[(size_t)row0 + min(key, S - 1)] : 1.f;
     }
     // V is requested before the scores are computed (its loads used to be issued only after Q K^T had waited for Q and K)
     uint4 sv[C::NLD];
@@ -187,7 +191,7 @@ __global__ void __launch_bounds__(WAVES * 64) attn_fwd_kernel(const T* __restric
         for (int i = 0; i < C::NLD; ++i) {
             const int id = lane + 64 * i, row = id / C::CPR, ch = id % C::CPR;
             if (row < S)
-                *reinterpret_cast<uint4*>(out + ((size_t)item * S + row) * ldo + head * DH + ch * C::PER) =
+                *reinterpret_cast<uint4*>(out + ((size_t)row0 + row) * ldo + head * DH + ch * C::PER) =
                     *reinterpret_cast<const uint4*>(Vs + row * C::OSTRIDE + ch * 16);
         }
     }
@@ -243,9 +247,10 @@ A4R_DEV void store_block(char* stage, const f32x4_t (&acc)[2][AttnCfg<T, DH>::DT
 template <typename T, int DH, int WAVES>
 __global__ void __launch_bounds__(WAVES * 64) attn_bwd_kernel(const T* __restrict__ qkv, int ld, int q_off, int k_off, int v_off,
                                                               const T* __restrict__ dout, int ldo, T* __restrict__ dqkv,
-                                                              const float* __restrict__ key_mask, int n_items, int S, int n_heads,
+                                                              const float* __restrict__ key_mask, int n_items, int S_in, int n_heads,
                                                               int causal, float scale, float mask_neg,
-                                                              uint64_t seed, uint32_t site, uint32_t thr16, float keep_scale) {
+                                                              uint64_t seed, uint32_t site, uint32_t thr16, float keep_scale,
+                                                              const int* __restrict__ offsets) {
     using C = AttnCfg<T, DH>;
     constexpr int TILE = 32 * C::GSTRIDE, IMG = 32 * C::PSTRIDE;
     constexpr int WAVE_LDS = 3 * TILE + 3 * IMG;
@@ -263,15 +268,17 @@ __global__ void __launch_bounds__(WAVES * 64) attn_bwd_kernel(const T* __restric
     const bool active = gw < total;
     if (!active) gw = total - 1;
     const int item = gw / n_heads, head = gw % n_heads;
-    const T* base = qkv + (size_t)item * S * ld + head * DH;
-    const T* dbase = dout + (size_t)item * S * ldo + head * DH;
-    T* gbase = dqkv + (size_t)item * S * ld + head * DH;
+    const int row0 = offsets ? __builtin_amdgcn_readfirstlane(offsets[item]) : item * S_in;
+    const int S = offsets ? __builtin_amdgcn_readfirstlane(offsets[item + 1]) - row0 : S_in;
+    const T* base = qkv + (size_t)row0 * ld + head * DH;
+    const T* dbase = dout + (size_t)row0 * ldo + head * DH;
+    T* gbase = dqkv + (size_t)row0 * ld + head * DH;
 
     float km[2];
 #pragma unroll
     for (int nt = 0; nt < 2; ++nt) {
         const int key = nt * 16 + r16;
-        km[nt] = key_mask ? key_mask[(size_t)item * S + min(key, S - 1)] : 1.f;      // (unconditional load, clamped; keys >= S zeroed below)
+        km[nt] = key_mask ? key_mask[(size_t)row0 + min(key, S - 1)] : 1.f;      // (unconditional load, clamped; keys >= S zeroed below)
     }
     // Every global read of the pair is requested BEFORE anything is consumed, and every byte ONCE: the row-major operand fragments
     // of Q K^T and dO V^T (lane (r16, kg) holds the 16-byte chunk ks * 4 + kg of rows r16 and 16 + r16) are exactly the chunks the
@@ -418,9 +425,10 @@ A4R_DEV float bt_red4(float v, bool mx) {       // over the 4 lanes l, l^16, l^3
 template <int DH, int WAVES>
 __global__ void __launch_bounds__(WAVES * 64, 3) attn_bwd_tr_kernel(const bf16_t* __restrict__ qkv, int ld, int q_off, int k_off, int v_off,
                                                                  const bf16_t* __restrict__ dout, int ldo, bf16_t* __restrict__ dqkv,
-                                                                 const float* __restrict__ key_mask, int n_items, int S, int n_heads,
+                                                                 const float* __restrict__ key_mask, int n_items, int S_in, int n_heads,
                                                                  int causal, float scale, float mask_neg,
-                                                                 uint64_t seed, uint32_t site, uint32_t thr16, float keep_scale) {
+                                                                 uint64_t seed, uint32_t site, uint32_t thr16, float keep_scale,
+                                                                 const int* __restrict__ offsets) {
     using T = bf16_t;
     using G = BtGeo<DH>;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -433,9 +441,11 @@ __global__ void __launch_bounds__(WAVES * 64, 3) attn_bwd_tr_kernel(const bf16_t
     const int gw = blockIdx.x * WAVES + wave;
     if (gw >= total) return;                      // whole waves leave (no workgroup barrier below; EXEC stays all ones for the transposed reads)
     const int item = gw / n_heads, head = gw % n_heads;
-    const T* base = qkv + (size_t)item * S * ld + head * DH;
-    const T* dbase = dout + (size_t)item * S * ldo + head * DH;
-    T* gbase = dqkv + (size_t)item * S * ld + head * DH;
+    const int row0 = offsets ? __builtin_amdgcn_readfirstlane(offsets[item]) : item * S_in;
+    const int S = offsets ? __builtin_amdgcn_readfirstlane(offsets[item + 1]) - row0 : S_in;
+    const T* base = qkv + (size_t)row0 * ld + head * DH;
+    const T* dbase = dout + (size_t)row0 * ldo + head * DH;
+    T* gbase = dqkv + (size_t)row0 * ld + head * DH;
 
     float kmT[2][4];                              // key mask of the keys down the lane's rows
 #pragma unroll
@@ -443,7 +453,7 @@ __global__ void __launch_bounds__(WAVES * 64, 3) attn_bwd_tr_kernel(const bf16_t
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int kt = nt * 16 + kg * 4 + r;
-            kmT[nt][r] = (kt < S) ? (key_mask ? key_mask[(size_t)item * S + kt] : 1.f) : 0.f;      // (as a clamped unconditional load hipcc turned each value into a predicate at once: eight serialized waits)
+            kmT[nt][r] = (kt < S) ? (key_mask ? key_mask[(size_t)row0 + kt] : 1.f) : 0.f;      // (as a clamped unconditional load hipcc turned each value into a predicate at once: eight serialized waits)
         }
     // every global read of the pair is requested before anything is consumed, every byte once (rows >= S: Q, K, V clamp to row S - 1,
     // finite values whose scores are masked / whose dS rows vanish because dO is zero there)
@@ -619,8 +629,8 @@ int launch_fwd(const Launch& L) {
     constexpr int LDS = WAVES * (32 * C::PSTRIDE + 32 * C::GSTRIDE);
     const int total = a.n_items * a.n_heads;
     hipLaunchKernelGGL((attn_fwd_kernel<T, DH, WAVES>), dim3((total + WAVES - 1) / WAVES), dim3(WAVES * 64), LDS, L.s,
-                       (const T*)a.qkv, a.ld, a.q_off, a.k_off, a.v_off, (T*)a.out, a.ldo, a.key_mask, a.n_items, a.S, a.n_heads,
-                       a.causal, a.scale, a.mask_neg, a.drop_seed, a.drop_site, L.thr, L.ks);
+                       (const T*)a.qkv, a.ld, a.q_off, a.k_off, a.v_off, (T*)a.out, a.ldo, a.offsets ? nullptr : a.key_mask, a.n_items, a.S, a.n_heads,
+                       a.causal, a.scale, a.mask_neg, a.drop_seed, a.drop_site, L.thr, L.ks, a.offsets);
     return a4r_launch_status();
 }
 template <typename T, int DH, int WAVES>
@@ -637,8 +647,8 @@ int launch_bwd(const Launch& L) {
     }
     const int total = a.n_items * a.n_heads;
     hipLaunchKernelGGL((attn_bwd_kernel<T, DH, WAVES>), dim3((total + WAVES - 1) / WAVES), dim3(WAVES * 64), LDS, L.s,
-                       (const T*)a.qkv, a.ld, a.q_off, a.k_off, a.v_off, (const T*)a.dout, a.ldo, (T*)a.dqkv, a.key_mask,
-                       a.n_items, a.S, a.n_heads, a.causal, a.scale, a.mask_neg, a.drop_seed, a.drop_site, L.thr, L.ks);
+                       (const T*)a.qkv, a.ld, a.q_off, a.k_off, a.v_off, (const T*)a.dout, a.ldo, (T*)a.dqkv, a.offsets ? nullptr : a.key_mask,
+                       a.n_items, a.S, a.n_heads, a.causal, a.scale, a.mask_neg, a.drop_seed, a.drop_site, L.thr, L.ks, a.offsets);
     return a4r_launch_status();
 }
 
@@ -653,8 +663,8 @@ int launch_bwd_tr(const Launch& L) {
     }
     const int total = a.n_items * a.n_heads;
     hipLaunchKernelGGL((attn_bwd_tr_kernel<DH, WAVES>), dim3((total + WAVES - 1) / WAVES), dim3(WAVES * 64), LDS, L.s,
-                       (const bf16_t*)a.qkv, a.ld, a.q_off, a.k_off, a.v_off, (const bf16_t*)a.dout, a.ldo, (bf16_t*)a.dqkv, a.key_mask,
-                       a.n_items, a.S, a.n_heads, a.causal, a.scale, a.mask_neg, a.drop_seed, a.drop_site, L.thr, L.ks);
+                       (const bf16_t*)a.qkv, a.ld, a.q_off, a.k_off, a.v_off, (const bf16_t*)a.dout, a.ldo, (bf16_t*)a.dqkv, a.offsets ? nullptr : a.key_mask,
+                       a.n_items, a.S, a.n_heads, a.causal, a.scale, a.mask_neg, a.drop_seed, a.drop_site, L.thr, L.ks, a.offsets);
     return a4r_launch_status();
 }
 const bool g_attn_bwd_tr = !(getenv("A4R_ATTN_BWD_TR") && atoi(getenv("A4R_ATTN_BWD_TR")) == 0);      // 0: the generic kernel for bf16 too (A/B, tests)
@@ -669,6 +679,7 @@ int check(const a4r_attn_t* a, bool bwd) {
     if ((a->ld * esz) % 16 || (a->ldo * esz) % 16 || a->q_off % per || a->k_off % per || a->v_off % per) return A4R_EINVAL;
     if (a->ldo < a->n_heads * a->dh) return A4R_EINVAL;
     if (a->drop_p < 0.f || a->drop_p >= 1.f) return A4R_EINVAL;
+    if (a->offsets && narrow) return A4R_EINVAL;        // packed items: the MFMA kernels only
     uintptr_t m = reinterpret_cast<uintptr_t>(a->qkv) | reinterpret_cast<uintptr_t>(a->out) | reinterpret_cast<uintptr_t>(a->dout) |
                   reinterpret_cast<uintptr_t>(a->dqkv);
     if (m & 15u) return A4R_EINVAL;

@@ -622,6 +622,7 @@ class TransRecEngine:
                     raise NotImplementedError(f'projection module {type(lin).__name__}')
             b.lora = _Lora.for_block((att.query, att.key, att.value), H, self, self.T)
             b.H, b.F, b.nh, b.dh, b.S = H, self.F, nh, H // nh, self.S
+            b.is_item = True                       # (a block of the item tower: follows self._pk)
             b.causal, b.mask_neg, b.scale = False, FMIN, 1.0 / math.sqrt(H // nh)
             b.ffn_act = L.ACT_GELU
             b.p_hidden, b.p_attn, b.site = self.p_hidden, self.p_attn, 16 * i
@@ -1015,6 +1016,28 @@ class TransRecEngine:
             L.gemm_nt(z, ad.wu, v, bias=ad.bu, R1=h, R2=resid, M=M)
         L.ln_fwd(v, ln.gamma, ln.beta, ln.eps, out, st, M=M)
 
+    # ---- packed titles (self._pk, set per step by train_forward): item i owns token rows [off[i], off[i + 1]) of every [M, .] tensor of the item
+    # tower -- its own token count instead of the batch's longest title (a4r_attn_t.offsets).  None: n_items x S rows as before.
+    _pk = None
+
+    def _off(self, blk):
+        return self._pk['off'] if (self._pk is not None and getattr(blk, 'is_item', False)) else None
+
+    def _cls_gather(self, src, dst, n_items, S, blk=None):
+        """dst[i] = row of token 0 of item i"""
+        if self._pk is not None and (blk is None or getattr(blk, 'is_item', False)):
+            L.rows_idx_copy(src, dst, self._pk['off'], n_items)
+        else:
+            L.gather_rows(src, dst, n_items, S)
+
+    def _cls_scatter_fill(self, src, dst, n_items, S, M, blk=None):
+        """dst[row of token 0 of item i] = src[i], every other row < M zero"""
+        if self._pk is not None and (blk is None or getattr(blk, 'is_item', False)):
+            L.zero(dst[:M])
+            L.rows_idx_copy(src, dst, self._pk['off'], n_items, scatter=True)
+        else:
+            L.scatter_rows_fill(src, dst, n_items, S, M)
+
     def _twin_of(self, t, M):
         """The fp32 twin of residual-stream tensor t ([>= M, H]) when the producing sub-layer left one in this forward (else None: the bf16
         tensor itself is the residual, e.g. the embedding output or a sub-layer that ran on the multi-launch path)."""
@@ -1055,15 +1078,15 @@ class TransRecEngine:
             # (trainable attention output: its weight gradient needs ctx per layer -- the attention kernel writes the kept buffer directly)
             ctx = bufs['ctx_s'] if ('ctx_s' in bufs and cls_rows is None) else self._buf('ctx', M, H, T)
             L.attn_fwd(bufs['qkv'], ctx, key_mask, n_items, blk.S, blk.nh, blk.dh, 0, H, 2 * H, blk.causal, blk.scale, blk.mask_neg,
-                       drop_p=pa, drop_site=blk.site, drop_seed=seed)
+                       drop_p=pa, drop_site=blk.site, drop_seed=seed, offsets=self._off(blk))
         if cls_rows is not None:
             ctx_c, x_c = self._buf('ctx_c', cls_rows, H, T), self._buf('x_c', cls_rows, H, T)
-            L.gather_rows(ctx, ctx_c, n_items, blk.S)
-            L.gather_rows(x, x_c, n_items, blk.S)
+            self._cls_gather(ctx, ctx_c, n_items, blk.S, blk)
+            self._cls_gather(x, x_c, n_items, blk.S, blk)
             x32 = self._twin_of(x, M) if self.res32 else None
             if x32 is not None:                        # the CLS rows of the fp32 residual stream too
                 x_c32 = self._buf('x_c32', cls_rows, H, torch.float32)
-                L.gather_rows(x32, x_c32, n_items, blk.S)
+                self._cls_gather(x32, x_c32, n_items, blk.S, blk)
                 self._twin[x_c.data_ptr()] = x_c32
             ctx, x, M = ctx_c, x_c, cls_rows
         if 'ctx_s' in bufs and ctx is not bufs['ctx_s']:
@@ -1338,19 +1361,20 @@ class TransRecEngine:
         if cls_rows is not None:                   # back to token rows: gradients live on the CLS rows only
             M = M_full
             full = self._buf('dctx', M, H, T)
-            L.scatter_rows_fill(dctx, full, n_items, blk.S, M)          # CLS rows written, every other row zeroed, one pass
+            self._cls_scatter_fill(dctx, full, n_items, blk.S, M, blk)  # CLS rows written, every other row zeroed, one pass
             dctx = full
             rfull = self._buf('dres_full', M, H, T)
-            L.scatter_rows_fill(dres1, rfull, n_items, blk.S, M)
+            self._cls_scatter_fill(dres1, rfull, n_items, blk.S, M, blk)
             dres1 = rfull
-        dqkv = self._buf_tail0('dqkv', M, 3 * H, T, n_items * blk.S)       # attn_bwd writes the real token rows only
+        n_tok = self._pk['Mtok'] if self._off(blk) is not None else n_items * blk.S
+        dqkv = self._buf_tail0('dqkv', M, 3 * H, T, n_tok)                 # attn_bwd writes the real token rows only
         if getattr(blk, 'long', False):
             ws = self._buf('attn_ws', bufs['lse'].shape[0], 1, torch.float32)
             L.attn_long_bwd(bufs['qkv'], bufs['ctx_o'], dctx, dqkv, bufs['lse'], ws, n_items, blk.S, blk.nh, blk.dh, 0, H, 2 * H, blk.scale,
                             drop_p=pa, drop_site=blk.site, drop_seed=seed)
         else:
             L.attn_bwd(bufs['qkv'], dctx, dqkv, key_mask, n_items, blk.S, blk.nh, blk.dh, 0, H, 2 * H, blk.causal, blk.scale, blk.mask_neg,
-                       drop_p=pa, drop_site=blk.site, drop_seed=seed)
+                       drop_p=pa, drop_site=blk.site, drop_seed=seed, offsets=self._off(blk))
         if blk.lora:
             self._lora_backward_all(blk, dqkv, bufs['xin'], M)
         self._dense_wgrads([(d, dqkv[:, sl * H:(sl + 1) * H], bufs.get('xin')) for sl, d in enumerate(blk.qkv)] + pend, M)
@@ -1428,7 +1452,8 @@ class TransRecEngine:
     def _encode(self, news, n_items, train, seed, saved):
         """news [n, 2S] int64 (ids || mask) -> (emb fp32 [Ipad, E], pre fp32 [Ipad, E]) ; keeps x_final for backward."""
         S, H = self.S, self.H
-        M = pad_to(n_items * S, 256)
+        pk = self._pk
+        M = pad_to(pk['Mtok'], 256) if pk is not None else pad_to(n_items * S, 256)
         self._twin.clear()
         key_mask = self._buf('kmask', n_items, S, torch.float32)          # filled by a4r_embed_ln from the mask half of the rows
         x = self._buf('xa', M, H, self.T)
@@ -1449,11 +1474,17 @@ class TransRecEngine:
             if self.roberta:                       # RoBERTa derives the position ids from the ORIGINAL ids: a redirected pad stays a pad
                 red = torch.where(news[:, :n] == self.pad_id, -red - 1, red)      # (a4r_embed_ln: negative id = row -(id + 1), counted as pad)
             news[:, :n] = red
+        x_emb = self._buf('x_unpacked', pad_to(n_items * S, 256), H, self.T) if pk is not None else x
         L.embed_ln(news, word, self.emb_pos, self.emb_type0, self.emb_ln.gamma, self.emb_ln.beta, self.emb_ln.eps,
-                   x, n_items, S, roberta=self.roberta, pad_id=self.pad_id,
+                   x_emb, n_items, S, roberta=self.roberta, pad_id=self.pad_id,
                    drop_p=self.p_hidden if train else 0.0, drop_site=999, drop_seed=seed,
                    pre_out=self._buf('emb_pre', M, H, self.T) if keep else None,
                    stats_out=self._buf('emb_st', M, 2, torch.float32) if keep else None, key_mask_out=key_mask)
+        if pk is not None:                         # the attended tokens of every title, title after title; rows behind them zero; no key mask: no pad rows exist
+            L.rows_idx_copy(x_emb, x, pk['map'], pk['Mtok'])
+            if M > pk['Mtok']:
+                L.zero(x[pk['Mtok']:M])
+            key_mask = None
         self._news = news
         other = self._buf('xb', M, H, self.T)
         xa_buf = self._buf('xa', M, H, self.T)     # (the transient buffer, also when the embedding went straight into layer 0's kept input)
@@ -1482,7 +1513,7 @@ class TransRecEngine:
         if self.bert_kads:
             self._kad_chain_forward(x, n_items, M, Ip, train, seed, cls, saved is not None)
         elif not self.cls_only:
-            L.gather_rows(x, cls, n_items, S)
+            self._cls_gather(x, cls, n_items, S)
         emb = self._buf('emb', Ip, self.E, torch.float32)
         pre = self._buf('embpre', Ip, self.E, torch.float32)
         L.gemm_nt(cls, self.fc_w, emb, bias=self.fc_b, C2=pre, act=L.ACT_GELU, M=Ip)
@@ -1539,6 +1570,7 @@ class TransRecEngine:
     def encode_items(self, news):
         L.require_gpu(news)
         self._set_S(self.S0)
+        self._pk = None                            # (inference: the rectangular layout)
         n = news.shape[0]
         news = news.contiguous()
         if news.dtype != torch.int64:
@@ -1590,6 +1622,7 @@ class TransRecEngine:
         return n_c if rounds(n_c) < rounds(B * 2 * self.Lseq) else None
 
     host_log_mask = None           # set by Model.forward when run.py hands log_mask over on the host
+    host_lens = None               # likewise: numpy int32 [items]: attended tokens per title, when every mask of the batch is a prefix (else None)
     host_max_tokens = None         # likewise: the longest title (tokens with attention mask 1) among the batch's items, read from the host copy
 
     def _set_S(self, S):
@@ -1625,8 +1658,8 @@ class TransRecEngine:
         n_static = self._kept_rows(B)
         if n_c == 0 or n_c >= (n_static if n_static is not None else B * 2 * Ls):
             return None
-        idx = torch.from_numpy(np.nonzero(need)[0].astype(np.int32))
-        return idx.to(self.dev, non_blocking=True), n_c
+        rows = np.nonzero(need)[0].astype(np.int32)
+        return torch.from_numpy(rows).to(self.dev, non_blocking=True), n_c, rows
 
     def _slots_copy(self, full, comp, B, to_compact, idx=None):
         """Between the full slot layout `full` [>= B*2L, W] and the compact one `comp` [>= n_c, W] (fp32 views, W % 4 == 0): strided row copies only.
@@ -1699,6 +1732,33 @@ class TransRecEngine:
                 and news.dtype == torch.int64 and news.shape[1] == 2 * self.S0 and _os.environ.get('A4R_SKIP_UNUSED_ITEMS', '1') != '0'):
             S_step = min(self.S0, max(2, (int(hmt) + 1) // 2 * 2))
         self._set_S(S_step)
+        # packed titles: every item runs on ITS OWN attended tokens (title lengths from the host copy of the rows, Model.forward), not on the batch's
+        # longest title.  Needs prefix masks (a left-padded tokenizer or a mask with holes keeps the rectangular form), the MFMA attention kernels
+        # (head dim 32 / 64) and a frozen embedding (its backward is written for the rectangular layout).  A4R_PACK_TITLES=0: off (A/B runs).
+        hl, self.host_lens = self.host_lens, None
+        self._pk = None
+        if (hl is not None and hmt is not None and S_step <= self.S0 and type(self) is TransRecEngine and not self.bert_kads and not self.prompt_n
+                and not self.train_emb and not self.fp8 and self.bert_blocks and self.bert_blocks[0].dh in (32, 64) and len(hl) == n_full
+                and _os.environ.get('A4R_PACK_TITLES', '1') != '0' and _os.environ.get('A4R_SKIP_UNUSED_ITEMS', '1') != '0'):
+            import numpy as np
+            if kidx is not None:
+                rows_h = kidx[2]
+            elif n_c is not None:                  # the static compaction's row order (_slots_copy)
+                Ls = self.Lseq
+                if self.arch == 'cpc':
+                    rows_h = np.concatenate([np.arange(0, B * 2 * Ls, 2), np.arange(B) * 2 * Ls + 2 * Ls - 3])
+                else:
+                    rows_h = (np.arange(B)[:, None] * 2 * Ls + np.arange(2 * Ls - 1)[None, :]).reshape(-1)
+            else:
+                rows_h = None
+            lens = np.minimum(hl if rows_h is None else hl[rows_h], S_step).astype(np.int64)
+            Mtok = int(lens.sum())
+            if len(lens) == n_items and Mtok < n_items * S_step - 255:        # (worth a gather only when it removes at least a row panel)
+                off = np.zeros(n_items + 1, np.int64)
+                np.cumsum(lens, out=off[1:])
+                rmap = np.arange(Mtok, dtype=np.int64) + np.repeat(np.arange(n_items, dtype=np.int64) * S_step - off[:-1], lens)
+                self._pk = dict(off=torch.from_numpy(off.astype(np.int32)).to(self.dev, non_blocking=True),
+                                map=torch.from_numpy(rmap.astype(np.int32)).to(self.dev, non_blocking=True), Mtok=Mtok, n=n_items)
         if S_step < self.S0:                       # rows [ids(S0) | mask(S0)] -> [ids(S) | mask(S)]
             src = news.view(torch.float32)
             dst = self._buf('items_t', n_items, 4 * S_step, torch.float32)
@@ -1709,7 +1769,7 @@ class TransRecEngine:
         self.pack_trainables()
         self.step_count += 1
         seed = (self.seed * 1000003 + self.step_count) & 0xFFFFFFFFFFFF
-        M = pad_to(n_items * self.S, 256)
+        M = pad_to(self._pk['Mtok'], 256) if self._pk is not None else pad_to(n_items * self.S, 256)
         Mu = pad_to(B * (self.Lseq - 1), 128)
         Ipc = pad_to(n_items, 128)
         if self._saved_bert is None or self._saved_M != M or self._saved_Mu != Mu or getattr(self, '_saved_Ip', Ipc) != Ipc:
@@ -1734,7 +1794,7 @@ class TransRecEngine:
         ws = self._buf('lossws', 1, 4, torch.float32)
         L.zero(ws)
         L.score_bce_fwd(emb, prec, lm, pos, neg, ws, B, self.Lseq, self.E, self.arch == 'cpc')
-        self._ctx = dict(B=B, n_items=n_items, n_full=n_full, kidx=kidx, S=self.S, M=M, Mu=Mu, seed=seed, train=train, lm=lm, key_mask=key_mask, emb=emb, pre=pre,
+        self._ctx = dict(B=B, n_items=n_items, n_full=n_full, kidx=kidx, S=self.S, pk=self._pk, M=M, Mu=Mu, seed=seed, train=train, lm=lm, key_mask=key_mask, emb=emb, pre=pre,
                          prec=prec, xin=xin, pos=pos, neg=neg, ws=ws, saved_b=saved_b, saved_s=saved_s)
         return ws[0, 0].clone()
 
@@ -1840,6 +1900,7 @@ class TransRecEngine:
             grad_out = grad_out.detach().to(torch.float32).reshape(1)
         B, n_items, M, Mu, seed = c['B'], c['n_items'], c['M'], c['Mu'], c['seed']
         self._set_S(c.get('S', self.S))            # (the token count the forward ran on)
+        self._pk = c.get('pk')
         n_full = c.get('n_full', n_items)          # the head works on the full slot layout, the item tower on the kept rows (train_forward)
         E, Tn = self.E, self.Lseq - 1
         train = c['train']
@@ -1924,7 +1985,7 @@ class TransRecEngine:
             if not (self.bert_trains or self.train_emb):
                 return                             # frozen backbone: nothing trainable lies upstream of its activations
         elif not self.cls_only:
-            L.scatter_rows_fill(dcls, dxb, n_items, self.S, M)
+            self._cls_scatter_fill(dcls, dxb, n_items, self.S, M)
         spare = self._buf('dx_b', M, self.H, self.T)
         last = len(self.bert_blocks) - 1
         for i in range(last, -1, -1):

@@ -102,9 +102,13 @@ class _TransRecBase(nn.Module):
             # (numpy, not torch: a torch CPU reduction wakes the whole intra-op thread pool -- 128 threads on the GPU boxes -- and cost ~19 ms per step)
             # The bound is the LAST attended position (not the count of mask ones): a left-padded tokenizer, a mask with holes or a non-0/1 mask
             # keeps every attended token, whatever its column.
+            eng.host_lens = None
             if sample_items.shape[0]:
                 m = sample_items.numpy()[:, sample_items.shape[1] // 2:] != 0
-                eng.host_max_tokens = int((m * np.arange(1, m.shape[1] + 1, dtype=np.int64)).max())
+                last = (m * np.arange(1, m.shape[1] + 1, dtype=np.int64)).max(1)
+                eng.host_max_tokens = int(last.max())
+                if (m.sum(1) == last).all():       # every mask a contiguous prefix: the titles can be packed (engine.py: train_forward); the pad item counts one token
+                    eng.host_lens = np.maximum(last, 1).astype(np.int32)
             sample_items = sample_items.to(eng.dev, non_blocking=True)
         if not log_mask.is_cuda:
             # log_mask still on the host (run.py hands over the DataLoader's tensor): the engine reads the batch's pad structure from it WITHOUT a

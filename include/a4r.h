@@ -36,7 +36,7 @@ extern "C" {
 
 /* ABI version: bumped whenever a signature or struct below changes.  The Python binding (adapter4rec_amd/_lib.py) refuses a
  * library whose a4r_version() differs, so an A/B build made before a signature change cannot be called with shifted arguments. */
-#define A4R_ABI_VERSION 406
+#define A4R_ABI_VERSION 407
 int a4r_version(void);
 
 /* C[M,N] = epilogue(alpha * A[M,K] . B[N,K]^T): every nn.Linear on the path (HF BertSelfAttention
@@ -217,6 +217,10 @@ typedef struct {
     int32_t n_items, S, n_heads, dh, causal, dtype;
     float scale, mask_neg;
     float drop_p; uint32_t drop_site; uint64_t drop_seed;
+    const int32_t* offsets;              /* ABI 407, a4r_attn_fwd / _bwd with dh 32 / 64 only (else A4R_EINVAL), NULL = off: PACKED items -- item i owns
+                                          * rows [offsets[i], offsets[i + 1]) of qkv / out / dout / dqkv (device int32 [n_items + 1], every length in
+                                          * 1 .. S), no pad rows exist and key_mask is ignored (a title's pad tokens never reach its CLS output:
+                                          * Downstream/Text/model/encoders.py:48-57); the dropout counter stays (item * heads + head, query, key) */
 } a4r_attn_t;
 int a4r_attn_fwd(void* stream, const a4r_attn_t* a);
 int a4r_attn_bwd(void* stream, const a4r_attn_t* a);

@@ -207,15 +207,41 @@ def _attn(qkv, key_mask, n_items, S, nh, dh, offs, causal, scale, mask_neg):
     return (torch.softmax(sc, -1) @ v).transpose(1, 2).reshape(n_items * S, Hd)
 
 
+def _packed_index(offsets, n_items, S):
+    """rows of the packed tensors as a padded [n_items, S] index (pad entries -> row 0) + the key mask that goes with it"""
+    off = offsets.long().cpu()
+    lens = off[1:n_items + 1] - off[:n_items]
+    t = torch.arange(S)[None, :]
+    valid = t < lens[:, None]
+    idx = torch.where(valid, off[:n_items, None] + t, torch.zeros(1, dtype=torch.long))
+    return idx, valid
+
+
 def attn_fwd(qkv, out, key_mask, n_items, S, n_heads, dh, q_off, k_off, v_off, causal, scale, mask_neg,
-             drop_p=0.0, drop_site=0, drop_seed=0):
+             drop_p=0.0, drop_site=0, drop_seed=0, offsets=None):
     assert drop_p == 0.0
+    if offsets is not None:              # packed items (a4r_attn_t.offsets): unpack to [n_items, S] with the pad keys masked, run, pack back
+        idx, valid = _packed_index(offsets, n_items, S)
+        o = _attn(qkv.float()[idx.reshape(-1)], valid.float(), n_items, S, n_heads, dh, (q_off, k_off, v_off), causal, scale, mask_neg)
+        out[idx[valid], :n_heads * dh] = o.view(n_items, S, -1)[valid].to(out.dtype)
+        return
     out[:n_items * S, :n_heads * dh] = _attn(qkv.float(), key_mask, n_items, S, n_heads, dh, (q_off, k_off, v_off), causal, scale, mask_neg).to(out.dtype)
 
 
 def attn_bwd(qkv, dout, dqkv, key_mask, n_items, S, n_heads, dh, q_off, k_off, v_off, causal, scale, mask_neg,
-             drop_p=0.0, drop_site=0, drop_seed=0):
+             drop_p=0.0, drop_site=0, drop_seed=0, offsets=None):
     assert drop_p == 0.0
+    if offsets is not None:
+        idx, valid = _packed_index(offsets, n_items, S)
+        with torch.enable_grad():
+            q = qkv.float()[idx.reshape(-1)].clone().requires_grad_(True)
+            o = _attn(q, valid.float(), n_items, S, n_heads, dh, (q_off, k_off, v_off), causal, scale, mask_neg)
+            do = dout.float()[idx.reshape(-1), :n_heads * dh] * valid.reshape(-1, 1).float()
+            o.backward(do)
+        g = q.grad.view(n_items, S, -1)[valid]
+        for off in (q_off, k_off, v_off):
+            dqkv[idx[valid], off:off + n_heads * dh] = g[:, off:off + n_heads * dh].to(dqkv.dtype)
+        return
     with torch.enable_grad():
         q = qkv.float().clone().requires_grad_(True)
         o = _attn(q, key_mask, n_items, S, n_heads, dh, (q_off, k_off, v_off), causal, scale, mask_neg)

@@ -299,6 +299,40 @@ def test_step_bf16_matches_bf16_restatement(name):
     assert worst < 0.04, (worst, where)      # (two bf16 implementations: 0.029 - 0.030 measured; not parity evidence, a plumbing check)
 
 
+@pytest.mark.parametrize('name,dtype', [('houlsby', 'fp32'), ('roberta_cpc_pfeiffer', 'fp32'), ('houlsby_parallel', 'fp32'), ('houlsby', 'bf16')])
+def test_step_titles_of_different_lengths_are_packed(name, dtype):
+    """Titles of 3 .. 20 tokens handed over on the host: the item tower runs on the attended tokens only (packed rows, a4r_attn_t.offsets) -- about
+    a third of the rectangular 30-token batch -- and loss and every gradient still equal the ORACLE on the rectangular batch (fp32: 1e-4; bf16: the
+    bounds of test_step_bf16_bound on conditioned weights)."""
+    from oracle import ref_cpu as R
+    import test_engine_host_logic as HL
+    root, args, sd, cfg, fx, items, mask = build(name, dtype)
+    if dtype == 'bf16':
+        sd = condition(sd)
+        root.load_state_dict({str(k): sd[strip(str(k))] for k in fx['all_keys']}, strict=True)
+    items = items.cpu().clone()
+    S = items.shape[1] // 2
+    g = torch.Generator().manual_seed(5)
+    lens = torch.randint(3, 21, (items.shape[0],), generator=g)
+    col = torch.arange(S)[None, :]
+    items[:, :S] = torch.where(col < lens[:, None], items[:, :S], torch.full_like(items[:, :S], 1 if name.startswith('roberta') else 0))
+    items[:, S:] = (col < lens[:, None]).long()
+    names = [str(k) for k in fx['trainable']]
+    out, grads = R.loss_and_grads(sd, [strip(k) for k in names], items, mask.cpu(), cfg)
+    loss = root(items, mask, 0)                       # the id rows on the HOST (what run.py's DataLoader hands over)
+    eng = getattr(root, 'model', root)._engine()
+    pk = eng._ctx['pk']
+    assert pk is not None and pk['Mtok'] < items.shape[0] * 21
+    loss.backward()
+    tol_l, tol_g = (1e-4, 1e-4) if dtype == 'fp32' else (2e-2, 0.15)
+    assert abs(loss.item() - float(out['loss'].detach())) < tol_l, (loss.item(), float(out['loss'].detach()))
+    params = dict(root.named_parameters())
+    for k in names:
+        ref = grads[strip(k)].numpy()
+        err = np.abs(params[k].grad.cpu().numpy() - ref).max() / (np.abs(ref).max() + 1e-12)
+        assert err < tol_g, (k, err)
+
+
 def test_dropout_training_mode_runs_and_is_seeded():
     root, args, sd, cfg, fx, items, mask = build('houlsby', 'bf16')
     root.train()

@@ -134,6 +134,45 @@ def test_host_logic_non_prefix_mask_keeps_every_attended_token(simulated, name):
         np.testing.assert_allclose(params[n].grad.numpy(), ref, atol=1e-6 + 1e-4 * np.abs(ref).max(), rtol=0, err_msg=n)
 
 
+def ragged_title_case(name, device='cpu', seed=5):
+    """A fixture's model on a batch whose titles have DIFFERENT lengths (3 .. 20 attended tokens, ids and mask zeroed behind them; RoBERTa: pad id 1):
+    handed over on the host the titles are PACKED -- item i runs on its own token rows (engine.py: train_forward, self._pk; a4r_attn_t.offsets).
+    The checker is the oracle on the same batch in the rectangular 30-token layout."""
+    from oracle import ref_cpu as R
+    from golden_util import load_variant
+    root, args, fx, items, mask = build_cpu(name)
+    sd, cfg, *_ = load_variant(name)
+    items = items.clone()
+    S = items.shape[1] // 2
+    g = torch.Generator().manual_seed(seed)
+    lens = torch.randint(3, 21, (items.shape[0],), generator=g)
+    col = torch.arange(S)[None, :]
+    items[:, :S] = torch.where(col < lens[:, None], items[:, :S], torch.full_like(items[:, :S], 1 if name.startswith('roberta') else 0))
+    items[:, S:] = (col < lens[:, None]).long()
+    names = [str(k) for k in fx['trainable']]
+    out, grads = R.loss_and_grads(sd, names, items, mask, cfg)
+    return root.to(device), items, mask, names, out, grads, int(lens.sum())
+
+
+@pytest.mark.parametrize('name', ['houlsby', 'roberta_cpc_pfeiffer', 'pfeiffer', 'houlsby_parallel'])
+def test_host_logic_titles_of_different_lengths_are_packed(simulated, name, monkeypatch):
+    monkeypatch.setenv('A4R_SKIP_UNUSED_ITEMS', '1')
+    root, items, mask, names, out, grads, n_tok = ragged_title_case(name)
+    inner = getattr(root, 'model', root)
+    loss = root(items, mask, 'cpu')
+    eng = inner._engine()
+    pk = eng._ctx['pk']
+    assert pk is not None and pk['Mtok'] <= n_tok and eng._ctx['M'] == -(-pk['Mtok'] // 256) * 256 < items.shape[0] * eng._ctx['S']
+    loss.backward()
+    assert abs(loss.item() - float(out['loss'].detach())) < 1e-4
+    params = dict(root.named_parameters())
+    for n in names:
+        ref = grads[n].numpy()
+        np.testing.assert_allclose(params[n].grad.numpy(), ref, atol=1e-6 + 1e-4 * np.abs(ref).max(), rtol=0, err_msg=n)
+    emb = inner.bert_encoder(items)                 # inference afterwards: the rectangular layout again
+    assert eng._pk is None and emb.shape[0] == items.shape[0]
+
+
 @pytest.mark.parametrize('name', ['houlsby', 'compacter'])
 def test_host_logic_fused_adam(simulated, name):
     from adapter4rec_amd.inject import optimizer_groups

@@ -1376,6 +1376,43 @@ def test_gemm256_four_wave_bit_equal_to_eight_wave(N, K):
     close(res[9]['plain'], A.float() @ B.float().t() + bias, t, 'four-wave plain vs torch')
 
 
+@pytest.mark.parametrize('dt', ['f32', 'bf16'])
+@pytest.mark.parametrize('dh,nh', [(64, 2), (32, 4)])
+def test_attn_packed_items_equal_rectangular(dt, dh, nh):
+    """a4r_attn_t.offsets (ABI 407): items of DIFFERENT token counts stored back to back.  Forward and backward (the generic and the transposed-read
+    bf16 kernel) must equal the rectangular form [n_items, S] with the pad keys masked, on the attended rows, bit for bit in the forward and to
+    fp32 summation order in the backward (same kernels, same per-item arithmetic); dropout draws the same (item, head, query, key) counters."""
+    from adapter4rec_amd import _lib as L
+    t = DT[dt]
+    n, S, H = 37, 30, nh * dh
+    g = torch.Generator().manual_seed(7)
+    lens = torch.randint(1, S + 1, (n,), generator=g)
+    lens[0], lens[1] = S, 1
+    off = torch.zeros(n + 1, dtype=torch.int32)
+    off[1:] = torch.cumsum(lens, 0).int()
+    Mtok = int(off[-1])
+    valid = (torch.arange(S)[None, :] < lens[:, None])
+    rect = rnd(n * S, 3 * H, dtype=t, seed=11)
+    dout_r = rnd(n * S, H, dtype=t, seed=12)
+    rows = valid.reshape(-1).nonzero().flatten().to(dev())
+    packed, dout_p = rect[rows].contiguous(), dout_r[rows].contiguous()
+    km = valid.float().to(dev())
+    offd = off.to(dev())
+    for p_drop in (0.0, 0.1):
+        kw = dict(drop_p=p_drop, drop_site=16, drop_seed=99)
+        o_r = torch.zeros(n * S, H, dtype=t, device=dev())
+        o_p = torch.zeros(Mtok, H, dtype=t, device=dev())
+        L.attn_fwd(rect, o_r, km, n, S, nh, dh, 0, H, 2 * H, False, dh ** -0.5, -1e9, **kw)
+        L.attn_fwd(packed, o_p, None, n, S, nh, dh, 0, H, 2 * H, False, dh ** -0.5, -1e9, offsets=offd, **kw)
+        assert torch.equal(o_p, o_r[rows]), (dt, dh, p_drop)
+        d_r = torch.zeros(n * S, 3 * H, dtype=t, device=dev())
+        d_p = torch.zeros(Mtok, 3 * H, dtype=t, device=dev())
+        do_r = dout_r * km.reshape(-1, 1).to(t)                   # pad queries carry no gradient in the packed form: they do not exist
+        L.attn_bwd(rect, do_r, d_r, km, n, S, nh, dh, 0, H, 2 * H, False, dh ** -0.5, -1e9, **kw)
+        L.attn_bwd(packed, dout_p, d_p, None, n, S, nh, dh, 0, H, 2 * H, False, dh ** -0.5, -1e9, offsets=offd, **kw)
+        close(d_p, d_r[rows], t, f'packed attention backward {dt} dh={dh} p={p_drop}')
+
+
 @pytest.mark.parametrize('K', [192, 256, 768])
 def test_gemm256_many_tiles_per_workgroup(K):
     """540 output tiles on 256 persistent workgroups: every workgroup walks 2 - 3 tiles, so the unit stream continues ACROSS tiles
