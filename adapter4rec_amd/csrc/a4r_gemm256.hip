@@ -399,17 +399,57 @@ A4R_DEV void gemm256_tiles(const a4r_gemm_t& p, char* lds, int ntm, int ntn, int
     __builtin_amdgcn_sched_barrier(0);                                                                \
     if (!(A4R_ABL & 8)) __builtin_amdgcn_s_barrier();                                                 \
     asm volatile("" ::: "memory");
+    // A4R_DMA_INTERLEAVE (round 5, from the four-wave kernel's measurements -- LOG part E: a 1-KiB piece costs its wave ~60 cycles of issue when the
+    // four waves of a ping-pong half ask the CU's one address unit at the same instant, ~16 when they do not): inside a LOAD segment the pieces are
+    // issued BETWEEN groups of fragment reads instead of in one burst behind them, and wave w of the half starts (w & 3) x 16 cycles late, so that the
+    // four waves' pieces reach the address unit one after the other.  Same pieces, same counted waits (they sit behind the segment's last issue).
+    // MEASURED SLOWER here (profiles/r05_i_w8_dma_interleave_ab.txt, same box: step 17.22 -> 17.99 ms, every shape 5 - 15 % slower): with two waves per
+    // SIMD the burst's issue stall is the PARTNER's MFMA time anyway, while reads queued behind a piece reach the LDS later and lengthen the segment.
+    // 0 = the burst behind the reads (rounds 3 - 4), kept as the default; 1 for A/B builds.
+#ifndef A4R_DMA_INTERLEAVE
+#define A4R_DMA_INTERLEAVE 0
+#endif
+#define A4R_ISSUE1(kind_, tile_, base_, off_, i_)                                                                    \
+    if ((tile_) < nk || has_next) {                                                                                  \
+        const char* src_ = (tile_) < nk ? (base_) + (size_t)(tile_) * ROWB : (base_##_nx) + (size_t)((tile_) - nk) * ROWB; \
+        glds16(src_, off_[i_], dma_dst + (uint32_t)((((tile_) & 1) * 4 + (kind_)) * UNIT_BYTES) + (i_) * 1024u);      \
+    }                                                                                                                \
+    __builtin_amdgcn_sched_barrier(0);
+#define A4R_RD_B1(dst_, buf_, unit_, ni_)                                                             \
+    _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                                  \
+        dst_[ni_][ks] = *reinterpret_cast<const uint4*>((lds + b_base[buf_][ks]) + ((unit_) * UNIT_BYTES + (ni_) * 2048)); \
+    __builtin_amdgcn_sched_barrier(0);
+#define A4R_RD_A1(dst_, buf_, unit_, mi_)                                                             \
+    _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                                  \
+        dst_[mi_][ks] = *reinterpret_cast<const uint4*>((lds + a_base[buf_][ks]) + ((unit_) * UNIT_BYTES + (mi_) * 2048)); \
+    __builtin_amdgcn_sched_barrier(0);
+#define A4R_WAVE_DELAY() for (int d_ = 0; d_ < (wave & 3); ++d_) asm volatile("s_nop 3");
+#if A4R_DMA_INTERLEAVE
+#define A4R_LOAD_A(u_, buf_)                                                                                                        \
+        A4R_WAVE_DELAY()                                                                                                            \
+        A4R_ISSUE1(U_BHI, (u_) + 1, Bbase, offB_hi, 0) A4R_RD_B1(b0, buf_, U_BLO, 0) A4R_RD_B1(b0, buf_, U_BLO, 1)                  \
+        A4R_ISSUE1(U_BHI, (u_) + 1, Bbase, offB_hi, 1) A4R_RD_B1(b1, buf_, U_BHI, 0) A4R_RD_B1(b1, buf_, U_BHI, 1)                  \
+        A4R_ISSUE1(U_AHI, (u_) + 1, Abase, offA_hi, 0) A4R_RD_A1(af, buf_, U_ALO, 0) A4R_RD_A1(af, buf_, U_ALO, 1)                  \
+        A4R_ISSUE1(U_AHI, (u_) + 1, Abase, offA_hi, 1) A4R_RD_A1(af, buf_, U_ALO, 2) A4R_RD_A1(af, buf_, U_ALO, 3)
+#define A4R_LOAD_B(u_, buf_)                                                                                                        \
+        A4R_WAVE_DELAY()                                                                                                            \
+        A4R_ISSUE1(U_ALO, (u_) + 2, Abase, offA_lo, 0) A4R_RD_A1(af, buf_, U_AHI, 0)                                                \
+        A4R_ISSUE1(U_ALO, (u_) + 2, Abase, offA_lo, 1) A4R_RD_A1(af, buf_, U_AHI, 1)                                                \
+        A4R_ISSUE1(U_BLO, (u_) + 2, Bbase, offB_lo, 0) A4R_RD_A1(af, buf_, U_AHI, 2)                                                \
+        A4R_ISSUE1(U_BLO, (u_) + 2, Bbase, offB_lo, 1) A4R_RD_A1(af, buf_, U_AHI, 3)
+#else
+#define A4R_LOAD_A(u_, buf_) A4R_RD_B(b0, buf_, U_BLO) A4R_RD_B(b1, buf_, U_BHI) A4R_RD_A(af, buf_, U_ALO) A4R_ISSUE(U_BHI, (u_) + 1, Bbase, offB_hi) A4R_ISSUE(U_AHI, (u_) + 1, Abase, offA_hi)
+#define A4R_LOAD_B(u_, buf_) A4R_RD_A(af, buf_, U_AHI) A4R_ISSUE(U_ALO, (u_) + 2, Abase, offA_lo) A4R_ISSUE(U_BLO, (u_) + 2, Bbase, offB_lo)
+#endif
 #define A4R_KTILE2(u_, buf_)                                                                                                        \
     {                                                                                                                               \
         const bool n1 = (u_) + 1 < nk || has_next, n2 = (u_) + 2 < nk || has_next;                                                  \
         const bool z0 = (buf_) == 0 && (u_) == 0;                                                                                   \
         asm volatile("" : "+v"(a_base[buf_][0]), "+v"(a_base[buf_][1]), "+v"(b_base[buf_][0]), "+v"(b_base[buf_][1]));              \
-        A4R_PHASE2(A4R_RD_B(b0, buf_, U_BLO) A4R_RD_B(b1, buf_, U_BHI) A4R_RD_A(af, buf_, U_ALO),                                   \
-                   A4R_ISSUE(U_BHI, (u_) + 1, Bbase, offB_hi) A4R_ISSUE(U_AHI, (u_) + 1, Abase, offA_hi),                           \
+        A4R_PHASE2(A4R_LOAD_A(u_, buf_), ,                                                                                          \
                    if (z0) { } else if (n1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");, \
                    af, b0, 0, b1, 2, 0, z0, kp_lo)                                                                                  \
-        A4R_PHASE2(A4R_RD_A(af, buf_, U_AHI),                                                                                       \
-                   A4R_ISSUE(U_ALO, (u_) + 2, Abase, offA_lo) A4R_ISSUE(U_BLO, (u_) + 2, Bbase, offB_lo),                           \
+        A4R_PHASE2(A4R_LOAD_B(u_, buf_), ,                                                                                          \
                    if (n2) asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); else if (n1) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");, \
                    af, b1, 2, b0, 0, 4, z0, kp_hi)                                                                                  \
     }
@@ -574,6 +614,12 @@ A4R_DEV void gemm256_tiles(const a4r_gemm_t& p, char* lds, int ntm, int ntn, int
 #undef A4R_KTILE
 #undef A4R_KTILE2
 #undef A4R_KTILE4
+#undef A4R_LOAD_A
+#undef A4R_LOAD_B
+#undef A4R_ISSUE1
+#undef A4R_RD_A1
+#undef A4R_RD_B1
+#undef A4R_WAVE_DELAY
 }
 
 // ntm = row panels of FULL tiles; the tail_rows rows behind them (0 = none) are cut into short tiles of 32 * tail_kp rows, tile j (row-panel
