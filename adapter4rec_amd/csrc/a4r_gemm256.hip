@@ -124,6 +124,33 @@ A4R_DEV void glds16(const void* base, uint32_t voff, uint32_t lds_dst) {
         : "memory");
 }
 
+// a unit's two pieces of one wave behind ONE m0 write: the instruction offset moves the LDS destination AND the source (tools/_probe/
+// lds_dma_offset_probe.hip), so the second piece carries offset:1024 and its source offset is passed 1024 bytes low.  6 instructions for 2 KiB
+// instead of 10 (A4R_GLDS_PAIR=0: two glds16, A/B builds).
+#ifndef A4R_GLDS_PAIR
+#define A4R_GLDS_PAIR 1
+#endif
+template <bool PAIR>
+A4R_DEV void glds16x2(const void* base, uint32_t voff0, uint32_t voff1, uint32_t lds_dst) {
+  if constexpr (PAIR && A4R_GLDS_PAIR) {      // (PAIR false: short tiles -- their clamped rows sit at offsets < 1024, which the second piece's 1024-low source offset cannot express)
+    uint32_t keep;
+    const uint32_t v1 = voff1 - 1024u;
+    asm volatile(
+        "s_mov_b32 %0, m0\n\t"
+        "s_mov_b32 m0, %4\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dwordx4 %1, %3\n\t"
+        "global_load_lds_dwordx4 %2, %3 offset:1024\n\t"
+        "s_mov_b32 m0, %0"
+        : "=&s"(keep)
+        : "v"(voff0), "v"(v1), "s"(base), "s"(lds_dst)
+        : "memory");
+  } else {
+    glds16(base, voff0, lds_dst);
+    glds16(base, voff1, lds_dst + 1024u);
+  }
+}
+
 typedef int i32x8_t __attribute__((ext_vector_type(8)));
 A4R_DEV f32x4_t mma_mx8(const uint4& a0, const uint4& a1, const uint4& b0, const uint4& b1, f32x4_t c) {
     const i32x8_t a = {(int)a0.x, (int)a0.y, (int)a0.z, (int)a0.w, (int)a1.x, (int)a1.y, (int)a1.z, (int)a1.w};
@@ -236,12 +263,12 @@ A4R_DEV void gemm256_tiles(const a4r_gemm_t& p, char* lds, int ntm, int ntn, int
     // K-tiles past the end of this output tile's K range are the first K-tiles of the workgroup's NEXT output tile (has_next: nk is
     // even, so ring-buffer parity carries over): the unit stream never stops between tiles, the next K loop starts on data that is
     // already in LDS and the epilogue's own loads (bias, Pre, R1) do not queue behind a 96 KiB prologue burst.
+#define A4R_PAIRED (!TAIL)
 #define A4R_ISSUE(kind_, tile_, base_, off_)                                                                         \
     if ((tile_) < nk || has_next) {                                                                                  \
         const char* src_ = (tile_) < nk ? (base_) + (size_t)(tile_) * ROWB : (base_##_nx) + (size_t)((tile_) - nk) * ROWB; \
         const uint32_t dst_ = dma_dst + (uint32_t)((((tile_) & 1) * 4 + (kind_)) * UNIT_BYTES);                       \
-        glds16(src_, off_[0], dst_);                                                                                 \
-        glds16(src_, off_[1], dst_ + 1024u);                                                                         \
+        glds16x2<A4R_PAIRED>(src_, off_[0], off_[1], dst_);                                                          \
     }
     // LOAD-segment pieces and the MFMA segment of a phase (see the header).  sched_barrier(0) pins the order hipcc emits.
 #define A4R_RD_A(dst_, buf_, unit_)                                                                   \
@@ -581,7 +608,11 @@ A4R_DEV void gemm256_tiles(const a4r_gemm_t& p, char* lds, int ntm, int ntn, int
             const int ul = 8 * (2 * wave + i) + (lane >> 3);
             tail_a_offsets(ul, (lane & 7) ^ ((ul >> 1) & 7), t_kp, lda * (int)sizeof(TI), ta_lo[i], ta_hi[i]);
         }
+#undef A4R_PAIRED
+#define A4R_PAIRED false          /* the short tile's A offsets (clamped rows) */
         A4R_PROLOGUE_AT(At, ta_lo, ta_hi, Bt)
+#undef A4R_PAIRED
+#define A4R_PAIRED (!TAIL)
         t_ready = true;
     }
 #define A4R_ACC_LOAD4(dst_, mi_, ni_) _Pragma("unroll") for (int r4_ = 0; r4_ < 4; ++r4_) dst_[r4_] = acc[mi_][ni_][r4_];
@@ -606,6 +637,7 @@ A4R_DEV void gemm256_tiles(const a4r_gemm_t& p, char* lds, int ntm, int ntn, int
 #undef A4R_NEXT_TILE
 #undef A4R_PROLOGUE
 #undef A4R_ISSUE
+#undef A4R_PAIRED
 #undef A4R_RD_A
 #undef A4R_RD_B
 #undef A4R_MFMA16
