@@ -713,7 +713,10 @@ extern "C" int a4r_gemm_tail_plan(int M, int N, int* p_full, int* kp) {
     *kp = 0;
     if (!on || ntn > grid || nt % grid == 0) return 0;
     const int pf = (nt / grid) * grid / ntn, rows = (ntm - pf) * 256;
-    for (int k = 1; k <= (on < 7 ? on : 7); ++k)
+    // (round 5) an UNDER-FILLED launch -- fewer tiles than CUs, pf == 0 -- takes any kp up to 7: its one round then costs f(kp) of a tile period on
+    // (nearly) every CU instead of a whole period on a fraction of them (8 users, N = 768: 120 full tiles on 256 CUs -> 240 tiles of 128 rows)
+    const int kmax = pf == 0 ? 7 : (on < 7 ? on : 7);
+    for (int k = 1; k <= kmax; ++k)
         if ((rows + 32 * k - 1) / (32 * k) * ntn <= grid) {
             *p_full = pf;
             *kp = k;

@@ -1,5 +1,5 @@
-# the round's final artifact set (gpurun_out/r04_r_*): copy what is cited to profiles/
-TAG=${1:-r04_r}
+# the round's final artifact set (gpurun_out/<tag>_*): copy what is cited to profiles/
+TAG=${1:-r05_z}
 bash tools/profile_step.sh $TAG pmc bert_houlsby bf16 > /dev/null 2>&1
 cp gpurun_out/${TAG}_pmc_hbm_traffic.json profiles/ 2>/dev/null      # bench.py reads the newest traffic file for its roofline.traffic
 python bench.py > gpurun_out/${TAG}_bench_full.json 2> gpurun_out/${TAG}_bench_full.err
@@ -24,3 +24,10 @@ try:
 except Exception as e: print(sys.argv[1], 'ERR', e)
 EOP
 done
+python tools/eval_bench.py > gpurun_out/${TAG}_eval_bench.json 2> gpurun_out/${TAG}_eval_bench.err
+: > gpurun_out/${TAG}_bench_realistic.jsonl
+python bench.py --steps 60 --warmup 15 --no-cpu-baseline --no-roofline --short-titles >> gpurun_out/${TAG}_bench_realistic.jsonl 2>/dev/null
+python bench.py --steps 60 --warmup 15 --no-cpu-baseline --no-roofline --ragged-histories >> gpurun_out/${TAG}_bench_realistic.jsonl 2>/dev/null
+python bench.py --steps 60 --warmup 15 --no-cpu-baseline --no-roofline --short-titles --ragged-histories >> gpurun_out/${TAG}_bench_realistic.jsonl 2>/dev/null
+python bench.py --steps 60 --warmup 15 --no-cpu-baseline --no-roofline --workload roberta_pfeiffer_cpc --short-titles --ragged-histories >> gpurun_out/${TAG}_bench_realistic.jsonl 2>/dev/null
+python tools/gemm_forms.py 40448 2>&1 | grep -v amdgpu > gpurun_out/${TAG}_gemm_forms.txt
