@@ -6,7 +6,7 @@
 #include "a4r_common.h"
 #include "../../include/a4r.h"
 #ifndef A4R_ABL
-#define A4R_ABL 0      /* timing-only diagnostic builds (tools/gemm_abl.sh, tools/epi_abl.sh); epilogue bits: 64 no GELU arithmetic, 128 no C2 store, 256 no Pre operand, 512 no C store, 1024 non-temporal C / C2 stores */
+#define A4R_ABL 0      /* timing-only diagnostic builds (tools/gemm_abl.sh, tools/epi_abl.sh); epilogue bits: 64 no GELU arithmetic, 128 no C2 store, 256 no Pre operand, 512 no C store, 1024 non-temporal C / C2 stores, 2048 / 4096 write-through (sc1 / sc0 sc1) C / C2 stores */
 #endif
 
 template <typename TO>
@@ -90,6 +90,14 @@ template <typename T, int NC> A4R_DEV void store_n(T* p, const float* o) {
         typedef unsigned int v4u __attribute__((ext_vector_type(4)));
         v4u x = {w.x, w.y, w.z, w.w};
         __builtin_nontemporal_store(x, reinterpret_cast<v4u*>(p));
+        return;
+    }
+    if constexpr (NC == 8 && sizeof(T) == 2 && (A4R_ABL & 6144) != 0) {        // 2048: write-through (sc1) stores, 4096: sc0 sc1 -- the end-of-kernel release finds nothing dirty
+        const uint4 w = Elem<T>::pack(o);
+        typedef unsigned int v4u __attribute__((ext_vector_type(4)));
+        v4u x = {w.x, w.y, w.z, w.w};
+        if constexpr ((A4R_ABL & 4096) != 0) asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(p), "v"(x) : "memory");
+        else asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(x) : "memory");
         return;
     }
     if constexpr (NC == 8) store_vec<T, 8>(p, o);

@@ -27,6 +27,14 @@ def fwd_fused():
     L.adapter_ln_fwd(h, h, x, Wd, bd, Wu, bu, gam, bet, 1e-12, 1, zp, z, v, y, st)
 
 
+def fwd_fused_y():          # the training step's form: only y = LN(v) is kept (backward rebuilds xhat from it)
+    L.adapter_ln_fwd(h, h, x, Wd, bd, Wu, bu, gam, bet, 1e-12, 1, zp, z, None, y, st)
+
+
+def bwd_fused_y():
+    L.adapter_ln_bwd(dy, y, st, gam, None, zp, 1, WuT, WdT, True, dv, dzp, dh, dbias=dbias, drop_p=0.1, drop_site=3, drop_seed=7, beta_y=bet)
+
+
 def fwd_three():
     L.gemm_nt(h, Wd, z, bias=bd, C2=zp, act=1)
     L.gemm_nt(z, Wu, v, bias=bu, R1=h, R2=x)
@@ -58,6 +66,10 @@ def timeit(f, n=50):
 
 fwd_three()
 alg = (4 * H + 128) * 2 * M
+alg_y = (3 * H + 128) * 2 * M
+for name, f, b in (('fwd fused (step)', fwd_fused_y, alg_y), ('bwd fused (step)', bwd_fused_y, alg)):
+    us = timeit(f)
+    print(f'{name:16s} {us:8.1f} us   {b / us / 1e6:6.2f} TB/s on {b / 1e6:.0f} MB')
 for name, f in (('fwd fused', fwd_fused), ('fwd 3 launches', fwd_three), ('bwd fused', bwd_fused), ('bwd 3 launches', bwd_three)):
     us = timeit(f)
     print(f'{name:16s} {us:8.1f} us   {alg / us / 1e6:6.2f} TB/s on the fused form\'s algorithmic bytes ({alg / 1e6:.0f} MB)')
