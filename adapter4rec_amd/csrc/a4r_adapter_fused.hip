@@ -85,28 +85,6 @@ A4R_DEV float kg_sum(float v) {    // over the 4 lanes (lane & 15 fixed) that ho
 }
 A4R_DEV float bf16_round(float x) { return bf16_bits_to_f32(f32_to_bf16_bits(x)); }
 
-// six 1-KiB LDS-DMA pieces behind one m0 write: LDS[dst + i * 1024 + lane * 16 .. + 16) <- base_a / base_o [voff_i] (the instruction offset
-// moves the LDS destination AND the source, tools/_probe/lds_dma_offset_probe.hip: every piece therefore gets its own address register)
-template <int KS>
-A4R_DEV void ring_dma(const void* base_a, const void* base_o, const uint32_t (&va)[KS], const uint32_t (&vo)[KS], uint32_t lds_dst) {
-#pragma unroll
-    for (int s = 0; s < KS; ++s) {
-        uint32_t keep;
-        asm volatile(
-            "s_mov_b32 %0, m0\n\t"
-            "s_mov_b32 m0, %5\n\t"
-            "s_nop 0\n\t"
-            "global_load_lds_dwordx4 %1, %3\n\t"
-            "s_mov_b32 m0, %6\n\t"
-            "s_nop 0\n\t"
-            "global_load_lds_dwordx4 %2, %4\n\t"
-            "s_mov_b32 m0, %0"
-            : "=&s"(keep)
-            : "v"(va[s]), "v"(vo[s]), "s"(base_a), "s"(base_o), "s"(lds_dst + (uint32_t)s * 1024u), "s"(lds_dst + (uint32_t)(KS + s) * 1024u)
-            : "memory");
-    }
-}
-
 struct AdFwdArgs {
     const bf16_t* A; const bf16_t* O; int lda, ldo, a_in_resid;
     const bf16_t* Wd; const bf16_t* Wu; const float* bd; const float* bu; const float* gamma; const float* beta;
@@ -144,17 +122,9 @@ A4R_DEV void store_bf16_n(bf16_t* dst, const float (&v)[EPT]) {
 A4R_DEV int zbf_off(int r, int zd) { return r * 128 + ((((zd >> 3) ^ ((r >> 1) & 7))) << 4) + (zd & 7) * 2; }
 
 // R32: the residual operand is the fp32 tensor O32 (two 16-byte pieces per 8 columns instead of one)
-// RING (round 5): the rows travel by LDS-DMA (global_load_lds_dwordx4) into a wave-private ring of two tile slots in LDS instead of a second
-// register set: TWO tiles (96 KB per CU) in flight at no register cost; a lane's 16-byte piece lands at slot + piece * 1024 + lane * 16, i.e. in
-// the very layout the register form loads, and is read back with one conflict-free ds_read_b128 per piece.  The DMA is invisible to hipcc's
-// s_waitcnt bookkeeping, so the wait in front of the read-back is counted by hand: vmcnt counts in order, every VMEM instruction issued after the
-// awaited tile's six pieces is the next tile's six + the stores of the tiles in between (p.nst per tile, a lower bound: over-waiting is safe).
-template <int CW, int NW, bool R32 = false, bool RING = false>
+template <int CW, int NW, bool R32 = false>
 __global__ void __launch_bounds__(NW * 64) adapter_ln_fwd_kernel(const AdFwdArgs p) {
     constexpr int KS = CW / 32, H = CW * NW, NT = NW * 64, EPT = 1024 / NT, OP = R32 ? 2 : 1;
-    static_assert(!(RING && R32), "the ring carries bf16 rows");
-    constexpr int SLOTB = 2 * KS * 1024;                    // one wave's rows of one tile: KS pieces of A, KS of O
-    __shared__ __attribute__((aligned(16))) char ring[RING ? NW * 2 * SLOTB : 16];
     __shared__ __attribute__((aligned(16))) float zpart[NW][16][ZLD];
     __shared__ __attribute__((aligned(16))) char zbf[16 * 128];
     __shared__ float red[NW][16][2];
@@ -167,22 +137,6 @@ __global__ void __launch_bounds__(NW * 64) adapter_ln_fwd_kernel(const AdFwdArgs
     const int cl = c0 + kg * 8;                              // + 32 s: first column of the lane's piece s
     A4R_ADF_LAUNCH(0)
     const int ntiles = p.M / 16;
-    const uint32_t ring0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)ring + (uint32_t)wave * (2u * SLOTB);
-    auto dma_tile = [&](int t, int slot) {      // rows of tile t -> this wave's ring slot
-        const uint32_t row = (uint32_t)t * 16u + (uint32_t)fr;
-        uint32_t va[KS], vo[KS];
-#pragma unroll
-        for (int s = 0; s < KS; ++s) {
-            va[s] = (row * (uint32_t)p.lda + (uint32_t)(cl + s * 32)) * 2u;
-            vo[s] = (row * (uint32_t)p.ldo + (uint32_t)(cl + s * 32)) * 2u;
-        }
-        ring_dma<KS>(p.A, p.O, va, vo, ring0 + (uint32_t)slot * SLOTB);
-    };
-    if constexpr (RING) {                       // first in the queue: everything hipcc counts comes behind these twelve
-        const int t1 = (int)blockIdx.x + (int)gridDim.x;
-        dma_tile((int)blockIdx.x, 0);
-        dma_tile(t1 < ntiles ? t1 : (int)blockIdx.x, 1);
-    }
     // the per-column parameters are REQUESTED here and written to LDS after the weight and first-tile requests below (round 4: as a plain copy loop this
     // compiled to H / NT dependent rounds of load -> wait -> ds_write ahead of everything else the workgroup asks for)
     constexpr int NPAR = (H + NT - 1) / NT;
@@ -226,39 +180,24 @@ __global__ void __launch_bounds__(NW * 64) adapter_ln_fwd_kernel(const AdFwdArgs
     } else {                                                                                                           \
         _Pragma("unroll") for (int s = 0; s < KS; ++s) dst_[s] = *reinterpret_cast<const uint4*>(p.O + (row_) * p.ldo + cl + s * 32); \
     }
-    if constexpr (!RING) {
+    {
         const size_t row = (size_t)blockIdx.x * 16 + fr;
 #pragma unroll
         for (int s = 0; s < KS; ++s) a_cur[s] = *reinterpret_cast<const uint4*>(p.A + row * p.lda + cl + s * 32);
         A4R_AD_LOAD_O(o_cur, row)
     }
+    A4R_ADF_LAUNCH(5)          // every request of the prologue issued
 #pragma unroll
     for (int i = 0; i < NPAR; ++i) {
         const int c = tid + i * NT;
         if (c < H) { par[0][c] = par_r[i][0]; par[1][c] = par_r[i][1]; par[2][c] = par_r[i][2]; }
     }
+    A4R_ADF_LAUNCH(6)          // the parameters (the first loads of the launch) have arrived
     A4R_LDS_BARRIER();                                       // par[] visible
     A4R_ADF_LAUNCH(1)
     int it = 0;
-    const int nrt = (p.y ? 1 : 0) + (p.v ? 1 : 0) + (p.y8 ? 1 : 0) + (p.y32 ? 2 : 0);
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x, ++it) {
-        if constexpr (RING) {
-            // this tile's six pieces have landed when at most (the next tile's six + the stores issued since) are outstanding
-            // (every wave stores zp and z, and KS pieces per row tensor it writes: nrt of y, v, y8, 2 x y32)
-            if (it == 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * KS) : "memory");
-            else if (it == 1 || nrt < 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * KS + 2) : "memory");
-            else if (nrt == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * KS + 2 * (2 + KS)) : "memory");
-            else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * KS + 2 * (2 + 2 * KS)) : "memory");
-            const char* rp = ring + (wave * 2 + (it & 1)) * SLOTB + lane * 16;
-#pragma unroll
-            for (int s = 0; s < KS; ++s) {
-                a_cur[s] = *reinterpret_cast<const uint4*>(rp + s * 1024);
-                o_cur[s] = *reinterpret_cast<const uint4*>(rp + (KS + s) * 1024);
-            }
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // the slot is read: two tiles ahead goes into it (past the end: this tile again)
-            const int tn = tile + 2 * (int)gridDim.x < ntiles ? tile + 2 * (int)gridDim.x : tile;
-            dma_tile(tn, it & 1);
-        } else {   // request the next tile's rows now (the last tile re-requests itself: the vmcnt schedule stays static)
+        {   // request the next tile's rows now (the last tile re-requests itself: the vmcnt schedule stays static)
             const int tn = tile + (int)gridDim.x < ntiles ? tile + (int)gridDim.x : tile;
             const size_t row = (size_t)tn * 16 + fr;
             if (A4R_AD_ABL & 8) {
@@ -401,15 +340,12 @@ __global__ void __launch_bounds__(NW * 64) adapter_ln_fwd_kernel(const AdFwdArgs
         }
         A4R_ADF_ST(7)
         if (it == 0) { A4R_ADF_LAUNCH(4) }
-        if constexpr (!RING) {
 #pragma unroll
-            for (int s = 0; s < KS; ++s) a_cur[s] = a_nxt[s];
+        for (int s = 0; s < KS; ++s) a_cur[s] = a_nxt[s];
 #pragma unroll
-            for (int s = 0; s < KS * OP; ++s) o_cur[s] = o_nxt[s];
-        }
+        for (int s = 0; s < KS * OP; ++s) o_cur[s] = o_nxt[s];
     }
     A4R_ADF_LAUNCH(2)
-    if constexpr (RING) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the re-requested pieces of the last tiles: nothing may land in LDS after the wave has left
 #undef A4R_AD_LOAD_O
 }
 
@@ -694,14 +630,8 @@ inline bool misaligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p)
 
 template <int CW, int NW>
 int launch_fwd(hipStream_t s, const AdFwdArgs& a, int grid) {
-    // A4R_AD_RING=0: the register form always (A/B).  The ring needs 2 x NW x 2 KS KiB of LDS next to the partial tiles (H <= 768) and 32-bit row offsets
-    static const int ring = getenv("A4R_AD_RING") ? atoi(getenv("A4R_AD_RING")) : 1;
     if (a.O32) hipLaunchKernelGGL((adapter_ln_fwd_kernel<CW, NW, true>), dim3(grid), dim3(NW * 64), 0, s, a);
-    else if constexpr (CW * NW <= 768) {
-        const uint64_t span = (uint64_t)a.M * (uint64_t)(a.lda > a.ldo ? a.lda : a.ldo) * 2u;
-        if (ring && span < (1ull << 32)) hipLaunchKernelGGL((adapter_ln_fwd_kernel<CW, NW, false, true>), dim3(grid), dim3(NW * 64), 0, s, a);
-        else hipLaunchKernelGGL((adapter_ln_fwd_kernel<CW, NW, false>), dim3(grid), dim3(NW * 64), 0, s, a);
-    } else hipLaunchKernelGGL((adapter_ln_fwd_kernel<CW, NW, false>), dim3(grid), dim3(NW * 64), 0, s, a);
+    else hipLaunchKernelGGL((adapter_ln_fwd_kernel<CW, NW, false>), dim3(grid), dim3(NW * 64), 0, s, a);
     return a4r_launch_status();
 }
 template <int CW, int NW, bool DRES>

@@ -16,11 +16,13 @@ us = AB.timeit(AB.fwd_fused_y)
 torch.cuda.synchronize()
 buf = (C.c_ulonglong * (256 * 2 * 8))()
 assert L.lib().a4r_debug_adapter_stamps(buf) == 0
-st = np.frombuffer(buf, dtype=np.uint64).reshape(256, 16).astype(np.int64)[:, :5] / 100.0
+st = np.frombuffer(buf, dtype=np.uint64).reshape(256, 16).astype(np.int64)[:, :7] / 100.0
 t0 = st[:, 0].min()
 q = lambda a: f'median {np.median(a):6.2f}  min {a.min():6.2f}  max {a.max():6.2f}'
 print(f'launch period (events, back to back) {us:.1f} us;  first entry -> last exit {st[:, 2].max() - t0:.2f} us')
 print('entry after the first workgroup     ', q(st[:, 0] - t0))
+print('entry -> every prologue request issued', q(st[:, 5] - st[:, 0]))
+print('-> first loads (parameters) arrived   ', q(st[:, 6] - st[:, 5]))
 print('prologue (entry -> parameters in LDS)', q(st[:, 1] - st[:, 0]))
 print('-> first tile past barrier 1         ', q(st[:, 3] - st[:, 1]))
 print('-> first tile done                   ', q(st[:, 4] - st[:, 3]))
