@@ -59,7 +59,17 @@ extern "C" int a4r_debug_adapter_stamps(unsigned long long* host_out) {
 #else
 #define A4R_ADF_LAUNCH(k_)
 #endif
+#if A4R_STAMP == 4          /* -DA4R_STAMP=4: the same for the backward launch (entry, prologue done, first tile done, last tile done) */
+#undef A4R_ADF_ST
+#undef A4R_AD_ST
+#define A4R_ADF_ST(k_)
+#define A4R_AD_ST(k_)
+#define A4R_ADB_LAUNCH(k_) if (lane == 0 && wave == 0 && blockIdx.x < 256) g_a4r_ad_stamps[blockIdx.x * 16 + (k_)] = __builtin_amdgcn_s_memrealtime();
 #else
+#define A4R_ADB_LAUNCH(k_)
+#endif
+#else
+#define A4R_ADB_LAUNCH(k_)
 #define A4R_AD_ST(k_)
 #define A4R_ADF_ST(k_)
 #define A4R_ADF_LAUNCH(k_)
@@ -381,24 +391,17 @@ __global__ void __launch_bounds__(NW * 64) adapter_ln_bwd_kernel(const AdBwdArgs
     const int fr = lane & 15, kg = lane >> 4;
     const int c0 = wave * CW;
     const int cl = c0 + kg * 8;
+    A4R_ADB_LAUNCH(0)
     __shared__ __attribute__((aligned(16))) float par_fy[FY ? 2 : 1][FY ? H : 4];      // 1 / gamma, -beta / gamma
-    {   // (all parameter requests first, then the LDS writes: as copy loops these were H / NT dependent rounds of load -> wait -> write)
-        constexpr int NPAR = (H + NT - 1) / NT;
-        float g_r[NPAR], b_r[NPAR];
+    // the per-column parameters are REQUESTED here and written to LDS behind every other request of the prologue (round 5: written at once, the
+    // wave sat out a whole memory round trip before it asked for its weight fragments and first rows: `entry -> every request issued` 4.4 us)
+    constexpr int NPAR = (H + NT - 1) / NT;
+    float g_r[NPAR], b_r[NPAR];
 #pragma unroll
-        for (int i = 0; i < NPAR; ++i) {
-            const int c = tid + i * NT;
-            g_r[i] = c < H ? p.gamma[c] : 1.f;
-            b_r[i] = (FY && c < H) ? p.beta[c] : 0.f;
-        }
-#pragma unroll
-        for (int i = 0; i < NPAR; ++i) {
-            const int c = tid + i * NT;
-            if (c < H) {
-                par[c] = g_r[i];
-                if constexpr (FY) { const float ig = 1.f / g_r[i]; par_fy[0][c] = ig; par_fy[1][c] = -b_r[i] * ig; }
-            }
-        }
+    for (int i = 0; i < NPAR; ++i) {
+        const int c = tid + i * NT;
+        g_r[i] = c < H ? p.gamma[c] : 1.f;
+        b_r[i] = (FY && c < H) ? p.beta[c] : 0.f;
     }
 
     // dz = dv . Wu (contraction over H: WuT [64, H]) keeps its fragments in registers; dh = dzp . Wd (contraction over 64:
@@ -411,6 +414,35 @@ __global__ void __launch_bounds__(NW * 64) adapter_ln_bwd_kernel(const AdBwdArgs
 #pragma unroll
         for (int nt = 0; nt < 4; ++nt)
             wu[s][nt] = *reinterpret_cast<const uint4*>(p.WuT + (size_t)(nt * 16 + fr) * H + cl + s * 32);
+    // (round 5) the image is written by LDS-DMA: a lane's 16 bytes land at piece + lane * 16, which IS wdl[wave][2 s + h][ks][lane] -- no trip through
+    // the registers, no wait in front of a ds_write: the launch's prologue 8.6 -> ? us (tools/adapter_launch_timeline.py bwd).  hipcc does not see
+    // these requests: the wait in front of the prologue's barrier is counted by hand (A4R_AD_WDL_DMA=0 at compile time: the register form, A/B)
+#ifndef A4R_AD_WDL_DMA
+#define A4R_AD_WDL_DMA 1
+#endif
+#if A4R_AD_WDL_DMA
+    {
+        const uint32_t img = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)&wdl[wave][0][0][0];
+#pragma unroll
+        for (int s = 0; s < KS; ++s)
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) {
+                    const uint32_t voff = (uint32_t)(((c0 + s * 32 + (fr >> 2) * 8 + h * 4 + (fr & 3)) * 64 + ks * 32 + kg * 8) * 2);
+                    uint32_t keep;
+                    asm volatile(
+                        "s_mov_b32 %0, m0\n\t"
+                        "s_mov_b32 m0, %3\n\t"
+                        "s_nop 0\n\t"
+                        "global_load_lds_dwordx4 %1, %2\n\t"
+                        "s_mov_b32 m0, %0"
+                        : "=&s"(keep)
+                        : "v"(voff), "s"(p.WdT), "s"(img + (uint32_t)(((2 * s + h) * 2 + ks) * 1024))
+                        : "memory");
+                }
+    }
+#else
 #pragma unroll
     for (int s = 0; s < KS; ++s)
 #pragma unroll
@@ -419,6 +451,7 @@ __global__ void __launch_bounds__(NW * 64) adapter_ln_bwd_kernel(const AdBwdArgs
             for (int ks = 0; ks < 2; ++ks)
                 wdl[wave][2 * s + h][ks][lane] =
                     *reinterpret_cast<const uint4*>(p.WdT + (size_t)(c0 + s * 32 + (fr >> 2) * 8 + h * 4 + (fr & 3)) * 64 + ks * 32 + kg * 8);
+#endif
 
     const int e0 = tid * EPT, rrow = e0 >> 6, rzd = e0 & 63;
     float sd[EPT];                          // column sums of dzp over this workgroup's tiles (the down-projection's bias gradient)
@@ -452,7 +485,23 @@ __global__ void __launch_bounds__(NW * 64) adapter_ln_bwd_kernel(const AdBwdArgs
     Rows cur, nxt, nn;
     request(cur, (int)blockIdx.x);
     if constexpr (DEEP) request(nxt, (int)blockIdx.x + G < ntiles ? (int)blockIdx.x + G : (int)blockIdx.x);
+#pragma unroll
+    for (int i = 0; i < NPAR; ++i) {
+        const int c = tid + i * NT;
+        if (c < H) {
+            par[c] = g_r[i];
+            if constexpr (FY) { const float ig = 1.f / g_r[i]; par_fy[0][c] = ig; par_fy[1][c] = -b_r[i] * ig; }
+        }
+    }
+    A4R_ADB_LAUNCH(5)
+#if A4R_AD_WDL_DMA
+    // the 4 KS pieces of the image have landed once at most the requests issued BEHIND them are outstanding (vmcnt counts in order): every wave
+    // issues the first tile's rows (2 KS + 2, + KS with a residual-stream gradient) and, DEEP, the second tile's; the parameter loads in between
+    // may be skipped by a whole wave and are not counted (a lower bound only over-waits)
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"((2 * KS + 2 + (DRES ? KS : 0)) * (DEEP ? 2 : 1)) : "memory");
+#endif
     A4R_LDS_BARRIER();
+    A4R_ADB_LAUNCH(1)
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         {
             const int ahead = (DEEP ? 2 : 1) * G;
@@ -589,9 +638,11 @@ __global__ void __launch_bounds__(NW * 64) adapter_ln_bwd_kernel(const AdBwdArgs
             else if (o8[0] == 12345.f) p.dbias[0] = o8[1];
         }
         A4R_AD_ST(7)
+        if (tile == (int)blockIdx.x) { A4R_ADB_LAUNCH(4) }
         if constexpr (DEEP) { cur = nxt; nxt = nn; }
         else cur = nn;
     }
+    A4R_ADB_LAUNCH(2)
     // ---- db_down = column sums of dzp: thread t holds columns (t EPT) & 63 of row (t EPT) >> 6 -> through LDS, one atomic per column
     if (A4R_AD_ABL & 4) return;                 // (timing only: no column-sum flush)
     if (p.dbd) {

@@ -31,8 +31,8 @@ def fwd_fused_y():          # the training step's form: only y = LN(v) is kept (
     L.adapter_ln_fwd(h, h, x, Wd, bd, Wu, bu, gam, bet, 1e-12, 1, zp, z, None, y, st)
 
 
-def bwd_fused_y():
-    L.adapter_ln_bwd(dy, y, st, gam, None, zp, 1, WuT, WdT, True, dv, dzp, dh, dbias=dbias, drop_p=0.1, drop_site=3, drop_seed=7, beta_y=bet)
+def bwd_fused_y():          # the step's form: xhat from y; the bias gradients ride in the weight-gradient launch (no column sums here)
+    L.adapter_ln_bwd(dy, y, st, gam, None, zp, 1, WuT, WdT, True, dv, dzp, dh, drop_p=0.1, drop_site=3, drop_seed=7, beta_y=bet)
 
 
 def fwd_three():
