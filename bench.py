@@ -400,6 +400,9 @@ def main():
                     help="text workloads, NOT the canonical benchmark: SURVEY 8(d)'s 'realistic' titles of n ~ U{6..20} tokens (30-token rows, the rest pad); the "
                          'batch is handed over on the HOST every step (as run.py does) and the step runs on the longest title of the batch')
     ap.add_argument('--short-titles-device', action='store_true', help='with --short-titles: batches resident on the device (30 tokens per item: the A/B)')
+    ap.add_argument('--residual-dtype', default='bf16', choices=['bf16', 'fp32'],
+                    help="text towers: --residual_dtype fp32 of parameters.py (the residual stream between sub-layers in fp32, as under the reference's "
+                         "autocast); its cost is NOT in the headline line: measure it with this flag (recorded in config.residual_dtype)")
     ap.add_argument('--gemm-variant', type=int, default=-1, help='A/B knob of a4r_gemm_variant (include/a4r.h); default: the library default')
     a = ap.parse_args()
     # Every A4R_* variable of the environment goes into the JSON line (`env_knobs`): a record made with an A/B knob set says so itself.
@@ -456,6 +459,7 @@ def main():
         batches = synth_image_batches(a.batch, 4 if a.ragged_histories else 2, device, SEED + rank, ragged=a.ragged_histories, host_mask=not a.ragged_device_mask)
     else:
         args = make_args(a.batch, a.dtype)
+        args.residual_dtype = a.residual_dtype
         if wl == 'roberta_pfeiffer_cpc':
             args.adapter_type, args.adapter_activation, args.arch, args.bert_model_load = 'pfeiffer', 'relu', 'cpc', 'roberta_base'
         if wl == 'bert_pretrain':
@@ -715,7 +719,8 @@ def main():
                        # item slots the model reads: Model.forward drops every user's last negative, ModelCPC.forward reads one negative only; the
                        # engine does not encode unread slots where that removes work (engine.py: _kept_rows; A4R_SKIP_UNUSED_ITEMS=0: all 42)
                        'items_encoded_per_user': (eng._kept_rows(a.batch) or 42 * a.batch) // a.batch, 'parallelism': f'dp{world}',
-                       'path': 'public: optimizer.zero_grad(); FlatDDP(model)(items, mask); loss.backward(); FusedAdam.step()'},
+                       'path': 'public: optimizer.zero_grad(); FlatDDP(model)(items, mask); loss.backward(); FusedAdam.step()',
+                       **({'residual_dtype': 'fp32'} if a.residual_dtype == 'fp32' else {})},
             'rccl_ranks': rccl_ranks, 'allreduce_bytes_per_step': int(eng.flat_g.numel() * 4) if world > 1 else 0, 'allreduce_us': ar_us,
             'ms_per_step_ranks': rank_ms, 'ms_per_step_spread': round(max(rank_ms) - min(rank_ms), 3),
             'allreduce_overlapped': bool(world > 1 and eng.OVERLAP_ALLREDUCE and eng._grad_chunks() is not None),
