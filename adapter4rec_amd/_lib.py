@@ -12,7 +12,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('A4R_LIB_PATH') or os.path.join(_HERE, 'liba4r_hip.so')    # A4R_LIB_PATH: A/B builds (tools/), same C ABI
 
-ABI_VERSION = 407          # = A4R_ABI_VERSION of include/a4r.h (tests/test_abi_cpu.py compares the two)
+ABI_VERSION = 408          # = A4R_ABI_VERSION of include/a4r.h (tests/test_abi_cpu.py compares the two)
 BF16, F32, FP8 = 0, 1, 2
 ACT_NONE, ACT_RELU, ACT_GELU, ACT_GELU_TANH, ACT_LEAKY = 0, 1, 2, 3, 4
 DACT_MUL = 15
@@ -196,31 +196,37 @@ def adapter_ln_ok(A, d):
     return A.dtype == torch.bfloat16 and d == 64 and A.shape[1] in (128, 256, 512, 768, 1024)
 
 
-def adapter_ln_fwd(A, R1, R2, Wd, bd, Wu, bu, gamma, beta, eps, act, zp, z, v, y, stats, M=None, y8=None, ys=None, res32=None, y32=None):
-    """res32 / y32 (fp32 [M, H], optional): the residual operand that is not A read in fp32, and y before its bf16 rounding (include/a4r.h)."""
+def adapter_ln_fwd(A, R1, R2, Wd, bd, Wu, bu, gamma, beta, eps, act, zp, z, v, y, stats, M=None, y8=None, ys=None, res32=None, y32=None, frag=None):
+    """res32 / y32 (fp32 [M, H], optional): the residual operand that is not A read in fp32, and y before its bf16 rounding (include/a4r.h).
+    frag = (Wd_f, Wu_f): the same matrices in fragment order (a4r_pack_matrices layouts 1 / 2): read instead of Wd / Wu (w_frag)."""
     require_gpu(A, R1, R2, v, y, res32, y32)
     M = A.shape[0] if M is None else M
     assert y is not None or y8 is not None
     assert all(t is None or (t.dtype == torch.float32 and t.shape[0] >= M) for t in (res32, y32))
+    wd_, wu_ = (Wd, Wu) if frag is None else frag
     _check(lib().a4r_adapter_ln_fwd(_stream(), _p(A), C.c_int(_ld(A)), _p(R1), C.c_int(_ld(R1)), _p(R2), C.c_int(_ld(R2) if R2 is not None else 0),
-                                    _p(Wd), _p(bd), _p(Wu), _p(bu), _p(gamma), _p(beta), C.c_float(eps), C.c_int(act),
+                                    _p(wd_), _p(bd), _p(wu_), _p(bu), _p(gamma), _p(beta), C.c_float(eps), C.c_int(act),
                                     _p(zp), _p(z), _p(v), C.c_int(_ld(v) if v is not None else 0), _p(y), C.c_int(_ld(y) if y is not None else 0), _p(stats),
                                     C.c_int(M), C.c_int(A.shape[1]), C.c_int(Wd.shape[0]), C.c_int(_dt(A)),
                                     _p(y8), C.c_int(_ld(y8) if y8 is not None else 0), _p(ys),
-                                    _p(res32), C.c_int(_ld(res32) if res32 is not None else 0), _p(y32), C.c_int(_ld(y32) if y32 is not None else 0)),
+                                    _p(res32), C.c_int(_ld(res32) if res32 is not None else 0), _p(y32), C.c_int(_ld(y32) if y32 is not None else 0),
+                                    C.c_int(0 if frag is None else 1)),
            'a4r_adapter_ln_fwd')
 
 
 def adapter_ln_bwd(dy, v, stats, gamma, dres, zp, act, WuT, WdT, inner_res, dv, dzp, dh, dgamma=None, dbeta=None, dbias=None, M=None,
-                   drop_p=0.0, drop_site=0, drop_seed=0, dbd=None, bias_total=False, beta_y=None):
-    """beta_y: the forward kept y = LN(v) instead of v (called with v=None); `v` is that y and xhat is rebuilt as (y - beta_y) / gamma."""
+                   drop_p=0.0, drop_site=0, drop_seed=0, dbd=None, bias_total=False, beta_y=None, frag=None):
+    """beta_y: the forward kept y = LN(v) instead of v (called with v=None); `v` is that y and xhat is rebuilt as (y - beta_y) / gamma.
+    frag = (WuT_f, WdT_f): the two matrices in fragment order (flags bit 1)."""
     require_gpu(dy, v, dv, dh)
     M = dy.shape[0] if M is None else M
+    wut_, wdt_ = (WuT, WdT) if frag is None else frag
     _check(lib().a4r_adapter_ln_bwd(_stream(), _p(dy), C.c_int(_ld(dy)), _p(v), C.c_int(_ld(v)), _p(stats), _p(gamma),
-                                    _p(dres), C.c_int(_ld(dres) if dres is not None else 0), _p(zp), C.c_int(act), _p(WuT), _p(WdT),
+                                    _p(dres), C.c_int(_ld(dres) if dres is not None else 0), _p(zp), C.c_int(act), _p(wut_), _p(wdt_),
                                     C.c_int(int(inner_res)), _p(dv), C.c_int(_ld(dv)), _p(dzp), _p(dh), C.c_int(_ld(dh)),
                                     _p(dgamma), _p(dbeta), _p(dbias), C.c_int(M), C.c_int(dy.shape[1]), C.c_int(WuT.shape[0]), C.c_int(_dt(dy)),
-                                    C.c_float(drop_p), C.c_uint32(drop_site), C.c_uint64(drop_seed), _p(dbd), C.c_int(int(bias_total)), _p(beta_y)), 'a4r_adapter_ln_bwd')
+                                    C.c_float(drop_p), C.c_uint32(drop_site), C.c_uint64(drop_seed), _p(dbd),
+                                    C.c_int(int(bias_total) | (0 if frag is None else 2)), _p(beta_y)), 'a4r_adapter_ln_bwd')
 
 
 def sasrec_block(desc, x, log_mask, out, n_users, T, train, dy=None):

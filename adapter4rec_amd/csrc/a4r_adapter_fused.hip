@@ -55,7 +55,7 @@ extern "C" int a4r_debug_adapter_stamps(unsigned long long* host_out) {
 #undef A4R_AD_ST
 #define A4R_ADF_ST(k_)
 #define A4R_AD_ST(k_)
-#define A4R_ADF_LAUNCH(k_) if (lane == 0 && wave == 0 && blockIdx.x < 256) g_a4r_ad_stamps[blockIdx.x * 16 + (k_)] = __builtin_amdgcn_s_memrealtime();
+#define A4R_ADF_LAUNCH(k_) if (lane == 0 && (wave == 0 || wave == NW - 1) && blockIdx.x < 256) g_a4r_ad_stamps[blockIdx.x * 16 + (wave ? 8 : 0) + (k_)] = __builtin_amdgcn_s_memrealtime();      /* slots 0-7: wave 0, 8-15: the last wave */
 #else
 #define A4R_ADF_LAUNCH(k_)
 #endif
@@ -104,6 +104,7 @@ struct AdFwdArgs {
     // --residual_dtype fp32 (round 4): the residual stream between sub-layers in fp32, as under the reference's autocast (its LayerNorm
     // outputs fp32 and the residual add promotes to it): O32 replaces O as the residual operand, y32 is y before its bf16 rounding
     const float* O32; int ldo32; float* y32; int ldy32;
+    int wfrag;                                  // Wd / Wu in fragment order
 };
 
 // sum of the NW partial [16][64] tiles for EPT consecutive bottleneck columns of one row (thread t: element t * EPT)
@@ -158,20 +159,25 @@ __global__ void __launch_bounds__(NW * 64) adapter_ln_fwd_kernel(const AdFwdArgs
         par_r[i][0] = in ? p.bu[c] : 0.f; par_r[i][1] = in ? p.gamma[c] : 0.f; par_r[i][2] = in ? p.beta[c] : 0.f;
     }
 
-    // weight fragments (W side of the MFMA: a lane supplies weight row (lane & 15), 8 contraction elements at lane >> 4)
+    // weight fragments (W side of the MFMA: a lane supplies weight row (lane & 15), 8 contraction elements at lane >> 4).
+    // wfrag (round 5): the matrices arrive in FRAGMENT order (a4r_pack_matrices layouts 1 / 2, include/a4r.h): a wave instruction then reads 1 KiB
+    // contiguous instead of 16 row pieces of 64 bytes, which the CU's address unit takes twice as long over -- all 8 waves' requests issued after
+    // 2.9 instead of 4.6 us, first tile 3 us earlier (tools/adapter_launch_timeline.py; profiles/r05_m_*)
     uint4 wd[KS][4], wu[2 * KS][2];
 #pragma unroll
     for (int s = 0; s < KS; ++s)
 #pragma unroll
         for (int nt = 0; nt < 4; ++nt)
-            wd[s][nt] = *reinterpret_cast<const uint4*>(p.Wd + (size_t)(nt * 16 + fr) * H + cl + s * 32);
+            wd[s][nt] = *reinterpret_cast<const uint4*>(p.wfrag ? p.Wd + (size_t)(((wave * KS + s) * 4 + nt) * 64 + lane) * 8
+                                                                 : p.Wd + (size_t)(nt * 16 + fr) * H + cl + s * 32);
 #pragma unroll
     for (int s = 0; s < KS; ++s)
 #pragma unroll
         for (int h = 0; h < 2; ++h)
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks)      // accumulator register (kg', r) of tile 2s+h <- weight row c0 + 32 s + 8 kg' + 4 h + r
-                wu[2 * s + h][ks] = *reinterpret_cast<const uint4*>(p.Wu + (size_t)(c0 + s * 32 + (fr >> 2) * 8 + h * 4 + (fr & 3)) * 64 + ks * 32 + kg * 8);
+                wu[2 * s + h][ks] = *reinterpret_cast<const uint4*>(p.wfrag ? p.Wu + (size_t)((((wave * KS + s) * 2 + h) * 2 + ks) * 64 + lane) * 8
+                                                                             : p.Wu + (size_t)(c0 + s * 32 + (fr >> 2) * 8 + h * 4 + (fr & 3)) * 64 + ks * 32 + kg * 8);
 
     const int e0 = tid * EPT, rrow = e0 >> 6, rzd = e0 & 63;  // this thread's share of the [16][64] reduction
     float bd_r[EPT];
@@ -366,7 +372,7 @@ struct AdBwdArgs {
     const bf16_t* WuT; const bf16_t* WdT; int inner_res;
     bf16_t* dv; bf16_t* dzp; bf16_t* dh; int lddv, lddh;
     float* dgamma; float* dbeta; float* dbias; float* dbd;
-    int M, bias_total;
+    int M, bias_total, wfrag;
     uint64_t seed; uint32_t site, thr16; float keep_scale;
 };
 
@@ -413,7 +419,8 @@ __global__ void __launch_bounds__(NW * 64) adapter_ln_bwd_kernel(const AdBwdArgs
     for (int s = 0; s < KS; ++s)
 #pragma unroll
         for (int nt = 0; nt < 4; ++nt)
-            wu[s][nt] = *reinterpret_cast<const uint4*>(p.WuT + (size_t)(nt * 16 + fr) * H + cl + s * 32);
+            wu[s][nt] = *reinterpret_cast<const uint4*>(p.wfrag ? p.WuT + (size_t)(((wave * KS + s) * 4 + nt) * 64 + lane) * 8      // (fragment order: see the forward)
+                                                                 : p.WuT + (size_t)(nt * 16 + fr) * H + cl + s * 32);
     // (round 5) the image is written by LDS-DMA: a lane's 16 bytes land at piece + lane * 16, which IS wdl[wave][2 s + h][ks][lane] -- no trip through
     // the registers, no wait in front of a ds_write: the launch's prologue 8.6 -> ? us (tools/adapter_launch_timeline.py bwd).  hipcc does not see
     // these requests: the wait in front of the prologue's barrier is counted by hand (A4R_AD_WDL_DMA=0 at compile time: the register form, A/B)
@@ -429,7 +436,8 @@ __global__ void __launch_bounds__(NW * 64) adapter_ln_bwd_kernel(const AdBwdArgs
             for (int h = 0; h < 2; ++h)
 #pragma unroll
                 for (int ks = 0; ks < 2; ++ks) {
-                    const uint32_t voff = (uint32_t)(((c0 + s * 32 + (fr >> 2) * 8 + h * 4 + (fr & 3)) * 64 + ks * 32 + kg * 8) * 2);
+                    const uint32_t voff = p.wfrag ? (uint32_t)((((((wave * KS + s) * 2 + h) * 2 + ks) * 64 + lane) * 8) * 2)
+                                                  : (uint32_t)(((c0 + s * 32 + (fr >> 2) * 8 + h * 4 + (fr & 3)) * 64 + ks * 32 + kg * 8) * 2);
                     uint32_t keep;
                     asm volatile(
                         "s_mov_b32 %0, m0\n\t"
@@ -450,7 +458,8 @@ __global__ void __launch_bounds__(NW * 64) adapter_ln_bwd_kernel(const AdBwdArgs
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks)
                 wdl[wave][2 * s + h][ks][lane] =
-                    *reinterpret_cast<const uint4*>(p.WdT + (size_t)(c0 + s * 32 + (fr >> 2) * 8 + h * 4 + (fr & 3)) * 64 + ks * 32 + kg * 8);
+                    *reinterpret_cast<const uint4*>(p.wfrag ? p.WdT + (size_t)((((wave * KS + s) * 2 + h) * 2 + ks) * 64 + lane) * 8
+                                                            : p.WdT + (size_t)(c0 + s * 32 + (fr >> 2) * 8 + h * 4 + (fr & 3)) * 64 + ks * 32 + kg * 8);
 #endif
 
     const int e0 = tid * EPT, rrow = e0 >> 6, rzd = e0 & 63;
@@ -714,7 +723,7 @@ extern "C" int a4r_adapter_ln_fwd(void* stream, const void* A, int lda, const vo
                                   const void* Wd, const float* bd, const void* Wu, const float* bu,
                                   const float* gamma, const float* beta, float eps, int act,
                                   void* zp, void* z, void* v, int ldv, void* y, int ldy, float* stats, int M, int H, int d, int dtype,
-                                  void* y8, int ld8, float* ys, const float* res32, int ldres32, float* y32, int ldy32) {
+                                  void* y8, int ld8, float* ys, const float* res32, int ldres32, float* y32, int ldy32, int w_frag) {
     if (!A || !R1 || !Wd || !bd || !Wu || !bu || !gamma || !beta || !zp || !z || (!v && !y) || (!y && !y8) || !stats) return A4R_EINVAL;      // v may be null when y is kept
     if ((res32 && (ldres32 % 4 || ldres32 < H || misaligned16(res32))) || (y32 && (ldy32 % 4 || ldy32 < H || misaligned16(y32)))) return A4R_EINVAL;
     if (y8 && (!ys || ld8 % 8 || ld8 < H || (reinterpret_cast<uintptr_t>(y8) & 7u))) return A4R_EINVAL;
@@ -736,6 +745,7 @@ extern "C" int a4r_adapter_ln_fwd(void* stream, const void* A, int lda, const vo
     a.ldv = ldv; a.ldy = ldy; a.stats = stats; a.M = M;
     a.y8 = reinterpret_cast<unsigned char*>(y8); a.ld8 = ld8; a.ys = ys;
     a.O32 = res32; a.ldo32 = ldres32; a.y32 = y32; a.ldy32 = ldy32;      // (res32: the fp32 twin of the residual operand that is not A)
+    a.wfrag = w_frag != 0;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     const int ntiles = M / 16, ncu = a4r_cu_count();
     const int grid = ntiles < ncu ? ntiles : ncu;
@@ -766,7 +776,7 @@ extern "C" int a4r_adapter_ln_bwd(void* stream, const void* dy, int lddy, const 
     a.zp = reinterpret_cast<const bf16_t*>(zp); a.act = act;
     a.WuT = reinterpret_cast<const bf16_t*>(WuT); a.WdT = reinterpret_cast<const bf16_t*>(WdT); a.inner_res = inner_res;
     a.dv = reinterpret_cast<bf16_t*>(dv); a.dzp = reinterpret_cast<bf16_t*>(dzp); a.dh = reinterpret_cast<bf16_t*>(dh);
-    a.lddv = lddv; a.lddh = lddh; a.dgamma = dgamma; a.dbeta = dbeta; a.dbias = dbias; a.dbd = dbd; a.M = M; a.bias_total = flags & 1;
+    a.lddv = lddv; a.lddh = lddh; a.dgamma = dgamma; a.dbeta = dbeta; a.dbias = dbias; a.dbd = dbd; a.M = M; a.bias_total = flags & 1; a.wfrag = (flags >> 1) & 1;
     a.seed = drop_seed; a.site = drop_site; a.thr16 = a4r_thr16(drop_p); a.keep_scale = a4r_keep_scale(drop_p);
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     const int ntiles = M / 16, ncu = a4r_cu_count();

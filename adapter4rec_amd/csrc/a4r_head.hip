@@ -158,18 +158,36 @@ __global__ void __launch_bounds__(256) adam4_kernel(float* __restrict__ p, const
 struct PackDesc {   // mirrors a4r_pack_desc_t
     int64_t src_off; void* dst; int32_t rows, cols, rows_pad, cols_pad, transpose, dst_ld;
 };
+// Where element (r, c) of the [rows_pad, cols_pad] destination goes.  layout 0: row-major with stride ld.  Layouts 1 / 2 (a4r_pack_desc_t.transpose bits
+// 1-2): the MFMA FRAGMENT order of the one-launch adapter kernels (a4r_adapter_fused.hip), H = NW x CW columns per row of activations, KS = CW / 32:
+//   1: a [64, H] matrix (fc_down.weight, fc_up.weight^T): 16 bytes of lane (kg, fr) in fragment (wave w, step s, row tile nt)
+//      = row 16 nt + fr, columns w CW + 32 s + 8 kg + [0, 8)                                  -> ((((w KS + s) 4 + nt) 64 + 16 kg + fr) 8 + j
+//   2: an [H, 64] matrix (fc_up.weight, fc_down.weight^T): fragment (w, s, half h, step ks) = row w CW + 32 s + 8 (fr >> 2) + 4 h + (fr & 3),
+//      columns 32 ks + 8 kg + [0, 8)                                                          -> (((((w KS + s) 2 + h) 2 + ks) 64 + 16 kg + fr) 8 + j
+// so that every wave instruction of those kernels' prologues reads 1 KiB contiguous.
+A4R_DEV size_t pack_dst_index(int layout, int r, int c, int rows_pad, int cols_pad, int ld) {
+    if (layout == 0) return (size_t)r * ld + c;
+    const int Hh = layout == 1 ? cols_pad : rows_pad, NW = Hh == 128 ? 4 : 8, CW = Hh / NW, KS = CW / 32;
+    if (layout == 1) {
+        const int w = c / CW, cc = c % CW, s_ = cc >> 5, kg = (cc & 31) >> 3, j = cc & 7, nt = r >> 4, fr = r & 15;
+        return (size_t)((((w * KS + s_) * 4 + nt) * 64 + kg * 16 + fr) * 8 + j);
+    }
+    const int w = r / CW, rr = r % CW, s_ = rr >> 5, q = rr & 31, fr = (q >> 3) * 4 + (q & 3), h = (q >> 2) & 1, ks = c >> 5, kg = (c & 31) >> 3, j = c & 7;
+    return (size_t)(((((w * KS + s_) * 2 + h) * 2 + ks) * 64 + kg * 16 + fr) * 8 + j);
+}
 template <typename T>
 __global__ void __launch_bounds__(256) pack_kernel(const float* __restrict__ flat, const PackDesc* __restrict__ desc) {
     const PackDesc d = desc[blockIdx.y];
     T* dst = reinterpret_cast<T*>(d.dst);
     const int total = d.rows_pad * d.cols_pad;
     const int ld = d.dst_ld ? d.dst_ld : d.cols_pad;          // dst may be a column block of a wider matrix (fused q|k|v operand)
+    const int tr = d.transpose & 1, layout = d.transpose >> 1;
     for (int i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
         const int r = i / d.cols_pad, c = i % d.cols_pad;     // destination coordinates
-        const int sr = d.transpose ? c : r, sc = d.transpose ? r : c;
+        const int sr = tr ? c : r, sc = tr ? r : c;
         float val = 0.f;
         if (sr < d.rows && sc < d.cols) val = flat[d.src_off + (int64_t)sr * d.cols + sc];
-        Elem<T>::st(dst + (size_t)r * ld + c, val);
+        Elem<T>::st(dst + pack_dst_index(layout, r, c, d.rows_pad, d.cols_pad, ld), val);
     }
 }
 
@@ -184,9 +202,10 @@ __global__ void __launch_bounds__(256) pack_tiled_kernel(const float* __restrict
     const int ld = d.dst_ld ? d.dst_ld : d.cols_pad;
     const int tr = (d.rows_pad + 63) >> 6, tc = (d.cols_pad + 63) >> 6;
     const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;          // 64 columns x 4 row lanes
+    const int layout = d.transpose >> 1;                             // (fragment-ordered adapter copies in a list that also holds large matrices)
     for (int t = blockIdx.x; t < tr * tc; t += gridDim.x) {
         const int r0 = (t / tc) * 64, c0 = (t % tc) * 64;            // destination tile
-        if (d.transpose) {                                           // dst[r, c] = src[c, r]: read source rows c0 .. c0 + 63, columns r0 .. r0 + 63
+        if (d.transpose & 1) {                                           // dst[r, c] = src[c, r]: read source rows c0 .. c0 + 63, columns r0 .. r0 + 63
             __syncthreads();
 #pragma unroll 4
             for (int k = ty; k < 64; k += 4) {
@@ -197,14 +216,14 @@ __global__ void __launch_bounds__(256) pack_tiled_kernel(const float* __restrict
 #pragma unroll 4
             for (int k = ty; k < 64; k += 4) {
                 const int r = r0 + k, c = c0 + tx;
-                if (r < d.rows_pad && c < d.cols_pad) Elem<T>::st(dst + (size_t)r * ld + c, tile[tx][k]);
+                if (r < d.rows_pad && c < d.cols_pad) Elem<T>::st(dst + pack_dst_index(layout, r, c, d.rows_pad, d.cols_pad, ld), tile[tx][k]);
             }
         } else {
 #pragma unroll 4
             for (int k = ty; k < 64; k += 4) {
                 const int r = r0 + k, c = c0 + tx;
                 if (r < d.rows_pad && c < d.cols_pad)
-                    Elem<T>::st(dst + (size_t)r * ld + c, (r < d.rows && c < d.cols) ? flat[d.src_off + (int64_t)r * d.cols + c] : 0.f);
+                    Elem<T>::st(dst + pack_dst_index(layout, r, c, d.rows_pad, d.cols_pad, ld), (r < d.rows && c < d.cols) ? flat[d.src_off + (int64_t)r * d.cols + c] : 0.f);
             }
         }
     }

@@ -101,7 +101,7 @@ void adapter_residual_ln_fwd(const Tensor& A, const Tensor& R1, const optional<T
                               bd.data_ptr<float>(), Wu.data_ptr(), bu.data_ptr<float>(), gamma.data_ptr<float>(), beta.data_ptr<float>(), (float)eps,
                               (int)act, zp.data_ptr(), z.data_ptr(), mptr(v), ld_of(v), y.data_ptr(), (int)y.stride(0), stats.data_ptr<float>(),
                               (int)M, (int)H, (int)d, A4R_BF16, nullptr, 0, nullptr, static_cast<const float*>(cptr(res32)), ld_of(res32),
-                              static_cast<float*>(mptr(y32)), ld_of(y32)),
+                              static_cast<float*>(mptr(y32)), ld_of(y32), /* w_frag: row-major weights through this layer */ 0),
            "a4r_adapter_ln_fwd");
 }
 

@@ -78,12 +78,22 @@ class _Adapter:
         self.g_bu = eng.grad_view(b_up)
         self.g_bd = eng.grad_view(b_down)
         self.g_wd = self.g_wu = None
+        # the same four matrices in the FRAGMENT order of the one-launch adapter kernels (a4r_pack_matrices layouts 1 / 2, include/a4r.h: every wave
+        # instruction of those kernels' prologues then reads 1 KiB contiguous; the first tile of a launch starts ~3 us earlier).  Row-major copies stay:
+        # the three-launch forms, the weight-gradient kernels' shapes and the tests read them.  (fwd: wd, wu; bwd: wuT, wdT)
+        self.frag_f = self.frag_b = None
+        if dt == torch.bfloat16 and self.dp == 64 and width in (128, 256, 512, 768, 1024) and _os.environ.get('A4R_ADAPTER_FRAG', '1') != '0':
+            mk = lambda: torch.zeros(64 * width, dtype=dt, device=dev)
+            self.frag_f, self.frag_b = (mk(), mk()), (mk(), mk())
         if self.virtual is None:
             self.g_wd, self.g_wu = eng.grad_view(self.p_wd), eng.grad_view(self.p_wu)
             eng.add_pack(self.p_wd, self.wd, False)
             eng.add_pack(self.p_wd, self.wdT, True)
             eng.add_pack(self.p_wu, self.wu, False)
             eng.add_pack(self.p_wu, self.wuT, True)
+            if self.frag_f is not None:
+                for p_, dst, code in self.frag_entries():
+                    eng.add_pack(p_, dst, code)
         else:
             eng.add_virtual(self)
         eng.add_pack_bias(b_down, self.bd)
@@ -97,6 +107,15 @@ class _Adapter:
             eng.add_corner(self.s_wd, self.p_wd, self.d, width)
         if self.s_bd is not None:
             eng.add_corner(self.s_bd.view(1, -1), b_down, 1, self.d)
+
+    def frag_entries(self, wd_src=None, wu_src=None):
+        """(source, destination, a4r_pack_desc_t.transpose code) of the four fragment-ordered copies: bit 0 transpose, bits 1-2 layout (1: [64, H], 2: [H, 64]);
+        destinations are viewed with their LOGICAL shape so that the descriptor carries rows_pad / cols_pad"""
+        wd_src = self.p_wd if wd_src is None else wd_src
+        wu_src = self.p_wu if wu_src is None else wu_src
+        W = self.width
+        return [(wd_src, self.frag_f[0].view(64, W), 2), (wu_src, self.frag_f[1].view(W, 64), 4),
+                (wu_src, self.frag_b[0].view(64, W), 2 | 1), (wd_src, self.frag_b[1].view(W, 64), 4 | 1)]
 
 
 class _Lora:
@@ -473,6 +492,9 @@ class TransRecEngine:
                 o += a.d * a.width
                 for shp, dst, tr in ((wu_shape, a.wu, False), (wu_shape, a.wuT, True)):
                     ents.append((shp, dst, tr)); offs.append(o)
+                if a.frag_f is not None:                   # fragment-ordered copies of the effective matrices
+                    for shp, dst, tr in a.frag_entries(wd_shape, wu_shape):
+                        ents.append((shp, dst, tr)); offs.append(o - a.d * a.width if shp is wd_shape else o)
                 o += a.d * a.width
             for c in (L.BF16, L.F32):
                 idx = [i for i, (_, d, _) in enumerate(ents) if code(d) == c]
@@ -976,13 +998,13 @@ class TransRecEngine:
                 L.gemm_nt(dense_in, w, hd, bias=bias, drop_p=p_drop, drop_site=site, drop_seed=seed, M=M, **sk)
                 L.ln_fwd_sum(hd, resid, ln.gamma, ln.beta, ln.eps, t, sta, M=M, res32=self._twin_of(resid, M), sum_out=va, sum32=va32)   # va = h + input
                 y32 = self._buf('res32.' + which, M, blk.H, torch.float32)
-                L.adapter_ln_fwd(t, va, None, ad.wd, ad.bd, ad.wu, ad.bu, lnn.gamma, lnn.beta, lnn.eps, ad.act, zp, z, v, out, st, M=M, res32=va32, y32=y32)
+                L.adapter_ln_fwd(t, va, None, ad.wd, ad.bd, ad.wu, ad.bu, lnn.gamma, lnn.beta, lnn.eps, ad.act, zp, z, v, out, st, M=M, res32=va32, y32=y32, frag=ad.frag_f)
                 self._twin[out.data_ptr()] = y32
                 return
             L.gemm_nt(dense_in, w, va, bias=bias, R1=resid, drop_p=p_drop, drop_site=site, drop_seed=seed, drop_first=True, M=M, **sk)   # h + input
             L.ln_fwd(va, ln.gamma, ln.beta, ln.eps, t, sta, M=M)
             if self._fuse(blk, ad, t):
-                L.adapter_ln_fwd(t, va, None, ad.wd, ad.bd, ad.wu, ad.bu, lnn.gamma, lnn.beta, lnn.eps, ad.act, zp, z, v, out, st, M=M)
+                L.adapter_ln_fwd(t, va, None, ad.wd, ad.bd, ad.wu, ad.bu, lnn.gamma, lnn.beta, lnn.eps, ad.act, zp, z, v, out, st, M=M, frag=ad.frag_f)
                 return
             L.gemm_nt(t, ad.wd, z, bias=ad.bd, C2=zp, act=ad.act, M=M)
             L.gemm_nt(z, ad.wu, v, bias=ad.bu, R1=va, M=M)                   # adapter(t) + h + input
@@ -1005,7 +1027,7 @@ class TransRecEngine:
                 r32 = self._twin_of(resid, M)
                 y32 = self._buf('res32.' + which, M, blk.H, torch.float32)
             L.adapter_ln_fwd(h, resid if comp else h, None if comp else resid, ad.wd, ad.bd, ad.wu, ad.bu, ln.gamma, ln.beta, ln.eps, ad.act,
-                             zp, z, v, out, st, M=M, y8=y8, ys=ys, **(dict(res32=r32, y32=y32) if y32 is not None else {}))
+                             zp, z, v, out, st, M=M, y8=y8, ys=ys, **(dict(res32=r32, y32=y32) if y32 is not None else {}), frag=ad.frag_f)
             if y32 is not None:
                 self._twin[out.data_ptr()] = y32
             return
@@ -1163,7 +1185,7 @@ class TransRecEngine:
             if self._fuse_bwd(blk, ad, dy):
                 b2 = self._tn2_bias_ok(ad, dv, M)
                 L.adapter_ln_bwd(dy, v, st, lnn.gamma, None, zp, ad.act, ad.wuT, ad.wdT, False, dv, dzp, dt,
-                                 dgamma=gg(lnn.g_gamma), dbeta=gg(lnn.g_beta), dbias=None if b2 else gg(ad.g_bu), M=M, dbd=None if b2 else self._bd_target(ad))
+                                 dgamma=gg(lnn.g_gamma), dbeta=gg(lnn.g_beta), dbias=None if b2 else gg(ad.g_bu), M=M, dbd=None if b2 else self._bd_target(ad), frag=ad.frag_b)
                 fused_bd = self._bd_target(ad) is not None
             else:
                 L.ln_bwd(dy, v, st, lnn.gamma, dv, M=M, dgamma=gg(lnn.g_gamma), dbeta=gg(lnn.g_beta), dbias=gg(ad.g_bu))
@@ -1183,7 +1205,7 @@ class TransRecEngine:
             b2 = self._tn2_bias_ok(ad, dv, M)
             L.adapter_ln_bwd(dy, v, st, ln.gamma, None, zp, ad.act, ad.wuT, ad.wdT, ad.kind != 'compacter', dv, dzp, dh,
                              dgamma=gg(ln.g_gamma), dbeta=gg(ln.g_beta), dbias=None if b2 else gg(ad.g_bu), M=M,
-                             drop_p=p_drop, drop_site=site, drop_seed=seed, dbd=None if b2 else self._bd_target(ad), beta_y=beta_y)
+                             drop_p=p_drop, drop_site=site, drop_seed=seed, dbd=None if b2 else self._bd_target(ad), beta_y=beta_y, frag=ad.frag_b)
             self._adapter_wgrads(ad, dv, z, dzp, h, M, bd_done=self._bd_target(ad) is not None, bias_in_tn2=b2)
             return dh, dv
         assert beta_y is None, 'a sub-layer that keeps y instead of v runs the fused backward only'

@@ -252,7 +252,7 @@ class ViTRecEngine(TransRecEngine):
                 n2q, n2s = self._buf('n2q', M, H, torch.uint8), self._buf('n2s', M, 1, torch.float32)
             L.adapter_ln_fwd(h, x if comp else h, None if comp else x, ad.wd, ad.bd, ad.wu, ad.bu, blk.lnB.gamma, blk.lnB.beta, blk.lnB.eps,
                              ad.act, bufs['zp1'], bufs['z1'], bufs['x1'], n2 if (not fp8_fc1 or 'n2_s' in bufs) else None, bufs['stb'], M=M,
-                             y8=n2q, ys=n2s)
+                             y8=n2q, ys=n2s, frag=ad.frag_f)
             n2_done = True
         else:
             self._vit_sub_forward(blk.ad1, ctx, blk.wo, blk.bo, x, bufs, '1', M, bufs['x1'])
@@ -290,7 +290,7 @@ class ViTRecEngine(TransRecEngine):
                 n1q, n1s = self._buf('n1q', M, H, torch.uint8), self._buf('n1s', M, 1, torch.float32)
             L.adapter_ln_fwd(h, bufs['x1'] if comp else h, None if comp else bufs['x1'], ad.wd, ad.bd, ad.wu, ad.bu,
                              nb_.lnA.gamma, nb_.lnA.beta, nb_.lnA.eps, ad.act, bufs['zp2'], bufs['z2'], x_out,
-                             n1n if (n1q is None or 'n1' in nbufs) else None, nbufs['sta'], M=M, y8=n1q, ys=n1s)
+                             n1n if (n1q is None or 'n1' in nbufs) else None, nbufs['sta'], M=M, y8=n1q, ys=n1s, frag=ad.frag_f)
             return True
         self._vit_sub_forward(blk.ad2, u, w2, blk.bo2, bufs['x1'], bufs, '2', M, x_out, scales=w2s)
         return False
@@ -359,7 +359,7 @@ class ViTRecEngine(TransRecEngine):
             b2 = self._tn2_bias_ok(ad, dx1, M)          # (bias_total: db_up = colsum of the TOTAL dx1 this launch writes = the weight-gradient launch's X operand)
             L.adapter_ln_bwd(dn2, bufs['x1'], bufs['stb'], blk.lnB.gamma, dres2, bufs['zp1'], ad.act, ad.wuT, ad.wdT, ad.kind != 'compacter',
                              dx1, dzp, da, dgamma=gg(blk.lnB.g_gamma), dbeta=gg(blk.lnB.g_beta), dbias=None if b2 else gg(ad.g_bu), M=M,
-                             dbd=None if b2 else bd, bias_total=True)
+                             dbd=None if b2 else bd, bias_total=True, frag=ad.frag_b)
             self._adapter_wgrads(ad, dx1, bufs['z1'], dzp, bufs['h1'], M, bd_done=bd is not None, bias_in_tn2=b2)
         else:
             L.ln_bwd(dn2, bufs['x1'], bufs['stb'], blk.lnB.gamma, dx1, M=M, dgamma=gg(blk.lnB.g_gamma), dbeta=gg(blk.lnB.g_beta), dres=dres2)
@@ -405,7 +405,7 @@ class ViTRecEngine(TransRecEngine):
                 b2 = self._tn2_bias_ok(ad, dx_in, M)
                 L.adapter_ln_bwd(dn1, bufs['x0'], bufs['sta'], blk.lnA.gamma, dx1, pbufs['zp2'], ad.act, ad.wuT, ad.wdT, ad.kind != 'compacter',
                                  dx_in, dzp, d_o_prev, dgamma=gg(blk.lnA.g_gamma), dbeta=gg(blk.lnA.g_beta), dbias=None if b2 else gg(ad.g_bu), M=M,
-                                 dbd=None if b2 else bd, bias_total=True)
+                                 dbd=None if b2 else bd, bias_total=True, frag=ad.frag_b)
                 self._adapter_wgrads(ad, dx_in, pbufs['z2'], dzp, pbufs['h2'], M, bd_done=bd is not None, bias_in_tn2=b2)
                 return d_o_prev, dx_in
             L.ln_bwd(dn1, bufs['x0'], bufs['sta'], blk.lnA.gamma, dx_in, M=M, dgamma=gg(blk.lnA.g_gamma), dbeta=gg(blk.lnA.g_beta), dres=dx1)

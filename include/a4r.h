@@ -36,7 +36,7 @@ extern "C" {
 
 /* ABI version: bumped whenever a signature or struct below changes.  The Python binding (adapter4rec_amd/_lib.py) refuses a
  * library whose a4r_version() differs, so an A/B build made before a signature change cannot be called with shifted arguments. */
-#define A4R_ABI_VERSION 407
+#define A4R_ABI_VERSION 408
 int a4r_version(void);
 
 /* C[M,N] = epilogue(alpha * A[M,K] . B[N,K]^T): every nn.Linear on the path (HF BertSelfAttention
@@ -188,7 +188,8 @@ int a4r_adapter_ln_fwd(void* stream, const void* A, int lda, const void* R1, int
                        void* zp, void* z, void* v, int ldv, void* y, int ldy, float* stats, int M, int H, int d, int dtype,
                        void* y8, int ld8, float* ys,    /* y8 / ys (optional; y may then be NULL): y as OCP e4m3 + per-row scale, the
                                                            arithmetic of a4r_ln_fwd_fp8 (the fp8 A operand of the GEMM that follows) */
-                       const float* res32, int ldres32, float* y32, int ldy32);
+                       const float* res32, int ldres32, float* y32, int ldy32,
+                       int w_frag);   /* != 0: Wd, Wu are in FRAGMENT order (a4r_pack_matrices layouts 1 and 2 below), see the note under the backward */
 /* The LayerNorm of the forward runs on the fp32 sum v (its bf16 copy `v`, when asked for, is for the backward only).
  * res32 / y32 (both optional; --residual_dtype fp32): the residual stream between sub-layers kept in fp32, as under the reference's
  * autocast (LayerNorm outputs fp32 there and `hidden_states + input_tensor` promotes to it, HF BertSelfOutput / BertOutput under
@@ -200,6 +201,11 @@ int a4r_adapter_ln_bwd(void* stream, const void* dy, int lddy, const void* v, in
                        int M, int H, int d, int dtype, float drop_p, uint32_t drop_site, uint64_t drop_seed, float* dbd, int flags,
                        const float* beta_y);      /* beta_y != NULL: the forward was called with v = NULL and `v` here is its y = LN(v): xhat = (y - beta_y) / gamma
                                                    * (post-LN form with frozen LayerNorm, no dres; min |gamma| is the caller's responsibility) */
+/* Fragment-ordered weights (ABI 408; forward: w_frag, backward: flags bit 1): every CU of these persistent kernels reads both matrices into MFMA
+ * operand fragments before its first tile.  From row-major copies a wave instruction gathers 16 row pieces of 64 bytes, which the CU's address unit
+ * takes twice as long over as 1 KiB contiguous: with the copies that a4r_pack_matrices writes in fragment order (layout 1 for the [64, H] matrices
+ * Wd and WuT, layout 2 for the [H, 64] matrices Wu and WdT) the first tile starts ~3 us earlier (forward 46.8 -> 43.2 us at M = 40 448, 27.5 -> 24.3
+ * at M = 16 896).  Same values, same arithmetic order: results are bit-identical to the row-major form. */
 
 /* Short-sequence self-attention, one wave per (item, head), S <= 32, dh in {32, 64}.
  * BERT layer: HF BertSelfAttention (called from model/encoders.py:53); SASRec: SelfAttention
@@ -364,7 +370,10 @@ int a4r_adam_step(void* stream, float* p, const float* g, float* m, float* v, in
                   const float* group_lr, int step, float beta1, float beta2, float eps, float grad_scale);
 
 /* Refresh the kernel-side copies of trainable matrices after an optimiser step:
- * dst[rows_pad, cols_pad] (dtype) = src (fp32 [rows, cols] at flat + src_off) or its transpose, zero padded. */
+ * dst[rows_pad, cols_pad] (dtype) = src (fp32 [rows, cols] at flat + src_off) or its transpose, zero padded.
+ * `transpose`: bit 0 = transpose; bits 1-2 = destination layout (ABI 408): 0 row-major (stride dst_ld), 1 / 2 = the fragment order of the one-launch
+ * adapter kernels for a [64, H] / an [H, 64] destination (rows_pad resp. cols_pad must be 64, H in {128, 256, 512, 768, 1024}, dst_ld ignored:
+ * the destination is rows_pad x cols_pad contiguous elements; the index formulas are in a4r_head.hip: pack_dst_index). */
 typedef struct {
     int64_t src_off; void* dst; int32_t rows, cols, rows_pad, cols_pad, transpose, dst_ld;   /* dst_ld 0 = cols_pad */
 } a4r_pack_desc_t;

@@ -98,7 +98,7 @@ def adapter_ln_ok(A, d):
     return REAL.adapter_ln_ok(A, d)
 
 
-def adapter_ln_fwd(A, R1, R2, Wd, bd, Wu, bu, gamma, beta, eps, act, zp, z, v, y, stats, M=None, y8=None, ys=None, res32=None, y32=None):
+def adapter_ln_fwd(A, R1, R2, Wd, bd, Wu, bu, gamma, beta, eps, act, zp, z, v, y, stats, M=None, y8=None, ys=None, res32=None, y32=None, frag=None):
     """a4r_adapter_ln_fwd: zp = A Wd^T + bd; z = act(zp); v = z Wu^T + bu + R1 + R2; y = LN(v) (bf16 storage points as the kernel's).
     res32: the fp32 twin of the residual operand that is not A; y32: y before its bf16 rounding."""
     M = A.shape[0] if M is None else M
@@ -132,7 +132,7 @@ def adapter_ln_fwd(A, R1, R2, Wd, bd, Wu, bu, gamma, beta, eps, act, zp, z, v, y
 
 
 def adapter_ln_bwd(dy, v, stats, gamma, dres, zp, act, WuT, WdT, inner_res, dv, dzp, dh, dgamma=None, dbeta=None, dbias=None, M=None,
-                   drop_p=0.0, drop_site=0, drop_seed=0, dbd=None, bias_total=False, beta_y=None):
+                   drop_p=0.0, drop_site=0, drop_seed=0, dbd=None, bias_total=False, beta_y=None, frag=None):
     """a4r_adapter_ln_bwd = ln_bwd | (dv Wu) * act'(zp) | dzp Wd (+ dv), with the kernel's bf16 storage points.
     beta_y: `v` is y = LN(v) (the forward did not keep v): xhat = (y - beta_y) / gamma."""
     assert drop_p == 0.0
@@ -590,14 +590,38 @@ def pack_matrices(flat, desc_dev, n_desc, max_elems, dtype):
     tdt = torch.bfloat16 if dtype == BF16 else torch.float32
     for d in arr:
         src = flat[d.src_off:d.src_off + d.rows * d.cols].view(d.rows, d.cols)
-        if d.transpose:
+        if d.transpose & 1:
             src = src.t()
-        ld = d.dst_ld or d.cols_pad
+        layout = d.transpose >> 1
+        ld = d.cols_pad if layout else (d.dst_ld or d.cols_pad)
         n = (d.rows_pad - 1) * ld + d.cols_pad
         buf = (ctypes.c_char * (n * (2 if dtype == BF16 else 4))).from_address(d.dst)
         dst = torch.frombuffer(buf, dtype=tdt).as_strided((d.rows_pad, d.cols_pad), (ld, 1))
+        if layout:           # fragment order of the one-launch adapter kernels (csrc/a4r_head.hip: pack_dst_index)
+            full = torch.zeros(d.rows_pad, d.cols_pad, dtype=tdt)
+            full[:src.shape[0], :src.shape[1]] = src.to(tdt)
+            dst.view(-1)[frag_index(layout, d.rows_pad, d.cols_pad).view(-1)] = full.view(-1)
+            continue
         dst.zero_()
         dst[:src.shape[0], :src.shape[1]] = src.to(tdt)
+
+
+def frag_index(layout, rows_pad, cols_pad):
+    """destination index of element (r, c) for a4r_pack_desc_t layouts 1 ([64, H]) and 2 ([H, 64]) -- restated from include/a4r.h"""
+    H = cols_pad if layout == 1 else rows_pad
+    NW = 4 if H == 128 else 8
+    CW = H // NW
+    KS = CW // 32
+    r = torch.arange(rows_pad).view(-1, 1).expand(rows_pad, cols_pad)
+    c = torch.arange(cols_pad).view(1, -1).expand(rows_pad, cols_pad)
+    if layout == 1:
+        w, cc = c // CW, c % CW
+        s_, kg, j, nt, fr = cc // 32, (cc % 32) // 8, cc % 8, r // 16, r % 16
+        return ((((w * KS + s_) * 4 + nt) * 64 + kg * 16 + fr) * 8 + j)
+    w, rr = r // CW, r % CW
+    s_, q = rr // 32, rr % 32
+    fr, h, ks, kg, j = (q // 8) * 4 + (q % 4), (q // 4) % 2, c // 32, (c % 32) // 8, c % 8
+    return (((((w * KS + s_) * 2 + h) * 2 + ks) * 64 + kg * 16 + fr) * 8 + j)
 
 
 def eval_rank(prec, item_emb, target, hist_ptr, hist_idx, rank):

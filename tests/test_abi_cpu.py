@@ -53,3 +53,29 @@ def test_no_cpu_fallback():
     a = torch.zeros(128, 64)
     with pytest.raises(RuntimeError):
         _lib.gemm_nt(a, a, a)
+
+
+def test_pack_fragment_layouts_are_permutations_of_the_kernels_read_order():
+    """a4r_pack_desc_t layouts 1 / 2 (ABI 408), restated in tests/sim_lib.py: frag_index must be a permutation of the destination, and element
+    (wave w, step s, [row tile nt | half h, step ks], lane, j) must be the matrix element the one-launch adapter kernels load for that fragment
+    from a ROW-major copy (csrc/a4r_adapter_fused.hip: the two address forms of wd / wu)."""
+    import torch
+    import sim_lib
+    for H in (128, 256, 512, 768, 1024):
+        NW = 4 if H == 128 else 8
+        CW, KS = H // NW, H // NW // 32
+        i1, i2 = sim_lib.frag_index(1, 64, H), sim_lib.frag_index(2, H, 64)
+        assert sorted(i1.reshape(-1).tolist()) == list(range(64 * H)) and sorted(i2.reshape(-1).tolist()) == list(range(64 * H))
+        for w in (0, NW - 1):
+            for lane in (0, 17, 63):
+                fr, kg = lane & 15, lane >> 4
+                for s in range(KS):
+                    for nt in range(4):        # forward wd[s][nt] / backward wu[s][nt]: row nt*16 + fr, columns w*CW + s*32 + kg*8 + j
+                        for j in (0, 7):
+                            assert int(i1[nt * 16 + fr, w * CW + s * 32 + kg * 8 + j]) == ((((w * KS + s) * 4 + nt) * 64 + lane) * 8 + j)
+                    for h in range(2):
+                        for ks in range(2):    # forward wu[2s+h][ks] / backward image: row w*CW + s*32 + (fr>>2)*8 + h*4 + (fr&3), columns ks*32 + kg*8 + j
+                            for j in (0, 7):
+                                r = w * CW + s * 32 + (fr >> 2) * 8 + h * 4 + (fr & 3)
+                                assert int(i2[r, ks * 32 + kg * 8 + j]) == (((((w * KS + s) * 2 + h) * 2 + ks) * 64 + lane) * 8 + j)
+

@@ -1921,3 +1921,53 @@ def test_ln_fwd_sum(t, twin):
     y2, st2 = torch.zeros(M, H, dtype=t, device=dev()), torch.zeros(M, 2, device=dev())
     L.ln_fwd_sum(h, r, gamma, beta, 1e-12, y2, st2, res32=r32 if twin else None)          # the optional outputs do not change y
     assert torch.equal(y, y2) and torch.equal(st, st2)
+
+
+@pytest.mark.parametrize('H', [128, 256, 512, 768])
+def test_adapter_ln_fragment_ordered_weights_bit_equal(H):
+    """ABI 408: the one-launch adapter kernels read their two weight matrices in FRAGMENT order (a4r_pack_matrices layouts 1 / 2: 1 KiB contiguous
+    per wave instruction in the prologue).  Same values, same arithmetic: every output bit-equal to the row-major launch; the copies come from
+    a4r_pack_matrices itself (fp32 masters -> bf16, with and without the transpose), so the pack kernel's index formulas are under test too."""
+    import ctypes as C
+    from adapter4rec_amd import _lib as L
+    M, dp, d, t = 16 * 37, 64, 48, torch.bfloat16                      # bottleneck 48, padded to 64 by the pack
+    A, R, _, _, bd, bu, gamma, beta = _adapter_case(H, M, seed=300 + H)
+    g = torch.Generator(device='cpu').manual_seed(H)
+    wd32 = (torch.randn(d, H, generator=g) * 0.05).to(dev())           # fc_down.weight [d, H], fc_up.weight [H, d]: the fp32 masters
+    wu32 = (torch.randn(H, d, generator=g) * 0.05).to(dev())
+    flat = torch.cat([wd32.reshape(-1), wu32.reshape(-1)])
+    o_wd, o_wu = 0, d * H
+    mkw = lambda r, c: torch.zeros(r, c, dtype=t, device=dev())
+    Wd, Wu, WuT, WdT = mkw(dp, H), mkw(H, dp), mkw(dp, H), mkw(H, dp)
+    f_wd, f_wu, f_wuT, f_wdT = mkw(dp, H), mkw(H, dp), mkw(dp, H), mkw(H, dp)       # fragment-ordered twins (viewed with their logical shape)
+    ents = [(o_wd, Wd, d, H, 0), (o_wu, Wu, H, d, 0), (o_wu, WuT, H, d, 1), (o_wd, WdT, d, H, 1),
+            (o_wd, f_wd, d, H, 2), (o_wu, f_wu, H, d, 4), (o_wu, f_wuT, H, d, 2 | 1), (o_wd, f_wdT, d, H, 4 | 1)]
+    arr = (L.PackDesc * len(ents))()
+    for i, (off, dst, rows, cols, code) in enumerate(ents):
+        arr[i] = L.PackDesc(off, dst.data_ptr(), rows, cols, dst.shape[0], dst.shape[1], code, 0)
+    tab = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(dev())
+    L.pack_matrices(flat, tab, len(ents), dp * H, L.BF16)
+    torch.cuda.synchronize()
+    assert torch.equal(Wd[:d].float(), wd32.to(t).float()) and torch.equal(WuT[:d].float(), wu32.t().to(t).float())
+    assert sorted(f_wd.view(-1).tolist()) == sorted(Wd.view(-1).tolist())            # a permutation of the same values
+    mk = lambda c: torch.zeros(M, c, dtype=t, device=dev())
+    bdp = torch.zeros(dp, device=dev()); bdp[:d] = bd[:d]
+    outs = []
+    for frag in (None, (f_wd, f_wu)):
+        zp, z, v, y, st = mk(dp), mk(dp), mk(H), mk(H), torch.zeros(M, 2, device=dev())
+        L.adapter_ln_fwd(A, A, R, Wd, bdp, Wu, bu, gamma, beta, 1e-12, 1, zp, z, v, y, st, frag=frag)
+        outs.append((zp, z, v, y, st))
+    for a, b, nm in zip(outs[0], outs[1], ('zp', 'z', 'v', 'y', 'stats')):
+        assert torch.equal(a, b), f'forward {nm}: fragment-ordered launch differs'
+    assert float(outs[0][1].abs().max()) > 0
+    zp, _, v, _, st = outs[0]
+    dy = rnd(M, H, dtype=t, seed=41)
+    outs = []
+    for frag in (None, (f_wuT, f_wdT)):
+        dv, dzp, dh, dbi, dbd = mk(H), mk(dp), mk(H), torch.zeros(H, device=dev()), torch.zeros(dp, device=dev())
+        L.adapter_ln_bwd(dy, v, st, gamma, None, zp, 1, WuT, WdT, True, dv, dzp, dh, dbias=dbi, drop_p=0.1, drop_site=5, drop_seed=77, dbd=dbd, frag=frag)
+        outs.append((dv, dzp, dh))
+    for a, b, nm in zip(outs[0], outs[1], ('dv', 'dzp', 'dh')):
+        assert torch.equal(a, b), f'backward {nm}: fragment-ordered launch differs'
+    assert float(outs[0][2].abs().max()) > 0
+

@@ -20,7 +20,7 @@ us = AB.timeit(AB.bwd_fused_y if BWD else AB.fwd_fused_y)
 torch.cuda.synchronize()
 buf = (C.c_ulonglong * (256 * 2 * 8))()
 assert L.lib().a4r_debug_adapter_stamps(buf) == 0
-st = np.frombuffer(buf, dtype=np.uint64).reshape(256, 16).astype(np.int64)[:, :7] / 100.0
+st = np.frombuffer(buf, dtype=np.uint64).reshape(256, 16).astype(np.int64) / 100.0
 t0 = st[:, 0].min()
 q = lambda a: f'median {np.median(a):6.2f}  min {a.min():6.2f}  max {a.max():6.2f}'
 print(f'launch period (events, back to back) {us:.1f} us;  first entry -> last exit {st[:, 2].max() - t0:.2f} us')
@@ -32,6 +32,9 @@ if BWD:
     print('-> last tile done                    ', q(st[:, 2] - st[:, 4]))
     print('exit before the last workgroup       ', q(st[:, 2].max() - st[:, 2]))
     sys.exit(0)
+print('last wave: entry after wave 0         ', q(st[:, 8] - st[:, 0]))
+print('last wave: entry -> requests issued   ', q(st[:, 13] - st[:, 8]))
+print('last wave: -> its parameters arrived  ', q(st[:, 14] - st[:, 13]))
 print('entry -> every prologue request issued', q(st[:, 5] - st[:, 0]))
 print('-> first loads (parameters) arrived   ', q(st[:, 6] - st[:, 5]))
 print('prologue (entry -> parameters in LDS)', q(st[:, 1] - st[:, 0]))
