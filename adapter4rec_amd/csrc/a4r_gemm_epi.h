@@ -96,8 +96,9 @@ template <typename T, int NC> A4R_DEV void store_n(T* p, const float* o) {
         const uint4 w = Elem<T>::pack(o);
         typedef unsigned int v4u __attribute__((ext_vector_type(4)));
         v4u x = {w.x, w.y, w.z, w.w};
-        if constexpr ((A4R_ABL & 4096) != 0) asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(p), "v"(x) : "memory");
-        else asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(x) : "memory");
+        // (s_nop: a VMEM store of more than 64 bits followed by a vector write of its data registers needs a wait state; hipcc cannot see into the asm)
+        if constexpr ((A4R_ABL & 4096) != 0) asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1\n\ts_nop 1" ::"v"(p), "v"(x) : "memory");
+        else asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(x) : "memory");
         return;
     }
     if constexpr (NC == 8) store_vec<T, 8>(p, o);
