@@ -479,3 +479,50 @@ def test_training_trajectory_bf16_vs_fp32_oracle_hr_ndcg():
     print(f'relative loss difference: max {rel.max():.2e}, first 10 steps {rel[:10].mean():.2e}, last 10 steps {rel[-10:].mean():.2e}')
     assert rel.max() < 1e-2, rel.max()                                      # per-step bf16 forward error (|score| up to ~40 here: loss 24 -> 14) ...
     assert rel[-10:].mean() < 2.0 * rel[:10].mean() + 1e-3                  # ... and no growth over the run: the trajectories do not drift apart
+
+
+# the other BERT sizes Downstream/Text/run.py:100-114 accepts next to `base` (google/bert_uncased_L-x_H-y_A-z): width, layers, heads, FFN
+OTHER_SIZES = {'tiny': (128, 2, 2, 512), 'mini': (256, 4, 4, 1024), 'medium': (512, 8, 8, 2048), 'large': (1024, 24, 16, 4096)}
+
+
+@pytest.mark.parametrize('size', list(OTHER_SIZES))
+def test_other_bert_sizes_step_fp32_vs_oracle(size):
+    """run.py:100-114 sets word_embedding_dim 128 / 256 / 512 / 1024 for bert_*_tiny / mini / medium / large: one training step of BERT + Houlsby at
+    those geometries (head width 64 everywhere; tiny: N = 128 launches below the 256-tile kernel; large: the fused adapter backward is not
+    instantiated at H = 1024 -> the three-launch form), fp32 instantiation vs the CPU oracle at 1e-4 (GELU adapters: smooth), and the bf16
+    instantiation runs inside the bf16 bounds of the base geometry."""
+    import argparse
+    from adapter4rec_amd.inject import freeze_all, inject_adapters
+    from adapter4rec_amd.model import BERT_BASE, BertBackbone, Model
+    from base_cases import build_text_case, text_args
+    from oracle import ref_cpu as R
+    H, layers, heads, F = OTHER_SIZES[size]
+    torch.manual_seed(11)
+    args = text_args('fp32', 'GELU')
+    args.word_embedding_dim, args.bert_model_load = H, f'bert_{size}_uncased'
+    model = Model(args, 512, True, BertBackbone(dict(BERT_BASE, hidden_size=H, num_hidden_layers=layers, num_attention_heads=heads, intermediate_size=F)))
+    freeze_all(model)
+    model = inject_adapters(model, model.args)
+    with torch.no_grad():
+        for n, p in model.named_parameters():
+            if p.requires_grad:
+                p.add_(0.02 * torch.randn_like(p))
+    model.eval()
+    _, items, mask = build_text_case(users=1, n_items=512)              # the batch builder of the base cases (its model is dropped)
+    sd = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    names = [n for n, p in model.named_parameters() if p.requires_grad]
+    out, grads = R.loss_and_grads(sd, names, items, mask, dict(R.DEFAULT_CFG, adapter_activation='GELU', bert_heads=heads))
+    valid = mask.bool()
+    ref = dict(loss=float(out['loss'].detach()), pos=out['pos_score'].detach()[valid], emb=out['input_embs_all'].detach(), grads=grads)
+    o = hip_step(model, 'fp32', items, mask)
+    e_g, where = grad_err(o['grads'], ref['grads'])
+    print(f'bert_{size} ({layers} x {H}) fp32: loss {abs(o["loss"] - ref["loss"]):.1e}, embeddings {float((o["emb"] - ref["emb"]).abs().max()):.1e}, '
+          f'worst gradient {e_g:.1e} ({where})')
+    assert abs(o['loss'] - ref['loss']) < 1e-4 and float((o['emb'] - ref['emb']).abs().max()) < 1e-4
+    assert float((o['pos'][valid] - ref['pos']).abs().max()) < 1e-4
+    assert e_g < 2e-4, (e_g, where)
+    b = hip_step(model, 'bf16', items, mask)
+    e_b, where_b = grad_err(b['grads'], ref['grads'])
+    print(f'bert_{size} bf16: loss {abs(b["loss"] - ref["loss"]):.1e}, worst gradient {e_b:.2f} ({where_b})')
+    assert abs(b['loss'] - ref['loss']) < 5e-2 and e_b < 0.25
+
