@@ -330,20 +330,21 @@ def attn_bwd(qkv, dout, dqkv, key_mask, n_items, S, n_heads, dh, q_off, k_off, v
     _check(lib().a4r_attn_bwd(_stream(), C.byref(a)), 'a4r_attn_bwd')
 
 
-def attn_long_fwd(qkv, out, lse, n_items, S, n_heads, dh, q_off, k_off, v_off, scale, drop_p=0.0, drop_site=0, drop_seed=0):
-    require_gpu(qkv, out, lse)
+def attn_long_fwd(qkv, out, lse, n_items, S, n_heads, dh, q_off, k_off, v_off, scale, drop_p=0.0, drop_site=0, drop_seed=0, key_mask=None):
+    """key_mask (fp32 [n_items, S], 1 = attend; optional, head width 64): HF's attention_mask -- text towers with more than 32 tokens per title"""
+    require_gpu(qkv, out, lse, key_mask)
     assert lse.dtype == torch.float32 and lse.numel() >= n_items * n_heads * S
-    a = _attn_args(qkv, q_off, k_off, v_off, None, n_items, S, n_heads, dh, False, scale, 0.0, drop_p, drop_site, drop_seed)
+    a = _attn_args(qkv, q_off, k_off, v_off, key_mask, n_items, S, n_heads, dh, False, scale, 0.0, drop_p, drop_site, drop_seed)
     a.out, a.ldo = _p(out), _ld(out)
     _check(lib().a4r_attn_long_fwd(_stream(), C.byref(a), _p(lse)), 'a4r_attn_long_fwd')
 
 
 def attn_long_bwd(qkv, out, dout, dqkv, lse, delta_ws, n_items, S, n_heads, dh, q_off, k_off, v_off, scale,
-                  drop_p=0.0, drop_site=0, drop_seed=0):
+                  drop_p=0.0, drop_site=0, drop_seed=0, key_mask=None):
     """out: the ctx attn_long_fwd wrote (backward takes delta = dO . O from it)."""
-    require_gpu(qkv, out, dout, dqkv, lse, delta_ws)
+    require_gpu(qkv, out, dout, dqkv, lse, delta_ws, key_mask)
     assert _ld(dqkv) == _ld(qkv) and delta_ws.dtype == torch.float32 and delta_ws.numel() >= n_items * n_heads * S
-    a = _attn_args(qkv, q_off, k_off, v_off, None, n_items, S, n_heads, dh, False, scale, 0.0, drop_p, drop_site, drop_seed)
+    a = _attn_args(qkv, q_off, k_off, v_off, key_mask, n_items, S, n_heads, dh, False, scale, 0.0, drop_p, drop_site, drop_seed)
     assert _ld(out) == _ld(dout)
     a.out, a.dout, a.ldo, a.dqkv = _p(out), _p(dout), _ld(dout), _p(dqkv)
     _check(lib().a4r_attn_long_bwd(_stream(), C.byref(a), _p(lse), _p(delta_ws)), 'a4r_attn_long_bwd')

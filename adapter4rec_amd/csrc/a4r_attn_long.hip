@@ -80,9 +80,11 @@ template <typename T, int DH> struct Geo {
 // LDS layout of a workgroup: the staged matrices (lds_main_*), then one output staging block per wave (bf16 only)
 template <typename T, int DH> struct STG { static constexpr int BYTES = sizeof(T) == 2 ? 16 * DH * 2 : 0; };
 template <typename T, int DH, int NKT> constexpr size_t img_t() { return 0; }   // (round 3: no transposed copy for fp32 either -- with it the fp32 backward needed 174 / 235 KB of LDS at S = 197 and could not run ViT-B/16)
-template <typename T, int DH, int NKT> constexpr size_t lds_main_fwd() { return 2 * (size_t)NKT * 16 * Geo<T, DH>::ROWB; }
-template <typename T, int DH, int NKT> constexpr size_t lds_main_dq() { return 2 * (size_t)NKT * 16 * Geo<T, DH>::ROWB + img_t<T, DH, NKT>(); }
-template <typename T, int DH, int NKT> constexpr size_t lds_main_dkdv() { return 2 * (size_t)NKT * 16 * Geo<T, DH>::ROWB + 2 * img_t<T, DH, NKT>() + 2 * NKT * 16 * sizeof(float); }
+// (+ NKT * 16 floats at the end of every main area: the item's key mask, staged per workgroup -- text towers with --num_words_title > 32, round 5)
+template <int NKT> constexpr size_t lds_km() { return (size_t)NKT * 16 * sizeof(float); }
+template <typename T, int DH, int NKT> constexpr size_t lds_main_fwd() { return 2 * (size_t)NKT * 16 * Geo<T, DH>::ROWB + lds_km<NKT>(); }
+template <typename T, int DH, int NKT> constexpr size_t lds_main_dq() { return 2 * (size_t)NKT * 16 * Geo<T, DH>::ROWB + img_t<T, DH, NKT>() + lds_km<NKT>(); }
+template <typename T, int DH, int NKT> constexpr size_t lds_main_dkdv() { return 2 * (size_t)NKT * 16 * Geo<T, DH>::ROWB + 2 * img_t<T, DH, NKT>() + 2 * NKT * 16 * sizeof(float) + lds_km<NKT>(); }
 
 // [S][DH] (global, row stride ld) -> LDS row-major [SP][DH], 16-byte chunks XOR-swizzled; rows >= S are zero.  Two phases, so that a workgroup has
 // the rows of BOTH its staged matrices in flight before the first LDS write (round 4: the one-call form compiled to a rolled loop of
@@ -265,13 +267,26 @@ A4R_DEV void scores_t(const char* Kr, const uint4 (&qf)[Geo<T, DH>::KS], f32x4_t
     mask_keys<NKT>(s, S, kg, -INFINITY);
 }
 
+// The item's key mask (HF attention_mask: 1 = attend; Downstream/Text/model/encoders.py:48-57), staged to LDS by the workgroup.  Masked keys get
+// probability 0 (HF adds finfo.min to their scores); an item with NO attended key -- the pad item -- attends uniformly over its S keys, as HF's
+// softmax over S equal scores does: its raw scores are replaced by 0 in the forward and in both backward kernels, so lse = log S recomputes P = 1 / S.
+// Returns whether the item has no attended key (wave-uniform; call before the workgroup's first __syncthreads, read km after it).
+template <int SP, int NTHR> A4R_DEV void stage_key_mask(float* km, const float* kmask, int item, int S, int tid) {
+    for (int i = tid; i < SP; i += NTHR) km[i] = i < S ? kmask[(size_t)item * S + i] : 0.f;
+}
+template <int SP> A4R_DEV bool none_attended(const float* km, int lane) {
+    float c = 0.f;
+    for (int i = lane; i < SP; i += 64) c += km[i] != 0.f ? 1.f : 0.f;
+    return __ballot(c > 0.f) == 0ull;
+}
+
 struct Drop { uint64_t seed; uint32_t site, thr16; float keep_scale; };
 
 // ------------------------------------------------------------------------------------------------ forward
-template <typename T, int DH, int NKT>
+template <typename T, int DH, int NKT, bool KM = false>      // KM: the launch carries a key mask (text towers; instantiated for head width 64)
 __global__ void __launch_bounds__(WG<NKT>::NTHR, 4) attn_long_fwd_kernel(const T* __restrict__ qkv, int ld, int q_off, int k_off, int v_off,
                                                             T* __restrict__ ctx, int ldo, float* __restrict__ lse,
-                                                            int S, int nh, float scale, Drop dr) {
+                                                            int S, int nh, float scale, Drop dr, const float* __restrict__ kmask) {
     using G = Geo<T, DH>;
     constexpr int NTHR = WG<NKT>::NTHR, NWAVE = WG<NKT>::NWAVE;
     constexpr int SP = NKT * 16, SPT = SP + 8, NST = SP / G::KSTEP;
@@ -299,7 +314,11 @@ __global__ void __launch_bounds__(WG<NKT>::NTHR, 4) attn_long_fwd_kernel(const T
         sk.commit(Kr, tid);
         sv.commit(Vimg, tid);
     }
+    [[maybe_unused]] float* km = reinterpret_cast<float*>(smem + lds_main_fwd<T, DH, NKT>() - lds_km<NKT>());
+    if constexpr (KM) stage_key_mask<SP, NTHR>(km, kmask, item, S, tid);
     __syncthreads();
+    bool none = false;
+    if constexpr (KM) none = none_attended<SP>(km, lane);
     for (int qb = wave; qb < nqb; qb += NWAVE) {
         const int rq = qb * 16 + fr;
         const bool valid = rq < S;
@@ -309,6 +328,14 @@ __global__ void __launch_bounds__(WG<NKT>::NTHR, 4) attn_long_fwd_kernel(const T
         if (qb + NWAVE < nqb) request_q(qb + NWAVE);
         f32x4_t s[NKT];
         scores_t<T, DH, NKT>(Kr, qf, s, S, fr, kg);
+        if constexpr (KM) {
+#pragma unroll
+            for (int kt = 0; kt < NKT; ++kt) {
+                const f32x4_t m4 = *reinterpret_cast<const f32x4_t*>(km + kt * 16 + kg * 4);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) s[kt][r] = none ? (kt * 16 + kg * 4 + r < S ? 0.f : -INFINITY) : (m4[r] != 0.f ? s[kt][r] : -INFINITY);
+            }
+        }
         float m = -INFINITY;
 #pragma unroll
         for (int kt = 0; kt < NKT; ++kt)
@@ -369,11 +396,11 @@ __global__ void __launch_bounds__(WG<NKT>::NTHR, 4) attn_long_fwd_kernel(const T
 }
 
 // ------------------------------------------------------------------------------------------------ backward: dq + delta
-template <typename T, int DH, int NKT>
+template <typename T, int DH, int NKT, bool KM = false>      // KM: the launch carries a key mask (text towers; instantiated for head width 64)
 __global__ void __launch_bounds__(WG<NKT>::NTHR, 4) attn_long_dq_kernel(const T* __restrict__ qkv, int ld, int q_off, int k_off, int v_off,
                                                            const T* __restrict__ dctx, int ldo, const T* __restrict__ octx,
                                                            const float* __restrict__ lse, float* __restrict__ delta,
-                                                           T* __restrict__ dqkv, int S, int nh, float scale, Drop dr) {
+                                                           T* __restrict__ dqkv, int S, int nh, float scale, Drop dr, const float* __restrict__ kmask) {
     using G = Geo<T, DH>;
     constexpr int NTHR = WG<NKT>::NTHR, NWAVE = WG<NKT>::NWAVE;
     constexpr int SP = NKT * 16, SPT = SP + 8, NST = SP / G::KSTEP;
@@ -412,7 +439,11 @@ __global__ void __launch_bounds__(WG<NKT>::NTHR, 4) attn_long_dq_kernel(const T*
         sk.commit(Kr, tid);
         sv.commit(Vr, tid);
     }
+    [[maybe_unused]] float* km = reinterpret_cast<float*>(smem + lds_main_dq<T, DH, NKT>() - lds_km<NKT>());
+    if constexpr (KM) stage_key_mask<SP, NTHR>(km, kmask, item, S, tid);
     __syncthreads();
+    bool none = false;
+    if constexpr (KM) none = none_attended<SP>(km, lane);
     const float c2 = scale * 1.44269504088896f;
     const f32x4_t c2v = {c2, c2, c2, c2};
     for (int qb = wave; qb < nqb; qb += NWAVE) {
@@ -478,9 +509,15 @@ __global__ void __launch_bounds__(WG<NKT>::NTHR, 4) attn_long_dq_kernel(const T*
 #pragma unroll
                     for (int j = 0; j < HALF; ++j) tf[0][j] = frag_T<T, DH>(Kimg, SPT, j * 16, st, lane);
                 }
+                if constexpr (KM) { if (none) sc = f32x4_t{0.f, 0.f, 0.f, 0.f}; }        // (an item without attended keys: the forward's convention)
                 f32x4_t pv = __builtin_elementwise_fma(sc, c2v, lqv);                   // P = exp(scale s - lse)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) pv[r] = __builtin_amdgcn_exp2f(pv[r]);
+                if constexpr (KM) if (!none) {
+                    const f32x4_t m4 = *reinterpret_cast<const f32x4_t*>(km + kt * 16 + kg * 4);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) pv[r] = m4[r] != 0.f ? pv[r] : 0.f;
+                }
                 if (kt >= kt_partial_lo<NKT>() && kt * 16 + 16 > S) {                    // wave-uniform: the last one or two tiles
                     asm volatile("" ::: "memory");
 #pragma unroll
@@ -516,11 +553,11 @@ __global__ void __launch_bounds__(WG<NKT>::NTHR, 4) attn_long_dq_kernel(const T*
 }
 
 // ------------------------------------------------------------------------------------------------ backward: dk, dv
-template <typename T, int DH, int NKT>
+template <typename T, int DH, int NKT, bool KM = false>      // KM: the launch carries a key mask (text towers; instantiated for head width 64)
 __global__ void __launch_bounds__(WG<NKT>::NTHR, 4) attn_long_dkdv_kernel(const T* __restrict__ qkv, int ld, int q_off, int k_off, int v_off,
                                                              const T* __restrict__ dctx, int ldo, const float* __restrict__ lse,
                                                              const float* __restrict__ delta, T* __restrict__ dqkv,
-                                                             int S, int nh, float scale, Drop dr) {
+                                                             int S, int nh, float scale, Drop dr, const float* __restrict__ kmask) {
     using G = Geo<T, DH>;
     constexpr int NTHR = WG<NKT>::NTHR, NWAVE = WG<NKT>::NWAVE;
     constexpr int SP = NKT * 16, SPT = SP + 8, NG = SP / G::KSTEP;          // NG query groups of KSTEP queries
@@ -563,7 +600,11 @@ __global__ void __launch_bounds__(WG<NKT>::NTHR, 4) attn_long_dkdv_kernel(const 
         so.commit(Or, tid);
         if (tid < SP) { lse_s[tid] = lv; del_s[tid] = dv0; }
     }
+    [[maybe_unused]] float* km = reinterpret_cast<float*>(smem + lds_main_dkdv<T, DH, NKT>() - lds_km<NKT>());
+    if constexpr (KM) stage_key_mask<SP, NTHR>(km, kmask, item, S, tid);
     __syncthreads();
+    bool none = false;
+    if constexpr (KM) none = none_attended<SP>(km, lane0);
     const float c2 = scale * 1.44269504088896f;
     const f32x4_t c2v = {c2, c2, c2, c2};
     for (int kt = wave; kt < nkt; kt += NWAVE) {
@@ -608,9 +649,11 @@ __global__ void __launch_bounds__(WG<NKT>::NTHR, 4) attn_long_dkdv_kernel(const 
 #pragma unroll
                     for (int j = 0; j < HALF; ++j) tf[0][j] = frag_T<T, DH>(Oimg, SPT, j * 16, g, lane);
                 }
+                if constexpr (KM) { if (none) sc = f32x4_t{0.f, 0.f, 0.f, 0.f}; }
                 f32x4_t pv = __builtin_elementwise_fma(sc, c2v, l4), dsv;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) pv[r] = __builtin_amdgcn_exp2f(pv[r]);
+                if constexpr (KM) { if (!none && km[kt * 16 + fr] == 0.f) pv = f32x4_t{0.f, 0.f, 0.f, 0.f}; }       // this lane's key is masked
                 if (dr.thr16) {                               // here the tile's 4 rows are 4 QUERIES at one key: one hash each
                     const int ol = opaque_lane(lane), ork = kt * 16 + (ol & 15), okg = ol >> 4;
 #pragma unroll
@@ -685,30 +728,45 @@ Drop drop_of(const a4r_attn_t* a) {
     return Drop{a->drop_seed, a->drop_site, a4r_thr16(a->drop_p), a4r_keep_scale(a->drop_p)};
 }
 
+template <typename T, int DH, int NKT, bool KM> int run_fwd_km(hipStream_t s, const a4r_attn_t* a, float* lse) {
+    const size_t lds = lds_fwd<T, DH, NKT>();
+    if (int rc = set_lds(attn_long_fwd_kernel<T, DH, NKT, KM>, lds)) return rc;
+    hipLaunchKernelGGL((attn_long_fwd_kernel<T, DH, NKT, KM>), dim3(a->n_items * a->n_heads), dim3(WG<NKT>::NTHR), lds, s, (const T*)a->qkv, a->ld, a->q_off,
+                       a->k_off, a->v_off, (T*)a->out, a->ldo, lse, a->S, a->n_heads, a->scale, drop_of(a), (const float*)a->key_mask);
+    return a4r_launch_status();
+}
 template <typename T, int DH, int NKT> int run_fwd(hipStream_t s, const a4r_attn_t* a, float* lse) {
     if (!s_fits<NKT>(a->S)) return A4R_EINVAL;
-    const size_t lds = lds_fwd<T, DH, NKT>();
-    if (int rc = set_lds(attn_long_fwd_kernel<T, DH, NKT>, lds)) return rc;
-    hipLaunchKernelGGL((attn_long_fwd_kernel<T, DH, NKT>), dim3(a->n_items * a->n_heads), dim3(WG<NKT>::NTHR), lds, s, (const T*)a->qkv, a->ld, a->q_off,
-                       a->k_off, a->v_off, (T*)a->out, a->ldo, lse, a->S, a->n_heads, a->scale, drop_of(a));
+    if (a->key_mask) {
+        if constexpr (DH == 64) return run_fwd_km<T, DH, NKT, true>(s, a, lse);
+        else return A4R_EINVAL;                               // (masked form: head width 64 only -- every BERT size of run.py:100-114)
+    }
+    return run_fwd_km<T, DH, NKT, false>(s, a, lse);
+}
+template <typename T, int DH, int NKT, bool KM> int run_bwd_km(hipStream_t s, const a4r_attn_t* a, const float* lse, float* delta) {
+    const size_t l1 = lds_dq<T, DH, NKT>(), l2 = lds_dkdv<T, DH, NKT>();
+    if (int rc = set_lds(attn_long_dq_kernel<T, DH, NKT, KM>, l1)) return rc;
+    if (int rc = set_lds(attn_long_dkdv_kernel<T, DH, NKT, KM>, l2)) return rc;
+    const dim3 grid(a->n_items * a->n_heads), block(WG<NKT>::NTHR);
+    hipLaunchKernelGGL((attn_long_dq_kernel<T, DH, NKT, KM>), grid, block, l1, s, (const T*)a->qkv, a->ld, a->q_off, a->k_off, a->v_off,
+                       (const T*)a->dout, a->ldo, (const T*)a->out, lse, delta, (T*)a->dqkv, a->S, a->n_heads, a->scale, drop_of(a), (const float*)a->key_mask);
+    hipLaunchKernelGGL((attn_long_dkdv_kernel<T, DH, NKT, KM>), grid, block, l2, s, (const T*)a->qkv, a->ld, a->q_off, a->k_off, a->v_off,
+                       (const T*)a->dout, a->ldo, lse, (const float*)delta, (T*)a->dqkv, a->S, a->n_heads, a->scale, drop_of(a), (const float*)a->key_mask);
     return a4r_launch_status();
 }
 template <typename T, int DH, int NKT> int run_bwd(hipStream_t s, const a4r_attn_t* a, const float* lse, float* delta) {
     if (!s_fits<NKT>(a->S)) return A4R_EINVAL;
-    const size_t l1 = lds_dq<T, DH, NKT>(), l2 = lds_dkdv<T, DH, NKT>();
-    if (int rc = set_lds(attn_long_dq_kernel<T, DH, NKT>, l1)) return rc;
-    if (int rc = set_lds(attn_long_dkdv_kernel<T, DH, NKT>, l2)) return rc;
-    const dim3 grid(a->n_items * a->n_heads), block(WG<NKT>::NTHR);
-    hipLaunchKernelGGL((attn_long_dq_kernel<T, DH, NKT>), grid, block, l1, s, (const T*)a->qkv, a->ld, a->q_off, a->k_off, a->v_off,
-                       (const T*)a->dout, a->ldo, (const T*)a->out, lse, delta, (T*)a->dqkv, a->S, a->n_heads, a->scale, drop_of(a));
-    hipLaunchKernelGGL((attn_long_dkdv_kernel<T, DH, NKT>), grid, block, l2, s, (const T*)a->qkv, a->ld, a->q_off, a->k_off, a->v_off,
-                       (const T*)a->dout, a->ldo, lse, (const float*)delta, (T*)a->dqkv, a->S, a->n_heads, a->scale, drop_of(a));
-    return a4r_launch_status();
+    if (a->key_mask) {
+        if constexpr (DH == 64) return run_bwd_km<T, DH, NKT, true>(s, a, lse, delta);
+        else return A4R_EINVAL;
+    }
+    return run_bwd_km<T, DH, NKT, false>(s, a, lse, delta);
 }
 
 int check(const a4r_attn_t* a, bool bwd) {
     if (!a || !a->qkv || a->n_items <= 0 || a->S <= 0 || a->S > 256 || (a->dh != 64 && a->dh != 32) || a->n_heads <= 0) return A4R_EINVAL;
-    if (a->key_mask || a->causal) return A4R_EINVAL;                               // neither the ViT / MAE tower nor its K-Adapter blocks mask
+    if (a->causal || a->offsets) return A4R_EINVAL;                                // no causal form, no packed items; key_mask (fp32 [n_items, S], optional): text towers with titles of more than 32 tokens
+    if (a->key_mask && (reinterpret_cast<uintptr_t>(a->key_mask) & 3u)) return A4R_EINVAL;
     if (a->drop_p < 0.f || a->drop_p >= 1.f) return A4R_EINVAL;
     if ((int64_t)a->n_items * a->n_heads >= (1ll << 40)) return A4R_EINVAL;        // dropout counter: 40 + 8 + 8 bits
     if (a->dtype != A4R_BF16 && a->dtype != A4R_F32) return A4R_EINVAL;

@@ -601,7 +601,8 @@ class TransRecEngine:
         g = self.geo
         H, nh = g['hidden_size'], g['num_attention_heads']
         self.H, self.F = H, g['intermediate_size']
-        if H % 64 or self.F % 64 or (H // nh) not in (32, 64) or self.S > 32:
+        # (--num_words_title > 32, round 5: the long attention kernels with the titles' key mask, head width 64 -- every BERT size of run.py:100-114)
+        if H % 64 or self.F % 64 or (H // nh) not in (32, 64) or self.S > 256 or (self.S > 32 and H // nh != 64):
             raise NotImplementedError(f'encoder geometry H={H} F={self.F} heads={nh} S={self.S}')
         emb = bert.embeddings
         tab = lambda p: p.data if p.requires_grad else self._f32(p)        # trainable tables are read from the flat fp32 master
@@ -645,6 +646,7 @@ class TransRecEngine:
             b.lora = _Lora.for_block((att.query, att.key, att.value), H, self, self.T)
             b.H, b.F, b.nh, b.dh, b.S = H, self.F, nh, H // nh, self.S
             b.is_item = True                       # (a block of the item tower: follows self._pk)
+            b.long = self.S > 32                   # titles of more than 32 tokens: a4r_attn_long_* with the key mask (any step length <= S)
             b.causal, b.mask_neg, b.scale = False, FMIN, 1.0 / math.sqrt(H // nh)
             b.ffn_act = L.ACT_GELU
             b.p_hidden, b.p_attn, b.site = self.p_hidden, self.p_attn, 16 * i
@@ -1092,10 +1094,9 @@ class TransRecEngine:
         if 'xin' in bufs and x.data_ptr() != bufs['xin'].data_ptr():
             L.gather_rows(x, bufs['xin'], M, 1)      # LoRA backward needs the block input (t = x A^T, dA = dt^T x)
         if getattr(blk, 'long', False):
-            assert key_mask is None
             ctx = bufs['ctx_o'] if 'ctx_o' in bufs else self._buf('ctx', M, H, T)
             L.attn_long_fwd(bufs['qkv'], ctx, bufs['lse'], n_items, blk.S, blk.nh, blk.dh, 0, H, 2 * H, blk.scale,
-                            drop_p=pa, drop_site=blk.site, drop_seed=seed)
+                            drop_p=pa, drop_site=blk.site, drop_seed=seed, key_mask=key_mask)
         else:
             # (trainable attention output: its weight gradient needs ctx per layer -- the attention kernel writes the kept buffer directly)
             ctx = bufs['ctx_s'] if ('ctx_s' in bufs and cls_rows is None) else self._buf('ctx', M, H, T)
@@ -1393,7 +1394,7 @@ class TransRecEngine:
         if getattr(blk, 'long', False):
             ws = self._buf('attn_ws', bufs['lse'].shape[0], 1, torch.float32)
             L.attn_long_bwd(bufs['qkv'], bufs['ctx_o'], dctx, dqkv, bufs['lse'], ws, n_items, blk.S, blk.nh, blk.dh, 0, H, 2 * H, blk.scale,
-                            drop_p=pa, drop_site=blk.site, drop_seed=seed)
+                            drop_p=pa, drop_site=blk.site, drop_seed=seed, key_mask=key_mask)
         else:
             L.attn_bwd(bufs['qkv'], dctx, dqkv, key_mask, n_items, blk.S, blk.nh, blk.dh, 0, H, 2 * H, blk.causal, blk.scale, blk.mask_neg,
                        drop_p=pa, drop_site=blk.site, drop_seed=seed, offsets=self._off(blk))
@@ -1761,6 +1762,7 @@ class TransRecEngine:
         self._pk = None
         if (hl is not None and hmt is not None and S_step <= self.S0 and type(self) is TransRecEngine and not self.bert_kads and not self.prompt_n
                 and not self.train_emb and not self.fp8 and self.bert_blocks and self.bert_blocks[0].dh in (32, 64) and len(hl) == n_full
+                and not getattr(self.bert_blocks[0], 'long', False)             # (the long attention kernels take no offsets)
                 and _os.environ.get('A4R_PACK_TITLES', '1') != '0' and _os.environ.get('A4R_SKIP_UNUSED_ITEMS', '1') != '0'):
             import numpy as np
             if kidx is not None:

@@ -231,8 +231,11 @@ typedef struct {
 int a4r_attn_fwd(void* stream, const a4r_attn_t* a);
 int a4r_attn_bwd(void* stream, const a4r_attn_t* a);
 
-/* The same attention for 32 < S <= 256 tokens per item and dh == 64 or 32, without mask / causal (key_mask NULL, causal 0,
- * else A4R_EINVAL): the ViT / ViT-MAE item tower (HF ViTSelfAttention under Downstream/CV/model/encoders.py:21-32;
+/* The same attention for 32 < S <= 256 tokens per item (any S <= 256 is accepted) and dh == 64 or 32, never causal, no packed items
+ * (causal 0, offsets NULL, else A4R_EINVAL).  key_mask (ABI 408, optional, dh == 64 only): HF's attention_mask, fp32 [n_items, S], 1 = attend --
+ * the text towers when --num_words_title exceeds 32 (Downstream/Text/parameters.py:44, model/encoders.py:48-57); masked keys get probability 0,
+ * an item without any attended key (the PAD item) attends uniformly over its S keys, as HF's softmax over S equal scores does.
+ * Without a mask: the ViT / ViT-MAE item tower (HF ViTSelfAttention under Downstream/CV/model/encoders.py:21-32;
  * S = 197 / 50, dh 64, drop_p 0) and the TransformerBlocks inside VITKAdaptedCVModel's KAdapterBlocks
  * (Downstream/CV/model/model.py:374-404, modules.py:24-36,148-187; width 384 = 12 heads of 32, all-ones mask, dropout
  * drop_p on the probabilities with the counter (item * heads + head, query, key)).  One workgroup per (item, head);

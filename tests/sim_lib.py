@@ -194,6 +194,9 @@ def colsum(X, out, M=None):
     out += X[:M].float().sum(0)
 
 
+FMIN = float(torch.finfo(torch.float32).min)
+
+
 def _attn(qkv, key_mask, n_items, S, nh, dh, offs, causal, scale, mask_neg):
     Hd = nh * dh
     q, k, v = [qkv[:n_items * S, o:o + Hd].view(n_items, S, nh, dh).transpose(1, 2) for o in offs]
@@ -250,20 +253,22 @@ def attn_bwd(qkv, dout, dqkv, key_mask, n_items, S, n_heads, dh, q_off, k_off, v
         dqkv[:n_items * S, off:off + n_heads * dh] = q.grad[:n_items * S, off:off + n_heads * dh].to(dqkv.dtype)
 
 
-def attn_long_fwd(qkv, out, lse, n_items, S, n_heads, dh, q_off, k_off, v_off, scale, drop_p=0.0, drop_site=0, drop_seed=0):
+def attn_long_fwd(qkv, out, lse, n_items, S, n_heads, dh, q_off, k_off, v_off, scale, drop_p=0.0, drop_site=0, drop_seed=0, key_mask=None):
     assert dh in (32, 64) and S <= 256 and drop_p == 0.0
     Hd = n_heads * dh
     x = qkv.float()
     q, k = [x[:n_items * S, o:o + Hd].view(n_items, S, n_heads, dh).transpose(1, 2) for o in (q_off, k_off)]
-    lse.view(-1)[:n_items * n_heads * S] = torch.logsumexp(q @ k.transpose(-1, -2) * scale, -1).reshape(-1)
-    km = torch.ones(n_items, S)
-    out[:n_items * S] = _attn(x, km, n_items, S, n_heads, dh, (q_off, k_off, v_off), False, scale, 0.0).to(out.dtype)
+    km = torch.ones(n_items, S) if key_mask is None else key_mask[:n_items].float()
+    sc = q @ k.transpose(-1, -2) * scale + (1.0 - km)[:, None, None, :] * FMIN
+    lse.view(-1)[:n_items * n_heads * S] = torch.logsumexp(sc, -1).reshape(-1)
+    out[:n_items * S] = _attn(x, km, n_items, S, n_heads, dh, (q_off, k_off, v_off), False, scale, FMIN).to(out.dtype)
 
 
 def attn_long_bwd(qkv, out, dout, dqkv, lse, delta_ws, n_items, S, n_heads, dh, q_off, k_off, v_off, scale,
-                  drop_p=0.0, drop_site=0, drop_seed=0):
+                  drop_p=0.0, drop_site=0, drop_seed=0, key_mask=None):
     assert drop_p == 0.0
-    attn_bwd(qkv, dout, dqkv, torch.ones(n_items, S), n_items, S, n_heads, dh, q_off, k_off, v_off, False, scale, 0.0)
+    km = torch.ones(n_items, S) if key_mask is None else key_mask[:n_items].float()
+    attn_bwd(qkv, dout, dqkv, km, n_items, S, n_heads, dh, q_off, k_off, v_off, False, scale, FMIN)
 
 
 def patchify(img, out, patch, keep_idx=None):

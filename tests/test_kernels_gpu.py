@@ -474,6 +474,49 @@ def test_attention_long_fwd_bwd(dt, S, nh, dh):
     assert torch.count_nonzero(dqkv[n_items * S:]) == 0
 
 
+@pytest.mark.parametrize('dt,S,nh', [('f32', 33, 2), ('f32', 50, 12), ('f32', 100, 3), ('f32', 197, 2), ('f32', 256, 2),
+                                     ('bf16', 40, 2), ('bf16', 50, 12), ('bf16', 64, 4), ('bf16', 128, 3), ('bf16', 197, 2), ('bf16', 256, 2)])
+def test_attention_long_key_mask_fwd_bwd(dt, S, nh):
+    """a4r_attn_long_* WITH a key mask (round 5: text towers with --num_words_title > 32; head width 64): prefix masks of different lengths, a mask with
+    holes, a full one and an item without any attended key (the PAD item: uniform attention over its S keys, as HF's softmax over S equal scores),
+    forward, lse and backward against fp32 torch softmax(QK^T / sqrt(dh) + (1 - mask) finfo.min) V."""
+    from adapter4rec_amd import _lib as L
+    t, dh = DT[dt], 64
+    n_items = 6
+    Hd = nh * dh
+    Mp = ((n_items * S + 255) // 256) * 256
+    qkv = rnd(Mp, 3 * Hd, dtype=t, seed=131 + S)
+    scale = 1.0 / math.sqrt(dh)
+    offs = (0, Hd, 2 * Hd)
+    km = torch.zeros(n_items, S, device=dev())
+    km[0, :S] = 1
+    km[1, :4] = 1
+    km[2, :S // 2 + 3] = 1
+    km[3, ::3] = 1                                    # holes
+    km[4, :1] = 1                                     # [CLS] only
+    # item 5: nothing attended
+    out = torch.zeros(Mp, Hd, dtype=t, device=dev())
+    lse = torch.zeros(n_items * nh * S, device=dev())
+    L.attn_long_fwd(qkv, out, lse, n_items, S, nh, dh, *offs, scale, key_mask=km)
+    qr = qkv.float().clone().requires_grad_(True)
+    FMIN = torch.finfo(torch.float32).min
+    ref = attn_ref(qr, km, n_items, S, nh, dh, False, scale, FMIN, offs)
+    close(out[:n_items * S], ref.detach(), t, f'attn_long masked fwd S={S} {dt}', atol32=1e-4, rtol32=1e-4)
+    dout = rnd(Mp, Hd, dtype=t, seed=132)
+    dout[n_items * S:] = 0
+    dqkv = torch.zeros_like(qkv)
+    ws = torch.zeros_like(lse)
+    L.attn_long_bwd(qkv, out, dout, dqkv, lse, ws, n_items, S, nh, dh, *offs, scale, key_mask=km)
+    ref.backward(dout[:n_items * S].float())
+    assert torch.isfinite(dqkv.float()).all()
+    close(dqkv[:n_items * S], qr.grad[:n_items * S], t, f'attn_long masked bwd S={S} {dt}', atol32=2e-4, rtol32=2e-4,
+          atol16=4e-2 * float(qr.grad.abs().max()))
+    # a masked key receives no gradient through K / V (item 1: keys >= 4)
+    assert float(dqkv[S + 4:2 * S, Hd:].float().abs().max()) == 0.0
+    with pytest.raises(RuntimeError):                 # head width 32 has no masked instantiation
+        L.attn_long_fwd(qkv[:, :3 * 64], out[:, :64], lse, n_items, S, 2, 32, 0, 64, 128, scale, key_mask=km)
+
+
 def test_attention_long_rejects():
     from adapter4rec_amd import _lib as L
     qkv = torch.zeros(512, 192, device=dev())

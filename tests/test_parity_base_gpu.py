@@ -22,7 +22,7 @@ def build_base(seed=3, users=2, n_items=4096, act='RELU'):
     return build_text_case('bert', act, seed=seed, users=users, n_items=n_items)
 
 
-def hip_step(model, dtype, items, mask, residual='bf16'):
+def hip_step(model, dtype, items, mask, residual='bf16', host=False):
     model.compute_dtype = dtype
     model.args.residual_dtype = residual
     model.invalidate_native()
@@ -30,12 +30,13 @@ def hip_step(model, dtype, items, mask, residual='bf16'):
         p.grad = None
     model.to(DEV)
     model.eval()
-    loss = model(items.to(DEV), mask.to(DEV), DEV)
+    loss = model(items, mask, DEV) if host else model(items.to(DEV), mask.to(DEV), DEV)       # host: the DataLoader's tensors (title lengths read there)
     pos, neg = model._engine().scores()
+    s_run = int(getattr(model._engine(), 'S', 0))          # tokens per item the text tower ran this step on
     loss.backward()
     emb = model.bert_encoder(items.to(DEV)).cpu()
     grads = {n: p.grad.detach().cpu().clone() for n, p in model.named_parameters() if p.requires_grad}
-    out = dict(loss=float(loss.detach()), pos=pos.cpu(), neg=neg.cpu(), emb=emb, grads=grads)
+    out = dict(loss=float(loss.detach()), pos=pos.cpu(), neg=neg.cpu(), emb=emb, grads=grads, s_run=s_run)
     model.cpu()
     return out
 
@@ -524,5 +525,62 @@ def test_other_bert_sizes_step_fp32_vs_oracle(size):
     b = hip_step(model, 'bf16', items, mask)
     e_b, where_b = grad_err(b['grads'], ref['grads'])
     print(f'bert_{size} bf16: loss {abs(b["loss"] - ref["loss"]):.1e}, worst gradient {e_b:.2f} ({where_b})')
+    assert abs(b['loss'] - ref['loss']) < 5e-2 and e_b < 0.25
+
+
+@pytest.mark.parametrize('S,short', [(50, False), (40, False), (100, False), (50, True)])
+def test_long_titles_step_fp32_vs_oracle(S, short):
+    """--num_words_title > 32 (parameters.py:44 takes any length; the abstracts / bodies of the reference's other news attributes are 50): the
+    text tower runs on the long attention kernels WITH the titles' key mask (round 5; before: NotImplementedError).  BERT-mini geometry (4 x 256,
+    heads of 64) + Houlsby, one user = 42 item slots with titles of 4 .. S tokens and pad slots holding the PAD item (no attended token: uniform
+    attention, as HF's softmax over equal scores): fp32 vs the CPU oracle 1e-4, bf16 inside the base geometry's bounds.  short: every title <= 20
+    tokens and the batch arrives on the HOST -- the step runs on the batch's longest title (<= 32 tokens here) through the same kernels."""
+    from adapter4rec_amd.inject import freeze_all, inject_adapters
+    from adapter4rec_amd.model import BERT_BASE, BertBackbone, Model
+    from base_cases import text_args
+    from oracle import ref_cpu as R
+    torch.manual_seed(21)
+    args = text_args('fp32', 'GELU')
+    args.word_embedding_dim, args.bert_model_load, args.num_words_title = 256, 'bert_mini_uncased', S
+    model = Model(args, 512, True, BertBackbone(dict(BERT_BASE, hidden_size=256, num_hidden_layers=4, num_attention_heads=4, intermediate_size=1024)))
+    freeze_all(model)
+    model = inject_adapters(model, model.args)
+    with torch.no_grad():
+        for n, p in model.named_parameters():
+            if p.requires_grad:
+                p.add_(0.02 * torch.randn_like(p))
+    model.eval()
+    g = torch.Generator().manual_seed(5)
+    Lq = 21
+    ids = torch.zeros(1, Lq, 2, 2 * S, dtype=torch.int64)
+    mask = torch.zeros(1, Lq - 1)
+    n = 13                                                     # a short history: 8 pad slots on the PAD item (all-zero ids AND mask)
+    for slot in range(Lq - n, Lq):
+        for side in range(2):
+            if side == 1 and slot == Lq - 1:
+                continue
+            ln = int(torch.randint(4, 21, (1,), generator=g)) if short else (S if (slot + side) % 3 == 0 else int(torch.randint(4, S, (1,), generator=g)))
+            ids[0, slot, side, 0] = 101
+            ids[0, slot, side, 1:ln - 1] = torch.randint(1000, 30000, (ln - 2,), generator=g)
+            ids[0, slot, side, ln - 1] = 102
+            ids[0, slot, side, S:S + ln] = 1
+    mask[0, Lq - n:] = 1
+    items = ids.view(-1, 2 * S)
+    sd = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    names = [nm for nm, p in model.named_parameters() if p.requires_grad]
+    out, grads = R.loss_and_grads(sd, names, items, mask, dict(R.DEFAULT_CFG, adapter_activation='GELU', bert_heads=4, num_words_title=S))
+    valid = mask.bool()
+    ref = dict(loss=float(out['loss'].detach()), pos=out['pos_score'].detach()[valid], emb=out['input_embs_all'].detach(), grads=grads)
+    o = hip_step(model, 'fp32', items, mask, host=short)
+    if short:
+        assert o['s_run'] <= 20, o['s_run']                    # the step ran on the batch's longest title
+    e_g, where = grad_err(o['grads'], ref['grads'])
+    print(f'S = {S} fp32: loss {abs(o["loss"] - ref["loss"]):.1e}, embeddings {float((o["emb"] - ref["emb"]).abs().max()):.1e}, worst gradient {e_g:.1e} ({where})')
+    assert abs(o['loss'] - ref['loss']) < 1e-4 and float((o['emb'] - ref['emb']).abs().max()) < 1e-4
+    assert float((o['pos'][valid] - ref['pos']).abs().max()) < 1e-4
+    assert e_g < 2e-4, (e_g, where)
+    b = hip_step(model, 'bf16', items, mask, host=short)
+    e_b, where_b = grad_err(b['grads'], ref['grads'])
+    print(f'S = {S} bf16: loss {abs(b["loss"] - ref["loss"]):.1e}, worst gradient {e_b:.2f} ({where_b})')
     assert abs(b['loss'] - ref['loss']) < 5e-2 and e_b < 0.25
 
