@@ -674,7 +674,9 @@ int check(const a4r_attn_t* a, bool bwd) {
     if (bwd ? (!a->dout || !a->dqkv) : !a->out) return A4R_EINVAL;
     if (a->dtype != A4R_BF16 && a->dtype != A4R_F32) return A4R_EINVAL;
     const bool narrow = a->dh > 0 && a->dh <= 16;          // K-Adapter blocks: scalar kernels of a4r_attn_small.hip
-    if (a->n_items <= 0 || a->n_heads <= 0 || a->S <= 0 || a->S > 32 || (a->dh != 32 && a->dh != 64 && !narrow)) return A4R_EINVAL;
+    // head widths 128 / 256 (fp32 only): the user tower at --embedding_dim 256 / 512 with the default 2 heads (Downstream/Text/parameters.py:27-28)
+    const bool wide = (a->dh == 128 || a->dh == 256) && a->dtype == A4R_F32 && !a->offsets;
+    if (a->n_items <= 0 || a->n_heads <= 0 || a->S <= 0 || a->S > 32 || (a->dh != 32 && a->dh != 64 && !narrow && !wide)) return A4R_EINVAL;
     const int esz = a->dtype == A4R_F32 ? 4 : 2, per = narrow ? 1 : 16 / esz;
     if ((a->ld * esz) % 16 || (a->ldo * esz) % 16 || a->q_off % per || a->k_off % per || a->v_off % per) return A4R_EINVAL;
     if (a->ldo < a->n_heads * a->dh) return A4R_EINVAL;
@@ -695,6 +697,8 @@ extern "C" int a4r_attn_fwd(void* stream, const a4r_attn_t* a) {
     if (a->dh <= 16) return a4r_attn_small(reinterpret_cast<hipStream_t>(stream), a, false);
     Launch L{reinterpret_cast<hipStream_t>(stream), a, a4r_thr16(a->drop_p), a4r_keep_scale(a->drop_p)};
     if (a->dtype == A4R_BF16) return a->dh == 64 ? launch_fwd<bf16_t, 64, 4>(L) : launch_fwd<bf16_t, 32, 4>(L);
+    if (a->dh == 128) return launch_fwd<float, 128, 2>(L);
+    if (a->dh == 256) return launch_fwd<float, 256, 1>(L);
     return a->dh == 64 ? launch_fwd<float, 64, 4>(L) : launch_fwd<float, 32, 4>(L);
 }
 
@@ -708,5 +712,7 @@ extern "C" int a4r_attn_bwd(void* stream, const a4r_attn_t* a) {
         return a->dh == 64 ? launch_bwd_tr<64, 4>(L) : launch_bwd_tr<32, 4>(L);
     }
     if (a->dtype == A4R_BF16) return a->dh == 64 ? launch_bwd<bf16_t, 64, 4>(L) : launch_bwd<bf16_t, 32, 4>(L);
+    if (a->dh == 128) return launch_bwd<float, 128, 1>(L);
+    if (a->dh == 256) return launch_bwd<float, 256, 1>(L);
     return a->dh == 64 ? launch_bwd<float, 64, 2>(L) : launch_bwd<float, 32, 4>(L);
 }

@@ -691,7 +691,8 @@ class TransRecEngine:
     def _build_sasrec(self):
         te = self.model.user_encoder.transformer_encoder
         E, nh = self.E, self.args.num_attention_heads
-        if (E // nh) not in (32, 64) or self.Lseq - 1 > 32:
+        # (head widths 128 / 256: --embedding_dim 256 / 512 with the default two heads, parameters.py:27-28 -- fp32 instantiations of the short attention kernel)
+        if (E // nh) not in (32, 64, 128, 256) or E % nh or self.Lseq - 1 > 32:
             raise NotImplementedError(f'SASRec geometry E={E} heads={nh} T={self.Lseq - 1}')
         pe = te.position_embedding.weight
         self.pos_emb = pe.data if pe.requires_grad else self._f32(pe)
@@ -775,7 +776,8 @@ class TransRecEngine:
         F = pad_to(Fv, 64)
         dh = Hv // nh
         long = S > 32                 # K-Adapter blocks over the ViT token rows (S = 197 / 50): a4r_attn_long_*, no mask, dh 64 / 32
-        if dh not in (32, 64) and not (0 < dh <= 16 and not long) or S > 256 or (long and (causal or H != Hv)):
+        wide = dh in (128, 256) and dt == torch.float32 and not long          # (the user tower at --embedding_dim 256 / 512)
+        if dh not in (32, 64) and not wide and not (0 < dh <= 16 and not long) or S > 256 or (long and (causal or H != Hv)):
             raise NotImplementedError(f'transformer block geometry width={Hv} heads={nh} S={S}')
         b = _Block()
         b.long = long

@@ -207,7 +207,8 @@ int a4r_adapter_ln_bwd(void* stream, const void* dy, int lddy, const void* v, in
  * Wd and WuT, layout 2 for the [H, 64] matrices Wu and WdT) the first tile starts ~3 us earlier (forward 46.8 -> 43.2 us at M = 40 448, 27.5 -> 24.3
  * at M = 16 896).  Same values, same arithmetic order: results are bit-identical to the row-major form. */
 
-/* Short-sequence self-attention, one wave per (item, head), S <= 32, dh in {32, 64}.
+/* Short-sequence self-attention, one wave per (item, head), S <= 32, dh in {32, 64} (fp32 also 128 and 256: the user tower at
+ * --embedding_dim 256 / 512 with two heads, Downstream/Text/parameters.py:27-28; <= 16: scalar kernels).
  * BERT layer: HF BertSelfAttention (called from model/encoders.py:53); SASRec: SelfAttention
  * model/modules.py:31-42 with the mask of model/encoders.py:24-28.
  * qkv [n_items*S, ld]: q at column q_off, k at k_off, v at v_off, head h at +h*dh.

@@ -584,3 +584,41 @@ def test_long_titles_step_fp32_vs_oracle(S, short):
     print(f'S = {S} bf16: loss {abs(b["loss"] - ref["loss"]):.1e}, worst gradient {e_b:.2f} ({where_b})')
     assert abs(b['loss'] - ref['loss']) < 5e-2 and e_b < 0.25
 
+
+@pytest.mark.parametrize('E,heads', [(256, 2), (128, 2), (512, 2), (256, 4)])
+def test_other_user_tower_widths_step_fp32_vs_oracle(E, heads):
+    """--embedding_dim other than the scripts' 64 (parameters.py:27-28 defaults: 256 wide, 2 heads = head width 128; 512 / 2 = 256): the user
+    tower's multi-launch path with the fp32 short attention kernel at head widths 64 / 128 / 256, BERT-tiny + Houlsby below it; fp32 vs the
+    CPU oracle at 1e-4 (round 5; before: NotImplementedError for the reference's own default)."""
+    from adapter4rec_amd.inject import freeze_all, inject_adapters
+    from adapter4rec_amd.model import BERT_BASE, BertBackbone, Model
+    from base_cases import build_text_case, text_args
+    from oracle import ref_cpu as R
+    torch.manual_seed(31)
+    args = text_args('fp32', 'GELU')
+    args.word_embedding_dim, args.bert_model_load, args.embedding_dim, args.num_attention_heads = 128, 'bert_tiny_uncased', E, heads
+    model = Model(args, 512, True, BertBackbone(dict(BERT_BASE, hidden_size=128, num_hidden_layers=2, num_attention_heads=2, intermediate_size=512)))
+    freeze_all(model)
+    model = inject_adapters(model, model.args)
+    with torch.no_grad():
+        for n, p in model.named_parameters():
+            if p.requires_grad:
+                p.add_(0.02 * torch.randn_like(p))
+    model.eval()
+    _, items, mask = build_text_case(users=2, n_items=512)
+    sd = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    names = [n for n, p in model.named_parameters() if p.requires_grad]
+    out, grads = R.loss_and_grads(sd, names, items, mask, dict(R.DEFAULT_CFG, adapter_activation='GELU', bert_heads=2, embedding_dim=E, sasrec_heads=heads))
+    valid = mask.bool()
+    ref = dict(loss=float(out['loss'].detach()), pos=out['pos_score'].detach()[valid], emb=out['input_embs_all'].detach(), grads=grads)
+    o = hip_step(model, 'fp32', items, mask)
+    e_g, where = grad_err(o['grads'], ref['grads'])
+    print(f'E = {E}, {heads} heads fp32: loss {abs(o["loss"] - ref["loss"]):.1e}, embeddings {float((o["emb"] - ref["emb"]).abs().max()):.1e}, worst gradient {e_g:.1e} ({where})')
+    assert abs(o['loss'] - ref['loss']) < 1e-4 and float((o['emb'] - ref['emb']).abs().max()) < 1e-4
+    assert float((o['pos'][valid] - ref['pos']).abs().max()) < 1e-4
+    assert e_g < 2e-4, (e_g, where)
+    b = hip_step(model, 'bf16', items, mask)
+    e_b, where_b = grad_err(b['grads'], ref['grads'])
+    print(f'E = {E} bf16: loss {abs(b["loss"] - ref["loss"]):.1e}, worst gradient {e_b:.2f} ({where_b})')
+    assert abs(b['loss'] - ref['loss']) < 5e-2 and e_b < 0.25
+
