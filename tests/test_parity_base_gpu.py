@@ -622,3 +622,39 @@ def test_other_user_tower_widths_step_fp32_vs_oracle(E, heads):
     print(f'E = {E} bf16: loss {abs(b["loss"] - ref["loss"]):.1e}, worst gradient {e_b:.2f} ({where_b})')
     assert abs(b['loss'] - ref['loss']) < 5e-2 and e_b < 0.25
 
+
+def test_shipped_lora_script_configuration_step_fp32_vs_oracle():
+    """Downstream/Text/script/adapter_lora.py:41-43: --adapter_type lora --bert_adapter_down_size 12 --adapter_down_size 4 (LoRA rank 12 on the text
+    tower's query / value, rank 4 in the user tower) -- ranks that are not the fixtures' (8 / 16 / 64): BERT-mini geometry, fp32 vs the CPU oracle."""
+    from adapter4rec_amd.inject import freeze_all, inject_adapters
+    from adapter4rec_amd.model import BERT_BASE, BertBackbone, Model
+    from base_cases import build_text_case, text_args
+    from oracle import ref_cpu as R
+    torch.manual_seed(41)
+    args = text_args('fp32', 'RELU', adapter_type='lora')
+    args.word_embedding_dim, args.bert_model_load, args.bert_adapter_down_size, args.adapter_down_size = 256, 'bert_mini_uncased', 12, 4
+    model = Model(args, 512, True, BertBackbone(dict(BERT_BASE, hidden_size=256, num_hidden_layers=4, num_attention_heads=4, intermediate_size=1024)))
+    freeze_all(model)
+    model = inject_adapters(model, model.args)
+    with torch.no_grad():
+        for n, p in model.named_parameters():
+            if p.requires_grad:
+                p.add_(0.02 * torch.randn_like(p))
+    model.eval()
+    _, items, mask = build_text_case(users=2, n_items=512)
+    sd = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    names = [n for n, p in model.named_parameters() if p.requires_grad]
+    assert any('lora_A' in n for n in names) and any('user_encoder' in n and 'lora' in n for n in names), names[:8]
+    out, grads = R.loss_and_grads(sd, names, items, mask, dict(R.DEFAULT_CFG, adapter_type='lora', bert_heads=4, lora_r_bert=12, lora_r_sasrec=4))
+    valid = mask.bool()
+    ref = dict(loss=float(out['loss'].detach()), pos=out['pos_score'].detach()[valid], emb=out['input_embs_all'].detach(), grads=grads)
+    o = hip_step(model, 'fp32', items, mask)
+    e_g, where = grad_err(o['grads'], ref['grads'])
+    print(f'lora r = 12 / 4 fp32: loss {abs(o["loss"] - ref["loss"]):.1e}, embeddings {float((o["emb"] - ref["emb"]).abs().max()):.1e}, worst gradient {e_g:.1e} ({where})')
+    assert abs(o['loss'] - ref['loss']) < 1e-4 and float((o['emb'] - ref['emb']).abs().max()) < 1e-4
+    assert e_g < 2e-4, (e_g, where)
+    b = hip_step(model, 'bf16', items, mask)
+    e_b, where_b = grad_err(b['grads'], ref['grads'])
+    print(f'lora r = 12 / 4 bf16: loss {abs(b["loss"] - ref["loss"]):.1e}, worst gradient {e_b:.2f} ({where_b})')
+    assert abs(b['loss'] - ref['loss']) < 5e-2 and e_b < 0.25
+
