@@ -23,18 +23,19 @@ def build_base(seed=3, users=2, n_items=4096, act='RELU'):
 
 
 def hip_step(model, dtype, items, mask, residual='bf16', host=False):
-    model.compute_dtype = dtype
-    model.args.residual_dtype = residual
-    model.invalidate_native()
+    inner = getattr(model, 'model', model)                 # (CompacterModel wraps the model it adapts)
+    inner.compute_dtype = dtype
+    inner.args.residual_dtype = residual
+    inner.invalidate_native()
     for p in model.parameters():
         p.grad = None
     model.to(DEV)
     model.eval()
     loss = model(items, mask, DEV) if host else model(items.to(DEV), mask.to(DEV), DEV)       # host: the DataLoader's tensors (title lengths read there)
-    pos, neg = model._engine().scores()
-    s_run = int(getattr(model._engine(), 'S', 0))          # tokens per item the text tower ran this step on
+    pos, neg = inner._engine().scores()
+    s_run = int(getattr(inner._engine(), 'S', 0))          # tokens per item the text tower ran this step on
     loss.backward()
-    emb = model.bert_encoder(items.to(DEV)).cpu()
+    emb = inner.bert_encoder(items.to(DEV)).cpu()
     grads = {n: p.grad.detach().cpu().clone() for n, p in model.named_parameters() if p.requires_grad}
     out = dict(loss=float(loss.detach()), pos=pos.cpu(), neg=neg.cpu(), emb=emb, grads=grads, s_run=s_run)
     model.cpu()
@@ -657,4 +658,49 @@ def test_shipped_lora_script_configuration_step_fp32_vs_oracle():
     e_b, where_b = grad_err(b['grads'], ref['grads'])
     print(f'lora r = 12 / 4 bf16: loss {abs(b["loss"] - ref["loss"]):.1e}, worst gradient {e_b:.2f} ({where_b})')
     assert abs(b['loss'] - ref['loss']) < 5e-2 and e_b < 0.25
+
+
+@pytest.mark.parametrize('adapter_type', ['compacter', 'pfeiffer_ver2', 'houslby'])
+def test_shipped_scripts_finetune_layernorm_with_adapters_fp32_vs_oracle(adapter_type):
+    """Downstream/Text/script/adapter_compacter.py and adapter_pfeifffer.py pass --finetune_layernorm TRUE together with their adapters: run.py:496-501
+    then makes every non-adapter LayerNorm of BOTH towers trainable (embedding LayerNorm, the two per BERT layer, the user tower's).  The fixtures pin
+    the flag without adapters and on the image tower; this is the text-tower combination the scripts run: BERT-mini geometry, fp32 vs the CPU oracle."""
+    from adapter4rec_amd.inject import freeze_all, inject_adapters
+    from adapter4rec_amd.model import BERT_BASE, BertBackbone, Model
+    from base_cases import build_text_case, text_args
+    from oracle import ref_cpu as R
+    torch.manual_seed(51)
+    args = text_args('fp32', 'RELU', adapter_type=adapter_type)
+    args.word_embedding_dim, args.bert_model_load, args.finetune_layernorm = 256, 'bert_mini_uncased', 'TRUE'
+    model = Model(args, 512, True, BertBackbone(dict(BERT_BASE, hidden_size=256, num_hidden_layers=4, num_attention_heads=4, intermediate_size=1024)))
+    freeze_all(model)
+    model = inject_adapters(model, model.args)
+    n_ln = 0
+    for name, param in model.named_parameters():                    # run.py:496-501
+        if 'adapter' not in name and ('LayerNorm' in name or 'layer_norm' in name):
+            param.requires_grad = True
+            n_ln += 1
+    assert n_ln >= 2 * (1 + 2 * 4)
+    with torch.no_grad():
+        for n, p in model.named_parameters():
+            if p.requires_grad:
+                p.add_(0.02 * torch.randn_like(p))
+    model.eval()
+    _, items, mask = build_text_case(users=2, n_items=512)
+    from golden_util import strip                                   # (CompacterModel wraps the model: its keys carry a 'model.' prefix)
+    sd = {strip(k): v.detach().clone() for k, v in model.state_dict().items()}
+    names = [n for n, p in model.named_parameters() if p.requires_grad]
+    out, grads = R.loss_and_grads(sd, [strip(n) for n in names], items, mask, dict(R.DEFAULT_CFG, adapter_type=adapter_type, bert_heads=4))
+    valid = mask.bool()
+    ref = dict(loss=float(out['loss'].detach()), emb=out['input_embs_all'].detach(), grads={n: grads[strip(n)] for n in names})
+    o = hip_step(model, 'fp32', items, mask)
+    e_g, where = grad_err(o['grads'], ref['grads'])
+    print(f'{adapter_type} + finetune_layernorm fp32: loss {abs(o["loss"] - ref["loss"]):.1e}, embeddings {float((o["emb"] - ref["emb"]).abs().max()):.1e}, '
+          f'worst gradient {e_g:.1e} ({where})')
+    assert abs(o['loss'] - ref['loss']) < 1e-4 and float((o['emb'] - ref['emb']).abs().max()) < 1e-4
+    assert e_g < 1e-3, (e_g, where)                                 # (RELU adapters: a flipped act' is ~1 / n_tokens of a row, see the base-geometry test)
+    b = hip_step(model, 'bf16', items, mask)
+    e_b, where_b = grad_err(b['grads'], ref['grads'])
+    print(f'{adapter_type} + finetune_layernorm bf16: loss {abs(b["loss"] - ref["loss"]):.1e}, worst gradient {e_b:.2f} ({where_b})')
+    assert abs(b['loss'] - ref['loss']) < 5e-2 and e_b < 0.3
 
