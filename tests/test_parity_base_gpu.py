@@ -704,3 +704,41 @@ def test_shipped_scripts_finetune_layernorm_with_adapters_fp32_vs_oracle(adapter
     print(f'{adapter_type} + finetune_layernorm bf16: loss {abs(b["loss"] - ref["loss"]):.1e}, worst gradient {e_b:.2f} ({where_b})')
     assert abs(b['loss'] - ref['loss']) < 5e-2 and e_b < 0.3
 
+
+@pytest.mark.parametrize('n_tokens', [30, 5])
+def test_shipped_prompt_script_configuration_fp32_vs_oracle(n_tokens):
+    """Downstream/Text/script/adapter_sp.py passes --adapter_type prompt and leaves --n_tokens at parameters.py:87's default 30 = --num_words_title:
+    SoftEmbedding (model.py:586-630) then replaces the word vector of EVERY title token by a learned row.  That corner (prompt as long as the
+    title) and a short prompt at BERT-mini geometry, fp32 vs the CPU oracle."""
+    from adapter4rec_amd.inject import freeze_all, inject_adapters
+    from adapter4rec_amd.model import BERT_BASE, BertBackbone, Model
+    from base_cases import build_text_case, text_args
+    from golden_util import strip
+    from oracle import ref_cpu as R
+    torch.manual_seed(61)
+    args = text_args('fp32', 'RELU', adapter_type='prompt')
+    args.word_embedding_dim, args.bert_model_load, args.n_tokens = 256, 'bert_mini_uncased', n_tokens
+    model = Model(args, 512, True, BertBackbone(dict(BERT_BASE, hidden_size=256, num_hidden_layers=4, num_attention_heads=4, intermediate_size=1024)))
+    freeze_all(model)
+    model = inject_adapters(model, model.args)
+    with torch.no_grad():
+        for n, p in model.named_parameters():
+            if p.requires_grad:
+                p.add_(0.02 * torch.randn_like(p))
+    model.eval()
+    _, items, mask = build_text_case(users=2, n_items=512)
+    sd = {strip(k): v.detach().clone() for k, v in model.state_dict().items()}
+    names = [n for n, p in model.named_parameters() if p.requires_grad]
+    assert any('learned_embedding' in n for n in names)
+    out, grads = R.loss_and_grads(sd, [strip(n) for n in names], items, mask, dict(R.DEFAULT_CFG, adapter_type='prompt', bert_heads=4))
+    ref = dict(loss=float(out['loss'].detach()), emb=out['input_embs_all'].detach(), grads={n: grads[strip(n)] for n in names})
+    o = hip_step(model, 'fp32', items, mask)
+    e_g, where = grad_err(o['grads'], ref['grads'])
+    print(f'prompt n_tokens = {n_tokens} fp32: loss {abs(o["loss"] - ref["loss"]):.1e}, embeddings {float((o["emb"] - ref["emb"]).abs().max()):.1e}, worst gradient {e_g:.1e} ({where})')
+    assert abs(o['loss'] - ref['loss']) < 1e-4 and float((o['emb'] - ref['emb']).abs().max()) < 1e-4
+    assert e_g < 1e-3, (e_g, where)
+    b = hip_step(model, 'bf16', items, mask)
+    e_b, where_b = grad_err(b['grads'], ref['grads'])
+    print(f'prompt n_tokens = {n_tokens} bf16: loss {abs(b["loss"] - ref["loss"]):.1e}, worst gradient {e_b:.2f} ({where_b})')
+    assert abs(b['loss'] - ref['loss']) < 5e-2 and e_b < 0.3
+
