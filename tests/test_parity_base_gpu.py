@@ -529,7 +529,7 @@ def test_other_bert_sizes_step_fp32_vs_oracle(size):
     assert abs(b['loss'] - ref['loss']) < 5e-2 and e_b < 0.25
 
 
-@pytest.mark.parametrize('S,short', [(50, False), (40, False), (100, False), (50, True)])
+@pytest.mark.parametrize('S,short', [(50, False), (40, False), (100, False), (50, True), (25, False), (31, True), (33, False)])      # (25 / 31: odd lengths on the short kernels)
 def test_long_titles_step_fp32_vs_oracle(S, short):
     """--num_words_title > 32 (parameters.py:44 takes any length; the abstracts / bodies of the reference's other news attributes are 50): the
     text tower runs on the long attention kernels WITH the titles' key mask (round 5; before: NotImplementedError).  BERT-mini geometry (4 x 256,
@@ -574,7 +574,7 @@ def test_long_titles_step_fp32_vs_oracle(S, short):
     ref = dict(loss=float(out['loss'].detach()), pos=out['pos_score'].detach()[valid], emb=out['input_embs_all'].detach(), grads=grads)
     o = hip_step(model, 'fp32', items, mask, host=short)
     if short:
-        assert o['s_run'] <= 20, o['s_run']                    # the step ran on the batch's longest title
+        assert o['s_run'] <= 20 or S % 2, o['s_run']           # the step ran on the batch's longest title (an odd --num_words_title keeps the full length: engine.py, train_forward)
     e_g, where = grad_err(o['grads'], ref['grads'])
     print(f'S = {S} fp32: loss {abs(o["loss"] - ref["loss"]):.1e}, embeddings {float((o["emb"] - ref["emb"]).abs().max()):.1e}, worst gradient {e_g:.1e} ({where})')
     assert abs(o['loss'] - ref['loss']) < 1e-4 and float((o['emb'] - ref['emb']).abs().max()) < 1e-4
