@@ -103,7 +103,7 @@ __global__ void fill_i32_kernel(int32_t* p, int n, int v) {
 extern "C" int a4r_eval_rank(void* stream, const float* prec, const float* item_emb, const int32_t* target,
                              const int32_t* hist_ptr, const int32_t* hist_idx, int32_t* rank, int U, int N1, int E) {
     if (!prec || !item_emb || !target || !hist_ptr || !hist_idx || !rank || U <= 0 || N1 < 2) return A4R_EINVAL;
-    if (E != 64 && E != 128 && E != 256) return A4R_EINVAL;
+    if (E != 64 && E != 128 && E != 256 && E != 512) return A4R_EINVAL;
     if ((reinterpret_cast<uintptr_t>(prec) | reinterpret_cast<uintptr_t>(item_emb)) & 15u) return A4R_EINVAL;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     hipLaunchKernelGGL(fill_i32_kernel, dim3((U + 255) / 256), dim3(256), 0, s, rank, U, 1);
@@ -113,6 +113,7 @@ extern "C" int a4r_eval_rank(void* stream, const float* prec, const float* item_
     if (gy > (ntiles + 3) / 4) gy = (ntiles + 3) / 4;
     if (E == 64) hipLaunchKernelGGL(eval_rank_kernel<64>, dim3(gx, gy), dim3(256), 0, s, prec, item_emb, target, hist_ptr, hist_idx, rank, U, N1);
     else if (E == 128) hipLaunchKernelGGL(eval_rank_kernel<128>, dim3(gx, gy), dim3(256), 0, s, prec, item_emb, target, hist_ptr, hist_idx, rank, U, N1);
-    else hipLaunchKernelGGL(eval_rank_kernel<256>, dim3(gx, gy), dim3(256), 0, s, prec, item_emb, target, hist_ptr, hist_idx, rank, U, N1);
+    else if (E == 256) hipLaunchKernelGGL(eval_rank_kernel<256>, dim3(gx, gy), dim3(256), 0, s, prec, item_emb, target, hist_ptr, hist_idx, rank, U, N1);
+    else hipLaunchKernelGGL(eval_rank_kernel<512>, dim3(gx, gy), dim3(256), 0, s, prec, item_emb, target, hist_ptr, hist_idx, rank, U, N1);
     return a4r_launch_status();
 }

@@ -995,9 +995,11 @@ def test_pack_matrices():
     assert torch.equal(d2.float(), flat[16 * 64:].view(768, 64).t().bfloat16().float())
 
 
-def test_eval_rank():
+@pytest.mark.parametrize('E', [64, 128, 256, 512])
+def test_eval_rank(E):
+    """(E = 256: the parser's default --embedding_dim; 512: instantiated in round 5)"""
     from adapter4rec_amd import _lib as L
-    U, N1, E = 37, 1001, 64
+    U, N1 = 37, 1001
     prec, items = rnd(U, E, seed=81), rnd(N1, E, seed=82)
     g = torch.Generator().manual_seed(3)
     target = torch.randint(1, N1, (U,), generator=g).int()

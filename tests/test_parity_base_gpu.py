@@ -777,3 +777,50 @@ def test_shipped_kadapter_script_configuration_fp32_vs_oracle():
     assert abs(o['loss'] - ref['loss']) < 1e-4 and float((o['emb'] - ref['emb']).abs().max()) < 1e-4
     assert e_g < 2e-3, (e_g, where)
 
+
+@pytest.mark.parametrize('E', [256, 512])
+def test_eval_at_other_user_tower_widths_vs_oracle(E):
+    """the evaluation path (item sweep, user encoder inference, a4r_eval_rank) at --embedding_dim 256 (the parser's default) and 512: per-user ranks of
+    the fp32 instantiation against the oracle's on 300 items x 60 users (equal up to fp32 near-ties)."""
+    from adapter4rec_amd.data_utils import get_item_embeddings
+    from adapter4rec_amd.data_utils.metrics import eval_ranks
+    from adapter4rec_amd.inject import freeze_all, inject_adapters
+    from adapter4rec_amd.model import BERT_BASE, BertBackbone, Model
+    from base_cases import text_args
+    from oracle import ref_cpu as R
+    torch.manual_seed(81)
+    args = text_args('fp32', 'GELU')
+    args.word_embedding_dim, args.bert_model_load, args.embedding_dim, args.num_attention_heads = 128, 'bert_tiny_uncased', E, 2
+    n_items, n_users = 300, 60
+    model = Model(args, n_items, True, BertBackbone(dict(BERT_BASE, hidden_size=128, num_hidden_layers=2, num_attention_heads=2, intermediate_size=512, vocab_size=500)))
+    freeze_all(model)
+    model = inject_adapters(model, model.args)
+    with torch.no_grad():
+        for n, p in model.named_parameters():
+            if p.requires_grad:
+                p.add_(0.02 * torch.randn_like(p))
+            if n.endswith('word_embeddings.weight'):
+                p.mul_(30.0)                                   # (a random-init encoder gives nearly identical embeddings for all items)
+    model.eval()
+    g = torch.Generator().manual_seed(7)
+    content = torch.zeros(n_items + 1, 60, dtype=torch.int64)
+    content[1:, 1:29] = torch.randint(5, 500, (n_items, 28), generator=g)
+    content[1:, 0], content[1:, 29], content[1:, 30:] = 101, 102, 1
+    rng = np.random.default_rng(7)
+    eval_seq, hist = {}, {}
+    for u in range(n_users):
+        seq = [int(x) for x in rng.choice(np.arange(1, n_items + 1), size=int(rng.integers(3, 22)), replace=False)]
+        eval_seq[u], hist[u] = seq, torch.LongTensor(seq[:-1])
+    sd = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    cfg = dict(R.DEFAULT_CFG, adapter_activation='GELU', bert_heads=2, embedding_dim=E, sasrec_heads=2)
+    emb_ref = R.item_embeddings(sd, content.numpy(), cfg)
+    _, ranks_ref = R.eval_ranks(sd, emb_ref, eval_seq, hist, cfg)
+    model.to(DEV)
+    emb = get_item_embeddings(model, content.numpy(), 128, args, True, 0)
+    assert float((emb.cpu() - emb_ref).abs().max()) < 1e-4
+    ranks = eval_ranks(model, hist, eval_seq, emb, 32, args, list(range(n_users))).cpu().numpy()
+    d = np.abs(ranks - np.asarray(ranks_ref))
+    print(f'E = {E}: {int((d == 0).sum())} of {n_users} ranks equal, largest difference {int(d.max())}')
+    assert (d == 0).mean() > 0.95 and d.max() <= 2
+    model.cpu()
+
