@@ -824,3 +824,39 @@ def test_eval_at_other_user_tower_widths_vs_oracle(E):
     assert (d == 0).mean() > 0.95 and d.max() <= 2
     model.cpu()
 
+
+@pytest.mark.parametrize('d_bert,d_sas', [(8, 8), (100, 48), (128, 16), (200, 64)])
+def test_other_bottleneck_widths_step_fp32_vs_oracle(d_bert, d_sas):
+    """--bert_adapter_down_size / --adapter_down_size other than the scripts' 64 / 16 (parameters.py:60,70 take any): bottlenecks below, at and above
+    the 64 the one-launch adapter kernels are built for (wider ones take the three-launch form), not multiples of 8; BERT-mini + Houlsby, fp32 vs
+    the CPU oracle."""
+    from adapter4rec_amd.inject import freeze_all, inject_adapters
+    from adapter4rec_amd.model import BERT_BASE, BertBackbone, Model
+    from base_cases import build_text_case, text_args
+    from oracle import ref_cpu as R
+    torch.manual_seed(91)
+    args = text_args('fp32', 'GELU')
+    args.word_embedding_dim, args.bert_model_load, args.bert_adapter_down_size, args.adapter_down_size = 256, 'bert_mini_uncased', d_bert, d_sas
+    model = Model(args, 512, True, BertBackbone(dict(BERT_BASE, hidden_size=256, num_hidden_layers=4, num_attention_heads=4, intermediate_size=1024)))
+    freeze_all(model)
+    model = inject_adapters(model, model.args)
+    with torch.no_grad():
+        for n, p in model.named_parameters():
+            if p.requires_grad:
+                p.add_(0.02 * torch.randn_like(p))
+    model.eval()
+    _, items, mask = build_text_case(users=2, n_items=512)
+    sd = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    names = [n for n, p in model.named_parameters() if p.requires_grad]
+    out, grads = R.loss_and_grads(sd, names, items, mask, dict(R.DEFAULT_CFG, adapter_activation='GELU', bert_heads=4))
+    ref = dict(loss=float(out['loss'].detach()), emb=out['input_embs_all'].detach(), grads=grads)
+    o = hip_step(model, 'fp32', items, mask)
+    e_g, where = grad_err(o['grads'], ref['grads'])
+    print(f'bottlenecks {d_bert} / {d_sas} fp32: loss {abs(o["loss"] - ref["loss"]):.1e}, embeddings {float((o["emb"] - ref["emb"]).abs().max()):.1e}, worst gradient {e_g:.1e} ({where})')
+    assert abs(o['loss'] - ref['loss']) < 1e-4 and float((o['emb'] - ref['emb']).abs().max()) < 1e-4
+    assert e_g < 2e-4, (e_g, where)
+    b = hip_step(model, 'bf16', items, mask)
+    e_b, where_b = grad_err(b['grads'], ref['grads'])
+    print(f'bottlenecks {d_bert} / {d_sas} bf16: loss {abs(b["loss"] - ref["loss"]):.1e}, worst gradient {e_b:.2f} ({where_b})')
+    assert abs(b['loss'] - ref['loss']) < 5e-2 and e_b < 0.25
+
