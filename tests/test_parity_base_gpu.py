@@ -860,3 +860,52 @@ def test_other_bottleneck_widths_step_fp32_vs_oracle(d_bert, d_sas):
     print(f'bottlenecks {d_bert} / {d_sas} bf16: loss {abs(b["loss"] - ref["loss"]):.1e}, worst gradient {e_b:.2f} ({where_b})')
     assert abs(b['loss'] - ref['loss']) < 5e-2 and e_b < 0.25
 
+
+@pytest.mark.parametrize('blocks,max_len', [(1, 20), (4, 20), (2, 10), (2, 31), (3, 5)])
+def test_other_user_tower_depths_and_history_lengths_fp32_vs_oracle(blocks, max_len):
+    """--transformer_block other than 2 and --max_seq_len other than 20 (parameters.py:29-30; the user tower's attention kernel holds up to 32 positions):
+    BERT-tiny + Houlsby below, three users with histories of different lengths, fp32 vs the CPU oracle."""
+    from adapter4rec_amd.inject import freeze_all, inject_adapters
+    from adapter4rec_amd.model import BERT_BASE, BertBackbone, Model
+    from base_cases import text_args
+    from oracle import ref_cpu as R
+    torch.manual_seed(101)
+    args = text_args('fp32', 'GELU')
+    args.word_embedding_dim, args.bert_model_load, args.transformer_block, args.max_seq_len = 128, 'bert_tiny_uncased', blocks, max_len
+    model = Model(args, 512, True, BertBackbone(dict(BERT_BASE, hidden_size=128, num_hidden_layers=2, num_attention_heads=2, intermediate_size=512)))
+    freeze_all(model)
+    model = inject_adapters(model, model.args)
+    with torch.no_grad():
+        for n, p in model.named_parameters():
+            if p.requires_grad:
+                p.add_(0.02 * torch.randn_like(p))
+    model.eval()
+    g = torch.Generator().manual_seed(9)
+    Lq, users = max_len + 1, 3
+    ids = torch.zeros(users, Lq, 2, 60, dtype=torch.int64)
+    mask = torch.zeros(users, Lq - 1)
+    for u, n in enumerate((Lq, max(3, Lq // 2), 3)):                 # a full history, a half one, the shortest the data pipeline keeps
+        for slot in range(Lq - n, Lq):
+            for side in range(2):
+                if side == 1 and slot == Lq - 1:
+                    continue
+                ln = int(torch.randint(4, 31, (1,), generator=g))
+                ids[u, slot, side, 0] = 101
+                ids[u, slot, side, 1:ln - 1] = torch.randint(1000, 30000, (ln - 2,), generator=g)
+                ids[u, slot, side, ln - 1] = 102
+                ids[u, slot, side, 30:30 + ln] = 1
+        mask[u, Lq - n:] = 1
+    items = ids.view(-1, 60)
+    sd = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    names = [n for n, p in model.named_parameters() if p.requires_grad]
+    out, grads = R.loss_and_grads(sd, names, items, mask, dict(R.DEFAULT_CFG, adapter_activation='GELU', bert_heads=2, max_seq_len=max_len))
+    ref = dict(loss=float(out['loss'].detach()), emb=out['input_embs_all'].detach(), grads=grads)
+    o = hip_step(model, 'fp32', items, mask)
+    e_g, where = grad_err(o['grads'], ref['grads'])
+    print(f'{blocks} blocks, max_seq_len {max_len} fp32: loss {abs(o["loss"] - ref["loss"]):.1e}, worst gradient {e_g:.1e} ({where})')
+    assert abs(o['loss'] - ref['loss']) < 1e-4 and float((o['emb'] - ref['emb']).abs().max()) < 1e-4
+    assert e_g < 2e-4, (e_g, where)
+    b = hip_step(model, 'bf16', items, mask)
+    e_b, where_b = grad_err(b['grads'], ref['grads'])
+    assert abs(b['loss'] - ref['loss']) < 5e-2 and e_b < 0.25, (b['loss'], e_b, where_b)
+
