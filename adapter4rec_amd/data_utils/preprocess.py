@@ -16,30 +16,45 @@ def read_news(news_path):
 
 
 def read_news_bert(news_path, args, tokenizer):
-    """preprocess.py:80-107: tokenise the lower-cased title to exactly num_words_title ids (+ attention mask)."""
+    """preprocess.py:80-107: tokenise the lower-cased title to exactly num_words_title ids (+ attention mask).
+    abstract / body (--news_attributes, :93-103): the reference reads them from variables its two-column split never defines (a NameError as
+    shipped); here they are the optional 3rd / 4th tab-separated columns of the news file, tokenised to num_words_abstract / num_words_body
+    (the body cut at 2 000 characters first, :100)."""
     item_id_to_dic, item_name_to_id = {}, {}
+    want = set(args.news_attributes)
     with open(news_path, 'r') as f:
         for item_id, line in enumerate(f, start=1):
-            doc_name, title = line.strip('\n').split('\t')
-            tok = tokenizer(title.lower(), max_length=args.num_words_title, padding='max_length', truncation=True) \
-                if 'title' in args.news_attributes else []
+            cols = line.strip('\n').split('\t')
+            doc_name, title = cols[0], cols[1]
+            tok = tokenizer(title.lower(), max_length=args.num_words_title, padding='max_length', truncation=True) if 'title' in want else []
+            extra = []
+            for k, (name, nw, cut) in enumerate((('abstract', getattr(args, 'num_words_abstract', 0), None), ('body', getattr(args, 'num_words_body', 0), 2000))):
+                if name in want:
+                    if len(cols) < 3 + k:
+                        raise ValueError(f'--news_attributes {name}: {news_path} has no column {3 + k} (doc_name, title, abstract, body)')
+                    extra.append(tokenizer(cols[2 + k].lower()[:cut], max_length=nw, padding='max_length', truncation=True))
+                else:
+                    extra.append([])
             item_name_to_id[doc_name] = item_id
-            item_id_to_dic[item_id] = [tok, [], []]
+            item_id_to_dic[item_id] = [tok] + extra
     return item_id_to_dic, item_name_to_id
 
 
 def get_doc_input_bert(item_id_to_content, args):
-    """preprocess.py:110-151: int32 [item_num + 1, L] id and mask matrices (row 0 = PAD item); abstract/body unused -> None."""
+    """preprocess.py:110-151: int32 [item_num + 1, L] id and mask matrices per attribute (row 0 = PAD item); None for the attributes not asked for."""
     n = len(item_id_to_content) + 1
-    title = mask = None
-    if 'title' in args.news_attributes:
-        title = np.zeros((n, args.num_words_title), dtype='int32')
-        mask = np.zeros((n, args.num_words_title), dtype='int32')
+    out = []
+    for k, (name, nw) in enumerate((('title', args.num_words_title), ('abstract', getattr(args, 'num_words_abstract', 0)), ('body', getattr(args, 'num_words_body', 0)))):
+        if name not in args.news_attributes:
+            out += [None, None]
+            continue
+        ids, mask = np.zeros((n, nw), dtype='int32'), np.zeros((n, nw), dtype='int32')
         for item_id in range(1, n):
-            t = item_id_to_content[item_id][0]
-            title[item_id] = t['input_ids']
+            t = item_id_to_content[item_id][k]
+            ids[item_id] = t['input_ids']
             mask[item_id] = t['attention_mask']
-    return title, mask, None, None, None, None
+        out += [ids, mask]
+    return tuple(out)
 
 
 def read_behaviors(behaviors_path, before_item_id_to_dic, before_item_name_to_id, max_seq_len, min_seq_len, Log_file):

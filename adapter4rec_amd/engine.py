@@ -259,7 +259,18 @@ class TransRecEngine:
         # --residual_dtype fp32 (bf16 storage): fp32 twins of the residual stream, keyed by the bf16 tensor they shadow (see _sub_forward)
         self.res32 = dtype != 'fp32' and getattr(args, 'residual_dtype', 'bf16') == 'fp32'
         self._twin = {}
-        self.S = getattr(args, 'num_words_title', 0)
+        # --news_attributes (encoders.py:62-99): rows are [ids | mask] per attribute, laid out title, abstract, body; every attribute runs through the
+        # same tower and the item vector is the mean.  With more than one, the attributes are stacked as extra items at the longest length
+        # (_stack_attrs): self.S = that length, key masks do the rest.
+        na = [a for a in ('title', 'abstract', 'body') if a in set(getattr(args, 'news_attributes', ['title']) or ['title'])] or ['title']
+        self.attrs, st = [], 0
+        for a in ('title', 'abstract', 'body'):
+            nw = int(getattr(args, 'num_words_' + a, 0)) if a in na else 0
+            if nw:
+                self.attrs.append((st, nw))
+            st += 2 * nw
+        self.n_attr = len(self.attrs) if type(self).__name__ == 'TransRecEngine' else 1
+        self.S = max(nw for _, nw in self.attrs) if self.attrs else getattr(args, 'num_words_title', 0)      # (a single attribute: its own length)
         self.S0 = self.S                           # the title length of the data; self.S may be shorter for one training step (train_forward)
         self.E = args.embedding_dim
         self.Lseq = args.max_seq_len + 1
@@ -1591,6 +1602,47 @@ class TransRecEngine:
         """torch-side preparation of a step that must sit BEFORE its first kernel (image tower: the ViT-MAE masking order)."""
 
     # ------------------------------------------------------------------ public: inference entry points
+    def _stack_attrs(self, news, n):
+        """[n, sum 2 S_a] (ids | mask per attribute) -> [n_attr * n, 2 S] int64, attribute-major, every attribute right-padded to the longest one
+        with pad id / mask 0 (data movement only)."""
+        S = self.S0
+        out = torch.zeros(self.n_attr * n, 2 * S, dtype=torch.int64, device=news.device)
+        if self.roberta:
+            out[:, :S] = self.pad_id
+        for k, (st, nw) in enumerate(self.attrs):
+            out[k * n:(k + 1) * n, :nw] = news[:n, st:st + nw]
+            out[k * n:(k + 1) * n, S:S + nw] = news[:n, st + nw:st + 2 * nw]
+        return out
+
+    _ADD_DESC_BYTES = 32                       # sizeof(a4r_add_desc_t)
+
+    def _attr_table(self, key, src, dst_off_rows, n, into_rows):
+        """descriptor table of one a4r_unpack_add launch that adds src blocks scaled by 1 / n_attr (cached per buffer address and item count)"""
+        cache = self.__dict__.setdefault('_attr_tabs', {})
+        k = (key, src.data_ptr(), n)
+        if k not in cache:
+            E, a = self.E, 1.0 / self.n_attr
+            ents = [L.AddDesc(src.data_ptr() + (0 if into_rows else j * n * E * 4), (j * n * E if into_rows else 0), n, E, E, a) for j in range(self.n_attr)]
+            cache[k] = L.desc_table(ents, self.dev)
+        return cache[k]
+
+    def _attr_mean(self, emb_all, n):
+        """emb [pad(n), E] = mean over the attributes of emb_all [n_attr * n, E] (encoders.py:96-98)"""
+        emb = self._buf('emb_mean', pad_to(n, 128), self.E, torch.float32)
+        L.zero(emb)
+        tab = self._attr_table('fwd', emb_all, 0, n, False)
+        for j in range(self.n_attr):               # one launch per attribute: the descriptors of a launch run concurrently and these share their target
+            L.unpack_add(emb, tab[j * self._ADD_DESC_BYTES:], 1, n * self.E)
+        return emb
+
+    def _attr_spread(self, d_emb, n):
+        """its backward: every attribute's vector receives d_emb / n_attr"""
+        Ip = pad_to(self.n_attr * n, 128)
+        d_all = self._buf('d_emb_attr', Ip, self.E, torch.float32)
+        L.zero(d_all)
+        L.unpack_add(d_all, self._attr_table('bwd', d_emb, 0, n, True), self.n_attr, n * self.E)
+        return d_all, Ip
+
     @torch.no_grad()
     def encode_items(self, news):
         L.require_gpu(news)
@@ -1601,6 +1653,9 @@ class TransRecEngine:
         if news.dtype != torch.int64:
             news = news.long()
         self.pack_trainables()
+        if self.n_attr > 1:
+            emb, _, _, _ = self._encode(self._stack_attrs(news, n), self.n_attr * n, False, 0, None)
+            return self._attr_mean(emb, n)[:n].clone()
         emb, _, _, _ = self._encode(news, n, False, 0, None)
         return emb[:n].clone()
 
@@ -1791,13 +1846,17 @@ class TransRecEngine:
             L.gather_rows(src[:, :2 * S_step], dst[:, :2 * S_step], n_items, 1)
             L.gather_rows(src[:, 2 * self.S0:2 * self.S0 + 2 * S_step], dst[:, 2 * S_step:], n_items, 1)
             news = dst.view(torch.int64)
-        self._pre_forward(n_items)
+        n_enc = n_items                            # rows the tower encodes: the kept items, times the news attributes
+        if self.n_attr > 1:
+            news = self._stack_attrs(news, n_items)
+            n_enc = self.n_attr * n_items
+        self._pre_forward(n_enc)
         self.pack_trainables()
         self.step_count += 1
         seed = (self.seed * 1000003 + self.step_count) & 0xFFFFFFFFFFFF
-        M = pad_to(self._pk['Mtok'], 256) if self._pk is not None else pad_to(n_items * self.S, 256)
+        M = pad_to(self._pk['Mtok'], 256) if self._pk is not None else pad_to(n_enc * self.S, 256)
         Mu = pad_to(B * (self.Lseq - 1), 128)
-        Ipc = pad_to(n_items, 128)
+        Ipc = pad_to(n_enc, 128)
         if self._saved_bert is None or self._saved_M != M or self._saved_Mu != Mu or getattr(self, '_saved_Ip', Ipc) != Ipc:
             self._saved_Ip = Ipc                   # (the item count changes from step to step when pad slots are left out)
             nb = len(self.bert_blocks)
@@ -1806,7 +1865,9 @@ class TransRecEngine:
             self._saved_sas = [self._block_bufs(f'sas.{j}', b, Mu, False) for j, b in enumerate(self.sas_blocks)]
             self._saved_M, self._saved_Mu = M, Mu
         saved_b, saved_s = self._saved_bert, self._saved_sas
-        emb, pre, key_mask, M = self._encode(news, n_items, train, seed, saved_b)
+        emb, pre, key_mask, M = self._encode(news, n_enc, train, seed, saved_b)
+        if self.n_attr > 1:
+            emb = self._attr_mean(emb, n_items)
         if n_c is not None:                        # back to the [B, L, 2] slot layout the head indexes
             emb_c = emb
             emb = self._buf('emb_full', pad_to(n_full, 128), self.E, torch.float32)
@@ -1820,7 +1881,7 @@ class TransRecEngine:
         ws = self._buf('lossws', 1, 4, torch.float32)
         L.zero(ws)
         L.score_bce_fwd(emb, prec, lm, pos, neg, ws, B, self.Lseq, self.E, self.arch == 'cpc')
-        self._ctx = dict(B=B, n_items=n_items, n_full=n_full, kidx=kidx, S=self.S, pk=self._pk, M=M, Mu=Mu, seed=seed, train=train, lm=lm, key_mask=key_mask, emb=emb, pre=pre,
+        self._ctx = dict(B=B, n_items=n_items, n_enc=n_enc, n_full=n_full, kidx=kidx, S=self.S, pk=self._pk, M=M, Mu=Mu, seed=seed, train=train, lm=lm, key_mask=key_mask, emb=emb, pre=pre,
                          prec=prec, xin=xin, pos=pos, neg=neg, ws=ws, saved_b=saved_b, saved_s=saved_s)
         return ws[0, 0].clone()
 
@@ -1978,6 +2039,9 @@ class TransRecEngine:
             d_emb_c = self._buf_tail0('d_emb_c', Ip, E, torch.float32, n_items)
             self._slots_copy(d_emb, d_emb_c, B, True, c.get('kidx'))
             d_emb = d_emb_c
+        if self.n_attr > 1:                        # the mean over the news attributes: every attribute's rows get d_emb / n_attr
+            d_emb, Ip = self._attr_spread(d_emb, n_items)
+            c = dict(c, n_items=c['n_enc'])
         self._items_backward(c, d_emb, Ip)
         self._wgrad_join()
         self._flush_corners()

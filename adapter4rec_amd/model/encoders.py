@@ -48,9 +48,11 @@ class Bert_Encoder(nn.Module):                  # encoders.py:60-99
             self.attributes2start[k] = s
             s += lengths[k]
         self.text_encoders = nn.ModuleDict({'title': Text_Encoder(bert_model, args.embedding_dim, args.word_embedding_dim)})
-        self.newsname = [n for n in set(args.news_attributes) & {'title', 'abstract', 'body'}]
-        if self.newsname != ['title']:
-            raise NotImplementedError('the shipped reference scripts only ever pass news_attributes=title')
+        # every attribute goes through the ONE Text_Encoder the reference builds ('title') and the item vector is the mean (encoders.py:89-99).  The
+        # native engine stacks the attributes as extra items at the longest attribute's length (engine.py: _stack_attrs), in this canonical order:
+        self.newsname = [n for n in ('title', 'abstract', 'body') if n in set(args.news_attributes)]
+        if not self.newsname:
+            raise ValueError(f'--news_attributes {args.news_attributes}: none of title, abstract, body')
         self._owner = [None]
 
     def forward(self, news):

@@ -96,7 +96,10 @@ class _TransRecBase(nn.Module):
     def forward(self, sample_items, log_mask, local_rank=None):
         eng = self._engine()
         eng.host_max_tokens = None
-        if not sample_items.is_cuda and sample_items.dim() == 2 and sample_items.dtype == torch.int64:
+        if not sample_items.is_cuda and sample_items.dim() == 2 and sample_items.dtype == torch.int64 and getattr(eng, 'n_attr', 1) > 1:
+            eng.host_lens = None                   # several news attributes per row: no single title length to read
+            sample_items = sample_items.to(eng.dev, non_blocking=True)
+        elif not sample_items.is_cuda and sample_items.dim() == 2 and sample_items.dtype == torch.int64:
             # the batch still on the host (run.py): the longest title among its items is read here -- a training step then runs on that many tokens
             # per item instead of --num_words_title (pad tokens never reach the CLS output) -- and the rows are uploaded
             # (numpy, not torch: a torch CPU reduction wakes the whole intra-op thread pool -- 128 threads on the GPU boxes -- and cost ~19 ms per step)

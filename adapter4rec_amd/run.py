@@ -105,8 +105,7 @@ def train(args, use_modal, local_rank, Log_file, Log_screen, model_dir, start_ti
     item_num, id2dic, users_train, users_valid, users_test, hist_valid, hist_test = read_behaviors(
         os.path.join(args.root_data_dir, args.dataset, args.behaviors), before_id2dic, before_name2id,
         args.max_seq_len, args.min_seq_len, Log_file)
-    title, mask, *_ = get_doc_input_bert(id2dic, args)
-    item_content = np.concatenate([title, mask], axis=1)
+    item_content = np.concatenate([x for x in get_doc_input_bert(id2dic, args) if x is not None], axis=1)          # run.py:130-139: [ids | mask] per attribute
     train_dataset = BuildTrainDataset(u2seq=users_train, item_content=item_content, item_num=item_num,
                                       max_seq_len=args.max_seq_len, use_modal=use_modal)
     sampler = torch.utils.data.distributed.DistributedSampler(train_dataset)
@@ -190,8 +189,7 @@ def test(args, use_modal, local_rank, Log_file, Log_screen, model_dir, start_tim
     item_num, id2dic, _, users_valid, users_test, hist_valid, hist_test = read_behaviors(
         os.path.join(args.root_data_dir, args.dataset, args.behaviors), before_id2dic, before_name2id,
         args.max_seq_len, args.min_seq_len, Log_file)
-    title, mask, *_ = get_doc_input_bert(id2dic, args)
-    item_content = np.concatenate([title, mask], axis=1)
+    item_content = np.concatenate([x for x in get_doc_input_bert(id2dic, args) if x is not None], axis=1)
     model, _, _ = build_model(args, item_num, use_modal, bert_model, local_rank, Log_file, model_dir)
     model = FlatDDP(model, device_ids=[local_rank], output_device=local_rank)
     run_eval_once(model, item_content, hist_valid, users_valid, 512, item_num, use_modal, 'valid', local_rank, args, Log_file)

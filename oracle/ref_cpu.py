@@ -41,7 +41,7 @@ DEFAULT_CFG = dict(
     adapter_type='houslby',     # sic, parameters.py:67
     adapter_activation='RELU',  # parameters.py:64
     is_serial='True',           # parameters.py:66
-    sasrec_heads=2, max_seq_len=20, embedding_dim=64, num_words_title=30,
+    sasrec_heads=2, max_seq_len=20, embedding_dim=64, num_words_title=30, num_words_abstract=50, num_words_body=50, news_attributes=['title'],
     lora_r_bert=64, lora_r_sasrec=16,
 )
 
@@ -218,8 +218,20 @@ def bert_encode(sd, ids, key_mask, cfg, return_all=False):
 
 
 def text_encoder(sd, news, cfg, return_all=False):
-    """model/encoders.py:48-57,89-99: ids || mask -> BERT -> fc(CLS) -> GELU."""
-    nw = cfg['num_words_title']
+    """model/encoders.py:48-57,89-99: ids || mask -> BERT -> fc(CLS) -> GELU.  With more than one news attribute (--news_attributes title,abstract,body,
+    encoders.py:62-99) every attribute's [ids | mask] slice -- laid out title, abstract, body, the lengths of the absent ones 0 -- goes through the
+    SAME encoder ('title': the only Text_Encoder the reference builds) and the item vector is the mean of the attributes' vectors."""
+    attrs = [a for a in ('title', 'abstract', 'body') if a in cfg.get('news_attributes', ['title'])]
+    if len(attrs) > 1:
+        assert not return_all
+        vecs, start = [], 0
+        for a in ('title', 'abstract', 'body'):
+            nw = cfg['num_words_' + a] if a in attrs else 0
+            if nw:
+                vecs.append(text_encoder(sd, news[:, start:start + 2 * nw], dict(cfg, news_attributes=['title'], num_words_title=nw)))
+            start += 2 * nw
+        return torch.stack(vecs, 1).mean(1)
+    nw = cfg['num_words_' + attrs[0]] if attrs else cfg['num_words_title']      # (Text_Encoder halves whatever slice it is given, encoders.py:49)
     ids, mask = news[:, :nw], news[:, nw:2 * nw]
     if BERT + 'com_dense.weight' in sd:          # K-Adapter, model/model.py:523-559 BertKAdaptedBertModel wraps the backbone
         inner = {(BERT + k[len(BERT + 'bert_model.'):] if k.startswith(BERT + 'bert_model.') else k): v for k, v in sd.items()}

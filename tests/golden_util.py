@@ -58,6 +58,22 @@ def load_variant(name):
     return sd, cfg, fx, trainable, batch, base
 
 
+def load_multi_attr():
+    """multi_attr.npz (tools/gen_golden_r5.py: the reference with --news_attributes title,abstract on the base.npz weights + Houlsby adapters)
+    -> (sd, cfg, fixture, trainable names, (sample_items [B * L * 2, 2 * (30 + 36)], log_mask))"""
+    from oracle.ref_cpu import DEFAULT_CFG
+    base = np.load(os.path.join(GOLDEN, 'base.npz'))
+    fx = np.load(os.path.join(GOLDEN, 'multi_attr.npz'))
+    base_sd = {k[3:]: torch.from_numpy(base[k]) for k in base.files if k.startswith('sd/')}
+    sd = {}
+    for k in fx['all_keys']:
+        k = str(k)
+        sd[strip(k)] = torch.from_numpy(fx['sd/' + k]) if 'sd/' + k in fx.files else base_sd[base_name(k)]
+    nt, na = (int(x) for x in fx['num_words'])
+    cfg = dict(DEFAULT_CFG, bert_heads=2, news_attributes=['title', 'abstract'], num_words_title=nt, num_words_abstract=na)
+    return sd, cfg, fx, [strip(str(k)) for k in fx['trainable']], (torch.from_numpy(fx['sample_items']), torch.from_numpy(fx['log_mask']))
+
+
 # ---------------------------------------------------------------- image path fixtures (tools/gen_golden_cv.py)
 CV_VARIANT_CFG = {
     'cv_vit_houlsby': dict(),

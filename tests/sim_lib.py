@@ -503,7 +503,7 @@ def phm_bwd(params, desc_dev, n_desc, grads):
 def unpack_add(target, desc_dev, n_desc, max_elems):
     for d in _parse(desc_dev, AddDesc, n_desc):
         src = torch.as_strided(_f32_at(d.src, (d.rows - 1) * d.ld + d.cols), (d.rows, d.cols), (d.ld, 1))
-        target[d.dst_off:d.dst_off + d.rows * d.cols] += d.alpha * src.reshape(-1)
+        target.view(-1)[d.dst_off:d.dst_off + d.rows * d.cols] += d.alpha * src.reshape(-1)
 
 
 def dropout_apply(x, y, drop_p, drop_site, drop_seed, M=None):

@@ -599,3 +599,39 @@ def _text_fp8_case(dev, adapter_type='houslby', act='GELU'):
 @pytest.mark.parametrize('adapter_type', ['houslby', 'pfeiffer'])
 def test_text_fp8_encoder_gpu(adapter_type):
     _text_fp8_case('cuda:0', adapter_type)
+
+
+def build_multi_attr(device, dtype='fp32'):
+    """the reference's --news_attributes title,abstract fixture (tests/golden/multi_attr.npz) loaded into this package's classes"""
+    from adapter4rec_amd.inject import freeze_all, inject_adapters
+    from adapter4rec_amd.model import BertBackbone, Model
+    from golden_util import load_multi_attr
+    sd, cfg, fx, trainable, (items, mask) = load_multi_attr()
+    args = make_args(compute_dtype=dtype, news_attributes=['title', 'abstract'], num_words_title=int(fx['num_words'][0]), num_words_abstract=int(fx['num_words'][1]))
+    torch.manual_seed(0)
+    model = Model(args, 200, True, BertBackbone(dict(GEOM)))
+    freeze_all(model)
+    root = inject_adapters(model, args)
+    root.load_state_dict({str(k): sd[strip(str(k))] for k in fx['all_keys']}, strict=True)
+    assert {n for n, p in root.named_parameters() if p.requires_grad} == {str(k) for k in fx['trainable']}
+    root.to(device)
+    root.eval()
+    return root, args, fx, items.to(device), mask.to(device)
+
+
+@pytest.mark.gpu
+def test_step_fp32_news_attributes_vs_reference_golden():
+    """--news_attributes title,abstract (encoders.py:60-99; round 5): the engine's attribute stacking against the imported reference's own numbers --
+    item embeddings (training batch and inference entry point), prec_vec, loss 1e-4; every adapter gradient 1e-4 x its max."""
+    root, args, fx, items, mask = build_multi_attr('cuda:0')
+    loss = root(items, mask, 0)
+    loss.backward()
+    assert abs(loss.item() - float(fx['loss'])) < 1e-4
+    real = (items != 0).any(1).cpu().numpy()           # (the PAD item's never-read vector: DESIGN section 7)
+    emb = root.bert_encoder(items).cpu().numpy()
+    np.testing.assert_allclose(emb[real], fx['input_embs_all'][real], atol=1e-4, rtol=0)
+    params = dict(root.named_parameters())
+    for k in fx['trainable']:
+        ref = fx['grad/' + str(k)]
+        np.testing.assert_allclose(params[str(k)].grad.cpu().numpy(), ref, atol=1e-6 + 1e-4 * np.abs(ref).max(), rtol=0, err_msg=str(k))
+

@@ -496,3 +496,72 @@ def test_host_logic_text_fp8_every_placement(simulated, name):
         g8 = res['fp8'][1][n]
         assert torch.isfinite(g8).all(), n
         assert float((g8 - g).abs().max()) <= 0.5 * float(g.abs().max()) + 1e-6, n
+
+
+@pytest.mark.parametrize('attrs', [('title', 'abstract'), ('title', 'abstract', 'body'), ('body',)])
+def test_host_logic_news_attributes(simulated, attrs):
+    """--news_attributes with more than the title (encoders.py:62-99: every attribute through the one Text_Encoder, item vector = their mean): the
+    engine stacks the attributes as extra items at the longest attribute's length.  Toy geometry, kernels simulated: loss and every gradient against
+    the CPU oracle, through the training entry point with the rows on the host and through the inference entry point."""
+    import adapter4rec_amd.inject as I
+    from adapter4rec_amd.model import BertBackbone, Model
+    from oracle import ref_cpu as R
+    torch.manual_seed(7)
+    args = TG.make_args(compute_dtype='fp32', **TG.ARGS['houlsby'])
+    args.news_attributes, args.num_words_title, args.num_words_abstract, args.num_words_body = list(attrs), 12, 20, 16
+    model = Model(args, 200, True, BertBackbone(dict(TG.GEOM)))
+    I.freeze_all(model)
+    root = I.inject_adapters(model, args)
+    with torch.no_grad():
+        for n, p in root.named_parameters():
+            if p.requires_grad:
+                p.add_(0.02 * torch.randn_like(p))
+    root.eval()
+    lens = [w for a, w in zip(('title', 'abstract', 'body'), (12, 20, 16)) if a in attrs]
+    g = torch.Generator().manual_seed(3)
+    B, Lq, width = 2, args.max_seq_len + 1, 2 * sum(lens)
+    ids = torch.zeros(B, Lq, 2, width, dtype=torch.int64)
+    mask = torch.zeros(B, Lq - 1)
+    for u, n in enumerate((Lq, 6)):
+        for slot in range(Lq - n, Lq):
+            for side in range(2):
+                if side == 1 and slot == Lq - 1:
+                    continue
+                st = 0
+                for w in lens:
+                    ln = int(torch.randint(3, w + 1, (1,), generator=g))
+                    ids[u, slot, side, st:st + ln] = torch.randint(5, 90, (ln,), generator=g)
+                    ids[u, slot, side, st + w:st + w + ln] = 1
+                    st += 2 * w
+        mask[u, Lq - n:] = 1
+    items = ids.view(-1, width)
+    sd = {strip(k): v.detach().clone() for k, v in root.state_dict().items()}
+    names = [n for n, p in root.named_parameters() if p.requires_grad]
+    cfg = dict(R.DEFAULT_CFG, **TG.CFG['houlsby']) if hasattr(TG, 'CFG') else dict(R.DEFAULT_CFG)
+    cfg.update(bert_heads=TG.GEOM['num_attention_heads'], news_attributes=list(attrs), num_words_title=12, num_words_abstract=20, num_words_body=16,
+               max_seq_len=args.max_seq_len, embedding_dim=args.embedding_dim, sasrec_heads=args.num_attention_heads,
+               adapter_activation=args.adapter_activation)
+    out, grads = R.loss_and_grads(sd, [strip(n) for n in names], items, mask, cfg)
+    loss = root(items, mask, 'cpu')
+    loss.backward()
+    assert abs(loss.item() - float(out['loss'].detach())) < 1e-4
+    params = dict(root.named_parameters())
+    for n in names:
+        ref = grads[strip(n)].numpy()
+        np.testing.assert_allclose(params[n].grad.numpy(), ref, atol=1e-6 + 1e-4 * np.abs(ref).max(), rtol=0, err_msg=n)
+    real = (items != 0).any(1)
+    emb = getattr(root, 'model', root).bert_encoder(items)
+    np.testing.assert_allclose(emb[real].numpy(), out['input_embs_all'].detach()[real].numpy(), atol=1e-4, rtol=0)
+
+
+def test_host_logic_news_attributes_vs_reference_golden(simulated):
+    """the same fixture through the simulated kernels (CPU): the engine's attribute stacking, the mean and its backward"""
+    root, args, fx, items, mask = TG.build_multi_attr('cpu')
+    loss = root(items, mask, 'cpu')
+    loss.backward()
+    assert abs(loss.item() - float(fx['loss'])) < 1e-4
+    params = dict(root.named_parameters())
+    for k in fx['trainable']:
+        ref = fx['grad/' + str(k)]
+        np.testing.assert_allclose(params[str(k)].grad.numpy(), ref, atol=1e-6 + 1e-4 * np.abs(ref).max(), rtol=0, err_msg=str(k))
+

@@ -200,3 +200,25 @@ def test_autocast_fixture_is_a_reduced_precision_run_of_the_same_step(name):
     assert 1e-4 < rel.max() < 0.2
     keys = [k for k in ac.files if k.startswith('grad/')]
     assert len(keys) == len(rel) == len([k for k in fx.files if k.startswith('grad/')])
+
+
+def test_multi_attribute_news_vs_reference():
+    """--news_attributes title,abstract (Downstream/Text/model/encoders.py:60-99): the oracle's multi-attribute branch against the imported reference's
+    own Bert_Encoder / Model (tests/golden/multi_attr.npz, tools/gen_golden_r5.py): per-attribute vectors, their mean, prec_vec, loss, every gradient."""
+    from golden_util import load_multi_attr
+    from oracle import ref_cpu as R
+    sd, cfg, fx, trainable, (items, mask) = load_multi_attr()
+    nt = int(fx['num_words'][0])
+    with torch.no_grad():
+        tv = R.text_encoder(sd, items[:, :2 * nt], dict(cfg, news_attributes=['title']))
+        av = R.text_encoder(sd, items[:, 2 * nt:], dict(cfg, news_attributes=['abstract']))
+    np.testing.assert_allclose(tv.numpy(), fx['title_vec'], atol=1e-4, rtol=0)
+    np.testing.assert_allclose(av.numpy(), fx['abstract_vec'], atol=1e-4, rtol=0)
+    out, grads = R.loss_and_grads(sd, trainable, items, mask, cfg)
+    assert abs(float(out['loss'].detach()) - float(fx['loss'])) < 1e-4
+    np.testing.assert_allclose(out['input_embs_all'].detach().numpy(), fx['input_embs_all'], atol=1e-4, rtol=0)
+    np.testing.assert_allclose(out['prec_vec'].detach().numpy(), fx['prec_vec'], atol=1e-4, rtol=0)
+    for k in fx['trainable']:
+        ref = fx['grad/' + str(k)]
+        np.testing.assert_allclose(grads[strip(str(k))].numpy(), ref, atol=1e-6 + 1e-4 * np.abs(ref).max(), rtol=0, err_msg=str(k))
+

@@ -909,3 +909,70 @@ def test_other_user_tower_depths_and_history_lengths_fp32_vs_oracle(blocks, max_
     e_b, where_b = grad_err(b['grads'], ref['grads'])
     assert abs(b['loss'] - ref['loss']) < 5e-2 and e_b < 0.25, (b['loss'], e_b, where_b)
 
+
+def multi_attr_case(attrs, nw=(30, 50, 50), users=2, seed=111, adapter_type='houslby'):
+    """BERT-mini + adapters with --news_attributes `attrs`: rows are [ids | mask] per attribute, laid out title, abstract, body (encoders.py:62-78)"""
+    from adapter4rec_amd.inject import freeze_all, inject_adapters
+    from adapter4rec_amd.model import BERT_BASE, BertBackbone, Model
+    from base_cases import text_args
+    torch.manual_seed(seed)
+    args = text_args('fp32', 'GELU', adapter_type=adapter_type)
+    args.word_embedding_dim, args.bert_model_load, args.news_attributes = 256, 'bert_mini_uncased', list(attrs)
+    args.num_words_title, args.num_words_abstract, args.num_words_body = nw
+    model = Model(args, 512, True, BertBackbone(dict(BERT_BASE, hidden_size=256, num_hidden_layers=4, num_attention_heads=4, intermediate_size=1024)))
+    freeze_all(model)
+    model = inject_adapters(model, model.args)
+    with torch.no_grad():
+        for n, p in model.named_parameters():
+            if p.requires_grad:
+                p.add_(0.02 * torch.randn_like(p))
+    model.eval()
+    g = torch.Generator().manual_seed(seed)
+    Lq = 21
+    lens = [w for a, w in zip(('title', 'abstract', 'body'), nw) if a in attrs]
+    width = 2 * sum(lens)
+    ids = torch.zeros(users, Lq, 2, width, dtype=torch.int64)
+    mask = torch.zeros(users, Lq - 1)
+    for u in range(users):
+        n = Lq if u == 0 else 8
+        for slot in range(Lq - n, Lq):
+            for side in range(2):
+                if side == 1 and slot == Lq - 1:
+                    continue
+                st = 0
+                for w in lens:
+                    ln = w if (slot + side) % 4 == 0 else int(torch.randint(3, w + 1, (1,), generator=g))
+                    ids[u, slot, side, st] = 101
+                    ids[u, slot, side, st + 1:st + ln - 1] = torch.randint(1000, 30000, (ln - 2,), generator=g)
+                    ids[u, slot, side, st + ln - 1] = 102
+                    ids[u, slot, side, st + w:st + w + ln] = 1
+                    st += 2 * w
+        mask[u, Lq - n:] = 1
+    cfg = dict(adapter_activation='GELU', bert_heads=4, news_attributes=list(attrs), num_words_title=nw[0], num_words_abstract=nw[1], num_words_body=nw[2],
+               adapter_type=adapter_type)
+    return model, ids.view(-1, width), mask, cfg
+
+
+@pytest.mark.parametrize('attrs,nw', [(('title', 'abstract'), (30, 50, 50)), (('title', 'abstract', 'body'), (30, 50, 50)), (('abstract',), (30, 50, 50)),
+                                      (('title', 'body'), (30, 50, 20)), (('title', 'abstract'), (20, 30, 50))])
+def test_news_attributes_step_and_items_fp32_vs_oracle(attrs, nw):
+    """--news_attributes with more than the title (parameters.py:47, model/encoders.py:62-99: every attribute through the one Text_Encoder, item vector =
+    their mean; round 5, before: NotImplementedError).  The engine stacks the attributes as extra items at the longest attribute's length; fp32 vs the
+    CPU oracle -- loss, item embeddings (training batch AND the inference entry point), every gradient -- and bf16 inside the base geometry's bounds."""
+    from oracle import ref_cpu as R
+    model, items, mask, ocfg = multi_attr_case(attrs, nw)
+    sd = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    names = [n for n, p in model.named_parameters() if p.requires_grad]
+    out, grads = R.loss_and_grads(sd, names, items, mask, dict(R.DEFAULT_CFG, **ocfg))
+    ref = dict(loss=float(out['loss'].detach()), emb=out['input_embs_all'].detach(), grads=grads)
+    o = hip_step(model, 'fp32', items, mask)
+    e_g, where = grad_err(o['grads'], ref['grads'])
+    real = (items != 0).any(1)                      # (the PAD item -- no attended token in any attribute -- attends uniformly over the step's token count, the
+    e_emb = float((o['emb'] - ref['emb'])[real].abs().max())      # longest attribute's here: its never-read vector is not the reference's, DESIGN section 7)
+    print(f'{"+".join(attrs)} {nw} fp32: loss {abs(o["loss"] - ref["loss"]):.1e}, embeddings {e_emb:.1e}, worst gradient {e_g:.1e} ({where})')
+    assert abs(o['loss'] - ref['loss']) < 1e-4 and e_emb < 1e-4
+    assert e_g < 2e-4, (e_g, where)
+    b = hip_step(model, 'bf16', items, mask)
+    e_b, where_b = grad_err(b['grads'], ref['grads'])
+    assert abs(b['loss'] - ref['loss']) < 5e-2 and e_b < 0.25, (b['loss'], e_b, where_b)
+

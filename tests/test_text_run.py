@@ -62,6 +62,33 @@ def test_text_host_readers(tmp_path):
     assert title.shape == (item_num + 1, 30) and (title[1:, 0] == 2).all() and (mask.sum(1)[1:] >= 5).all()      # [CLS] first, >= 3 words + 2
 
 
+def test_text_host_readers_news_attributes(tmp_path):
+    """abstract / body as the optional 3rd / 4th columns of the news file (the reference's reader names them without ever splitting them off,
+    preprocess.py:85-103): the per-attribute [ids | mask] matrices in the order run.py:134-139 concatenates them; a missing column is an error."""
+    from transformers import BertTokenizer
+    from adapter4rec_amd.data_utils import get_doc_input_bert, read_news_bert
+    from adapter4rec_amd.parameters import parse_args
+    data = write_toy(str(tmp_path))
+    tok = BertTokenizer.from_pretrained(str(tmp_path / 'pretrained_models' / 'bert' / 'bert_tiny'))
+    src = os.path.join(data, 'toy', 'news.tsv')
+    rows = [l.rstrip('\n').split('\t') for l in open(src)]
+    four = os.path.join(data, 'toy', 'news4.tsv')
+    with open(four, 'w') as f:
+        for name, title in rows:
+            f.write(f'{name}\t{title}\t{title} {title}\t{title} ' * 1 + f'{title} {title}\n')
+    args = parse_args(['--num_words_title', '30', '--num_words_abstract', '50', '--num_words_body', '40', '--news_attributes', 'title,abstract,body'])
+    id2dic, _ = read_news_bert(four, args, tok)
+    t, tm, a, am, b, bm = get_doc_input_bert(id2dic, args)
+    n = len(rows) + 1
+    assert t.shape == (n, 30) and a.shape == am.shape == (n, 50) and b.shape == bm.shape == (n, 40)
+    assert (am.sum(1)[1:] >= tm.sum(1)[1:]).all() and (a[1:, 0] == t[1:, 0]).all()
+    content = np.concatenate([x for x in (t, tm, a, am, b, bm) if x is not None], axis=1)
+    assert content.shape == (n, 2 * (30 + 50 + 40))
+    args.news_attributes = ['title', 'abstract']
+    with pytest.raises(ValueError):
+        read_news_bert(src, args, tok)                          # two columns only
+
+
 def _run(argv, monkeypatch, record):
     import torch.distributed as dist
     from adapter4rec_amd import run
