@@ -18,7 +18,7 @@ ACT_NONE, ACT_RELU, ACT_GELU, ACT_GELU_TANH, ACT_LEAKY = 0, 1, 2, 3, 4
 DACT_MUL = 15
 DACT_MUL_Q8 = 14          # Pre = the uint8 derivative tensor a c2_deriv='q8' launch wrote (include/a4r.h: c2_mode 2)
 Q8_OFF, Q8_STEP = 0.1289, 0.0049326
-EVAL_MAX_HISTORY = 64          # A4R_EVAL_MAX_HISTORY (include/a4r.h)
+EVAL_MAX_HISTORY = 264         # A4R_EVAL_MAX_HISTORY (include/a4r.h)
 ACT_BY_NAME = {'none': 0, 'relu': 1, 'RELU': 1, 'gelu': 2, 'GELU': 2, 'gelu_new': 3, 'leaky_relu': 4}
 
 EXPORTS = [
@@ -330,21 +330,21 @@ def attn_bwd(qkv, dout, dqkv, key_mask, n_items, S, n_heads, dh, q_off, k_off, v
     _check(lib().a4r_attn_bwd(_stream(), C.byref(a)), 'a4r_attn_bwd')
 
 
-def attn_long_fwd(qkv, out, lse, n_items, S, n_heads, dh, q_off, k_off, v_off, scale, drop_p=0.0, drop_site=0, drop_seed=0, key_mask=None):
+def attn_long_fwd(qkv, out, lse, n_items, S, n_heads, dh, q_off, k_off, v_off, scale, drop_p=0.0, drop_site=0, drop_seed=0, key_mask=None, causal=False):
     """key_mask (fp32 [n_items, S], 1 = attend; optional, head width 64): HF's attention_mask -- text towers with more than 32 tokens per title"""
     require_gpu(qkv, out, lse, key_mask)
     assert lse.dtype == torch.float32 and lse.numel() >= n_items * n_heads * S
-    a = _attn_args(qkv, q_off, k_off, v_off, key_mask, n_items, S, n_heads, dh, False, scale, 0.0, drop_p, drop_site, drop_seed)
+    a = _attn_args(qkv, q_off, k_off, v_off, key_mask, n_items, S, n_heads, dh, causal, scale, 0.0, drop_p, drop_site, drop_seed)
     a.out, a.ldo = _p(out), _ld(out)
     _check(lib().a4r_attn_long_fwd(_stream(), C.byref(a), _p(lse)), 'a4r_attn_long_fwd')
 
 
 def attn_long_bwd(qkv, out, dout, dqkv, lse, delta_ws, n_items, S, n_heads, dh, q_off, k_off, v_off, scale,
-                  drop_p=0.0, drop_site=0, drop_seed=0, key_mask=None):
+                  drop_p=0.0, drop_site=0, drop_seed=0, key_mask=None, causal=False):
     """out: the ctx attn_long_fwd wrote (backward takes delta = dO . O from it)."""
     require_gpu(qkv, out, dout, dqkv, lse, delta_ws, key_mask)
     assert _ld(dqkv) == _ld(qkv) and delta_ws.dtype == torch.float32 and delta_ws.numel() >= n_items * n_heads * S
-    a = _attn_args(qkv, q_off, k_off, v_off, key_mask, n_items, S, n_heads, dh, False, scale, 0.0, drop_p, drop_site, drop_seed)
+    a = _attn_args(qkv, q_off, k_off, v_off, key_mask, n_items, S, n_heads, dh, causal, scale, 0.0, drop_p, drop_site, drop_seed)
     assert _ld(out) == _ld(dout)
     a.out, a.dout, a.ldo, a.dqkv = _p(out), _p(dout), _ld(dout), _p(dqkv)
     _check(lib().a4r_attn_long_bwd(_stream(), C.byref(a), _p(lse), _p(delta_ws)), 'a4r_attn_long_bwd')

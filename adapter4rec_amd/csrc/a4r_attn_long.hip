@@ -270,15 +270,21 @@ A4R_DEV void scores_t(const char* Kr, const uint4 (&qf)[Geo<T, DH>::KS], f32x4_t
 // The item's key mask (HF attention_mask: 1 = attend; Downstream/Text/model/encoders.py:48-57), staged to LDS by the workgroup.  Masked keys get
 // probability 0 (HF adds finfo.min to their scores); an item with NO attended key -- the pad item -- attends uniformly over its S keys, as HF's
 // softmax over S equal scores does: its raw scores are replaced by 0 in the forward and in both backward kernels, so lse = log S recomputes P = 1 / S.
-// Returns whether the item has no attended key (wave-uniform; call before the workgroup's first __syncthreads, read km after it).
 template <int SP, int NTHR> A4R_DEV void stage_key_mask(float* km, const float* kmask, int item, int S, int tid) {
     for (int i = tid; i < SP; i += NTHR) km[i] = i < S ? kmask[(size_t)item * S + i] : 0.f;
 }
-template <int SP> A4R_DEV bool none_attended(const float* km, int lane) {
-    float c = 0.f;
-    for (int i = lane; i < SP; i += 64) c += km[i] != 0.f ? 1.f : 0.f;
-    return __ballot(c > 0.f) == 0ull;
+// index of the item's first attended key (SP when it has none), the same value in every lane
+template <int SP> A4R_DEV int first_attended(const float* km, int lane) {
+    int f = SP;
+    for (int i = lane; i < SP; i += 64) f = (km[i] != 0.f && i < f) ? i : f;
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) { const int o = __shfl_xor(f, d, 64); f = o < f ? o : f; }
+    return f;
 }
+// CAUSAL (round 5, with a key mask only: the user tower at --max_seq_len > 32, model/modules.py:31-42 with the mask of model/encoders.py:24-28): key k
+// is allowed for query q when the mask has it AND k <= q.  A query row without any allowed key (the left-padded positions of a short history: q below
+// the first attended key; without causal: an item without attended keys) attends uniformly over the S keys in the forward -- the reference adds -1e9
+// to every score of such a row, which leaves them equal -- and contributes nothing to the backward (its output gradient is zero behind the loss mask).
 
 struct Drop { uint64_t seed; uint32_t site, thr16; float keep_scale; };
 
@@ -286,7 +292,7 @@ struct Drop { uint64_t seed; uint32_t site, thr16; float keep_scale; };
 template <typename T, int DH, int NKT, bool KM = false>      // KM: the launch carries a key mask (text towers; instantiated for head width 64)
 __global__ void __launch_bounds__(WG<NKT>::NTHR, 4) attn_long_fwd_kernel(const T* __restrict__ qkv, int ld, int q_off, int k_off, int v_off,
                                                             T* __restrict__ ctx, int ldo, float* __restrict__ lse,
-                                                            int S, int nh, float scale, Drop dr, const float* __restrict__ kmask) {
+                                                            int S, int nh, float scale, Drop dr, const float* __restrict__ kmask, int causal) {
     using G = Geo<T, DH>;
     constexpr int NTHR = WG<NKT>::NTHR, NWAVE = WG<NKT>::NWAVE;
     constexpr int SP = NKT * 16, SPT = SP + 8, NST = SP / G::KSTEP;
@@ -317,8 +323,8 @@ __global__ void __launch_bounds__(WG<NKT>::NTHR, 4) attn_long_fwd_kernel(const T
     [[maybe_unused]] float* km = reinterpret_cast<float*>(smem + lds_main_fwd<T, DH, NKT>() - lds_km<NKT>());
     if constexpr (KM) stage_key_mask<SP, NTHR>(km, kmask, item, S, tid);
     __syncthreads();
-    bool none = false;
-    if constexpr (KM) none = none_attended<SP>(km, lane);
+    int first = 0;
+    if constexpr (KM) first = first_attended<SP>(km, lane);
     for (int qb = wave; qb < nqb; qb += NWAVE) {
         const int rq = qb * 16 + fr;
         const bool valid = rq < S;
@@ -329,11 +335,16 @@ __global__ void __launch_bounds__(WG<NKT>::NTHR, 4) attn_long_fwd_kernel(const T
         f32x4_t s[NKT];
         scores_t<T, DH, NKT>(Kr, qf, s, S, fr, kg);
         if constexpr (KM) {
+            const bool empty = causal ? rq < first : first >= S;          // this query has no allowed key
+            const int kmax = causal ? rq : SP;
 #pragma unroll
             for (int kt = 0; kt < NKT; ++kt) {
                 const f32x4_t m4 = *reinterpret_cast<const f32x4_t*>(km + kt * 16 + kg * 4);
 #pragma unroll
-                for (int r = 0; r < 4; ++r) s[kt][r] = none ? (kt * 16 + kg * 4 + r < S ? 0.f : -INFINITY) : (m4[r] != 0.f ? s[kt][r] : -INFINITY);
+                for (int r = 0; r < 4; ++r) {
+                    const int key = kt * 16 + kg * 4 + r;
+                    s[kt][r] = empty ? (key < S ? 0.f : -INFINITY) : ((m4[r] != 0.f && key <= kmax) ? s[kt][r] : -INFINITY);
+                }
             }
         }
         float m = -INFINITY;
@@ -400,7 +411,7 @@ template <typename T, int DH, int NKT, bool KM = false>      // KM: the launch c
 __global__ void __launch_bounds__(WG<NKT>::NTHR, 4) attn_long_dq_kernel(const T* __restrict__ qkv, int ld, int q_off, int k_off, int v_off,
                                                            const T* __restrict__ dctx, int ldo, const T* __restrict__ octx,
                                                            const float* __restrict__ lse, float* __restrict__ delta,
-                                                           T* __restrict__ dqkv, int S, int nh, float scale, Drop dr, const float* __restrict__ kmask) {
+                                                           T* __restrict__ dqkv, int S, int nh, float scale, Drop dr, const float* __restrict__ kmask, int causal) {
     using G = Geo<T, DH>;
     constexpr int NTHR = WG<NKT>::NTHR, NWAVE = WG<NKT>::NWAVE;
     constexpr int SP = NKT * 16, SPT = SP + 8, NST = SP / G::KSTEP;
@@ -442,13 +453,15 @@ __global__ void __launch_bounds__(WG<NKT>::NTHR, 4) attn_long_dq_kernel(const T*
     [[maybe_unused]] float* km = reinterpret_cast<float*>(smem + lds_main_dq<T, DH, NKT>() - lds_km<NKT>());
     if constexpr (KM) stage_key_mask<SP, NTHR>(km, kmask, item, S, tid);
     __syncthreads();
-    bool none = false;
-    if constexpr (KM) none = none_attended<SP>(km, lane);
+    int first = 0;
+    if constexpr (KM) first = first_attended<SP>(km, lane);
     const float c2 = scale * 1.44269504088896f;
     const f32x4_t c2v = {c2, c2, c2, c2};
     for (int qb = wave; qb < nqb; qb += NWAVE) {
         const int rq = qb * 16 + fr;
         const bool valid = rq < S;
+        [[maybe_unused]] const bool empty = KM && (causal ? rq < first : first >= S);
+        [[maybe_unused]] const int kmax = causal ? rq : SP;
         if (qb != wave) request_rows(qb);
         uint4 qf[G::KS], dof[G::KS], of[G::KS];
 #pragma unroll
@@ -509,14 +522,14 @@ __global__ void __launch_bounds__(WG<NKT>::NTHR, 4) attn_long_dq_kernel(const T*
 #pragma unroll
                     for (int j = 0; j < HALF; ++j) tf[0][j] = frag_T<T, DH>(Kimg, SPT, j * 16, st, lane);
                 }
-                if constexpr (KM) { if (none) sc = f32x4_t{0.f, 0.f, 0.f, 0.f}; }        // (an item without attended keys: the forward's convention)
+                if constexpr (KM) { if (empty) sc = f32x4_t{0.f, 0.f, 0.f, 0.f}; }       // (a query without allowed keys: the forward's convention)
                 f32x4_t pv = __builtin_elementwise_fma(sc, c2v, lqv);                   // P = exp(scale s - lse)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) pv[r] = __builtin_amdgcn_exp2f(pv[r]);
-                if constexpr (KM) if (!none) {
+                if constexpr (KM) if (!empty) {
                     const f32x4_t m4 = *reinterpret_cast<const f32x4_t*>(km + kt * 16 + kg * 4);
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) pv[r] = m4[r] != 0.f ? pv[r] : 0.f;
+                    for (int r = 0; r < 4; ++r) pv[r] = (m4[r] != 0.f && kt * 16 + kg * 4 + r <= kmax) ? pv[r] : 0.f;
                 }
                 if (kt >= kt_partial_lo<NKT>() && kt * 16 + 16 > S) {                    // wave-uniform: the last one or two tiles
                     asm volatile("" ::: "memory");
@@ -557,7 +570,7 @@ template <typename T, int DH, int NKT, bool KM = false>      // KM: the launch c
 __global__ void __launch_bounds__(WG<NKT>::NTHR, 4) attn_long_dkdv_kernel(const T* __restrict__ qkv, int ld, int q_off, int k_off, int v_off,
                                                              const T* __restrict__ dctx, int ldo, const float* __restrict__ lse,
                                                              const float* __restrict__ delta, T* __restrict__ dqkv,
-                                                             int S, int nh, float scale, Drop dr, const float* __restrict__ kmask) {
+                                                             int S, int nh, float scale, Drop dr, const float* __restrict__ kmask, int causal) {
     using G = Geo<T, DH>;
     constexpr int NTHR = WG<NKT>::NTHR, NWAVE = WG<NKT>::NWAVE;
     constexpr int SP = NKT * 16, SPT = SP + 8, NG = SP / G::KSTEP;          // NG query groups of KSTEP queries
@@ -603,8 +616,8 @@ __global__ void __launch_bounds__(WG<NKT>::NTHR, 4) attn_long_dkdv_kernel(const 
     [[maybe_unused]] float* km = reinterpret_cast<float*>(smem + lds_main_dkdv<T, DH, NKT>() - lds_km<NKT>());
     if constexpr (KM) stage_key_mask<SP, NTHR>(km, kmask, item, S, tid);
     __syncthreads();
-    bool none = false;
-    if constexpr (KM) none = none_attended<SP>(km, lane0);
+    int first = 0;
+    if constexpr (KM) first = first_attended<SP>(km, lane0);
     const float c2 = scale * 1.44269504088896f;
     const f32x4_t c2v = {c2, c2, c2, c2};
     for (int kt = wave; kt < nkt; kt += NWAVE) {
@@ -649,11 +662,23 @@ __global__ void __launch_bounds__(WG<NKT>::NTHR, 4) attn_long_dkdv_kernel(const 
 #pragma unroll
                     for (int j = 0; j < HALF; ++j) tf[0][j] = frag_T<T, DH>(Oimg, SPT, j * 16, g, lane);
                 }
-                if constexpr (KM) { if (none) sc = f32x4_t{0.f, 0.f, 0.f, 0.f}; }
+                if constexpr (KM) {                            // rows = queries q0 + 4 kg + r, this lane's key = 16 kt + fr
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) if (causal ? q0 + kg * 4 + r < first : first >= S) sc[r] = 0.f;
+                }
                 f32x4_t pv = __builtin_elementwise_fma(sc, c2v, l4), dsv;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) pv[r] = __builtin_amdgcn_exp2f(pv[r]);
-                if constexpr (KM) { if (!none && km[kt * 16 + fr] == 0.f) pv = f32x4_t{0.f, 0.f, 0.f, 0.f}; }       // this lane's key is masked
+                if constexpr (KM) {
+                    const int key = kt * 16 + fr;
+                    const bool kon = km[key] != 0.f;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int q = q0 + kg * 4 + r;
+                        const bool empty = causal ? q < first : first >= S;
+                        if (!empty && !(kon && (!causal || key <= q))) pv[r] = 0.f;
+                    }
+                }
                 if (dr.thr16) {                               // here the tile's 4 rows are 4 QUERIES at one key: one hash each
                     const int ol = opaque_lane(lane), ork = kt * 16 + (ol & 15), okg = ol >> 4;
 #pragma unroll
@@ -732,15 +757,12 @@ template <typename T, int DH, int NKT, bool KM> int run_fwd_km(hipStream_t s, co
     const size_t lds = lds_fwd<T, DH, NKT>();
     if (int rc = set_lds(attn_long_fwd_kernel<T, DH, NKT, KM>, lds)) return rc;
     hipLaunchKernelGGL((attn_long_fwd_kernel<T, DH, NKT, KM>), dim3(a->n_items * a->n_heads), dim3(WG<NKT>::NTHR), lds, s, (const T*)a->qkv, a->ld, a->q_off,
-                       a->k_off, a->v_off, (T*)a->out, a->ldo, lse, a->S, a->n_heads, a->scale, drop_of(a), (const float*)a->key_mask);
+                       a->k_off, a->v_off, (T*)a->out, a->ldo, lse, a->S, a->n_heads, a->scale, drop_of(a), (const float*)a->key_mask, a->causal);
     return a4r_launch_status();
 }
 template <typename T, int DH, int NKT> int run_fwd(hipStream_t s, const a4r_attn_t* a, float* lse) {
     if (!s_fits<NKT>(a->S)) return A4R_EINVAL;
-    if (a->key_mask) {
-        if constexpr (DH == 64) return run_fwd_km<T, DH, NKT, true>(s, a, lse);
-        else return A4R_EINVAL;                               // (masked form: head width 64 only -- every BERT size of run.py:100-114)
-    }
+    if (a->key_mask) return run_fwd_km<T, DH, NKT, true>(s, a, lse);
     return run_fwd_km<T, DH, NKT, false>(s, a, lse);
 }
 template <typename T, int DH, int NKT, bool KM> int run_bwd_km(hipStream_t s, const a4r_attn_t* a, const float* lse, float* delta) {
@@ -749,23 +771,20 @@ template <typename T, int DH, int NKT, bool KM> int run_bwd_km(hipStream_t s, co
     if (int rc = set_lds(attn_long_dkdv_kernel<T, DH, NKT, KM>, l2)) return rc;
     const dim3 grid(a->n_items * a->n_heads), block(WG<NKT>::NTHR);
     hipLaunchKernelGGL((attn_long_dq_kernel<T, DH, NKT, KM>), grid, block, l1, s, (const T*)a->qkv, a->ld, a->q_off, a->k_off, a->v_off,
-                       (const T*)a->dout, a->ldo, (const T*)a->out, lse, delta, (T*)a->dqkv, a->S, a->n_heads, a->scale, drop_of(a), (const float*)a->key_mask);
+                       (const T*)a->dout, a->ldo, (const T*)a->out, lse, delta, (T*)a->dqkv, a->S, a->n_heads, a->scale, drop_of(a), (const float*)a->key_mask, a->causal);
     hipLaunchKernelGGL((attn_long_dkdv_kernel<T, DH, NKT, KM>), grid, block, l2, s, (const T*)a->qkv, a->ld, a->q_off, a->k_off, a->v_off,
-                       (const T*)a->dout, a->ldo, lse, (const float*)delta, (T*)a->dqkv, a->S, a->n_heads, a->scale, drop_of(a), (const float*)a->key_mask);
+                       (const T*)a->dout, a->ldo, lse, (const float*)delta, (T*)a->dqkv, a->S, a->n_heads, a->scale, drop_of(a), (const float*)a->key_mask, a->causal);
     return a4r_launch_status();
 }
 template <typename T, int DH, int NKT> int run_bwd(hipStream_t s, const a4r_attn_t* a, const float* lse, float* delta) {
     if (!s_fits<NKT>(a->S)) return A4R_EINVAL;
-    if (a->key_mask) {
-        if constexpr (DH == 64) return run_bwd_km<T, DH, NKT, true>(s, a, lse, delta);
-        else return A4R_EINVAL;
-    }
+    if (a->key_mask) return run_bwd_km<T, DH, NKT, true>(s, a, lse, delta);
     return run_bwd_km<T, DH, NKT, false>(s, a, lse, delta);
 }
 
 int check(const a4r_attn_t* a, bool bwd) {
     if (!a || !a->qkv || a->n_items <= 0 || a->S <= 0 || a->S > 256 || (a->dh != 64 && a->dh != 32) || a->n_heads <= 0) return A4R_EINVAL;
-    if (a->causal || a->offsets) return A4R_EINVAL;                                // no causal form, no packed items; key_mask (fp32 [n_items, S], optional): text towers with titles of more than 32 tokens
+    if (a->offsets || (a->causal && !a->key_mask)) return A4R_EINVAL;              // no packed items; causal only together with a key mask (the user tower); key_mask (fp32 [n_items, S], optional)
     if (a->key_mask && (reinterpret_cast<uintptr_t>(a->key_mask) & 3u)) return A4R_EINVAL;
     if (a->drop_p < 0.f || a->drop_p >= 1.f) return A4R_EINVAL;
     if ((int64_t)a->n_items * a->n_heads >= (1ll << 40)) return A4R_EINVAL;        // dropout counter: 40 + 8 + 8 bits

@@ -14,7 +14,7 @@
 
 namespace {
 
-constexpr int MAXH = A4R_EVAL_MAX_HISTORY;   // history ids per user kept in LDS (reference keeps <= max_seq_len + 2 = 22; the engine allows max_seq_len <= 32)
+constexpr int MAXH = A4R_EVAL_MAX_HISTORY;   // history ids per user kept in LDS (reference keeps <= max_seq_len + 2 = 22; the engine allows max_seq_len <= 255)
 
 template <int E>
 __global__ void __launch_bounds__(256) eval_rank_kernel(const float* __restrict__ prec, const float* __restrict__ item_emb,
@@ -28,12 +28,11 @@ __global__ void __launch_bounds__(256) eval_rank_kernel(const float* __restrict_
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r16 = lane & 15, kg = lane >> 4;
     const int u0 = blockIdx.x * 16;
-    if (tid < 16) {
-        const int u = min(u0 + tid, U - 1);
+    {   // 16 threads per user copy its history ids
+        const int ul = tid >> 4, u = min(u0 + ul, U - 1);
         const int b = hist_ptr[u], n = min(hist_ptr[u + 1] - b, MAXH);
-        nhist[tid] = n;
-        for (int j = 0; j < n; ++j) hist[tid][j] = hist_idx[b + j];
-        cnt[tid] = 0;
+        for (int j = tid & 15; j < n; j += 16) hist[ul][j] = hist_idx[b + j];
+        if ((tid & 15) == 0) { nhist[ul] = n; cnt[ul] = 0; }
     }
     // A operand: 16 users x E, lane (user r16, kg) holds chunk (ks*4 + kg)
     uint4 ua[KS];

@@ -703,7 +703,8 @@ class TransRecEngine:
         te = self.model.user_encoder.transformer_encoder
         E, nh = self.E, self.args.num_attention_heads
         # (head widths 128 / 256: --embedding_dim 256 / 512 with the default two heads, parameters.py:27-28 -- fp32 instantiations of the short attention kernel)
-        if (E // nh) not in (32, 64, 128, 256) or E % nh or self.Lseq - 1 > 32:
+        # (histories of more than 32 items, --max_seq_len > 32: the causal, key-masked form of the long attention kernels, head width 32 / 64)
+        if (E // nh) not in (32, 64, 128, 256) or E % nh or self.Lseq - 1 > 256 or (self.Lseq - 1 > 32 and (E // nh) not in (32, 64)):
             raise NotImplementedError(f'SASRec geometry E={E} heads={nh} T={self.Lseq - 1}')
         pe = te.position_embedding.weight
         self.pos_emb = pe.data if pe.requires_grad else self._f32(pe)
@@ -788,7 +789,7 @@ class TransRecEngine:
         dh = Hv // nh
         long = S > 32                 # K-Adapter blocks over the ViT token rows (S = 197 / 50): a4r_attn_long_*, no mask, dh 64 / 32
         wide = dh in (128, 256) and dt == torch.float32 and not long          # (the user tower at --embedding_dim 256 / 512)
-        if dh not in (32, 64) and not wide and not (0 < dh <= 16 and not long) or S > 256 or (long and (causal or H != Hv)):
+        if dh not in (32, 64) and not wide and not (0 < dh <= 16 and not long) or S > 256 or (long and H != Hv):
             raise NotImplementedError(f'transformer block geometry width={Hv} heads={nh} S={S}')
         b = _Block()
         b.long = long
@@ -1109,7 +1110,7 @@ class TransRecEngine:
         if getattr(blk, 'long', False):
             ctx = bufs['ctx_o'] if 'ctx_o' in bufs else self._buf('ctx', M, H, T)
             L.attn_long_fwd(bufs['qkv'], ctx, bufs['lse'], n_items, blk.S, blk.nh, blk.dh, 0, H, 2 * H, blk.scale,
-                            drop_p=pa, drop_site=blk.site, drop_seed=seed, key_mask=key_mask)
+                            drop_p=pa, drop_site=blk.site, drop_seed=seed, key_mask=key_mask, causal=blk.causal)
         else:
             # (trainable attention output: its weight gradient needs ctx per layer -- the attention kernel writes the kept buffer directly)
             ctx = bufs['ctx_s'] if ('ctx_s' in bufs and cls_rows is None) else self._buf('ctx', M, H, T)
@@ -1407,7 +1408,7 @@ class TransRecEngine:
         if getattr(blk, 'long', False):
             ws = self._buf('attn_ws', bufs['lse'].shape[0], 1, torch.float32)
             L.attn_long_bwd(bufs['qkv'], bufs['ctx_o'], dctx, dqkv, bufs['lse'], ws, n_items, blk.S, blk.nh, blk.dh, 0, H, 2 * H, blk.scale,
-                            drop_p=pa, drop_site=blk.site, drop_seed=seed, key_mask=key_mask)
+                            drop_p=pa, drop_site=blk.site, drop_seed=seed, key_mask=key_mask, causal=blk.causal)
         else:
             L.attn_bwd(bufs['qkv'], dctx, dqkv, key_mask, n_items, blk.S, blk.nh, blk.dh, 0, H, 2 * H, blk.causal, blk.scale, blk.mask_neg,
                        drop_p=pa, drop_site=blk.site, drop_seed=seed, offsets=self._off(blk))

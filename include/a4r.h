@@ -232,10 +232,13 @@ typedef struct {
 int a4r_attn_fwd(void* stream, const a4r_attn_t* a);
 int a4r_attn_bwd(void* stream, const a4r_attn_t* a);
 
-/* The same attention for 32 < S <= 256 tokens per item (any S <= 256 is accepted) and dh == 64 or 32, never causal, no packed items
- * (causal 0, offsets NULL, else A4R_EINVAL).  key_mask (ABI 408, optional, dh == 64 only): HF's attention_mask, fp32 [n_items, S], 1 = attend --
+/* The same attention for 32 < S <= 256 tokens per item (any S <= 256 is accepted) and dh == 64 or 32, no packed items (offsets NULL, else
+ * A4R_EINVAL).  key_mask (ABI 408, optional): HF's attention_mask, fp32 [n_items, S], 1 = attend --
  * the text towers when --num_words_title exceeds 32 (Downstream/Text/parameters.py:44, model/encoders.py:48-57); masked keys get probability 0,
  * an item without any attended key (the PAD item) attends uniformly over its S keys, as HF's softmax over S equal scores does.
+ * causal 1 is accepted WITH a key_mask only (else A4R_EINVAL): the user tower at --max_seq_len above 32 (parameters.py:29,
+ * model/user_encoders.py:20-27: att_mask = log_mask & tril, added as -1e9): query t attends keys j <= t with key_mask[j] != 0; a query without any
+ * such key (the left padding of a short history) attends uniformly over all S keys, which is what fp32 softmax over S scores of -1e9 + s gives.
  * Without a mask: the ViT / ViT-MAE item tower (HF ViTSelfAttention under Downstream/CV/model/encoders.py:21-32;
  * S = 197 / 50, dh 64, drop_p 0) and the TransformerBlocks inside VITKAdaptedCVModel's KAdapterBlocks
  * (Downstream/CV/model/model.py:374-404, modules.py:24-36,148-187; width 384 = 12 heads of 32, all-ones mask, dropout
@@ -434,7 +437,7 @@ int a4r_memset_zero(void* stream, void* p, int64_t bytes);
  * history may hold at most A4R_EVAL_MAX_HISTORY ids (the reference keeps max_seq_len + 2, preprocess.py:51-59) --
  * the caller checks this (the host cannot read hist_ptr without a sync); longer lists are NOT silently truncated by
  * the Python mirror (data_utils/metrics.py raises). */
-#define A4R_EVAL_MAX_HISTORY 64
+#define A4R_EVAL_MAX_HISTORY 264
 int a4r_eval_rank(void* stream, const float* prec, const float* item_emb, const int32_t* target,
                   const int32_t* hist_ptr, const int32_t* hist_idx, int32_t* rank, int U, int N1, int E);
 

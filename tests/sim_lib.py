@@ -253,22 +253,26 @@ def attn_bwd(qkv, dout, dqkv, key_mask, n_items, S, n_heads, dh, q_off, k_off, v
         dqkv[:n_items * S, off:off + n_heads * dh] = q.grad[:n_items * S, off:off + n_heads * dh].to(dqkv.dtype)
 
 
-def attn_long_fwd(qkv, out, lse, n_items, S, n_heads, dh, q_off, k_off, v_off, scale, drop_p=0.0, drop_site=0, drop_seed=0, key_mask=None):
+def attn_long_fwd(qkv, out, lse, n_items, S, n_heads, dh, q_off, k_off, v_off, scale, drop_p=0.0, drop_site=0, drop_seed=0, key_mask=None, causal=False):
     assert dh in (32, 64) and S <= 256 and drop_p == 0.0
     Hd = n_heads * dh
     x = qkv.float()
     q, k = [x[:n_items * S, o:o + Hd].view(n_items, S, n_heads, dh).transpose(1, 2) for o in (q_off, k_off)]
     km = torch.ones(n_items, S) if key_mask is None else key_mask[:n_items].float()
-    sc = q @ k.transpose(-1, -2) * scale + (1.0 - km)[:, None, None, :] * FMIN
+    neg = -1e9 if causal else FMIN
+    allowed = (km != 0)[:, None, None, :].expand(n_items, 1, S, S)
+    if causal:
+        allowed = torch.tril(allowed)
+    sc = q @ k.transpose(-1, -2) * scale + torch.where(allowed, torch.tensor(0.0), torch.tensor(neg))
     lse.view(-1)[:n_items * n_heads * S] = torch.logsumexp(sc, -1).reshape(-1)
-    out[:n_items * S] = _attn(x, km, n_items, S, n_heads, dh, (q_off, k_off, v_off), False, scale, FMIN).to(out.dtype)
+    out[:n_items * S] = _attn(x, km, n_items, S, n_heads, dh, (q_off, k_off, v_off), causal, scale, neg).to(out.dtype)
 
 
 def attn_long_bwd(qkv, out, dout, dqkv, lse, delta_ws, n_items, S, n_heads, dh, q_off, k_off, v_off, scale,
-                  drop_p=0.0, drop_site=0, drop_seed=0, key_mask=None):
+                  drop_p=0.0, drop_site=0, drop_seed=0, key_mask=None, causal=False):
     assert drop_p == 0.0
     km = torch.ones(n_items, S) if key_mask is None else key_mask[:n_items].float()
-    attn_bwd(qkv, dout, dqkv, km, n_items, S, n_heads, dh, q_off, k_off, v_off, False, scale, FMIN)
+    attn_bwd(qkv, dout, dqkv, km, n_items, S, n_heads, dh, q_off, k_off, v_off, causal, scale, -1e9 if causal else FMIN)
 
 
 def patchify(img, out, patch, keep_idx=None):

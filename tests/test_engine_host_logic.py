@@ -554,6 +554,54 @@ def test_host_logic_news_attributes(simulated, attrs):
     np.testing.assert_allclose(emb[real].numpy(), out['input_embs_all'].detach()[real].numpy(), atol=1e-4, rtol=0)
 
 
+@pytest.mark.parametrize('max_len', [33, 45])
+def test_host_logic_long_histories(simulated, max_len):
+    """--max_seq_len above 32 (parameters.py:29): the user tower's blocks run the causal, key-masked form of the long attention kernels
+    (model/user_encoders.py:20-27: att_mask = log_mask & tril).  Toy geometry, kernels simulated: loss and every gradient against the CPU oracle."""
+    import adapter4rec_amd.inject as I
+    from adapter4rec_amd.model import BertBackbone, Model
+    from oracle import ref_cpu as R
+    torch.manual_seed(8)
+    args = TG.make_args(compute_dtype='fp32', **TG.ARGS['houlsby'])
+    args.max_seq_len = max_len
+    model = Model(args, 200, True, BertBackbone(dict(TG.GEOM)))
+    I.freeze_all(model)
+    root = I.inject_adapters(model, args)
+    with torch.no_grad():
+        for n, p in root.named_parameters():
+            if p.requires_grad:
+                p.add_(0.02 * torch.randn_like(p))
+    root.eval()
+    W = args.num_words_title
+    g = torch.Generator().manual_seed(4)
+    B, Lq = 3, max_len + 1
+    ids = torch.zeros(B, Lq, 2, 2 * W, dtype=torch.int64)
+    mask = torch.zeros(B, Lq - 1)
+    for u, n in enumerate((Lq, 35, 3)):
+        for slot in range(Lq - n, Lq):
+            for side in range(2):
+                if side == 1 and slot == Lq - 1:
+                    continue
+                ln = int(torch.randint(3, W + 1, (1,), generator=g))
+                ids[u, slot, side, :ln] = torch.randint(5, 90, (ln,), generator=g)
+                ids[u, slot, side, W:W + ln] = 1
+        mask[u, Lq - n:] = 1
+    items = ids.view(-1, 2 * W)
+    sd = {strip(k): v.detach().clone() for k, v in root.state_dict().items()}
+    names = [n for n, p in root.named_parameters() if p.requires_grad]
+    cfg = dict(R.DEFAULT_CFG)
+    cfg.update(bert_heads=TG.GEOM['num_attention_heads'], num_words_title=W, max_seq_len=max_len, embedding_dim=args.embedding_dim,
+               sasrec_heads=args.num_attention_heads, adapter_activation=args.adapter_activation)
+    out, grads = R.loss_and_grads(sd, [strip(n) for n in names], items, mask, cfg)
+    loss = root(items, mask, 'cpu')
+    loss.backward()
+    assert abs(loss.item() - float(out['loss'].detach())) < 1e-4
+    params = dict(root.named_parameters())
+    for n in names:
+        ref = grads[strip(n)].numpy()
+        np.testing.assert_allclose(params[n].grad.numpy(), ref, atol=1e-6 + 1e-4 * np.abs(ref).max(), rtol=0, err_msg=n)
+
+
 def test_host_logic_news_attributes_vs_reference_golden(simulated):
     """the same fixture through the simulated kernels (CPU): the engine's attribute stacking, the mean and its backward"""
     root, args, fx, items, mask = TG.build_multi_attr('cpu')

@@ -513,8 +513,45 @@ def test_attention_long_key_mask_fwd_bwd(dt, S, nh):
           atol16=4e-2 * float(qr.grad.abs().max()))
     # a masked key receives no gradient through K / V (item 1: keys >= 4)
     assert float(dqkv[S + 4:2 * S, Hd:].float().abs().max()) == 0.0
-    with pytest.raises(RuntimeError):                 # head width 32 has no masked instantiation
-        L.attn_long_fwd(qkv[:, :3 * 64], out[:, :64], lse, n_items, S, 2, 32, 0, 64, 128, scale, key_mask=km)
+
+
+@pytest.mark.parametrize('dt,S,nh,dh', [('f32', 40, 2, 32), ('f32', 50, 2, 32), ('f32', 100, 2, 64), ('f32', 200, 2, 32), ('bf16', 50, 2, 32), ('bf16', 64, 4, 64),
+                                        ('bf16', 130, 2, 32), ('f32', 20, 2, 32)])
+def test_attention_long_causal_key_mask_fwd_bwd(dt, S, nh, dh):
+    """a4r_attn_long_* causal + key mask (round 5: the user tower at --max_seq_len > 32; SelfAttention of model/modules.py:31-42 with the mask of
+    model/encoders.py:24-28 = log_mask AND lower-triangular, -1e9 added elsewhere): left-padded histories of different lengths (their padded
+    positions are queries without any allowed key: uniform attention, no gradient), a full one, an empty one; forward and backward against fp32 torch."""
+    from adapter4rec_amd import _lib as L
+    t = DT[dt]
+    n_items = 5
+    Hd = nh * dh
+    Mp = ((n_items * S + 255) // 256) * 256
+    qkv = rnd(Mp, 3 * Hd, dtype=t, seed=231 + S)
+    scale = 1.0 / math.sqrt(dh)
+    offs = (0, Hd, 2 * Hd)
+    km = torch.zeros(n_items, S, device=dev())
+    km[0, :] = 1
+    km[1, S - 3:] = 1                                  # a short history: positions 0 .. S-4 are padding
+    km[2, S // 2:] = 1
+    km[3, 1:] = 1
+    # item 4: nothing attended
+    out = torch.zeros(Mp, Hd, dtype=t, device=dev())
+    lse = torch.zeros(n_items * nh * S, device=dev())
+    L.attn_long_fwd(qkv, out, lse, n_items, S, nh, dh, *offs, scale, key_mask=km, causal=True)
+    qr = qkv.float().clone().requires_grad_(True)
+    ref = attn_ref(qr, km, n_items, S, nh, dh, True, scale, -1e9, offs)
+    close(out[:n_items * S], ref.detach(), t, f'attn_long causal fwd S={S} {dt}', atol32=1e-4, rtol32=1e-4)
+    dout = rnd(Mp, Hd, dtype=t, seed=232)
+    dout[n_items * S:] = 0
+    allowed_any = (torch.tril(torch.ones(S, S, device=dev()))[None] * km[:, None, :]).sum(-1) > 0          # [item, query]
+    dout[:n_items * S] = dout[:n_items * S] * allowed_any.reshape(-1, 1).to(t)                               # rows behind the loss mask carry no gradient
+    dqkv = torch.zeros_like(qkv)
+    ws = torch.zeros_like(lse)
+    L.attn_long_bwd(qkv, out, dout, dqkv, lse, ws, n_items, S, nh, dh, *offs, scale, key_mask=km, causal=True)
+    ref.backward(dout[:n_items * S].float())
+    assert torch.isfinite(dqkv.float()).all()
+    close(dqkv[:n_items * S], qr.grad[:n_items * S], t, f'attn_long causal bwd S={S} {dt}', atol32=2e-4, rtol32=2e-4,
+          atol16=4e-2 * float(qr.grad.abs().max()))
 
 
 def test_attention_long_rejects():
@@ -995,18 +1032,20 @@ def test_pack_matrices():
     assert torch.equal(d2.float(), flat[16 * 64:].view(768, 64).t().bfloat16().float())
 
 
-@pytest.mark.parametrize('E', [64, 128, 256, 512])
-def test_eval_rank(E):
-    """(E = 256: the parser's default --embedding_dim; 512: instantiated in round 5)"""
+@pytest.mark.parametrize('E,max_hist', [(64, 22), (128, 22), (256, 22), (512, 22), (64, 264), (128, 102)])
+def test_eval_rank(E, max_hist):
+    """(E = 256: the parser's default --embedding_dim; 512: instantiated in round 5; histories of up to A4R_EVAL_MAX_HISTORY = 264 ids:
+    --max_seq_len up to 255 keeps max_seq_len + 2 of them, preprocess.py:51-59)"""
     from adapter4rec_amd import _lib as L
+    assert L.EVAL_MAX_HISTORY == 264
     U, N1 = 37, 1001
     prec, items = rnd(U, E, seed=81), rnd(N1, E, seed=82)
     g = torch.Generator().manual_seed(3)
     target = torch.randint(1, N1, (U,), generator=g).int()
     hist, ptr = [], [0]
     for u in range(U):
-        h = torch.randint(1, N1, (int(torch.randint(0, 23, (1,), generator=g)),), generator=g).tolist()
-        h = [x for x in h if x != int(target[u])]
+        h = torch.randint(1, N1, (max_hist if u == 5 else int(torch.randint(0, max_hist + 1, (1,), generator=g)),), generator=g).tolist()
+        h = [x for x in h if x != int(target[u])] if u != 5 else [x if x != int(target[u]) else (x % (N1 - 1)) + 1 for x in h]
         hist += h
         ptr.append(len(hist))
     rank = torch.zeros(U, dtype=torch.int32, device=dev())

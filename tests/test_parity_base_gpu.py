@@ -778,10 +778,11 @@ def test_shipped_kadapter_script_configuration_fp32_vs_oracle():
     assert e_g < 2e-3, (e_g, where)
 
 
-@pytest.mark.parametrize('E', [256, 512])
-def test_eval_at_other_user_tower_widths_vs_oracle(E):
-    """the evaluation path (item sweep, user encoder inference, a4r_eval_rank) at --embedding_dim 256 (the parser's default) and 512: per-user ranks of
-    the fp32 instantiation against the oracle's on 300 items x 60 users (equal up to fp32 near-ties)."""
+@pytest.mark.parametrize('E,max_len', [(256, 20), (512, 20), (64, 80)])
+def test_eval_at_other_user_tower_widths_vs_oracle(E, max_len):
+    """the evaluation path (item sweep, user encoder inference, a4r_eval_rank) at --embedding_dim 256 (the parser's default) and 512, and at
+    --max_seq_len 80 (histories of up to 82 ids in a4r_eval_rank, the user tower on the long attention kernels): per-user ranks of the fp32
+    instantiation against the oracle's on 300 items x 60 users (equal up to fp32 near-ties)."""
     from adapter4rec_amd.data_utils import get_item_embeddings
     from adapter4rec_amd.data_utils.metrics import eval_ranks
     from adapter4rec_amd.inject import freeze_all, inject_adapters
@@ -790,7 +791,7 @@ def test_eval_at_other_user_tower_widths_vs_oracle(E):
     from oracle import ref_cpu as R
     torch.manual_seed(81)
     args = text_args('fp32', 'GELU')
-    args.word_embedding_dim, args.bert_model_load, args.embedding_dim, args.num_attention_heads = 128, 'bert_tiny_uncased', E, 2
+    args.word_embedding_dim, args.bert_model_load, args.embedding_dim, args.num_attention_heads, args.max_seq_len = 128, 'bert_tiny_uncased', E, 2, max_len
     n_items, n_users = 300, 60
     model = Model(args, n_items, True, BertBackbone(dict(BERT_BASE, hidden_size=128, num_hidden_layers=2, num_attention_heads=2, intermediate_size=512, vocab_size=500)))
     freeze_all(model)
@@ -809,10 +810,10 @@ def test_eval_at_other_user_tower_widths_vs_oracle(E):
     rng = np.random.default_rng(7)
     eval_seq, hist = {}, {}
     for u in range(n_users):
-        seq = [int(x) for x in rng.choice(np.arange(1, n_items + 1), size=int(rng.integers(3, 22)), replace=False)]
+        seq = [int(x) for x in rng.choice(np.arange(1, n_items + 1), size=max_len + 1 if u == 0 else int(rng.integers(3, max_len + 2)), replace=False)]
         eval_seq[u], hist[u] = seq, torch.LongTensor(seq[:-1])
     sd = {k: v.detach().clone() for k, v in model.state_dict().items()}
-    cfg = dict(R.DEFAULT_CFG, adapter_activation='GELU', bert_heads=2, embedding_dim=E, sasrec_heads=2)
+    cfg = dict(R.DEFAULT_CFG, adapter_activation='GELU', bert_heads=2, embedding_dim=E, sasrec_heads=2, max_seq_len=max_len)
     emb_ref = R.item_embeddings(sd, content.numpy(), cfg)
     _, ranks_ref = R.eval_ranks(sd, emb_ref, eval_seq, hist, cfg)
     model.to(DEV)
@@ -861,10 +862,12 @@ def test_other_bottleneck_widths_step_fp32_vs_oracle(d_bert, d_sas):
     assert abs(b['loss'] - ref['loss']) < 5e-2 and e_b < 0.25
 
 
-@pytest.mark.parametrize('blocks,max_len', [(1, 20), (4, 20), (2, 10), (2, 31), (3, 5)])
-def test_other_user_tower_depths_and_history_lengths_fp32_vs_oracle(blocks, max_len):
-    """--transformer_block other than 2 and --max_seq_len other than 20 (parameters.py:29-30; the user tower's attention kernel holds up to 32 positions):
-    BERT-tiny + Houlsby below, three users with histories of different lengths, fp32 vs the CPU oracle."""
+@pytest.mark.parametrize('blocks,max_len,emb_dim', [(1, 20, 64), (4, 20, 64), (2, 10, 64), (2, 31, 64), (3, 5, 64),
+                                                    (2, 33, 64), (2, 50, 64), (1, 100, 128), (2, 40, 128)])
+def test_other_user_tower_depths_and_history_lengths_fp32_vs_oracle(blocks, max_len, emb_dim):
+    """--transformer_block other than 2 and --max_seq_len other than 20 (parameters.py:29-30; the user tower's short attention kernel holds up to 32
+    positions, longer histories run the causal, key-masked form of the long kernels -- head width 32 or 64): BERT-tiny + Houlsby below, three users with
+    histories of different lengths, fp32 vs the CPU oracle."""
     from adapter4rec_amd.inject import freeze_all, inject_adapters
     from adapter4rec_amd.model import BERT_BASE, BertBackbone, Model
     from base_cases import text_args
@@ -872,6 +875,7 @@ def test_other_user_tower_depths_and_history_lengths_fp32_vs_oracle(blocks, max_
     torch.manual_seed(101)
     args = text_args('fp32', 'GELU')
     args.word_embedding_dim, args.bert_model_load, args.transformer_block, args.max_seq_len = 128, 'bert_tiny_uncased', blocks, max_len
+    args.embedding_dim = emb_dim
     model = Model(args, 512, True, BertBackbone(dict(BERT_BASE, hidden_size=128, num_hidden_layers=2, num_attention_heads=2, intermediate_size=512)))
     freeze_all(model)
     model = inject_adapters(model, model.args)
@@ -898,7 +902,7 @@ def test_other_user_tower_depths_and_history_lengths_fp32_vs_oracle(blocks, max_
     items = ids.view(-1, 60)
     sd = {k: v.detach().clone() for k, v in model.state_dict().items()}
     names = [n for n, p in model.named_parameters() if p.requires_grad]
-    out, grads = R.loss_and_grads(sd, names, items, mask, dict(R.DEFAULT_CFG, adapter_activation='GELU', bert_heads=2, max_seq_len=max_len))
+    out, grads = R.loss_and_grads(sd, names, items, mask, dict(R.DEFAULT_CFG, adapter_activation='GELU', bert_heads=2, max_seq_len=max_len, embedding_dim=emb_dim))
     ref = dict(loss=float(out['loss'].detach()), emb=out['input_embs_all'].detach(), grads=grads)
     o = hip_step(model, 'fp32', items, mask)
     e_g, where = grad_err(o['grads'], ref['grads'])
