@@ -68,15 +68,17 @@ class _LmdbTxn:
 
 
 def open_image_db(path):
-    """``--lmdb_data``: an LMDB directory/file (needs the lmdb module) or a pickled RecordStore (``*.pkl``: the same
-    key -> pickled LMDB_Image records, for machines without lmdb)."""
+    """``--lmdb_data``: an LMDB directory / file (dataset.py:69-74: through the ``lmdb`` module where it is installed, else through
+    ``cv/lmdb_reader.py``, a read-only reader of the same file format) or a pickled RecordStore (``*.pkl``: the same key -> pickled
+    LMDB_Image records)."""
     if path.endswith('.pkl'):
         with open(path, 'rb') as f:
             return RecordStore(pickle.load(f))
     try:
         return _LmdbTxn(path)
-    except ImportError as e:
-        raise RuntimeError(f'{path}: reading an LMDB needs the `lmdb` module; convert it to a pickled RecordStore (.pkl) instead') from e
+    except ImportError:
+        from .lmdb_reader import LmdbReader
+        return LmdbReader(path)
 
 
 def get_itemLMDB_embeddings(model, item_num, item_id_to_keys, test_batch_size, args, local_rank, db=None):

@@ -99,6 +99,83 @@ def test_dataset_sampling_and_transform(monkeypatch):
         np.testing.assert_array_equal(mask.numpy(), np.array([0] * pad + [1] * (len(seq) - 1), np.float32))
 
 
+@pytest.mark.parametrize('psize,n,cap,newest', [(4096, 0, None, 1), (4096, 1, None, 1), (4096, 700, None, 1), (4096, 700, None, 0),
+                                                  (4096, 900, 5, 1), (512, 300, 3, 1), (16384, 50, None, 0)])
+def test_lmdb_reader_point_lookups(tmp_path, psize, n, cap, newest):
+    """cv/lmdb_reader.py against files written by tests/lmdb_writer.py (the format of liblmdb 0.9.x restated twice; no liblmdb in the image):
+    every key back byte for byte -- small values inside leaf pages, large ones on overflow pages, trees of depth 1 .. 5 --, absent keys
+    (before the first, between two, after the last, a prefix, an extension) -> None, the newest of the two meta pages wins."""
+    from adapter4rec_amd.cv.lmdb_reader import LmdbReader
+    from lmdb_writer import write_lmdb
+    rng = np.random.default_rng(n + psize)
+    recs = {}
+    for i in range(n):
+        size = int(rng.choice([0, 1, 7, 100, psize // 2 - 40, psize // 2, psize - 16, psize - 15, 3 * psize + 5, 40000]))
+        recs[f'item{int(rng.integers(0, 10 ** 6))}'.encode('ascii')] = rng.integers(0, 256, size, dtype=np.uint8).tobytes()
+    if n:
+        recs[b'__len__'] = pickle.dumps(len(recs))
+    path = str(tmp_path / 'image.lmdb')
+    st = write_lmdb(path, recs, psize=psize, newest_meta=newest, max_leaf_nodes=cap)
+    db = LmdbReader(path)
+    assert db.stat()['entries'] == len(recs) and db.stat()['depth'] == st['depth'] and db.psize == psize
+    if cap:
+        assert st['depth'] >= 4
+    with db.begin() as txn:
+        for k, v in recs.items():
+            assert txn.get(k) == v, k
+        ks = sorted(recs)
+        for k in [b'', b'\x00', b'zzzz'] + [k + b'0' for k in ks[:50]] + [k[:-1] for k in ks[:50]] + [k[:-1] + bytes([k[-1] + 1]) for k in ks[:50]]:
+            assert txn.get(k) == recs.get(k), k
+    db.close()
+
+
+def test_lmdb_reader_refuses_what_it_does_not_read(tmp_path):
+    from adapter4rec_amd.cv.lmdb_reader import LmdbFormatError, LmdbReader
+    from lmdb_writer import write_lmdb
+    path = str(tmp_path / 'data.mdb')
+    write_lmdb(path, {b'a': b'1' * 10000, b'b': b'2'})
+    assert LmdbReader(str(tmp_path)).get(b'b') == b'2'                # a directory: <dir>/data.mdb, as lmdb.open(subdir=True) reads
+    raw = bytearray(open(path, 'rb').read())
+    for off, val, what in [(16, b'\xDE\xC0\xEF\xBF', 'magic'), (20, b'\x02\x00\x00\x00', 'version'), (10, b'\x02\x00', 'meta')]:
+        bad = bytearray(raw)
+        bad[off:off + len(val)] = val
+        open(path, 'wb').write(bad)
+        with pytest.raises(LmdbFormatError, match=what):
+            LmdbReader(path)
+    open(path, 'wb').write(raw[:3 * 4096])                              # a truncated copy
+    with pytest.raises(LmdbFormatError, match='truncated'):
+        LmdbReader(path)
+    bad = bytearray(raw)
+    bad[4096 + 16 + 24 + 48 + 4] = 0x08                                 # MDB_INTEGERKEY on the main database of the live meta page
+    open(path, 'wb').write(bad)
+    with pytest.raises(LmdbFormatError, match='integer keys'):
+        LmdbReader(path)
+
+
+def test_dataset_reads_an_lmdb_file(tmp_path, monkeypatch):
+    """--lmdb_data pointing at an LMDB file in an image without the lmdb module: open_image_db -> LmdbReader -> Build_Lmdb_Dataset gives the
+    samples the in-memory RecordStore gives (dataset.py:69-74,95-113)."""
+    import adapter4rec_amd.cv.image_io as IO
+    from adapter4rec_amd.cv.data_utils import open_image_db
+    from lmdb_writer import write_lmdb
+    monkeypatch.setattr(IO, 'L', sim_lib)
+    monkeypatch.setitem(sys.modules, 'lmdb', None)                      # (import lmdb -> ImportError, also where the module exists)
+    rng = np.random.default_rng(6)
+    st, keys, raw = _store(rng, 30, [(40, 30), (32, 32), (50, 64)])
+    path = str(tmp_path / 'image.lmdb')
+    write_lmdb(path, dict(st))
+    db = open_image_db(path)
+    assert type(db).__name__ == 'LmdbReader'
+    u2seq = {0: [3, 9, 1, 22, 7], 1: list(range(10, 31))}
+    a, b = IO.Build_Lmdb_Dataset(u2seq, 30, 20, st, keys, 32, device='cpu'), IO.Build_Lmdb_Dataset(u2seq, 30, 20, db, keys, 32, device='cpu')
+    for u in u2seq:
+        random.seed(7 + u)
+        sa, ma = a[u]
+        random.seed(7 + u)
+        sb, mb = b[u]
+        assert torch.equal(sa, sb) and torch.equal(ma, mb)
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize('hw', SIZES)
 def test_gpu_resize_is_pillow(hw):
