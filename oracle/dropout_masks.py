@@ -16,6 +16,7 @@ element index every kernel family hands it:
                          S <= 32:         ((pair * 32 + q) * 32 + k)               a4r_attn.hip:151
                          else:            ((pair * 256 + q) << 8) + k              a4r_attn_long.hip:151
     kind 'attn_user'  SASRec block probabilities [users, heads, T, T]:  (((user * heads + head) * 32 + q) << 5) + k       a4r_sasrec.hip:202
+                      (T > 32, the long attention kernels:               (((user * heads + head) * 256 + q) << 8) + k)
     kind 'rows_user'  SASRec block rows [users, T, E]:                   (user * 32 + t) * E + c                           a4r_sasrec.hip:217,269
                       (sasrec_fused=False, the multi-launch user tower:   (user * T + t) * E + c, the GEMM epilogue's index on [users * T, E] rows)
 
@@ -96,7 +97,10 @@ class DropoutStream:
             e = (u * np.uint64(32 if self.sasrec_fused else shp[1]) + t) * np.uint64(shp[2]) + c
         elif kind == 'attn_user':
             u, h, q, k = np.meshgrid(*[np.arange(n, dtype=np.uint64) for n in shp], indexing='ij')
-            e = (((u * np.uint64(shp[1]) + h) * np.uint64(32) + q) << np.uint64(5)) + k
+            if shp[2] <= 32:
+                e = (((u * np.uint64(shp[1]) + h) * np.uint64(32) + q) << np.uint64(5)) + k
+            else:                                            # --max_seq_len above 32: the long attention kernels' index
+                e = (((u * np.uint64(shp[1]) + h) * np.uint64(256) + q) << np.uint64(8)) + k
         elif kind == 'attn_item':
             i, h, q, k = np.meshgrid(*[np.arange(n, dtype=np.uint64) for n in shp], indexing='ij')
             pair, S = i * np.uint64(shp[1]) + h, shp[2]

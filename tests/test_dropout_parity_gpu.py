@@ -33,10 +33,12 @@ def test_row_masks_equal_the_librarys(M, N, p, site):
     assert abs(frac - p) < 0.02, frac                      # and it IS a dropout of rate p
 
 
-@pytest.mark.parametrize('S,dh,nh', [(30, 64, 2), (20, 32, 2), (30, 16, 4), (50, 64, 2)])
-def test_attention_masks_equal_the_librarys(S, dh, nh):
+@pytest.mark.parametrize('S,dh,nh,causal', [(30, 64, 2, False), (20, 32, 2, False), (30, 16, 4, False), (50, 64, 2, False),
+                                            (20, 32, 2, True), (50, 32, 2, True), (40, 64, 2, True), (100, 64, 1, True)])
+def test_attention_masks_equal_the_librarys(S, dh, nh, causal):
     """probabilities are uniform for Q = K = 0; with V[k] = one-hot(k - off) the context row q holds keep(q, k) / S in column k - off:
-    the mask as the kernel applied it, whatever its internal index (head dim < S: several windows)."""
+    the mask as the kernel applied it, whatever its internal index (head dim < S: several windows).  causal (the user tower; above 32
+    positions the key-masked causal form of the long kernels): row q is uniform over its q + 1 keys, the lower triangle is compared."""
     from adapter4rec_amd import _lib as L
     from oracle.dropout_masks import DropoutStream
     n_items, p, site, seed = 5, 0.1, 16, 0x5eed * 1000003 + 3
@@ -51,14 +53,18 @@ def test_attention_masks_equal_the_librarys(S, dh, nh):
         out = torch.zeros(n_items * S, H, device=dev())
         km = torch.ones(n_items, S, device=dev())
         if S <= 32:
-            L.attn_fwd(qkv, out, km, n_items, S, nh, dh, 0, H, 2 * H, False, 1.0, -1e9, drop_p=p, drop_site=site, drop_seed=seed)
+            L.attn_fwd(qkv, out, km, n_items, S, nh, dh, 0, H, 2 * H, causal, 1.0, -1e9, drop_p=p, drop_site=site, drop_seed=seed)
         else:
             lse = torch.zeros(n_items * nh * S, device=dev())
-            L.attn_long_fwd(qkv, out, lse, n_items, S, nh, dh, 0, H, 2 * H, 1.0, drop_p=p, drop_site=site, drop_seed=seed)
+            L.attn_long_fwd(qkv, out, lse, n_items, S, nh, dh, 0, H, 2 * H, 1.0, drop_p=p, drop_site=site, drop_seed=seed,
+                            key_mask=km if causal else None, causal=causal)
         o = out.cpu().view(n_items, S, nh, dh).permute(0, 2, 1, 3)              # [item, head, q, column]
         w = min(S, off + dh) - off
-        got[:, :, :, off:off + w] = o[:, :, :, :w] * S
+        n_keys = torch.arange(1, S + 1, dtype=torch.float32)[None, None, :, None] if causal else float(S)
+        got[:, :, :, off:off + w] = o[:, :, :, :w] * n_keys
     ref = DropoutStream(seed).mask('attn_item', site, torch.empty(n_items, nh, S, S), p, head_dim=dh)
+    if causal:
+        ref = torch.tril(ref)
     assert torch.allclose(got, ref, atol=1e-5), float((got - ref).abs().max())
 
 
@@ -149,3 +155,58 @@ def test_step_fp32_dropout_on_vit_houlsby_same_masks(monkeypatch):
     assert abs(float(out['loss'].detach()) - float(fx['loss'])) > 1e-3
     worst, where = _check_step(root, names, out, grads, loss, 1e-4, 1e-4)
     print(f'dropout ON, fp32 cv_vit_houlsby: loss {loss.item():.6f}, worst gradient {worst:.2e} ({where})')
+
+
+@pytest.mark.parametrize('title,max_len', [(30, 40), (40, 20), (36, 33)])
+def test_step_fp32_dropout_on_long_inputs_same_masks(title, max_len, monkeypatch):
+    """dropout ON where the LONG attention kernels run: titles above 32 tokens (key mask) and histories above 32 positions (causal + key mask;
+    parameters.py:29,44).  BERT-tiny + Houlsby, three users with histories of different lengths, fp32 instantiation vs the oracle under the same masks."""
+    from adapter4rec_amd.inject import freeze_all, inject_adapters
+    from adapter4rec_amd.model import BERT_BASE, BertBackbone, Model
+    from base_cases import text_args
+    from oracle import ref_cpu as R
+    monkeypatch.setenv('A4R_SKIP_UNUSED_ITEMS', '0')
+    torch.manual_seed(103)
+    args = text_args('fp32', 'GELU')
+    args.word_embedding_dim, args.bert_model_load, args.max_seq_len, args.num_words_title = 128, 'bert_tiny_uncased', max_len, title
+    geom = dict(BERT_BASE, hidden_size=128, num_hidden_layers=2, num_attention_heads=2, intermediate_size=512)
+    model = Model(args, 512, True, BertBackbone(geom))
+    freeze_all(model)
+    model = inject_adapters(model, model.args)
+    with torch.no_grad():
+        for n, p in model.named_parameters():
+            if p.requires_grad:
+                p.add_(0.02 * torch.randn_like(p))
+    g = torch.Generator().manual_seed(10)
+    Lq, users = max_len + 1, 3
+    ids = torch.zeros(users, Lq, 2, 2 * title, dtype=torch.int64)
+    mask = torch.zeros(users, Lq - 1)
+    for u, n in enumerate((Lq, max(3, Lq // 2), 3)):
+        for slot in range(Lq - n, Lq):
+            for side in range(2):
+                if side == 1 and slot == Lq - 1:
+                    continue
+                ln = int(torch.randint(4, title + 1, (1,), generator=g))
+                ids[u, slot, side, 0] = 101
+                ids[u, slot, side, 1:ln - 1] = torch.randint(1000, 30000, (ln - 2,), generator=g)
+                ids[u, slot, side, ln - 1] = 102
+                ids[u, slot, side, title:title + ln] = 1
+        mask[u, Lq - n:] = 1
+    items = ids.view(-1, 2 * title)
+    sd = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    names = [n for n, p in model.named_parameters() if p.requires_grad]
+    cfg = dict(R.DEFAULT_CFG, adapter_activation='GELU', bert_heads=2, max_seq_len=max_len, num_words_title=title)
+    out0, _ = R.loss_and_grads(sd, names, items, mask, cfg)
+    model.to('cuda:0')
+    model.train()
+    eng = model._engine()
+    eng.step_count = 0
+    loss = model(items.to('cuda:0'), mask.to('cuda:0'), 0)
+    loss.backward()
+    seed = (eng.seed * 1000003 + eng.step_count) & 0xFFFFFFFFFFFF
+    ocfg = _oracle_cfg(cfg, args, geom, seed, eng)
+    out, grads = R.loss_and_grads(sd, names, items, mask, ocfg)
+    assert abs(float(out['loss'].detach()) - float(out0['loss'].detach())) > 1e-3          # the masks did change the step
+    worst, where = _check_step(model, names, out, grads, loss, 1e-4, 1e-4)
+    print(f'dropout ON, fp32, {title}-token titles, {max_len} positions: loss {loss.item():.6f} vs {float(out["loss"].detach()):.6f}, worst gradient {worst:.2e} ({where})')
+    model.cpu()
