@@ -224,6 +224,37 @@ def test_text_run_device_sampler_simulated(tmp_path, monkeypatch):
     _device_sampler_run(tmp_path, monkeypatch)
 
 
+def _long_inputs_run(tmp_path, monkeypatch, zero_cfg=False):
+    data = write_toy(str(tmp_path))
+    if zero_cfg:                                                       # (the simulated long attention has no dropout form)
+        cp = os.path.join(str(tmp_path), 'pretrained_models', 'bert', 'bert_tiny', 'config.json')
+        c = json.load(open(cp))
+        c.update(hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0)
+        json.dump(c, open(cp, 'w'))
+    monkeypatch.chdir(os.path.join(str(tmp_path), 'work'))
+    a = dict(loss=[], batch=[], eval=[])
+    _run(['--root_data_dir', data, '--dataset', 'toy', '--behaviors', 'behaviors.tsv', '--news', 'news.tsv', '--mode', 'train',
+          '--bert_model_load', 'bert_tiny', '--freeze_paras_before', '0', '--adapter_type', 'houslby', '--adding_adapter_to', 'all',
+          '--fine_tune_to', 'None', '--pretrained_model_name', 'None', '--embedding_dim', '64', '--batch_size', '16', '--num_workers', '1',
+          '--logging_num', '3', '--testing_num', '1', '--max_seq_len', '40', '--num_words_title', '36', '--min_seq_len', '5', '--lr', '1e-3',
+          '--adapter_bert_lr', '1e-3', '--adapter_sasrec_lr', '1e-3', '--label_screen', 'dev', '--epoch', '3'], monkeypatch, a)
+    assert a['batch'] == [16, 16, 8] * 3, a['batch']
+    assert all(np.isfinite(a['loss'])) and np.mean(a['loss'][-3:]) < np.mean(a['loss'][:3]), a['loss']
+    assert len(a['eval']) >= 3 and all(0.0 <= h <= 100.0 for _, h in a['eval'])
+
+
+@pytest.mark.gpu
+def test_text_run_long_titles_and_histories_gpu(tmp_path, monkeypatch):
+    """run.py with --max_seq_len 40 --num_words_title 36 (both above the short attention kernels' 32): DataLoader batches, three epochs, finite
+    falling loss, evaluation (histories of up to 27 ids) and checkpoints -- the long attention kernels in their key-masked / causal forms end to end."""
+    _long_inputs_run(tmp_path, monkeypatch)
+
+
+def test_text_run_long_titles_and_histories_simulated(tmp_path, monkeypatch):
+    _simulate(monkeypatch)
+    _long_inputs_run(tmp_path, monkeypatch, zero_cfg=True)
+
+
 def _simulate(monkeypatch):
     import torch.distributed as dist
     import sim_lib
