@@ -381,14 +381,15 @@ def test_cv_finetune_all_fp32_vs_oracle():
     _check_all_grads(*build_cv_finetune_all(device='cuda:0'), 'cuda:0')
 
 
-def build_cv_other_geometry(device='cpu'):
-    """48 x 48 images, patch 8 -> 37 tokens (the 64-key instantiation of the attention kernels), 3 users, Houlsby; oracle-checked."""
+def build_cv_other_geometry(device='cpu', max_len=6, size=48):
+    """48 x 48 images, patch 8 -> 37 tokens (the 64-key instantiation of the attention kernels), 3 users, Houlsby; oracle-checked.
+    (max_len above 32: the user tower behind the image tower on the causal long attention kernels; 16 x 16 images keep that case small)"""
     from adapter4rec_amd.cv import Model, ViTForImageClassification
     from adapter4rec_amd.cv.inject import inject_adapters
     from adapter4rec_amd.inject import freeze_all
     torch.manual_seed(77)
-    geom = dict(GEOM, image_size=48)
-    args = make_args(CV_resize=48, max_seq_len=6)
+    geom = dict(GEOM, image_size=size)
+    args = make_args(CV_resize=size, max_seq_len=max_len)
     model = Model(args, 30, True, ViTForImageClassification(geom))
     with torch.no_grad():
         for p in model.parameters():
@@ -401,10 +402,14 @@ def build_cv_other_geometry(device='cpu'):
             if p.requires_grad:
                 p.add_(0.05 * torch.randn_like(p))
     model.eval()
-    images = torch.randn(3 * 7 * 2, 3, 48, 48)
-    mask = torch.ones(3, 6)
-    mask[1, :4] = 0
-    return model.to(device), dict(tower='image', vit_heads=2, max_seq_len=6), images.to(device), mask.to(device)
+    images = torch.randn(3 * (max_len + 1) * 2, 3, size, size)
+    mask = torch.ones(3, max_len)
+    mask[1, :max_len - 2] = 0
+    mask[2, :max_len // 2] = 0
+    im = images.view(3, max_len + 1, 2, 3, size, size)
+    for u in range(3):                                          # pad slots hold the all-zero image (dataset.py:163-166)
+        im[u, :int((mask[u] == 0).sum())] = 0
+    return model.to(device), dict(tower='image', vit_heads=2, max_seq_len=max_len), images.to(device), mask.to(device)
 
 
 def _fp8_case(dev):
@@ -467,9 +472,9 @@ def test_cv_fp8_encoder_gpu():
     _fp8_case('cuda:0')
 
 
-def _check_other_geometry(dev):
+def _check_other_geometry(dev, **kw):
     from oracle import ref_cpu as R
-    model, extra, images, mask = build_cv_other_geometry(dev)
+    model, extra, images, mask = build_cv_other_geometry(dev, **kw)
     sd = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
     cfg = dict(R.DEFAULT_CFG, **extra)
     names = [n for n, p in model.named_parameters() if p.requires_grad]
@@ -490,6 +495,16 @@ def test_cv_host_logic_other_geometry(simulated):
 @pytest.mark.gpu
 def test_cv_other_geometry_gpu():
     _check_other_geometry('cuda:0')
+
+
+def test_cv_host_logic_long_history(simulated):
+    _check_other_geometry('cpu', max_len=40, size=16)
+
+
+@pytest.mark.gpu
+def test_cv_long_history_gpu():
+    """--max_seq_len 40 behind the image tower (Downstream/CV/parameters.py: the same flag): fp32 loss and gradients vs the oracle"""
+    _check_other_geometry('cuda:0', max_len=40, size=16)
 
 
 def _cv_eval_case(dev):
