@@ -24,9 +24,11 @@ enum { A4R_BF16 = 0, A4R_F32 = 1, A4R_FP8 = 2 };      // A4R_FP8: OCP e4m3fn ope
 enum { A4R_ACT_NONE = 0, A4R_ACT_RELU = 1, A4R_ACT_GELU = 2, A4R_ACT_GELU_TANH = 3, A4R_ACT_LEAKY = 4, A4R_DACT_MULQ8_ = 14, A4R_DACT_MUL_ = 15 };
 
 // ---------------------------------------------------------------- error codes (C ABI)
+#ifndef A4R_OK            // (also in include/a4r.h, the public copy)
 #define A4R_OK 0
 #define A4R_EINVAL (-1)   // bad shape / alignment / dtype
 #define A4R_ELAUNCH (-2)  // hipGetLastError() != hipSuccess after launch
+#endif
 
 static inline int a4r_launch_status() { return hipGetLastError() == hipSuccess ? A4R_OK : A4R_ELAUNCH; }
 

@@ -34,6 +34,14 @@ extern "C" {
 #define A4R_DACT_MUL 15       /* dact only: multiply by Pre itself (Pre holds a stored derivative, see c2_mode) */
 #define A4R_DACT_MUL_Q8 14    /* dact only, out_dtype bf16: the same, Pre is the uint8 tensor c2_mode 2 wrote (ldpre in bytes) */
 
+/* Return codes of the int-returning entry points (those whose comment names a count, a flag or a previous value return that instead).  Every
+ * argument check happens BEFORE anything is enqueued: A4R_EINVAL means nothing was launched and no output was touched. */
+#ifndef A4R_OK
+#define A4R_OK 0
+#define A4R_EINVAL (-1)   /* NULL / misaligned pointer, unsupported shape, dtype or flag combination */
+#define A4R_ELAUNCH (-2)  /* hipGetLastError() != hipSuccess after the launch */
+#endif
+
 /* ABI version: bumped whenever a signature or struct below changes.  The Python binding (adapter4rec_amd/_lib.py) refuses a
  * library whose a4r_version() differs, so an A/B build made before a signature change cannot be called with shifted arguments. */
 #define A4R_ABI_VERSION 408

@@ -47,6 +47,46 @@ def test_binding_struct_sizes_match_header():
                                      ctypes.sizeof(_lib.SasrecBlock), _lib.SasrecBlock.drop_seed.offset, _lib.GemmArgs.c_scale_out.offset]
 
 
+def test_every_entry_point_refuses_null_pointers_before_launching():
+    """Error behaviour at the boundary: called with NULL for every pointer and 0 for every scalar (the two argument structs zero-filled), each
+    entry point that takes a pointer returns A4R_EINVAL (include/a4r.h) -- the checks sit in front of the first HIP call, so this runs without a GPU
+    and nothing is enqueued.  (a4r_gemm_tail_plan is a host-side query whose outputs are optional: it returns its flag.)"""
+    import torch
+    from adapter4rec_amd import _lib
+    if torch.cuda.is_available():
+        pytest.skip('argument-check probe is a CPU test')
+    hdr = re.sub(r'/\*.*?\*/', '', open(os.path.join(ROOT, 'include', 'a4r.h')).read(), flags=re.S)
+    codes = dict(re.findall(r'#define (A4R_OK|A4R_EINVAL|A4R_ELAUNCH) \(?(-?\d+)\)?', hdr))
+    assert {k: int(v) for k, v in codes.items()} == dict(A4R_OK=0, A4R_EINVAL=-1, A4R_ELAUNCH=-2)
+    protos = re.findall(r'\n\s*int\s+(a4r_\w+)\s*\(([^;{]*?)\)\s*;', hdr)
+    lib = ctypes.CDLL(_lib.LIB_PATH)
+    structs = dict(a4r_gemm_t=ctypes.sizeof(_lib.GemmArgs), a4r_attn_t=ctypes.sizeof(_lib.AttnArgs))
+    probed, keep = 0, []
+    for name, args in protos:
+        parts = [a.strip() for a in args.split(',')] if args.strip() not in ('', 'void') else []
+        if not any('*' in a for a in parts) or name == 'a4r_gemm_tail_plan':
+            continue
+        vals, types = [], []
+        for a in parts:
+            m = re.match(r'const\s+(a4r_\w+_t)\s*\*', a)
+            if m and m.group(1) in structs:
+                keep.append(ctypes.create_string_buffer(structs[m.group(1)]))
+                vals.append(ctypes.cast(keep[-1], ctypes.c_void_p)), types.append(ctypes.c_void_p)
+            elif '*' in a:
+                vals.append(None), types.append(ctypes.c_void_p)
+            elif re.match(r'(const\s+)?float\b', a):
+                vals.append(0.0), types.append(ctypes.c_float)
+            elif re.match(r'(const\s+)?(int64_t|uint64_t|size_t)\b', a):
+                vals.append(0), types.append(ctypes.c_int64)
+            else:
+                vals.append(0), types.append(ctypes.c_int32)
+        f = getattr(lib, name)
+        f.argtypes, f.restype = types, ctypes.c_int
+        assert f(*vals) == -1, name
+        probed += 1
+    assert probed >= 44, probed
+
+
 def test_no_cpu_fallback():
     import torch
     from adapter4rec_amd import _lib
