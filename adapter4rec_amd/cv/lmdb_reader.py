@@ -47,6 +47,16 @@ class LmdbReader:
     def __init__(self, path, subdir=None):
         subdir = os.path.isdir(path) if subdir is None else subdir
         self.path = os.path.join(path, 'data.mdb') if subdir else path
+        self._open()
+
+    def __getstate__(self):                      # (a DataLoader worker started by spawn re-opens the file; the mapping itself does not pickle)
+        return {'path': self.path}
+
+    def __setstate__(self, st):
+        self.path = st['path']
+        self._open()
+
+    def _open(self):
         self._f = open(self.path, 'rb')
         size = os.fstat(self._f.fileno()).st_size
         if size < 2 * 512:

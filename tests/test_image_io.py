@@ -135,6 +135,8 @@ def test_lmdb_reader_refuses_what_it_does_not_read(tmp_path):
     path = str(tmp_path / 'data.mdb')
     write_lmdb(path, {b'a': b'1' * 10000, b'b': b'2'})
     assert LmdbReader(str(tmp_path)).get(b'b') == b'2'                # a directory: <dir>/data.mdb, as lmdb.open(subdir=True) reads
+    again = pickle.loads(pickle.dumps(LmdbReader(path)))              # (what a spawned DataLoader worker receives)
+    assert again.get(b'a') == b'1' * 10000 and again.stat()['entries'] == 2
     raw = bytearray(open(path, 'rb').read())
     for off, val, what in [(16, b'\xDE\xC0\xEF\xBF', 'magic'), (20, b'\x02\x00\x00\x00', 'version'), (10, b'\x02\x00', 'meta')]:
         bad = bytearray(raw)
