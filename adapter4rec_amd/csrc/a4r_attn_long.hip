@@ -284,7 +284,8 @@ template <int SP> A4R_DEV int first_attended(const float* km, int lane) {
 // CAUSAL (round 5, with a key mask only: the user tower at --max_seq_len > 32, model/modules.py:31-42 with the mask of model/encoders.py:24-28): key k
 // is allowed for query q when the mask has it AND k <= q.  A query row without any allowed key (the left-padded positions of a short history: q below
 // the first attended key; without causal: an item without attended keys) attends uniformly over the S keys in the forward -- the reference adds -1e9
-// to every score of such a row, which leaves them equal -- and contributes nothing to the backward (its output gradient is zero behind the loss mask).
+// to every score of such a row, which leaves them equal in fp32 --; both backward kernels treat such a row the same way (raw scores 0, P = 1 / S over all S
+// keys: the softmax Jacobian autograd applies to it).  In the model its output gradient is zero behind the loss mask, so nothing flows from it.
 
 struct Drop { uint64_t seed; uint32_t site, thr16; float keep_scale; };
 
