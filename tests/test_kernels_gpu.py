@@ -515,9 +515,10 @@ def test_attention_long_key_mask_fwd_bwd(dt, S, nh):
     assert float(dqkv[S + 4:2 * S, Hd:].float().abs().max()) == 0.0
 
 
-@pytest.mark.parametrize('dt,S,nh,dh', [('f32', 40, 2, 32), ('f32', 50, 2, 32), ('f32', 100, 2, 64), ('f32', 200, 2, 32), ('bf16', 50, 2, 32), ('bf16', 64, 4, 64),
-                                        ('bf16', 130, 2, 32), ('f32', 20, 2, 32)])
-def test_attention_long_causal_key_mask_fwd_bwd(dt, S, nh, dh):
+@pytest.mark.parametrize('dt,S,nh,dh,all_rows', [('f32', 40, 2, 32, False), ('f32', 50, 2, 32, False), ('f32', 100, 2, 64, False), ('f32', 200, 2, 32, False),
+                                                 ('bf16', 50, 2, 32, False), ('bf16', 64, 4, 64, False), ('bf16', 130, 2, 32, False), ('f32', 20, 2, 32, False),
+                                                 ('f32', 40, 2, 32, True), ('f32', 100, 2, 64, True), ('bf16', 50, 2, 32, True)])
+def test_attention_long_causal_key_mask_fwd_bwd(dt, S, nh, dh, all_rows):
     """a4r_attn_long_* causal + key mask (round 5: the user tower at --max_seq_len > 32; SelfAttention of model/modules.py:31-42 with the mask of
     model/encoders.py:24-28 = log_mask AND lower-triangular, -1e9 added elsewhere): left-padded histories of different lengths (their padded
     positions are queries without any allowed key: uniform attention, no gradient), a full one, an empty one; forward and backward against fp32 torch."""
@@ -544,7 +545,8 @@ def test_attention_long_causal_key_mask_fwd_bwd(dt, S, nh, dh):
     dout = rnd(Mp, Hd, dtype=t, seed=232)
     dout[n_items * S:] = 0
     allowed_any = (torch.tril(torch.ones(S, S, device=dev()))[None] * km[:, None, :]).sum(-1) > 0          # [item, query]
-    dout[:n_items * S] = dout[:n_items * S] * allowed_any.reshape(-1, 1).to(t)                               # rows behind the loss mask carry no gradient
+    if not all_rows:                                    # rows behind the loss mask carry no gradient in the model; all_rows: they do here -- the kernels then apply
+        dout[:n_items * S] = dout[:n_items * S] * allowed_any.reshape(-1, 1).to(t)      # the Jacobian of the uniform row over all S keys, as autograd does
     dqkv = torch.zeros_like(qkv)
     ws = torch.zeros_like(lse)
     L.attn_long_bwd(qkv, out, dout, dqkv, lse, ws, n_items, S, nh, dh, *offs, scale, key_mask=km, causal=True)
