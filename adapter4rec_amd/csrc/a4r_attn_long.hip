@@ -74,7 +74,7 @@ template <typename T, int DH> struct Geo {
     static constexpr int TPS = KSTEP / 16;                  // score tiles per chunk step (2 / 1)
     static constexpr int ND = DH / 16;                      // 16-column tiles of the head width
     // 16 rows x one 16-byte chunk column per quarter wave: rows that share a 256-byte bank window get distinct chunk slots
-    static A4R_DEV int swz(int row) { return CPR == 16 ? (row & 15) : CPR == 8 ? ((row >> 1) & 7) : ((row >> 2) & 3); }
+    static A4R_DEV int swz(int row) { return CPR >= 16 ? (row & 15) : CPR == 8 ? ((row >> 1) & 7) : ((row >> 2) & 3); }      // (CPR 32: fp32 rows of 128 columns, two bank windows per row)
 };
 
 // LDS layout of a workgroup: the staged matrices (lds_main_*), then one output staging block per wave (bf16 only)
@@ -291,7 +291,7 @@ struct Drop { uint64_t seed; uint32_t site, thr16; float keep_scale; };
 
 // ------------------------------------------------------------------------------------------------ forward
 template <typename T, int DH, int NKT, bool KM = false>      // KM: the launch carries a key mask (text towers; instantiated for head width 64)
-__global__ void __launch_bounds__(WG<NKT>::NTHR, 4) attn_long_fwd_kernel(const T* __restrict__ qkv, int ld, int q_off, int k_off, int v_off,
+__global__ void __launch_bounds__(WG<NKT>::NTHR, DH > 64 ? 2 : 4) attn_long_fwd_kernel(const T* __restrict__ qkv, int ld, int q_off, int k_off, int v_off,
                                                             T* __restrict__ ctx, int ldo, float* __restrict__ lse,
                                                             int S, int nh, float scale, Drop dr, const float* __restrict__ kmask, int causal) {
     using G = Geo<T, DH>;
@@ -409,7 +409,7 @@ __global__ void __launch_bounds__(WG<NKT>::NTHR, 4) attn_long_fwd_kernel(const T
 
 // ------------------------------------------------------------------------------------------------ backward: dq + delta
 template <typename T, int DH, int NKT, bool KM = false>      // KM: the launch carries a key mask (text towers; instantiated for head width 64)
-__global__ void __launch_bounds__(WG<NKT>::NTHR, 4) attn_long_dq_kernel(const T* __restrict__ qkv, int ld, int q_off, int k_off, int v_off,
+__global__ void __launch_bounds__(WG<NKT>::NTHR, DH > 64 ? 2 : 4) attn_long_dq_kernel(const T* __restrict__ qkv, int ld, int q_off, int k_off, int v_off,
                                                            const T* __restrict__ dctx, int ldo, const T* __restrict__ octx,
                                                            const float* __restrict__ lse, float* __restrict__ delta,
                                                            T* __restrict__ dqkv, int S, int nh, float scale, Drop dr, const float* __restrict__ kmask, int causal) {
@@ -558,6 +558,10 @@ __global__ void __launch_bounds__(WG<NKT>::NTHR, 4) attn_long_dq_kernel(const T*
 #pragma unroll
                 for (int j = 0; j < HALF; ++j) Mma<T>::mma(tf[1][j], dsf, o[HALF + j]);
             }
+            if constexpr (G::ND > 2 * HALF) {                       // head width 128 (fp32, the user tower): the column tiles behind the first four, unscheduled
+#pragma unroll
+                for (int j = 2 * HALF; j < G::ND; ++j) Mma<T>::mma(frag_T<T, DH>(Kimg, SPT, j * 16, st, lane), dsf, o[j]);
+            }
             __builtin_amdgcn_sched_barrier(0);
         }
 #pragma unroll
@@ -568,7 +572,7 @@ __global__ void __launch_bounds__(WG<NKT>::NTHR, 4) attn_long_dq_kernel(const T*
 
 // ------------------------------------------------------------------------------------------------ backward: dk, dv
 template <typename T, int DH, int NKT, bool KM = false>      // KM: the launch carries a key mask (text towers; instantiated for head width 64)
-__global__ void __launch_bounds__(WG<NKT>::NTHR, 4) attn_long_dkdv_kernel(const T* __restrict__ qkv, int ld, int q_off, int k_off, int v_off,
+__global__ void __launch_bounds__(WG<NKT>::NTHR, DH > 64 ? 2 : 4) attn_long_dkdv_kernel(const T* __restrict__ qkv, int ld, int q_off, int k_off, int v_off,
                                                              const T* __restrict__ dctx, int ldo, const float* __restrict__ lse,
                                                              const float* __restrict__ delta, T* __restrict__ dqkv,
                                                              int S, int nh, float scale, Drop dr, const float* __restrict__ kmask, int causal) {
@@ -725,6 +729,13 @@ __global__ void __launch_bounds__(WG<NKT>::NTHR, 4) attn_long_dkdv_kernel(const 
 #pragma unroll
                 for (int j = 0; j < HALF; ++j) Mma<T>::mma(tf[1][j], dsf, dk[HALF + j]);
             }
+            if constexpr (G::ND > 2 * HALF) {                       // head width 128: the column tiles behind the first four, unscheduled
+#pragma unroll
+                for (int j = 2 * HALF; j < G::ND; ++j) {
+                    Mma<T>::mma(frag_T<T, DH>(Oimg, SPT, j * 16, g, lane), pf, dv[j]);
+                    Mma<T>::mma(frag_T<T, DH>(Qimg, SPT, j * 16, g, lane), dsf, dk[j]);
+                }
+            }
             __builtin_amdgcn_sched_barrier(0);
         }
 #pragma unroll
@@ -784,7 +795,8 @@ template <typename T, int DH, int NKT> int run_bwd(hipStream_t s, const a4r_attn
 }
 
 int check(const a4r_attn_t* a, bool bwd) {
-    if (!a || !a->qkv || a->n_items <= 0 || a->S <= 0 || a->S > 256 || (a->dh != 64 && a->dh != 32) || a->n_heads <= 0) return A4R_EINVAL;
+    if (!a || !a->qkv || a->n_items <= 0 || a->S <= 0 || a->S > 256 || (a->dh != 64 && a->dh != 32 && a->dh != 128) || a->n_heads <= 0) return A4R_EINVAL;
+    if (a->dh == 128 && (a->dtype != A4R_F32 || a->S > 128)) return A4R_EINVAL;     // head width 128: fp32, up to 128 tokens (two [128, 128] fp32 images = 128 KB of LDS)
     if (a->offsets || (a->causal && !a->key_mask)) return A4R_EINVAL;              // no packed items; causal only together with a key mask (the user tower); key_mask (fp32 [n_items, S], optional)
     if (a->key_mask && (reinterpret_cast<uintptr_t>(a->key_mask) & 3u)) return A4R_EINVAL;
     if (a->drop_p < 0.f || a->drop_p >= 1.f) return A4R_EINVAL;
@@ -809,6 +821,13 @@ int check(const a4r_attn_t* a, bool bwd) {
     }
 #define A4R_DH_SWITCH(T_, CALL_)                                            \
     if (a->dh == 64) { A4R_NKT_SWITCH(T_, 64, CALL_) } else { A4R_NKT_SWITCH(T_, 32, CALL_) }
+// head width 128 (fp32, S <= 128: the user tower at the parser's default --embedding_dim 256 with two heads and --max_seq_len above 32)
+#define A4R_DH128_SWITCH(CALL_)                         \
+    if (a->dh == 128) switch (nkt_for(a->S)) {          \
+        case 2: return CALL_(float, 128, 2);            \
+        case 4: return CALL_(float, 128, 4);            \
+        default: return CALL_(float, 128, 8);           \
+    }
 
 }  // namespace
 
@@ -818,6 +837,7 @@ extern "C" int a4r_attn_long_fwd(void* stream, const a4r_attn_t* a, float* lse) 
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
 #define A4R_F(T_, D_, N_) run_fwd<T_, D_, N_>(s, a, lse)
     if (a->dtype == A4R_BF16) { A4R_DH_SWITCH(bf16_t, A4R_F) }
+    A4R_DH128_SWITCH(A4R_F)
     A4R_DH_SWITCH(float, A4R_F)
 #undef A4R_F
 }
@@ -828,6 +848,7 @@ extern "C" int a4r_attn_long_bwd(void* stream, const a4r_attn_t* a, const float*
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
 #define A4R_B(T_, D_, N_) run_bwd<T_, D_, N_>(s, a, lse, delta_ws)
     if (a->dtype == A4R_BF16) { A4R_DH_SWITCH(bf16_t, A4R_B) }
+    A4R_DH128_SWITCH(A4R_B)
     A4R_DH_SWITCH(float, A4R_B)
 #undef A4R_B
 }

@@ -703,8 +703,9 @@ class TransRecEngine:
         te = self.model.user_encoder.transformer_encoder
         E, nh = self.E, self.args.num_attention_heads
         # (head widths 128 / 256: --embedding_dim 256 / 512 with the default two heads, parameters.py:27-28 -- fp32 instantiations of the short attention kernel)
-        # (histories of more than 32 items, --max_seq_len > 32: the causal, key-masked form of the long attention kernels, head width 32 / 64)
-        if (E // nh) not in (32, 64, 128, 256) or E % nh or self.Lseq - 1 > 256 or (self.Lseq - 1 > 32 and (E // nh) not in (32, 64)):
+        # (histories of more than 32 items, --max_seq_len > 32: the causal, key-masked form of the long attention kernels, head width 32 / 64; 128 up to 128 positions)
+        if (E // nh) not in (32, 64, 128, 256) or E % nh or self.Lseq - 1 > 256 or (self.Lseq - 1 > 32 and (E // nh) not in (32, 64)
+                                                                                   and not (E // nh == 128 and self.Lseq - 1 <= 128)):
             raise NotImplementedError(f'SASRec geometry E={E} heads={nh} T={self.Lseq - 1}')
         pe = te.position_embedding.weight
         self.pos_emb = pe.data if pe.requires_grad else self._f32(pe)
@@ -789,7 +790,8 @@ class TransRecEngine:
         dh = Hv // nh
         long = S > 32                 # K-Adapter blocks over the ViT token rows (S = 197 / 50): a4r_attn_long_*, no mask, dh 64 / 32
         wide = dh in (128, 256) and dt == torch.float32 and not long          # (the user tower at --embedding_dim 256 / 512)
-        if dh not in (32, 64) and not wide and not (0 < dh <= 16 and not long) or S > 256 or (long and H != Hv):
+        wide_long = long and dh == 128 and dt == torch.float32 and S <= 128      # (--embedding_dim 256 with two heads AND --max_seq_len 33 .. 128: the long kernels' fp32 head width 128)
+        if dh not in (32, 64) and not wide and not wide_long and not (0 < dh <= 16 and not long) or S > 256 or (long and H != Hv):
             raise NotImplementedError(f'transformer block geometry width={Hv} heads={nh} S={S}')
         b = _Block()
         b.long = long

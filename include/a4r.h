@@ -240,8 +240,8 @@ typedef struct {
 int a4r_attn_fwd(void* stream, const a4r_attn_t* a);
 int a4r_attn_bwd(void* stream, const a4r_attn_t* a);
 
-/* The same attention for 32 < S <= 256 tokens per item (any S <= 256 is accepted) and dh == 64 or 32, no packed items (offsets NULL, else
- * A4R_EINVAL).  key_mask (ABI 408, optional): HF's attention_mask, fp32 [n_items, S], 1 = attend --
+/* The same attention for 32 < S <= 256 tokens per item (any S <= 256 is accepted) and dh == 64 or 32 (fp32 also dh == 128 with S <= 128: the user tower
+ * at the parser's default --embedding_dim 256 with two heads and --max_seq_len 33 .. 128), no packed items (offsets NULL, else A4R_EINVAL).  key_mask (ABI 408, optional): HF's attention_mask, fp32 [n_items, S], 1 = attend --
  * the text towers when --num_words_title exceeds 32 (Downstream/Text/parameters.py:44, model/encoders.py:48-57); masked keys get probability 0,
  * an item without any attended key (the PAD item) attends uniformly over its S keys, as HF's softmax over S equal scores does.
  * causal 1 is accepted WITH a key_mask only (else A4R_EINVAL): the user tower at --max_seq_len above 32 (parameters.py:29,

@@ -517,7 +517,8 @@ def test_attention_long_key_mask_fwd_bwd(dt, S, nh):
 
 @pytest.mark.parametrize('dt,S,nh,dh,all_rows', [('f32', 40, 2, 32, False), ('f32', 50, 2, 32, False), ('f32', 100, 2, 64, False), ('f32', 200, 2, 32, False),
                                                  ('bf16', 50, 2, 32, False), ('bf16', 64, 4, 64, False), ('bf16', 130, 2, 32, False), ('f32', 20, 2, 32, False),
-                                                 ('f32', 40, 2, 32, True), ('f32', 100, 2, 64, True), ('bf16', 50, 2, 32, True)])
+                                                 ('f32', 40, 2, 32, True), ('f32', 100, 2, 64, True), ('bf16', 50, 2, 32, True),
+                                                 ('f32', 40, 2, 128, False), ('f32', 100, 2, 128, True), ('f32', 128, 1, 128, False), ('f32', 24, 2, 128, False)])
 def test_attention_long_causal_key_mask_fwd_bwd(dt, S, nh, dh, all_rows):
     """a4r_attn_long_* causal + key mask (round 5: the user tower at --max_seq_len > 32; SelfAttention of model/modules.py:31-42 with the mask of
     model/encoders.py:24-28 = log_mask AND lower-triangular, -1e9 added elsewhere): left-padded histories of different lengths (their padded
@@ -567,6 +568,11 @@ def test_attention_long_rejects():
         L.attn_long_fwd(qkv, out, lse, 1, 300, 1, 64, 0, 64, 128, 0.125)       # S > 256
     with pytest.raises(RuntimeError):
         L.attn_long_fwd(qkv, out, lse, 1, 100, 1, 48, 0, 64, 128, 0.125)       # head width other than 64 / 32
+    q2, o2 = torch.zeros(512, 384, device=dev()), torch.zeros(512, 128, device=dev())
+    with pytest.raises(RuntimeError):
+        L.attn_long_fwd(q2, o2, lse, 1, 200, 1, 128, 0, 128, 256, 0.1)           # head width 128: up to 128 tokens
+    with pytest.raises(RuntimeError):
+        L.attn_long_fwd(q2.bfloat16(), o2.bfloat16(), lse, 1, 100, 1, 128, 0, 128, 256, 0.1)      # ... and fp32 only
     with pytest.raises(RuntimeError):
         L.attn_long_fwd(qkv, out, lse, 1, 100, 1, 64, 0, 64, 128, 0.125, drop_p=1.0)
 

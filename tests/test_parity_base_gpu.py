@@ -863,7 +863,7 @@ def test_other_bottleneck_widths_step_fp32_vs_oracle(d_bert, d_sas):
 
 
 @pytest.mark.parametrize('blocks,max_len,emb_dim', [(1, 20, 64), (4, 20, 64), (2, 10, 64), (2, 31, 64), (3, 5, 64),
-                                                    (2, 33, 64), (2, 50, 64), (1, 100, 128), (2, 40, 128)])
+                                                    (2, 33, 64), (2, 50, 64), (1, 100, 128), (2, 40, 128), (2, 40, 256), (1, 128, 256)])
 def test_other_user_tower_depths_and_history_lengths_fp32_vs_oracle(blocks, max_len, emb_dim):
     """--transformer_block other than 2 and --max_seq_len other than 20 (parameters.py:29-30; the user tower's short attention kernel holds up to 32
     positions, longer histories run the causal, key-masked form of the long kernels -- head width 32 or 64): BERT-tiny + Houlsby below, three users with
