@@ -16,7 +16,8 @@
 // bf16, four 4-byte gathers for fp32 (frag_T; no second, transposed image of anything).
 //
 // forward  (per 16-query block): S^T = K Q^T | softmax | O^T = V^T P^T         + lse = max + log(sum) per query (fp32)
-// backward, two launches (FlashAttention-2 split, no atomics):
+// backward, two kernels (FlashAttention-2 split, no atomics) -- as two launches above 64 tokens, as ONE launch (attn_long_bwd_kernel: dq half, barrier, dkdv half in the
+// same workgroup and LDS) up to 64, where the second half then finds the first half's reads in the caches:
 //   dq   (per 16-query block): delta = dO . O (forward output), then per chunk step of keys S^T, dP^T = V dO^T,
 //        dS = P (dP - delta) scale, dQ^T += K^T dS^T  (nothing held for the whole key range)
 //   dkdv (per 16-key tile, a wave owns its key tiles): S = Q K^T, dP = dO V^T (tiles with the KEY on the lane),
@@ -408,11 +409,9 @@ __global__ void __launch_bounds__(WG<NKT>::NTHR, DH > 64 ? 2 : 4) attn_long_fwd_
 }
 
 // ------------------------------------------------------------------------------------------------ backward: dq + delta
-template <typename T, int DH, int NKT, bool KM = false>      // KM: the launch carries a key mask (text towers; instantiated for head width 64)
-__global__ void __launch_bounds__(WG<NKT>::NTHR, DH > 64 ? 2 : 4) attn_long_dq_kernel(const T* __restrict__ qkv, int ld, int q_off, int k_off, int v_off,
-                                                           const T* __restrict__ dctx, int ldo, const T* __restrict__ octx,
-                                                           const float* __restrict__ lse, float* __restrict__ delta,
-                                                           T* __restrict__ dqkv, int S, int nh, float scale, Drop dr, const float* __restrict__ kmask, int causal) {
+template <typename T, int DH, int NKT, bool KM>
+A4R_DEV void dq_body(const T* __restrict__ qkv, int ld, int q_off, int k_off, int v_off, const T* __restrict__ dctx, int ldo, const T* __restrict__ octx,
+                     const float* __restrict__ lse, float* delta, T* dqkv, int S, int nh, float scale, Drop dr, const float* __restrict__ kmask, int causal) {
     using G = Geo<T, DH>;
     constexpr int NTHR = WG<NKT>::NTHR, NWAVE = WG<NKT>::NWAVE;
     constexpr int SP = NKT * 16, SPT = SP + 8, NST = SP / G::KSTEP;
@@ -570,12 +569,18 @@ __global__ void __launch_bounds__(WG<NKT>::NTHR, DH > 64 ? 2 : 4) attn_long_dq_k
     }
 }
 
+template <typename T, int DH, int NKT, bool KM = false>      // KM: the launch carries a key mask (text towers / the user tower)
+__global__ void __launch_bounds__(WG<NKT>::NTHR, DH > 64 ? 2 : 4) attn_long_dq_kernel(const T* __restrict__ qkv, int ld, int q_off, int k_off, int v_off,
+                                                           const T* __restrict__ dctx, int ldo, const T* __restrict__ octx,
+                                                           const float* __restrict__ lse, float* __restrict__ delta,
+                                                           T* __restrict__ dqkv, int S, int nh, float scale, Drop dr, const float* __restrict__ kmask, int causal) {
+    dq_body<T, DH, NKT, KM>(qkv, ld, q_off, k_off, v_off, dctx, ldo, octx, lse, delta, dqkv, S, nh, scale, dr, kmask, causal);
+}
+
 // ------------------------------------------------------------------------------------------------ backward: dk, dv
-template <typename T, int DH, int NKT, bool KM = false>      // KM: the launch carries a key mask (text towers; instantiated for head width 64)
-__global__ void __launch_bounds__(WG<NKT>::NTHR, DH > 64 ? 2 : 4) attn_long_dkdv_kernel(const T* __restrict__ qkv, int ld, int q_off, int k_off, int v_off,
-                                                             const T* __restrict__ dctx, int ldo, const float* __restrict__ lse,
-                                                             const float* __restrict__ delta, T* __restrict__ dqkv,
-                                                             int S, int nh, float scale, Drop dr, const float* __restrict__ kmask, int causal) {
+template <typename T, int DH, int NKT, bool KM>
+A4R_DEV void dkdv_body(const T* __restrict__ qkv, int ld, int q_off, int k_off, int v_off, const T* __restrict__ dctx, int ldo, const float* __restrict__ lse,
+                       const float* delta, T* dqkv, int S, int nh, float scale, Drop dr, const float* __restrict__ kmask, int causal) {
     using G = Geo<T, DH>;
     constexpr int NTHR = WG<NKT>::NTHR, NWAVE = WG<NKT>::NWAVE;
     constexpr int SP = NKT * 16, SPT = SP + 8, NG = SP / G::KSTEP;          // NG query groups of KSTEP queries
@@ -745,6 +750,28 @@ __global__ void __launch_bounds__(WG<NKT>::NTHR, DH > 64 ? 2 : 4) attn_long_dkdv
     }
 }
 
+template <typename T, int DH, int NKT, bool KM = false>
+__global__ void __launch_bounds__(WG<NKT>::NTHR, DH > 64 ? 2 : 4) attn_long_dkdv_kernel(const T* __restrict__ qkv, int ld, int q_off, int k_off, int v_off,
+                                                             const T* __restrict__ dctx, int ldo, const float* __restrict__ lse,
+                                                             const float* __restrict__ delta, T* __restrict__ dqkv,
+                                                             int S, int nh, float scale, Drop dr, const float* __restrict__ kmask, int causal) {
+    dkdv_body<T, DH, NKT, KM>(qkv, ld, q_off, k_off, v_off, dctx, ldo, lse, delta, dqkv, S, nh, scale, dr, kmask, causal);
+}
+
+// Both halves of the backward in ONE launch per (item, head): dq + delta first, then -- same workgroup, same LDS -- dk and dv.  The second half's reads of
+// Q / K / V / dO repeat what this workgroup read tens of microseconds earlier (L2 / Infinity Cache instead of HBM: as two launches over all items the dkdv
+// kernel found nothing of the dq kernel's stream left in a 256-MB cache at ViT-B/16's 500 MB), and delta goes through global memory within the workgroup.
+template <typename T, int DH, int NKT, bool KM = false>
+__global__ void __launch_bounds__(WG<NKT>::NTHR, DH > 64 ? 2 : 4) attn_long_bwd_kernel(const T* __restrict__ qkv, int ld, int q_off, int k_off, int v_off,
+                                                            const T* __restrict__ dctx, int ldo, const T* __restrict__ octx,
+                                                            const float* __restrict__ lse, float* delta, T* dqkv,
+                                                            int S, int nh, float scale, Drop dr, const float* __restrict__ kmask, int causal) {
+    dq_body<T, DH, NKT, KM>(qkv, ld, q_off, k_off, v_off, dctx, ldo, octx, lse, delta, dqkv, S, nh, scale, dr, kmask, causal);
+    __threadfence_block();                                  // delta written by this workgroup's waves is read by others of it below
+    __syncthreads();                                        // ... and the LDS images of the first half are dead
+    dkdv_body<T, DH, NKT, KM>(qkv, ld, q_off, k_off, v_off, dctx, ldo, lse, delta, dqkv, S, nh, scale, dr, kmask, causal);
+}
+
 int nkt_for(int S) { return S <= 32 ? 2 : S <= 64 ? 4 : S <= 128 ? 8 : S <= 224 ? 14 : 16; }
 // kt_partial_lo<NKT>() (which key tiles can reach past S) restates this map: a launch whose S does not fit its instantiation's assumption is refused
 template <int NKT> bool s_fits(int S) { return S <= NKT * 16 && S > 16 * kt_partial_lo<NKT>(); }
@@ -782,6 +809,17 @@ template <typename T, int DH, int NKT, bool KM> int run_bwd_km(hipStream_t s, co
     if (int rc = set_lds(attn_long_dq_kernel<T, DH, NKT, KM>, l1)) return rc;
     if (int rc = set_lds(attn_long_dkdv_kernel<T, DH, NKT, KM>, l2)) return rc;
     const dim3 grid(a->n_items * a->n_heads), block(WG<NKT>::NTHR);
+    // one launch up to 64 tokens (ViT-MAE's 50: 56 -> 48 us, the step -0.6 % bf16 / -0.9 % fp8); above, the two launches stay -- at ViT-B/16's 197 the one-launch
+    // form measured the same (351 vs 340 - 354 us, step -0.1 %) with 7 spilled registers instead of 2 (profiles/r05_q_attn_bwd_fused.txt).  A4R_ATTN_BWD_FUSED=0 / 1 forces either.
+    static const int knob = []{ const char* e = getenv("A4R_ATTN_BWD_FUSED"); return e ? (atoi(e) != 0 ? 1 : 0) : -1; }();
+    const bool fused = knob < 0 ? NKT <= 4 : knob != 0;
+    if (fused) {
+        const size_t l = l1 > l2 ? l1 : l2;
+        if (int rc = set_lds(attn_long_bwd_kernel<T, DH, NKT, KM>, l)) return rc;
+        hipLaunchKernelGGL((attn_long_bwd_kernel<T, DH, NKT, KM>), grid, block, l, s, (const T*)a->qkv, a->ld, a->q_off, a->k_off, a->v_off,
+                           (const T*)a->dout, a->ldo, (const T*)a->out, lse, delta, (T*)a->dqkv, a->S, a->n_heads, a->scale, drop_of(a), (const float*)a->key_mask, a->causal);
+        return a4r_launch_status();
+    }
     hipLaunchKernelGGL((attn_long_dq_kernel<T, DH, NKT, KM>), grid, block, l1, s, (const T*)a->qkv, a->ld, a->q_off, a->k_off, a->v_off,
                        (const T*)a->dout, a->ldo, (const T*)a->out, lse, delta, (T*)a->dqkv, a->S, a->n_heads, a->scale, drop_of(a), (const float*)a->key_mask, a->causal);
     hipLaunchKernelGGL((attn_long_dkdv_kernel<T, DH, NKT, KM>), grid, block, l2, s, (const T*)a->qkv, a->ld, a->q_off, a->k_off, a->v_off,
