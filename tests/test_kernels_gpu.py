@@ -557,6 +557,21 @@ def test_attention_long_causal_key_mask_fwd_bwd(dt, S, nh, dh, all_rows):
           atol16=4e-2 * float(qr.grad.abs().max()))
 
 
+@pytest.mark.parametrize('form', ['0', '1'])
+def test_attention_long_backward_both_launch_forms(form):
+    """A4R_ATTN_BWD_FUSED=0 / 1 force the two-launch / one-launch backward for EVERY sequence length (the default picks by length; the switch is read
+    once per process, hence the child process): the un-masked, key-masked and causal backward tests must pass in both forms."""
+    import os
+    import subprocess
+    import sys
+    env = dict(os.environ, A4R_ATTN_BWD_FUSED=form)
+    r = subprocess.run([sys.executable, '-m', 'pytest', os.path.abspath(__file__), '-q', '-x', '-p', 'no:cacheprovider',
+                        '-k', 'attention_long_fwd_bwd or attention_long_key_mask or attention_long_causal or attention_long_dropout'],
+                       env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert ' passed' in r.stdout and 'failed' not in r.stdout, r.stdout[-500:]
+
+
 def test_attention_long_rejects():
     from adapter4rec_amd import _lib as L
     qkv = torch.zeros(512, 192, device=dev())
