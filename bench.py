@@ -138,7 +138,15 @@ def synth_content(n_items, g):
     return c
 
 
-def synth_batches(content, n_items, batch, n_batches, g, ragged=False):
+def real_shapes():
+    """tests/golden/real_shapes.json (data, written by tools/gen_golden_r6.py from the reference's readers on the files it ships): counts of attended
+    tokens per Adressa title (bert_base_uncased, --num_words_title 30) and of training-history items per Amazon user (--max_seq_len 20)."""
+    with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'tests', 'golden', 'real_shapes.json')) as f:
+        sh = json.load(f)
+    return (torch.tensor(sh['title_tokens']['counts'], dtype=torch.float64), torch.tensor(sh['history_items']['counts'], dtype=torch.float64), sh)
+
+
+def synth_batches(content, n_items, batch, n_batches, g, ragged=False, hist_counts=None):
     """Full 23-item histories: train seq = 21 items, log_mask = ones(20); one uniformly sampled negative per position.
     ragged (--ragged-histories, reported separately): train lengths ~ U{2..21}, left-padded with item 0 in the positive AND the negative slot, log_mask =
     [0] * pad + [1] * (len - 1) -- BuildTrainDataset.__getitem__, Downstream/Text/data_utils/dataset.py:24-49."""
@@ -148,7 +156,8 @@ def synth_batches(content, n_items, batch, n_batches, g, ragged=False):
         negs = torch.randint(1, n_items + 1, (batch, 21), generator=g)
         negs[:, -1] = 0
         if ragged:
-            lens = torch.randint(2, 22, (batch,), generator=g)
+            # --real-shaped: lengths drawn from the real histogram (index = items of the train sequence) instead of U{2..21}
+            lens = torch.multinomial(hist_counts, batch, replacement=True, generator=g) if hist_counts is not None else torch.randint(2, 22, (batch,), generator=g)
             lm = torch.zeros(batch, 20)
             for b in range(batch):
                 pad = 21 - int(lens[b])
@@ -399,12 +408,18 @@ def main():
     ap.add_argument('--short-titles', action='store_true',
                     help="text workloads, NOT the canonical benchmark: SURVEY 8(d)'s 'realistic' titles of n ~ U{6..20} tokens (30-token rows, the rest pad); the "
                          'batch is handed over on the HOST every step (as run.py does) and the step runs on the longest title of the batch')
+    ap.add_argument('--real-shaped', action='store_true',
+                    help='text workloads, NOT the canonical benchmark: title lengths drawn from the histogram of the 20 373 real Adressa titles (mean 11.6 '
+                         'tokens) and history lengths from the 21 153 real Amazon users (mean 4.1 of 21 slots) that the reference ships '
+                         '(tests/golden/real_shapes.json); implies --short-titles --ragged-histories (host hand-over, titles packed, pad slots not encoded)')
     ap.add_argument('--short-titles-device', action='store_true', help='with --short-titles: batches resident on the device (30 tokens per item: the A/B)')
     ap.add_argument('--residual-dtype', default='bf16', choices=['bf16', 'fp32'],
                     help="text towers: --residual_dtype fp32 of parameters.py (the residual stream between sub-layers in fp32, as under the reference's "
                          "autocast); its cost is NOT in the headline line: measure it with this flag (recorded in config.residual_dtype)")
     ap.add_argument('--gemm-variant', type=int, default=-1, help='A/B knob of a4r_gemm_variant (include/a4r.h); default: the library default')
     a = ap.parse_args()
+    if a.real_shaped:
+        a.short_titles = a.ragged_histories = True
     # Every A4R_* variable of the environment goes into the JSON line (`env_knobs`): a record made with an A/B knob set says so itself.
     # Knobs that make results WRONG on purpose only exist in tools-only builds (make DEBUG_KNOBS=1, tools/*.sh -D builds under tools/_ab/);
     # bench.py refuses to run with one of them set, whatever library is loaded.
@@ -475,6 +490,8 @@ def main():
         # i.e. every slot encoded -- the A/B of that path)
         if a.short_titles:                                         # titles of 6 .. 20 tokens: [CLS] t .. [SEP] pad ...
             lens = torch.randint(6, 21, (content.shape[0],), generator=gc)
+            if a.real_shaped:
+                lens = torch.multinomial(real_shapes()[0], content.shape[0], replacement=True, generator=gc).clamp_(min=2)
             col = torch.arange(30)[None, :]
             sep = 2 if wl == 'roberta_pfeiffer_cpc' else 102
             padid = 1 if wl == 'roberta_pfeiffer_cpc' else 0
@@ -486,7 +503,7 @@ def main():
             content = torch.cat([ids, am], 1)
         batches = [((i.pin_memory() if (a.short_titles and not a.short_titles_device) else i.to(device)),
                     m if ((a.ragged_histories and not a.ragged_device_mask) or (a.short_titles and not a.short_titles_device)) else m.to(device))
-                   for i, m in synth_batches(content, 65536, a.batch, 4, g, ragged=a.ragged_histories)]
+                   for i, m in synth_batches(content, 65536, a.batch, 4, g, ragged=a.ragged_histories, hist_counts=real_shapes()[1] if a.real_shaped else None)]
     from adapter4rec_amd.ddp import FlatDDP
     ddp = FlatDDP(model, device_ids=[local], output_device=local)     # broadcasts rank 0's state once (run.py:503); frozen weights never move again
     inner = getattr(model, 'model', model)
@@ -712,7 +729,8 @@ def main():
             'value': round(users / dt, 2),
             'unit': 'user-sequences/sec', 'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup,
             'ms_per_step': round(dt / a.steps * 1e3, 3), 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
-            'dtype': a.dtype, 'data': WORKLOADS[wl][3] + (' -- RAGGED histories of 2..21 items (not the canonical benchmark)' if getattr(a, 'ragged_histories', False) else '') + (' -- SHORT titles of 6..20 tokens (not the canonical benchmark)' if getattr(a, 'short_titles', False) else ''),
+            'dtype': a.dtype, 'data': WORKLOADS[wl][3] + (' -- RAGGED histories of 2..21 items (not the canonical benchmark)' if getattr(a, 'ragged_histories', False) else '') + (' -- SHORT titles of 6..20 tokens (not the canonical benchmark)' if getattr(a, 'short_titles', False) else '')
+                    + (' -- REAL-SHAPED: title lengths ~ the 20 373 Adressa titles, history lengths ~ the 21 153 Amazon users the reference ships (tests/golden/real_shapes.json)' if getattr(a, 'real_shaped', False) else ''),
             'config': {'workload': WORKLOADS[wl][2], 'baseline_config': WORKLOADS[wl][0] + (' in bf16 (run with --dtype fp8 for its fp8 encoder)' if wl == 'mae_compacter' and a.dtype != 'fp8' else ''),
                        'users_per_gpu': a.batch, 'global_batch': world * a.batch, 'seq_len': 23,
                        'tokens_per_item': eng.S, 'items_per_user': 42,

@@ -61,6 +61,29 @@ def build_text_case(encoder='bert', act='RELU', adapter_type='houslby', arch='sa
     return model, ids.view(-1, 60), mask
 
 
+REAL_MINI = dict(hidden_size=256, num_hidden_layers=4, num_attention_heads=4, intermediate_size=1024)
+
+
+def build_real_case(item_num, seed=5):
+    """The model of tests/golden/real_batch.npz (tools/gen_golden_r6.py): BERT-mini geometry (4 x 256, 4 heads, F = 1024: run.py:100-114's
+    `bert_mini`) with the REAL 30 522-entry vocabulary, Houlsby adapters (GELU: smooth, so gradients hold 1e-4), seeded weights.  The batch is
+    not built here: it is the fixture's (real Adressa titles, real Amazon histories)."""
+    from adapter4rec_amd.inject import freeze_all, inject_adapters
+    from adapter4rec_amd.model import BERT_BASE, BertBackbone, Model
+    torch.manual_seed(seed)
+    args = text_args('fp32', 'GELU')
+    args.word_embedding_dim, args.bert_model_load = 256, 'bert_mini_uncased'
+    model = Model(args, item_num, True, BertBackbone(dict(BERT_BASE, **REAL_MINI)))
+    freeze_all(model)
+    model = inject_adapters(model, model.args)
+    with torch.no_grad():
+        for n, p in model.named_parameters():
+            if p.requires_grad:
+                p.add_(0.02 * torch.randn_like(p))
+    model.eval()
+    return model
+
+
 def checksum(model):
     """Order-dependent fp64 checksum of every tensor of the state dict (fixture <-> rebuilt weights)."""
     tot = 0.0

@@ -149,3 +149,33 @@ def lora_pin_case(tower, r_enc=8, r_sas=4, seed=11):
         expect[p + 'lora_A'] = (B.t() @ dW) / r
         expect[p + 'lora_B'] = (dW @ A.t()) / r
     return sd, cfg, batch, pin, expect
+
+
+# ---- round 6: the reference's readers on its own shipped data files (tools/gen_golden_r6.py, tests/test_real_data.py) ----
+def sha_array(a):
+    """SHA-256 of an array's dtype, shape and C-order bytes."""
+    import hashlib
+    a = np.ascontiguousarray(a)
+    h = hashlib.sha256()
+    h.update(f'{a.dtype.str}|{a.shape}|'.encode())
+    h.update(a.tobytes())
+    return h.hexdigest()
+
+
+def sha_mapping(d):
+    """SHA-256 of a dict in ITERATION order (the readers' dicts are insertion-ordered and that order is the user / item numbering):
+    one line per entry, 'key<TAB>value'; lists / tensors / arrays as space-separated integers, bytes decoded."""
+    import hashlib
+    h = hashlib.sha256()
+    for k, v in d.items():
+        if isinstance(v, torch.Tensor):
+            v = v.tolist()
+        elif isinstance(v, np.ndarray):
+            v = v.tolist()
+        if isinstance(v, (list, tuple)):
+            v = ' '.join(str(int(x)) for x in v)
+        elif isinstance(v, bytes):
+            v = v.decode('ascii')
+        k = k.decode('ascii') if isinstance(k, bytes) else k
+        h.update(f'{k}\t{v}\n'.encode())
+    return h.hexdigest()
