@@ -281,7 +281,9 @@ extern "C" int a4r_gemm_tail_plan(int M, int N, int* p_full, int* kp);   // a4r_
 static int run_256(hipStream_t s, const a4r_gemm_t& g) { return a4r_gemm_nt_256(s, g); }
 
 extern int g_tn256_on;                                       // a4r_gemm_tn256.hip: 0 = large weight gradients on the 64-tile kernels too (tests)
-int a4r_gemm_w4(int v);                                      // a4r_gemm256.hip
+#ifdef A4R_WITH_W4
+int a4r_gemm_w4(int v);                                      // a4r_gemm256.hip (tools-only build: make W4=1)
+#endif
 extern int g_tn_variant;                                     // a4r_gemm_tn.hip: 0 = register-staged weight-gradient kernel for bf16 too
 
 // Leading rows (a multiple of 256) of an [M, N] output that the 256 x 256-tile kernel computes; the rows behind them go to the 128-tile
@@ -328,7 +330,11 @@ static void split_rows(const a4r_gemm_t& g, int64_t head_rows, int isz, int osz,
 extern "C" int a4r_gemm_variant(int v) {
     const int old = g_variant;
     if (v == 3 || v == 5) return -1;         // the four-wave forms were measured slower and are no longer part of the library
-    if (v == 8 || v == 9) { a4r_gemm_w4(v == 9); return old; }       // the four-wave hand-scheduled 256-tile kernel (a4r_gemm256w4.hip): 8 = off, 9 = on
+#ifdef A4R_WITH_W4
+    if (v == 8 || v == 9) { a4r_gemm_w4(v == 9); return old; }       // tools-only build (make W4=1): the four-wave hand-scheduled 256-tile kernel of tools/w4/: 8 = off, 9 = on
+#else
+    if (v == 8 || v == 9) return -1;         // the four-wave hand-scheduled kernel is not part of the library (tools/w4/README.md)
+#endif
     if (v == 6 || v == 7) { g_tn256_on = v == 7; return old; }      // large weight gradients (a4r_gemm_tn256.hip): 6 = on the 64-tile kernels, 7 = default
     if (v >= 0 && v <= 4) g_tn_variant = v != 0;
     if (v >= 0 && v <= 4) g_variant = v;     // 0/1: 128-tile kernels, 2: automatic (default), 4: eight-wave 256 tile forced

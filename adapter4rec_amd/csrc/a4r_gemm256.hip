@@ -725,7 +725,9 @@ extern "C" int a4r_gemm_tail_plan(int M, int N, int* p_full, int* kp) {
     return 0;
 }
 
-// a4r_gemm256w4.hip: the four-wave, hand-scheduled form of this kernel (bf16 operands, no short-tile tail, an even K-tile count >= 4)
+// tools/w4/a4r_gemm256w4.hip: the four-wave, hand-scheduled form of this kernel (round 5: bit-equal, at the matrix pipe's cycle floor, NOT faster end
+// to end on a power-limited chip).  It is an experiment, not product: compiled in only by `make W4=1` (tools/w4/README.md), never into the shipped library.
+#ifdef A4R_WITH_W4
 int a4r_gemm_nt_256w4(hipStream_t s, const a4r_gemm_t& g, int to_f32, int act, int dact, int ef, int ntm, int ntn, int gn, int grid);
 static int g_w4 = -1;
 int a4r_gemm_w4(int v) {            // v = 0 / 1 sets, anything else queries (a4r_gemm_variant 8 / 9; initial value: A4R_GEMM_W4 or 0)
@@ -734,6 +736,7 @@ int a4r_gemm_w4(int v) {            // v = 0 / 1 sets, anything else queries (a4
     if (v == 0 || v == 1) g_w4 = v;
     return old;
 }
+#endif
 
 namespace {
 
@@ -796,6 +799,7 @@ int launch256(hipStream_t s, const a4r_gemm_t& g) {
     static const int band_tail = getenv("A4R_GEMM_BAND_TAIL") ? atoi(getenv("A4R_GEMM_BAND_TAIL")) != 0 : 1;
     const bool band_ok = tail_kp == 0 || (band_tail && sizeof(TI) == 2 && ntm > 0 && ntm % 8 == 0 && grid == n_cu);   // (ViT + LoRA same box: bf16 30.16 -> 30.05 ms; e4m3 +0.4 %: bf16 only)
     const int gn = (band_ok ? band_for(g, ntm, ntn, grid, (int)sizeof(TI)) : 0) | (no_stream << 16) | (delay << 17);
+#ifdef A4R_WITH_W4
     if constexpr (sizeof(TI) == 2) {                       // bf16 operands: the four-wave kernel (a4r_gemm256w4.hip) where it applies and is switched on
         const int nk = g.K / 64;
         if (a4r_gemm_w4(-1) && tail_kp == 0 && ntm > 0 && nk >= 4 && !(nk & 1)) {
@@ -803,6 +807,7 @@ int launch256(hipStream_t s, const a4r_gemm_t& g) {
             if (r != 1) return r;                          // (1: this epilogue form is not instantiated there)
         }
     }
+#endif
     hipLaunchKernelGGL((gemm_nt_256_kernel<TI, TO, ACT, DACT, EF>), dim3(grid), dim3(512), 0, s, g, ntm, ntn, gn,
                        a4r_thr16(g.drop_p), a4r_keep_scale(g.drop_p), tail_kp, tail_rows);
     return a4r_launch_status();

@@ -116,8 +116,16 @@ def train(args, use_modal, local_rank, Log_file, Log_screen, model_dir, start_ti
     train_dataset = Build_Lmdb_Dataset(users_train, item_num, args.max_seq_len, db, item_id_to_keys, args.CV_resize, device=f'cuda:{local_rank}', host=host)
     sampler = torch.utils.data.distributed.DistributedSampler(train_dataset)
     if host:
+        # The workers draw the negatives (Python `random`, Build_Lmdb_Dataset.__getitem__): reseeded as the reference does (run_adapter.py:326-334)
+        # from the worker's torch seed + worker id + rank.  NOT persistent: every epoch's iterator takes a fresh base seed from the torch generator
+        # -- the state a checkpoint holds (utils.py:109-115) --, so a resumed run's workers draw what the uninterrupted run's would have, and two
+        # ranks never share a negative stream.
+        def worker_init(worker_id):
+            seed = torch.initial_seed() % 2 ** 31 + worker_id + dist.get_rank()
+            random.seed(seed)
+            np.random.seed(seed)
         train_dl = DataLoader(train_dataset, batch_size=args.batch_size, num_workers=args.num_workers, sampler=sampler, collate_fn=collate_host,
-                              pin_memory=True, persistent_workers=True, prefetch_factor=2)
+                              worker_init_fn=worker_init, pin_memory=True, prefetch_factor=2)
     else:
         train_dl = DataLoader(train_dataset, batch_size=args.batch_size, num_workers=0, sampler=sampler, collate_fn=_collate)
     model, start_epoch, ckpt2 = build_model(args, item_num, use_modal, cv_model, local_rank, Log_file, model_dir)
@@ -136,9 +144,10 @@ def train(args, use_modal, local_rank, Log_file, Log_screen, model_dir, start_ti
         loss, batch_index, need_break = 0.0, 1, False
         model.train()
         train_dl.sampler.set_epoch(now_epoch)
-        # Build_Lmdb_Dataset draws its negatives from Python's `random` in THIS process (no worker pool, see above), and the checkpoint holds the torch
-        # RNG state only (utils.py:109-115): the epoch's stream is re-seeded from the torch generator, so a resumed run draws the negatives the
-        # uninterrupted run would have (the text entry point gets the same from its DataLoader workers' torch-derived seeds)
+        # --num_workers 0: Build_Lmdb_Dataset draws its negatives from Python's `random` in THIS process, and the checkpoint holds the torch RNG state
+        # only (utils.py:109-115): the epoch's stream is re-seeded from the torch generator, so a resumed run draws the negatives the uninterrupted
+        # run would have.  With a worker pool the draw below is kept (both runs consume the same generator state) and the workers' streams come from
+        # the iterator's base seed (worker_init above) -- the text entry point's arrangement.
         random.seed(int(torch.randint(0, 2 ** 31 - 1, (1,)).item()))
         for sample_items, log_mask in train_dl:
             if host:

@@ -179,12 +179,6 @@ class _Lora:
             out.append(cls(lins[i], width, eng, dt, i, share=(share, 16 * small.index(i)) if share is not None else None))
         return out
 
-    def merged(self):
-        m = self.mod
-        if self.r == 0:
-            return m.weight.detach()
-        return m.weight.detach() + (m.lora_B.detach() @ m.lora_A.detach()) * self.scaling
-
 
 class _Block:
     """One post-LN transformer block (BERT layer or SASRec block) with optional adapters."""
@@ -527,6 +521,24 @@ class TransRecEngine:
                 self._phm_tab, self._phm_n = L.desc_table(ents, self.dev), len(ents)
             elif any(q.requires_grad for q in leaves):
                 raise NotImplementedError('Compacter tensors must be trainable (or frozen) together')
+            else:
+                # frozen Compacter tensors (a forward-only snapshot engine, e.g. the fp32 evaluation sweep of a trained model): the leaves are not in
+                # the flat trainable buffer -- a flat device copy of their own and the same a4r_phm_build launch (no gradient scratch: build only)
+                uniq, o = {}, 0
+                for q in leaves:
+                    if id(q) not in uniq:
+                        uniq[id(q)] = (o, q)
+                        o += (q.numel() + 3) // 4 * 4
+                self._phm_frozen = torch.zeros(max(o, 4), dtype=torch.float32, device=self.dev)
+                for o_, q in uniq.values():
+                    self._phm_frozen[o_:o_ + q.numel()].copy_(q.detach().reshape(-1))
+                off = lambda q: uniq[id(q)][0]
+                ents = []
+                for a in self._virtual:
+                    dn, up = a.virtual
+                    ents.append(L.PhmDesc(off(dn.phm_rule), off(dn.W_left), off(dn.W_right), a.v_off, 0, 0, dn.in_features, dn.out_features, dn.phm_dim, 0))
+                    ents.append(L.PhmDesc(off(up.phm_rule), off(up.W_left), off(up.W_right), a.v_off + a.d * a.width, 0, 0, up.in_features, up.out_features, up.phm_dim, 0))
+                self._phm_frozen_tab = (L.desc_table(ents, self.dev), len(ents))
 
     def pack_trainables(self):
         """Refresh the kernel-side copies of the trainable matrices (call after every optimiser step)."""
@@ -551,12 +563,8 @@ class TransRecEngine:
         if self._virtual:
             if self._phm_tab is not None:                     # Compacter: effective matrices from (phm_rule, W_left, W_right), one launch
                 L.phm_build(self.flat_p, self._phm_tab, self._phm_n, self._virt_flat)
-            else:                                             # frozen Compacter tensors (inference snapshot): not in the flat buffer
-                with torch.no_grad():
-                    for a in self._virtual:
-                        n = a.d * a.width
-                        self._virt_flat[a.v_off:a.v_off + n].copy_(a.virtual[0].effective_weight().reshape(-1))
-                        self._virt_flat[a.v_off + n:a.v_off + 2 * n].copy_(a.virtual[1].effective_weight().reshape(-1))
+            else:                                             # frozen Compacter tensors (inference snapshot): their own flat copy, the same kernel
+                L.phm_build(self._phm_frozen, self._phm_frozen_tab[0], self._phm_frozen_tab[1], self._virt_flat)
             for tab, n, mx, c in self._tabs_virt:
                 L.pack_matrices(self._virt_flat, tab, n, mx, c)
 
@@ -1624,6 +1632,8 @@ class TransRecEngine:
         cache = self.__dict__.setdefault('_attr_tabs', {})
         k = (key, src.data_ptr(), n)
         if k not in cache:
+            if len(cache) >= 64:                   # ragged histories change n almost every step: keep the table count (and the H2D copies' garbage) bounded
+                cache.clear()
             E, a = self.E, 1.0 / self.n_attr
             ents = [L.AddDesc(src.data_ptr() + (0 if into_rows else j * n * E * 4), (j * n * E if into_rows else 0), n, E, E, a) for j in range(self.n_attr)]
             cache[k] = L.desc_table(ents, self.dev)

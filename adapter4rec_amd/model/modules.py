@@ -106,14 +106,6 @@ class PHMLinear(_Container):                    # layers.py:25-166 in the config
     def set_phm_rule(self, phm_rule=None, **_):
         self.phm_rule = phm_rule
 
-    def effective_weight(self):
-        """nn.Linear-style [out, in] matrix of y = x @ sum_i kron(rule[i], W_left[i] @ W_right[i]) + b."""
-        w = torch.bmm(self.W_left, self.W_right)
-        n = self.phm_dim
-        rule = self.phm_rule
-        kron = (rule[:, :, None, :, None] * w[:, None, :, None, :]).reshape(n, self.in_features, self.out_features)
-        return kron.sum(0).t()
-
 
 class HyperComplexAdapterBlock(_Container):     # modules.py:209-252
     kind = 'compacter'

@@ -201,13 +201,14 @@ def _oracle_hr(sd, data, va, hv, item_id_to_keys, mae=False):
     return R.hit_ndcg(ranks)[0]
 
 
-def _cv_two_epochs_resume_and_oracle_hr(tmp_path, monkeypatch):
+def _cv_two_epochs_resume_and_oracle_hr(tmp_path, monkeypatch, workers=0):
     import logging
     root = str(tmp_path)
     data = _write_tiny(root)
     monkeypatch.chdir(os.path.join(root, 'work'))
     common = ['--root_data_dir', data] + COMMON_CV + ['--CV_model_load', 'vit-base-patch16-224', '--adapter_type', 'houslby', '--adding_adapter_to', 'all',
                                                        '--lr', '1e-3', '--adapter_cv_lr', '1e-3', '--adapter_sasrec_lr', '1e-3', '--label_screen', 'cv']
+    common[common.index('--num_workers') + 1] = str(workers)
     a = dict(loss=[], batch=[], eval=[])
     _run_cv(common + ['--epoch', '2'], monkeypatch, a)
     assert a['batch'] == [16, 16, 8] * 2, a['batch']
@@ -286,6 +287,18 @@ def test_cv_run_two_epochs_resume_and_oracle_hr_gpu(tmp_path, monkeypatch):
 def test_cv_run_two_epochs_resume_and_oracle_hr_simulated(tmp_path, monkeypatch):
     _simulate_cv(monkeypatch)
     _cv_two_epochs_resume_and_oracle_hr(tmp_path, monkeypatch)
+
+
+def test_cv_run_resume_with_worker_pool_simulated(tmp_path, monkeypatch):
+    """with --num_workers > 0 the WORKERS draw the negatives.  They are reseeded per epoch from the torch generator (worker_init_fn
+    = the reference's, run_adapter.py:326-334; workers not persistent), so resume = the uninterrupted run holds with a pool as well."""
+    _simulate_cv(monkeypatch)
+    _cv_two_epochs_resume_and_oracle_hr(tmp_path, monkeypatch, workers=2)
+
+
+@pytest.mark.gpu
+def test_cv_run_resume_with_worker_pool_gpu(tmp_path, monkeypatch):
+    _cv_two_epochs_resume_and_oracle_hr(tmp_path, monkeypatch, workers=2)
 
 
 @pytest.mark.gpu

@@ -401,10 +401,12 @@ def test_host_logic_bound_backward_path(simulated):
         np.testing.assert_allclose(params[k].grad.numpy(), 1.5 * r.numpy(), atol=1e-7 + 1e-5 * r.abs().max().item(), rtol=0, err_msg=k)
 
 
-def test_host_logic_eval_item_sweep_in_fp32_snapshot(simulated):
+@pytest.mark.parametrize('variant', ['houlsby', 'compacter'])
+def test_host_logic_eval_item_sweep_in_fp32_snapshot(simulated, variant):
     """--eval_compute_dtype fp32 under bf16 training: the item sweep runs on a forward-only fp32 snapshot engine of the CURRENT
-    weights; it equals the fp32 engine's embeddings and leaves the training engine (which owns the parameters' flat buffer) alone."""
-    root, args, fx, items, mask = build_cpu('houlsby')
+    weights; it equals the fp32 engine's embeddings and leaves the training engine (which owns the parameters' flat buffer) alone.
+    compacter: the snapshot's PHM tensors are frozen -- their effective matrices still come from a4r_phm_build (round 6: no eager bmm)."""
+    root, args, fx, items, mask = build_cpu(variant)
     inner = getattr(root, 'model', root)
     ref = inner.bert_encoder(items).clone()                          # fp32 engine
     inner.compute_dtype = 'bf16'

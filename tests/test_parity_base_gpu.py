@@ -34,10 +34,11 @@ def hip_step(model, dtype, items, mask, residual='bf16', host=False):
     loss = model(items, mask, DEV) if host else model(items.to(DEV), mask.to(DEV), DEV)       # host: the DataLoader's tensors (title lengths read there)
     pos, neg = inner._engine().scores()
     s_run = int(getattr(inner._engine(), 'S', 0))          # tokens per item the text tower ran this step on
+    pk = (getattr(inner._engine(), '_ctx', None) or {}).get('pk')      # packed titles: token rows the item tower ran on
     loss.backward()
     emb = inner.bert_encoder(items.to(DEV)).cpu()
     grads = {n: p.grad.detach().cpu().clone() for n, p in model.named_parameters() if p.requires_grad}
-    out = dict(loss=float(loss.detach()), pos=pos.cpu(), neg=neg.cpu(), emb=emb, grads=grads, s_run=s_run)
+    out = dict(loss=float(loss.detach()), pos=pos.cpu(), neg=neg.cpu(), emb=emb, grads=grads, s_run=s_run, packed_tokens=(int(pk['Mtok']) if pk else None))
     model.cpu()
     return out
 

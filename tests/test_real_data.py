@@ -193,11 +193,11 @@ def test_real_batch_step_hip_vs_reference():
     valid = mask.bool()
     read = torch.from_numpy(_slots_read(fx))
     o = hip_step(model, 'fp32', items, mask, host=True)
-    eng = getattr(model, 'model', model)._engine()
-    assert getattr(eng, '_pk', None) is not None, 'the titles were not packed'
     n_tok = int(fx['sample_items'].reshape(-1, 60)[read.numpy()][:, 30:].sum())
     print(f'real batch: {int(read.sum())} of {read.numel()} item slots read, {n_tok} attended tokens of {read.numel() * 30} rectangular '
-          f'({n_tok / (read.numel() * 30):.3f})')
+          f'({n_tok / (read.numel() * 30):.3f}); the item tower ran on {o["packed_tokens"]} token rows')
+    assert o['packed_tokens'] is not None and o['packed_tokens'] <= n_tok + 64, 'the titles were not packed / pad slots were encoded'
+
     d = dict(loss=abs(o['loss'] - ref['loss']), pos=float((o['pos'][valid] - ref['pos']).abs().max()), neg=float((o['neg'][valid] - ref['neg']).abs().max()),
              emb=float((o['emb'] - ref['emb'])[read].abs().max()))
     g, where = grad_err(o['grads'], ref['grads'])

@@ -1,4 +1,4 @@
-"""The four-wave GEMM (adapter4rec_amd/csrc/a4r_gemm256w4.hip) keeps its accumulators in AGPRs the compiler is told nothing about between the
+"""The four-wave GEMM experiment (tools/w4/a4r_gemm256w4.hip; not part of the shipped library, so not part of tests/ either: python -m pytest tools/w4/check_isa.py) keeps its accumulators in AGPRs the compiler is told nothing about between the
 hand-scheduled K loop and the epilogue's reads.  That is only sound while hipcc itself never touches an AGPR in those kernels and nothing spills:
 checked here in the ISA hipcc emits for EVERY instantiation (device-only -S, ~25 s, no GPU).  Also: the committed loop text is what the generator
 writes for the variant its header names."""
@@ -10,27 +10,28 @@ import sys
 
 import pytest
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
 CSRC = os.path.join(ROOT, 'adapter4rec_amd', 'csrc')
 HIPCC = '/opt/rocm/bin/hipcc'
 
 
 def test_loop_text_is_generator_output(tmp_path):
-    inc = os.path.join(CSRC, 'a4r_gemm256w4_loop.inc')
+    inc = os.path.join(HERE, 'a4r_gemm256w4_loop.inc')
     head = open(inc).readline()
     m = re.search(r'--variant (\w+)', head)
     assert m, head
     out = tmp_path / 'loop.inc'
-    subprocess.check_call([sys.executable, os.path.join(ROOT, 'tools', 'gen_gemm_w4_loop.py'), '--variant', m.group(1), '--out', str(out)], stdout=subprocess.DEVNULL)
-    assert open(inc).read() == open(out).read(), 'a4r_gemm256w4_loop.inc is stale: run tools/gen_gemm_w4_loop.py --variant ' + m.group(1)
+    subprocess.check_call([sys.executable, os.path.join(HERE, 'gen_gemm_w4_loop.py'), '--variant', m.group(1), '--out', str(out)], stdout=subprocess.DEVNULL)
+    assert open(inc).read() == open(out).read(), 'a4r_gemm256w4_loop.inc is stale: run tools/w4/gen_gemm_w4_loop.py --variant ' + m.group(1)
 
 
 def test_scoreboard_waits_cover_every_fragment():
     """independent re-check of insert_lgkm_waits: replay the text with in-order LDS returns and make sure no MFMA can read a fragment whose read
     is not provably complete (reads complete oldest first; a counted wait lgkmcnt(n) leaves at most the n youngest outstanding)"""
-    sys.path.insert(0, os.path.join(ROOT, 'tools'))
+    sys.path.insert(0, HERE)
     import gen_gemm_w4_loop as G
-    head = open(os.path.join(CSRC, 'a4r_gemm256w4_loop.inc')).readline()
+    head = open(os.path.join(HERE, 'a4r_gemm256w4_loop.inc')).readline()
     cfg = G.VARIANTS[re.search(r'--variant (\w+)', head).group(1)]
     for wave in range(4):
         L = G.body(cfg, wave, '_t')
@@ -55,7 +56,7 @@ def test_scoreboard_waits_cover_every_fragment():
 def test_no_agpr_outside_the_asm_blocks_and_no_scratch(tmp_path):
     s_path = tmp_path / 'w4.s'
     subprocess.check_call([HIPCC, '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-fno-gpu-rdc', '-Wno-unused-function', '-Wno-unused-command-line-argument',
-                           '--cuda-device-only', '-S', os.path.join(CSRC, 'a4r_gemm256w4.hip'), '-o', str(s_path)], cwd=CSRC)
+                           '--cuda-device-only', '-I' + CSRC, '-S', os.path.join(HERE, 'a4r_gemm256w4.hip'), '-o', str(s_path)], cwd=CSRC)
     kernels, cur, in_asm = {}, None, False
     areg = re.compile(r'(?<![\w.$])a\[?\d')
     meta_scratch = {}

@@ -1,8 +1,8 @@
 #!/usr/bin/env python
-"""Generator of adapter4rec_amd/csrc/a4r_gemm256w4_loop.inc: the hand-scheduled K loop of the four-wave 256 x 256 NT GEMM
+"""Generator of tools/w4/a4r_gemm256w4_loop.inc: the hand-scheduled K loop of the four-wave 256 x 256 NT GEMM
 (gemm_nt_256w4_kernel, a4r_gemm256w4.hip) as ONE inline-asm text.
 
-    python tools/gen_gemm_w4_loop.py [--out PATH] [--variant NAME]
+    python tools/w4/gen_gemm_w4_loop.py [--out PATH] [--variant NAME]
 
 Why text and not HIP C++: one wave per SIMD has nobody to cover an idle matrix pipe, so every LDS read, LDS-DMA and wait has to sit in
 a chosen gap between two MFMAs; hipcc clumps the reads behind one s_waitcnt (profiles/LOG.md, "Four waves, one per SIMD, on the
@@ -45,7 +45,7 @@ K-tiles 0 and 1 have landed).
 import argparse
 import os
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 UNIT = 16384
 BUF = 4 * UNIT
@@ -120,7 +120,7 @@ def ktile(buf, first, cfg, wave=0):
     if cfg.get('stagger', 0):
         # STAGGERED issue: the four waves leave the barrier together; with every wave's piece n in the same gap their requests meet at the CU's
         # one address unit (16 cycles per 1-KiB piece) and each wave's issue -- the in-order stream, MFMAs included -- waits for the other
-        # three (measured: ~60 cycles per piece and wave, tools/_ab/w4_sweep.sh).  Wave w owns the gaps = w (mod 4) behind the barrier.
+        # three (measured: ~60 cycles per piece and wave, tools/w4/w4_sweep.sh).  Wave w owns the gaps = w (mod 4) behind the barrier.
         st = cfg['stagger']
         pos = bar + 1 + wave * (st // 4)
         n_glds = 0
@@ -346,7 +346,7 @@ def build(cfg):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument('--out', default=os.path.join(ROOT, 'adapter4rec_amd', 'csrc', 'a4r_gemm256w4_loop.inc'))
+    ap.add_argument('--out', default=os.path.join(os.path.dirname(os.path.abspath(__file__)), 'a4r_gemm256w4_loop.inc'))
     ap.add_argument('--variant', default='v1')
     ap.add_argument('--abl', type=int, default=0, help='timing-only ablation bits (see ablate()); never for the shipped library')
     a = ap.parse_args()
@@ -354,7 +354,7 @@ def main():
     L = ablate(build(cfg), a.abl)
     n_mfma = sum(1 for x in L if x.startswith('v_mfma'))
     with open(a.out, 'w') as f:
-        f.write('// GENERATED by tools/gen_gemm_w4_loop.py --variant %s -- do not edit; the schedule and the register map are documented there.\n' % a.variant)
+        f.write('// GENERATED by tools/w4/gen_gemm_w4_loop.py --variant %s -- do not edit; the schedule and the register map are documented there.\n' % a.variant)
         f.write('// %d instructions, %d MFMAs.\n' % (sum(1 for x in L if not x.endswith(':')), n_mfma))
         f.write('#define A4R_W4_PIECE_OFFSETS %d\n' % (0 if cfg.get('per_piece_m0', False) else 1))
         f.write('#define A4R_W4_LOOP_ASM \\\n')

@@ -2,11 +2,11 @@
 """The four-wave hand-scheduled 256-tile GEMM (a4r_gemm_variant 9, a4r_gemm256w4.hip) against the eight-wave kernel (variant 8) on the
 training step's shapes and epilogue forms: outputs must be BIT-EQUAL (same K order per element, same epilogue text), then us per launch of
 both, interleaved in one process (and the vendor library on the plain form for orientation, measurement only).
-usage: python tools/w4_check.py [M=40448] [rounds=3] [quick]"""
+usage: python tools/w4/w4_check.py [M=40448] [rounds=3] [quick]"""
 import os
 import sys
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from adapter4rec_amd import _lib as L
 

@@ -1,10 +1,10 @@
 #!/usr/bin/env python
 """One NT GEMM shape, one kernel variant, n launches -- the program to put behind `rocprofv3 ... --` for counter passes.
-usage: python3 tools/w4_one.py <variant 8|9> <N> <K> [M=40448] [n=20]"""
+usage: python3 tools/w4/w4_one.py <variant 8|9> <N> <K> [M=40448] [n=20]"""
 import os
 import sys
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from adapter4rec_amd import _lib as L
 

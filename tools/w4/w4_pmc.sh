@@ -5,7 +5,7 @@ N=${N:-768}; K=${K:-3072}
 for v in 8 9; do
   for pass in "FETCH_SIZE" "TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum" "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY" "WRITE_SIZE"; do
     d=$OUT/pmc_tmp; rm -rf $d
-    rocprofv3 --pmc $pass --kernel-trace -d $d -o p --output-format csv -- python3 $ROOT/tools/w4_one.py $v $N $K > /dev/null 2>&1
+    rocprofv3 --pmc $pass --kernel-trace -d $d -o p --output-format csv -- python3 $ROOT/tools/w4/w4_one.py $v $N $K > /dev/null 2>&1
     python3 - "$d" "$v" "$pass" <<'PY'
 import csv, glob, os, sys, collections
 d, v, p = sys.argv[1], sys.argv[2], sys.argv[3]

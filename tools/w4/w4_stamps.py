@@ -1,12 +1,12 @@
 #!/usr/bin/env python
-"""In-kernel stamps of the four-wave GEMM's K loop (a library built with -DA4R_W4_STAMP: bash tools/w4_variants.sh <variant> with STAMP=1):
+"""In-kernel stamps of the four-wave GEMM's K loop (a library built with -DA4R_W4_STAMP: bash tools/w4/w4_variants.sh <variant> with STAMP=1):
 shader cycles per K-tile (2 048 = the matrix pipe's own time for 128 MFMAs 16x16x32), the clock the chip holds inside the loop and the
-epilogue's time, medians over workgroups.  usage: A4R_LIB_PATH=tools/_ab/liba4r_w4_<v>_st.so python tools/w4_stamps.py [M=40448]"""
+epilogue's time, medians over workgroups.  usage: A4R_LIB_PATH=tools/_ab/liba4r_w4_<v>_st.so python tools/w4/w4_stamps.py [M=40448]"""
 import ctypes as C
 import os
 import sys
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 import torch
 from adapter4rec_amd import _lib as L
