@@ -26,9 +26,11 @@ torch.cuda.synchronize()
 buf = np.zeros(256 * 8, dtype=np.uint64)
 assert L.lib().a4r_debug_op_stamps(buf.ctypes.data_as(C.c_void_p)) == 0
 s = buf.reshape(256, 8).astype(np.int64)
-names = ['wait for DMA / K / V / O + barrier B0', 'delta, stats, K blocks, K^T fragments (B1, B2)', 'main loop (7 steps)', 'dk / dv stores']
+names = ['wait for DMA / K / V / O + barrier B0', 'delta, stats, K image (B1, B2)', 'DMA issue + 7 steps', 'requests + final barrier', 'dk / dv stores']
+order = [0, 1, 2, 3, 5, 4]
 for i, n in enumerate(names):
-    d = s[:, i + 1] - s[:, i]
+    d = s[:, order[i + 1]] - s[:, order[i]]
     print(f'{n:32s} median {np.median(d):8.0f} cycles  (min {d.min():7d}, max {d.max():7d})')
+print(f'{"  of which: issuing the requests":32s} median {np.median(s[:, 6] - s[:, 3]):8.0f} cycles; consumer wave reaches the final barrier {np.median(s[:, 7] - s[:, 3]):8.0f} cycles after wave 0 left its steps')
 tot = s[:, 4] - s[:, 0]
 print(f'{"whole workgroup":32s} median {np.median(tot):8.0f} cycles')
