@@ -30,6 +30,7 @@ class FlatDDP(nn.Module):
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
         self._avg = dist.is_initialized() and dist.get_backend(process_group) == 'nccl'
         self._pending = []
+        self._order, self.last_order_hash = 0, 0              # rolling hash of this step's launch_ ranges / of the last completed step's
         if self.world > 1 and broadcast:                       # DDP constructor semantics: rank 0's state everywhere
             with torch.no_grad():
                 for t in list(module.parameters()) + list(module.buffers()):
@@ -60,6 +61,8 @@ class FlatDDP(nn.Module):
         launches the same ranges in the same order (the engine derives them from the parameter list)."""
         if hi <= lo:
             return
+        # launch-order fingerprint of the step (every rank must launch the same ranges in the same order: bench.py gathers it, VERDICT r5 item 9)
+        self._order = (self._order * 1000003 + (lo * 2654435761 + hi)) & 0x7FFFFFFFFFFFFFFF
         view = flat[lo:hi]
         op = dist.ReduceOp.AVG if self._avg else dist.ReduceOp.SUM
         self._pending.append((dist.all_reduce(view, op=op, group=self.process_group, async_op=True), view))
@@ -68,6 +71,7 @@ class FlatDDP(nn.Module):
         """Join every chunk launched since the last call.  Always runs (engine.backward_bound calls it from a `finally`): a backward
         that raised after some launches must not leave works in flight whose 1/world scaling (gloo) would be applied to a later step."""
         pending, self._pending = self._pending, []
+        self.last_order_hash, self._order = self._order, 0
         for work, view in pending:
             work.wait()
             if not self._avg:

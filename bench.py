@@ -365,6 +365,23 @@ def self_launch(a, argv):
     raise SystemExit(subprocess.run(cmd, env=env).returncode)
 
 
+def lockstep_fields(flat_p, order_hash, world, rank, device):
+    """Per-rank proof of lock-step for a SCALE record (the reference's DDP keeps replicas identical by construction,
+    run.py:503,584): every rank's exact checksum of the flat parameter buffer after the last step (int64 sum of the fp32 bit patterns: replicas must
+    agree BIT FOR BIT) and the fingerprint of the order in which it launched its gradient chunks (FlatDDP.last_order_hash)."""
+    import torch.distributed as dist
+    bits = int(flat_p.detach().contiguous().view(torch.int32).to(torch.int64).sum().item())
+    mine = torch.tensor([bits, int(order_hash)], dtype=torch.int64, device=device)
+    if world > 1:
+        allr = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(allr, mine)
+    else:
+        allr = [mine]
+    sums, orders = [int(t[0].item()) for t in allr], [int(t[1].item()) for t in allr]
+    return {'replica_param_checksums': [f'{v & 0xFFFFFFFFFFFFFFFF:016x}' for v in sums], 'replicas_bit_identical': len(set(sums)) == 1,
+            'chunk_order_hashes': [f'{v:016x}' for v in orders], 'chunk_order_identical': len(set(orders)) == 1}
+
+
 def control_only(a, world, rank):
     """A4R_BENCH_CONTROL_ONLY=1 (tests/test_bench_launch.py, no GPU): the launch / rendezvous / rank-accounting control flow of
     this file with the gloo backend and no compute -- rank 0 prints the JSON skeleton with value null."""
@@ -375,10 +392,12 @@ def control_only(a, world, rank):
     ranks = int(t.item())
     if ranks != a.gpus:
         raise SystemExit(f'--gpus {a.gpus} but the all-reduce saw {ranks} rank(s)')
+    # the lock-step fields of a real run (replica checksums, chunk-order hashes), here over a stand-in buffer every rank fills alike
+    lock = lockstep_fields(torch.arange(1000, dtype=torch.float32) * 0.5, 12345, world, rank, torch.device('cpu'))
     if rank == 0:
         print(json.dumps({'metric': 'user-sequences/sec, seq_len=23 BERT+SASRec+Adapter', 'value': None, 'unit': 'user-sequences/sec',
                           'n_gpus': world, 'rccl_ranks': ranks, 'backend': os.environ.get('A4R_BENCH_BACKEND', 'nccl'),
-                          'control_only': True}))
+                          'control_only': True, **lock}))
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
@@ -550,6 +569,9 @@ def main():
         dt = float(t.item())
     loss_val = float(loss.detach())
     assert loss_val == loss_val, 'NaN loss'
+    lock = lockstep_fields(eng.flat_p, getattr(ddp, 'last_order_hash', 0), world, rank, device)     # (a collective: every rank, before rank 0 goes on alone)
+    if world > 1 and not (lock['replicas_bit_identical'] and lock['chunk_order_identical']):
+        raise SystemExit(f'bench.py: the replicas left lock-step: {lock}')
 
     ar_us = None
     if world > 1:                                              # the exchange step on its own: 20 all-reduces of the flat gradient buffer
@@ -743,7 +765,7 @@ def main():
             'ms_per_step_ranks': rank_ms, 'ms_per_step_spread': round(max(rank_ms) - min(rank_ms), 3),
             'allreduce_overlapped': bool(world > 1 and eng.OVERLAP_ALLREDUCE and eng._grad_chunks() is not None),
             'loss': round(loss_val, 5), 'roofline': roof, 'cpu_baseline': cpu,
-            'env_knobs': env_knobs(), 'lib': lib_id(),
+            'env_knobs': env_knobs(), 'lib': lib_id(), **lock,
         }
         if host_leg is not None:
             out['host_images'] = host_leg

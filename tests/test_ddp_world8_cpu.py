@@ -183,3 +183,6 @@ def test_world8_bench_launch_control_only():
     lines = json_lines(r.stdout)
     assert len(lines) == 1, r.stdout
     assert lines[0]['n_gpus'] == 8 and lines[0]['rccl_ranks'] == 8
+    # the lock-step proof a SCALE record carries by itself: one exact parameter checksum and one chunk-order fingerprint per rank, all equal
+    assert len(lines[0]['replica_param_checksums']) == 8 and lines[0]['replicas_bit_identical'] is True
+    assert len(lines[0]['chunk_order_hashes']) == 8 and lines[0]['chunk_order_identical'] is True
