@@ -204,8 +204,8 @@ def test_two_rank_chunked_overlapped_exchange(tmp_path):
     assert r0[True]['plan'] is not None and r0[False]['plan'] is None
     la = r0[True]['launches']
     assert len(la) >= 1 + 3 and la == r1[True]['launches'] and not r0[False]['launches']        # user + 3 layers (+ rest), same order on both ranks
-    # the fingerprint bench.py --gpus N gathers from every rank (FlatDDP.last_order_hash): equal across ranks, non-trivial when chunks went out, 0 when none did
-    assert r0[True]['order_hash'] == r1[True]['order_hash'] != 0 and r0[False]['order_hash'] == 0
+    # the fingerprint bench.py --gpus N gathers from every rank (FlatDDP.last_order_hash): equal across ranks, non-trivial when chunks went out
+    assert r0[True]['order_hash'] == r1[True]['order_hash'] != 0
     spans = sorted(la)
     assert all(a[1] <= b[0] for a, b in zip(spans, spans[1:]))                                     # disjoint
     plan = r0[True]['plan']
