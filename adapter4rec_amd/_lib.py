@@ -12,7 +12,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('A4R_LIB_PATH') or os.path.join(_HERE, 'liba4r_hip.so')    # A4R_LIB_PATH: A/B builds (tools/), same C ABI
 
-ABI_VERSION = 408          # = A4R_ABI_VERSION of include/a4r.h (tests/test_abi_cpu.py compares the two)
+ABI_VERSION = 409          # = A4R_ABI_VERSION of include/a4r.h (tests/test_abi_cpu.py compares the two)
 BF16, F32, FP8 = 0, 1, 2
 ACT_NONE, ACT_RELU, ACT_GELU, ACT_GELU_TANH, ACT_LEAKY = 0, 1, 2, 3, 4
 DACT_MUL = 15
@@ -198,11 +198,14 @@ def adapter_ln_ok(A, d):
 
 def adapter_ln_fwd(A, R1, R2, Wd, bd, Wu, bu, gamma, beta, eps, act, zp, z, v, y, stats, M=None, y8=None, ys=None, res32=None, y32=None, frag=None):
     """res32 / y32 (fp32 [M, H], optional): the residual operand that is not A read in fp32, and y before its bf16 rounding (include/a4r.h).
+    The same two as int8 [M, H] (--residual_dtype bf24, w_frag bit 1): byte planes beside the bf16 tensors -- residual read / y written as 24-bit floats.
     frag = (Wd_f, Wu_f): the same matrices in fragment order (a4r_pack_matrices layouts 1 / 2): read instead of Wd / Wu (w_frag)."""
     require_gpu(A, R1, R2, v, y, res32, y32)
     M = A.shape[0] if M is None else M
     assert y is not None or y8 is not None
-    assert all(t is None or (t.dtype == torch.float32 and t.shape[0] >= M) for t in (res32, y32))
+    twins = [t for t in (res32, y32) if t is not None]
+    lo8 = bool(twins) and twins[0].dtype == torch.int8
+    assert all(t.dtype == (torch.int8 if lo8 else torch.float32) and t.shape[0] >= M for t in twins)
     wd_, wu_ = (Wd, Wu) if frag is None else frag
     _check(lib().a4r_adapter_ln_fwd(_stream(), _p(A), C.c_int(_ld(A)), _p(R1), C.c_int(_ld(R1)), _p(R2), C.c_int(_ld(R2) if R2 is not None else 0),
                                     _p(wd_), _p(bd), _p(wu_), _p(bu), _p(gamma), _p(beta), C.c_float(eps), C.c_int(act),
@@ -210,7 +213,7 @@ def adapter_ln_fwd(A, R1, R2, Wd, bd, Wu, bu, gamma, beta, eps, act, zp, z, v, y
                                     C.c_int(M), C.c_int(A.shape[1]), C.c_int(Wd.shape[0]), C.c_int(_dt(A)),
                                     _p(y8), C.c_int(_ld(y8) if y8 is not None else 0), _p(ys),
                                     _p(res32), C.c_int(_ld(res32) if res32 is not None else 0), _p(y32), C.c_int(_ld(y32) if y32 is not None else 0),
-                                    C.c_int(0 if frag is None else 1)),
+                                    C.c_int((0 if frag is None else 1) | (2 if lo8 else 0))),
            'a4r_adapter_ln_fwd')
 
 

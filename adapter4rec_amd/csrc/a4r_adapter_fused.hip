@@ -104,6 +104,9 @@ struct AdFwdArgs {
     // --residual_dtype fp32 (round 4): the residual stream between sub-layers in fp32, as under the reference's autocast (its LayerNorm
     // outputs fp32 and the residual add promotes to it): O32 replaces O as the residual operand, y32 is y before its bf16 rounding
     const float* O32; int ldo32; float* y32; int ldy32;
+    // --residual_dtype bf24 (round 6): the same twins as ONE BYTE per element beside the bf16 tensor -- the next 8 mantissa bits of the fp32 value
+    // as a signed offset from its bf16 rounding (lo8_of / lo8_join below): O + Olo is read as a 24-bit float, y + ylo written as one
+    const signed char* Olo; int ldolo; signed char* ylo; int ldylo;
     int wfrag;                                  // Wd / Wu in fragment order
 };
 
@@ -132,10 +135,28 @@ A4R_DEV void store_bf16_n(bf16_t* dst, const float (&v)[EPT]) {
 // byte offset of bottleneck column zd of row r in the swizzled bf16 [16][64] operand image (16-byte chunk c at c ^ ((r >> 1) & 7))
 A4R_DEV int zbf_off(int r, int zd) { return r * 128 + ((((zd >> 3) ^ ((r >> 1) & 7))) << 4) + (zd & 7) * 2; }
 
-// R32: the residual operand is the fp32 tensor O32 (two 16-byte pieces per 8 columns instead of one)
-template <int CW, int NW, bool R32 = false>
+// The 24-bit residual stream: the bf16 tensor stays the RNE rounding the GEMMs read; a byte plane beside it holds the SIGNED byte
+// d = (bits(x) - (bits(bf16) << 16)) >> 8  (the next 8 mantissa bits of the fp32 value x, truncated, as an offset in [-128, 127] from its bf16 rounding:
+// bit-pattern arithmetic, binade crossings need no case; an exact tie rounded down, d = +128, is stored as 127) and
+// x24 = (bits(bf16) << 16) + (d << 8) restores x to 2^-15 relative (7 + 8 explicit mantissa bits).  A zero byte is a zero offset: rows nobody wrote (padding) read as their bf16 value.
+// Both directions are byte permutes: 2 (join) / ~4 (split) vector instructions per element.
+A4R_DEV float lo8_join(uint32_t hw, uint32_t lw, int j) {     // element j (0 .. 7) of a piece: hw = the word of its bf16 pair, lw = the word of its byte quad
+    const uint32_t sel = ((j & 1) ? 0x07060000u : 0x05040000u) | ((uint32_t)(j & 3) << 8) | 0x0cu;
+    return __uint_as_float((__builtin_amdgcn_perm(hw, lw, sel) ^ 0x8000u) - 0x8000u);      // (hi16 | d << 8) with d sign-extended into the upper half
+}
+A4R_DEV uint32_t lo8_split4(const float (&x)[8], int m, uint32_t hw0, uint32_t hw1) {   // the byte quad of elements 4 m .. 4 m + 3 (bf16 pairs hw0, hw1 as stored)
+    auto off = [](float v, uint32_t hi16) { const int d = (int)(__float_as_uint(v) - hi16); return (uint32_t)(d < 0x7FFF ? d : 0x7FFF); };
+    const uint32_t d0 = off(x[4 * m], hw0 << 16), d1 = off(x[4 * m + 1], hw0 & 0xFFFF0000u);
+    const uint32_t d2 = off(x[4 * m + 2], hw1 << 16), d3 = off(x[4 * m + 3], hw1 & 0xFFFF0000u);
+    const uint32_t p01 = __builtin_amdgcn_perm(d1, d0, 0x0c0c0501u), p23 = __builtin_amdgcn_perm(d3, d2, 0x0c0c0501u);
+    return __builtin_amdgcn_perm(p23, p01, 0x05040100u);
+}
+
+// RM = 1: the residual operand is the fp32 tensor O32 (two 16-byte pieces per 8 columns instead of one); RM = 2: the bf16 tensor O + its byte plane Olo
+template <int CW, int NW, int RM = 0>
 __global__ void __launch_bounds__(NW * 64) adapter_ln_fwd_kernel(const AdFwdArgs p) {
-    constexpr int KS = CW / 32, H = CW * NW, NT = NW * 64, EPT = 1024 / NT, OP = R32 ? 2 : 1;
+    constexpr int KS = CW / 32, H = CW * NW, NT = NW * 64, EPT = 1024 / NT, OP = RM ? 2 : 1;
+    constexpr bool R32 = RM == 1;
     __shared__ __attribute__((aligned(16))) float zpart[NW][16][ZLD];
     __shared__ __attribute__((aligned(16))) char zbf[16 * 128];
     __shared__ float red[NW][16][2];
@@ -192,6 +213,12 @@ __global__ void __launch_bounds__(NW * 64) adapter_ln_fwd_kernel(const AdFwdArgs
         _Pragma("unroll") for (int s = 0; s < KS; ++s) {                                                               \
             dst_[2 * s] = *reinterpret_cast<const uint4*>(p.O32 + (row_) * p.ldo32 + cl + s * 32);                      \
             dst_[2 * s + 1] = *reinterpret_cast<const uint4*>(p.O32 + (row_) * p.ldo32 + cl + s * 32 + 4);              \
+        }                                                                                                              \
+    } else if constexpr (RM == 2) {                                                                                    \
+        _Pragma("unroll") for (int s = 0; s < KS; ++s) {                                                               \
+            dst_[2 * s] = *reinterpret_cast<const uint4*>(p.O + (row_) * p.ldo + cl + s * 32);                          \
+            const uint2 l_ = *reinterpret_cast<const uint2*>(p.Olo + (row_) * p.ldolo + cl + s * 32);                   \
+            dst_[2 * s + 1] = make_uint4(l_.x, l_.y, 0u, 0u);                                                           \
         }                                                                                                              \
     } else {                                                                                                           \
         _Pragma("unroll") for (int s = 0; s < KS; ++s) dst_[s] = *reinterpret_cast<const uint4*>(p.O + (row_) * p.ldo + cl + s * 32); \
@@ -281,6 +308,10 @@ __global__ void __launch_bounds__(NW * 64) adapter_ln_fwd_kernel(const AdFwdArgs
             if constexpr (R32) {
                 *reinterpret_cast<uint4*>(of) = o_cur[2 * s];
                 *reinterpret_cast<uint4*>(of + 4) = o_cur[2 * s + 1];
+            } else if constexpr (RM == 2) {
+                const uint32_t hw[4] = {o_cur[2 * s].x, o_cur[2 * s].y, o_cur[2 * s].z, o_cur[2 * s].w}, lw[2] = {o_cur[2 * s + 1].x, o_cur[2 * s + 1].y};
+#pragma unroll
+                for (int j = 0; j < 8; ++j) of[j] = lo8_join(hw[j >> 1], lw[j >> 2], j);
             } else {
                 Elem<bf16_t>::unpack(o_cur[s], of);
             }
@@ -329,6 +360,11 @@ __global__ void __launch_bounds__(NW * 64) adapter_ln_fwd_kernel(const AdFwdArgs
 #pragma unroll
             for (int j = 0; j < 8; ++j) { yv[s][j] = (vv[s][j] - mean) * rstd * g8[j] + b8[j]; am = fmaxf(am, fabsf(yv[s][j])); }
             if (p.y && (!(A4R_AD_ABL & 16) || yv[s][0] == 123.456f)) *reinterpret_cast<uint4*>(p.y + row * p.ldy + cl + s * 32) = Elem<bf16_t>::pack(yv[s]);
+            if (p.ylo) {                                     // the byte plane of y: offsets from the bf16 values just stored
+                const uint4 pk = Elem<bf16_t>::pack(yv[s]);
+                const uint32_t hw[4] = {pk.x, pk.y, pk.z, pk.w};
+                *reinterpret_cast<uint2*>(p.ylo + row * p.ldylo + cl + s * 32) = make_uint2(lo8_split4(yv[s], 0, hw[0], hw[1]), lo8_split4(yv[s], 1, hw[2], hw[3]));
+            }
             if (p.y32) {
                 *reinterpret_cast<float4*>(p.y32 + row * p.ldy32 + cl + s * 32) = make_float4(yv[s][0], yv[s][1], yv[s][2], yv[s][3]);
                 *reinterpret_cast<float4*>(p.y32 + row * p.ldy32 + cl + s * 32 + 4) = make_float4(yv[s][4], yv[s][5], yv[s][6], yv[s][7]);
@@ -690,8 +726,9 @@ inline bool misaligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p)
 
 template <int CW, int NW>
 int launch_fwd(hipStream_t s, const AdFwdArgs& a, int grid) {
-    if (a.O32) hipLaunchKernelGGL((adapter_ln_fwd_kernel<CW, NW, true>), dim3(grid), dim3(NW * 64), 0, s, a);
-    else hipLaunchKernelGGL((adapter_ln_fwd_kernel<CW, NW, false>), dim3(grid), dim3(NW * 64), 0, s, a);
+    if (a.O32) hipLaunchKernelGGL((adapter_ln_fwd_kernel<CW, NW, 1>), dim3(grid), dim3(NW * 64), 0, s, a);
+    else if (a.Olo) hipLaunchKernelGGL((adapter_ln_fwd_kernel<CW, NW, 2>), dim3(grid), dim3(NW * 64), 0, s, a);
+    else hipLaunchKernelGGL((adapter_ln_fwd_kernel<CW, NW, 0>), dim3(grid), dim3(NW * 64), 0, s, a);
     return a4r_launch_status();
 }
 template <int CW, int NW, bool DRES>
@@ -725,7 +762,10 @@ extern "C" int a4r_adapter_ln_fwd(void* stream, const void* A, int lda, const vo
                                   void* zp, void* z, void* v, int ldv, void* y, int ldy, float* stats, int M, int H, int d, int dtype,
                                   void* y8, int ld8, float* ys, const float* res32, int ldres32, float* y32, int ldy32, int w_frag) {
     if (!A || !R1 || !Wd || !bd || !Wu || !bu || !gamma || !beta || !zp || !z || (!v && !y) || (!y && !y8) || !stats) return A4R_EINVAL;      // v may be null when y is kept
-    if ((res32 && (ldres32 % 4 || ldres32 < H || misaligned16(res32))) || (y32 && (ldy32 % 4 || ldy32 < H || misaligned16(y32)))) return A4R_EINVAL;
+    const bool lo8 = (w_frag & 2) != 0;                  // res32 / y32 are BYTE planes (the 24-bit residual stream): 8-byte pieces, leading dimension in bytes
+    if (lo8) {
+        if ((res32 && (ldres32 % 8 || ldres32 < H || (reinterpret_cast<uintptr_t>(res32) & 7u))) || (y32 && (ldy32 % 8 || ldy32 < H || (reinterpret_cast<uintptr_t>(y32) & 7u)))) return A4R_EINVAL;
+    } else if ((res32 && (ldres32 % 4 || ldres32 < H || misaligned16(res32))) || (y32 && (ldy32 % 4 || ldy32 < H || misaligned16(y32)))) return A4R_EINVAL;
     if (y8 && (!ys || ld8 % 8 || ld8 < H || (reinterpret_cast<uintptr_t>(y8) & 7u))) return A4R_EINVAL;
     if (dtype != A4R_BF16 || d != 64 || M <= 0 || M % 16) return A4R_EINVAL;
     if (lda % 8 || ldr1 % 8 || (R2 && ldr2 % 8) || (v && ldv % 8) || (y && ldy % 8)) return A4R_EINVAL;
@@ -744,8 +784,9 @@ extern "C" int a4r_adapter_ln_fwd(void* stream, const void* A, int lda, const vo
     a.zp = reinterpret_cast<bf16_t*>(zp); a.z = reinterpret_cast<bf16_t*>(z); a.v = reinterpret_cast<bf16_t*>(v); a.y = reinterpret_cast<bf16_t*>(y);
     a.ldv = ldv; a.ldy = ldy; a.stats = stats; a.M = M;
     a.y8 = reinterpret_cast<unsigned char*>(y8); a.ld8 = ld8; a.ys = ys;
-    a.O32 = res32; a.ldo32 = ldres32; a.y32 = y32; a.ldy32 = ldy32;      // (res32: the fp32 twin of the residual operand that is not A)
-    a.wfrag = w_frag != 0;
+    if (lo8) { a.Olo = reinterpret_cast<const signed char*>(res32); a.ldolo = ldres32; a.ylo = reinterpret_cast<signed char*>(y32); a.ldylo = ldy32; }
+    else { a.O32 = res32; a.ldo32 = ldres32; a.y32 = y32; a.ldy32 = ldy32; }      // (res32: the fp32 twin of the residual operand that is not A)
+    a.wfrag = (w_frag & 1) != 0;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     const int ntiles = M / 16, ncu = a4r_cu_count();
     const int grid = ntiles < ncu ? ntiles : ncu;

@@ -251,7 +251,10 @@ class TransRecEngine:
         self.q8_deriv = dtype != 'fp32' and _os.environ.get('A4R_Q8_DERIV', '1') != '0'
         self.T = torch.float32 if dtype == 'fp32' else torch.bfloat16
         # --residual_dtype fp32 (bf16 storage): fp32 twins of the residual stream, keyed by the bf16 tensor they shadow (see _sub_forward)
-        self.res32 = dtype != 'fp32' and getattr(args, 'residual_dtype', 'bf16') == 'fp32'
+        self.res32 = dtype != 'fp32' and getattr(args, 'residual_dtype', 'bf24') == 'fp32'
+        # --residual_dtype bf24 (round 6): the same twins as ONE byte per element (the 24-bit residual stream of a4r_adapter_ln_fwd, w_frag bit 1) on the
+        # sub-layers that run the one-launch serial adapter kernel; the others keep the bf16 stream
+        self.res24 = dtype != 'fp32' and getattr(args, 'residual_dtype', 'bf24') == 'bf24'       # (the default since round 6)
         self._twin = {}
         # --news_attributes (encoders.py:62-99): rows are [ids | mask] per attribute, laid out title, abstract, body; every attribute runs through the
         # same tower and the item vector is the mean.  With more than one, the attributes are stacked as extra items at the longest length
@@ -1046,12 +1049,13 @@ class TransRecEngine:
         comp = ad.kind == 'compacter'  # no inner residual (modules.py:248-252); Houlsby: fc_up(act(fc_down(h))) + h, then + input (model.py:292-297)
         if self._fuse(blk, ad, h):     # ONE launch: down-projection, activation, up-projection, residual(s), LayerNorm (a4r_adapter_fused.hip)
             r32 = y32 = None
-            if self.res32 and blk.T == torch.bfloat16:
+            if (self.res32 or self.res24) and blk.T == torch.bfloat16:
                 # the residual stream in fp32 (reference under autocast: LayerNorm outputs fp32, BertSelfOutput's add promotes to it): this
                 # sub-layer reads the fp32 twin of its residual input when the sub-layer below left one, and leaves the twin of its output
-                # in one of two transient buffers (attention half / FFN half: a half's twin is dead once the next half of its kind has run)
+                # in one of two transient buffers (attention half / FFN half: a half's twin is dead once the next half of its kind has run).
+                # bf24: the twin is a byte plane (int8) -- the next 8 mantissa bits beside the bf16 tensor.
                 r32 = self._twin_of(resid, M)
-                y32 = self._buf('res32.' + which, M, blk.H, torch.float32)
+                y32 = self._buf(('res8.' if self.res24 else 'res32.') + which, M, blk.H, torch.int8 if self.res24 else torch.float32)
             L.adapter_ln_fwd(h, resid if comp else h, None if comp else resid, ad.wd, ad.bd, ad.wu, ad.bu, ln.gamma, ln.beta, ln.eps, ad.act,
                              zp, z, v, out, st, M=M, y8=y8, ys=ys, **(dict(res32=r32, y32=y32) if y32 is not None else {}), frag=ad.frag_f)
             if y32 is not None:
@@ -1130,10 +1134,14 @@ class TransRecEngine:
             ctx_c, x_c = self._buf('ctx_c', cls_rows, H, T), self._buf('x_c', cls_rows, H, T)
             self._cls_gather(ctx, ctx_c, n_items, blk.S, blk)
             self._cls_gather(x, x_c, n_items, blk.S, blk)
-            x32 = self._twin_of(x, M) if self.res32 else None
+            x32 = self._twin_of(x, M) if (self.res32 or self.res24) else None
             if x32 is not None:                        # the CLS rows of the fp32 residual stream too
-                x_c32 = self._buf('x_c32', cls_rows, H, torch.float32)
-                self._cls_gather(x32, x_c32, n_items, blk.S, blk)
+                if x32.dtype == torch.int8:            # (byte plane: its rows move as H / 2 two-byte elements)
+                    x_c32 = self._buf('x_c8', cls_rows, H, torch.int8)
+                    self._cls_gather(x32.view(torch.bfloat16), x_c32.view(torch.bfloat16), n_items, blk.S, blk)
+                else:
+                    x_c32 = self._buf('x_c32', cls_rows, H, torch.float32)
+                    self._cls_gather(x32, x_c32, n_items, blk.S, blk)
                 self._twin[x_c.data_ptr()] = x_c32
             ctx, x, M = ctx_c, x_c, cls_rows
         if 'ctx_s' in bufs and ctx is not bufs['ctx_s']:

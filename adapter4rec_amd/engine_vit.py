@@ -68,6 +68,7 @@ class ViTRecEngine(TransRecEngine):
         self.train_emb = self.d_patch.trainable or self.g_cls is not None or self.g_postab is not None or self.g_prompt is not None
         if self.g_prompt is not None and self.mae and self.train_emb:
             raise NotImplementedError('soft prompt on a ViT-MAE tower with a trainable embedding side is not wired')
+        self.res24 = False                                # (the default 24-bit stream is a post-LN text-tower form: the pre-LN image tower stores its residual stream v itself)
         if self.res32:
             raise NotImplementedError('--residual_dtype fp32 is wired for the text tower (post-LN sub-layers on the one-launch adapter kernels); the pre-LN '
                                       'image tower stores its residual stream v itself in the compute dtype')

@@ -432,9 +432,10 @@ def main():
                          'tokens) and history lengths from the 21 153 real Amazon users (mean 4.1 of 21 slots) that the reference ships '
                          '(tests/golden/real_shapes.json); implies --short-titles --ragged-histories (host hand-over, titles packed, pad slots not encoded)')
     ap.add_argument('--short-titles-device', action='store_true', help='with --short-titles: batches resident on the device (30 tokens per item: the A/B)')
-    ap.add_argument('--residual-dtype', default='bf16', choices=['bf16', 'fp32'],
-                    help="text towers: --residual_dtype fp32 of parameters.py (the residual stream between sub-layers in fp32, as under the reference's "
-                         "autocast); its cost is NOT in the headline line: measure it with this flag (recorded in config.residual_dtype)")
+    ap.add_argument('--residual-dtype', default='bf24', choices=['bf16', 'fp32', 'bf24'],
+                    help="text towers: --residual_dtype of parameters.py.  Default bf24 = the product's default since round 6 (the residual stream between sub-layers "
+                         "as bf16 + one byte: at least the accuracy of the reference's autocast path, +2.3 %% on the headline step); bf16 = round 5's stream; "
+                         'recorded in config.residual_dtype')
     ap.add_argument('--gemm-variant', type=int, default=-1, help='A/B knob of a4r_gemm_variant (include/a4r.h); default: the library default')
     a = ap.parse_args()
     if a.real_shaped:
@@ -760,7 +761,7 @@ def main():
                        # engine does not encode unread slots where that removes work (engine.py: _kept_rows; A4R_SKIP_UNUSED_ITEMS=0: all 42)
                        'items_encoded_per_user': (eng._kept_rows(a.batch) or 42 * a.batch) // a.batch, 'parallelism': f'dp{world}',
                        'path': 'public: optimizer.zero_grad(); FlatDDP(model)(items, mask); loss.backward(); FusedAdam.step()',
-                       **({'residual_dtype': 'fp32'} if a.residual_dtype == 'fp32' else {})},
+                       **({'residual_dtype': a.residual_dtype} if not image else {})},
             'rccl_ranks': rccl_ranks, 'allreduce_bytes_per_step': int(eng.flat_g.numel() * 4) if world > 1 else 0, 'allreduce_us': ar_us,
             'ms_per_step_ranks': rank_ms, 'ms_per_step_spread': round(max(rank_ms) - min(rank_ms), 3),
             'allreduce_overlapped': bool(world > 1 and eng.OVERLAP_ALLREDUCE and eng._grad_chunks() is not None),

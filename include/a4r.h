@@ -44,7 +44,7 @@ extern "C" {
 
 /* ABI version: bumped whenever a signature or struct below changes.  The Python binding (adapter4rec_amd/_lib.py) refuses a
  * library whose a4r_version() differs, so an A/B build made before a signature change cannot be called with shifted arguments. */
-#define A4R_ABI_VERSION 408
+#define A4R_ABI_VERSION 409
 int a4r_version(void);
 
 /* C[M,N] = epilogue(alpha * A[M,K] . B[N,K]^T): every nn.Linear on the path (HF BertSelfAttention
@@ -197,7 +197,11 @@ int a4r_adapter_ln_fwd(void* stream, const void* A, int lda, const void* R1, int
                        void* y8, int ld8, float* ys,    /* y8 / ys (optional; y may then be NULL): y as OCP e4m3 + per-row scale, the
                                                            arithmetic of a4r_ln_fwd_fp8 (the fp8 A operand of the GEMM that follows) */
                        const float* res32, int ldres32, float* y32, int ldy32,
-                       int w_frag);   /* != 0: Wd, Wu are in FRAGMENT order (a4r_pack_matrices layouts 1 and 2 below), see the note under the backward */
+                       int w_frag);   /* bit 0: Wd, Wu are in FRAGMENT order (a4r_pack_matrices layouts 1 and 2 below), see the note under the backward;
+                                         bit 1 (ABI 409, --residual_dtype bf24): res32 / y32 are BYTE planes (int8 [M, ld], ld in bytes, 8-byte aligned) -- the 24-bit
+                                         residual stream: value = (bits(bf16 tensor) << 16) + (signed byte << 8), i.e. the fp32 value cut to 15 explicit mantissa
+                                         bits, stored as its bf16 rounding (the tensor the GEMMs read, unchanged) + the offset from it (a zero byte = no offset).  One more byte
+                                         read and written per element instead of four, the accuracy of the fp32 stream to 2^-15 (7 + 8 explicit mantissa bits) */
 /* The LayerNorm of the forward runs on the fp32 sum v (its bf16 copy `v`, when asked for, is for the backward only).
  * res32 / y32 (both optional; --residual_dtype fp32): the residual stream between sub-layers kept in fp32, as under the reference's
  * autocast (LayerNorm outputs fp32 there and `hidden_states + input_tensor` promotes to it, HF BertSelfOutput / BertOutput under

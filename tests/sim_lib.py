@@ -102,6 +102,10 @@ def adapter_ln_fwd(A, R1, R2, Wd, bd, Wu, bu, gamma, beta, eps, act, zp, z, v, y
     """a4r_adapter_ln_fwd: zp = A Wd^T + bd; z = act(zp); v = z Wu^T + bu + R1 + R2; y = LN(v) (bf16 storage points as the kernel's).
     res32: the fp32 twin of the residual operand that is not A; y32: y before its bf16 rounding."""
     M = A.shape[0] if M is None else M
+    lo8 = (res32 is not None and res32.dtype == torch.int8) or (y32 is not None and y32.dtype == torch.int8)
+    if lo8 and res32 is not None:            # the byte plane joins the bf16 residual that is not A into a 24-bit float
+        other = R2 if (R2 is not None and (R1 is A or R1.data_ptr() == A.data_ptr())) else R1
+        res32 = lo8_join(other[:M], res32[:M])
     if res32 is not None:                    # replaces the residual that is not A
         if R2 is None or R1 is A or R1.data_ptr() == A.data_ptr():
             R1, R2 = (R1, res32) if R2 is not None else (res32, None)
@@ -126,9 +130,30 @@ def adapter_ln_fwd(A, R1, R2, Wd, bd, Wu, bu, gamma, beta, eps, act, zp, z, v, y
     if y is not None:
         y[:M] = out.to(y.dtype)
     if y32 is not None:
-        y32[:M] = out
+        if lo8:
+            y32[:M] = lo8_of(out, out.to(torch.bfloat16))
+        else:
+            y32[:M] = out
     if y8 is not None:
         _quant_rows(out, y8, ys)
+
+
+def lo8_of(x, xb):
+    """The byte plane of the 24-bit residual stream (csrc/a4r_adapter_fused.hip: lo8_split4): the next 8 mantissa bits of the fp32 value x (truncated)
+    as a signed offset in [-128, 127] from its bf16 rounding xb -- bit-pattern arithmetic; an exact tie rounded down (+128) is stored as 127."""
+    b = x.contiguous().view(torch.int32).to(torch.int64) & 0xFFFFFFFF
+    bf = (xb.contiguous().view(torch.int16).to(torch.int64) & 0xFFFF) << 16
+    d = (b - bf) & 0xFFFFFFFF
+    d = torch.where(d >= 2 ** 31, d - 2 ** 32, d)
+    return (torch.clamp(d, max=0x7FFF) >> 8).to(torch.int8)
+
+
+def lo8_join(xb, lo):
+    """bf16 tensor + byte plane -> the 24-bit float as fp32: (bits(bf16) << 16) + (d << 8)"""
+    bf = (xb.contiguous().view(torch.int16).to(torch.int64) & 0xFFFF) << 16
+    bits = (bf + (lo.to(torch.int64) << 8)) & 0xFFFFFFFF
+    bits = torch.where(bits >= 2 ** 31, bits - 2 ** 32, bits).to(torch.int32)
+    return bits.view(torch.float32)
 
 
 def adapter_ln_bwd(dy, v, stats, gamma, dres, zp, act, WuT, WdT, inner_res, dv, dzp, dh, dgamma=None, dbeta=None, dbias=None, M=None,

@@ -240,14 +240,14 @@ def test_step_bf16_residual_fp32():
     out, grads = R.loss_and_grads(sd, trainable, items.cpu(), mask.cpu(), cfg)
     inner = getattr(root, 'model', root)
     res = {}
-    for rd in ('bf16', 'fp32'):
+    for rd in ('bf16', 'fp32', 'bf24'):
         inner.args.residual_dtype = rd
         inner.invalidate_native()
         for p in root.parameters():
             p.grad = None
         loss = root(items, mask, 0)
         loss.backward()
-        assert inner._engine().res32 == (rd == 'fp32')
+        assert inner._engine().res32 == (rd == 'fp32') and inner._engine().res24 == (rd == 'bf24')
         emb = inner.bert_encoder(items).cpu()
         params = dict(root.named_parameters())
         worst = max(float(np.abs(params[str(k)].grad.cpu().numpy() - grads[strip(str(k))].numpy()).max() / (np.abs(grads[strip(str(k))].numpy()).max() + 1e-12))
@@ -259,6 +259,9 @@ def test_step_bf16_residual_fp32():
     assert r32['loss'] < 2e-2 and r32['emb_err'] < 2e-2 and r32['grad'] < 0.15, r32
     assert not torch.equal(r32['emb'], r16['emb'])
     assert r32['emb_rms'] <= 1.05 * r16['emb_rms'], (r32['emb_rms'], r16['emb_rms'])
+    r24 = res['bf24']                                  # the 24-bit stream (one byte per element beside the bf16 tensor): what the fp32 twins buy
+    assert r24['loss'] < 2e-2 and r24['emb_err'] < 2e-2 and r24['grad'] < 0.15, r24
+    assert not torch.equal(r24['emb'], r16['emb']) and r24['emb_rms'] <= 1.02 * r32['emb_rms'] + 1e-6, (r24['emb_rms'], r32['emb_rms'])
 
 
 @pytest.mark.parametrize('name', ['houlsby', 'roberta_cpc_pfeiffer'])

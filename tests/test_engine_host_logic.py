@@ -234,7 +234,7 @@ def test_host_logic_residual_fp32(simulated, name):
     tr = [strip(str(k)) for k in fx['trainable']]
     out, grads = R.loss_and_grads(sd, tr, items, mask, cfg)
     res = {}
-    for rd in ('bf16', 'fp32'):
+    for rd in ('bf16', 'fp32', 'bf24'):              # bf24 (round 6): the same twins as one byte per element, on the one-launch serial adapter sub-layers
         inner.args.residual_dtype = rd
         inner.invalidate_native()
         for p in root.parameters():
@@ -256,6 +256,11 @@ def test_host_logic_residual_fp32(simulated, name):
     assert res['fp32'][0] < 2e-2 and res['fp32'][3] < 0.15, (res['fp32'][::3], res['bf16'][::3])
     assert not torch.equal(res['fp32'][1], res['bf16'][1])
     assert res['fp32'][2] <= 1.05 * res['bf16'][2], (res['fp32'][2], res['bf16'][2])
+    assert res['bf24'][0] < 2e-2 and res['bf24'][3] < 0.15, res['bf24'][::3]
+    assert res['bf24'][2] <= 1.05 * res['bf16'][2], (res['bf24'][2], res['bf16'][2])
+    if name == 'houlsby':                            # every sub-layer on the one-launch kernel: the byte planes are consumed, and buy what the fp32 twins buy
+        assert not torch.equal(res['bf24'][1], res['bf16'][1])
+        assert res['bf24'][2] <= 1.02 * res['fp32'][2] + 1e-6, (res['bf24'][2], res['fp32'][2])
 
 
 def build_lora_cpu(dtype='fp32'):

@@ -2035,3 +2035,45 @@ def test_adapter_ln_fragment_ordered_weights_bit_equal(H):
         assert torch.equal(a, b), f'backward {nm}: fragment-ordered launch differs'
     assert float(outs[0][2].abs().max()) > 0
 
+
+
+def test_adapter_ln_fwd_24bit_residual_stream():
+    """--residual_dtype bf24 (ABI 409, w_frag bit 1): the fused adapter forward reads its residual as bf16 tensor + byte plane (a 24-bit float) and writes
+    y the same way.  (a) the byte plane it writes joins with y (bf16) to the fp32 LayerNorm output within 2^-16 relative (the fp32 twin of the same
+    launch is the reference); (b) fed back as the residual of a second launch, the result equals the launch fed the fp32 twin to 1e-5 -- and differs
+    from the launch fed the bf16 tensor alone; (c) the plane is exactly what tests/sim_lib.lo8_of restates."""
+    from adapter4rec_amd import _lib as L
+    import sim_lib
+    M, H, d = 2048, 768, 64
+    t = torch.bfloat16
+    A, R = rnd(M, H, dtype=t, seed=1), rnd(M, H, dtype=t, seed=2)
+    Wd, Wu = rnd(d, H, dtype=t, scale=0.05, seed=3), rnd(H, d, dtype=t, scale=0.05, seed=4)
+    bd, bu, gam, bet = rnd(d, scale=0.1, seed=5), rnd(H, scale=0.1, seed=6), 1 + rnd(H, scale=0.1, seed=7), rnd(H, scale=0.1, seed=8)
+    mk = lambda c, dt=t: torch.zeros(M, c, dtype=dt, device=dev())
+    def run(res=None, twin_dtype=None):
+        zp, z, v, y, st = mk(d), mk(d), mk(H), mk(H), torch.zeros(M, 2, device=dev())
+        tw = mk(H, twin_dtype) if twin_dtype is not None else None
+        L.adapter_ln_fwd(A, A, R, Wd, bd, Wu, bu, gam, bet, 1e-12, L.ACT_GELU, zp, z, v, y, st, **(dict(res32=res, y32=tw) if (res is not None or tw is not None) else {}))
+        return y, tw
+    y0, y32 = run(twin_dtype=torch.float32)
+    y1, y8 = run(twin_dtype=torch.int8)
+    assert torch.equal(y0, y1)                                   # the bf16 tensor the GEMMs read is untouched
+    joined = sim_lib.lo8_join(y1.cpu(), y8.cpu())
+    rel = ((joined - y32.cpu()).abs() / y32.cpu().abs().clamp_min(1e-3)).max().item()
+    assert rel < 2.0 ** -14, rel                        # (7 + 8 = 15 explicit mantissa bits, truncated: < 2^-15)
+    assert float((y1.float().cpu() - y32.cpu()).abs().max()) > 20 * float((joined - y32.cpu()).abs().max())      # ... and far closer than bf16 alone
+    assert torch.equal(y8.cpu(), sim_lib.lo8_of(y32.cpu(), y1.cpu()))             # (both cut the SAME fp32 values: the kernel writes y32 and the plane from one register)
+    # second launch: residual = the first launch's output, as fp32 twin / as byte plane / bf16 only
+    R2 = y1
+    def run2(res):
+        zp, z, v, y, st = mk(d), mk(d), mk(H), mk(H), torch.zeros(M, 2, device=dev())
+        out32 = mk(H, torch.float32) if (res is None or res.dtype == torch.float32) else None
+        o8 = mk(H, torch.int8) if out32 is None else None
+        L.adapter_ln_fwd(A, A, R2, Wd, bd, Wu, bu, gam, bet, 1e-12, L.ACT_GELU, zp, z, v, y, st, res32=res, y32=out32 if out32 is not None else o8)
+        return out32 if out32 is not None else sim_lib.lo8_join(y.cpu(), o8.cpu()).to(dev())
+    f32 = run2(y32)
+    b24 = run2(y8)
+    b16 = run2(None)
+    e24, e16 = float((b24 - f32).abs().max()), float((b16 - f32).abs().max())
+    print(f'second sub-layer vs the fp32-stream launch: 24-bit stream {e24:.2e}, bf16 stream {e16:.2e}')
+    assert e24 < 2e-4 and e16 > 10 * e24
