@@ -293,6 +293,42 @@ def test_cv_bf16_vs_oracle(name):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize('name', ['cv_vit_houlsby', 'cv_vit_compacter'])
+def test_cv_bf16_vs_reference_autocast(name):
+    """The image tower's bf16 step against the reference's OWN reduced-precision path (round 6; the text tower has had this since round 3):
+    <name>_autocast.npz (tools/gen_golden_cv.py --autocast-only) holds the reference's wrappers under torch.autocast(bfloat16) -- `with autocast():
+    bz_loss = model(...)`, Downstream/CV/run_adapter.py:565-593 (fp16 + GradScaler on CUDA there) -- on the weights and batch of <name>.npz.  Both
+    distances are measured from the SAME fp32 reference numbers: HIP bf16 may be at most 2x as far from them as the reference's autocast step."""
+    import os
+    from golden_util import GOLDEN
+    root, args, sd, cfg, fx, images, mask, noise = build(name, device='cuda:0', dtype='bf16')
+    ac = np.load(os.path.join(GOLDEN, name + '_autocast.npz'))
+    loss = root(images, mask, 'cuda:0')
+    loss.backward()
+    inner = getattr(root, 'model', root)
+    embs = inner.cv_encoder(images).cpu().numpy()
+    params = dict(root.named_parameters())
+    rms = lambda a: float(np.sqrt(np.mean(np.square(a.astype(np.float64)))))
+    d_hip = dict(loss=abs(loss.item() - float(fx['loss'])), emb=rms(embs - fx['input_embs_all']))
+    d_ac = dict(loss=abs(float(ac['loss']) - float(fx['loss'])), emb=rms(ac['input_embs_all'] - fx['input_embs_all']))
+    g_hip, g_ac = [], []
+    for k in fx['trainable']:
+        k = str(k)
+        ref = fx['grad/' + k]
+        s_ = np.abs(ref).max() + 1e-30
+        g_hip.append(np.abs(params[k].grad.cpu().numpy() - ref).max() / s_)
+        g_ac.append(np.abs(ac['grad/' + k] - ref).max() / s_)
+    ratio = np.array(g_hip) / (np.array(g_ac) + 1e-12)
+    med, p90 = float(np.median(ratio)), float(np.percentile(ratio, 90))
+    print(f'{name}: HIP bf16 vs fp32 reference {d_hip}, worst gradient {max(g_hip):.3f}; reference autocast(bf16) vs fp32 reference {d_ac}, worst gradient {max(g_ac):.3f}; '
+          f'per-tensor gradient error ratio: median {med:.2f}, 90th percentile {p90:.2f}')
+    assert d_hip['emb'] <= 2.0 * d_ac['emb'] + 1e-3, (d_hip, d_ac)
+    assert d_hip['loss'] <= 2.0 * d_ac['loss'] + 5e-2, (d_hip, d_ac)
+    assert med <= 2.0 and p90 <= 3.0, (med, p90)
+    assert max(g_hip) <= 3.0 * max(g_ac) + 2e-2, (max(g_hip), max(g_ac))
+
+
+@pytest.mark.gpu
 def test_cv_patchify_u8_matches_float():
     from adapter4rec_amd import _lib as L
     g = torch.Generator().manual_seed(3)

@@ -299,7 +299,7 @@ def base_name(k):
         .replace('.transformer_blocks.transformer_blocks.', '.transformer_blocks.')
 
 
-def run_variant(name, base_model, images, masks, noise, args, layernorm=False):
+def run_variant(name, base_model, images, masks, noise, args, layernorm=False, autocast_only=False):
     torch.manual_seed(2000 + sum(map(ord, name)))
     m = copy.deepcopy(base_model)
     if args.arch == 'cpc':
@@ -345,6 +345,24 @@ def run_variant(name, base_model, images, masks, noise, args, layernorm=False):
     for n_, p in m.named_parameters():
         if p.requires_grad:
             out['grad/' + n_] = p.grad.detach().numpy().copy()
+    if autocast_only:
+        # round 6 (VERDICT r5 housekeeping): the same weights and batch once more under torch.autocast(bfloat16) -- the reference's reduced-precision
+        # path (`with autocast(): bz_loss = model(...)`, Downstream/CV/run_adapter.py:565-593; fp16 + GradScaler on CUDA, bf16 here as for the text
+        # tower's *_autocast.npz) -> <name>_autocast.npz: loss, embeddings, every trainable gradient; the fp32 numbers stay in <name>.npz
+        fx = np.load(os.path.join(OUT, name + '.npz'))
+        assert abs(float(fx['loss']) - float(loss)) < 1e-6, 'the rebuilt model is not the fixture\'s'
+        m.zero_grad()
+        with torch.autocast('cpu', dtype=torch.bfloat16):
+            l_ac = m(images, masks, 'cpu')
+            embs_ac = inner.cv_encoder(images)
+        l_ac.float().backward()
+        ac = dict(loss=np.array(float(l_ac.detach().float())), input_embs_all=embs_ac.detach().float().numpy())
+        for n_, p in m.named_parameters():
+            if p.requires_grad:
+                ac['grad/' + n_] = p.grad.detach().float().numpy().copy()
+        np.savez_compressed(os.path.join(OUT, name + '_autocast.npz'), **ac)
+        print(f"{name}_autocast: loss {float(ac['loss']):.6f} (fp32 {float(loss):.6f}); emb err {np.abs(ac['input_embs_all'] - out['input_embs_all']).max():.3e}")
+        return
     if trainable:
         opt = optimizer_for(m)
         losses = []
@@ -401,7 +419,7 @@ def main():
     base_mae.eval()
     d1, d2 = check_against_installed_hf(vit, mae_net, images[:6], noise[:6])
 
-    if not (len(sys.argv) > 1 and sys.argv[1] in ('--parallel-only', '--prompt-only', '--kadapter-only')):
+    if not (len(sys.argv) > 1 and sys.argv[1] in ('--parallel-only', '--prompt-only', '--kadapter-only', '--autocast-only')):
       np.savez_compressed(os.path.join(OUT, 'cv_base.npz'), images=images.numpy(), log_mask=masks.numpy(), noise=noise.numpy(),
                         hf_check=np.array([d1, d2]), **{'sd/' + k: v.numpy() for k, v in base.state_dict().items()})
       np.savez_compressed(os.path.join(OUT, 'cv_base_mae.npz'), **{'sd/' + k: v.numpy() for k, v in base_mae.state_dict().items()})
@@ -412,6 +430,10 @@ def main():
         run_variant('cv_vit_kadapter', base, images, masks, noise,
                     make_args(adapter_type='kadapter', k_adapter_bert_list='0,1', k_adapter_bert_hidden_dim=64, num_adapter_heads_bert=2,
                               num_adapter_heads_sasrec=2))
+        return
+    if len(sys.argv) > 1 and sys.argv[1] == '--autocast-only':     # added in round 6: <name>_autocast.npz for two variants, the others untouched
+        run_variant('cv_vit_houlsby', base, images, masks, noise, make_args(), autocast_only=True)
+        run_variant('cv_vit_compacter', base, images, masks, noise, make_args(adapter_type='compacter'), autocast_only=True)
         return
     if len(sys.argv) > 1 and sys.argv[1] == '--prompt-only':
         run_variant('cv_vit_prompt', base, images, masks, noise, make_args(adapter_type='prompt', n_tokens=5))
