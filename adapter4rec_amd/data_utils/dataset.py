@@ -125,5 +125,12 @@ class SequentialDistributedSampler(torch.utils.data.sampler.Sampler):
         idx += [idx[-1]] * (self.total_size - len(idx))
         return iter(idx[self.rank * self.num_samples:(self.rank + 1) * self.num_samples])
 
+    def indices(self):
+        """this rank's indices as an int64 array (what __iter__ yields; eval_model takes them without a Python list of 10^5 ints)"""
+        import numpy as np
+        n = len(self.dataset)
+        idx = np.minimum(np.arange(self.rank * self.num_samples, (self.rank + 1) * self.num_samples, dtype=np.int64), n - 1)
+        return idx
+
     def __len__(self):
         return self.num_samples

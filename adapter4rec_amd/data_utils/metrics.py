@@ -80,12 +80,12 @@ def _prepare_eval_set(eval_seq, user_history, Lm, dev):
     evaluation of a run: the tensors are cached per (dict identities, sizes) and stay on the device."""
     import itertools
     n = len(eval_seq)
-    lens = np.fromiter((len(eval_seq[u]) for u in range(n)), dtype=np.int64, count=n)
-    total = int(lens.sum())
-    key = (id(eval_seq), id(user_history), n, total, Lm, str(dev))
+    key = (id(eval_seq), id(user_history), n, Lm, str(dev))
     hit = _PREP.get(key)
     if hit is not None and hit['_src'][0] is eval_seq and hit['_src'][1] is user_history:      # (the entry keeps both dicts alive: their ids cannot be re-used)
         return hit
+    lens = np.fromiter((len(eval_seq[u]) for u in range(n)), dtype=np.int64, count=n)
+    total = int(lens.sum())
     if n and int(lens.max()) > Lm:
         raise ValueError(f'an evaluation sequence of {int(lens.max())} items exceeds max_seq_len + 1 = {Lm}')
     flat = np.fromiter(itertools.chain.from_iterable(eval_seq[u] for u in range(n)), dtype=np.int64, count=total)
@@ -115,7 +115,8 @@ def _prepare_eval_set(eval_seq, user_history, Lm, dev):
     hptr = np.zeros(n + 1, dtype=np.int64)
     np.cumsum(hl, out=hptr[1:])
     prep = dict(ids=torch.from_numpy(ids).to(dev), mask=torch.from_numpy(mask).to(dev), target=torch.from_numpy(target).to(dev),
-                hptr=torch.from_numpy(hptr).to(dev), hlen=torch.from_numpy(hl).to(dev), hflat=hflat.to(dev), _src=(eval_seq, user_history))
+                hptr=torch.from_numpy(hptr).to(dev), hptr_host=hptr, target32=torch.from_numpy(target.astype(np.int32)).to(dev),
+                hflat32=torch.cat([hflat.to(torch.int32), torch.zeros(1, dtype=torch.int32)]).to(dev), _src=(eval_seq, user_history))
     if len(_PREP) >= 8:
         _PREP.clear()
     _PREP[key] = prep
@@ -132,28 +133,37 @@ def eval_ranks(model, user_history, eval_seq, item_embeddings, test_batch_size, 
     if len(user_ids) == 0:
         return torch.zeros(0, dtype=torch.int32, device=dev)
     P = _prepare_eval_set(eval_seq, user_history, Lm, dev)
-    uid = torch.as_tensor(np.asarray(user_ids, dtype=np.int64), device=dev)
+    uid_all = np.asarray(user_ids, dtype=np.int64)
+    # (the sampler pads its tail by REPEATING the last user: a repeated id takes the rank of the entry before it)
+    first = np.concatenate([[True], np.diff(uid_all) != 0])
+    uid_np = uid_all[first]
+    # SequentialDistributedSampler hands every rank a run of consecutive users (its tail repeats the last ones): a batch of CONSECUTIVE users is a
+    # slice of every prepared tensor -- no gather, no host-device round trip for the history count
+    runs = np.flatnonzero(np.diff(uid_np) != 1) + 1
+    bounds = np.concatenate([[0], runs, [uid_np.size]])
     # the reference's test_batch_size (256 - 512 users) is sized for ITS [users, items] score matrix; nothing of that size exists here: the user tower
     # and the rank kernel take 8 192 users per call (A4R_EVAL_USER_BATCH overrides it)
     step = int(os.environ.get('A4R_EVAL_USER_BATCH', 0)) or max(int(test_batch_size), 8192)
+    hptr_host = P['hptr_host']
     ranks = []
     with torch.no_grad():
-        for s in range(0, uid.numel(), step):
-            ub = uid[s:s + step]
-            nb = ub.numel()
-            input_embs = emb[P['ids'][ub].view(-1)].view(nb, Lm - 1, E)
-            prec = inner.user_encoder(input_embs, P['mask'][ub], None)[:, -1].contiguous()
-            # this batch's histories as CSR: ptr = running sum of their lengths, ids gathered from the flat store
-            hl = P['hlen'][ub]
-            ptr = torch.zeros(nb + 1, dtype=torch.int64, device=dev)
-            torch.cumsum(hl, 0, out=ptr[1:])
-            tot = int(ptr[-1].item())
-            src = torch.repeat_interleave(P['hptr'][ub] - ptr[:-1], hl, output_size=tot) + torch.arange(tot, device=dev)
-            hist = torch.cat([P['hflat'][src], torch.zeros(1, dtype=torch.int64, device=dev)]).to(torch.int32)
-            rank = torch.zeros(nb, dtype=torch.int32, device=dev)
-            L.eval_rank(prec, emb, P['target'][ub].to(torch.int32), ptr.to(torch.int32), hist, rank)
-            ranks.append(rank)
-    return torch.cat(ranks)
+        for r0, r1 in zip(bounds[:-1], bounds[1:]):
+            for s0 in range(int(r0), int(r1), step):
+                a = int(uid_np[s0])
+                nb = min(step, int(r1) - s0)
+                b = a + nb
+                input_embs = emb[P['ids'][a:b].reshape(-1)].view(nb, Lm - 1, E)
+                prec = inner.user_encoder(input_embs, P['mask'][a:b], None)[:, -1].contiguous()
+                h0, h1 = int(hptr_host[a]), int(hptr_host[b])
+                ptr = (P['hptr'][a:b + 1] - h0).to(torch.int32)
+                hist = P['hflat32'][h0:h1 + 1]                 # (+ 1: the kernel's table is never empty; the store ends in one spare 0)
+                rank = torch.zeros(nb, dtype=torch.int32, device=dev)
+                L.eval_rank(prec, emb, P['target32'][a:b], ptr, hist, rank)
+                ranks.append(rank)
+    out = torch.cat(ranks)
+    if not first.all():
+        out = out[torch.from_numpy(np.cumsum(first) - 1).to(dev)]
+    return out
 
 
 def eval_model(model, user_history, eval_seq, item_embeddings, test_batch_size, args, item_num, Log_file, v_or_t, local_rank):
@@ -161,8 +171,8 @@ def eval_model(model, user_history, eval_seq, item_embeddings, test_batch_size, 
     world = dist.get_world_size() if dist.is_initialized() else 1
     rank_id = dist.get_rank() if dist.is_initialized() else 0
     n_users = len(eval_seq)
-    sampler = SequentialDistributedSampler(list(range(n_users)), test_batch_size, rank=rank_id, num_replicas=world)
-    user_ids = list(iter(sampler))
+    sampler = SequentialDistributedSampler(range(n_users), test_batch_size, rank=rank_id, num_replicas=world)
+    user_ids = sampler.indices()
     model.eval()
     topK = 10
     Log_file.info(v_or_t + '_methods   {}'.format('\t'.join(['Hit{}'.format(topK), 'nDCG{}'.format(topK)])))
