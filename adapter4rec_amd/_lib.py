@@ -27,6 +27,7 @@ EXPORTS = [
     'a4r_score_bce_bwd', 'a4r_emb_grad_add_inputs', 'a4r_take_inputs', 'a4r_adam_step', 'a4r_pack_matrices',
     'a4r_eval_rank', 'a4r_dropout_apply', 'a4r_gemm_variant', 'a4r_gemm_tail_plan', 'a4r_gemm_tail_max', 'a4r_gemm_rows_256', 'a4r_adapter_ln_fwd', 'a4r_adapter_ln_bwd', 'a4r_ln_fwd_fp8', 'a4r_ln_fwd_sum', 'a4r_quant_rows_fp8', 'a4r_lora_merge', 'a4r_lora_merge_batch', 'a4r_lora_bwd_fused', 'a4r_lora_bwd_fused_ws_floats', 'a4r_phm_build', 'a4r_phm_bwd', 'a4r_unpack_add', 'a4r_memset_zero',
     'a4r_sasrec_block_fwd', 'a4r_sasrec_block_bwd', 'a4r_scatter_rows_fill', 'a4r_attn_long_fwd', 'a4r_attn_long_bwd', 'a4r_patchify', 'a4r_vit_assemble', 'a4r_resample_u8', 'a4r_embed_bwd', 'a4r_mae_keep_indices',
+    'a4r_encoder_layer_fwd', 'a4r_encoder_layer_bwd',
 ]
 
 
@@ -58,6 +59,24 @@ class PackDesc(C.Structure):
 class PhmDesc(C.Structure):
     _fields_ = [('rule_off', C.c_int64), ('wl_off', C.c_int64), ('wr_off', C.c_int64), ('out_off', C.c_int64), ('G', C.c_void_p),
                 ('ldg', C.c_int32), ('in_f', C.c_int32), ('out_f', C.c_int32), ('n', C.c_int32), ('pad_', C.c_int32)]
+
+
+class LayerAdapter(C.Structure):
+    """a4r_layer_adapter_t (include/a4r.h)."""
+    _fields_ = [(n, C.c_void_p) for n in ('wd', 'wu', 'wdT', 'wuT', 'wd_f', 'wu_f', 'wdT_f', 'wuT_f', 'bd', 'bu', 'g_wu', 'g_wd', 'g_bu', 'g_bd')] + \
+               [(n, C.c_int32) for n in ('ldg_wu', 'ldg_wd', 'act', 'pad_')]
+
+
+class EncoderLayer(C.Structure):
+    """a4r_encoder_layer_t (include/a4r.h): one post-LN encoder layer with serial Houlsby adapters for a4r_encoder_layer_fwd / _bwd."""
+    _fields_ = [(n, C.c_int32) for n in ('M', 'H', 'F', 'n_items', 'S', 'n_heads', 'dh', 'causal')] + \
+               [(n, C.c_float) for n in ('scale', 'mask_neg', 'ln_eps', 'p_attn', 'p_hidden')] + [('drop_site', C.c_uint32), ('drop_seed', C.c_uint64)] + \
+               [(n, C.c_void_p) for n in ('key_mask', 'offsets', 'wqkv', 'wqkvT', 'wo', 'woT', 'wi', 'wiT', 'wo2', 'wo2T',
+                                          'bqkv', 'bo', 'bi', 'bo2', 'ln1_g', 'ln1_b', 'ln2_g', 'ln2_b')] + \
+               [('ad', LayerAdapter * 2)] + \
+               [(n, C.c_void_p) for n in ('qkv', 'ctx', 'h1', 'v1', 'zp1', 'z1', 'u', 'upre', 'h2', 'v2', 'zp2', 'z2', 'st1', 'st2')] + \
+               [('upre_q8', C.c_int32), ('q8_tiled', C.c_int32)] + \
+               [(n, C.c_void_p) for n in ('x_lo', 'x1_lo', 'xout_lo', 'dv1', 'dv2', 'dzp', 'd_h', 'du', 'dx1', 'dctx', 'dqkv')]
 
 
 class SasrecBlock(C.Structure):
@@ -351,6 +370,18 @@ def attn_long_bwd(qkv, out, dout, dqkv, lse, delta_ws, n_items, S, n_heads, dh, 
     assert _ld(out) == _ld(dout)
     a.out, a.dout, a.ldo, a.dqkv = _p(out), _p(dout), _ld(dout), _p(dqkv)
     _check(lib().a4r_attn_long_bwd(_stream(), C.byref(a), _p(lse), _p(delta_ws)), 'a4r_attn_long_bwd')
+
+
+def encoder_layer_fwd(desc, x, x1, x_out):
+    """a4r_encoder_layer_fwd: the 7 launches of one post-LN encoder layer with serial Houlsby adapters from ONE call (desc: EncoderLayer)."""
+    require_gpu(x, x1, x_out)
+    _check(lib().a4r_encoder_layer_fwd(_stream(), C.byref(desc), _p(x), _p(x1), _p(x_out)), 'a4r_encoder_layer_fwd')
+
+
+def encoder_layer_bwd(desc, x1, x_out, dx_out, dx_in):
+    """a4r_encoder_layer_bwd: its 9 backward launches (dx_in None: the d qkv product is skipped)."""
+    require_gpu(x1, x_out, dx_out, dx_in)
+    _check(lib().a4r_encoder_layer_bwd(_stream(), C.byref(desc), _p(x1), _p(x_out), _p(dx_out), _p(dx_in)), 'a4r_encoder_layer_bwd')
 
 
 def patchify(img, out, patch, keep_idx=None):

@@ -1103,12 +1103,121 @@ class TransRecEngine:
         """The one-launch adapter kernels apply (bf16, bottleneck 64, a width they are instantiated for, no zero-padded block)."""
         return self.fuse_adapters and getattr(blk, 'Hv', blk.H) == blk.H and L.adapter_ln_ok(t, ad.dp)
 
+    # ---- one C call per layer (a4r_encoder_layer_fwd / _bwd, ABI 409): the launches below, sequenced by the library for the layers it covers --
+    # bf16, short attention, serial Houlsby adapters on the one-launch kernels on both halves, frozen backbone.  Bit-identical to the per-launch path
+    # (tests/test_layer_call_gpu.py); A4R_LAYER_CALL=0 keeps the per-launch path everywhere.
+    LAYER_CALL = _os.environ.get('A4R_LAYER_CALL', '1') != '0'
+    _LAYER_DBG = _os.environ.get('A4R_LAYER_CALL', '1')          # (2: forward only, 3: backward only -- bisecting)
+
+    def _layer_ok(self, blk, bufs, cls_rows, backward):
+        if not (self.LAYER_CALL and hasattr(L, 'encoder_layer_fwd') and blk.T == torch.bfloat16 and not self.fp8 and not self.res32):
+            return False
+        if (self._LAYER_DBG == '2' and backward) or (self._LAYER_DBG == '3' and not backward):
+            return False
+        if cls_rows is not None or getattr(blk, 'long', False) or blk.lora or blk.train_dense or hasattr(blk, 'lnA') or getattr(blk, 'Hv', blk.H) != blk.H:
+            return False
+        if any(k in bufs for k in ('xin', 'x1s', 'ctx_s', 'u_s')) or blk.ffn_act != L.ACT_GELU or blk.S > 32 or blk.H not in (128, 256, 512, 768):
+            return False
+        if any(d is not None and d.trainable for d in blk.qkv):
+            return False
+        for ad, pl, ln in ((blk.ad1, blk.pl1, blk.ln1), (blk.ad2, blk.pl2, blk.ln2)):
+            if ad is None or pl != 'serial' or ad.kind == 'compacter' or ad.virtual is not None or ad.dp != 64 or not self.fuse_adapters:
+                return False
+            if ln.g_gamma is not None or ln.g_beta is not None:
+                return False
+            if backward and ad.g_wu is not None and not (TN2 and TN2_BIAS and not WGRAD_STREAM and ad.s_wu is None and ad.s_bd is None and ad.g_bu is not None
+                                                         and ad.g_bd is not None and self._bd_target(ad) is not None):
+                return False
+        return True
+
+    def _layer_desc(self, blk, bufs, M):
+        """The a4r_encoder_layer_t of (block, buffer set): static fields once, the per-step ones (seed, item count, masks, twins) by the caller."""
+        key = (id(blk), id(bufs), M)
+        cache = self.__dict__.setdefault('_layer_descs', {})
+        hit = cache.get(key)
+        if hit is not None and hit['bufs'] is bufs:        # (the entry keeps the buffer set alive: its id cannot be re-used by another one)
+            return hit
+        if len(cache) >= 256:                              # (a new buffer set per call under ragged batches / inference: bounded)
+            cache.clear()
+        T, H, F = blk.T, blk.H, blk.F
+        d = L.EncoderLayer()
+        d.M, d.H, d.F, d.S, d.n_heads, d.dh, d.causal = M, H, F, blk.S, blk.nh, blk.dh, int(blk.causal)
+        d.scale, d.mask_neg, d.ln_eps = blk.scale, blk.mask_neg, blk.ln1.eps
+        p = lambda t: None if t is None else t.data_ptr()
+        d.wqkv, d.wqkvT, d.wo, d.woT, d.wi, d.wiT, d.wo2, d.wo2T = (p(t) for t in (blk.wqkv, blk.wqkvT, blk.wo, blk.woT, blk.wi, blk.wiT, blk.wo2, blk.wo2T))
+        d.bqkv, d.bo, d.bi, d.bo2 = p(blk.bqkv), p(blk.bo), p(blk.bi), p(blk.bo2)
+        d.ln1_g, d.ln1_b, d.ln2_g, d.ln2_b = p(blk.ln1.gamma), p(blk.ln1.beta), p(blk.ln2.gamma), p(blk.ln2.beta)
+        keep = []
+        for i, ad in enumerate((blk.ad1, blk.ad2)):
+            a = d.ad[i]
+            a.wd, a.wu, a.wdT, a.wuT, a.bd, a.bu, a.act = p(ad.wd), p(ad.wu), p(ad.wdT), p(ad.wuT), p(ad.bd), p(ad.bu), ad.act
+            if ad.frag_f is not None:
+                a.wd_f, a.wu_f, a.wuT_f, a.wdT_f = p(ad.frag_f[0]), p(ad.frag_f[1]), p(ad.frag_b[0]), p(ad.frag_b[1])
+            # (the gradient targets are resolved per backward call: the flat gradient buffer they view is re-bound when an optimizer attaches)
+        x1 = bufs['y1'] if 'y1' in bufs else self._buf('x1', M, H, T)
+        ws = dict(ctx=self._buf('ctx', M, H, T), u=self._buf('u', M, F, T), x1=x1)
+        d.qkv, d.ctx, d.h1, d.v1, d.zp1, d.z1 = p(bufs['qkv']), p(ws['ctx']), p(bufs['h1']), p(bufs.get('v1')), p(bufs['zp1']), p(bufs['z1'])
+        d.u, d.upre, d.h2, d.v2, d.zp2, d.z2 = p(ws['u']), p(bufs['upre']), p(bufs['h2']), p(bufs.get('v2')), p(bufs['zp2']), p(bufs['z2'])
+        d.st1, d.st2 = p(bufs['st1']), p(bufs['st2'])
+        d.upre_q8, d.q8_tiled = int(self._q8(blk)), int(self._q8t(blk, M))
+        hit = dict(d=d, x1=x1, keep=keep, ws=ws, bufs=bufs)
+        cache[key] = hit
+        return hit
+
+    def _layer_forward(self, blk, x, key_mask, n_items, M, bufs, train, seed, x_out):
+        e = self._layer_desc(blk, bufs, M)
+        d, x1 = e['d'], e['x1']
+        d.n_items, d.p_attn, d.p_hidden = n_items, (blk.p_attn if train else 0.0), (blk.p_hidden if train else 0.0)
+        d.drop_site, d.drop_seed = blk.site, seed
+        d.key_mask = None if key_mask is None else key_mask.data_ptr()
+        off = self._off(blk)
+        d.offsets = None if off is None else off.data_ptr()
+        x_lo = self._twin_of(x, M) if self.res24 else None
+        x1_lo = self._buf('res8.1', M, blk.H, torch.int8) if self.res24 else None
+        xo_lo = self._buf('res8.2', M, blk.H, torch.int8) if self.res24 else None
+        d.x_lo, d.x1_lo, d.xout_lo = (None if t is None else t.data_ptr() for t in (x_lo, x1_lo, xo_lo))
+        self._twin.pop(x1.data_ptr(), None)
+        self._twin.pop(x_out.data_ptr(), None)
+        if 'y2' in bufs:
+            assert x_out.data_ptr() == bufs['y2'].data_ptr()
+        L.encoder_layer_fwd(d, x, x1, x_out)
+        if self.res24:
+            self._twin[x1.data_ptr()], self._twin[x_out.data_ptr()] = x1_lo, xo_lo
+
+    def _layer_backward(self, blk, dx_out, key_mask, n_items, M, bufs, train, seed, dx_in):
+        e = self._layer_desc(blk, bufs, M)
+        d, T, H, F = e['d'], blk.T, blk.H, blk.F
+        d.n_items, d.p_attn, d.p_hidden = n_items, (blk.p_attn if train else 0.0), (blk.p_hidden if train else 0.0)
+        d.drop_site, d.drop_seed = blk.site, seed
+        d.key_mask = None if key_mask is None else key_mask.data_ptr()
+        off = self._off(blk)
+        d.offsets = None if off is None else off.data_ptr()
+        self._wgrad_join()
+        for i, ad in enumerate((blk.ad1, blk.ad2)):
+            a = d.ad[i]
+            if ad.g_wu is not None:
+                gw, gd, gbu, gbd = ad.g_wu(), ad.g_wd(), ad.g_bu(), ad.g_bd()
+                a.g_wu, a.g_wd, a.g_bu, a.g_bd, a.ldg_wu, a.ldg_wd = gw.data_ptr(), gd.data_ptr(), gbu.data_ptr(), gbd.data_ptr(), gw.stride(0), gd.stride(0)
+            else:
+                a.g_wu = a.g_wd = a.g_bu = a.g_bd = None
+        n_tok = self._pk['Mtok'] if off is not None else n_items * blk.S
+        sc = dict(dv1=self._buf('dv1', M, H, T), dv2=self._buf('dv2', M, H, T), dzp=self._buf('dzp', M, 64, T), d_h=self._buf('dh2', M, H, T),
+                  du=self._buf('du', M, F, T), dx1=self._buf('dx1', M, H, T), dctx=self._buf('dctx', M, H, T))
+        for k, t in sc.items():
+            setattr(d, k, t.data_ptr())
+        d.dqkv = self._buf_tail0('dqkv', M, 3 * H, T, n_tok).data_ptr() if dx_in is not None else self._buf('dqkv', M, 3 * H, T).data_ptr()
+        x_out = bufs['y2'] if 'y2' in bufs else bufs['v2']           # (with v2 kept the library never reads x_out)
+        L.encoder_layer_bwd(d, e['x1'], x_out, dx_out, dx_in)
+
     def _block_forward(self, blk, x, key_mask, n_items, M, bufs, train, seed, x_out, cls_rows=None, x8=None, want8=False):
         """cls_rows = Ip: after attention only row 0 of every item (the CLS token, all the item head reads,
         model/encoders.py:55) is carried through attention-output, FFN and adapters: x_out is then [Ip, H].
         fp8 encoder (post-LN text tower): x8 = (e4m3 rows, row scales) of x when the layer below produced them; want8: return the same
         for x_out (None otherwise).  Frozen qkv / attention-output / FFN-up / FFN-down run on e4m3 operands, everything else as in bf16."""
         T, H = blk.T, blk.H
+        if x8 is None and not want8 and self._layer_ok(blk, bufs, cls_rows, False):
+            self._layer_forward(blk, x, key_mask, n_items, M, bufs, train, seed, x_out)
+            return None
         pa = blk.p_attn if train else 0.0
         ph = blk.p_hidden if train else 0.0
         f8 = self.fp8 and T == torch.bfloat16 and M % 256 == 0 and getattr(blk, 'wqkv8', None) is not None
@@ -1379,6 +1488,9 @@ class TransRecEngine:
 
     def _block_backward(self, blk, dx_out, key_mask, n_items, M, bufs, train, seed, dx_in, cls_rows=None):
         T, H, F = blk.T, blk.H, blk.F
+        if self._layer_ok(blk, bufs, cls_rows, True):
+            self._layer_backward(blk, dx_out, key_mask, n_items, M, bufs, train, seed, dx_in)
+            return
         pa = blk.p_attn if train else 0.0
         ph = blk.p_hidden if train else 0.0
         M_full = M

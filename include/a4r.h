@@ -453,6 +453,46 @@ int a4r_memset_zero(void* stream, void* p, int64_t bytes);
 int a4r_eval_rank(void* stream, const float* prec, const float* item_emb, const int32_t* target,
                   const int32_t* hist_ptr, const int32_t* hist_idx, int32_t* rank, int U, int N1, int E);
 
+/* ONE post-LN encoder layer per call (ABI 409; SURVEY 8(b) `encoder_layer_fwd / bwd`): HF BertLayer with the reference's serial Houlsby wrappers on
+ * both sub-layers (Downstream/Text/model/model.py:292-297 on attention.output and output, injected at run.py:452-465), frozen backbone.  The call
+ * ENQUEUES the launches the per-kernel path issues for such a layer, in the same order with the same arguments -- results are bit-identical to
+ * calling the entry points one by one:
+ *   fwd: a4r_gemm_nt (qkv) | a4r_attn_fwd | a4r_gemm_nt (attention output, + dropout) | a4r_adapter_ln_fwd | a4r_gemm_nt (FFN up, GELU + derivative)
+ *        | a4r_gemm_nt (FFN down, + dropout) | a4r_adapter_ln_fwd                                                                   -- 7 launches
+ *   bwd: a4r_adapter_ln_bwd | a4r_gemm_tn2 | a4r_gemm_nt (d FFN-down * derivative) | a4r_gemm_nt (d FFN-up + residual) | a4r_adapter_ln_bwd | a4r_gemm_tn2
+ *        | a4r_gemm_nt (d attention output) | a4r_attn_bwd | a4r_gemm_nt (d qkv + residual; skipped when dx_in is NULL)              -- 9 launches
+ * Scope: dtype A4R_BF16, S <= 32 (the short attention kernels), H in {128, 256, 512, 768}, adapter bottleneck padded to 64, both adapters present;
+ * anything else returns A4R_EINVAL and the caller sequences the kernels itself.  Everything is caller-allocated device memory; M = padded token rows. */
+typedef struct {
+    const void *wd, *wu, *wdT, *wuT;           /* [64, H], [H, 64] and their transposes (bf16) */
+    const void *wd_f, *wu_f, *wdT_f, *wuT_f;   /* the same four in fragment order (a4r_pack_matrices layouts 1 / 2), or all NULL */
+    const float *bd, *bu;                       /* [64], [H] */
+    float *g_wu, *g_wd, *g_bu, *g_bd;           /* gradient targets (fp32, +=): [H, ldg_wu >= 64], [64, ldg_wd >= H], [H], [64]; all NULL: frozen adapter */
+    int32_t ldg_wu, ldg_wd, act, pad_;
+} a4r_layer_adapter_t;
+typedef struct {
+    int32_t M, H, F, n_items, S, n_heads, dh, causal;
+    float scale, mask_neg, ln_eps, p_attn, p_hidden;   /* dropout: probabilities of the attention map and of the two dense outputs (0 = eval) */
+    uint32_t drop_site; uint64_t drop_seed;             /* sites drop_site (attention), + 1 (attention output), + 2 (FFN output) */
+    const float* key_mask; const int32_t* offsets;      /* a4r_attn_t.key_mask / offsets (either may be NULL) */
+    const void *wqkv, *wqkvT, *wo, *woT, *wi, *wiT, *wo2, *wo2T;      /* forward operands W [out, in] and dgrad operands W^T (bf16) */
+    const float *bqkv, *bo, *bi, *bo2, *ln1_g, *ln1_b, *ln2_g, *ln2_b;
+    a4r_layer_adapter_t ad[2];                          /* attention-output half, FFN-output half */
+    /* saved for backward / workspace (bf16 unless stated): qkv [M, 3H]; ctx, h1, h2 [M, H]; v1 / v2 [M, H] or NULL (then backward rebuilds xhat from
+     * x1 / x_out: a4r_adapter_ln_bwd's beta_y form); st1, st2 [M, 2] fp32; zp1, z1, zp2, z2 [M, 64]; u [M, F]; upre [M, F]: gelu'(pre) as bf16, or
+     * one byte per element when upre_q8 (tile-native order when q8_tiled: a4r_gemm_t.q8_tiled) */
+    void *qkv, *ctx, *h1, *v1, *zp1, *z1, *u, *upre, *h2, *v2, *zp2, *z2; float *st1, *st2;
+    int32_t upre_q8, q8_tiled;
+    const void* x_lo; void *x1_lo, *xout_lo;            /* byte planes of the 24-bit residual stream (a4r_adapter_ln_fwd w_frag bit 1): each may be NULL */
+    /* backward scratch: dv1, dv2, d_h (the gradient of a dense output, both halves in turn), dx1, dctx [M, H]; dzp [M, 64]; du [M, F]; dqkv [M, 3H] (rows >= n_items * S must be zero on entry: the attention
+     * backward writes the real token rows only) */
+    void *dv1, *dv2, *dzp, *d_h, *du, *dx1, *dctx, *dqkv;
+} a4r_encoder_layer_t;
+/* x [M, H] -> x1 [M, H] (the attention half's output, kept: the FFN half's residual and backward's y1) -> x_out [M, H] */
+int a4r_encoder_layer_fwd(void* stream, const a4r_encoder_layer_t* l, const void* x, void* x1, void* x_out);
+/* dx_out [M, H] -> dx_in [M, H] (NULL: the first layer of a frozen tower -- the d qkv product is skipped); x1 / x_out: the forward's outputs */
+int a4r_encoder_layer_bwd(void* stream, const a4r_encoder_layer_t* l, const void* x1, const void* x_out, const void* dx_out, void* dx_in);
+
 #ifdef __cplusplus
 }
 #endif

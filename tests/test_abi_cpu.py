@@ -38,13 +38,17 @@ def test_binding_struct_sizes_match_header():
     import subprocess
     import tempfile
     from adapter4rec_amd import _lib
-    src = '#include <stdio.h>\n#include <stddef.h>\n#include "a4r.h"\nint main(){printf("%zu %zu %zu %zu %zu %zu\\n", sizeof(a4r_gemm_t), sizeof(a4r_attn_t), sizeof(a4r_pack_desc_t), sizeof(a4r_sasrec_block_t), offsetof(a4r_sasrec_block_t, drop_seed), offsetof(a4r_gemm_t, c_scale_out));return 0;}\n'
+    src = ('#include <stdio.h>\n#include <stddef.h>\n#include "a4r.h"\nint main(){printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu\\n", sizeof(a4r_gemm_t), sizeof(a4r_attn_t), '
+           'sizeof(a4r_pack_desc_t), sizeof(a4r_sasrec_block_t), offsetof(a4r_sasrec_block_t, drop_seed), offsetof(a4r_gemm_t, c_scale_out), sizeof(a4r_layer_adapter_t), '
+           'sizeof(a4r_encoder_layer_t), offsetof(a4r_encoder_layer_t, drop_seed), offsetof(a4r_encoder_layer_t, ad), offsetof(a4r_encoder_layer_t, dqkv));return 0;}\n')
     with tempfile.TemporaryDirectory() as d:
         open(os.path.join(d, 'p.c'), 'w').write(src)
         subprocess.check_call(['gcc', '-I', os.path.join(ROOT, 'include'), os.path.join(d, 'p.c'), '-o', os.path.join(d, 'p')])
         out = subprocess.check_output([os.path.join(d, 'p')]).decode().split()
     assert [int(x) for x in out] == [ctypes.sizeof(_lib.GemmArgs), ctypes.sizeof(_lib.AttnArgs), ctypes.sizeof(_lib.PackDesc),
-                                     ctypes.sizeof(_lib.SasrecBlock), _lib.SasrecBlock.drop_seed.offset, _lib.GemmArgs.c_scale_out.offset]
+                                     ctypes.sizeof(_lib.SasrecBlock), _lib.SasrecBlock.drop_seed.offset, _lib.GemmArgs.c_scale_out.offset,
+                                     ctypes.sizeof(_lib.LayerAdapter), ctypes.sizeof(_lib.EncoderLayer), _lib.EncoderLayer.drop_seed.offset, _lib.EncoderLayer.ad.offset,
+                                     _lib.EncoderLayer.dqkv.offset]
 
 
 def test_every_entry_point_refuses_null_pointers_before_launching():
@@ -60,7 +64,7 @@ def test_every_entry_point_refuses_null_pointers_before_launching():
     assert {k: int(v) for k, v in codes.items()} == dict(A4R_OK=0, A4R_EINVAL=-1, A4R_ELAUNCH=-2)
     protos = re.findall(r'\n\s*int\s+(a4r_\w+)\s*\(([^;{]*?)\)\s*;', hdr)
     lib = ctypes.CDLL(_lib.LIB_PATH)
-    structs = dict(a4r_gemm_t=ctypes.sizeof(_lib.GemmArgs), a4r_attn_t=ctypes.sizeof(_lib.AttnArgs))
+    structs = dict(a4r_gemm_t=ctypes.sizeof(_lib.GemmArgs), a4r_attn_t=ctypes.sizeof(_lib.AttnArgs), a4r_encoder_layer_t=ctypes.sizeof(_lib.EncoderLayer))
     probed, keep = 0, []
     for name, args in protos:
         parts = [a.strip() for a in args.split(',')] if args.strip() not in ('', 'void') else []
