@@ -15,7 +15,15 @@
 //   torch.ops.a4r.fused_adam_step          a4r_adam_step          optim.Adam over the flat buffers, lr groups (run.py:505-529)
 //   torch.ops.a4r.topk_rank_eval           a4r_eval_rank          eval_model's per-user rank                (data_utils/metrics.py:82-116)
 //   torch.ops.a4r.lora_bwd                 a4r_lora_bwd_fused     loralib Linear (query, value): every low-rank gradient in one pass (run_adapter.py:384-395)
+//   torch.ops.a4r.encoder_layer_fwd / _bwd a4r_encoder_layer_fwd / _bwd  one post-LN HF BertLayer + serial Houlsby wrappers per call (model/encoders.py:39-56, model/model.py:292-297)
+//   torch.ops.a4r.sasrec_block_fwd / _bwd  a4r_sasrec_block_fwd / _bwd   one adapted SASRec TransformerBlock per call (model/modules.py:45-87, model/model.py:341-376)
+//   torch.ops.a4r.embed_ln_fwd             a4r_embed_ln           HF BertEmbeddings / RobertaEmbeddings (word + position + type -> LayerNorm -> dropout)
+//   torch.ops.a4r.patch_embed_fwd          a4r_patchify           ViTPatchEmbeddings' im2col (+ the uint8 ToTensor / Normalize of dataset.py:77-81); the projection is gemm_nt
+//   torch.ops.a4r.vit_assemble             a4r_vit_assemble       cls token + position rows around the projected patches (HF ViTEmbeddings / ViTMAEEmbeddings)
 //   torch.ops.a4r.abi_version              a4r_version
+// (SURVEY 8(b) also lists lora_qv_fwd and allreduce_flat: a LoRA projection's forward IS gemm_nt on the merged operand (a4r_lora_merge, once per step; its
+//  backward is lora_bwd above), and the gradient exchange is torch.distributed's all_reduce on the flat buffer (adapter4rec_amd/ddp.py) -- RCCL has no
+//  C entry point in this library to wrap.)
 #include <ATen/ATen.h>
 #include <c10/hip/HIPStream.h>
 #include <torch/library.h>
@@ -234,6 +242,179 @@ void lora_bwd(const Tensor& x, const Tensor& dqa, const Tensor& dqb, const Tenso
            "a4r_lora_bwd_fused");
 }
 
+void chk_dev(const Tensor& t, const char* name, const Tensor& like, at::ScalarType st) {
+    TORCH_CHECK(t.defined() && t.is_cuda() && t.device() == like.device(), "a4r: ", name, " must be a device tensor on ", like.device(), " (no CPU path)");
+    TORCH_CHECK(t.scalar_type() == st, "a4r: ", name, " must be ", st, ", got ", t.scalar_type());
+    TORCH_CHECK(t.dim() == 0 || t.stride(t.dim() - 1) == 1, "a4r: ", name, " must have unit stride in its last dimension");
+}
+void chk_list(at::TensorList l, size_t n, const char* name) { TORCH_CHECK(l.size() == n, "a4r: ", name, " must hold ", n, " tensors, got ", l.size()); }
+
+// One post-LN encoder layer with serial Houlsby adapters on both halves (include/a4r.h: a4r_encoder_layer_t).  Tensor lists, in the struct's order:
+//   w     = [wqkv, bqkv, wo, bo, wi, bi, wo2, bo2, ln1_g, ln1_b, ln2_g, ln2_b]     (weights bf16 [out, in], the rest fp32)
+//   ad1/2 = [wd [64, H], bd [64], wu [H, 64], bu [H]]                               (row-major through this layer)
+//   saved = [qkv, ctx, h1, v1, zp1, z1, u, upre, h2, v2, zp2, z2, st1, st2]          (upre bf16 [M, F], or uint8 = the 8-bit derivative; v1 / v2 always kept here)
+void fill_layer(a4r_encoder_layer_t& l, const Tensor& x, at::TensorList w, at::TensorList ad1, at::TensorList ad2, at::TensorList saved, const optional<Tensor>& key_mask,
+                const optional<Tensor>& offsets, int64_t n_items, int64_t S, int64_t n_heads, bool causal, double scale, double mask_neg, double ln_eps, double p_attn,
+                double p_hidden, int64_t drop_site, int64_t drop_seed, int64_t act1, int64_t act2, bool q8_tiled) {
+    chk_mat(x, "x", x);
+    TORCH_CHECK(x.scalar_type() == at::kBFloat16, "a4r::encoder_layer: bf16 activations only");
+    chk_list(w, 12, "w"); chk_list(ad1, 4, "ad1"); chk_list(ad2, 4, "ad2"); chk_list(saved, 14, "saved");
+    const int64_t M = x.size(0), H = x.size(1), F = w[4].size(0);
+    for (int i : {0, 2, 4, 6}) chk_dev(w[i], "a weight matrix", x, at::kBFloat16);
+    for (int i : {1, 3, 5, 7, 8, 9, 10, 11}) chk_dev(w[i], "a bias / LayerNorm vector", x, at::kFloat);
+    TORCH_CHECK(w[0].size(0) == 3 * H && w[0].size(1) == H && w[2].size(0) == H && w[2].size(1) == H && w[4].size(1) == H && w[6].size(0) == H && w[6].size(1) == F,
+                "a4r::encoder_layer: weight shapes must be [3H, H], [H, H], [F, H], [H, F]");
+    l.M = (int)M; l.H = (int)H; l.F = (int)F; l.n_items = (int)n_items; l.S = (int)S; l.n_heads = (int)n_heads; l.dh = (int)(H / (n_heads > 0 ? n_heads : 1)); l.causal = causal;
+    l.scale = (float)scale; l.mask_neg = (float)mask_neg; l.ln_eps = (float)ln_eps; l.p_attn = (float)p_attn; l.p_hidden = (float)p_hidden;
+    l.drop_site = (uint32_t)drop_site; l.drop_seed = (uint64_t)drop_seed;
+    l.key_mask = static_cast<const float*>(cptr(key_mask)); l.offsets = static_cast<const int32_t*>(cptr(offsets));
+    l.wqkv = w[0].data_ptr(); l.bqkv = w[1].data_ptr<float>(); l.wo = w[2].data_ptr(); l.bo = w[3].data_ptr<float>(); l.wi = w[4].data_ptr(); l.bi = w[5].data_ptr<float>();
+    l.wo2 = w[6].data_ptr(); l.bo2 = w[7].data_ptr<float>(); l.ln1_g = w[8].data_ptr<float>(); l.ln1_b = w[9].data_ptr<float>(); l.ln2_g = w[10].data_ptr<float>(); l.ln2_b = w[11].data_ptr<float>();
+    int k = 0;
+    for (at::TensorList a : {ad1, ad2}) {
+        chk_dev(a[0], "wd", x, at::kBFloat16); chk_dev(a[1], "bd", x, at::kFloat); chk_dev(a[2], "wu", x, at::kBFloat16); chk_dev(a[3], "bu", x, at::kFloat);
+        TORCH_CHECK(a[0].size(0) == 64 && a[0].size(1) == H && a[2].size(0) == H && a[2].size(1) == 64, "a4r::encoder_layer: adapter matrices must be [64, H] and [H, 64]");
+        l.ad[k].wd = a[0].data_ptr(); l.ad[k].bd = a[1].data_ptr<float>(); l.ad[k].wu = a[2].data_ptr(); l.ad[k].bu = a[3].data_ptr<float>();
+        l.ad[k].act = (int)(k == 0 ? act1 : act2);
+        ++k;
+    }
+    const int64_t cols[14] = {3 * H, H, H, H, 64, 64, F, F, H, H, 64, 64, 2, 2};
+    for (int i = 0; i < 14; ++i) {
+        const bool f32 = i >= 12, any8 = i == 7;
+        TORCH_CHECK(saved[i].is_cuda() && saved[i].dim() == 2 && saved[i].size(0) >= M && saved[i].size(1) == cols[i] && saved[i].is_contiguous(),
+                    "a4r::encoder_layer: saved[", i, "] must be a contiguous device tensor [>= M, ", cols[i], "]");
+        TORCH_CHECK(f32 ? saved[i].scalar_type() == at::kFloat : (saved[i].scalar_type() == at::kBFloat16 || (any8 && saved[i].scalar_type() == at::kByte)), "a4r::encoder_layer: saved[", i, "] dtype");
+    }
+    l.qkv = saved[0].data_ptr(); l.ctx = saved[1].data_ptr(); l.h1 = saved[2].data_ptr(); l.v1 = saved[3].data_ptr(); l.zp1 = saved[4].data_ptr(); l.z1 = saved[5].data_ptr();
+    l.u = saved[6].data_ptr(); l.upre = saved[7].data_ptr(); l.h2 = saved[8].data_ptr(); l.v2 = saved[9].data_ptr(); l.zp2 = saved[10].data_ptr(); l.z2 = saved[11].data_ptr();
+    l.st1 = saved[12].data_ptr<float>(); l.st2 = saved[13].data_ptr<float>();
+    l.upre_q8 = saved[7].scalar_type() == at::kByte; l.q8_tiled = q8_tiled && l.upre_q8;
+}
+
+void encoder_layer_fwd(const Tensor& x, at::TensorList w, at::TensorList ad1, at::TensorList ad2, at::TensorList saved, Tensor x1, Tensor x_out, const optional<Tensor>& key_mask,
+                       const optional<Tensor>& offsets, int64_t n_items, int64_t S, int64_t n_heads, bool causal, double scale, double mask_neg, double ln_eps, double p_attn,
+                       double p_hidden, int64_t drop_site, int64_t drop_seed, int64_t act1, int64_t act2, bool q8_tiled) {
+    a4r_encoder_layer_t l{};
+    fill_layer(l, x, w, ad1, ad2, saved, key_mask, offsets, n_items, S, n_heads, causal, scale, mask_neg, ln_eps, p_attn, p_hidden, drop_site, drop_seed, act1, act2, q8_tiled);
+    chk_mat(x1, "x1", x); chk_mat(x_out, "x_out", x);
+    TORCH_CHECK(x1.sizes() == x.sizes() && x_out.sizes() == x.sizes() && x1.is_contiguous() && x_out.is_contiguous() && x.is_contiguous(), "a4r::encoder_layer_fwd: x, x1, x_out must be contiguous [M, H]");
+    status(a4r_encoder_layer_fwd(cur_stream(x), &l, x.data_ptr(), x1.data_ptr(), x_out.data_ptr()), "a4r_encoder_layer_fwd");
+}
+
+// wT = [wqkvT [H, 3H], woT [H, H], wiT [H, F], wo2T [F, H]]; adT1/2 = [wdT [H, 64], wuT [64, H]]; scratch = [dv1, dv2, dzp, d_h, du, dx1, dctx, dqkv];
+// grads1/2 = [g_wu [H, 64], g_wd [64, H], g_bu [H], g_bd [64]] (fp32, accumulated) or empty lists for a frozen adapter
+void encoder_layer_bwd(const Tensor& dx_out, const Tensor& x1, const Tensor& x_out, at::TensorList w, at::TensorList wT, at::TensorList ad1, at::TensorList ad2, at::TensorList adT1,
+                       at::TensorList adT2, at::TensorList saved, at::TensorList scratch, at::TensorList grads1, at::TensorList grads2, const optional<Tensor>& dx_in,
+                       const optional<Tensor>& key_mask, const optional<Tensor>& offsets, int64_t n_items, int64_t S, int64_t n_heads, bool causal, double scale, double mask_neg,
+                       double ln_eps, double p_attn, double p_hidden, int64_t drop_site, int64_t drop_seed, int64_t act1, int64_t act2, bool q8_tiled) {
+    a4r_encoder_layer_t l{};
+    fill_layer(l, x1, w, ad1, ad2, saved, key_mask, offsets, n_items, S, n_heads, causal, scale, mask_neg, ln_eps, p_attn, p_hidden, drop_site, drop_seed, act1, act2, q8_tiled);
+    chk_list(wT, 4, "wT"); chk_list(adT1, 2, "adT1"); chk_list(adT2, 2, "adT2"); chk_list(scratch, 8, "scratch");
+    for (const auto& t : wT) chk_dev(t, "a transposed weight", x1, at::kBFloat16);
+    l.wqkvT = wT[0].data_ptr(); l.woT = wT[1].data_ptr(); l.wiT = wT[2].data_ptr(); l.wo2T = wT[3].data_ptr();
+    int k = 0;
+    for (at::TensorList a : {adT1, adT2}) {
+        chk_dev(a[0], "wdT", x1, at::kBFloat16); chk_dev(a[1], "wuT", x1, at::kBFloat16);
+        l.ad[k].wdT = a[0].data_ptr(); l.ad[k].wuT = a[1].data_ptr();
+        ++k;
+    }
+    k = 0;
+    for (at::TensorList g : {grads1, grads2}) {
+        TORCH_CHECK(g.size() == 0 || g.size() == 4, "a4r::encoder_layer_bwd: grads must be [g_wu, g_wd, g_bu, g_bd] or empty");
+        if (g.size() == 4) {
+            for (const auto& t : g) chk_dev(t, "an adapter gradient", x1, at::kFloat);
+            l.ad[k].g_wu = g[0].data_ptr<float>(); l.ad[k].g_wd = g[1].data_ptr<float>(); l.ad[k].g_bu = g[2].data_ptr<float>(); l.ad[k].g_bd = g[3].data_ptr<float>();
+            l.ad[k].ldg_wu = (int)g[0].stride(0); l.ad[k].ldg_wd = (int)g[1].stride(0);
+        }
+        ++k;
+    }
+    const int64_t M = l.M, H = l.H, F = l.F, cols[8] = {H, H, 64, H, F, H, H, 3 * H};
+    void** dst[8] = {&l.dv1, &l.dv2, &l.dzp, &l.d_h, &l.du, &l.dx1, &l.dctx, &l.dqkv};
+    for (int i = 0; i < 8; ++i) {
+        chk_dev(scratch[i], "a scratch tensor", x1, at::kBFloat16);
+        TORCH_CHECK(scratch[i].dim() == 2 && scratch[i].size(0) >= M && scratch[i].size(1) == cols[i] && scratch[i].is_contiguous(), "a4r::encoder_layer_bwd: scratch[", i, "] must be contiguous [>= M, ", cols[i], "]");
+        *dst[i] = scratch[i].data_ptr();
+    }
+    chk_mat(dx_out, "dx_out", x1);
+    status(a4r_encoder_layer_bwd(cur_stream(x1), &l, x1.data_ptr(), x_out.data_ptr(), dx_out.data_ptr(), mptr(dx_in)), "a4r_encoder_layer_bwd");
+}
+
+// One adapted SASRec block (include/a4r.h: a4r_sasrec_block_t).  w = [wqkv, wfc, w1, b1, w2, b2, ln1_g, ln1_b, ln2_g, ln2_b, wd1, bd1, wu1, bu1, wd2, bd2, wu2, bu2] (fp32);
+// grads (bwd) = [g_wd1, g_bd1, g_wu1, g_bu1, g_wd2, g_bd2, g_wu2, g_bu2] or empty
+void fill_sasrec(a4r_sasrec_block_t& b, const Tensor& x, at::TensorList w, int64_t n_heads, int64_t F, int64_t d, int64_t act, bool inner_res, double eps, double mask_neg,
+                 double drop_attn, double drop_hidden, int64_t drop_site, int64_t drop_seed) {
+    chk_list(w, 18, "w");
+    for (const auto& t : w) chk_dev(t, "a block parameter", x, at::kFloat);
+    const float** p[18] = {&b.wqkv, &b.wfc, &b.w1, &b.b1, &b.w2, &b.b2, &b.ln1_g, &b.ln1_b, &b.ln2_g, &b.ln2_b, &b.wd1, &b.bd1, &b.wu1, &b.bu1, &b.wd2, &b.bd2, &b.wu2, &b.bu2};
+    for (int i = 0; i < 18; ++i) *p[i] = w[i].data_ptr<float>();
+    b.E = (int)x.size(-1); b.n_heads = (int)n_heads; b.F = (int)F; b.d = (int)d; b.ldwu = (int)w[12].stride(0); b.act = (int)act; b.inner_res = inner_res;
+    b.eps = (float)eps; b.mask_neg = (float)mask_neg; b.drop_attn = (float)drop_attn; b.drop_hidden = (float)drop_hidden; b.drop_site = (uint32_t)drop_site; b.drop_seed = (uint64_t)drop_seed;
+}
+void sasrec_block_fwd(const Tensor& x, const Tensor& log_mask, Tensor y, at::TensorList w, int64_t n_heads, int64_t F, int64_t d, int64_t act, bool inner_res, double eps,
+                      double mask_neg, double drop_attn, double drop_hidden, int64_t drop_site, int64_t drop_seed, bool train) {
+    chk_dev(x, "x", x, at::kFloat); chk_dev(log_mask, "log_mask", x, at::kFloat); chk_dev(y, "y", x, at::kFloat);
+    TORCH_CHECK(x.dim() == 3 && x.is_contiguous() && y.sizes() == x.sizes() && y.is_contiguous() && log_mask.is_contiguous() && log_mask.numel() == x.size(0) * x.size(1),
+                "a4r::sasrec_block_fwd: x, y contiguous [users, T, E]; log_mask [users, T]");
+    a4r_sasrec_block_t b{};
+    fill_sasrec(b, x, w, n_heads, F, d, act, inner_res, eps, mask_neg, drop_attn, drop_hidden, drop_site, drop_seed);
+    status(a4r_sasrec_block_fwd(cur_stream(x), &b, x.data_ptr<float>(), log_mask.data_ptr<float>(), y.data_ptr<float>(), (int)x.size(0), (int)x.size(1), train), "a4r_sasrec_block_fwd");
+}
+void sasrec_block_bwd(const Tensor& x, const Tensor& log_mask, const Tensor& dy, Tensor dx, at::TensorList w, at::TensorList grads, int64_t n_heads, int64_t F, int64_t d,
+                      int64_t act, bool inner_res, double eps, double mask_neg, double drop_attn, double drop_hidden, int64_t drop_site, int64_t drop_seed, bool train) {
+    chk_dev(x, "x", x, at::kFloat); chk_dev(log_mask, "log_mask", x, at::kFloat); chk_dev(dy, "dy", x, at::kFloat); chk_dev(dx, "dx", x, at::kFloat);
+    TORCH_CHECK(x.dim() == 3 && x.is_contiguous() && dy.sizes() == x.sizes() && dy.is_contiguous() && dx.sizes() == x.sizes() && dx.is_contiguous() && log_mask.is_contiguous(),
+                "a4r::sasrec_block_bwd: x, dy, dx contiguous [users, T, E]");
+    a4r_sasrec_block_t b{};
+    fill_sasrec(b, x, w, n_heads, F, d, act, inner_res, eps, mask_neg, drop_attn, drop_hidden, drop_site, drop_seed);
+    TORCH_CHECK(grads.size() == 0 || grads.size() == 8, "a4r::sasrec_block_bwd: grads must be the 8 adapter gradients or empty");
+    if (grads.size() == 8) {
+        for (const auto& t : grads) chk_dev(t, "an adapter gradient", x, at::kFloat);
+        float** g[8] = {&b.g_wd1, &b.g_bd1, &b.g_wu1, &b.g_bu1, &b.g_wd2, &b.g_bd2, &b.g_wu2, &b.g_bu2};
+        for (int i = 0; i < 8; ++i) *g[i] = grads[i].data_ptr<float>();
+        b.ldg_d = (int)grads[0].stride(0); b.ldg_u = (int)grads[2].stride(0);
+    }
+    status(a4r_sasrec_block_bwd(cur_stream(x), &b, x.data_ptr<float>(), log_mask.data_ptr<float>(), dy.data_ptr<float>(), dx.data_ptr<float>(), (int)x.size(0), (int)x.size(1), train),
+           "a4r_sasrec_block_bwd");
+}
+
+// HF BertEmbeddings / RobertaEmbeddings: word[id] + pos + type[0] -> LayerNorm -> dropout; ids int64 [n_items, >= S] (row stride taken from the tensor)
+void embed_ln_fwd(const Tensor& ids, const Tensor& word, const Tensor& pos, const Tensor& type0, const Tensor& gamma, const Tensor& beta, double eps, Tensor out, int64_t S,
+                  bool roberta, int64_t pad_id, double drop_p, int64_t drop_site, int64_t drop_seed, const optional<Tensor>& pre_out, const optional<Tensor>& stats_out,
+                  const optional<Tensor>& key_mask_out) {
+    chk_dev(ids, "ids", out, at::kLong); chk_dev(word, "word", out, at::kFloat); chk_dev(pos, "pos", out, at::kFloat); chk_dev(type0, "type0", out, at::kFloat);
+    chk_mat(out, "out", out);
+    TORCH_CHECK(ids.dim() == 2 && ids.size(1) >= S && word.dim() == 2 && out.size(1) == word.size(1) && out.size(0) >= ids.size(0) * S, "a4r::embed_ln_fwd: ids [n, >= S], word [V, H], out [>= n S, H]");
+    chk_f32_vec(gamma, "gamma", out, word.size(1)); chk_f32_vec(beta, "beta", out, word.size(1));
+    status(a4r_embed_ln(cur_stream(out), ids.data_ptr<int64_t>(), (int)ids.stride(0), word.data_ptr<float>(), pos.data_ptr<float>(), type0.data_ptr<float>(), gamma.data_ptr<float>(),
+                        beta.data_ptr<float>(), (float)eps, out.data_ptr(), (int)out.stride(0), (int)ids.size(0), (int)S, (int)word.size(1), roberta, (int)pad_id, dt_of(out),
+                        (float)drop_p, (uint32_t)drop_site, (uint64_t)drop_seed, mptr(pre_out), static_cast<float*>(mptr(stats_out)), static_cast<float*>(mptr(key_mask_out))),
+           "a4r_embed_ln");
+}
+
+// ViTPatchEmbeddings' im2col: img fp32 [n, C, H, W] (normalised) or uint8 [n, H, W, C] (raw: ToTensor + Normalize(0.5, 0.5) applied here) -> out [n * n_keep, >= C P P]
+void patch_embed_fwd(const Tensor& img, Tensor out, int64_t patch, const optional<Tensor>& keep_idx) {
+    chk_mat(out, "out", out);
+    TORCH_CHECK(img.is_cuda() && img.device() == out.device() && img.dim() == 4 && img.is_contiguous() && (img.scalar_type() == at::kFloat || img.scalar_type() == at::kByte),
+                "a4r::patch_embed_fwd: img must be a contiguous device tensor, fp32 [n, C, H, W] or uint8 [n, H, W, C]");
+    const bool u8 = img.scalar_type() == at::kByte;
+    const int64_t n = img.size(0), Cc = u8 ? img.size(3) : img.size(1), Hi = u8 ? img.size(1) : img.size(2), Wi = u8 ? img.size(2) : img.size(3);
+    int64_t n_keep = (Hi / patch) * (Wi / patch);
+    if (keep_idx.has_value() && keep_idx->defined()) {
+        TORCH_CHECK(keep_idx->is_cuda() && keep_idx->scalar_type() == at::kInt && keep_idx->is_contiguous() && keep_idx->dim() == 2 && keep_idx->size(0) == n, "a4r::patch_embed_fwd: keep_idx must be int32 [n, n_keep]");
+        n_keep = keep_idx->size(1);
+    }
+    TORCH_CHECK(out.size(0) >= n * n_keep && out.size(1) >= Cc * patch * patch, "a4r::patch_embed_fwd: out must be [>= n n_keep, >= C P P]");
+    status(a4r_patchify(cur_stream(out), img.data_ptr(), u8 ? 1 : 0, out.data_ptr(), (int)out.stride(0), static_cast<const int32_t*>(cptr(keep_idx)), (int)n_keep, (int)n, (int)Cc, (int)Hi,
+                        (int)Wi, (int)patch, dt_of(out)),
+           "a4r_patchify");
+}
+void vit_assemble(const Tensor& patches, const Tensor& cls, const Tensor& pos, Tensor out, int64_t n_items, int64_t n_keep, const optional<Tensor>& keep_idx, int64_t tokens_out) {
+    chk_mat(patches, "patches", out); chk_mat(out, "out", out); chk_dev(cls, "cls", out, at::kFloat); chk_dev(pos, "pos", out, at::kFloat);
+    status(a4r_vit_assemble(cur_stream(out), patches.data_ptr(), (int)patches.stride(0), cls.data_ptr<float>(), pos.data_ptr<float>(), static_cast<const int32_t*>(cptr(keep_idx)),
+                            out.data_ptr(), (int)out.stride(0), (int)n_items, (int)n_keep, (int)cls.numel(), dt_of(out), (int)tokens_out),
+           "a4r_vit_assemble");
+}
+
 int64_t abi_version() { return a4r_version(); }
 
 }  // namespace
@@ -257,5 +438,19 @@ TORCH_LIBRARY(a4r, m) {
     m.def("topk_rank_eval(Tensor prec, Tensor item_emb, Tensor target, Tensor hist_ptr, Tensor hist_idx, Tensor(a!) rank) -> ()", &topk_rank_eval);
     m.def("lora_bwd(Tensor x, Tensor dqa, Tensor dqb, Tensor Aa, Tensor Ab, Tensor BTa, Tensor BTb, float scale_a, float scale_b, Tensor(a!) dAa, Tensor(b!) dAb, "
           "Tensor(c!) dBa, Tensor(d!) dBb, Tensor(e!)? dbias_a, Tensor(f!)? dbias_b, Tensor(g!) ws) -> ()", &lora_bwd);
+    m.def("encoder_layer_fwd(Tensor x, Tensor[] w, Tensor[] ad1, Tensor[] ad2, Tensor[] saved, Tensor(a!) x1, Tensor(b!) x_out, Tensor? key_mask, Tensor? offsets, int n_items, int S, "
+          "int n_heads, bool causal, float scale, float mask_neg, float ln_eps, float p_attn=0.0, float p_hidden=0.0, int drop_site=0, int drop_seed=0, int act1=1, int act2=1, "
+          "bool q8_tiled=False) -> ()", &encoder_layer_fwd);
+    m.def("encoder_layer_bwd(Tensor dx_out, Tensor x1, Tensor x_out, Tensor[] w, Tensor[] wT, Tensor[] ad1, Tensor[] ad2, Tensor[] adT1, Tensor[] adT2, Tensor[] saved, Tensor[] scratch, "
+          "Tensor[] grads1, Tensor[] grads2, Tensor(a!)? dx_in, Tensor? key_mask, Tensor? offsets, int n_items, int S, int n_heads, bool causal, float scale, float mask_neg, float ln_eps, "
+          "float p_attn=0.0, float p_hidden=0.0, int drop_site=0, int drop_seed=0, int act1=1, int act2=1, bool q8_tiled=False) -> ()", &encoder_layer_bwd);
+    m.def("sasrec_block_fwd(Tensor x, Tensor log_mask, Tensor(a!) y, Tensor[] w, int n_heads, int F, int d, int act, bool inner_res, float eps, float mask_neg, float drop_attn=0.0, "
+          "float drop_hidden=0.0, int drop_site=0, int drop_seed=0, bool train=False) -> ()", &sasrec_block_fwd);
+    m.def("sasrec_block_bwd(Tensor x, Tensor log_mask, Tensor dy, Tensor(a!) dx, Tensor[] w, Tensor[] grads, int n_heads, int F, int d, int act, bool inner_res, float eps, float mask_neg, "
+          "float drop_attn=0.0, float drop_hidden=0.0, int drop_site=0, int drop_seed=0, bool train=False) -> ()", &sasrec_block_bwd);
+    m.def("embed_ln_fwd(Tensor ids, Tensor word, Tensor pos, Tensor type0, Tensor gamma, Tensor beta, float eps, Tensor(a!) out, int S, bool roberta=False, int pad_id=0, float drop_p=0.0, "
+          "int drop_site=0, int drop_seed=0, Tensor(b!)? pre_out=None, Tensor(c!)? stats_out=None, Tensor(d!)? key_mask_out=None) -> ()", &embed_ln_fwd);
+    m.def("patch_embed_fwd(Tensor img, Tensor(a!) out, int patch, Tensor? keep_idx=None) -> ()", &patch_embed_fwd);
+    m.def("vit_assemble(Tensor patches, Tensor cls, Tensor pos, Tensor(a!) out, int n_items, int n_keep, Tensor? keep_idx=None, int tokens_out=0) -> ()", &vit_assemble);
     m.def("abi_version() -> int", &abi_version);
 }

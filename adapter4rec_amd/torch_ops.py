@@ -14,7 +14,8 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 OPS_LIB_PATH = os.path.join(_HERE, 'liba4r_torch_ops.so')
 OPS = ('gemm_nt', 'adapter_residual_ln_fwd', 'adapter_residual_ln_bwd', 'ln_fwd', 'score_bce_fwd', 'score_bce_bwd', 'fused_adam_step',
-       'topk_rank_eval', 'lora_bwd', 'abi_version')
+       'topk_rank_eval', 'lora_bwd', 'encoder_layer_fwd', 'encoder_layer_bwd', 'sasrec_block_fwd', 'sasrec_block_bwd', 'embed_ln_fwd', 'patch_embed_fwd',
+       'vit_assemble', 'abi_version')
 _loaded = False
 
 

@@ -128,3 +128,105 @@ def test_ops_equal_ctypes_binding():
     assert float(res[1][0].abs().max()) > 0 and float(res[1][1][:, 32].abs().max()) > 0
     with pytest.raises(RuntimeError, match='rank rows'):
         ops.lora_bwd(xl, dqa, dqb, Aop[0:4], Aop[16:20], BTa[0:4], BTb[16:20], 1.0, 1.0, sA[0:4], sA[16:20], sBa[:, 0:8], sBb[:, 16:24], None, None, ws)
+
+
+@pytest.mark.gpu
+def test_layer_level_ops_equal_ctypes_binding():
+    """The round-6 ops of SURVEY 8(b)'s list -- encoder_layer_fwd / _bwd, sasrec_block_fwd / _bwd, embed_ln_fwd, patch_embed_fwd, vit_assemble -- against the
+    ctypes binding of the same C entry points (bit-equal outputs; fp32 atomic sums to their order)."""
+    import math
+    ops, _ = _ops()
+    from adapter4rec_amd import _lib as L
+    from test_kernels_gpu import _sasrec_case
+    dev, t = 'cuda:0', torch.bfloat16
+    g = torch.Generator(device=dev).manual_seed(11)
+    r = lambda *s, sc=1.0: torch.randn(*s, device=dev, generator=g) * sc
+    # ---- one encoder layer, forward and backward
+    n_items, S, H, F, nh = 40, 30, 256, 512, 4
+    M = 1280
+    x = r(M, H).to(t)
+    x[n_items * S:] = 0
+    w = [r(3 * H, H, sc=0.05).to(t), r(3 * H, sc=0.1), r(H, H, sc=0.05).to(t), r(H, sc=0.1), r(F, H, sc=0.05).to(t), r(F, sc=0.1), r(H, F, sc=0.05).to(t), r(H, sc=0.1),
+         1 + r(H, sc=0.1), r(H, sc=0.1), 1 + r(H, sc=0.1), r(H, sc=0.1)]
+    ads = [[r(64, H, sc=0.05).to(t), r(64, sc=0.1), r(H, 64, sc=0.05).to(t), r(H, sc=0.1)] for _ in range(2)]
+    mk = lambda c, dt=t: torch.zeros(M, c, dtype=dt, device=dev)
+    km = torch.ones(n_items, S, device=dev)
+    km[3, 20:] = 0
+    scalars = dict(n_items=n_items, S=S, n_heads=nh, causal=False, scale=1 / math.sqrt(H // nh), mask_neg=float(torch.finfo(torch.float32).min), ln_eps=1e-12,
+                   p_attn=0.1, p_hidden=0.1, drop_site=7, drop_seed=123, act1=L.ACT_GELU, act2=L.ACT_RELU)
+    dx_fixed = r(M, H, sc=0.1).to(t)
+    dx_fixed[n_items * S:] = 0
+    runs = []
+    for use_op in (True, False):
+        saved = [mk(3 * H), mk(H), mk(H), mk(H), mk(64), mk(64), mk(F), mk(F, torch.uint8), mk(H), mk(H), mk(64), mk(64), mk(2, torch.float32), mk(2, torch.float32)]
+        x1, xo = mk(H), mk(H)
+        scratch = [mk(H), mk(H), mk(64), mk(H), mk(F), mk(H), mk(H), mk(3 * H)]
+        grads = [[torch.zeros(H, 64, device=dev), torch.zeros(64, H, device=dev), torch.zeros(H, device=dev), torch.zeros(64, device=dev)] for _ in range(2)]
+        dx_out, dx_in = dx_fixed, mk(H)
+        wT = [w[0].t().contiguous(), w[2].t().contiguous(), w[4].t().contiguous(), w[6].t().contiguous()]
+        adT = [[a[0].t().contiguous(), a[2].t().contiguous()] for a in ads]
+        if use_op:
+            ops.encoder_layer_fwd(x, w, ads[0], ads[1], saved, x1, xo, km, None, q8_tiled=False, **scalars)
+            ops.encoder_layer_bwd(dx_out, x1, xo, w, wT, ads[0], ads[1], adT[0], adT[1], saved, scratch, grads[0], grads[1], dx_in, km, None, q8_tiled=False, **scalars)
+        else:
+            d = L.EncoderLayer()
+            d.M, d.H, d.F, d.n_items, d.S, d.n_heads, d.dh, d.causal = M, H, F, n_items, S, nh, H // nh, 0
+            d.scale, d.mask_neg, d.ln_eps, d.p_attn, d.p_hidden, d.drop_site, d.drop_seed = scalars['scale'], scalars['mask_neg'], 1e-12, 0.1, 0.1, 7, 123
+            d.key_mask = km.data_ptr()
+            for name, ten in zip(('wqkv', 'bqkv', 'wo', 'bo', 'wi', 'bi', 'wo2', 'bo2', 'ln1_g', 'ln1_b', 'ln2_g', 'ln2_b'), w):
+                setattr(d, name, ten.data_ptr())
+            for name, ten in zip(('wqkvT', 'woT', 'wiT', 'wo2T'), wT):
+                setattr(d, name, ten.data_ptr())
+            for k in range(2):
+                a = d.ad[k]
+                a.wd, a.bd, a.wu, a.bu, a.wdT, a.wuT = (q.data_ptr() for q in (ads[k][0], ads[k][1], ads[k][2], ads[k][3], adT[k][0], adT[k][1]))
+                a.act = scalars['act1'] if k == 0 else scalars['act2']
+                a.g_wu, a.g_wd, a.g_bu, a.g_bd, a.ldg_wu, a.ldg_wd = grads[k][0].data_ptr(), grads[k][1].data_ptr(), grads[k][2].data_ptr(), grads[k][3].data_ptr(), 64, H
+            for name, ten in zip(('qkv', 'ctx', 'h1', 'v1', 'zp1', 'z1', 'u', 'upre', 'h2', 'v2', 'zp2', 'z2', 'st1', 'st2'), saved):
+                setattr(d, name, ten.data_ptr())
+            d.upre_q8 = 1
+            for name, ten in zip(('dv1', 'dv2', 'dzp', 'd_h', 'du', 'dx1', 'dctx', 'dqkv'), scratch):
+                setattr(d, name, ten.data_ptr())
+            L.encoder_layer_fwd(d, x, x1, xo)
+            L.encoder_layer_bwd(d, x1, xo, dx_out, dx_in)
+        runs.append(dict(x1=x1, xo=xo, dx_in=dx_in, grads=grads, dx_out=dx_out))
+    assert torch.equal(runs[0]['x1'], runs[1]['x1']) and torch.equal(runs[0]['xo'], runs[1]['xo']) and torch.equal(runs[0]['dx_in'], runs[1]['dx_in'])
+    for k in range(2):
+        for ga, gb in zip(runs[0]['grads'][k], runs[1]['grads'][k]):
+            torch.testing.assert_close(ga, gb, rtol=1e-4, atol=1e-5 * float(gb.abs().max()))
+    assert float(runs[0]['xo'].float().abs().max()) > 0.1 and float(runs[0]['dx_in'].float().abs().max()) > 0
+    assert all(float(gr.abs().max()) > 0 for k in range(2) for gr in runs[0]['grads'][k])
+    # ---- SASRec block
+    desc, xs, mask, dy = _sasrec_case(16, 1, True, seed=5, mode=0)
+    B, T = 6, 20
+    y0, y1 = torch.zeros_like(xs), torch.zeros_like(xs)
+    L.sasrec_block(desc, xs, mask, y0, B, T, False)
+    names = ('wqkv', 'wfc', 'w1', 'b1', 'w2', 'b2', 'ln1_g', 'ln1_b', 'ln2_g', 'ln2_b', 'wd1', 'bd1', 'wu1', 'bu1', 'wd2', 'bd2', 'wu2', 'bu2')
+    wl = [desc[n] for n in names]
+    common = dict(n_heads=desc['n_heads'], F=desc['F'], d=desc['d'], act=desc['act'], inner_res=bool(desc['inner_res']), eps=desc['eps'], mask_neg=desc['mask_neg'])
+    ops.sasrec_block_fwd(xs.view(B, T, 64), mask.view(B, T), y1.view(B, T, 64), wl, **common)
+    assert torch.equal(y0, y1)
+    gl = [torch.zeros_like(desc['g_' + n]) for n in ('wd1', 'bd1', 'wu1', 'bu1', 'wd2', 'bd2', 'wu2', 'bu2')]
+    dx0, dx1 = torch.zeros_like(xs), torch.zeros_like(xs)
+    L.sasrec_block(desc, xs, mask, dx0, B, T, False, dy=dy)
+    ops.sasrec_block_bwd(xs.view(B, T, 64), mask.view(B, T), dy.view(B, T, 64), dx1.view(B, T, 64), wl, gl, **common)
+    assert torch.equal(dx0, dx1)
+    for n, gnew in zip(('wd1', 'bd1', 'wu1', 'bu1', 'wd2', 'bd2', 'wu2', 'bu2'), gl):
+        torch.testing.assert_close(gnew, desc['g_' + n], rtol=1e-4, atol=1e-5 * float(desc['g_' + n].abs().max()) + 1e-9)
+    # ---- embeddings
+    V, Hh, n, S2 = 500, 256, 24, 30
+    ids = torch.randint(1, V, (n, 2 * S2), device=dev, generator=g)
+    word, pos, typ, gam, bet = r(V, Hh, sc=0.1), r(64, Hh, sc=0.1), r(Hh, sc=0.1), 1 + r(Hh, sc=0.1), r(Hh, sc=0.1)
+    Mp = 768
+    e0, e1 = torch.zeros(Mp, Hh, dtype=t, device=dev), torch.zeros(Mp, Hh, dtype=t, device=dev)
+    L.embed_ln(ids, word, pos, typ, gam, bet, 1e-12, e0, n, S2, drop_p=0.1, drop_site=3, drop_seed=9)
+    ops.embed_ln_fwd(ids, word, pos, typ, gam, bet, 1e-12, e1, S2, False, 0, 0.1, 3, 9)
+    assert torch.equal(e0, e1) and float(e0.float().abs().max()) > 0
+    # ---- patch embedding input side
+    img = torch.randint(0, 256, (3, 32, 32, 3), dtype=torch.uint8, device=dev, generator=g)
+    p0, p1 = torch.zeros(128, 768, dtype=t, device=dev), torch.zeros(128, 768, dtype=t, device=dev)
+    L.patchify(img, p0, 16)
+    ops.patch_embed_fwd(img, p1, 16)
+    assert torch.equal(p0, p1) and float(p0.float().abs().max()) > 0
+    with pytest.raises(RuntimeError, match='invalid argument'):
+        ops.encoder_layer_fwd(x, w, ads[0], ads[1], saved, x1, xo, None, None, n_items, 64, nh, False, 0.1, -1e9, 1e-12)        # 64 tokens: outside the layer call's scope
