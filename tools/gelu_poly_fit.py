@@ -1,6 +1,11 @@
 """Coefficients and error table of csrc/a4r_common.h: gelu_poly_both_n (GELU + GELU' without exp / rcp for the bf16 + 8-bit-derivative epilogue).
 Phi(x) - 0.5 = x P(t), phi(x) = G(t), t = x^2 / 8 - 1 on |x| <= 4; Chebyshev fits converted to monomials in t, evaluated as the kernel does
-(fp32 Horner, x clamped to [-4, 4]) against float64 erf.       python tools/gelu_poly_fit.py"""
+(fp32 Horner, x clamped to [-4, 4]) against float64 erf.       python tools/gelu_poly_fit.py
+
+The device function it was fitted for is NOT in the library (it lost its A/B: profiles/r06_g_gelu_poly.txt).  Per pair of elements (packed fp32):
+    xc = {v_med3_f32(x.x, -4, 4), v_med3_f32(x.y, -4, 4)};  xs = xc * 0.35355339;  t = xs * xs - 1
+    pp = CP[8];  for k = 7 .. 0: pp = pp * t + CP[k]          gg = CG[7];  for k = 6 .. 0: gg = gg * t + CG[k]      (the two chains of four pairs interleaved)
+    cdf = xc * pp + 0.5;   gelu = x * cdf;   gelu' = xc * gg + cdf"""
 import numpy as np
 from numpy.polynomial import chebyshev as Ch
 from scipy.special import erf
