@@ -506,7 +506,10 @@ __global__ void __launch_bounds__(WG<NKT>::NTHR, DH > 64 ? 2 : 4) attn_long_bwd_
                                                             const float* __restrict__ lse, float* delta, T* dqkv,
                                                             int S, int nh, float scale, Drop dr, const float* __restrict__ kmask, int causal) {
     dq_body<T, DH, NKT, KM>(qkv, ld, q_off, k_off, v_off, dctx, ldo, octx, lse, delta, dqkv, S, nh, scale, dr, kmask, causal);
-    __threadfence_block();                                  // delta written by this workgroup's waves is read by others of it below
+    // delta written by this workgroup's waves is read by others of it below: workgroup-scope visibility (the fence) + the barrier.  Two things this relies on:
+    // dq_body has NO early return (every wave of the workgroup reaches the barrier; a bounds exit would have to become a predicate), and the workgroup runs
+    // on one CU (CU mode: its waves share the L1 the fence makes coherent).  tests/test_kernels_gpu.py forces this form at S = 197 as well (A4R_ATTN_BWD_FUSED=1).
+    __threadfence_block();
     __syncthreads();                                        // ... and the LDS images of the first half are dead
     dkdv_body<T, DH, NKT, KM>(qkv, ld, q_off, k_off, v_off, dctx, ldo, lse, delta, dqkv, S, nh, scale, dr, kmask, causal);
 }

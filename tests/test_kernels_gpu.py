@@ -564,7 +564,7 @@ def test_attention_long_backward_both_launch_forms(form):
     import os
     import subprocess
     import sys
-    env = dict(os.environ, A4R_ATTN_BWD_FUSED=form)
+    env = dict(os.environ, A4R_ATTN_BWD_FUSED=form, A4R_ATTN_BWD_ONEPASS='0')      # (the persistent one-pass kernel, the default at 129 .. 224 tokens, would take ViT-B/16's shape from both)
     r = subprocess.run([sys.executable, '-m', 'pytest', os.path.abspath(__file__), '-q', '-x', '-p', 'no:cacheprovider',
                         '-k', 'attention_long_fwd_bwd or attention_long_key_mask or attention_long_causal or attention_long_dropout'],
                        env=env, capture_output=True, text=True, timeout=900)
