@@ -230,10 +230,16 @@ class GemmProbe:
                 tile = (128 if N % 128 == 0 else 64,)
             self.rec.append((str(A.dtype), 'torch.bfloat16' if Cout.dtype == torch.uint8 else str(Cout.dtype), tile, M, N, K, e0, e1))      # (an e4m3 C belongs to the bf16-storage step)
         self.L.gemm_nt = wrapped
+        # the instrumented steps issue every launch from Python: the one-call-per-layer sequencer (a4r_encoder_layer_fwd / _bwd, csrc/a4r_layer.hip) enqueues the
+        # SAME launches with the same arguments from C, where this wrapper cannot put events around them (tests/test_layer_call_gpu.py: bit-identical)
+        from adapter4rec_amd.engine import TransRecEngine
+        self._layer_call, TransRecEngine.LAYER_CALL = TransRecEngine.LAYER_CALL, False
         return self
 
     def __exit__(self, *exc):
+        from adapter4rec_amd.engine import TransRecEngine
         self.L.gemm_nt = self.real
+        TransRecEngine.LAYER_CALL = self._layer_call
 
     def summary(self):
         torch.cuda.synchronize()
@@ -761,7 +767,9 @@ def main():
                        # engine does not encode unread slots where that removes work (engine.py: _kept_rows; A4R_SKIP_UNUSED_ITEMS=0: all 42)
                        'items_encoded_per_user': (eng._kept_rows(a.batch) or 42 * a.batch) // a.batch, 'parallelism': f'dp{world}',
                        'path': 'public: optimizer.zero_grad(); FlatDDP(model)(items, mask); loss.backward(); FusedAdam.step()',
-                       **({'residual_dtype': a.residual_dtype} if not image else {})},
+                       **({'residual_dtype': a.residual_dtype,
+                           'residual_dtype_cost': 'bf24 (default): +2.3 .. +2.5 % step time against --residual-dtype bf16 same-box (profiles/r06_d_residual_bf24.txt, '
+                                                  'r06_z_bench_full*.json); buys rms error <= 1.0 x the reference-under-autocast (bf16 stream: 1.2 - 1.3 x)'} if not image else {})},
             'rccl_ranks': rccl_ranks, 'allreduce_bytes_per_step': int(eng.flat_g.numel() * 4) if world > 1 else 0, 'allreduce_us': ar_us,
             'ms_per_step_ranks': rank_ms, 'ms_per_step_spread': round(max(rank_ms) - min(rank_ms), 3),
             'allreduce_overlapped': bool(world > 1 and eng.OVERLAP_ALLREDUCE and eng._grad_chunks() is not None),
