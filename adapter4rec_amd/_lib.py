@@ -76,7 +76,7 @@ class EncoderLayer(C.Structure):
                [('ad', LayerAdapter * 2)] + \
                [(n, C.c_void_p) for n in ('qkv', 'ctx', 'h1', 'v1', 'zp1', 'z1', 'u', 'upre', 'h2', 'v2', 'zp2', 'z2', 'st1', 'st2')] + \
                [('upre_q8', C.c_int32), ('q8_tiled', C.c_int32)] + \
-               [(n, C.c_void_p) for n in ('x_lo', 'x1_lo', 'xout_lo', 'dv1', 'dv2', 'dzp', 'd_h', 'du', 'dx1', 'dctx', 'dqkv')]
+               [(n, C.c_void_p) for n in ('x_lo', 'x1_lo', 'xout_lo', 'dv1', 'dv2', 'dzp', 'd_h', 'du', 'dx1', 'dctx', 'dqkv')] + [('lo_nibble', C.c_int32)]
 
 
 class SasrecBlock(C.Structure):
@@ -217,7 +217,8 @@ def adapter_ln_ok(A, d):
 
 def adapter_ln_fwd(A, R1, R2, Wd, bd, Wu, bu, gamma, beta, eps, act, zp, z, v, y, stats, M=None, y8=None, ys=None, res32=None, y32=None, frag=None):
     """res32 / y32 (fp32 [M, H], optional): the residual operand that is not A read in fp32, and y before its bf16 rounding (include/a4r.h).
-    The same two as int8 [M, H] (--residual_dtype bf24, w_frag bit 1): byte planes beside the bf16 tensors -- residual read / y written as 24-bit floats.
+    The same two as int8 [M, H] (--residual_dtype bf24, w_frag bit 1): byte planes beside the bf16 tensors -- residual read / y written as 24-bit floats;
+    as int8 [M, H / 2] (--residual_dtype bf20, w_frag bits 1 + 2): nibble planes, 20-bit floats.
     frag = (Wd_f, Wu_f): the same matrices in fragment order (a4r_pack_matrices layouts 1 / 2): read instead of Wd / Wu (w_frag)."""
     require_gpu(A, R1, R2, v, y, res32, y32)
     M = A.shape[0] if M is None else M
@@ -225,6 +226,8 @@ def adapter_ln_fwd(A, R1, R2, Wd, bd, Wu, bu, gamma, beta, eps, act, zp, z, v, y
     twins = [t for t in (res32, y32) if t is not None]
     lo8 = bool(twins) and twins[0].dtype == torch.int8
     assert all(t.dtype == (torch.int8 if lo8 else torch.float32) and t.shape[0] >= M for t in twins)
+    lo4 = lo8 and twins[0].shape[1] == A.shape[1] // 2
+    assert not lo8 or all(t.shape[1] == (A.shape[1] // 2 if lo4 else A.shape[1]) for t in twins)
     wd_, wu_ = (Wd, Wu) if frag is None else frag
     _check(lib().a4r_adapter_ln_fwd(_stream(), _p(A), C.c_int(_ld(A)), _p(R1), C.c_int(_ld(R1)), _p(R2), C.c_int(_ld(R2) if R2 is not None else 0),
                                     _p(wd_), _p(bd), _p(wu_), _p(bu), _p(gamma), _p(beta), C.c_float(eps), C.c_int(act),
@@ -232,7 +235,7 @@ def adapter_ln_fwd(A, R1, R2, Wd, bd, Wu, bu, gamma, beta, eps, act, zp, z, v, y
                                     C.c_int(M), C.c_int(A.shape[1]), C.c_int(Wd.shape[0]), C.c_int(_dt(A)),
                                     _p(y8), C.c_int(_ld(y8) if y8 is not None else 0), _p(ys),
                                     _p(res32), C.c_int(_ld(res32) if res32 is not None else 0), _p(y32), C.c_int(_ld(y32) if y32 is not None else 0),
-                                    C.c_int((0 if frag is None else 1) | (2 if lo8 else 0))),
+                                    C.c_int((0 if frag is None else 1) | (2 if lo8 else 0) | (4 if lo4 else 0))),
            'a4r_adapter_ln_fwd')
 
 

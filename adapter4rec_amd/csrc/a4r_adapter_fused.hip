@@ -107,6 +107,7 @@ struct AdFwdArgs {
     // --residual_dtype bf24 (round 6): the same twins as ONE BYTE per element beside the bf16 tensor -- the next 8 mantissa bits of the fp32 value
     // as a signed offset from its bf16 rounding (lo8_of / lo8_join below): O + Olo is read as a 24-bit float, y + ylo written as one
     const signed char* Olo; int ldolo; signed char* ylo; int ldylo;
+    int lo4;                                    // the planes hold 4 bits per element (w_frag bit 2): --residual_dtype bf20
     int wfrag;                                  // Wd / Wu in fragment order
 };
 
@@ -152,7 +153,34 @@ A4R_DEV uint32_t lo8_split4(const float (&x)[8], int m, uint32_t hw0, uint32_t h
     return __builtin_amdgcn_perm(p23, p01, 0x05040100u);
 }
 
-// RM = 1: the residual operand is the fp32 tensor O32 (two 16-byte pieces per 8 columns instead of one); RM = 2: the bf16 tensor O + its byte plane Olo
+// The 20-bit form (w_frag bit 2, --residual_dtype bf20): FOUR more mantissa bits, rounded to nearest, as a signed nibble n = clamp((bits(x) - (bits(bf16) << 16) + 0x800) >> 12, -8, 7);
+// x20 = (bits(bf16) << 16) + (n << 12).  Eight consecutive elements share one 32-bit word, element j in bits [4 j, 4 j + 4): half the plane bytes of the
+// 24-bit form.  What the residual stream needs beyond bf16 is ~2 bits (its rounding error enters the rms distance in quadrature: 2^-13 against the 2^-9 of the
+// other bf16 tensors of a sub-layer); rounding, not truncation: a truncated nibble shrinks every element by 2^-13 of itself, coherently over 24 sub-layers.
+A4R_DEV float lo4_join(uint32_t hw, uint32_t lw, int j) {
+    const uint32_t hi16 = (j & 1) ? (hw & 0xFFFF0000u) : (hw << 16);
+    const int n = __builtin_amdgcn_sbfe((int)lw, 4 * j, 4);
+    return __uint_as_float(hi16 + ((uint32_t)n << 12));
+}
+A4R_DEV uint32_t lo4_split8(const float (&x)[8], const uint32_t (&hw)[4]) {
+    uint32_t w = 0;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const uint32_t hi16 = (j & 1) ? (hw[j >> 1] & 0xFFFF0000u) : (hw[j >> 1] << 16);
+        int d = (int)(__float_as_uint(x[j]) - hi16) + 0x800;
+        d = d < 0x7FFF ? d : 0x7FFF;
+        w |= __builtin_amdgcn_ubfe((uint32_t)d, 12, 4) << (4 * j);
+    }
+    return w;
+}
+
+// The nibble plane is laid out in the kernel's LANE order within a row (it is written and read by this kernel only; whole rows may be moved): the KS words of lane
+// (wave, kg) -- its pieces s = 0 .. KS - 1, columns wave CW + 32 s + 8 kg + [0, 8) -- sit together at word (wave 4 + kg) KS, so a lane moves them with ONE
+// memory instruction.  (Measured first in row-major order: three 4-byte requests per lane and tile cost what the byte plane's three 8-byte ones do -- the
+// fused forward pays per memory INSTRUCTION through its address unit, not per byte: profiles/r06_h_residual_bf20.txt.)
+template <int KS> struct LoWords { uint32_t w[KS]; };
+
+// RM = 1: the residual operand is the fp32 tensor O32 (two 16-byte pieces per 8 columns instead of one); RM = 2: the bf16 tensor O + its byte plane Olo; RM = 3: ... + its nibble plane
 template <int CW, int NW, int RM = 0>
 __global__ void __launch_bounds__(NW * 64) adapter_ln_fwd_kernel(const AdFwdArgs p) {
     constexpr int KS = CW / 32, H = CW * NW, NT = NW * 64, EPT = 1024 / NT, OP = RM ? 2 : 1;
@@ -219,6 +247,12 @@ __global__ void __launch_bounds__(NW * 64) adapter_ln_fwd_kernel(const AdFwdArgs
             dst_[2 * s] = *reinterpret_cast<const uint4*>(p.O + (row_) * p.ldo + cl + s * 32);                          \
             const uint2 l_ = *reinterpret_cast<const uint2*>(p.Olo + (row_) * p.ldolo + cl + s * 32);                   \
             dst_[2 * s + 1] = make_uint4(l_.x, l_.y, 0u, 0u);                                                           \
+        }                                                                                                              \
+    } else if constexpr (RM == 3) {                                                                                    \
+        const LoWords<KS> l_ = *reinterpret_cast<const LoWords<KS>*>(p.Olo + (row_) * p.ldolo + (wave * 4 + kg) * KS * 4); \
+        _Pragma("unroll") for (int s = 0; s < KS; ++s) {                                                               \
+            dst_[2 * s] = *reinterpret_cast<const uint4*>(p.O + (row_) * p.ldo + cl + s * 32);                          \
+            dst_[2 * s + 1] = make_uint4(l_.w[s], 0u, 0u, 0u);                                                          \
         }                                                                                                              \
     } else {                                                                                                           \
         _Pragma("unroll") for (int s = 0; s < KS; ++s) dst_[s] = *reinterpret_cast<const uint4*>(p.O + (row_) * p.ldo + cl + s * 32); \
@@ -312,6 +346,10 @@ __global__ void __launch_bounds__(NW * 64) adapter_ln_fwd_kernel(const AdFwdArgs
                 const uint32_t hw[4] = {o_cur[2 * s].x, o_cur[2 * s].y, o_cur[2 * s].z, o_cur[2 * s].w}, lw[2] = {o_cur[2 * s + 1].x, o_cur[2 * s + 1].y};
 #pragma unroll
                 for (int j = 0; j < 8; ++j) of[j] = lo8_join(hw[j >> 1], lw[j >> 2], j);
+            } else if constexpr (RM == 3) {
+                const uint32_t hw[4] = {o_cur[2 * s].x, o_cur[2 * s].y, o_cur[2 * s].z, o_cur[2 * s].w};
+#pragma unroll
+                for (int j = 0; j < 8; ++j) of[j] = lo4_join(hw[j >> 1], o_cur[2 * s + 1].x, j);
             } else {
                 Elem<bf16_t>::unpack(o_cur[s], of);
             }
@@ -350,6 +388,7 @@ __global__ void __launch_bounds__(NW * 64) adapter_ln_fwd_kernel(const AdFwdArgs
         if (wave == 0 && kg == 0) { p.stats[2 * row] = mean; p.stats[2 * row + 1] = rstd; }
         float yv[KS][8];
         float am = 0.f;
+        LoWords<KS> ylw;                                     // (nibble plane of y: the lane's KS words, stored together after the loop)
 #pragma unroll
         for (int s = 0; s < KS; ++s) {
             float g8[8], b8[8];
@@ -363,13 +402,15 @@ __global__ void __launch_bounds__(NW * 64) adapter_ln_fwd_kernel(const AdFwdArgs
             if (p.ylo) {                                     // the byte plane of y: offsets from the bf16 values just stored
                 const uint4 pk = Elem<bf16_t>::pack(yv[s]);
                 const uint32_t hw[4] = {pk.x, pk.y, pk.z, pk.w};
-                *reinterpret_cast<uint2*>(p.ylo + row * p.ldylo + cl + s * 32) = make_uint2(lo8_split4(yv[s], 0, hw[0], hw[1]), lo8_split4(yv[s], 1, hw[2], hw[3]));
+                if (p.lo4) ylw.w[s] = lo4_split8(yv[s], hw);
+                else *reinterpret_cast<uint2*>(p.ylo + row * p.ldylo + cl + s * 32) = make_uint2(lo8_split4(yv[s], 0, hw[0], hw[1]), lo8_split4(yv[s], 1, hw[2], hw[3]));
             }
             if (p.y32) {
                 *reinterpret_cast<float4*>(p.y32 + row * p.ldy32 + cl + s * 32) = make_float4(yv[s][0], yv[s][1], yv[s][2], yv[s][3]);
                 *reinterpret_cast<float4*>(p.y32 + row * p.ldy32 + cl + s * 32 + 4) = make_float4(yv[s][4], yv[s][5], yv[s][6], yv[s][7]);
             }
         }
+        if (p.ylo && p.lo4) *reinterpret_cast<LoWords<KS>*>(p.ylo + row * p.ldylo + (wave * 4 + kg) * KS * 4) = ylw;
         if (p.y8) {      // e4m3 row = y * 448 / max|y| from the fp32 values (one rounding; the same arithmetic as a4r_ln_fwd_fp8), scale = max|y| / 448
             am = fmaxf(am, __shfl_xor(am, 16, 64));
             am = fmaxf(am, __shfl_xor(am, 32, 64));
@@ -727,6 +768,7 @@ inline bool misaligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p)
 template <int CW, int NW>
 int launch_fwd(hipStream_t s, const AdFwdArgs& a, int grid) {
     if (a.O32) hipLaunchKernelGGL((adapter_ln_fwd_kernel<CW, NW, 1>), dim3(grid), dim3(NW * 64), 0, s, a);
+    else if (a.Olo && a.lo4) hipLaunchKernelGGL((adapter_ln_fwd_kernel<CW, NW, 3>), dim3(grid), dim3(NW * 64), 0, s, a);
     else if (a.Olo) hipLaunchKernelGGL((adapter_ln_fwd_kernel<CW, NW, 2>), dim3(grid), dim3(NW * 64), 0, s, a);
     else hipLaunchKernelGGL((adapter_ln_fwd_kernel<CW, NW, 0>), dim3(grid), dim3(NW * 64), 0, s, a);
     return a4r_launch_status();
@@ -763,8 +805,10 @@ extern "C" int a4r_adapter_ln_fwd(void* stream, const void* A, int lda, const vo
                                   void* y8, int ld8, float* ys, const float* res32, int ldres32, float* y32, int ldy32, int w_frag) {
     if (!A || !R1 || !Wd || !bd || !Wu || !bu || !gamma || !beta || !zp || !z || (!v && !y) || (!y && !y8) || !stats) return A4R_EINVAL;      // v may be null when y is kept
     const bool lo8 = (w_frag & 2) != 0;                  // res32 / y32 are BYTE planes (the 24-bit residual stream): 8-byte pieces, leading dimension in bytes
+    if ((w_frag & 4) && !lo8) return A4R_EINVAL;
     if (lo8) {
-        if ((res32 && (ldres32 % 8 || ldres32 < H || (reinterpret_cast<uintptr_t>(res32) & 7u))) || (y32 && (ldy32 % 8 || ldy32 < H || (reinterpret_cast<uintptr_t>(y32) & 7u)))) return A4R_EINVAL;
+        const int hb = (w_frag & 4) ? H / 2 : H, al = (w_frag & 4) ? 4 : 8;      // bytes of a row of the plane; its pieces are 4 (nibbles) / 8 bytes
+        if ((res32 && (ldres32 % al || ldres32 < hb || (reinterpret_cast<uintptr_t>(res32) & (al - 1)))) || (y32 && (ldy32 % al || ldy32 < hb || (reinterpret_cast<uintptr_t>(y32) & (al - 1))))) return A4R_EINVAL;
     } else if ((res32 && (ldres32 % 4 || ldres32 < H || misaligned16(res32))) || (y32 && (ldy32 % 4 || ldy32 < H || misaligned16(y32)))) return A4R_EINVAL;
     if (y8 && (!ys || ld8 % 8 || ld8 < H || (reinterpret_cast<uintptr_t>(y8) & 7u))) return A4R_EINVAL;
     if (dtype != A4R_BF16 || d != 64 || M <= 0 || M % 16) return A4R_EINVAL;
@@ -784,6 +828,7 @@ extern "C" int a4r_adapter_ln_fwd(void* stream, const void* A, int lda, const vo
     a.zp = reinterpret_cast<bf16_t*>(zp); a.z = reinterpret_cast<bf16_t*>(z); a.v = reinterpret_cast<bf16_t*>(v); a.y = reinterpret_cast<bf16_t*>(y);
     a.ldv = ldv; a.ldy = ldy; a.stats = stats; a.M = M;
     a.y8 = reinterpret_cast<unsigned char*>(y8); a.ld8 = ld8; a.ys = ys;
+    a.lo4 = (w_frag & 4) != 0;
     if (lo8) { a.Olo = reinterpret_cast<const signed char*>(res32); a.ldolo = ldres32; a.ylo = reinterpret_cast<signed char*>(y32); a.ldylo = ldy32; }
     else { a.O32 = res32; a.ldo32 = ldres32; a.y32 = y32; a.ldy32 = ldy32; }      // (res32: the fp32 twin of the residual operand that is not A)
     a.wfrag = (w_frag & 1) != 0;

@@ -54,10 +54,11 @@ int sub_forward(void* s, const a4r_encoder_layer_t* l, int half, const void* den
     g.bias = bias; g.drop_p = l->p_hidden; g.drop_site = l->drop_site + 1 + half; g.drop_seed = l->drop_seed;
     if (int rc = a4r_gemm_nt(s, &g)) return rc;
     const bool frag = a.wd_f != nullptr, lo = resid_lo != nullptr || out_lo != nullptr;
+    const int ldlo = l->lo_nibble ? H / 2 : H;                   // bytes per row of a plane
     return a4r_adapter_ln_fwd(s, h, H, h, H, resid, H, frag ? a.wd_f : a.wd, a.bd, frag ? a.wu_f : a.wu, a.bu, ln_g, ln_b, l->ln_eps, a.act, zp, z,
                               v, v ? H : 0, out, H, st, M, H, 64, A4R_BF16, nullptr, 0, nullptr,
-                              reinterpret_cast<const float*>(lo ? resid_lo : nullptr), lo && resid_lo ? H : 0,
-                              reinterpret_cast<float*>(lo ? out_lo : nullptr), lo && out_lo ? H : 0, (frag ? 1 : 0) | (lo ? 2 : 0));
+                              reinterpret_cast<const float*>(lo ? resid_lo : nullptr), lo && resid_lo ? ldlo : 0,
+                              reinterpret_cast<float*>(lo ? out_lo : nullptr), lo && out_lo ? ldlo : 0, (frag ? 1 : 0) | (lo ? (l->lo_nibble ? 6 : 2) : 0));
 }
 
 // backward of sub_forward (engine.py: _sub_backward, fused form with both bias gradients in the weight-gradient launch): dy -> dh (gradient of the

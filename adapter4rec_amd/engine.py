@@ -251,10 +251,12 @@ class TransRecEngine:
         self.q8_deriv = dtype != 'fp32' and _os.environ.get('A4R_Q8_DERIV', '1') != '0'
         self.T = torch.float32 if dtype == 'fp32' else torch.bfloat16
         # --residual_dtype fp32 (bf16 storage): fp32 twins of the residual stream, keyed by the bf16 tensor they shadow (see _sub_forward)
-        self.res32 = dtype != 'fp32' and getattr(args, 'residual_dtype', 'bf24') == 'fp32'
+        self.res32 = dtype != 'fp32' and getattr(args, 'residual_dtype', 'bf20') == 'fp32'
         # --residual_dtype bf24 (round 6): the same twins as ONE byte per element (the 24-bit residual stream of a4r_adapter_ln_fwd, w_frag bit 1) on the
         # sub-layers that run the one-launch serial adapter kernel; the others keep the bf16 stream
-        self.res24 = dtype != 'fp32' and getattr(args, 'residual_dtype', 'bf24') == 'bf24'       # (the default since round 6)
+        # the residual stream as the bf16 tensor + a low-bit plane: 8 more mantissa bits per element (bf24) or 4 (bf20: half the plane bytes)
+        self.res24 = dtype != 'fp32' and getattr(args, 'residual_dtype', 'bf20') in ('bf24', 'bf20')
+        self.lo_div = 2 if getattr(args, 'residual_dtype', 'bf20') == 'bf20' else 1               # plane bytes per row = H / lo_div
         self._twin = {}
         # --news_attributes (encoders.py:62-99): rows are [ids | mask] per attribute, laid out title, abstract, body; every attribute runs through the
         # same tower and the item vector is the mean.  With more than one, the attributes are stacked as extra items at the longest length
@@ -1055,7 +1057,7 @@ class TransRecEngine:
                 # in one of two transient buffers (attention half / FFN half: a half's twin is dead once the next half of its kind has run).
                 # bf24: the twin is a byte plane (int8) -- the next 8 mantissa bits beside the bf16 tensor.
                 r32 = self._twin_of(resid, M)
-                y32 = self._buf(('res8.' if self.res24 else 'res32.') + which, M, blk.H, torch.int8 if self.res24 else torch.float32)
+                y32 = self._buf(('res8.' if self.res24 else 'res32.') + which, M, blk.H // self.lo_div if self.res24 else blk.H, torch.int8 if self.res24 else torch.float32)
             L.adapter_ln_fwd(h, resid if comp else h, None if comp else resid, ad.wd, ad.bd, ad.wu, ad.bu, ln.gamma, ln.beta, ln.eps, ad.act,
                              zp, z, v, out, st, M=M, y8=y8, ys=ys, **(dict(res32=r32, y32=y32) if y32 is not None else {}), frag=ad.frag_f)
             if y32 is not None:
@@ -1094,7 +1096,7 @@ class TransRecEngine:
         """The fp32 twin of residual-stream tensor t ([>= M, H]) when the producing sub-layer left one in this forward (else None: the bf16
         tensor itself is the residual, e.g. the embedding output or a sub-layer that ran on the multi-launch path)."""
         w = self._twin.get(t.data_ptr())
-        return w if (w is not None and w.shape[0] >= M and w.shape[1] == t.shape[1]) else None
+        return w if (w is not None and w.shape[0] >= M and w.shape[1] == (t.shape[1] // self.lo_div if w.dtype == torch.int8 else t.shape[1])) else None
 
     def _fuse_bwd(self, blk, ad, t):
         return self._fuse(blk, ad, t) and blk.H != 1024          # (the backward kernel's LDS image of Wd does not fit at H = 1024)
@@ -1173,9 +1175,10 @@ class TransRecEngine:
         off = self._off(blk)
         d.offsets = None if off is None else off.data_ptr()
         x_lo = self._twin_of(x, M) if self.res24 else None
-        x1_lo = self._buf('res8.1', M, blk.H, torch.int8) if self.res24 else None
-        xo_lo = self._buf('res8.2', M, blk.H, torch.int8) if self.res24 else None
+        x1_lo = self._buf('res8.1', M, blk.H // self.lo_div, torch.int8) if self.res24 else None
+        xo_lo = self._buf('res8.2', M, blk.H // self.lo_div, torch.int8) if self.res24 else None
         d.x_lo, d.x1_lo, d.xout_lo = (None if t is None else t.data_ptr() for t in (x_lo, x1_lo, xo_lo))
+        d.lo_nibble = 1 if (self.res24 and self.lo_div == 2) else 0
         self._twin.pop(x1.data_ptr(), None)
         self._twin.pop(x_out.data_ptr(), None)
         if 'y2' in bufs:
@@ -1246,7 +1249,7 @@ class TransRecEngine:
             x32 = self._twin_of(x, M) if (self.res32 or self.res24) else None
             if x32 is not None:                        # the CLS rows of the fp32 residual stream too
                 if x32.dtype == torch.int8:            # (byte plane: its rows move as H / 2 two-byte elements)
-                    x_c32 = self._buf('x_c8', cls_rows, H, torch.int8)
+                    x_c32 = self._buf('x_c8', cls_rows, x32.shape[1], torch.int8)
                     self._cls_gather(x32.view(torch.bfloat16), x_c32.view(torch.bfloat16), n_items, blk.S, blk)
                 else:
                     x_c32 = self._buf('x_c32', cls_rows, H, torch.float32)

@@ -78,13 +78,13 @@ def build_parser():
                         "negatives by vectorised rejection) instead of BuildTrainDataset + DataLoader workers -- the same distribution as "
                         'Downstream/Text/data_utils/dataset.py:24-49, not the same random stream; the host then only enqueues.  0 (default): the '
                         "reference's DataLoader path (bit-pinned); it keeps up with the GPU from ~4 workers on (profiles/r04_*_run_throughput.json)")
-    p.add_argument('--residual_dtype', type=str, default='bf24', choices=['bf16', 'fp32', 'bf24'],
+    p.add_argument('--residual_dtype', type=str, default='bf20', choices=['bf16', 'fp32', 'bf24', 'bf20'],
                    help="bf16 storage only: how the item encoder's residual stream between sub-layers is kept.  The reference's autocast(bfloat16) keeps it "
-                        'in fp32 (its LayerNorm outputs fp32).  bf24 (default since round 6): the bf16 tensor + one byte per element (8 more mantissa bits) on '
-                        'the sub-layers that run the one-launch serial adapter kernel (Houlsby / Compacter): scores / embeddings at 0.55 - 0.92x the distance '
-                        "of the reference's own autocast path from fp32, for +2.3 %% of the BERT-base + Houlsby step.  fp32: fp32 twins (0.5 - 0.9x, +5.3 %%; "
-                        'also un-adapted sub-layers and Pfeiffer through a4r_ln_fwd_sum).  bf16: no twin (1.2 - 1.3x, the fastest).  Parallel Houlsby and '
-                        'K-Adapter blocks keep the bf16 stream; text tower only')
+                        'in fp32 (its LayerNorm outputs fp32).  bf20 (default since round 6): the bf16 tensor + a NIBBLE per element (4 more mantissa bits, rounded) '
+                        'on the sub-layers that run the one-launch serial adapter kernel (Houlsby / Compacter): scores / embeddings at 0.5 - 0.9x the distance '
+                        "of the reference's own autocast path from fp32, for +1.6 %% of the BERT-base + Houlsby step.  bf24: a byte per element (8 more bits; the same "
+                        'accuracy, +2.4 %%).  fp32: fp32 twins (0.5 - 0.9x, +5.3 %%; also un-adapted sub-layers and Pfeiffer through a4r_ln_fwd_sum).  bf16: no twin '
+                        '(1.2 - 1.3x, the fastest).  Parallel Houlsby and K-Adapter blocks keep the bf16 stream; text tower only')
     p.add_argument('--eval_compute_dtype', type=str, default='fp32', choices=['bf16', 'fp32'],
                    help="dtype of eval's item sweep (get_item_embeddings).  Default fp32 = the reference's eval precision: HR@10 / nDCG@10 "
                         'and per-user ranks then match the fp32 reference exactly on the trained weights (a bf16 sweep moves a few users across '

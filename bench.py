@@ -438,10 +438,10 @@ def main():
                          'tokens) and history lengths from the 21 153 real Amazon users (mean 4.1 of 21 slots) that the reference ships '
                          '(tests/golden/real_shapes.json); implies --short-titles --ragged-histories (host hand-over, titles packed, pad slots not encoded)')
     ap.add_argument('--short-titles-device', action='store_true', help='with --short-titles: batches resident on the device (30 tokens per item: the A/B)')
-    ap.add_argument('--residual-dtype', default='bf24', choices=['bf16', 'fp32', 'bf24'],
-                    help="text towers: --residual_dtype of parameters.py.  Default bf24 = the product's default since round 6 (the residual stream between sub-layers "
-                         "as bf16 + one byte: at least the accuracy of the reference's autocast path, +2.3 %% on the headline step); bf16 = round 5's stream; "
-                         'recorded in config.residual_dtype')
+    ap.add_argument('--residual-dtype', default='bf20', choices=['bf16', 'fp32', 'bf24', 'bf20'],
+                    help="text towers: --residual_dtype of parameters.py.  Default bf20 = the product's default since round 6 (the residual stream between sub-layers "
+                         "as bf16 + a nibble per element: at least the accuracy of the reference's autocast path, +1.6 %% on the headline step); bf24: a byte per "
+                         "element (+2.4 %%); bf16 = round 5's stream; recorded in config.residual_dtype")
     ap.add_argument('--gemm-variant', type=int, default=-1, help='A/B knob of a4r_gemm_variant (include/a4r.h); default: the library default')
     a = ap.parse_args()
     if a.real_shaped:
@@ -768,8 +768,8 @@ def main():
                        'items_encoded_per_user': (eng._kept_rows(a.batch) or 42 * a.batch) // a.batch, 'parallelism': f'dp{world}',
                        'path': 'public: optimizer.zero_grad(); FlatDDP(model)(items, mask); loss.backward(); FusedAdam.step()',
                        **({'residual_dtype': a.residual_dtype,
-                           'residual_dtype_cost': 'bf24 (default): +2.3 .. +2.5 % step time against --residual-dtype bf16 same-box (profiles/r06_d_residual_bf24.txt, '
-                                                  'r06_z_bench_full*.json); buys rms error <= 1.0 x the reference-under-autocast (bf16 stream: 1.2 - 1.3 x)'} if not image else {})},
+                           'residual_dtype_cost': 'bf20 (default): +1.6 % step time against --residual-dtype bf16 same-box, bf24 +2.4 % (profiles/r06_h_residual_bf20.txt); '
+                                                  'either buys rms error <= 1.0 x the reference-under-autocast (bf16 stream: 1.2 - 1.3 x)'} if not image else {})},
             'rccl_ranks': rccl_ranks, 'allreduce_bytes_per_step': int(eng.flat_g.numel() * 4) if world > 1 else 0, 'allreduce_us': ar_us,
             'ms_per_step_ranks': rank_ms, 'ms_per_step_spread': round(max(rank_ms) - min(rank_ms), 3),
             'allreduce_overlapped': bool(world > 1 and eng.OVERLAP_ALLREDUCE and eng._grad_chunks() is not None),

@@ -201,7 +201,12 @@ int a4r_adapter_ln_fwd(void* stream, const void* A, int lda, const void* R1, int
                                          bit 1 (ABI 409, --residual_dtype bf24): res32 / y32 are BYTE planes (int8 [M, ld], ld in bytes, 8-byte aligned) -- the 24-bit
                                          residual stream: value = (bits(bf16 tensor) << 16) + (signed byte << 8), i.e. the fp32 value cut to 15 explicit mantissa
                                          bits, stored as its bf16 rounding (the tensor the GEMMs read, unchanged) + the offset from it (a zero byte = no offset).  One more byte
-                                         read and written per element instead of four, the accuracy of the fp32 stream to 2^-15 (7 + 8 explicit mantissa bits) */
+                                         read and written per element instead of four, the accuracy of the fp32 stream to 2^-15 (7 + 8 explicit mantissa bits);
+                                         bit 2 (with bit 1; --residual_dtype bf20): the planes hold a signed NIBBLE per element ([M, ld] bytes, ld >= H / 2, 4-byte aligned;
+                                         eight consecutive elements share a 32-bit word, element j in bits [4 j, 4 j + 4)): value = (bits(bf16) << 16) + (nibble << 12), the offset
+                                         rounded to nearest -- 11 explicit mantissa bits for half a byte read and written per element.  The ORDER of the words within a row
+                                         is the kernel's own (a lane's words together: one memory instruction per lane and tile) -- the plane is meaningful only to this entry
+                                         point at the same H; move whole rows, never columns (tests/sim_lib.py: lo4_word_index restates the order) */
 /* The LayerNorm of the forward runs on the fp32 sum v (its bf16 copy `v`, when asked for, is for the backward only).
  * res32 / y32 (both optional; --residual_dtype fp32): the residual stream between sub-layers kept in fp32, as under the reference's
  * autocast (LayerNorm outputs fp32 there and `hidden_states + input_tensor` promotes to it, HF BertSelfOutput / BertOutput under
@@ -483,10 +488,11 @@ typedef struct {
      * one byte per element when upre_q8 (tile-native order when q8_tiled: a4r_gemm_t.q8_tiled) */
     void *qkv, *ctx, *h1, *v1, *zp1, *z1, *u, *upre, *h2, *v2, *zp2, *z2; float *st1, *st2;
     int32_t upre_q8, q8_tiled;
-    const void* x_lo; void *x1_lo, *xout_lo;            /* byte planes of the 24-bit residual stream (a4r_adapter_ln_fwd w_frag bit 1): each may be NULL */
+    const void* x_lo; void *x1_lo, *xout_lo;            /* byte (or nibble: lo_nibble) planes of the 24- / 20-bit residual stream (a4r_adapter_ln_fwd w_frag bits 1, 2): each may be NULL */
     /* backward scratch: dv1, dv2, d_h (the gradient of a dense output, both halves in turn), dx1, dctx [M, H]; dzp [M, 64]; du [M, F]; dqkv [M, 3H] (rows >= n_items * S must be zero on entry: the attention
      * backward writes the real token rows only) */
     void *dv1, *dv2, *dzp, *d_h, *du, *dx1, *dctx, *dqkv;
+    int32_t lo_nibble;                                   /* the planes x_lo / x1_lo / xout_lo hold 4 bits per element (a4r_adapter_ln_fwd w_frag bit 2: [M, H / 2] bytes) */
 } a4r_encoder_layer_t;
 /* x [M, H] -> x1 [M, H] (the attention half's output, kept: the FFN half's residual and backward's y1) -> x_out [M, H] */
 int a4r_encoder_layer_fwd(void* stream, const a4r_encoder_layer_t* l, const void* x, void* x1, void* x_out);

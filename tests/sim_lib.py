@@ -105,7 +105,7 @@ def adapter_ln_fwd(A, R1, R2, Wd, bd, Wu, bu, gamma, beta, eps, act, zp, z, v, y
     lo8 = (res32 is not None and res32.dtype == torch.int8) or (y32 is not None and y32.dtype == torch.int8)
     if lo8 and res32 is not None:            # the byte plane joins the bf16 residual that is not A into a 24-bit float
         other = R2 if (R2 is not None and (R1 is A or R1.data_ptr() == A.data_ptr())) else R1
-        res32 = lo8_join(other[:M], res32[:M])
+        res32 = (lo4_join if res32.shape[1] == other.shape[1] // 2 else lo8_join)(other[:M], res32[:M])
     if res32 is not None:                    # replaces the residual that is not A
         if R2 is None or R1 is A or R1.data_ptr() == A.data_ptr():
             R1, R2 = (R1, res32) if R2 is not None else (res32, None)
@@ -131,11 +131,50 @@ def adapter_ln_fwd(A, R1, R2, Wd, bd, Wu, bu, gamma, beta, eps, act, zp, z, v, y
         y[:M] = out.to(y.dtype)
     if y32 is not None:
         if lo8:
-            y32[:M] = lo8_of(out, out.to(torch.bfloat16))
+            y32[:M] = (lo4_of if y32.shape[1] == out.shape[1] // 2 else lo8_of)(out, out.to(torch.bfloat16))
         else:
             y32[:M] = out
     if y8 is not None:
         _quant_rows(out, y8, ys)
+
+
+def lo4_word_index(H):
+    """Position of the nibble word of columns [8 c, 8 c + 8) within a row of the plane (csrc/a4r_adapter_fused.hip: LoWords): the kernel's lane order --
+    wave w owns columns [w CW, (w + 1) CW), lane group kg the pieces 32 s + 8 kg + [0, 8); the KS = CW / 32 words of (w, kg) sit together."""
+    CW = {128: 32, 256: 32, 512: 64, 768: 96, 1024: 128}[H]
+    KS = CW // 32
+    col = torch.arange(H // 8) * 8
+    w, within = col // CW, col % CW
+    s_, kg = within // 32, (within % 32) // 8
+    return (w * 4 + kg) * KS + s_
+
+
+def lo4_of(x, xb):
+    """The nibble plane of the 20-bit residual stream (lo4_split8): n = clamp((bits(x) - (bits(bf16) << 16) + 0x800) >> 12, max 7), eight elements per
+    32-bit word, element j in bits [4 j, 4 j + 4); returned as int8 [rows, H / 2] (little-endian bytes of those words)."""
+    b = x.contiguous().view(torch.int32).to(torch.int64) & 0xFFFFFFFF
+    bf = (xb.contiguous().view(torch.int16).to(torch.int64) & 0xFFFF) << 16
+    d = (b - bf) & 0xFFFFFFFF
+    d = torch.where(d >= 2 ** 31, d - 2 ** 32, d) + 0x800
+    n = (torch.clamp(d, max=0x7FFF) >> 12) & 0xF
+    n = n.reshape(n.shape[0], -1, 8)
+    words = torch.zeros_like(n)
+    words[:, lo4_word_index(x.shape[1])] = n                     # word of columns [8 c, 8 c + 8) -> its place in the kernel's order
+    n = words.reshape(n.shape[0], -1, 2)
+    byte = n[..., 0] | (n[..., 1] << 4)
+    return torch.where(byte >= 128, byte - 256, byte).to(torch.int8)
+
+
+def lo4_join(xb, lo):
+    """bf16 tensor + nibble plane -> the 20-bit float as fp32: (bits(bf16) << 16) + (n << 12)"""
+    byte = lo.to(torch.int64) & 0xFF
+    n = torch.stack([byte & 0xF, byte >> 4], -1).reshape(lo.shape[0], -1, 8)
+    n = n[:, lo4_word_index(xb.shape[1])].reshape(lo.shape[0], -1)          # back to column order
+    n = torch.where(n >= 8, n - 16, n)
+    bf = (xb.contiguous().view(torch.int16).to(torch.int64) & 0xFFFF) << 16
+    bits = (bf + (n << 12)) & 0xFFFFFFFF
+    bits = torch.where(bits >= 2 ** 31, bits - 2 ** 32, bits).to(torch.int32)
+    return bits.view(torch.float32)
 
 
 def lo8_of(x, xb):

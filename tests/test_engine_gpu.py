@@ -240,14 +240,14 @@ def test_step_bf16_residual_fp32():
     out, grads = R.loss_and_grads(sd, trainable, items.cpu(), mask.cpu(), cfg)
     inner = getattr(root, 'model', root)
     res = {}
-    for rd in ('bf16', 'fp32', 'bf24'):
+    for rd in ('bf16', 'fp32', 'bf24', 'bf20'):
         inner.args.residual_dtype = rd
         inner.invalidate_native()
         for p in root.parameters():
             p.grad = None
         loss = root(items, mask, 0)
         loss.backward()
-        assert inner._engine().res32 == (rd == 'fp32') and inner._engine().res24 == (rd == 'bf24')
+        assert inner._engine().res32 == (rd == 'fp32') and inner._engine().res24 == (rd in ('bf24', 'bf20')) and inner._engine().lo_div == (2 if rd == 'bf20' else 1)
         emb = inner.bert_encoder(items).cpu()
         params = dict(root.named_parameters())
         worst = max(float(np.abs(params[str(k)].grad.cpu().numpy() - grads[strip(str(k))].numpy()).max() / (np.abs(grads[strip(str(k))].numpy()).max() + 1e-12))
@@ -262,6 +262,9 @@ def test_step_bf16_residual_fp32():
     r24 = res['bf24']                                  # the 24-bit stream (one byte per element beside the bf16 tensor): what the fp32 twins buy
     assert r24['loss'] < 2e-2 and r24['emb_err'] < 2e-2 and r24['grad'] < 0.15, r24
     assert not torch.equal(r24['emb'], r16['emb']) and r24['emb_rms'] <= 1.02 * r32['emb_rms'] + 1e-6, (r24['emb_rms'], r32['emb_rms'])
+    r20 = res['bf20']                                  # the 20-bit stream (a nibble per element): the same to within the 2^-13 it rounds at
+    assert r20['loss'] < 2e-2 and r20['emb_err'] < 2e-2 and r20['grad'] < 0.15, r20
+    assert not torch.equal(r20['emb'], r16['emb']) and r20['emb_rms'] <= 1.05 * r32['emb_rms'] + 1e-6, (r20['emb_rms'], r32['emb_rms'])
 
 
 @pytest.mark.parametrize('name', ['houlsby', 'roberta_cpc_pfeiffer'])

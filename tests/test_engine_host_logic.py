@@ -234,7 +234,7 @@ def test_host_logic_residual_fp32(simulated, name):
     tr = [strip(str(k)) for k in fx['trainable']]
     out, grads = R.loss_and_grads(sd, tr, items, mask, cfg)
     res = {}
-    for rd in ('bf16', 'fp32', 'bf24'):              # bf24 (round 6): the same twins as one byte per element, on the one-launch serial adapter sub-layers
+    for rd in ('bf16', 'fp32', 'bf24', 'bf20'):      # bf24 (round 6; bf20: a nibble per element): the same twins as one byte per element, on the one-launch serial adapter sub-layers
         inner.args.residual_dtype = rd
         inner.invalidate_native()
         for p in root.parameters():
@@ -258,9 +258,12 @@ def test_host_logic_residual_fp32(simulated, name):
     assert res['fp32'][2] <= 1.05 * res['bf16'][2], (res['fp32'][2], res['bf16'][2])
     assert res['bf24'][0] < 2e-2 and res['bf24'][3] < 0.15, res['bf24'][::3]
     assert res['bf24'][2] <= 1.05 * res['bf16'][2], (res['bf24'][2], res['bf16'][2])
+    assert res['bf20'][0] < 2e-2 and res['bf20'][3] < 0.15 and res['bf20'][2] <= 1.05 * res['bf16'][2], res['bf20'][::3]
     if name == 'houlsby':                            # every sub-layer on the one-launch kernel: the byte planes are consumed, and buy what the fp32 twins buy
         assert not torch.equal(res['bf24'][1], res['bf16'][1])
         assert res['bf24'][2] <= 1.02 * res['fp32'][2] + 1e-6, (res['bf24'][2], res['fp32'][2])
+        assert not torch.equal(res['bf20'][1], res['bf16'][1])          # (bf20 and bf24 may coincide after the two layers' bf16 roundings at this geometry)
+        assert res['bf20'][2] <= 1.05 * res['fp32'][2] + 1e-6, (res['bf20'][2], res['fp32'][2])
 
 
 def build_lora_cpu(dtype='fp32'):

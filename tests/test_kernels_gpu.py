@@ -2077,3 +2077,43 @@ def test_adapter_ln_fwd_24bit_residual_stream():
     e24, e16 = float((b24 - f32).abs().max()), float((b16 - f32).abs().max())
     print(f'second sub-layer vs the fp32-stream launch: 24-bit stream {e24:.2e}, bf16 stream {e16:.2e}')
     assert e24 < 2e-4 and e16 > 10 * e24
+
+
+@pytest.mark.gpu
+def test_adapter_ln_fwd_20bit_residual_stream():
+    """--residual_dtype bf20 (w_frag bits 1 + 2): the same with a signed NIBBLE per element, rounded to nearest (int8 [M, H / 2], eight elements per 32-bit
+    word).  (a) y (bf16) + its nibble plane = the fp32 LayerNorm output within 2^-12 relative (11 explicit mantissa bits, rounded: 2^-13 + the clamp at
+    an upward tie); (b) as the residual of a second launch: within 3e-3 of the launch fed the fp32 twin and >= 5 x closer than the bf16 tensor alone;
+    (c) the plane is exactly tests/sim_lib.lo4_of; (d) a plane of the wrong width is refused."""
+    from adapter4rec_amd import _lib as L
+    import sim_lib
+    M, H, d = 2048, 768, 64
+    t = torch.bfloat16
+    A, R = rnd(M, H, dtype=t, seed=1), rnd(M, H, dtype=t, seed=2)
+    Wd, Wu = rnd(d, H, dtype=t, scale=0.05, seed=3), rnd(H, d, dtype=t, scale=0.05, seed=4)
+    bd, bu, gam, bet = rnd(d, scale=0.1, seed=5), rnd(H, scale=0.1, seed=6), 1 + rnd(H, scale=0.1, seed=7), rnd(H, scale=0.1, seed=8)
+    mk = lambda c, dt=t: torch.zeros(M, c, dtype=dt, device=dev())
+    def run(resid, res=None, twin=None):
+        zp, z, v, y, st = mk(d), mk(d), mk(H), mk(H), torch.zeros(M, 2, device=dev())
+        L.adapter_ln_fwd(A, A, resid, Wd, bd, Wu, bu, gam, bet, 1e-12, L.ACT_GELU, zp, z, v, y, st, **(dict(res32=res, y32=twin) if (res is not None or twin is not None) else {}))
+        return y
+    y32, y4 = mk(H, torch.float32), mk(H // 2, torch.int8)
+    y0 = run(R, twin=y32)
+    y1 = run(R, twin=y4)
+    assert torch.equal(y0, y1)
+    joined = sim_lib.lo4_join(y1.cpu(), y4.cpu())
+    rel = ((joined - y32.cpu()).abs() / y32.cpu().abs().clamp_min(1e-3)).max().item()
+    assert rel < 2.0 ** -11, rel
+    assert float((y1.float().cpu() - y32.cpu()).abs().max()) > 4 * float((joined - y32.cpu()).abs().max())
+    assert torch.equal(y4.cpu(), sim_lib.lo4_of(y32.cpu(), y1.cpu()))
+    o32, o4 = mk(H, torch.float32), mk(H // 2, torch.int8)
+    run(y1, res=y32, twin=o32)
+    yb = run(y1, res=y4, twin=o4)
+    b20 = sim_lib.lo4_join(yb.cpu(), o4.cpu()).to(dev())
+    o16 = mk(H, torch.float32)
+    run(y1, twin=o16)
+    e20, e16 = float((b20 - o32).abs().max()), float((o16 - o32).abs().max())
+    print(f'second sub-layer vs the fp32-stream launch: 20-bit stream {e20:.2e}, bf16 stream {e16:.2e}')
+    assert e20 < 3e-3 and e16 > 3 * e20
+    with pytest.raises((RuntimeError, AssertionError)):
+        run(y1, res=mk(H // 4, torch.int8), twin=mk(H // 4, torch.int8))

@@ -43,7 +43,7 @@ def _step(model, items, mask, layer_call, residual, train, host=False):
     return out
 
 
-@pytest.mark.parametrize('residual,train,host', [('bf24', True, False), ('bf16', True, False), ('bf24', False, False), ('bf24', True, True)])
+@pytest.mark.parametrize('residual,train,host', [('bf24', True, False), ('bf16', True, False), ('bf24', False, False), ('bf24', True, True), ('bf20', True, False)])
 def test_layer_calls_are_bit_identical_to_the_per_launch_path(residual, train, host):
     import adapter4rec_amd.engine as E
     from base_cases import build_text_case

@@ -190,6 +190,16 @@ def test_base_geometry_step_fp32_and_bf16_vs_oracle_and_reference(name):
                     assert rep24[k]['hip_rms'] <= 1.0 * rep24[k]['ref_autocast_rms'] + 1e-3, (k, rep24[k])
             g24, w24 = grad_err(r24['grads'], ref['grads'])
             assert g24 < 0.2 and abs(r24['loss'] - ref['loss']) < 3e-2, (g24, w24, r24['loss'])
+            # --residual_dtype bf20: a NIBBLE per element (11 explicit mantissa bits): the same bar for half the plane bytes
+            r20 = step('bf16', 'bf20')
+            hip20 = dict(pos=r20['pos'] - rfx['pos'], neg=r20['neg'] - rfx['neg'], emb=r20['emb'] - rfx['emb'])
+            rep20 = {k: dict(hip_rms=rms(hip20[k]), ref_autocast_rms=rms(acd[k]), ratio=rms(hip20[k]) / max(rms(acd[k]), 1e-30)) for k in hip20}
+            print(f'{name} HIP bf16 + --residual_dtype bf20 vs the reference under autocast(bfloat16):', {k: round(v['ratio'], 3) for k, v in rep20.items()})
+            for k in ('pos', 'neg', 'emb'):
+                if hip20[k].numel() >= 16:
+                    assert rep20[k]['hip_rms'] <= 1.0 * rep20[k]['ref_autocast_rms'] + 1e-3, (k, rep20[k])
+            g20, w20 = grad_err(r20['grads'], ref['grads'])
+            assert g20 < 0.2 and abs(r20['loss'] - ref['loss']) < 3e-2, (g20, w20, r20['loss'])
     assert rep['grad']['median_ratio'] <= 2.0 and rep['grad']['hip_worst'] <= 2.0 * rep['grad']['ref_autocast_worst'] + 0.02, rep['grad']
     # fp8 encoder on the text tower (north_star: "fp8 MFMA encoder"): frozen qkv / attention-output / FFN GEMMs + the FFN dgrads on e4m3
     # operands (per-token x per-channel scales), everything else as in bf16.  Measured bounds with ~2x headroom.
