@@ -6,8 +6,8 @@
 // 16x16x4 tiles whose B operand streams 16 items at a time straight from global memory (the item
 // table is read once per 16 users; it is L2/Infinity-Cache resident).  The target's score is
 // produced by the very same instruction sequence (B rows = the 16 users' target items, diagonal
-// taken), so the comparison is bit-consistent.  History items are excluded by a scan of the user's
-// (<= max_seq_len + 2) history ids kept in LDS.  fp32 throughout: ranks are integers (bit-exact
+// taken), so the comparison is bit-consistent.  History items are excluded by counting every item first and taking back the user's
+// (<= A4R_EVAL_MAX_HISTORY, distinct) history ids that beat the target -- their scores from the same instruction sequence again.  fp32 throughout: ranks are integers (bit-exact
 // against the oracle up to fp32 summation order of the 64-term dot products).
 #include "a4r_common.h"
 #include "../../include/a4r.h"
@@ -61,25 +61,55 @@ __global__ void __launch_bounds__(256) eval_rank_kernel(const float* __restrict_
     for (int rr = 0; rr < 4; ++rr) ts[rr] = tscore[kg * 4 + rr];
     int local[4] = {0, 0, 0, 0};
     // items 1 .. N1-1 in tiles of 16; the 4 waves of the block take every 4th tile
-    const int ntiles = (N1 - 1 + 15) / 16;
-    for (int t = blockIdx.y * 4 + wave; t < ntiles; t += gridDim.y * 4) {
+    // The item fragments of the NEXT tile are requested before this tile's products (round 6): the table comes from L2 / the Infinity Cache at 500+ cycles a
+    // request, and with one tile in flight per wave the launch ran at 0.23 of the fp32 MFMA rate -- waiting, not streaming (profiles/r06_e_eval_host.txt).
+    const int ntiles = (N1 - 1 + 15) / 16, tstep = gridDim.y * 4;
+    int t = blockIdx.y * 4 + wave;
+    uint4 bn[KS];
+    {
+        const int irow = min(1 + min(t, ntiles - 1) * 16 + r16, N1 - 1);
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) bn[ks] = *reinterpret_cast<const uint4*>(item_emb + (size_t)irow * E + (ks * 4 + kg) * 4);
+    }
+    for (; t < ntiles; t += tstep) {
         const int i = 1 + t * 16 + r16;                 // this lane's item column
-        const int irow = min(i, N1 - 1);
+        uint4 b[KS];
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) b[ks] = bn[ks];
+        {
+            const int irow = min(1 + min(t + tstep, ntiles - 1) * 16 + r16, N1 - 1);      // (past the end: the last tile again, never used)
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) bn[ks] = *reinterpret_cast<const uint4*>(item_emb + (size_t)irow * E + (ks * 4 + kg) * 4);
+        }
         f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int ks = 0; ks < KS; ++ks) {
-            const uint4 b = *reinterpret_cast<const uint4*>(item_emb + (size_t)irow * E + (ks * 4 + kg) * 4);
-            Mma<float>::mma(ua[ks], b, acc);
-        }
+        for (int ks = 0; ks < KS; ++ks) Mma<float>::mma(ua[ks], b[ks], acc);
+        // EVERY item that beats the target is counted here; the user's history items among them are taken back below -- a scan of the (up to 264) history ids
+        // per beating item was most of this loop (on random scores half the items beat the target: 36 TF/s = 0.23 of the fp32 MFMA rate, round 5)
 #pragma unroll
-        for (int rr = 0; rr < 4; ++rr) {
-            if (i < N1 && acc[rr] > ts[rr]) {
-                const int ul = kg * 4 + rr;
-                bool in_hist = false;
-                const int n = nhist[ul];
-                for (int j = 0; j < n; ++j) in_hist |= (hist[ul][j] == i);
-                local[rr] += in_hist ? 0 : 1;
+        for (int rr = 0; rr < 4; ++rr) local[rr] += (i < N1 && acc[rr] > ts[rr]) ? 1 : 0;
+    }
+    // The history items: score(u, h) for the j-th history id of each of the 16 users by the SAME instruction sequence (B rows = those ids, the diagonal kept, as for
+    // the target: an element's bits do not depend on the column it sits in), once per id -- a repeated id, the pad item 0 or an id outside the table counts nothing,
+    // as a mask would.  Only the workgroup that owns the first item range does this (the others share its users).
+    if (blockIdx.y == 0) {
+        int mx = 0;
+#pragma unroll
+        for (int u = 0; u < 16; ++u) mx = max(mx, nhist[u]);
+        for (int j = wave; j < mx; j += 4) {
+            const int h = j < nhist[r16] ? hist[r16][j] : 0;
+            bool ok = h >= 1 && h < N1 && u0 + r16 < U;
+            for (int k = 0; k < j && ok; ++k) ok = hist[r16][k] != h;          // first occurrence only
+            const int hrow = ok ? h : 0;
+            f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                const uint4 b = *reinterpret_cast<const uint4*>(item_emb + (size_t)hrow * E + (ks * 4 + kg) * 4);
+                Mma<float>::mma(ua[ks], b, acc);
             }
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr)
+                if (kg * 4 + rr == r16 && ok && acc[rr] > ts[rr]) atomicSub(&cnt[r16], 1);
         }
     }
 #pragma unroll
