@@ -835,7 +835,7 @@ def test_ln_bwd_second_output_through_dropout(dt):
             assert torch.equal(dh_a, dh_b)
         else:                        # the fused launch scales the fp32 value and rounds ONCE; the two-launch form rounds dv first
             torch.testing.assert_close(dh_a.float(), dh_b.float(), rtol=2 ** -7, atol=1e-3)
-        torch.testing.assert_close(dba, dbb, rtol=1e-5, atol=1e-5)
+        torch.testing.assert_close(dba, dbb, rtol=1e-4, atol=1e-4)       # (column sums flushed with fp32 atomics: the order differs from launch to launch -- 1e-5 failed once in ~5 runs)
         assert abs((dh_b == 0).float().mean().item() - 0.2) < 0.02
 
 
