@@ -230,3 +230,79 @@ def test_layer_level_ops_equal_ctypes_binding():
     assert torch.equal(p0, p1) and float(p0.float().abs().max()) > 0
     with pytest.raises(RuntimeError, match='invalid argument'):
         ops.encoder_layer_fwd(x, w, ads[0], ads[1], saved, x1, xo, None, None, n_items, 64, nh, False, 0.1, -1e9, 1e-12)        # 64 tokens: outside the layer call's scope
+
+
+@pytest.mark.gpu
+def test_autograd_functions_over_the_layer_ops():
+    """torch_ops.EncoderLayerFunction / SasrecBlockFunction (round 6: the autograd forms of encoder_layer_fwd / _bwd and sasrec_block_fwd / _bwd).
+    (a) the encoder layer against torch autograd of a plain fp32 restatement of the same layer (HF BertLayer + serial Houlsby adapters, dropout off):
+        output within 3e-2, d x and every adapter gradient within 6 % of its tensor's max (bf16 storage against fp32);
+    (b) the SASRec block against the out-variant ops called directly (bit-equal d x, gradients to atomic order)."""
+    import math
+    ops, _ = _ops()
+    from adapter4rec_amd import _lib as L
+    from adapter4rec_amd import torch_ops
+    from test_kernels_gpu import _sasrec_case
+    dev, t = 'cuda:0', torch.bfloat16
+    g = torch.Generator(device=dev).manual_seed(21)
+    r = lambda *s, sc=1.0: torch.randn(*s, device=dev, generator=g) * sc
+    n_items, S, H, F, nh = 40, 30, 256, 512, 4
+    M = 1280
+    x = r(M, H).to(t)
+    x[n_items * S:] = 0
+    frozen = [r(3 * H, H, sc=0.05).to(t), r(3 * H, sc=0.1), r(H, H, sc=0.05).to(t), r(H, sc=0.1), r(F, H, sc=0.05).to(t), r(F, sc=0.1), r(H, F, sc=0.05).to(t), r(H, sc=0.1),
+              1 + r(H, sc=0.1), r(H, sc=0.1), 1 + r(H, sc=0.1), r(H, sc=0.1)]
+    ads = [r(64, H, sc=0.05), r(64, sc=0.1), r(H, 64, sc=0.05), r(H, sc=0.1), r(64, H, sc=0.05), r(64, sc=0.1), r(H, 64, sc=0.05), r(H, sc=0.1)]
+    km = torch.ones(n_items, S, device=dev)
+    km[3, 20:] = 0
+    cfg = dict(n_items=n_items, S=S, n_heads=nh, act1=L.ACT_GELU, act2=L.ACT_GELU)
+    dy = r(M, H, sc=0.1)
+    dy[n_items * S:] = 0
+    xa = x.clone().requires_grad_(True)
+    pa = [p.clone().requires_grad_(True) for p in ads]
+    y = torch_ops.EncoderLayerFunction.apply(xa, *pa, frozen, km, cfg)
+    y.backward(dy.to(t))
+    # fp32 restatement
+    n = n_items * S
+    xr = x[:n].float().clone().requires_grad_(True)
+    pr = [p.clone().requires_grad_(True) for p in ads]
+    W = [q.float() for q in frozen]
+    gelu = torch.nn.functional.gelu
+    qkv = xr @ W[0].t() + W[1]
+    q, k, v = (z.view(n_items, S, nh, H // nh).transpose(1, 2) for z in qkv.split(H, 1))
+    sc = q @ k.transpose(-1, -2) / math.sqrt(H // nh) + (1 - km)[:, None, None, :] * -1e9
+    ctxr = (torch.softmax(sc, -1) @ v).transpose(1, 2).reshape(n, H)
+    h1 = ctxr @ W[2].t() + W[3]
+    a1 = gelu(h1 @ pr[0].t() + pr[1]) @ pr[2].t() + pr[3] + h1
+    x1 = torch.nn.functional.layer_norm(a1 + xr, (H,), W[8], W[9], 1e-12)
+    u = gelu(x1 @ W[4].t() + W[5])
+    h2 = u @ W[6].t() + W[7]
+    a2 = gelu(h2 @ pr[4].t() + pr[5]) @ pr[6].t() + pr[7] + h2
+    yr = torch.nn.functional.layer_norm(a2 + x1, (H,), W[10], W[11], 1e-12)
+    yr.backward(dy[:n])
+    assert float((y[:n].float() - yr).abs().max()) < 3e-2 * max(1.0, float(yr.abs().max()))
+    rel = lambda a, b: float((a.float() - b.float()).abs().max() / b.float().abs().max())
+    errs = {'dx': rel(xa.grad[:n], xr.grad)}
+    for i, (a, b) in enumerate(zip(pa, pr)):
+        assert a.grad is not None and a.grad.shape == b.grad.shape and a.grad.dtype == torch.float32
+        errs[f'p{i}'] = rel(a.grad, b.grad)
+    print('EncoderLayerFunction vs fp32 torch autograd:', {k: round(v, 4) for k, v in errs.items()})
+    assert max(errs.values()) < 0.06, errs
+    # ---- SASRec block
+    desc, xs, mask, dys = _sasrec_case(16, 1, True, seed=5, mode=0)
+    B, T = 6, 20
+    fz = tuple(desc[n_] for n_ in ('wqkv', 'wfc', 'w1', 'b1', 'w2', 'b2', 'ln1_g', 'ln1_b', 'ln2_g', 'ln2_b'))
+    adn = ('wd1', 'bd1', 'wu1', 'bu1', 'wd2', 'bd2', 'wu2', 'bu2')
+    adp = [desc[n_].clone().requires_grad_(True) for n_ in adn]
+    cfg2 = dict(n_heads=desc['n_heads'], F=desc['F'], d=desc['d'], act=desc['act'], inner_res=bool(desc['inner_res']), eps=desc['eps'], mask_neg=desc['mask_neg'])
+    xq = xs.view(B, T, 64).clone().requires_grad_(True)
+    yq = torch_ops.SasrecBlockFunction.apply(xq, mask.view(B, T), fz, *adp, cfg2)
+    yq.backward(dys.view(B, T, 64))
+    wl = [*fz, *[desc[n_] for n_ in adn]]
+    y0, dx0 = torch.zeros_like(xs), torch.zeros_like(xs)
+    gl = [torch.zeros_like(desc[n_]) for n_ in adn]
+    ops.sasrec_block_fwd(xs.view(B, T, 64), mask.view(B, T), y0.view(B, T, 64), wl, **cfg2)
+    ops.sasrec_block_bwd(xs.view(B, T, 64), mask.view(B, T), dys.view(B, T, 64), dx0.view(B, T, 64), wl, gl, **cfg2)
+    assert torch.equal(yq.detach().reshape(-1), y0.reshape(-1)) and torch.equal(xq.grad.reshape(-1), dx0.reshape(-1))
+    for a, b in zip(adp, gl):
+        torch.testing.assert_close(a.grad, b, rtol=1e-4, atol=1e-5 * float(b.abs().max()) + 1e-9)
