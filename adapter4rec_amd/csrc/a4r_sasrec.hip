@@ -27,10 +27,27 @@ constexpr int SX = E + 4, SQ = 3 * E + 4, SU = F + 4, SPR = RP + 4;      // LDS 
 
 struct Lay {                      // LDS layout in floats (dpe = adapter width rounded up to 16)
     int x, qkv, p, ctx, h, zp1, z1, v1, x1, u, h2, zp2, z2, v2, st, g1, total, sz;
-    __host__ __device__ explicit Lay(int dpe) {
+    // fwd_only (round 6): the forward launch keeps nothing for a backward pass (the backward kernel recomputes the forward in ITS full layout), so images with
+    // disjoint lifetimes share storage -- 75 KB instead of 150 KB, TWO workgroups per CU (one user per workgroup is latency-bound: the evaluation's user tower,
+    // 8 192 users per launch, ran 32 workgroups deep on every CU).  Lifetimes in block_forward: qkv, p die with ctx (step 2); u is written in step 5 over qkv + p;
+    // h (steps 3 - 4; Pfeiffer: again in step 7, when u is dead) sits where p was; x dies with v1 (step 4) and h2 (step 6) takes its place; zp2 / z2 / v2 (step 7)
+    // re-use zp1 / z1 / v1 (step 4); the log_mask row needs 32 floats, not an image.
+    __host__ __device__ explicit Lay(int dpe, bool fwd_only = false) {
         sz = dpe + 4;
         int o = 0;
         auto take = [&](int n) { const int r = o; o += n; return r; };
+        if (fwd_only) {
+            x = take(RP * SX); h2 = x;
+            qkv = take(RP * SQ); p = take(NH * RP * SPR); u = qkv; h = p;
+            static_assert(RP * SU <= RP * SQ + NH * RP * SPR && RP * SX <= NH * RP * SPR, "u over qkv + p, h over p");
+            ctx = take(RP * SX);
+            zp1 = take(RP * sz); z1 = take(RP * sz); zp2 = zp1; z2 = z1;
+            v1 = take(RP * SX); v2 = v1;
+            x1 = take(RP * SX);
+            st = take(6 * RP); g1 = take(RP);
+            total = o;
+            return;
+        }
         x = take(RP * SX); qkv = take(RP * SQ); p = take(NH * RP * SPR); ctx = take(RP * SX); h = take(RP * SX);
         zp1 = take(RP * sz); z1 = take(RP * sz); v1 = take(RP * SX); x1 = take(RP * SX); u = take(RP * SU); h2 = take(RP * SX);
         zp2 = take(RP * sz); z2 = take(RP * sz); v2 = take(RP * SX); st = take(6 * RP); g1 = take(RP * SX);
@@ -334,7 +351,7 @@ template <bool TRAIN>
 __global__ void __launch_bounds__(256) sasrec_block_fwd_kernel(const float* __restrict__ x, const float* __restrict__ log_mask, float* __restrict__ y,
                                                                 BlockW w, int T, int dpe) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    const Lay L(dpe);
+    const Lay L(dpe, true);
     const int user = blockIdx.x, tid = threadIdx.x;
     load_rows(lds + L.x, x + (size_t)user * T * E, T, tid);
     float* km = lds + L.g1;                                       // the user's log_mask row (T floats)
@@ -672,7 +689,7 @@ extern "C" int a4r_sasrec_block_fwd(void* stream, const a4r_sasrec_block_t* b, c
     if (!x || !log_mask || !y || n_users <= 0) return A4R_EINVAL;
     if ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y)) & 15u) return A4R_EINVAL;
     if (int rc = fill(b, T, train, w, dpe)) return rc;
-    const size_t lds = (size_t)Lay(dpe).total * sizeof(float);
+    const size_t lds = (size_t)Lay(dpe, true).total * sizeof(float);
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     const bool tr = w.thr_attn || w.thr_hidden;
     if (tr) {
